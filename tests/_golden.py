@@ -1,0 +1,44 @@
+"""Loader for tests/golden/*.npz (written by tools/gen_golden.py from the real reference)."""
+import glob
+import hashlib
+import json
+import os
+
+import numpy as np
+
+from lightningfastspeech2_amd.config import Fs2Config
+from lightningfastspeech2_amd.weights import synth_state_dict
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def sd_digest(sd) -> str:
+    h = hashlib.sha256()
+    for k, v in sd.items():
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(v).tobytes())
+    return h.hexdigest()
+
+
+class Golden:
+    def __init__(self, name):
+        z = np.load(os.path.join(GOLDEN_DIR, f"{name}.npz"))
+        self.name = name
+        self.cfg = Fs2Config.from_json(str(z["config_json"]))
+        self.synth = json.loads(str(z["synth_json"]))
+        self.sd_sha256 = str(z["sd_sha256"])
+        self.phones = z["phones"]
+        self.speaker = z["speaker"]
+        self.out = {k[4:]: z[k] for k in z.files if k.startswith("out_")}
+        self.mid = {k[4:]: z[k] for k in z.files if k.startswith("mid_")}
+        self.margins = z["margins"]
+        self.n_guard = int(z["n_guard"])
+
+    def state_dict(self):
+        sd = synth_state_dict(self.cfg, **self.synth)
+        assert sd_digest(sd) == self.sd_sha256, "synthetic weight recipe drifted from the fixture"
+        return sd

@@ -1,0 +1,169 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by running the REAL reference forward (build container only).
+
+    python tools/gen_golden.py            # writes tests/golden/<case>.npz
+
+Each fixture holds: the config (json), the synthetic-weight recipe (seed + kwargs of
+``synth_state_dict`` — weights are re-derived from it, a sha256 of their bytes is stored to
+detect drift), the inputs (``phones``, ``speaker``) and what the unmodified
+``litfass.fastspeech2.fastspeech2.FastSpeech2.forward(batch, inference=True)`` returned for them
+(``mel``, ``duration_prediction``, ``duration_rounded``, ``src_mask``, ``tgt_mask``,
+``variances_*``) plus hooked intermediates for the small cases.  Seeds are searched so that every
+discrete decision (duration rounding model.py:300, bucketize model.py:437) keeps a margin from its
+threshold, which makes exact decision equality a fair demand on an fp32 re-implementation.
+The reference's source never enters the fixture: these are inputs and outputs only.
+"""
+from __future__ import annotations
+
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from lightningfastspeech2_amd.config import Fs2Config  # noqa: E402
+from lightningfastspeech2_amd.weights import synth_inputs, synth_state_dict  # noqa: E402
+from tools.ref_import import run_reference  # noqa: E402
+
+OUT_DIR = os.path.join(ROOT, "tests", "golden")
+ROUND_MARGIN = 2e-3   # |frac(exp(p)-1) - .5| must exceed this
+BUCKET_MARGIN = 2e-3  # distance of pred*std+mean to the nearest bin edge must exceed this
+
+
+def small(**kw):
+    base = dict(n_phones=40, encoder_hidden=64, decoder_hidden=64, encoder_head=2, decoder_head=2,
+                encoder_layers=2, decoder_layers=2, encoder_kernel_sizes=[3, 5], decoder_kernel_sizes=[5, 3],
+                encoder_conv_filter_size=128, decoder_conv_filter_size=128,
+                encoder_depthwise_conv=False, decoder_depthwise_conv=False,
+                variance_filter_size=64, variance_depthwise_conv=False, variance_nlayers=[2, 2, 2],
+                duration_filter_size=64, duration_depthwise_conv=False, variance_nbins=16, n_mels=8,
+                stats={"pitch": {"min": -2.0, "max": 2.5, "mean": 0.1, "std": 1.5},
+                       "energy": {"min": -3.0, "max": 3.0, "mean": 0.0, "std": 1.0},
+                       "snr": {"min": -1.0, "max": 4.0, "mean": 1.2, "std": 2.0}})
+    base.update(kw)
+    return Fs2Config(**base)
+
+
+CASES = {
+    # name: (config, B, L, lengths, synth kwargs, want)
+    "dense_small": (small(), 3, 11, [11, 7, 4], dict(duration_bias=1.2), {}),
+    "dw_small": (small(encoder_depthwise_conv=True, decoder_depthwise_conv=True,
+                       variance_depthwise_conv=True, duration_depthwise_conv=True,
+                       encoder_conv_filter_size=256, decoder_conv_filter_size=256,
+                       encoder_kernel_sizes=[5, 9], decoder_kernel_sizes=[7, 3], n_mels=80),
+                 3, 13, [13, 9, 5], dict(duration_bias=1.0), {}),
+    "mixed_small": (small(encoder_depthwise_conv=True, decoder_depthwise_conv=False,
+                          variance_depthwise_conv=False, duration_depthwise_conv=True,
+                          encoder_conv_filter_size=128, encoder_layers=1, decoder_layers=3,
+                          encoder_kernel_sizes=[7], decoder_kernel_sizes=[3, 9, 1],
+                          variances=["energy", "pitch"], variance_nlayers=[1, 3],
+                          variance_kernel_size=[5, 3], variance_levels=["frame", "frame"],
+                          variance_transforms=["none", "none"], variance_nbins=32),
+                    4, 9, [9, 9, 3, 1], dict(duration_bias=0.9), {}),
+    "guard_small": (small(), 4, 10, [10, 8, 6, 3], dict(duration_bias=0.35, duration_weight_scale=1.5),
+                    {"guard": "some"}),
+    "clip_small": (small(max_length=20.5 * 256 / 22050), 3, 12, [12, 12, 6], dict(duration_bias=1.3),
+                   {"clip": True}),
+    "mid_dense_d128": (Fs2Config(n_phones=80, encoder_hidden=256, decoder_hidden=256, encoder_head=2,
+                                 decoder_head=2, encoder_layers=1, decoder_layers=2,
+                                 encoder_kernel_sizes=[9], decoder_kernel_sizes=[9, 9],
+                                 encoder_depthwise_conv=False, decoder_depthwise_conv=False,
+                                 encoder_conv_filter_size=1024, decoder_conv_filter_size=1024,
+                                 variance_filter_size=256, variance_depthwise_conv=False,
+                                 variance_nlayers=[2, 2, 2], duration_filter_size=256,
+                                 duration_depthwise_conv=False),
+                       2, 24, [24, 17], dict(duration_bias=1.4), {"slim": True, "bucket_margin": 1e-4}),
+    "mid_dw_d64": (Fs2Config(n_phones=80, encoder_hidden=128, decoder_hidden=128, encoder_head=2,
+                             decoder_head=2, encoder_layers=2, decoder_layers=2,
+                             encoder_kernel_sizes=[5, 25], decoder_kernel_sizes=[17, 21],
+                             encoder_conv_filter_size=512, decoder_conv_filter_size=512,
+                             variance_filter_size=128, variance_nlayers=[2, 2, 2],
+                             duration_filter_size=128),
+                   2, 20, [20, 12], dict(duration_bias=1.4), {"slim": True, "bucket_margin": 1e-4}),
+}
+
+
+def sd_digest(sd) -> str:
+    h = hashlib.sha256()
+    for k, v in sd.items():
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(v).tobytes())
+    return h.hexdigest()
+
+
+def margins(cfg, out):
+    p = out["duration_prediction"].double()
+    valid = ~out["src_mask"]
+    v = (torch.exp(p) - 1)[valid]
+    v = v[v > -0.4]  # far-negative values clamp to 0 without rounding risk
+    frac = v - torch.floor(v)
+    round_margin = float((frac - 0.5).abs().min()) if v.numel() else 1.0
+    bucket_margin = 1.0
+    for var in cfg.variances:
+        st = cfg.stats[var]
+        bins = torch.linspace(st["min"], st["max"], cfg.variance_nbins - 1).double()
+        # pad frames carry pred == 0 exactly (masked_fill, model.py:518) -> value == mean in any
+        # implementation, so only valid frames can flip
+        val = (out[f"variances_{var}"].double() * st["std"] + st["mean"])[~out["tgt_mask"]]
+        bucket_margin = min(bucket_margin, float((val[..., None] - bins).abs().min()))
+    return round_margin, bucket_margin
+
+
+def make_case(name, cfg, B, L, lengths, skw, want):
+    for seed in range(0, 400):
+        sd = synth_state_dict(cfg, seed, randomize_norm=True, **skw)
+        inp = synth_inputs(cfg, B, L, seed=1000 + seed, lengths=lengths)
+        out = run_reference(cfg, sd, inp["phones"], inp["speaker"], capture=True)
+        rm, bm = margins(cfg, out)
+        n_guard = out["_stdout"].count("Zero duration")
+        totals = out["duration_rounded"].long().sum(1)
+        clipped = bool((totals > cfg.max_frames).any())
+        ok = rm > want.get("round_margin", ROUND_MARGIN) and bm > want.get("bucket_margin", BUCKET_MARGIN)
+        if want.get("guard") == "some":
+            ok = ok and 0 < n_guard < B
+        else:
+            ok = ok and n_guard == 0
+        ok = ok and (clipped == bool(want.get("clip", False)))
+        ok = ok and int(out["mel"].shape[1]) >= 4
+        if not ok:
+            continue
+        arrays = {
+            "config_json": np.array(cfg.to_json()),
+            "synth_json": np.array(json.dumps(dict(seed=seed, randomize_norm=True, **skw), sort_keys=True)),
+            "sd_sha256": np.array(sd_digest(sd)),
+            "phones": inp["phones"], "speaker": inp["speaker"],
+            "margins": np.array([rm, bm]), "n_guard": np.array(n_guard),
+        }
+        for k, v in out.items():
+            if k.startswith("_"):
+                continue
+            arrays[f"out_{k}"] = v.numpy()
+        if not want.get("slim"):
+            for k, v in out["_intermediates"].items():
+                arrays[f"mid_{k}"] = v.numpy()
+        path = os.path.join(OUT_DIR, f"{name}.npz")
+        np.savez_compressed(path, **arrays)
+        print(f"{name}: seed={seed} T={out['mel'].shape[1]} totals={totals.tolist()} guard={n_guard} "
+              f"clipped={clipped} round_margin={rm:.2e} bucket_margin={bm:.2e} "
+              f"-> {os.path.getsize(path) / 1024:.1f} KiB")
+        return
+    raise SystemExit(f"{name}: no seed satisfied the margins/wants")
+
+
+def main():
+    os.makedirs(OUT_DIR, exist_ok=True)
+    only = sys.argv[1:]
+    torch.manual_seed(0)
+    for name, (cfg, B, L, lengths, skw, want) in CASES.items():
+        if only and name not in only:
+            continue
+        make_case(name, cfg, B, L, lengths, skw, want)
+
+
+if __name__ == "__main__":
+    main()
