@@ -1,0 +1,155 @@
+/* C ABI of the MI355X-native FastSpeech2 / LightSpeech mel forward (libfs2_hip.so).
+ *
+ * The reference (MiniXC/LightningFastSpeech2) has no FFI layer: its "operator API" for this path is
+ * the Python method  FastSpeech2.forward(targets: dict, inference) -> dict
+ * (litfass/fastspeech2/fastspeech2.py:636-784) over a state_dict whose key names are fixed by the
+ * module tree built at fastspeech2.py:242-438.  This header is what a binding for
+ * that method binds (ctypes stub in INTEGRATION.md; the in-tree host mirror is
+ * lightningfastspeech2_amd/model.py):
+ *
+ *   fs2_create / fs2_load_weight / fs2_finalize   <- FastSpeech2.__init__ + load_state_dict
+ *                                                    (fastspeech2.py:46-491, :530-620): weights are
+ *                                                    passed under the reference's own key names
+ *   fs2_encode + fs2_decode                       <- FastSpeech2.forward(batch, inference=True)
+ *                                                    (fastspeech2.py:636-731), split at the one point
+ *                                                    where the output length T becomes known
+ *                                                    (LengthRegulator, model.py:354-355)
+ *
+ * Plain pointers and sizes only; device pointers are HIP device addresses on the engine's device
+ * (e.g. torch tensors' data_ptr()).  All work is enqueued on the caller's stream; no hidden streams,
+ * no global state, one engine per device.  Every function returns a status code (0 = OK);
+ * fs2_last_error() has the text.  No exceptions cross this boundary.
+ */
+#ifndef FS2_H_
+#define FS2_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FS2_ABI_VERSION 1
+#define FS2_MAX_LAYERS 32
+#define FS2_MAX_VARIANCES 4
+#define FS2_NAME_LEN 32
+
+enum fs2_status {
+    FS2_OK = 0,
+    FS2_ERR_HIP = 1,     /* a HIP runtime call or kernel launch failed */
+    FS2_ERR_SHAPE = 2,   /* shape/config outside what the kernels support */
+    FS2_ERR_ARG = 3,     /* null / inconsistent argument */
+    FS2_ERR_WEIGHT = 4,  /* unknown weight name, wrong shape, or weights missing at finalize */
+    FS2_ERR_STATE = 5,   /* call order violated (e.g. decode before encode) */
+    FS2_ERR_NOMEM = 6
+};
+
+enum fs2_dtype { FS2_F32 = 0, FS2_BF16 = 1 };
+
+/* Mirrors the hparams that shape FastSpeech2.forward (fastspeech2.py:46-130). */
+typedef struct fs2_config {
+    int32_t abi_version;   /* FS2_ABI_VERSION */
+    int32_t dtype;         /* fs2_dtype: arithmetic mode. F32 = parity mode (fp32 MFMA, <=1e-3 vs the
+                              reference); BF16 = throughput mode (bf16 storage + MFMA, fp32 accumulate,
+                              fp32 softmax/LayerNorm statistics/predictor heads/bucketize) */
+    int32_t n_phones;      /* len(phone2id) */
+    int32_t hidden;        /* encoder_hidden == decoder_hidden */
+    int32_t n_mels;
+    int32_t dvec_dim;      /* 256 */
+    int32_t max_frames;    /* int(max_length * sampling_rate / hop_length) = 2756 */
+    int32_t pe_len;        /* rows of positional_encoding.pe (5000) */
+    int32_t enc_layers, enc_heads, enc_filter, enc_depthwise;
+    int32_t enc_kernels[FS2_MAX_LAYERS];
+    int32_t dec_layers, dec_heads, dec_filter, dec_depthwise;
+    int32_t dec_kernels[FS2_MAX_LAYERS];
+    int32_t n_variances;   /* frame-level, transform 'none', in hparams order */
+    char var_names[FS2_MAX_VARIANCES][FS2_NAME_LEN];
+    int32_t var_nlayers[FS2_MAX_VARIANCES];
+    int32_t var_kernel[FS2_MAX_VARIANCES];
+    float var_mean[FS2_MAX_VARIANCES];  /* stats[var]["mean"/"std"] (model.py:406-407,434) */
+    float var_std[FS2_MAX_VARIANCES];
+    int32_t var_filter, var_nbins, var_depthwise;
+    int32_t dur_nlayers, dur_kernel, dur_filter, dur_depthwise;
+} fs2_config;
+
+typedef struct fs2_engine fs2_engine;
+
+/* Caller-owned DEVICE buffers fs2_decode fills (shapes use T returned by fs2_encode).  Any pointer
+ * may be NULL to skip that output.  Mask bytes are 1 = pad, directly usable as torch.bool storage. */
+typedef struct fs2_outputs {
+    float* mel;                    /* (B, T, n_mels) fp32, pad rows included (fastspeech2.py:723) */
+    float* duration_prediction;    /* (B, L) log(1+d) domain, 0 at pads (model.py:259,517-518) */
+    int32_t* duration_rounded;     /* (B, L) (model.py:299-309) */
+    uint8_t* src_mask;             /* (B, L) phones == 0 (fastspeech2.py:651) */
+    uint8_t* tgt_mask;             /* (B, T) t >= total_b (model.py:358-361) */
+    float* variances[FS2_MAX_VARIANCES];  /* (B, T) each, 0 at pads (model.py:328) */
+} fs2_outputs;
+
+int fs2_abi_version(void);
+const char* fs2_status_string(int status);
+const char* fs2_last_error(const fs2_engine* e);
+
+int fs2_create(const fs2_config* cfg, fs2_engine** out);
+int fs2_destroy(fs2_engine* e);
+
+/* One call per state_dict entry, reference key names, fp32 HOST data, torch shape.
+ * Unknown names that belong to off-path modules are rejected with FS2_ERR_WEIGHT. */
+int fs2_load_weight(fs2_engine* e, const char* name, const float* host_data, const int64_t* shape, int32_t ndim);
+/* Packs (conv weights tap-major, grouped 1x1 folded into the following pointwise conv), converts to
+ * the arithmetic dtype and uploads.  FS2_ERR_WEIGHT if any tensor of the architecture is missing. */
+int fs2_finalize(fs2_engine* e);
+
+/* Phase 1: embedding + encoder + duration predictor + rounding/guard + prefix sums.
+ *   phones   (B, L) int64 device, 0 = [PAD];  speaker (B, dvec_dim) fp32 device.
+ *   forced_durations: NULL, or (B, L) int32 device durations used instead of the predicted ones.
+ * Synchronises the stream once to return T = min(max_b sum_l d[b,l], max_frames). */
+int fs2_encode(fs2_engine* e, const int64_t* phones, const float* speaker, int32_t B, int32_t L,
+               const int32_t* forced_durations, void* hip_stream, int32_t* T_out);
+/* Per-utterance frame totals (untruncated) and zero-duration-guard flags of the last fs2_encode. */
+int fs2_last_totals(const fs2_engine* e, int32_t* totals_host, int32_t* guard_host, int32_t B);
+/* Phase 2: length regulator + variance encoders + decoder + mel linear, into caller buffers. */
+int fs2_decode(fs2_engine* e, const fs2_outputs* out, void* hip_stream);
+
+/* Parity taps: copy an intermediate of the last forward as fp32 into a caller DEVICE buffer.
+ * what = "encoder_out" (B,L,H) | "regulated" | "adaptor_out" | "decoder_out" (B,T,H) |
+ *        "bucket_<var>" (B,T) int32.  Requires fs2_set_debug(e, 1) before fs2_encode. */
+int fs2_set_debug(fs2_engine* e, int32_t on);
+int fs2_debug_copy(fs2_engine* e, const char* what, void* dst_device, void* hip_stream);
+
+/* Kernel timing with HIP events on the launch stream (bench.py roofline).  kernel_class: */
+enum fs2_kernel_class { FS2_K_CONV_GEMM = 0, FS2_K_GEMM = 1, FS2_K_ATTENTION = 2, FS2_K_ROWOPS = 3, FS2_K_COUNT = 4 };
+int fs2_profile_enable(fs2_engine* e, int32_t kernel_class, int32_t enable);
+/* Sums elapsed ms / launches / algorithmic flops / algorithmic bytes since enable; syncs the events. */
+int fs2_profile_read(fs2_engine* e, int32_t kernel_class, double* total_ms, int64_t* launches,
+                     double* flops, double* bytes);
+
+/* ---- single-operator entry points (device pointers; used by the parity tests) ------------- */
+int fs2_op_gemm(int32_t dtype, int32_t out_dtype, const void* x, const void* w, const float* bias, void* c,
+                int32_t M, int32_t N, int32_t Cin, int32_t taps, int32_t S, int32_t relu, void* hip_stream);
+int fs2_op_attention(int32_t dtype, const void* qkv, const uint8_t* key_pad_mask, void* out, void* vt_scratch,
+                     uint64_t* bits_scratch, int32_t B, int32_t S, int32_t H, int32_t heads, void* hip_stream);
+size_t fs2_op_attention_scratch_bytes(int32_t dtype, int32_t B, int32_t S, int32_t H, int32_t heads, size_t* bits_bytes);
+int fs2_op_layernorm(int32_t dtype, const void* x, const void* res, const float* gamma, const float* beta, void* y,
+                     const float* dot_w, float dot_b, const uint8_t* mask, float* pred, int32_t M, int32_t H,
+                     void* hip_stream);
+int fs2_op_dwconv(int32_t dtype, const void* x, const float* w, const float* bias, void* y, int32_t B, int32_t S,
+                  int32_t C, int32_t k, void* hip_stream);
+int fs2_op_durations(const float* dur_pred, const uint8_t* src_mask, const int32_t* forced, int32_t* dur,
+                     int32_t* cum, int32_t* totals, int32_t* guard, int32_t B, int32_t L, void* hip_stream);
+int fs2_op_regulate(int32_t dtype, const void* x, const int32_t* cum, const int32_t* totals, void* y,
+                    uint8_t* tgt_mask, int32_t B, int32_t L, int32_t T, int32_t H, void* hip_stream);
+int fs2_op_bucket_embed(int32_t dtype, const void* x, const float* pred, const float* bins, const float* emb,
+                        int32_t nbins, float std, float mean, const float* pe, const float* spk, void* y,
+                        int32_t* idx_out, int32_t B, int32_t T, int32_t H, void* hip_stream);
+int fs2_op_embed(int32_t dtype, const int64_t* phones, const float* table, const float* pe, const float* spk,
+                 void* x, uint8_t* src_mask, int32_t B, int32_t L, int32_t H, int32_t n_phones, void* hip_stream);
+int fs2_op_spk_proj(const float* dvec, const float* w, const float* b, float* spk, int32_t B, int32_t H,
+                    int32_t Din, void* hip_stream);
+/* dtype conversion helpers for tests: fp32 <-> engine dtype, n elements, device pointers */
+int fs2_op_convert(int32_t src_dtype, int32_t dst_dtype, const void* src, void* dst, size_t n, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FS2_H_ */

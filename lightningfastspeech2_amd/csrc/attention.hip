@@ -1,0 +1,266 @@
+// Fused multi-head self-attention core for gfx950: softmax(q k^T / sqrt(d) + key-padding) v,
+// flash style (scores never reach HBM).  Replaces the attention inside nn.MultiheadAttention as
+// nn.TransformerEncoderLayer._sa_block calls it from ConformerEncoderLayer.forward
+// (/root/reference/litfass/fastspeech2/model.py:108-116): padded KEYS get -inf, padded queries are
+// still computed.
+//
+// One workgroup = NW waves = NW*32 queries of one (utterance, head); KV advances in tiles of 64
+// keys (bf16) / 32 keys (fp32) staged in LDS with a 16-byte XOR swizzle.
+//   S^T = K Q^T  via 32x32 MFMA with K as the row operand: each lane then owns ONE query (lane&31)
+//                and 16 keys per 32-key block, so row max / row sum are in-register + one
+//                lane^32 exchange.
+//   O^T = V^T P^T with V^T as the row operand and the lane's own P registers as the column
+//                operand (no cross-lane movement): the MFMA's k-slot <-> key assignment is whatever
+//                the S^T register layout gives, and V^T is stored with its keys pre-permuted to
+//                match (transpose_v kernel), so each operand is one ds_read_b128.
+// Key padding arrives as a 64-bit valid mask per 64-key group (any mask shape, not only suffix
+// padding); fully padded tiles are skipped.
+#include "fs2_common.h"
+#include "fs2_kernels.h"
+
+namespace fs2 {
+
+template <int RB>  // RB = row bytes
+__device__ inline int swz_row(int row, int slot) {
+    constexpr int NS = RB / 16;
+    if constexpr (NS >= 16) return row * RB + ((slot ^ (row & 15)) << 4);
+    else if constexpr (NS == 8) return row * RB + ((slot ^ ((row >> 1) & 7)) << 4);
+    else if constexpr (NS == 4) return row * RB + ((slot ^ ((row >> 2) & 3)) << 4);
+    else return row * RB + ((slot ^ ((row >> 3) & 1)) << 4);
+}
+
+template <typename T, int D, int NW>
+__global__ __launch_bounds__(NW * 64) void attention_kernel(AttnArgs p) {
+    constexpr int NT = NW * 64;
+    constexpr int KVB = sizeof(T) == 2 ? 64 : 32;      // keys per tile
+    constexpr int E16 = Num<T>::kPer16B;
+    constexpr int KC = Mma32<T>::K_PER_CHUNK;          // k-values per 2x16B chunk
+    constexpr int NQC = D / KC;                        // q chunks (16 B per lane each)
+    constexpr int KRB = D * (int)sizeof(T);            // K tile row bytes
+    constexpr int KNS = KRB / 16;
+    constexpr int VRB = 128;                           // Vt tile row bytes (KVB keys)
+    constexpr int NKB = KVB / 32;                      // 32-key blocks per tile
+    constexpr int ND = D / 32;                         // 32-wide dv blocks
+
+    __shared__ __attribute__((aligned(16))) unsigned char sK[KVB * KRB];
+    __shared__ __attribute__((aligned(16))) unsigned char sV[D * VRB];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, hi = lane >> 5;
+    const int bh = blockIdx.y, b = bh / p.heads, h = bh % p.heads;
+    const int q0 = blockIdx.x * (NW * 32);
+    const int ld = 3 * p.H;
+    const T* __restrict__ qkv = (const T*)p.qkv;
+    const T* __restrict__ vt = (const T*)p.vt;
+
+    // ---- Q fragments (column operand of S^T = K Q^T), pre-scaled by log2(e)/sqrt(d) ----
+    uint4 qf[NQC];
+    {
+        int qrow = q0 + wave * 32 + li;
+        if (qrow >= p.S) qrow = p.S - 1;
+        const T* src = qkv + (size_t)(b * p.S + qrow) * ld + h * D + hi * E16;
+#pragma unroll
+        for (int c = 0; c < NQC; ++c) {
+            uint4 u = *(const uint4*)(src + c * KC);
+            float f[Vec16<T>::N];
+            Vec16<T>::unpack(u, f);
+#pragma unroll
+            for (int e = 0; e < Vec16<T>::N; ++e) f[e] *= p.scale_log2e;
+            qf[c] = Vec16<T>::pack(f);
+        }
+    }
+
+    f32x16_t oacc[ND];
+#pragma unroll
+    for (int i = 0; i < ND; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int ntiles = (p.S + KVB - 1) / KVB;
+    const T* kbase = qkv + (size_t)b * p.S * ld + p.H + h * D;
+    const T* vbase = vt + (size_t)bh * D * p.Spad;
+
+    for (int j = 0; j < ntiles; ++j) {
+        const int kv0 = j * KVB;
+        unsigned long long bits = p.kbits[(size_t)b * p.nw64 + (kv0 >> 6)];
+        if (KVB == 32) bits = (bits >> (kv0 & 32)) & 0xffffffffull;
+        if (bits == 0ull) continue;  // whole tile padded (block-uniform)
+
+        __syncthreads();  // everyone is done reading the previous tile
+        for (int q = tid; q < KVB * KNS; q += NT) {
+            const int row = q / KNS, slot = q % KNS;
+            int key = kv0 + row;
+            if (key >= p.S) key = p.S - 1;  // masked below; keep the load in bounds
+            *(uint4*)(sK + swz_row<KRB>(row, slot)) = *(const uint4*)(kbase + (size_t)key * ld + slot * E16);
+        }
+        for (int q = tid; q < D * 8; q += NT) {
+            const int row = q >> 3, slot = q & 7;
+            *(uint4*)(sV + swz_row<VRB>(row, slot)) = *(const uint4*)(vbase + (size_t)row * p.Spad + kv0 + slot * E16);
+        }
+        __syncthreads();
+
+        // ---- S^T = K Q^T ----
+        f32x16_t sacc[NKB];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+#pragma unroll
+            for (int c = 0; c < NQC; ++c) {
+                const uint4 kf = *(const uint4*)(sK + swz_row<KRB>(kb * 32 + li, c * 2 + hi));
+                Mma32<T>::step(kf, qf[c], sacc[kb]);
+            }
+        }
+        // ---- mask + online softmax (base-2) ----
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ko = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const bool valid = (bits >> ko) & 1ull;
+                const float s = valid ? sacc[kb][r] : -INFINITY;
+                sacc[kb][r] = s;
+                mx = fmaxf(mx, s);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = exp2f(m_run - m_use);  // m_run = -inf -> 0
+        float rs = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = exp2f(sacc[kb][r] - m_use);
+                sacc[kb][r] = e;
+                rs += e;
+            }
+        rs += __shfl_xor(rs, 32, 64);
+        l_run = l_run * alpha + rs;
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < ND; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+
+        // ---- P fragments (column operand), straight from the lane's own registers ----
+        uint4 pf[4];
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            float f[Vec16<T>::N];
+#pragma unroll
+            for (int e = 0; e < Vec16<T>::N; ++e) {
+                const int flat = ch * Vec16<T>::N + e;
+                f[e] = sacc[flat >> 4][flat & 15];
+            }
+            pf[ch] = Vec16<T>::pack(f);
+        }
+        // ---- O^T += V^T P^T ----
+#pragma unroll
+        for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) {
+                const uint4 vf = *(const uint4*)(sV + swz_row<VRB>(nd * 32 + li, ch * 2 + hi));
+                Mma32<T>::step(vf, pf[ch], oacc[nd]);
+            }
+    }
+
+    // ---- normalise and store: lane owns query li, dv = nd*32 + (r&3) + 8*(r>>2) + 4*hi ----
+    const int qrow = q0 + wave * 32 + li;
+    if (qrow < p.S) {
+        const float inv = 1.f / l_run;  // all keys padded -> NaN, as the reference's softmax gives
+        T* dst = (T*)p.out + (size_t)(b * p.S + qrow) * p.H + h * D;
+#pragma unroll
+        for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int dv = nd * 32 + 8 * g + 4 * hi;
+                const float v0 = oacc[nd][4 * g + 0] * inv, v1 = oacc[nd][4 * g + 1] * inv;
+                const float v2 = oacc[nd][4 * g + 2] * inv, v3 = oacc[nd][4 * g + 3] * inv;
+                if constexpr (sizeof(T) == 4) {
+                    *(float4*)(dst + dv) = make_float4(v0, v1, v2, v3);
+                } else {
+                    *(uint2*)(dst + dv) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                }
+            }
+    }
+}
+
+// ---- V^T staging: qkv's V columns -> Vt[(b*heads+h)][dv][Spad], zero padded to Spad; for bf16
+// the keys inside each 16-group are permuted to the order the S^T register layout consumes:
+//   pos(o) = ((o>>2)&1)*8 + (o&3) + 4*(o>>3).
+template <typename T, int D>
+__global__ __launch_bounds__(256) void transpose_v_kernel(AttnArgs p) {
+    __shared__ float tile[64][D + 1];
+    const int bh = blockIdx.y, b = bh / p.heads, h = bh % p.heads;
+    const int k0 = blockIdx.x * 64;
+    const int tid = threadIdx.x;
+    const T* __restrict__ qkv = (const T*)p.qkv;
+    const int ld = 3 * p.H;
+    for (int i = tid; i < 64 * D; i += 256) {
+        const int key = i / D, dv = i % D;
+        float v = 0.f;
+        if (k0 + key < p.S) v = Num<T>::to_f32(qkv[(size_t)(b * p.S + k0 + key) * ld + 2 * p.H + h * D + dv]);
+        tile[key][dv] = v;
+    }
+    __syncthreads();
+    T* __restrict__ vt = (T*)p.vt + (size_t)bh * D * p.Spad + k0;
+    for (int i = tid; i < 64 * D; i += 256) {
+        const int dv = i / 64, pos = i % 64;
+        int key = pos;
+        if (sizeof(T) == 2) {  // inverse of pos(o): within the 16-group, pos = hi*8 + j
+            const int g16 = pos & ~15, q = pos & 15, hh = q >> 3, jj = q & 7;
+            key = g16 + (jj & 3) + 8 * (jj >> 2) + 4 * hh;
+        }
+        vt[(size_t)dv * p.Spad + pos] = Num<T>::from_f32(tile[key][dv]);
+    }
+}
+
+template <typename T, int D>
+static int launch_tv(const AttnArgs& a, hipStream_t stream) {
+    hipLaunchKernelGGL((transpose_v_kernel<T, D>), dim3(a.Spad / 64, a.B * a.heads), dim3(256), 0, stream, a);
+    return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
+}
+
+template <typename T, int D>
+static int launch_td(const AttnArgs& a, hipStream_t stream) {
+    const int BH = a.B * a.heads;
+    // small sequences: 2-wave workgroups so the grid still covers the 256 CUs
+    const long blocks4 = (long)((a.S + 127) / 128) * BH;
+    if (blocks4 >= 512) {
+        hipLaunchKernelGGL((attention_kernel<T, D, 4>), dim3((a.S + 127) / 128, BH), dim3(256), 0, stream, a);
+    } else {
+        hipLaunchKernelGGL((attention_kernel<T, D, 2>), dim3((a.S + 63) / 64, BH), dim3(128), 0, stream, a);
+    }
+    return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
+}
+
+int launch_transpose_v(const AttnArgs& a, int dtype, hipStream_t stream) {
+    if (a.B <= 0 || a.S <= 0) return FS2_OK;
+    if (a.Spad % 64 || a.Spad < a.S || a.H % a.heads) return FS2_ERR_SHAPE;
+    const int d = a.H / a.heads;
+#define FS2_TV_CASE(DD)                                                          \
+    if (d == DD) return dtype == FS2_BF16 ? launch_tv<bf16, DD>(a, stream) : launch_tv<float, DD>(a, stream);
+    FS2_TV_CASE(32)
+    FS2_TV_CASE(64)
+    FS2_TV_CASE(128)
+#undef FS2_TV_CASE
+    return FS2_ERR_SHAPE;
+}
+
+int launch_attention(const AttnArgs& a, int dtype, hipStream_t stream) {
+    if (a.B <= 0 || a.S <= 0) return FS2_OK;
+    if (a.Spad % 64 || a.Spad < a.S || a.H % a.heads) return FS2_ERR_SHAPE;
+    const int d = a.H / a.heads;
+#define FS2_ATTN_CASE(DD)                                                        \
+    if (d == DD) return dtype == FS2_BF16 ? launch_td<bf16, DD>(a, stream) : launch_td<float, DD>(a, stream);
+    FS2_ATTN_CASE(32)
+    FS2_ATTN_CASE(64)
+    FS2_ATTN_CASE(128)
+#undef FS2_ATTN_CASE
+    return FS2_ERR_SHAPE;
+}
+
+}  // namespace fs2

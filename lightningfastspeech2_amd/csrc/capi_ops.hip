@@ -1,0 +1,119 @@
+// Single-operator entry points of the C ABI (include/fs2.h): each wraps one launcher so the
+// parity tests can compare every kernel against the CPU oracle's corresponding op in isolation.
+#include <math.h>
+
+#include "fs2_common.h"
+#include "fs2_kernels.h"
+
+using namespace fs2;
+
+namespace fs2 {
+
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void convert_kernel(const S* __restrict__ s, D* __restrict__ d, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        d[i] = Num<D>::from_f32(Num<S>::to_f32(s[i]));
+}
+
+int launch_convert(const ConvertArgs& a, int sdt, int ddt, hipStream_t st) {
+    if (a.n == 0) return FS2_OK;
+    size_t blocks = (a.n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    const dim3 g((unsigned)blocks), b(256);
+    if (sdt == FS2_F32 && ddt == FS2_F32) hipLaunchKernelGGL((convert_kernel<float, float>), g, b, 0, st, (const float*)a.src, (float*)a.dst, a.n);
+    else if (sdt == FS2_F32 && ddt == FS2_BF16) hipLaunchKernelGGL((convert_kernel<float, bf16>), g, b, 0, st, (const float*)a.src, (bf16*)a.dst, a.n);
+    else if (sdt == FS2_BF16 && ddt == FS2_F32) hipLaunchKernelGGL((convert_kernel<bf16, float>), g, b, 0, st, (const bf16*)a.src, (float*)a.dst, a.n);
+    else if (sdt == FS2_BF16 && ddt == FS2_BF16) hipLaunchKernelGGL((convert_kernel<bf16, bf16>), g, b, 0, st, (const bf16*)a.src, (bf16*)a.dst, a.n);
+    else return FS2_ERR_ARG;
+    return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
+}
+
+}  // namespace fs2
+
+extern "C" {
+
+int fs2_op_convert(int32_t sdt, int32_t ddt, const void* src, void* dst, size_t n, void* stream) {
+    ConvertArgs a{src, dst, n};
+    return launch_convert(a, sdt, ddt, (hipStream_t)stream);
+}
+
+int fs2_op_gemm(int32_t dtype, int32_t out_dtype, const void* x, const void* w, const float* bias, void* c,
+                int32_t M, int32_t N, int32_t Cin, int32_t taps, int32_t S, int32_t relu, void* stream) {
+    GemmArgs a;
+    a.X = x; a.W = w; a.bias = bias; a.C = c;
+    a.M = M; a.N = N; a.K = taps * Cin; a.ldx = Cin; a.ldc = N;
+    a.Cin = Cin; a.taps = taps; a.pad = (taps - 1) / 2; a.S = S; a.relu = relu;
+    return launch_gemm(a, dtype, out_dtype, (hipStream_t)stream);
+}
+
+size_t fs2_op_attention_scratch_bytes(int32_t dtype, int32_t B, int32_t S, int32_t H, int32_t heads, size_t* bits_bytes) {
+    (void)heads;
+    const size_t Spad = ((size_t)S + 63) / 64 * 64;
+    if (bits_bytes) *bits_bytes = (size_t)B * (Spad / 64) * 8;
+    return (size_t)B * H * Spad * (dtype == FS2_BF16 ? 2 : 4);
+}
+
+int fs2_op_attention(int32_t dtype, const void* qkv, const uint8_t* key_pad_mask, void* out, void* vt_scratch,
+                     uint64_t* bits_scratch, int32_t B, int32_t S, int32_t H, int32_t heads, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int Spad = (S + 63) / 64 * 64;
+    MaskBitsArgs mb{key_pad_mask, bits_scratch, B, S, Spad / 64};
+    int r = launch_mask_bits(mb, st);
+    if (r != FS2_OK) return r;
+    AttnArgs a;
+    a.qkv = qkv; a.vt = vt_scratch; a.kbits = bits_scratch; a.out = out;
+    a.B = B; a.S = S; a.H = H; a.heads = heads; a.Spad = Spad; a.nw64 = Spad / 64;
+    a.scale_log2e = (float)(1.4426950408889634 / sqrt((double)(H / heads)));
+    r = launch_transpose_v(a, dtype, st);
+    if (r != FS2_OK) return r;
+    return launch_attention(a, dtype, st);
+}
+
+int fs2_op_layernorm(int32_t dtype, const void* x, const void* res, const float* gamma, const float* beta, void* y,
+                     const float* dot_w, float dot_b, const uint8_t* mask, float* pred, int32_t M, int32_t H,
+                     void* stream) {
+    LayerNormArgs a;
+    a.x = x; a.res = res; a.gamma = gamma; a.beta = beta; a.y = y;
+    a.dot_w = dot_w; a.dot_b = dot_b; a.mask = mask; a.pred = pred;
+    a.M = M; a.H = H; a.eps = 1e-5f;
+    return launch_layernorm(a, dtype, (hipStream_t)stream);
+}
+
+int fs2_op_dwconv(int32_t dtype, const void* x, const float* w, const float* bias, void* y, int32_t B, int32_t S,
+                  int32_t C, int32_t k, void* stream) {
+    DwConvArgs a{x, w, bias, y, B, S, C, k, (k - 1) / 2};
+    return launch_dwconv(a, dtype, (hipStream_t)stream);
+}
+
+int fs2_op_durations(const float* dur_pred, const uint8_t* src_mask, const int32_t* forced, int32_t* dur,
+                     int32_t* cum, int32_t* totals, int32_t* guard, int32_t B, int32_t L, void* stream) {
+    DurationArgs a{dur_pred, src_mask, forced, dur, cum, totals, guard, B, L};
+    return launch_durations(a, (hipStream_t)stream);
+}
+
+int fs2_op_regulate(int32_t dtype, const void* x, const int32_t* cum, const int32_t* totals, void* y,
+                    uint8_t* tgt_mask, int32_t B, int32_t L, int32_t T, int32_t H, void* stream) {
+    RegulateArgs a{x, cum, totals, y, tgt_mask, B, L, T, H};
+    return launch_regulate(a, dtype, (hipStream_t)stream);
+}
+
+int fs2_op_bucket_embed(int32_t dtype, const void* x, const float* pred, const float* bins, const float* emb,
+                        int32_t nbins, float std, float mean, const float* pe, const float* spk, void* y,
+                        int32_t* idx_out, int32_t B, int32_t T, int32_t H, void* stream) {
+    BucketArgs a{x, pred, bins, emb, nbins, std, mean, pe, spk, y, idx_out, B, T, H};
+    return launch_bucket_embed(a, dtype, (hipStream_t)stream);
+}
+
+int fs2_op_embed(int32_t dtype, const int64_t* phones, const float* table, const float* pe, const float* spk,
+                 void* x, uint8_t* src_mask, int32_t B, int32_t L, int32_t H, int32_t n_phones, void* stream) {
+    EmbedArgs a{phones, table, pe, spk, x, src_mask, B, L, H, n_phones};
+    return launch_embed(a, dtype, (hipStream_t)stream);
+}
+
+int fs2_op_spk_proj(const float* dvec, const float* w, const float* b, float* spk, int32_t B, int32_t H,
+                    int32_t Din, void* stream) {
+    SpkProjArgs a{dvec, w, b, spk, B, H, Din};
+    return launch_spk_proj(a, (hipStream_t)stream);
+}
+
+}  // extern "C"

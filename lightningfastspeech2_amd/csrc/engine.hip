@@ -1,0 +1,835 @@
+// Host side of libfs2_hip.so: weight store (reference state_dict names), packing/folding, the
+// two-phase forward and the extern "C" surface declared in include/fs2.h.
+//
+// Forward composition follows FastSpeech2.forward (litfass/fastspeech2/fastspeech2.py:636-731)
+// and VarianceAdaptor.forward (litfass/fastspeech2/model.py:249-341); see DESIGN.md for the
+// kernel-by-kernel map.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "fs2_common.h"
+#include "fs2_kernels.h"
+
+using namespace fs2;
+
+namespace {
+
+struct HostTensor {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+};
+
+struct Arena {
+    char* base = nullptr;
+    size_t cap = 0, off = 0;
+    int reserve(size_t bytes) {
+        off = 0;
+        if (bytes <= cap) return FS2_OK;
+        if (base) (void)hipFree(base);
+        base = nullptr;
+        cap = 0;
+        bytes += bytes / 8;  // slack so slowly growing shapes do not reallocate every call
+        if (hipMalloc((void**)&base, bytes) != hipSuccess) return FS2_ERR_NOMEM;
+        cap = bytes;
+        return FS2_OK;
+    }
+    void* take(size_t bytes) {
+        const size_t a = (off + 255) & ~(size_t)255;
+        if (a + bytes > cap) return nullptr;
+        off = a + bytes;
+        return base + a;
+    }
+    void release() {
+        if (base) (void)hipFree(base);
+        base = nullptr;
+        cap = off = 0;
+    }
+};
+inline size_t al(size_t b) { return (b + 255) & ~(size_t)255; }
+
+struct ConvW {     // dense conv or pointwise: W (N, taps*Cin) in engine dtype, bias fp32
+    void* w = nullptr;
+    float* b = nullptr;
+    int N = 0, Cin = 0, taps = 1;
+};
+struct DwW {       // depth-wise conv weights fp32 (C, k) + bias
+    float* w = nullptr;
+    float* b = nullptr;
+    int C = 0, k = 1;
+};
+struct LayerW {
+    ConvW in_proj, out_proj;
+    float *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
+    bool depthwise = false;
+    DwW dw;          // conv1.0 (depth-wise only)
+    ConvW c1, c2;    // dense: conv1 (k taps) / conv2; depth-wise: conv1.1 / folded conv2.0*conv2.1
+};
+struct PredLayerW {
+    bool depthwise = false;
+    DwW dw;
+    ConvW c;
+    float *g = nullptr, *b = nullptr;
+};
+struct PredictorW {
+    std::vector<PredLayerW> layers;
+    float* head_w = nullptr;
+    float head_b = 0.f;
+    int filt = 0;
+};
+struct VarianceW {
+    PredictorW pred;
+    float* bins = nullptr;
+    float* emb = nullptr;
+};
+
+struct ProfSlot {
+    bool enabled = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    size_t used = 0;
+    double flops = 0, bytes = 0;
+};
+
+}  // namespace
+
+struct fs2_engine {
+    fs2_config cfg;
+    int dt = FS2_F32;
+    size_t esz = 4;
+    char err[512];
+    bool finalized = false;
+    bool debug = false;
+    std::map<std::string, HostTensor> host;
+    std::map<std::string, std::vector<int64_t>> spec;
+    std::vector<void*> dev_allocs;
+    // device weights
+    float *phone_table = nullptr, *pe = nullptr, *spk_w = nullptr, *spk_b = nullptr;
+    std::vector<LayerW> enc, dec;
+    PredictorW dur;
+    std::vector<VarianceW> vars;
+    ConvW mel;
+    // run state
+    Arena persist, scratch, dbg;
+    int B = 0, L = 0, T = 0;
+    bool encoded = false;
+    void *xA = nullptr, *xB = nullptr;  // (B*L, H) encoder ping-pong; xA = encoder_out
+    float* spk = nullptr;
+    float* dur_pred = nullptr;
+    int32_t *d_dur = nullptr, *d_cum = nullptr, *d_totals = nullptr, *d_guard = nullptr;
+    uint8_t* src_mask = nullptr;
+    int32_t* h_pinned = nullptr;  // 2*B ints: totals, guard
+    int h_pinned_cap = 0;
+    std::vector<int32_t> totals, guard;
+    std::map<std::string, std::pair<void*, size_t>> taps;
+    ProfSlot prof[FS2_K_COUNT];
+};
+
+namespace {
+
+int fail(fs2_engine* e, int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(e->err, sizeof(e->err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIPCHK(e, call)                                                                        \
+    do {                                                                                       \
+        hipError_t _s = (call);                                                                \
+        if (_s != hipSuccess) return fail(e, FS2_ERR_HIP, "%s: %s", #call, hipGetErrorString(_s)); \
+    } while (0)
+#define CHK(call)                       \
+    do {                                \
+        int _r = (call);                \
+        if (_r != FS2_OK) return _r;    \
+    } while (0)
+
+// ---- expected tensors (mirror of lightningfastspeech2_amd/weights.py:state_dict_spec) -----------
+void conformer_spec(fs2_engine* e, const std::string& p, int H, int F, int k, bool dw) {
+    auto& s = e->spec;
+    s[p + ".self_attn.in_proj_weight"] = {3 * H, H};
+    s[p + ".self_attn.in_proj_bias"] = {3 * H};
+    s[p + ".self_attn.out_proj.weight"] = {H, H};
+    s[p + ".self_attn.out_proj.bias"] = {H};
+    s[p + ".norm1.weight"] = {H};
+    s[p + ".norm1.bias"] = {H};
+    s[p + ".norm2.weight"] = {H};
+    s[p + ".norm2.bias"] = {H};
+    if (dw) {
+        s[p + ".conv1.0.weight"] = {H, 1, k};
+        s[p + ".conv1.0.bias"] = {H};
+        s[p + ".conv1.1.weight"] = {F, H, 1};
+        s[p + ".conv1.1.bias"] = {F};
+        s[p + ".conv2.0.weight"] = {F, F / H, 1};
+        s[p + ".conv2.0.bias"] = {F};
+        s[p + ".conv2.1.weight"] = {H, F, 1};
+        s[p + ".conv2.1.bias"] = {H};
+    } else {
+        s[p + ".conv1.weight"] = {F, H, k};
+        s[p + ".conv1.bias"] = {F};
+        s[p + ".conv2.weight"] = {H, F, 1};
+        s[p + ".conv2.bias"] = {H};
+    }
+}
+void predictor_spec(fs2_engine* e, const std::string& p, int nl, int cin, int filt, int k, bool dw) {
+    auto& s = e->spec;
+    for (int j = 0; j < nl; ++j) {
+        const std::string q = p + ".layers." + std::to_string(j) + ".layers";
+        if (dw) {
+            s[q + ".0.module.0.weight"] = {cin, 1, k};
+            s[q + ".0.module.0.bias"] = {cin};
+            s[q + ".0.module.1.weight"] = {filt, cin, 1};
+            s[q + ".0.module.1.bias"] = {filt};
+        } else {
+            s[q + ".0.module.weight"] = {filt, cin, k};
+            s[q + ".0.module.bias"] = {filt};
+        }
+        s[q + ".2.weight"] = {filt};
+        s[q + ".2.bias"] = {filt};
+    }
+    s[p + ".linear.weight"] = {1, filt};
+    s[p + ".linear.bias"] = {1};
+}
+void build_spec(fs2_engine* e) {
+    const fs2_config& c = e->cfg;
+    const int H = c.hidden;
+    e->spec["phone_embedding.weight"] = {c.n_phones, H};
+    for (int i = 0; i < c.enc_layers; ++i)
+        conformer_spec(e, "encoder.layers." + std::to_string(i), H, c.enc_filter, c.enc_kernels[i], c.enc_depthwise);
+    for (int i = 0; i < c.dec_layers; ++i)
+        conformer_spec(e, "decoder.layers." + std::to_string(i), H, c.dec_filter, c.dec_kernels[i], c.dec_depthwise);
+    e->spec["positional_encoding.pe"] = {1, c.pe_len, H};
+    predictor_spec(e, "variance_adaptor.duration_predictor", c.dur_nlayers, H, c.dur_filter, c.dur_kernel, c.dur_depthwise);
+    for (int v = 0; v < c.n_variances; ++v) {
+        const std::string p = std::string("variance_adaptor.encoders.") + c.var_names[v];
+        e->spec[p + ".bins"] = {c.var_nbins - 1};
+        e->spec[p + ".embedding.weight"] = {c.var_nbins, H};
+        predictor_spec(e, p + ".predictor", c.var_nlayers[v], H, c.var_filter, c.var_kernel[v], c.var_depthwise);
+    }
+    e->spec["linear.weight"] = {c.n_mels, H};
+    e->spec["linear.bias"] = {c.n_mels};
+    e->spec["speaker_embedding.projection.weight"] = {H, c.dvec_dim};
+    e->spec["speaker_embedding.projection.bias"] = {H};
+}
+
+int check_config(fs2_engine* e) {
+    const fs2_config& c = e->cfg;
+    if (c.abi_version != FS2_ABI_VERSION) return fail(e, FS2_ERR_ARG, "abi_version %d != %d", c.abi_version, FS2_ABI_VERSION);
+    if (c.dtype != FS2_F32 && c.dtype != FS2_BF16) return fail(e, FS2_ERR_ARG, "bad dtype");
+    const int H = c.hidden;
+    if (H <= 0 || H % 64 || H > 1024) return fail(e, FS2_ERR_SHAPE, "hidden=%d must be a multiple of 64, <= 1024", H);
+    if (c.enc_layers < 0 || c.enc_layers > FS2_MAX_LAYERS || c.dec_layers < 0 || c.dec_layers > FS2_MAX_LAYERS)
+        return fail(e, FS2_ERR_SHAPE, "layer count out of range");
+    if (c.n_variances < 0 || c.n_variances > FS2_MAX_VARIANCES) return fail(e, FS2_ERR_SHAPE, "n_variances out of range");
+    const int heads[2] = {c.enc_heads, c.dec_heads};
+    for (int i = 0; i < 2; ++i) {
+        if (heads[i] <= 0 || H % heads[i]) return fail(e, FS2_ERR_SHAPE, "heads must divide hidden");
+        const int d = H / heads[i];
+        if (d != 32 && d != 64 && d != 128) return fail(e, FS2_ERR_SHAPE, "head dim %d not in {32,64,128}", d);
+    }
+    const int F[2] = {c.enc_filter, c.dec_filter};
+    const int dw[2] = {c.enc_depthwise, c.dec_depthwise};
+    for (int i = 0; i < 2; ++i) {
+        if (F[i] <= 0 || F[i] % 64) return fail(e, FS2_ERR_SHAPE, "conv_filter_size must be a multiple of 64");
+        if (dw[i] && F[i] % H) return fail(e, FS2_ERR_SHAPE, "depth-wise FFN needs filter %% hidden == 0");
+    }
+    for (int i = 0; i < c.enc_layers; ++i)
+        if (c.enc_kernels[i] < 1 || c.enc_kernels[i] > 31 || !(c.enc_kernels[i] & 1)) return fail(e, FS2_ERR_SHAPE, "encoder kernel sizes must be odd, <= 31");
+    for (int i = 0; i < c.dec_layers; ++i)
+        if (c.dec_kernels[i] < 1 || c.dec_kernels[i] > 31 || !(c.dec_kernels[i] & 1)) return fail(e, FS2_ERR_SHAPE, "decoder kernel sizes must be odd, <= 31");
+    if (c.var_filter % 64 || c.dur_filter % 64 || c.var_filter > 1024 || c.dur_filter > 1024)
+        return fail(e, FS2_ERR_SHAPE, "predictor filter sizes must be multiples of 64, <= 1024");
+    if (c.dur_nlayers < 1) return fail(e, FS2_ERR_SHAPE, "duration_nlayers < 1");
+    if (c.dur_nlayers > 1 && c.dur_filter != H) return fail(e, FS2_ERR_SHAPE, "duration_filter_size != hidden with nlayers > 1");
+    if (!(c.dur_kernel & 1) || c.dur_kernel > 31) return fail(e, FS2_ERR_SHAPE, "duration kernel must be odd, <= 31");
+    for (int v = 0; v < c.n_variances; ++v) {
+        if (c.var_nlayers[v] < 1) return fail(e, FS2_ERR_SHAPE, "variance_nlayers < 1");
+        if (c.var_nlayers[v] > 1 && c.var_filter != H) return fail(e, FS2_ERR_SHAPE, "variance_filter_size != hidden with nlayers > 1");
+        if (!(c.var_kernel[v] & 1) || c.var_kernel[v] > 31) return fail(e, FS2_ERR_SHAPE, "variance kernel must be odd, <= 31");
+    }
+    if (c.var_nbins < 2 && c.n_variances) return fail(e, FS2_ERR_SHAPE, "variance_nbins < 2");
+    if (c.n_mels <= 0 || c.n_mels % 4) return fail(e, FS2_ERR_SHAPE, "n_mels must be a positive multiple of 4");
+    if (c.dvec_dim <= 0 || c.max_frames <= 0 || c.pe_len <= 0 || c.n_phones <= 0) return fail(e, FS2_ERR_ARG, "non-positive size");
+    return FS2_OK;
+}
+
+// ---- upload helpers ---------------------------------------------------------------------------
+int dev_alloc(fs2_engine* e, void** p, size_t bytes) {
+    if (hipMalloc(p, bytes ? bytes : 256) != hipSuccess) return fail(e, FS2_ERR_NOMEM, "hipMalloc(%zu) failed", bytes);
+    e->dev_allocs.push_back(*p);
+    return FS2_OK;
+}
+int upload_f32(fs2_engine* e, const float* h, size_t n, float** out) {
+    CHK(dev_alloc(e, (void**)out, n * 4));
+    HIPCHK(e, hipMemcpy(*out, h, n * 4, hipMemcpyHostToDevice));
+    return FS2_OK;
+}
+int upload_mat(fs2_engine* e, const float* h, size_t n, void** out) {  // in the engine dtype
+    if (e->dt == FS2_F32) return upload_f32(e, h, n, (float**)out);
+    std::vector<unsigned short> tmp(n);
+    for (size_t i = 0; i < n; ++i) tmp[i] = f32_to_bf16(h[i]).v;
+    CHK(dev_alloc(e, out, n * 2));
+    HIPCHK(e, hipMemcpy(*out, tmp.data(), n * 2, hipMemcpyHostToDevice));
+    return FS2_OK;
+}
+const HostTensor& W(fs2_engine* e, const std::string& n) { return e->host.at(n); }
+
+// conv weight (N, Cin, k) -> (N, k*Cin) tap-major
+int make_conv(fs2_engine* e, const std::string& wname, const std::string& bname, ConvW* out) {
+    const HostTensor& w = W(e, wname);
+    const int N = (int)w.shape[0], Cin = (int)w.shape[1], k = w.shape.size() > 2 ? (int)w.shape[2] : 1;
+    std::vector<float> packed((size_t)N * Cin * k);
+    for (int n = 0; n < N; ++n)
+        for (int c = 0; c < Cin; ++c)
+            for (int t = 0; t < k; ++t) packed[((size_t)n * k + t) * Cin + c] = w.data[((size_t)n * Cin + c) * k + t];
+    out->N = N;
+    out->Cin = Cin;
+    out->taps = k;
+    CHK(upload_mat(e, packed.data(), packed.size(), &out->w));
+    const HostTensor& b = W(e, bname);
+    return upload_f32(e, b.data.data(), b.data.size(), &out->b);
+}
+int make_dw(fs2_engine* e, const std::string& wname, const std::string& bname, DwW* out) {
+    const HostTensor& w = W(e, wname);  // (C, 1, k)
+    out->C = (int)w.shape[0];
+    out->k = (int)w.shape[2];
+    CHK(upload_f32(e, w.data.data(), w.data.size(), &out->w));
+    const HostTensor& b = W(e, bname);
+    return upload_f32(e, b.data.data(), b.data.size(), &out->b);
+}
+// conv2 = Sequential(grouped k=1 conv (groups=H over F channels), pointwise F->H) has no
+// non-linearity in between (model.py:84-93), so it is one linear map: W' = W21 * blockdiag(G),
+// b' = W21 * bg + b21.  Folded once here in double precision.
+int make_folded_conv2(fs2_engine* e, const std::string& p, int H, int F, ConvW* out) {
+    const HostTensor& G = W(e, p + ".conv2.0.weight");   // (F, F/H, 1)
+    const HostTensor& bg = W(e, p + ".conv2.0.bias");    // (F)
+    const HostTensor& W2 = W(e, p + ".conv2.1.weight");  // (H, F, 1)
+    const HostTensor& b2 = W(e, p + ".conv2.1.bias");    // (H)
+    const int gs = F / H;
+    std::vector<float> Wf((size_t)H * F), bf(H);
+    for (int o = 0; o < H; ++o) {
+        double bacc = b2.data[o];
+        for (int f = 0; f < F; ++f) bacc += (double)W2.data[(size_t)o * F + f] * bg.data[f];
+        bf[o] = (float)bacc;
+        for (int g = 0; g < H; ++g)
+            for (int j = 0; j < gs; ++j) {
+                double acc = 0;
+                for (int i = 0; i < gs; ++i) {
+                    const int f = g * gs + i;  // output channel of the grouped conv inside group g
+                    acc += (double)W2.data[(size_t)o * F + f] * G.data[(size_t)f * gs + j];
+                }
+                Wf[(size_t)o * F + g * gs + j] = (float)acc;
+            }
+    }
+    out->N = H;
+    out->Cin = F;
+    out->taps = 1;
+    CHK(upload_mat(e, Wf.data(), Wf.size(), &out->w));
+    return upload_f32(e, bf.data(), bf.size(), &out->b);
+}
+int up_vec(fs2_engine* e, const std::string& n, float** out) {
+    const HostTensor& t = W(e, n);
+    return upload_f32(e, t.data.data(), t.data.size(), out);
+}
+int make_layer(fs2_engine* e, const std::string& p, int H, int F, bool dw, LayerW* L) {
+    L->depthwise = dw;
+    CHK(make_conv(e, p + ".self_attn.in_proj_weight", p + ".self_attn.in_proj_bias", &L->in_proj));
+    CHK(make_conv(e, p + ".self_attn.out_proj.weight", p + ".self_attn.out_proj.bias", &L->out_proj));
+    CHK(up_vec(e, p + ".norm1.weight", &L->g1));
+    CHK(up_vec(e, p + ".norm1.bias", &L->b1));
+    CHK(up_vec(e, p + ".norm2.weight", &L->g2));
+    CHK(up_vec(e, p + ".norm2.bias", &L->b2));
+    if (dw) {
+        CHK(make_dw(e, p + ".conv1.0.weight", p + ".conv1.0.bias", &L->dw));
+        CHK(make_conv(e, p + ".conv1.1.weight", p + ".conv1.1.bias", &L->c1));
+        CHK(make_folded_conv2(e, p, H, F, &L->c2));
+    } else {
+        CHK(make_conv(e, p + ".conv1.weight", p + ".conv1.bias", &L->c1));
+        CHK(make_conv(e, p + ".conv2.weight", p + ".conv2.bias", &L->c2));
+    }
+    return FS2_OK;
+}
+int make_predictor(fs2_engine* e, const std::string& p, int nl, int filt, bool dw, PredictorW* P) {
+    P->filt = filt;
+    P->layers.resize(nl);
+    for (int j = 0; j < nl; ++j) {
+        const std::string q = p + ".layers." + std::to_string(j) + ".layers";
+        PredLayerW& Lw = P->layers[j];
+        Lw.depthwise = dw;
+        if (dw) {
+            CHK(make_dw(e, q + ".0.module.0.weight", q + ".0.module.0.bias", &Lw.dw));
+            CHK(make_conv(e, q + ".0.module.1.weight", q + ".0.module.1.bias", &Lw.c));
+        } else {
+            CHK(make_conv(e, q + ".0.module.weight", q + ".0.module.bias", &Lw.c));
+        }
+        CHK(up_vec(e, q + ".2.weight", &Lw.g));
+        CHK(up_vec(e, q + ".2.bias", &Lw.b));
+    }
+    CHK(up_vec(e, p + ".linear.weight", &P->head_w));
+    P->head_b = W(e, p + ".linear.bias").data[0];
+    return FS2_OK;
+}
+
+// ---- profiling brackets -----------------------------------------------------------------------
+struct Bracket {
+    fs2_engine* e;
+    int cls;
+    hipStream_t st;
+    hipEvent_t stop = nullptr;
+    Bracket(fs2_engine* e_, int cls_, hipStream_t st_, double flops, double bytes) : e(e_), cls(cls_), st(st_) {
+        ProfSlot& s = e->prof[cls];
+        if (!s.enabled) return;
+        if (s.used == s.ev.size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+            s.ev.emplace_back(a, b);
+        }
+        (void)hipEventRecord(s.ev[s.used].first, st);
+        stop = s.ev[s.used].second;
+        s.used++;
+        s.flops += flops;
+        s.bytes += bytes;
+    }
+    ~Bracket() {
+        if (stop) (void)hipEventRecord(stop, st);
+    }
+};
+
+// ---- op wrappers used by the forward ------------------------------------------------------------
+int gemm(fs2_engine* e, hipStream_t st, const ConvW& w, const void* x, void* c, int M, int S, bool relu, int out_dt) {
+    GemmArgs a;
+    a.X = x;
+    a.W = w.w;
+    a.bias = w.b;
+    a.C = c;
+    a.M = M;
+    a.N = w.N;
+    a.K = w.taps * w.Cin;
+    a.ldx = w.Cin;
+    a.ldc = w.N;
+    a.Cin = w.Cin;
+    a.taps = w.taps;
+    a.pad = (w.taps - 1) / 2;
+    a.S = S;
+    a.relu = relu;
+    const double osz = out_dt == FS2_BF16 ? 2 : 4;
+    Bracket br(e, w.taps > 1 ? FS2_K_CONV_GEMM : FS2_K_GEMM, st, 2.0 * M * (double)a.N * a.K,
+               (double)M * w.Cin * e->esz + (double)a.N * a.K * e->esz + (double)M * a.N * osz);
+    const int r = launch_gemm(a, e->dt, out_dt, st);
+    if (r != FS2_OK) return fail(e, r, "gemm launch failed (M=%d N=%d K=%d)", M, a.N, a.K);
+    return FS2_OK;
+}
+int layernorm(fs2_engine* e, hipStream_t st, const void* x, const void* res, const float* g, const float* b, void* y,
+              int M, int H, const float* dot_w = nullptr, float dot_b = 0.f, const uint8_t* mask = nullptr,
+              float* pred = nullptr) {
+    LayerNormArgs a;
+    a.x = x; a.res = res; a.gamma = g; a.beta = b; a.y = y;
+    a.dot_w = dot_w; a.dot_b = dot_b; a.mask = mask; a.pred = pred;
+    a.M = M; a.H = H; a.eps = 1e-5f;
+    Bracket br(e, FS2_K_ROWOPS, st, 0, (double)M * H * e->esz * (res ? 3 : 2));
+    const int r = launch_layernorm(a, e->dt, st);
+    if (r != FS2_OK) return fail(e, r, "layernorm launch failed");
+    return FS2_OK;
+}
+int dwconv(fs2_engine* e, hipStream_t st, const DwW& w, const void* x, void* y, int B, int S) {
+    DwConvArgs a;
+    a.x = x; a.w = w.w; a.bias = w.b; a.y = y;
+    a.B = B; a.S = S; a.C = w.C; a.k = w.k; a.pad = (w.k - 1) / 2;
+    Bracket br(e, FS2_K_ROWOPS, st, 2.0 * B * S * (double)w.C * w.k, 2.0 * B * S * (double)w.C * e->esz);
+    const int r = launch_dwconv(a, e->dt, st);
+    if (r != FS2_OK) return fail(e, r, "dwconv launch failed");
+    return FS2_OK;
+}
+
+struct LayerScratch {
+    void *qkv, *att, *proj, *hid, *u, *vt;
+    uint64_t* bits;
+    int Spad, nw64;
+};
+
+// ConformerEncoderLayer.forward, post-LN (model.py:113-115); result back in x (tmp is the other
+// half of the ping-pong pair).
+int conformer(fs2_engine* e, hipStream_t st, const LayerW& w, void* x, void* tmp, int B, int S, int heads,
+              const LayerScratch& sc) {
+    const int H = e->cfg.hidden, M = B * S;
+    CHK(gemm(e, st, w.in_proj, x, sc.qkv, M, M, false, e->dt));
+    AttnArgs a;
+    a.qkv = sc.qkv; a.vt = sc.vt; a.kbits = sc.bits; a.out = sc.att;
+    a.B = B; a.S = S; a.H = H; a.heads = heads; a.Spad = sc.Spad; a.nw64 = sc.nw64;
+    a.scale_log2e = (float)(1.4426950408889634 / sqrt((double)(H / heads)));
+    {
+        Bracket br(e, FS2_K_ROWOPS, st, 0, 2.0 * M * H * e->esz);
+        const int r = launch_transpose_v(a, e->dt, st);
+        if (r != FS2_OK) return fail(e, r, "transpose_v launch failed");
+    }
+    {
+        Bracket br(e, FS2_K_ATTENTION, st, 4.0 * B * (double)S * S * H, 4.0 * M * H * e->esz);
+        const int r = launch_attention(a, e->dt, st);
+        if (r != FS2_OK) return fail(e, r, "attention launch failed");
+    }
+    CHK(gemm(e, st, w.out_proj, sc.att, sc.proj, M, M, false, e->dt));
+    CHK(layernorm(e, st, sc.proj, x, w.g1, w.b1, tmp, M, H));
+    if (w.depthwise) {
+        CHK(dwconv(e, st, w.dw, tmp, sc.u, B, S));
+        CHK(gemm(e, st, w.c1, sc.u, sc.hid, M, S, true, e->dt));
+    } else {
+        CHK(gemm(e, st, w.c1, tmp, sc.hid, M, S, true, e->dt));
+    }
+    CHK(gemm(e, st, w.c2, sc.hid, sc.proj, M, S, false, e->dt));
+    CHK(layernorm(e, st, sc.proj, tmp, w.g2, w.b2, x, M, H));
+    return FS2_OK;
+}
+
+// VariancePredictor.forward (model.py:510-522): pred (B*S) fp32, 0 where mask
+int predictor(fs2_engine* e, hipStream_t st, const PredictorW& P, const void* x, int B, int S, const uint8_t* mask,
+              float* pred, const LayerScratch& sc) {
+    const int M = B * S;
+    const void* src = x;
+    for (size_t j = 0; j < P.layers.size(); ++j) {
+        const PredLayerW& Lw = P.layers[j];
+        const bool last = j + 1 == P.layers.size();
+        if (Lw.depthwise) {
+            CHK(dwconv(e, st, Lw.dw, src, sc.u, B, S));
+            CHK(gemm(e, st, Lw.c, sc.u, sc.proj, M, S, true, e->dt));
+        } else {
+            CHK(gemm(e, st, Lw.c, src, sc.proj, M, S, true, e->dt));
+        }
+        if (last) CHK(layernorm(e, st, sc.proj, nullptr, Lw.g, Lw.b, nullptr, M, P.filt, P.head_w, P.head_b, mask, pred));
+        else CHK(layernorm(e, st, sc.proj, nullptr, Lw.g, Lw.b, sc.att, M, P.filt));
+        src = sc.att;
+    }
+    return FS2_OK;
+}
+
+size_t layer_scratch_bytes(const fs2_engine* e, int B, int S) {
+    const fs2_config& c = e->cfg;
+    const size_t H = c.hidden, M = (size_t)B * S, esz = e->esz;
+    size_t Fm = c.enc_filter > c.dec_filter ? c.enc_filter : c.dec_filter;
+    size_t Pm = H;
+    if ((size_t)c.var_filter > Pm) Pm = c.var_filter;
+    if ((size_t)c.dur_filter > Pm) Pm = c.dur_filter;
+    const size_t Spad = ((size_t)S + 63) / 64 * 64;
+    return al(M * 3 * H * esz) + 2 * al(M * Pm * esz) + al(M * Fm * esz) + al(M * H * esz) + al((size_t)B * H * Spad * esz) +
+           al((size_t)B * (Spad / 64) * 8) + 4096;
+}
+int take_layer_scratch(fs2_engine* e, Arena& ar, int B, int S, LayerScratch* sc) {
+    const fs2_config& c = e->cfg;
+    const size_t H = c.hidden, M = (size_t)B * S, esz = e->esz;
+    size_t Fm = c.enc_filter > c.dec_filter ? c.enc_filter : c.dec_filter;
+    size_t Pm = H;
+    if ((size_t)c.var_filter > Pm) Pm = c.var_filter;
+    if ((size_t)c.dur_filter > Pm) Pm = c.dur_filter;
+    sc->Spad = (S + 63) / 64 * 64;
+    sc->nw64 = sc->Spad / 64;
+    sc->qkv = ar.take(M * 3 * H * esz);
+    sc->att = ar.take(M * Pm * esz);
+    sc->proj = ar.take(M * Pm * esz);
+    sc->hid = ar.take(M * Fm * esz);
+    sc->u = ar.take(M * H * esz);
+    sc->vt = ar.take((size_t)B * H * sc->Spad * esz);
+    sc->bits = (uint64_t*)ar.take((size_t)B * sc->nw64 * 8);
+    if (!sc->qkv || !sc->att || !sc->proj || !sc->hid || !sc->u || !sc->vt || !sc->bits)
+        return fail(e, FS2_ERR_NOMEM, "scratch arena too small");
+    return FS2_OK;
+}
+
+int tap_store(fs2_engine* e, hipStream_t st, const std::string& name, const void* src, size_t n, int src_dt) {
+    void* dst = e->dbg.take(n * 4);
+    if (!dst) return fail(e, FS2_ERR_NOMEM, "debug arena too small");
+    ConvertArgs a{src, dst, n};
+    const int r = launch_convert(a, src_dt, FS2_F32, st);
+    if (r != FS2_OK) return fail(e, r, "convert launch failed");
+    e->taps[name] = {dst, n * 4};
+    return FS2_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int fs2_abi_version(void) { return FS2_ABI_VERSION; }
+
+const char* fs2_status_string(int s) {
+    switch (s) {
+        case FS2_OK: return "ok";
+        case FS2_ERR_HIP: return "HIP runtime error";
+        case FS2_ERR_SHAPE: return "unsupported shape/config";
+        case FS2_ERR_ARG: return "bad argument";
+        case FS2_ERR_WEIGHT: return "weight error";
+        case FS2_ERR_STATE: return "call order violated";
+        case FS2_ERR_NOMEM: return "out of device memory";
+    }
+    return "unknown status";
+}
+
+const char* fs2_last_error(const fs2_engine* e) { return e ? e->err : "null engine"; }
+
+int fs2_create(const fs2_config* cfg, fs2_engine** out) {
+    if (!cfg || !out) return FS2_ERR_ARG;
+    fs2_engine* e = new fs2_engine();
+    e->cfg = *cfg;
+    e->err[0] = 0;
+    *out = e;  // returned even on failure so the caller can read fs2_last_error, then destroy
+    const int r = check_config(e);
+    if (r != FS2_OK) return r;
+    e->dt = cfg->dtype;
+    e->esz = cfg->dtype == FS2_BF16 ? 2 : 4;
+    build_spec(e);
+    return FS2_OK;
+}
+
+int fs2_destroy(fs2_engine* e) {
+    if (!e) return FS2_OK;
+    (void)hipDeviceSynchronize();
+    for (void* p : e->dev_allocs) (void)hipFree(p);
+    e->persist.release();
+    e->scratch.release();
+    e->dbg.release();
+    if (e->h_pinned) (void)hipHostFree(e->h_pinned);
+    for (auto& s : e->prof)
+        for (auto& ev : s.ev) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    delete e;
+    return FS2_OK;
+}
+
+int fs2_load_weight(fs2_engine* e, const char* name, const float* data, const int64_t* shape, int32_t ndim) {
+    if (!e || !name || !data || !shape || ndim < 0) return FS2_ERR_ARG;
+    if (e->finalized) return fail(e, FS2_ERR_STATE, "weights already finalized");
+    auto it = e->spec.find(name);
+    if (it == e->spec.end()) return fail(e, FS2_ERR_WEIGHT, "unexpected weight '%s' for this config", name);
+    const std::vector<int64_t>& want = it->second;
+    bool ok = (size_t)ndim == want.size();
+    size_t n = 1;
+    for (int i = 0; ok && i < ndim; ++i) { ok = shape[i] == want[i]; n *= (size_t)shape[i]; }
+    if (!ok) return fail(e, FS2_ERR_WEIGHT, "shape mismatch for '%s'", name);
+    HostTensor t;
+    t.shape.assign(shape, shape + ndim);
+    t.data.assign(data, data + n);
+    e->host[name] = std::move(t);
+    return FS2_OK;
+}
+
+int fs2_finalize(fs2_engine* e) {
+    if (!e) return FS2_ERR_ARG;
+    if (e->finalized) return FS2_OK;
+    for (auto& kv : e->spec)
+        if (!e->host.count(kv.first)) return fail(e, FS2_ERR_WEIGHT, "missing weight '%s'", kv.first.c_str());
+    const fs2_config& c = e->cfg;
+    const int H = c.hidden;
+    CHK(up_vec(e, "phone_embedding.weight", &e->phone_table));
+    CHK(up_vec(e, "positional_encoding.pe", &e->pe));
+    CHK(up_vec(e, "speaker_embedding.projection.weight", &e->spk_w));
+    CHK(up_vec(e, "speaker_embedding.projection.bias", &e->spk_b));
+    e->enc.resize(c.enc_layers);
+    for (int i = 0; i < c.enc_layers; ++i)
+        CHK(make_layer(e, "encoder.layers." + std::to_string(i), H, c.enc_filter, c.enc_depthwise, &e->enc[i]));
+    e->dec.resize(c.dec_layers);
+    for (int i = 0; i < c.dec_layers; ++i)
+        CHK(make_layer(e, "decoder.layers." + std::to_string(i), H, c.dec_filter, c.dec_depthwise, &e->dec[i]));
+    CHK(make_predictor(e, "variance_adaptor.duration_predictor", c.dur_nlayers, c.dur_filter, c.dur_depthwise, &e->dur));
+    e->vars.resize(c.n_variances);
+    for (int v = 0; v < c.n_variances; ++v) {
+        const std::string p = std::string("variance_adaptor.encoders.") + c.var_names[v];
+        CHK(make_predictor(e, p + ".predictor", c.var_nlayers[v], c.var_filter, c.var_depthwise, &e->vars[v].pred));
+        CHK(up_vec(e, p + ".bins", &e->vars[v].bins));
+        CHK(up_vec(e, p + ".embedding.weight", &e->vars[v].emb));
+    }
+    CHK(make_conv(e, "linear.weight", "linear.bias", &e->mel));
+    e->host.clear();
+    e->finalized = true;
+    return FS2_OK;
+}
+
+int fs2_set_debug(fs2_engine* e, int32_t on) {
+    if (!e) return FS2_ERR_ARG;
+    e->debug = on != 0;
+    return FS2_OK;
+}
+
+int fs2_encode(fs2_engine* e, const int64_t* phones, const float* speaker, int32_t B, int32_t L,
+               const int32_t* forced, void* stream, int32_t* T_out) {
+    if (!e || !phones || !speaker || !T_out || B <= 0 || L <= 0) return e ? fail(e, FS2_ERR_ARG, "bad encode argument") : FS2_ERR_ARG;
+    if (!e->finalized) return fail(e, FS2_ERR_STATE, "fs2_finalize not called");
+    if (L > e->cfg.pe_len) return fail(e, FS2_ERR_SHAPE, "L=%d exceeds positional table %d", L, e->cfg.pe_len);
+    hipStream_t st = (hipStream_t)stream;
+    const fs2_config& c = e->cfg;
+    const size_t H = c.hidden, ML = (size_t)B * L, esz = e->esz;
+    e->encoded = false;
+    e->B = B;
+    e->L = L;
+    e->taps.clear();
+    // the arenas are reused across calls: earlier work on this stream that still reads them is
+    // ordered before the kernels below; a (rare) growth reallocates after a device sync
+    const size_t need_p = al((size_t)B * H * 4) + 2 * al(ML * H * esz) + al(ML * 4) + 2 * al(ML * 4) + 2 * al((size_t)B * 4) + al(ML) + 4096;
+    if (need_p > e->persist.cap) HIPCHK(e, hipDeviceSynchronize());
+    if (e->persist.reserve(need_p) != FS2_OK) return fail(e, FS2_ERR_NOMEM, "persist arena %zu bytes", need_p);
+    const size_t need_s = layer_scratch_bytes(e, B, L);
+    if (need_s > e->scratch.cap) HIPCHK(e, hipDeviceSynchronize());
+    if (e->scratch.reserve(need_s) != FS2_OK) return fail(e, FS2_ERR_NOMEM, "scratch arena %zu bytes", need_s);
+    e->spk = (float*)e->persist.take((size_t)B * H * 4);
+    e->xA = e->persist.take(ML * H * esz);
+    e->xB = e->persist.take(ML * H * esz);
+    e->dur_pred = (float*)e->persist.take(ML * 4);
+    e->d_dur = (int32_t*)e->persist.take(ML * 4);
+    e->d_cum = (int32_t*)e->persist.take(ML * 4);
+    e->d_totals = (int32_t*)e->persist.take((size_t)B * 4);
+    e->d_guard = (int32_t*)e->persist.take((size_t)B * 4);
+    e->src_mask = (uint8_t*)e->persist.take(ML);
+    if (!e->src_mask) return fail(e, FS2_ERR_NOMEM, "persist arena too small");
+    LayerScratch sc;
+    CHK(take_layer_scratch(e, e->scratch, B, L, &sc));
+    if (e->h_pinned_cap < 2 * B) {
+        if (e->h_pinned) (void)hipHostFree(e->h_pinned);
+        e->h_pinned = nullptr;
+        HIPCHK(e, hipHostMalloc((void**)&e->h_pinned, (size_t)2 * B * 4, hipHostMallocDefault));
+        e->h_pinned_cap = 2 * B;
+    }
+
+    {   // speaker projection + phone embedding + PE                       fastspeech2.py:651-660
+        Bracket br(e, FS2_K_ROWOPS, st, 0, ML * H * esz);
+        SpkProjArgs sp{speaker, e->spk_w, e->spk_b, e->spk, B, (int)H, c.dvec_dim};
+        if (launch_spk_proj(sp, st) != FS2_OK) return fail(e, FS2_ERR_HIP, "spk_proj launch failed");
+        EmbedArgs em{phones, e->phone_table, e->pe, e->spk, e->xA, e->src_mask, B, L, (int)H, c.n_phones};
+        if (launch_embed(em, e->dt, st) != FS2_OK) return fail(e, FS2_ERR_HIP, "embed launch failed");
+        MaskBitsArgs mb{e->src_mask, sc.bits, B, L, sc.nw64};
+        if (launch_mask_bits(mb, st) != FS2_OK) return fail(e, FS2_ERR_HIP, "mask_bits launch failed");
+    }
+    for (int i = 0; i < c.enc_layers; ++i)                                   // fastspeech2.py:685
+        CHK(conformer(e, st, e->enc[i], e->xA, e->xB, B, L, c.enc_heads, sc));
+    // duration predictor + rounding + prefix sums                          model.py:259,299-309
+    CHK(predictor(e, st, e->dur, e->xA, B, L, e->src_mask, e->dur_pred, sc));
+    DurationArgs da{e->dur_pred, e->src_mask, forced, e->d_dur, e->d_cum, e->d_totals, e->d_guard, B, L};
+    if (launch_durations(da, st) != FS2_OK) return fail(e, FS2_ERR_HIP, "durations launch failed");
+    HIPCHK(e, hipMemcpyAsync(e->h_pinned, e->d_totals, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(e, hipMemcpyAsync(e->h_pinned + B, e->d_guard, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(e, hipStreamSynchronize(st));  // the one host sync of the forward (output shape)
+    e->totals.assign(e->h_pinned, e->h_pinned + B);
+    e->guard.assign(e->h_pinned + B, e->h_pinned + 2 * B);
+    int mx = 0;
+    for (int b = 0; b < B; ++b) mx = e->totals[b] > mx ? e->totals[b] : mx;
+    e->T = mx < c.max_frames ? mx : c.max_frames;                            // model.py:355
+    if (e->T > c.pe_len) return fail(e, FS2_ERR_SHAPE, "T=%d exceeds positional table %d", e->T, c.pe_len);
+    *T_out = e->T;
+    e->encoded = true;
+    return FS2_OK;
+}
+
+int fs2_last_totals(const fs2_engine* e, int32_t* totals, int32_t* guard, int32_t B) {
+    if (!e || !e->encoded || B != e->B) return FS2_ERR_STATE;
+    if (totals) memcpy(totals, e->totals.data(), (size_t)B * 4);
+    if (guard) memcpy(guard, e->guard.data(), (size_t)B * 4);
+    return FS2_OK;
+}
+
+int fs2_decode(fs2_engine* e, const fs2_outputs* out, void* stream) {
+    if (!e || !out) return FS2_ERR_ARG;
+    if (!e->encoded) return fail(e, FS2_ERR_STATE, "fs2_decode without a preceding successful fs2_encode");
+    hipStream_t st = (hipStream_t)stream;
+    const fs2_config& c = e->cfg;
+    const int B = e->B, L = e->L, T = e->T;
+    const size_t H = c.hidden, MT = (size_t)B * T, ML = (size_t)B * L, esz = e->esz;
+    if (out->duration_prediction) HIPCHK(e, hipMemcpyAsync(out->duration_prediction, e->dur_pred, ML * 4, hipMemcpyDeviceToDevice, st));
+    if (out->duration_rounded) HIPCHK(e, hipMemcpyAsync(out->duration_rounded, e->d_dur, ML * 4, hipMemcpyDeviceToDevice, st));
+    if (out->src_mask) HIPCHK(e, hipMemcpyAsync(out->src_mask, e->src_mask, ML, hipMemcpyDeviceToDevice, st));
+    if (T == 0) { e->encoded = false; return FS2_OK; }
+
+    const size_t need_s = layer_scratch_bytes(e, B, T) + 2 * al(MT * H * esz) + al(MT) + (size_t)c.n_variances * al(MT * 4) + 4096;
+    if (need_s > e->scratch.cap) HIPCHK(e, hipDeviceSynchronize());
+    if (e->scratch.reserve(need_s) != FS2_OK) return fail(e, FS2_ERR_NOMEM, "scratch arena %zu bytes", need_s);
+    void* yA = e->scratch.take(MT * H * esz);
+    void* yB = e->scratch.take(MT * H * esz);
+    uint8_t* tmask = (uint8_t*)e->scratch.take(MT);
+    float* vpred[FS2_MAX_VARIANCES] = {nullptr, nullptr, nullptr, nullptr};
+    for (int v = 0; v < c.n_variances; ++v) vpred[v] = (float*)e->scratch.take(MT * 4);
+    LayerScratch sc;
+    CHK(take_layer_scratch(e, e->scratch, B, T, &sc));
+    if (!yA || !yB || !tmask) return fail(e, FS2_ERR_NOMEM, "scratch arena too small");
+    if (e->debug) {
+        const size_t need_d = al(ML * H * 4) + 3 * al(MT * H * 4) + (size_t)c.n_variances * al(MT * 4) + 4096;
+        if (need_d > e->dbg.cap) HIPCHK(e, hipDeviceSynchronize());
+        if (e->dbg.reserve(need_d) != FS2_OK) return fail(e, FS2_ERR_NOMEM, "debug arena");
+        CHK(tap_store(e, st, "encoder_out", e->xA, ML * H, e->dt));
+    }
+
+    {   // length regulator                                                  model.py:311,349-370
+        Bracket br(e, FS2_K_ROWOPS, st, 0, 2.0 * MT * H * esz);
+        RegulateArgs ra{e->xA, e->d_cum, e->d_totals, yA, tmask, B, L, T, (int)H};
+        if (launch_regulate(ra, e->dt, st) != FS2_OK) return fail(e, FS2_ERR_HIP, "regulate launch failed");
+        MaskBitsArgs mb{tmask, sc.bits, B, T, sc.nw64};
+        if (launch_mask_bits(mb, st) != FS2_OK) return fail(e, FS2_ERR_HIP, "mask_bits launch failed");
+    }
+    if (e->debug) CHK(tap_store(e, st, "regulated", yA, MT * H, e->dt));
+    // frame-level variance encoders, sequential                            model.py:315-333
+    const bool fuse_pe = !e->debug;
+    for (int v = 0; v < c.n_variances; ++v) {
+        CHK(predictor(e, st, e->vars[v].pred, yA, B, T, tmask, vpred[v], sc));
+        const bool last = v + 1 == c.n_variances;
+        int32_t* idx = nullptr;
+        if (e->debug) {
+            idx = (int32_t*)e->dbg.take(MT * 4);
+            if (!idx) return fail(e, FS2_ERR_NOMEM, "debug arena too small");
+            e->taps[std::string("bucket_") + c.var_names[v]] = {idx, MT * 4};
+        }
+        Bracket br(e, FS2_K_ROWOPS, st, 0, 2.0 * MT * H * esz);
+        BucketArgs ba{yA, vpred[v], e->vars[v].bins, e->vars[v].emb, c.var_nbins, c.var_std[v], c.var_mean[v],
+                      (last && fuse_pe) ? e->pe : nullptr, (last && fuse_pe) ? e->spk : nullptr, yA, idx, B, T, (int)H};
+        if (launch_bucket_embed(ba, e->dt, st) != FS2_OK) return fail(e, FS2_ERR_HIP, "bucket_embed launch failed");
+        if (out->variances[v]) HIPCHK(e, hipMemcpyAsync(out->variances[v], vpred[v], MT * 4, hipMemcpyDeviceToDevice, st));
+    }
+    if (e->debug) CHK(tap_store(e, st, "adaptor_out", yA, MT * H, e->dt));
+    if (!fuse_pe || c.n_variances == 0) {  // y = (x + pe) + spk               fastspeech2.py:705-718
+        BucketArgs ba{yA, nullptr, nullptr, nullptr, 0, 0.f, 0.f, e->pe, e->spk, yA, nullptr, B, T, (int)H};
+        if (launch_bucket_embed(ba, e->dt, st) != FS2_OK) return fail(e, FS2_ERR_HIP, "pe/spk add launch failed");
+    }
+    for (int i = 0; i < c.dec_layers; ++i)                                   // fastspeech2.py:719-721
+        CHK(conformer(e, st, e->dec[i], yA, yB, B, T, c.dec_heads, sc));
+    if (e->debug) CHK(tap_store(e, st, "decoder_out", yA, MT * H, e->dt));
+    if (out->mel) CHK(gemm(e, st, e->mel, yA, out->mel, (int)MT, (int)MT, false, FS2_F32));  // fastspeech2.py:723
+    if (out->tgt_mask) HIPCHK(e, hipMemcpyAsync(out->tgt_mask, tmask, MT, hipMemcpyDeviceToDevice, st));
+    return FS2_OK;
+}
+
+int fs2_debug_copy(fs2_engine* e, const char* what, void* dst, void* stream) {
+    if (!e || !what || !dst) return FS2_ERR_ARG;
+    auto it = e->taps.find(what);
+    if (it == e->taps.end()) return fail(e, FS2_ERR_STATE, "no debug tap '%s' (fs2_set_debug before encode?)", what);
+    HIPCHK(e, hipMemcpyAsync(dst, it->second.first, it->second.second, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return FS2_OK;
+}
+
+int fs2_profile_enable(fs2_engine* e, int32_t cls, int32_t enable) {
+    if (!e || cls < 0 || cls >= FS2_K_COUNT) return FS2_ERR_ARG;
+    ProfSlot& s = e->prof[cls];
+    s.enabled = enable != 0;
+    s.used = 0;
+    s.flops = s.bytes = 0;
+    return FS2_OK;
+}
+
+int fs2_profile_read(fs2_engine* e, int32_t cls, double* total_ms, int64_t* launches, double* flops, double* bytes) {
+    if (!e || cls < 0 || cls >= FS2_K_COUNT) return FS2_ERR_ARG;
+    ProfSlot& s = e->prof[cls];
+    double ms = 0;
+    for (size_t i = 0; i < s.used; ++i) {
+        HIPCHK(e, hipEventSynchronize(s.ev[i].second));
+        float t = 0;
+        HIPCHK(e, hipEventElapsedTime(&t, s.ev[i].first, s.ev[i].second));
+        ms += t;
+    }
+    if (total_ms) *total_ms = ms;
+    if (launches) *launches = (int64_t)s.used;
+    if (flops) *flops = s.flops;
+    if (bytes) *bytes = s.bytes;
+    s.used = 0;
+    s.flops = s.bytes = 0;
+    return FS2_OK;
+}
+
+}  // extern "C"

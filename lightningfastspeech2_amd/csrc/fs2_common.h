@@ -1,0 +1,130 @@
+// Shared device helpers for the gfx950 (CDNA4) kernels of the FastSpeech2 mel forward.
+// Wave = 64 lanes; MFMA fragment maps follow /opt/skills/guides/cdna_hip_programming.md §3.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fs2 {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+// bf16 is carried as raw 16-bit storage; arithmetic is always fp32.
+struct bf16 {
+    unsigned short v;
+};
+
+__host__ __device__ inline float bf16_to_f32(bf16 x) {
+    union { uint32_t u; float f; } c;
+    c.u = ((uint32_t)x.v) << 16;
+    return c.f;
+}
+__host__ __device__ inline bf16 f32_to_bf16(float f) {  // round-to-nearest-even
+    union { uint32_t u; float f; } c;
+    c.f = f;
+    uint32_t u = c.u;
+    bf16 r;
+    if ((u & 0x7fffffffu) > 0x7f800000u) { r.v = (unsigned short)((u >> 16) | 0x40); return r; }  // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    r.v = (unsigned short)(u >> 16);
+    return r;
+}
+
+template <typename T> struct Num;
+template <> struct Num<float> {
+    __host__ __device__ static inline float to_f32(float x) { return x; }
+    __host__ __device__ static inline float from_f32(float x) { return x; }
+    static constexpr int kPer16B = 4;
+};
+template <> struct Num<bf16> {
+    __host__ __device__ static inline float to_f32(bf16 x) { return bf16_to_f32(x); }
+    __host__ __device__ static inline bf16 from_f32(float x) { return f32_to_bf16(x); }
+    static constexpr int kPer16B = 8;
+};
+
+// 16-byte vector <-> fp32 lanes
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+    static constexpr int N = 4;
+    __device__ static inline void unpack(const uint4& u, float* f) {
+        f[0] = __uint_as_float(u.x); f[1] = __uint_as_float(u.y);
+        f[2] = __uint_as_float(u.z); f[3] = __uint_as_float(u.w);
+    }
+    __device__ static inline uint4 pack(const float* f) {
+        return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
+    }
+};
+__device__ inline uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo).v | ((uint32_t)f32_to_bf16(hi).v << 16);
+}
+template <> struct Vec16<bf16> {
+    static constexpr int N = 8;
+    __device__ static inline void unpack(const uint4& u, float* f) {
+        f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+        f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+        f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
+        f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+    }
+    __device__ static inline uint4 pack(const float* f) {
+        return make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]),
+                          pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
+    }
+};
+
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- MFMA wrappers: one "16-byte K chunk per lane" step -------------------------------------
+// Both operands are read K-contiguously, 16 bytes per lane.  For bf16 that is one MFMA
+// (8 k-values per lane); for fp32 it is four MFMAs (one k-value per lane each).  Because the same
+// (lane-group, element) -> k assignment is used for both operands, the k order inside a chunk
+// is a free permutation of the dot product.
+//
+// 16x16 tile: "row operand" lane supplies R[i = lane&15][k], "col operand" C[k][j = lane&15];
+// D: lane holds col j = lane&15, rows i = (lane>>4)*4 + reg.
+template <typename T> struct Mma16;
+template <> struct Mma16<bf16> {
+    static constexpr int K_PER_CHUNK = 32;  // k-values one 16-B-per-lane step covers (4 groups x 8)
+    __device__ static inline void step(const uint4& r, const uint4& c, f32x4_t& acc) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)&r, *(const bf16x8_t*)&c, acc, 0, 0, 0);
+    }
+};
+template <> struct Mma16<float> {
+    static constexpr int K_PER_CHUNK = 16;  // 4 groups x 4 floats
+    __device__ static inline void step(const uint4& r, const uint4& c, f32x4_t& acc) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(r.x), __uint_as_float(c.x), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(r.y), __uint_as_float(c.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(r.z), __uint_as_float(c.z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(r.w), __uint_as_float(c.w), acc, 0, 0, 0);
+    }
+};
+
+// 32x32 tile: row operand R[i = lane&31][k], col operand C[k][j = lane&31], k-slots owned by
+// hi = lane>>5; D: lane holds col j = lane&31, rows i = (reg&3) + 8*(reg>>2) + 4*hi.
+template <typename T> struct Mma32;
+template <> struct Mma32<bf16> {
+    static constexpr int K_PER_CHUNK = 16;  // 2 groups x 8
+    __device__ static inline void step(const uint4& r, const uint4& c, f32x16_t& acc) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8_t*)&r, *(const bf16x8_t*)&c, acc, 0, 0, 0);
+    }
+};
+template <> struct Mma32<float> {
+    static constexpr int K_PER_CHUNK = 8;  // 2 groups x 4
+    __device__ static inline void step(const uint4& r, const uint4& c, f32x16_t& acc) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(r.x), __uint_as_float(c.x), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(r.y), __uint_as_float(c.y), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(r.z), __uint_as_float(c.z), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(r.w), __uint_as_float(c.w), acc, 0, 0, 0);
+    }
+};
+
+}  // namespace fs2

@@ -1,0 +1,129 @@
+// Internal launcher interface between the engine (host C++) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fs2.h"
+
+namespace fs2 {
+
+struct GemmArgs {
+    const void* X;      // (M, ldx) activations, row-major
+    const void* W;      // (N, K) weights, K = taps*Cin (tap-major)
+    const float* bias;  // (N) or null
+    void* C;            // (M, ldc)
+    int M, N, K;
+    int ldx, ldc;
+    int Cin, taps, pad;  // implicit conv: K index = tap*Cin + c, source row = m + tap - pad
+    int S;               // rows per utterance (zero padding does not cross utterances)
+    int relu;
+};
+int launch_gemm(const GemmArgs& a, int in_dtype, int out_dtype, hipStream_t stream);
+
+struct AttnArgs {
+    const void* qkv;        // (B*S, 3H): [q | k | v] columns, head h at h*d
+    void* vt;               // (B*heads, d, Spad) scratch: V^T, zero padded (written by the launcher)
+    const uint64_t* kbits;  // (B, nw64) bit k of word w set <=> key w*64+k is a valid (unpadded) key
+    void* out;              // (B*S, H)
+    int B, S, H, heads, Spad, nw64;
+    float scale_log2e;      // log2(e) / sqrt(d)
+};
+int launch_transpose_v(const AttnArgs& a, int dtype, hipStream_t stream);  // fills a.vt from a.qkv
+int launch_attention(const AttnArgs& a, int dtype, hipStream_t stream);    // needs a.vt filled
+
+struct ConvertArgs {
+    const void* src;
+    void* dst;
+    size_t n;
+};
+int launch_convert(const ConvertArgs& a, int src_dtype, int dst_dtype, hipStream_t stream);
+
+struct LayerNormArgs {
+    const void* x;        // (M, H)
+    const void* res;      // (M, H) or null: y = LN(x + res)
+    const float* gamma;   // (H)
+    const float* beta;    // (H)
+    void* y;              // (M, H) or null (skip the store when only the row-dot is needed)
+    const float* dot_w;   // (H) or null: pred[m] = mask[m] ? 0 : sum_c y[m,c]*dot_w[c] + dot_b
+    float dot_b;
+    const uint8_t* mask;  // (M) 1 = pad, or null
+    float* pred;          // (M)
+    int M, H;
+    float eps;
+};
+int launch_layernorm(const LayerNormArgs& a, int dtype, hipStream_t stream);
+
+struct DwConvArgs {
+    const void* x;      // (B*S, C)
+    const float* w;     // (C, k)
+    const float* bias;  // (C) or null
+    void* y;            // (B*S, C)
+    int B, S, C, k, pad;
+};
+int launch_dwconv(const DwConvArgs& a, int dtype, hipStream_t stream);
+
+struct EmbedArgs {
+    const int64_t* phones;  // (B, L)
+    const float* table;     // (n_phones, H), row 0 == 0
+    const float* pe;        // (>=L, H)
+    const float* spk;       // (B, H)
+    void* x;                // (B*L, H)
+    uint8_t* src_mask;      // (B, L) 1 = pad
+    int B, L, H, n_phones;
+};
+int launch_embed(const EmbedArgs& a, int dtype, hipStream_t stream);
+
+struct SpkProjArgs {
+    const float* dvec;  // (B, Din)
+    const float* w;     // (H, Din)
+    const float* b;     // (H)
+    float* spk;         // (B, H) = relu(W dvec + b)
+    int B, H, Din;
+};
+int launch_spk_proj(const SpkProjArgs& a, hipStream_t stream);
+
+struct MaskBitsArgs {
+    const uint8_t* mask;  // (B, S) 1 = pad
+    uint64_t* bits;       // (B, nw64)
+    int B, S, nw64;
+};
+int launch_mask_bits(const MaskBitsArgs& a, hipStream_t stream);
+
+struct DurationArgs {
+    const float* dur_pred;    // (B, L) log-domain prediction, 0 at pads
+    const uint8_t* src_mask;  // (B, L)
+    const int32_t* forced;    // (B, L) or null: use these durations (no rounding, no guard)
+    int32_t* dur;             // (B, L) out
+    int32_t* cum;             // (B, L) inclusive prefix sum
+    int32_t* totals;          // (B)
+    int32_t* guard;           // (B) 1 if the zero-duration guard fired
+    int B, L;
+};
+int launch_durations(const DurationArgs& a, hipStream_t stream);
+
+struct RegulateArgs {
+    const void* x;            // (B*L, H)
+    const int32_t* cum;       // (B, L)
+    const int32_t* totals;    // (B)
+    void* y;                  // (B*T, H)
+    uint8_t* tgt_mask;        // (B, T) 1 = pad (t >= total, untruncated)
+    int B, L, T, H;
+};
+int launch_regulate(const RegulateArgs& a, int dtype, hipStream_t stream);
+
+struct BucketArgs {
+    const void* x;        // (B*T, H)
+    const float* pred;    // (B*T) or null (no embedding: only + pe + spk)
+    const float* bins;    // (nbins-1)
+    const float* emb;     // (nbins, H)
+    int nbins;
+    float std, mean;
+    const float* pe;      // (>=T, H) or null
+    const float* spk;     // (B, H) or null
+    void* y;              // (B*T, H) (may alias x)
+    int32_t* idx_out;     // (B*T) or null: bucket indices (debug / parity)
+    int B, T, H;
+};
+int launch_bucket_embed(const BucketArgs& a, int dtype, hipStream_t stream);
+
+}  // namespace fs2

@@ -1,0 +1,403 @@
+// HBM-bound row kernels of the FastSpeech2 forward for gfx950: everything that is not a GEMM or
+// the attention core.  Activations are (B*S, C) row-major; one wave (64 lanes) owns one row
+// wherever a row reduction is needed, loads are 8/16-byte vectors along the channel axis.
+#include "fs2_common.h"
+#include "fs2_kernels.h"
+
+namespace fs2 {
+
+// ---- 4 consecutive channels per lane ---------------------------------------------------------
+template <typename T> __device__ inline void load4(const T* p, float* f);
+template <> __device__ inline void load4<float>(const float* p, float* f) {
+    const float4 v = *(const float4*)p;
+    f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+}
+template <> __device__ inline void load4<bf16>(const bf16* p, float* f) {
+    const uint2 v = *(const uint2*)p;
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+template <typename T> __device__ inline void store4(T* p, const float* f);
+template <> __device__ inline void store4<float>(float* p, const float* f) {
+    *(float4*)p = make_float4(f[0], f[1], f[2], f[3]);
+}
+template <> __device__ inline void store4<bf16>(bf16* p, const float* f) {
+    *(uint2*)p = make_uint2(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]));
+}
+
+// =============================================================================================
+// LayerNorm(x [+ res]) * gamma + beta, eps inside the sqrt — nn.LayerNorm as used by
+// ConformerEncoderLayer.norm1/norm2 (model.py:114-115) and VarianceConvolutionLayer (model.py:538).
+// Optional fused head: pred = masked_fill(Linear(filter,1)(y), mask, 0)  (model.py:512-518).
+// =============================================================================================
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(LayerNormArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.M) return;
+    const T* x = (const T*)p.x + (size_t)row * p.H;
+    const T* res = p.res ? (const T*)p.res + (size_t)row * p.H : nullptr;
+    float v[NV][4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < p.H) {
+            load4<T>(x + c, v[i]);
+            if (res) {
+                float r[4];
+                load4<T>(res + c, r);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[i][e] += r[e];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[i][e] = 0.f;
+        }
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    const float mean = wave_sum(s) / (float)p.H;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < p.H) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)p.H + p.eps);
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < p.H) {
+            float g[4], bb[4], y[4];
+            load4<float>(p.gamma + c, g);
+            load4<float>(p.beta + c, bb);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * g[e] + bb[e];
+            if (p.y) store4<T>((T*)p.y + (size_t)row * p.H + c, y);
+            if (p.dot_w) {
+                float w[4];
+                load4<float>(p.dot_w + c, w);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dot += y[e] * w[e];
+            }
+        }
+    }
+    if (p.dot_w) {
+        dot = wave_sum(dot) + p.dot_b;
+        if (lane == 0) p.pred[row] = (p.mask && p.mask[row]) ? 0.f : dot;
+    }
+}
+
+int launch_layernorm(const LayerNormArgs& a, int dtype, hipStream_t stream) {
+    if (a.M <= 0) return FS2_OK;
+    if (a.H % 4 || a.H > 1024) return FS2_ERR_SHAPE;
+    const int nv = (a.H + 255) / 256;
+    const dim3 grid((a.M + 3) / 4), block(256);
+#define FS2_LN(NVV)                                                                                     \
+    if (nv == NVV) {                                                                                    \
+        if (dtype == FS2_BF16) hipLaunchKernelGGL((layernorm_kernel<bf16, NVV>), grid, block, 0, stream, a); \
+        else hipLaunchKernelGGL((layernorm_kernel<float, NVV>), grid, block, 0, stream, a);             \
+    }
+    FS2_LN(1) FS2_LN(2) FS2_LN(3) FS2_LN(4)
+#undef FS2_LN
+    return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
+}
+
+// =============================================================================================
+// Depth-wise Conv1d over time, zero "same" padding per utterance, unmasked — conv1.0 of the
+// LightSpeech FFN (model.py:75-81) and module.0 of the depth-wise predictor layer
+// (model.py:545-551).  LDS-staged (TR + k - 1) x 64 slab, one output channel per lane.
+// =============================================================================================
+static constexpr int DW_TR = 64, DW_CT = 64, DW_KMAX = 31;
+
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_kernel(DwConvArgs p) {
+    __shared__ float tile[(DW_TR + DW_KMAX - 1) * DW_CT];
+    __shared__ float wl[DW_CT * DW_KMAX];
+    const int tid = threadIdx.x;
+    const int t0 = blockIdx.x * DW_TR, c0 = blockIdx.y * DW_CT, b = blockIdx.z;
+    const T* x = (const T*)p.x + (size_t)b * p.S * p.C;
+    const int rows = DW_TR + p.k - 1;
+    for (int i = tid; i < rows * DW_CT; i += 256) {
+        const int r = i / DW_CT, c = i % DW_CT;
+        const int t = t0 + r - p.pad;
+        float v = 0.f;
+        if (t >= 0 && t < p.S && c0 + c < p.C) v = Num<T>::to_f32(x[(size_t)t * p.C + c0 + c]);
+        tile[i] = v;
+    }
+    for (int i = tid; i < DW_CT * p.k; i += 256) {
+        const int c = i / p.k, tap = i % p.k;
+        wl[c * p.k + tap] = (c0 + c < p.C) ? p.w[(size_t)(c0 + c) * p.k + tap] : 0.f;
+    }
+    __syncthreads();
+    const int c = tid & 63, ry = tid >> 6;
+    if (c0 + c >= p.C) return;
+    const float bias = p.bias ? p.bias[c0 + c] : 0.f;
+    T* y = (T*)p.y + (size_t)b * p.S * p.C;
+    for (int rr = ry; rr < DW_TR; rr += 4) {
+        const int t = t0 + rr;
+        if (t >= p.S) break;
+        float acc = 0.f;
+        for (int tap = 0; tap < p.k; ++tap) acc = fmaf(wl[c * p.k + tap], tile[(rr + tap) * DW_CT + c], acc);
+        y[(size_t)t * p.C + c0 + c] = Num<T>::from_f32(acc + bias);
+    }
+}
+
+int launch_dwconv(const DwConvArgs& a, int dtype, hipStream_t stream) {
+    if (a.B <= 0 || a.S <= 0) return FS2_OK;
+    if (a.k < 1 || a.k > DW_KMAX) return FS2_ERR_SHAPE;
+    const dim3 grid((a.S + DW_TR - 1) / DW_TR, (a.C + DW_CT - 1) / DW_CT, a.B), block(256);
+    if (dtype == FS2_BF16) hipLaunchKernelGGL(dwconv_kernel<bf16>, grid, block, 0, stream, a);
+    else hipLaunchKernelGGL(dwconv_kernel<float>, grid, block, 0, stream, a);
+    return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
+}
+
+// =============================================================================================
+// x[b,l,:] = (E[phones[b,l]] + pe[l]) + spk[b]; src_mask = phones == 0
+// (fastspeech2.py:651-660, model.py:53-55,143).  Row 0 of E is the zero padding row, PE and the
+// speaker vector are still added at pad positions.
+// =============================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void embed_kernel(EmbedArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.B * p.L) return;
+    const int b = row / p.L, l = row % p.L;
+    long long ph = p.phones[row];
+    if (lane == 0) p.src_mask[row] = ph == 0;
+    if (ph < 0 || ph >= p.n_phones) ph = 0;  // caller validates ids on the host side of the ABI
+    const float* e = p.table + (size_t)ph * p.H;
+    const float* pe = p.pe + (size_t)l * p.H;
+    const float* sp = p.spk + (size_t)b * p.H;
+    T* x = (T*)p.x + (size_t)row * p.H;
+    for (int c = lane * 4; c < p.H; c += 256) {
+        float a[4], q[4], s[4], o[4];
+        load4<float>(e + c, a);
+        load4<float>(pe + c, q);
+        load4<float>(sp + c, s);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = __fadd_rn(__fadd_rn(a[i], q[i]), s[i]);
+        store4<T>(x + c, o);
+    }
+}
+
+int launch_embed(const EmbedArgs& a, int dtype, hipStream_t stream) {
+    if (a.B * a.L <= 0) return FS2_OK;
+    if (a.H % 4) return FS2_ERR_SHAPE;
+    const dim3 grid((a.B * a.L + 3) / 4), block(256);
+    if (dtype == FS2_BF16) hipLaunchKernelGGL(embed_kernel<bf16>, grid, block, 0, stream, a);
+    else hipLaunchKernelGGL(embed_kernel<float>, grid, block, 0, stream, a);
+    return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
+}
+
+// spk[b,:] = relu(W dvec[b] + bias)  — SpeakerEmbedding.forward, model.py:137-143 (computed once
+// per forward; the reference evaluates it twice, fastspeech2.py:658,707, with identical results)
+__global__ __launch_bounds__(256) void spk_proj_kernel(SpkProjArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= p.B * p.H) return;
+    const int b = o / p.H, n = o % p.H;
+    const float* w = p.w + (size_t)n * p.Din;
+    const float* d = p.dvec + (size_t)b * p.Din;
+    float s = 0.f;
+    for (int k = lane; k < p.Din; k += 64) s = fmaf(w[k], d[k], s);
+    s = wave_sum(s) + p.b[n];
+    if (lane == 0) p.spk[o] = fmaxf(s, 0.f);
+}
+
+int launch_spk_proj(const SpkProjArgs& a, hipStream_t stream) {
+    if (a.B <= 0) return FS2_OK;
+    hipLaunchKernelGGL(spk_proj_kernel, dim3((a.B * a.H + 3) / 4), dim3(256), 0, stream, a);
+    return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
+}
+
+// key-padding byte mask -> one 64-bit valid word per 64 keys (consumed by the attention kernel)
+__global__ __launch_bounds__(64) void mask_bits_kernel(MaskBitsArgs p) {
+    const int w = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int key = w * 64 + lane;
+    const bool valid = key < p.S && p.mask[(size_t)b * p.S + key] == 0;
+    const unsigned long long bal = __ballot(valid);
+    if (lane == 0) p.bits[(size_t)b * p.nw64 + w] = bal;
+}
+
+int launch_mask_bits(const MaskBitsArgs& a, hipStream_t stream) {
+    if (a.B <= 0 || a.nw64 <= 0) return FS2_OK;
+    hipLaunchKernelGGL(mask_bits_kernel, dim3(a.nw64, a.B), dim3(64), 0, stream, a);
+    return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
+}
+
+// =============================================================================================
+// Duration rounding + zero-duration guard + prefix sum (model.py:299-309 and the lengths the
+// LengthRegulator derives, model.py:350-354).  One workgroup per utterance.
+//   d = int(clamp(round_half_even(exp(p) - 1), 0));  if sum_valid d <= n_valid // 2: d[valid] = 1
+// =============================================================================================
+__device__ inline int dur_from_pred(float p) {
+    const float v = rintf(__fsub_rn(expf(p), 1.0f));  // torch.round = half-to-even
+    return v > 0.f ? (int)v : 0;
+}
+
+__global__ __launch_bounds__(256) void durations_kernel(DurationArgs p) {
+    __shared__ int red[2][4];
+    __shared__ int wsum[4];
+    __shared__ int guard_s;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* dp = p.dur_pred + (size_t)b * p.L;
+    const uint8_t* mk = p.src_mask + (size_t)b * p.L;
+    const int32_t* forced = p.forced ? p.forced + (size_t)b * p.L : nullptr;
+    int guard = 0;
+    if (!forced) {
+        int sd = 0, nv = 0;
+        for (int l = tid; l < p.L; l += 256) {
+            if (!mk[l]) { sd += dur_from_pred(dp[l]); nv += 1; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { sd += __shfl_xor(sd, o, 64); nv += __shfl_xor(nv, o, 64); }
+        if (lane == 0) { red[0][wave] = sd; red[1][wave] = nv; }
+        __syncthreads();
+        if (tid == 0) {
+            const int s = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+            const int n = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+            guard_s = s <= n / 2;
+        }
+        __syncthreads();
+        guard = guard_s;
+    }
+    int running = 0;
+    for (int base = 0; base < p.L; base += 256) {
+        const int l = base + tid;
+        int d = 0;
+        if (l < p.L) {
+            if (forced) d = forced[l];
+            else d = (guard && !mk[l]) ? 1 : dur_from_pred(dp[l]);
+            if (d < 0) d = 0;
+        }
+        int inc = d;  // inclusive scan inside the wave
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int n = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += n;
+        }
+        __syncthreads();  // wsum reuse across iterations
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int off = running;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        if (l < p.L) {
+            p.dur[(size_t)b * p.L + l] = d;
+            p.cum[(size_t)b * p.L + l] = off + inc;
+        }
+        running += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    }
+    if (tid == 0) {
+        p.totals[b] = running;
+        p.guard[b] = guard;
+    }
+}
+
+int launch_durations(const DurationArgs& a, hipStream_t stream) {
+    if (a.B <= 0) return FS2_OK;
+    hipLaunchKernelGGL(durations_kernel, dim3(a.B), dim3(256), 0, stream, a);
+    return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
+}
+
+// =============================================================================================
+// Length regulator as a prefix-sum gather (LengthRegulator.forward, model.py:349-370):
+//   y[b,t,:] = x[b,p,:] with cum[p-1] <= t < cum[p]  for t < total_b, else 0;
+//   tgt_mask[b,t] = t >= total_b  (the UNtruncated total: a clipped utterance has no pad).
+// =============================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void regulate_kernel(RegulateArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+    if (t >= p.T) return;
+    const int total = p.totals[b];
+    const int32_t* cum = p.cum + (size_t)b * p.L;
+    if (lane == 0) p.tgt_mask[(size_t)b * p.T + t] = t >= total;
+    uint4* dst = (uint4*)((T*)p.y + ((size_t)b * p.T + t) * p.H);
+    const int nvec = p.H * (int)sizeof(T) / 16;
+    if (t < total) {
+        int lo = 0, hi = p.L;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (cum[mid] > t) hi = mid; else lo = mid + 1;
+        }
+        const uint4* src = (const uint4*)((const T*)p.x + ((size_t)b * p.L + lo) * p.H);
+        for (int i = lane; i < nvec; i += 64) dst[i] = src[i];
+    } else {
+        for (int i = lane; i < nvec; i += 64) dst[i] = make_uint4(0, 0, 0, 0);
+    }
+}
+
+int launch_regulate(const RegulateArgs& a, int dtype, hipStream_t stream) {
+    if (a.B <= 0 || a.T <= 0) return FS2_OK;
+    const int esz = dtype == FS2_BF16 ? 2 : 4;
+    if ((a.H * esz) % 16) return FS2_ERR_SHAPE;
+    const dim3 grid((a.T + 3) / 4, a.B), block(256);
+    if (dtype == FS2_BF16) hipLaunchKernelGGL(regulate_kernel<bf16>, grid, block, 0, stream, a);
+    else hipLaunchKernelGGL(regulate_kernel<float>, grid, block, 0, stream, a);
+    return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
+}
+
+// =============================================================================================
+// Variance embedding add (VarianceEncoder.forward inference branch, model.py:434-438, and the
+// adaptor's x = x + emb, model.py:333):  idx = bucketize(pred*std + mean, bins) (right=False);
+// y = x + Emb[idx]; optionally the decoder-side  y = (y + pe[t]) + spk[b]  (fastspeech2.py:705-718)
+// fused behind it.  The compare is fp32 mul-then-add (no FMA) like the reference's tensor ops.
+// =============================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void bucket_embed_kernel(BucketArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.B * p.T) return;
+    const int b = row / p.T, t = row % p.T;
+    const float* e = nullptr;
+    if (p.pred) {
+        const float v = __fadd_rn(__fmul_rn(p.pred[row], p.std), p.mean);
+        int lo = 0, hi = p.nbins - 1;  // lower_bound over nbins-1 boundaries
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (p.bins[mid] < v) lo = mid + 1; else hi = mid;
+        }
+        if (lane == 0 && p.idx_out) p.idx_out[row] = lo;
+        e = p.emb + (size_t)lo * p.H;
+    }
+    const T* x = (const T*)p.x + (size_t)row * p.H;
+    T* y = (T*)p.y + (size_t)row * p.H;
+    const float* pe = p.pe ? p.pe + (size_t)t * p.H : nullptr;
+    const float* sp = p.spk ? p.spk + (size_t)b * p.H : nullptr;
+    for (int c = lane * 4; c < p.H; c += 256) {
+        float v[4], a[4];
+        load4<T>(x + c, v);
+        if (e) {
+            load4<float>(e + c, a);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = __fadd_rn(v[i], a[i]);
+        }
+        if (pe) {
+            load4<float>(pe + c, a);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = __fadd_rn(v[i], a[i]);
+        }
+        if (sp) {
+            load4<float>(sp + c, a);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = __fadd_rn(v[i], a[i]);
+        }
+        store4<T>(y + c, v);
+    }
+}
+
+int launch_bucket_embed(const BucketArgs& a, int dtype, hipStream_t stream) {
+    if (a.B * a.T <= 0) return FS2_OK;
+    if (a.H % 4) return FS2_ERR_SHAPE;
+    const dim3 grid((a.B * a.T + 3) / 4), block(256);
+    if (dtype == FS2_BF16) hipLaunchKernelGGL(bucket_embed_kernel<bf16>, grid, block, 0, stream, a);
+    else hipLaunchKernelGGL(bucket_embed_kernel<float>, grid, block, 0, stream, a);
+    return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
+}
+
+}  // namespace fs2

@@ -1,0 +1,228 @@
+"""Host-side mirror of the reference's model interface for the mel forward.
+
+``FastSpeech2`` here plays the role of ``litfass.fastspeech2.fastspeech2.FastSpeech2`` for its
+callers on the inference path — ``SpeechGenerator.generate_samples`` does
+``self.model(batch, inference=True)`` and reads ``mel`` / ``tgt_mask`` (synthesis/generator.py:158-165)
+and ``generate.py`` reads ``.hparams``, ``.phone2id``, ``.speaker2dvector``, ``.stats``, ``.device``
+(generate.py:139-151,200-204) — with the same dict-in / dict-out contract as
+``FastSpeech2.forward`` (fastspeech2.py:636-784).  All arithmetic happens in libfs2_hip.so (hand-written
+gfx950 kernels) through the C ABI in include/fs2.h; PyTorch is used for device memory and streams
+only.  There is no CPU fallback: without the HIP library or a GPU this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from types import SimpleNamespace
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import Fs2Config
+
+_PRECISIONS = {"fp32": _lib.FS2_F32, "f32": _lib.FS2_F32, "bf16": _lib.FS2_BF16}
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class Engine:
+    """Thin owner of one ``fs2_engine`` handle (one per device)."""
+
+    def __init__(self, cfg: Fs2Config, state_dict, precision: str = "fp32", device="cuda:0"):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("lightningfastspeech2_amd needs an MI355X (no CPU fallback for the product path)")
+        self.cfg = cfg
+        self.precision = precision
+        self.dtype = _PRECISIONS[precision]
+        self.device = torch.device(device)
+        self.handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            cc = _lib.config_to_c(cfg, self.dtype)
+            st = self.lib.fs2_create(C.byref(cc), C.byref(self.handle))
+            try:
+                _lib.check(st, self.handle, "create")
+                self._load(state_dict)
+            except Exception:
+                self.close()
+                raise
+        self._last = None
+
+    def _load(self, state_dict):
+        from .weights import state_dict_spec
+        spec = state_dict_spec(self.cfg)
+        for name in spec:
+            if name not in state_dict:
+                raise KeyError(f"state_dict is missing '{name}'")
+            v = state_dict[name]
+            if isinstance(v, torch.Tensor):
+                v = v.detach().cpu().float().numpy()
+            a = np.ascontiguousarray(v, dtype=np.float32)
+            shape = (C.c_int64 * a.ndim)(*a.shape)
+            st = self.lib.fs2_load_weight(self.handle, name.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim)
+            _lib.check(st, self.handle, f"load_weight({name})")
+        _lib.check(self.lib.fs2_finalize(self.handle), self.handle, "finalize")
+
+    def close(self):
+        if getattr(self, "handle", None) and self.handle.value:
+            self.lib.fs2_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def set_debug(self, on: bool):
+        _lib.check(self.lib.fs2_set_debug(self.handle, int(on)), self.handle, "set_debug")
+
+    def encode(self, phones: torch.Tensor, speaker: torch.Tensor, forced_durations: Optional[torch.Tensor] = None) -> int:
+        B, L = phones.shape
+        T = C.c_int32(0)
+        with torch.cuda.device(self.device):
+            st = self.lib.fs2_encode(self.handle, _ptr(phones), _ptr(speaker), B, L, _ptr(forced_durations),
+                                     self._stream(), C.byref(T))
+        _lib.check(st, self.handle, "encode")
+        self._last = (B, L, T.value)
+        return T.value
+
+    def totals(self):
+        B = self._last[0]
+        tot = np.zeros(B, np.int32)
+        grd = np.zeros(B, np.int32)
+        _lib.check(self.lib.fs2_last_totals(self.handle, tot.ctypes.data_as(C.c_void_p),
+                                            grd.ctypes.data_as(C.c_void_p), B), self.handle, "last_totals")
+        return tot, grd
+
+    def decode(self, want_aux: bool = True) -> Dict[str, torch.Tensor]:
+        B, L, T = self._last
+        dev = self.device
+        out = _lib.Fs2OutputsC()
+        res = {"mel": torch.empty(B, T, self.cfg.n_mels, dtype=torch.float32, device=dev)}
+        out.mel = res["mel"].data_ptr()
+        if want_aux:
+            res["duration_prediction"] = torch.empty(B, L, dtype=torch.float32, device=dev)
+            res["duration_rounded"] = torch.empty(B, L, dtype=torch.int32, device=dev)
+            res["src_mask"] = torch.empty(B, L, dtype=torch.bool, device=dev)
+            res["tgt_mask"] = torch.empty(B, T, dtype=torch.bool, device=dev)
+            out.duration_prediction = res["duration_prediction"].data_ptr()
+            out.duration_rounded = res["duration_rounded"].data_ptr()
+            out.src_mask = res["src_mask"].data_ptr()
+            out.tgt_mask = res["tgt_mask"].data_ptr()
+            for i, var in enumerate(self.cfg.variances):
+                t = torch.empty(B, T, dtype=torch.float32, device=dev)
+                res[f"variances_{var}"] = t
+                out.variances[i] = t.data_ptr()
+        with torch.cuda.device(dev):
+            st = self.lib.fs2_decode(self.handle, C.byref(out), self._stream())
+        _lib.check(st, self.handle, "decode")
+        return res
+
+    def debug_tensor(self, what: str) -> torch.Tensor:
+        B, L, T = self._last
+        H = self.cfg.hidden
+        if what == "encoder_out":
+            t = torch.empty(B, L, H, dtype=torch.float32, device=self.device)
+        elif what.startswith("bucket_"):
+            t = torch.empty(B, T, dtype=torch.int32, device=self.device)
+        else:
+            t = torch.empty(B, T, H, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.fs2_debug_copy(self.handle, what.encode(), _ptr(t), self._stream()), self.handle,
+                   f"debug_copy({what})")
+        return t
+
+    def profile_enable(self, kernel_class: int, on: bool = True):
+        _lib.check(self.lib.fs2_profile_enable(self.handle, kernel_class, int(on)), self.handle, "profile_enable")
+
+    def profile_read(self, kernel_class: int):
+        ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+        _lib.check(self.lib.fs2_profile_read(self.handle, kernel_class, C.byref(ms), C.byref(n), C.byref(fl),
+                                             C.byref(by)), self.handle, "profile_read")
+        return {"ms": ms.value, "launches": n.value, "flops": fl.value, "bytes": by.value}
+
+
+class FastSpeech2:
+    """Drop-in for the reference model object on the inference path.
+
+    ``model(batch, inference=True)`` returns the same dict as the reference: ``mel`` (B,T,n_mels)
+    fp32 including pad rows, ``duration_prediction``, ``duration_rounded`` (int32), ``src_mask`` /
+    ``tgt_mask`` (bool, True = pad) and ``variances_<var>``; tensors live on ``self.device``.
+    """
+
+    def __init__(self, cfg: Fs2Config, state_dict, *, precision: str = "fp32", device="cuda:0",
+                 phone2id: Optional[dict] = None, speaker2dvector: Optional[dict] = None,
+                 extra_hparams: Optional[dict] = None):
+        self.cfg = cfg
+        self.stats = cfg.stats
+        self.phone2id = phone2id
+        self.speaker2dvector = speaker2dvector
+        hp = cfg.to_dict()
+        hp.pop("stats", None)
+        hp.pop("n_phones", None)
+        hp.update(dict(speaker_embedding_every_layer=False, prior_embedding_every_layer=False,
+                       fastdiff_variances=False, fastdiff_speakers=False, duration_stochastic=False))
+        hp.update(extra_hparams or {})
+        self.hparams = SimpleNamespace(**hp)
+        self.engine = Engine(cfg, state_dict, precision=precision, device=device)
+        self.device = self.engine.device
+        self.training = False
+
+    # ---- reference-style construction from a Lightning checkpoint dict (fastspeech2.py:530-634) --
+    @classmethod
+    def from_checkpoint(cls, checkpoint, *, precision: str = "fp32", device="cuda:0"):
+        if isinstance(checkpoint, (str, bytes)) or hasattr(checkpoint, "__fspath__"):
+            checkpoint = torch.load(checkpoint, map_location="cpu", weights_only=False)
+        hparams = checkpoint["hyper_parameters"]
+        stats = checkpoint["stats"]
+        phone2id = checkpoint["phone2id"]
+        cfg = Fs2Config.from_hparams(hparams, stats=stats, n_phones=len(phone2id))
+        return cls(cfg, checkpoint["state_dict"], precision=precision, device=device, phone2id=phone2id,
+                   speaker2dvector=checkpoint.get("speaker2dvector"))
+
+    # ---- nn.Module-ish surface the callers touch (generator.py:58-62) -----------------------
+    def eval(self):
+        self.training = False
+        return self
+
+    def to(self, device):
+        if torch.device(device) != self.device:
+            raise RuntimeError("an fs2 engine is bound to the device it was created on; build a new "
+                               "FastSpeech2(..., device=...) for another GPU")
+        return self
+
+    def __call__(self, targets, inference: bool = False):
+        return self.forward(targets, inference)
+
+    def forward(self, targets: dict, inference: bool = False, *, force_durations=None) -> dict:
+        if not inference and force_durations is None:
+            raise NotImplementedError(
+                "teacher-forced/training forward (inference=False, model.py:296-297,317-325) is outside "
+                "the accelerated path; call model(batch, inference=True)")
+        phones = targets["phones"]
+        speaker = targets["speaker"]
+        if not isinstance(phones, torch.Tensor):
+            phones = torch.as_tensor(np.asarray(phones))
+        if not isinstance(speaker, torch.Tensor):
+            speaker = torch.as_tensor(np.asarray(speaker))
+        if phones.dim() != 2 or speaker.dim() != 2 or speaker.shape[0] != phones.shape[0]:
+            raise ValueError("phones must be (B, L) and speaker (B, 256)")
+        if not phones.is_cuda:  # same failure the reference's nn.Embedding raises on a bad id
+            if phones.numel() and (int(phones.min()) < 0 or int(phones.max()) >= self.cfg.n_phones):
+                raise IndexError("phone id out of range")
+        phones = phones.to(self.device, dtype=torch.int64).contiguous()      # fastspeech2.py:639
+        speaker = speaker.to(self.device, dtype=torch.float32).contiguous()  # fastspeech2.py:641
+        forced = None
+        if force_durations is not None:
+            forced = torch.as_tensor(force_durations).to(self.device, dtype=torch.int32).contiguous()
+        self.engine.encode(phones, speaker, forced)
+        _, guard = self.engine.totals()
+        for _ in range(int(guard.sum())):
+            print("Zero duration, setting to 1")  # the reference's one stdout side effect (model.py:309)
+        return self.engine.decode()

@@ -1,0 +1,99 @@
+"""CPU-side checks of the C-ABI boundary (no compute calls: there is no GPU here)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from lightningfastspeech2_amd import _lib
+from lightningfastspeech2_amd.config import Fs2Config, preset
+from lightningfastspeech2_amd.weights import state_dict_spec, synth_state_dict
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return _lib.load()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    names = _lib.declared_symbols()
+    assert len(names) >= 20 and "fs2_encode" in names and "fs2_decode" in names
+    for n in names:
+        assert hasattr(lib, n), n
+    assert lib.fs2_abi_version() == _lib.FS2_ABI_VERSION
+
+
+def test_struct_layout_matches_header():
+    # sizes follow from include/fs2.h: 8 + (4+32)*2 ints, 1 int, 4*32 chars, 2*4 ints, 2*4 floats, 7 ints
+    assert C.sizeof(_lib.Fs2ConfigC) == 4 * (8 + 36 + 36 + 1) + 4 * 32 + 4 * (4 + 4) + 4 * (4 + 4) + 4 * 7
+    assert C.sizeof(_lib.Fs2OutputsC) == 8 * (5 + _lib.FS2_MAX_VARIANCES)
+
+
+def _create(lib, cfg, dtype=_lib.FS2_F32):
+    cc = _lib.config_to_c(cfg, dtype)
+    h = C.c_void_p()
+    st = lib.fs2_create(C.byref(cc), C.byref(h))
+    return st, h
+
+
+def test_create_validates_config(lib):
+    st, h = _create(lib, preset("c2"), _lib.FS2_BF16)
+    assert st == 0
+    lib.fs2_destroy(h)
+    bad = Fs2Config(encoder_hidden=96, decoder_hidden=96, encoder_conv_filter_size=192,
+                    decoder_conv_filter_size=192, variance_filter_size=96, duration_filter_size=96,
+                    encoder_head=1, decoder_head=1)
+    st, h = _create(lib, bad)
+    assert st == 2 and b"multiple of 64" in lib.fs2_last_error(h)  # FS2_ERR_SHAPE, loud and specific
+    lib.fs2_destroy(h)
+    st, h = _create(lib, Fs2Config(encoder_head=16, decoder_head=16))  # head dim 16 unsupported
+    assert st == 2
+    lib.fs2_destroy(h)
+
+
+def test_load_weight_checks_names_and_shapes(lib):
+    cfg = preset("ref-default")
+    st, h = _create(lib, cfg)
+    assert st == 0
+    sd = synth_state_dict(cfg, 0)
+
+    def load(name, arr):
+        a = np.ascontiguousarray(arr, np.float32)
+        shape = (C.c_int64 * a.ndim)(*a.shape)
+        return lib.fs2_load_weight(h, name.encode(), a.ctypes.data_as(C.c_void_p), shape, a.ndim)
+
+    # every tensor of the reference state_dict (reference key names) is accepted ...
+    for name, shape in state_dict_spec(cfg).items():
+        assert load(name, sd[name]) == 0, name
+    # ... off-path / misspelled names and wrong shapes are refused
+    assert load("fastdiff_linear.0.weight", np.zeros((256, 256))) == 4
+    assert load("encoder.layers.0.conv1.weight", np.zeros((1024, 256, 5))) == 4  # dense key on a depth-wise config
+    assert load("linear.weight", np.zeros((80, 255))) == 4
+    assert b"shape mismatch" in lib.fs2_last_error(h)
+    # decode before encode is a state error, not a crash
+    out = _lib.Fs2OutputsC()
+    assert lib.fs2_decode(h, C.byref(out), None) == 5
+    lib.fs2_destroy(h)
+
+
+def test_product_path_has_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from lightningfastspeech2_amd.model import FastSpeech2
+    cfg = preset("ref-default")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        FastSpeech2(cfg, synth_state_dict(cfg, 0))
+
+
+def test_product_package_never_imports_the_oracle():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "lightningfastspeech2_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dp, f)).read()
+                assert "oracle_cpu" not in text and "import oracle" not in text and "from oracle" not in text, f

@@ -1,0 +1,230 @@
+"""Per-kernel parity (`-m gpu`): every HIP operator, called through the C ABI, against the same op
+of the CPU oracle / plain torch fp32 on seeded inputs.  fp32 mode is held to float-roundoff;
+bf16 mode is compared with fp32 math on the bf16-rounded inputs (tolerance = bf16 output rounding).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import _gpu as G
+from oracle import oracle_cpu
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [pytest.param(G.F32, id="fp32"), pytest.param(G.BF16, id="bf16")]
+
+
+def tol(dtype, ref, f32=2e-5, bf16=1.2e-2):
+    scale = float(ref.abs().max()) + 1e-6
+    return (bf16 if dtype == G.BF16 else f32) * scale
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K,relu", [(200, 80, 64, False), (128, 128, 128, True), (300, 260, 256, False),
+                                         (1000, 768, 256, True), (37, 4, 64, False), (513, 1024, 1024, False)])
+def test_gemm_plain(dtype, M, N, K, relu):
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    # asymmetric, transpose-detecting reference
+    ref = G.rounded(x, dtype) @ G.rounded(w, dtype).T + b
+    if relu:
+        ref = torch.relu(ref)
+    got = G.gemm(dtype, x, w, b, relu=relu)
+    err = float((got - ref).abs().max())
+    assert err <= tol(dtype, ref), (err, tol(dtype, ref))
+
+
+def test_gemm_bf16_in_fp32_out():
+    x, w, b = rnd(150, 256, seed=4), rnd(80, 256, seed=5, scale=1 / 16), rnd(80, seed=6)
+    ref = G.rounded(x, G.BF16) @ G.rounded(w, G.BF16).T + b
+    got = G.gemm(G.BF16, x, w, b, out_dtype=G.F32)
+    assert float((got - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
+
+
+def test_gemm_identity_layout():
+    # A = I picks W^T exactly: catches swapped row/col maps that symmetric data would hide
+    K = 64
+    x = torch.eye(K)
+    w = torch.arange(K * K, dtype=torch.float32).reshape(K, K) / 64.0  # asymmetric
+    got = G.gemm(G.F32, x, w, None)
+    assert torch.equal(got, w.T.contiguous())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,S,Cin,N,k", [(3, 37, 64, 128, 3), (2, 130, 64, 64, 9), (4, 11, 128, 256, 5),
+                                          (2, 300, 256, 1024, 9), (1, 5, 64, 64, 25)])
+def test_gemm_conv_same_padding_per_utterance(dtype, B, S, Cin, N, k):
+    x = rnd(B, S, Cin, seed=7)
+    w = rnd(N, Cin, k, seed=8, scale=(Cin * k) ** -0.5)
+    b = rnd(N, seed=9)
+    ref = F.conv1d(G.rounded(x, dtype).transpose(1, 2), G.rounded(w, dtype), b, padding="same").transpose(1, 2)
+    got = G.gemm(dtype, x.reshape(B * S, Cin), G.pack_conv_weight(w), b, taps=k, S=S).reshape(B, S, N)
+    err = float((got - ref).abs().max())
+    assert err <= tol(dtype, ref), (err, tol(dtype, ref))
+
+
+# ------------------------------------------------------------------------------------------------
+def _attn_ref(qkv, mask, B, S, H, heads):
+    d = H // heads
+    q, k, v = qkv.view(B, S, 3 * H).split(H, dim=-1)
+    q = q.view(B, S, heads, d).transpose(1, 2) * (1.0 / math.sqrt(d))
+    k = k.view(B, S, heads, d).transpose(1, 2)
+    v = v.view(B, S, heads, d).transpose(1, 2)
+    s = (q @ k.transpose(-1, -2)).masked_fill(mask[:, None, None, :], float("-inf"))
+    return (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B * S, H)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,S,H,heads,mask_kind", [
+    (2, 40, 64, 2, "suffix"), (3, 130, 128, 2, "suffix"), (2, 200, 256, 2, "suffix"),
+    (2, 64, 256, 2, "none"), (2, 257, 256, 2, "scatter"), (1, 700, 256, 2, "suffix"), (2, 33, 128, 4, "scatter")])
+def test_attention(dtype, B, S, H, heads, mask_kind):
+    qkv = rnd(B * S, 3 * H, seed=10)
+    mask = torch.zeros(B, S, dtype=torch.bool)
+    if mask_kind == "suffix":
+        for b in range(B):
+            mask[b, S - (7 + 13 * b) % S:] = True
+        mask[0, :] = False
+        mask[0, S - S // 2:] = True   # a long padded tail: whole tiles get skipped
+    elif mask_kind == "scatter":
+        g = torch.Generator().manual_seed(11)
+        mask = torch.rand(B, S, generator=g) < 0.3
+        mask[:, 0] = False
+    ref = _attn_ref(G.rounded(qkv, dtype), mask, B, S, H, heads)
+    got = G.attention(dtype, qkv, mask, B, S, H, heads)
+    err = float((got - ref).abs().max())
+    assert err <= tol(dtype, ref, f32=5e-5, bf16=2e-2), (err, tol(dtype, ref))
+
+
+def test_attention_spike_forces_rescale():
+    # one key dominates late in the sequence: the running max jumps at a late tile (rule 26)
+    B, S, H, heads = 1, 256, 256, 2
+    qkv = rnd(B * S, 3 * H, seed=12)
+    qkv[200, H:H + 128] = 6.0 * qkv[5, :128]  # key 200 aligned with query 5 (head 0)
+    mask = torch.zeros(B, S, dtype=torch.bool)
+    ref = _attn_ref(qkv, mask, B, S, H, heads)
+    got = G.attention(G.F32, qkv, mask, B, S, H, heads)
+    assert float((got - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,H", [(37, 64), (100, 256), (9, 768), (130, 1024), (5, 128)])
+def test_layernorm_residual_and_head(dtype, M, H):
+    x, r = rnd(M, H, seed=13, scale=2.0), rnd(M, H, seed=14)
+    g, b = 1 + 0.2 * rnd(H, seed=15), 0.1 * rnd(H, seed=16)
+    w = rnd(H, seed=17, scale=H ** -0.5)
+    mask = torch.zeros(M, dtype=torch.bool)
+    mask[::3] = True
+    ref = F.layer_norm(G.rounded(x, dtype) + G.rounded(r, dtype), (H,), g, b, 1e-5)
+    y, pred = G.layernorm(dtype, x, r, g, b, dot_w=w, dot_b=0.25, mask=mask)
+    assert float((y - ref).abs().max()) <= tol(dtype, ref)
+    pref = (ref @ w + 0.25).masked_fill(mask, 0)
+    assert float((pred - pref).abs().max()) <= 5e-5 * (float(pref.abs().max()) + 1)
+    y2, _ = G.layernorm(dtype, x, None, g, b)
+    ref2 = F.layer_norm(G.rounded(x, dtype), (H,), g, b, 1e-5)
+    assert float((y2 - ref2).abs().max()) <= tol(dtype, ref2)
+    _, pred2 = G.layernorm(dtype, x, r, g, b, dot_w=w, dot_b=0.25, mask=mask, want_y=False)
+    assert torch.equal(pred, pred2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,S,C,k", [(3, 37, 64, 3), (2, 130, 256, 25), (2, 70, 768, 17), (1, 4, 64, 9), (2, 64, 128, 1)])
+def test_dwconv(dtype, B, S, C, k):
+    x, w, b = rnd(B, S, C, seed=18), rnd(C, 1, k, seed=19, scale=k ** -0.5), rnd(C, seed=20)
+    ref = F.conv1d(G.rounded(x, dtype).transpose(1, 2), w, b, padding="same", groups=C).transpose(1, 2)
+    got = G.dwconv(dtype, x.reshape(B * S, C), w, b, B, S).reshape(B, S, C)
+    assert float((got - ref).abs().max()) <= tol(dtype, ref)
+
+
+# ------------------------------------------------------------------------------------------------
+def test_durations_round_guard_prefix():
+    B, L = 6, 300
+    g = torch.Generator().manual_seed(21)
+    p = torch.rand(B, L, generator=g) * 2.4 - 0.3
+    p[1] = p[1] * 0.1 - 0.2          # rounds to all zeros -> guard
+    p[2, :] = math.log(1.5)          # exp(p)-1 = .5 (to rounding) -> half-even
+    p[3, :] = math.log(3.5)
+    mask = torch.zeros(B, L, dtype=torch.bool)
+    for b in range(B):
+        mask[b, L - 17 * b:] = b > 0
+    p = p.masked_fill(mask, 0)
+    ref, guarded = oracle_cpu.round_durations(p.clone(), mask)
+    dur, cum, tot, grd = G.durations(p, mask)
+    exact = (torch.exp(p) - 1)
+    risky = ((exact - torch.floor(exact)) - 0.5).abs() < 1e-5  # GPU/CPU expf may differ by an ulp here
+    assert torch.equal(dur[~risky], ref[~risky])
+    assert sorted(guarded) == sorted(torch.nonzero(grd).flatten().tolist())
+    assert torch.equal(cum, torch.cumsum(dur, 1).int())
+    assert torch.equal(tot, dur.sum(1).int())
+    forced = torch.randint(0, 9, (B, L), generator=g).int()
+    dur2, cum2, tot2, grd2 = G.durations(p, mask, forced)
+    assert torch.equal(dur2, forced) and torch.equal(cum2, torch.cumsum(forced, 1).int()) and int(grd2.sum()) == 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cap", [None, 50])
+def test_length_regulator(dtype, cap):
+    B, L, H = 4, 23, 64
+    g = torch.Generator().manual_seed(22)
+    x = rnd(B, L, H, seed=23)
+    dur = torch.randint(0, 7, (B, L), generator=g).int()
+    dur[3, 10:] = 0
+    ref, rmask = oracle_cpu.length_regulator(G.rounded(x, dtype), dur, cap if cap else 1e9)
+    T = ref.shape[1]
+    y, mk = G.regulate(dtype, x.reshape(B * L, H), torch.cumsum(dur, 1), dur.sum(1), B, L, T, H)
+    assert torch.equal(mk, rmask)
+    assert torch.equal(y.reshape(B, T, H), ref)  # a pure gather: bit exact in either dtype
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_bucketize_embed_add(dtype):
+    B, T, H, nb = 3, 41, 128, 256
+    bins = torch.linspace(-3, 3, nb - 1)
+    pred = rnd(B * T, seed=24, scale=1.5)
+    pred[:nb - 1] = bins                      # exactly on every edge
+    pred[nb:nb + 5] = torch.tensor([-5.0, 3.0, 3.01, 0.0, -3.0])
+    emb, x = rnd(nb, H, seed=25), rnd(B * T, H, seed=26)
+    pe, spk = rnd(T, H, seed=27), rnd(B, H, seed=28)
+    std, mean = 1.3, -0.2
+    idx_ref = torch.bucketize(pred * std + mean, bins)
+    xr = G.rounded(x, dtype)
+    ref = (xr + emb[idx_ref]).reshape(B, T, H) + pe[None] + spk[:, None]
+    y, idx = G.bucket_embed(dtype, x, pred, bins, emb, std, mean, pe, spk, B, T, H)
+    assert torch.equal(idx.long(), idx_ref)
+    assert float((y.reshape(B, T, H) - ref).abs().max()) <= tol(dtype, ref, f32=1e-6)
+    y2, _ = G.bucket_embed(dtype, x, None, None, None, 0, 0, pe, spk, B, T, H)
+    ref2 = xr.reshape(B, T, H) + pe[None] + spk[:, None]
+    assert float((y2.reshape(B, T, H) - ref2).abs().max()) <= tol(dtype, ref2, f32=1e-6)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_embed_pe_speaker(dtype):
+    B, L, H, V = 3, 19, 256, 40
+    g = torch.Generator().manual_seed(29)
+    phones = torch.randint(1, V, (B, L), generator=g)
+    phones[1, 12:] = 0
+    phones[2, 3:] = 0
+    table = rnd(V, H, seed=30)
+    table[0] = 0
+    pe, spk = rnd(L, H, seed=31), rnd(B, H, seed=32)
+    ref = (table[phones] + pe[None]) + spk[:, None]
+    x, mk = G.embed(dtype, phones, table, pe, spk, V)
+    assert torch.equal(mk, phones.eq(0))
+    assert float((x.reshape(B, L, H) - ref).abs().max()) <= tol(dtype, ref, f32=1e-6)
+
+
+def test_speaker_projection():
+    B, H, D = 5, 256, 256
+    dv, w, b = rnd(B, D, seed=33), rnd(H, D, seed=34, scale=1 / 16), rnd(H, seed=35)
+    ref = torch.relu(dv @ w.T + b)
+    got = G.spk_proj(dv, w, b)
+    assert float((got - ref).abs().max()) <= 1e-5
