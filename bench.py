@@ -1,0 +1,177 @@
+#!/usr/bin/env python
+"""Headline benchmark: mel-frames/s of the FastSpeech2 mel forward on synthetic 256-phoneme x
+batch-32 inputs (BASELINE.json metric / configs[1]: FS2-27M, bf16, batch 32, 256 phonemes).
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = one pass of the hot path (fs2_encode + fs2_decode through the drop-in model object)
+over one batch per rank, inputs already resident in HBM; with N > 1 every rank runs its own
+batch-32 shard (weak scaling) and the final mels are all-gathered with RCCL.  Rank 0 prints ONE
+JSON line.  ``roofline`` is for the dominant kernel (the implicit-GEMM dense Conv1d): algorithmic
+FLOPs per launch / average launch duration measured with HIP events on the launch stream inside the
+timed region.  ``cpu_baseline`` times the CPU oracle (a port, not the product) on a bounded sample
+of the same workload on this box's host cores (rank 0, N=1 only).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+MFMA_PEAK = {"bf16": 2.5e15, "fp32": 157.3e12}  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+HOP, SR = 256, 22050
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c2", help="c2 (FS2-27M) | c3 (LS-76M) | c5 (FS2-1B) | ref-default")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
+    ap.add_argument("--phones", type=int, default=256)
+    ap.add_argument("--frames-per-phone", type=int, default=6)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-batch", type=int, default=8)
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, sd, args):
+    """The CPU oracle on the first `cpu-sample-batch` utterances of the same synthetic workload."""
+    from lightningfastspeech2_amd.weights import synth_inputs
+    from oracle import oracle_cpu  # cpu_baseline leg only
+    B = args.cpu_sample_batch
+    inp = synth_inputs(cfg, args.batch, args.phones, seed=1234)
+    ph, sp = inp["phones"][:B], inp["speaker"][:B]
+    cores = torch.get_num_threads()
+    oracle_cpu.forward(sd, cfg, ph[:1], sp[:1])  # warm the thread pool / allocator
+    reps, t_tot, frames = 2, 0.0, 0
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        out = oracle_cpu.forward(sd, cfg, ph, sp)
+        t_tot += time.perf_counter() - t0
+        frames += int((~out["tgt_mask"]).sum())
+    return {"value": frames / t_tot, "unit": "mel-frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/oracle_cpu.py (torch {torch.__version__} CPU fp32 ops), {reps} passes over the "
+                      f"first {B} of the {args.batch} x {args.phones}-phoneme utterances, {t_tot:.1f} s",
+            "rtf": t_tot / (frames * HOP / SR)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    if world != args.gpus and rank == 0:
+        print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+
+    from lightningfastspeech2_amd import _lib
+    from lightningfastspeech2_amd.config import preset
+    from lightningfastspeech2_amd.dist import gather_mels
+    from lightningfastspeech2_amd.model import FastSpeech2
+    from lightningfastspeech2_amd.weights import synth_inputs, synth_state_dict
+
+    cfg = preset(args.config)
+    # duration head weight 0 / bias ln(1+f): every phone gets f frames -> T = f * phones
+    sd = synth_state_dict(cfg, 0, duration_bias=math.log(1.0 + args.frames_per_phone), duration_weight_scale=0.0)
+    model = FastSpeech2(cfg, sd, precision=args.precision, device=dev)
+    inp = synth_inputs(cfg, args.batch, args.phones, seed=1234 + 17 * rank)
+    batch = {"phones": torch.from_numpy(inp["phones"]).to(dev), "speaker": torch.from_numpy(inp["speaker"]).to(dev)}
+
+    def step():
+        out = model(batch, inference=True)
+        if world > 1:
+            mel_all, frames = gather_mels(out["mel"], out["tgt_mask"])
+            return out, int(frames.numel())
+        return out, out["mel"].shape[0]
+
+    for _ in range(args.warmup):
+        out, _ = step()
+    frames_rank = int((~out["tgt_mask"]).sum())
+    T = int(out["mel"].shape[1])
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    model.engine.profile_enable(_lib.K_CONV_GEMM if not cfg.decoder_depthwise_conv else _lib.K_GEMM, True)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    kcls = _lib.K_CONV_GEMM if not cfg.decoder_depthwise_conv else _lib.K_GEMM
+    prof = model.engine.profile_read(kcls)
+    model.engine.profile_enable(kcls, False)
+
+    t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    frames_all = torch.tensor([frames_rank], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        dist.all_reduce(frames_all, op=dist.ReduceOp.SUM)
+    elapsed = float(t_max.item())
+    total_frames = int(frames_all.item())
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = total_frames * args.steps / elapsed
+        n = max(prof["launches"], 1)
+        avg_s = prof["ms"] / n * 1e-3
+        achieved = (prof["flops"] / n) / avg_s if avg_s > 0 else 0.0
+        peak = MFMA_PEAK[args.precision]
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tpath) and args.config == "c2" and args.precision == "bf16":
+            try:
+                traffic = json.load(open(tpath)).get("conv_gemm_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "mel-frames/sec (whole node), 256-phoneme batch-32",
+            "value": value, "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic",
+            "rtf": elapsed / args.steps / (total_frames * HOP / SR),
+            "config": {"workload": f"{args.config}: "
+                       + {"c2": "FS2-27M dense k=9 H=256 F=1024 4+4 layers",
+                          "c3": "LS-76M depth-wise H=768 F=3072 4+5 layers",
+                          "c5": "FS2-1B dense k=9 H=1024 F=4096 12+12 layers"}.get(args.config, args.config)
+                       + f", batch {args.batch}/GPU x {args.phones} phonemes, {args.frames_per_phone} frames/phone "
+                         f"-> T={T}, random-init weights", "batch_per_gpu": args.batch, "phonemes": args.phones,
+                       "frames_per_utterance": T, "global_batch": args.batch * world,
+                       "parallelism": f"dp{world} (utterance shards, RCCL all-gather of mels only)" if world > 1 else "single GPU",
+                       "params": cfg.param_count()},
+            "roofline": {"bound": "mfma", "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
+                         "frac": achieved / peak, "traffic": traffic,
+                         "kernel": "gemm_conv_kernel (implicit-GEMM Conv1d)" if kcls == _lib.K_CONV_GEMM else "gemm_conv_kernel (pointwise GEMMs)",
+                         "launches_timed": prof["launches"], "avg_launch_us": avg_s * 1e6,
+                         "flops_per_launch": prof["flops"] / n},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, sd, args)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -115,6 +115,10 @@ int fs2_decode(fs2_engine* e, const fs2_outputs* out, void* hip_stream);
  * what = "encoder_out" (B,L,H) | "regulated" | "adaptor_out" | "decoder_out" (B,T,H) |
  *        "bucket_<var>" (B,T) int32.  Requires fs2_set_debug(e, 1) before fs2_encode. */
 int fs2_set_debug(fs2_engine* e, int32_t on);
+/* Parity aid (the analogue of the reference's teacher forcing of variance targets,
+ * model.py:417-422): the NEXT fs2_decode embeds these (B, T) int32 device bucket indices for
+ * variance `variance_index` instead of bucketizing its own prediction.  One-shot. */
+int fs2_force_buckets(fs2_engine* e, int32_t variance_index, const int32_t* idx_device);
 int fs2_debug_copy(fs2_engine* e, const char* what, void* dst_device, void* hip_stream);
 
 /* Kernel timing with HIP events on the launch stream (bench.py roofline).  kernel_class: */

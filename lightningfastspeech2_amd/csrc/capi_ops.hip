@@ -100,7 +100,7 @@ int fs2_op_regulate(int32_t dtype, const void* x, const int32_t* cum, const int3
 int fs2_op_bucket_embed(int32_t dtype, const void* x, const float* pred, const float* bins, const float* emb,
                         int32_t nbins, float std, float mean, const float* pe, const float* spk, void* y,
                         int32_t* idx_out, int32_t B, int32_t T, int32_t H, void* stream) {
-    BucketArgs a{x, pred, bins, emb, nbins, std, mean, pe, spk, y, idx_out, B, T, H};
+    BucketArgs a{x, pred, bins, emb, nbins, std, mean, pe, spk, y, idx_out, B, T, H, nullptr};
     return launch_bucket_embed(a, dtype, (hipStream_t)stream);
 }
 

@@ -126,6 +126,7 @@ struct fs2_engine {
     int h_pinned_cap = 0;
     std::vector<int32_t> totals, guard;
     std::map<std::string, std::pair<void*, size_t>> taps;
+    const int32_t* forced_idx[FS2_MAX_VARIANCES] = {nullptr, nullptr, nullptr, nullptr};
     ProfSlot prof[FS2_K_COUNT];
 };
 
@@ -779,13 +780,14 @@ int fs2_decode(fs2_engine* e, const fs2_outputs* out, void* stream) {
         }
         Bracket br(e, FS2_K_ROWOPS, st, 0, 2.0 * MT * H * esz);
         BucketArgs ba{yA, vpred[v], e->vars[v].bins, e->vars[v].emb, c.var_nbins, c.var_std[v], c.var_mean[v],
-                      (last && fuse_pe) ? e->pe : nullptr, (last && fuse_pe) ? e->spk : nullptr, yA, idx, B, T, (int)H};
+                      (last && fuse_pe) ? e->pe : nullptr, (last && fuse_pe) ? e->spk : nullptr, yA, idx, B, T, (int)H,
+                      e->forced_idx[v]};
         if (launch_bucket_embed(ba, e->dt, st) != FS2_OK) return fail(e, FS2_ERR_HIP, "bucket_embed launch failed");
         if (out->variances[v]) HIPCHK(e, hipMemcpyAsync(out->variances[v], vpred[v], MT * 4, hipMemcpyDeviceToDevice, st));
     }
     if (e->debug) CHK(tap_store(e, st, "adaptor_out", yA, MT * H, e->dt));
     if (!fuse_pe || c.n_variances == 0) {  // y = (x + pe) + spk               fastspeech2.py:705-718
-        BucketArgs ba{yA, nullptr, nullptr, nullptr, 0, 0.f, 0.f, e->pe, e->spk, yA, nullptr, B, T, (int)H};
+        BucketArgs ba{yA, nullptr, nullptr, nullptr, 0, 0.f, 0.f, e->pe, e->spk, yA, nullptr, B, T, (int)H, nullptr};
         if (launch_bucket_embed(ba, e->dt, st) != FS2_OK) return fail(e, FS2_ERR_HIP, "pe/spk add launch failed");
     }
     for (int i = 0; i < c.dec_layers; ++i)                                   // fastspeech2.py:719-721
@@ -793,6 +795,13 @@ int fs2_decode(fs2_engine* e, const fs2_outputs* out, void* stream) {
     if (e->debug) CHK(tap_store(e, st, "decoder_out", yA, MT * H, e->dt));
     if (out->mel) CHK(gemm(e, st, e->mel, yA, out->mel, (int)MT, (int)MT, false, FS2_F32));  // fastspeech2.py:723
     if (out->tgt_mask) HIPCHK(e, hipMemcpyAsync(out->tgt_mask, tmask, MT, hipMemcpyDeviceToDevice, st));
+    for (int v = 0; v < FS2_MAX_VARIANCES; ++v) e->forced_idx[v] = nullptr;  // one-shot
+    return FS2_OK;
+}
+
+int fs2_force_buckets(fs2_engine* e, int32_t variance_index, const int32_t* idx) {
+    if (!e || variance_index < 0 || variance_index >= e->cfg.n_variances) return FS2_ERR_ARG;
+    e->forced_idx[variance_index] = idx;
     return FS2_OK;
 }
 

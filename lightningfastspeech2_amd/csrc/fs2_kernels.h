@@ -123,6 +123,7 @@ struct BucketArgs {
     void* y;              // (B*T, H) (may alias x)
     int32_t* idx_out;     // (B*T) or null: bucket indices (debug / parity)
     int B, T, H;
+    const int32_t* forced_idx;  // (B*T) or null: use these bucket indices instead of searching
 };
 int launch_bucket_embed(const BucketArgs& a, int dtype, hipStream_t stream);
 

@@ -362,6 +362,10 @@ __global__ __launch_bounds__(256) void bucket_embed_kernel(BucketArgs p) {
             const int mid = (lo + hi) >> 1;
             if (p.bins[mid] < v) lo = mid + 1; else hi = mid;
         }
+        if (p.forced_idx) {
+            lo = p.forced_idx[row];
+            lo = lo < 0 ? 0 : (lo >= p.nbins ? p.nbins - 1 : lo);
+        }
         if (lane == 0 && p.idx_out) p.idx_out[row] = lo;
         e = p.emb + (size_t)lo * p.H;
     }

@@ -101,6 +101,11 @@ class Engine:
                                             grd.ctypes.data_as(C.c_void_p), B), self.handle, "last_totals")
         return tot, grd
 
+    def force_buckets(self, var_index: int, idx: torch.Tensor):
+        """Next decode embeds these (B, T) int32 bucket indices for that variance (parity aid)."""
+        self._keep = getattr(self, "_keep", []) + [idx]
+        _lib.check(self.lib.fs2_force_buckets(self.handle, var_index, _ptr(idx)), self.handle, "force_buckets")
+
     def decode(self, want_aux: bool = True) -> Dict[str, torch.Tensor]:
         B, L, T = self._last
         dev = self.device
@@ -123,6 +128,7 @@ class Engine:
         with torch.cuda.device(dev):
             st = self.lib.fs2_decode(self.handle, C.byref(out), self._stream())
         _lib.check(st, self.handle, "decode")
+        self._keep = []
         return res
 
     def debug_tensor(self, what: str) -> torch.Tensor:
@@ -200,7 +206,7 @@ class FastSpeech2:
     def __call__(self, targets, inference: bool = False):
         return self.forward(targets, inference)
 
-    def forward(self, targets: dict, inference: bool = False, *, force_durations=None) -> dict:
+    def forward(self, targets: dict, inference: bool = False, *, force_durations=None, force_buckets=None) -> dict:
         if not inference and force_durations is None:
             raise NotImplementedError(
                 "teacher-forced/training forward (inference=False, model.py:296-297,317-325) is outside "
@@ -221,7 +227,12 @@ class FastSpeech2:
         forced = None
         if force_durations is not None:
             forced = torch.as_tensor(force_durations).to(self.device, dtype=torch.int32).contiguous()
-        self.engine.encode(phones, speaker, forced)
+        T = self.engine.encode(phones, speaker, forced)
+        for var, idx in (force_buckets or {}).items():
+            idx = torch.as_tensor(idx).to(self.device, dtype=torch.int32).contiguous()
+            if tuple(idx.shape) != (phones.shape[0], T):
+                raise ValueError(f"force_buckets[{var!r}] must be (B, T)=({phones.shape[0]}, {T})")
+            self.engine.force_buckets(self.cfg.variances.index(var), idx)
         _, guard = self.engine.totals()
         for _ in range(int(guard.sum())):
             print("Zero duration, setting to 1")  # the reference's one stdout side effect (model.py:309)

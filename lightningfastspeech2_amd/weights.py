@@ -91,21 +91,28 @@ def state_dict_spec(cfg: Fs2Config) -> "OrderedDict[str, tuple]":
 
 
 def positional_table(H: int, max_len: int = PE_MAX_LEN) -> np.ndarray:
-    """PositionalEncoding buffer, model.py:43-50 (float32 arithmetic as torch does it)."""
-    import torch
-    pe = torch.zeros(max_len, H)
-    position = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1)
-    div_term = torch.exp(torch.arange(0, H, 2).float() * (-math.log(10000.0) / H))
-    pe[:, 0::2] = torch.sin(position * div_term)
-    pe[:, 1::2] = torch.cos(position * div_term)
-    return pe.unsqueeze(0).numpy()
+    """PositionalEncoding buffer, model.py:43-50: pe[p, 2i] = sin(p * exp(-2i ln(1e4)/H)),
+    pe[p, 2i+1] = cos(.).  Evaluated in float64 and rounded once to float32 so the table is the
+    same bits on every host (torch's float32 sin/cos differ by an ulp between CPU dispatch paths);
+    it travels in the state_dict (``positional_encoding.pe`` is a registered buffer), so the
+    reference, the oracle and the engine all consume this exact tensor."""
+    position = np.arange(max_len, dtype=np.float64)[:, None]
+    div_term = np.exp(np.arange(0, H, 2, dtype=np.float64) * (-math.log(10000.0) / H))
+    pe = np.zeros((max_len, H), np.float64)
+    pe[:, 0::2] = np.sin(position * div_term)
+    pe[:, 1::2] = np.cos(position * div_term)
+    return pe[None].astype(np.float32)
 
 
 def variance_bins(cfg: Fs2Config, var: str) -> np.ndarray:
-    """VarianceEncoder.bins = torch.linspace(min, max, nbins-1), model.py:397-400."""
-    import torch
+    """VarianceEncoder.bins = linspace(min, max, nbins-1), model.py:397-400 (float64 arithmetic,
+    one rounding; carried in the state_dict as the ``bins`` parameter)."""
     st = cfg.stats[var]
-    return torch.linspace(st["min"], st["max"], cfg.variance_nbins - 1).numpy()
+    n = cfg.variance_nbins - 1
+    lo, hi = float(st["min"]), float(st["max"])
+    if n == 1:
+        return np.array([lo], np.float32)
+    return (lo + (hi - lo) * (np.arange(n, dtype=np.float64) / (n - 1))).astype(np.float32)
 
 
 def synth_state_dict(cfg: Fs2Config, seed: int = 0, *, randomize_norm: bool = False,

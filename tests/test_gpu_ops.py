@@ -187,7 +187,7 @@ def test_length_regulator(dtype, cap):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_bucketize_embed_add(dtype):
-    B, T, H, nb = 3, 41, 128, 256
+    B, T, H, nb = 3, 100, 128, 256
     bins = torch.linspace(-3, 3, nb - 1)
     pred = rnd(B * T, seed=24, scale=1.5)
     pred[:nb - 1] = bins                      # exactly on every edge

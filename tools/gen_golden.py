@@ -91,6 +91,8 @@ CASES = {
 def sd_digest(sd) -> str:
     h = hashlib.sha256()
     for k, v in sd.items():
+        if k.endswith(".pe") or k.endswith(".bins"):
+            continue  # libm-dependent in the last ulp across hosts; they travel inside the state_dict
         h.update(k.encode())
         h.update(np.ascontiguousarray(v).tobytes())
     return h.hexdigest()
