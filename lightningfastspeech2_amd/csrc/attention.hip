@@ -5,7 +5,9 @@
 // still computed.
 //
 // One workgroup = NW waves = NW*32 queries of one (utterance, head); KV advances in tiles of 64
-// keys (bf16) / 32 keys (fp32) staged in LDS with a 16-byte XOR swizzle.
+// keys (bf16) / 32 keys (fp32).  K and V^T tiles are streamed global->LDS by DMA
+// (global_load_lds, no staging registers) into two single buffers with a 16-byte XOR swizzle applied
+// on the source address: V^T_j lands underneath Q.K^T_j and K_{j+1} underneath P.V_j.
 //   S^T = K Q^T  via 32x32 MFMA with K as the row operand: each lane then owns ONE query (lane&31)
 //                and 16 keys per 32-key block, so row max / row sum are in-register + one
 //                lane^32 exchange.
@@ -29,9 +31,25 @@ __device__ inline int swz_row(int row, int slot) {
     else return row * RB + ((slot ^ ((row >> 3) & 1)) << 4);
 }
 
+// 16-byte global -> LDS DMA: LDS address = (wave-uniform) lds_base + lane*16; the global source
+// address is per lane, which is where the XOR swizzle goes (linear destination, permuted source,
+// same XOR on the ds_read side — cdna_hip_programming.md §5.4 rule 21).
+__device__ inline void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int RB>  // inverse view of swz_row: which logical slot lives at physical slot ps of `row`
+__device__ inline int unswz_slot(int row, int ps) {
+    constexpr int NS = RB / 16;
+    if constexpr (NS >= 16) return ps ^ (row & 15);
+    else if constexpr (NS == 8) return ps ^ ((row >> 1) & 7);
+    else if constexpr (NS == 4) return ps ^ ((row >> 2) & 3);
+    else return ps ^ ((row >> 3) & 1);
+}
+
 template <typename T, int D, int NW>
-__global__ __launch_bounds__(NW * 64) void attention_kernel(AttnArgs p) {
-    constexpr int NT = NW * 64;
+__global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128) ? 2 : 1) void attention_kernel(AttnArgs p) {
     constexpr int KVB = sizeof(T) == 2 ? 64 : 32;      // keys per tile
     constexpr int E16 = Num<T>::kPer16B;
     constexpr int KC = Mma32<T>::K_PER_CHUNK;          // k-values per 2x16B chunk
@@ -41,33 +59,76 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(AttnArgs p) {
     constexpr int VRB = 128;                           // Vt tile row bytes (KVB keys)
     constexpr int NKB = KVB / 32;                      // 32-key blocks per tile
     constexpr int ND = D / 32;                         // 32-wide dv blocks
+    constexpr int TILE_B = 128 * D;                    // bytes of a K tile == bytes of a Vt tile
+    constexpr int NINST = TILE_B / 1024 / NW;          // 1-KiB DMA instructions per wave per tile
+    constexpr float THR = sizeof(T) == 2 ? 6.0f : 0.0f;  // defer-max threshold (log2 units), exact in fp32
+    static_assert(TILE_B % (1024 * NW) == 0, "tile must split into whole wave DMAs");
 
-    __shared__ __attribute__((aligned(16))) unsigned char sK[KVB * KRB];
-    __shared__ __attribute__((aligned(16))) unsigned char sV[D * VRB];
+    __shared__ __attribute__((aligned(16))) unsigned char sK[TILE_B];
+    __shared__ __attribute__((aligned(16))) unsigned char sV[TILE_B];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, hi = lane >> 5;
-    const int bh = blockIdx.y, b = bh / p.heads, h = bh % p.heads;
-    const int q0 = blockIdx.x * (NW * 32);
+    // XCD-aware mapping: workgroup id % 8 is the XCD it lands on (observed dispatch order); all
+    // query blocks of one (utterance, head) share its K/V, so keep them on one XCD's L2.
+    const int nq = (p.S + NW * 32 - 1) / (NW * 32);
+    const int xcd = blockIdx.x & 7, r8 = blockIdx.x >> 3;
+    const int bh = (r8 / nq) * 8 + xcd;
+    if (bh >= p.B * p.heads) return;
+    const int b = bh / p.heads, h = bh % p.heads;
+    const int q0 = (r8 % nq) * (NW * 32);
     const int ld = 3 * p.H;
     const T* __restrict__ qkv = (const T*)p.qkv;
     const T* __restrict__ vt = (const T*)p.vt;
+    const T* kbase = qkv + (size_t)b * p.S * ld + p.H + h * D;
+    const T* vbase = vt + (size_t)bh * D * p.Spad;
+    const uint64_t* kbits = p.kbits + (size_t)b * p.nw64;
+    const int ntiles = (p.S + KVB - 1) / KVB;
 
-    // ---- Q fragments (column operand of S^T = K Q^T), pre-scaled by log2(e)/sqrt(d) ----
+    auto tile_bits = [&](int j) -> unsigned long long {
+        unsigned long long w = kbits[(j * KVB) >> 6];
+        if (KVB == 32) w = (w >> ((j * KVB) & 32)) & 0xffffffffull;
+        return w;
+    };
+    auto next_tile = [&](int j) {  // first tile >= j with at least one valid key (block-uniform)
+        while (j < ntiles && tile_bits(j) == 0ull) ++j;
+        return j;
+    };
+    auto issue_k = [&](int j) {
+        const int kv0 = j * KVB;
+#pragma unroll
+        for (int i = 0; i < NINST; ++i) {
+            const int g = i * NW + wave;
+            const int P = g * 64 + lane;
+            const int row = P / KNS, ps = P % KNS;
+            int key = kv0 + row;
+            if (key >= p.S) key = p.S - 1;  // masked by the valid bits; keeps the load in bounds
+            glds16(kbase + (size_t)key * ld + unswz_slot<KRB>(row, ps) * E16, sK + g * 1024);
+        }
+    };
+    auto issue_v = [&](int j) {
+        const int kv0 = j * KVB;
+#pragma unroll
+        for (int i = 0; i < NINST; ++i) {
+            const int g = i * NW + wave;
+            const int P = g * 64 + lane;
+            const int row = P >> 3, ps = P & 7;
+            glds16(vbase + (size_t)row * p.Spad + kv0 + unswz_slot<VRB>(row, ps) * E16, sV + g * 1024);
+        }
+    };
+
+    int j = next_tile(0);
+    if (j < ntiles) issue_k(j);
+
+    // ---- Q fragments (column operand of S^T = K Q^T) ----
     uint4 qf[NQC];
     {
         int qrow = q0 + wave * 32 + li;
         if (qrow >= p.S) qrow = p.S - 1;
         const T* src = qkv + (size_t)(b * p.S + qrow) * ld + h * D + hi * E16;
 #pragma unroll
-        for (int c = 0; c < NQC; ++c) {
-            uint4 u = *(const uint4*)(src + c * KC);
-            float f[Vec16<T>::N];
-            Vec16<T>::unpack(u, f);
-#pragma unroll
-            for (int e = 0; e < Vec16<T>::N; ++e) f[e] *= p.scale_log2e;
-            qf[c] = Vec16<T>::pack(f);
-        }
+        for (int c = 0; c < NQC; ++c) qf[c] = *(const uint4*)(src + c * KC);
     }
 
     f32x16_t oacc[ND];
@@ -75,30 +136,15 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(AttnArgs p) {
     for (int i = 0; i < ND; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;  // running max (scaled, log2 units) and denominator
+    const float sc = p.scale_log2e;
 
-    const int ntiles = (p.S + KVB - 1) / KVB;
-    const T* kbase = qkv + (size_t)b * p.S * ld + p.H + h * D;
-    const T* vbase = vt + (size_t)bh * D * p.Spad;
-
-    for (int j = 0; j < ntiles; ++j) {
-        const int kv0 = j * KVB;
-        unsigned long long bits = p.kbits[(size_t)b * p.nw64 + (kv0 >> 6)];
-        if (KVB == 32) bits = (bits >> (kv0 & 32)) & 0xffffffffull;
-        if (bits == 0ull) continue;  // whole tile padded (block-uniform)
-
-        __syncthreads();  // everyone is done reading the previous tile
-        for (int q = tid; q < KVB * KNS; q += NT) {
-            const int row = q / KNS, slot = q % KNS;
-            int key = kv0 + row;
-            if (key >= p.S) key = p.S - 1;  // masked below; keep the load in bounds
-            *(uint4*)(sK + swz_row<KRB>(row, slot)) = *(const uint4*)(kbase + (size_t)key * ld + slot * E16);
-        }
-        for (int q = tid; q < D * 8; q += NT) {
-            const int row = q >> 3, slot = q & 7;
-            *(uint4*)(sV + swz_row<VRB>(row, slot)) = *(const uint4*)(vbase + (size_t)row * p.Spad + kv0 + slot * E16);
-        }
-        __syncthreads();
+    while (j < ntiles) {
+        const unsigned long long bits = tile_bits(j);
+        const int jn = next_tile(j + 1);
+        __syncthreads();   // K_j landed (the compiler drains this wave's DMA before the barrier);
+                           // every wave is done with P.V of the previous tile -> sV is free
+        issue_v(j);        // V^T_j streams in underneath Q.K^T
 
         // ---- S^T = K Q^T ----
         f32x16_t sacc[NKB];
@@ -112,38 +158,47 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(AttnArgs p) {
                 Mma32<T>::step(kf, qf[c], sacc[kb]);
             }
         }
-        // ---- mask + online softmax (base-2) ----
-        float mx = -INFINITY;
+        // ---- key-padding mask (only tiles that contain a padded key pay for it) ----
+        const unsigned long long full = KVB == 64 ? ~0ull : 0xffffffffull;
+        if (bits != full) {
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ko = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (!((bits >> ko) & 1ull)) sacc[kb][r] = -INFINITY;
+                }
+        }
+        // ---- online softmax, base 2, scale folded into the exponent's FMA ----
+        float mx = sacc[0][0];
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ko = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const bool valid = (bits >> ko) & 1ull;
-                const float s = valid ? sacc[kb][r] : -INFINITY;
-                sacc[kb][r] = s;
-                mx = fmaxf(mx, s);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-        const float alpha = exp2f(m_run - m_use);  // m_run = -inf -> 0
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sc;
+        if (__any(mx > m_run + THR)) {  // some row's max grew past the threshold: rescale (wave-uniform)
+            const float m_new = fmaxf(m_run, mx);
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);  // m_run = -inf -> 0
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < ND; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+            m_run = m_new;
+        }
+        const float m_neg = (m_run == -INFINITY) ? 0.f : -m_run;
         float rs = 0.f;
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = exp2f(sacc[kb][r] - m_use);
+                const float e = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], sc, m_neg));
                 sacc[kb][r] = e;
                 rs += e;
             }
         rs += __shfl_xor(rs, 32, 64);
-        l_run = l_run * alpha + rs;
-        m_run = m_new;
-#pragma unroll
-        for (int i = 0; i < ND; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+        l_run += rs;
 
         // ---- P fragments (column operand), straight from the lane's own registers ----
         uint4 pf[4];
@@ -157,6 +212,8 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(AttnArgs p) {
             }
             pf[ch] = Vec16<T>::pack(f);
         }
+        __syncthreads();   // V^T_j landed; every wave is done reading sK
+        if (jn < ntiles) issue_k(jn);  // next K streams in underneath P.V
         // ---- O^T += V^T P^T ----
 #pragma unroll
         for (int nd = 0; nd < ND; ++nd)
@@ -165,6 +222,7 @@ __global__ __launch_bounds__(NW * 64) void attention_kernel(AttnArgs p) {
                 const uint4 vf = *(const uint4*)(sV + swz_row<VRB>(nd * 32 + li, ch * 2 + hi));
                 Mma32<T>::step(vf, pf[ch], oacc[nd]);
             }
+        j = jn;
     }
 
     // ---- normalise and store: lane owns query li, dv = nd*32 + (r&3) + 8*(r>>2) + 4*hi ----
@@ -226,13 +284,14 @@ static int launch_tv(const AttnArgs& a, hipStream_t stream) {
 
 template <typename T, int D>
 static int launch_td(const AttnArgs& a, hipStream_t stream) {
-    const int BH = a.B * a.heads;
-    // small sequences: 2-wave workgroups so the grid still covers the 256 CUs
+    const int BH = a.B * a.heads, BH8 = (BH + 7) / 8 * 8;
+    // grid = ceil(BH/8)*8 * nq, decoded XCD-aware in the kernel.  Small sequences: 2-wave
+    // workgroups so the grid still covers the 256 CUs.
     const long blocks4 = (long)((a.S + 127) / 128) * BH;
     if (blocks4 >= 512) {
-        hipLaunchKernelGGL((attention_kernel<T, D, 4>), dim3((a.S + 127) / 128, BH), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((attention_kernel<T, D, 4>), dim3(((a.S + 127) / 128) * BH8), dim3(256), 0, stream, a);
     } else {
-        hipLaunchKernelGGL((attention_kernel<T, D, 2>), dim3((a.S + 63) / 64, BH), dim3(128), 0, stream, a);
+        hipLaunchKernelGGL((attention_kernel<T, D, 2>), dim3(((a.S + 63) / 64) * BH8), dim3(128), 0, stream, a);
     }
     return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
 }

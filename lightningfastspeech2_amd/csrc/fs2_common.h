@@ -39,7 +39,16 @@ template <> struct Num<float> {
 };
 template <> struct Num<bf16> {
     __host__ __device__ static inline float to_f32(bf16 x) { return bf16_to_f32(x); }
-    __host__ __device__ static inline bf16 from_f32(float x) { return f32_to_bf16(x); }
+    __host__ __device__ static inline bf16 from_f32(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        bf16 r;
+        const __bf16 h = (__bf16)x;  // v_cvt_pk_bf16_f32
+        r.v = *(const unsigned short*)&h;
+        return r;
+#else
+        return f32_to_bf16(x);
+#endif
+    }
     static constexpr int kPer16B = 8;
 };
 
@@ -55,8 +64,12 @@ template <> struct Vec16<float> {
         return make_uint4(__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3]));
     }
 };
-__device__ inline uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo).v | ((uint32_t)f32_to_bf16(hi).v << 16);
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+__device__ inline uint32_t pack_bf16x2(float lo, float hi) {  // v_cvt_pk_bf16_f32 (RNE)
+    const f32x2_t f = {lo, hi};
+    const bf16x2_t v = __builtin_convertvector(f, bf16x2_t);
+    return *(const uint32_t*)&v;
 }
 template <> struct Vec16<bf16> {
     static constexpr int N = 8;
