@@ -37,6 +37,11 @@ int fs2_op_convert(int32_t sdt, int32_t ddt, const void* src, void* dst, size_t 
     return launch_convert(a, sdt, ddt, (hipStream_t)stream);
 }
 
+int fs2_op_set_gemm_variant(int32_t variant) {
+    fs2::g_gemm_variant = variant;
+    return FS2_OK;
+}
+
 int fs2_op_gemm(int32_t dtype, int32_t out_dtype, const void* x, const void* w, const float* bias, void* c,
                 int32_t M, int32_t N, int32_t Cin, int32_t taps, int32_t S, int32_t relu, void* stream) {
     GemmArgs a;

@@ -19,6 +19,7 @@ struct GemmArgs {
     int relu;
 };
 int launch_gemm(const GemmArgs& a, int in_dtype, int out_dtype, hipStream_t stream);
+extern int g_gemm_variant;  // test/bench knob: 0 auto, 1 force the 128x128 kernel, 2 force the DMA kernel
 
 struct AttnArgs {
     const void* qkv;        // (B*S, 3H): [q | k | v] columns, head h at h*d

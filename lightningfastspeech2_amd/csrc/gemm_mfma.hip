@@ -157,6 +157,181 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmArgs p) {
     }
 }
 
+// =================================================================================================
+// Large-problem variant: 128 (x rows) x 256 (W rows) per 512-thread workgroup (8 waves as 2 x 4,
+// each again a 64x64 patch), operands streamed global -> LDS by DMA (global_load_lds, 16 B per lane,
+// no staging registers, XOR swizzle applied on the source address) through a 3-stage ring:
+// chunk kc+2 is in flight while chunk kc is multiplied, with a counted vmcnt (never 0 in the steady
+// state) and one raw s_barrier per chunk (cdna_hip_programming.md §5 "Pipelining across barriers").
+// Rows that must read as zero (conv halo outside the utterance, M/N tails) are DMA'd from a zero
+// page.  All LDS lives in ONE extern array (a second __shared__ object would make hipcc drain
+// vmcnt before every ds_read).
+// =================================================================================================
+static constexpr int G2_BM = 128, G2_BN = 256, G2_STAGES = 3;
+static constexpr int G2_XB = G2_BM * ROWB;        // 16 KiB
+static constexpr int G2_WB = G2_BN * ROWB;        // 32 KiB
+static constexpr int G2_STAGE = G2_XB + G2_WB;    // 48 KiB
+__device__ __attribute__((aligned(256))) unsigned char g_zero_page[256];
+
+__device__ inline void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <typename T, typename OutT>
+__global__ __launch_bounds__(512) void gemm_conv_glds_kernel(GemmArgs p) {
+    // one array PER STAGE: hipcc tracks pending LDS-DMA writes per LDS object, so ds_reads of the
+    // stage being multiplied do not wait for the DMAs still filling the other two
+    __shared__ __attribute__((aligned(16))) unsigned char st0[G2_STAGE];  // [X 16K | W 32K]
+    __shared__ __attribute__((aligned(16))) unsigned char st1[G2_STAGE];
+    __shared__ __attribute__((aligned(16))) unsigned char st2[G2_STAGE];
+    constexpr int E16 = Num<T>::kPer16B;
+    constexpr int KE = ROWB / (int)sizeof(T);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_n = (p.N + G2_BN - 1) / G2_BN;
+    const int bm = blockIdx.x / tiles_n, bn = blockIdx.x % tiles_n;
+    const int m0 = bm * G2_BM, n0 = bn * G2_BN;
+    const T* __restrict__ X = (const T*)p.X;
+    const T* __restrict__ W = (const T*)p.W;
+
+    // DMA assignment: a wave instruction moves 64 x 16 B = 8 LDS rows.  X: 2 per wave, W: 4.
+    // Exactly 6 DMA instructions per chunk per wave, unconditionally (the counted vmcnt below
+    // relies on it): lanes whose row must read as zero point at the zero page instead of branching.
+    int xt[2];            // row position inside its utterance (0 for plain GEMMs: always in range)
+    uintptr_t xmask[2];   // all ones if row < M
+    uintptr_t xaddr[2];   // byte address of (row, logical slot) at tap shift 0, channel 0
+    uintptr_t waddr[4];   // byte address of (n, logical slot) at k = 0, or the zero page
+    uintptr_t wstep[4];   // K advance in bytes (0 for zero-page lanes)
+    const uintptr_t zaddr = (uintptr_t)g_zero_page;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int P = (i * 8 + wave) * 64 + lane, row = P >> 3, ps = P & 7;
+        const int m = m0 + row;
+        xmask[i] = (uintptr_t)0 - (uintptr_t)(m < p.M);
+        xt[i] = (p.taps > 1) ? (m % p.S) : 0;
+        xaddr[i] = (uintptr_t)(X + (size_t)m * p.ldx + (ps ^ (row & 7)) * E16);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int P = (i * 8 + wave) * 64 + lane, row = P >> 3, ps = P & 7;
+        const int n = n0 + row;
+        const uintptr_t in = (uintptr_t)0 - (uintptr_t)(n < p.N);
+        waddr[i] = ((uintptr_t)(W + (size_t)n * p.K + (ps ^ (row & 7)) * E16) & in) | (zaddr & ~in);
+        wstep[i] = (uintptr_t)(KE * sizeof(T)) & in;
+    }
+    const int nk = p.K / KE;
+    const int Seff = p.taps > 1 ? p.S : 1;
+    int is_tap = 0, is_c0 = 0;  // (tap, channel offset) of the next chunk to be issued, in issue order
+    const ptrdiff_t row_bytes = (ptrdiff_t)p.ldx * (ptrdiff_t)sizeof(T);
+
+    auto issue = [&](unsigned char* sx) {  // chunks are issued strictly in order 0, 1, 2, ...
+        const int shift = is_tap - p.pad;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int t = xt[i] + shift;
+            const uintptr_t ok = xmask[i] & ((uintptr_t)0 - (uintptr_t)((t >= 0) & (t < Seff)));
+            const uintptr_t a = xaddr[i] + (uintptr_t)(shift * row_bytes + is_c0 * (ptrdiff_t)sizeof(T));
+            glds16((const void*)((a & ok) | (zaddr & ~ok)), sx + (i * 8 + wave) * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            glds16((const void*)waddr[i], sx + G2_XB + (i * 8 + wave) * 1024);
+            waddr[i] += wstep[i];
+        }
+        is_c0 += KE;
+        if (is_c0 == p.Cin) { is_c0 = 0; ++is_tap; }
+    };
+
+    f32x4_t acc[4][4];  // [ni][mi]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int wm = wave >> 2, wn = wave & 3;
+    const int fr = lane & 15, fg = lane >> 4;
+
+    auto compute = [&](const unsigned char* bx) {
+        const unsigned char* bw = bx + G2_XB;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 fw[4], fx[4];
+            const int slot = ks * 4 + fg;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                fw[i] = *(const uint4*)(bw + swz(wn * 64 + i * 16 + fr, slot));
+                fx[i] = *(const uint4*)(bx + swz(wm * 64 + i * 16 + fr, slot));
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) Mma16<T>::step(fw[ni], fx[mi], acc[ni][mi]);
+        }
+    };
+    // one pipeline step: chunk kc (in `cur`) has landed once at most the 6 DMAs of chunk kc+1 are
+    // still outstanding; the barrier also frees the stage chunk kc-1 was multiplied from, which is
+    // where chunk kc+2 goes
+#define FS2_G2_STEP(cur, nxt2, kcv)                                                   \
+    {                                                                                 \
+        if ((kcv) + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");           \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          \
+        __builtin_amdgcn_s_barrier();                                                 \
+        if ((kcv) + 2 < nk) issue(nxt2);                                               \
+        compute(cur);                                                                 \
+    }
+    issue(st0);
+    if (nk > 1) issue(st1);
+    for (int kc = 0; kc < nk; kc += 3) {
+        FS2_G2_STEP(st0, st2, kc)
+        if (kc + 1 < nk) FS2_G2_STEP(st1, st0, kc + 1)
+        if (kc + 2 < nk) FS2_G2_STEP(st2, st1, kc + 2)
+    }
+#undef FS2_G2_STEP
+
+    OutT* __restrict__ C = (OutT*)p.C;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int n = n0 + wn * 64 + ni * 16 + fg * 4;
+        if (n >= p.N) continue;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (n + r < p.N) bv[r] = p.bias[n + r];
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int m = m0 + wm * 64 + mi * 16 + fr;
+            if (m >= p.M) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc[ni][mi][r] + bv[r];
+                if (p.relu) v[r] = fmaxf(v[r], 0.f);
+            }
+            OutT* dst = C + (size_t)m * p.ldc + n;
+            if (n + 3 < p.N) {
+                if constexpr (sizeof(OutT) == 4) {
+                    *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    *(uint2*)dst = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (n + r < p.N) dst[r] = Num<OutT>::from_f32(v[r]);
+            }
+        }
+    }
+}
+
+template <typename T, typename OutT>
+static int launch_glds_t(const GemmArgs& a, hipStream_t stream) {
+    const int tiles = ((a.M + G2_BM - 1) / G2_BM) * ((a.N + G2_BN - 1) / G2_BN);
+    hipLaunchKernelGGL((gemm_conv_glds_kernel<T, OutT>), dim3(tiles), dim3(512), 0, stream, a);
+    return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
+}
+
 template <typename T, typename OutT>
 static int launch_t(const GemmArgs& a, hipStream_t stream) {
     static bool attr_set = false;
@@ -172,12 +347,23 @@ static int launch_t(const GemmArgs& a, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
 }
 
+int g_gemm_variant = 0;
+
 int launch_gemm(const GemmArgs& a, int in_dtype, int out_dtype, hipStream_t stream) {
     if (a.M <= 0 || a.N <= 0) return FS2_OK;
     const int ke = in_dtype == FS2_BF16 ? 64 : 32;
     const int e16 = in_dtype == FS2_BF16 ? 8 : 4;
     if (a.K % ke || a.Cin % ke || a.ldx % e16 || a.K != a.taps * a.Cin) return FS2_ERR_SHAPE;
     if (a.ldc % 4) return FS2_ERR_SHAPE;
+    // big problems: the DMA-pipelined 128x256 kernel (needs enough tiles to cover the 256 CUs)
+    const long big_tiles = (long)((a.M + G2_BM - 1) / G2_BM) * ((a.N + G2_BN - 1) / G2_BN);
+    const int variant = g_gemm_variant;  // 0 = auto, 1 = force 128x128 register-staged, 2 = force DMA
+    if (variant == 2 || (variant == 0 && a.N >= 192 && big_tiles >= 192)) {
+        if (in_dtype == FS2_F32 && out_dtype == FS2_F32) return launch_glds_t<float, float>(a, stream);
+        if (in_dtype == FS2_BF16 && out_dtype == FS2_BF16) return launch_glds_t<bf16, bf16>(a, stream);
+        if (in_dtype == FS2_BF16 && out_dtype == FS2_F32) return launch_glds_t<bf16, float>(a, stream);
+        return FS2_ERR_SHAPE;
+    }
     if (in_dtype == FS2_F32 && out_dtype == FS2_F32) return launch_t<float, float>(a, stream);
     if (in_dtype == FS2_BF16 && out_dtype == FS2_BF16) return launch_t<bf16, bf16>(a, stream);
     if (in_dtype == FS2_BF16 && out_dtype == FS2_F32) return launch_t<bf16, float>(a, stream);

@@ -27,11 +27,19 @@ def rnd(*shape, seed=0, scale=1.0):
     return torch.randn(*shape, generator=g) * scale
 
 
+@pytest.fixture(params=[1, 2], ids=["gemm128x128", "gemm128x256dma"])
+def gemm_variant(request):
+    """Run every GEMM/conv case on BOTH kernels (the engine picks by problem size)."""
+    G.lib().fs2_op_set_gemm_variant(request.param)
+    yield request.param
+    G.lib().fs2_op_set_gemm_variant(0)
+
+
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K,relu", [(200, 80, 64, False), (128, 128, 128, True), (300, 260, 256, False),
                                          (1000, 768, 256, True), (37, 4, 64, False), (513, 1024, 1024, False)])
-def test_gemm_plain(dtype, M, N, K, relu):
+def test_gemm_plain(dtype, M, N, K, relu, gemm_variant):
     x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
     # asymmetric, transpose-detecting reference
     ref = G.rounded(x, dtype) @ G.rounded(w, dtype).T + b
@@ -42,14 +50,14 @@ def test_gemm_plain(dtype, M, N, K, relu):
     assert err <= tol(dtype, ref), (err, tol(dtype, ref))
 
 
-def test_gemm_bf16_in_fp32_out():
+def test_gemm_bf16_in_fp32_out(gemm_variant):
     x, w, b = rnd(150, 256, seed=4), rnd(80, 256, seed=5, scale=1 / 16), rnd(80, seed=6)
     ref = G.rounded(x, G.BF16) @ G.rounded(w, G.BF16).T + b
     got = G.gemm(G.BF16, x, w, b, out_dtype=G.F32)
     assert float((got - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
 
 
-def test_gemm_identity_layout():
+def test_gemm_identity_layout(gemm_variant):
     # A = I picks W^T exactly: catches swapped row/col maps that symmetric data would hide
     K = 64
     x = torch.eye(K)
@@ -61,13 +69,35 @@ def test_gemm_identity_layout():
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,S,Cin,N,k", [(3, 37, 64, 128, 3), (2, 130, 64, 64, 9), (4, 11, 128, 256, 5),
                                           (2, 300, 256, 1024, 9), (1, 5, 64, 64, 25)])
-def test_gemm_conv_same_padding_per_utterance(dtype, B, S, Cin, N, k):
+def test_gemm_conv_same_padding_per_utterance(dtype, B, S, Cin, N, k, gemm_variant):
     x = rnd(B, S, Cin, seed=7)
     w = rnd(N, Cin, k, seed=8, scale=(Cin * k) ** -0.5)
     b = rnd(N, seed=9)
     ref = F.conv1d(G.rounded(x, dtype).transpose(1, 2), G.rounded(w, dtype), b, padding="same").transpose(1, 2)
     got = G.gemm(dtype, x.reshape(B * S, Cin), G.pack_conv_weight(w), b, taps=k, S=S).reshape(B, S, N)
     err = float((got - ref).abs().max())
+    assert err <= tol(dtype, ref), (err, tol(dtype, ref))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_dma_pipeline_large_and_repeatable(dtype):
+    """Full-size decoder conv tile stream (K = 9*256 -> 36 chunks through the 3-stage DMA ring),
+    many workgroups per CU in flight: compare with torch and demand bit-identical reruns (a DMA /
+    barrier race shows up as run-to-run differences)."""
+    B, S, Cin, N, k = 4, 1536, 256, 1024, 9
+    x = rnd(B, S, Cin, seed=40)
+    w = rnd(N, Cin, k, seed=41, scale=(Cin * k) ** -0.5)
+    b = rnd(N, seed=42)
+    ref = F.conv1d(G.rounded(x, dtype).transpose(1, 2), G.rounded(w, dtype), b, padding="same").transpose(1, 2)
+    ref = torch.relu(ref)
+    G.lib().fs2_op_set_gemm_variant(2)
+    try:
+        runs = [G.gemm(dtype, x.reshape(B * S, Cin), G.pack_conv_weight(w), b, taps=k, S=S, relu=True) for _ in range(4)]
+    finally:
+        G.lib().fs2_op_set_gemm_variant(0)
+    for r in runs[1:]:
+        assert torch.equal(r, runs[0])
+    err = float((runs[0].reshape(B, S, N) - ref).abs().max())
     assert err <= tol(dtype, ref), (err, tol(dtype, ref))
 
 

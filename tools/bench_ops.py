@@ -1,0 +1,89 @@
+#!/usr/bin/env python
+"""Micro-benchmarks of single operators through the C ABI (device-resident, HIP-event timed).
+    python tools/bench_ops.py [gemm|attn|all] [--variant V] [--reps R]
+Shapes are the C2 (FS2-27M, B=32, L=256, T=1536) launches of the forward."""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from lightningfastspeech2_amd import _lib  # noqa: E402
+
+lib = _lib.load()
+DEV = "cuda:0"
+BF16 = _lib.FS2_BF16
+
+
+def p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def timeit(fn, reps):
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for _ in range(3):
+        fn(st)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn(st)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e-3
+
+
+def gemm_case(name, M, N, Cin, taps, S, reps, variant):
+    lib.fs2_op_set_gemm_variant(variant)
+    x = torch.randn(M, Cin, device=DEV).to(torch.bfloat16)
+    w = (torch.randn(N, taps * Cin, device=DEV) * (taps * Cin) ** -0.5).to(torch.bfloat16)
+    b = torch.randn(N, device=DEV)
+    c = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    t = timeit(lambda st: lib.fs2_op_gemm(BF16, BF16, p(x), p(w), p(b), p(c), M, N, Cin, taps, S, 1, st), reps)
+    fl = 2.0 * M * N * Cin * taps
+    print(f"{name:28s} M={M:6d} N={N:5d} K={taps*Cin:5d} variant={variant}  {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TF  ({fl/t/2.5e15*100:4.1f}% of 2.5 PF)")
+    lib.fs2_op_set_gemm_variant(0)
+
+
+def attn_case(name, B, S, H, heads, reps):
+    qkv = torch.randn(B * S, 3 * H, device=DEV).to(torch.bfloat16)
+    mask = torch.zeros(B, S, dtype=torch.uint8, device=DEV)
+    out = torch.empty(B * S, H, dtype=torch.bfloat16, device=DEV)
+    bb = C.c_size_t()
+    vb = lib.fs2_op_attention_scratch_bytes(BF16, B, S, H, heads, C.byref(bb))
+    vt = torch.empty(vb, dtype=torch.uint8, device=DEV)
+    bits = torch.empty(bb.value, dtype=torch.uint8, device=DEV)
+    t = timeit(lambda st: lib.fs2_op_attention(BF16, p(qkv), p(mask), p(out), p(vt), p(bits), B, S, H, heads, st), reps)
+    fl = 4.0 * B * S * S * H
+    print(f"{name:28s} B={B} S={S} H={H} heads={heads}  {t*1e6:8.1f} us (incl. mask bits + V^T staging)  {fl/t/1e12:7.1f} TF")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", nargs="?", default="all")
+    ap.add_argument("--variant", type=int, default=-1)
+    ap.add_argument("--reps", type=int, default=20)
+    a = ap.parse_args()
+    variants = [1, 2] if a.variant < 0 else [a.variant]
+    if a.what in ("gemm", "all"):
+        for v in variants:
+            gemm_case("dec conv1 k=9", 49152, 1024, 256, 9, 1536, a.reps, v)
+            gemm_case("same as plain GEMM", 49152, 1024, 2304, 1, 49152, a.reps, v)
+            gemm_case("var-pred conv k=3", 49152, 256, 256, 3, 1536, a.reps, v)
+            gemm_case("dec conv2 1x1", 49152, 256, 1024, 1, 49152, a.reps, v)
+            gemm_case("dec in_proj", 49152, 768, 256, 1, 49152, a.reps, v)
+            gemm_case("dec out_proj", 49152, 256, 256, 1, 49152, a.reps, v)
+            gemm_case("enc conv1 k=9", 8192, 1024, 256, 9, 256, a.reps, v)
+            gemm_case("enc conv2 1x1", 8192, 256, 1024, 1, 8192, a.reps, v)
+            gemm_case("square 4096^3", 4096, 4096, 4096, 1, 4096, a.reps, v)
+    if a.what in ("attn", "all"):
+        attn_case("decoder attention", 32, 1536, 256, 2, a.reps)
+        attn_case("encoder attention", 32, 256, 256, 2, a.reps)
+
+
+if __name__ == "__main__":
+    main()
