@@ -332,6 +332,201 @@ static int launch_glds_t(const GemmArgs& a, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
 }
 
+// =================================================================================================
+// Slab kernel: (MI*32) rows of ONE utterance x 256 output channels per 512-thread workgroup
+// (8 waves as 2 x 4, wave patch (MI*16) x 64).  For a k-tap conv the x operand of all taps is the
+// same (rows + k - 1) x 64-channel slab: it is DMA'd into LDS ONCE per channel block and the taps
+// walk it with a row offset, so per output tile the activation traffic through L2 -> LDS drops
+// k-fold; only the (256 x 64) weight tile changes every step.  Loop order: channel block (outer),
+// tap (inner) - a pure re-association of the K sum.  Zero "same" padding = slab rows outside
+// [0, S) of the utterance read the zero page.  Two slab buffers + two weight buffers, each its own
+// LDS object; every step: __syncthreads (hipcc drains this wave's DMAs in front of it), issue the
+// next step's DMAs, multiply the current one.
+// =================================================================================================
+template <int MI> struct SlabCfg {
+    static constexpr int BM = MI * 32;
+    static constexpr int SLAB_GROUPS = (BM + 30 + 7) / 8;          // 8-row (1 KiB) DMA groups, k <= 31
+    static constexpr int SI = (SLAB_GROUPS + 7) / 8;                // slab DMA instructions per wave
+    static constexpr int SLAB_BYTES = SI * 8 * 1024;
+};
+static constexpr int S_BN = 256, S_WB = S_BN * ROWB;  // 32 KiB weight tile
+
+template <typename T, typename OutT, int MI>
+__global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the buffer-resource builtins only exist in the device pass
+    using Cfg = SlabCfg<MI>;
+    constexpr int BMs = Cfg::BM, SI = Cfg::SI;
+    __shared__ __attribute__((aligned(16))) unsigned char slab0[Cfg::SLAB_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char slab1[Cfg::SLAB_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char wt0[S_WB];
+    __shared__ __attribute__((aligned(16))) unsigned char wt1[S_WB];
+    constexpr int KE = ROWB / (int)sizeof(T);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int S = p.S, nutt = p.M / S;
+    const int tiles_n = (p.N + S_BN - 1) / S_BN;
+    const int tiles_m = (S + BMs - 1) / BMs;
+    int bid = blockIdx.x;
+    const int bn = bid % tiles_n; bid /= tiles_n;
+    const int tm = bid % tiles_m, ub = bid / tiles_m;
+    if (ub >= nutt) return;
+    const int t0 = tm * BMs, n0 = bn * S_BN;
+    const T* __restrict__ Xu = (const T*)p.X + (size_t)ub * S * p.ldx;  // this utterance's rows
+    const int ntap = p.taps, ncc = p.Cin / KE;
+    // Operands are fetched with buffer loads straight into LDS: a descriptor per operand in SGPRs,
+    // one 32-bit byte offset per lane per DMA, the channel/tap advance in the scalar offset.  Lanes
+    // whose row must read as zero (outside the utterance, M/N tails) carry an out-of-range offset:
+    // the hardware bounds check returns zeros for them.
+    constexpr unsigned OOB = 0xFFFFF000u;
+    const unsigned xbytes = (unsigned)(((size_t)(S - 1) * p.ldx + p.Cin) * sizeof(T));
+    const unsigned wbytes = (unsigned)((size_t)p.N * p.K * sizeof(T));
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)Xu, 0, xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, wbytes, 0x00020000);
+    unsigned svoff[SI];
+#pragma unroll
+    for (int i = 0; i < SI; ++i) {
+        const int P = (i * 8 + wave) * 64 + lane, row = P >> 3, ps = P & 7;
+        const int t = t0 - p.pad + row;
+        const bool ok = (t >= 0) & (t < S) & (row < BMs + ntap - 1);
+        svoff[i] = ok ? (unsigned)((size_t)t * p.ldx * sizeof(T)) + (unsigned)((ps ^ (row & 7)) << 4) : OOB;
+    }
+    unsigned wvoff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int P = (i * 8 + wave) * 64 + lane, row = P >> 3, ps = P & 7;
+        const int n = n0 + row;
+        wvoff[i] = n < p.N ? (unsigned)((size_t)n * p.K * sizeof(T)) + (unsigned)((ps ^ (row & 7)) << 4) : OOB;
+    }
+    auto issue_slab = [&](unsigned char* dst, int cc) {
+#pragma unroll
+        for (int i = 0; i < SI; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(dst + (i * 8 + wave) * 1024),
+                                                     16, svoff[i], cc * ROWB, 0, 0);
+    };
+    auto issue_w = [&](unsigned char* dst, int cc, int tap) {
+        const int koff = (tap * p.Cin + cc * KE) * (int)sizeof(T);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)(dst + (i * 8 + wave) * 1024),
+                                                     16, wvoff[i], koff, 0, 0);
+    };
+
+    f32x4_t acc[4][MI];  // [ni][mi]
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < MI; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    const int wm = wave >> 2, wn = wave & 3;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int xrow0 = wm * (MI * 16) + fr;  // slab row of fragment 0 at tap 0
+    int woff[4][2];                          // weight fragment byte offsets (tap independent)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) woff[i][ks] = swz(wn * 64 + i * 16 + fr, ks * 4 + fg);
+
+    auto compute = [&](const unsigned char* sl, const unsigned char* wt, int tap) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 fw[4], fx[MI];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fw[i] = *(const uint4*)(wt + woff[i][ks]);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) fx[i] = *(const uint4*)(sl + swz(xrow0 + i * 16 + tap, ks * 4 + fg));
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) Mma16<T>::step(fw[ni], fx[mi], acc[ni][mi]);
+        }
+    };
+
+    // Step (cc, tap) uses slab[cc & 1] and wt[(cc*ntap + tap) & 1]; ntap is odd (the launcher checks),
+    // so the weight parity is (cc + tap) & 1.  The steps are laid out as straight-line code with
+    // STATIC buffer names (no pointer selects: hipcc then knows which LDS object each ds_read
+    // touches and does not wait for the DMAs it has just issued into the other buffers).
+#define FS2_SLAB_STEP(slab_cur, slab_nxt, w_cur, w_nxt, ccv, tapv)                          \
+    {                                                                                       \
+        __syncthreads(); /* operands of this step landed; the other buffers are free */     \
+        int ntp = (tapv) + 1, ncb = (ccv);                                                  \
+        if (ntp == ntap) { ntp = 0; ++ncb; }                                                \
+        if (ncb < ncc) issue_w(w_nxt, ncb, ntp);                                            \
+        if ((tapv) == 0 && (ccv) + 1 < ncc) issue_slab(slab_nxt, (ccv) + 1);                \
+        compute(slab_cur, w_cur, (tapv));                                                   \
+    }
+    issue_slab(slab0, 0);
+    issue_w(wt0, 0, 0);
+    for (int cc = 0; cc < ncc; cc += 2) {
+        for (int tap = 0; tap < ntap; tap += 2) {
+            FS2_SLAB_STEP(slab0, slab1, wt0, wt1, cc, tap)
+            if (tap + 1 < ntap) FS2_SLAB_STEP(slab0, slab1, wt1, wt0, cc, tap + 1)
+        }
+        if (cc + 1 < ncc) {
+            for (int tap = 0; tap < ntap; tap += 2) {
+                FS2_SLAB_STEP(slab1, slab0, wt1, wt0, cc + 1, tap)
+                if (tap + 1 < ntap) FS2_SLAB_STEP(slab1, slab0, wt0, wt1, cc + 1, tap + 1)
+            }
+        }
+    }
+#undef FS2_SLAB_STEP
+
+    OutT* __restrict__ C = (OutT*)p.C + (size_t)ub * S * p.ldc;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int n = n0 + wn * 64 + ni * 16 + fg * 4;
+        if (n >= p.N) continue;
+        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (n + r < p.N) bv[r] = p.bias[n + r];
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int t = t0 + wm * (MI * 16) + mi * 16 + fr;
+            if (t >= S) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r] = acc[ni][mi][r] + bv[r];
+                if (p.relu) v[r] = fmaxf(v[r], 0.f);
+            }
+            OutT* dst = C + (size_t)t * p.ldc + n;
+            if (n + 3 < p.N) {
+                if constexpr (sizeof(OutT) == 4) {
+                    *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    *(uint2*)dst = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (n + r < p.N) dst[r] = Num<OutT>::from_f32(v[r]);
+            }
+        }
+    }
+#else
+    (void)p;
+#endif
+}
+
+template <typename T, typename OutT, int MI>
+static int launch_slab_t(const GemmArgs& a0, hipStream_t stream) {
+    GemmArgs a = a0;
+    if (a.taps == 1) a.S = a.M;  // plain GEMM: one "utterance" of M rows
+    const int BMs = SlabCfg<MI>::BM;
+    const int tiles = (a.M / a.S) * ((a.S + BMs - 1) / BMs) * ((a.N + S_BN - 1) / S_BN);
+    hipLaunchKernelGGL((gemm_conv_slab_kernel<T, OutT, MI>), dim3(tiles), dim3(512), 0, stream, a);
+    return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
+}
+
+template <int MI>
+static int launch_slab(const GemmArgs& a, int in_dtype, int out_dtype, hipStream_t stream) {
+    if (in_dtype == FS2_F32 && out_dtype == FS2_F32) return launch_slab_t<float, float, MI>(a, stream);
+    if (in_dtype == FS2_BF16 && out_dtype == FS2_BF16) return launch_slab_t<bf16, bf16, MI>(a, stream);
+    if (in_dtype == FS2_BF16 && out_dtype == FS2_F32) return launch_slab_t<bf16, float, MI>(a, stream);
+    return FS2_ERR_SHAPE;
+}
+
 template <typename T, typename OutT>
 static int launch_t(const GemmArgs& a, hipStream_t stream) {
     static bool attr_set = false;
@@ -355,14 +550,38 @@ int launch_gemm(const GemmArgs& a, int in_dtype, int out_dtype, hipStream_t stre
     const int e16 = in_dtype == FS2_BF16 ? 8 : 4;
     if (a.K % ke || a.Cin % ke || a.ldx % e16 || a.K != a.taps * a.Cin) return FS2_ERR_SHAPE;
     if (a.ldc % 4) return FS2_ERR_SHAPE;
-    // big problems: the DMA-pipelined 128x256 kernel (needs enough tiles to cover the 256 CUs)
-    const long big_tiles = (long)((a.M + G2_BM - 1) / G2_BM) * ((a.N + G2_BN - 1) / G2_BN);
-    const int variant = g_gemm_variant;  // 0 = auto, 1 = force 128x128 register-staged, 2 = force DMA
-    if (variant == 2 || (variant == 0 && a.N >= 192 && big_tiles >= 192)) {
+    const int variant = g_gemm_variant;  // 0 = auto, 1 = 128x128 register-staged, 2 = 128x256 DMA ring,
+                                         // 3/4/5 = slab kernel with 128/192/256-row tiles
+    const bool slab_ok = a.M % a.S == 0 && (a.taps & 1);
+    if (variant >= 3 && variant <= 5 && slab_ok) {
+        if (variant == 3) return launch_slab<4>(a, in_dtype, out_dtype, stream);
+        if (variant == 4) return launch_slab<6>(a, in_dtype, out_dtype, stream);
+        return launch_slab<8>(a, in_dtype, out_dtype, stream);
+    }
+    if (variant == 2) {
         if (in_dtype == FS2_F32 && out_dtype == FS2_F32) return launch_glds_t<float, float>(a, stream);
         if (in_dtype == FS2_BF16 && out_dtype == FS2_BF16) return launch_glds_t<bf16, bf16>(a, stream);
         if (in_dtype == FS2_BF16 && out_dtype == FS2_F32) return launch_glds_t<bf16, float>(a, stream);
         return FS2_ERR_SHAPE;
+    }
+    if (variant == 0 && slab_ok && a.N >= 192) {
+        // One 512-thread workgroup per CU: pick the row-tile height that minimises
+        // (rounds over the 256 CUs) x (tile rows + ~40 rows' worth of prologue/epilogue), measured
+        // on MI355X (tools/bench_ops.py); fall back to the flat 128x128 kernel when utterances are
+        // so short that per-utterance tiles would be mostly padding.
+        const int S = a.taps == 1 ? a.M : a.S, nutt = a.M / S, tn = (a.N + S_BN - 1) / S_BN;
+        int best = 0;
+        long best_cost = 0, best_rows = 0;
+        for (int mi = 4; mi <= 8; mi += 2) {
+            const long bm = mi * 32, tm = (S + bm - 1) / bm, tiles = (long)nutt * tm * tn;
+            const long cost = ((tiles + 255) / 256) * (bm + 40);
+            if (!best || cost < best_cost) { best = mi; best_cost = cost; best_rows = (long)nutt * tm * bm; }
+        }
+        if (best_rows <= 2L * a.M) {
+            if (best == 4) return launch_slab<4>(a, in_dtype, out_dtype, stream);
+            if (best == 6) return launch_slab<6>(a, in_dtype, out_dtype, stream);
+            return launch_slab<8>(a, in_dtype, out_dtype, stream);
+        }
     }
     if (in_dtype == FS2_F32 && out_dtype == FS2_F32) return launch_t<float, float>(a, stream);
     if (in_dtype == FS2_BF16 && out_dtype == FS2_BF16) return launch_t<bf16, bf16>(a, stream);

@@ -27,7 +27,7 @@ def rnd(*shape, seed=0, scale=1.0):
     return torch.randn(*shape, generator=g) * scale
 
 
-@pytest.fixture(params=[1, 2], ids=["gemm128x128", "gemm128x256dma"])
+@pytest.fixture(params=[1, 2, 3, 4, 5], ids=["gemm128x128", "gemm128x256dma", "slab128", "slab192", "slab256"])
 def gemm_variant(request):
     """Run every GEMM/conv case on BOTH kernels (the engine picks by problem size)."""
     G.lib().fs2_op_set_gemm_variant(request.param)
@@ -90,15 +90,16 @@ def test_gemm_dma_pipeline_large_and_repeatable(dtype):
     b = rnd(N, seed=42)
     ref = F.conv1d(G.rounded(x, dtype).transpose(1, 2), G.rounded(w, dtype), b, padding="same").transpose(1, 2)
     ref = torch.relu(ref)
-    G.lib().fs2_op_set_gemm_variant(2)
-    try:
-        runs = [G.gemm(dtype, x.reshape(B * S, Cin), G.pack_conv_weight(w), b, taps=k, S=S, relu=True) for _ in range(4)]
-    finally:
-        G.lib().fs2_op_set_gemm_variant(0)
-    for r in runs[1:]:
-        assert torch.equal(r, runs[0])
-    err = float((runs[0].reshape(B, S, N) - ref).abs().max())
-    assert err <= tol(dtype, ref), (err, tol(dtype, ref))
+    for variant in (2, 3, 4, 5):
+        G.lib().fs2_op_set_gemm_variant(variant)
+        try:
+            runs = [G.gemm(dtype, x.reshape(B * S, Cin), G.pack_conv_weight(w), b, taps=k, S=S, relu=True) for _ in range(3)]
+        finally:
+            G.lib().fs2_op_set_gemm_variant(0)
+        for r in runs[1:]:
+            assert torch.equal(r, runs[0]), variant
+        err = float((runs[0].reshape(B, S, N) - ref).abs().max())
+        assert err <= tol(dtype, ref), (variant, err, tol(dtype, ref))
 
 
 # ------------------------------------------------------------------------------------------------

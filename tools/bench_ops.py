@@ -68,7 +68,7 @@ def main():
     ap.add_argument("--variant", type=int, default=-1)
     ap.add_argument("--reps", type=int, default=20)
     a = ap.parse_args()
-    variants = [1, 2] if a.variant < 0 else [a.variant]
+    variants = [2, 3, 4, 5] if a.variant < 0 else [a.variant]
     if a.what in ("gemm", "all"):
         for v in variants:
             gemm_case("dec conv1 k=9", 49152, 1024, 256, 9, 1536, a.reps, v)
