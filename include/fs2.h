@@ -136,6 +136,12 @@ int fs2_op_gemm(int32_t dtype, int32_t out_dtype, const void* x, const void* w, 
                 int32_t M, int32_t N, int32_t Cin, int32_t taps, int32_t S, int32_t relu, void* hip_stream);
 int fs2_op_attention(int32_t dtype, const void* qkv, const uint8_t* key_pad_mask, void* out, void* vt_scratch,
                      uint64_t* bits_scratch, int32_t B, int32_t S, int32_t H, int32_t heads, void* hip_stream);
+/* GEMM/conv with the fused row epilogue  y = LayerNorm(act(xW^T + b) [+ res]) [, pred = head(y)]
+ * (y or pred may be NULL; tmp = (M, N) scratch used when the shape cannot be fused) */
+int fs2_op_gemm_ln(int32_t dtype, const void* x, const void* w, const float* bias, const void* res,
+                   const float* ln_g, const float* ln_b, const float* dot_w, float dot_b, const uint8_t* mask,
+                   float* pred, void* y, void* tmp, int32_t M, int32_t N, int32_t Cin, int32_t taps, int32_t S,
+                   int32_t relu, void* hip_stream);
 size_t fs2_op_attention_scratch_bytes(int32_t dtype, int32_t B, int32_t S, int32_t H, int32_t heads, size_t* bits_bytes);
 int fs2_op_layernorm(int32_t dtype, const void* x, const void* res, const float* gamma, const float* beta, void* y,
                      const float* dot_w, float dot_b, const uint8_t* mask, float* pred, int32_t M, int32_t H,

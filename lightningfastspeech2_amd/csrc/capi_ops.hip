@@ -51,6 +51,19 @@ int fs2_op_gemm(int32_t dtype, int32_t out_dtype, const void* x, const void* w, 
     return launch_gemm(a, dtype, out_dtype, (hipStream_t)stream);
 }
 
+int fs2_op_gemm_ln(int32_t dtype, const void* x, const void* w, const float* bias, const void* res,
+                   const float* ln_g, const float* ln_b, const float* dot_w, float dot_b, const uint8_t* mask,
+                   float* pred, void* y, void* tmp, int32_t M, int32_t N, int32_t Cin, int32_t taps, int32_t S,
+                   int32_t relu, void* stream) {
+    GemmArgs a;
+    a.X = x; a.W = w; a.bias = bias; a.C = y;
+    a.M = M; a.N = N; a.K = taps * Cin; a.ldx = Cin; a.ldc = N;
+    a.Cin = Cin; a.taps = taps; a.pad = (taps - 1) / 2; a.S = S; a.relu = relu;
+    a.res = res; a.ln_g = ln_g; a.ln_b = ln_b; a.dot_w = dot_w; a.dot_b = dot_b; a.mask = mask; a.pred = pred;
+    a.ln_tmp = tmp;
+    return launch_gemm(a, dtype, dtype, (hipStream_t)stream);
+}
+
 size_t fs2_op_attention_scratch_bytes(int32_t dtype, int32_t B, int32_t S, int32_t H, int32_t heads, size_t* bits_bytes) {
     (void)heads;
     const size_t Spad = ((size_t)S + 63) / 64 * 64;

@@ -403,7 +403,19 @@ struct Bracket {
 };
 
 // ---- op wrappers used by the forward ------------------------------------------------------------
-int gemm(fs2_engine* e, hipStream_t st, const ConvW& w, const void* x, void* c, int M, int S, bool relu, int out_dt) {
+struct LnFuse {  // optional fused epilogue: y = LN(act(gemm) [+ res]) [-> head]
+    const void* res = nullptr;
+    const float* g = nullptr;
+    const float* b = nullptr;
+    const float* dot_w = nullptr;
+    float dot_b = 0.f;
+    const uint8_t* mask = nullptr;
+    float* pred = nullptr;
+    void* tmp = nullptr;  // (M, N) scratch for the unfused fallback
+};
+
+int gemm(fs2_engine* e, hipStream_t st, const ConvW& w, const void* x, void* c, int M, int S, bool relu, int out_dt,
+         const LnFuse* ln = nullptr) {
     GemmArgs a;
     a.X = x;
     a.W = w.w;
@@ -419,6 +431,10 @@ int gemm(fs2_engine* e, hipStream_t st, const ConvW& w, const void* x, void* c, 
     a.pad = (w.taps - 1) / 2;
     a.S = S;
     a.relu = relu;
+    if (ln) {
+        a.res = ln->res; a.ln_g = ln->g; a.ln_b = ln->b; a.ln_eps = 1e-5f;
+        a.dot_w = ln->dot_w; a.dot_b = ln->dot_b; a.mask = ln->mask; a.pred = ln->pred; a.ln_tmp = ln->tmp;
+    }
     const double osz = out_dt == FS2_BF16 ? 2 : 4;
     Bracket br(e, w.taps > 1 ? FS2_K_CONV_GEMM : FS2_K_GEMM, st, 2.0 * M * (double)a.N * a.K,
                (double)M * w.Cin * e->esz + (double)a.N * a.K * e->esz + (double)M * a.N * osz);
@@ -474,16 +490,22 @@ int conformer(fs2_engine* e, hipStream_t st, const LayerW& w, void* x, void* tmp
         const int r = launch_attention(a, e->dt, st);
         if (r != FS2_OK) return fail(e, r, "attention launch failed");
     }
-    CHK(gemm(e, st, w.out_proj, sc.att, sc.proj, M, M, false, e->dt));
-    CHK(layernorm(e, st, sc.proj, x, w.g1, w.b1, tmp, M, H));
+    {   // tmp = LN1(x + out_proj(att))
+        LnFuse ln;
+        ln.res = x; ln.g = w.g1; ln.b = w.b1; ln.tmp = sc.proj;
+        CHK(gemm(e, st, w.out_proj, sc.att, tmp, M, M, false, e->dt, &ln));
+    }
     if (w.depthwise) {
         CHK(dwconv(e, st, w.dw, tmp, sc.u, B, S));
         CHK(gemm(e, st, w.c1, sc.u, sc.hid, M, S, true, e->dt));
     } else {
         CHK(gemm(e, st, w.c1, tmp, sc.hid, M, S, true, e->dt));
     }
-    CHK(gemm(e, st, w.c2, sc.hid, sc.proj, M, S, false, e->dt));
-    CHK(layernorm(e, st, sc.proj, tmp, w.g2, w.b2, x, M, H));
+    {   // x = LN2(tmp + conv2(hid))
+        LnFuse ln;
+        ln.res = tmp; ln.g = w.g2; ln.b = w.b2; ln.tmp = sc.proj;
+        CHK(gemm(e, st, w.c2, sc.hid, x, M, S, false, e->dt, &ln));
+    }
     return FS2_OK;
 }
 
@@ -495,15 +517,23 @@ int predictor(fs2_engine* e, hipStream_t st, const PredictorW& P, const void* x,
     for (size_t j = 0; j < P.layers.size(); ++j) {
         const PredLayerW& Lw = P.layers[j];
         const bool last = j + 1 == P.layers.size();
+        // conv -> ReLU -> LayerNorm fused in the GEMM epilogue; the last layer also applies the
+        // Linear(filter, 1) head + mask and never stores its activations.  Outputs ping-pong
+        // between att and proj (a conv must not write the buffer it reads neighbours from).
+        void* out = (j & 1) ? sc.proj : sc.att;
+        void* other = (j & 1) ? sc.att : sc.proj;
+        LnFuse ln;
+        ln.g = Lw.g; ln.b = Lw.b;
+        if (last) { ln.dot_w = P.head_w; ln.dot_b = P.head_b; ln.mask = mask; ln.pred = pred; }
         if (Lw.depthwise) {
             CHK(dwconv(e, st, Lw.dw, src, sc.u, B, S));
-            CHK(gemm(e, st, Lw.c, sc.u, sc.proj, M, S, true, e->dt));
+            ln.tmp = other;  // src (= other for j > 0) is dead once the depth-wise conv has run
+            CHK(gemm(e, st, Lw.c, sc.u, last ? nullptr : out, M, S, true, e->dt, &ln));
         } else {
-            CHK(gemm(e, st, Lw.c, src, sc.proj, M, S, true, e->dt));
+            ln.tmp = sc.u;
+            CHK(gemm(e, st, Lw.c, src, last ? nullptr : out, M, S, true, e->dt, &ln));
         }
-        if (last) CHK(layernorm(e, st, sc.proj, nullptr, Lw.g, Lw.b, nullptr, M, P.filt, P.head_w, P.head_b, mask, pred));
-        else CHK(layernorm(e, st, sc.proj, nullptr, Lw.g, Lw.b, sc.att, M, P.filt));
-        src = sc.att;
+        src = out;
     }
     return FS2_OK;
 }
@@ -516,7 +546,7 @@ size_t layer_scratch_bytes(const fs2_engine* e, int B, int S) {
     if ((size_t)c.var_filter > Pm) Pm = c.var_filter;
     if ((size_t)c.dur_filter > Pm) Pm = c.dur_filter;
     const size_t Spad = ((size_t)S + 63) / 64 * 64;
-    return al(M * 3 * H * esz) + 2 * al(M * Pm * esz) + al(M * Fm * esz) + al(M * H * esz) + al((size_t)B * H * Spad * esz) +
+    return al(M * 3 * H * esz) + 3 * al(M * Pm * esz) + al(M * Fm * esz) + al((size_t)B * H * Spad * esz) +
            al((size_t)B * (Spad / 64) * 8) + 4096;
 }
 int take_layer_scratch(fs2_engine* e, Arena& ar, int B, int S, LayerScratch* sc) {
@@ -532,7 +562,7 @@ int take_layer_scratch(fs2_engine* e, Arena& ar, int B, int S, LayerScratch* sc)
     sc->att = ar.take(M * Pm * esz);
     sc->proj = ar.take(M * Pm * esz);
     sc->hid = ar.take(M * Fm * esz);
-    sc->u = ar.take(M * H * esz);
+    sc->u = ar.take(M * Pm * esz);
     sc->vt = ar.take((size_t)B * H * sc->Spad * esz);
     sc->bits = (uint64_t*)ar.take((size_t)B * sc->nw64 * 8);
     if (!sc->qkv || !sc->att || !sc->proj || !sc->hid || !sc->u || !sc->vt || !sc->bits)

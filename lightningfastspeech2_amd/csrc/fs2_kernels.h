@@ -17,6 +17,19 @@ struct GemmArgs {
     int Cin, taps, pad;  // implicit conv: K index = tap*Cin + c, source row = m + tap - pad
     int S;               // rows per utterance (zero padding does not cross utterances)
     int relu;
+    // Optional fused row epilogue (needs a whole output row in one workgroup: N <= 256 on the slab
+    // kernel; otherwise the launcher writes the GEMM result to ln_tmp and runs layernorm_kernel):
+    //   y = LayerNorm(act(acc + bias) [+ res]) * ln_g + ln_b ;  C = y (skipped if C == null)
+    //   pred[m] = mask[m] ? 0 : sum_n y[m,n] * dot_w[n] + dot_b     (if dot_w)
+    const void* res = nullptr;      // (M, ldc) residual, same dtype as X
+    const float* ln_g = nullptr;    // (N)  non-null enables the fused epilogue
+    const float* ln_b = nullptr;
+    float ln_eps = 1e-5f;
+    const float* dot_w = nullptr;   // (N)
+    float dot_b = 0.f;
+    const uint8_t* mask = nullptr;  // (M) 1 = pad
+    float* pred = nullptr;          // (M)
+    void* ln_tmp = nullptr;         // (M, ldc) scratch for the unfused fallback
 };
 int launch_gemm(const GemmArgs& a, int in_dtype, int out_dtype, hipStream_t stream);
 extern int g_gemm_variant;  // test/bench knob: 0 auto, 1 force the 128x128 kernel, 2 force the DMA kernel

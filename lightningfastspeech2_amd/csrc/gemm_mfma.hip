@@ -351,7 +351,7 @@ template <int MI> struct SlabCfg {
 };
 static constexpr int S_BN = 256, S_WB = S_BN * ROWB;  // 32 KiB weight tile
 
-template <typename T, typename OutT, int MI>
+template <typename T, typename OutT, int MI, bool LN>
 __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-resource builtins only exist in the device pass
     using Cfg = SlabCfg<MI>;
@@ -471,6 +471,159 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
     }
 #undef FS2_SLAB_STEP
 
+    if constexpr (LN) {
+        // ---- fused row epilogue: the workgroup owns whole rows (tiles_n == 1) ----
+        // LayerNorm(act(acc + bias) [+ res]) with two-pass statistics: lane partials -> lane-group
+        // shuffles -> one LDS exchange between the four column waves; optional predictor head.
+        const size_t rowbase = (size_t)ub * S;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n = wn * 64 + ni * 16 + fg * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool nv = n + r < p.N;
+                const float bvv = (nv && p.bias) ? p.bias[n + r] : 0.f;
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    float v = acc[ni][mi][r] + bvv;
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    acc[ni][mi][r] = nv ? v : 0.f;
+                }
+            }
+        }
+        if (p.res) {
+            const T* R = (const T*)p.res;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                int t = t0 + wm * (MI * 16) + mi * 16 + fr;
+                if (t >= S) t = S - 1;  // rows past the utterance end are never stored
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const int n = wn * 64 + ni * 16 + fg * 4;
+                    if (n + 3 < p.N) {
+                        float rv[4];
+                        if constexpr (sizeof(T) == 4) {
+                            const float4 q = *(const float4*)(R + (rowbase + t) * p.ldc + n);
+                            rv[0] = q.x; rv[1] = q.y; rv[2] = q.z; rv[3] = q.w;
+                        } else {
+                            const uint2 q = *(const uint2*)(R + (rowbase + t) * p.ldc + n);
+                            rv[0] = __uint_as_float(q.x << 16); rv[1] = __uint_as_float(q.x & 0xffff0000u);
+                            rv[2] = __uint_as_float(q.y << 16); rv[3] = __uint_as_float(q.y & 0xffff0000u);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[ni][mi][r] += rv[r];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (n + r < p.N) acc[ni][mi][r] += Num<T>::to_f32(R[(rowbase + t) * p.ldc + n + r]);
+                    }
+                }
+            }
+        }
+        __syncthreads();  // every wave is done with the operand buffers: reuse them for the exchange
+        float* red = (float*)slab0;  // [4 column waves][BMs rows]
+        float* lnp = (float*)wt0;    // [gamma 256 | beta 256 | head weight 256]
+        if (tid < S_BN) {
+            const bool nv = tid < p.N;
+            lnp[tid] = nv ? p.ln_g[tid] : 0.f;
+            lnp[S_BN + tid] = nv ? p.ln_b[tid] : 0.f;
+            lnp[2 * S_BN + tid] = (nv && p.dot_w) ? p.dot_w[tid] : 0.f;
+        }
+        const float invn = 1.0f / (float)p.N;
+        float mean[MI], rstd[MI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            float sm = 0.f;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) sm += (acc[ni][mi][0] + acc[ni][mi][1]) + (acc[ni][mi][2] + acc[ni][mi][3]);
+            sm += __shfl_xor(sm, 16, 64);
+            sm += __shfl_xor(sm, 32, 64);
+            if (fg == 0) red[wn * BMs + wm * (MI * 16) + mi * 16 + fr] = sm;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int row = wm * (MI * 16) + mi * 16 + fr;
+            mean[mi] = ((red[row] + red[BMs + row]) + (red[2 * BMs + row] + red[3 * BMs + row])) * invn;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            float q = 0.f;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int n = wn * 64 + ni * 16 + fg * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float d = (n + r < p.N) ? acc[ni][mi][r] - mean[mi] : 0.f;
+                    q += d * d;
+                }
+            }
+            q += __shfl_xor(q, 16, 64);
+            q += __shfl_xor(q, 32, 64);
+            if (fg == 0) red[wn * BMs + wm * (MI * 16) + mi * 16 + fr] = q;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int row = wm * (MI * 16) + mi * 16 + fr;
+            const float var = ((red[row] + red[BMs + row]) + (red[2 * BMs + row] + red[3 * BMs + row])) * invn;
+            rstd[mi] = 1.0f / sqrtf(var + p.ln_eps);
+        }
+        OutT* __restrict__ Cn = p.C ? (OutT*)p.C + rowbase * p.ldc : nullptr;
+        float dsum[MI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int t = t0 + wm * (MI * 16) + mi * 16 + fr;
+            dsum[mi] = 0.f;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int n = wn * 64 + ni * 16 + fg * 4;
+                const float4 g4 = *(const float4*)(lnp + n), b4 = *(const float4*)(lnp + S_BN + n);
+                const float4 w4 = *(const float4*)(lnp + 2 * S_BN + n);
+                const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
+                const float ww[4] = {w4.x, w4.y, w4.z, w4.w};
+                float y[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    y[r] = (acc[ni][mi][r] - mean[mi]) * rstd[mi] * gg[r] + bb[r];
+                    dsum[mi] += y[r] * ww[r];
+                }
+                if (Cn && t < S && n < p.N) {
+                    OutT* dst = Cn + (size_t)t * p.ldc + n;
+                    if (n + 3 < p.N) {
+                        if constexpr (sizeof(OutT) == 4) *(float4*)dst = make_float4(y[0], y[1], y[2], y[3]);
+                        else *(uint2*)dst = make_uint2(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]));
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) if (n + r < p.N) dst[r] = Num<OutT>::from_f32(y[r]);
+                    }
+                }
+            }
+        }
+        if (p.dot_w) {
+            __syncthreads();
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                float d = dsum[mi];
+                d += __shfl_xor(d, 16, 64);
+                d += __shfl_xor(d, 32, 64);
+                if (fg == 0) red[wn * BMs + wm * (MI * 16) + mi * 16 + fr] = d;
+            }
+            __syncthreads();
+            if (wn == 0 && fg == 0) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const int row = wm * (MI * 16) + mi * 16 + fr, t = t0 + row;
+                    if (t < S) {
+                        const float d = ((red[row] + red[BMs + row]) + (red[2 * BMs + row] + red[3 * BMs + row])) + p.dot_b;
+                        p.pred[rowbase + t] = (p.mask && p.mask[rowbase + t]) ? 0.f : d;
+                    }
+                }
+            }
+        }
+        return;
+    }
     OutT* __restrict__ C = (OutT*)p.C + (size_t)ub * S * p.ldc;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
@@ -509,21 +662,29 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
 #endif
 }
 
-template <typename T, typename OutT, int MI>
+template <typename T, typename OutT, int MI, bool LN>
 static int launch_slab_t(const GemmArgs& a0, hipStream_t stream) {
     GemmArgs a = a0;
     if (a.taps == 1) a.S = a.M;  // plain GEMM: one "utterance" of M rows
     const int BMs = SlabCfg<MI>::BM;
     const int tiles = (a.M / a.S) * ((a.S + BMs - 1) / BMs) * ((a.N + S_BN - 1) / S_BN);
-    hipLaunchKernelGGL((gemm_conv_slab_kernel<T, OutT, MI>), dim3(tiles), dim3(512), 0, stream, a);
+    hipLaunchKernelGGL((gemm_conv_slab_kernel<T, OutT, MI, LN>), dim3(tiles), dim3(512), 0, stream, a);
     return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
 }
 
 template <int MI>
 static int launch_slab(const GemmArgs& a, int in_dtype, int out_dtype, hipStream_t stream) {
-    if (in_dtype == FS2_F32 && out_dtype == FS2_F32) return launch_slab_t<float, float, MI>(a, stream);
-    if (in_dtype == FS2_BF16 && out_dtype == FS2_BF16) return launch_slab_t<bf16, bf16, MI>(a, stream);
-    if (in_dtype == FS2_BF16 && out_dtype == FS2_F32) return launch_slab_t<bf16, float, MI>(a, stream);
+    if (a.ln_g) {  // fused LayerNorm epilogue: whole rows per workgroup, tile heights 128 / 192 only
+        if constexpr (MI <= 6) {
+            if (a.N > S_BN) return FS2_ERR_SHAPE;
+            if (in_dtype == FS2_F32 && out_dtype == FS2_F32) return launch_slab_t<float, float, MI, true>(a, stream);
+            if (in_dtype == FS2_BF16 && out_dtype == FS2_BF16) return launch_slab_t<bf16, bf16, MI, true>(a, stream);
+        }
+        return FS2_ERR_SHAPE;
+    }
+    if (in_dtype == FS2_F32 && out_dtype == FS2_F32) return launch_slab_t<float, float, MI, false>(a, stream);
+    if (in_dtype == FS2_BF16 && out_dtype == FS2_BF16) return launch_slab_t<bf16, bf16, MI, false>(a, stream);
+    if (in_dtype == FS2_BF16 && out_dtype == FS2_F32) return launch_slab_t<bf16, float, MI, false>(a, stream);
     return FS2_ERR_SHAPE;
 }
 
@@ -544,7 +705,33 @@ static int launch_t(const GemmArgs& a, hipStream_t stream) {
 
 int g_gemm_variant = 0;
 
+static int launch_gemm_plain(const GemmArgs& a, int in_dtype, int out_dtype, hipStream_t stream, bool* fused);
+
 int launch_gemm(const GemmArgs& a, int in_dtype, int out_dtype, hipStream_t stream) {
+    if (!a.ln_g) return launch_gemm_plain(a, in_dtype, out_dtype, stream, nullptr);
+    // fused row epilogue requested: try the slab kernel (whole rows per workgroup), else GEMM -> ln_tmp
+    // followed by the stand-alone LayerNorm kernel (same arithmetic, one more HBM round trip)
+    bool fused = false;
+    if (a.N <= S_BN && in_dtype == out_dtype) {
+        const int r = launch_gemm_plain(a, in_dtype, out_dtype, stream, &fused);
+        if (r != FS2_OK || fused) return r;
+    }
+    if (!a.ln_tmp || in_dtype != out_dtype) return FS2_ERR_ARG;
+    GemmArgs g = a;
+    g.ln_g = nullptr;
+    g.C = a.ln_tmp;
+    const int r = launch_gemm_plain(g, in_dtype, out_dtype, stream, nullptr);
+    if (r != FS2_OK) return r;
+    LayerNormArgs l;
+    l.x = a.ln_tmp; l.res = a.res; l.gamma = a.ln_g; l.beta = a.ln_b; l.y = a.C;
+    l.dot_w = a.dot_w; l.dot_b = a.dot_b; l.mask = a.mask; l.pred = a.pred;
+    l.M = a.M; l.H = a.N; l.eps = a.ln_eps;
+    return launch_layernorm(l, out_dtype, stream);
+}
+
+// fused != nullptr: the caller wants the LN epilogue; only the slab kernel provides it.  If the slab
+// kernel is not selected, nothing is launched and *fused stays false.
+static int launch_gemm_plain(const GemmArgs& a, int in_dtype, int out_dtype, hipStream_t stream, bool* fused) {
     if (a.M <= 0 || a.N <= 0) return FS2_OK;
     const int ke = in_dtype == FS2_BF16 ? 64 : 32;
     const int e16 = in_dtype == FS2_BF16 ? 8 : 4;
@@ -553,11 +740,13 @@ int launch_gemm(const GemmArgs& a, int in_dtype, int out_dtype, hipStream_t stre
     const int variant = g_gemm_variant;  // 0 = auto, 1 = 128x128 register-staged, 2 = 128x256 DMA ring,
                                          // 3/4/5 = slab kernel with 128/192/256-row tiles
     const bool slab_ok = a.M % a.S == 0 && (a.taps & 1);
-    if (variant >= 3 && variant <= 5 && slab_ok) {
+    if (variant >= 3 && variant <= 5 && slab_ok && !(fused && variant == 5)) {
+        if (fused) *fused = true;
         if (variant == 3) return launch_slab<4>(a, in_dtype, out_dtype, stream);
         if (variant == 4) return launch_slab<6>(a, in_dtype, out_dtype, stream);
         return launch_slab<8>(a, in_dtype, out_dtype, stream);
     }
+    if (fused && variant != 0) return FS2_OK;  // forced non-slab kernel: caller falls back
     if (variant == 2) {
         if (in_dtype == FS2_F32 && out_dtype == FS2_F32) return launch_glds_t<float, float>(a, stream);
         if (in_dtype == FS2_BF16 && out_dtype == FS2_BF16) return launch_glds_t<bf16, bf16>(a, stream);
@@ -572,17 +761,19 @@ int launch_gemm(const GemmArgs& a, int in_dtype, int out_dtype, hipStream_t stre
         const int S = a.taps == 1 ? a.M : a.S, nutt = a.M / S, tn = (a.N + S_BN - 1) / S_BN;
         int best = 0;
         long best_cost = 0, best_rows = 0;
-        for (int mi = 4; mi <= 8; mi += 2) {
+        for (int mi = 4; mi <= (fused ? 6 : 8); mi += 2) {
             const long bm = mi * 32, tm = (S + bm - 1) / bm, tiles = (long)nutt * tm * tn;
             const long cost = ((tiles + 255) / 256) * (bm + 40);
             if (!best || cost < best_cost) { best = mi; best_cost = cost; best_rows = (long)nutt * tm * bm; }
         }
         if (best_rows <= 2L * a.M) {
+            if (fused) *fused = true;
             if (best == 4) return launch_slab<4>(a, in_dtype, out_dtype, stream);
             if (best == 6) return launch_slab<6>(a, in_dtype, out_dtype, stream);
             return launch_slab<8>(a, in_dtype, out_dtype, stream);
         }
     }
+    if (fused) return FS2_OK;  // not the slab kernel: caller falls back to GEMM + LayerNorm kernel
     if (in_dtype == FS2_F32 && out_dtype == FS2_F32) return launch_t<float, float>(a, stream);
     if (in_dtype == FS2_BF16 && out_dtype == FS2_BF16) return launch_t<bf16, bf16>(a, stream);
     if (in_dtype == FS2_BF16 && out_dtype == FS2_F32) return launch_t<bf16, float>(a, stream);

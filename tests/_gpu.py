@@ -54,6 +54,23 @@ def gemm(dtype, x, w_packed, bias, taps=1, S=None, relu=False, out_dtype=None):
     return c.float().cpu()
 
 
+def gemm_ln(dtype, x, w_packed, bias, res, g, b, taps=1, S=None, relu=False, dot_w=None, dot_b=0.0, mask=None, want_y=True):
+    M, Cin = x.shape
+    N = w_packed.shape[0]
+    f = lambda a: None if a is None else torch.as_tensor(a).float().to(DEV).contiguous()
+    xd, wd = to_dev(x, dtype), to_dev(w_packed, dtype)
+    rd = None if res is None else to_dev(res, dtype)
+    y = torch.empty(M, N, dtype=tdt(dtype), device=DEV) if want_y else None
+    tmp = torch.empty(M, N, dtype=tdt(dtype), device=DEV)
+    pred = torch.empty(M, dtype=torch.float32, device=DEV) if dot_w is not None else None
+    mk = None if mask is None else torch.as_tensor(mask).to(torch.uint8).to(DEV)
+    bd, gd, bed, dwd = f(bias), f(g), f(b), f(dot_w)
+    ok(lib().fs2_op_gemm_ln(dtype, p(xd), p(wd), p(bd), p(rd), p(gd), p(bed), p(dwd), float(dot_b), p(mk), p(pred),
+                            p(y), p(tmp), M, N, Cin, taps, S or M, int(relu), stream()), "gemm_ln")
+    torch.cuda.synchronize()
+    return (None if y is None else y.float().cpu()), (None if pred is None else pred.cpu())
+
+
 def pack_conv_weight(w):
     """torch (N, Cin, k) -> (N, k*Cin) tap-major (what the engine builds at fs2_finalize)."""
     w = torch.as_tensor(w).float()

@@ -80,6 +80,42 @@ def test_gemm_conv_same_padding_per_utterance(dtype, B, S, Cin, N, k, gemm_varia
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("variant", [0, 1, 3, 4], ids=["auto", "unfused128x128", "slab128", "slab192"])
+@pytest.mark.parametrize("B,S,Cin,N,k,relu,use_res", [(3, 200, 256, 256, 3, True, False), (2, 333, 1024, 256, 1, False, True),
+                                                     (2, 70, 64, 192, 5, True, True), (1, 1536, 256, 256, 9, False, True),
+                                                     (2, 50, 768, 768, 1, False, True)])
+def test_gemm_fused_layernorm_epilogue(dtype, variant, B, S, Cin, N, k, relu, use_res):
+    """conv/GEMM -> (+ReLU) -> (+residual) -> LayerNorm (-> predictor head), fused in the slab
+    kernel's epilogue when the row fits one workgroup (N <= 256), else GEMM + LayerNorm kernel."""
+    x = rnd(B, S, Cin, seed=50)
+    w = rnd(N, Cin, k, seed=51, scale=(Cin * k) ** -0.5)
+    b, res = rnd(N, seed=52), rnd(B * S, N, seed=53)
+    g, be = 1 + 0.2 * rnd(N, seed=54), 0.1 * rnd(N, seed=55)
+    hw = rnd(N, seed=56, scale=N ** -0.5)
+    mask = torch.zeros(B * S, dtype=torch.bool)
+    mask[::5] = True
+    z = F.conv1d(G.rounded(x, dtype).transpose(1, 2), G.rounded(w, dtype), b, padding="same").transpose(1, 2).reshape(B * S, N)
+    if relu:
+        z = torch.relu(z)
+    if use_res:
+        z = z + G.rounded(res, dtype)
+    ref = F.layer_norm(z, (N,), g, be, 1e-5)
+    pref = (ref @ hw + 0.3).masked_fill(mask, 0)
+    G.lib().fs2_op_set_gemm_variant(variant)
+    try:
+        y, pred = G.gemm_ln(dtype, x.reshape(B * S, Cin), G.pack_conv_weight(w), b, res if use_res else None, g, be,
+                            taps=k, S=S, relu=relu, dot_w=hw, dot_b=0.3, mask=mask)
+        _, pred2 = G.gemm_ln(dtype, x.reshape(B * S, Cin), G.pack_conv_weight(w), b, res if use_res else None, g, be,
+                             taps=k, S=S, relu=relu, dot_w=hw, dot_b=0.3, mask=mask, want_y=False)
+    finally:
+        G.lib().fs2_op_set_gemm_variant(0)
+    assert float((y - ref).abs().max()) <= tol(dtype, ref, f32=5e-5, bf16=2.5e-2)
+    ptol = 1e-4 if dtype == G.F32 else 3e-2
+    assert float((pred - pref).abs().max()) <= ptol * (float(pref.abs().max()) + 1)
+    assert torch.equal(pred, pred2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_dma_pipeline_large_and_repeatable(dtype):
     """Full-size decoder conv tile stream (K = 9*256 -> 36 chunks through the 3-stage DMA ring),
     many workgroups per CU in flight: compare with torch and demand bit-identical reruns (a DMA /
