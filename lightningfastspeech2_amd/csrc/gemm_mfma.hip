@@ -343,6 +343,13 @@ static int launch_glds_t(const GemmArgs& a, hipStream_t stream) {
 // LDS object; every step: __syncthreads (hipcc drains this wave's DMAs in front of it), issue the
 // next step's DMAs, multiply the current one.
 // =================================================================================================
+// Slab-kernel weight tile: MFMA row i (= lane group fg*4 + r in the accumulator) of fragment ni is
+// mapped to output channel  (ni>>1)*32 + (i>>2)*8 + (ni&1)*4 + (i&3)  of the wave's 64, so that a lane
+// ends up with 8 consecutive channels per fragment pair (wide, line-friendly stores).  wswz is the
+// 16-byte XOR swizzle that keeps those fragment reads bank-conflict free.
+__device__ inline int wcol(int ni, int fgq) { return (ni >> 1) * 32 + fgq * 8 + (ni & 1) * 4; }
+__device__ inline int wswz(int row) { return ((row >> 1) & 1) | (((row >> 3) & 3) << 1); }
+
 template <int MI> struct SlabCfg {
     static constexpr int BM = MI * 32;
     static constexpr int SLAB_GROUPS = (BM + 30 + 7) / 8;          // 8-row (1 KiB) DMA groups, k <= 31
@@ -396,7 +403,7 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
     for (int i = 0; i < 4; ++i) {
         const int P = (i * 8 + wave) * 64 + lane, row = P >> 3, ps = P & 7;
         const int n = n0 + row;
-        wvoff[i] = n < p.N ? (unsigned)((size_t)n * p.K * sizeof(T)) + (unsigned)((ps ^ (row & 7)) << 4) : OOB;
+        wvoff[i] = n < p.N ? (unsigned)((size_t)n * p.K * sizeof(T)) + (unsigned)((ps ^ wswz(row)) << 4) : OOB;
     }
     auto issue_slab = [&](unsigned char* dst, int cc) {
 #pragma unroll
@@ -425,7 +432,10 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) woff[i][ks] = swz(wn * 64 + i * 16 + fr, ks * 4 + fg);
+        for (int ks = 0; ks < 2; ++ks) {
+            const int wrow = wn * 64 + wcol(i, fr >> 2) + (fr & 3);  // MFMA row fr of fragment i <-> channel
+            woff[i][ks] = wrow * ROWB + (((ks * 4 + fg) ^ wswz(wrow)) << 4);
+        }
 
     auto compute = [&](const unsigned char* sl, const unsigned char* wt, int tap) {
 #pragma unroll
@@ -478,7 +488,7 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
         const size_t rowbase = (size_t)ub * S;
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
-            const int n = wn * 64 + ni * 16 + fg * 4;
+            const int n = wn * 64 + wcol(ni, fg);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const bool nv = n + r < p.N;
@@ -499,7 +509,7 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
                 if (t >= S) t = S - 1;  // rows past the utterance end are never stored
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) {
-                    const int n = wn * 64 + ni * 16 + fg * 4;
+                    const int n = wn * 64 + wcol(ni, fg);
                     if (n + 3 < p.N) {
                         float rv[4];
                         if constexpr (sizeof(T) == 4) {
@@ -552,7 +562,7 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
             float q = 0.f;
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
-                const int n = wn * 64 + ni * 16 + fg * 4;
+                const int n = wn * 64 + wcol(ni, fg);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float d = (n + r < p.N) ? acc[ni][mi][r] - mean[mi] : 0.f;
@@ -577,26 +587,34 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
             const int t = t0 + wm * (MI * 16) + mi * 16 + fr;
             dsum[mi] = 0.f;
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                const int n = wn * 64 + ni * 16 + fg * 4;
-                const float4 g4 = *(const float4*)(lnp + n), b4 = *(const float4*)(lnp + S_BN + n);
-                const float4 w4 = *(const float4*)(lnp + 2 * S_BN + n);
-                const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
-                const float ww[4] = {w4.x, w4.y, w4.z, w4.w};
-                float y[4];
+            for (int j = 0; j < 2; ++j) {
+                const int n = wn * 64 + j * 32 + fg * 8;  // 8 consecutive channels of fragments 2j, 2j+1
+                float y[8];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    y[r] = (acc[ni][mi][r] - mean[mi]) * rstd[mi] * gg[r] + bb[r];
-                    dsum[mi] += y[r] * ww[r];
+                for (int h = 0; h < 2; ++h) {
+                    const float4 g4 = *(const float4*)(lnp + n + 4 * h), b4 = *(const float4*)(lnp + S_BN + n + 4 * h);
+                    const float4 w4 = *(const float4*)(lnp + 2 * S_BN + n + 4 * h);
+                    const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
+                    const float ww[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        y[4 * h + r] = (acc[2 * j + h][mi][r] - mean[mi]) * rstd[mi] * gg[r] + bb[r];
+                        dsum[mi] += y[4 * h + r] * ww[r];
+                    }
                 }
                 if (Cn && t < S && n < p.N) {
                     OutT* dst = Cn + (size_t)t * p.ldc + n;
-                    if (n + 3 < p.N) {
-                        if constexpr (sizeof(OutT) == 4) *(float4*)dst = make_float4(y[0], y[1], y[2], y[3]);
-                        else *(uint2*)dst = make_uint2(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]));
+                    if (n + 7 < p.N) {
+                        if constexpr (sizeof(OutT) == 4) {
+                            *(float4*)dst = make_float4(y[0], y[1], y[2], y[3]);
+                            *(float4*)(dst + 4) = make_float4(y[4], y[5], y[6], y[7]);
+                        } else {
+                            *(uint4*)dst = make_uint4(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]),
+                                                      pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7]));
+                        }
                     } else {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) if (n + r < p.N) dst[r] = Num<OutT>::from_f32(y[r]);
+                        for (int r = 0; r < 8; ++r) if (n + r < p.N) dst[r] = Num<OutT>::from_f32(y[r]);
                     }
                 }
             }
@@ -625,35 +643,38 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
         return;
     }
     OutT* __restrict__ C = (OutT*)p.C + (size_t)ub * S * p.ldc;
+    // lane (fr, fg) holds, for output row t, the 8 consecutive channels n .. n+7 of each fragment
+    // pair (2j, 2j+1): one 16-byte (bf16) / two 16-byte (fp32) stores, 64 contiguous bytes per row
+    // across the four lane groups
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-        const int n = n0 + wn * 64 + ni * 16 + fg * 4;
+    for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + fg * 8;
         if (n >= p.N) continue;
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) {
+        float bv[8];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) if (n + r < p.N) bv[r] = p.bias[n + r];
-        }
+        for (int r = 0; r < 8; ++r) bv[r] = (p.bias && n + r < p.N) ? p.bias[n + r] : 0.f;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const int t = t0 + wm * (MI * 16) + mi * 16 + fr;
             if (t >= S) continue;
-            float v[4];
+            float v[8];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v[r] = acc[ni][mi][r] + bv[r];
+            for (int r = 0; r < 8; ++r) {
+                v[r] = acc[2 * j + (r >> 2)][mi][r & 3] + bv[r];
                 if (p.relu) v[r] = fmaxf(v[r], 0.f);
             }
             OutT* dst = C + (size_t)t * p.ldc + n;
-            if (n + 3 < p.N) {
+            if (n + 7 < p.N) {
                 if constexpr (sizeof(OutT) == 4) {
                     *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+                    *(float4*)(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
                 } else {
-                    *(uint2*)dst = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                    *(uint4*)dst = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]),
+                                              pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
                 }
             } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) if (n + r < p.N) dst[r] = Num<OutT>::from_f32(v[r]);
+                for (int r = 0; r < 8; ++r) if (n + r < p.N) dst[r] = Num<OutT>::from_f32(v[r]);
             }
         }
     }

@@ -67,8 +67,14 @@ def main():
     ap.add_argument("what", nargs="?", default="all")
     ap.add_argument("--variant", type=int, default=-1)
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--only", default="", help="substring filter on the case name")
     a = ap.parse_args()
-    variants = [2, 3, 4, 5] if a.variant < 0 else [a.variant]
+    global gemm_case, attn_case
+    if a.only:
+        g0, a0 = gemm_case, attn_case
+        gemm_case = lambda name, *r: g0(name, *r) if a.only in name else None
+        attn_case = lambda name, *r: a0(name, *r) if a.only in name else None
+    variants = [0, 2, 3, 4, 5] if a.variant < 0 else [a.variant]
     if a.what in ("gemm", "all"):
         for v in variants:
             gemm_case("dec conv1 k=9", 49152, 1024, 256, 9, 1536, a.reps, v)
