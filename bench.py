@@ -111,14 +111,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    model.engine.profile_enable(_lib.K_CONV_GEMM if not cfg.decoder_depthwise_conv else _lib.K_GEMM, True)
+    # dominant kernel: the decoder FFN's dense k-tap conv (implicit GEMM); depth-wise configs have no
+    # dense conv, there the pointwise GEMM launches (aggregated) dominate
+    kcls = _lib.K_DEC_FFN_CONV1 if not cfg.decoder_depthwise_conv else _lib.K_GEMM
+    model.engine.profile_enable(kcls, True)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     sync()
     elapsed = time.perf_counter() - t0
-    kcls = _lib.K_CONV_GEMM if not cfg.decoder_depthwise_conv else _lib.K_GEMM
     prof = model.engine.profile_read(kcls)
     model.engine.profile_enable(kcls, False)
 
@@ -161,7 +163,9 @@ def main():
                        "params": cfg.param_count()},
             "roofline": {"bound": "mfma", "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic,
-                         "kernel": "gemm_conv_kernel (implicit-GEMM Conv1d)" if kcls == _lib.K_CONV_GEMM else "gemm_conv_kernel (pointwise GEMMs)",
+                         "kernel": ("gemm_conv_slab_kernel: decoder FFN conv1, implicit-GEMM Conv1d "
+                                    f"M={args.batch * T} N={cfg.decoder_conv_filter_size} K={cfg.decoder_kernel_sizes[0]}x{cfg.hidden}")
+                         if kcls == _lib.K_DEC_FFN_CONV1 else "gemm_conv_slab_kernel (pointwise GEMM launches, aggregated)",
                          "launches_timed": prof["launches"], "avg_launch_us": avg_s * 1e6,
                          "flops_per_launch": prof["flops"] / n},
         }

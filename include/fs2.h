@@ -122,7 +122,14 @@ int fs2_force_buckets(fs2_engine* e, int32_t variance_index, const int32_t* idx_
 int fs2_debug_copy(fs2_engine* e, const char* what, void* dst_device, void* hip_stream);
 
 /* Kernel timing with HIP events on the launch stream (bench.py roofline).  kernel_class: */
-enum fs2_kernel_class { FS2_K_CONV_GEMM = 0, FS2_K_GEMM = 1, FS2_K_ATTENTION = 2, FS2_K_ROWOPS = 3, FS2_K_COUNT = 4 };
+enum fs2_kernel_class {
+    FS2_K_CONV_GEMM = 0,   /* every implicit-GEMM Conv1d launch (taps > 1) */
+    FS2_K_GEMM = 1,        /* pointwise / linear GEMM launches */
+    FS2_K_ATTENTION = 2,
+    FS2_K_ROWOPS = 3,
+    FS2_K_DEC_FFN_CONV1 = 4, /* the decoder FFN's first conv only: the single dominant launch shape */
+    FS2_K_COUNT = 5
+};
 int fs2_profile_enable(fs2_engine* e, int32_t kernel_class, int32_t enable);
 /* Sums elapsed ms / launches / algorithmic flops / algorithmic bytes since enable; syncs the events. */
 int fs2_profile_read(fs2_engine* e, int32_t kernel_class, double* total_ms, int64_t* launches,

@@ -383,9 +383,10 @@ struct Bracket {
     int cls;
     hipStream_t st;
     hipEvent_t stop = nullptr;
-    Bracket(fs2_engine* e_, int cls_, hipStream_t st_, double flops, double bytes) : e(e_), cls(cls_), st(st_) {
+    Bracket(fs2_engine* e_, int cls_, hipStream_t st_, double flops, double bytes, bool active = true)
+        : e(e_), cls(cls_), st(st_) {
         ProfSlot& s = e->prof[cls];
-        if (!s.enabled) return;
+        if (!active || !s.enabled) return;
         if (s.used == s.ev.size()) {
             hipEvent_t a, b;
             if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
@@ -415,7 +416,7 @@ struct LnFuse {  // optional fused epilogue: y = LN(act(gemm) [+ res]) [-> head]
 };
 
 int gemm(fs2_engine* e, hipStream_t st, const ConvW& w, const void* x, void* c, int M, int S, bool relu, int out_dt,
-         const LnFuse* ln = nullptr) {
+         const LnFuse* ln = nullptr, int extra_class = -1) {
     GemmArgs a;
     a.X = x;
     a.W = w.w;
@@ -436,8 +437,10 @@ int gemm(fs2_engine* e, hipStream_t st, const ConvW& w, const void* x, void* c, 
         a.dot_w = ln->dot_w; a.dot_b = ln->dot_b; a.mask = ln->mask; a.pred = ln->pred; a.ln_tmp = ln->tmp;
     }
     const double osz = out_dt == FS2_BF16 ? 2 : 4;
-    Bracket br(e, w.taps > 1 ? FS2_K_CONV_GEMM : FS2_K_GEMM, st, 2.0 * M * (double)a.N * a.K,
-               (double)M * w.Cin * e->esz + (double)a.N * a.K * e->esz + (double)M * a.N * osz);
+    const double fl = 2.0 * M * (double)a.N * a.K;
+    const double by = (double)M * w.Cin * e->esz + (double)a.N * a.K * e->esz + (double)M * a.N * osz;
+    Bracket br(e, w.taps > 1 ? FS2_K_CONV_GEMM : FS2_K_GEMM, st, fl, by);
+    Bracket br2(e, extra_class >= 0 ? extra_class : FS2_K_COUNT - 1, st, fl, by, extra_class >= 0);
     const int r = launch_gemm(a, e->dt, out_dt, st);
     if (r != FS2_OK) return fail(e, r, "gemm launch failed (M=%d N=%d K=%d)", M, a.N, a.K);
     return FS2_OK;
@@ -473,7 +476,7 @@ struct LayerScratch {
 // ConformerEncoderLayer.forward, post-LN (model.py:113-115); result back in x (tmp is the other
 // half of the ping-pong pair).
 int conformer(fs2_engine* e, hipStream_t st, const LayerW& w, void* x, void* tmp, int B, int S, int heads,
-              const LayerScratch& sc) {
+              const LayerScratch& sc, bool is_decoder) {
     const int H = e->cfg.hidden, M = B * S;
     CHK(gemm(e, st, w.in_proj, x, sc.qkv, M, M, false, e->dt));
     AttnArgs a;
@@ -499,7 +502,7 @@ int conformer(fs2_engine* e, hipStream_t st, const LayerW& w, void* x, void* tmp
         CHK(dwconv(e, st, w.dw, tmp, sc.u, B, S));
         CHK(gemm(e, st, w.c1, sc.u, sc.hid, M, S, true, e->dt));
     } else {
-        CHK(gemm(e, st, w.c1, tmp, sc.hid, M, S, true, e->dt));
+        CHK(gemm(e, st, w.c1, tmp, sc.hid, M, S, true, e->dt, nullptr, is_decoder ? FS2_K_DEC_FFN_CONV1 : -1));
     }
     {   // x = LN2(tmp + conv2(hid))
         LnFuse ln;
@@ -733,7 +736,7 @@ int fs2_encode(fs2_engine* e, const int64_t* phones, const float* speaker, int32
         if (launch_mask_bits(mb, st) != FS2_OK) return fail(e, FS2_ERR_HIP, "mask_bits launch failed");
     }
     for (int i = 0; i < c.enc_layers; ++i)                                   // fastspeech2.py:685
-        CHK(conformer(e, st, e->enc[i], e->xA, e->xB, B, L, c.enc_heads, sc));
+        CHK(conformer(e, st, e->enc[i], e->xA, e->xB, B, L, c.enc_heads, sc, false));
     // duration predictor + rounding + prefix sums                          model.py:259,299-309
     CHK(predictor(e, st, e->dur, e->xA, B, L, e->src_mask, e->dur_pred, sc));
     DurationArgs da{e->dur_pred, e->src_mask, forced, e->d_dur, e->d_cum, e->d_totals, e->d_guard, B, L};
@@ -776,9 +779,11 @@ int fs2_decode(fs2_engine* e, const fs2_outputs* out, void* stream) {
     if (e->scratch.reserve(need_s) != FS2_OK) return fail(e, FS2_ERR_NOMEM, "scratch arena %zu bytes", need_s);
     void* yA = e->scratch.take(MT * H * esz);
     void* yB = e->scratch.take(MT * H * esz);
-    uint8_t* tmask = (uint8_t*)e->scratch.take(MT);
+    // mask / variance predictions go straight into the caller's buffers when it wants them
+    uint8_t* tmask = out->tgt_mask ? out->tgt_mask : (uint8_t*)e->scratch.take(MT);
     float* vpred[FS2_MAX_VARIANCES] = {nullptr, nullptr, nullptr, nullptr};
-    for (int v = 0; v < c.n_variances; ++v) vpred[v] = (float*)e->scratch.take(MT * 4);
+    for (int v = 0; v < c.n_variances; ++v)
+        vpred[v] = out->variances[v] ? out->variances[v] : (float*)e->scratch.take(MT * 4);
     LayerScratch sc;
     CHK(take_layer_scratch(e, e->scratch, B, T, &sc));
     if (!yA || !yB || !tmask) return fail(e, FS2_ERR_NOMEM, "scratch arena too small");
@@ -813,7 +818,6 @@ int fs2_decode(fs2_engine* e, const fs2_outputs* out, void* stream) {
                       (last && fuse_pe) ? e->pe : nullptr, (last && fuse_pe) ? e->spk : nullptr, yA, idx, B, T, (int)H,
                       e->forced_idx[v]};
         if (launch_bucket_embed(ba, e->dt, st) != FS2_OK) return fail(e, FS2_ERR_HIP, "bucket_embed launch failed");
-        if (out->variances[v]) HIPCHK(e, hipMemcpyAsync(out->variances[v], vpred[v], MT * 4, hipMemcpyDeviceToDevice, st));
     }
     if (e->debug) CHK(tap_store(e, st, "adaptor_out", yA, MT * H, e->dt));
     if (!fuse_pe || c.n_variances == 0) {  // y = (x + pe) + spk               fastspeech2.py:705-718
@@ -821,10 +825,9 @@ int fs2_decode(fs2_engine* e, const fs2_outputs* out, void* stream) {
         if (launch_bucket_embed(ba, e->dt, st) != FS2_OK) return fail(e, FS2_ERR_HIP, "pe/spk add launch failed");
     }
     for (int i = 0; i < c.dec_layers; ++i)                                   // fastspeech2.py:719-721
-        CHK(conformer(e, st, e->dec[i], yA, yB, B, T, c.dec_heads, sc));
+        CHK(conformer(e, st, e->dec[i], yA, yB, B, T, c.dec_heads, sc, true));
     if (e->debug) CHK(tap_store(e, st, "decoder_out", yA, MT * H, e->dt));
     if (out->mel) CHK(gemm(e, st, e->mel, yA, out->mel, (int)MT, (int)MT, false, FS2_F32));  // fastspeech2.py:723
-    if (out->tgt_mask) HIPCHK(e, hipMemcpyAsync(out->tgt_mask, tmask, MT, hipMemcpyDeviceToDevice, st));
     for (int v = 0; v < FS2_MAX_VARIANCES; ++v) e->forced_idx[v] = nullptr;  // one-shot
     return FS2_OK;
 }

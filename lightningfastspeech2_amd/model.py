@@ -106,26 +106,34 @@ class Engine:
         self._keep = getattr(self, "_keep", []) + [idx]
         _lib.check(self.lib.fs2_force_buckets(self.handle, var_index, _ptr(idx)), self.handle, "force_buckets")
 
-    def decode(self, want_aux: bool = True) -> Dict[str, torch.Tensor]:
-        B, L, T = self._last
+    def alloc_outputs(self, B: int, L: int, T: int, want_aux: bool = True) -> Dict[str, torch.Tensor]:
+        """Fresh output tensors for a (B, L, T) forward (the reference returns fresh tensors too)."""
         dev = self.device
-        out = _lib.Fs2OutputsC()
         res = {"mel": torch.empty(B, T, self.cfg.n_mels, dtype=torch.float32, device=dev)}
-        out.mel = res["mel"].data_ptr()
         if want_aux:
             res["duration_prediction"] = torch.empty(B, L, dtype=torch.float32, device=dev)
             res["duration_rounded"] = torch.empty(B, L, dtype=torch.int32, device=dev)
             res["src_mask"] = torch.empty(B, L, dtype=torch.bool, device=dev)
             res["tgt_mask"] = torch.empty(B, T, dtype=torch.bool, device=dev)
+            for var in self.cfg.variances:
+                res[f"variances_{var}"] = torch.empty(B, T, dtype=torch.float32, device=dev)
+        return res
+
+    def decode(self, want_aux: bool = True, outputs: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+        B, L, T = self._last
+        res = outputs
+        if res is None or tuple(res["mel"].shape) != (B, T, self.cfg.n_mels):
+            res = self.alloc_outputs(B, L, T, want_aux)
+        out = _lib.Fs2OutputsC()
+        out.mel = res["mel"].data_ptr()
+        if "tgt_mask" in res:
             out.duration_prediction = res["duration_prediction"].data_ptr()
             out.duration_rounded = res["duration_rounded"].data_ptr()
             out.src_mask = res["src_mask"].data_ptr()
             out.tgt_mask = res["tgt_mask"].data_ptr()
             for i, var in enumerate(self.cfg.variances):
-                t = torch.empty(B, T, dtype=torch.float32, device=dev)
-                res[f"variances_{var}"] = t
-                out.variances[i] = t.data_ptr()
-        with torch.cuda.device(dev):
+                out.variances[i] = res[f"variances_{var}"].data_ptr()
+        with torch.cuda.device(self.device):
             st = self.lib.fs2_decode(self.handle, C.byref(out), self._stream())
         _lib.check(st, self.handle, "decode")
         self._keep = []
@@ -179,6 +187,7 @@ class FastSpeech2:
         self.engine = Engine(cfg, state_dict, precision=precision, device=device)
         self.device = self.engine.device
         self.training = False
+        self._t_guess = {}
 
     # ---- reference-style construction from a Lightning checkpoint dict (fastspeech2.py:530-634) --
     @classmethod
@@ -227,13 +236,22 @@ class FastSpeech2:
         forced = None
         if force_durations is not None:
             forced = torch.as_tensor(force_durations).to(self.device, dtype=torch.int32).contiguous()
+        # Output buffers are allocated BEFORE the forward's one host sync (inside fs2_encode), sized
+        # with the frame count of the previous call: in steady state (same T) the allocator work
+        # overlaps the encoder instead of sitting between the two phases; a different T just
+        # allocates again.  Fresh tensors every call, like the reference.
+        B, L = phones.shape
+        guess = self._t_guess.get((B, L))
+        pre = self.engine.alloc_outputs(B, L, guess) if guess else None
         T = self.engine.encode(phones, speaker, forced)
+        self._t_guess[(B, L)] = T
         for var, idx in (force_buckets or {}).items():
             idx = torch.as_tensor(idx).to(self.device, dtype=torch.int32).contiguous()
             if tuple(idx.shape) != (phones.shape[0], T):
                 raise ValueError(f"force_buckets[{var!r}] must be (B, T)=({phones.shape[0]}, {T})")
             self.engine.force_buckets(self.cfg.variances.index(var), idx)
+        res = self.engine.decode(outputs=pre)
         _, guard = self.engine.totals()
         for _ in range(int(guard.sum())):
             print("Zero duration, setting to 1")  # the reference's one stdout side effect (model.py:309)
-        return self.engine.decode()
+        return res
