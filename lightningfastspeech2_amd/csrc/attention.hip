@@ -48,6 +48,23 @@ __device__ inline int unswz_slot(int row, int ps) {
     else return ps ^ ((row >> 3) & 1);
 }
 
+// Row-major V tile read with ds_read_b64_tr_b16 (bf16 path): a 16-lane group fetches a
+// 4 (keys) x 16 (dv) block and every lane receives one dv column = 4 consecutive keys.  The four
+// key rows of a block sit 1 row apart (same banks when a row is >= 256 B), so the 16-byte slot is
+// XORed with a function of (key & 3) that spreads them over the 256-byte bank window.
+template <int RB>
+__device__ inline int vswz(int row) {
+    constexpr int NS = RB / 16;
+    if constexpr (NS >= 16) return (row & 3) << 2;
+    else if constexpr (NS == 8) return ((row >> 1) & 1) << 2;
+    else return 0;
+}
+typedef __attribute__((ext_vector_type(4))) short tr_s4;
+__device__ inline uint2 tr_read_b64(const unsigned char* lds_addr) {  // lane i of a 16-group -> column i
+    const tr_s4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) tr_s4*)lds_addr);
+    return *(const uint2*)&v;
+}
+
 template <typename T, int D, int NW>
 __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128) ? 2 : 1) void attention_kernel(AttnArgs p) {
     constexpr int KVB = sizeof(T) == 2 ? 64 : 32;      // keys per tile
@@ -62,6 +79,7 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128) ? 2 : 1) void
     constexpr int TILE_B = 128 * D;                    // bytes of a K tile == bytes of a Vt tile
     constexpr int NINST = TILE_B / 1024 / NW;          // 1-KiB DMA instructions per wave per tile
     constexpr float THR = sizeof(T) == 2 ? 6.0f : 0.0f;  // defer-max threshold (log2 units), exact in fp32
+    constexpr bool TRV = sizeof(T) == 2;  // bf16: V stays row-major (straight from qkv), hardware transpose read
     static_assert(TILE_B % (1024 * NW) == 0, "tile must split into whole wave DMAs");
 
     __shared__ __attribute__((aligned(16))) unsigned char sK[TILE_B];
@@ -113,8 +131,15 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128) ? 2 : 1) void
         for (int i = 0; i < NINST; ++i) {
             const int g = i * NW + wave;
             const int P = g * 64 + lane;
-            const int row = P >> 3, ps = P & 7;
-            glds16(vbase + (size_t)row * p.Spad + kv0 + unswz_slot<VRB>(row, ps) * E16, sV + g * 1024);
+            if constexpr (TRV) {  // [key][dv] rows of the packed qkv, like K but at column 2H
+                const int row = P / KNS, ps = P % KNS;
+                int key = kv0 + row;
+                if (key >= p.S) key = p.S - 1;
+                glds16(kbase + p.H + (size_t)key * ld + (ps ^ vswz<KRB>(row)) * E16, sV + g * 1024);
+            } else {
+                const int row = P >> 3, ps = P & 7;
+                glds16(vbase + (size_t)row * p.Spad + kv0 + unswz_slot<VRB>(row, ps) * E16, sV + g * 1024);
+            }
         }
     };
 
@@ -215,13 +240,33 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128) ? 2 : 1) void
         __syncthreads();   // V^T_j landed; every wave is done reading sK
         if (jn < ntiles) issue_k(jn);  // next K streams in underneath P.V
         // ---- O^T += V^T P^T ----
+        if constexpr (TRV) {
+            // lane (dv = lane&31, hi): elements 0..3 <- keys ch*16 + 4hi + 0..3, 4..7 <- +8: the same
+            // k-slot <-> key map the P registers carry
+            const int i16 = lane & 15, g1 = (lane >> 4) & 1;
+            const int rsub = i16 >> 2;                      // key row inside the 4-row block (== key & 3)
+            const int rowb = (4 * hi + rsub) * KRB + (i16 & 1) * 8;
 #pragma unroll
-        for (int nd = 0; nd < ND; ++nd)
+            for (int nd = 0; nd < ND; ++nd) {
+                const int slot = (nd * 4 + g1 * 2 + ((i16 & 3) >> 1)) ^ vswz<KRB>(rsub);
+                const unsigned char* vb = sV + rowb + (slot << 4);
 #pragma unroll
-            for (int ch = 0; ch < 4; ++ch) {
-                const uint4 vf = *(const uint4*)(sV + swz_row<VRB>(nd * 32 + li, ch * 2 + hi));
-                Mma32<T>::step(vf, pf[ch], oacc[nd]);
+                for (int ch = 0; ch < 4; ++ch) {
+                    const uint2 lo = tr_read_b64(vb + ch * 16 * KRB);
+                    const uint2 hi2 = tr_read_b64(vb + (ch * 16 + 8) * KRB);
+                    const uint4 vf = make_uint4(lo.x, lo.y, hi2.x, hi2.y);
+                    Mma32<T>::step(vf, pf[ch], oacc[nd]);
+                }
             }
+        } else {
+#pragma unroll
+            for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch) {
+                    const uint4 vf = *(const uint4*)(sV + swz_row<VRB>(nd * 32 + li, ch * 2 + hi));
+                    Mma32<T>::step(vf, pf[ch], oacc[nd]);
+                }
+        }
         j = jn;
     }
 
@@ -298,6 +343,7 @@ static int launch_td(const AttnArgs& a, hipStream_t stream) {
 
 int launch_transpose_v(const AttnArgs& a, int dtype, hipStream_t stream) {
     if (a.B <= 0 || a.S <= 0) return FS2_OK;
+    if (dtype == FS2_BF16) return FS2_OK;  // bf16 attention reads V row-major with the hardware transpose read
     if (a.Spad % 64 || a.Spad < a.S || a.H % a.heads) return FS2_ERR_SHAPE;
     const int d = a.H / a.heads;
 #define FS2_TV_CASE(DD)                                                          \
