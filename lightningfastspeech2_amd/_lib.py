@@ -14,7 +14,8 @@ import re
 import torch  # noqa: F401  (must precede the dlopen below)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfs2_hip.so")
+# FS2_LIB: alternative build of the same ABI (kernel A/B experiments); default = the in-tree library
+LIB_PATH = os.environ.get("FS2_LIB") or os.path.join(_HERE, "libfs2_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "fs2.h")
 
 FS2_ABI_VERSION = 1

@@ -1,0 +1,13 @@
+#!/bin/bash
+# Build libfs2_hip.so variants for A/B runs: tools/build_variant.sh NAME path/to/attention.hip [path/to/gemm_mfma.hip]
+# -> gpurun_out is not shipped; variants go to lightningfastspeech2_amd/variants/libfs2_NAME.so (git-ignored *.so)
+set -e
+NAME=$1; ATT=${2:-lightningfastspeech2_amd/csrc/attention.hip}; GEMM=${3:-lightningfastspeech2_amd/csrc/gemm_mfma.hip}
+D=lightningfastspeech2_amd/csrc; V=lightningfastspeech2_amd/variants; mkdir -p $V/obj_$NAME
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$D"
+/opt/rocm/bin/hipcc $FLAGS -c $ATT -o $V/obj_$NAME/attention.o &
+/opt/rocm/bin/hipcc $FLAGS -c $GEMM -o $V/obj_$NAME/gemm_mfma.o &
+wait
+for f in rowops capi_ops engine; do [ -f $D/$f.o ] || /opt/rocm/bin/hipcc $FLAGS -c $D/$f.hip -o $D/$f.o; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $V/libfs2_$NAME.so $V/obj_$NAME/attention.o $V/obj_$NAME/gemm_mfma.o $D/rowops.o $D/capi_ops.o $D/engine.o
+echo built $V/libfs2_$NAME.so
