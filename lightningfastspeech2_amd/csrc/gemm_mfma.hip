@@ -761,6 +761,11 @@ static int launch_gemm_plain(const GemmArgs& a, int in_dtype, int out_dtype, hip
     const int variant = g_gemm_variant;  // 0 = auto, 1 = 128x128 register-staged, 2 = 128x256 DMA ring,
                                          // 3/4/5 = slab kernel with 128/192/256-row tiles
     const bool slab_ok = a.M % a.S == 0 && (a.taps & 1);
+    if (variant >= 6 && variant <= 7 && slab_ok) {  // 6/7 = slab kernel with 32/64-row tiles
+        if (fused) *fused = true;
+        if (variant == 6) return launch_slab<1>(a, in_dtype, out_dtype, stream);
+        return launch_slab<2>(a, in_dtype, out_dtype, stream);
+    }
     if (variant >= 3 && variant <= 5 && slab_ok && !(fused && variant == 5)) {
         if (fused) *fused = true;
         if (variant == 3) return launch_slab<4>(a, in_dtype, out_dtype, stream);
@@ -782,13 +787,18 @@ static int launch_gemm_plain(const GemmArgs& a, int in_dtype, int out_dtype, hip
         const int S = a.taps == 1 ? a.M : a.S, nutt = a.M / S, tn = (a.N + S_BN - 1) / S_BN;
         int best = 0;
         long best_cost = 0, best_rows = 0;
-        for (int mi = 4; mi <= (fused ? 6 : 8); mi += 2) {
+        static const int kHeights[5] = {1, 2, 4, 6, 8};  // x32 rows; 32/64-row tiles keep small-M launches
+        for (int hi = 0; hi < 5; ++hi) {                  // (the encoder's) spread over all CUs
+            const int mi = kHeights[hi];
+            if (fused && mi > 6) continue;
             const long bm = mi * 32, tm = (S + bm - 1) / bm, tiles = (long)nutt * tm * tn;
             const long cost = ((tiles + 255) / 256) * (bm + 40);
             if (!best || cost < best_cost) { best = mi; best_cost = cost; best_rows = (long)nutt * tm * bm; }
         }
         if (best_rows <= 2L * a.M) {
             if (fused) *fused = true;
+            if (best == 1) return launch_slab<1>(a, in_dtype, out_dtype, stream);
+            if (best == 2) return launch_slab<2>(a, in_dtype, out_dtype, stream);
             if (best == 4) return launch_slab<4>(a, in_dtype, out_dtype, stream);
             if (best == 6) return launch_slab<6>(a, in_dtype, out_dtype, stream);
             return launch_slab<8>(a, in_dtype, out_dtype, stream);

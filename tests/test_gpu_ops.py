@@ -27,7 +27,8 @@ def rnd(*shape, seed=0, scale=1.0):
     return torch.randn(*shape, generator=g) * scale
 
 
-@pytest.fixture(params=[1, 2, 3, 4, 5], ids=["gemm128x128", "gemm128x256dma", "slab128", "slab192", "slab256"])
+@pytest.fixture(params=[1, 2, 3, 4, 5, 6, 7],
+                ids=["gemm128x128", "gemm128x256dma", "slab128", "slab192", "slab256", "slab32", "slab64"])
 def gemm_variant(request):
     """Run every GEMM/conv case on BOTH kernels (the engine picks by problem size)."""
     G.lib().fs2_op_set_gemm_variant(request.param)
@@ -80,7 +81,7 @@ def test_gemm_conv_same_padding_per_utterance(dtype, B, S, Cin, N, k, gemm_varia
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("variant", [0, 1, 3, 4], ids=["auto", "unfused128x128", "slab128", "slab192"])
+@pytest.mark.parametrize("variant", [0, 1, 3, 4, 6, 7], ids=["auto", "unfused128x128", "slab128", "slab192", "slab32", "slab64"])
 @pytest.mark.parametrize("B,S,Cin,N,k,relu,use_res", [(3, 200, 256, 256, 3, True, False), (2, 333, 1024, 256, 1, False, True),
                                                      (2, 70, 64, 192, 5, True, True), (1, 1536, 256, 256, 9, False, True),
                                                      (2, 50, 768, 768, 1, False, True)])

@@ -74,7 +74,7 @@ def main():
         g0, a0 = gemm_case, attn_case
         gemm_case = lambda name, *r: g0(name, *r) if a.only in name else None
         attn_case = lambda name, *r: a0(name, *r) if a.only in name else None
-    variants = [0, 2, 3, 4, 5] if a.variant < 0 else [a.variant]
+    variants = [0, 3, 4, 5, 6, 7] if a.variant < 0 else [a.variant]
     if a.what in ("gemm", "all"):
         for v in variants:
             gemm_case("dec conv1 k=9", 49152, 1024, 256, 9, 1536, a.reps, v)
@@ -85,6 +85,9 @@ def main():
             gemm_case("dec out_proj", 49152, 256, 256, 1, 49152, a.reps, v)
             gemm_case("enc conv1 k=9", 8192, 1024, 256, 9, 256, a.reps, v)
             gemm_case("enc conv2 1x1", 8192, 256, 1024, 1, 8192, a.reps, v)
+            gemm_case("enc out_proj", 8192, 256, 256, 1, 8192, a.reps, v)
+            gemm_case("enc in_proj", 8192, 768, 256, 1, 8192, a.reps, v)
+            gemm_case("dur-pred conv k=3", 8192, 256, 256, 3, 256, a.reps, v)
             gemm_case("square 4096^3", 4096, 4096, 4096, 1, 4096, a.reps, v)
     if a.what in ("attn", "all"):
         attn_case("decoder attention", 32, 1536, 256, 2, a.reps)
