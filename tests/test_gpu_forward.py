@@ -207,3 +207,39 @@ def test_rejects_training_forward_and_bad_ids():
     bad[0, 0] = g.cfg.n_phones
     with pytest.raises(IndexError):
         m({"phones": bad, "speaker": batch["speaker"]}, inference=True)
+
+
+def test_one_engine_many_shapes_and_checkpoint_roundtrip(tmp_path):
+    """The same engine serves batches of changing (B, L, T) (arena regrowth, output pre-allocation
+    guess misses) and gives the same answer as a fresh engine; a Lightning-style checkpoint dict
+    (state_dict + hyper_parameters + stats + phone2id, fastspeech2.py:622-634) loads through
+    FastSpeech2.from_checkpoint."""
+    from lightningfastspeech2_amd.model import FastSpeech2
+    g = Golden("mid_dense_d128")
+    sd = g.state_dict()
+    ckpt = {
+        "state_dict": {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()},
+        "hyper_parameters": {**{k: v for k, v in g.cfg.to_dict().items() if k not in ("stats", "n_phones")},
+                             "lr": 1e-4, "fastdiff_variances": False},  # extra keys are ignored
+        "stats": g.cfg.stats,
+        "phone2id": {f"p{i}": i for i in range(g.cfg.n_phones)},
+        "speaker2dvector": {"spk": g.speaker[0]},
+    }
+    path = tmp_path / "lit_model.ckpt"
+    torch.save(ckpt, path)
+    m = FastSpeech2.from_checkpoint(str(path), precision="fp32", device="cuda:0")
+    assert m.hparams.encoder_hidden == g.cfg.hidden and len(m.phone2id) == g.cfg.n_phones
+    out = _cpu(m({"phones": torch.from_numpy(g.phones), "speaker": torch.from_numpy(g.speaker)}, inference=True))
+    assert float(np.abs(out["mel"].numpy() - g.out["mel"]).max()) <= MEL_TOL_FP32
+    # other shapes through the same engine, then the first batch again
+    for B, L, seed in ((5, 40, 1), (1, 7, 2), (3, 90, 3)):
+        inp = synth_inputs(g.cfg, B, L, seed=seed, lengths=[L] + [max(1, L // (i + 2)) for i in range(B - 1)])
+        ref = oracle_cpu.forward(sd, g.cfg, inp["phones"], inp["speaker"])
+        o = _cpu(m({"phones": torch.from_numpy(inp["phones"]), "speaker": torch.from_numpy(inp["speaker"])}, inference=True))
+        assert tuple(o["mel"].shape) == tuple(ref["mel"].shape)
+        if torch.equal(o["duration_rounded"], ref["duration_rounded"]):
+            mism = sum(int((o[f"variances_{v}"] - ref[f"variances_{v}"]).abs().max() > 1e-3) for v in g.cfg.variances)
+            if mism == 0:
+                assert float((o["mel"] - ref["mel"]).abs().max()) <= 5e-2  # free-running: a near-tie bucket may flip
+    again = _cpu(m({"phones": torch.from_numpy(g.phones), "speaker": torch.from_numpy(g.speaker)}, inference=True))
+    assert torch.equal(again["mel"], out["mel"])
