@@ -65,8 +65,13 @@ __device__ inline uint2 tr_read_b64(const unsigned char* lds_addr) {  // lane i 
     return *(const uint2*)&v;
 }
 
-template <typename T, int D, int NW>
-__global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128) ? 2 : 1) void attention_kernel(AttnArgs p) {
+// NW = waves along the queries (32 each), KS = waves along the keys: with KS = 2 the upper half of
+// the workgroup's waves processes the second half of the KV tiles with its own LDS buffers and the
+// two partial (m, l, O) states are merged through LDS at the end.  Same DMA traffic per query, but
+// twice as many half-length wave tasks: 768 x 8-wave workgroups on 256 CUs are exactly 3 rounds,
+// where 768 x 4-wave workgroups on 512 slots left a half-empty second round.
+template <typename T, int D, int NW, int KS>
+__global__ __launch_bounds__(NW * KS * 64, (sizeof(T) == 2 && D == 128 && KS == 1) ? 2 : 1) void attention_kernel(AttnArgs p) {
     constexpr int KVB = sizeof(T) == 2 ? 64 : 32;      // keys per tile
     constexpr int E16 = Num<T>::kPer16B;
     constexpr int KC = Mma32<T>::K_PER_CHUNK;          // k-values per 2x16B chunk
@@ -82,11 +87,16 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128) ? 2 : 1) void
     constexpr bool TRV = sizeof(T) == 2;  // bf16: V stays row-major (straight from qkv), hardware transpose read
     static_assert(TILE_B % (1024 * NW) == 0, "tile must split into whole wave DMAs");
 
-    __shared__ __attribute__((aligned(16))) unsigned char sK[TILE_B];
-    __shared__ __attribute__((aligned(16))) unsigned char sV[TILE_B];
+    __shared__ __attribute__((aligned(16))) unsigned char sKa[TILE_B];
+    __shared__ __attribute__((aligned(16))) unsigned char sVa[TILE_B];
+    __shared__ __attribute__((aligned(16))) unsigned char sKb[KS == 2 ? TILE_B : 16];
+    __shared__ __attribute__((aligned(16))) unsigned char sVb[KS == 2 ? TILE_B : 16];
+    __shared__ float sml[KS == 2 ? 2 * NW * 64 : 1];
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = wave_all % NW;   // query group (also this wave's share of its half's tile DMAs)
+    const int kh = wave_all / NW;     // which half of the KV tiles
     const int li = lane & 31, hi = lane >> 5;
     // XCD-aware mapping: workgroup id % 8 is the XCD it lands on (observed dispatch order); all
     // query blocks of one (utterance, head) share its K/V, so keep them on one XCD's L2.
@@ -113,7 +123,7 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128) ? 2 : 1) void
         while (j < ntiles && tile_bits(j) == 0ull) ++j;
         return j;
     };
-    auto issue_k = [&](int j) {
+    auto issue_k = [&](int j, unsigned char* sK) {
         const int kv0 = j * KVB;
 #pragma unroll
         for (int i = 0; i < NINST; ++i) {
@@ -125,7 +135,7 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128) ? 2 : 1) void
             glds16(kbase + (size_t)key * ld + unswz_slot<KRB>(row, ps) * E16, sK + g * 1024);
         }
     };
-    auto issue_v = [&](int j) {
+    auto issue_v = [&](int j, unsigned char* sV) {
         const int kv0 = j * KVB;
 #pragma unroll
         for (int i = 0; i < NINST; ++i) {
@@ -143,8 +153,6 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128) ? 2 : 1) void
         }
     };
 
-    int j = next_tile(0);
-    if (j < ntiles) issue_k(j);
 
     // ---- Q fragments (column operand of S^T = K Q^T) ----
     uint4 qf[NQC];
@@ -164,110 +172,145 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128) ? 2 : 1) void
     float m_run = -INFINITY, l_run = 0.f;  // running max (scaled, log2 units) and denominator
     const float sc = p.scale_log2e;
 
-    while (j < ntiles) {
-        const unsigned long long bits = tile_bits(j);
-        const int jn = next_tile(j + 1);
-        __syncthreads();   // K_j landed (the compiler drains this wave's DMA before the barrier);
-                           // every wave is done with P.V of the previous tile -> sV is free
-        issue_v(j);        // V^T_j streams in underneath Q.K^T
+    // This half's tile range; all halves run the same number of (two-barrier) iterations.
+    const int nhalf = (ntiles + KS - 1) / KS;
+    const int jbeg = kh * nhalf, jend = (jbeg + nhalf < ntiles) ? jbeg + nhalf : ntiles;
+    auto run = [&](unsigned char* sK, unsigned char* sV) {
+        if (jbeg < jend && tile_bits(jbeg) != 0ull) issue_k(jbeg, sK);
+        for (int it = 0; it < nhalf; ++it) {
+            const int j = jbeg + it;
+            const unsigned long long bits = j < jend ? tile_bits(j) : 0ull;
+            const bool valid = bits != 0ull;  // fully padded tiles cost two barriers, nothing else
+            __syncthreads();   // K_j landed (hipcc drains this wave's DMA before the barrier); every
+                               // wave is done with P.V of the previous tile -> sV is free
+            if (valid) issue_v(j, sV);  // V_j streams in underneath Q.K^T
+            uint4 pf[4];
+            if (valid) {
+            // ---- S^T = K Q^T ----
+            f32x16_t sacc[NKB];
+    #pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+    #pragma unroll
+                for (int c = 0; c < NQC; ++c) {
+                    const uint4 kf = *(const uint4*)(sK + swz_row<KRB>(kb * 32 + li, c * 2 + hi));
+                    Mma32<T>::step(kf, qf[c], sacc[kb]);
+                }
+            }
+            // ---- key-padding mask (only tiles that contain a padded key pay for it) ----
+            const unsigned long long full = KVB == 64 ? ~0ull : 0xffffffffull;
+            if (bits != full) {
+    #pragma unroll
+                for (int kb = 0; kb < NKB; ++kb)
+    #pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ko = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        if (!((bits >> ko) & 1ull)) sacc[kb][r] = -INFINITY;
+                    }
+            }
+            // ---- online softmax, base 2, scale folded into the exponent's FMA ----
+            float mx = sacc[0][0];
+    #pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sc;
+            if (__any(mx > m_run + THR)) {  // some row's max grew past the threshold: rescale (wave-uniform)
+                const float m_new = fmaxf(m_run, mx);
+                const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);  // m_run = -inf -> 0
+                l_run *= alpha;
+    #pragma unroll
+                for (int i = 0; i < ND; ++i)
+    #pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+                m_run = m_new;
+            }
+            const float m_neg = (m_run == -INFINITY) ? 0.f : -m_run;
+            float rs = 0.f;
+    #pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], sc, m_neg));
+                    sacc[kb][r] = e;
+                    rs += e;
+                }
+            rs += __shfl_xor(rs, 32, 64);
+            l_run += rs;
 
-        // ---- S^T = K Q^T ----
-        f32x16_t sacc[NKB];
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
-#pragma unroll
-            for (int c = 0; c < NQC; ++c) {
-                const uint4 kf = *(const uint4*)(sK + swz_row<KRB>(kb * 32 + li, c * 2 + hi));
-                Mma32<T>::step(kf, qf[c], sacc[kb]);
+            // ---- P fragments (column operand), straight from the lane's own registers ----
+    #pragma unroll
+            for (int ch = 0; ch < 4; ++ch) {
+                float f[Vec16<T>::N];
+    #pragma unroll
+                for (int e = 0; e < Vec16<T>::N; ++e) {
+                    const int flat = ch * Vec16<T>::N + e;
+                    f[e] = sacc[flat >> 4][flat & 15];
+                }
+                pf[ch] = Vec16<T>::pack(f);
+            }
+            }
+            __syncthreads();   // V_j landed; every wave is done reading sK
+            if (j + 1 < jend && tile_bits(j + 1) != 0ull) issue_k(j + 1, sK);  // next K under P.V
+            if (valid) {
+            // ---- O^T += V^T P^T ----
+            if constexpr (TRV) {
+                // lane (dv = lane&31, hi): elements 0..3 <- keys ch*16 + 4hi + 0..3, 4..7 <- +8: the same
+                // k-slot <-> key map the P registers carry
+                const int i16 = lane & 15, g1 = (lane >> 4) & 1;
+                const int rsub = i16 >> 2;                      // key row inside the 4-row block (== key & 3)
+                const int rowb = (4 * hi + rsub) * KRB + (i16 & 1) * 8;
+    #pragma unroll
+                for (int nd = 0; nd < ND; ++nd) {
+                    const int slot = (nd * 4 + g1 * 2 + ((i16 & 3) >> 1)) ^ vswz<KRB>(rsub);
+                    const unsigned char* vb = sV + rowb + (slot << 4);
+    #pragma unroll
+                    for (int ch = 0; ch < 4; ++ch) {
+                        const uint2 lo = tr_read_b64(vb + ch * 16 * KRB);
+                        const uint2 hi2 = tr_read_b64(vb + (ch * 16 + 8) * KRB);
+                        const uint4 vf = make_uint4(lo.x, lo.y, hi2.x, hi2.y);
+                        Mma32<T>::step(vf, pf[ch], oacc[nd]);
+                    }
+                }
+            } else {
+    #pragma unroll
+                for (int nd = 0; nd < ND; ++nd)
+    #pragma unroll
+                    for (int ch = 0; ch < 4; ++ch) {
+                        const uint4 vf = *(const uint4*)(sV + swz_row<VRB>(nd * 32 + li, ch * 2 + hi));
+                        Mma32<T>::step(vf, pf[ch], oacc[nd]);
+                    }
+            }
             }
         }
-        // ---- key-padding mask (only tiles that contain a padded key pay for it) ----
-        const unsigned long long full = KVB == 64 ? ~0ull : 0xffffffffull;
-        if (bits != full) {
-#pragma unroll
-            for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ko = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (!((bits >> ko) & 1ull)) sacc[kb][r] = -INFINITY;
-                }
-        }
-        // ---- online softmax, base 2, scale folded into the exponent's FMA ----
-        float mx = sacc[0][0];
-#pragma unroll
-        for (int kb = 0; kb < NKB; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sc;
-        if (__any(mx > m_run + THR)) {  // some row's max grew past the threshold: rescale (wave-uniform)
-            const float m_new = fmaxf(m_run, mx);
-            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);  // m_run = -inf -> 0
-            l_run *= alpha;
+    };
+    if (KS == 1 || kh == 0) run(sKa, sVa); else run(sKb, sVb);
+
+    if constexpr (KS == 2) {
+        // ---- merge the two KV halves: the upper half hands (m, l, O) to its partner through LDS ----
+        __syncthreads();  // every wave is done with the tile buffers
+        float* xo = (float*)(wave == 0 ? sKa : wave == 1 ? sVa : wave == 2 ? sKb : sVb);  // 16 KiB per query group
+        if (kh == 1) {
+            sml[wave * 64 + lane] = m_run;
+            sml[(NW + wave) * 64 + lane] = l_run;
 #pragma unroll
             for (int i = 0; i < ND; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
-            m_run = m_new;
+                for (int r = 0; r < 16; ++r) xo[(i * 16 + r) * 64 + lane] = oacc[i][r];
         }
-        const float m_neg = (m_run == -INFINITY) ? 0.f : -m_run;
-        float rs = 0.f;
+        __syncthreads();
+        if (kh == 1) return;
+        const float m1 = sml[wave * 64 + lane], l1 = sml[(NW + wave) * 64 + lane];
+        const float mm = fmaxf(m_run, m1);
+        const float mu = (mm == -INFINITY) ? 0.f : mm;
+        const float a0 = __builtin_amdgcn_exp2f(m_run - mu), a1 = __builtin_amdgcn_exp2f(m1 - mu);
+        l_run = l_run * a0 + l1 * a1;
 #pragma unroll
-        for (int kb = 0; kb < NKB; ++kb)
+        for (int i = 0; i < ND; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], sc, m_neg));
-                sacc[kb][r] = e;
-                rs += e;
-            }
-        rs += __shfl_xor(rs, 32, 64);
-        l_run += rs;
-
-        // ---- P fragments (column operand), straight from the lane's own registers ----
-        uint4 pf[4];
-#pragma unroll
-        for (int ch = 0; ch < 4; ++ch) {
-            float f[Vec16<T>::N];
-#pragma unroll
-            for (int e = 0; e < Vec16<T>::N; ++e) {
-                const int flat = ch * Vec16<T>::N + e;
-                f[e] = sacc[flat >> 4][flat & 15];
-            }
-            pf[ch] = Vec16<T>::pack(f);
-        }
-        __syncthreads();   // V^T_j landed; every wave is done reading sK
-        if (jn < ntiles) issue_k(jn);  // next K streams in underneath P.V
-        // ---- O^T += V^T P^T ----
-        if constexpr (TRV) {
-            // lane (dv = lane&31, hi): elements 0..3 <- keys ch*16 + 4hi + 0..3, 4..7 <- +8: the same
-            // k-slot <-> key map the P registers carry
-            const int i16 = lane & 15, g1 = (lane >> 4) & 1;
-            const int rsub = i16 >> 2;                      // key row inside the 4-row block (== key & 3)
-            const int rowb = (4 * hi + rsub) * KRB + (i16 & 1) * 8;
-#pragma unroll
-            for (int nd = 0; nd < ND; ++nd) {
-                const int slot = (nd * 4 + g1 * 2 + ((i16 & 3) >> 1)) ^ vswz<KRB>(rsub);
-                const unsigned char* vb = sV + rowb + (slot << 4);
-#pragma unroll
-                for (int ch = 0; ch < 4; ++ch) {
-                    const uint2 lo = tr_read_b64(vb + ch * 16 * KRB);
-                    const uint2 hi2 = tr_read_b64(vb + (ch * 16 + 8) * KRB);
-                    const uint4 vf = make_uint4(lo.x, lo.y, hi2.x, hi2.y);
-                    Mma32<T>::step(vf, pf[ch], oacc[nd]);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int nd = 0; nd < ND; ++nd)
-#pragma unroll
-                for (int ch = 0; ch < 4; ++ch) {
-                    const uint4 vf = *(const uint4*)(sV + swz_row<VRB>(nd * 32 + li, ch * 2 + hi));
-                    Mma32<T>::step(vf, pf[ch], oacc[nd]);
-                }
-        }
-        j = jn;
+            for (int r = 0; r < 16; ++r) oacc[i][r] = oacc[i][r] * a0 + xo[(i * 16 + r) * 64 + lane] * a1;
     }
 
     // ---- normalise and store: lane owns query li, dv = nd*32 + (r&3) + 8*(r>>2) + 4*hi ----
@@ -327,16 +370,25 @@ static int launch_tv(const AttnArgs& a, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
 }
 
+int g_attn_kv_split = 0;
+
 template <typename T, int D>
 static int launch_td(const AttnArgs& a, hipStream_t stream) {
     const int BH = a.B * a.heads, BH8 = (BH + 7) / 8 * 8;
     // grid = ceil(BH/8)*8 * nq, decoded XCD-aware in the kernel.  Small sequences: 2-wave
     // workgroups so the grid still covers the 256 CUs.
     const long blocks4 = (long)((a.S + 127) / 128) * BH;
-    if (blocks4 >= 512) {
-        hipLaunchKernelGGL((attention_kernel<T, D, 4>), dim3(((a.S + 127) / 128) * BH8), dim3(256), 0, stream, a);
+    constexpr int KVBh = sizeof(T) == 2 ? 64 : 32;
+    if (g_attn_kv_split && sizeof(T) == 2 && D == 128 && (a.S + KVBh - 1) / KVBh >= 8) {
+        // experimental: 8-wave workgroups (4 query groups x 2 KV halves), one per CU.  Measured 7 %
+        // SLOWER than two independent 4-wave workgroups per CU (all 8 waves share every barrier, so
+        // the halves run phase-locked instead of overlapping one workgroup's softmax with the
+        // other's MFMAs); kept selectable for A/B runs.
+        hipLaunchKernelGGL((attention_kernel<T, D, 4, 2>), dim3(((a.S + 127) / 128) * BH8), dim3(512), 0, stream, a);
+    } else if (blocks4 >= 512) {
+        hipLaunchKernelGGL((attention_kernel<T, D, 4, 1>), dim3(((a.S + 127) / 128) * BH8), dim3(256), 0, stream, a);
     } else {
-        hipLaunchKernelGGL((attention_kernel<T, D, 2>), dim3(((a.S + 63) / 64) * BH8), dim3(128), 0, stream, a);
+        hipLaunchKernelGGL((attention_kernel<T, D, 2, 1>), dim3(((a.S + 63) / 64) * BH8), dim3(128), 0, stream, a);
     }
     return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
 }
