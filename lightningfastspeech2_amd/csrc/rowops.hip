@@ -114,42 +114,79 @@ int launch_layernorm(const LayerNormArgs& a, int dtype, hipStream_t stream) {
 // =============================================================================================
 static constexpr int DW_TR = 64, DW_CT = 64, DW_KMAX = 31;
 
+// Workgroup = 64 rows x 64 channels of one utterance.  The (64 + k - 1) x 64 input slab and the
+// (k x 64) weights are staged in LDS as fp32, channel-contiguous; a thread owns 4 rows x 4
+// channels and walks the taps with one 16-byte weight read + four 16-byte input reads per 16 MACs.
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv_kernel(DwConvArgs p) {
-    __shared__ float tile[(DW_TR + DW_KMAX - 1) * DW_CT];
-    __shared__ float wl[DW_CT * DW_KMAX];
+    __shared__ __attribute__((aligned(16))) float tile[(DW_TR + DW_KMAX - 1) * DW_CT];
+    __shared__ __attribute__((aligned(16))) float wl[DW_KMAX * DW_CT];  // [tap][channel]
     const int tid = threadIdx.x;
     const int t0 = blockIdx.x * DW_TR, c0 = blockIdx.y * DW_CT, b = blockIdx.z;
     const T* x = (const T*)p.x + (size_t)b * p.S * p.C;
     const int rows = DW_TR + p.k - 1;
-    for (int i = tid; i < rows * DW_CT; i += 256) {
-        const int r = i / DW_CT, c = i % DW_CT;
+    const bool full_c = c0 + DW_CT <= p.C;
+    for (int i = tid; i < rows * (DW_CT / 4); i += 256) {  // 4 channels per load
+        const int r = i >> 4, cq = (i & 15) * 4;
         const int t = t0 + r - p.pad;
-        float v = 0.f;
-        if (t >= 0 && t < p.S && c0 + c < p.C) v = Num<T>::to_f32(x[(size_t)t * p.C + c0 + c]);
-        tile[i] = v;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (t >= 0 && t < p.S) {
+            if (full_c) {
+                load4<T>(x + (size_t)t * p.C + c0 + cq, v);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (c0 + cq + e < p.C) v[e] = Num<T>::to_f32(x[(size_t)t * p.C + c0 + cq + e]);
+            }
+        }
+        *(float4*)(tile + r * DW_CT + cq) = make_float4(v[0], v[1], v[2], v[3]);
     }
     for (int i = tid; i < DW_CT * p.k; i += 256) {
-        const int c = i / p.k, tap = i % p.k;
-        wl[c * p.k + tap] = (c0 + c < p.C) ? p.w[(size_t)(c0 + c) * p.k + tap] : 0.f;
+        const int tap = i / DW_CT, c = i % DW_CT;
+        wl[tap * DW_CT + c] = (c0 + c < p.C) ? p.w[(size_t)(c0 + c) * p.k + tap] : 0.f;
     }
     __syncthreads();
-    const int c = tid & 63, ry = tid >> 6;
-    if (c0 + c >= p.C) return;
-    const float bias = p.bias ? p.bias[c0 + c] : 0.f;
+    const int cq = (tid & 15) * 4, r0 = (tid >> 4) * 4;
+    float acc[4][4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[rr][e] = 0.f;
+    for (int tap = 0; tap < p.k; ++tap) {
+        const float4 w4 = *(const float4*)(wl + tap * DW_CT + cq);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const float4 x4 = *(const float4*)(tile + (r0 + rr + tap) * DW_CT + cq);
+            acc[rr][0] = fmaf(w4.x, x4.x, acc[rr][0]);
+            acc[rr][1] = fmaf(w4.y, x4.y, acc[rr][1]);
+            acc[rr][2] = fmaf(w4.z, x4.z, acc[rr][2]);
+            acc[rr][3] = fmaf(w4.w, x4.w, acc[rr][3]);
+        }
+    }
+    float bias[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) bias[e] = (p.bias && c0 + cq + e < p.C) ? p.bias[c0 + cq + e] : 0.f;
     T* y = (T*)p.y + (size_t)b * p.S * p.C;
-    for (int rr = ry; rr < DW_TR; rr += 4) {
-        const int t = t0 + rr;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        const int t = t0 + r0 + rr;
         if (t >= p.S) break;
-        float acc = 0.f;
-        for (int tap = 0; tap < p.k; ++tap) acc = fmaf(wl[c * p.k + tap], tile[(rr + tap) * DW_CT + c], acc);
-        y[(size_t)t * p.C + c0 + c] = Num<T>::from_f32(acc + bias);
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = acc[rr][e] + bias[e];
+        if (full_c) {
+            store4<T>(y + (size_t)t * p.C + c0 + cq, o);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c0 + cq + e < p.C) y[(size_t)t * p.C + c0 + cq + e] = Num<T>::from_f32(o[e]);
+        }
     }
 }
 
 int launch_dwconv(const DwConvArgs& a, int dtype, hipStream_t stream) {
     if (a.B <= 0 || a.S <= 0) return FS2_OK;
-    if (a.k < 1 || a.k > DW_KMAX) return FS2_ERR_SHAPE;
+    if (a.k < 1 || a.k > DW_KMAX || a.C % 4) return FS2_ERR_SHAPE;
     const dim3 grid((a.S + DW_TR - 1) / DW_TR, (a.C + DW_CT - 1) / DW_CT, a.B), block(256);
     if (dtype == FS2_BF16) hipLaunchKernelGGL(dwconv_kernel<bf16>, grid, block, 0, stream, a);
     else hipLaunchKernelGGL(dwconv_kernel<float>, grid, block, 0, stream, a);
