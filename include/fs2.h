@@ -71,6 +71,8 @@ typedef struct fs2_config {
     float var_std[FS2_MAX_VARIANCES];
     int32_t var_filter, var_nbins, var_depthwise;
     int32_t dur_nlayers, dur_kernel, dur_filter, dur_depthwise;
+    int32_t n_priors;      /* hparams.priors (default []): PriorEmbedding rows added after the encoder */
+    char prior_names[FS2_MAX_VARIANCES][FS2_NAME_LEN];
 } fs2_config;
 
 typedef struct fs2_engine fs2_engine;
@@ -106,6 +108,10 @@ int fs2_finalize(fs2_engine* e);
  * Synchronises the stream once to return T = min(max_b sum_l d[b,l], max_frames). */
 int fs2_encode(fs2_engine* e, const int64_t* phones, const float* speaker, int32_t B, int32_t L,
                const int32_t* forced_durations, void* hip_stream, int32_t* T_out);
+/* Utterance-level priors for the NEXT fs2_encode (one-shot): (n_priors, B) fp32 device values, row p
+ * = targets["priors_<prior_names[p]>"] (fastspeech2.py:687-692; PriorEmbedding, model.py:146-164).
+ * Required before every fs2_encode when n_priors > 0. */
+int fs2_set_priors(fs2_engine* e, const float* priors_device, int32_t B);
 /* Per-utterance frame totals (untruncated) and zero-duration-guard flags of the last fs2_encode. */
 int fs2_last_totals(const fs2_engine* e, int32_t* totals_host, int32_t* guard_host, int32_t B);
 /* Phase 2: length regulator + variance encoders + decoder + mel linear, into caller buffers. */

@@ -43,6 +43,8 @@ class Fs2ConfigC(C.Structure):
         ("var_std", C.c_float * FS2_MAX_VARIANCES),
         ("var_filter", C.c_int32), ("var_nbins", C.c_int32), ("var_depthwise", C.c_int32),
         ("dur_nlayers", C.c_int32), ("dur_kernel", C.c_int32), ("dur_filter", C.c_int32), ("dur_depthwise", C.c_int32),
+        ("n_priors", C.c_int32),
+        ("prior_names", (C.c_char * FS2_NAME_LEN) * FS2_MAX_VARIANCES),
     ]
 
 
@@ -93,6 +95,7 @@ def load():
     lib.fs2_finalize.argtypes = [vp]
     lib.fs2_encode.argtypes = [vp, vp, vp, i32, i32, vp, vp, C.POINTER(i32)]
     lib.fs2_last_totals.argtypes = [vp, vp, vp, i32]
+    lib.fs2_set_priors.argtypes = [vp, vp, i32]
     lib.fs2_decode.argtypes = [vp, C.POINTER(Fs2OutputsC), vp]
     lib.fs2_set_debug.argtypes = [vp, i32]
     lib.fs2_debug_copy.argtypes = [vp, C.c_char_p, vp, vp]
@@ -168,6 +171,11 @@ def config_to_c(cfg, dtype: int) -> Fs2ConfigC:
         c.var_std[i] = cfg.stats[v]["std"]
     c.var_filter, c.var_nbins = cfg.variance_filter_size, cfg.variance_nbins
     c.var_depthwise = int(cfg.variance_depthwise_conv)
+    if len(cfg.priors) > FS2_MAX_VARIANCES:
+        raise ValueError("too many priors for the C ABI")
+    c.n_priors = len(cfg.priors)
+    for i, pr in enumerate(cfg.priors):
+        c.prior_names[i].value = pr.encode()
     c.dur_nlayers, c.dur_kernel = cfg.duration_nlayers, cfg.duration_kernel_size
     c.dur_filter, c.dur_depthwise = cfg.duration_filter_size, int(cfg.duration_depthwise_conv)
     return c

@@ -111,9 +111,11 @@ class Fs2Config:
                 raise ValueError(f"stats missing for variance {v!r}")
         if self.duration_nlayers > 1 and self.duration_filter_size != H:
             raise ValueError("duration_filter_size must equal hidden when nlayers>1")
-        if self.priors:
-            raise ValueError("priors are off by default in the reference (fastspeech2.py:82) "
-                             "and not on the accelerated path yet")
+        for pr in self.priors:
+            # PriorEmbedding(H, variance_nbins, stats[f"{prior}_prior"]) (fastspeech2.py:416-424)
+            st = self.stats.get(f"{pr}_prior")
+            if not st or "min" not in st or "max" not in st:
+                raise ValueError(f"stats['{pr}_prior'] with min/max is required for prior {pr!r}")
 
     # ---- (de)serialisation ----------------------------------------------------------------
     def to_dict(self) -> dict:

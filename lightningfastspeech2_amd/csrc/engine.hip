@@ -113,8 +113,11 @@ struct fs2_engine {
     PredictorW dur;
     std::vector<VarianceW> vars;
     ConvW mel;
+    std::vector<VarianceW> priors_w;  // bins + relu(embedding) per prior (predictor unused)
+    const float* priors_dev = nullptr;
+    int priors_B = 0;
     // run state
-    Arena persist, scratch, dbg;
+    Arena persist, scratch, dbg, dbg_enc;
     int B = 0, L = 0, T = 0;
     bool encoded = false;
     void *xA = nullptr, *xB = nullptr;  // (B*L, H) encoder ping-pong; xA = encoder_out
@@ -217,6 +220,11 @@ void build_spec(fs2_engine* e) {
     e->spec["linear.bias"] = {c.n_mels};
     e->spec["speaker_embedding.projection.weight"] = {H, c.dvec_dim};
     e->spec["speaker_embedding.projection.bias"] = {H};
+    for (int p = 0; p < c.n_priors; ++p) {
+        const std::string q = std::string("prior_embeddings.") + c.prior_names[p];
+        e->spec[q + ".bins"] = {c.var_nbins - 1};
+        e->spec[q + ".embedding.weight"] = {c.var_nbins, H};
+    }
 }
 
 int check_config(fs2_engine* e) {
@@ -228,6 +236,8 @@ int check_config(fs2_engine* e) {
     if (c.enc_layers < 0 || c.enc_layers > FS2_MAX_LAYERS || c.dec_layers < 0 || c.dec_layers > FS2_MAX_LAYERS)
         return fail(e, FS2_ERR_SHAPE, "layer count out of range");
     if (c.n_variances < 0 || c.n_variances > FS2_MAX_VARIANCES) return fail(e, FS2_ERR_SHAPE, "n_variances out of range");
+    if (c.n_priors < 0 || c.n_priors > FS2_MAX_VARIANCES) return fail(e, FS2_ERR_SHAPE, "n_priors out of range");
+    if (c.n_priors && c.var_nbins < 2) return fail(e, FS2_ERR_SHAPE, "variance_nbins < 2");
     const int heads[2] = {c.enc_heads, c.dec_heads};
     for (int i = 0; i < 2; ++i) {
         if (heads[i] <= 0 || H % heads[i]) return fail(e, FS2_ERR_SHAPE, "heads must divide hidden");
@@ -573,8 +583,9 @@ int take_layer_scratch(fs2_engine* e, Arena& ar, int B, int S, LayerScratch* sc)
     return FS2_OK;
 }
 
-int tap_store(fs2_engine* e, hipStream_t st, const std::string& name, const void* src, size_t n, int src_dt) {
-    void* dst = e->dbg.take(n * 4);
+int tap_store(fs2_engine* e, hipStream_t st, const std::string& name, const void* src, size_t n, int src_dt,
+              Arena* arena = nullptr) {
+    void* dst = (arena ? arena : &e->dbg)->take(n * 4);
     if (!dst) return fail(e, FS2_ERR_NOMEM, "debug arena too small");
     ConvertArgs a{src, dst, n};
     const int r = launch_convert(a, src_dt, FS2_F32, st);
@@ -626,6 +637,7 @@ int fs2_destroy(fs2_engine* e) {
     e->persist.release();
     e->scratch.release();
     e->dbg.release();
+    e->dbg_enc.release();
     if (e->h_pinned) (void)hipHostFree(e->h_pinned);
     for (auto& s : e->prof)
         for (auto& ev : s.ev) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
@@ -676,6 +688,15 @@ int fs2_finalize(fs2_engine* e) {
         CHK(up_vec(e, p + ".embedding.weight", &e->vars[v].emb));
     }
     CHK(make_conv(e, "linear.weight", "linear.bias", &e->mel));
+    e->priors_w.resize(c.n_priors);
+    for (int p = 0; p < c.n_priors; ++p) {
+        const std::string q = std::string("prior_embeddings.") + c.prior_names[p];
+        CHK(up_vec(e, q + ".bins", &e->priors_w[p].bins));
+        // relu(Embedding[idx]) (model.py:161) == Embedding'[idx] with the table rectified once here
+        std::vector<float> t = W(e, q + ".embedding.weight").data;
+        for (float& v : t) v = v > 0.f ? v : 0.f;
+        CHK(upload_f32(e, t.data(), t.size(), &e->priors_w[p].emb));
+    }
     e->host.clear();
     e->finalized = true;
     return FS2_OK;
@@ -737,6 +758,21 @@ int fs2_encode(fs2_engine* e, const int64_t* phones, const float* speaker, int32
     }
     for (int i = 0; i < c.enc_layers; ++i)                                   // fastspeech2.py:685
         CHK(conformer(e, st, e->enc[i], e->xA, e->xB, B, L, c.enc_heads, sc, false));
+    if (e->debug) {  // the reference's encoder output, i.e. before the prior embeddings are added
+        const size_t need_d = al(ML * H * 4) + 4096;
+        if (need_d > e->dbg_enc.cap) HIPCHK(e, hipDeviceSynchronize());
+        if (e->dbg_enc.reserve(need_d) != FS2_OK) return fail(e, FS2_ERR_NOMEM, "debug arena");
+        CHK(tap_store(e, st, "encoder_out", e->xA, ML * H, e->dt, &e->dbg_enc));
+    }
+    if (c.n_priors) {                                                        // fastspeech2.py:687-692
+        if (!e->priors_dev || e->priors_B != B) return fail(e, FS2_ERR_STATE, "fs2_set_priors(B=%d) required before fs2_encode", B);
+        for (int p = 0; p < c.n_priors; ++p) {
+            BucketArgs ba{e->xA, e->priors_dev + (size_t)p * B, e->priors_w[p].bins, e->priors_w[p].emb, c.var_nbins,
+                          1.0f, 0.0f, nullptr, nullptr, e->xA, nullptr, B, L, (int)H, nullptr, 1};
+            if (launch_bucket_embed(ba, e->dt, st) != FS2_OK) return fail(e, FS2_ERR_HIP, "prior embedding launch failed");
+        }
+        e->priors_dev = nullptr;  // one-shot
+    }
     // duration predictor + rounding + prefix sums                          model.py:259,299-309
     CHK(predictor(e, st, e->dur, e->xA, B, L, e->src_mask, e->dur_pred, sc));
     DurationArgs da{e->dur_pred, e->src_mask, forced, e->d_dur, e->d_cum, e->d_totals, e->d_guard, B, L};
@@ -752,6 +788,14 @@ int fs2_encode(fs2_engine* e, const int64_t* phones, const float* speaker, int32
     if (e->T > c.pe_len) return fail(e, FS2_ERR_SHAPE, "T=%d exceeds positional table %d", e->T, c.pe_len);
     *T_out = e->T;
     e->encoded = true;
+    return FS2_OK;
+}
+
+int fs2_set_priors(fs2_engine* e, const float* priors_device, int32_t B) {
+    if (!e || !priors_device || B <= 0) return FS2_ERR_ARG;
+    if (e->cfg.n_priors == 0) return fail(e, FS2_ERR_STATE, "this engine was configured without priors");
+    e->priors_dev = priors_device;
+    e->priors_B = B;
     return FS2_OK;
 }
 
@@ -788,10 +832,9 @@ int fs2_decode(fs2_engine* e, const fs2_outputs* out, void* stream) {
     CHK(take_layer_scratch(e, e->scratch, B, T, &sc));
     if (!yA || !yB || !tmask) return fail(e, FS2_ERR_NOMEM, "scratch arena too small");
     if (e->debug) {
-        const size_t need_d = al(ML * H * 4) + 3 * al(MT * H * 4) + (size_t)c.n_variances * al(MT * 4) + 4096;
+        const size_t need_d = 3 * al(MT * H * 4) + (size_t)c.n_variances * al(MT * 4) + 4096;
         if (need_d > e->dbg.cap) HIPCHK(e, hipDeviceSynchronize());
         if (e->dbg.reserve(need_d) != FS2_OK) return fail(e, FS2_ERR_NOMEM, "debug arena");
-        CHK(tap_store(e, st, "encoder_out", e->xA, ML * H, e->dt));
     }
 
     {   // length regulator                                                  model.py:311,349-370

@@ -138,6 +138,7 @@ struct BucketArgs {
     int32_t* idx_out;     // (B*T) or null: bucket indices (debug / parity)
     int B, T, H;
     const int32_t* forced_idx;  // (B*T) or null: use these bucket indices instead of searching
+    int pred_per_utt = 0;       // 1: pred has one value per utterance (B), broadcast over T
 };
 int launch_bucket_embed(const BucketArgs& a, int dtype, hipStream_t stream);
 

@@ -83,9 +83,12 @@ class Engine:
     def set_debug(self, on: bool):
         _lib.check(self.lib.fs2_set_debug(self.handle, int(on)), self.handle, "set_debug")
 
-    def encode(self, phones: torch.Tensor, speaker: torch.Tensor, forced_durations: Optional[torch.Tensor] = None) -> int:
+    def encode(self, phones: torch.Tensor, speaker: torch.Tensor, forced_durations: Optional[torch.Tensor] = None,
+               priors: Optional[torch.Tensor] = None) -> int:
         B, L = phones.shape
         T = C.c_int32(0)
+        if priors is not None:  # (n_priors, B) fp32 on the device
+            _lib.check(self.lib.fs2_set_priors(self.handle, _ptr(priors), B), self.handle, "set_priors")
         with torch.cuda.device(self.device):
             st = self.lib.fs2_encode(self.handle, _ptr(phones), _ptr(speaker), B, L, _ptr(forced_durations),
                                      self._stream(), C.byref(T))
@@ -243,7 +246,11 @@ class FastSpeech2:
         B, L = phones.shape
         guess = self._t_guess.get((B, L))
         pre = self.engine.alloc_outputs(B, L, guess) if guess else None
-        T = self.engine.encode(phones, speaker, forced)
+        priors = None
+        if self.cfg.priors:  # utterance-level priors, fastspeech2.py:687-692
+            rows = [torch.as_tensor(np.asarray(targets[f"priors_{pr}"], dtype=np.float32)).reshape(B) for pr in self.cfg.priors]
+            priors = torch.stack(rows).to(self.device, dtype=torch.float32).contiguous()
+        T = self.engine.encode(phones, speaker, forced, priors)
         self._t_guess[(B, L)] = T
         for var, idx in (force_buckets or {}).items():
             idx = torch.as_tensor(idx).to(self.device, dtype=torch.int32).contiguous()

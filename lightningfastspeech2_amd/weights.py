@@ -87,6 +87,9 @@ def state_dict_spec(cfg: Fs2Config) -> "OrderedDict[str, tuple]":
     out["linear.bias"] = (cfg.n_mels,)
     out["speaker_embedding.projection.weight"] = (H, DVECTOR_DIM)
     out["speaker_embedding.projection.bias"] = (H,)
+    for pr in cfg.priors:  # PriorEmbedding, model.py:146-164 (ModuleDict at fastspeech2.py:416-424)
+        out[f"prior_embeddings.{pr}.bins"] = (cfg.variance_nbins - 1,)
+        out[f"prior_embeddings.{pr}.embedding.weight"] = (cfg.variance_nbins, H)
     return out
 
 
@@ -105,8 +108,9 @@ def positional_table(H: int, max_len: int = PE_MAX_LEN) -> np.ndarray:
 
 
 def variance_bins(cfg: Fs2Config, var: str) -> np.ndarray:
-    """VarianceEncoder.bins = linspace(min, max, nbins-1), model.py:397-400 (float64 arithmetic,
-    one rounding; carried in the state_dict as the ``bins`` parameter)."""
+    """VarianceEncoder.bins / PriorEmbedding.bins = linspace(min, max, nbins-1), model.py:397-400,
+    150-153 (float64 arithmetic, one rounding; carried in the state_dict as the ``bins`` parameter).
+    ``var`` is a variance name or ``"<prior>_prior"``."""
     st = cfg.stats[var]
     n = cfg.variance_nbins - 1
     lo, hi = float(st["min"]), float(st["max"])
@@ -134,7 +138,8 @@ def synth_state_dict(cfg: Fs2Config, seed: int = 0, *, randomize_norm: bool = Fa
             sd[name] = positional_table(cfg.hidden)
             continue
         if name.endswith(".bins"):
-            sd[name] = variance_bins(cfg, name.split(".")[2])
+            parts = name.split(".")
+            sd[name] = variance_bins(cfg, parts[2] if parts[0] == "variance_adaptor" else f"{parts[1]}_prior")
             continue
         if name.endswith("embedding.weight"):
             w = rs.standard_normal(shape).astype(np.float32)
@@ -179,7 +184,8 @@ def synth_state_dict(cfg: Fs2Config, seed: int = 0, *, randomize_norm: bool = Fa
 
 def synth_inputs(cfg: Fs2Config, B: int, L: int, seed: int = 1234, *, lengths=None):
     """Synthetic batch in the reference's collate format (datasets.py:852-882): ``phones`` int64
-    (B, L) zero-padded on the right, ``speaker`` float32 (B, 256) unit-norm d-vectors."""
+    (B, L) zero-padded on the right, ``speaker`` float32 (B, 256) unit-norm d-vectors, and one
+    ``priors_<p>`` float32 (B,) per configured prior, drawn inside its [min, max] range."""
     rs = np.random.RandomState(seed)
     phones = rs.randint(1, cfg.n_phones, size=(B, L)).astype(np.int64)
     if lengths is not None:
@@ -187,4 +193,9 @@ def synth_inputs(cfg: Fs2Config, B: int, L: int, seed: int = 1234, *, lengths=No
             phones[b, int(n):] = 0
     spk = np.random.RandomState(seed + 1).standard_normal((B, DVECTOR_DIM)).astype(np.float32)
     spk /= np.linalg.norm(spk, axis=1, keepdims=True)
-    return {"phones": phones, "speaker": spk.astype(np.float32)}
+    out = {"phones": phones, "speaker": spk.astype(np.float32)}
+    prs = np.random.RandomState(seed + 2)
+    for pr in cfg.priors:
+        st = cfg.stats[f"{pr}_prior"]
+        out[f"priors_{pr}"] = prs.uniform(st["min"] - 0.1, st["max"] + 0.1, size=B).astype(np.float32)
+    return out

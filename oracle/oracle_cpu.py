@@ -162,8 +162,17 @@ def variance_encoder(sd, cfg, var_index: int, x, mask):
 
 
 @torch.no_grad()
+def prior_embedding(sd, cfg, prior: str, values: torch.Tensor) -> torch.Tensor:
+    """PriorEmbedding.forward, model.py:160-164 — relu(Emb[bucketize(prior, bins)]), one row per
+    utterance, broadcast over time by the caller."""
+    p = f"prior_embeddings.{prior}"
+    idx = torch.bucketize(values, _t(sd, f"{p}.bins"))
+    return torch.relu(F.embedding(idx, _t(sd, f"{p}.embedding.weight")))
+
+
 def forward(sd, cfg, phones, speaker, *, return_intermediates: bool = False,
-            force_durations: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+            force_durations: Optional[torch.Tensor] = None, priors: Optional[dict] = None
+            ) -> Dict[str, torch.Tensor]:
     """FastSpeech2.forward(targets, inference=True), fastspeech2.py:636-731 (mel path only; the
     fastdiff_var branch :733-736 is broken at HEAD and not part of mel — SURVEY §0.6)."""
     phones = torch.as_tensor(phones).long()
@@ -180,6 +189,9 @@ def forward(sd, cfg, phones, speaker, *, return_intermediates: bool = False,
         x = conformer_layer(sd, f"encoder.layers.{i}", x, cfg.encoder_head,
                             cfg.encoder_depthwise_conv, src_mask)
     inter["encoder_out"] = x
+    for pr in cfg.priors:                                                     # :687-692
+        v = torch.as_tensor(np.asarray(priors[f"priors_{pr}"])).float()
+        x = x + prior_embedding(sd, cfg, pr, v)[:, None, :]
     # ---- VarianceAdaptor.forward, model.py:249-341 ----
     dur_pred = variance_predictor(sd, "variance_adaptor.duration_predictor", x, cfg.duration_nlayers,
                                   cfg.duration_kernel_size, cfg.duration_depthwise_conv, src_mask)

@@ -48,7 +48,7 @@ def test_fp32_matches_reference_golden(name):
     g = Golden(name)
     m = _model(g.cfg, g.state_dict(), "fp32")
     m.engine.set_debug(True)
-    out = _cpu(m({"phones": torch.from_numpy(g.phones), "speaker": torch.from_numpy(g.speaker)}, inference=True))
+    out = _cpu(m({"phones": torch.from_numpy(g.phones), "speaker": torch.from_numpy(g.speaker), **g.priors}, inference=True))
     errs = {}
     assert tuple(out["mel"].shape) == g.out["mel"].shape
     assert out["duration_rounded"].dtype == torch.int32 and out["tgt_mask"].dtype == torch.bool

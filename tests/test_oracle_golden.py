@@ -14,7 +14,7 @@ ORACLE_TOL = 2e-5  # fp32 restatement vs the reference's own fp32 forward (obser
 
 def test_fixtures_present():
     names = golden_names()
-    for want in ("dense_small", "dw_small", "mixed_small", "guard_small", "clip_small",
+    for want in ("dense_small", "dw_small", "mixed_small", "guard_small", "clip_small", "priors_small",
                  "mid_dense_d128", "mid_dw_d64"):
         assert want in names
 
@@ -22,7 +22,7 @@ def test_fixtures_present():
 @pytest.mark.parametrize("name", golden_names())
 def test_oracle_matches_reference_golden(name):
     g = Golden(name)
-    out = oracle_cpu.forward(g.state_dict(), g.cfg, g.phones, g.speaker, return_intermediates=True)
+    out = oracle_cpu.forward(g.state_dict(), g.cfg, g.phones, g.speaker, return_intermediates=True, priors=g.priors)
     assert out["mel"].shape == g.out["mel"].shape
     for k in ("duration_rounded", "src_mask", "tgt_mask"):
         assert np.array_equal(out[k].numpy(), g.out[k]), k

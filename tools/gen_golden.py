@@ -65,6 +65,12 @@ CASES = {
                           variance_kernel_size=[5, 3], variance_levels=["frame", "frame"],
                           variance_transforms=["none", "none"], variance_nbins=32),
                     4, 9, [9, 9, 3, 1], dict(duration_bias=0.9), {}),
+    "priors_small": (small(priors=["pitch", "duration"],
+                           stats={"pitch": {"min": -2.0, "max": 2.5, "mean": 0.1, "std": 1.5},
+                                  "energy": {"min": -3.0, "max": 3.0, "mean": 0.0, "std": 1.0},
+                                  "snr": {"min": -1.0, "max": 4.0, "mean": 1.2, "std": 2.0},
+                                  "pitch_prior": {"min": -1.0, "max": 1.0}, "duration_prior": {"min": 0.0, "max": 5.0}}),
+                     3, 10, [10, 6, 8], dict(duration_bias=1.1), {}),
     "guard_small": (small(), 4, 10, [10, 8, 6, 3], dict(duration_bias=0.35, duration_weight_scale=1.5),
                     {"guard": "some"}),
     "clip_small": (small(max_length=20.5 * 256 / 22050), 3, 12, [12, 12, 6], dict(duration_bias=1.3),
@@ -120,7 +126,8 @@ def make_case(name, cfg, B, L, lengths, skw, want):
     for seed in range(0, 400):
         sd = synth_state_dict(cfg, seed, randomize_norm=True, **skw)
         inp = synth_inputs(cfg, B, L, seed=1000 + seed, lengths=lengths)
-        out = run_reference(cfg, sd, inp["phones"], inp["speaker"], capture=True)
+        pri = {k: v for k, v in inp.items() if k.startswith("priors_")}
+        out = run_reference(cfg, sd, inp["phones"], inp["speaker"], capture=True, priors=pri)
         rm, bm = margins(cfg, out)
         n_guard = out["_stdout"].count("Zero duration")
         totals = out["duration_rounded"].long().sum(1)
@@ -138,7 +145,7 @@ def make_case(name, cfg, B, L, lengths, skw, want):
             "config_json": np.array(cfg.to_json()),
             "synth_json": np.array(json.dumps(dict(seed=seed, randomize_norm=True, **skw), sort_keys=True)),
             "sd_sha256": np.array(sd_digest(sd)),
-            "phones": inp["phones"], "speaker": inp["speaker"],
+            "phones": inp["phones"], "speaker": inp["speaker"], **{f"in_{k}": v for k, v in pri.items()},
             "margins": np.array([rm, bm]), "n_guard": np.array(n_guard),
         }
         for k, v in out.items():

@@ -106,7 +106,7 @@ def build_reference_model(cfg, state_dict):
     obj = fs.FastSpeech2.__new__(fs.FastSpeech2)
     nn.Module.__init__(obj)
     obj.__dict__["hparams"] = SimpleNamespace(
-        speaker_embedding_every_layer=False, prior_embedding_every_layer=False, priors=[],
+        speaker_embedding_every_layer=False, prior_embedding_every_layer=False, priors=list(cfg.priors),
         variances=list(cfg.variances), fastdiff_variances=False,
         encoder_hidden=H, decoder_hidden=H, n_mels=cfg.n_mels, speaker_type="dvector",
     )
@@ -132,6 +132,8 @@ def build_reference_model(cfg, state_dict):
                           for i in range(cfg.decoder_layers)])
     obj.linear = nn.Linear(H, cfg.n_mels)
     obj.speaker_embedding = m.SpeakerEmbedding(H, "dvector")
+    obj.prior_embeddings = nn.ModuleDict({
+        pr: m.PriorEmbedding(H, cfg.variance_nbins, cfg.stats[f"{pr}_prior"]) for pr in cfg.priors})
     # forward() calls self.fastdiff_linear unconditionally (fastspeech2.py:733) although it only
     # exists with a FastDiff vocoder attached; a dummy keeps the unmodified forward runnable and
     # does not touch `mel` (computed at :723).
@@ -150,7 +152,7 @@ def build_reference_model(cfg, state_dict):
 
 
 @torch.no_grad()
-def run_reference(cfg, state_dict, phones, speaker, capture=True):
+def run_reference(cfg, state_dict, phones, speaker, capture=True, priors=None):
     """Run the unmodified reference forward; optionally capture intermediates with hooks."""
     model = build_reference_model(cfg, state_dict)
     inter = {}
@@ -167,7 +169,10 @@ def run_reference(cfg, state_dict, phones, speaker, capture=True):
     import io
     buf = io.StringIO()
     with contextlib.redirect_stdout(buf):  # "Zero duration, setting to 1" prints (model.py:309)
-        out = model({"phones": torch.as_tensor(phones), "speaker": torch.as_tensor(speaker)}, inference=True)
+        batch = {"phones": torch.as_tensor(phones), "speaker": torch.as_tensor(speaker)}
+        for k, v in (priors or {}).items():
+            batch[k] = np.asarray(v)  # forward() wraps it with torch.tensor(...) (fastspeech2.py:690)
+        out = model(batch, inference=True)
     for h in hooks:
         h.remove()
     out = {k: v for k, v in out.items() if k != "fastdiff_var"}
