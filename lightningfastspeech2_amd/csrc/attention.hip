@@ -189,15 +189,18 @@ __global__ __launch_bounds__(NW * KS * 64, (sizeof(T) == 2 && D == 128 && KS == 
             // ---- S^T = K Q^T ----
             f32x16_t sacc[NKB];
     #pragma unroll
-            for (int kb = 0; kb < NKB; ++kb) {
+            for (int kb = 0; kb < NKB; ++kb)
     #pragma unroll
                 for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+            // chunk-outer / key-block-inner: consecutive MFMAs hit DIFFERENT accumulators, so the
+            // accumulate latency of one chain hides under the other
     #pragma unroll
-                for (int c = 0; c < NQC; ++c) {
+            for (int c = 0; c < NQC; ++c)
+    #pragma unroll
+                for (int kb = 0; kb < NKB; ++kb) {
                     const uint4 kf = *(const uint4*)(sK + swz_row<KRB>(kb * 32 + li, c * 2 + hi));
                     Mma32<T>::step(kf, qf[c], sacc[kb]);
                 }
-            }
             // ---- key-padding mask (only tiles that contain a padded key pay for it) ----
             const unsigned long long full = KVB == 64 ? ~0ull : 0xffffffffull;
             if (bits != full) {
@@ -262,23 +265,26 @@ __global__ __launch_bounds__(NW * KS * 64, (sizeof(T) == 2 && D == 128 && KS == 
                 const int i16 = lane & 15, g1 = (lane >> 4) & 1;
                 const int rsub = i16 >> 2;                      // key row inside the 4-row block (== key & 3)
                 const int rowb = (4 * hi + rsub) * KRB + (i16 & 1) * 8;
+                int vcol[ND];
     #pragma unroll
-                for (int nd = 0; nd < ND; ++nd) {
-                    const int slot = (nd * 4 + g1 * 2 + ((i16 & 3) >> 1)) ^ vswz<KRB>(rsub);
-                    const unsigned char* vb = sV + rowb + (slot << 4);
+                for (int nd = 0; nd < ND; ++nd)
+                    vcol[nd] = rowb + (((nd * 4 + g1 * 2 + ((i16 & 3) >> 1)) ^ vswz<KRB>(rsub)) << 4);
+                // key-chunk outer / dv-block inner: consecutive MFMAs accumulate into different oacc[nd]
     #pragma unroll
-                    for (int ch = 0; ch < 4; ++ch) {
+                for (int ch = 0; ch < 4; ++ch)
+    #pragma unroll
+                    for (int nd = 0; nd < ND; ++nd) {
+                        const unsigned char* vb = sV + vcol[nd];
                         const uint2 lo = tr_read_b64(vb + ch * 16 * KRB);
                         const uint2 hi2 = tr_read_b64(vb + (ch * 16 + 8) * KRB);
                         const uint4 vf = make_uint4(lo.x, lo.y, hi2.x, hi2.y);
                         Mma32<T>::step(vf, pf[ch], oacc[nd]);
                     }
-                }
             } else {
     #pragma unroll
-                for (int nd = 0; nd < ND; ++nd)
+                for (int ch = 0; ch < 4; ++ch)
     #pragma unroll
-                    for (int ch = 0; ch < 4; ++ch) {
+                    for (int nd = 0; nd < ND; ++nd) {
                         const uint4 vf = *(const uint4*)(sV + swz_row<VRB>(nd * 32 + li, ch * 2 + hi));
                         Mma32<T>::step(vf, pf[ch], oacc[nd]);
                     }
