@@ -125,6 +125,12 @@ int fs2_set_debug(fs2_engine* e, int32_t on);
  * model.py:417-422): the NEXT fs2_decode embeds these (B, T) int32 device bucket indices for
  * variance `variance_index` instead of bucketizing its own prediction.  One-shot. */
 int fs2_force_buckets(fs2_engine* e, int32_t variance_index, const int32_t* idx_device);
+/* Teacher forcing as the reference's non-inference forward does it (model.py:317-325,417-422): the
+ * NEXT fs2_decode embeds bucketize(target*std + mean) of these (B, T) fp32 device target values for
+ * variance `variance_index`; the prediction is still computed and returned.  One-shot.  Together
+ * with fs2_encode's forced_durations (= targets["duration"], model.py:296-297) this is
+ * FastSpeech2.forward(batch, inference=False) without the loss. */
+int fs2_force_variance_targets(fs2_engine* e, int32_t variance_index, const float* target_device);
 int fs2_debug_copy(fs2_engine* e, const char* what, void* dst_device, void* hip_stream);
 
 /* Kernel timing with HIP events on the launch stream (bench.py roofline).  kernel_class: */

@@ -100,6 +100,7 @@ def load():
     lib.fs2_set_debug.argtypes = [vp, i32]
     lib.fs2_debug_copy.argtypes = [vp, C.c_char_p, vp, vp]
     lib.fs2_force_buckets.argtypes = [vp, i32, vp]
+    lib.fs2_force_variance_targets.argtypes = [vp, i32, vp]
     lib.fs2_profile_enable.argtypes = [vp, i32, i32]
     lib.fs2_profile_read.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                      C.POINTER(C.c_double), C.POINTER(C.c_double)]

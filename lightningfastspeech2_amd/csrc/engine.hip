@@ -130,6 +130,7 @@ struct fs2_engine {
     std::vector<int32_t> totals, guard;
     std::map<std::string, std::pair<void*, size_t>> taps;
     const int32_t* forced_idx[FS2_MAX_VARIANCES] = {nullptr, nullptr, nullptr, nullptr};
+    const float* forced_tgt[FS2_MAX_VARIANCES] = {nullptr, nullptr, nullptr, nullptr};
     ProfSlot prof[FS2_K_COUNT];
 };
 
@@ -859,7 +860,7 @@ int fs2_decode(fs2_engine* e, const fs2_outputs* out, void* stream) {
         Bracket br(e, FS2_K_ROWOPS, st, 0, 2.0 * MT * H * esz);
         BucketArgs ba{yA, vpred[v], e->vars[v].bins, e->vars[v].emb, c.var_nbins, c.var_std[v], c.var_mean[v],
                       (last && fuse_pe) ? e->pe : nullptr, (last && fuse_pe) ? e->spk : nullptr, yA, idx, B, T, (int)H,
-                      e->forced_idx[v]};
+                      e->forced_idx[v], 0, e->forced_tgt[v]};
         if (launch_bucket_embed(ba, e->dt, st) != FS2_OK) return fail(e, FS2_ERR_HIP, "bucket_embed launch failed");
     }
     if (e->debug) CHK(tap_store(e, st, "adaptor_out", yA, MT * H, e->dt));
@@ -871,13 +872,19 @@ int fs2_decode(fs2_engine* e, const fs2_outputs* out, void* stream) {
         CHK(conformer(e, st, e->dec[i], yA, yB, B, T, c.dec_heads, sc, true));
     if (e->debug) CHK(tap_store(e, st, "decoder_out", yA, MT * H, e->dt));
     if (out->mel) CHK(gemm(e, st, e->mel, yA, out->mel, (int)MT, (int)MT, false, FS2_F32));  // fastspeech2.py:723
-    for (int v = 0; v < FS2_MAX_VARIANCES; ++v) e->forced_idx[v] = nullptr;  // one-shot
+    for (int v = 0; v < FS2_MAX_VARIANCES; ++v) e->forced_idx[v] = nullptr, e->forced_tgt[v] = nullptr;  // one-shot
     return FS2_OK;
 }
 
 int fs2_force_buckets(fs2_engine* e, int32_t variance_index, const int32_t* idx) {
     if (!e || variance_index < 0 || variance_index >= e->cfg.n_variances) return FS2_ERR_ARG;
     e->forced_idx[variance_index] = idx;
+    return FS2_OK;
+}
+
+int fs2_force_variance_targets(fs2_engine* e, int32_t variance_index, const float* tgt) {
+    if (!e || variance_index < 0 || variance_index >= e->cfg.n_variances) return FS2_ERR_ARG;
+    e->forced_tgt[variance_index] = tgt;
     return FS2_OK;
 }
 

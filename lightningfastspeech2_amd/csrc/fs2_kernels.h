@@ -139,6 +139,7 @@ struct BucketArgs {
     int B, T, H;
     const int32_t* forced_idx;  // (B*T) or null: use these bucket indices instead of searching
     int pred_per_utt = 0;       // 1: pred has one value per utterance (B), broadcast over T
+    const float* bucket_src = nullptr;  // (B*T) or null: bucketize THIS (teacher-forced target) instead of pred
 };
 int launch_bucket_embed(const BucketArgs& a, int dtype, hipStream_t stream);
 

@@ -393,7 +393,8 @@ __global__ __launch_bounds__(256) void bucket_embed_kernel(BucketArgs p) {
     const int b = row / p.T, t = row % p.T;
     const float* e = nullptr;
     if (p.pred) {
-        const float v = __fadd_rn(__fmul_rn(p.pred[p.pred_per_utt ? b : row], p.std), p.mean);
+        const float src = p.bucket_src ? p.bucket_src[row] : p.pred[p.pred_per_utt ? b : row];
+        const float v = __fadd_rn(__fmul_rn(src, p.std), p.mean);
         int lo = 0, hi = p.nbins - 1;  // lower_bound over nbins-1 boundaries
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;

@@ -122,6 +122,12 @@ class Engine:
                 res[f"variances_{var}"] = torch.empty(B, T, dtype=torch.float32, device=dev)
         return res
 
+    def force_variance_targets(self, var_index: int, tgt: torch.Tensor):
+        """Next decode embeds bucketize(tgt*std+mean) for that variance (teacher forcing)."""
+        self._keep = getattr(self, "_keep", []) + [tgt]
+        _lib.check(self.lib.fs2_force_variance_targets(self.handle, var_index, _ptr(tgt)), self.handle,
+                   "force_variance_targets")
+
     def decode(self, want_aux: bool = True, outputs: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
         B, L, T = self._last
         res = outputs
@@ -219,10 +225,15 @@ class FastSpeech2:
         return self.forward(targets, inference)
 
     def forward(self, targets: dict, inference: bool = False, *, force_durations=None, force_buckets=None) -> dict:
-        if not inference and force_durations is None:
-            raise NotImplementedError(
-                "teacher-forced/training forward (inference=False, model.py:296-297,317-325) is outside "
-                "the accelerated path; call model(batch, inference=True)")
+        teacher = not inference and force_durations is None
+        if teacher:
+            # FastSpeech2.forward(batch) as the Lightning hooks call it (fastspeech2.py:787,800):
+            # target durations (model.py:296-297) and target variances (model.py:317-325) are teacher
+            # forced; forward only — the loss/backward of training_step stay with the caller.
+            missing = [k for k in ["duration"] + [f"variances_{v}" for v in self.cfg.variances] if k not in targets]
+            if missing:
+                raise KeyError(f"inference=False needs teacher-forcing targets {missing} (model.py:296-297,317-325)")
+            force_durations = targets["duration"]
         phones = targets["phones"]
         speaker = targets["speaker"]
         if not isinstance(phones, torch.Tensor):
@@ -252,12 +263,22 @@ class FastSpeech2:
             priors = torch.stack(rows).to(self.device, dtype=torch.float32).contiguous()
         T = self.engine.encode(phones, speaker, forced, priors)
         self._t_guess[(B, L)] = T
+        if teacher:
+            for vi, var in enumerate(self.cfg.variances):
+                tgt = torch.as_tensor(np.asarray(targets[f"variances_{var}"]) if not isinstance(targets[f"variances_{var}"], torch.Tensor)
+                                      else targets[f"variances_{var}"]).to(self.device, dtype=torch.float32)
+                if tgt.dim() != 2 or tgt.shape[0] != B or tgt.shape[1] < T:
+                    raise ValueError(f"targets['variances_{var}'] must be (B, >= T) = ({B}, >= {T})")
+                self.engine.force_variance_targets(vi, tgt[:, :T].contiguous())
         for var, idx in (force_buckets or {}).items():
             idx = torch.as_tensor(idx).to(self.device, dtype=torch.int32).contiguous()
             if tuple(idx.shape) != (phones.shape[0], T):
                 raise ValueError(f"force_buckets[{var!r}] must be (B, T)=({phones.shape[0]}, {T})")
             self.engine.force_buckets(self.cfg.variances.index(var), idx)
         res = self.engine.decode(outputs=pre)
+        if teacher:  # the reference hands back the target tensor itself (model.py:297,337)
+            d = targets["duration"]
+            res["duration_rounded"] = d.to(self.device) if isinstance(d, torch.Tensor) else torch.as_tensor(np.asarray(d)).to(self.device)
         _, guard = self.engine.totals()
         for _ in range(int(guard.sum())):
             print("Zero duration, setting to 1")  # the reference's one stdout side effect (model.py:309)

@@ -148,14 +148,16 @@ def length_regulator(x: torch.Tensor, durations: torch.Tensor, max_length: float
     return out, mask
 
 
-def variance_encoder(sd, cfg, var_index: int, x, mask):
-    """VarianceEncoder.forward, non-CWT inference branch (model.py:409-441)."""
+def variance_encoder(sd, cfg, var_index: int, x, mask, tgt=None):
+    """VarianceEncoder.forward, non-CWT branch (model.py:409-441): with ``tgt`` (teacher forcing,
+    model.py:417-422) the embedding comes from bucketize(tgt*std+mean), the prediction is still
+    computed and returned."""
     var = cfg.variances[var_index]
     p = f"variance_adaptor.encoders.{var}"
     pred = variance_predictor(sd, f"{p}.predictor", x, cfg.variance_nlayers[var_index],
                               cfg.variance_kernel_size[var_index], cfg.variance_depthwise_conv, mask)
     st = cfg.stats[var]
-    bucket_value = pred * st["std"] + st["mean"]  # model.py:434
+    bucket_value = (pred if tgt is None else tgt) * st["std"] + st["mean"]  # model.py:434 / :421
     idx = torch.bucketize(bucket_value, _t(sd, f"{p}.bins"))  # right=False
     emb = F.embedding(idx, _t(sd, f"{p}.embedding.weight"))
     return pred, emb, idx
@@ -171,8 +173,8 @@ def prior_embedding(sd, cfg, prior: str, values: torch.Tensor) -> torch.Tensor:
 
 
 def forward(sd, cfg, phones, speaker, *, return_intermediates: bool = False,
-            force_durations: Optional[torch.Tensor] = None, priors: Optional[dict] = None
-            ) -> Dict[str, torch.Tensor]:
+            force_durations: Optional[torch.Tensor] = None, priors: Optional[dict] = None,
+            teacher_targets: Optional[dict] = None) -> Dict[str, torch.Tensor]:
     """FastSpeech2.forward(targets, inference=True), fastspeech2.py:636-731 (mel path only; the
     fastdiff_var branch :733-736 is broken at HEAD and not part of mel — SURVEY §0.6)."""
     phones = torch.as_tensor(phones).long()
@@ -195,7 +197,9 @@ def forward(sd, cfg, phones, speaker, *, return_intermediates: bool = False,
     # ---- VarianceAdaptor.forward, model.py:249-341 ----
     dur_pred = variance_predictor(sd, "variance_adaptor.duration_predictor", x, cfg.duration_nlayers,
                                   cfg.duration_kernel_size, cfg.duration_depthwise_conv, src_mask)
-    if force_durations is None:
+    if teacher_targets is not None:   # inference=False: targets["duration"], no rounding/guard (model.py:296-297)
+        dur_rounded, guarded = torch.as_tensor(np.asarray(teacher_targets["duration"])), []
+    elif force_durations is None:
         dur_rounded, guarded = round_durations(dur_pred, src_mask)
     else:
         dur_rounded, guarded = torch.as_tensor(force_durations).int(), []
@@ -203,7 +207,10 @@ def forward(sd, cfg, phones, speaker, *, return_intermediates: bool = False,
     inter["regulated"] = x
     result = {}
     for vi, var in enumerate(cfg.variances):                                  # model.py:315-333
-        pred, emb, idx = variance_encoder(sd, cfg, vi, x, tgt_mask)
+        tgt = None
+        if teacher_targets is not None:  # model.py:317-325
+            tgt = torch.as_tensor(np.asarray(teacher_targets[f"variances_{var}"])).float()
+        pred, emb, idx = variance_encoder(sd, cfg, vi, x, tgt_mask, tgt)
         result[f"variances_{var}"] = pred
         inter[f"bucket_{var}"] = idx
         x = x + emb

@@ -36,6 +36,7 @@ class Golden:
         self.phones = z["phones"]
         self.speaker = z["speaker"]
         self.priors = {k[3:]: z[k] for k in z.files if k.startswith("in_priors_")}
+        self.teacher = {k[3:]: z[k] for k in z.files if k.startswith("tf_")} or None
         self.out = {k[4:]: z[k] for k in z.files if k.startswith("out_")}
         self.mid = {k[4:]: z[k] for k in z.files if k.startswith("mid_")}
         self.margins = z["margins"]

@@ -48,10 +48,16 @@ def test_fp32_matches_reference_golden(name):
     g = Golden(name)
     m = _model(g.cfg, g.state_dict(), "fp32")
     m.engine.set_debug(True)
-    out = _cpu(m({"phones": torch.from_numpy(g.phones), "speaker": torch.from_numpy(g.speaker), **g.priors}, inference=True))
+    batch = {"phones": torch.from_numpy(g.phones), "speaker": torch.from_numpy(g.speaker), **g.priors}
+    if g.teacher is not None:  # teacher-forced forward, as the Lightning hooks call it: model(batch)
+        batch.update({k: torch.from_numpy(v) for k, v in g.teacher.items()})
+        out = _cpu(m(batch))
+    else:
+        out = _cpu(m(batch, inference=True))
     errs = {}
     assert tuple(out["mel"].shape) == g.out["mel"].shape
-    assert out["duration_rounded"].dtype == torch.int32 and out["tgt_mask"].dtype == torch.bool
+    assert out["tgt_mask"].dtype == torch.bool
+    assert out["duration_rounded"].dtype == (torch.int32 if g.teacher is None else torch.int64)
     for k in ("duration_rounded", "src_mask", "tgt_mask"):
         assert np.array_equal(out[k].numpy(), g.out[k]), k
     for k, ref in g.out.items():
@@ -201,8 +207,8 @@ def test_rejects_training_forward_and_bad_ids():
     g = Golden("dense_small")
     m = _model(g.cfg, g.state_dict(), "fp32")
     batch = {"phones": torch.from_numpy(g.phones), "speaker": torch.from_numpy(g.speaker)}
-    with pytest.raises(NotImplementedError):
-        m(batch)  # inference=False is the training forward (out of scope)
+    with pytest.raises(KeyError):
+        m(batch)  # inference=False is the teacher-forced forward: it needs targets["duration"], ["variances_*"]
     bad = torch.from_numpy(g.phones).clone()
     bad[0, 0] = g.cfg.n_phones
     with pytest.raises(IndexError):

@@ -14,7 +14,7 @@ ORACLE_TOL = 2e-5  # fp32 restatement vs the reference's own fp32 forward (obser
 
 def test_fixtures_present():
     names = golden_names()
-    for want in ("dense_small", "dw_small", "mixed_small", "guard_small", "clip_small", "priors_small",
+    for want in ("dense_small", "dw_small", "mixed_small", "guard_small", "clip_small", "priors_small", "teacher_small",
                  "mid_dense_d128", "mid_dw_d64"):
         assert want in names
 
@@ -22,11 +22,12 @@ def test_fixtures_present():
 @pytest.mark.parametrize("name", golden_names())
 def test_oracle_matches_reference_golden(name):
     g = Golden(name)
-    out = oracle_cpu.forward(g.state_dict(), g.cfg, g.phones, g.speaker, return_intermediates=True, priors=g.priors)
+    out = oracle_cpu.forward(g.state_dict(), g.cfg, g.phones, g.speaker, return_intermediates=True, priors=g.priors,
+                             teacher_targets=g.teacher)
     assert out["mel"].shape == g.out["mel"].shape
     for k in ("duration_rounded", "src_mask", "tgt_mask"):
         assert np.array_equal(out[k].numpy(), g.out[k]), k
-    assert out["duration_rounded"].dtype == torch.int32
+    assert out["duration_rounded"].dtype == (torch.int32 if g.teacher is None else torch.int64)
     for k, ref in g.out.items():
         if ref.dtype.kind == "f":
             err = float(np.abs(out[k].numpy() - ref).max())

@@ -71,6 +71,7 @@ CASES = {
                                   "snr": {"min": -1.0, "max": 4.0, "mean": 1.2, "std": 2.0},
                                   "pitch_prior": {"min": -1.0, "max": 1.0}, "duration_prior": {"min": 0.0, "max": 5.0}}),
                      3, 10, [10, 6, 8], dict(duration_bias=1.1), {}),
+    "teacher_small": (small(), 3, 11, [11, 7, 4], dict(duration_bias=1.2), {"teacher": True}),
     "guard_small": (small(), 4, 10, [10, 8, 6, 3], dict(duration_bias=0.35, duration_weight_scale=1.5),
                     {"guard": "some"}),
     "clip_small": (small(max_length=20.5 * 256 / 22050), 3, 12, [12, 12, 6], dict(duration_bias=1.3),
@@ -127,12 +128,28 @@ def make_case(name, cfg, B, L, lengths, skw, want):
         sd = synth_state_dict(cfg, seed, randomize_norm=True, **skw)
         inp = synth_inputs(cfg, B, L, seed=1000 + seed, lengths=lengths)
         pri = {k: v for k, v in inp.items() if k.startswith("priors_")}
-        out = run_reference(cfg, sd, inp["phones"], inp["speaker"], capture=True, priors=pri)
+        tt = None
+        if want.get("teacher"):  # teacher-forced forward: target durations + target variance values
+            rs = np.random.RandomState(7000 + seed)
+            dur = rs.randint(0, 6, size=(B, L)).astype(np.int64)
+            for b, n in enumerate(lengths):
+                dur[b, n:] = 0
+            Tt = int(dur.sum(1).max())
+            tt = {"duration": dur, **{f"variances_{v}": (1.2 * rs.randn(B, Tt)).astype(np.float32) for v in cfg.variances}}
+        out = run_reference(cfg, sd, inp["phones"], inp["speaker"], capture=True, priors=pri, teacher_targets=tt)
         rm, bm = margins(cfg, out)
         n_guard = out["_stdout"].count("Zero duration")
         totals = out["duration_rounded"].long().sum(1)
         clipped = bool((totals > cfg.max_frames).any())
         ok = rm > want.get("round_margin", ROUND_MARGIN) and bm > want.get("bucket_margin", BUCKET_MARGIN)
+        if want.get("teacher"):
+            st_ok = True
+            for v in cfg.variances:  # the forced targets must keep a margin from the bin edges too
+                stv = cfg.stats[v]
+                bins = torch.linspace(stv["min"], stv["max"], cfg.variance_nbins - 1).double()
+                val = torch.as_tensor(tt[f"variances_{v}"]).double() * stv["std"] + stv["mean"]
+                st_ok = st_ok and float((val[..., None] - bins).abs().min()) > 1e-4
+            ok = st_ok
         if want.get("guard") == "some":
             ok = ok and 0 < n_guard < B
         else:
@@ -146,6 +163,7 @@ def make_case(name, cfg, B, L, lengths, skw, want):
             "synth_json": np.array(json.dumps(dict(seed=seed, randomize_norm=True, **skw), sort_keys=True)),
             "sd_sha256": np.array(sd_digest(sd)),
             "phones": inp["phones"], "speaker": inp["speaker"], **{f"in_{k}": v for k, v in pri.items()},
+            **{f"tf_{k}": v for k, v in (tt or {}).items()},
             "margins": np.array([rm, bm]), "n_guard": np.array(n_guard),
         }
         for k, v in out.items():

@@ -152,7 +152,7 @@ def build_reference_model(cfg, state_dict):
 
 
 @torch.no_grad()
-def run_reference(cfg, state_dict, phones, speaker, capture=True, priors=None):
+def run_reference(cfg, state_dict, phones, speaker, capture=True, priors=None, teacher_targets=None):
     """Run the unmodified reference forward; optionally capture intermediates with hooks."""
     model = build_reference_model(cfg, state_dict)
     inter = {}
@@ -172,7 +172,13 @@ def run_reference(cfg, state_dict, phones, speaker, capture=True, priors=None):
         batch = {"phones": torch.as_tensor(phones), "speaker": torch.as_tensor(speaker)}
         for k, v in (priors or {}).items():
             batch[k] = np.asarray(v)  # forward() wraps it with torch.tensor(...) (fastspeech2.py:690)
-        out = model(batch, inference=True)
+        if teacher_targets is not None:  # the Lightning hooks' teacher-forced call self(batch) (fastspeech2.py:787,800)
+            for k, v in teacher_targets.items():
+                batch[k] = torch.as_tensor(np.asarray(v))
+            np.random.seed(0)  # tf_val = np.random.uniform(0, 1) <= 1.0 is always True (model.py:272)
+            out = model(batch)
+        else:
+            out = model(batch, inference=True)
     for h in hooks:
         h.remove()
     out = {k: v for k, v in out.items() if k != "fastdiff_var"}
