@@ -91,10 +91,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # FS2_BENCH_DEVICE / FS2_BENCH_BACKEND exist only to rehearse the multi-rank control flow on a
+    # single-GPU box (all ranks on one device over gloo); the real run is one rank per GPU over RCCL.
+    backend = os.environ.get("FS2_BENCH_BACKEND", "nccl")
+    if "FS2_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["FS2_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend)
     if world != args.gpus and rank == 0:
         print(f"note: --gpus {args.gpus} but WORLD_SIZE={world}; reporting n_gpus={world}", file=sys.stderr)
     dev = torch.device(f"cuda:{local_rank}")
@@ -115,7 +123,10 @@ def main():
     def step():
         out = model(batch, inference=True)
         if world > 1:
-            mel_all, frames = gather_mels(out["mel"], out["tgt_mask"])
+            if backend == "nccl":
+                mel_all, frames = gather_mels(out["mel"], out["tgt_mask"])
+            else:  # rehearsal path: gloo moves host tensors
+                mel_all, frames = gather_mels(out["mel"].cpu(), out["tgt_mask"].cpu())
             return out, int(frames.numel())
         return out, out["mel"].shape[0]
 
@@ -142,8 +153,9 @@ def main():
     prof = model.engine.profile_read(kcls)
     model.engine.profile_enable(kcls, False)
 
-    t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    frames_all = torch.tensor([frames_rank], dtype=torch.int64, device=dev)
+    cdev = dev if backend == "nccl" else torch.device("cpu")
+    t_max = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+    frames_all = torch.tensor([frames_rank], dtype=torch.int64, device=cdev)
     if world > 1:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
         dist.all_reduce(frames_all, op=dist.ReduceOp.SUM)
