@@ -72,6 +72,7 @@ __device__ inline uint2 tr_read_b64(const unsigned char* lds_addr) {  // lane i 
 // where 768 x 4-wave workgroups on 512 slots left a half-empty second round.
 template <typename T, int D, int NW, int KS>
 __global__ __launch_bounds__(NW * KS * 64, (sizeof(T) == 2 && D == 128 && KS == 1) ? 2 : 1) void attention_kernel(AttnArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins exist in the device pass only
     constexpr int KVB = sizeof(T) == 2 ? 64 : 32;      // keys per tile
     constexpr int E16 = Num<T>::kPer16B;
     constexpr int KC = Mma32<T>::K_PER_CHUNK;          // k-values per 2x16B chunk
@@ -108,9 +109,6 @@ __global__ __launch_bounds__(NW * KS * 64, (sizeof(T) == 2 && D == 128 && KS == 
     const int q0 = (r8 % nq) * (NW * 32);
     const int ld = 3 * p.H;
     const T* __restrict__ qkv = (const T*)p.qkv;
-    const T* __restrict__ vt = (const T*)p.vt;
-    const T* kbase = qkv + (size_t)b * p.S * ld + p.H + h * D;
-    const T* vbase = vt + (size_t)bh * D * p.Spad;
     const uint64_t* kbits = p.kbits + (size_t)b * p.nw64;
     const int ntiles = (p.S + KVB - 1) / KVB;
 
@@ -123,36 +121,45 @@ __global__ __launch_bounds__(NW * KS * 64, (sizeof(T) == 2 && D == 128 && KS == 
         while (j < ntiles && tile_bits(j) == 0ull) ++j;
         return j;
     };
-    auto issue_k = [&](int j, unsigned char* sK) {
-        const int kv0 = j * KVB;
+    // K / V tiles come in by buffer-load-to-LDS DMA: one descriptor over THIS utterance's qkv rows
+    // (SGPRs), a per-lane byte offset that is constant up to the tile advance, no per-tile address
+    // arithmetic beyond one add.  Keys past the end of the utterance fall outside the descriptor's
+    // range: the hardware bounds check (on the VGPR offset) returns zeros for them, and they are
+    // masked by the valid-key words anyway.
+    const unsigned utt_bytes = (unsigned)((size_t)p.S * ld * sizeof(T));
+    const __amdgpu_buffer_rsrc_t qrs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(qkv + (size_t)b * p.S * ld), 0, utt_bytes, 0x00020000);
+    const unsigned vt_bytes = TRV ? 16u : (unsigned)((size_t)p.B * p.heads * D * p.Spad * sizeof(T));
+    const __amdgpu_buffer_rsrc_t vrs =
+        __builtin_amdgcn_make_buffer_rsrc(TRV ? (void*)p.qkv : (void*)p.vt, 0, vt_bytes, 0x00020000);
+    unsigned kvo[NINST], vvo[NINST];
 #pragma unroll
-        for (int i = 0; i < NINST; ++i) {
-            const int g = i * NW + wave;
-            const int P = g * 64 + lane;
-            const int row = P / KNS, ps = P % KNS;
-            int key = kv0 + row;
-            if (key >= p.S) key = p.S - 1;  // masked by the valid bits; keeps the load in bounds
-            glds16(kbase + (size_t)key * ld + unswz_slot<KRB>(row, ps) * E16, sK + g * 1024);
+    for (int i = 0; i < NINST; ++i) {
+        const int P = (i * NW + wave) * 64 + lane;
+        const int row = P / KNS, ps = P % KNS;
+        kvo[i] = (unsigned)((row * ld + p.H + h * D) * (int)sizeof(T) + (unswz_slot<KRB>(row, ps) << 4));
+        if constexpr (TRV) {
+            vvo[i] = (unsigned)((row * ld + 2 * p.H + h * D) * (int)sizeof(T) + ((ps ^ vswz<KRB>(row)) << 4));
+        } else {
+            const int vrow = P >> 3, vps = P & 7;
+            vvo[i] = (unsigned)(((bh * D + vrow) * p.Spad) * (int)sizeof(T) + (unswz_slot<VRB>(vrow, vps) << 4));
         }
+    }
+    const unsigned ktile = (unsigned)(KVB * ld * (int)sizeof(T));  // byte advance of the qkv rows per KV tile
+    auto dma16 = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned char* dst, unsigned voff) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, voff, 0, 0, 0);
+    };
+    auto issue_k = [&](int j, unsigned char* sK) {
+#pragma unroll
+        for (int i = 0; i < NINST; ++i) dma16(qrs, sK + (i * NW + wave) * 1024, kvo[i] + (unsigned)j * ktile);
     };
     auto issue_v = [&](int j, unsigned char* sV) {
-        const int kv0 = j * KVB;
 #pragma unroll
         for (int i = 0; i < NINST; ++i) {
-            const int g = i * NW + wave;
-            const int P = g * 64 + lane;
-            if constexpr (TRV) {  // [key][dv] rows of the packed qkv, like K but at column 2H
-                const int row = P / KNS, ps = P % KNS;
-                int key = kv0 + row;
-                if (key >= p.S) key = p.S - 1;
-                glds16(kbase + p.H + (size_t)key * ld + (ps ^ vswz<KRB>(row)) * E16, sV + g * 1024);
-            } else {
-                const int row = P >> 3, ps = P & 7;
-                glds16(vbase + (size_t)row * p.Spad + kv0 + unswz_slot<VRB>(row, ps) * E16, sV + g * 1024);
-            }
+            if constexpr (TRV) dma16(qrs, sV + (i * NW + wave) * 1024, vvo[i] + (unsigned)j * ktile);
+            else dma16(vrs, sV + (i * NW + wave) * 1024, vvo[i] + (unsigned)(j * KVB * (int)sizeof(T)));
         }
     };
-
 
     // ---- Q fragments (column operand of S^T = K Q^T) ----
     uint4 qf[NQC];
@@ -161,7 +168,13 @@ __global__ __launch_bounds__(NW * KS * 64, (sizeof(T) == 2 && D == 128 && KS == 
         if (qrow >= p.S) qrow = p.S - 1;
         const T* src = qkv + (size_t)(b * p.S + qrow) * ld + h * D + hi * E16;
 #pragma unroll
-        for (int c = 0; c < NQC; ++c) qf[c] = *(const uint4*)(src + c * KC);
+        for (int c = 0; c < NQC; ++c) {  // q * log2(e)/sqrt(d), once: scores come out of the MFMA in exp2 units
+            float f[Vec16<T>::N];
+            Vec16<T>::unpack(*(const uint4*)(src + c * KC), f);
+#pragma unroll
+            for (int e = 0; e < Vec16<T>::N; ++e) f[e] *= p.scale_log2e;
+            qf[c] = Vec16<T>::pack(f);
+        }
     }
 
     f32x16_t oacc[ND];
@@ -170,7 +183,6 @@ __global__ __launch_bounds__(NW * KS * 64, (sizeof(T) == 2 && D == 128 && KS == 
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;  // running max (scaled, log2 units) and denominator
-    const float sc = p.scale_log2e;
 
     // This half's tile range; all halves run the same number of (two-barrier) iterations.
     const int nhalf = (ntiles + KS - 1) / KS;
@@ -186,12 +198,16 @@ __global__ __launch_bounds__(NW * KS * 64, (sizeof(T) == 2 && D == 128 && KS == 
             if (valid) issue_v(j, sV);  // V_j streams in underneath Q.K^T
             uint4 pf[4];
             if (valid) {
+            // the running max rides in the accumulator's initial value, so the common path is
+            // p = exp2(acc) with no per-element subtract
+            const float m_eff = (m_run == -INFINITY) ? 0.f : m_run;
+            const float m_init = -m_eff;
             // ---- S^T = K Q^T ----
             f32x16_t sacc[NKB];
     #pragma unroll
             for (int kb = 0; kb < NKB; ++kb)
     #pragma unroll
-                for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+                for (int r = 0; r < 16; ++r) sacc[kb][r] = m_init;  // accumulate (s - m) directly
             // chunk-outer / key-block-inner: consecutive MFMAs hit DIFFERENT accumulators, so the
             // accumulate latency of one chain hides under the other
     #pragma unroll
@@ -212,31 +228,35 @@ __global__ __launch_bounds__(NW * KS * 64, (sizeof(T) == 2 && D == 128 && KS == 
                         if (!((bits >> ko) & 1ull)) sacc[kb][r] = -INFINITY;
                     }
             }
-            // ---- online softmax, base 2, scale folded into the exponent's FMA ----
+            // ---- online softmax, base 2: acc holds s - m_eff ----
             float mx = sacc[0][0];
     #pragma unroll
             for (int kb = 0; kb < NKB; ++kb)
     #pragma unroll
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * sc;
-            if (__any(mx > m_run + THR)) {  // some row's max grew past the threshold: rescale (wave-uniform)
-                const float m_new = fmaxf(m_run, mx);
-                const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-                const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);  // m_run = -inf -> 0
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));  // growth of the row max relative to m_eff
+            float delta = 0.f;
+            if (__any(m_run == -INFINITY || mx > THR)) {  // first tile of a row, or its max grew past the threshold
+                const float m_new = fmaxf(m_run, m_eff + mx);
+                const float alpha = (m_new == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m_run - m_new);  // m_run=-inf -> 0
+                delta = (m_new == -INFINITY) ? 0.f : m_new - m_eff;
                 l_run *= alpha;
     #pragma unroll
                 for (int i = 0; i < ND; ++i)
     #pragma unroll
                     for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
                 m_run = m_new;
+    #pragma unroll
+                for (int kb = 0; kb < NKB; ++kb)
+    #pragma unroll
+                    for (int r = 0; r < 16; ++r) sacc[kb][r] -= delta;
             }
-            const float m_neg = (m_run == -INFINITY) ? 0.f : -m_run;
             float rs = 0.f;
     #pragma unroll
             for (int kb = 0; kb < NKB; ++kb)
     #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float e = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r], sc, m_neg));
+                    const float e = __builtin_amdgcn_exp2f(sacc[kb][r]);
                     sacc[kb][r] = e;
                     rs += e;
                 }
@@ -338,6 +358,9 @@ __global__ __launch_bounds__(NW * KS * 64, (sizeof(T) == 2 && D == 128 && KS == 
                 }
             }
     }
+#else
+    (void)p;
+#endif
 }
 
 // ---- V^T staging: qkv's V columns -> Vt[(b*heads+h)][dv][Spad], zero padded to Spad; for bf16

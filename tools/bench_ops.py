@@ -49,6 +49,26 @@ def gemm_case(name, M, N, Cin, taps, S, reps, variant):
     lib.fs2_op_set_gemm_variant(0)
 
 
+def gemm_ln_case(name, M, N, Cin, taps, S, reps, variant, res=True, relu=False):
+    """GEMM/conv + fused LayerNorm epilogue (the N=256 launches of the forward)."""
+    lib.fs2_op_set_gemm_variant(variant)
+    x = torch.randn(M, Cin, device=DEV).to(torch.bfloat16)
+    w = (torch.randn(N, taps * Cin, device=DEV) * (taps * Cin) ** -0.5).to(torch.bfloat16)
+    b = torch.randn(N, device=DEV)
+    r = torch.randn(M, N, device=DEV).to(torch.bfloat16) if res else None
+    g = torch.randn(N, device=DEV)
+    be = torch.randn(N, device=DEV)
+    y = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    tmp = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    t = timeit(lambda st: lib.fs2_op_gemm_ln(BF16, p(x), p(w), p(b), p(r), p(g), p(be), None, C.c_float(0.0), None, None,
+                                             p(y), p(tmp), M, N, Cin, taps, S, int(relu), st), reps)
+    fl = 2.0 * M * N * Cin * taps
+    by = 2.0 * (M * Cin + M * N * (2 if res else 1))
+    print(f"{name:28s} M={M:6d} N={N:5d} K={taps*Cin:5d} variant={variant}  {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TF  "
+          f"({fl/t/2.5e15*100:4.1f}% of 2.5 PF)  {by/t/1e12:5.2f} TB/s algorithmic")
+    lib.fs2_op_set_gemm_variant(0)
+
+
 def attn_case(name, B, S, H, heads, reps):
     qkv = torch.randn(B * S, 3 * H, device=DEV).to(torch.bfloat16)
     mask = torch.zeros(B, S, dtype=torch.uint8, device=DEV)
@@ -69,9 +89,10 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default="", help="substring filter on the case name")
     a = ap.parse_args()
-    global gemm_case, attn_case
+    global gemm_case, attn_case, gemm_ln_case
     if a.only:
-        g0, a0 = gemm_case, attn_case
+        g0, a0, l0 = gemm_case, attn_case, gemm_ln_case
+        gemm_ln_case = lambda name, *r, **k: l0(name, *r, **k) if a.only in name else None
         gemm_case = lambda name, *r: g0(name, *r) if a.only in name else None
         attn_case = lambda name, *r: a0(name, *r) if a.only in name else None
     variants = [0, 3, 4, 5, 6, 7] if a.variant < 0 else [a.variant]
@@ -89,6 +110,14 @@ def main():
             gemm_case("enc in_proj", 8192, 768, 256, 1, 8192, a.reps, v)
             gemm_case("dur-pred conv k=3", 8192, 256, 256, 3, 256, a.reps, v)
             gemm_case("square 4096^3", 4096, 4096, 4096, 1, 4096, a.reps, v)
+    if a.what in ("ln", "all"):
+        for v in ([0, 6, 7, 3, 4] if a.variant < 0 else [a.variant]):
+            gemm_ln_case("var-pred conv k=3 +LN", 49152, 256, 256, 3, 1536, a.reps, v, res=False, relu=True)
+            gemm_ln_case("dec conv2 1x1 +res+LN", 49152, 256, 1024, 1, 49152, a.reps, v)
+            gemm_ln_case("dec out_proj +res+LN", 49152, 256, 256, 1, 49152, a.reps, v)
+            gemm_ln_case("enc conv2 1x1 +res+LN", 8192, 256, 1024, 1, 8192, a.reps, v)
+            gemm_ln_case("enc out_proj +res+LN", 8192, 256, 256, 1, 8192, a.reps, v)
+            gemm_ln_case("dur-pred conv k=3 +LN", 8192, 256, 256, 3, 256, a.reps, v, res=False, relu=True)
     if a.what in ("attn", "all"):
         attn_case("decoder attention", 32, 1536, 256, 2, a.reps)
         attn_case("encoder attention", 32, 256, 256, 2, a.reps)

@@ -4,7 +4,7 @@
 set -e
 NAME=$1; ATT=${2:-lightningfastspeech2_amd/csrc/attention.hip}; GEMM=${3:-lightningfastspeech2_amd/csrc/gemm_mfma.hip}
 D=lightningfastspeech2_amd/csrc; V=lightningfastspeech2_amd/variants; mkdir -p $V/obj_$NAME
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$D"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$D $EXTRA"   # EXTRA="-DFOO" for ablation builds
 /opt/rocm/bin/hipcc $FLAGS -c $ATT -o $V/obj_$NAME/attention.o &
 /opt/rocm/bin/hipcc $FLAGS -c $GEMM -o $V/obj_$NAME/gemm_mfma.o &
 wait
