@@ -117,10 +117,6 @@ __global__ __launch_bounds__(NW * KS * 64, (sizeof(T) == 2 && D == 128 && KS == 
         if (KVB == 32) w = (w >> ((j * KVB) & 32)) & 0xffffffffull;
         return w;
     };
-    auto next_tile = [&](int j) {  // first tile >= j with at least one valid key (block-uniform)
-        while (j < ntiles && tile_bits(j) == 0ull) ++j;
-        return j;
-    };
     // K / V tiles come in by buffer-load-to-LDS DMA: one descriptor over THIS utterance's qkv rows
     // (SGPRs), a per-lane byte offset that is constant up to the tile advance, no per-tile address
     // arithmetic beyond one add.  Keys past the end of the utterance fall outside the descriptor's
@@ -193,8 +189,9 @@ __global__ __launch_bounds__(NW * KS * 64, (sizeof(T) == 2 && D == 128 && KS == 
             const int j = jbeg + it;
             const unsigned long long bits = j < jend ? tile_bits(j) : 0ull;
             const bool valid = bits != 0ull;  // fully padded tiles cost two barriers, nothing else
-            __syncthreads();   // K_j landed (hipcc drains this wave's DMA before the barrier); every
-                               // wave is done with P.V of the previous tile -> sV is free
+            dma_drain();       // this wave's share of K_j has landed (explicit: never left to hipcc's
+            __syncthreads();   // placement); after the barrier everyone's has, and every wave is
+                               // done with P.V of the previous tile -> sV is free
             if (valid) issue_v(j, sV);  // V_j streams in underneath Q.K^T
             uint4 pf[4];
             if (valid) {
@@ -275,6 +272,7 @@ __global__ __launch_bounds__(NW * KS * 64, (sizeof(T) == 2 && D == 128 && KS == 
                 pf[ch] = Vec16<T>::pack(f);
             }
             }
+            dma_drain();
             __syncthreads();   // V_j landed; every wave is done reading sK
             if (j + 1 < jend && tile_bits(j + 1) != 0ull) issue_k(j + 1, sK);  // next K under P.V
             if (valid) {

@@ -140,4 +140,10 @@ template <> struct Mma32<float> {
     }
 };
 
+// LDS-DMA completion is made explicit wherever a barrier publishes DMA'd operands: hipcc usually
+// puts a vmcnt(0) in front of such a barrier itself, but it may hoist that wait out of a loop (seen
+// when VGPR-returning loads sit ahead of the loop), which leaves the back-edge barrier unprotected
+// - a sporadic stale-operand race.
+__device__ inline void dma_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 }  // namespace fs2

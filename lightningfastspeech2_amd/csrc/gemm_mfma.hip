@@ -340,7 +340,7 @@ static int launch_glds_t(const GemmArgs& a, hipStream_t stream) {
 // k-fold; only the (256 x 64) weight tile changes every step.  Loop order: channel block (outer),
 // tap (inner) - a pure re-association of the K sum.  Zero "same" padding = slab rows outside
 // [0, S) of the utterance read the zero page.  Two slab buffers + two weight buffers, each its own
-// LDS object; every step: __syncthreads (hipcc drains this wave's DMAs in front of it), issue the
+// LDS object; every step: explicit vmcnt(0) + __syncthreads, issue the
 // next step's DMAs, multiply the current one.
 // =================================================================================================
 // Slab-kernel weight tile: MFMA row i (= lane group fg*4 + r in the accumulator) of fragment ni is
@@ -428,6 +428,46 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
     const int wm = wave >> 2, wn = wave & 3;
     const int fr = lane & 15, fg = lane >> 4;
     const int xrow0 = wm * (MI * 16) + fr;  // slab row of fragment 0 at tap 0
+    // Residual without an activation in front of it: start the accumulators AT the residual, fetched
+    // with 16-byte loads that land underneath the first operand DMAs instead of sitting, exposed,
+    // between the K loop and the row statistics.
+    const bool res_in_acc = LN && p.res && !p.relu;
+    if constexpr (LN) {
+        if (res_in_acc) {
+            const T* R = (const T*)p.res + (size_t)ub * S * p.ldc;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                int t = t0 + wm * (MI * 16) + mi * 16 + fr;
+                if (t >= S) t = S - 1;  // rows past the utterance end are never stored
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int n = wn * 64 + j * 32 + fg * 8;
+                    const T* src = R + (size_t)t * p.ldc + n;
+                    float rv[8];
+                    if (n + 7 < p.N) {
+                        if constexpr (sizeof(T) == 4) {
+                            const float4 q0 = *(const float4*)src, q1 = *(const float4*)(src + 4);
+                            rv[0] = q0.x; rv[1] = q0.y; rv[2] = q0.z; rv[3] = q0.w;
+                            rv[4] = q1.x; rv[5] = q1.y; rv[6] = q1.z; rv[7] = q1.w;
+                        } else {
+                            const uint4 q = *(const uint4*)src;
+                            const unsigned w4[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                rv[2 * e] = __uint_as_float(w4[e] << 16);
+                                rv[2 * e + 1] = __uint_as_float(w4[e] & 0xffff0000u);
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) rv[r] = (n + r < p.N) ? Num<T>::to_f32(src[r]) : 0.f;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) acc[2 * j + (r >> 2)][mi][r & 3] = rv[r];
+                }
+            }
+        }
+    }
     int woff[4][2];                          // weight fragment byte offsets (tap independent)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -458,7 +498,8 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
     // touches and does not wait for the DMAs it has just issued into the other buffers).
 #define FS2_SLAB_STEP(slab_cur, slab_nxt, w_cur, w_nxt, ccv, tapv)                          \
     {                                                                                       \
-        __syncthreads(); /* operands of this step landed; the other buffers are free */     \
+        dma_drain();     /* this wave's DMAs have landed ...                          */     \
+        __syncthreads(); /* ... and so have everyone else's; the other buffers are free */  \
         int ntp = (tapv) + 1, ncb = (ccv);                                                  \
         if (ntp == ntap) { ntp = 0; ++ncb; }                                                \
         if (ncb < ncc) issue_w(w_nxt, ncb, ntp);                                            \
@@ -501,7 +542,7 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
                 }
             }
         }
-        if (p.res) {
+        if (p.res && !res_in_acc) {
             const T* R = (const T*)p.res;
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {

@@ -117,6 +117,28 @@ def test_gemm_fused_layernorm_epilogue(dtype, variant, B, S, Cin, N, k, relu, us
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("variant", [6, 7, 3], ids=["slab32", "slab64", "slab128"])
+def test_gemm_fused_layernorm_residual_repeatable(dtype, variant):
+    """The residual is fetched into the accumulators ahead of the DMA'd K loop; a missing DMA wait on
+    the loop's back-edge barrier showed up here as sporadic stale-operand rows (about 1 launch in 15
+    at fp32, 64-row tiles).  Many reruns must be bit-identical and correct."""
+    B, S, Cin, N = 2, 333, 1024, 256
+    x, w = rnd(B * S, Cin, seed=50), rnd(N, Cin, 1, seed=51, scale=Cin ** -0.5)
+    b, res = rnd(N, seed=52), rnd(B * S, N, seed=53)
+    g, be = 1 + 0.2 * rnd(N, seed=54), 0.1 * rnd(N, seed=55)
+    z = G.rounded(x, dtype) @ G.rounded(w[:, :, 0], dtype).T + b + G.rounded(res, dtype)
+    ref = F.layer_norm(z, (N,), g, be, 1e-5)
+    G.lib().fs2_op_set_gemm_variant(variant)
+    try:
+        runs = [G.gemm_ln(dtype, x, G.pack_conv_weight(w), b, res, g, be)[0] for _ in range(25)]
+    finally:
+        G.lib().fs2_op_set_gemm_variant(0)
+    assert float((runs[0] - ref).abs().max()) <= tol(dtype, ref, f32=5e-5, bf16=2.5e-2)
+    for r in runs[1:]:
+        assert torch.equal(r, runs[0])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_dma_pipeline_large_and_repeatable(dtype):
     """Full-size decoder conv tile stream (K = 9*256 -> 36 chunks through the 3-stage DMA ring),
     many workgroups per CU in flight: compare with torch and demand bit-identical reruns (a DMA /
