@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--phones", type=int, default=256)
     ap.add_argument("--frames-per-phone", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fused-predictor", action="store_true", help="A/B: variance predictors layer by layer")
     ap.add_argument("--cpu-sample-batch", type=int, default=8)
     return ap.parse_args()
 
@@ -117,6 +118,8 @@ def main():
     # duration head weight 0 / bias ln(1+f): every phone gets f frames -> T = f * phones
     sd = synth_state_dict(cfg, 0, duration_bias=math.log(1.0 + args.frames_per_phone), duration_weight_scale=0.0)
     model = FastSpeech2(cfg, sd, precision=args.precision, device=dev)
+    if args.no_fused_predictor:
+        model.engine.set_fused_predictor(False)
     inp = synth_inputs(cfg, args.batch, args.phones, seed=1234 + 17 * rank)
     batch = {"phones": torch.from_numpy(inp["phones"]).to(dev), "speaker": torch.from_numpy(inp["speaker"]).to(dev)}
 

@@ -121,6 +121,9 @@ int fs2_decode(fs2_engine* e, const fs2_outputs* out, void* hip_stream);
  * what = "encoder_out" (B,L,H) | "regulated" | "adaptor_out" | "decoder_out" (B,T,H) |
  *        "bucket_<var>" (B,T) int32.  Requires fs2_set_debug(e, 1) before fs2_encode. */
 int fs2_set_debug(fs2_engine* e, int32_t on);
+/* A/B and parity aid: on = 0 runs every VariancePredictor as per-layer conv+LayerNorm launches, 1
+ * (default) as the single-launch kernel where the shape allows it (bf16, filter 256, k = 3, dense). */
+int fs2_set_fused_predictor(fs2_engine* e, int32_t on);
 /* Parity aid (the analogue of the reference's teacher forcing of variance targets,
  * model.py:417-422): the NEXT fs2_decode embeds these (B, T) int32 device bucket indices for
  * variance `variance_index` instead of bucketizing its own prediction.  One-shot. */
@@ -178,6 +181,13 @@ int fs2_op_embed(int32_t dtype, const int64_t* phones, const float* table, const
                  void* x, uint8_t* src_mask, int32_t B, int32_t L, int32_t H, int32_t n_phones, void* hip_stream);
 int fs2_op_spk_proj(const float* dvec, const float* w, const float* b, float* spk, int32_t B, int32_t H,
                     int32_t Din, void* hip_stream);
+/* VariancePredictor (model.py:482-522), dense k=3, H=256, bf16, one launch: w = (nlayers, H, taps*H)
+ * tap-major rows, bias / ln_g / ln_b = (nlayers, H) fp32, packed_scratch = nlayers * H * taps * H * 2
+ * bytes (fragment-ordered copy of w, built by this call).  FS2_ERR_SHAPE if the shape is not covered. */
+int fs2_op_predictor(int32_t dtype, const void* x, const void* w, const float* bias, const float* ln_g,
+                     const float* ln_b, const float* head_w, float head_b, const uint8_t* mask, float* pred,
+                     void* packed_scratch, int32_t B, int32_t S, int32_t H, int32_t nlayers, int32_t taps,
+                     void* hip_stream);
 /* dtype conversion helpers for tests: fp32 <-> engine dtype, n elements, device pointers */
 int fs2_op_convert(int32_t src_dtype, int32_t dst_dtype, const void* src, void* dst, size_t n, void* hip_stream);
 

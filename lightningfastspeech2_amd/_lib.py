@@ -98,6 +98,7 @@ def load():
     lib.fs2_set_priors.argtypes = [vp, vp, i32]
     lib.fs2_decode.argtypes = [vp, C.POINTER(Fs2OutputsC), vp]
     lib.fs2_set_debug.argtypes = [vp, i32]
+    lib.fs2_set_fused_predictor.argtypes = [vp, i32]
     lib.fs2_debug_copy.argtypes = [vp, C.c_char_p, vp, vp]
     lib.fs2_force_buckets.argtypes = [vp, i32, vp]
     lib.fs2_force_variance_targets.argtypes = [vp, i32, vp]
@@ -105,6 +106,7 @@ def load():
     lib.fs2_profile_read.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                      C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.fs2_op_convert.argtypes = [i32, i32, vp, vp, C.c_size_t, vp]
+    lib.fs2_op_predictor.argtypes = [i32, vp, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.fs2_op_set_gemm_variant.argtypes = [i32]
     lib.fs2_op_gemm.argtypes = [i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.fs2_op_gemm_ln.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]

@@ -37,6 +37,24 @@ int fs2_op_convert(int32_t sdt, int32_t ddt, const void* src, void* dst, size_t 
     return launch_convert(a, sdt, ddt, (hipStream_t)stream);
 }
 
+int fs2_op_predictor(int32_t dtype, const void* x, const void* w, const float* bias, const float* ln_g,
+                     const float* ln_b, const float* head_w, float head_b, const uint8_t* mask, float* pred,
+                     void* packed_scratch, int32_t B, int32_t S, int32_t H, int32_t nlayers, int32_t taps,
+                     void* stream) {
+    if (!predictor_fused_supported(dtype, H, taps, nlayers, S)) return FS2_ERR_SHAPE;
+    if (!x || !w || !bias || !ln_g || !ln_b || !head_w || !pred || !packed_scratch) return FS2_ERR_ARG;
+    const size_t lb = predictor_packed_bytes_per_layer();
+    for (int l = 0; l < nlayers; ++l) {
+        const int r = launch_pack_predictor_weights((const char*)w + (size_t)l * H * taps * H * 2,
+                                                    (char*)packed_scratch + lb * l, (hipStream_t)stream);
+        if (r != FS2_OK) return r;
+    }
+    PredictorArgs a;
+    a.x = x; a.wpk = packed_scratch; a.bias = bias; a.ln_g = ln_g; a.ln_b = ln_b; a.head_w = head_w; a.head_b = head_b;
+    a.mask = mask; a.pred = pred; a.B = B; a.S = S; a.H = H; a.nlayers = nlayers; a.taps = taps; a.eps = 1e-5f;
+    return launch_predictor_fused(a, (hipStream_t)stream);
+}
+
 int fs2_op_set_gemm_variant(int32_t variant) {
     fs2::g_gemm_variant = variant;
     return FS2_OK;

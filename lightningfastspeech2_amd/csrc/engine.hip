@@ -81,6 +81,9 @@ struct PredictorW {
     float* head_w = nullptr;
     float head_b = 0.f;
     int filt = 0;
+    // one-launch path (predictor_fused.hip): weights in MFMA fragment order, per-layer vectors stacked
+    void* wpk = nullptr;
+    float *bias_all = nullptr, *g_all = nullptr, *b_all = nullptr;
 };
 struct VarianceW {
     PredictorW pred;
@@ -104,6 +107,7 @@ struct fs2_engine {
     char err[512];
     bool finalized = false;
     bool debug = false;
+    bool fuse_predictor = true;
     std::map<std::string, HostTensor> host;
     std::map<std::string, std::vector<int64_t>> spec;
     std::vector<void*> dev_allocs;
@@ -385,6 +389,24 @@ int make_predictor(fs2_engine* e, const std::string& p, int nl, int filt, bool d
     }
     CHK(up_vec(e, p + ".linear.weight", &P->head_w));
     P->head_b = W(e, p + ".linear.bias").data[0];
+    const int taps = nl ? P->layers[0].c.taps : 0, cin = nl ? P->layers[0].c.Cin : 0;
+    if (!dw && nl && cin == filt && predictor_fused_supported(e->dt, filt, taps, nl, 1)) {
+        const size_t lb = predictor_packed_bytes_per_layer();
+        CHK(dev_alloc(e, &P->wpk, lb * nl));
+        std::vector<float> bias, g, b;
+        for (int j = 0; j < nl; ++j) {
+            const std::string q = p + ".layers." + std::to_string(j) + ".layers";
+            CHK(launch_pack_predictor_weights(P->layers[j].c.w, (char*)P->wpk + lb * j, nullptr));
+            const auto &hb = W(e, q + ".0.module.bias").data, &hg = W(e, q + ".2.weight").data, &hbe = W(e, q + ".2.bias").data;
+            bias.insert(bias.end(), hb.begin(), hb.end());
+            g.insert(g.end(), hg.begin(), hg.end());
+            b.insert(b.end(), hbe.begin(), hbe.end());
+        }
+        HIPCHK(e, hipStreamSynchronize(nullptr));
+        CHK(upload_f32(e, bias.data(), bias.size(), &P->bias_all));
+        CHK(upload_f32(e, g.data(), g.size(), &P->g_all));
+        CHK(upload_f32(e, b.data(), b.size(), &P->b_all));
+    }
     return FS2_OK;
 }
 
@@ -527,6 +549,18 @@ int conformer(fs2_engine* e, hipStream_t st, const LayerW& w, void* x, void* tmp
 int predictor(fs2_engine* e, hipStream_t st, const PredictorW& P, const void* x, int B, int S, const uint8_t* mask,
               float* pred, const LayerScratch& sc) {
     const int M = B * S;
+    if (P.wpk && e->fuse_predictor && predictor_fused_supported(e->dt, P.filt, P.layers[0].c.taps, (int)P.layers.size(), S)) {
+        PredictorArgs a;
+        a.x = x; a.wpk = P.wpk; a.bias = P.bias_all; a.ln_g = P.g_all; a.ln_b = P.b_all;
+        a.head_w = P.head_w; a.head_b = P.head_b; a.mask = mask; a.pred = pred;
+        a.B = B; a.S = S; a.H = P.filt; a.nlayers = (int)P.layers.size(); a.taps = P.layers[0].c.taps; a.eps = 1e-5f;
+        const double fl = 2.0 * M * (double)P.filt * P.filt * a.taps * a.nlayers;
+        const double by = (double)M * P.filt * e->esz + (double)M * 4;
+        Bracket br(e, FS2_K_CONV_GEMM, st, fl, by);
+        const int r = launch_predictor_fused(a, st);
+        if (r != FS2_OK) return fail(e, r, "fused predictor launch failed (B=%d S=%d)", B, S);
+        return FS2_OK;
+    }
     const void* src = x;
     for (size_t j = 0; j < P.layers.size(); ++j) {
         const PredLayerW& Lw = P.layers[j];
@@ -700,6 +734,12 @@ int fs2_finalize(fs2_engine* e) {
     }
     e->host.clear();
     e->finalized = true;
+    return FS2_OK;
+}
+
+int fs2_set_fused_predictor(fs2_engine* e, int32_t on) {
+    if (!e) return FS2_ERR_ARG;
+    e->fuse_predictor = on != 0;
     return FS2_OK;
 }
 

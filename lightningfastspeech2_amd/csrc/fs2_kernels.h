@@ -45,6 +45,27 @@ struct AttnArgs {
 int launch_transpose_v(const AttnArgs& a, int dtype, hipStream_t stream);  // fills a.vt from a.qkv
 int launch_attention(const AttnArgs& a, int dtype, hipStream_t stream);    // needs a.vt filled
 
+// Whole dense VariancePredictor (n x [conv k=3 -> ReLU -> LN] -> Linear(H,1) -> mask) in one launch;
+// bf16, H = 256, k = 3 (predictor_fused.hip).  wpk = per-layer weights in MFMA fragment order
+// (launch_pack_predictor_weights), bias / ln_g / ln_b = (nlayers, H) fp32.
+struct PredictorArgs {
+    const void* x;          // (B*S, H) bf16
+    const void* wpk;        // nlayers * predictor_packed_bytes_per_layer()
+    const float* bias;
+    const float* ln_g;
+    const float* ln_b;
+    const float* head_w;    // (H)
+    float head_b;
+    const uint8_t* mask;    // (B*S) 1 = pad -> pred 0, or null
+    float* pred;            // (B*S)
+    int B, S, H, nlayers, taps;
+    float eps;
+};
+bool predictor_fused_supported(int dtype, int H, int taps, int nlayers, int S);
+size_t predictor_packed_bytes_per_layer();
+int launch_pack_predictor_weights(const void* w_layer /*(H, taps*H) tap-major bf16*/, void* out_layer, hipStream_t stream);
+int launch_predictor_fused(const PredictorArgs& a, hipStream_t stream);
+
 struct ConvertArgs {
     const void* src;
     void* dst;

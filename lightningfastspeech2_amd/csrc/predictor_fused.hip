@@ -1,0 +1,265 @@
+// Whole VariancePredictor in one launch (reference: litfass/fastspeech2/model.py:482-522, dense
+// VarianceConvolutionLayer :525-561): n x [Conv1d(256 -> 256, k=3, same) -> ReLU -> LayerNorm] ->
+// Linear(256, 1) -> masked_fill, bf16 storage / fp32 arithmetic.
+//
+// Why a dedicated kernel: as five conv+LN launches every layer is one tile per CU with an exposed
+// load -> 12 K-steps -> store chain (25-27 us each, ~30 % of the MFMA rate) and a 50 MB HBM round
+// trip of activations nobody needs.  Here a workgroup keeps a (32*MI + 2)-row x 256-channel slab of
+// ONE utterance in LDS for the whole predictor:
+//   * the slab is filled once by buffer-load-to-LDS DMA (rows outside the utterance read zeros =
+//     the conv's "same" padding);
+//   * every layer's weights stream from L2 straight into MFMA B-fragments (pre-packed in fragment
+//     order at fs2_finalize, 1 KiB contiguous per wave-load, 4-deep register ring that runs across
+//     layer boundaries), so the K loop has NO barrier and no weight LDS traffic;
+//   * the conv+ReLU+LN epilogue writes the next layer's input back into the slab in place (rows
+//     outside [0, S) as zeros); only the last layer's scalar head leaves the chip.
+// Each layer makes one more row at both slab edges stale (its neighbour was not recomputed), so a
+// tile of R = 32*MI rows yields R - 2(n-1) finished rows; tiles overlap by that halo.
+#include "fs2_common.h"
+#include "fs2_kernels.h"
+
+namespace fs2 {
+
+namespace {
+constexpr int PF_H = 256, PF_TAPS = 3, PF_KB = PF_H / 32, PF_STEPS = PF_TAPS * PF_KB;  // 24 k-steps of 32
+constexpr int PF_STEP_U4 = 8 * 2 * 64;  // 16-byte fragments per k-step: [wave][fragment][lane]
+constexpr int PF_ROWB = PF_H * 2;       // slab row bytes (bf16)
+
+}  // namespace
+
+// W: (256, 3*256) tap-major bf16 rows of one layer -> fragment order [tap][kb][wave][ni][lane] x 16 B.
+// Wave wv owns output channels wv*32 .. +31; MFMA row i of fragment ni <-> channel
+// wv*32 + (i>>2)*8 + ni*4 + (i&3), so that a lane ends up with 8 consecutive channels (one 16-byte
+// slab slot) per row.
+__global__ void pack_predictor_weights_kernel(const bf16* __restrict__ W, uint4* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= PF_STEPS * PF_STEP_U4) return;
+    const int lane = idx & 63, ni = (idx >> 6) & 1, wv = (idx >> 7) & 7, step = idx >> 10;
+    const int tap = step / PF_KB, kb = step % PF_KB, fr = lane & 15, fg = lane >> 4;
+    const int ch = wv * 32 + (fr >> 2) * 8 + ni * 4 + (fr & 3);
+    out[idx] = *(const uint4*)(W + (size_t)ch * (PF_TAPS * PF_H) + tap * PF_H + kb * 32 + fg * 8);
+}
+
+// 8 waves, each: ALL R rows x 32 output channels (accumulators 2 x R/16 fragments).  The weight
+// fragments a wave needs are private to it (no redundant loads inside the workgroup, 2 KiB per wave
+// per k-step) and ride a 4-deep register ring: L2 latency under 256 CUs pulling the same lines is
+// ~2k cycles, a k-step is 450-900.  The activation fragments come from the LDS slab in two halves
+// of R/32 so that they never hold more than 28 VGPRs.
+template <int MI>
+__global__ __launch_bounds__(512) void predictor_fused_kernel(PredictorArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins exist in the device pass only
+    constexpr int R = MI * 32, HF = MI;  // HF = row fragments per half
+    __shared__ __attribute__((aligned(16))) unsigned char slab[(R + 2) * PF_ROWB];  // slab index i <-> t = t0 - 1 + i
+    __shared__ float red[2][8 * R];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int S = p.S, nl = p.nlayers, halo = nl - 1, V = R - 2 * halo;
+    const int tiles = (S + V - 1) / V;
+    const int ub = blockIdx.x / tiles, tm = blockIdx.x % tiles;
+    const int t0 = tm * V - halo;  // time of tile row 0
+
+    // ---- slab fill: 2 rows (1 KiB) per DMA instruction, 16-byte XOR swizzle applied on the source side
+    {
+        const bf16* xu = (const bf16*)p.x + (size_t)ub * S * PF_H;
+        const __amdgpu_buffer_rsrc_t xrs =
+            __builtin_amdgcn_make_buffer_rsrc((void*)xu, 0, (unsigned)((size_t)S * PF_ROWB), 0x00020000);
+        constexpr int NCH = (R + 2) / 2;
+#pragma unroll
+        for (int k = 0; k < (NCH + 7) / 8; ++k) {
+            const int c = k * 8 + wv;
+            if (c < NCH) {
+                const int i = 2 * c + (lane >> 5), ps = lane & 31, t = t0 - 1 + i;
+                const unsigned voff = (t >= 0 && t < S) ? (unsigned)(t * PF_ROWB + ((ps ^ (i & 15)) << 4)) : 0xFFFFF000u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(slab + c * 1024),
+                                                         16, voff, 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- weight stream: step g = (layer*3 + tap)*8 + kb, 16 KiB per step, this wave's 2 fragments
+    const uint4* __restrict__ wbase = (const uint4*)p.wpk + wv * 2 * 64 + lane;
+    const int total = nl * PF_STEPS;
+    auto loadB = [&](uint4 (&b)[2], int g) {
+        g = g < total ? g : total - 1;  // past the end: a harmless re-read instead of a branch
+        b[0] = wbase[(size_t)g * PF_STEP_U4];
+        b[1] = wbase[(size_t)g * PF_STEP_U4 + 64];
+    };
+    uint4 bw[4][2];
+    loadB(bw[0], 0);
+    loadB(bw[1], 1);
+    loadB(bw[2], 2);
+
+    dma_drain();
+    __syncthreads();
+
+    const int n0 = wv * 32 + fg * 8;  // this lane's 8 consecutive output channels
+    for (int l = 0; l < nl; ++l) {
+        f32x4_t acc[2][2 * HF];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2 * HF; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        // tile row r at tap tp lives at slab index r + tp; its 16-byte slot (kb*4 + fg) is stored at
+        // slot ^ (index & 15).  Taps: a rolled loop (short live ranges); the 8 k-blocks of a tap are
+        // unrolled so that the ring index is static.
+#pragma unroll 1
+        for (int tp = 0; tp < PF_TAPS; ++tp) {
+            const int i0 = fr + tp;
+            const unsigned char* arow_p = slab + i0 * PF_ROWB;
+            const int acx = (fg ^ (i0 & 15)) << 4;
+#pragma unroll
+            for (int kb = 0; kb < PF_KB; ++kb) {
+                loadB(bw[(kb + 3) & 3], (l * PF_TAPS + tp) * PF_KB + kb + 3);
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    uint4 fx[HF];
+#pragma unroll
+                    for (int mi = 0; mi < HF; ++mi)
+                        fx[mi] = *(const uint4*)(arow_p + (hf * HF + mi) * 16 * PF_ROWB + (acx ^ (kb << 6)));
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                        for (int mi = 0; mi < HF; ++mi) Mma16<bf16>::step(bw[kb & 3][ni], fx[mi], acc[ni][hf * HF + mi]);
+                }
+            }
+        }
+
+        // ---- bias + ReLU ----  lane: rows (m*16 + fr), channels n0 + ni*4 + r
+        {
+            const float* bias = p.bias + l * PF_H + n0;
+            const float4 b0 = *(const float4*)bias, b1 = *(const float4*)(bias + 4);
+            const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int m = 0; m < 2 * HF; ++m)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) acc[r >> 2][m][r & 3] = fmaxf(acc[r >> 2][m][r & 3] + bb[r], 0.f);
+        }
+        // ---- LayerNorm statistics, two-pass: lane partial -> lane groups -> the 8 column waves via LDS
+        const float invn = 1.0f / (float)PF_H;
+        float mean[2 * HF], rstd[2 * HF];
+#pragma unroll
+        for (int m = 0; m < 2 * HF; ++m) {
+            float sm = ((acc[0][m][0] + acc[0][m][1]) + (acc[0][m][2] + acc[0][m][3])) +
+                       ((acc[1][m][0] + acc[1][m][1]) + (acc[1][m][2] + acc[1][m][3]));
+            sm += __shfl_xor(sm, 16, 64);
+            sm += __shfl_xor(sm, 32, 64);
+            if (fg == 0) red[0][wv * R + m * 16 + fr] = sm;
+        }
+        __syncthreads();  // also: every wave is past its K loop -> the slab may be rewritten below
+#pragma unroll
+        for (int m = 0; m < 2 * HF; ++m) {
+            const int row = m * 16 + fr;
+            float t8 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) t8 += red[0][w * R + row];
+            mean[m] = t8 * invn;
+            float q = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float d = acc[r >> 2][m][r & 3] - mean[m];
+                q += d * d;
+            }
+            q += __shfl_xor(q, 16, 64);
+            q += __shfl_xor(q, 32, 64);
+            if (fg == 0) red[1][wv * R + row] = q;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 2 * HF; ++m) {
+            const int row = m * 16 + fr;
+            float t8 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) t8 += red[1][w * R + row];
+            rstd[m] = 1.0f / sqrtf(t8 * invn + p.eps);
+        }
+        const bool last = l + 1 == nl;
+        float gg[8], ee[8], hw[8];
+        {
+            const float* gam = p.ln_g + l * PF_H + n0;
+            const float* bet = p.ln_b + l * PF_H + n0;
+            const float4 g0 = *(const float4*)gam, g1 = *(const float4*)(gam + 4);
+            const float4 e0 = *(const float4*)bet, e1 = *(const float4*)(bet + 4);
+            gg[0] = g0.x; gg[1] = g0.y; gg[2] = g0.z; gg[3] = g0.w; gg[4] = g1.x; gg[5] = g1.y; gg[6] = g1.z; gg[7] = g1.w;
+            ee[0] = e0.x; ee[1] = e0.y; ee[2] = e0.z; ee[3] = e0.w; ee[4] = e1.x; ee[5] = e1.y; ee[6] = e1.z; ee[7] = e1.w;
+            if (last) {
+                const float4 h0 = *(const float4*)(p.head_w + n0), h1 = *(const float4*)(p.head_w + n0 + 4);
+                hw[0] = h0.x; hw[1] = h0.y; hw[2] = h0.z; hw[3] = h0.w; hw[4] = h1.x; hw[5] = h1.y; hw[6] = h1.z; hw[7] = h1.w;
+            }
+        }
+        if (!last) {
+            // next layer's input, in place; rows outside the utterance stay the conv's zero padding
+#pragma unroll
+            for (int m = 0; m < 2 * HF; ++m) {
+                const int row = m * 16 + fr, t = t0 + row, i = row + 1;
+                float y[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) y[r] = (acc[r >> 2][m][r & 3] - mean[m]) * rstd[m] * gg[r] + ee[r];
+                const bool inside = t >= 0 && t < S;
+                const uint4 o = inside ? make_uint4(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]),
+                                                    pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7]))
+                                       : make_uint4(0u, 0u, 0u, 0u);
+                *(uint4*)(slab + i * PF_ROWB + (((n0 >> 3) ^ (i & 15)) << 4)) = o;
+            }
+            __syncthreads();  // slab holds layer l's output
+            continue;
+        }
+        // ---- Linear(256, 1) head + mask (model.py:519-522) ----
+#pragma unroll
+        for (int m = 0; m < 2 * HF; ++m) {
+            float d = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) d += ((acc[r >> 2][m][r & 3] - mean[m]) * rstd[m] * gg[r] + ee[r]) * hw[r];
+            d += __shfl_xor(d, 16, 64);
+            d += __shfl_xor(d, 32, 64);
+            if (fg == 0) red[0][wv * R + m * 16 + fr] = d;  // red[0] was last read two barriers ago
+        }
+        __syncthreads();
+        if (tid < R) {
+            const int row = tid, t = t0 + row;
+            if (row >= halo && row < R - halo && t < S) {
+                float d = p.head_b;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) d += red[0][w * R + row];
+                const size_t o = (size_t)ub * S + t;
+                p.pred[o] = (p.mask && p.mask[o]) ? 0.f : d;
+            }
+        }
+    }
+#else
+    (void)p;
+#endif
+}
+
+bool predictor_fused_supported(int dtype, int H, int taps, int nlayers, int S) {
+    return dtype == FS2_BF16 && H == PF_H && taps == PF_TAPS && nlayers >= 1 && nlayers <= 16 && S >= 1 &&
+           (size_t)S * PF_ROWB < 0xFFFFF000ull;
+}
+
+int launch_pack_predictor_weights(const void* w_layer, void* out_layer, hipStream_t stream) {
+    const int n = PF_STEPS * PF_STEP_U4;
+    hipLaunchKernelGGL(pack_predictor_weights_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (const bf16*)w_layer,
+                       (uint4*)out_layer);
+    return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
+}
+
+size_t predictor_packed_bytes_per_layer() { return (size_t)PF_STEPS * PF_STEP_U4 * 16; }
+
+int launch_predictor_fused(const PredictorArgs& a, hipStream_t stream) {
+    if (!predictor_fused_supported(FS2_BF16, a.H, a.taps, a.nlayers, a.S)) return FS2_ERR_SHAPE;
+    if (a.B <= 0) return FS2_OK;
+    // tile height: 224 rows fills the chip at the decoder's frame counts; short sequences (the
+    // duration predictor at phone level) take 96-row tiles so that more CUs get one
+    const int halo2 = 2 * (a.nlayers - 1);
+    auto tiles = [&](int R) { return (long)a.B * ((a.S + (R - halo2) - 1) / (R - halo2)); };
+    if (96 - halo2 >= 32 && tiles(224) < 200 && tiles(96) > tiles(224)) {
+        hipLaunchKernelGGL((predictor_fused_kernel<3>), dim3((unsigned)tiles(96)), dim3(512), 0, stream, a);
+    } else {
+        if (224 - halo2 < 32) return FS2_ERR_SHAPE;
+        hipLaunchKernelGGL((predictor_fused_kernel<7>), dim3((unsigned)tiles(224)), dim3(512), 0, stream, a);
+    }
+    return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
+}
+
+}  // namespace fs2

@@ -161,6 +161,10 @@ class Engine:
                    f"debug_copy({what})")
         return t
 
+    def set_fused_predictor(self, on: bool):
+        """A/B: run the variance/duration predictors as one launch each (default) or layer by layer."""
+        _lib.check(self.lib.fs2_set_fused_predictor(self.handle, int(on)), self.handle, "set_fused_predictor")
+
     def profile_enable(self, kernel_class: int, on: bool = True):
         _lib.check(self.lib.fs2_profile_enable(self.handle, kernel_class, int(on)), self.handle, "profile_enable")
 

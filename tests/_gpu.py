@@ -71,6 +71,23 @@ def gemm_ln(dtype, x, w_packed, bias, res, g, b, taps=1, S=None, relu=False, dot
     return (None if y is None else y.float().cpu()), (None if pred is None else pred.cpu())
 
 
+def predictor(x, ws, biases, gammas, betas, head_w, head_b, mask, B, S):
+    """Single-launch VariancePredictor (bf16): ws = list of (H, H, k) conv weights (torch layout)."""
+    H, nl, k = x.shape[-1], len(ws), ws[0].shape[2]
+    xd = to_dev(x.reshape(B * S, H), BF16)
+    wd = to_dev(torch.stack([pack_conv_weight(w) for w in ws]), BF16)
+    f = lambda a: torch.stack([torch.as_tensor(v).float() for v in a]).to(DEV).contiguous()
+    bd, gd, bed = f(biases), f(gammas), f(betas)
+    hw = torch.as_tensor(head_w).float().to(DEV)
+    mk = None if mask is None else torch.as_tensor(mask).to(torch.uint8).to(DEV).contiguous()
+    pred = torch.full((B * S,), float("nan"), dtype=torch.float32, device=DEV)
+    scratch = torch.empty(nl * H * k * H * 2, dtype=torch.uint8, device=DEV)
+    ok(lib().fs2_op_predictor(BF16, p(xd), p(wd), p(bd), p(gd), p(bed), p(hw), float(head_b), p(mk), p(pred), p(scratch),
+                              B, S, H, nl, k, stream()), "predictor")
+    torch.cuda.synchronize()
+    return pred.cpu().reshape(B, S)
+
+
 def pack_conv_weight(w):
     """torch (N, Cin, k) -> (N, k*Cin) tap-major (what the engine builds at fs2_finalize)."""
     w = torch.as_tensor(w).float()

@@ -138,6 +138,43 @@ def test_gemm_fused_layernorm_residual_repeatable(dtype, variant):
         assert torch.equal(r, runs[0])
 
 
+def _predictor_ref(x, ws, bs, gs, bes, hw, hb, mask):
+    """model.py:510-522 with the kernel's storage rounding: bf16 x / weights / inter-layer
+    activations, fp32 arithmetic."""
+    r = lambda t: t.to(torch.bfloat16).float()
+    h = r(x)
+    for j, (w, b, g, be) in enumerate(zip(ws, bs, gs, bes)):
+        z = F.conv1d(h.transpose(1, 2), r(w), b, padding="same").transpose(1, 2)
+        h = F.layer_norm(torch.relu(z), (x.shape[-1],), g, be, 1e-5)
+        if j + 1 < len(ws):
+            h = r(h)
+    return (h @ hw + hb).masked_fill(mask, 0)
+
+
+@pytest.mark.parametrize("B,S,nl", [(2, 300, 5), (3, 37, 2), (1, 1536, 5), (2, 217, 1), (4, 216, 5), (2, 450, 3), (5, 5, 5)])
+def test_predictor_single_launch(B, S, nl):
+    """n x [conv k=3 -> ReLU -> LN] -> Linear -> mask in ONE launch with the activations resident in
+    LDS (predictor_fused.hip): tile seams (halo rows), utterance edges (zero padding at every
+    layer, not only the first) and masking against a torch restatement."""
+    H = 256
+    x = rnd(B, S, H, seed=70)
+    ws = [rnd(H, H, 3, seed=71 + j, scale=(3 * H) ** -0.5) for j in range(nl)]
+    bs = [0.3 * rnd(H, seed=80 + j) for j in range(nl)]
+    gs = [1 + 0.2 * rnd(H, seed=90 + j) for j in range(nl)]
+    bes = [0.1 * rnd(H, seed=100 + j) for j in range(nl)]
+    hw, hb = rnd(H, seed=110, scale=H ** -0.5), 0.25
+    mask = torch.zeros(B, S, dtype=torch.bool)
+    mask[:, S - S // 4:] = True
+    ref = _predictor_ref(x, ws, bs, gs, bes, hw, hb, mask)
+    got = G.predictor(x, ws, bs, gs, bes, hw, hb, mask, B, S)
+    assert not torch.isnan(got).any()
+    assert torch.equal(got[mask], torch.zeros_like(got[mask]))
+    err = float((got - ref).abs().max())
+    assert err <= 2e-2 * (float(ref.abs().max()) + 1), err
+    again = G.predictor(x, ws, bs, gs, bes, hw, hb, mask, B, S)
+    assert torch.equal(again, got)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_dma_pipeline_large_and_repeatable(dtype):
     """Full-size decoder conv tile stream (K = 9*256 -> 36 chunks through the 3-stage DMA ring),

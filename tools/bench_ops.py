@@ -69,6 +69,22 @@ def gemm_ln_case(name, M, N, Cin, taps, S, reps, variant, res=True, relu=False):
     lib.fs2_op_set_gemm_variant(0)
 
 
+def predictor_case(name, B, S, nl, reps):
+    """Whole dense VariancePredictor (nl x conv k=3 + ReLU + LN, head) as one launch."""
+    H, k = 256, 3
+    x = torch.randn(B * S, H, device=DEV).to(torch.bfloat16)
+    w = (torch.randn(nl, H, k * H, device=DEV) * (k * H) ** -0.5).to(torch.bfloat16)
+    b, g, be = (torch.randn(nl, H, device=DEV) for _ in range(3))
+    hw = torch.randn(H, device=DEV)
+    pred = torch.empty(B * S, device=DEV)
+    scratch = torch.empty(nl * H * k * H * 2, dtype=torch.uint8, device=DEV)
+    t = timeit(lambda st: lib.fs2_op_predictor(BF16, p(x), p(w), p(b), p(g), p(be), p(hw), C.c_float(0.1), None, p(pred),
+                                               p(scratch), B, S, H, nl, k, st), reps)
+    fl = 2.0 * B * S * H * H * k * nl
+    print(f"{name:28s} B={B} S={S} layers={nl}  {t*1e6:8.1f} us (incl. {nl} weight-pack launches)  {fl/t/1e12:7.1f} TF  "
+          f"({fl/t/2.5e15*100:4.1f}% of 2.5 PF)")
+
+
 def attn_case(name, B, S, H, heads, reps):
     qkv = torch.randn(B * S, 3 * H, device=DEV).to(torch.bfloat16)
     mask = torch.zeros(B, S, dtype=torch.uint8, device=DEV)
@@ -118,6 +134,9 @@ def main():
             gemm_ln_case("enc conv2 1x1 +res+LN", 8192, 256, 1024, 1, 8192, a.reps, v)
             gemm_ln_case("enc out_proj +res+LN", 8192, 256, 256, 1, 8192, a.reps, v)
             gemm_ln_case("dur-pred conv k=3 +LN", 8192, 256, 256, 3, 256, a.reps, v, res=False, relu=True)
+    if a.what in ("pred", "all"):
+        predictor_case("variance predictor fused", 32, 1536, 5, a.reps)
+        predictor_case("duration predictor fused", 32, 256, 2, a.reps)
     if a.what in ("attn", "all"):
         attn_case("decoder attention", 32, 1536, 256, 2, a.reps)
         attn_case("encoder attention", 32, 256, 256, 2, a.reps)
