@@ -191,6 +191,48 @@ int fs2_op_predictor(int32_t dtype, const void* x, const void* w, const float* b
 /* dtype conversion helpers for tests: fp32 <-> engine dtype, n elements, device pointers */
 int fs2_op_convert(int32_t src_dtype, int32_t dst_dtype, const void* src, void* dst, size_t n, void* hip_stream);
 
+/* ================================================================================================
+ * HiFi-GAN generator: the step right after the mel forward.  Replaces
+ * litfass.third_party.hifigan.Synthesiser.__call__ -> Generator.forward
+ * (litfass/third_party/hifigan/__init__.py:19-43, models.py:112-165), resblock type "1".
+ * Weights are passed under the generator's own state_dict names AFTER remove_weight_norm
+ * ("conv_pre.weight", "ups.0.weight" (Cin, Cout, k), "resblocks.3.convs1.0.weight", "conv_post.bias" ...);
+ * the host mirror (lightningfastspeech2_amd/hifigan.py) folds weight_g / weight_v pairs.
+ * ================================================================================================ */
+#define FS2_VOC_MAX_STAGES 8
+#define FS2_VOC_MAX_KERNELS 4
+typedef struct fs2_voc_config {
+    int32_t abi_version;      /* FS2_ABI_VERSION */
+    int32_t dtype;            /* fs2_dtype */
+    int32_t n_mels;           /* 80 */
+    int32_t initial_channel;  /* upsample_initial_channel (config.json:13); halves per stage, multiples of 32 */
+    int32_t n_stages;
+    int32_t up_rates[FS2_VOC_MAX_STAGES];     /* upsample_rates; kernel - 2 * padding must equal the rate */
+    int32_t up_kernels[FS2_VOC_MAX_STAGES];   /* upsample_kernel_sizes */
+    int32_t n_kernels;                        /* len(resblock_kernel_sizes) */
+    int32_t rb_kernels[FS2_VOC_MAX_KERNELS];  /* odd */
+    int32_t rb_dilations[FS2_VOC_MAX_KERNELS][3];
+} fs2_voc_config;
+typedef struct fs2_vocoder fs2_vocoder;
+
+int fs2_voc_create(const fs2_voc_config* cfg, fs2_vocoder** out);
+void fs2_voc_destroy(fs2_vocoder* v);
+const char* fs2_voc_last_error(const fs2_vocoder* v);
+/* host fp32 data; ndim/shape as torch reports them */
+int fs2_voc_load_weight(fs2_vocoder* v, const char* name, const float* data, const int64_t* shape, int32_t ndim);
+int fs2_voc_finalize(fs2_vocoder* v);
+/* samples per mel frame = prod(up_rates) */
+int32_t fs2_voc_hop(const fs2_vocoder* v);
+/* mel: (B, T, n_mels) fp32 device (FastSpeech2's output layout); lengths: (B) int32 device valid frames
+ * per utterance or NULL; wav: (B, T * hop) fp32 device in [-1, 1] (samples past an utterance's length
+ * are left untouched).  Each utterance is synthesised as the reference does it: alone, zero padding at
+ * its own ends in every layer (generator.py:163-170). */
+int fs2_voc_synthesize(fs2_vocoder* v, const float* mel, const int32_t* lengths, int32_t B, int32_t T, float* wav,
+                       void* hip_stream);
+/* parity tap: copy stage output `stage` (0 = conv_pre, i = after upsample stage i) of the last call as
+ * fp32 (B, T * up_i, C_i) into a device buffer */
+int fs2_voc_debug_copy(fs2_vocoder* v, int32_t stage, float* dst, void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

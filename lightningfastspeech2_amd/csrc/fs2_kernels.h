@@ -66,6 +66,29 @@ size_t predictor_packed_bytes_per_layer();
 int launch_pack_predictor_weights(const void* w_layer /*(H, taps*H) tap-major bf16*/, void* out_layer, hipStream_t stream);
 int launch_predictor_fused(const PredictorArgs& a, hipStream_t stream);
 
+// One Conv1d of the HiFi-GAN generator (vocoder_conv.hip).  Activations are (B, S, channels)
+// time-major in the engine dtype; w is the layer's weights in MFMA fragment order
+// [n-tile][step = tap * (cin_pad / KE) + kc, padded to a multiple of 4][wn][2][64] x 16 B.
+struct VocConvArgs {
+    const void* x;          // (B, S, cin) engine dtype, or fp32 when in_fp32 (the mel)
+    const void* w;
+    const float* bias;      // (n)
+    const void* res;        // (B, S, n) or null: added before scaling
+    void* out;              // (B, S, n); post: (B, S) fp32
+    const int32_t* lengths; // (B) valid FRAMES per utterance or null (= all S rows valid)
+    int len_scale;          // rows of this layer per frame
+    int B, S;
+    int cin, cin_pad, n, taps, dil, pad;  // out[t] = sum_tap x[t - pad + tap*dil] . W[tap]
+    int wn;                 // wave columns (n-tile = wn * 32 channels), 8 / wn wave rows
+    float in_slope;         // LeakyReLU slope applied to the input while staging (1 = none)
+    float scale;            // (acc + bias + res) * scale
+    int accumulate;         // += previous contents of out
+    int in_fp32;
+    int post;               // conv_post: one channel, tanh, fp32 out
+};
+int voc_steps_padded(int taps, int cin_pad, int dtype);
+int launch_vocoder_conv(const VocConvArgs& a, int dtype, hipStream_t stream);
+
 struct ConvertArgs {
     const void* src;
     void* dst;
