@@ -86,6 +86,7 @@ struct VocConvArgs {
     int in_fp32;
     int post;               // conv_post: one channel, tanh, fp32 out
 };
+extern int g_voc_lds_limit;  // KiB cap on a conv workgroup's slab; 0 = heuristic
 int voc_steps_padded(int taps, int cin_pad, int dtype);
 int launch_vocoder_conv(const VocConvArgs& a, int dtype, hipStream_t stream);
 

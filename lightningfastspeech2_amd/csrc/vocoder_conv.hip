@@ -53,31 +53,43 @@ __global__ __launch_bounds__(512) void vocoder_conv_kernel(VocConvArgs p) {
     {
         const int rows = BM + halo, pieces = rows * ns;
         const size_t ubase = (size_t)ub * p.S;
-        for (int q = tid; q < pieces; q += 512) {
-            const int i = q / ns, s = q - i * ns, t = t0 - p.pad + i, c = s * E16;
-            float f[E16];
+        // FB pieces per thread per trip: all their global loads are issued before the first is used
+        constexpr int FB = 4;
+        for (int q0 = tid; q0 < pieces; q0 += 512 * FB) {
+            float f[FB][E16];
+            int dst[FB];
 #pragma unroll
-            for (int e = 0; e < E16; ++e) f[e] = 0.f;
-            if (t >= 0 && t < len && c < p.cin) {
-                if (p.in_fp32) {
-                    const float* src = (const float*)p.x + (ubase + t) * p.cin + c;
+            for (int u = 0; u < FB; ++u) {
+                const int q = q0 + u * 512;
+                const int i = q / ns, s = q - i * ns, t = t0 - p.pad + i, c = s * E16;
+                dst[u] = q < pieces ? i * rowb + ((s ^ ((i >> sh) & smask)) << 4) : -1;
 #pragma unroll
-                    for (int e = 0; e < E16; e += 4) {
-                        if (c + e < p.cin) {  // cin is a multiple of 4
-                            const float4 v = *(const float4*)(src + e);
-                            f[e] = v.x; f[e + 1] = v.y; f[e + 2] = v.z; f[e + 3] = v.w;
+                for (int e = 0; e < E16; ++e) f[u][e] = 0.f;
+                if (q < pieces && t >= 0 && t < len && c < p.cin) {
+                    if (p.in_fp32) {
+                        const float* src = (const float*)p.x + (ubase + t) * p.cin + c;
+#pragma unroll
+                        for (int e = 0; e < E16; e += 4) {
+                            if (c + e < p.cin) {  // cin is a multiple of 4
+                                const float4 v = *(const float4*)(src + e);
+                                f[u][e] = v.x; f[u][e + 1] = v.y; f[u][e + 2] = v.z; f[u][e + 3] = v.w;
+                            }
                         }
+                    } else {
+                        const uint4 v = *(const uint4*)((const T*)p.x + (ubase + t) * p.cin + c);
+                        Vec16<T>::unpack(v, f[u]);
                     }
-                } else {
-                    const uint4 v = *(const uint4*)((const T*)p.x + (ubase + t) * p.cin + c);
-                    Vec16<T>::unpack(v, f);
-                }
-                if (p.in_slope != 1.f) {
-#pragma unroll
-                    for (int e = 0; e < E16; ++e) f[e] = lrelu(f[e], p.in_slope);
                 }
             }
-            *(uint4*)(slab + i * rowb + ((s ^ ((i >> sh) & smask)) << 4)) = Vec16<T>::pack(f);
+#pragma unroll
+            for (int u = 0; u < FB; ++u) {
+                if (dst[u] < 0) continue;
+                if (p.in_slope != 1.f) {
+#pragma unroll
+                    for (int e = 0; e < E16; ++e) f[u][e] = lrelu(f[u][e], p.in_slope);
+                }
+                *(uint4*)(slab + dst[u]) = Vec16<T>::pack(f[u]);
+            }
         }
     }
 
@@ -196,13 +208,19 @@ __global__ __launch_bounds__(512) void vocoder_conv_kernel(VocConvArgs p) {
     }
 }
 
+int g_voc_lds_limit = 0;  // KiB; 0 = heuristic (tuning knob, fs2_op_set_vocoder_lds_limit)
+
 // rows per wave (x16) the slab of this layer leaves room for
 static int voc_pick_mi16(const VocConvArgs& a, int esz, size_t* smem) {
     static const int cand[4] = {14, 8, 4, 2};
     const int WM = 8 / a.wn;
+    // One maximal slab per CU leaves a workgroup alone with its fill -> multiply -> store chain;
+    // slabs of at most 76 KiB put two workgroups on a CU that cover each other (measured on the V1
+    // generator, 32 x 1536 frames: 62.6 ms at 150 KiB, 46.8 at 76, 47.7 at 52, 51.2 at 36).
+    const size_t limit = (size_t)(g_voc_lds_limit > 0 ? g_voc_lds_limit : 76) * 1024;
     for (int c = 0; c < 4; ++c) {
         const size_t b = (size_t)(WM * cand[c] * 16 + (a.taps - 1) * a.dil) * a.cin_pad * esz;
-        if (b <= 150 * 1024) {
+        if (b <= limit || (c == 3 && b <= 150 * 1024)) {
             *smem = b;
             return cand[c];
         }

@@ -1,0 +1,47 @@
+#!/usr/bin/env python
+"""Per-layer times of one HiFi-GAN pass from a rocprofv3 rocpd database (kernel trace of
+tools/bench_vocoder.py): the last 78 vocoder_conv dispatches, in launch order, labelled by layer."""
+import sqlite3
+import sys
+
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lightningfastspeech2_amd.hifigan import HifiGanConfig
+
+
+def labels(cfg):
+    ch = cfg.channels()
+    out = [("conv_pre", 2.0 * 80 * ch[0] * 7, 1)]
+    up = 1
+    for i, (u, k) in enumerate(zip(cfg.upsample_rates, cfg.upsample_kernel_sizes)):
+        out.append((f"ups{i} {ch[i]}->{ch[i+1]} x{u}", up * u * 2.0 * ch[i] * ch[i + 1] * (k / u), up))
+        up *= u
+        for rk, rd in zip(cfg.resblock_kernel_sizes, cfg.resblock_dilation_sizes):
+            for d in rd:
+                out.append((f"s{i} C={ch[i+1]} k={rk} d={d}", up * 2.0 * ch[i + 1] ** 2 * rk, up))
+                out.append((f"s{i} C={ch[i+1]} k={rk} d=1 +res", up * 2.0 * ch[i + 1] ** 2 * rk, up))
+    out.append(("conv_post", up * 2.0 * ch[-1] * 7, up))
+    return out
+
+
+def main(db, frames):
+    con = sqlite3.connect(db)
+    rows = con.execute("select name, start, end from kernels where name like '%vocoder_conv%' order by start").fetchall()
+    lab = labels(HifiGanConfig())
+    rows = rows[-len(lab):]
+    tot = 0.0
+    agg = {}
+    for (name, s, e), (l, fl, up) in zip(rows, lab):
+        us = (e - s) / 1e3
+        tot += us
+        key = l.split(" d=")[0] if l.startswith("s") else l
+        a = agg.setdefault(key, [0.0, 0.0])
+        a[0] += us
+        a[1] += fl * frames
+    print(f"one pass: {tot/1e3:.2f} ms kernel time over {len(rows)} launches")
+    for k, (us, fl) in agg.items():
+        print(f"{k:28s} {us:9.1f} us  {fl/us/1e6:8.1f} TF  ({fl/us/1e6/2500*100:4.1f}% of 2.5 PF)  {100*us/tot:5.1f}% of pass")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], float(sys.argv[2]))
