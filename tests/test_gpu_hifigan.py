@@ -97,3 +97,39 @@ def test_errors():
     g = HifiGan(cfg, sd)
     with pytest.raises(ValueError):
         g.synthesize(torch.zeros(1, 4, 64))
+
+
+def test_mel_forward_into_vocoder_matches_per_utterance_reference_flow():
+    """SpeechGenerator.generate_samples (generator.py:151-223): FastSpeech2 forward -> per-utterance
+    unpadded mel -> generator -> int16 -> float32/32767.  HIP: the padded mel batch stays in HBM and
+    the generator takes the valid frame counts; oracle: the reference's own per-utterance loop."""
+    from lightningfastspeech2_amd.config import Fs2Config
+    from lightningfastspeech2_amd.model import FastSpeech2
+    from lightningfastspeech2_amd.synthesis import SpeechGenerator
+    from lightningfastspeech2_amd.weights import synth_inputs, synth_state_dict as fs2_sd
+    from oracle import oracle_cpu
+    cfg = Fs2Config(n_phones=40, encoder_hidden=64, decoder_hidden=64, encoder_head=2, decoder_head=2,
+                    encoder_layers=2, decoder_layers=2, encoder_kernel_sizes=[3, 5], decoder_kernel_sizes=[5, 3],
+                    encoder_conv_filter_size=128, decoder_conv_filter_size=128, encoder_depthwise_conv=False,
+                    decoder_depthwise_conv=False, variance_filter_size=64, variance_depthwise_conv=False,
+                    variance_nlayers=[2, 2, 2], duration_filter_size=64, duration_depthwise_conv=False, n_mels=80)
+    sd = fs2_sd(cfg, 3, randomize_norm=True, duration_bias=1.3)
+    inp = synth_inputs(cfg, 3, 12, seed=5, lengths=[12, 8, 3])
+    vcfg = HifiGanConfig(upsample_rates=[4, 2], upsample_kernel_sizes=[8, 4], upsample_initial_channel=128,
+                         resblock_kernel_sizes=[3, 5], resblock_dilation_sizes=[[1, 2, 3], [1, 3, 5]])
+    vsd = synth_state_dict(vcfg, 4)
+    ref = oracle_cpu.forward(sd, cfg, inp["phones"], inp["speaker"])
+    model = FastSpeech2(cfg, sd, precision="fp32", device="cuda:0")
+    gen = SpeechGenerator(model, HifiGan(vcfg, vsd, precision="fp32"))
+    out = gen.generate_samples({"phones": torch.from_numpy(inp["phones"]), "speaker": torch.from_numpy(inp["speaker"])},
+                               return_duration=True)
+    assert out["fs"] == 22050 and len(out["audios"]) == 3
+    for b in range(3):
+        keep = ~ref["tgt_mask"][b]
+        n = int(keep.sum())
+        wav = hifigan_cpu.synthesize(vsd, vcfg, ref["mel"][b][keep].unsqueeze(0))[0]
+        want = (wav.numpy() * 32768.0).astype("int16").astype(np.float32) / 32767.0
+        got = out["audios"][b]
+        assert got.dtype == np.float32 and got.shape == (n * vcfg.hop,)
+        assert float(np.abs(got - want).max()) <= F32_TOL
+        assert torch.equal(out["durations"][b], ref["duration_rounded"][b])
