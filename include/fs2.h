@@ -156,6 +156,8 @@ int fs2_profile_read(fs2_engine* e, int32_t kernel_class, double* total_ms, int6
 int fs2_op_set_gemm_variant(int32_t variant);
 /* tuning knob: cap (KiB) on the LDS operand slab of a vocoder conv workgroup; 0 = built-in heuristic */
 int fs2_op_set_vocoder_lds_limit(int32_t kib);
+/* A/B knob: 1 (default) = whole resblocks of the 32/64-channel stages as one LDS-resident launch, 0 = conv by conv */
+int fs2_op_set_vocoder_fused_resblock(int32_t on);
 int fs2_op_gemm(int32_t dtype, int32_t out_dtype, const void* x, const void* w, const float* bias, void* c,
                 int32_t M, int32_t N, int32_t Cin, int32_t taps, int32_t S, int32_t relu, void* hip_stream);
 int fs2_op_attention(int32_t dtype, const void* qkv, const uint8_t* key_pad_mask, void* out, void* vt_scratch,

@@ -55,6 +55,11 @@ int fs2_op_predictor(int32_t dtype, const void* x, const void* w, const float* b
     return launch_predictor_fused(a, (hipStream_t)stream);
 }
 
+int fs2_op_set_vocoder_fused_resblock(int32_t on) {
+    fs2::g_voc_fused_resblock = on ? 1 : 0;
+    return FS2_OK;
+}
+
 int fs2_op_set_vocoder_lds_limit(int32_t kib) {
     fs2::g_voc_lds_limit = kib;
     return FS2_OK;

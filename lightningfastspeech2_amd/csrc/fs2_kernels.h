@@ -86,6 +86,22 @@ struct VocConvArgs {
     int in_fp32;
     int post;               // conv_post: one channel, tanh, fp32 out
 };
+// One whole ResBlock "1" (three (c1 dilated, c2) pairs) on an LDS-resident tile, vocoder_resblock.hip.
+struct VocResblockArgs {
+    const void* x;          // (B, S, C) block input
+    void* out;              // (B, S, C): (resblock(x)) * scale (+ previous contents)
+    const void* w;          // six convs back to back, fragment order [conv][step][wn][2][64] x 16 B
+    const float* bias;      // (6, C): c1[0], c2[0], c1[1], c2[1], c1[2], c2[2]
+    const int32_t* lengths;
+    int len_scale;
+    int B, S, C, taps, wn;
+    int dil[3];
+    float slope, scale;
+    int accumulate;
+};
+extern int g_voc_fused_resblock;  // 1 = use the fused kernel where it applies
+int voc_resblock_mi16(const VocResblockArgs& a, int dtype);  // 0 = shape not covered
+int launch_vocoder_resblock(const VocResblockArgs& a, int dtype, hipStream_t stream);
 extern int g_voc_lds_limit;  // KiB cap on a conv workgroup's slab; 0 = heuristic
 int voc_steps_padded(int taps, int cin_pad, int dtype);
 int launch_vocoder_conv(const VocConvArgs& a, int dtype, hipStream_t stream);

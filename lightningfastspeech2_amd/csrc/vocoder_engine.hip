@@ -56,6 +56,8 @@ struct fs2_vocoder {
     VocLayer pre, post;
     std::vector<VocLayer> ups;
     std::vector<VocLayer> c1, c2;  // [(stage * n_kernels + j) * 3 + m]
+    struct FusedRb { void* w = nullptr; float* b = nullptr; };
+    std::vector<FusedRb> rb;       // [stage * n_kernels + j]: six convs back to back (narrow stages)
     std::vector<int> chan, upf;    // channels / cumulative upsampling after stage i (index 0 = conv_pre)
     // workspace
     void* ws = nullptr;
@@ -97,7 +99,45 @@ int next_pow2(int x) {
 }
 
 // W (n, cin, taps) fp32 host (conv form: out[t] = sum_tap x[t - pad + tap*dil] . W[:, :, tap]) ->
-// fragment order on the device, in the engine dtype
+// fragment order [n-tile][step][wn][2][64] x 16 B as fp32 staging
+void frag_order(int dt, const std::vector<float>& W, int n, int cin, int cin_pad, int taps, int wn_cols, bool post,
+                std::vector<float>* stage) {
+    const int KE = dt == FS2_BF16 ? 32 : 16, e16 = dt == FS2_BF16 ? 8 : 4;
+    const int nkc = cin_pad / KE, nsteps4 = voc_steps_padded(taps, cin_pad, dt);
+    const int ntiles = post ? 1 : n / (wn_cols * 32);
+    const size_t nfrag = (size_t)ntiles * nsteps4 * wn_cols * 2 * 64;
+    stage->assign(nfrag * e16, 0.f);
+    for (int nt = 0; nt < ntiles; ++nt)
+        for (int g = 0; g < taps * nkc; ++g) {
+            const int tap = g / nkc, kc = g % nkc;
+            for (int wn = 0; wn < wn_cols; ++wn)
+                for (int ni = 0; ni < 2; ++ni)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int fr = lane & 15, fg = lane >> 4;
+                        const int ch = nt * wn_cols * 32 + wn * 32 + (fr >> 2) * 8 + ni * 4 + (fr & 3);
+                        if (ch >= n) continue;
+                        float* dst = &(*stage)[((((size_t)nt * nsteps4 + g) * wn_cols + wn) * 2 + ni) * 64 * e16 + (size_t)lane * e16];
+                        for (int e = 0; e < e16; ++e) {
+                            const int c = kc * KE + fg * e16 + e;
+                            if (c < cin) dst[e] = W[((size_t)ch * cin + c) * taps + tap];
+                        }
+                    }
+        }
+}
+
+int upload_frags(fs2_vocoder* v, const std::vector<float>& stage, void** out) {
+    if (v->dt == FS2_F32) {
+        VCHK(vdev_alloc(v, out, stage.size() * 4));
+        VHIP(v, hipMemcpy(*out, stage.data(), stage.size() * 4, hipMemcpyHostToDevice));
+    } else {
+        std::vector<unsigned short> h(stage.size());
+        for (size_t i = 0; i < stage.size(); ++i) h[i] = f32_to_bf16(stage[i]).v;
+        VCHK(vdev_alloc(v, out, h.size() * 2));
+        VHIP(v, hipMemcpy(*out, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+    }
+    return FS2_OK;
+}
+
 int pack_layer(fs2_vocoder* v, const std::vector<float>& W, const std::vector<float>& bias, int n, int cin, int taps,
                int dil, int pad, bool post, VocLayer* L) {
     L->cin = cin;
@@ -109,36 +149,9 @@ int pack_layer(fs2_vocoder* v, const std::vector<float>& W, const std::vector<fl
     const int n32 = post ? 1 : n / 32;
     if (!post && n % 32) return vfail(v, FS2_ERR_SHAPE, "channel count %d is not a multiple of 32", n);
     L->wn = (n32 % 8 == 0) ? 8 : (n32 % 4 == 0) ? 4 : (n32 % 2 == 0) ? 2 : 1;
-    const int KE = v->dt == FS2_BF16 ? 32 : 16, e16 = v->dt == FS2_BF16 ? 8 : 4;
-    const int nkc = L->cin_pad / KE, nsteps4 = voc_steps_padded(taps, L->cin_pad, v->dt);
-    const int ntiles = post ? 1 : n / (L->wn * 32);
-    const size_t nfrag = (size_t)ntiles * nsteps4 * L->wn * 2 * 64;
-    std::vector<float> stage(nfrag * e16, 0.f);
-    for (int nt = 0; nt < ntiles; ++nt)
-        for (int g = 0; g < taps * nkc; ++g) {
-            const int tap = g / nkc, kc = g % nkc;
-            for (int wn = 0; wn < L->wn; ++wn)
-                for (int ni = 0; ni < 2; ++ni)
-                    for (int lane = 0; lane < 64; ++lane) {
-                        const int fr = lane & 15, fg = lane >> 4;
-                        const int ch = nt * L->wn * 32 + wn * 32 + (fr >> 2) * 8 + ni * 4 + (fr & 3);
-                        if (ch >= n) continue;
-                        float* dst = &stage[((((size_t)nt * nsteps4 + g) * L->wn + wn) * 2 + ni) * 64 * e16 + (size_t)lane * e16];
-                        for (int e = 0; e < e16; ++e) {
-                            const int c = kc * KE + fg * e16 + e;
-                            if (c < cin) dst[e] = W[((size_t)ch * cin + c) * taps + tap];
-                        }
-                    }
-        }
-    if (v->dt == FS2_F32) {
-        VCHK(vdev_alloc(v, &L->w, stage.size() * 4));
-        VHIP(v, hipMemcpy(L->w, stage.data(), stage.size() * 4, hipMemcpyHostToDevice));
-    } else {
-        std::vector<unsigned short> h(stage.size());
-        for (size_t i = 0; i < stage.size(); ++i) h[i] = f32_to_bf16(stage[i]).v;
-        VCHK(vdev_alloc(v, &L->w, h.size() * 2));
-        VHIP(v, hipMemcpy(L->w, h.data(), h.size() * 2, hipMemcpyHostToDevice));
-    }
+    std::vector<float> stage;
+    frag_order(v->dt, W, n, cin, L->cin_pad, taps, L->wn, post, &stage);
+    VCHK(upload_frags(v, stage, &L->w));
     std::vector<float> bp(post ? 32 : n, 0.f);
     for (size_t i = 0; i < bias.size() && i < bp.size(); ++i) bp[i] = bias[i];
     VCHK(vdev_alloc(v, (void**)&L->b, bp.size() * 4));
@@ -288,6 +301,29 @@ int fs2_voc_finalize(fs2_vocoder* v) {
         }
     }
     VCHK(conv_layer(v, "conv_post", 1, v->chan.back(), 7, 1, true, &v->post));
+    // narrow stages: the six convs of a resblock back to back for the LDS-resident kernel
+    v->rb.resize((size_t)c.n_stages * c.n_kernels);
+    for (int i = 0; i < c.n_stages; ++i) {
+        const int C = v->chan[i + 1];
+        if (C != 32 && C != 64) continue;
+        for (int j = 0; j < c.n_kernels; ++j) {
+            const std::string r = "resblocks." + std::to_string(i * c.n_kernels + j);
+            std::vector<float> all, bias;
+            for (int m = 0; m < 3; ++m)
+                for (const char* grp : {".convs1.", ".convs2."}) {
+                    const HostT& w = v->host.at(r + grp + std::to_string(m) + ".weight");
+                    const HostT& b = v->host.at(r + grp + std::to_string(m) + ".bias");
+                    std::vector<float> st;
+                    frag_order(v->dt, w.data, C, C, C, c.rb_kernels[j], C / 32, false, &st);
+                    all.insert(all.end(), st.begin(), st.end());
+                    bias.insert(bias.end(), b.data.begin(), b.data.end());
+                }
+            fs2_vocoder::FusedRb& f = v->rb[(size_t)i * c.n_kernels + j];
+            VCHK(upload_frags(v, all, &f.w));
+            VCHK(vdev_alloc(v, (void**)&f.b, bias.size() * 4));
+            VHIP(v, hipMemcpy(f.b, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
+        }
+    }
     v->host.clear();
     v->finalized = true;
     return FS2_OK;
@@ -338,6 +374,19 @@ int fs2_voc_synthesize(fs2_vocoder* v, const float* mel, const int32_t* lengths,
         VCHK(run_conv(v, st, v->ups[i], v->stage_out[i], u, nullptr, lengths, v->upf[i], B, T * v->upf[i], 0.1f, 1.f, false));
         const int S = T * v->upf[i + 1], sc = v->upf[i + 1];
         for (int j = 0; j < c.n_kernels; ++j) {
+            const fs2_vocoder::FusedRb& f = v->rb[(size_t)i * c.n_kernels + j];
+            if (f.w) {
+                VocResblockArgs ra;
+                ra.x = u; ra.out = v->stage_out[i + 1]; ra.w = f.w; ra.bias = f.b; ra.lengths = lengths; ra.len_scale = sc;
+                ra.B = B; ra.S = S; ra.C = v->chan[i + 1]; ra.taps = c.rb_kernels[j]; ra.wn = ra.C / 32;
+                for (int m = 0; m < 3; ++m) ra.dil[m] = c.rb_dilations[j][m];
+                ra.slope = 0.1f; ra.scale = inv; ra.accumulate = j > 0 ? 1 : 0;
+                if (voc_resblock_mi16(ra, v->dt)) {
+                    const int rr = launch_vocoder_resblock(ra, v->dt, st);
+                    if (rr != FS2_OK) return vfail(v, rr, "fused resblock launch failed (C=%d k=%d)", ra.C, ra.taps);
+                    continue;
+                }
+            }
             const void* r = u;
             for (int m = 0; m < 3; ++m) {
                 const size_t idx = ((size_t)i * c.n_kernels + j) * 3 + m;

@@ -1,0 +1,247 @@
+// One whole HiFi-GAN ResBlock "1" (reference: litfass/third_party/hifigan/models.py:98-104) per launch
+// for the narrow stages (32 / 64 channels):
+//     for (c1, c2, d) in pairs:  x = c2(lrelu(c1_d(lrelu(x)))) + x
+// As six separate convs these stages move ~2 GB of activations per conv for a few GFLOP each and sit
+// on HBM / launch latency.  Here a workgroup keeps its tile of the residual stream AND
+// of the intermediate in LDS for all six convs (the single-launch predictor's scheme,
+// predictor_fused.hip):
+//   slab X = lrelu(x) of the tile (+ guard rows), slab Y = lrelu(c1 output); both hold the
+//   ACTIVATED values because that is what the next conv multiplies; the raw residual is recovered
+//   from X by the inverse map (a < 0 ? a / slope : a) in the epilogue of c2, which then overwrites
+//   its own elements of X in place.  Rows outside the utterance are written as zeros after every
+//   conv (the reference pads every conv of a single unpadded utterance with zeros).
+//   Weights of the six convs lie back to back in fragment order; one 4-deep register ring streams
+//   them from L2 across conv boundaries; no barrier inside a K loop, two per conv pair.
+// Every conv makes (k-1)/2 * dil more rows at both tile edges stale, so a tile of R rows finishes
+// R - 2H rows, H = sum over pairs of (k-1)/2 * (d + 1); tiles overlap by that halo.
+#include "fs2_common.h"
+#include "fs2_kernels.h"
+
+namespace fs2 {
+
+namespace {
+template <typename T> struct RbT;
+template <> struct RbT<bf16> { static constexpr int KE = 32; };
+template <> struct RbT<float> { static constexpr int KE = 16; };
+__device__ inline float rb_lrelu(float v, float slope) { return v < 0.f ? v * slope : v; }
+}  // namespace
+
+template <typename T, int MI16>
+__global__ __launch_bounds__(512) void vocoder_resblock_kernel(VocResblockArgs p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int KE = RbT<T>::KE, HF = MI16 / 2, RW = MI16 * 16;
+    constexpr int E16 = 16 / (int)sizeof(T), SPL = 8 / E16;  // slots per lane per row (8 channels)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int WN = p.wn, WM = 8 / WN;
+    const int wn = wave % WN, wm = wave / WN;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int R = WM * RW, c = (p.taps - 1) / 2;
+    const int dmax = p.dil[0] > p.dil[1] ? (p.dil[0] > p.dil[2] ? p.dil[0] : p.dil[2]) : (p.dil[1] > p.dil[2] ? p.dil[1] : p.dil[2]);
+    const int H = c * (p.dil[0] + p.dil[1] + p.dil[2] + 3), G = c * dmax, V = R - 2 * H;
+    const int tiles = (p.S + V - 1) / V;
+    const int ub = blockIdx.x / tiles, tm = blockIdx.x % tiles;
+    const int len = p.lengths ? p.lengths[ub] * p.len_scale : p.S;
+    const int t0 = tm * V;
+    if (t0 >= len) return;  // block-uniform
+    const int tbase = t0 - H;  // time of tile row 0; slab index i <-> tile row i - G
+
+    const int rowb = p.C * (int)sizeof(T), ns = rowb >> 4;
+    const int sh = ns >= 16 ? 0 : (ns == 8 ? 1 : 2), smask = (ns >= 16 ? 16 : ns) - 1;
+    const int srows = R + 2 * G;
+    unsigned char* slabX = lds;
+    unsigned char* slabY = lds + (size_t)srows * rowb;
+    auto slot_off = [&](int i, int s) { return i * rowb + ((s ^ ((i >> sh) & smask)) << 4); };
+
+    // ---- X <- lrelu(x) for every slab row (guards included), zeros outside the utterance; Y guards <- 0
+    {
+        const size_t ubase = (size_t)ub * p.S;
+        const int pieces = srows * ns;
+        constexpr int FB = 4;
+        for (int q0 = tid; q0 < pieces; q0 += 512 * FB) {
+            float f[FB][E16];
+            int dst[FB];
+#pragma unroll
+            for (int u = 0; u < FB; ++u) {
+                const int q = q0 + u * 512;
+                const int i = q / ns, s = q - i * ns, t = tbase - G + i;
+                dst[u] = q < pieces ? slot_off(i, s) : -1;
+#pragma unroll
+                for (int e = 0; e < E16; ++e) f[u][e] = 0.f;
+                if (q < pieces && t >= 0 && t < len)
+                    Vec16<T>::unpack(*(const uint4*)((const T*)p.x + (ubase + t) * p.C + s * E16), f[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < FB; ++u) {
+                if (dst[u] < 0) continue;
+#pragma unroll
+                for (int e = 0; e < E16; ++e) f[u][e] = rb_lrelu(f[u][e], p.slope);
+                *(uint4*)(slabX + dst[u]) = Vec16<T>::pack(f[u]);
+            }
+        }
+        const int gp = 2 * G * ns;
+        for (int q = tid; q < gp; q += 512) {
+            int i = q / ns;
+            const int s = q - i * ns;
+            if (i >= G) i += R;
+            *(uint4*)(slabY + slot_off(i, s)) = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+
+    // ---- weight stream over all six convs: [conv][step][wave column][fragment][lane] x 16 B ----
+    const int nkc = p.C / KE, nsteps = p.taps * nkc, nsteps4 = (nsteps + 3) & ~3;
+    const int total = 6 * nsteps4;
+    const uint4* __restrict__ wbase = (const uint4*)p.w + (size_t)wn * 128 + lane;
+    const size_t wstep = (size_t)WN * 128;
+    auto loadB = [&](uint4 (&b)[2], int g) {
+        g = g < total ? g : total - 1;
+        b[0] = wbase[g * wstep];
+        b[1] = wbase[g * wstep + 64];
+    };
+    uint4 bw[4][2];
+    loadB(bw[0], 0);
+    loadB(bw[1], 1);
+    loadB(bw[2], 2);
+
+    const int wrow0 = wm * RW;
+    const int nkc_shift = __builtin_ctz(nkc);
+    const int n0 = wn * 32 + fg * 8;  // this lane's 8 consecutive channels
+    const float inv_slope = 1.0f / p.slope;
+    __syncthreads();
+
+#pragma unroll 1
+    for (int j = 0; j < 6; ++j) {
+        const int second = j & 1;
+        const int dil = second ? 1 : p.dil[j >> 1];
+        const unsigned char* src = second ? slabY : slabX;
+        const int ibase = G - c * dil + wrow0 + fr;  // slab index of this lane's fragment-0 row at tap 0
+
+        f32x4_t acc[2][MI16];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < MI16; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int g0 = 0; g0 < nsteps4; g0 += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int g = g0 + u;
+                loadB(bw[(u + 3) & 3], j * nsteps4 + g + 3);
+                int tap = g >> nkc_shift;
+                const int kc = g & (nkc - 1);
+                tap = tap < p.taps ? tap : p.taps - 1;  // padded steps: zero weights x any valid rows
+                const int i0 = ibase + tap * dil;
+                const unsigned char* arow_p = src + i0 * rowb;
+                const int acx = ((kc * 4 + fg) ^ ((i0 >> sh) & smask)) << 4;
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    uint4 fx[HF];
+#pragma unroll
+                    for (int mi = 0; mi < HF; ++mi) fx[mi] = *(const uint4*)(arow_p + (hf * HF + mi) * 16 * rowb + acx);
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                        for (int mi = 0; mi < HF; ++mi) Mma16<T>::step(bw[u][ni], fx[mi], acc[ni][hf * HF + mi]);
+                }
+            }
+        }
+
+        // ---- epilogue: lane = rows (m*16 + fr), channels n0 .. n0+7 ----
+        float bb[8];
+        {
+            const float* bp = p.bias + j * p.C + n0;
+            const float4 b0 = *(const float4*)bp, b1 = *(const float4*)(bp + 4);
+            bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
+        }
+        const bool last = j == 5;
+#pragma unroll
+        for (int m = 0; m < MI16; ++m) {
+            const int row = wrow0 + m * 16 + fr, t = tbase + row, i = G + row;
+            const bool inside = t >= 0 && t < len;
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = acc[r >> 2][m][r & 3] + bb[r];
+            if (second) {  // + residual, recovered from the activated copy
+                float a[8];
+#pragma unroll
+                for (int q = 0; q < SPL; ++q) Vec16<T>::unpack(*(const uint4*)(slabX + slot_off(i, n0 / E16 + q)), a + q * E16);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] += a[r] < 0.f ? a[r] * inv_slope : a[r];
+            }
+            if (!last) {
+                unsigned char* dstb = second ? slabX : slabY;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] = inside ? rb_lrelu(v[r], p.slope) : 0.f;
+#pragma unroll
+                for (int q = 0; q < SPL; ++q) *(uint4*)(dstb + slot_off(i, n0 / E16 + q)) = Vec16<T>::pack(v + q * E16);
+            } else if (inside && row >= H && row < H + V) {
+                T* dst = (T*)p.out + ((size_t)ub * p.S + t) * p.C + n0;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] *= p.scale;
+                if (p.accumulate) {
+                    float ov[8];
+#pragma unroll
+                    for (int q = 0; q < SPL; ++q) Vec16<T>::unpack(*(const uint4*)(dst + q * E16), ov + q * E16);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] += ov[r];
+                }
+#pragma unroll
+                for (int q = 0; q < SPL; ++q) *(uint4*)(dst + q * E16) = Vec16<T>::pack(v + q * E16);
+            }
+        }
+        if (!last) __syncthreads();
+    }
+}
+
+int g_voc_fused_resblock = 1;  // A/B knob (fs2_op_set_vocoder_fused_resblock)
+
+static size_t rb_lds_bytes(const VocResblockArgs& a, int mi16, int esz) {
+    const int c = (a.taps - 1) / 2;
+    int dmax = a.dil[0];
+    for (int m = 1; m < 3; ++m) dmax = a.dil[m] > dmax ? a.dil[m] : dmax;
+    const int R = (8 / a.wn) * mi16 * 16;
+    return (size_t)2 * (R + 2 * c * dmax) * a.C * esz;
+}
+
+// tile height (x16 rows per wave) for this resblock, 0 = not covered by the fused kernel
+int voc_resblock_mi16(const VocResblockArgs& a, int dtype) {
+    if (!g_voc_fused_resblock) return 0;
+    const int esz = dtype == FS2_BF16 ? 2 : 4;
+    if (a.C != 32 && a.C != 64) return 0;
+    if (a.wn != a.C / 32 || !(a.taps & 1)) return 0;
+    const int c = (a.taps - 1) / 2, H = c * (a.dil[0] + a.dil[1] + a.dil[2] + 3);
+    static const int cand[2] = {8, 4};
+    for (int k = 0; k < 2; ++k) {
+        const int R = (8 / a.wn) * cand[k] * 16;
+        if (rb_lds_bytes(a, cand[k], esz) <= 150 * 1024 && R - 2 * H >= R / 2) return cand[k];
+    }
+    return 0;
+}
+
+template <typename T, int MI16>
+static int rb_launch_t(const VocResblockArgs& a, size_t smem, hipStream_t stream) {
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)vocoder_resblock_kernel<T, MI16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                150 * 1024) != hipSuccess)
+            return FS2_ERR_HIP;
+        attr = true;
+    }
+    const int c = (a.taps - 1) / 2, H = c * (a.dil[0] + a.dil[1] + a.dil[2] + 3);
+    const int R = (8 / a.wn) * MI16 * 16, V = R - 2 * H;
+    const int tiles = (a.S + V - 1) / V;
+    hipLaunchKernelGGL((vocoder_resblock_kernel<T, MI16>), dim3((unsigned)(tiles * a.B)), dim3(512), smem, stream, a);
+    return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
+}
+
+int launch_vocoder_resblock(const VocResblockArgs& a, int dtype, hipStream_t stream) {
+    if (a.B <= 0 || a.S <= 0) return FS2_OK;
+    const int mi = voc_resblock_mi16(a, dtype);
+    if (!mi) return FS2_ERR_SHAPE;
+    const size_t smem = rb_lds_bytes(a, mi, dtype == FS2_BF16 ? 2 : 4);
+    if (dtype == FS2_BF16) return mi == 8 ? rb_launch_t<bf16, 8>(a, smem, stream) : rb_launch_t<bf16, 4>(a, smem, stream);
+    return mi == 8 ? rb_launch_t<float, 8>(a, smem, stream) : rb_launch_t<float, 4>(a, smem, stream);
+}
+
+}  // namespace fs2

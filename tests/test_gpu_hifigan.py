@@ -66,6 +66,34 @@ def test_stage_outputs_and_tile_seams(precision):
     assert float((wav - ref_wav).abs().max()) <= tol
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_fused_resblock_equals_conv_by_conv(precision):
+    """The LDS-resident resblock kernel (32/64-channel stages) against the same generator run conv by
+    conv: same arithmetic up to the storage rounding of the residual stream, several tiles, ragged."""
+    from lightningfastspeech2_amd import _lib
+    cfg = HifiGanConfig()
+    sd = synth_state_dict(cfg, 8)
+    rs = np.random.RandomState(2)
+    mel = torch.from_numpy((rs.standard_normal((2, 23, 80)) * 1.5 - 4.0).astype(np.float32))
+    lengths = torch.tensor([23, 10], dtype=torch.int32)
+    g = HifiGan(cfg, sd, precision=precision)
+    try:
+        _lib.load().fs2_op_set_vocoder_fused_resblock(0)
+        plain = g.synthesize(mel, lengths).cpu()
+        s_plain = [g.debug_stage(s).cpu() for s in (3, 4)]
+        _lib.load().fs2_op_set_vocoder_fused_resblock(1)
+        fused = g.synthesize(mel, lengths).cpu()
+        s_fused = [g.debug_stage(s).cpu() for s in (3, 4)]
+    finally:
+        _lib.load().fs2_op_set_vocoder_fused_resblock(1)
+    tol = 2e-5 if precision == "fp32" else 5e-2
+    for a, b, up in zip(s_plain, s_fused, (128, 256)):
+        for u, n in enumerate(lengths.tolist()):
+            ref = a[u, :n * up]
+            assert float((b[u, :n * up] - ref).abs().max()) <= tol * (float(ref.abs().max()) + 1.0)
+    assert float((plain - fused).abs().max()) <= (2e-5 if precision == "fp32" else BF16_TOL)
+
+
 def test_synthesiser_mirror_int16():
     """Synthesiser(mel) -> int16 (1, T*256), the reference wrapper's contract (__init__.py:37-43),
     from a checkpoint-form state_dict ({"generator": weight_g / weight_v ...})."""

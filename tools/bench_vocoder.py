@@ -47,14 +47,16 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=192)
+    ap.add_argument("--no-fused-resblock", action="store_true", help="A/B: narrow-stage resblocks conv by conv")
     ap.add_argument("--lds-limit", type=int, default=0, help="tuning: KiB cap on a conv workgroup's LDS slab (0 = heuristic)")
     a = ap.parse_args()
     cfg = HifiGanConfig()
     sd = synth_state_dict(cfg, 0)
     g = HifiGan(cfg, sd, precision=a.precision)
+    from lightningfastspeech2_amd import _lib
     if a.lds_limit:
-        from lightningfastspeech2_amd import _lib
         _lib.load().fs2_op_set_vocoder_lds_limit(a.lds_limit)
+    _lib.load().fs2_op_set_vocoder_fused_resblock(0 if a.no_fused_resblock else 1)
     rs = np.random.RandomState(1234)
     mel = torch.from_numpy((rs.standard_normal((a.batch, a.frames, 80)) * 1.5 - 4.0).astype(np.float32)).cuda()
     for _ in range(a.warmup):
