@@ -86,16 +86,17 @@ struct VocConvArgs {
     int in_fp32;
     int post;               // conv_post: one channel, tanh, fp32 out
 };
-// One whole ResBlock "1" (three (c1 dilated, c2) pairs) on an LDS-resident tile, vocoder_resblock.hip.
+// A whole ResBlock "1" (npairs = 3 (c1 dilated, c2) pairs) or one pair (npairs = 1) on an LDS-resident
+// tile, vocoder_resblock.hip.  out = (x after the pairs) * scale (+ previous contents).
 struct VocResblockArgs {
     const void* x;          // (B, S, C) block input
     void* out;              // (B, S, C): (resblock(x)) * scale (+ previous contents)
-    const void* w;          // six convs back to back, fragment order [conv][step][wn][2][64] x 16 B
-    const float* bias;      // (6, C): c1[0], c2[0], c1[1], c2[1], c1[2], c2[2]
+    const void* w;          // 2*npairs convs back to back, fragment order [conv][step][wn][2][64] x 16 B
+    const float* bias;      // (2*npairs, C): c1, c2 of each pair in turn
     const int32_t* lengths;
     int len_scale;
-    int B, S, C, taps, wn;
-    int dil[3];
+    int B, S, C, taps, wn, npairs;
+    int dil[3];             // dilation of c1 of each pair (c2 is undilated)
     float slope, scale;
     int accumulate;
 };

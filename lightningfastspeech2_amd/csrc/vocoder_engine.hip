@@ -56,7 +56,7 @@ struct fs2_vocoder {
     VocLayer pre, post;
     std::vector<VocLayer> ups;
     std::vector<VocLayer> c1, c2;  // [(stage * n_kernels + j) * 3 + m]
-    struct FusedRb { void* w = nullptr; float* b = nullptr; };
+    struct FusedRb { void* w = nullptr; float* b = nullptr; size_t conv_bytes = 0; };
     std::vector<FusedRb> rb;       // [stage * n_kernels + j]: six convs back to back (narrow stages)
     std::vector<int> chan, upf;    // channels / cumulative upsampling after stage i (index 0 = conv_pre)
     // workspace
@@ -305,7 +305,7 @@ int fs2_voc_finalize(fs2_vocoder* v) {
     v->rb.resize((size_t)c.n_stages * c.n_kernels);
     for (int i = 0; i < c.n_stages; ++i) {
         const int C = v->chan[i + 1];
-        if (C != 32 && C != 64) continue;
+        if (C != 32 && C != 64 && C != 128) continue;
         for (int j = 0; j < c.n_kernels; ++j) {
             const std::string r = "resblocks." + std::to_string(i * c.n_kernels + j);
             std::vector<float> all, bias;
@@ -319,6 +319,7 @@ int fs2_voc_finalize(fs2_vocoder* v) {
                     bias.insert(bias.end(), b.data.begin(), b.data.end());
                 }
             fs2_vocoder::FusedRb& f = v->rb[(size_t)i * c.n_kernels + j];
+            f.conv_bytes = all.size() / 6 * v->esz;
             VCHK(upload_frags(v, all, &f.w));
             VCHK(vdev_alloc(v, (void**)&f.b, bias.size() * 4));
             VHIP(v, hipMemcpy(f.b, bias.data(), bias.size() * 4, hipMemcpyHostToDevice));
@@ -378,14 +379,38 @@ int fs2_voc_synthesize(fs2_vocoder* v, const float* mel, const int32_t* lengths,
             if (f.w) {
                 VocResblockArgs ra;
                 ra.x = u; ra.out = v->stage_out[i + 1]; ra.w = f.w; ra.bias = f.b; ra.lengths = lengths; ra.len_scale = sc;
-                ra.B = B; ra.S = S; ra.C = v->chan[i + 1]; ra.taps = c.rb_kernels[j]; ra.wn = ra.C / 32;
+                ra.B = B; ra.S = S; ra.C = v->chan[i + 1]; ra.taps = c.rb_kernels[j]; ra.wn = ra.C / 32; ra.npairs = 3;
                 for (int m = 0; m < 3; ++m) ra.dil[m] = c.rb_dilations[j][m];
                 ra.slope = 0.1f; ra.scale = inv; ra.accumulate = j > 0 ? 1 : 0;
-                if (voc_resblock_mi16(ra, v->dt)) {
+                if (voc_resblock_mi16(ra, v->dt)) {  // the whole block in one launch
                     const int rr = launch_vocoder_resblock(ra, v->dt, st);
                     if (rr != FS2_OK) return vfail(v, rr, "fused resblock launch failed (C=%d k=%d)", ra.C, ra.taps);
                     continue;
                 }
+                // else pair by pair: a (c1, c2) pair on an LDS-resident tile where it fits and pays,
+                // two plain convs otherwise
+                const void* rin = u;
+                for (int m = 0; m < 3; ++m) {
+                    void* o = m == 0 ? r1 : (m == 1 ? r2 : v->stage_out[i + 1]);
+                    VocResblockArgs pa = ra;
+                    pa.npairs = 1;
+                    pa.dil[0] = c.rb_dilations[j][m];
+                    pa.x = rin;
+                    pa.out = o;
+                    pa.w = (const char*)f.w + f.conv_bytes * 2 * m;
+                    pa.bias = f.b + (size_t)2 * m * ra.C;
+                    if (m < 2) { pa.scale = 1.f; pa.accumulate = 0; }
+                    if (voc_resblock_mi16(pa, v->dt)) {
+                        const int rr = launch_vocoder_resblock(pa, v->dt, st);
+                        if (rr != FS2_OK) return vfail(v, rr, "fused conv pair launch failed (C=%d k=%d)", ra.C, ra.taps);
+                    } else {
+                        const size_t idx = ((size_t)i * c.n_kernels + j) * 3 + m;
+                        VCHK(run_conv(v, st, v->c1[idx], rin, a, nullptr, lengths, sc, B, S, 0.1f, 1.f, false));
+                        VCHK(run_conv(v, st, v->c2[idx], a, o, rin, lengths, sc, B, S, 0.1f, m < 2 ? 1.f : inv, m == 2 && j > 0));
+                    }
+                    rin = o;
+                }
+                continue;
             }
             const void* r = u;
             for (int m = 0; m < 3; ++m) {

@@ -38,8 +38,12 @@ __global__ __launch_bounds__(512) void vocoder_resblock_kernel(VocResblockArgs p
     const int wn = wave % WN, wm = wave / WN;
     const int fr = lane & 15, fg = lane >> 4;
     const int R = WM * RW, c = (p.taps - 1) / 2;
-    const int dmax = p.dil[0] > p.dil[1] ? (p.dil[0] > p.dil[2] ? p.dil[0] : p.dil[2]) : (p.dil[1] > p.dil[2] ? p.dil[1] : p.dil[2]);
-    const int H = c * (p.dil[0] + p.dil[1] + p.dil[2] + 3), G = c * dmax, V = R - 2 * H;
+    int dmax = 1, dsum = 0;
+    for (int m = 0; m < p.npairs; ++m) {
+        dmax = p.dil[m] > dmax ? p.dil[m] : dmax;
+        dsum += p.dil[m] + 1;
+    }
+    const int H = c * dsum, G = c * dmax, GY = c, V = R - 2 * H;  // X guard: widest dilated conv; Y guard: c2 (dil 1)
     const int tiles = (p.S + V - 1) / V;
     const int ub = blockIdx.x / tiles, tm = blockIdx.x % tiles;
     const int len = p.lengths ? p.lengths[ub] * p.len_scale : p.S;
@@ -50,8 +54,8 @@ __global__ __launch_bounds__(512) void vocoder_resblock_kernel(VocResblockArgs p
     const int rowb = p.C * (int)sizeof(T), ns = rowb >> 4;
     const int sh = ns >= 16 ? 0 : (ns == 8 ? 1 : 2), smask = (ns >= 16 ? 16 : ns) - 1;
     const int srows = R + 2 * G;
-    unsigned char* slabX = lds;
-    unsigned char* slabY = lds + (size_t)srows * rowb;
+    unsigned char* slabX = lds;                           // slab index i <-> tile row i - G
+    unsigned char* slabY = lds + (size_t)srows * rowb;    // slab index i <-> tile row i - GY
     auto slot_off = [&](int i, int s) { return i * rowb + ((s ^ ((i >> sh) & smask)) << 4); };
 
     // ---- X <- lrelu(x) for every slab row (guards included), zeros outside the utterance; Y guards <- 0
@@ -80,18 +84,18 @@ __global__ __launch_bounds__(512) void vocoder_resblock_kernel(VocResblockArgs p
                 *(uint4*)(slabX + dst[u]) = Vec16<T>::pack(f[u]);
             }
         }
-        const int gp = 2 * G * ns;
+        const int gp = 2 * GY * ns;
         for (int q = tid; q < gp; q += 512) {
             int i = q / ns;
             const int s = q - i * ns;
-            if (i >= G) i += R;
+            if (i >= GY) i += R;
             *(uint4*)(slabY + slot_off(i, s)) = make_uint4(0u, 0u, 0u, 0u);
         }
     }
 
     // ---- weight stream over all six convs: [conv][step][wave column][fragment][lane] x 16 B ----
     const int nkc = p.C / KE, nsteps = p.taps * nkc, nsteps4 = (nsteps + 3) & ~3;
-    const int total = 6 * nsteps4;
+    const int nconv = 2 * p.npairs, total = nconv * nsteps4;
     const uint4* __restrict__ wbase = (const uint4*)p.w + (size_t)wn * 128 + lane;
     const size_t wstep = (size_t)WN * 128;
     auto loadB = [&](uint4 (&b)[2], int g) {
@@ -111,11 +115,11 @@ __global__ __launch_bounds__(512) void vocoder_resblock_kernel(VocResblockArgs p
     __syncthreads();
 
 #pragma unroll 1
-    for (int j = 0; j < 6; ++j) {
+    for (int j = 0; j < nconv; ++j) {
         const int second = j & 1;
         const int dil = second ? 1 : p.dil[j >> 1];
         const unsigned char* src = second ? slabY : slabX;
-        const int ibase = G - c * dil + wrow0 + fr;  // slab index of this lane's fragment-0 row at tap 0
+        const int ibase = (second ? GY : G) - c * dil + wrow0 + fr;  // slab index of this lane's fragment-0 row at tap 0
 
         f32x4_t acc[2][MI16];
 #pragma unroll
@@ -154,10 +158,10 @@ __global__ __launch_bounds__(512) void vocoder_resblock_kernel(VocResblockArgs p
             const float4 b0 = *(const float4*)bp, b1 = *(const float4*)(bp + 4);
             bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
         }
-        const bool last = j == 5;
+        const bool last = j == nconv - 1;
 #pragma unroll
         for (int m = 0; m < MI16; ++m) {
-            const int row = wrow0 + m * 16 + fr, t = tbase + row, i = G + row;
+            const int row = wrow0 + m * 16 + fr, t = tbase + row, i = G + row, iy = GY + row;
             const bool inside = t >= 0 && t < len;
             float v[8];
 #pragma unroll
@@ -171,10 +175,11 @@ __global__ __launch_bounds__(512) void vocoder_resblock_kernel(VocResblockArgs p
             }
             if (!last) {
                 unsigned char* dstb = second ? slabX : slabY;
+                const int id = second ? i : iy;
 #pragma unroll
                 for (int r = 0; r < 8; ++r) v[r] = inside ? rb_lrelu(v[r], p.slope) : 0.f;
 #pragma unroll
-                for (int q = 0; q < SPL; ++q) *(uint4*)(dstb + slot_off(i, n0 / E16 + q)) = Vec16<T>::pack(v + q * E16);
+                for (int q = 0; q < SPL; ++q) *(uint4*)(dstb + slot_off(id, n0 / E16 + q)) = Vec16<T>::pack(v + q * E16);
             } else if (inside && row >= H && row < H + V) {
                 T* dst = (T*)p.out + ((size_t)ub * p.S + t) * p.C + n0;
 #pragma unroll
@@ -194,27 +199,39 @@ __global__ __launch_bounds__(512) void vocoder_resblock_kernel(VocResblockArgs p
     }
 }
 
-int g_voc_fused_resblock = 1;  // A/B knob (fs2_op_set_vocoder_fused_resblock)
+int g_voc_fused_resblock = 1;  // A/B knob (fs2_op_set_vocoder_fused_resblock): 0 off, 1 auto, 2 pairs only
 
-static size_t rb_lds_bytes(const VocResblockArgs& a, int mi16, int esz) {
+static void rb_geom(const VocResblockArgs& a, int mi16, int* R, int* H, int* G) {
     const int c = (a.taps - 1) / 2;
-    int dmax = a.dil[0];
-    for (int m = 1; m < 3; ++m) dmax = a.dil[m] > dmax ? a.dil[m] : dmax;
-    const int R = (8 / a.wn) * mi16 * 16;
-    return (size_t)2 * (R + 2 * c * dmax) * a.C * esz;
+    int dmax = 1, dsum = 0;
+    for (int m = 0; m < a.npairs; ++m) {
+        dmax = a.dil[m] > dmax ? a.dil[m] : dmax;
+        dsum += a.dil[m] + 1;
+    }
+    *R = (8 / a.wn) * mi16 * 16;
+    *H = c * dsum;
+    *G = c * dmax;
+}
+static size_t rb_lds_bytes(const VocResblockArgs& a, int mi16, int esz) {
+    int R, H, G;
+    rb_geom(a, mi16, &R, &H, &G);
+    return (size_t)((R + 2 * G) + (R + 2 * ((a.taps - 1) / 2))) * a.C * esz;
 }
 
-// tile height (x16 rows per wave) for this resblock, 0 = not covered by the fused kernel
+// tile height (x16 rows per wave) for this launch (npairs = 3: whole resblock, 1: one (c1, c2) pair),
+// 0 = not worth it / does not fit: the LDS must hold both slabs and the halo may eat at most a fifth
+// of the tile (measured: a whole 64-channel k=11 block at 77 % useful rows is slower than conv by conv)
 int voc_resblock_mi16(const VocResblockArgs& a, int dtype) {
-    if (!g_voc_fused_resblock) return 0;
+    if (!g_voc_fused_resblock || (g_voc_fused_resblock == 2 && a.npairs != 1)) return 0;
     const int esz = dtype == FS2_BF16 ? 2 : 4;
-    if (a.C != 32 && a.C != 64) return 0;
-    if (a.wn != a.C / 32 || !(a.taps & 1)) return 0;
-    const int c = (a.taps - 1) / 2, H = c * (a.dil[0] + a.dil[1] + a.dil[2] + 3);
-    static const int cand[2] = {8, 4};
-    for (int k = 0; k < 2; ++k) {
-        const int R = (8 / a.wn) * cand[k] * 16;
-        if (rb_lds_bytes(a, cand[k], esz) <= 150 * 1024 && R - 2 * H >= R / 2) return cand[k];
+    if (a.C != 32 && a.C != 64 && a.C != 128) return 0;
+    if (a.wn != a.C / 32 || !(a.taps & 1) || (a.npairs != 1 && a.npairs != 3)) return 0;
+    static const int cand[3] = {14, 8, 4};
+    for (int k = 0; k < 3; ++k) {
+        if (cand[k] == 14 && a.wn != 4) continue;  // 14 only helps the 2-row-wave layout reach 448 rows
+        int R, H, G;
+        rb_geom(a, cand[k], &R, &H, &G);
+        if (rb_lds_bytes(a, cand[k], esz) <= 150 * 1024 && (R - 2 * H) * 5 >= R * 4) return cand[k];
     }
     return 0;
 }
@@ -228,8 +245,9 @@ static int rb_launch_t(const VocResblockArgs& a, size_t smem, hipStream_t stream
             return FS2_ERR_HIP;
         attr = true;
     }
-    const int c = (a.taps - 1) / 2, H = c * (a.dil[0] + a.dil[1] + a.dil[2] + 3);
-    const int R = (8 / a.wn) * MI16 * 16, V = R - 2 * H;
+    int R, H, G;
+    rb_geom(a, MI16, &R, &H, &G);
+    const int V = R - 2 * H;
     const int tiles = (a.S + V - 1) / V;
     hipLaunchKernelGGL((vocoder_resblock_kernel<T, MI16>), dim3((unsigned)(tiles * a.B)), dim3(512), smem, stream, a);
     return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
@@ -240,7 +258,11 @@ int launch_vocoder_resblock(const VocResblockArgs& a, int dtype, hipStream_t str
     const int mi = voc_resblock_mi16(a, dtype);
     if (!mi) return FS2_ERR_SHAPE;
     const size_t smem = rb_lds_bytes(a, mi, dtype == FS2_BF16 ? 2 : 4);
-    if (dtype == FS2_BF16) return mi == 8 ? rb_launch_t<bf16, 8>(a, smem, stream) : rb_launch_t<bf16, 4>(a, smem, stream);
+    if (dtype == FS2_BF16) {
+        if (mi == 14) return rb_launch_t<bf16, 14>(a, smem, stream);
+        return mi == 8 ? rb_launch_t<bf16, 8>(a, smem, stream) : rb_launch_t<bf16, 4>(a, smem, stream);
+    }
+    if (mi == 14) return rb_launch_t<float, 14>(a, smem, stream);
     return mi == 8 ? rb_launch_t<float, 8>(a, smem, stream) : rb_launch_t<float, 4>(a, smem, stream);
 }
 

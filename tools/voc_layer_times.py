@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lightningfastspeech2_amd.hifigan import HifiGanConfig
 
 
-def labels(cfg):
+def labels(cfg, fused=True):
     ch = cfg.channels()
     out = [("conv_pre", 2.0 * 80 * ch[0] * 7, 1)]
     up = 1
@@ -17,6 +17,9 @@ def labels(cfg):
         out.append((f"ups{i} {ch[i]}->{ch[i+1]} x{u}", up * u * 2.0 * ch[i] * ch[i + 1] * (k / u), up))
         up *= u
         for rk, rd in zip(cfg.resblock_kernel_sizes, cfg.resblock_dilation_sizes):
+            if fused and ch[i + 1] <= 64:
+                out.append((f"s{i} C={ch[i+1]} k={rk} fused", up * 6 * 2.0 * ch[i + 1] ** 2 * rk, up))
+                continue
             for d in rd:
                 out.append((f"s{i} C={ch[i+1]} k={rk} d={d}", up * 2.0 * ch[i + 1] ** 2 * rk, up))
                 out.append((f"s{i} C={ch[i+1]} k={rk} d=1 +res", up * 2.0 * ch[i + 1] ** 2 * rk, up))
@@ -24,17 +27,17 @@ def labels(cfg):
     return out
 
 
-def main(db, frames):
+def main(db, frames, fused=True):
     con = sqlite3.connect(db)
-    rows = con.execute("select name, start, end from kernels where name like '%vocoder_conv%' order by start").fetchall()
-    lab = labels(HifiGanConfig())
+    rows = con.execute("select name, start, end from kernels where name like '%vocoder_%' order by start").fetchall()
+    lab = labels(HifiGanConfig(), fused)
     rows = rows[-len(lab):]
     tot = 0.0
     agg = {}
     for (name, s, e), (l, fl, up) in zip(rows, lab):
         us = (e - s) / 1e3
         tot += us
-        key = l.split(" d=")[0] if l.startswith("s") else l
+        key = l.split(" d=")[0].replace(" fused", "") if l.startswith("s") else l
         a = agg.setdefault(key, [0.0, 0.0])
         a[0] += us
         a[1] += fl * frames
@@ -44,4 +47,4 @@ def main(db, frames):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], float(sys.argv[2]))
+    main(sys.argv[1], float(sys.argv[2]), fused=(len(sys.argv) < 4 or sys.argv[3] != "unfused"))
