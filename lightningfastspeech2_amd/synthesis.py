@@ -36,9 +36,20 @@ class SpeechGenerator:
     int16-quantised generator output rescaled by 1/32767 exactly as the reference does
     (Synthesiser.__call__ then int16_samples_to_float32)."""
 
-    def __init__(self, model: FastSpeech2, vocoder: HifiGan):
-        self.model, self.synth = model, vocoder
+    def __init__(self, model: FastSpeech2, vocoder: HifiGan, g2p_model=None):
+        self.model, self.synth, self.g2p = model, vocoder, g2p_model
         self.model.eval()
+
+    def generate_from_text(self, text: str, speaker) -> np.ndarray:
+        """generator.py:96-150 for the default (no priors) d-vector model: text -> phones the model
+        knows -> batch of one -> audio.  ``speaker`` is a key of ``model.speaker2dvector`` or a
+        256-d vector (the reference draws a random speaker when none is given; here it is explicit)."""
+        from .frontend import text_to_batch
+        if self.g2p is None:
+            raise RuntimeError("no G2P model was given to SpeechGenerator")
+        dvec = self.model.speaker2dvector[speaker] if not hasattr(speaker, "__len__") or isinstance(speaker, str) else speaker
+        batch = text_to_batch(self.model.phone2id, self.g2p, text, dvec)
+        return self.generate_samples(batch)["audios"][0]
 
     def generate_samples(self, batch: Dict, return_duration: bool = False) -> Dict:
         result = self.model(batch, inference=True)                       # generator.py:158
