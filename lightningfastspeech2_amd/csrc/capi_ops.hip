@@ -56,7 +56,7 @@ int fs2_op_predictor(int32_t dtype, const void* x, const void* w, const float* b
 }
 
 int fs2_op_set_vocoder_fused_resblock(int32_t on) {
-    fs2::g_voc_fused_resblock = on ? 1 : 0;
+    fs2::g_voc_fused_resblock = on;
     return FS2_OK;
 }
 

@@ -199,7 +199,7 @@ __global__ __launch_bounds__(512) void vocoder_resblock_kernel(VocResblockArgs p
     }
 }
 
-int g_voc_fused_resblock = 1;  // A/B knob (fs2_op_set_vocoder_fused_resblock): 0 off, 1 auto, 2 pairs only
+int g_voc_fused_resblock = 1;  // A/B knob (fs2_op_set_vocoder_fused_resblock): 0 off, 1 auto, 2 pairs only, 4 = tallest tiles only
 
 static void rb_geom(const VocResblockArgs& a, int mi16, int* R, int* H, int* G) {
     const int c = (a.taps - 1) / 2;
@@ -226,6 +226,12 @@ int voc_resblock_mi16(const VocResblockArgs& a, int dtype) {
     const int esz = dtype == FS2_BF16 ? 2 : 4;
     if (a.C != 32 && a.C != 64 && a.C != 128) return 0;
     if (a.wn != a.C / 32 || !(a.taps & 1) || (a.npairs != 1 && a.npairs != 3)) return 0;
+    {   // two workgroups per CU (<= 76 KiB each) cover each other's barriers and epilogues: take the
+        // half-height tile when its halo still leaves >= 85 % useful rows
+        int R, H, G;
+        rb_geom(a, 4, &R, &H, &G);
+        if (g_voc_fused_resblock != 4 && rb_lds_bytes(a, 4, esz) <= 76 * 1024 && (R - 2 * H) * 20 >= R * 17) return 4;
+    }
     static const int cand[3] = {14, 8, 4};
     for (int k = 0; k < 3; ++k) {
         if (cand[k] == 14 && a.wn != 4) continue;  // 14 only helps the 2-row-wave layout reach 448 rows

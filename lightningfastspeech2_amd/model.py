@@ -211,8 +211,15 @@ class FastSpeech2:
         stats = checkpoint["stats"]
         phone2id = checkpoint["phone2id"]
         cfg = Fs2Config.from_hparams(hparams, stats=stats, n_phones=len(phone2id))
-        return cls(cfg, checkpoint["state_dict"], precision=precision, device=device, phone2id=phone2id,
-                   speaker2dvector=checkpoint.get("speaker2dvector"))
+        # keys of off-path modules (fastdiff_*, loss.*) are simply not asked for; a tensor of the wrong
+        # shape is an error naming it (the reference prints "Skip loading parameter" and keeps a random
+        # init, fastspeech2.py:598-617 - useless for inference, so it is not imitated)
+        model = cls(cfg, checkpoint["state_dict"], precision=precision, device=device, phone2id=phone2id,
+                    speaker2dvector=checkpoint.get("speaker2dvector"))
+        for extra in ("speaker2id", "speaker2priors", "speaker_gmms", "dvector_gmms"):  # fastspeech2.py:571-587
+            if extra in checkpoint:
+                setattr(model, extra, checkpoint[extra])
+        return model
 
     # ---- nn.Module-ish surface the callers touch (generator.py:58-62) -----------------------
     def eval(self):

@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=192)
     ap.add_argument("--no-fused-resblock", action="store_true", help="A/B: narrow-stage resblocks conv by conv")
+    ap.add_argument("--fused-mode", type=int, default=1, help="A/B: 1 auto, 2 pairs only, 4 tallest tiles only")
     ap.add_argument("--lds-limit", type=int, default=0, help="tuning: KiB cap on a conv workgroup's LDS slab (0 = heuristic)")
     a = ap.parse_args()
     cfg = HifiGanConfig()
@@ -56,7 +57,7 @@ def main():
     from lightningfastspeech2_amd import _lib
     if a.lds_limit:
         _lib.load().fs2_op_set_vocoder_lds_limit(a.lds_limit)
-    _lib.load().fs2_op_set_vocoder_fused_resblock(0 if a.no_fused_resblock else 1)
+    _lib.load().fs2_op_set_vocoder_fused_resblock(0 if a.no_fused_resblock else a.fused_mode)
     rs = np.random.RandomState(1234)
     mel = torch.from_numpy((rs.standard_normal((a.batch, a.frames, 80)) * 1.5 - 4.0).astype(np.float32)).cuda()
     for _ in range(a.warmup):

@@ -9,20 +9,41 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from lightningfastspeech2_amd.hifigan import HifiGanConfig
 
 
+def fused_mi16(C, k, dils, esz=2):
+    """Mirror of voc_resblock_mi16 (vocoder_resblock.hip): tile height or 0."""
+    if C not in (32, 64, 128):
+        return 0
+    c = (k - 1) // 2
+    H, G = c * sum(d + 1 for d in dils), c * max(dils)
+    for mi in (14, 8, 4):
+        if mi == 14 and C // 32 != 4:
+            continue
+        R = (8 // (C // 32)) * mi * 16
+        if ((R + 2 * G) + (R + 2 * c)) * C * esz <= 150 * 1024 and (R - 2 * H) * 5 >= R * 4:
+            return mi
+    return 0
+
+
 def labels(cfg, fused=True):
+    """One (label, flops per frame) per launch of a pass, in launch order (vocoder_engine.hip)."""
     ch = cfg.channels()
     out = [("conv_pre", 2.0 * 80 * ch[0] * 7, 1)]
     up = 1
     for i, (u, k) in enumerate(zip(cfg.upsample_rates, cfg.upsample_kernel_sizes)):
         out.append((f"ups{i} {ch[i]}->{ch[i+1]} x{u}", up * u * 2.0 * ch[i] * ch[i + 1] * (k / u), up))
         up *= u
+        C = ch[i + 1]
         for rk, rd in zip(cfg.resblock_kernel_sizes, cfg.resblock_dilation_sizes):
-            if fused and ch[i + 1] <= 64:
-                out.append((f"s{i} C={ch[i+1]} k={rk} fused", up * 6 * 2.0 * ch[i + 1] ** 2 * rk, up))
+            conv = up * 2.0 * C * C * rk
+            if fused and fused_mi16(C, rk, rd):
+                out.append((f"s{i} C={C} k={rk} block", 6 * conv, up))
                 continue
             for d in rd:
-                out.append((f"s{i} C={ch[i+1]} k={rk} d={d}", up * 2.0 * ch[i + 1] ** 2 * rk, up))
-                out.append((f"s{i} C={ch[i+1]} k={rk} d=1 +res", up * 2.0 * ch[i + 1] ** 2 * rk, up))
+                if fused and fused_mi16(C, rk, [d]):
+                    out.append((f"s{i} C={C} k={rk} pair d={d}", 2 * conv, up))
+                else:
+                    out.append((f"s{i} C={C} k={rk} d={d}", conv, up))
+                    out.append((f"s{i} C={C} k={rk} d=1 +res", conv, up))
     out.append(("conv_post", up * 2.0 * ch[-1] * 7, up))
     return out
 
@@ -37,7 +58,7 @@ def main(db, frames, fused=True):
     for (name, s, e), (l, fl, up) in zip(rows, lab):
         us = (e - s) / 1e3
         tot += us
-        key = l.split(" d=")[0].replace(" fused", "") if l.startswith("s") else l
+        key = l.split(" d=")[0].replace(" block", "").replace(" pair", "") if l.startswith("s") else l
         a = agg.setdefault(key, [0.0, 0.0])
         a[0] += us
         a[1] += fl * frames
