@@ -110,7 +110,7 @@ def main():
 
     from lightningfastspeech2_amd import _lib
     from lightningfastspeech2_amd.config import preset
-    from lightningfastspeech2_amd.dist import gather_mels
+    from lightningfastspeech2_amd.dist import gather_mels_async
     from lightningfastspeech2_amd.model import FastSpeech2
     from lightningfastspeech2_amd.weights import synth_inputs, synth_state_dict
 
@@ -123,18 +123,29 @@ def main():
     inp = synth_inputs(cfg, args.batch, args.phones, seed=1234 + 17 * rank)
     batch = {"phones": torch.from_numpy(inp["phones"]).to(dev), "speaker": torch.from_numpy(inp["speaker"]).to(dev)}
 
+    # N > 1: the all-gather of step i's mels rides the collective stream underneath the forward of
+    # step i+1 (at most one in flight; the last one is waited for before the closing barrier + sync)
+    pending = []
+
     def step():
         out = model(batch, inference=True)
         if world > 1:
+            if pending:
+                pending.pop().wait()
             if backend == "nccl":
-                mel_all, frames = gather_mels(out["mel"], out["tgt_mask"])
+                pending.append(gather_mels_async(out["mel"], out["tgt_mask"]))
             else:  # rehearsal path: gloo moves host tensors
-                mel_all, frames = gather_mels(out["mel"].cpu(), out["tgt_mask"].cpu())
-            return out, int(frames.numel())
-        return out, out["mel"].shape[0]
+                pending.append(gather_mels_async(out["mel"].cpu(), out["tgt_mask"].cpu()))
+        return out
+
+    def drain():
+        if pending:
+            mel_all, frames = pending.pop().wait()
+            assert mel_all.shape[0] == frames.numel()
 
     for _ in range(args.warmup):
-        out, _ = step()
+        out = step()
+    drain()
     frames_rank = int((~out["tgt_mask"]).sum())
     T = int(out["mel"].shape[1])
 
@@ -151,6 +162,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()
     sync()
     elapsed = time.perf_counter() - t0
     prof = model.engine.profile_read(kcls)

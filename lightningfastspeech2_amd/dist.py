@@ -39,35 +39,62 @@ def shard_batch(batch: Dict[str, torch.Tensor], world: int, rank: int) -> Dict[s
     return out
 
 
-def gather_mels(mel: torch.Tensor, tgt_mask: torch.Tensor, group=None):
-    """All-gather the final mels of every rank's shard.
+class MelGather:
+    """An all-gather of the final mels in flight (``gather_mels_async``); ``wait()`` -> (mel_all, frames).
+    The exchange runs on the collective library's own stream, so a caller that keeps launching the next
+    forward overlaps it with compute; nothing here blocks the host except the tiny shape exchange."""
 
-    mel (B_r, T_r, n_mels) fp32 and tgt_mask (B_r, T_r) bool (True = pad) of this rank ->
-    ``(mel_all (B, T_max, n_mels), frames (B,) int64)`` on every rank, utterances in global batch
-    order, rows beyond an utterance's frame count zeroed.
+    def __init__(self, works, all_mel, all_fr, Bs, B_max):
+        self._works, self._all_mel, self._all_fr, self._Bs, self._B_max = works, all_mel, all_fr, Bs, B_max
+
+    def wait(self):
+        for w in self._works:
+            w.wait()   # nccl: the current stream waits for the collective's stream; gloo: host wait
+        self._works = []
+        if all(b == self._B_max for b in self._Bs):
+            return self._all_mel, self._all_fr
+        dev = self._all_mel.device
+        keep = torch.cat([torch.arange(r * self._B_max, r * self._B_max + b, device=dev) for r, b in enumerate(self._Bs)])
+        return self._all_mel[keep], self._all_fr[keep]
+
+
+def gather_mels_async(mel: torch.Tensor, tgt_mask: torch.Tensor, group=None) -> MelGather:
+    """Start the all-gather of every rank's final mels.
+
+    mel (B_r, T_r, n_mels) fp32 and tgt_mask (B_r, T_r) bool (True = pad) of this rank; the result of
+    ``wait()`` is ``(mel_all (B, T_max, n_mels), frames (B,) int64)`` on every rank, utterances in global
+    batch order, rows beyond an utterance's frame count zeroed.  Two steps: the per-rank (B_r, T_r)
+    pairs (16 bytes, read back on the host to size the buffers), then the padded mels and the frame
+    counts as asynchronous collectives.
     """
     world = dist.get_world_size(group)
     dev = mel.device
     B_r, T_r, n_mels = mel.shape
     meta = torch.tensor([B_r, T_r], dtype=torch.int64, device=dev)
-    metas = [torch.empty_like(meta) for _ in range(world)]
-    dist.all_gather(metas, meta, group=group)
-    Bs = [int(m[0]) for m in metas]
-    T_max = max(int(m[1]) for m in metas)
-    B_max = max(Bs)
+    metas = torch.empty(world * 2, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(metas, meta, group=group)
+    metas = metas.cpu().view(world, 2)
+    Bs = [int(b) for b in metas[:, 0]]
+    T_max, B_max = int(metas[:, 1].max()), max(Bs)
     frames_r = (~tgt_mask).sum(dim=1).to(torch.int64)
-    buf = torch.zeros(B_max, T_max, n_mels, dtype=mel.dtype, device=dev)
-    buf[:B_r, :T_r] = mel * (~tgt_mask).unsqueeze(-1)
-    fr = torch.zeros(B_max, dtype=torch.int64, device=dev)
-    fr[:B_r] = frames_r
+    if B_r == B_max and T_r == T_max:
+        buf = mel * (~tgt_mask).unsqueeze(-1)
+        fr = frames_r
+    else:
+        buf = torch.zeros(B_max, T_max, n_mels, dtype=mel.dtype, device=dev)
+        buf[:B_r, :T_r] = mel * (~tgt_mask).unsqueeze(-1)
+        fr = torch.zeros(B_max, dtype=torch.int64, device=dev)
+        fr[:B_r] = frames_r
     all_mel = torch.empty(world * B_max, T_max, n_mels, dtype=mel.dtype, device=dev)
     all_fr = torch.empty(world * B_max, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(all_mel, buf, group=group)
-    dist.all_gather_into_tensor(all_fr, fr, group=group)
-    if all(b == B_max for b in Bs):
-        return all_mel, all_fr
-    keep = torch.cat([torch.arange(r * B_max, r * B_max + b, device=dev) for r, b in enumerate(Bs)])
-    return all_mel[keep], all_fr[keep]
+    works = [dist.all_gather_into_tensor(all_mel, buf, group=group, async_op=True),
+             dist.all_gather_into_tensor(all_fr, fr, group=group, async_op=True)]
+    return MelGather(works, all_mel, all_fr, Bs, B_max)
+
+
+def gather_mels(mel: torch.Tensor, tgt_mask: torch.Tensor, group=None):
+    """Blocking form of :func:`gather_mels_async`."""
+    return gather_mels_async(mel, tgt_mask, group=group).wait()
 
 
 def forward_sharded(forward_fn: Callable[[Dict[str, torch.Tensor]], Dict[str, torch.Tensor]],
