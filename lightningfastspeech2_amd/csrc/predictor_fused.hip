@@ -4,7 +4,7 @@
 //
 // Why a dedicated kernel: as five conv+LN launches every layer is one tile per CU with an exposed
 // load -> 12 K-steps -> store chain (25-27 us each, ~30 % of the MFMA rate) and a 50 MB HBM round
-// trip of activations nobody needs.  Here a workgroup keeps a (32*MI + 2)-row x 256-channel slab of
+// trip of activations nobody needs.  Here a workgroup keeps a (16*MI16 + 2)-row x 256-channel slab of
 // ONE utterance in LDS for the whole predictor:
 //   * the slab is filled once by buffer-load-to-LDS DMA (rows outside the utterance read zeros =
 //     the conv's "same" padding);
@@ -14,7 +14,7 @@
 //   * the conv+ReLU+LN epilogue writes the next layer's input back into the slab in place (rows
 //     outside [0, S) as zeros); only the last layer's scalar head leaves the chip.
 // Each layer makes one more row at both slab edges stale (its neighbour was not recomputed), so a
-// tile of R = 32*MI rows yields R - 2(n-1) finished rows; tiles overlap by that halo.
+// tile of R = 16*MI16 rows yields R - 2(n-1) finished rows; tiles overlap by that halo.
 #include "fs2_common.h"
 #include "fs2_kernels.h"
 
@@ -45,10 +45,10 @@ __global__ void pack_predictor_weights_kernel(const bf16* __restrict__ W, uint4*
 // per k-step) and ride a 4-deep register ring: L2 latency under 256 CUs pulling the same lines is
 // ~2k cycles, a k-step is 450-900.  The activation fragments come from the LDS slab in two halves
 // of R/32 so that they never hold more than 28 VGPRs.
-template <int MI>
-__global__ __launch_bounds__(512) void predictor_fused_kernel(PredictorArgs p) {
+template <int MI16, int MINW>
+__global__ __launch_bounds__(512, MINW) void predictor_fused_kernel(PredictorArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins exist in the device pass only
-    constexpr int R = MI * 32, HF = MI;  // HF = row fragments per half
+    constexpr int R = MI16 * 16, HFA = (MI16 + 1) / 2;  // row fragments: first half HFA, second MI16 - HFA
     __shared__ __attribute__((aligned(16))) unsigned char slab[(R + 2) * PF_ROWB];  // slab index i <-> t = t0 - 1 + i
     __shared__ float red[2][8 * R];
 
@@ -96,11 +96,11 @@ __global__ __launch_bounds__(512) void predictor_fused_kernel(PredictorArgs p) {
 
     const int n0 = wv * 32 + fg * 8;  // this lane's 8 consecutive output channels
     for (int l = 0; l < nl; ++l) {
-        f32x4_t acc[2][2 * HF];
+        f32x4_t acc[2][MI16];
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int b = 0; b < 2 * HF; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            for (int b = 0; b < MI16; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         // tile row r at tap tp lives at slab index r + tp; its 16-byte slot (kb*4 + fg) is stored at
         // slot ^ (index & 15).  Taps: a rolled loop (short live ranges); the 8 k-blocks of a tap are
         // unrolled so that the ring index is static.
@@ -114,14 +114,17 @@ __global__ __launch_bounds__(512) void predictor_fused_kernel(PredictorArgs p) {
                 loadB(bw[(kb + 3) & 3], (l * PF_TAPS + tp) * PF_KB + kb + 3);
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
-                    uint4 fx[HF];
+                    constexpr int HFB = MI16 - HFA;
+                    const int m0 = hf * HFA, cnt = hf ? HFB : HFA;
+                    uint4 fx[HFA];
 #pragma unroll
-                    for (int mi = 0; mi < HF; ++mi)
-                        fx[mi] = *(const uint4*)(arow_p + (hf * HF + mi) * 16 * PF_ROWB + (acx ^ (kb << 6)));
+                    for (int mi = 0; mi < HFA; ++mi)
+                        if (mi < cnt) fx[mi] = *(const uint4*)(arow_p + (m0 + mi) * 16 * PF_ROWB + (acx ^ (kb << 6)));
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                        for (int mi = 0; mi < HF; ++mi) Mma16<bf16>::step(bw[kb & 3][ni], fx[mi], acc[ni][hf * HF + mi]);
+                        for (int mi = 0; mi < HFA; ++mi)
+                            if (mi < cnt) Mma16<bf16>::step(bw[kb & 3][ni], fx[mi], acc[ni][m0 + mi]);
                 }
             }
         }
@@ -132,15 +135,15 @@ __global__ __launch_bounds__(512) void predictor_fused_kernel(PredictorArgs p) {
             const float4 b0 = *(const float4*)bias, b1 = *(const float4*)(bias + 4);
             const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-            for (int m = 0; m < 2 * HF; ++m)
+            for (int m = 0; m < MI16; ++m)
 #pragma unroll
                 for (int r = 0; r < 8; ++r) acc[r >> 2][m][r & 3] = fmaxf(acc[r >> 2][m][r & 3] + bb[r], 0.f);
         }
         // ---- LayerNorm statistics, two-pass: lane partial -> lane groups -> the 8 column waves via LDS
         const float invn = 1.0f / (float)PF_H;
-        float mean[2 * HF], rstd[2 * HF];
+        float mean[MI16], rstd[MI16];
 #pragma unroll
-        for (int m = 0; m < 2 * HF; ++m) {
+        for (int m = 0; m < MI16; ++m) {
             float sm = ((acc[0][m][0] + acc[0][m][1]) + (acc[0][m][2] + acc[0][m][3])) +
                        ((acc[1][m][0] + acc[1][m][1]) + (acc[1][m][2] + acc[1][m][3]));
             sm += __shfl_xor(sm, 16, 64);
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(512) void predictor_fused_kernel(PredictorArgs p) {
         }
         __syncthreads();  // also: every wave is past its K loop -> the slab may be rewritten below
 #pragma unroll
-        for (int m = 0; m < 2 * HF; ++m) {
+        for (int m = 0; m < MI16; ++m) {
             const int row = m * 16 + fr;
             float t8 = 0.f;
 #pragma unroll
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(512) void predictor_fused_kernel(PredictorArgs p) {
         }
         __syncthreads();
 #pragma unroll
-        for (int m = 0; m < 2 * HF; ++m) {
+        for (int m = 0; m < MI16; ++m) {
             const int row = m * 16 + fr;
             float t8 = 0.f;
 #pragma unroll
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(512) void predictor_fused_kernel(PredictorArgs p) {
         if (!last) {
             // next layer's input, in place; rows outside the utterance stay the conv's zero padding
 #pragma unroll
-            for (int m = 0; m < 2 * HF; ++m) {
+            for (int m = 0; m < MI16; ++m) {
                 const int row = m * 16 + fr, t = t0 + row, i = row + 1;
                 float y[8];
 #pragma unroll
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(512) void predictor_fused_kernel(PredictorArgs p) {
         }
         // ---- Linear(256, 1) head + mask (model.py:519-522) ----
 #pragma unroll
-        for (int m = 0; m < 2 * HF; ++m) {
+        for (int m = 0; m < MI16; ++m) {
             float d = 0.f;
 #pragma unroll
             for (int r = 0; r < 8; ++r) d += ((acc[r >> 2][m][r & 3] - mean[m]) * rstd[m] * gg[r] + ee[r]) * hw[r];
@@ -232,6 +235,8 @@ __global__ __launch_bounds__(512) void predictor_fused_kernel(PredictorArgs p) {
 #endif
 }
 
+int g_predictor_variant = 0;  // 0 auto, 2 = 224-row tiles, 3 = 96-row tiles
+
 bool predictor_fused_supported(int dtype, int H, int taps, int nlayers, int S) {
     return dtype == FS2_BF16 && H == PF_H && taps == PF_TAPS && nlayers >= 1 && nlayers <= 16 && S >= 1 &&
            (size_t)S * PF_ROWB < 0xFFFFF000ull;
@@ -253,11 +258,14 @@ int launch_predictor_fused(const PredictorArgs& a, hipStream_t stream) {
     // duration predictor at phone level) take 96-row tiles so that more CUs get one
     const int halo2 = 2 * (a.nlayers - 1);
     auto tiles = [&](int R) { return (long)a.B * ((a.S + (R - halo2) - 1) / (R - halo2)); };
-    if (96 - halo2 >= 32 && tiles(224) < 200 && tiles(96) > tiles(224)) {
-        hipLaunchKernelGGL((predictor_fused_kernel<3>), dim3((unsigned)tiles(96)), dim3(512), 0, stream, a);
-    } else {
-        if (224 - halo2 < 32) return FS2_ERR_SHAPE;
-        hipLaunchKernelGGL((predictor_fused_kernel<7>), dim3((unsigned)tiles(224)), dim3(512), 0, stream, a);
+    const int variant = g_predictor_variant;
+    if (96 - halo2 < 32) return FS2_ERR_SHAPE;
+    // (112-row tiles under a 128-VGPR cap, i.e. two workgroups per CU, were measured: 213 us vs 145 us
+    // for the 5-layer predictor - the epilogue spills and the LDS reads per MFMA double)
+    if (variant == 2 || (variant == 0 && tiles(224) >= 200) || (variant == 0 && tiles(96) <= tiles(224))) {
+        hipLaunchKernelGGL((predictor_fused_kernel<14, 2>), dim3((unsigned)tiles(224)), dim3(512), 0, stream, a);
+    } else {  // short sequences (the duration predictor at phone level): more, smaller tiles
+        hipLaunchKernelGGL((predictor_fused_kernel<6, 2>), dim3((unsigned)tiles(96)), dim3(512), 0, stream, a);
     }
     return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
 }
