@@ -30,9 +30,11 @@ struct GemmArgs {
     const uint8_t* mask = nullptr;  // (M) 1 = pad
     float* pred = nullptr;          // (M)
     void* ln_tmp = nullptr;         // (M, ldc) scratch for the unfused fallback
+    int xcd_remap = 0;              // set by the launcher
 };
 int launch_gemm(const GemmArgs& a, int in_dtype, int out_dtype, hipStream_t stream);
-extern int g_gemm_variant;  // test/bench knob: 0 auto, 1 force the 128x128 kernel, 2 force the DMA kernel
+extern int g_gemm_variant;
+extern int g_slab_xcd_remap;  // 1 = XCD-contiguous tile order in the slab kernel (A/B knob)  // test/bench knob: 0 auto, 1 force the 128x128 kernel, 2 force the DMA kernel
 
 struct AttnArgs {
     const void* qkv;        // (B*S, 3H): [q | k | v] columns, head h at h*d

@@ -375,6 +375,13 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
     const int tiles_n = (p.N + S_BN - 1) / S_BN;
     const int tiles_m = (S + BMs - 1) / BMs;
     int bid = blockIdx.x;
+    if (p.xcd_remap) {
+        // Workgroup i is dispatched to XCD i % 8.  Hand every XCD a CONTIGUOUS range of tiles, so that
+        // the column tiles of one row tile (which read the same activation slab) run on the same XCD at
+        // the same time and share it in that XCD's L2 instead of fetching it once per XCD.
+        const int nt = gridDim.x, per = nt >> 3, rem = nt & 7, xcd = bid & 7;
+        bid = xcd * per + (xcd < rem ? xcd : rem) + (bid >> 3);
+    }
     const int bn = bid % tiles_n; bid /= tiles_n;
     const int tm = bid % tiles_m, ub = bid / tiles_m;
     if (ub >= nutt) return;
@@ -728,6 +735,7 @@ template <typename T, typename OutT, int MI, bool LN>
 static int launch_slab_t(const GemmArgs& a0, hipStream_t stream) {
     GemmArgs a = a0;
     if (a.taps == 1) a.S = a.M;  // plain GEMM: one "utterance" of M rows
+    a.xcd_remap = g_slab_xcd_remap;
     const int BMs = SlabCfg<MI>::BM;
     const int tiles = (a.M / a.S) * ((a.S + BMs - 1) / BMs) * ((a.N + S_BN - 1) / S_BN);
     hipLaunchKernelGGL((gemm_conv_slab_kernel<T, OutT, MI, LN>), dim3(tiles), dim3(512), 0, stream, a);
@@ -766,6 +774,7 @@ static int launch_t(const GemmArgs& a, hipStream_t stream) {
 }
 
 int g_gemm_variant = 0;
+int g_slab_xcd_remap = 1;
 
 static int launch_gemm_plain(const GemmArgs& a, int in_dtype, int out_dtype, hipStream_t stream, bool* fused);
 
