@@ -214,10 +214,12 @@ int g_voc_lds_limit = 0;  // KiB; 0 = heuristic (tuning knob, fs2_op_set_vocoder
 static int voc_pick_mi16(const VocConvArgs& a, int esz, size_t* smem) {
     static const int cand[4] = {14, 8, 4, 2};
     const int WM = 8 / a.wn;
-    // One maximal slab per CU leaves a workgroup alone with its fill -> multiply -> store chain;
-    // slabs of at most 76 KiB put two workgroups on a CU that cover each other (measured on the V1
-    // generator, 32 x 1536 frames: 62.6 ms at 150 KiB, 46.8 at 76, 47.7 at 52, 51.2 at 36).
-    const size_t limit = (size_t)(g_voc_lds_limit > 0 ? g_voc_lds_limit : 76) * 1024;
+    // One maximal slab per CU leaves a workgroup alone with its fill -> multiply -> store chain; a cap
+    // makes room for a second workgroup that covers it.  Measured on the V1 generator (32 x 1536
+    // frames, every conv through this kernel): 62.6 ms per pass at 150 KiB, 46.8 at 76, 47.7 at 52, 51.2
+    // at 36; with the narrow stages on the resident-resblock kernel: 42.1 / 39.0 / 39.8 / 40.6 ms at
+    // 150 / 110 / 76 / 52 (110 = 128-row tiles at 256 channels, 256-row tiles x 2 workgroups at 128).
+    const size_t limit = (size_t)(g_voc_lds_limit > 0 ? g_voc_lds_limit : 110) * 1024;
     for (int c = 0; c < 4; ++c) {
         const size_t b = (size_t)(WM * cand[c] * 16 + (a.taps - 1) * a.dil) * a.cin_pad * esz;
         if (b <= limit || (c == 3 && b <= 150 * 1024)) {
