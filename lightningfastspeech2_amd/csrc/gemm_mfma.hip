@@ -693,22 +693,26 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
     OutT* __restrict__ C = (OutT*)p.C + (size_t)ub * S * p.ldc;
     // lane (fr, fg) holds, for output row t, the 8 consecutive channels n .. n+7 of each fragment
     // pair (2j, 2j+1): one 16-byte (bf16) / two 16-byte (fp32) stores, 64 contiguous bytes per row
-    // across the four lane groups
+    // across the four lane groups; the two halves (j = 0, 1) of a row's 128-byte line go out back to back
+    float bv[2][8];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int n = n0 + wn * 64 + j * 32 + fg * 8;
-        if (n >= p.N) continue;
-        float bv[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) bv[r] = (p.bias && n + r < p.N) ? p.bias[n + r] : 0.f;
+        for (int r = 0; r < 8; ++r) bv[j][r] = (p.bias && n + r < p.N) ? p.bias[n + r] : 0.f;
+    }
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const int t = t0 + wm * (MI * 16) + mi * 16 + fr;
-            if (t >= S) continue;
+    for (int mi = 0; mi < MI; ++mi) {
+        const int t = t0 + wm * (MI * 16) + mi * 16 + fr;
+        if (t >= S) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + fg * 8;
+            if (n >= p.N) continue;
             float v[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                v[r] = acc[2 * j + (r >> 2)][mi][r & 3] + bv[r];
+                v[r] = acc[2 * j + (r >> 2)][mi][r & 3] + bv[j][r];
                 if (p.relu) v[r] = fmaxf(v[r], 0.f);
             }
             OutT* dst = C + (size_t)t * p.ldc + n;

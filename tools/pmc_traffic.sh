@@ -1,0 +1,23 @@
+#!/bin/bash
+# tools/pmc_traffic.sh : HBM-side traffic of the decoder conv1 launch (bench.py's roofline.traffic).
+# Two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over tools/bench_ops.py gemm --only "dec conv1";
+# FETCH_SIZE is doubled (gfx950 counts 128-byte requests at 64 B, MI355X_MICROARCH.md HBM note); both are KiB.
+# Writes gpurun_out/pmc_traffic.json (copy to profiles/r01_pmc_traffic.json).
+R=${GRAFT_REPO_ROOT:-$PWD}; OUT=$R/gpurun_out/pmc_t; mkdir -p $R/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf $OUT; timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT -o pmc -- python $R/tools/bench_ops.py gemm --variant 0 --only "dec conv1" --reps 3 > /dev/null 2>&1
+  python3 - "$c" "$OUT/pmc_counter_collection.csv" <<'PY' > $R/gpurun_out/pmc_$c.txt
+import csv, sys
+v=[float(r["Counter_Value"]) for r in csv.DictReader(open(sys.argv[2])) if "gemm_conv_slab_kernel" in r["Kernel_Name"] and r["Counter_Name"]==sys.argv[1]]
+print(sum(v[-3:])/3 if len(v)>=3 else v[-1])
+PY
+done
+python3 - <<PY
+import json
+f=float(open("$R/gpurun_out/pmc_FETCH_SIZE.txt").read()); w=float(open("$R/gpurun_out/pmc_WRITE_SIZE.txt").read())
+d={"kernel":"gemm_conv_slab_kernel<bf16,bf16,8,false> decoder conv1 (M=49152,N=1024,K=2304)","FETCH_SIZE_KiB_per_launch":f,"WRITE_SIZE_KiB_per_launch":w,
+   "fetch_bytes_corrected_x2":f*1024*2,"write_bytes":w*1024,"conv_gemm_hbm_bytes_per_launch":f*1024*2+w*1024,"algorithmic_bytes_per_launch":130547712,
+   "note":"tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over tools/bench_ops.py gemm --only 'dec conv1' (mean of the 3 timed launches); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests at 64 B); L2<->fabric traffic, Infinity-Cache hits included"}
+json.dump(d,open("$R/gpurun_out/pmc_traffic.json","w"),indent=1); print(d)
+PY
