@@ -346,26 +346,52 @@ int launch_durations(const DurationArgs& a, hipStream_t stream) {
 //   y[b,t,:] = x[b,p,:] with cum[p-1] <= t < cum[p]  for t < total_b, else 0;
 //   tgt_mask[b,t] = t >= total_b  (the UNtruncated total: a clipped utterance has no pad).
 // =============================================================================================
+// One wave per RG_ROWS consecutive frames of one utterance.  The search "which phone owns frame t" is
+// not a per-row chain of dependent loads: the wave keeps the utterance's prefix sums in registers (one
+// coalesced load, RG_MAXC per lane) and the owner of t is the NUMBER of prefix sums <= t, a ballot +
+// popcount per register - exact integer arithmetic, same result as the upper_bound it replaces.
+constexpr int RG_ROWS = 16, RG_MAXC = 16;  // up to 64 * 16 = 1024 phones per utterance on the fast path
 template <typename T>
 __global__ __launch_bounds__(256) void regulate_kernel(RegulateArgs p) {
     const int lane = threadIdx.x & 63;
-    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
-    if (t >= p.T) return;
+    const int tb = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RG_ROWS, b = blockIdx.y;
+    if (tb >= p.T) return;
     const int total = p.totals[b];
     const int32_t* cum = p.cum + (size_t)b * p.L;
-    if (lane == 0) p.tgt_mask[(size_t)b * p.T + t] = t >= total;
-    uint4* dst = (uint4*)((T*)p.y + ((size_t)b * p.T + t) * p.H);
     const int nvec = p.H * (int)sizeof(T) / 16;
-    if (t < total) {
-        int lo = 0, hi = p.L;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (cum[mid] > t) hi = mid; else lo = mid + 1;
+    const bool fast = p.L <= 64 * RG_MAXC;
+    int32_t cl[RG_MAXC];
+    if (fast) {
+#pragma unroll
+        for (int k = 0; k < RG_MAXC; ++k) {
+            const int i = lane + 64 * k;
+            cl[k] = i < p.L ? cum[i] : 0x7fffffff;
         }
-        const uint4* src = (const uint4*)((const T*)p.x + ((size_t)b * p.L + lo) * p.H);
-        for (int i = lane; i < nvec; i += 64) dst[i] = src[i];
-    } else {
-        for (int i = lane; i < nvec; i += 64) dst[i] = make_uint4(0, 0, 0, 0);
+    }
+    const int nc = (p.L + 63) / 64;
+    for (int r = 0; r < RG_ROWS; ++r) {
+        const int t = tb + r;
+        if (t >= p.T) break;
+        if (lane == 0) p.tgt_mask[(size_t)b * p.T + t] = t >= total;
+        uint4* dst = (uint4*)((T*)p.y + ((size_t)b * p.T + t) * p.H);
+        if (t < total) {
+            int lo = 0;
+            if (fast) {
+#pragma unroll
+                for (int k = 0; k < RG_MAXC; ++k)
+                    if (k < nc) lo += __popcll(__ballot(cl[k] <= t));
+            } else {
+                int hi = p.L;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (cum[mid] > t) hi = mid; else lo = mid + 1;
+                }
+            }
+            const uint4* src = (const uint4*)((const T*)p.x + ((size_t)b * p.L + lo) * p.H);
+            for (int i = lane; i < nvec; i += 64) dst[i] = src[i];
+        } else {
+            for (int i = lane; i < nvec; i += 64) dst[i] = make_uint4(0, 0, 0, 0);
+        }
     }
 }
 
@@ -373,7 +399,7 @@ int launch_regulate(const RegulateArgs& a, int dtype, hipStream_t stream) {
     if (a.B <= 0 || a.T <= 0) return FS2_OK;
     const int esz = dtype == FS2_BF16 ? 2 : 4;
     if ((a.H * esz) % 16) return FS2_ERR_SHAPE;
-    const dim3 grid((a.T + 3) / 4, a.B), block(256);
+    const dim3 grid((a.T + 4 * RG_ROWS - 1) / (4 * RG_ROWS), a.B), block(256);
     if (dtype == FS2_BF16) hipLaunchKernelGGL(regulate_kernel<bf16>, grid, block, 0, stream, a);
     else hipLaunchKernelGGL(regulate_kernel<float>, grid, block, 0, stream, a);
     return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
@@ -385,58 +411,85 @@ int launch_regulate(const RegulateArgs& a, int dtype, hipStream_t stream) {
 // y = x + Emb[idx]; optionally the decoder-side  y = (y + pe[t]) + spk[b]  (fastspeech2.py:705-718)
 // fused behind it.  The compare is fp32 mul-then-add (no FMA) like the reference's tensor ops.
 // =============================================================================================
+// One wave per BE_ROWS consecutive rows.  bucketize = lower_bound over the sorted bin edges = the NUMBER
+// of edges < v: the wave holds the edges in registers (BE_MAXB per lane, loaded once) and counts with
+// a ballot + popcount per register instead of walking a chain of dependent loads per row.
+constexpr int BE_ROWS = 8, BE_MAXB = 8;  // up to 512 edges on the fast path
 template <typename T>
 __global__ __launch_bounds__(256) void bucket_embed_kernel(BucketArgs p) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= p.B * p.T) return;
-    const int b = row / p.T, t = row % p.T;
-    const float* e = nullptr;
-    if (p.pred) {
-        const float src = p.bucket_src ? p.bucket_src[row] : p.pred[p.pred_per_utt ? b : row];
-        const float v = __fadd_rn(__fmul_rn(src, p.std), p.mean);
-        int lo = 0, hi = p.nbins - 1;  // lower_bound over nbins-1 boundaries
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (p.bins[mid] < v) lo = mid + 1; else hi = mid;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * BE_ROWS;
+    const int M = p.B * p.T;
+    if (row0 >= M) return;
+    const int nedge = p.nbins - 1;
+    const bool fast = nedge <= 64 * BE_MAXB;
+    float bl[BE_MAXB];
+    if (p.pred && fast) {
+#pragma unroll
+        for (int k = 0; k < BE_MAXB; ++k) {
+            const int i = lane + 64 * k;
+            bl[k] = i < nedge ? p.bins[i] : INFINITY;  // +inf < v is false for every v: never counted
         }
-        if (p.forced_idx) {
-            lo = p.forced_idx[row];
-            lo = lo < 0 ? 0 : (lo >= p.nbins ? p.nbins - 1 : lo);
-        }
-        if (lane == 0 && p.idx_out) p.idx_out[row] = lo;
-        e = p.emb + (size_t)lo * p.H;
     }
-    const T* x = (const T*)p.x + (size_t)row * p.H;
-    T* y = (T*)p.y + (size_t)row * p.H;
-    const float* pe = p.pe ? p.pe + (size_t)t * p.H : nullptr;
-    const float* sp = p.spk ? p.spk + (size_t)b * p.H : nullptr;
-    for (int c = lane * 4; c < p.H; c += 256) {
-        float v[4], a[4];
-        load4<T>(x + c, v);
-        if (e) {
-            load4<float>(e + c, a);
+    const int nb = (nedge + 63) / 64;
+    for (int r = 0; r < BE_ROWS; ++r) {
+        const int row = row0 + r;
+        if (row >= M) break;
+        const int b = row / p.T, t = row % p.T;
+        const float* e = nullptr;
+        if (p.pred) {
+            const float src = p.bucket_src ? p.bucket_src[row] : p.pred[p.pred_per_utt ? b : row];
+            const float v = __fadd_rn(__fmul_rn(src, p.std), p.mean);
+            int lo = 0;
+            if (fast) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = __fadd_rn(v[i], a[i]);
+                for (int k = 0; k < BE_MAXB; ++k)
+                    if (k < nb) lo += __popcll(__ballot(bl[k] < v));
+            } else {
+                int hi = nedge;  // lower_bound over nbins-1 boundaries
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (p.bins[mid] < v) lo = mid + 1; else hi = mid;
+                }
+            }
+            if (p.forced_idx) {
+                lo = p.forced_idx[row];
+                lo = lo < 0 ? 0 : (lo >= p.nbins ? p.nbins - 1 : lo);
+            }
+            if (lane == 0 && p.idx_out) p.idx_out[row] = lo;
+            e = p.emb + (size_t)lo * p.H;
         }
-        if (pe) {
-            load4<float>(pe + c, a);
+        const T* x = (const T*)p.x + (size_t)row * p.H;
+        T* y = (T*)p.y + (size_t)row * p.H;
+        const float* pe = p.pe ? p.pe + (size_t)t * p.H : nullptr;
+        const float* sp = p.spk ? p.spk + (size_t)b * p.H : nullptr;
+        for (int c = lane * 4; c < p.H; c += 256) {
+            float v[4], a[4];
+            load4<T>(x + c, v);
+            if (e) {
+                load4<float>(e + c, a);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = __fadd_rn(v[i], a[i]);
-        }
-        if (sp) {
-            load4<float>(sp + c, a);
+                for (int i = 0; i < 4; ++i) v[i] = __fadd_rn(v[i], a[i]);
+            }
+            if (pe) {
+                load4<float>(pe + c, a);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = __fadd_rn(v[i], a[i]);
+                for (int i = 0; i < 4; ++i) v[i] = __fadd_rn(v[i], a[i]);
+            }
+            if (sp) {
+                load4<float>(sp + c, a);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = __fadd_rn(v[i], a[i]);
+            }
+            store4<T>(y + c, v);
         }
-        store4<T>(y + c, v);
     }
 }
 
 int launch_bucket_embed(const BucketArgs& a, int dtype, hipStream_t stream) {
     if (a.B * a.T <= 0) return FS2_OK;
     if (a.H % 4) return FS2_ERR_SHAPE;
-    const dim3 grid((a.B * a.T + 3) / 4), block(256);
+    const dim3 grid((a.B * a.T + 4 * BE_ROWS - 1) / (4 * BE_ROWS)), block(256);
     if (dtype == FS2_BF16) hipLaunchKernelGGL(bucket_embed_kernel<bf16>, grid, block, 0, stream, a);
     else hipLaunchKernelGGL(bucket_embed_kernel<float>, grid, block, 0, stream, a);
     return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
