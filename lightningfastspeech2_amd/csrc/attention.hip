@@ -207,13 +207,21 @@ __global__ __launch_bounds__(NW * KS * 64, (sizeof(T) == 2 && D == 128 && KS == 
                 for (int r = 0; r < 16; ++r) sacc[kb][r] = m_init;  // accumulate (s - m) directly
             // chunk-outer / key-block-inner: consecutive MFMAs hit DIFFERENT accumulators, so the
             // accumulate latency of one chain hides under the other
+            {   // rolling prefetch: PD K fragments are in flight ahead of the MFMA that consumes them, so a
+                // wave's Q.K^T is paced by the matrix pipe, not by an LDS round trip per MFMA pair
+                constexpr int NF = NQC * NKB, PD = NF < 6 ? NF : 6;
+                uint4 kq[PD];
+                auto kaddr = [&](int i) { return sK + swz_row<KRB>((i % NKB) * 32 + li, (i / NKB) * 2 + hi); };
     #pragma unroll
-            for (int c = 0; c < NQC; ++c)
+                for (int i = 0; i < PD; ++i) kq[i] = *(const uint4*)kaddr(i);
+                __builtin_amdgcn_sched_barrier(0);  // keep the issue order: hipcc otherwise re-serialises to 2 in flight
     #pragma unroll
-                for (int kb = 0; kb < NKB; ++kb) {
-                    const uint4 kf = *(const uint4*)(sK + swz_row<KRB>(kb * 32 + li, c * 2 + hi));
-                    Mma32<T>::step(kf, qf[c], sacc[kb]);
+                for (int i = 0; i < NF; ++i) {
+                    Mma32<T>::step(kq[i % PD], qf[i / NKB], sacc[i % NKB]);
+                    if (i + PD < NF) kq[i % PD] = *(const uint4*)kaddr(i + PD);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+            }
             // ---- key-padding mask (only tiles that contain a padded key pay for it) ----
             const unsigned long long full = KVB == 64 ? ~0ull : 0xffffffffull;
             if (bits != full) {
@@ -288,16 +296,25 @@ __global__ __launch_bounds__(NW * KS * 64, (sizeof(T) == 2 && D == 128 && KS == 
                 for (int nd = 0; nd < ND; ++nd)
                     vcol[nd] = rowb + (((nd * 4 + g1 * 2 + ((i16 & 3) >> 1)) ^ vswz<KRB>(rsub)) << 4);
                 // key-chunk outer / dv-block inner: consecutive MFMAs accumulate into different oacc[nd]
+                {   // same rolling prefetch for the transposed V fragments (two 8-byte reads each)
+                    constexpr int NF = 4 * ND, PD = 4;
+                    uint4 vq[PD];
+                    auto vload = [&](int i) {
+                        const unsigned char* vb = sV + vcol[i % ND] + (i / ND) * 16 * KRB;
+                        const uint2 lo = tr_read_b64(vb);
+                        const uint2 hi2 = tr_read_b64(vb + 8 * KRB);
+                        return make_uint4(lo.x, lo.y, hi2.x, hi2.y);
+                    };
     #pragma unroll
-                for (int ch = 0; ch < 4; ++ch)
+                    for (int i = 0; i < PD; ++i) vq[i] = vload(i);
+                    __builtin_amdgcn_sched_barrier(0);
     #pragma unroll
-                    for (int nd = 0; nd < ND; ++nd) {
-                        const unsigned char* vb = sV + vcol[nd];
-                        const uint2 lo = tr_read_b64(vb + ch * 16 * KRB);
-                        const uint2 hi2 = tr_read_b64(vb + (ch * 16 + 8) * KRB);
-                        const uint4 vf = make_uint4(lo.x, lo.y, hi2.x, hi2.y);
-                        Mma32<T>::step(vf, pf[ch], oacc[nd]);
+                    for (int i = 0; i < NF; ++i) {
+                        Mma32<T>::step(vq[i % PD], pf[i / ND], oacc[i % ND]);
+                        if (i + PD < NF) vq[i % PD] = vload(i + PD);
+                        __builtin_amdgcn_sched_barrier(0);
                     }
+                }
             } else {
     #pragma unroll
                 for (int ch = 0; ch < 4; ++ch)
