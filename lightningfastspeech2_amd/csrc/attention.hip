@@ -70,6 +70,18 @@ __device__ inline uint2 tr_read_b64(const unsigned char* lds_addr) {  // lane i 
 // two partial (m, l, O) states are merged through LDS at the end.  Same DMA traffic per query, but
 // twice as many half-length wave tasks: 768 x 8-wave workgroups on 256 CUs are exactly 3 rounds,
 // where 768 x 4-wave workgroups on 512 slots left a half-empty second round.
+// Combine a value with its lane ^ 32 partner through v_permlane32_swap (a VALU op, gfx950) instead
+// of a ds_bpermute round trip through the LDS: after swapping the upper half of one copy with the
+// lower half of another, every lane holds {own, partner} in the two results.
+__device__ inline float half_max(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ inline float half_sum(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 template <typename T, int D, int NW, int KS>
 __global__ __launch_bounds__(NW * KS * 64, (sizeof(T) == 2 && D == 128 && KS == 1) ? 2 : 1) void attention_kernel(AttnArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins exist in the device pass only
@@ -239,7 +251,7 @@ __global__ __launch_bounds__(NW * KS * 64, (sizeof(T) == 2 && D == 128 && KS == 
             for (int kb = 0; kb < NKB; ++kb)
     #pragma unroll
                 for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));  // growth of the row max relative to m_eff
+            mx = half_max(mx);  // growth of the row max relative to m_eff (the other 16 keys: lane ^ 32)
             float delta = 0.f;
             if (__any(m_run == -INFINITY || mx > THR)) {  // first tile of a row, or its max grew past the threshold
                 const float m_new = fmaxf(m_run, m_eff + mx);
@@ -265,7 +277,7 @@ __global__ __launch_bounds__(NW * KS * 64, (sizeof(T) == 2 && D == 128 && KS == 
                     sacc[kb][r] = e;
                     rs += e;
                 }
-            rs += __shfl_xor(rs, 32, 64);
+            rs = half_sum(rs);
             l_run += rs;
 
             // ---- P fragments (column operand), straight from the lane's own registers ----
