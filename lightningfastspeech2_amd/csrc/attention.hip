@@ -5,16 +5,21 @@
 // still computed.
 //
 // One workgroup = NW waves = NW*32 queries of one (utterance, head); KV advances in tiles of 64
-// keys (bf16) / 32 keys (fp32).  K and V^T tiles are streamed global->LDS by DMA
-// (global_load_lds, no staging registers) into two single buffers with a 16-byte XOR swizzle applied
-// on the source address: V^T_j lands underneath Q.K^T_j and K_{j+1} underneath P.V_j.
+// keys (bf16) / 32 keys (fp32).  K and V tiles are streamed global->LDS by buffer-load DMA (no staging
+// registers; a descriptor per utterance, constant per-lane offsets, out-of-range keys read zeros)
+// into two single buffers with a 16-byte XOR swizzle applied on the source address: V_j lands
+// underneath Q.K^T_j and K_{j+1} underneath P.V_j (two barriers per tile).
 //   S^T = K Q^T  via 32x32 MFMA with K as the row operand: each lane then owns ONE query (lane&31)
-//                and 16 keys per 32-key block, so row max / row sum are in-register + one
-//                lane^32 exchange.
+//                and 16 keys per 32-key block, so row max / row sum are in-register + one lane^32
+//                exchange (v_permlane32_swap).  The running max is the accumulators' initial value:
+//                p = exp2(acc) with no per-element subtract; the rescale is deferred (threshold).
 //   O^T = V^T P^T with V^T as the row operand and the lane's own P registers as the column
 //                operand (no cross-lane movement): the MFMA's k-slot <-> key assignment is whatever
-//                the S^T register layout gives, and V^T is stored with its keys pre-permuted to
-//                match (transpose_v kernel), so each operand is one ds_read_b128.
+//                the S^T register layout gives.  bf16: V stays row-major as it sits in the packed qkv
+//                and is read with the hardware transpose read (ds_read_b64_tr_b16); fp32: a V^T scratch
+//                with its keys pre-permuted to match (transpose_v kernel), one ds_read_b128 each.
+//   K and V fragments are prefetched 6 / 4 MFMAs ahead in a pinned issue order (hipcc otherwise keeps
+//   two in flight and the wave runs at LDS latency).
 // Key padding arrives as a 64-bit valid mask per 64-key group (any mask shape, not only suffix
 // padding); fully padded tiles are skipped.
 #include "fs2_common.h"
@@ -65,11 +70,9 @@ __device__ inline uint2 tr_read_b64(const unsigned char* lds_addr) {  // lane i 
     return *(const uint2*)&v;
 }
 
-// NW = waves along the queries (32 each), KS = waves along the keys: with KS = 2 the upper half of
-// the workgroup's waves processes the second half of the KV tiles with its own LDS buffers and the
-// two partial (m, l, O) states are merged through LDS at the end.  Same DMA traffic per query, but
-// twice as many half-length wave tasks: 768 x 8-wave workgroups on 256 CUs are exactly 3 rounds,
-// where 768 x 4-wave workgroups on 512 slots left a half-empty second round.
+// NW = waves along the queries (32 each).  (A variant with a second group of waves working on the
+// other half of the KV tiles - 8-wave workgroups, one per CU - was measured 7 % slower than two
+// independent 4-wave workgroups per CU and retired.)
 // Combine a value with its lane ^ 32 partner through v_permlane32_swap (a VALU op, gfx950) instead
 // of a ds_bpermute round trip through the LDS: after swapping the upper half of one copy with the
 // lower half of another, every lane holds {own, partner} in the two results.
@@ -82,8 +85,8 @@ __device__ inline float half_sum(float x) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-template <typename T, int D, int NW, int KS>
-__global__ __launch_bounds__(NW * KS * 64, (sizeof(T) == 2 && D == 128 && KS == 1) ? 2 : 1) void attention_kernel(AttnArgs p) {
+template <typename T, int D, int NW>
+__global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128) ? 2 : 1) void attention_kernel(AttnArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins exist in the device pass only
     constexpr int KVB = sizeof(T) == 2 ? 64 : 32;      // keys per tile
     constexpr int E16 = Num<T>::kPer16B;
@@ -102,14 +105,9 @@ __global__ __launch_bounds__(NW * KS * 64, (sizeof(T) == 2 && D == 128 && KS == 
 
     __shared__ __attribute__((aligned(16))) unsigned char sKa[TILE_B];
     __shared__ __attribute__((aligned(16))) unsigned char sVa[TILE_B];
-    __shared__ __attribute__((aligned(16))) unsigned char sKb[KS == 2 ? TILE_B : 16];
-    __shared__ __attribute__((aligned(16))) unsigned char sVb[KS == 2 ? TILE_B : 16];
-    __shared__ float sml[KS == 2 ? 2 * NW * 64 : 1];
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave = wave_all % NW;   // query group (also this wave's share of its half's tile DMAs)
-    const int kh = wave_all / NW;     // which half of the KV tiles
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // query group (also this wave's share of the tile DMAs)
     const int li = lane & 31, hi = lane >> 5;
     // XCD-aware mapping: workgroup id % 8 is the XCD it lands on (observed dispatch order); all
     // query blocks of one (utterance, head) share its K/V, so keep them on one XCD's L2.
@@ -193,8 +191,7 @@ __global__ __launch_bounds__(NW * KS * 64, (sizeof(T) == 2 && D == 128 && KS == 
     float m_run = -INFINITY, l_run = 0.f;  // running max (scaled, log2 units) and denominator
 
     // This half's tile range; all halves run the same number of (two-barrier) iterations.
-    const int nhalf = (ntiles + KS - 1) / KS;
-    const int jbeg = kh * nhalf, jend = (jbeg + nhalf < ntiles) ? jbeg + nhalf : ntiles;
+    const int nhalf = ntiles, jbeg = 0, jend = ntiles;
     auto run = [&](unsigned char* sK, unsigned char* sV) {
         if (jbeg < jend && tile_bits(jbeg) != 0ull) issue_k(jbeg, sK);
         for (int it = 0; it < nhalf; ++it) {
@@ -339,32 +336,7 @@ __global__ __launch_bounds__(NW * KS * 64, (sizeof(T) == 2 && D == 128 && KS == 
             }
         }
     };
-    if (KS == 1 || kh == 0) run(sKa, sVa); else run(sKb, sVb);
-
-    if constexpr (KS == 2) {
-        // ---- merge the two KV halves: the upper half hands (m, l, O) to its partner through LDS ----
-        __syncthreads();  // every wave is done with the tile buffers
-        float* xo = (float*)(wave == 0 ? sKa : wave == 1 ? sVa : wave == 2 ? sKb : sVb);  // 16 KiB per query group
-        if (kh == 1) {
-            sml[wave * 64 + lane] = m_run;
-            sml[(NW + wave) * 64 + lane] = l_run;
-#pragma unroll
-            for (int i = 0; i < ND; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) xo[(i * 16 + r) * 64 + lane] = oacc[i][r];
-        }
-        __syncthreads();
-        if (kh == 1) return;
-        const float m1 = sml[wave * 64 + lane], l1 = sml[(NW + wave) * 64 + lane];
-        const float mm = fmaxf(m_run, m1);
-        const float mu = (mm == -INFINITY) ? 0.f : mm;
-        const float a0 = __builtin_amdgcn_exp2f(m_run - mu), a1 = __builtin_amdgcn_exp2f(m1 - mu);
-        l_run = l_run * a0 + l1 * a1;
-#pragma unroll
-        for (int i = 0; i < ND; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[i][r] = oacc[i][r] * a0 + xo[(i * 16 + r) * 64 + lane] * a1;
-    }
+    run(sKa, sVa);
 
     // ---- normalise and store: lane owns query li, dv = nd*32 + (r&3) + 8*(r>>2) + 4*hi ----
     const int qrow = q0 + wave * 32 + li;
@@ -426,25 +398,16 @@ static int launch_tv(const AttnArgs& a, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
 }
 
-int g_attn_kv_split = 0;
-
 template <typename T, int D>
 static int launch_td(const AttnArgs& a, hipStream_t stream) {
     const int BH = a.B * a.heads, BH8 = (BH + 7) / 8 * 8;
     // grid = ceil(BH/8)*8 * nq, decoded XCD-aware in the kernel.  Small sequences: 2-wave
     // workgroups so the grid still covers the 256 CUs.
     const long blocks4 = (long)((a.S + 127) / 128) * BH;
-    constexpr int KVBh = sizeof(T) == 2 ? 64 : 32;
-    if (g_attn_kv_split && sizeof(T) == 2 && D == 128 && (a.S + KVBh - 1) / KVBh >= 8) {
-        // experimental: 8-wave workgroups (4 query groups x 2 KV halves), one per CU.  Measured 7 %
-        // SLOWER than two independent 4-wave workgroups per CU (all 8 waves share every barrier, so
-        // the halves run phase-locked instead of overlapping one workgroup's softmax with the
-        // other's MFMAs); kept selectable for A/B runs.
-        hipLaunchKernelGGL((attention_kernel<T, D, 4, 2>), dim3(((a.S + 127) / 128) * BH8), dim3(512), 0, stream, a);
-    } else if (blocks4 >= 512) {
-        hipLaunchKernelGGL((attention_kernel<T, D, 4, 1>), dim3(((a.S + 127) / 128) * BH8), dim3(256), 0, stream, a);
+    if (blocks4 >= 512) {
+        hipLaunchKernelGGL((attention_kernel<T, D, 4>), dim3(((a.S + 127) / 128) * BH8), dim3(256), 0, stream, a);
     } else {
-        hipLaunchKernelGGL((attention_kernel<T, D, 2, 1>), dim3(((a.S + 63) / 64) * BH8), dim3(128), 0, stream, a);
+        hipLaunchKernelGGL((attention_kernel<T, D, 2>), dim3(((a.S + 63) / 64) * BH8), dim3(128), 0, stream, a);
     }
     return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
 }
