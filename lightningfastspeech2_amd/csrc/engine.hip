@@ -478,18 +478,6 @@ int gemm(fs2_engine* e, hipStream_t st, const ConvW& w, const void* x, void* c, 
     if (r != FS2_OK) return fail(e, r, "gemm launch failed (M=%d N=%d K=%d)", M, a.N, a.K);
     return FS2_OK;
 }
-int layernorm(fs2_engine* e, hipStream_t st, const void* x, const void* res, const float* g, const float* b, void* y,
-              int M, int H, const float* dot_w = nullptr, float dot_b = 0.f, const uint8_t* mask = nullptr,
-              float* pred = nullptr) {
-    LayerNormArgs a;
-    a.x = x; a.res = res; a.gamma = g; a.beta = b; a.y = y;
-    a.dot_w = dot_w; a.dot_b = dot_b; a.mask = mask; a.pred = pred;
-    a.M = M; a.H = H; a.eps = 1e-5f;
-    Bracket br(e, FS2_K_ROWOPS, st, 0, (double)M * H * e->esz * (res ? 3 : 2));
-    const int r = launch_layernorm(a, e->dt, st);
-    if (r != FS2_OK) return fail(e, r, "layernorm launch failed");
-    return FS2_OK;
-}
 int dwconv(fs2_engine* e, hipStream_t st, const DwW& w, const void* x, void* y, int B, int S) {
     DwConvArgs a;
     a.x = x; a.w = w.w; a.bias = w.b; a.y = y;

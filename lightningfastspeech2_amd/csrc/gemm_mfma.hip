@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmArgs p) {
 // page.  All LDS lives in ONE extern array (a second __shared__ object would make hipcc drain
 // vmcnt before every ds_read).
 // =================================================================================================
-static constexpr int G2_BM = 128, G2_BN = 256, G2_STAGES = 3;
+static constexpr int G2_BM = 128, G2_BN = 256;  // 3 LDS stages
 static constexpr int G2_XB = G2_BM * ROWB;        // 16 KiB
 static constexpr int G2_WB = G2_BN * ROWB;        // 32 KiB
 static constexpr int G2_STAGE = G2_XB + G2_WB;    // 48 KiB
@@ -356,7 +356,7 @@ template <int MI> struct SlabCfg {
     static constexpr int SI = (SLAB_GROUPS + 7) / 8;                // slab DMA instructions per wave
     static constexpr int SLAB_BYTES = SI * 8 * 1024;
 };
-static constexpr int S_BN = 256, S_WB = S_BN * ROWB;  // 32 KiB weight tile
+static constexpr int S_BN = 256;
 
 template <typename T, typename OutT, int MI, bool LN>
 __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
@@ -365,8 +365,8 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
     constexpr int BMs = Cfg::BM, SI = Cfg::SI;
     __shared__ __attribute__((aligned(16))) unsigned char slab0[Cfg::SLAB_BYTES];
     __shared__ __attribute__((aligned(16))) unsigned char slab1[Cfg::SLAB_BYTES];
-    __shared__ __attribute__((aligned(16))) unsigned char wt0[S_WB];
-    __shared__ __attribute__((aligned(16))) unsigned char wt1[S_WB];
+    __shared__ __attribute__((aligned(16))) unsigned char wt0[S_BN * ROWB];  // 32 KiB weight tile per stage
+    __shared__ __attribute__((aligned(16))) unsigned char wt1[S_BN * ROWB];
     constexpr int KE = ROWB / (int)sizeof(T);
 
     const int tid = threadIdx.x, lane = tid & 63;
