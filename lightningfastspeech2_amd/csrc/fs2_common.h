@@ -85,6 +85,21 @@ template <> struct Vec16<bf16> {
     }
 };
 
+// Sum over the four lanes {l, l^16, l^32, l^48} (the four 16-lane groups that share an MFMA column)
+// with v_permlane16_swap / v_permlane32_swap (VALU, gfx950) instead of two ds_bpermute round trips:
+// swapping the odd rows of one copy with the even rows of another leaves {own, partner} in the two
+// results.  Same association as  x += shfl_xor(x, 16); x += shfl_xor(x, 32).
+__device__ inline float group4_sum(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+#else
+    return x;
+#endif
+}
+
 __device__ inline float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

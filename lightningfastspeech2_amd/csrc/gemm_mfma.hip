@@ -594,8 +594,7 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
             float sm = 0.f;
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) sm += (acc[ni][mi][0] + acc[ni][mi][1]) + (acc[ni][mi][2] + acc[ni][mi][3]);
-            sm += __shfl_xor(sm, 16, 64);
-            sm += __shfl_xor(sm, 32, 64);
+            sm = group4_sum(sm);
             if (fg == 0) red[wn * BMs + wm * (MI * 16) + mi * 16 + fr] = sm;
         }
         __syncthreads();
@@ -617,8 +616,7 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
                     q += d * d;
                 }
             }
-            q += __shfl_xor(q, 16, 64);
-            q += __shfl_xor(q, 32, 64);
+            q = group4_sum(q);
             if (fg == 0) red[wn * BMs + wm * (MI * 16) + mi * 16 + fr] = q;
         }
         __syncthreads();
@@ -672,8 +670,7 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
                 float d = dsum[mi];
-                d += __shfl_xor(d, 16, 64);
-                d += __shfl_xor(d, 32, 64);
+                d = group4_sum(d);
                 if (fg == 0) red[wn * BMs + wm * (MI * 16) + mi * 16 + fr] = d;
             }
             __syncthreads();

@@ -146,8 +146,7 @@ __global__ __launch_bounds__(512, MINW) void predictor_fused_kernel(PredictorArg
         for (int m = 0; m < MI16; ++m) {
             float sm = ((acc[0][m][0] + acc[0][m][1]) + (acc[0][m][2] + acc[0][m][3])) +
                        ((acc[1][m][0] + acc[1][m][1]) + (acc[1][m][2] + acc[1][m][3]));
-            sm += __shfl_xor(sm, 16, 64);
-            sm += __shfl_xor(sm, 32, 64);
+            sm = group4_sum(sm);
             if (fg == 0) red[0][wv * R + m * 16 + fr] = sm;
         }
         __syncthreads();  // also: every wave is past its K loop -> the slab may be rewritten below
@@ -164,8 +163,7 @@ __global__ __launch_bounds__(512, MINW) void predictor_fused_kernel(PredictorArg
                 const float d = acc[r >> 2][m][r & 3] - mean[m];
                 q += d * d;
             }
-            q += __shfl_xor(q, 16, 64);
-            q += __shfl_xor(q, 32, 64);
+            q = group4_sum(q);
             if (fg == 0) red[1][wv * R + row] = q;
         }
         __syncthreads();
@@ -214,8 +212,7 @@ __global__ __launch_bounds__(512, MINW) void predictor_fused_kernel(PredictorArg
             float d = 0.f;
 #pragma unroll
             for (int r = 0; r < 8; ++r) d += ((acc[r >> 2][m][r & 3] - mean[m]) * rstd[m] * gg[r] + ee[r]) * hw[r];
-            d += __shfl_xor(d, 16, 64);
-            d += __shfl_xor(d, 32, 64);
+            d = group4_sum(d);
             if (fg == 0) red[0][wv * R + m * 16 + fr] = d;  // red[0] was last read two barriers ago
         }
         __syncthreads();
