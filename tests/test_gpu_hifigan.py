@@ -161,3 +161,26 @@ def test_mel_forward_into_vocoder_matches_per_utterance_reference_flow():
         assert got.dtype == np.float32 and got.shape == (n * vcfg.hop,)
         assert float(np.abs(got - want).max()) <= F32_TOL
         assert torch.equal(out["durations"][b], ref["duration_rounded"][b])
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_full_size_time_shift_equivariance(precision):
+    """Size-independent property at the benchmark's utterance length (1536 frames -> 393 216 samples, far
+    beyond what the CPU oracle runs in seconds): the generator is a stack of convolutions, so dropping the
+    first k frames of the mel shifts the waveform by k*256 samples away from the utterance edges.  Every
+    sample keeps its own arithmetic order whatever tile it falls in, hence the comparison is bit-exact;
+    a tile-seam, halo or phase-ordering error in any of the 40 launches breaks it."""
+    cfg = HifiGanConfig()
+    sd = synth_state_dict(cfg, 21)
+    g = HifiGan(cfg, sd, precision=precision)
+    rs = np.random.RandomState(4)
+    T, k, margin = (1536, 8, 32) if precision == "bf16" else (384, 5, 32)
+    mel = torch.from_numpy((rs.standard_normal((2, T, 80)) * 1.5 - 4.0).astype(np.float32))
+    full = g.synthesize(mel).cpu()
+    shifted = g.synthesize(mel[:, k:].contiguous()).cpu()
+    hop = cfg.hop
+    a = full[:, (k + margin) * hop:(T - margin) * hop]
+    b = shifted[:, margin * hop:(T - k - margin) * hop]
+    assert torch.isfinite(full).all() and float(full.abs().max()) <= 1.0
+    assert torch.equal(a, b)
+    assert not torch.equal(full[:, :margin * hop // 2], shifted[:, :margin * hop // 2])   # edges do differ
