@@ -25,7 +25,7 @@ template <typename T> struct VocT;
 template <> struct VocT<bf16> { static constexpr int KE = 32; };   // elements per 64-byte k-step
 template <> struct VocT<float> { static constexpr int KE = 16; };
 
-__device__ inline float lrelu(float v, float slope) { return v < 0.f ? v * slope : v; }
+__device__ inline float lrelu(float v, float slope) { return fmaxf(v, v * slope); }  // 0 < slope <= 1
 
 }  // namespace
 

@@ -23,7 +23,8 @@ namespace {
 template <typename T> struct RbT;
 template <> struct RbT<bf16> { static constexpr int KE = 32; };
 template <> struct RbT<float> { static constexpr int KE = 16; };
-__device__ inline float rb_lrelu(float v, float slope) { return v < 0.f ? v * slope : v; }
+// 0 < slope <= 1: LeakyReLU(v) = max(v, slope*v), its inverse = min(a, a/slope) - two VALU ops each
+__device__ inline float rb_lrelu(float v, float slope) { return fmaxf(v, v * slope); }
 }  // namespace
 
 template <typename T, int MI16>
@@ -121,11 +122,17 @@ __global__ __launch_bounds__(512) void vocoder_resblock_kernel(VocResblockArgs p
         const unsigned char* src = second ? slabY : slabX;
         const int ibase = (second ? GY : G) - c * dil + wrow0 + fr;  // slab index of this lane's fragment-0 row at tap 0
 
+        // the bias rides in as the accumulators' initial value (lane: channels n0 .. n0+7 of every row)
         f32x4_t acc[2][MI16];
+        {
+            const float* bp = p.bias + j * p.C + n0;
+            const float4 b0 = *(const float4*)bp, b1 = *(const float4*)(bp + 4);
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < MI16; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            for (int b = 0; b < MI16; ++b) {
+                acc[0][b] = (f32x4_t){b0.x, b0.y, b0.z, b0.w};
+                acc[1][b] = (f32x4_t){b1.x, b1.y, b1.z, b1.w};
+            }
+        }
 #pragma unroll 1
         for (int g0 = 0; g0 < nsteps4; g0 += 4) {
 #pragma unroll
@@ -152,12 +159,6 @@ __global__ __launch_bounds__(512) void vocoder_resblock_kernel(VocResblockArgs p
         }
 
         // ---- epilogue: lane = rows (m*16 + fr), channels n0 .. n0+7 ----
-        float bb[8];
-        {
-            const float* bp = p.bias + j * p.C + n0;
-            const float4 b0 = *(const float4*)bp, b1 = *(const float4*)(bp + 4);
-            bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
-        }
         const bool last = j == nconv - 1;
 #pragma unroll
         for (int m = 0; m < MI16; ++m) {
@@ -165,13 +166,13 @@ __global__ __launch_bounds__(512) void vocoder_resblock_kernel(VocResblockArgs p
             const bool inside = t >= 0 && t < len;
             float v[8];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) v[r] = acc[r >> 2][m][r & 3] + bb[r];
+            for (int r = 0; r < 8; ++r) v[r] = acc[r >> 2][m][r & 3];
             if (second) {  // + residual, recovered from the activated copy
                 float a[8];
 #pragma unroll
                 for (int q = 0; q < SPL; ++q) Vec16<T>::unpack(*(const uint4*)(slabX + slot_off(i, n0 / E16 + q)), a + q * E16);
 #pragma unroll
-                for (int r = 0; r < 8; ++r) v[r] += a[r] < 0.f ? a[r] * inv_slope : a[r];
+                for (int r = 0; r < 8; ++r) v[r] += fminf(a[r], a[r] * inv_slope);
             }
             if (!last) {
                 unsigned char* dstb = second ? slabX : slabY;
