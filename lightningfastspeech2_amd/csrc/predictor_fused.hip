@@ -96,11 +96,17 @@ __global__ __launch_bounds__(512, MINW) void predictor_fused_kernel(PredictorArg
 
     const int n0 = wv * 32 + fg * 8;  // this lane's 8 consecutive output channels
     for (int l = 0; l < nl; ++l) {
+        // bias rides in as the accumulators' initial value (lane: channels n0 .. n0+7 of every row)
         f32x4_t acc[2][MI16];
+        {
+            const float* bias = p.bias + l * PF_H + n0;
+            const float4 b0 = *(const float4*)bias, b1 = *(const float4*)(bias + 4);
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < MI16; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            for (int b = 0; b < MI16; ++b) {
+                acc[0][b] = (f32x4_t){b0.x, b0.y, b0.z, b0.w};
+                acc[1][b] = (f32x4_t){b1.x, b1.y, b1.z, b1.w};
+            }
+        }
         // tile row r at tap tp lives at slab index r + tp; its 16-byte slot (kb*4 + fg) is stored at
         // slot ^ (index & 15).  Taps: a rolled loop (short live ranges); the 8 k-blocks of a tap are
         // unrolled so that the ring index is static.
@@ -129,16 +135,11 @@ __global__ __launch_bounds__(512, MINW) void predictor_fused_kernel(PredictorArg
             }
         }
 
-        // ---- bias + ReLU ----  lane: rows (m*16 + fr), channels n0 + ni*4 + r
-        {
-            const float* bias = p.bias + l * PF_H + n0;
-            const float4 b0 = *(const float4*)bias, b1 = *(const float4*)(bias + 4);
-            const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        // ---- ReLU ----  lane: rows (m*16 + fr), channels n0 + ni*4 + r
 #pragma unroll
-            for (int m = 0; m < MI16; ++m)
+        for (int m = 0; m < MI16; ++m)
 #pragma unroll
-                for (int r = 0; r < 8; ++r) acc[r >> 2][m][r & 3] = fmaxf(acc[r >> 2][m][r & 3] + bb[r], 0.f);
-        }
+            for (int r = 0; r < 8; ++r) acc[r >> 2][m][r & 3] = fmaxf(acc[r >> 2][m][r & 3], 0.f);
         // ---- LayerNorm statistics, two-pass: lane partial -> lane groups -> the 8 column waves via LDS
         const float invn = 1.0f / (float)PF_H;
         float mean[MI16], rstd[MI16];
