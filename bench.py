@@ -122,8 +122,6 @@ def main():
         model.engine.set_fused_predictor(False)
     if os.environ.get("FS2_XCD_REMAP"):  # A/B: 0 = plain tile order in the slab GEMM
         _lib.load().fs2_op_set_gemm_variant(200 + int(os.environ["FS2_XCD_REMAP"]))
-    if os.environ.get("FS2_PRED_VARIANT"):  # A/B: predictor tile height (1 = 112 rows, 2 = 224 rows)
-        _lib.load().fs2_op_set_gemm_variant(100 + int(os.environ["FS2_PRED_VARIANT"]))
     inp = synth_inputs(cfg, args.batch, args.phones, seed=1234 + 17 * rank)
     batch = {"phones": torch.from_numpy(inp["phones"]).to(dev), "speaker": torch.from_numpy(inp["speaker"]).to(dev)}
 

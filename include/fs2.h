@@ -155,7 +155,6 @@ int fs2_profile_read(fs2_engine* e, int32_t kernel_class, double* total_ms, int6
  *   0       auto (by problem size)
  *   1       128x128 register-staged GEMM      2       128x256 LDS-DMA ring GEMM
  *   3/4/5   slab kernel, 128/192/256-row tiles   6/7   slab kernel, 32/64-row tiles
- *   100+v   tile height of the single-launch predictor (0 auto, 2 = 224 rows, 3 = 96 rows)
  *   200/201 slab kernel tile order: plain / XCD-contiguous (default) */
 int fs2_op_set_gemm_variant(int32_t variant);
 /* tuning knob: cap (KiB) on the LDS operand slab of a vocoder conv workgroup; 0 = built-in heuristic */

@@ -66,9 +66,7 @@ int fs2_op_set_vocoder_lds_limit(int32_t kib) {
 }
 
 int fs2_op_set_gemm_variant(int32_t variant) {
-    if (variant >= 100 && variant < 200) fs2::g_predictor_variant = variant - 100;  // 100 + v: predictor tile height
     if (variant >= 200) { fs2::g_slab_xcd_remap = variant - 200; return FS2_OK; }  // 200 / 201: tile order knob
-    if (variant >= 100) return FS2_OK;
     fs2::g_gemm_variant = variant;
     return FS2_OK;
 }

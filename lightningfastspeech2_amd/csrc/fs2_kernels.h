@@ -63,7 +63,6 @@ struct PredictorArgs {
     int B, S, H, nlayers, taps;
     float eps;
 };
-extern int g_predictor_variant;  // tile-height override for A/B runs (0 = auto)
 bool predictor_fused_supported(int dtype, int H, int taps, int nlayers, int S);
 size_t predictor_packed_bytes_per_layer();
 int launch_pack_predictor_weights(const void* w_layer /*(H, taps*H) tap-major bf16*/, void* out_layer, hipStream_t stream);

@@ -40,17 +40,23 @@ __global__ void pack_predictor_weights_kernel(const bf16* __restrict__ W, uint4*
     out[idx] = *(const uint4*)(W + (size_t)ch * (PF_TAPS * PF_H) + tap * PF_H + kb * 32 + fg * 8);
 }
 
-// 8 waves, each: ALL R rows x 32 output channels (accumulators 2 x R/16 fragments).  The weight
-// fragments a wave needs are private to it (no redundant loads inside the workgroup, 2 KiB per wave
-// per k-step) and ride a 4-deep register ring: L2 latency under 256 CUs pulling the same lines is
-// ~2k cycles, a k-step is 450-900.  The activation fragments come from the LDS slab in two halves
-// of R/32 so that they never hold more than 28 VGPRs.
-template <int MI16, int MINW>
-__global__ __launch_bounds__(512, MINW) void predictor_fused_kernel(PredictorArgs p) {
+// NWV waves, each: ALL R rows x (256 / NWV) output channels = NFR MFMA column fragments (a lane owns 8
+// consecutive channels per fragment pair).  The weight fragments a wave needs are private to it (no
+// redundant loads inside the workgroup) and ride a 4-deep register ring: L2 latency under 256 CUs
+// pulling the same lines is ~2k cycles, a k-step is 450-900.  The activation fragments come from the
+// LDS slab in two halves so that they never hold more than 16-28 VGPRs.
+// The shipped form is 4 waves x 64 channels on 112-row tiles, TWO workgroups per CU: independent
+// workgroups run out of phase (one's LayerNorm epilogue under the other's K loop), and 15 x 112 rows
+// cover 1536 frames with less halo waste than 8 x 224 (5 layers: 121 us vs 137 us for the 8-wave,
+// 224-row, one-workgroup-per-CU form).  One form for every shape keeps results independent of how an
+// utterance is batched (the cross-wave reduction tree is part of the arithmetic).
+template <int MI16, int NWV, int MINW>
+__global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(PredictorArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins exist in the device pass only
     constexpr int R = MI16 * 16, HFA = (MI16 + 1) / 2;  // row fragments: first half HFA, second MI16 - HFA
+    constexpr int NFR = PF_H / (NWV * 16), NP = NFR / 2;
     __shared__ __attribute__((aligned(16))) unsigned char slab[(R + 2) * PF_ROWB];  // slab index i <-> t = t0 - 1 + i
-    __shared__ float red[2][8 * R];
+    __shared__ float red[2][NWV * R];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -67,8 +73,8 @@ __global__ __launch_bounds__(512, MINW) void predictor_fused_kernel(PredictorArg
             __builtin_amdgcn_make_buffer_rsrc((void*)xu, 0, (unsigned)((size_t)S * PF_ROWB), 0x00020000);
         constexpr int NCH = (R + 2) / 2;
 #pragma unroll
-        for (int k = 0; k < (NCH + 7) / 8; ++k) {
-            const int c = k * 8 + wv;
+        for (int k = 0; k < (NCH + NWV - 1) / NWV; ++k) {
+            const int c = k * NWV + wv;
             if (c < NCH) {
                 const int i = 2 * c + (lane >> 5), ps = lane & 31, t = t0 - 1 + i;
                 const unsigned voff = (t >= 0 && t < S) ? (unsigned)(t * PF_ROWB + ((ps ^ (i & 15)) << 4)) : 0xFFFFF000u;
@@ -78,15 +84,16 @@ __global__ __launch_bounds__(512, MINW) void predictor_fused_kernel(PredictorArg
         }
     }
 
-    // ---- weight stream: step g = (layer*3 + tap)*8 + kb, 16 KiB per step, this wave's 2 fragments
-    const uint4* __restrict__ wbase = (const uint4*)p.wpk + wv * 2 * 64 + lane;
+    // ---- weight stream: step g = (layer*3 + tap)*8 + kb, 16 KiB per step, this wave's NFR fragments
+    // (fragment order [step][32-channel group][2][lane]: a wave's fragments are contiguous for any NWV)
+    const uint4* __restrict__ wbase = (const uint4*)p.wpk + wv * NFR * 64 + lane;
     const int total = nl * PF_STEPS;
-    auto loadB = [&](uint4 (&b)[2], int g) {
+    auto loadB = [&](uint4 (&b)[NFR], int g) {
         g = g < total ? g : total - 1;  // past the end: a harmless re-read instead of a branch
-        b[0] = wbase[(size_t)g * PF_STEP_U4];
-        b[1] = wbase[(size_t)g * PF_STEP_U4 + 64];
+#pragma unroll
+        for (int ni = 0; ni < NFR; ++ni) b[ni] = wbase[(size_t)g * PF_STEP_U4 + ni * 64];
     };
-    uint4 bw[4][2];
+    uint4 bw[4][NFR];
     loadB(bw[0], 0);
     loadB(bw[1], 1);
     loadB(bw[2], 2);
@@ -94,17 +101,18 @@ __global__ __launch_bounds__(512, MINW) void predictor_fused_kernel(PredictorArg
     dma_drain();
     __syncthreads();
 
-    const int n0 = wv * 32 + fg * 8;  // this lane's 8 consecutive output channels
+    const int n0 = wv * (NFR * 16) + fg * 8;  // fragment pair j: this lane's channels n0 + 32*j .. +7
     for (int l = 0; l < nl; ++l) {
-        // bias rides in as the accumulators' initial value (lane: channels n0 .. n0+7 of every row)
-        f32x4_t acc[2][MI16];
-        {
-            const float* bias = p.bias + l * PF_H + n0;
+        // bias rides in as the accumulators' initial value
+        f32x4_t acc[NFR][MI16];
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const float* bias = p.bias + l * PF_H + n0 + 32 * j;
             const float4 b0 = *(const float4*)bias, b1 = *(const float4*)(bias + 4);
 #pragma unroll
             for (int b = 0; b < MI16; ++b) {
-                acc[0][b] = (f32x4_t){b0.x, b0.y, b0.z, b0.w};
-                acc[1][b] = (f32x4_t){b1.x, b1.y, b1.z, b1.w};
+                acc[2 * j][b] = (f32x4_t){b0.x, b0.y, b0.z, b0.w};
+                acc[2 * j + 1][b] = (f32x4_t){b1.x, b1.y, b1.z, b1.w};
             }
         }
         // tile row r at tap tp lives at slab index r + tp; its 16-byte slot (kb*4 + fg) is stored at
@@ -127,7 +135,7 @@ __global__ __launch_bounds__(512, MINW) void predictor_fused_kernel(PredictorArg
                     for (int mi = 0; mi < HFA; ++mi)
                         if (mi < cnt) fx[mi] = *(const uint4*)(arow_p + (m0 + mi) * 16 * PF_ROWB + (acx ^ (kb << 6)));
 #pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
+                    for (int ni = 0; ni < NFR; ++ni)
 #pragma unroll
                         for (int mi = 0; mi < HFA; ++mi)
                             if (mi < cnt) Mma16<bf16>::step(bw[kb & 3][ni], fx[mi], acc[ni][m0 + mi]);
@@ -135,18 +143,21 @@ __global__ __launch_bounds__(512, MINW) void predictor_fused_kernel(PredictorArg
             }
         }
 
-        // ---- ReLU ----  lane: rows (m*16 + fr), channels n0 + ni*4 + r
+        // ---- ReLU ----  lane: rows (m*16 + fr), channels n0 + 32*(ni>>1) + (ni&1)*4 + r
 #pragma unroll
-        for (int m = 0; m < MI16; ++m)
+        for (int ni = 0; ni < NFR; ++ni)
 #pragma unroll
-            for (int r = 0; r < 8; ++r) acc[r >> 2][m][r & 3] = fmaxf(acc[r >> 2][m][r & 3], 0.f);
-        // ---- LayerNorm statistics, two-pass: lane partial -> lane groups -> the 8 column waves via LDS
+            for (int m = 0; m < MI16; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[ni][m][r] = fmaxf(acc[ni][m][r], 0.f);
+        // ---- LayerNorm statistics, two-pass: lane partial -> lane groups -> the column waves via LDS
         const float invn = 1.0f / (float)PF_H;
         float mean[MI16], rstd[MI16];
 #pragma unroll
         for (int m = 0; m < MI16; ++m) {
-            float sm = ((acc[0][m][0] + acc[0][m][1]) + (acc[0][m][2] + acc[0][m][3])) +
-                       ((acc[1][m][0] + acc[1][m][1]) + (acc[1][m][2] + acc[1][m][3]));
+            float sm = 0.f;
+#pragma unroll
+            for (int ni = 0; ni < NFR; ++ni) sm += (acc[ni][m][0] + acc[ni][m][1]) + (acc[ni][m][2] + acc[ni][m][3]);
             sm = group4_sum(sm);
             if (fg == 0) red[0][wv * R + m * 16 + fr] = sm;
         }
@@ -156,14 +167,16 @@ __global__ __launch_bounds__(512, MINW) void predictor_fused_kernel(PredictorArg
             const int row = m * 16 + fr;
             float t8 = 0.f;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) t8 += red[0][w * R + row];
+            for (int w = 0; w < NWV; ++w) t8 += red[0][w * R + row];
             mean[m] = t8 * invn;
             float q = 0.f;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const float d = acc[r >> 2][m][r & 3] - mean[m];
-                q += d * d;
-            }
+            for (int ni = 0; ni < NFR; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float d = acc[ni][m][r] - mean[m];
+                    q += d * d;
+                }
             q = group4_sum(q);
             if (fg == 0) red[1][wv * R + row] = q;
         }
@@ -173,47 +186,56 @@ __global__ __launch_bounds__(512, MINW) void predictor_fused_kernel(PredictorArg
             const int row = m * 16 + fr;
             float t8 = 0.f;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) t8 += red[1][w * R + row];
+            for (int w = 0; w < NWV; ++w) t8 += red[1][w * R + row];
             rstd[m] = 1.0f / sqrtf(t8 * invn + p.eps);
         }
         const bool last = l + 1 == nl;
-        float gg[8], ee[8], hw[8];
-        {
-            const float* gam = p.ln_g + l * PF_H + n0;
-            const float* bet = p.ln_b + l * PF_H + n0;
-            const float4 g0 = *(const float4*)gam, g1 = *(const float4*)(gam + 4);
-            const float4 e0 = *(const float4*)bet, e1 = *(const float4*)(bet + 4);
-            gg[0] = g0.x; gg[1] = g0.y; gg[2] = g0.z; gg[3] = g0.w; gg[4] = g1.x; gg[5] = g1.y; gg[6] = g1.z; gg[7] = g1.w;
-            ee[0] = e0.x; ee[1] = e0.y; ee[2] = e0.z; ee[3] = e0.w; ee[4] = e1.x; ee[5] = e1.y; ee[6] = e1.z; ee[7] = e1.w;
-            if (last) {
-                const float4 h0 = *(const float4*)(p.head_w + n0), h1 = *(const float4*)(p.head_w + n0 + 4);
-                hw[0] = h0.x; hw[1] = h0.y; hw[2] = h0.z; hw[3] = h0.w; hw[4] = h1.x; hw[5] = h1.y; hw[6] = h1.z; hw[7] = h1.w;
+        float dsum[MI16];
+#pragma unroll
+        for (int m = 0; m < MI16; ++m) dsum[m] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int n = n0 + 32 * j;
+            float gg[8], ee[8], hw[8];
+            {
+                const float* gam = p.ln_g + l * PF_H + n;
+                const float* bet = p.ln_b + l * PF_H + n;
+                const float4 g0 = *(const float4*)gam, g1 = *(const float4*)(gam + 4);
+                const float4 e0 = *(const float4*)bet, e1 = *(const float4*)(bet + 4);
+                gg[0] = g0.x; gg[1] = g0.y; gg[2] = g0.z; gg[3] = g0.w; gg[4] = g1.x; gg[5] = g1.y; gg[6] = g1.z; gg[7] = g1.w;
+                ee[0] = e0.x; ee[1] = e0.y; ee[2] = e0.z; ee[3] = e0.w; ee[4] = e1.x; ee[5] = e1.y; ee[6] = e1.z; ee[7] = e1.w;
+                if (last) {
+                    const float4 h0 = *(const float4*)(p.head_w + n), h1 = *(const float4*)(p.head_w + n + 4);
+                    hw[0] = h0.x; hw[1] = h0.y; hw[2] = h0.z; hw[3] = h0.w; hw[4] = h1.x; hw[5] = h1.y; hw[6] = h1.z; hw[7] = h1.w;
+                }
             }
-        }
-        if (!last) {
-            // next layer's input, in place; rows outside the utterance stay the conv's zero padding
 #pragma unroll
             for (int m = 0; m < MI16; ++m) {
                 const int row = m * 16 + fr, t = t0 + row, i = row + 1;
                 float y[8];
 #pragma unroll
-                for (int r = 0; r < 8; ++r) y[r] = (acc[r >> 2][m][r & 3] - mean[m]) * rstd[m] * gg[r] + ee[r];
-                const bool inside = t >= 0 && t < S;
-                const uint4 o = inside ? make_uint4(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]),
-                                                    pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7]))
-                                       : make_uint4(0u, 0u, 0u, 0u);
-                *(uint4*)(slab + i * PF_ROWB + (((n0 >> 3) ^ (i & 15)) << 4)) = o;
+                for (int r = 0; r < 8; ++r) y[r] = (acc[2 * j + (r >> 2)][m][r & 3] - mean[m]) * rstd[m] * gg[r] + ee[r];
+                if (last) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) dsum[m] += y[r] * hw[r];
+                } else {
+                    // next layer's input, in place; rows outside the utterance stay the conv's zero padding
+                    const bool inside = t >= 0 && t < S;
+                    const uint4 o = inside ? make_uint4(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]),
+                                                        pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7]))
+                                           : make_uint4(0u, 0u, 0u, 0u);
+                    *(uint4*)(slab + i * PF_ROWB + (((n >> 3) ^ (i & 15)) << 4)) = o;
+                }
             }
+        }
+        if (!last) {
             __syncthreads();  // slab holds layer l's output
             continue;
         }
         // ---- Linear(256, 1) head + mask (model.py:519-522) ----
 #pragma unroll
         for (int m = 0; m < MI16; ++m) {
-            float d = 0.f;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) d += ((acc[r >> 2][m][r & 3] - mean[m]) * rstd[m] * gg[r] + ee[r]) * hw[r];
-            d = group4_sum(d);
+            const float d = group4_sum(dsum[m]);
             if (fg == 0) red[0][wv * R + m * 16 + fr] = d;  // red[0] was last read two barriers ago
         }
         __syncthreads();
@@ -222,7 +244,7 @@ __global__ __launch_bounds__(512, MINW) void predictor_fused_kernel(PredictorArg
             if (row >= halo && row < R - halo && t < S) {
                 float d = p.head_b;
 #pragma unroll
-                for (int w = 0; w < 8; ++w) d += red[0][w * R + row];
+                for (int w = 0; w < NWV; ++w) d += red[0][w * R + row];
                 const size_t o = (size_t)ub * S + t;
                 p.pred[o] = (p.mask && p.mask[o]) ? 0.f : d;
             }
@@ -232,8 +254,6 @@ __global__ __launch_bounds__(512, MINW) void predictor_fused_kernel(PredictorArg
     (void)p;
 #endif
 }
-
-int g_predictor_variant = 0;  // 0 auto, 2 = 224-row tiles, 3 = 96-row tiles
 
 bool predictor_fused_supported(int dtype, int H, int taps, int nlayers, int S) {
     return dtype == FS2_BF16 && H == PF_H && taps == PF_TAPS && nlayers >= 1 && nlayers <= 16 && S >= 1 &&
@@ -252,18 +272,15 @@ size_t predictor_packed_bytes_per_layer() { return (size_t)PF_STEPS * PF_STEP_U4
 int launch_predictor_fused(const PredictorArgs& a, hipStream_t stream) {
     if (!predictor_fused_supported(FS2_BF16, a.H, a.taps, a.nlayers, a.S)) return FS2_ERR_SHAPE;
     if (a.B <= 0) return FS2_OK;
-    // tile height: 224 rows fills the chip at the decoder's frame counts; short sequences (the
-    // duration predictor at phone level) take 96-row tiles so that more CUs get one
     const int halo2 = 2 * (a.nlayers - 1);
+    if (112 - halo2 < 32) return FS2_ERR_SHAPE;
     auto tiles = [&](int R) { return (long)a.B * ((a.S + (R - halo2) - 1) / (R - halo2)); };
-    const int variant = g_predictor_variant;
-    if (96 - halo2 < 32) return FS2_ERR_SHAPE;
-    // (112-row tiles under a 128-VGPR cap, i.e. two workgroups per CU, were measured: 213 us vs 145 us
-    // for the 5-layer predictor - the epilogue spills and the LDS reads per MFMA double)
-    if (variant == 2 || (variant == 0 && tiles(224) >= 200) || (variant == 0 && tiles(96) <= tiles(224))) {
-        hipLaunchKernelGGL((predictor_fused_kernel<14, 2>), dim3((unsigned)tiles(224)), dim3(512), 0, stream, a);
-    } else {  // short sequences (the duration predictor at phone level): more, smaller tiles
-        hipLaunchKernelGGL((predictor_fused_kernel<6, 2>), dim3((unsigned)tiles(96)), dim3(512), 0, stream, a);
+    // the tile HEIGHT does not enter the arithmetic (rows are independent), the wave layout does: one
+    // layout for everything, shorter tiles when 112-row tiles would leave most CUs without work
+    if (tiles(112) < 200 && 64 - halo2 >= 32) {
+        hipLaunchKernelGGL((predictor_fused_kernel<4, 4, 2>), dim3((unsigned)tiles(64)), dim3(256), 0, stream, a);
+    } else {
+        hipLaunchKernelGGL((predictor_fused_kernel<7, 4, 2>), dim3((unsigned)tiles(112)), dim3(256), 0, stream, a);
     }
     return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
 }
