@@ -29,7 +29,10 @@ __device__ inline float lrelu(float v, float slope) { return fmaxf(v, v * slope)
 
 }  // namespace
 
-template <typename T, int MI16>
+// CP = padded input channels as a compile-time constant (0 = read it from the arguments): row stride,
+// fragment offsets and swizzle fold into immediates; with a runtime stride every fragment address cost a
+// VALU add and the K loop was issue-bound
+template <typename T, int MI16, int CP>
 __global__ __launch_bounds__(512) void vocoder_conv_kernel(VocConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char slab[];
     constexpr int KE = VocT<T>::KE, HF = MI16 / 2, RW = MI16 * 16;
@@ -47,54 +50,71 @@ __global__ __launch_bounds__(512) void vocoder_conv_kernel(VocConvArgs p) {
     const int t0 = tm * BM;
     if (t0 >= len) return;  // block-uniform
 
-    // ---- operand slab: index i <-> t = t0 - pad + i; 16-byte slot s of row i stored at s ^ swz(i) ----
-    const int rowb = p.cin_pad * (int)sizeof(T), ns = rowb >> 4;            // slots per row (power of two, >= 4)
-    const int sh = ns >= 16 ? 0 : (ns == 8 ? 1 : 2), smask = (ns >= 16 ? 16 : ns) - 1;
+    // ---- operand slab: index i <-> t = t0 - pad + i; 16-byte slot s of row i stored at SlabSwizzle::slot(s, i) ----
+    const int cin_pad = CP ? CP : p.cin_pad;
+    const int rowb = cin_pad * (int)sizeof(T), ns = rowb >> 4;  // slots per row (power of two, >= 4)
+    const SlabSwizzle swz(ns);
     {
-        const int rows = BM + halo, pieces = rows * ns;
+        const int rows = BM + halo, pieces = rows * ns, ns_sh = __builtin_ctz(ns);
         const size_t ubase = (size_t)ub * p.S;
-        // FB pieces per thread per trip: all their global loads are issued before the first is used
-        constexpr int FB = 4;
-        for (int q0 = tid; q0 < pieces; q0 += 512 * FB) {
-            float f[FB][E16];
-            int dst[FB];
+        if (p.in_fp32) {  // conv_pre only (fp32 mel, 80 channels padded to cin_pad): 0.1 % of a pass
+            for (int q = tid; q < pieces; q += 512) {
+                const int i = q >> ns_sh, s = q & (ns - 1), t = t0 - p.pad + i, c = s * E16;
+                float f[E16];
 #pragma unroll
-            for (int u = 0; u < FB; ++u) {
-                const int q = q0 + u * 512;
-                const int i = q / ns, s = q - i * ns, t = t0 - p.pad + i, c = s * E16;
-                dst[u] = q < pieces ? i * rowb + ((s ^ ((i >> sh) & smask)) << 4) : -1;
+                for (int e = 0; e < E16; ++e) f[e] = 0.f;
+                if (t >= 0 && t < len && c < p.cin) {
+                    const float* src = (const float*)p.x + (ubase + t) * p.cin + c;
 #pragma unroll
-                for (int e = 0; e < E16; ++e) f[u][e] = 0.f;
-                if (q < pieces && t >= 0 && t < len && c < p.cin) {
-                    if (p.in_fp32) {
-                        const float* src = (const float*)p.x + (ubase + t) * p.cin + c;
-#pragma unroll
-                        for (int e = 0; e < E16; e += 4) {
-                            if (c + e < p.cin) {  // cin is a multiple of 4
-                                const float4 v = *(const float4*)(src + e);
-                                f[u][e] = v.x; f[u][e + 1] = v.y; f[u][e + 2] = v.z; f[u][e + 3] = v.w;
-                            }
+                    for (int e = 0; e < E16; e += 4) {
+                        if (c + e < p.cin) {  // cin is a multiple of 4
+                            const float4 v = *(const float4*)(src + e);
+                            f[e] = v.x; f[e + 1] = v.y; f[e + 2] = v.z; f[e + 3] = v.w;
                         }
-                    } else {
-                        const uint4 v = *(const uint4*)((const T*)p.x + (ubase + t) * p.cin + c);
-                        Vec16<T>::unpack(v, f[u]);
                     }
                 }
-            }
-#pragma unroll
-            for (int u = 0; u < FB; ++u) {
-                if (dst[u] < 0) continue;
                 if (p.in_slope != 1.f) {
 #pragma unroll
-                    for (int e = 0; e < E16; ++e) f[u][e] = lrelu(f[u][e], p.in_slope);
+                    for (int e = 0; e < E16; ++e) f[e] = lrelu(f[e], p.in_slope);
                 }
-                *(uint4*)(slab + dst[u]) = Vec16<T>::pack(f[u]);
+                *(uint4*)(slab + i * rowb + (swz.slot(s, i) << 4)) = Vec16<T>::pack(f);
+            }
+        } else {
+            // FB pieces per thread per trip, every load unconditional (clamped address, zeroed afterwards):
+            // a trip costs ONE memory round trip, not one per piece behind its bounds branch
+            constexpr int FB = 8;
+            const T* xb = (const T*)p.x + ubase * p.cin;
+            for (int q0 = tid; q0 < pieces; q0 += 512 * FB) {
+                uint4 raw[FB];
+                int dst[FB];
+#pragma unroll
+                for (int u = 0; u < FB; ++u) {
+                    const int q = q0 + u * 512, qq = q < pieces ? q : pieces - 1;
+                    const int i = qq >> ns_sh, s = qq & (ns - 1), t = t0 - p.pad + i, c = s * E16;
+                    const bool ok = t >= 0 && t < len && c < p.cin;
+                    const int tc = t < 0 ? 0 : (t < len ? t : len - 1), cc = c < p.cin ? c : 0;
+                    dst[u] = q < pieces ? i * rowb + (swz.slot(s, i) << 4) : -1;
+                    raw[u] = *(const uint4*)(xb + (size_t)tc * p.cin + cc);
+                    if (!ok) raw[u] = make_uint4(0u, 0u, 0u, 0u);
+                }
+#pragma unroll
+                for (int u = 0; u < FB; ++u) {
+                    if (dst[u] < 0) continue;
+                    if (p.in_slope != 1.f) {
+                        float f[E16];
+                        Vec16<T>::unpack(raw[u], f);
+#pragma unroll
+                        for (int e = 0; e < E16; ++e) f[e] = lrelu(f[e], p.in_slope);
+                        raw[u] = Vec16<T>::pack(f);
+                    }
+                    *(uint4*)(slab + dst[u]) = raw[u];
+                }
             }
         }
     }
 
     // ---- weight stream: [n-tile][step][wave column][fragment][lane] x 16 B, 4-deep ring ----
-    const int nkc = p.cin_pad / KE, nsteps = p.taps * nkc, nsteps4 = (nsteps + 3) & ~3;
+    const int nkc = cin_pad / KE, nsteps = p.taps * nkc, nsteps4 = (nsteps + 3) & ~3;
     const uint4* __restrict__ wbase = (const uint4*)p.w + ((size_t)nt * nsteps4 * WN + wn) * 128 + lane;
     const size_t wstep = (size_t)WN * 128;
     auto loadB = [&](uint4 (&b)[2], int g) {
@@ -117,27 +137,44 @@ __global__ __launch_bounds__(512) void vocoder_conv_kernel(VocConvArgs p) {
 
     const int wrow0 = wm * RW;
     const int nkc_shift = __builtin_ctz(nkc);
+    // operand fragments run one group (PF fragments) ahead of the MFMAs that use them (two register sets, issue order
+    // pinned): left to itself the compiler reads a fragment right before its MFMA and every MFMA group then
+    // waits out an LDS round trip
+    auto a_addr = [&](int g) {  // this lane's fragment-0 address of step g
+        g = g < nsteps4 ? g : nsteps4 - 1;
+        int tap = g >> nkc_shift;
+        const int kc = g & (nkc - 1);
+        tap = tap < p.taps ? tap : p.taps - 1;  // padded steps multiply zero weights by any valid rows
+        const int i0 = wrow0 + fr + tap * p.dil;
+        return slab + i0 * rowb + (swz.slot(kc * 4 + fg, i0) << 4);
+    };
+    constexpr int PF = 2, NG = MI16 / PF;  // fragments per group, groups per step
+    uint4 fx[2][PF];
+    {
+        const unsigned char* a0 = a_addr(0);
+#pragma unroll
+        for (int mi = 0; mi < PF; ++mi) fx[0][mi] = *(const uint4*)(a0 + mi * 16 * rowb);
+    }
 #pragma unroll 1
     for (int g0 = 0; g0 < nsteps4; g0 += 4) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int g = g0 + u;
             loadB(bw[(u + 3) & 3], g + 3);
-            int tap = g >> nkc_shift;
-            const int kc = g & (nkc - 1);
-            tap = tap < p.taps ? tap : p.taps - 1;  // padded steps multiply zero weights by any valid rows
-            const int i0 = wrow0 + fr + tap * p.dil;
-            const unsigned char* arow_p = slab + i0 * rowb;
-            const int acx = ((kc * 4 + fg) ^ ((i0 >> sh) & smask)) << 4;
+            const unsigned char* acur = a_addr(g);
+            const unsigned char* anext = a_addr(g + 1);
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                uint4 fx[HF];
+            for (int q = 0; q < NG; ++q) {
+                const int cur = (u * NG + q) & 1;  // 4 * NG groups per trip: the parity restarts at 0
+                const unsigned char* na = q + 1 < NG ? acur + (q + 1) * PF * 16 * rowb : anext;
 #pragma unroll
-                for (int mi = 0; mi < HF; ++mi) fx[mi] = *(const uint4*)(arow_p + (hf * HF + mi) * 16 * rowb + acx);
+                for (int mi = 0; mi < PF; ++mi) fx[cur ^ 1][mi] = *(const uint4*)(na + mi * 16 * rowb);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                    for (int mi = 0; mi < HF; ++mi) Mma16<T>::step(bw[u][ni], fx[mi], acc[ni][hf * HF + mi]);
+                    for (int mi = 0; mi < PF; ++mi) Mma16<T>::step(bw[u][ni], fx[cur][mi], acc[ni][q * PF + mi]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
@@ -164,46 +201,60 @@ __global__ __launch_bounds__(512) void vocoder_conv_kernel(VocConvArgs p) {
         bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
     }
     const size_t obase = (size_t)ub * p.S;
+    // residual / previous-output rows are fetched MC rows at a time BEFORE any of them is used or stored
+    // (unconditional loads from clamped rows): one memory round trip per chunk instead of two per row
+    constexpr int NP = 8 / E16;  // 16-byte pieces of a lane's 8 channels
+    constexpr int MC = MI16 == 14 ? (sizeof(T) == 2 ? 7 : 2) : (MI16 >= 4 ? 4 : 2);
 #pragma unroll
-    for (int m = 0; m < MI16; ++m) {
-        const int t = t0 + wrow0 + m * 16 + fr;
-        if (t >= len) continue;
-        const size_t o = (obase + t) * p.n + n0;
-        float v[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = acc[r >> 2][m][r & 3] + bb[r];
+    for (int m0 = 0; m0 < MI16; m0 += MC) {
+        uint4 rr[MC][NP], oo[MC][NP];
         if (p.res) {
-            float rv[8];
-            if constexpr (sizeof(T) == 2) {
-                Vec16<T>::unpack(*(const uint4*)((const T*)p.res + o), rv);
-            } else {
-                Vec16<T>::unpack(*(const uint4*)((const T*)p.res + o), rv);
-                Vec16<T>::unpack(*(const uint4*)((const T*)p.res + o + 4), rv + 4);
+#pragma unroll
+            for (int mm = 0; mm < MC; ++mm) {
+                const int t = t0 + wrow0 + (m0 + mm) * 16 + fr, tc = t < len ? t : len - 1;
+                const uint4* src = (const uint4*)((const T*)p.res + (obase + tc) * p.n + n0);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) rr[mm][q] = src[q];
             }
-#pragma unroll
-            for (int r = 0; r < 8; ++r) v[r] += rv[r];
         }
-        if (p.scale != 1.f) {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) v[r] *= p.scale;
-        }
-        T* dst = (T*)p.out + o;
         if (p.accumulate) {
-            float ov[8];
-            if constexpr (sizeof(T) == 2) {
-                Vec16<T>::unpack(*(const uint4*)dst, ov);
-            } else {
-                Vec16<T>::unpack(*(const uint4*)dst, ov);
-                Vec16<T>::unpack(*(const uint4*)(dst + 4), ov + 4);
-            }
 #pragma unroll
-            for (int r = 0; r < 8; ++r) v[r] += ov[r];
+            for (int mm = 0; mm < MC; ++mm) {
+                const int t = t0 + wrow0 + (m0 + mm) * 16 + fr, tc = t < len ? t : len - 1;
+                const uint4* src = (const uint4*)((const T*)p.out + (obase + tc) * p.n + n0);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) oo[mm][q] = src[q];
+            }
         }
-        if constexpr (sizeof(T) == 2) {
-            *(uint4*)dst = Vec16<T>::pack(v);
-        } else {
-            *(uint4*)dst = Vec16<T>::pack(v);
-            *(uint4*)(dst + 4) = Vec16<T>::pack(v + 4);
+#pragma unroll
+        for (int mm = 0; mm < MC; ++mm) {
+            const int m = m0 + mm, t = t0 + wrow0 + m * 16 + fr;
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = acc[r >> 2][m][r & 3] + bb[r];
+            if (p.res) {
+                float rv[8];
+#pragma unroll
+                for (int q = 0; q < NP; ++q) Vec16<T>::unpack(rr[mm][q], rv + q * E16);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] += rv[r];
+            }
+            if (p.scale != 1.f) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] *= p.scale;
+            }
+            if (p.accumulate) {
+                float ov[8];
+#pragma unroll
+                for (int q = 0; q < NP; ++q) Vec16<T>::unpack(oo[mm][q], ov + q * E16);
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] += ov[r];
+            }
+            if (t < len) {
+                uint4* dst = (uint4*)((T*)p.out + (obase + t) * p.n + n0);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) dst[q] = Vec16<T>::pack(v + q * E16);
+            }
         }
     }
 }
@@ -230,11 +281,11 @@ static int voc_pick_mi16(const VocConvArgs& a, int esz, size_t* smem) {
     return 0;
 }
 
-template <typename T, int MI16>
-static int voc_launch_t(const VocConvArgs& a, size_t smem, hipStream_t stream) {
+template <typename T, int MI16, int CP>
+static int voc_launch_c(const VocConvArgs& a, size_t smem, hipStream_t stream) {
     static size_t attr = 0;
     if (smem > attr) {
-        if (hipFuncSetAttribute((const void*)vocoder_conv_kernel<T, MI16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void*)vocoder_conv_kernel<T, MI16, CP>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 150 * 1024) != hipSuccess)
             return FS2_ERR_HIP;
         attr = 150 * 1024;
@@ -242,9 +293,21 @@ static int voc_launch_t(const VocConvArgs& a, size_t smem, hipStream_t stream) {
     const int BM = (8 / a.wn) * MI16 * 16;
     const int tiles = (a.S + BM - 1) / BM;
     const int ntiles = a.post ? 1 : (a.n + a.wn * 32 - 1) / (a.wn * 32);
-    hipLaunchKernelGGL((vocoder_conv_kernel<T, MI16>), dim3((unsigned)(tiles * a.B), (unsigned)ntiles), dim3(512), smem,
+    hipLaunchKernelGGL((vocoder_conv_kernel<T, MI16, CP>), dim3((unsigned)(tiles * a.B), (unsigned)ntiles), dim3(512), smem,
                        stream, a);
     return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
+}
+
+template <typename T, int MI16>
+static int voc_launch_t(const VocConvArgs& a, size_t smem, hipStream_t stream) {
+    switch (a.cin_pad) {  // the V1 / V2 / V3 generators' widths; anything else takes the runtime-stride build
+        case 32: return voc_launch_c<T, MI16, 32>(a, smem, stream);
+        case 64: return voc_launch_c<T, MI16, 64>(a, smem, stream);
+        case 128: return voc_launch_c<T, MI16, 128>(a, smem, stream);
+        case 256: return voc_launch_c<T, MI16, 256>(a, smem, stream);
+        case 512: return voc_launch_c<T, MI16, 512>(a, smem, stream);
+        default: return voc_launch_c<T, MI16, 0>(a, smem, stream);
+    }
 }
 
 int voc_steps_padded(int taps, int cin_pad, int dtype) {

@@ -12,8 +12,9 @@
 //   conv (the reference pads every conv of a single unpadded utterance with zeros).
 //   Weights of the six convs lie back to back in fragment order; one 4-deep register ring streams
 //   them from L2 across conv boundaries; no barrier inside a K loop, two per conv pair.
-// Every conv makes (k-1)/2 * dil more rows at both tile edges stale, so a tile of R rows finishes
-// R - 2H rows, H = sum over pairs of (k-1)/2 * (d + 1); tiles overlap by that halo.
+// Every conv but the first (whose guard rows hold real samples) makes (k-1)/2 * dil more rows at both tile
+// edges stale, so a tile of R rows finishes R - 2H rows, H = (k-1)/2 * (sum over pairs of (d + 1) - d_first);
+// tiles overlap by that halo.
 #include "fs2_common.h"
 #include "fs2_kernels.h"
 
@@ -27,24 +28,34 @@ template <> struct RbT<float> { static constexpr int KE = 16; };
 __device__ inline float rb_lrelu(float v, float slope) { return fmaxf(v, v * slope); }
 }  // namespace
 
-template <typename T, int MI16>
-__global__ __launch_bounds__(512) void vocoder_resblock_kernel(VocResblockArgs p) {
+// CH = channels (32 / 64 / 128) as a compile-time constant: row strides, fragment offsets and the swizzle
+// fold into immediates - with a runtime row stride every fragment address cost its own VALU add and the
+// K loop was issue-bound (35 scalar/vector instructions per 8 MFMAs)
+// NW = waves per workgroup: 8, or 4 for the half-height tile that shares a CU with a second workgroup - two
+// INDEPENDENT 4-wave workgroups (one wave per SIMD each) instead of eight lock-step waves: the issue arbiter
+// serves the oldest wave first, so of two waves of ONE workgroup on a SIMD the younger reaches every barrier
+// ~40 % late (measured with s_memtime stamps) while the older one idles there
+template <typename T, int MI16, int CH, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void vocoder_resblock_kernel(VocResblockArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int KE = RbT<T>::KE, HF = MI16 / 2, RW = MI16 * 16;
     constexpr int E16 = 16 / (int)sizeof(T), SPL = 8 / E16;  // slots per lane per row (8 channels)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int WN = p.wn, WM = 8 / WN;
+    constexpr int C = CH, WN = CH / 32, WM = NW / WN, NT = NW * 64;
     const int wn = wave % WN, wm = wave / WN;
     const int fr = lane & 15, fg = lane >> 4;
-    const int R = WM * RW, c = (p.taps - 1) / 2;
+    constexpr int R = WM * RW;
+    const int c = (p.taps - 1) / 2;
     int dmax = 1, dsum = 0;
     for (int m = 0; m < p.npairs; ++m) {
         dmax = p.dil[m] > dmax ? p.dil[m] : dmax;
         dsum += p.dil[m] + 1;
     }
-    const int H = c * dsum, G = c * dmax, GY = c, V = R - 2 * H;  // X guard: widest dilated conv; Y guard: c2 (dil 1)
+    // X guard: widest dilated conv; Y guard: c2 (dil 1).  The X guard rows are loaded with real samples, so the
+    // very first conv loses no rows: a single pair only gives up the c rows of its c2 at each edge
+    const int H = c * (dsum - p.dil[0]), G = c * dmax, GY = c, V = R - 2 * H;
     const int tiles = (p.S + V - 1) / V;
     const int ub = blockIdx.x / tiles, tm = blockIdx.x % tiles;
     const int len = p.lengths ? p.lengths[ub] * p.len_scale : p.S;
@@ -52,41 +63,45 @@ __global__ __launch_bounds__(512) void vocoder_resblock_kernel(VocResblockArgs p
     if (t0 >= len) return;  // block-uniform
     const int tbase = t0 - H;  // time of tile row 0; slab index i <-> tile row i - G
 
-    const int rowb = p.C * (int)sizeof(T), ns = rowb >> 4;
-    const int sh = ns >= 16 ? 0 : (ns == 8 ? 1 : 2), smask = (ns >= 16 ? 16 : ns) - 1;
+    constexpr int rowb = C * (int)sizeof(T), ns = rowb >> 4;
+    const SlabSwizzle swz(ns);
     const int srows = R + 2 * G;
     unsigned char* slabX = lds;                           // slab index i <-> tile row i - G
     unsigned char* slabY = lds + (size_t)srows * rowb;    // slab index i <-> tile row i - GY
-    auto slot_off = [&](int i, int s) { return i * rowb + ((s ^ ((i >> sh) & smask)) << 4); };
+    auto slot_off = [&](int i, int s) { return i * rowb + (swz.slot(s, i) << 4); };
 
     // ---- X <- lrelu(x) for every slab row (guards included), zeros outside the utterance; Y guards <- 0
     {
-        const size_t ubase = (size_t)ub * p.S;
+        // FB pieces per thread per trip, every load unconditional (clamped row, zeroed afterwards): one
+        // memory round trip per trip
+        const T* xb = (const T*)p.x + (size_t)ub * p.S * C;
         const int pieces = srows * ns;
-        constexpr int FB = 4;
-        for (int q0 = tid; q0 < pieces; q0 += 512 * FB) {
-            float f[FB][E16];
+        constexpr int ns_sh = ns == 4 ? 2 : (ns == 8 ? 3 : (ns == 16 ? 4 : (ns == 32 ? 5 : 6)));
+        constexpr int FB = 8;
+        for (int q0 = tid; q0 < pieces; q0 += NT * FB) {
+            uint4 raw[FB];
             int dst[FB];
 #pragma unroll
             for (int u = 0; u < FB; ++u) {
-                const int q = q0 + u * 512;
-                const int i = q / ns, s = q - i * ns, t = tbase - G + i;
+                const int q = q0 + u * NT, qq = q < pieces ? q : pieces - 1;
+                const int i = qq >> ns_sh, s = qq & (ns - 1), t = tbase - G + i;
+                const int tc = t < 0 ? 0 : (t < len ? t : len - 1);
                 dst[u] = q < pieces ? slot_off(i, s) : -1;
-#pragma unroll
-                for (int e = 0; e < E16; ++e) f[u][e] = 0.f;
-                if (q < pieces && t >= 0 && t < len)
-                    Vec16<T>::unpack(*(const uint4*)((const T*)p.x + (ubase + t) * p.C + s * E16), f[u]);
+                raw[u] = *(const uint4*)(xb + (size_t)tc * C + s * E16);
+                if (t < 0 || t >= len) raw[u] = make_uint4(0u, 0u, 0u, 0u);
             }
 #pragma unroll
             for (int u = 0; u < FB; ++u) {
                 if (dst[u] < 0) continue;
+                float f[E16];
+                Vec16<T>::unpack(raw[u], f);
 #pragma unroll
-                for (int e = 0; e < E16; ++e) f[u][e] = rb_lrelu(f[u][e], p.slope);
-                *(uint4*)(slabX + dst[u]) = Vec16<T>::pack(f[u]);
+                for (int e = 0; e < E16; ++e) f[e] = rb_lrelu(f[e], p.slope);
+                *(uint4*)(slabX + dst[u]) = Vec16<T>::pack(f);
             }
         }
         const int gp = 2 * GY * ns;
-        for (int q = tid; q < gp; q += 512) {
+        for (int q = tid; q < gp; q += NT) {
             int i = q / ns;
             const int s = q - i * ns;
             if (i >= GY) i += R;
@@ -95,7 +110,8 @@ __global__ __launch_bounds__(512) void vocoder_resblock_kernel(VocResblockArgs p
     }
 
     // ---- weight stream over all six convs: [conv][step][wave column][fragment][lane] x 16 B ----
-    const int nkc = p.C / KE, nsteps = p.taps * nkc, nsteps4 = (nsteps + 3) & ~3;
+    constexpr int nkc = C / KE;
+    const int nsteps = p.taps * nkc, nsteps4 = (nsteps + 3) & ~3;
     const int nconv = 2 * p.npairs, total = nconv * nsteps4;
     const uint4* __restrict__ wbase = (const uint4*)p.w + (size_t)wn * 128 + lane;
     const size_t wstep = (size_t)WN * 128;
@@ -110,7 +126,7 @@ __global__ __launch_bounds__(512) void vocoder_resblock_kernel(VocResblockArgs p
     loadB(bw[2], 2);
 
     const int wrow0 = wm * RW;
-    const int nkc_shift = __builtin_ctz(nkc);
+    constexpr int nkc_shift = nkc == 1 ? 0 : (nkc == 2 ? 1 : (nkc == 4 ? 2 : (nkc == 8 ? 3 : 4)));
     const int n0 = wn * 32 + fg * 8;  // this lane's 8 consecutive channels
     const float inv_slope = 1.0f / p.slope;
     __syncthreads();
@@ -125,7 +141,7 @@ __global__ __launch_bounds__(512) void vocoder_resblock_kernel(VocResblockArgs p
         // the bias rides in as the accumulators' initial value (lane: channels n0 .. n0+7 of every row)
         f32x4_t acc[2][MI16];
         {
-            const float* bp = p.bias + j * p.C + n0;
+            const float* bp = p.bias + j * C + n0;
             const float4 b0 = *(const float4*)bp, b1 = *(const float4*)(bp + 4);
 #pragma unroll
             for (int b = 0; b < MI16; ++b) {
@@ -133,35 +149,65 @@ __global__ __launch_bounds__(512) void vocoder_resblock_kernel(VocResblockArgs p
                 acc[1][b] = (f32x4_t){b1.x, b1.y, b1.z, b1.w};
             }
         }
+        // operand fragments run one group (PF fragments) ahead of the MFMAs that use them (two register sets, issue order
+        // pinned): left to itself the compiler reads a fragment right before its MFMA and every MFMA group
+        // then waits out an LDS round trip
+        auto a_addr = [&](int g) {  // this lane's fragment-0 address of step g
+            g = g < nsteps4 ? g : nsteps4 - 1;
+            int tap = g >> nkc_shift;
+            const int kc = g & (nkc - 1);
+            tap = tap < p.taps ? tap : p.taps - 1;  // padded steps: zero weights x any valid rows
+            const int i0 = ibase + tap * dil;
+            return src + i0 * rowb + (swz.slot(kc * 4 + fg, i0) << 4);
+        };
+        constexpr int PF = MI16 == 8 ? 4 : 2, NG = MI16 / PF;  // fragments per group, groups per step
+        uint4 fx[2][PF];
+        {
+            const unsigned char* a0 = a_addr(0);
+#pragma unroll
+            for (int mi = 0; mi < PF; ++mi) fx[0][mi] = *(const uint4*)(a0 + mi * 16 * rowb);
+        }
 #pragma unroll 1
         for (int g0 = 0; g0 < nsteps4; g0 += 4) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int g = g0 + u;
                 loadB(bw[(u + 3) & 3], j * nsteps4 + g + 3);
-                int tap = g >> nkc_shift;
-                const int kc = g & (nkc - 1);
-                tap = tap < p.taps ? tap : p.taps - 1;  // padded steps: zero weights x any valid rows
-                const int i0 = ibase + tap * dil;
-                const unsigned char* arow_p = src + i0 * rowb;
-                const int acx = ((kc * 4 + fg) ^ ((i0 >> sh) & smask)) << 4;
+                const unsigned char* acur = a_addr(g);
+                const unsigned char* anext = a_addr(g + 1);
 #pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    uint4 fx[HF];
+                for (int q = 0; q < NG; ++q) {
+                    const int cur = (u * NG + q) & 1;  // 4 * NG groups per trip: the parity restarts at 0
+                    const unsigned char* na = q + 1 < NG ? acur + (q + 1) * PF * 16 * rowb : anext;
 #pragma unroll
-                    for (int mi = 0; mi < HF; ++mi) fx[mi] = *(const uint4*)(arow_p + (hf * HF + mi) * 16 * rowb + acx);
+                    for (int mi = 0; mi < PF; ++mi) fx[cur ^ 1][mi] = *(const uint4*)(na + mi * 16 * rowb);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                        for (int mi = 0; mi < HF; ++mi) Mma16<T>::step(bw[u][ni], fx[mi], acc[ni][hf * HF + mi]);
+                        for (int mi = 0; mi < PF; ++mi) Mma16<T>::step(bw[u][ni], fx[cur][mi], acc[ni][q * PF + mi]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
 
         // ---- epilogue: lane = rows (m*16 + fr), channels n0 .. n0+7 ----
         const bool last = j == nconv - 1;
+        // the block's result is added to the previous output: those rows are fetched MC at a time before any
+        // row of the chunk is stored (unconditional loads, clamped rows) - one memory round trip per chunk
+        constexpr int MC = MI16 == 4 ? 2 : 4;
+        uint4 oo[MC][SPL];
 #pragma unroll
         for (int m = 0; m < MI16; ++m) {
+            if (m % MC == 0 && last && p.accumulate) {
+#pragma unroll
+                for (int mm = 0; mm < MC; ++mm) {
+                    const int tt = tbase + wrow0 + (m + mm) * 16 + fr, tc = tt < 0 ? 0 : (tt < len ? tt : len - 1);
+                    const uint4* src = (const uint4*)((const T*)p.out + ((size_t)ub * p.S + tc) * C + n0);
+#pragma unroll
+                    for (int q = 0; q < SPL; ++q) oo[mm][q] = src[q];
+                }
+            }
             const int row = wrow0 + m * 16 + fr, t = tbase + row, i = G + row, iy = GY + row;
             const bool inside = t >= 0 && t < len;
             float v[8];
@@ -182,13 +228,13 @@ __global__ __launch_bounds__(512) void vocoder_resblock_kernel(VocResblockArgs p
 #pragma unroll
                 for (int q = 0; q < SPL; ++q) *(uint4*)(dstb + slot_off(id, n0 / E16 + q)) = Vec16<T>::pack(v + q * E16);
             } else if (inside && row >= H && row < H + V) {
-                T* dst = (T*)p.out + ((size_t)ub * p.S + t) * p.C + n0;
+                T* dst = (T*)p.out + ((size_t)ub * p.S + t) * C + n0;
 #pragma unroll
                 for (int r = 0; r < 8; ++r) v[r] *= p.scale;
                 if (p.accumulate) {
                     float ov[8];
 #pragma unroll
-                    for (int q = 0; q < SPL; ++q) Vec16<T>::unpack(*(const uint4*)(dst + q * E16), ov + q * E16);
+                    for (int q = 0; q < SPL; ++q) Vec16<T>::unpack(oo[m % MC][q], ov + q * E16);
 #pragma unroll
                     for (int r = 0; r < 8; ++r) v[r] += ov[r];
                 }
@@ -200,77 +246,88 @@ __global__ __launch_bounds__(512) void vocoder_resblock_kernel(VocResblockArgs p
     }
 }
 
-int g_voc_fused_resblock = 1;  // A/B knob (fs2_op_set_vocoder_fused_resblock): 0 off, 1 auto, 2 pairs only, 4 = tallest tiles only
+int g_voc_fused_resblock = 1;  // A/B knob (fs2_op_set_vocoder_fused_resblock): 0 off, 1 auto, 2 pairs only, 4 = full-height 8-wave tiles only
 
-static void rb_geom(const VocResblockArgs& a, int mi16, int* R, int* H, int* G) {
+static void rb_geom(const VocResblockArgs& a, int nw, int mi16, int* R, int* H, int* G) {
     const int c = (a.taps - 1) / 2;
     int dmax = 1, dsum = 0;
     for (int m = 0; m < a.npairs; ++m) {
         dmax = a.dil[m] > dmax ? a.dil[m] : dmax;
         dsum += a.dil[m] + 1;
     }
-    *R = (8 / a.wn) * mi16 * 16;
-    *H = c * dsum;
+    *R = (nw / a.wn) * mi16 * 16;
+    *H = c * (dsum - a.dil[0]);
     *G = c * dmax;
 }
-static size_t rb_lds_bytes(const VocResblockArgs& a, int mi16, int esz) {
+static size_t rb_lds_bytes(const VocResblockArgs& a, int nw, int mi16, int esz) {
     int R, H, G;
-    rb_geom(a, mi16, &R, &H, &G);
+    rb_geom(a, nw, mi16, &R, &H, &G);
     return (size_t)((R + 2 * G) + (R + 2 * ((a.taps - 1) / 2))) * a.C * esz;
 }
 
-// tile height (x16 rows per wave) for this launch (npairs = 3: whole resblock, 1: one (c1, c2) pair),
-// 0 = not worth it / does not fit: the LDS must hold both slabs and the halo may eat at most a fifth
-// of the tile (measured: a whole 64-channel k=11 block at 77 % useful rows is slower than conv by conv)
+// tile shape for this launch (npairs = 3: whole resblock, 1: one (c1, c2) pair) as 100 * waves + (16-row
+// fragments per wave), 0 = not worth it / does not fit: the LDS must hold both slabs and the halo may eat at
+// most a fifth of the tile (measured: a whole 64-channel k=11 block at 77 % useful rows is slower than conv by
+// conv).  A 4-wave workgroup on <= 76 KiB (two per CU, covering each other's fills, barriers and epilogues)
+// is taken when >= 85 % of its rows are useful: 3-9 % faster than the 8-wave full-height tile on the 32/64-
+// channel stages and on the 128-channel k=7 pairs, equal elsewhere (repeated A/B runs).
 int voc_resblock_mi16(const VocResblockArgs& a, int dtype) {
     if (!g_voc_fused_resblock || (g_voc_fused_resblock == 2 && a.npairs != 1)) return 0;
     const int esz = dtype == FS2_BF16 ? 2 : 4;
     if (a.C != 32 && a.C != 64 && a.C != 128) return 0;
     if (a.wn != a.C / 32 || !(a.taps & 1) || (a.npairs != 1 && a.npairs != 3)) return 0;
-    {   // two workgroups per CU (<= 76 KiB each) cover each other's barriers and epilogues: take the
-        // half-height tile when its halo still leaves >= 85 % useful rows
+    const bool try_half = g_voc_fused_resblock != 4;
+    if (try_half) {
         int R, H, G;
-        rb_geom(a, 4, &R, &H, &G);
-        if (g_voc_fused_resblock != 4 && rb_lds_bytes(a, 4, esz) <= 76 * 1024 && (R - 2 * H) * 20 >= R * 17) return 4;
+        rb_geom(a, 4, 8, &R, &H, &G);
+        if (rb_lds_bytes(a, 4, 8, esz) <= 76 * 1024 && (R - 2 * H) * 100 >= R * 85) return 408;
     }
-    static const int cand[3] = {14, 8, 4};
-    for (int k = 0; k < 3; ++k) {
-        if (cand[k] == 14 && a.wn != 4) continue;  // 14 only helps the 2-row-wave layout reach 448 rows
+    static const int cand[2] = {8, 4};
+    for (int k = 0; k < 2; ++k) {
         int R, H, G;
-        rb_geom(a, cand[k], &R, &H, &G);
-        if (rb_lds_bytes(a, cand[k], esz) <= 150 * 1024 && (R - 2 * H) * 5 >= R * 4) return cand[k];
+        rb_geom(a, 8, cand[k], &R, &H, &G);
+        if (rb_lds_bytes(a, 8, cand[k], esz) <= 150 * 1024 && (R - 2 * H) * 5 >= R * 4) return 800 + cand[k];
     }
     return 0;
 }
 
-template <typename T, int MI16>
-static int rb_launch_t(const VocResblockArgs& a, size_t smem, hipStream_t stream) {
+template <typename T, int MI16, int CH, int NW>
+static int rb_launch_c(const VocResblockArgs& a, size_t smem, hipStream_t stream) {
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)vocoder_resblock_kernel<T, MI16>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                150 * 1024) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)vocoder_resblock_kernel<T, MI16, CH, NW>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
             return FS2_ERR_HIP;
         attr = true;
     }
     int R, H, G;
-    rb_geom(a, MI16, &R, &H, &G);
+    rb_geom(a, NW, MI16, &R, &H, &G);
     const int V = R - 2 * H;
     const int tiles = (a.S + V - 1) / V;
-    hipLaunchKernelGGL((vocoder_resblock_kernel<T, MI16>), dim3((unsigned)(tiles * a.B)), dim3(512), smem, stream, a);
+    hipLaunchKernelGGL((vocoder_resblock_kernel<T, MI16, CH, NW>), dim3((unsigned)(tiles * a.B)), dim3(NW * 64), smem, stream,
+                       a);
     return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
+}
+
+template <typename T, int MI16, int NW>
+static int rb_launch_t(const VocResblockArgs& a, size_t smem, hipStream_t stream) {
+    if (a.C == 32) return rb_launch_c<T, MI16, 32, NW>(a, smem, stream);
+    if (a.C == 64) return rb_launch_c<T, MI16, 64, NW>(a, smem, stream);
+    return rb_launch_c<T, MI16, 128, NW>(a, smem, stream);
 }
 
 int launch_vocoder_resblock(const VocResblockArgs& a, int dtype, hipStream_t stream) {
     if (a.B <= 0 || a.S <= 0) return FS2_OK;
-    const int mi = voc_resblock_mi16(a, dtype);
-    if (!mi) return FS2_ERR_SHAPE;
-    const size_t smem = rb_lds_bytes(a, mi, dtype == FS2_BF16 ? 2 : 4);
+    const int cfg = voc_resblock_mi16(a, dtype);
+    if (!cfg) return FS2_ERR_SHAPE;
+    const int nw = cfg / 100, mi = cfg % 100;
+    const size_t smem = rb_lds_bytes(a, nw, mi, dtype == FS2_BF16 ? 2 : 4);
     if (dtype == FS2_BF16) {
-        if (mi == 14) return rb_launch_t<bf16, 14>(a, smem, stream);
-        return mi == 8 ? rb_launch_t<bf16, 8>(a, smem, stream) : rb_launch_t<bf16, 4>(a, smem, stream);
+        if (nw == 4) return rb_launch_t<bf16, 8, 4>(a, smem, stream);
+        return mi == 8 ? rb_launch_t<bf16, 8, 8>(a, smem, stream) : rb_launch_t<bf16, 4, 8>(a, smem, stream);
     }
-    if (mi == 14) return rb_launch_t<float, 14>(a, smem, stream);
-    return mi == 8 ? rb_launch_t<float, 8>(a, smem, stream) : rb_launch_t<float, 4>(a, smem, stream);
+    if (nw == 4) return rb_launch_t<float, 8, 4>(a, smem, stream);
+    return mi == 8 ? rb_launch_t<float, 8, 8>(a, smem, stream) : rb_launch_t<float, 4, 8>(a, smem, stream);
 }
 
 }  // namespace fs2

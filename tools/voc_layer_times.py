@@ -14,10 +14,8 @@ def fused_mi16(C, k, dils, esz=2):
     if C not in (32, 64, 128):
         return 0
     c = (k - 1) // 2
-    H, G = c * sum(d + 1 for d in dils), c * max(dils)
-    for mi in (14, 8, 4):
-        if mi == 14 and C // 32 != 4:
-            continue
+    H, G = c * (sum(d + 1 for d in dils) - dils[0]), c * max(dils)
+    for mi in (8, 4):
         R = (8 // (C // 32)) * mi * 16
         if ((R + 2 * G) + (R + 2 * c)) * C * esz <= 150 * 1024 and (R - 2 * H) * 5 >= R * 4:
             return mi
