@@ -77,7 +77,7 @@ __global__ __launch_bounds__(NW * 64, 2) void vocoder_resblock_kernel(VocResbloc
         const T* xb = (const T*)p.x + (size_t)ub * p.S * C;
         const int pieces = srows * ns;
         constexpr int ns_sh = ns == 4 ? 2 : (ns == 8 ? 3 : (ns == 16 ? 4 : (ns == 32 ? 5 : 6)));
-        constexpr int FB = 8;
+        constexpr int FB = 12;  // one trip covers a 4-wave tile
         for (int q0 = tid; q0 < pieces; q0 += NT * FB) {
             uint4 raw[FB];
             int dst[FB];
@@ -160,12 +160,17 @@ __global__ __launch_bounds__(NW * 64, 2) void vocoder_resblock_kernel(VocResbloc
             const int i0 = ibase + tap * dil;
             return src + i0 * rowb + (swz.slot(kc * 4 + fg, i0) << 4);
         };
-        constexpr int PF = MI16 == 8 ? 4 : 2, NG = MI16 / PF;  // fragments per group, groups per step
-        uint4 fx[2][PF];
-        {
-            const unsigned char* a0 = a_addr(0);
+        // PF fragments per group, NG groups per step, NS register sets: the set freed by group i-1 is refilled
+        // with group i + NS - 1 while group i multiplies (4 * NG groups per trip, a multiple of NS)
+        // (2 fragments x 4 sets measured 1.7 % faster per pass than 4 x 2 on the same registers; 4 x 4 and 2 x 8 no better)
+        constexpr int PF = 2, NG = MI16 / PF, NS = 4, D = NS - 1, NA = (NG - 1 + D) / NG + 1;
+        static_assert((4 * NG) % NS == 0, "set index must restart every trip");
+        uint4 fx[NS][PF];
 #pragma unroll
-            for (int mi = 0; mi < PF; ++mi) fx[0][mi] = *(const uint4*)(a0 + mi * 16 * rowb);
+        for (int gi = 0; gi < D; ++gi) {
+            const unsigned char* a0 = a_addr(gi / NG) + (gi % NG) * PF * 16 * rowb;
+#pragma unroll
+            for (int mi = 0; mi < PF; ++mi) fx[gi][mi] = *(const uint4*)(a0 + mi * 16 * rowb);
         }
 #pragma unroll 1
         for (int g0 = 0; g0 < nsteps4; g0 += 4) {
@@ -173,14 +178,15 @@ __global__ __launch_bounds__(NW * 64, 2) void vocoder_resblock_kernel(VocResbloc
             for (int u = 0; u < 4; ++u) {
                 const int g = g0 + u;
                 loadB(bw[(u + 3) & 3], j * nsteps4 + g + 3);
-                const unsigned char* acur = a_addr(g);
-                const unsigned char* anext = a_addr(g + 1);
+                const unsigned char* as[NA];
+#pragma unroll
+                for (int k = 0; k < NA; ++k) as[k] = a_addr(g + k);
 #pragma unroll
                 for (int q = 0; q < NG; ++q) {
-                    const int cur = (u * NG + q) & 1;  // 4 * NG groups per trip: the parity restarts at 0
-                    const unsigned char* na = q + 1 < NG ? acur + (q + 1) * PF * 16 * rowb : anext;
+                    const int gi = u * NG + q, cur = gi % NS, tgt = (gi + D) % NS;
+                    const unsigned char* na = as[(q + D) / NG] + ((q + D) % NG) * PF * 16 * rowb;
 #pragma unroll
-                    for (int mi = 0; mi < PF; ++mi) fx[cur ^ 1][mi] = *(const uint4*)(na + mi * 16 * rowb);
+                    for (int mi = 0; mi < PF; ++mi) fx[tgt][mi] = *(const uint4*)(na + mi * 16 * rowb);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni)
