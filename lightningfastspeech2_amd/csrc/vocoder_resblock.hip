@@ -282,11 +282,15 @@ int voc_resblock_mi16(const VocResblockArgs& a, int dtype) {
     const int esz = dtype == FS2_BF16 ? 2 : 4;
     if (a.C != 32 && a.C != 64 && a.C != 128) return 0;
     if (a.wn != a.C / 32 || !(a.taps & 1) || (a.npairs != 1 && a.npairs != 3)) return 0;
+    // a whole block per launch pays while a conv's K loop is short (<= 7 steps of 32 channels): measured 5-15 %
+    // faster than three pair launches at 32 ch k=3/7 and 64 ch k=3, 5-7 % slower at 64 ch k=7 and 32 ch k=11
+    if (a.npairs == 3 && a.taps * a.C > 224 && g_voc_fused_resblock != 7) return 0;
     const bool try_half = g_voc_fused_resblock != 4;
     if (try_half) {
         int R, H, G;
         rb_geom(a, 4, 8, &R, &H, &G);
-        if (rb_lds_bytes(a, 4, 8, esz) <= 76 * 1024 && (R - 2 * H) * 100 >= R * 85) return 408;
+        const int pct = g_voc_fused_resblock >= 50 ? g_voc_fused_resblock : 85;  // knob >= 50: threshold in percent (tuning)
+        if (rb_lds_bytes(a, 4, 8, esz) <= 76 * 1024 && (R - 2 * H) * 100 >= R * pct) return 408;
     }
     static const int cand[2] = {8, 4};
     for (int k = 0; k < 2; ++k) {

@@ -13,6 +13,8 @@ def fused_mi16(C, k, dils, esz=2):
     """Mirror of voc_resblock_mi16 (vocoder_resblock.hip): tile height or 0."""
     if C not in (32, 64, 128):
         return 0
+    if len(dils) == 3 and k * C > 224:
+        return 0
     c = (k - 1) // 2
     H, G = c * (sum(d + 1 for d in dils) - dils[0]), c * max(dils)
     for mi in (8, 4):
@@ -22,7 +24,7 @@ def fused_mi16(C, k, dils, esz=2):
     return 0
 
 
-def labels(cfg, fused=True):
+def labels(cfg, fused=True, blocks=True):
     """One (label, flops per frame) per launch of a pass, in launch order (vocoder_engine.hip)."""
     ch = cfg.channels()
     out = [("conv_pre", 2.0 * 80 * ch[0] * 7, 1)]
@@ -33,7 +35,7 @@ def labels(cfg, fused=True):
         C = ch[i + 1]
         for rk, rd in zip(cfg.resblock_kernel_sizes, cfg.resblock_dilation_sizes):
             conv = up * 2.0 * C * C * rk
-            if fused and fused_mi16(C, rk, rd):
+            if fused and blocks and fused_mi16(C, rk, rd):
                 out.append((f"s{i} C={C} k={rk} block", 6 * conv, up))
                 continue
             for d in rd:
@@ -46,10 +48,10 @@ def labels(cfg, fused=True):
     return out
 
 
-def main(db, frames, fused=True):
+def main(db, frames, fused=True, blocks=True):
     con = sqlite3.connect(db)
     rows = con.execute("select name, start, end from kernels where name like '%vocoder_%' order by start").fetchall()
-    lab = labels(HifiGanConfig(), fused)
+    lab = labels(HifiGanConfig(), fused, blocks)
     rows = rows[-len(lab):]
     tot = 0.0
     agg = {}
@@ -66,4 +68,5 @@ def main(db, frames, fused=True):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], float(sys.argv[2]), fused=(len(sys.argv) < 4 or sys.argv[3] != "unfused"))
+    mode = sys.argv[3] if len(sys.argv) > 3 else "fused"  # fused | pairs (no whole-block launches) | unfused
+    main(sys.argv[1], float(sys.argv[2]), fused=mode != "unfused", blocks=mode == "fused")
