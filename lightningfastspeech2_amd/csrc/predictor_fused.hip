@@ -77,7 +77,9 @@ __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(Predict
             const int c = k * NWV + wv;
             if (c < NCH) {
                 const int i = 2 * c + (lane >> 5), ps = lane & 31, t = t0 - 1 + i;
-                const unsigned voff = (t >= 0 && t < S) ? (unsigned)(t * PF_ROWB + ((ps ^ (i & 15)) << 4)) : 0xFFFFF000u;
+                // physical slot ps of slab row i holds logical slot ls (the inverse of SlabSwizzle::slot, fs2_common.h)
+                const int ls = (ps & 16) | ((((ps & 7) ^ (i & 7)) << 1) | ((ps >> 3) & 1));
+                const unsigned voff = (t >= 0 && t < S) ? (unsigned)(t * PF_ROWB + (ls << 4)) : 0xFFFFF000u;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(slab + c * 1024),
                                                          16, voff, 0, 0, 0);
             }
@@ -116,13 +118,14 @@ __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(Predict
             }
         }
         // tile row r at tap tp lives at slab index r + tp; its 16-byte slot (kb*4 + fg) is stored at
-        // slot ^ (index & 15).  Taps: a rolled loop (short live ranges); the 8 k-blocks of a tap are
+        // SlabSwizzle::slot(slot, index) (conflict-free fragment reads for every start row; the plain
+        // slot ^ (index & 15) map measured 20 % bank-conflict cycles).  Taps: a rolled loop (short live ranges); the 8 k-blocks of a tap are
         // unrolled so that the ring index is static.
 #pragma unroll 1
         for (int tp = 0; tp < PF_TAPS; ++tp) {
             const int i0 = fr + tp;
             const unsigned char* arow_p = slab + i0 * PF_ROWB;
-            const int acx = (fg ^ (i0 & 15)) << 4;
+            const int acx = (((fg & 1) << 3) | ((fg >> 1) ^ (i0 & 7))) << 4;  // SlabSwizzle::slot(fg, i0); + kb below
 #pragma unroll
             for (int kb = 0; kb < PF_KB; ++kb) {
                 loadB(bw[(kb + 3) & 3], (l * PF_TAPS + tp) * PF_KB + kb + 3);
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(Predict
                     uint4 fx[HFA];
 #pragma unroll
                     for (int mi = 0; mi < HFA; ++mi)
-                        if (mi < cnt) fx[mi] = *(const uint4*)(arow_p + (m0 + mi) * 16 * PF_ROWB + (acx ^ (kb << 6)));
+                        if (mi < cnt) fx[mi] = *(const uint4*)(arow_p + (m0 + mi) * 16 * PF_ROWB + (acx ^ ((((kb & 3) << 1) | ((kb >> 2) << 4)) << 4)));
 #pragma unroll
                     for (int ni = 0; ni < NFR; ++ni)
 #pragma unroll
@@ -224,7 +227,7 @@ __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(Predict
                     const uint4 o = inside ? make_uint4(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]),
                                                         pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7]))
                                            : make_uint4(0u, 0u, 0u, 0u);
-                    *(uint4*)(slab + i * PF_ROWB + (((n >> 3) ^ (i & 15)) << 4)) = o;
+                    *(uint4*)(slab + i * PF_ROWB + (SlabSwizzle(PF_ROWB / 16).slot(n >> 3, i) << 4)) = o;
                 }
             }
         }
