@@ -195,6 +195,15 @@ int fs2_op_predictor(int32_t dtype, const void* x, const void* w, const float* b
                      const float* ln_b, const float* head_w, float head_b, const uint8_t* mask, float* pred,
                      void* packed_scratch, int32_t B, int32_t S, int32_t H, int32_t nlayers, int32_t taps,
                      void* hip_stream);
+/* FastSpeech2Loss.get_loss for "l1" / "mse" (litfass/fastspeech2/loss.py:57-81, called from forward :83-213):
+ * out2[0] = mean over the rows whose pad_mask is 0 of |pred - truth| (kind 0) or (pred - truth)^2 (kind 1),
+ * out2[1] = number of selected elements; pred = (rows, inner) fp32; truth_kind 0: fp32 (rows, inner),
+ * 1: int64 target durations compared as log(d + 1) (loss.py:176); ws = fs2_op_masked_loss_ws_bytes() device
+ * bytes, zero-filled once by the caller and reusable across calls on one stream.  Deterministic (fp64
+ * partials added in a fixed order, no float atomics).  All device pointers. */
+size_t fs2_op_masked_loss_ws_bytes(void);
+int fs2_op_masked_loss(const float* pred, const void* truth, int32_t truth_kind, const uint8_t* pad_mask, int64_t rows,
+                       int32_t inner, int32_t kind, void* ws, float* out2, void* hip_stream);
 /* dtype conversion helpers for tests: fp32 <-> engine dtype, n elements, device pointers */
 int fs2_op_convert(int32_t src_dtype, int32_t dst_dtype, const void* src, void* dst, size_t n, void* hip_stream);
 

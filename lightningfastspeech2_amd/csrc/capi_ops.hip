@@ -55,6 +55,18 @@ int fs2_op_predictor(int32_t dtype, const void* x, const void* w, const float* b
     return launch_predictor_fused(a, (hipStream_t)stream);
 }
 
+size_t fs2_op_masked_loss_ws_bytes(void) { return fs2::masked_loss_ws_bytes(); }
+
+int fs2_op_masked_loss(const float* pred, const void* truth, int32_t truth_kind, const uint8_t* pad_mask, int64_t rows,
+                       int32_t inner, int32_t kind, void* ws, float* out2, void* stream) {
+    if (!pred || !truth || !pad_mask || !ws || !out2) return FS2_ERR_ARG;
+    if ((kind != 0 && kind != 1) || (truth_kind != 0 && truth_kind != 1)) return FS2_ERR_ARG;
+    fs2::LossArgs a;
+    a.pred = pred; a.truth = truth; a.mask = pad_mask; a.ws = ws; a.out = out2;
+    a.rows = rows; a.inner = inner; a.kind = kind; a.truth_kind = truth_kind;
+    return fs2::launch_masked_loss(a, (hipStream_t)stream);
+}
+
 int fs2_op_set_vocoder_fused_resblock(int32_t on) {
     fs2::g_voc_fused_resblock = on;
     return FS2_OK;

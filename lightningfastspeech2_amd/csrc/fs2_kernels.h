@@ -103,6 +103,17 @@ struct VocResblockArgs {
     int accumulate;
 };
 extern int g_voc_fused_resblock;  // 1 = use the fused kernel where it applies
+struct LossArgs {
+    const float* pred;   // (rows, inner) fp32
+    const void* truth;   // truth_kind 0: fp32 (rows, inner); 1: int64 durations, compared as log(d + 1)
+    const uint8_t* mask; // (rows) 1 = pad (excluded)
+    void* ws;            // masked_loss_ws_bytes() bytes, zeroed once by the caller
+    float* out;          // [mean over the selected elements, number of selected elements]
+    int64_t rows;
+    int inner, kind, truth_kind;  // kind 0 = l1, 1 = mse
+};
+size_t masked_loss_ws_bytes();
+int launch_masked_loss(const LossArgs& a, hipStream_t stream);
 int voc_resblock_mi16(const VocResblockArgs& a, int dtype);  // 0 = shape not covered
 int launch_vocoder_resblock(const VocResblockArgs& a, int dtype, hipStream_t stream);
 extern int g_voc_lds_limit;  // KiB cap on a conv workgroup's slab; 0 = heuristic

@@ -35,7 +35,7 @@ __device__ inline float lrelu(float v, float slope) { return fmaxf(v, v * slope)
 template <typename T, int MI16, int CP>
 __global__ __launch_bounds__(512) void vocoder_conv_kernel(VocConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char slab[];
-    constexpr int KE = VocT<T>::KE, HF = MI16 / 2, RW = MI16 * 16;
+    constexpr int KE = VocT<T>::KE, RW = MI16 * 16;
     constexpr int E16 = 16 / (int)sizeof(T);  // elements per 16-byte piece
 
     const int tid = threadIdx.x, lane = tid & 63;

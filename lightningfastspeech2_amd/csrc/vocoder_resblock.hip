@@ -38,7 +38,7 @@ __device__ inline float rb_lrelu(float v, float slope) { return fmaxf(v, v * slo
 template <typename T, int MI16, int CH, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void vocoder_resblock_kernel(VocResblockArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    constexpr int KE = RbT<T>::KE, HF = MI16 / 2, RW = MI16 * 16;
+    constexpr int KE = RbT<T>::KE, RW = MI16 * 16;
     constexpr int E16 = 16 / (int)sizeof(T), SPL = 8 / E16;  // slots per lane per row (8 channels)
 
     const int tid = threadIdx.x, lane = tid & 63;

@@ -1,0 +1,91 @@
+"""Host mirror of the reference's ``FastSpeech2Loss`` (litfass/fastspeech2/loss.py:8-213), forward only:
+what ``validation_step`` evaluates after the teacher-forced forward (fastspeech2.py:800-802:
+``result = self(batch); losses = self.loss(result, batch)``).
+
+Same constructor arguments, same ``forward(result, target)`` contract and key names
+(``{variance..., "mel", "duration", "total"}``), values as 0-dim device tensors.  Every term is one
+launch of the masked-mean HIP kernel behind ``fs2_op_masked_loss`` (csrc/loss.hip); there is no CPU or
+torch fallback - without the HIP library the constructor raises.  Covered: frame-level variances with
+transform "none", losses "l1" / "mse", deterministic durations (the shipped recipe,
+scripts/train.sh:30).  Not covered and rejected loudly: "soft_dtw", the CWT pitch head, FastDiff terms,
+stochastic durations, and backward (SURVEY §8 f4's second half).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib
+
+_KIND = {"l1": 0, "mse": 1}
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class FastSpeech2Loss:
+    def __init__(self, variances=("energy", "pitch", "snr"), variance_levels=("frame", "frame", "frame"),
+                 variance_transforms=("none", "none", "none"), variance_losses=("mse", "mse", "mse"),
+                 mel_loss="l1", duration_loss="mse", duration_stochastic=False, max_length=4096,
+                 loss_alphas=None, soft_dtw_gamma=0.01, soft_dtw_chunk_size=256, fastdiff_loss=None,
+                 fastdiff_variances=False):
+        self.variances: List[str] = list(variances)
+        self.variance_levels = list(variance_levels)
+        self.variance_transforms = list(variance_transforms)
+        self.variance_losses = list(variance_losses)
+        self.mel_loss, self.duration_loss, self.max_length = mel_loss, duration_loss, max_length
+        self.loss_alphas: Dict[str, float] = dict(loss_alphas) if loss_alphas is not None else {
+            "mel": 1.0, "pitch": 1e-1, "energy": 1e-1, "snr": 1e-1, "duration": 1e-4, "fastdiff": 1e-1, "speakers": 1}
+        for what, ok in (("variance level", all(l == "frame" for l in self.variance_levels)),
+                         ("variance transform", all(t == "none" for t in self.variance_transforms)),
+                         ("loss kind", all(k in _KIND for k in self.variance_losses + [mel_loss, duration_loss])),
+                         ("stochastic durations", not duration_stochastic),
+                         ("FastDiff terms", fastdiff_loss is None and not fastdiff_variances)):
+            if not ok:
+                raise NotImplementedError(f"FastSpeech2Loss: this {what} configuration is outside the built path "
+                                          "(frame-level 'none' variances, 'l1'/'mse', deterministic durations)")
+        self.lib = _lib.load()  # raises if the HIP library is missing
+        self._ws: Dict[torch.device, torch.Tensor] = {}
+
+    def _masked_mean(self, pred: torch.Tensor, truth: torch.Tensor, truth_kind: int, pad_mask: torch.Tensor,
+                     inner: int, kind: str) -> torch.Tensor:
+        dev = pred.device
+        if dev.type != "cuda":
+            raise RuntimeError("FastSpeech2Loss runs on the GPU the forward ran on (no CPU path)")
+        if dev not in self._ws:
+            self._ws[dev] = torch.zeros(int(self.lib.fs2_op_masked_loss_ws_bytes()), dtype=torch.uint8, device=dev)
+        pred = pred.to(torch.float32).contiguous()
+        truth = truth.to(device=dev).contiguous()
+        truth = truth.to(torch.float32) if truth_kind == 0 else truth.to(torch.int64)
+        mask = pad_mask.to(device=dev, dtype=torch.uint8).contiguous()
+        rows = mask.numel()
+        if pred.numel() != rows * inner or truth.numel() != rows * inner:
+            raise ValueError(f"shape mismatch: pred {tuple(pred.shape)}, truth {tuple(truth.shape)}, mask {tuple(mask.shape)}")
+        out = torch.empty(2, dtype=torch.float32, device=dev)
+        st = self.lib.fs2_op_masked_loss(_ptr(pred), _ptr(truth), truth_kind, _ptr(mask), rows, inner, _KIND[kind],
+                                         _ptr(self._ws[dev]), _ptr(out), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        _lib.check(st, None, "fs2_op_masked_loss")
+        return out[0]
+
+    def __call__(self, result, target, frozen_components=()):
+        return self.forward(result, target, frozen_components)
+
+    def forward(self, result: dict, target: dict, frozen_components=()) -> dict:
+        losses = {}
+        tgt_pad, src_pad = result["tgt_mask"], result["src_mask"]  # True = pad (loss.py:96-97 inverts them)
+        if self.max_length is not None:
+            if target["mel"].shape[1] > self.max_length:
+                raise AssertionError("target mel longer than max_length (loss.py:101)")
+            for var, kind in zip(self.variances, self.variance_losses):
+                tgt = target[f"variances_{var}"][:, :int(self.max_length)]
+                losses[var] = self._masked_mean(result[f"variances_{var}"], tgt, 0, tgt_pad, 1, kind)
+        n_mels = result["mel"].shape[-1]
+        losses["mel"] = self._masked_mean(result["mel"], target["mel"], 0, tgt_pad, n_mels, self.mel_loss)
+        losses["duration"] = self._masked_mean(result["duration_prediction"], target["duration"], 1, src_pad, 1,
+                                               self.duration_loss)
+        total = sum(v * self.loss_alphas[k] for k, v in losses.items() if not any(f in k for f in frozen_components))
+        losses["total"] = total
+        return losses
