@@ -34,6 +34,8 @@ extern "C" int fs2_dbg_rb_stamps(unsigned long long* host) {
 }
 namespace fs2 {
 int g_voc_fused_resblock = 1;''')
+rb=rep(rb,'dim3(NW * 64), smem, stream,','dim3(NW * 64), smem + (NW == 4 ? SOLO_PAD : 0), stream,')
+rb=rb.replace('namespace fs2 {\n__device__ unsigned long long g_rb_stamps','#ifndef SOLO_PAD\n#define SOLO_PAD 0  // -DSOLO_PAD=24576: one 4-wave workgroup per CU (solo K-loop rate)\n#endif\nnamespace fs2 {\n__device__ unsigned long long g_rb_stamps',1)
 open('/tmp/fs2_stamp/vocoder_resblock.hip','w').write(rb)
 cv=open(R+'vocoder_conv.hip').read()
 cv=rep(cv,"namespace fs2 {\n\nnamespace {\n\ntemplate <typename T> struct VocT;",'''namespace fs2 {
