@@ -13,7 +13,8 @@
 // fp32->bf16, LeakyReLU), the weights stream from L2 straight into MFMA fragments (packed in
 // fragment order at finalize; 4-deep register ring) and the K loop has no barrier.  Channel counts
 // halve per stage while the sample count grows, so WM x WN goes 1x8 (256 ch) -> 2x4 -> 4x2 -> 8x1
-// (32 ch) with the SAME per-wave work and an almost constant 112 KiB slab.
+// (32 ch) with the SAME per-wave work; the slab is capped (voc_pick_mi16) so that two workgroups share a CU
+// where the layer allows.  The narrow stages' resblocks run through vocoder_resblock.hip instead.
 #include "fs2_common.h"
 #include "fs2_kernels.h"
 

@@ -1,20 +1,20 @@
-// One whole HiFi-GAN ResBlock "1" (reference: litfass/third_party/hifigan/models.py:98-104) per launch
-// for the narrow stages (32 / 64 channels):
+// HiFi-GAN ResBlock "1" (reference: litfass/third_party/hifigan/models.py:98-104) on LDS-resident tiles:
 //     for (c1, c2, d) in pairs:  x = c2(lrelu(c1_d(lrelu(x)))) + x
-// As six separate convs these stages move ~2 GB of activations per conv for a few GFLOP each and sit
-// on HBM / launch latency.  Here a workgroup keeps its tile of the residual stream AND
-// of the intermediate in LDS for all six convs (the single-launch predictor's scheme,
-// predictor_fused.hip):
+// one (c1, c2) pair per launch, or all three pairs of a block where the convs' K loops are short
+// (voc_resblock_mi16), for the 32 / 64 / 128-channel stages.  Conv by conv these stages move ~2 GB of
+// activations per conv for a few GFLOP each and sit on HBM / launch latency.  Here a
+// workgroup keeps its tile of the residual stream AND of the intermediate in LDS (the single-launch
+// predictor's scheme, predictor_fused.hip):
 //   slab X = lrelu(x) of the tile (+ guard rows), slab Y = lrelu(c1 output); both hold the
 //   ACTIVATED values because that is what the next conv multiplies; the raw residual is recovered
 //   from X by the inverse map (a < 0 ? a / slope : a) in the epilogue of c2, which then overwrites
 //   its own elements of X in place.  Rows outside the utterance are written as zeros after every
 //   conv (the reference pads every conv of a single unpadded utterance with zeros).
-//   Weights of the six convs lie back to back in fragment order; one 4-deep register ring streams
+//   Weights of the convs lie back to back in fragment order; one 4-deep register ring streams
 //   them from L2 across conv boundaries; no barrier inside a K loop, two per conv pair.
 // Every conv but the first (whose guard rows hold real samples) makes (k-1)/2 * dil more rows at both tile
-// edges stale, so a tile of R rows finishes R - 2H rows, H = (k-1)/2 * (sum over pairs of (d + 1) - d_first);
-// tiles overlap by that halo.
+// edges stale, so a tile of R rows finishes R - 2H rows, H = (k-1)/2 * (sum over pairs of (d + 1) - d_first)
+// - for a single pair just the (k-1)/2 rows of its c2; tiles overlap by that halo.
 #include "fs2_common.h"
 #include "fs2_kernels.h"
 
