@@ -106,6 +106,10 @@ struct SlabSwizzle {
     __device__ inline int slot(int L, int row) const {
         return (L & ~nbm) | ((L & 1) * half) | ((((L & nbm) >> 1) ^ (row >> sh)) & (half - 1));
     }
+    // the logical slot stored at physical slot ps of `row` (for LDS-DMA fills, which write lane l at l * 16)
+    __device__ inline int logical(int ps, int row) const {
+        return (ps & ~nbm) | ((((ps & (half - 1)) ^ ((row >> sh) & (half - 1))) << 1) | ((ps & half) ? 1 : 0));
+    }
 };
 
 // Sum over the four lanes {l, l^16, l^32, l^48} (the four 16-lane groups that share an MFMA column)

@@ -101,6 +101,8 @@ struct VocResblockArgs {
     int dil[3];             // dilation of c1 of each pair (c2 is undilated)
     float slope, scale;
     int accumulate;
+    int x_act = 0;          // x already holds lrelu(x) (written by a launch with out_act): the fill is a plain LDS-DMA copy
+    int out_act = 0;        // store lrelu(result) for such a consumer (pairs inside a block; never with accumulate)
 };
 extern int g_voc_fused_resblock;  // 1 = use the fused kernel where it applies
 struct LossArgs {

@@ -390,6 +390,13 @@ int fs2_voc_synthesize(fs2_vocoder* v, const float* mel, const int32_t* lengths,
                 // else pair by pair: a (c1, c2) pair on an LDS-resident tile where it fits and pays,
                 // two plain convs otherwise
                 const void* rin = u;
+                bool resident[3];
+                for (int m = 0; m < 3; ++m) {
+                    VocResblockArgs pa = ra;
+                    pa.npairs = 1;
+                    pa.dil[0] = c.rb_dilations[j][m];
+                    resident[m] = voc_resblock_mi16(pa, v->dt) != 0;
+                }
                 for (int m = 0; m < 3; ++m) {
                     void* o = m == 0 ? r1 : (m == 1 ? r2 : v->stage_out[i + 1]);
                     VocResblockArgs pa = ra;
@@ -400,7 +407,11 @@ int fs2_voc_synthesize(fs2_vocoder* v, const float* mel, const int32_t* lengths,
                     pa.w = (const char*)f.w + f.conv_bytes * 2 * m;
                     pa.bias = f.b + (size_t)2 * m * ra.C;
                     if (m < 2) { pa.scale = 1.f; pa.accumulate = 0; }
-                    if (voc_resblock_mi16(pa, v->dt)) {
+                    // between two resident pairs the residual stream travels as lrelu(x): the consumer's slab fill is
+                    // then a plain LDS-DMA copy and it recovers x by the inverse map it applies anyway
+                    pa.x_act = m > 0 && resident[m - 1] && resident[m] && g_voc_fused_resblock != 9;
+                    pa.out_act = m < 2 && resident[m] && resident[m + 1] && g_voc_fused_resblock != 9;
+                    if (resident[m]) {
                         const int rr = launch_vocoder_resblock(pa, v->dt, st);
                         if (rr != FS2_OK) return vfail(v, rr, "fused conv pair launch failed (C=%d k=%d)", ra.C, ra.taps);
                     } else {

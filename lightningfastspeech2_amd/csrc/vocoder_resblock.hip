@@ -72,11 +72,27 @@ __global__ __launch_bounds__(NW * 64, 2) void vocoder_resblock_kernel(VocResbloc
 
     // ---- X <- lrelu(x) for every slab row (guards included), zeros outside the utterance; Y guards <- 0
     {
-        // FB pieces per thread per trip, every load unconditional (clamped row, zeroed afterwards): one
-        // memory round trip per trip
         const T* xb = (const T*)p.x + (size_t)ub * p.S * C;
         const int pieces = srows * ns;
         constexpr int ns_sh = ns == 4 ? 2 : (ns == 8 ? 3 : (ns == 16 ? 4 : (ns == 32 ? 5 : 6)));
+        if (p.x_act) {
+#if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins exist in the device pass only
+            // the producer stored lrelu(x): straight global -> LDS DMA, 1 KiB (64 pieces) per wave instruction, no
+            // VGPRs and no VALU; lane l of chunk k lands at physical piece k*64 + l, so it FETCHES the logical slot
+            // that the swizzle keeps there; rows outside the utterance are out of the buffer's range -> zeros.
+            // (A last partial chunk spills zeros into Y's leading guard rows, which are zero anyway.)
+            const __amdgpu_buffer_rsrc_t xrs =
+                __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (unsigned)((size_t)len * rowb), 0x00020000);
+            for (int k = wave; k * 64 < pieces; k += NW) {
+                const int P = k * 64 + lane, i = P >> ns_sh, ps = P & (ns - 1), t = tbase - G + i;
+                const unsigned voff = (P < pieces && t >= 0 && t < len) ? (unsigned)(t * rowb + (swz.logical(ps, i) << 4)) : 0xFFFFF000u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(slabX + k * 1024), 16, voff, 0,
+                                                         0, 0);
+            }
+#endif
+        } else {
+        // FB pieces per thread per trip, every load unconditional (clamped row, zeroed afterwards): one
+        // memory round trip per trip
         constexpr int FB = 12;  // one trip covers a 4-wave tile
         for (int q0 = tid; q0 < pieces; q0 += NT * FB) {
             uint4 raw[FB];
@@ -99,6 +115,7 @@ __global__ __launch_bounds__(NW * 64, 2) void vocoder_resblock_kernel(VocResbloc
                 for (int e = 0; e < E16; ++e) f[e] = rb_lrelu(f[e], p.slope);
                 *(uint4*)(slabX + dst[u]) = Vec16<T>::pack(f);
             }
+        }
         }
         const int gp = 2 * GY * ns;
         for (int q = tid; q < gp; q += NT) {
@@ -129,6 +146,8 @@ __global__ __launch_bounds__(NW * 64, 2) void vocoder_resblock_kernel(VocResbloc
     constexpr int nkc_shift = nkc == 1 ? 0 : (nkc == 2 ? 1 : (nkc == 4 ? 2 : (nkc == 8 ? 3 : 4)));
     const int n0 = wn * 32 + fg * 8;  // this lane's 8 consecutive channels
     const float inv_slope = 1.0f / p.slope;
+    const float oslope = p.out_act ? p.slope : 1.0f;  // max(v, 1 * v) == v: no branch in the store loop
+    if (p.x_act) dma_drain();  // this wave's slab DMAs have landed before the barrier publishes them
     __syncthreads();
 
 #pragma unroll 1
@@ -237,6 +256,8 @@ __global__ __launch_bounds__(NW * 64, 2) void vocoder_resblock_kernel(VocResbloc
                 T* dst = (T*)p.out + ((size_t)ub * p.S + t) * C + n0;
 #pragma unroll
                 for (int r = 0; r < 8; ++r) v[r] *= p.scale;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] = rb_lrelu(v[r], oslope);  // out_act: the next pair reads it with x_act
                 if (p.accumulate) {
                     float ov[8];
 #pragma unroll

@@ -25,7 +25,7 @@ rb=rep(rb,"    const int tbase = t0 - H;  // time of tile row 0; slab index i <-
     STAMP_AT(0);
     if (st_ptr) st_ptr[15] = wall_clock64();
 ''')
-rb=rep(rb,"    const float inv_slope = 1.0f / p.slope;\n    __syncthreads();\n","    const float inv_slope = 1.0f / p.slope;\n    __syncthreads();\n    STAMP_AT(1);\n")
+rb=rep(rb,"    if (p.x_act) dma_drain();  // this wave's slab DMAs have landed before the barrier publishes them\n    __syncthreads();\n","    if (p.x_act) dma_drain();\n    __syncthreads();\n    STAMP_AT(1);\n")
 rb=rep(rb,"        // ---- epilogue: lane = rows (m*16 + fr), channels n0 .. n0+7 ----\n","        STAMP_AT(2 + 2 * j);\n        if (st_w && j == 0) *st_w = __builtin_amdgcn_s_memtime();\n        // ---- epilogue: lane = rows (m*16 + fr), channels n0 .. n0+7 ----\n")
 rb=rep(rb,"        if (!last) __syncthreads();\n    }\n}","        if (!last) __syncthreads();\n        STAMP_AT(3 + 2 * j);\n    }\n    if (st_ptr) st_ptr[14] = wall_clock64();\n}")
 rb=rep(rb,"int g_voc_fused_resblock = 1;",'''}  // namespace fs2
