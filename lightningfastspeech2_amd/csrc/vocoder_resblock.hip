@@ -103,7 +103,7 @@ __global__ __launch_bounds__(NW * 64, 2) void vocoder_resblock_kernel(VocResbloc
                 const int i = qq >> ns_sh, s = qq & (ns - 1), t = tbase - G + i;
                 const int tc = t < 0 ? 0 : (t < len ? t : len - 1);
                 dst[u] = q < pieces ? slot_off(i, s) : -1;
-                raw[u] = *(const uint4*)(xb + (size_t)tc * C + s * E16);
+                raw[u] = *(const uint4*)((const char*)xb + (unsigned)(tc * rowb + (s << 4)));  // uniform base + 32-bit offset
                 if (t < 0 || t >= len) raw[u] = make_uint4(0u, 0u, 0u, 0u);
             }
 #pragma unroll
@@ -146,6 +146,10 @@ __global__ __launch_bounds__(NW * 64, 2) void vocoder_resblock_kernel(VocResbloc
     constexpr int nkc_shift = nkc == 1 ? 0 : (nkc == 2 ? 1 : (nkc == 4 ? 2 : (nkc == 8 ? 3 : 4)));
     const int n0 = wn * 32 + fg * 8;  // this lane's 8 consecutive channels
     const float inv_slope = 1.0f / p.slope;
+    // output rows are addressed as a workgroup-uniform 64-bit base + a 32-bit per-lane byte offset (an utterance
+    // is < 4 GiB): per-row 64-bit pointer arithmetic was ~100 VALU instructions per conv
+    char* ob = (char*)p.out + (size_t)ub * p.S * rowb;
+    const unsigned nb = (unsigned)n0 * (unsigned)sizeof(T);
     const float oslope = p.out_act ? p.slope : 1.0f;  // max(v, 1 * v) == v: no branch in the store loop
     if (p.x_act) dma_drain();  // this wave's slab DMAs have landed before the barrier publishes them
     __syncthreads();
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(NW * 64, 2) void vocoder_resblock_kernel(VocResbloc
 #pragma unroll
                 for (int mm = 0; mm < MC; ++mm) {
                     const int tt = tbase + wrow0 + (m + mm) * 16 + fr, tc = tt < 0 ? 0 : (tt < len ? tt : len - 1);
-                    const uint4* src = (const uint4*)((const T*)p.out + ((size_t)ub * p.S + tc) * C + n0);
+                    const uint4* src = (const uint4*)(ob + (unsigned)(tc * rowb) + nb);
 #pragma unroll
                     for (int q = 0; q < SPL; ++q) oo[mm][q] = src[q];
                 }
@@ -249,11 +253,11 @@ __global__ __launch_bounds__(NW * 64, 2) void vocoder_resblock_kernel(VocResbloc
                 unsigned char* dstb = second ? slabX : slabY;
                 const int id = second ? i : iy;
 #pragma unroll
-                for (int r = 0; r < 8; ++r) v[r] = inside ? rb_lrelu(v[r], p.slope) : 0.f;
+                for (int r = 0; r < 8; ++r) v[r] = rb_lrelu(v[r], p.slope);
 #pragma unroll
                 for (int q = 0; q < SPL; ++q) *(uint4*)(dstb + slot_off(id, n0 / E16 + q)) = Vec16<T>::pack(v + q * E16);
             } else if (inside && row >= H && row < H + V) {
-                T* dst = (T*)p.out + ((size_t)ub * p.S + t) * C + n0;
+                uint4* dst = (uint4*)(ob + (unsigned)(t * rowb) + nb);
 #pragma unroll
                 for (int r = 0; r < 8; ++r) v[r] *= p.scale;
 #pragma unroll
@@ -266,10 +270,25 @@ __global__ __launch_bounds__(NW * 64, 2) void vocoder_resblock_kernel(VocResbloc
                     for (int r = 0; r < 8; ++r) v[r] += ov[r];
                 }
 #pragma unroll
-                for (int q = 0; q < SPL; ++q) *(uint4*)(dst + q * E16) = Vec16<T>::pack(v + q * E16);
+                for (int q = 0; q < SPL; ++q) dst[q] = Vec16<T>::pack(v + q * E16);
             }
         }
-        if (!last) __syncthreads();
+        if (!last) {
+            // rows outside the utterance are the next conv's zero padding: only a wave whose rows cross an utterance
+            // end re-zeroes them (a per-element select in the loop above cost 64 VALU instructions per conv)
+            if (tbase + wrow0 < 0 || tbase + wrow0 + RW > len) {
+                unsigned char* dstb = second ? slabX : slabY;
+#pragma unroll
+                for (int m = 0; m < MI16; ++m) {
+                    const int row = wrow0 + m * 16 + fr, t = tbase + row, id = (second ? G : GY) + row;
+                    if (t < 0 || t >= len) {
+#pragma unroll
+                        for (int q = 0; q < SPL; ++q) *(uint4*)(dstb + slot_off(id, n0 / E16 + q)) = make_uint4(0u, 0u, 0u, 0u);
+                    }
+                }
+            }
+            __syncthreads();
+        }
     }
 }
 
