@@ -87,6 +87,7 @@ struct VocConvArgs {
     int accumulate;         // += previous contents of out
     int in_fp32;
     int post;               // conv_post: one channel, tanh, fp32 out
+    float out_slope = 1.f;  // store LeakyReLU(result): every consumer is a resident resblock launch with x_act
 };
 // A whole ResBlock "1" (npairs = 3 (c1 dilated, c2) pairs) or one pair (npairs = 1) on an LDS-resident
 // tile, vocoder_resblock.hip.  out = (x after the pairs) * scale (+ previous contents).

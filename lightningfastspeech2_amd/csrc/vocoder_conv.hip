@@ -251,6 +251,10 @@ __global__ __launch_bounds__(512) void vocoder_conv_kernel(VocConvArgs p) {
 #pragma unroll
                 for (int r = 0; r < 8; ++r) v[r] += ov[r];
             }
+            if (p.out_slope != 1.f) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] = lrelu(v[r], p.out_slope);
+            }
             if (t < len) {
                 uint4* dst = (uint4*)((T*)p.out + (obase + t) * p.n + n0);
 #pragma unroll

@@ -194,8 +194,9 @@ int up_layer(fs2_vocoder* v, const std::string& name, int cin, int cout, int k, 
 
 int run_conv(fs2_vocoder* v, hipStream_t st, const VocLayer& L, const void* x, void* out, const void* res,
              const int32_t* lengths, int len_scale, int B, int S, float in_slope, float scale, bool accumulate,
-             bool in_fp32 = false, bool post = false) {
+             bool in_fp32 = false, bool post = false, float out_slope = 1.f) {
     VocConvArgs a;
+    a.out_slope = out_slope;
     a.x = x; a.w = L.w; a.bias = L.b; a.res = res; a.out = out; a.lengths = lengths; a.len_scale = len_scale;
     a.B = B; a.S = S; a.cin = L.cin; a.cin_pad = L.cin_pad; a.n = L.n; a.taps = L.taps; a.dil = L.dil; a.pad = L.pad;
     a.wn = L.wn; a.in_slope = in_slope; a.scale = scale; a.accumulate = accumulate ? 1 : 0;
@@ -372,8 +373,28 @@ int fs2_voc_synthesize(fs2_vocoder* v, const float* mel, const int32_t* lengths,
     const float inv = 1.0f / (float)c.n_kernels;
     for (int i = 0; i < ns; ++i) {
         // transposed conv, at the INPUT resolution, to up_rate * Cout phase-major channels
-        VCHK(run_conv(v, st, v->ups[i], v->stage_out[i], u, nullptr, lengths, v->upf[i], B, T * v->upf[i], 0.1f, 1.f, false));
         const int S = T * v->upf[i + 1], sc = v->upf[i + 1];
+        // when every resblock of this stage runs on LDS-resident tiles, the upsampled stream travels as lrelu(x):
+        // all its consumers then fill their slabs by plain LDS-DMA (x_act, vocoder_resblock.hip)
+        bool stage_act = g_voc_fused_resblock != 9;
+        for (int j = 0; j < c.n_kernels && stage_act; ++j) {
+            const fs2_vocoder::FusedRb& f = v->rb[(size_t)i * c.n_kernels + j];
+            if (!f.w) { stage_act = false; break; }
+            VocResblockArgs ra;
+            ra.x = u; ra.out = v->stage_out[i + 1]; ra.w = f.w; ra.bias = f.b; ra.lengths = lengths; ra.len_scale = sc;
+            ra.B = B; ra.S = S; ra.C = v->chan[i + 1]; ra.taps = c.rb_kernels[j]; ra.wn = ra.C / 32; ra.npairs = 3;
+            for (int m = 0; m < 3; ++m) ra.dil[m] = c.rb_dilations[j][m];
+            ra.slope = 0.1f; ra.scale = 1.f; ra.accumulate = 0;
+            if (voc_resblock_mi16(ra, v->dt)) continue;
+            for (int m = 0; m < 3 && stage_act; ++m) {
+                VocResblockArgs pa = ra;
+                pa.npairs = 1;
+                pa.dil[0] = c.rb_dilations[j][m];
+                if (!voc_resblock_mi16(pa, v->dt)) stage_act = false;
+            }
+        }
+        VCHK(run_conv(v, st, v->ups[i], v->stage_out[i], u, nullptr, lengths, v->upf[i], B, T * v->upf[i], 0.1f, 1.f, false, false,
+                      false, stage_act ? 0.1f : 1.f));
         for (int j = 0; j < c.n_kernels; ++j) {
             const fs2_vocoder::FusedRb& f = v->rb[(size_t)i * c.n_kernels + j];
             if (f.w) {
@@ -382,6 +403,7 @@ int fs2_voc_synthesize(fs2_vocoder* v, const float* mel, const int32_t* lengths,
                 ra.B = B; ra.S = S; ra.C = v->chan[i + 1]; ra.taps = c.rb_kernels[j]; ra.wn = ra.C / 32; ra.npairs = 3;
                 for (int m = 0; m < 3; ++m) ra.dil[m] = c.rb_dilations[j][m];
                 ra.slope = 0.1f; ra.scale = inv; ra.accumulate = j > 0 ? 1 : 0;
+                ra.x_act = stage_act ? 1 : 0;
                 if (voc_resblock_mi16(ra, v->dt)) {  // the whole block in one launch
                     const int rr = launch_vocoder_resblock(ra, v->dt, st);
                     if (rr != FS2_OK) return vfail(v, rr, "fused resblock launch failed (C=%d k=%d)", ra.C, ra.taps);
@@ -409,7 +431,7 @@ int fs2_voc_synthesize(fs2_vocoder* v, const float* mel, const int32_t* lengths,
                     if (m < 2) { pa.scale = 1.f; pa.accumulate = 0; }
                     // between two resident pairs the residual stream travels as lrelu(x): the consumer's slab fill is
                     // then a plain LDS-DMA copy and it recovers x by the inverse map it applies anyway
-                    pa.x_act = m > 0 && resident[m - 1] && resident[m] && g_voc_fused_resblock != 9;
+                    pa.x_act = (m == 0 ? stage_act : (resident[m - 1] && resident[m] && g_voc_fused_resblock != 9)) ? 1 : 0;
                     pa.out_act = m < 2 && resident[m] && resident[m + 1] && g_voc_fused_resblock != 9;
                     if (resident[m]) {
                         const int rr = launch_vocoder_resblock(pa, v->dt, st);
