@@ -35,7 +35,9 @@ __device__ inline float rb_lrelu(float v, float slope) { return fmaxf(v, v * slo
 // INDEPENDENT 4-wave workgroups (one wave per SIMD each) instead of eight lock-step waves: the issue arbiter
 // serves the oldest wave first, so of two waves of ONE workgroup on a SIMD the younger reaches every barrier
 // ~40 % late (measured with s_memtime stamps) while the older one idles there
-template <typename T, int MI16, int CH, int NW>
+// MID = a pair in the middle of a block (out_act: scale 1, nothing to add to, result stored activated) - its
+// store loop carries neither the scale multiply nor the previous-output path; !MID carries no output LeakyReLU
+template <typename T, int MI16, int CH, int NW, bool MID>
 __global__ __launch_bounds__(NW * 64, 2) void vocoder_resblock_kernel(VocResblockArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int KE = RbT<T>::KE, RW = MI16 * 16;
@@ -150,7 +152,6 @@ __global__ __launch_bounds__(NW * 64, 2) void vocoder_resblock_kernel(VocResbloc
     // is < 4 GiB): per-row 64-bit pointer arithmetic was ~100 VALU instructions per conv
     char* ob = (char*)p.out + (size_t)ub * p.S * rowb;
     const unsigned nb = (unsigned)n0 * (unsigned)sizeof(T);
-    const float oslope = p.out_act ? p.slope : 1.0f;  // max(v, 1 * v) == v: no branch in the store loop
     if (p.x_act) dma_drain();  // this wave's slab DMAs have landed before the barrier publishes them
     __syncthreads();
 
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(NW * 64, 2) void vocoder_resblock_kernel(VocResbloc
         uint4 oo[MC][SPL];
 #pragma unroll
         for (int m = 0; m < MI16; ++m) {
-            if (m % MC == 0 && last && p.accumulate) {
+            if (!MID && m % MC == 0 && last && p.accumulate) {
 #pragma unroll
                 for (int mm = 0; mm < MC; ++mm) {
                     const int tt = tbase + wrow0 + (m + mm) * 16 + fr, tc = tt < 0 ? 0 : (tt < len ? tt : len - 1);
@@ -258,11 +259,14 @@ __global__ __launch_bounds__(NW * 64, 2) void vocoder_resblock_kernel(VocResbloc
                 for (int q = 0; q < SPL; ++q) *(uint4*)(dstb + slot_off(id, n0 / E16 + q)) = Vec16<T>::pack(v + q * E16);
             } else if (inside && row >= H && row < H + V) {
                 uint4* dst = (uint4*)(ob + (unsigned)(t * rowb) + nb);
+                if constexpr (MID) {  // the next pair of this block reads it with x_act
 #pragma unroll
-                for (int r = 0; r < 8; ++r) v[r] *= p.scale;
+                    for (int r = 0; r < 8; ++r) v[r] = rb_lrelu(v[r], p.slope);
+                } else {
 #pragma unroll
-                for (int r = 0; r < 8; ++r) v[r] = rb_lrelu(v[r], oslope);  // out_act: the next pair reads it with x_act
-                if (p.accumulate) {
+                    for (int r = 0; r < 8; ++r) v[r] *= p.scale;
+                }
+                if (!MID && p.accumulate) {
                     float ov[8];
 #pragma unroll
                     for (int q = 0; q < SPL; ++q) Vec16<T>::unpack(oo[m % MC][q], ov + q * E16);
@@ -341,11 +345,11 @@ int voc_resblock_mi16(const VocResblockArgs& a, int dtype) {
     return 0;
 }
 
-template <typename T, int MI16, int CH, int NW>
+template <typename T, int MI16, int CH, int NW, bool MID>
 static int rb_launch_c(const VocResblockArgs& a, size_t smem, hipStream_t stream) {
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute((const void*)vocoder_resblock_kernel<T, MI16, CH, NW>,
+        if (hipFuncSetAttribute((const void*)vocoder_resblock_kernel<T, MI16, CH, NW, MID>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
             return FS2_ERR_HIP;
         attr = true;
@@ -354,16 +358,18 @@ static int rb_launch_c(const VocResblockArgs& a, size_t smem, hipStream_t stream
     rb_geom(a, NW, MI16, &R, &H, &G);
     const int V = R - 2 * H;
     const int tiles = (a.S + V - 1) / V;
-    hipLaunchKernelGGL((vocoder_resblock_kernel<T, MI16, CH, NW>), dim3((unsigned)(tiles * a.B)), dim3(NW * 64), smem, stream,
-                       a);
+    hipLaunchKernelGGL((vocoder_resblock_kernel<T, MI16, CH, NW, MID>), dim3((unsigned)(tiles * a.B)), dim3(NW * 64), smem,
+                       stream, a);
     return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
 }
 
 template <typename T, int MI16, int NW>
 static int rb_launch_t(const VocResblockArgs& a, size_t smem, hipStream_t stream) {
-    if (a.C == 32) return rb_launch_c<T, MI16, 32, NW>(a, smem, stream);
-    if (a.C == 64) return rb_launch_c<T, MI16, 64, NW>(a, smem, stream);
-    return rb_launch_c<T, MI16, 128, NW>(a, smem, stream);
+    const bool mid = a.out_act != 0;
+    if (mid && (a.npairs != 1 || a.scale != 1.f || a.accumulate)) return FS2_ERR_ARG;
+    if (a.C == 32) return mid ? rb_launch_c<T, MI16, 32, NW, true>(a, smem, stream) : rb_launch_c<T, MI16, 32, NW, false>(a, smem, stream);
+    if (a.C == 64) return mid ? rb_launch_c<T, MI16, 64, NW, true>(a, smem, stream) : rb_launch_c<T, MI16, 64, NW, false>(a, smem, stream);
+    return mid ? rb_launch_c<T, MI16, 128, NW, true>(a, smem, stream) : rb_launch_c<T, MI16, 128, NW, false>(a, smem, stream);
 }
 
 int launch_vocoder_resblock(const VocResblockArgs& a, int dtype, hipStream_t stream) {

@@ -7,7 +7,7 @@ for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
   rm -rf $OUT; FS2_LIB=$LIB timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT -o pmc -- python $GRAFT_REPO_ROOT/tools/bench_vocoder.py --no-cpu-baseline --steps 1 --warmup 1 > /dev/null 2>&1
   python3 - <<PY
 import csv, collections
-rows=[r for r in csv.DictReader(open("$OUT/pmc_counter_collection.csv")) if "resblock_kernel<fs2::bf16, 8, 128, 4>" in r["Kernel_Name"]]
+rows=[r for r in csv.DictReader(open("$OUT/pmc_counter_collection.csv")) if "resblock_kernel<fs2::bf16, 8, 128, 4, " in r["Kernel_Name"]]
 byd=collections.OrderedDict()
 for r in rows: byd.setdefault(r["Dispatch_Id"],{})[r["Counter_Name"]]=float(r["Counter_Value"])
 ds=list(byd.values())
