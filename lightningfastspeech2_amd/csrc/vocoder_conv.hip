@@ -81,10 +81,27 @@ __global__ __launch_bounds__(512) void vocoder_conv_kernel(VocConvArgs p) {
                 *(uint4*)(slab + i * rowb + (swz.slot(s, i) << 4)) = Vec16<T>::pack(f);
             }
         } else {
+            const T* xb = (const T*)p.x + ubase * p.cin;
+            if (p.in_slope == 1.f && p.cin == cin_pad) {
+#if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins exist in the device pass only
+                // nothing to apply while staging (the producer stored the activated values): straight global -> LDS
+                // DMA, 1 KiB per wave instruction; lane l of chunk k lands at physical piece k*64 + l, so it fetches
+                // the logical slot the swizzle keeps there; rows outside the utterance are out of the buffer's range
+                // -> zeros (the launcher rounds the slab up to whole chunks)
+                const __amdgpu_buffer_rsrc_t xrs =
+                    __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (unsigned)((size_t)len * rowb), 0x00020000);
+                for (int k = wave; k * 64 < pieces; k += 8) {
+                    const int P = k * 64 + lane, i = P >> ns_sh, ps = P & (ns - 1), t = t0 - p.pad + i;
+                    const unsigned voff = (P < pieces && t >= 0 && t < len) ? (unsigned)(t * rowb + (swz.logical(ps, i) << 4)) : 0xFFFFF000u;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(slab + k * 1024), 16, voff,
+                                                             0, 0, 0);
+                }
+                dma_drain();
+#endif
+            } else {
             // FB pieces per thread per trip, every load unconditional (clamped address, zeroed afterwards):
             // a trip costs ONE memory round trip, not one per piece behind its bounds branch
             constexpr int FB = 8;
-            const T* xb = (const T*)p.x + ubase * p.cin;
             for (int q0 = tid; q0 < pieces; q0 += 512 * FB) {
                 uint4 raw[FB];
                 int dst[FB];
@@ -110,6 +127,7 @@ __global__ __launch_bounds__(512) void vocoder_conv_kernel(VocConvArgs p) {
                     }
                     *(uint4*)(slab + dst[u]) = raw[u];
                 }
+            }
             }
         }
     }
@@ -277,7 +295,7 @@ static int voc_pick_mi16(const VocConvArgs& a, int esz, size_t* smem) {
     // 150 / 110 / 76 / 52 (110 = 128-row tiles at 256 channels, 256-row tiles x 2 workgroups at 128).
     const size_t limit = (size_t)(g_voc_lds_limit > 0 ? g_voc_lds_limit : 110) * 1024;
     for (int c = 0; c < 4; ++c) {
-        const size_t b = (size_t)(WM * cand[c] * 16 + (a.taps - 1) * a.dil) * a.cin_pad * esz;
+        const size_t b = ((size_t)(WM * cand[c] * 16 + (a.taps - 1) * a.dil) * a.cin_pad * esz + 1023) & ~(size_t)1023;  // whole DMA chunks
         if (b <= limit || (c == 3 && b <= 150 * 1024)) {
             *smem = b;
             return cand[c];

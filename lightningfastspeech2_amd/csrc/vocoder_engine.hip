@@ -438,8 +438,9 @@ int fs2_voc_synthesize(fs2_vocoder* v, const float* mel, const int32_t* lengths,
                         if (rr != FS2_OK) return vfail(v, rr, "fused conv pair launch failed (C=%d k=%d)", ra.C, ra.taps);
                     } else {
                         const size_t idx = ((size_t)i * c.n_kernels + j) * 3 + m;
-                        VCHK(run_conv(v, st, v->c1[idx], rin, a, nullptr, lengths, sc, B, S, 0.1f, 1.f, false));
-                        VCHK(run_conv(v, st, v->c2[idx], a, o, rin, lengths, sc, B, S, 0.1f, m < 2 ? 1.f : inv, m == 2 && j > 0));
+                        // c1 stores lrelu(out): c2 then stages it untouched (LDS-DMA fill in vocoder_conv.hip)
+                        VCHK(run_conv(v, st, v->c1[idx], rin, a, nullptr, lengths, sc, B, S, 0.1f, 1.f, false, false, false, 0.1f));
+                        VCHK(run_conv(v, st, v->c2[idx], a, o, rin, lengths, sc, B, S, 1.f, m < 2 ? 1.f : inv, m == 2 && j > 0));
                     }
                     rin = o;
                 }
@@ -448,13 +449,14 @@ int fs2_voc_synthesize(fs2_vocoder* v, const float* mel, const int32_t* lengths,
             const void* r = u;
             for (int m = 0; m < 3; ++m) {
                 const size_t idx = ((size_t)i * c.n_kernels + j) * 3 + m;
-                VCHK(run_conv(v, st, v->c1[idx], r, a, nullptr, lengths, sc, B, S, 0.1f, 1.f, false));
+                // c1 stores lrelu(out): c2 then stages it untouched (LDS-DMA fill in vocoder_conv.hip)
+                VCHK(run_conv(v, st, v->c1[idx], r, a, nullptr, lengths, sc, B, S, 0.1f, 1.f, false, false, false, 0.1f));
                 if (m < 2) {
                     void* o = m == 0 ? r1 : r2;
-                    VCHK(run_conv(v, st, v->c2[idx], a, o, r, lengths, sc, B, S, 0.1f, 1.f, false));
+                    VCHK(run_conv(v, st, v->c2[idx], a, o, r, lengths, sc, B, S, 1.f, 1.f, false));
                     r = o;
                 } else {  // last pair of the block: (xt + x) / n_kernels summed into the stage output
-                    VCHK(run_conv(v, st, v->c2[idx], a, v->stage_out[i + 1], r, lengths, sc, B, S, 0.1f, inv, j > 0));
+                    VCHK(run_conv(v, st, v->c2[idx], a, v->stage_out[i + 1], r, lengths, sc, B, S, 1.f, inv, j > 0));
                 }
             }
         }
