@@ -357,6 +357,7 @@ template <int MI> struct SlabCfg {
     static constexpr int SLAB_BYTES = SI * 8 * 1024;
 };
 static constexpr int S_BN = 256;
+template <bool B> struct BoolC { static constexpr bool value = B; };
 
 template <typename T, typename OutT, int MI, bool LN>
 __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
@@ -534,18 +535,33 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
         // LayerNorm(act(acc + bias) [+ res]) with two-pass statistics: lane partials -> lane-group
         // shuffles -> one LDS exchange between the four column waves; optional predictor head.
         const size_t rowbase = (size_t)ub * S;
+        // On a SIMD the epilogue's VALU instructions and the MFMA passes of the other resident wave mostly ADD UP
+        // (for the K = 256 launches this epilogue is as many issue cycles as the K loop), so the
+        // per-element selects that only matter for N < 256, for ReLU or for the predictor head are compiled out
+        // of the common case by workgroup-uniform dispatch - same arithmetic, same order, same results.
+        const bool full = p.N == S_BN;
+        {   // ReLU as max(v, lo) with lo = 0 / -inf: one instruction either way, no per-element select
+            const float lo = p.relu ? 0.f : -__builtin_inff();
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const int n = wn * 64 + wcol(ni, fg);
+            for (int ni = 0; ni < 4; ++ni) {
+                const int n = wn * 64 + wcol(ni, fg);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool nv = n + r < p.N;
-                const float bvv = (nv && p.bias) ? p.bias[n + r] : 0.f;
+                for (int r = 0; r < 4; ++r) {
+                    const float bvv = (p.bias && n + r < p.N) ? p.bias[n + r] : 0.f;
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) {
-                    float v = acc[ni][mi][r] + bvv;
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    acc[ni][mi][r] = nv ? v : 0.f;
+                    for (int mi = 0; mi < MI; ++mi) acc[ni][mi][r] = fmaxf(acc[ni][mi][r] + bvv, lo);
+                }
+            }
+            if (!full) {  // columns past N hold act(0 + 0): make them exact zeros for the row sums
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    const int n = wn * 64 + wcol(ni, fg);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n + r >= p.N) {
+#pragma unroll
+                            for (int mi = 0; mi < MI; ++mi) acc[ni][mi][r] = 0.f;
+                        }
                 }
             }
         }
@@ -604,21 +620,25 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
             mean[mi] = ((red[row] + red[BMs + row]) + (red[2 * BMs + row] + red[3 * BMs + row])) * invn;
         }
         __syncthreads();
+        auto sq_dev = [&](auto full_c) {
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            float q = 0.f;
+            for (int mi = 0; mi < MI; ++mi) {
+                float q = 0.f;
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                const int n = wn * 64 + wcol(ni, fg);
+                for (int ni = 0; ni < 4; ++ni) {
+                    const int n = wn * 64 + wcol(ni, fg);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float d = (n + r < p.N) ? acc[ni][mi][r] - mean[mi] : 0.f;
-                    q += d * d;
+                    for (int r = 0; r < 4; ++r) {
+                        const float d = (decltype(full_c)::value || n + r < p.N) ? acc[ni][mi][r] - mean[mi] : 0.f;
+                        q = __builtin_fmaf(d, d, q);  // explicit: an SLP-packed mul + add would round differently per variant
+                    }
                 }
+                q = group4_sum(q);
+                if (fg == 0) red[wn * BMs + wm * (MI * 16) + mi * 16 + fr] = q;
             }
-            q = group4_sum(q);
-            if (fg == 0) red[wn * BMs + wm * (MI * 16) + mi * 16 + fr] = q;
-        }
+        };
+        if (full) sq_dev(BoolC<true>{});
+        else sq_dev(BoolC<false>{});
         __syncthreads();
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
@@ -627,11 +647,9 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
             rstd[mi] = 1.0f / sqrtf(var + p.ln_eps);
         }
         OutT* __restrict__ Cn = p.C ? (OutT*)p.C + rowbase * p.ldc : nullptr;
-        float dsum[MI];
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const int t = t0 + wm * (MI * 16) + mi * 16 + fr;
-            dsum[mi] = 0.f;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int n = wn * 64 + j * 32 + fg * 8;  // 8 consecutive channels of fragments 2j, 2j+1
@@ -639,14 +657,9 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const float4 g4 = *(const float4*)(lnp + n + 4 * h), b4 = *(const float4*)(lnp + S_BN + n + 4 * h);
-                    const float4 w4 = *(const float4*)(lnp + 2 * S_BN + n + 4 * h);
                     const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
-                    const float ww[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        y[4 * h + r] = (acc[2 * j + h][mi][r] - mean[mi]) * rstd[mi] * gg[r] + bb[r];
-                        dsum[mi] += y[4 * h + r] * ww[r];
-                    }
+                    for (int r = 0; r < 4; ++r) y[4 * h + r] = __builtin_fmaf((acc[2 * j + h][mi][r] - mean[mi]) * rstd[mi], gg[r], bb[r]);
                 }
                 if (Cn && t < S && n < p.N) {
                     OutT* dst = Cn + (size_t)t * p.ldc + n;
@@ -665,7 +678,26 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
                 }
             }
         }
-        if (p.dot_w) {
+        if (p.dot_w) {  // predictor head (rare): the normalised values once more, times the head weights
+            float dsum[MI];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                dsum[mi] = 0.f;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int n = wn * 64 + j * 32 + fg * 8;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const float4 g4 = *(const float4*)(lnp + n + 4 * h), b4 = *(const float4*)(lnp + S_BN + n + 4 * h);
+                        const float4 w4 = *(const float4*)(lnp + 2 * S_BN + n + 4 * h);
+                        const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
+                        const float ww[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            dsum[mi] = __builtin_fmaf(__builtin_fmaf((acc[2 * j + h][mi][r] - mean[mi]) * rstd[mi], gg[r], bb[r]), ww[r], dsum[mi]);
+                    }
+                }
+            }
             __syncthreads();
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
@@ -698,6 +730,9 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) bv[j][r] = (p.bias && n + r < p.N) ? p.bias[n + r] : 0.f;
     }
+    // ReLU and the N-tail checks are compiled out of the common case by workgroup-uniform dispatch (see the
+    // LayerNorm epilogue above): at K = 256 this store loop is as many issue cycles as the K loop
+    auto store = [&](auto relu_c, auto full_c) {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int t = t0 + wm * (MI * 16) + mi * 16 + fr;
@@ -705,15 +740,15 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int n = n0 + wn * 64 + j * 32 + fg * 8;
-            if (n >= p.N) continue;
+            if (!decltype(full_c)::value && n >= p.N) continue;
             float v[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 v[r] = acc[2 * j + (r >> 2)][mi][r & 3] + bv[j][r];
-                if (p.relu) v[r] = fmaxf(v[r], 0.f);
+                if constexpr (decltype(relu_c)::value) v[r] = fmaxf(v[r], 0.f);
             }
             OutT* dst = C + (size_t)t * p.ldc + n;
-            if (n + 7 < p.N) {
+            if (decltype(full_c)::value || n + 7 < p.N) {
                 if constexpr (sizeof(OutT) == 4) {
                     *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
                     *(float4*)(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
@@ -726,6 +761,15 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
                 for (int r = 0; r < 8; ++r) if (n + r < p.N) dst[r] = Num<OutT>::from_f32(v[r]);
             }
         }
+    }
+    };
+    const bool fulln = n0 + S_BN <= p.N;  // this column tile lies wholly inside N
+    if (fulln) {
+        if (p.relu) store(BoolC<true>{}, BoolC<true>{});
+        else store(BoolC<false>{}, BoolC<true>{});
+    } else {
+        if (p.relu) store(BoolC<true>{}, BoolC<false>{});
+        else store(BoolC<false>{}, BoolC<false>{});
     }
 #else
     (void)p;

@@ -355,3 +355,32 @@ def test_speaker_projection():
     ref = torch.relu(dv @ w.T + b)
     got = G.spk_proj(dv, w, b)
     assert float((got - ref).abs().max()) <= 1e-5
+
+
+def test_slab_gemm_bits_do_not_depend_on_tile_height():
+    """The launcher picks the tile height (MI variant) from the row count; the same rows must give the same bits
+    through every variant - the forward's shard == whole property rests on it.  (A packed mul + add that the
+    compiler chose in ONE template instantiation of the LayerNorm epilogue broke this once: the fused
+    multiply-adds there are explicit now.)"""
+    torch.manual_seed(0)
+    S = 1536
+    for (K, N, taps, ln, relu, res) in ((256, 256, 1, True, False, True), (1024, 256, 1, True, False, True),
+                                        (256, 256, 3, True, True, False), (256, 1024, 9, False, True, False),
+                                        (256, 768, 1, False, False, False)):
+        x = torch.randn(32 * S, K)
+        w = torch.randn(N, K * taps) / (K * taps) ** 0.5
+        b, g, be, hw = torch.randn(N), torch.randn(N), torch.randn(N), torch.randn(N)
+        r = torch.randn(32 * S, N) if res else None
+        outs, preds = [], []
+        for nb in (32, 8, 1):
+            if ln:
+                y, pr = G.gemm_ln(G.BF16, x[:nb * S], w, b, None if r is None else r[:nb * S], g, be, taps=taps, S=S, relu=relu,
+                                     dot_w=hw, dot_b=0.3)
+                preds.append(pr[:S])
+            else:
+                y = G.gemm(G.BF16, x[:nb * S], w, b, taps=taps, S=S, relu=relu)
+            outs.append(y[:S])
+        for o in outs[1:]:
+            assert torch.equal(outs[0], o), (K, N, taps, ln, relu)
+        for q in preds[1:]:
+            assert torch.equal(preds[0], q), (K, N, taps, "head")
