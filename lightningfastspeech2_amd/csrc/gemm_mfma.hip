@@ -620,6 +620,12 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
             mean[mi] = ((red[row] + red[BMs + row]) + (red[2 * BMs + row] + red[3 * BMs + row])) * invn;
         }
         __syncthreads();
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)  // acc <- acc - mean once: the variance and the normalisation both use it
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[ni][mi][r] -= mean[mi];
         auto sq_dev = [&](auto full_c) {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
@@ -629,7 +635,7 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
                     const int n = wn * 64 + wcol(ni, fg);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float d = (decltype(full_c)::value || n + r < p.N) ? acc[ni][mi][r] - mean[mi] : 0.f;
+                        const float d = (decltype(full_c)::value || n + r < p.N) ? acc[ni][mi][r] : 0.f;
                         q = __builtin_fmaf(d, d, q);  // explicit: an SLP-packed mul + add would round differently per variant
                     }
                 }
@@ -659,7 +665,7 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
                     const float4 g4 = *(const float4*)(lnp + n + 4 * h), b4 = *(const float4*)(lnp + S_BN + n + 4 * h);
                     const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, bb[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) y[4 * h + r] = __builtin_fmaf((acc[2 * j + h][mi][r] - mean[mi]) * rstd[mi], gg[r], bb[r]);
+                    for (int r = 0; r < 4; ++r) y[4 * h + r] = __builtin_fmaf(acc[2 * j + h][mi][r] * rstd[mi], gg[r], bb[r]);
                 }
                 if (Cn && t < S && n < p.N) {
                     OutT* dst = Cn + (size_t)t * p.ldc + n;
@@ -694,7 +700,7 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
                         const float ww[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            dsum[mi] = __builtin_fmaf(__builtin_fmaf((acc[2 * j + h][mi][r] - mean[mi]) * rstd[mi], gg[r], bb[r]), ww[r], dsum[mi]);
+                            dsum[mi] = __builtin_fmaf(__builtin_fmaf(acc[2 * j + h][mi][r] * rstd[mi], gg[r], bb[r]), ww[r], dsum[mi]);
                     }
                 }
             }

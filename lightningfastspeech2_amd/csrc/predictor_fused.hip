@@ -178,7 +178,8 @@ __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(Predict
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float d = acc[ni][m][r] - mean[m];
-                    q += d * d;
+                    acc[ni][m][r] = d;  // kept: the normalisation below needs the same difference
+                    q = __builtin_fmaf(d, d, q);
                 }
             q = group4_sum(q);
             if (fg == 0) red[1][wv * R + row] = q;
@@ -217,10 +218,10 @@ __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(Predict
                 const int row = m * 16 + fr, t = t0 + row, i = row + 1;
                 float y[8];
 #pragma unroll
-                for (int r = 0; r < 8; ++r) y[r] = (acc[2 * j + (r >> 2)][m][r & 3] - mean[m]) * rstd[m] * gg[r] + ee[r];
+                for (int r = 0; r < 8; ++r) y[r] = __builtin_fmaf(acc[2 * j + (r >> 2)][m][r & 3] * rstd[m], gg[r], ee[r]);
                 if (last) {
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) dsum[m] += y[r] * hw[r];
+                    for (int r = 0; r < 8; ++r) dsum[m] = __builtin_fmaf(y[r], hw[r], dsum[m]);
                 } else {
                     // next layer's input, in place; rows outside the utterance stay the conv's zero padding
                     const bool inside = t >= 0 && t < S;
