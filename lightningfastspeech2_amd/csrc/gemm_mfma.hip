@@ -404,14 +404,14 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
         const int P = (i * 8 + wave) * 64 + lane, row = P >> 3, ps = P & 7;
         const int t = t0 - p.pad + row;
         const bool ok = (t >= 0) & (t < S) & (row < BMs + ntap - 1);
-        svoff[i] = ok ? (unsigned)((size_t)t * p.ldx * sizeof(T)) + (unsigned)((ps ^ (row & 7)) << 4) : OOB;
+        svoff[i] = ok ? (unsigned)t * (unsigned)(p.ldx * (int)sizeof(T)) + (unsigned)((ps ^ (row & 7)) << 4) : OOB;  // < 4 GiB (xbytes)
     }
     unsigned wvoff[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int P = (i * 8 + wave) * 64 + lane, row = P >> 3, ps = P & 7;
         const int n = n0 + row;
-        wvoff[i] = n < p.N ? (unsigned)((size_t)n * p.K * sizeof(T)) + (unsigned)((ps ^ wswz(row)) << 4) : OOB;
+        wvoff[i] = n < p.N ? (unsigned)n * (unsigned)(p.K * (int)sizeof(T)) + (unsigned)((ps ^ wswz(row)) << 4) : OOB;  // < 4 GiB (wbytes)
     }
     auto issue_slab = [&](unsigned char* dst, int cc) {
 #pragma unroll
@@ -753,7 +753,7 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
                 v[r] = acc[2 * j + (r >> 2)][mi][r & 3] + bv[j][r];
                 if constexpr (decltype(relu_c)::value) v[r] = fmaxf(v[r], 0.f);
             }
-            OutT* dst = C + (size_t)t * p.ldc + n;
+            OutT* dst = (OutT*)((char*)C + (unsigned)(t * p.ldc + n) * (unsigned)sizeof(OutT));  // one utterance < 4 GiB
             if (decltype(full_c)::value || n + 7 < p.N) {
                 if constexpr (sizeof(OutT) == 4) {
                     *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
