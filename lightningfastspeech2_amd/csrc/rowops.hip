@@ -112,11 +112,15 @@ int launch_layernorm(const LayerNormArgs& a, int dtype, hipStream_t stream) {
 // LightSpeech FFN (model.py:75-81) and module.0 of the depth-wise predictor layer
 // (model.py:545-551).  LDS-staged (TR + k - 1) x 64 slab, one output channel per lane.
 // =============================================================================================
-static constexpr int DW_TR = 64, DW_CT = 64, DW_KMAX = 31;
+static constexpr int DW_TR = 128, DW_CT = 64, DW_KMAX = 32, DW_RR = 8, DW_TC = 8;
 
-// Workgroup = 64 rows x 64 channels of one utterance.  The (64 + k - 1) x 64 input slab and the
-// (k x 64) weights are staged in LDS as fp32, channel-contiguous; a thread owns 4 rows x 4
-// channels and walks the taps with one 16-byte weight read + four 16-byte input reads per 16 MACs.
+// Workgroup = 128 rows x 64 channels of one utterance; a thread owns 8 consecutive rows x 4 channels.  The
+// (128 + k' - 1) x 64 input slab (k' = k rounded up to a multiple of 8; zeros outside the utterance) and the
+// k' x 64 weights (zeros past k) are staged in LDS as fp32.  Taps go in chunks of 8: the chunk's 8 x 4 weights sit
+// in registers and the thread walks the 15 input rows the chunk touches ONCE - one 16-byte LDS read feeds up
+// to 8 x 4 multiply-adds (input row o + j contributes tap c*8 + j to output row o).  The previous kernel read an
+// input row per output row per tap (5 LDS reads per 16 MACs) and sat on the LDS port at k = 17..25, 2.6x off
+// the HBM time of its 0.15 GB.  Per output the taps are still added in ascending order: bit-identical results.
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv_kernel(DwConvArgs p) {
     __shared__ __attribute__((aligned(16))) float tile[(DW_TR + DW_KMAX - 1) * DW_CT];
@@ -124,43 +128,71 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwConvArgs p) {
     const int tid = threadIdx.x;
     const int t0 = blockIdx.x * DW_TR, c0 = blockIdx.y * DW_CT, b = blockIdx.z;
     const T* x = (const T*)p.x + (size_t)b * p.S * p.C;
-    const int rows = DW_TR + p.k - 1;
+    const int nch = (p.k + DW_TC - 1) / DW_TC, kp = nch * DW_TC;
+    const int rows = DW_TR + kp - 1;
     const bool full_c = c0 + DW_CT <= p.C;
-    for (int i = tid; i < rows * (DW_CT / 4); i += 256) {  // 4 channels per load
-        const int r = i >> 4, cq = (i & 15) * 4;
-        const int t = t0 + r - p.pad;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (t >= 0 && t < p.S) {
-            if (full_c) {
-                load4<T>(x + (size_t)t * p.C + c0 + cq, v);
-            } else {
+    if (full_c) {
+        // every load of the slab is issued before the first is used (unconditional, clamped row, zeroed afterwards):
+        // ONE memory round trip for the fill instead of one per 256 pieces
+        constexpr int FB = ((DW_TR + DW_KMAX - 1) * (DW_CT / 4) + 255) / 256;
+        float v[FB][4];
+        const int npc = rows * (DW_CT / 4);
+#pragma unroll
+        for (int u = 0; u < FB; ++u) {
+            const int i = tid + u * 256, ii = i < npc ? i : npc - 1;
+            const int r = ii >> 4, cq = (ii & 15) * 4, t = t0 + r - p.pad;
+            const int tc = t < 0 ? 0 : (t < p.S ? t : p.S - 1);
+            load4<T>(x + (size_t)tc * p.C + c0 + cq, v[u]);
+            if (t < 0 || t >= p.S) v[u][0] = v[u][1] = v[u][2] = v[u][3] = 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < FB; ++u) {
+            const int i = tid + u * 256;
+            if (i < npc) *(float4*)(tile + (i >> 4) * DW_CT + (i & 15) * 4) = make_float4(v[u][0], v[u][1], v[u][2], v[u][3]);
+        }
+    } else {
+        for (int i = tid; i < rows * (DW_CT / 4); i += 256) {  // channel tail tile: element by element
+            const int r = i >> 4, cq = (i & 15) * 4;
+            const int t = t0 + r - p.pad;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (t >= 0 && t < p.S) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if (c0 + cq + e < p.C) v[e] = Num<T>::to_f32(x[(size_t)t * p.C + c0 + cq + e]);
             }
+            *(float4*)(tile + r * DW_CT + cq) = make_float4(v[0], v[1], v[2], v[3]);
         }
-        *(float4*)(tile + r * DW_CT + cq) = make_float4(v[0], v[1], v[2], v[3]);
     }
-    for (int i = tid; i < DW_CT * p.k; i += 256) {
+    for (int i = tid; i < DW_CT * kp; i += 256) {
         const int tap = i / DW_CT, c = i % DW_CT;
-        wl[tap * DW_CT + c] = (c0 + c < p.C) ? p.w[(size_t)(c0 + c) * p.k + tap] : 0.f;
+        wl[tap * DW_CT + c] = (tap < p.k && c0 + c < p.C) ? p.w[(size_t)(c0 + c) * p.k + tap] : 0.f;
     }
     __syncthreads();
-    const int cq = (tid & 15) * 4, r0 = (tid >> 4) * 4;
-    float acc[4][4];
+    const int cq = (tid & 15) * 4, r0 = (tid >> 4) * DW_RR;
+    float acc[DW_RR][4];
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr)
+    for (int o = 0; o < DW_RR; ++o)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[rr][e] = 0.f;
-    for (int tap = 0; tap < p.k; ++tap) {
-        const float4 w4 = *(const float4*)(wl + tap * DW_CT + cq);
+        for (int e = 0; e < 4; ++e) acc[o][e] = 0.f;
+#pragma unroll 1
+    for (int c = 0; c < nch; ++c) {
+        float4 w[DW_TC];
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-            const float4 x4 = *(const float4*)(tile + (r0 + rr + tap) * DW_CT + cq);
-            acc[rr][0] = fmaf(w4.x, x4.x, acc[rr][0]);
-            acc[rr][1] = fmaf(w4.y, x4.y, acc[rr][1]);
-            acc[rr][2] = fmaf(w4.z, x4.z, acc[rr][2]);
-            acc[rr][3] = fmaf(w4.w, x4.w, acc[rr][3]);
+        for (int j = 0; j < DW_TC; ++j) w[j] = *(const float4*)(wl + (c * DW_TC + j) * DW_CT + cq);
+        const float* trow = tile + (r0 + c * DW_TC) * DW_CT + cq;
+#pragma unroll
+        for (int rr = 0; rr < DW_RR + DW_TC - 1; ++rr) {
+            const float4 x4 = *(const float4*)(trow + rr * DW_CT);
+#pragma unroll
+            for (int o = 0; o < DW_RR; ++o) {
+                const int j = rr - o;  // compile-time after unrolling: tap c*8 + j of output row o
+                if (j >= 0 && j < DW_TC) {
+                    acc[o][0] = fmaf(w[j].x, x4.x, acc[o][0]);
+                    acc[o][1] = fmaf(w[j].y, x4.y, acc[o][1]);
+                    acc[o][2] = fmaf(w[j].z, x4.z, acc[o][2]);
+                    acc[o][3] = fmaf(w[j].w, x4.w, acc[o][3]);
+                }
+            }
         }
     }
     float bias[4];
@@ -168,18 +200,18 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwConvArgs p) {
     for (int e = 0; e < 4; ++e) bias[e] = (p.bias && c0 + cq + e < p.C) ? p.bias[c0 + cq + e] : 0.f;
     T* y = (T*)p.y + (size_t)b * p.S * p.C;
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-        const int t = t0 + r0 + rr;
+    for (int o = 0; o < DW_RR; ++o) {
+        const int t = t0 + r0 + o;
         if (t >= p.S) break;
-        float o[4];
+        float ov[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = acc[rr][e] + bias[e];
+        for (int e = 0; e < 4; ++e) ov[e] = acc[o][e] + bias[e];
         if (full_c) {
-            store4<T>(y + (size_t)t * p.C + c0 + cq, o);
+            store4<T>(y + (size_t)t * p.C + c0 + cq, ov);
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (c0 + cq + e < p.C) y[(size_t)t * p.C + c0 + cq + e] = Num<T>::from_f32(o[e]);
+                if (c0 + cq + e < p.C) y[(size_t)t * p.C + c0 + cq + e] = Num<T>::from_f32(ov[e]);
         }
     }
 }
