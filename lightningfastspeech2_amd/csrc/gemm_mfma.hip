@@ -398,32 +398,41 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
     const unsigned wbytes = (unsigned)((size_t)p.N * p.K * sizeof(T));
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)Xu, 0, xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, wbytes, 0x00020000);
-    unsigned svoff[SI];
+    // DMA duty is NOT shared evenly: only waves 0 .. DW-1 issue the operand DMAs (2x the pieces each).  The issue
+    // arbiter serves the oldest wave of a SIMD first, so waves 0-3 finish a step's MFMAs ~1000 cycles before
+    // waves 4-7 and idle at the barrier, while an LDS-DMA instruction costs its wave 100-150 issue cycles next to
+    // MFMAs (tools/probes/slab_stamps.py, step_shape_mfma.hip): the ~500 cycles of DMA issue per step belong on
+    // the waves that have the slack, off the critical ones.
+    constexpr int DW = 4, DSI = SI * 8 / DW, DWI = 32 / DW;
+    const bool dma_wave = wave < DW;
+    unsigned svoff[DSI];
 #pragma unroll
-    for (int i = 0; i < SI; ++i) {
-        const int P = (i * 8 + wave) * 64 + lane, row = P >> 3, ps = P & 7;
+    for (int i = 0; i < DSI; ++i) {
+        const int P = (i * DW + (wave & (DW - 1))) * 64 + lane, row = P >> 3, ps = P & 7;
         const int t = t0 - p.pad + row;
         const bool ok = (t >= 0) & (t < S) & (row < BMs + ntap - 1);
         svoff[i] = ok ? (unsigned)t * (unsigned)(p.ldx * (int)sizeof(T)) + (unsigned)((ps ^ (row & 7)) << 4) : OOB;  // < 4 GiB (xbytes)
     }
-    unsigned wvoff[4];
+    unsigned wvoff[DWI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int P = (i * 8 + wave) * 64 + lane, row = P >> 3, ps = P & 7;
+    for (int i = 0; i < DWI; ++i) {
+        const int P = (i * DW + (wave & (DW - 1))) * 64 + lane, row = P >> 3, ps = P & 7;
         const int n = n0 + row;
         wvoff[i] = n < p.N ? (unsigned)n * (unsigned)(p.K * (int)sizeof(T)) + (unsigned)((ps ^ wswz(row)) << 4) : OOB;  // < 4 GiB (wbytes)
     }
     auto issue_slab = [&](unsigned char* dst, int cc) {
+        if (!dma_wave) return;
 #pragma unroll
-        for (int i = 0; i < SI; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(dst + (i * 8 + wave) * 1024),
+        for (int i = 0; i < DSI; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(dst + (i * DW + wave) * 1024),
                                                      16, svoff[i], cc * ROWB, 0, 0);
     };
     auto issue_w = [&](unsigned char* dst, int cc, int tap) {
+        if (!dma_wave) return;
         const int koff = (tap * p.Cin + cc * KE) * (int)sizeof(T);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)(dst + (i * 8 + wave) * 1024),
+        for (int i = 0; i < DWI; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)(dst + (i * DW + wave) * 1024),
                                                      16, wvoff[i], koff, 0, 0);
     };
 
