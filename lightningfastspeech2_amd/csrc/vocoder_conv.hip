@@ -146,11 +146,23 @@ __global__ __launch_bounds__(512) void vocoder_conv_kernel(VocConvArgs p) {
     loadB(bw[1], 1);
     loadB(bw[2], 2);
 
+    // the bias rides in as the accumulators' initial value (lane: channels n0 .. n0+7 of every row): the zero
+    // fill costs the same moves and the epilogue loses an add per element (its VALU instructions and the MFMA
+    // passes add up on a SIMD: this kernel's pipe is 67 % busy with another 32 % of VALU issue beside it)
+    const int n0 = nt * WN * 32 + wn * 32 + fg * 8;
     f32x4_t acc[2][MI16];
+    {
+        float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+        if (!p.post && n0 < p.n) {
+            b0 = *(const float4*)(p.bias + n0);
+            b1 = *(const float4*)(p.bias + n0 + 4);
+        }
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < MI16; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < MI16; ++b) {
+            acc[0][b] = (f32x4_t){b0.x, b0.y, b0.z, b0.w};
+            acc[1][b] = (f32x4_t){b1.x, b1.y, b1.z, b1.w};
+        }
+    }
 
     __syncthreads();
 
@@ -199,7 +211,6 @@ __global__ __launch_bounds__(512) void vocoder_conv_kernel(VocConvArgs p) {
     }
 
     // ---- epilogue: lane = rows (m*16 + fr), 8 consecutive channels n0 .. n0+7 ----
-    const int n0 = nt * WN * 32 + wn * 32 + fg * 8;
     if (p.post) {
         // conv_post + tanh (models.py:160-162): a single output channel, fp32 samples
         if (n0 == 0) {
@@ -214,12 +225,11 @@ __global__ __launch_bounds__(512) void vocoder_conv_kernel(VocConvArgs p) {
         return;
     }
     if (n0 >= p.n) return;
-    float bb[8];
-    {
-        const float4 b0 = *(const float4*)(p.bias + n0), b1 = *(const float4*)(p.bias + n0 + 4);
-        bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
-    }
-    const size_t obase = (size_t)ub * p.S;
+    // rows are addressed as a workgroup-uniform 64-bit base + a 32-bit per-lane byte offset (one utterance < 4 GiB)
+    const size_t ubytes = (size_t)ub * p.S * p.n * sizeof(T);
+    const char* resb = (const char*)p.res + ubytes;
+    char* outb = (char*)p.out + ubytes;
+    const unsigned rown = (unsigned)p.n * (unsigned)sizeof(T), nb0 = (unsigned)n0 * (unsigned)sizeof(T);
     // residual / previous-output rows are fetched MC rows at a time BEFORE any of them is used or stored
     // (unconditional loads from clamped rows): one memory round trip per chunk instead of two per row
     constexpr int NP = 8 / E16;  // 16-byte pieces of a lane's 8 channels
@@ -231,7 +241,7 @@ __global__ __launch_bounds__(512) void vocoder_conv_kernel(VocConvArgs p) {
 #pragma unroll
             for (int mm = 0; mm < MC; ++mm) {
                 const int t = t0 + wrow0 + (m0 + mm) * 16 + fr, tc = t < len ? t : len - 1;
-                const uint4* src = (const uint4*)((const T*)p.res + (obase + tc) * p.n + n0);
+                const uint4* src = (const uint4*)(resb + ((unsigned)tc * rown + nb0));
 #pragma unroll
                 for (int q = 0; q < NP; ++q) rr[mm][q] = src[q];
             }
@@ -240,7 +250,7 @@ __global__ __launch_bounds__(512) void vocoder_conv_kernel(VocConvArgs p) {
 #pragma unroll
             for (int mm = 0; mm < MC; ++mm) {
                 const int t = t0 + wrow0 + (m0 + mm) * 16 + fr, tc = t < len ? t : len - 1;
-                const uint4* src = (const uint4*)((const T*)p.out + (obase + tc) * p.n + n0);
+                const uint4* src = (const uint4*)(outb + ((unsigned)tc * rown + nb0));
 #pragma unroll
                 for (int q = 0; q < NP; ++q) oo[mm][q] = src[q];
             }
@@ -250,7 +260,7 @@ __global__ __launch_bounds__(512) void vocoder_conv_kernel(VocConvArgs p) {
             const int m = m0 + mm, t = t0 + wrow0 + m * 16 + fr;
             float v[8];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) v[r] = acc[r >> 2][m][r & 3] + bb[r];
+            for (int r = 0; r < 8; ++r) v[r] = acc[r >> 2][m][r & 3];
             if (p.res) {
                 float rv[8];
 #pragma unroll
@@ -274,7 +284,7 @@ __global__ __launch_bounds__(512) void vocoder_conv_kernel(VocConvArgs p) {
                 for (int r = 0; r < 8; ++r) v[r] = lrelu(v[r], p.out_slope);
             }
             if (t < len) {
-                uint4* dst = (uint4*)((T*)p.out + (obase + t) * p.n + n0);
+                uint4* dst = (uint4*)(outb + ((unsigned)t * rown + nb0));
 #pragma unroll
                 for (int q = 0; q < NP; ++q) dst[q] = Vec16<T>::pack(v + q * E16);
             }
