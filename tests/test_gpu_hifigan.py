@@ -94,6 +94,35 @@ def test_fused_resblock_equals_conv_by_conv(precision):
     assert float((plain - fused).abs().max()) <= (2e-5 if precision == "fp32" else BF16_TOL)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_activated_stream_equals_raw_stream(precision):
+    """Between LDS-resident launches the residual stream (and a fully resident stage's upsampler output) is stored
+    as lrelu(x) and the consumers fill their slabs by LDS-DMA (knob 1); knob 9 stores raw x everywhere.  Same
+    arithmetic up to one storage rounding per hop; ragged batch, several tiles per utterance."""
+    from lightningfastspeech2_amd import _lib
+    cfg = HifiGanConfig()
+    sd = synth_state_dict(cfg, 11)
+    rs = np.random.RandomState(4)
+    mel = torch.from_numpy((rs.standard_normal((3, 37, 80)) * 1.5 - 4.0).astype(np.float32))
+    lengths = torch.tensor([37, 12, 1], dtype=torch.int32)
+    g = HifiGan(cfg, sd, precision=precision)
+    try:
+        _lib.load().fs2_op_set_vocoder_fused_resblock(9)
+        raw = g.synthesize(mel, lengths).cpu()
+        s_raw = [g.debug_stage(s).cpu() for s in (2, 3, 4)]
+        _lib.load().fs2_op_set_vocoder_fused_resblock(1)
+        act = g.synthesize(mel, lengths).cpu()
+        s_act = [g.debug_stage(s).cpu() for s in (2, 3, 4)]
+    finally:
+        _lib.load().fs2_op_set_vocoder_fused_resblock(1)
+    tol = 2e-5 if precision == "fp32" else 5e-2
+    for a, b, up in zip(s_raw, s_act, (64, 128, 256)):
+        for u, n in enumerate(lengths.tolist()):
+            ref = a[u, :n * up]
+            assert float((b[u, :n * up] - ref).abs().max()) <= tol * (float(ref.abs().max()) + 1.0)
+    assert float((raw - act).abs().max()) <= (2e-5 if precision == "fp32" else BF16_TOL)
+
+
 def test_synthesiser_mirror_int16():
     """Synthesiser(mel) -> int16 (1, T*256), the reference wrapper's contract (__init__.py:37-43),
     from a checkpoint-form state_dict ({"generator": weight_g / weight_v ...})."""
