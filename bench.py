@@ -8,15 +8,22 @@ batch-32 inputs (BASELINE.json metric / configs[1]: FS2-27M, bf16, batch 32, 256
 One step = one pass of the hot path (fs2_encode + fs2_decode through the drop-in model object)
 over one batch per rank, inputs already resident in HBM; with N > 1 every rank runs its own
 batch-32 shard (weak scaling) and the final mels are all-gathered with RCCL.  Rank 0 prints ONE
-JSON line.  ``roofline`` is for the dominant kernel (the implicit-GEMM dense Conv1d): algorithmic
-FLOPs per launch / average launch duration measured with HIP events on the launch stream inside the
-timed region.  ``cpu_baseline`` times the CPU oracle (a port, not the product) on a bounded sample
-of the same workload on this box's host cores (rank 0, N=1 only).
+JSON line.
+  roofline      the dominant kernel (the implicit-GEMM dense Conv1d): algorithmic FLOPs per launch /
+                average launch duration measured with HIP events on the launch stream inside the timed
+                region; traffic = HBM bytes per launch from this round's committed PMC passes.
+  cpu_baseline  the CPU oracle (a port, not the product) on this box's host cores, rank 0 / N=1 only.
+  parity        what tolerance the timed mode holds: the same engine in fp32 parity mode (ms/step, mel
+                max-abs vs the oracle on a sample), and for the timed bf16 mode the free-running decision
+                flips vs the oracle and the mel error under the oracle's decisions.
+  value_incl_pcie  the same step with the inputs starting and the mels ending in pinned host memory.
 """
 import argparse
 import json
 import math
 import os
+import statistics
+import subprocess
 import sys
 import time
 
@@ -30,6 +37,7 @@ import torch.distributed as dist
 
 MFMA_PEAK = {"bf16": 2.5e15, "fp32": 157.3e12}  # dense, /opt/skills/guides/MI355X_MICROARCH.md
 HOP, SR = 256, 22050
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
 
 
 def parse():
@@ -38,53 +46,132 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c2", help="c2 (FS2-27M) | c3 (LS-76M) | c5 (FS2-1B) | ref-default")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "mixed"])
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
     ap.add_argument("--phones", type=int, default=256)
     ap.add_argument("--frames-per-phone", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-fused-predictor", action="store_true", help="A/B: variance predictors layer by layer")
-    ap.add_argument("--cpu-sample-batch", type=int, default=8)
+    ap.add_argument("--parity-sample", type=int, default=2, help="utterances of the workload the parity block checks")
     return ap.parse_args()
 
 
+def physical_cores():
+    """(physical cores, model name) from lscpu; falls back to the logical count."""
+    try:
+        txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        kv = {l.split(":", 1)[0].strip(): l.split(":", 1)[1].strip() for l in txt.splitlines() if ":" in l}
+        return int(kv["Core(s) per socket"]) * int(kv["Socket(s)"]), kv.get("Model name", "?")
+    except Exception:
+        return os.cpu_count() or 1, "?"
+
+
 def cpu_baseline(cfg, sd, args):
-    """The CPU oracle on the first `cpu-sample-batch` utterances of the same synthetic workload.
-    torch's intra-op pool stops scaling long before a 2 x 64-core host is full (the forward is many
-    small ops), so the thread count is swept and the BEST one is reported (a strong baseline)."""
+    """The CPU oracle on the same synthetic workload: a thread sweep on 8 utterances (torch's intra-op pool
+    stops scaling long before a 2 x 64-core host is full, so the BEST count is the baseline of record and the
+    physical-core count is one of the candidates), then the WHOLE batch at that count (1 warm-up + 3 passes,
+    median), and a 1-thread figure on 2 utterances.  Also returns the oracle's outputs for the parity block."""
     from lightningfastspeech2_amd.weights import synth_inputs
     from oracle import oracle_cpu  # cpu_baseline leg only
-    B = args.cpu_sample_batch
     inp = synth_inputs(cfg, args.batch, args.phones, seed=1234)
-    ph, sp = inp["phones"][:B], inp["speaker"][:B]
+    ph, sp = inp["phones"], inp["speaker"]
     ncpu = os.cpu_count() or 1
+    phys, model = physical_cores()
     default_threads = torch.get_num_threads()
+    spent = 0.0
 
-    def one_pass():
+    def one_pass(B):
         t0 = time.perf_counter()
-        out = oracle_cpu.forward(sd, cfg, ph, sp)
+        out = oracle_cpu.forward(sd, cfg, ph[:B], sp[:B])
         return time.perf_counter() - t0, int((~out["tgt_mask"]).sum())
 
-    best_nt, best_rate, spent = default_threads, 0.0, 0.0
-    for nt in sorted({n for n in (8, 16, 32, 64, default_threads) if n <= ncpu}):
+    sweep = {}
+    Bs = min(8, args.batch)
+    for nt in sorted({n for n in (8, 16, 32, 64, phys, default_threads) if n <= ncpu}):
         torch.set_num_threads(nt)
         oracle_cpu.forward(sd, cfg, ph[:1], sp[:1])  # warm the pool at this size
-        t, fr = one_pass()
+        t, fr = one_pass(Bs)
         spent += t
-        if fr / t > best_rate:
-            best_nt, best_rate = nt, fr / t
+        sweep[nt] = fr / t
+    best_nt = max(sweep, key=sweep.get)
     torch.set_num_threads(best_nt)
-    reps, t_tot, frames = 3, 0.0, 0
-    for _ in range(reps):
-        t, fr = one_pass()
-        t_tot += t
-        frames += fr
+    t, _ = one_pass(args.batch)  # warm-up at the full batch
+    spent += t
+    times, frames = [], 0
+    for _ in range(3):
+        t, frames = one_pass(args.batch)
+        times.append(t)
+        spent += t
+    med = statistics.median(times)
+    torch.set_num_threads(1)
+    t1, f1 = one_pass(min(2, args.batch))
+    spent += t1
     torch.set_num_threads(default_threads)
-    return {"value": frames / t_tot, "unit": "mel-frames/s", "cores": best_nt, "kind": "port",
-            "sample": f"oracle/oracle_cpu.py (torch {torch.__version__} CPU fp32 ops), {reps} passes over the "
-                      f"first {B} of the {args.batch} x {args.phones}-phoneme utterances at the best of a "
-                      f"thread sweep ({best_nt} threads; host has {ncpu} logical CPUs), {t_tot + spent:.1f} s of CPU work",
-            "rtf": t_tot / (frames * HOP / SR)}
+    return {"value": frames / med, "unit": "mel-frames/s", "cores": best_nt, "kind": "port",
+            "sample": f"oracle/oracle_cpu.py (torch {torch.__version__} CPU fp32 ops) on all {args.batch} x {args.phones}-phoneme "
+                      f"utterances of the workload: 1 warm-up + 3 passes, median, at the best of a thread sweep over "
+                      f"{sorted(sweep)} ({best_nt} threads); {spent:.1f} s of CPU work in total",
+            "rtf": med / (frames * HOP / SR),
+            "physical_cores": phys, "logical_cpus": ncpu, "cpu_model": model,
+            "value_at_physical_cores": sweep.get(phys), "value_1_thread": f1 / t1,
+            "thread_sweep_frames_per_s": {str(k): round(v) for k, v in sweep.items()}}
+
+
+def parity_block(cfg, sd, args, dev, timed_model):
+    """fp32 parity mode timed + checked against the oracle on a sample of the workload, and the timed mode's
+    decision flips / forced-decision mel error on the same sample (rank 0, N=1)."""
+    from lightningfastspeech2_amd.model import FastSpeech2
+    from lightningfastspeech2_amd.weights import synth_inputs
+    from oracle import oracle_cpu  # checker only
+    Bs = max(1, min(args.parity_sample, args.batch))
+    inp = synth_inputs(cfg, args.batch, args.phones, seed=1234)
+    ph, sp = inp["phones"][:Bs], inp["speaker"][:Bs]
+    ref = oracle_cpu.forward(sd, cfg, ph, sp, return_intermediates=True)
+    sample = {"phones": torch.from_numpy(ph).to(dev), "speaker": torch.from_numpy(sp).to(dev)}
+    full = {"phones": torch.from_numpy(inp["phones"]).to(dev), "speaker": torch.from_numpy(inp["speaker"]).to(dev)}
+    ref_b = {v: ref["_intermediates"][f"bucket_{v}"] for v in cfg.variances}
+
+    def check(model):
+        model.engine.set_debug(True)
+        out = model(sample, inference=True)
+        dfl = int((out["duration_rounded"].cpu() != ref["duration_rounded"]).sum())
+        same_T = out["mel"].shape == ref["mel"].shape
+        bfl = -1
+        if dfl == 0 and same_T:
+            bfl = sum(int((model.engine.debug_tensor(f"bucket_{v}").cpu().long() != ref_b[v]).sum()) for v in cfg.variances)
+        free = float((out["mel"].cpu() - ref["mel"]).abs().max()) if same_T else float("nan")
+        out = model.forward(sample, force_durations=ref["duration_rounded"], force_buckets=ref_b)
+        forced = float((out["mel"].cpu() - ref["mel"]).abs().max())
+        model.engine.set_debug(False)
+        return dfl, bfl, free, forced
+
+    res = {"sample": f"first {Bs} of the {args.batch} utterances of the timed workload (as their own batch: utterances "
+                     f"are independent and unpadded here), oracle/oracle_cpu.py as the reference",
+           "buckets_compared": int(sum(ref_b[v].numel() for v in cfg.variances)),
+           "durations_compared": int(ref["duration_rounded"].numel()),
+           "note": "the workload's duration head is weight 0 / bias ln 7 (T fixed at 6 frames/phone), so duration flips are "
+                   "0 by construction here; tests/test_gpu_forward.py reports them on ragged random-head batches"}
+    if args.precision != "fp32":
+        m32 = FastSpeech2(cfg, sd, precision="fp32", device=dev)
+        dfl, bfl, free, forced = check(m32)
+        for _ in range(2):
+            m32(full, inference=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n32 = 3
+        for _ in range(n32):
+            m32(full, inference=True)
+        torch.cuda.synchronize()
+        res.update({"fp32_ms_per_step": (time.perf_counter() - t0) / n32 * 1e3, "fp32_duration_flips": dfl,
+                    "fp32_bucket_flips": bfl, "fp32_mel_maxabs_vs_oracle": forced if bfl else free,
+                    "fp32_mel_maxabs_is": "under the oracle's decisions" if bfl else "free-running"})
+        del m32
+    dfl, bfl, free, forced = check(timed_model)
+    p = args.precision
+    res.update({f"{p}_duration_flips": dfl, f"{p}_bucket_flips": bfl, f"{p}_mel_maxabs_free": free,
+                f"{p}_mel_maxabs_forced": forced, "mel_scale": float(ref["mel"].abs().max())})
+    return res
 
 
 def main():
@@ -110,7 +197,7 @@ def main():
 
     from lightningfastspeech2_amd import _lib
     from lightningfastspeech2_amd.config import preset
-    from lightningfastspeech2_amd.dist import gather_mels_async
+    from lightningfastspeech2_amd.dist import gather_mels_async, global_frames
     from lightningfastspeech2_amd.model import FastSpeech2
     from lightningfastspeech2_amd.weights import synth_inputs, synth_state_dict
 
@@ -125,19 +212,27 @@ def main():
     inp = synth_inputs(cfg, args.batch, args.phones, seed=1234 + 17 * rank)
     batch = {"phones": torch.from_numpy(inp["phones"]).to(dev), "speaker": torch.from_numpy(inp["speaker"]).to(dev)}
 
-    # N > 1: the all-gather of step i's mels rides the collective stream underneath the forward of
-    # step i+1 (at most one in flight; the last one is waited for before the closing barrier + sync)
+    # N > 1: the all-gather of step i's mels rides the collective stream underneath the forward of step i+1
+    # (at most one in flight; the last one is waited for before the closing barrier + sync).  Every rank's
+    # (B_r, T) is fixed for this workload and agreed ONCE after the first warm-up step, so a step queues its
+    # collectives without any exchange or host read-back; pad rows are zeroed by the mel GEMM's own store.
     pending = []
+    shapes = [None]
+    if world > 1:
+        model.engine.set_zero_pad_mel(True)
 
     def step():
         out = model(batch, inference=True)
         if world > 1:
             if pending:
                 pending.pop().wait()
+            if shapes[0] is None:
+                cdev0 = dev if backend == "nccl" else torch.device("cpu")
+                shapes[0] = ([args.batch] * world, global_frames(out["mel"].shape[1], cdev0))
             if backend == "nccl":
-                pending.append(gather_mels_async(out["mel"], out["tgt_mask"]))
+                pending.append(gather_mels_async(out["mel"], out["tgt_mask"], shapes=shapes[0], zeroed=True))
             else:  # rehearsal path: gloo moves host tensors
-                pending.append(gather_mels_async(out["mel"].cpu(), out["tgt_mask"].cpu()))
+                pending.append(gather_mels_async(out["mel"].cpu(), out["tgt_mask"].cpu(), shapes=shapes[0], zeroed=True))
         return out
 
     def drain():
@@ -145,8 +240,10 @@ def main():
             mel_all, frames = pending.pop().wait()
             assert mel_all.shape[0] == frames.numel()
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 1) if world > 1 else args.warmup):
         out = step()
+    if args.warmup == 0 and world == 1:
+        out = model(batch, inference=True)
     drain()
     frames_rank = int((~out["tgt_mask"]).sum())
     T = int(out["mel"].shape[1])
@@ -185,12 +282,13 @@ def main():
         n = max(prof["launches"], 1)
         avg_s = prof["ms"] / n * 1e-3
         achieved = (prof["flops"] / n) / avg_s if avg_s > 0 else 0.0
-        peak = MFMA_PEAK[args.precision]
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tpath) and args.config == "c2" and args.precision == "bf16":
+        peak = MFMA_PEAK["fp32" if args.precision == "fp32" else "bf16"]
+        traffic, traffic_src = None, None
+        if os.path.exists(TRAFFIC_FILE) and args.config == "c2" and args.precision == "bf16" and args.batch == 32:
             try:
-                traffic = json.load(open(tpath)).get("conv_gemm_hbm_bytes_per_launch")
+                traffic = json.load(open(TRAFFIC_FILE)).get("conv_gemm_hbm_bytes_per_launch")
+                traffic_src = ("profiles/r02_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + --pmc WRITE_SIZE, "
+                               "separate passes over this launch shape (tools/pmc_traffic.sh), this round's kernel")
             except Exception:
                 traffic = None
         line = {
@@ -209,13 +307,42 @@ def main():
                        "parallelism": f"dp{world} (utterance shards, RCCL all-gather of mels only)" if world > 1 else "single GPU",
                        "params": cfg.param_count()},
             "roofline": {"bound": "mfma", "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic,
+                         "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": ("gemm_conv_slab_kernel: decoder FFN conv1, implicit-GEMM Conv1d "
                                     f"M={args.batch * T} N={cfg.decoder_conv_filter_size} K={cfg.decoder_kernel_sizes[0]}x{cfg.hidden}")
                          if kcls == _lib.K_DEC_FFN_CONV1 else "gemm_conv_slab_kernel (pointwise GEMM launches, aggregated)",
                          "launches_timed": prof["launches"], "avg_launch_us": avg_s * 1e6,
                          "flops_per_launch": prof["flops"] / n},
         }
+        if world == 1:
+            # the boundary takes device pointers; a host caller also pays H2D of phones + speaker and D2H of the
+            # fp32 mels + mask per batch (SURVEY 8d's metric definition): timed separately, never `value`
+            hp = torch.from_numpy(inp["phones"]).pin_memory()
+            hs = torch.from_numpy(inp["speaker"]).pin_memory()
+            hmel = torch.empty(args.batch, T, cfg.n_mels, dtype=torch.float32).pin_memory()
+            hmask = torch.empty(args.batch, T, dtype=torch.bool).pin_memory()
+            k2 = max(3, min(args.steps, 10))
+
+            def pcie_step():
+                b = {"phones": hp.to(dev, non_blocking=True), "speaker": hs.to(dev, non_blocking=True)}
+                o = model(b, inference=True)
+                hmel.copy_(o["mel"], non_blocking=True)
+                hmask.copy_(o["tgt_mask"], non_blocking=True)
+            pcie_step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(k2):
+                pcie_step()
+            torch.cuda.synchronize()
+            el2 = time.perf_counter() - t0
+            line["value_incl_pcie"] = {"value": frames_rank * k2 / el2, "ms_per_step": el2 / k2 * 1e3, "steps": k2,
+                                       "what": "inputs from / mels + mask to pinned host memory every step (66 KB H2D, "
+                                               f"{hmel.numel() * 4 / 1e6:.1f} MB D2H)"}
+        if world == 1 and not args.no_parity:
+            try:
+                line["parity"] = parity_block(cfg, sd, args, dev, model)
+            except Exception as ex:  # never lose the timed line to the checker
+                line["parity"] = {"error": repr(ex)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, sd, args)
         print(json.dumps(line), flush=True)

@@ -45,14 +45,23 @@ enum fs2_status {
     FS2_ERR_NOMEM = 6
 };
 
-enum fs2_dtype { FS2_F32 = 0, FS2_BF16 = 1 };
+enum fs2_dtype {
+    FS2_F32 = 0,
+    FS2_BF16 = 1,
+    FS2_MIXED = 2  /* engine mode only (fs2_config.dtype): fp32 "front" + bf16 "back", see fs2_config.dtype */
+};
 
 /* Mirrors the hparams that shape FastSpeech2.forward (fastspeech2.py:46-130). */
 typedef struct fs2_config {
     int32_t abi_version;   /* FS2_ABI_VERSION */
     int32_t dtype;         /* fs2_dtype: arithmetic mode. F32 = parity mode (fp32 MFMA, <=1e-3 vs the
                               reference); BF16 = throughput mode (bf16 storage + MFMA, fp32 accumulate,
-                              fp32 softmax/LayerNorm statistics/predictor heads/bucketize) */
+                              fp32 softmax/LayerNorm statistics/predictor heads/bucketize);
+                              MIXED = decision-safe throughput mode: everything a discrete decision depends on
+                              (embedding, encoder, duration predictor and rounding, length regulator, variance
+                              predictors and bucketize - model.py:259,299-309,315-333,434-438) runs as in F32, the
+                              decoder and the mel head (where an error stays an error of O(bf16 rounding) in the
+                              mel) as in BF16: durations / buckets follow the fp32 path's, at bf16 decoder speed */
     int32_t n_phones;      /* len(phone2id) */
     int32_t hidden;        /* encoder_hidden == decoder_hidden */
     int32_t n_mels;
@@ -117,6 +126,23 @@ int fs2_last_totals(const fs2_engine* e, int32_t* totals_host, int32_t* guard_ho
 /* Phase 2: length regulator + variance encoders + decoder + mel linear, into caller buffers. */
 int fs2_decode(fs2_engine* e, const fs2_outputs* out, void* hip_stream);
 
+/* Workspace.  By default the engine keeps two grow-only device arenas of its own.  A caller that
+ * wants every byte to come from its allocator (torch's caching allocator in the host mirror) asks for the sizes
+ * and hands the buffers over; the engine then never calls hipMalloc/hipFree on the forward path.
+ *   persist: live from fs2_encode to the end of fs2_decode (encoder output, durations, prefix sums); depends on (B, L)
+ *   scratch: per-phase; for T = 0 the size fs2_encode needs, for T > 0 max(encode, decode at T frames)
+ * fs2_set_workspace(NULL, 0, NULL, 0) returns to engine-owned arenas.  Between fs2_encode and fs2_decode only the
+ * scratch buffer may be replaced (the usual pattern: T is known only after fs2_encode).  Buffers 256-byte aligned;
+ * a buffer that is too small makes the next phase fail with FS2_ERR_NOMEM and the needed size in fs2_last_error. */
+int fs2_workspace_bytes(const fs2_engine* e, int32_t B, int32_t L, int32_t T, size_t* persist_bytes, size_t* scratch_bytes);
+int fs2_set_workspace(fs2_engine* e, void* persist_device, size_t persist_bytes, void* scratch_device, size_t scratch_bytes);
+/* Data-parallel "global pad" mode: after fs2_encode, raise this shard's frame count to the maximum over
+ * all ranks so that fs2_decode pads exactly as the whole batch would (T can only grow, <= max_frames). */
+int fs2_set_frames(fs2_engine* e, int32_t T);
+/* on = 1: fs2_decode writes zeros into the mel rows of pad frames (t >= the utterance's total) instead of the
+ * reference's deterministic pad-row values - what the multi-GPU mel gather ships, fused into the mel GEMM's store. */
+int fs2_set_zero_pad_mel(fs2_engine* e, int32_t on);
+
 /* Parity taps: copy an intermediate of the last forward as fp32 into a caller DEVICE buffer.
  * what = "encoder_out" (B,L,H) | "regulated" | "adaptor_out" | "decoder_out" (B,T,H) |
  *        "bucket_<var>" (B,T) int32.  Requires fs2_set_debug(e, 1) before fs2_encode. */
@@ -155,7 +181,9 @@ int fs2_profile_read(fs2_engine* e, int32_t kernel_class, double* total_ms, int6
  *   0       auto (by problem size)
  *   1       128x128 register-staged GEMM      2       128x256 LDS-DMA ring GEMM
  *   3/4/5   slab kernel, 128/192/256-row tiles   6/7   slab kernel, 32/64-row tiles
- *   200/201 slab kernel tile order: plain / XCD-contiguous (default) */
+ *   200/201 slab kernel tile order: plain / XCD-contiguous (default)
+ *   300/301 LayerNorm epilogue for rows wider than 256: GEMM + stand-alone LayerNorm launch (default) / in-place fused
+ *   400/404/406 attention query tile on long bf16 d=128 sequences: auto / 128 queries (4 waves) / 192 queries (6 waves) */
 int fs2_op_set_gemm_variant(int32_t variant);
 /* tuning knob: cap (KiB) on the LDS operand slab of a vocoder conv workgroup; 0 = built-in heuristic */
 int fs2_op_set_vocoder_lds_limit(int32_t kib);

@@ -23,7 +23,7 @@ FS2_MAX_LAYERS = 32
 FS2_MAX_VARIANCES = 4
 FS2_NAME_LEN = 32
 FS2_OK = 0
-FS2_F32, FS2_BF16 = 0, 1
+FS2_F32, FS2_BF16, FS2_MIXED = 0, 1, 2
 K_CONV_GEMM, K_GEMM, K_ATTENTION, K_ROWOPS, K_DEC_FFN_CONV1 = 0, 1, 2, 3, 4
 
 
@@ -98,6 +98,10 @@ def load():
     lib.fs2_set_priors.argtypes = [vp, vp, i32]
     lib.fs2_decode.argtypes = [vp, C.POINTER(Fs2OutputsC), vp]
     lib.fs2_set_debug.argtypes = [vp, i32]
+    lib.fs2_workspace_bytes.argtypes = [vp, i32, i32, i32, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    lib.fs2_set_workspace.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t]
+    lib.fs2_set_frames.argtypes = [vp, i32]
+    lib.fs2_set_zero_pad_mel.argtypes = [vp, i32]
     lib.fs2_set_fused_predictor.argtypes = [vp, i32]
     lib.fs2_debug_copy.argtypes = [vp, C.c_char_p, vp, vp]
     lib.fs2_force_buckets.argtypes = [vp, i32, vp]

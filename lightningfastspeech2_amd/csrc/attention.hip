@@ -86,7 +86,7 @@ __device__ inline float half_sum(float x) {
 }
 
 template <typename T, int D, int NW>
-__global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128) ? 2 : 1) void attention_kernel(AttnArgs p) {
+__global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128) ? (NW == 6 ? 3 : 2) : 1) void attention_kernel(AttnArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins exist in the device pass only
     constexpr int KVB = sizeof(T) == 2 ? 64 : 32;      // keys per tile
     constexpr int E16 = Num<T>::kPer16B;
@@ -98,10 +98,13 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128) ? 2 : 1) void
     constexpr int NKB = KVB / 32;                      // 32-key blocks per tile
     constexpr int ND = D / 32;                         // 32-wide dv blocks
     constexpr int TILE_B = 128 * D;                    // bytes of a K tile == bytes of a Vt tile
-    constexpr int NINST = TILE_B / 1024 / NW;          // 1-KiB DMA instructions per wave per tile
+    // K / V tile DMAs: 16 KiB / 1 KiB = 16 pieces per tile, issued by the first NDW waves (all of them when the count
+    // divides evenly; the 6-wave form lets waves 0-3 issue 4 pieces each)
+    constexpr int NDW = (TILE_B / 1024) % NW == 0 ? NW : 4;
+    constexpr int NINST = TILE_B / 1024 / NDW;         // 1-KiB DMA instructions per issuing wave per tile
     constexpr float THR = sizeof(T) == 2 ? 6.0f : 0.0f;  // defer-max threshold (log2 units), exact in fp32
     constexpr bool TRV = sizeof(T) == 2;  // bf16: V stays row-major (straight from qkv), hardware transpose read
-    static_assert(TILE_B % (1024 * NW) == 0, "tile must split into whole wave DMAs");
+    static_assert(TILE_B % (1024 * NDW) == 0 && NDW <= NW, "tile must split into whole wave DMAs");
 
     __shared__ __attribute__((aligned(16))) unsigned char sKa[TILE_B];
     __shared__ __attribute__((aligned(16))) unsigned char sVa[TILE_B];
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128) ? 2 : 1) void
     unsigned kvo[NINST], vvo[NINST];
 #pragma unroll
     for (int i = 0; i < NINST; ++i) {
-        const int P = (i * NW + wave) * 64 + lane;
+        const int P = (i * NDW + (wave % NDW)) * 64 + lane;
         const int row = P / KNS, ps = P % KNS;
         kvo[i] = (unsigned)((row * ld + p.H + h * D) * (int)sizeof(T) + (unswz_slot<KRB>(row, ps) << 4));
         if constexpr (TRV) {
@@ -156,14 +159,16 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128) ? 2 : 1) void
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)dst, 16, voff, 0, 0, 0);
     };
     auto issue_k = [&](int j, unsigned char* sK) {
+        if (NDW != NW && wave >= NDW) return;
 #pragma unroll
-        for (int i = 0; i < NINST; ++i) dma16(qrs, sK + (i * NW + wave) * 1024, kvo[i] + (unsigned)j * ktile);
+        for (int i = 0; i < NINST; ++i) dma16(qrs, sK + (i * NDW + wave) * 1024, kvo[i] + (unsigned)j * ktile);
     };
     auto issue_v = [&](int j, unsigned char* sV) {
+        if (NDW != NW && wave >= NDW) return;
 #pragma unroll
         for (int i = 0; i < NINST; ++i) {
-            if constexpr (TRV) dma16(qrs, sV + (i * NW + wave) * 1024, vvo[i] + (unsigned)j * ktile);
-            else dma16(vrs, sV + (i * NW + wave) * 1024, vvo[i] + (unsigned)(j * KVB * (int)sizeof(T)));
+            if constexpr (TRV) dma16(qrs, sV + (i * NDW + wave) * 1024, vvo[i] + (unsigned)j * ktile);
+            else dma16(vrs, sV + (i * NDW + wave) * 1024, vvo[i] + (unsigned)(j * KVB * (int)sizeof(T)));
         }
     };
 
@@ -398,12 +403,25 @@ static int launch_tv(const AttnArgs& a, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
 }
 
+int g_attn_nw = 0;  // A/B knob: 0 = auto, 4 / 6 = waves (x32 queries) per workgroup on long sequences
+
 template <typename T, int D>
 static int launch_td(const AttnArgs& a, hipStream_t stream) {
     const int BH = a.B * a.heads, BH8 = (BH + 7) / 8 * 8;
     // grid = ceil(BH/8)*8 * nq, decoded XCD-aware in the kernel.  Small sequences: 2-wave
     // workgroups so the grid still covers the 256 CUs.
     const long blocks4 = (long)((a.S + 127) / 128) * BH;
+    // Long sequences, bf16, d = 128: 192 queries (6 waves) per workgroup when that fills two workgroups per CU evenly -
+    // every workgroup streams ALL keys of its (utterance, head) through LDS, so fewer, taller query tiles cut that
+    // traffic by a third (C2 decoder: 512 workgroups x 786 KB instead of 768 x 786 KB).
+    const long blocks6 = (long)((a.S + 191) / 192) * BH;
+    const int nw = g_attn_nw ? g_attn_nw : ((sizeof(T) == 2 && D == 128 && blocks6 >= 384 && a.S >= 768) ? 6 : 4);
+    if constexpr (sizeof(T) == 2 && D == 128) {
+        if (nw == 6 && (g_attn_nw == 6 || blocks4 >= 512)) {
+            hipLaunchKernelGGL((attention_kernel<T, D, 6>), dim3(((a.S + 191) / 192) * BH8), dim3(384), 0, stream, a);
+            return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
+        }
+    }
     if (blocks4 >= 512) {
         hipLaunchKernelGGL((attention_kernel<T, D, 4>), dim3(((a.S + 127) / 128) * BH8), dim3(256), 0, stream, a);
     } else {

@@ -28,9 +28,11 @@ struct HostTensor {
 struct Arena {
     char* base = nullptr;
     size_t cap = 0, off = 0;
+    bool external = false;  // caller-owned memory (fs2_set_workspace): never freed or grown here
     int reserve(size_t bytes) {
         off = 0;
         if (bytes <= cap) return FS2_OK;
+        if (external) return FS2_ERR_NOMEM;
         if (base) (void)hipFree(base);
         base = nullptr;
         cap = 0;
@@ -46,17 +48,23 @@ struct Arena {
         return base + a;
     }
     void release() {
-        if (base) (void)hipFree(base);
+        if (base && !external) (void)hipFree(base);
         base = nullptr;
         cap = off = 0;
+        external = false;
+    }
+    void adopt(void* p, size_t bytes) {  // p == nullptr: back to an engine-owned, grow-only arena
+        release();
+        if (p) { base = (char*)p; cap = bytes; external = true; }
     }
 };
 inline size_t al(size_t b) { return (b + 255) & ~(size_t)255; }
 
-struct ConvW {     // dense conv or pointwise: W (N, taps*Cin) in engine dtype, bias fp32
+struct ConvW {     // dense conv or pointwise: W (N, taps*Cin) in its side's dtype, bias fp32
     void* w = nullptr;
     float* b = nullptr;
     int N = 0, Cin = 0, taps = 1;
+    int dt = FS2_F32;  // dtype of w and of the activations this layer reads
 };
 struct DwW {       // depth-wise conv weights fp32 (C, k) + bias
     float* w = nullptr;
@@ -77,6 +85,7 @@ struct PredLayerW {
     float *g = nullptr, *b = nullptr;
 };
 struct PredictorW {
+    int dt = FS2_F32;
     std::vector<PredLayerW> layers;
     float* head_w = nullptr;
     float head_b = 0.f;
@@ -102,12 +111,15 @@ struct ProfSlot {
 
 struct fs2_engine {
     fs2_config cfg;
-    int dt = FS2_F32;
-    size_t esz = 4;
+    int dt = FS2_F32;          // configured mode (FS2_F32 / FS2_BF16 / FS2_MIXED)
+    int fdt = FS2_F32, bdt = FS2_F32;  // arithmetic of the front (encoder + variance adaptor: every discrete decision)
+                                       // and of the back (decoder + mel head); they differ only in FS2_MIXED
+    size_t esz = 4;            // bytes per activation element, the larger of the two (arena sizing)
     char err[512];
     bool finalized = false;
     bool debug = false;
     bool fuse_predictor = true;
+    bool zero_pad_mel = false;
     std::map<std::string, HostTensor> host;
     std::map<std::string, std::vector<int64_t>> spec;
     std::vector<void*> dev_allocs;
@@ -124,6 +136,7 @@ struct fs2_engine {
     Arena persist, scratch, dbg, dbg_enc;
     int B = 0, L = 0, T = 0;
     bool encoded = false;
+    bool mid_forward = false;  // fs2_encode done, fs2_decode not yet: the persist arena is live
     void *xA = nullptr, *xB = nullptr;  // (B*L, H) encoder ping-pong; xA = encoder_out
     float* spk = nullptr;
     float* dur_pred = nullptr;
@@ -235,7 +248,7 @@ void build_spec(fs2_engine* e) {
 int check_config(fs2_engine* e) {
     const fs2_config& c = e->cfg;
     if (c.abi_version != FS2_ABI_VERSION) return fail(e, FS2_ERR_ARG, "abi_version %d != %d", c.abi_version, FS2_ABI_VERSION);
-    if (c.dtype != FS2_F32 && c.dtype != FS2_BF16) return fail(e, FS2_ERR_ARG, "bad dtype");
+    if (c.dtype != FS2_F32 && c.dtype != FS2_BF16 && c.dtype != FS2_MIXED) return fail(e, FS2_ERR_ARG, "bad dtype");
     const int H = c.hidden;
     if (H <= 0 || H % 64 || H > 1024) return fail(e, FS2_ERR_SHAPE, "hidden=%d must be a multiple of 64, <= 1024", H);
     if (c.enc_layers < 0 || c.enc_layers > FS2_MAX_LAYERS || c.dec_layers < 0 || c.dec_layers > FS2_MAX_LAYERS)
@@ -286,8 +299,8 @@ int upload_f32(fs2_engine* e, const float* h, size_t n, float** out) {
     HIPCHK(e, hipMemcpy(*out, h, n * 4, hipMemcpyHostToDevice));
     return FS2_OK;
 }
-int upload_mat(fs2_engine* e, const float* h, size_t n, void** out) {  // in the engine dtype
-    if (e->dt == FS2_F32) return upload_f32(e, h, n, (float**)out);
+int upload_mat(fs2_engine* e, const float* h, size_t n, void** out, int dt) {
+    if (dt == FS2_F32) return upload_f32(e, h, n, (float**)out);
     std::vector<unsigned short> tmp(n);
     for (size_t i = 0; i < n; ++i) tmp[i] = f32_to_bf16(h[i]).v;
     CHK(dev_alloc(e, out, n * 2));
@@ -297,7 +310,8 @@ int upload_mat(fs2_engine* e, const float* h, size_t n, void** out) {  // in the
 const HostTensor& W(fs2_engine* e, const std::string& n) { return e->host.at(n); }
 
 // conv weight (N, Cin, k) -> (N, k*Cin) tap-major
-int make_conv(fs2_engine* e, const std::string& wname, const std::string& bname, ConvW* out) {
+int make_conv(fs2_engine* e, const std::string& wname, const std::string& bname, ConvW* out, int dt) {
+    out->dt = dt;
     const HostTensor& w = W(e, wname);
     const int N = (int)w.shape[0], Cin = (int)w.shape[1], k = w.shape.size() > 2 ? (int)w.shape[2] : 1;
     std::vector<float> packed((size_t)N * Cin * k);
@@ -307,7 +321,7 @@ int make_conv(fs2_engine* e, const std::string& wname, const std::string& bname,
     out->N = N;
     out->Cin = Cin;
     out->taps = k;
-    CHK(upload_mat(e, packed.data(), packed.size(), &out->w));
+    CHK(upload_mat(e, packed.data(), packed.size(), &out->w, dt));
     const HostTensor& b = W(e, bname);
     return upload_f32(e, b.data.data(), b.data.size(), &out->b);
 }
@@ -322,7 +336,8 @@ int make_dw(fs2_engine* e, const std::string& wname, const std::string& bname, D
 // conv2 = Sequential(grouped k=1 conv (groups=H over F channels), pointwise F->H) has no
 // non-linearity in between (model.py:84-93), so it is one linear map: W' = W21 * blockdiag(G),
 // b' = W21 * bg + b21.  Folded once here in double precision.
-int make_folded_conv2(fs2_engine* e, const std::string& p, int H, int F, ConvW* out) {
+int make_folded_conv2(fs2_engine* e, const std::string& p, int H, int F, ConvW* out, int dt) {
+    out->dt = dt;
     const HostTensor& G = W(e, p + ".conv2.0.weight");   // (F, F/H, 1)
     const HostTensor& bg = W(e, p + ".conv2.0.bias");    // (F)
     const HostTensor& W2 = W(e, p + ".conv2.1.weight");  // (H, F, 1)
@@ -346,33 +361,34 @@ int make_folded_conv2(fs2_engine* e, const std::string& p, int H, int F, ConvW* 
     out->N = H;
     out->Cin = F;
     out->taps = 1;
-    CHK(upload_mat(e, Wf.data(), Wf.size(), &out->w));
+    CHK(upload_mat(e, Wf.data(), Wf.size(), &out->w, dt));
     return upload_f32(e, bf.data(), bf.size(), &out->b);
 }
 int up_vec(fs2_engine* e, const std::string& n, float** out) {
     const HostTensor& t = W(e, n);
     return upload_f32(e, t.data.data(), t.data.size(), out);
 }
-int make_layer(fs2_engine* e, const std::string& p, int H, int F, bool dw, LayerW* L) {
+int make_layer(fs2_engine* e, const std::string& p, int H, int F, bool dw, LayerW* L, int dt) {
     L->depthwise = dw;
-    CHK(make_conv(e, p + ".self_attn.in_proj_weight", p + ".self_attn.in_proj_bias", &L->in_proj));
-    CHK(make_conv(e, p + ".self_attn.out_proj.weight", p + ".self_attn.out_proj.bias", &L->out_proj));
+    CHK(make_conv(e, p + ".self_attn.in_proj_weight", p + ".self_attn.in_proj_bias", &L->in_proj, dt));
+    CHK(make_conv(e, p + ".self_attn.out_proj.weight", p + ".self_attn.out_proj.bias", &L->out_proj, dt));
     CHK(up_vec(e, p + ".norm1.weight", &L->g1));
     CHK(up_vec(e, p + ".norm1.bias", &L->b1));
     CHK(up_vec(e, p + ".norm2.weight", &L->g2));
     CHK(up_vec(e, p + ".norm2.bias", &L->b2));
     if (dw) {
         CHK(make_dw(e, p + ".conv1.0.weight", p + ".conv1.0.bias", &L->dw));
-        CHK(make_conv(e, p + ".conv1.1.weight", p + ".conv1.1.bias", &L->c1));
-        CHK(make_folded_conv2(e, p, H, F, &L->c2));
+        CHK(make_conv(e, p + ".conv1.1.weight", p + ".conv1.1.bias", &L->c1, dt));
+        CHK(make_folded_conv2(e, p, H, F, &L->c2, dt));
     } else {
-        CHK(make_conv(e, p + ".conv1.weight", p + ".conv1.bias", &L->c1));
-        CHK(make_conv(e, p + ".conv2.weight", p + ".conv2.bias", &L->c2));
+        CHK(make_conv(e, p + ".conv1.weight", p + ".conv1.bias", &L->c1, dt));
+        CHK(make_conv(e, p + ".conv2.weight", p + ".conv2.bias", &L->c2, dt));
     }
     return FS2_OK;
 }
-int make_predictor(fs2_engine* e, const std::string& p, int nl, int filt, bool dw, PredictorW* P) {
+int make_predictor(fs2_engine* e, const std::string& p, int nl, int filt, bool dw, PredictorW* P, int dt) {
     P->filt = filt;
+    P->dt = dt;
     P->layers.resize(nl);
     for (int j = 0; j < nl; ++j) {
         const std::string q = p + ".layers." + std::to_string(j) + ".layers";
@@ -380,9 +396,9 @@ int make_predictor(fs2_engine* e, const std::string& p, int nl, int filt, bool d
         Lw.depthwise = dw;
         if (dw) {
             CHK(make_dw(e, q + ".0.module.0.weight", q + ".0.module.0.bias", &Lw.dw));
-            CHK(make_conv(e, q + ".0.module.1.weight", q + ".0.module.1.bias", &Lw.c));
+            CHK(make_conv(e, q + ".0.module.1.weight", q + ".0.module.1.bias", &Lw.c, dt));
         } else {
-            CHK(make_conv(e, q + ".0.module.weight", q + ".0.module.bias", &Lw.c));
+            CHK(make_conv(e, q + ".0.module.weight", q + ".0.module.bias", &Lw.c, dt));
         }
         CHK(up_vec(e, q + ".2.weight", &Lw.g));
         CHK(up_vec(e, q + ".2.bias", &Lw.b));
@@ -390,7 +406,7 @@ int make_predictor(fs2_engine* e, const std::string& p, int nl, int filt, bool d
     CHK(up_vec(e, p + ".linear.weight", &P->head_w));
     P->head_b = W(e, p + ".linear.bias").data[0];
     const int taps = nl ? P->layers[0].c.taps : 0, cin = nl ? P->layers[0].c.Cin : 0;
-    if (!dw && nl && cin == filt && predictor_fused_supported(e->dt, filt, taps, nl, 1)) {
+    if (!dw && nl && cin == filt && predictor_fused_supported(dt, filt, taps, nl, 1)) {
         const size_t lb = predictor_packed_bytes_per_layer();
         CHK(dev_alloc(e, &P->wpk, lb * nl));
         std::vector<float> bias, g, b;
@@ -449,8 +465,9 @@ struct LnFuse {  // optional fused epilogue: y = LN(act(gemm) [+ res]) [-> head]
 };
 
 int gemm(fs2_engine* e, hipStream_t st, const ConvW& w, const void* x, void* c, int M, int S, bool relu, int out_dt,
-         const LnFuse* ln = nullptr, int extra_class = -1) {
+         const LnFuse* ln = nullptr, int extra_class = -1, const uint8_t* zero_rows = nullptr) {
     GemmArgs a;
+    a.zero_rows = zero_rows;
     a.X = x;
     a.W = w.w;
     a.bias = w.b;
@@ -471,19 +488,20 @@ int gemm(fs2_engine* e, hipStream_t st, const ConvW& w, const void* x, void* c, 
     }
     const double osz = out_dt == FS2_BF16 ? 2 : 4;
     const double fl = 2.0 * M * (double)a.N * a.K;
-    const double by = (double)M * w.Cin * e->esz + (double)a.N * a.K * e->esz + (double)M * a.N * osz;
+    const double wsz = w.dt == FS2_BF16 ? 2 : 4;
+    const double by = (double)M * w.Cin * wsz + (double)a.N * a.K * wsz + (double)M * a.N * osz;
     Bracket br(e, w.taps > 1 ? FS2_K_CONV_GEMM : FS2_K_GEMM, st, fl, by);
     Bracket br2(e, extra_class >= 0 ? extra_class : FS2_K_COUNT - 1, st, fl, by, extra_class >= 0);
-    const int r = launch_gemm(a, e->dt, out_dt, st);
+    const int r = launch_gemm(a, w.dt, out_dt, st);
     if (r != FS2_OK) return fail(e, r, "gemm launch failed (M=%d N=%d K=%d)", M, a.N, a.K);
     return FS2_OK;
 }
-int dwconv(fs2_engine* e, hipStream_t st, const DwW& w, const void* x, void* y, int B, int S) {
+int dwconv(fs2_engine* e, hipStream_t st, const DwW& w, const void* x, void* y, int B, int S, int dt) {
     DwConvArgs a;
     a.x = x; a.w = w.w; a.bias = w.b; a.y = y;
     a.B = B; a.S = S; a.C = w.C; a.k = w.k; a.pad = (w.k - 1) / 2;
-    Bracket br(e, FS2_K_ROWOPS, st, 2.0 * B * S * (double)w.C * w.k, 2.0 * B * S * (double)w.C * e->esz);
-    const int r = launch_dwconv(a, e->dt, st);
+    Bracket br(e, FS2_K_ROWOPS, st, 2.0 * B * S * (double)w.C * w.k, 2.0 * B * S * (double)w.C * (dt == FS2_BF16 ? 2 : 4));
+    const int r = launch_dwconv(a, dt, st);
     if (r != FS2_OK) return fail(e, r, "dwconv launch failed");
     return FS2_OK;
 }
@@ -498,37 +516,38 @@ struct LayerScratch {
 // half of the ping-pong pair).
 int conformer(fs2_engine* e, hipStream_t st, const LayerW& w, void* x, void* tmp, int B, int S, int heads,
               const LayerScratch& sc, bool is_decoder) {
-    const int H = e->cfg.hidden, M = B * S;
-    CHK(gemm(e, st, w.in_proj, x, sc.qkv, M, M, false, e->dt));
+    const int H = e->cfg.hidden, M = B * S, dt = w.in_proj.dt;
+    const double dsz = dt == FS2_BF16 ? 2 : 4;
+    CHK(gemm(e, st, w.in_proj, x, sc.qkv, M, M, false, dt));
     AttnArgs a;
     a.qkv = sc.qkv; a.vt = sc.vt; a.kbits = sc.bits; a.out = sc.att;
     a.B = B; a.S = S; a.H = H; a.heads = heads; a.Spad = sc.Spad; a.nw64 = sc.nw64;
     a.scale_log2e = (float)(1.4426950408889634 / sqrt((double)(H / heads)));
     {
-        Bracket br(e, FS2_K_ROWOPS, st, 0, 2.0 * M * H * e->esz);
-        const int r = launch_transpose_v(a, e->dt, st);
+        Bracket br(e, FS2_K_ROWOPS, st, 0, 2.0 * M * H * dsz);
+        const int r = launch_transpose_v(a, dt, st);
         if (r != FS2_OK) return fail(e, r, "transpose_v launch failed");
     }
     {
-        Bracket br(e, FS2_K_ATTENTION, st, 4.0 * B * (double)S * S * H, 4.0 * M * H * e->esz);
-        const int r = launch_attention(a, e->dt, st);
+        Bracket br(e, FS2_K_ATTENTION, st, 4.0 * B * (double)S * S * H, 4.0 * M * H * dsz);
+        const int r = launch_attention(a, dt, st);
         if (r != FS2_OK) return fail(e, r, "attention launch failed");
     }
     {   // tmp = LN1(x + out_proj(att))
         LnFuse ln;
         ln.res = x; ln.g = w.g1; ln.b = w.b1; ln.tmp = sc.proj;
-        CHK(gemm(e, st, w.out_proj, sc.att, tmp, M, M, false, e->dt, &ln));
+        CHK(gemm(e, st, w.out_proj, sc.att, tmp, M, M, false, dt, &ln));
     }
     if (w.depthwise) {
-        CHK(dwconv(e, st, w.dw, tmp, sc.u, B, S));
-        CHK(gemm(e, st, w.c1, sc.u, sc.hid, M, S, true, e->dt));
+        CHK(dwconv(e, st, w.dw, tmp, sc.u, B, S, dt));
+        CHK(gemm(e, st, w.c1, sc.u, sc.hid, M, S, true, dt));
     } else {
-        CHK(gemm(e, st, w.c1, tmp, sc.hid, M, S, true, e->dt, nullptr, is_decoder ? FS2_K_DEC_FFN_CONV1 : -1));
+        CHK(gemm(e, st, w.c1, tmp, sc.hid, M, S, true, dt, nullptr, is_decoder ? FS2_K_DEC_FFN_CONV1 : -1));
     }
     {   // x = LN2(tmp + conv2(hid))
         LnFuse ln;
         ln.res = tmp; ln.g = w.g2; ln.b = w.b2; ln.tmp = sc.proj;
-        CHK(gemm(e, st, w.c2, sc.hid, x, M, S, false, e->dt, &ln));
+        CHK(gemm(e, st, w.c2, sc.hid, x, M, S, false, dt, &ln));
     }
     return FS2_OK;
 }
@@ -537,13 +556,13 @@ int conformer(fs2_engine* e, hipStream_t st, const LayerW& w, void* x, void* tmp
 int predictor(fs2_engine* e, hipStream_t st, const PredictorW& P, const void* x, int B, int S, const uint8_t* mask,
               float* pred, const LayerScratch& sc) {
     const int M = B * S;
-    if (P.wpk && e->fuse_predictor && predictor_fused_supported(e->dt, P.filt, P.layers[0].c.taps, (int)P.layers.size(), S)) {
+    if (P.wpk && e->fuse_predictor && predictor_fused_supported(P.dt, P.filt, P.layers[0].c.taps, (int)P.layers.size(), S)) {
         PredictorArgs a;
         a.x = x; a.wpk = P.wpk; a.bias = P.bias_all; a.ln_g = P.g_all; a.ln_b = P.b_all;
         a.head_w = P.head_w; a.head_b = P.head_b; a.mask = mask; a.pred = pred;
         a.B = B; a.S = S; a.H = P.filt; a.nlayers = (int)P.layers.size(); a.taps = P.layers[0].c.taps; a.eps = 1e-5f;
         const double fl = 2.0 * M * (double)P.filt * P.filt * a.taps * a.nlayers;
-        const double by = (double)M * P.filt * e->esz + (double)M * 4;
+        const double by = (double)M * P.filt * 2 + (double)M * 4;
         Bracket br(e, FS2_K_CONV_GEMM, st, fl, by);
         const int r = launch_predictor_fused(a, st);
         if (r != FS2_OK) return fail(e, r, "fused predictor launch failed (B=%d S=%d)", B, S);
@@ -562,12 +581,12 @@ int predictor(fs2_engine* e, hipStream_t st, const PredictorW& P, const void* x,
         ln.g = Lw.g; ln.b = Lw.b;
         if (last) { ln.dot_w = P.head_w; ln.dot_b = P.head_b; ln.mask = mask; ln.pred = pred; }
         if (Lw.depthwise) {
-            CHK(dwconv(e, st, Lw.dw, src, sc.u, B, S));
+            CHK(dwconv(e, st, Lw.dw, src, sc.u, B, S, P.dt));
             ln.tmp = other;  // src (= other for j > 0) is dead once the depth-wise conv has run
-            CHK(gemm(e, st, Lw.c, sc.u, last ? nullptr : out, M, S, true, e->dt, &ln));
+            CHK(gemm(e, st, Lw.c, sc.u, last ? nullptr : out, M, S, true, P.dt, &ln));
         } else {
             ln.tmp = sc.u;
-            CHK(gemm(e, st, Lw.c, src, last ? nullptr : out, M, S, true, e->dt, &ln));
+            CHK(gemm(e, st, Lw.c, src, last ? nullptr : out, M, S, true, P.dt, &ln));
         }
         src = out;
     }
@@ -603,6 +622,23 @@ int take_layer_scratch(fs2_engine* e, Arena& ar, int B, int S, LayerScratch* sc)
     sc->bits = (uint64_t*)ar.take((size_t)B * sc->nw64 * 8);
     if (!sc->qkv || !sc->att || !sc->proj || !sc->hid || !sc->u || !sc->vt || !sc->bits)
         return fail(e, FS2_ERR_NOMEM, "scratch arena too small");
+    return FS2_OK;
+}
+
+size_t persist_bytes(const fs2_engine* e, int B, int L) {
+    const size_t H = e->cfg.hidden, ML = (size_t)B * L, esz = e->esz;
+    return al((size_t)B * H * 4) + 2 * al(ML * H * esz) + al(ML * 4) + 2 * al(ML * 4) + 2 * al((size_t)B * 4) + al(ML) + 4096;
+}
+size_t decode_scratch_bytes(const fs2_engine* e, int B, int T) {
+    const size_t H = e->cfg.hidden, MT = (size_t)B * T, esz = e->esz;
+    return layer_scratch_bytes(e, B, T) + 2 * al(MT * H * esz) + al(MT) + (size_t)e->cfg.n_variances * al(MT * 4) + 4096;
+}
+// Grow-only engine arena, or the caller's buffer (fs2_set_workspace) which must already be large enough.
+int ensure_arena(fs2_engine* e, Arena& ar, size_t need, const char* what) {
+    if (need > ar.cap && !ar.external) HIPCHK(e, hipDeviceSynchronize());  // earlier work may still read the old block
+    if (ar.reserve(need) != FS2_OK)
+        return fail(e, FS2_ERR_NOMEM, ar.external ? "caller workspace too small: %s needs %zu bytes (fs2_workspace_bytes)"
+                                                  : "%s arena: hipMalloc of %zu bytes failed", what, need);
     return FS2_OK;
 }
 
@@ -648,6 +684,8 @@ int fs2_create(const fs2_config* cfg, fs2_engine** out) {
     const int r = check_config(e);
     if (r != FS2_OK) return r;
     e->dt = cfg->dtype;
+    e->fdt = cfg->dtype == FS2_BF16 ? FS2_BF16 : FS2_F32;
+    e->bdt = cfg->dtype == FS2_F32 ? FS2_F32 : FS2_BF16;
     e->esz = cfg->dtype == FS2_BF16 ? 2 : 4;
     build_spec(e);
     return FS2_OK;
@@ -698,19 +736,19 @@ int fs2_finalize(fs2_engine* e) {
     CHK(up_vec(e, "speaker_embedding.projection.bias", &e->spk_b));
     e->enc.resize(c.enc_layers);
     for (int i = 0; i < c.enc_layers; ++i)
-        CHK(make_layer(e, "encoder.layers." + std::to_string(i), H, c.enc_filter, c.enc_depthwise, &e->enc[i]));
+        CHK(make_layer(e, "encoder.layers." + std::to_string(i), H, c.enc_filter, c.enc_depthwise, &e->enc[i], e->fdt));
     e->dec.resize(c.dec_layers);
     for (int i = 0; i < c.dec_layers; ++i)
-        CHK(make_layer(e, "decoder.layers." + std::to_string(i), H, c.dec_filter, c.dec_depthwise, &e->dec[i]));
-    CHK(make_predictor(e, "variance_adaptor.duration_predictor", c.dur_nlayers, c.dur_filter, c.dur_depthwise, &e->dur));
+        CHK(make_layer(e, "decoder.layers." + std::to_string(i), H, c.dec_filter, c.dec_depthwise, &e->dec[i], e->bdt));
+    CHK(make_predictor(e, "variance_adaptor.duration_predictor", c.dur_nlayers, c.dur_filter, c.dur_depthwise, &e->dur, e->fdt));
     e->vars.resize(c.n_variances);
     for (int v = 0; v < c.n_variances; ++v) {
         const std::string p = std::string("variance_adaptor.encoders.") + c.var_names[v];
-        CHK(make_predictor(e, p + ".predictor", c.var_nlayers[v], c.var_filter, c.var_depthwise, &e->vars[v].pred));
+        CHK(make_predictor(e, p + ".predictor", c.var_nlayers[v], c.var_filter, c.var_depthwise, &e->vars[v].pred, e->fdt));
         CHK(up_vec(e, p + ".bins", &e->vars[v].bins));
         CHK(up_vec(e, p + ".embedding.weight", &e->vars[v].emb));
     }
-    CHK(make_conv(e, "linear.weight", "linear.bias", &e->mel));
+    CHK(make_conv(e, "linear.weight", "linear.bias", &e->mel, e->bdt));
     e->priors_w.resize(c.n_priors);
     for (int p = 0; p < c.n_priors; ++p) {
         const std::string q = std::string("prior_embeddings.") + c.prior_names[p];
@@ -737,6 +775,41 @@ int fs2_set_debug(fs2_engine* e, int32_t on) {
     return FS2_OK;
 }
 
+int fs2_set_zero_pad_mel(fs2_engine* e, int32_t on) {
+    if (!e) return FS2_ERR_ARG;
+    e->zero_pad_mel = on != 0;
+    return FS2_OK;
+}
+
+int fs2_workspace_bytes(const fs2_engine* e, int32_t B, int32_t L, int32_t T, size_t* persist, size_t* scratch) {
+    if (!e || B <= 0 || L <= 0 || T < 0) return FS2_ERR_ARG;
+    if (persist) *persist = persist_bytes(e, B, L);
+    if (scratch) {
+        const size_t enc = layer_scratch_bytes(e, B, L), dec = T > 0 ? decode_scratch_bytes(e, B, T) : 0;
+        *scratch = enc > dec ? enc : dec;
+    }
+    return FS2_OK;
+}
+
+int fs2_set_workspace(fs2_engine* e, void* persist, size_t persist_bytes_, void* scratch, size_t scratch_bytes_) {
+    if (!e || (persist == nullptr) != (scratch == nullptr)) return e ? fail(e, FS2_ERR_ARG, "give both buffers or neither") : FS2_ERR_ARG;
+    if (((uintptr_t)persist | (uintptr_t)scratch) & 255) return fail(e, FS2_ERR_ARG, "workspace buffers must be 256-byte aligned");
+    if (e->mid_forward && (char*)persist != e->persist.base)
+        return fail(e, FS2_ERR_STATE, "the persist buffer holds the encoder state between fs2_encode and fs2_decode: only scratch may change there");
+    if (!e->mid_forward) e->persist.adopt(persist, persist_bytes_);
+    e->scratch.adopt(scratch, scratch_bytes_);
+    return FS2_OK;
+}
+
+int fs2_set_frames(fs2_engine* e, int32_t T) {
+    if (!e) return FS2_ERR_ARG;
+    if (!e->encoded) return fail(e, FS2_ERR_STATE, "fs2_set_frames without a preceding successful fs2_encode");
+    if (T < e->T) return fail(e, FS2_ERR_ARG, "fs2_set_frames can only pad: T=%d < this batch's %d", T, e->T);
+    if (T > e->cfg.max_frames || T > e->cfg.pe_len) return fail(e, FS2_ERR_SHAPE, "T=%d exceeds max_frames/positional table", T);
+    e->T = T;
+    return FS2_OK;
+}
+
 int fs2_encode(fs2_engine* e, const int64_t* phones, const float* speaker, int32_t B, int32_t L,
                const int32_t* forced, void* stream, int32_t* T_out) {
     if (!e || !phones || !speaker || !T_out || B <= 0 || L <= 0) return e ? fail(e, FS2_ERR_ARG, "bad encode argument") : FS2_ERR_ARG;
@@ -746,17 +819,14 @@ int fs2_encode(fs2_engine* e, const int64_t* phones, const float* speaker, int32
     const fs2_config& c = e->cfg;
     const size_t H = c.hidden, ML = (size_t)B * L, esz = e->esz;
     e->encoded = false;
+    e->mid_forward = false;
     e->B = B;
     e->L = L;
     e->taps.clear();
     // the arenas are reused across calls: earlier work on this stream that still reads them is
     // ordered before the kernels below; a (rare) growth reallocates after a device sync
-    const size_t need_p = al((size_t)B * H * 4) + 2 * al(ML * H * esz) + al(ML * 4) + 2 * al(ML * 4) + 2 * al((size_t)B * 4) + al(ML) + 4096;
-    if (need_p > e->persist.cap) HIPCHK(e, hipDeviceSynchronize());
-    if (e->persist.reserve(need_p) != FS2_OK) return fail(e, FS2_ERR_NOMEM, "persist arena %zu bytes", need_p);
-    const size_t need_s = layer_scratch_bytes(e, B, L);
-    if (need_s > e->scratch.cap) HIPCHK(e, hipDeviceSynchronize());
-    if (e->scratch.reserve(need_s) != FS2_OK) return fail(e, FS2_ERR_NOMEM, "scratch arena %zu bytes", need_s);
+    CHK(ensure_arena(e, e->persist, persist_bytes(e, B, L), "persist"));
+    CHK(ensure_arena(e, e->scratch, layer_scratch_bytes(e, B, L), "scratch"));
     e->spk = (float*)e->persist.take((size_t)B * H * 4);
     e->xA = e->persist.take(ML * H * esz);
     e->xB = e->persist.take(ML * H * esz);
@@ -781,7 +851,7 @@ int fs2_encode(fs2_engine* e, const int64_t* phones, const float* speaker, int32
         SpkProjArgs sp{speaker, e->spk_w, e->spk_b, e->spk, B, (int)H, c.dvec_dim};
         if (launch_spk_proj(sp, st) != FS2_OK) return fail(e, FS2_ERR_HIP, "spk_proj launch failed");
         EmbedArgs em{phones, e->phone_table, e->pe, e->spk, e->xA, e->src_mask, B, L, (int)H, c.n_phones};
-        if (launch_embed(em, e->dt, st) != FS2_OK) return fail(e, FS2_ERR_HIP, "embed launch failed");
+        if (launch_embed(em, e->fdt, st) != FS2_OK) return fail(e, FS2_ERR_HIP, "embed launch failed");
         MaskBitsArgs mb{e->src_mask, sc.bits, B, L, sc.nw64};
         if (launch_mask_bits(mb, st) != FS2_OK) return fail(e, FS2_ERR_HIP, "mask_bits launch failed");
     }
@@ -791,14 +861,14 @@ int fs2_encode(fs2_engine* e, const int64_t* phones, const float* speaker, int32
         const size_t need_d = al(ML * H * 4) + 4096;
         if (need_d > e->dbg_enc.cap) HIPCHK(e, hipDeviceSynchronize());
         if (e->dbg_enc.reserve(need_d) != FS2_OK) return fail(e, FS2_ERR_NOMEM, "debug arena");
-        CHK(tap_store(e, st, "encoder_out", e->xA, ML * H, e->dt, &e->dbg_enc));
+        CHK(tap_store(e, st, "encoder_out", e->xA, ML * H, e->fdt, &e->dbg_enc));
     }
     if (c.n_priors) {                                                        // fastspeech2.py:687-692
         if (!e->priors_dev || e->priors_B != B) return fail(e, FS2_ERR_STATE, "fs2_set_priors(B=%d) required before fs2_encode", B);
         for (int p = 0; p < c.n_priors; ++p) {
             BucketArgs ba{e->xA, e->priors_dev + (size_t)p * B, e->priors_w[p].bins, e->priors_w[p].emb, c.var_nbins,
                           1.0f, 0.0f, nullptr, nullptr, e->xA, nullptr, B, L, (int)H, nullptr, 1};
-            if (launch_bucket_embed(ba, e->dt, st) != FS2_OK) return fail(e, FS2_ERR_HIP, "prior embedding launch failed");
+            if (launch_bucket_embed(ba, e->fdt, st) != FS2_OK) return fail(e, FS2_ERR_HIP, "prior embedding launch failed");
         }
         e->priors_dev = nullptr;  // one-shot
     }
@@ -817,6 +887,7 @@ int fs2_encode(fs2_engine* e, const int64_t* phones, const float* speaker, int32
     if (e->T > c.pe_len) return fail(e, FS2_ERR_SHAPE, "T=%d exceeds positional table %d", e->T, c.pe_len);
     *T_out = e->T;
     e->encoded = true;
+    e->mid_forward = true;
     return FS2_OK;
 }
 
@@ -845,11 +916,10 @@ int fs2_decode(fs2_engine* e, const fs2_outputs* out, void* stream) {
     if (out->duration_prediction) HIPCHK(e, hipMemcpyAsync(out->duration_prediction, e->dur_pred, ML * 4, hipMemcpyDeviceToDevice, st));
     if (out->duration_rounded) HIPCHK(e, hipMemcpyAsync(out->duration_rounded, e->d_dur, ML * 4, hipMemcpyDeviceToDevice, st));
     if (out->src_mask) HIPCHK(e, hipMemcpyAsync(out->src_mask, e->src_mask, ML, hipMemcpyDeviceToDevice, st));
-    if (T == 0) { e->encoded = false; return FS2_OK; }
+    if (T == 0) { e->encoded = false; e->mid_forward = false; return FS2_OK; }
 
-    const size_t need_s = layer_scratch_bytes(e, B, T) + 2 * al(MT * H * esz) + al(MT) + (size_t)c.n_variances * al(MT * 4) + 4096;
-    if (need_s > e->scratch.cap) HIPCHK(e, hipDeviceSynchronize());
-    if (e->scratch.reserve(need_s) != FS2_OK) return fail(e, FS2_ERR_NOMEM, "scratch arena %zu bytes", need_s);
+    CHK(ensure_arena(e, e->scratch, decode_scratch_bytes(e, B, T), "scratch"));  // too small: the caller may retry with more
+    e->mid_forward = false;  // from here on the encoder state is consumed by this call
     void* yA = e->scratch.take(MT * H * esz);
     void* yB = e->scratch.take(MT * H * esz);
     // mask / variance predictions go straight into the caller's buffers when it wants them
@@ -869,11 +939,11 @@ int fs2_decode(fs2_engine* e, const fs2_outputs* out, void* stream) {
     {   // length regulator                                                  model.py:311,349-370
         Bracket br(e, FS2_K_ROWOPS, st, 0, 2.0 * MT * H * esz);
         RegulateArgs ra{e->xA, e->d_cum, e->d_totals, yA, tmask, B, L, T, (int)H};
-        if (launch_regulate(ra, e->dt, st) != FS2_OK) return fail(e, FS2_ERR_HIP, "regulate launch failed");
+        if (launch_regulate(ra, e->fdt, st) != FS2_OK) return fail(e, FS2_ERR_HIP, "regulate launch failed");
         MaskBitsArgs mb{tmask, sc.bits, B, T, sc.nw64};
         if (launch_mask_bits(mb, st) != FS2_OK) return fail(e, FS2_ERR_HIP, "mask_bits launch failed");
     }
-    if (e->debug) CHK(tap_store(e, st, "regulated", yA, MT * H, e->dt));
+    if (e->debug) CHK(tap_store(e, st, "regulated", yA, MT * H, e->fdt));
     // frame-level variance encoders, sequential                            model.py:315-333
     const bool fuse_pe = !e->debug;
     for (int v = 0; v < c.n_variances; ++v) {
@@ -889,17 +959,23 @@ int fs2_decode(fs2_engine* e, const fs2_outputs* out, void* stream) {
         BucketArgs ba{yA, vpred[v], e->vars[v].bins, e->vars[v].emb, c.var_nbins, c.var_std[v], c.var_mean[v],
                       (last && fuse_pe) ? e->pe : nullptr, (last && fuse_pe) ? e->spk : nullptr, yA, idx, B, T, (int)H,
                       e->forced_idx[v], 0, e->forced_tgt[v]};
-        if (launch_bucket_embed(ba, e->dt, st) != FS2_OK) return fail(e, FS2_ERR_HIP, "bucket_embed launch failed");
+        if (launch_bucket_embed(ba, e->fdt, st) != FS2_OK) return fail(e, FS2_ERR_HIP, "bucket_embed launch failed");
     }
-    if (e->debug) CHK(tap_store(e, st, "adaptor_out", yA, MT * H, e->dt));
+    if (e->debug) CHK(tap_store(e, st, "adaptor_out", yA, MT * H, e->fdt));
     if (!fuse_pe || c.n_variances == 0) {  // y = (x + pe) + spk               fastspeech2.py:705-718
         BucketArgs ba{yA, nullptr, nullptr, nullptr, 0, 0.f, 0.f, e->pe, e->spk, yA, nullptr, B, T, (int)H, nullptr};
-        if (launch_bucket_embed(ba, e->dt, st) != FS2_OK) return fail(e, FS2_ERR_HIP, "pe/spk add launch failed");
+        if (launch_bucket_embed(ba, e->fdt, st) != FS2_OK) return fail(e, FS2_ERR_HIP, "pe/spk add launch failed");
+    }
+    if (e->fdt != e->bdt) {  // FS2_MIXED: the decoder's input, rounded once to the back dtype (yB is free until layer 0 writes it)
+        ConvertArgs ca{yA, yB, MT * H};
+        if (launch_convert(ca, e->fdt, e->bdt, st) != FS2_OK) return fail(e, FS2_ERR_HIP, "front -> back conversion failed");
+        std::swap(yA, yB);
     }
     for (int i = 0; i < c.dec_layers; ++i)                                   // fastspeech2.py:719-721
         CHK(conformer(e, st, e->dec[i], yA, yB, B, T, c.dec_heads, sc, true));
-    if (e->debug) CHK(tap_store(e, st, "decoder_out", yA, MT * H, e->dt));
-    if (out->mel) CHK(gemm(e, st, e->mel, yA, out->mel, (int)MT, (int)MT, false, FS2_F32));  // fastspeech2.py:723
+    if (e->debug) CHK(tap_store(e, st, "decoder_out", yA, MT * H, e->bdt));
+    if (out->mel)                                                            // fastspeech2.py:723
+        CHK(gemm(e, st, e->mel, yA, out->mel, (int)MT, (int)MT, false, FS2_F32, nullptr, -1, e->zero_pad_mel ? tmask : nullptr));
     for (int v = 0; v < FS2_MAX_VARIANCES; ++v) e->forced_idx[v] = nullptr, e->forced_tgt[v] = nullptr;  // one-shot
     return FS2_OK;
 }

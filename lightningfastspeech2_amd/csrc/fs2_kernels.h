@@ -31,9 +31,12 @@ struct GemmArgs {
     float* pred = nullptr;          // (M)
     void* ln_tmp = nullptr;         // (M, ldc) scratch for the unfused fallback
     int xcd_remap = 0;              // set by the launcher
+    const uint8_t* zero_rows = nullptr;  // (M) 1 = store zeros for this row (128x128 kernel only: the mel head)
 };
 int launch_gemm(const GemmArgs& a, int in_dtype, int out_dtype, hipStream_t stream);
 extern int g_gemm_variant;
+extern int g_wide_ln;
+extern int g_attn_nw;
 extern int g_slab_xcd_remap;  // 1 = XCD-contiguous tile order in the slab kernel (A/B knob)  // test/bench knob: 0 auto, 1 force the 128x128 kernel, 2 force the DMA kernel
 
 struct AttnArgs {

@@ -26,7 +26,7 @@ static constexpr int TILE_BYTES = BM * ROWB;           // 16 KiB per operand per
 
 __device__ inline int swz(int row, int slot) { return row * ROWB + ((slot ^ (row & 7)) << 4); }
 
-template <typename T, typename OutT>
+template <typename T, typename OutT, bool ZR = false>
 __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sX = smem;                   // [2][TILE_BYTES]
@@ -136,11 +136,13 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmArgs p) {
         for (int mi = 0; mi < 4; ++mi) {
             const int m = m0 + wm * 64 + mi * 16 + fr;
             if (m >= p.M) continue;
+            const bool zr = ZR && p.zero_rows[m];
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 v[r] = acc[ni][mi][r] + bv[r];
                 if (p.relu) v[r] = fmaxf(v[r], 0.f);
+                if (ZR) v[r] = zr ? 0.f : v[r];
             }
             OutT* dst = C + (size_t)m * p.ldc + n;
             if (n + 3 < p.N) {
@@ -359,7 +361,14 @@ template <int MI> struct SlabCfg {
 static constexpr int S_BN = 256;
 template <bool B> struct BoolC { static constexpr bool value = B; };
 
-template <typename T, typename OutT, int MI, bool LN>
+// WIDE (with LN): the fused LayerNorm epilogue for N > 256.  A workgroup still owns whole rows, but walks the
+// N / 256 column tiles one after the other (each a complete K loop): per tile it stores the pre-norm values
+// v = act(acc + bias) + res and keeps per-row partial sums of v and v^2 in registers; after the last tile the
+// row statistics are exchanged through LDS and the workgroup re-reads ITS OWN rows (just written, L2-resident),
+// normalises them in place and, for a predictor's last layer, evaluates the Linear(filter, 1) head.  That
+// replaces a GEMM launch + a stand-alone LayerNorm launch (one more HBM round trip of the (M, N) tensor and of
+// the residual) for hidden sizes 768 / 1024 (BASELINE configs C3 / C5).
+template <typename T, typename OutT, int MI, bool LN, bool WIDE = false>
 __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-resource builtins only exist in the device pass
     using Cfg = SlabCfg<MI>;
@@ -383,10 +392,12 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
         const int nt = gridDim.x, per = nt >> 3, rem = nt & 7, xcd = bid & 7;
         bid = xcd * per + (xcd < rem ? xcd : rem) + (bid >> 3);
     }
-    const int bn = bid % tiles_n; bid /= tiles_n;
+    int bn = 0;
+    if constexpr (!WIDE) { bn = bid % tiles_n; bid /= tiles_n; }
     const int tm = bid % tiles_m, ub = bid / tiles_m;
     if (ub >= nutt) return;
-    const int t0 = tm * BMs, n0 = bn * S_BN;
+    const int t0 = tm * BMs;
+    int n0 = bn * S_BN;
     const T* __restrict__ Xu = (const T*)p.X + (size_t)ub * S * p.ldx;  // this utterance's rows
     const int ntap = p.taps, ncc = p.Cin / KE;
     // Operands are fetched with buffer loads straight into LDS: a descriptor per operand in SGPRs,
@@ -414,12 +425,15 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
         svoff[i] = ok ? (unsigned)t * (unsigned)(p.ldx * (int)sizeof(T)) + (unsigned)((ps ^ (row & 7)) << 4) : OOB;  // < 4 GiB (xbytes)
     }
     unsigned wvoff[DWI];
+    auto set_wvoff = [&]() {
 #pragma unroll
-    for (int i = 0; i < DWI; ++i) {
-        const int P = (i * DW + (wave & (DW - 1))) * 64 + lane, row = P >> 3, ps = P & 7;
-        const int n = n0 + row;
-        wvoff[i] = n < p.N ? (unsigned)n * (unsigned)(p.K * (int)sizeof(T)) + (unsigned)((ps ^ wswz(row)) << 4) : OOB;  // < 4 GiB (wbytes)
-    }
+        for (int i = 0; i < DWI; ++i) {
+            const int P = (i * DW + (wave & (DW - 1))) * 64 + lane, row = P >> 3, ps = P & 7;
+            const int n = n0 + row;
+            wvoff[i] = n < p.N ? (unsigned)n * (unsigned)(p.K * (int)sizeof(T)) + (unsigned)((ps ^ wswz(row)) << 4) : OOB;  // < 4 GiB (wbytes)
+        }
+    };
+    set_wvoff();
     auto issue_slab = [&](unsigned char* dst, int cc) {
         if (!dma_wave) return;
 #pragma unroll
@@ -437,11 +451,6 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
     };
 
     f32x4_t acc[4][MI];  // [ni][mi]
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < MI; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
     const int wm = wave >> 2, wn = wave & 3;
     const int fr = lane & 15, fg = lane >> 4;
     const int xrow0 = wm * (MI * 16) + fr;  // slab row of fragment 0 at tap 0
@@ -449,42 +458,6 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
     // with 16-byte loads that land underneath the first operand DMAs instead of sitting, exposed,
     // between the K loop and the row statistics.
     const bool res_in_acc = LN && p.res && !p.relu;
-    if constexpr (LN) {
-        if (res_in_acc) {
-            const T* R = (const T*)p.res + (size_t)ub * S * p.ldc;
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                int t = t0 + wm * (MI * 16) + mi * 16 + fr;
-                if (t >= S) t = S - 1;  // rows past the utterance end are never stored
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int n = wn * 64 + j * 32 + fg * 8;
-                    const T* src = R + (size_t)t * p.ldc + n;
-                    float rv[8];
-                    if (n + 7 < p.N) {
-                        if constexpr (sizeof(T) == 4) {
-                            const float4 q0 = *(const float4*)src, q1 = *(const float4*)(src + 4);
-                            rv[0] = q0.x; rv[1] = q0.y; rv[2] = q0.z; rv[3] = q0.w;
-                            rv[4] = q1.x; rv[5] = q1.y; rv[6] = q1.z; rv[7] = q1.w;
-                        } else {
-                            const uint4 q = *(const uint4*)src;
-                            const unsigned w4[4] = {q.x, q.y, q.z, q.w};
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                rv[2 * e] = __uint_as_float(w4[e] << 16);
-                                rv[2 * e + 1] = __uint_as_float(w4[e] & 0xffff0000u);
-                            }
-                        }
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 8; ++r) rv[r] = (n + r < p.N) ? Num<T>::to_f32(src[r]) : 0.f;
-                    }
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) acc[2 * j + (r >> 2)][mi][r & 3] = rv[r];
-                }
-            }
-        }
-    }
     int woff[4][2];                          // weight fragment byte offsets (tap independent)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -523,6 +496,60 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
         if ((tapv) == 0 && (ccv) + 1 < ncc) issue_slab(slab_nxt, (ccv) + 1);                \
         compute(slab_cur, w_cur, (tapv));                                                   \
     }
+    float ws1[WIDE ? MI : 1], ws2[WIDE ? MI : 1];  // WIDE: this lane's share of sum(v), sum(v^2) per row, over all tiles
+    if constexpr (WIDE) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) ws1[mi] = ws2[mi] = 0.f;
+    }
+    const int nct = WIDE ? tiles_n : 1;
+    for (int ct = 0; ct < nct; ++ct) {  // WIDE: one pass of the whole K loop per 256-column tile; otherwise once
+    if constexpr (WIDE) {
+        n0 = ct * S_BN;
+        if (ct) {
+            __syncthreads();  // every wave has left the previous tile's last step: its operand buffers are free
+            set_wvoff();
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < MI; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    if constexpr (LN) {
+        if (res_in_acc) {
+            const T* R = (const T*)p.res + (size_t)ub * S * p.ldc;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                int t = t0 + wm * (MI * 16) + mi * 16 + fr;
+                if (t >= S) t = S - 1;  // rows past the utterance end are never stored
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int n = n0 + wn * 64 + j * 32 + fg * 8;
+                    const T* src = R + (size_t)t * p.ldc + n;
+                    float rv[8];
+                    if (n + 7 < p.N) {
+                        if constexpr (sizeof(T) == 4) {
+                            const float4 q0 = *(const float4*)src, q1 = *(const float4*)(src + 4);
+                            rv[0] = q0.x; rv[1] = q0.y; rv[2] = q0.z; rv[3] = q0.w;
+                            rv[4] = q1.x; rv[5] = q1.y; rv[6] = q1.z; rv[7] = q1.w;
+                        } else {
+                            const uint4 q = *(const uint4*)src;
+                            const unsigned w4[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                rv[2 * e] = __uint_as_float(w4[e] << 16);
+                                rv[2 * e + 1] = __uint_as_float(w4[e] & 0xffff0000u);
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) rv[r] = (n + r < p.N) ? Num<T>::to_f32(src[r]) : 0.f;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) acc[2 * j + (r >> 2)][mi][r & 3] = rv[r];
+                }
+            }
+        }
+    }
     issue_slab(slab0, 0);
     issue_w(wt0, 0, 0);
     for (int cc = 0; cc < ncc; cc += 2) {
@@ -537,9 +564,134 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
             }
         }
     }
+    if constexpr (WIDE) {
+        // this column tile's pre-norm values v = act(acc + bias) + res: row partial sums + one 16-byte store per
+        // 8 consecutive channels (columns past N come out of the K loop as exact zeros and stay zero)
+        const float lo = p.relu ? 0.f : -__builtin_inff();
+        OutT* __restrict__ Cp = (OutT*)(p.C ? p.C : p.ln_tmp) + (size_t)ub * S * p.ldc;
+        const T* R = (p.res && !res_in_acc) ? (const T*)p.res + (size_t)ub * S * p.ldc : nullptr;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + fg * 8;
+            float bv[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) bv[r] = (p.bias && n + r < p.N) ? p.bias[n + r] : 0.f;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int t = t0 + wm * (MI * 16) + mi * 16 + fr;
+                float v[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] = fmaxf(acc[2 * j + (r >> 2)][mi][r & 3] + bv[r], lo);
+                if (R) {
+                    const T* src = R + (size_t)(t < S ? t : S - 1) * p.ldc + n;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) if (n + r < p.N) v[r] += Num<T>::to_f32(src[r]);
+                }
+                if (n + 7 >= p.N) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) if (n + r >= p.N) v[r] = 0.f;
+                }
+                float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) { a1 += v[r]; a2 = __builtin_fmaf(v[r], v[r], a2); }
+                ws1[mi] += a1;
+                ws2[mi] += a2;
+                if (t < S && n < p.N) {
+                    OutT* dst = Cp + (size_t)t * p.ldc + n;
+                    if (n + 7 < p.N) {
+                        if constexpr (sizeof(OutT) == 4) {
+                            *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+                            *(float4*)(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                        } else {
+                            *(uint4*)dst = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]),
+                                                      pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) if (n + r < p.N) dst[r] = Num<OutT>::from_f32(v[r]);
+                    }
+                }
+            }
+        }
+    }
+    }  // column tiles
 #undef FS2_SLAB_STEP
 
-    if constexpr (LN) {
+    if constexpr (WIDE) {
+        // ---- row statistics over all column tiles, then normalise this workgroup's own rows in place ----
+        static_assert(sizeof(T) == sizeof(OutT), "the wide LayerNorm epilogue rewrites its own output");
+        const size_t rowbase = (size_t)ub * S;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pre-norm stores have left the CU ...
+        __syncthreads();  // ... and so have everyone else's (one CU, one L1: visible to the whole workgroup); buffers free
+        float* red = (float*)slab0;  // [2][4 column waves][BMs rows]
+        float* lnp = (float*)wt0;    // [gamma N | beta N | head weight N], N <= 1024
+        for (int i = tid; i < p.N; i += 512) {
+            lnp[i] = p.ln_g[i];
+            lnp[p.N + i] = p.ln_b[i];
+            lnp[2 * p.N + i] = p.dot_w ? p.dot_w[i] : 0.f;
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const float a1 = group4_sum(ws1[mi]), a2 = group4_sum(ws2[mi]);
+            if (fg == 0) {
+                const int row = wm * (MI * 16) + mi * 16 + fr;
+                red[wn * BMs + row] = a1;
+                red[(4 + wn) * BMs + row] = a2;
+            }
+        }
+        __syncthreads();
+        constexpr int E16 = 16 / (int)sizeof(T);          // elements per 16-byte chunk
+        constexpr int MAXC = 1024 / E16 / 64;             // chunks per lane at N = 1024
+        constexpr int RB = sizeof(T) == 2 ? 4 : 2;        // rows in flight per wave
+        const int nch = p.N / E16;
+        const float invn = 1.0f / (float)p.N;
+        T* __restrict__ Cp = (T*)(p.C ? p.C : p.ln_tmp) + rowbase * p.ldc;
+        for (int rb = wave * RB; rb < BMs; rb += 8 * RB) {
+            uint4 q[RB][MAXC];
+#pragma unroll
+            for (int k = 0; k < RB; ++k) {
+                const int t = t0 + rb + k;
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c) {
+                    const int ch = lane + 64 * c;
+                    if (ch < nch && t < S) q[k][c] = *(const uint4*)(Cp + (size_t)t * p.ldc + ch * E16);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < RB; ++k) {
+                const int row = rb + k, t = t0 + row;
+                if (t >= S) continue;
+                const float s1 = (red[row] + red[BMs + row]) + (red[2 * BMs + row] + red[3 * BMs + row]);
+                const float s2 = (red[4 * BMs + row] + red[5 * BMs + row]) + (red[6 * BMs + row] + red[7 * BMs + row]);
+                const float mean = s1 * invn;
+                const float var = fmaxf(__builtin_fmaf(-mean, mean, s2 * invn), 0.f);
+                const float rstd = 1.0f / sqrtf(var + p.ln_eps);
+                float dsum = 0.f;
+#pragma unroll
+                for (int c = 0; c < MAXC; ++c) {
+                    const int ch = lane + 64 * c;
+                    if (ch < nch) {
+                        float f[E16], y[E16];
+                        Vec16<T>::unpack(q[k][c], f);
+#pragma unroll
+                        for (int e = 0; e < E16; ++e) {
+                            const int n = ch * E16 + e;
+                            y[e] = __builtin_fmaf((f[e] - mean) * rstd, lnp[n], lnp[p.N + n]);
+                            dsum = __builtin_fmaf(y[e], lnp[2 * p.N + n], dsum);
+                        }
+                        if (p.C) *(uint4*)(Cp + (size_t)t * p.ldc + ch * E16) = Vec16<T>::pack(y);
+                    }
+                }
+                if (p.dot_w) {
+                    dsum = wave_sum(dsum) + p.dot_b;
+                    if (lane == 0) p.pred[rowbase + t] = (p.mask && p.mask[rowbase + t]) ? 0.f : dsum;
+                }
+            }
+        }
+        return;
+    }
+
+    if constexpr (LN && !WIDE) {
         // ---- fused row epilogue: the workgroup owns whole rows (tiles_n == 1) ----
         // LayerNorm(act(acc + bias) [+ res]) with two-pass statistics: lane partials -> lane-group
         // shuffles -> one LDS exchange between the four column waves; optional predictor head.
@@ -791,14 +943,14 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
 #endif
 }
 
-template <typename T, typename OutT, int MI, bool LN>
+template <typename T, typename OutT, int MI, bool LN, bool WIDE = false>
 static int launch_slab_t(const GemmArgs& a0, hipStream_t stream) {
     GemmArgs a = a0;
     if (a.taps == 1) a.S = a.M;  // plain GEMM: one "utterance" of M rows
     a.xcd_remap = g_slab_xcd_remap;
     const int BMs = SlabCfg<MI>::BM;
-    const int tiles = (a.M / a.S) * ((a.S + BMs - 1) / BMs) * ((a.N + S_BN - 1) / S_BN);
-    hipLaunchKernelGGL((gemm_conv_slab_kernel<T, OutT, MI, LN>), dim3(tiles), dim3(512), 0, stream, a);
+    const int tiles = (a.M / a.S) * ((a.S + BMs - 1) / BMs) * (WIDE ? 1 : (a.N + S_BN - 1) / S_BN);
+    hipLaunchKernelGGL((gemm_conv_slab_kernel<T, OutT, MI, LN, WIDE>), dim3(tiles), dim3(512), 0, stream, a);
     return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
 }
 
@@ -806,7 +958,12 @@ template <int MI>
 static int launch_slab(const GemmArgs& a, int in_dtype, int out_dtype, hipStream_t stream) {
     if (a.ln_g) {  // fused LayerNorm epilogue: whole rows per workgroup, tile heights 128 / 192 only
         if constexpr (MI <= 6) {
-            if (a.N > S_BN) return FS2_ERR_SHAPE;
+            if (a.N > S_BN) {  // wide rows: column tiles walked inside the workgroup, normalised in place
+                if (a.N > 1024 || (!a.C && !a.ln_tmp)) return FS2_ERR_SHAPE;
+                if (in_dtype == FS2_F32 && out_dtype == FS2_F32) return launch_slab_t<float, float, MI, true, true>(a, stream);
+                if (in_dtype == FS2_BF16 && out_dtype == FS2_BF16) return launch_slab_t<bf16, bf16, MI, true, true>(a, stream);
+                return FS2_ERR_SHAPE;
+            }
             if (in_dtype == FS2_F32 && out_dtype == FS2_F32) return launch_slab_t<float, float, MI, true>(a, stream);
             if (in_dtype == FS2_BF16 && out_dtype == FS2_BF16) return launch_slab_t<bf16, bf16, MI, true>(a, stream);
         }
@@ -818,23 +975,28 @@ static int launch_slab(const GemmArgs& a, int in_dtype, int out_dtype, hipStream
     return FS2_ERR_SHAPE;
 }
 
-template <typename T, typename OutT>
+template <typename T, typename OutT, bool ZR = false>
 static int launch_t(const GemmArgs& a, hipStream_t stream) {
     static bool attr_set = false;
     const size_t smem = 4 * TILE_BYTES;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)gemm_conv_kernel<T, OutT>,
+        hipError_t e = hipFuncSetAttribute((const void*)gemm_conv_kernel<T, OutT, ZR>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return FS2_ERR_HIP;
         attr_set = true;
     }
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-    hipLaunchKernelGGL((gemm_conv_kernel<T, OutT>), dim3(tiles), dim3(256), smem, stream, a);
+    hipLaunchKernelGGL((gemm_conv_kernel<T, OutT, ZR>), dim3(tiles), dim3(256), smem, stream, a);
     return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
 }
 
 int g_gemm_variant = 0;
 int g_slab_xcd_remap = 1;
+// 1 = rows wider than 256 by the in-place WIDE epilogue, 0 = GEMM launch + stand-alone LayerNorm launch.  Measured on
+// MI355X (tools/bench_ops.py wide, r02): the WIDE form only ties at M = 49152, K = 768 (118 vs 120 us) and LOSES
+// elsewhere (K = 3072: 357 vs 294 us - a workgroup re-streams its x tile once per column tile and 32 such tiles per XCD
+// do not fit the 4 MiB L2; M = 8192 / 12288: 1.5-2.2x slower - a third or a quarter of the workgroups), so it is OFF.
+int g_wide_ln = 0;
 
 static int launch_gemm_plain(const GemmArgs& a, int in_dtype, int out_dtype, hipStream_t stream, bool* fused);
 
@@ -843,7 +1005,7 @@ int launch_gemm(const GemmArgs& a, int in_dtype, int out_dtype, hipStream_t stre
     // fused row epilogue requested: try the slab kernel (whole rows per workgroup), else GEMM -> ln_tmp
     // followed by the stand-alone LayerNorm kernel (same arithmetic, one more HBM round trip)
     bool fused = false;
-    if (a.N <= S_BN && in_dtype == out_dtype) {
+    if ((a.N <= S_BN || (g_wide_ln && a.N <= 1024 && (a.C || a.ln_tmp))) && in_dtype == out_dtype) {
         const int r = launch_gemm_plain(a, in_dtype, out_dtype, stream, &fused);
         if (r != FS2_OK || fused) return r;
     }
@@ -868,6 +1030,12 @@ static int launch_gemm_plain(const GemmArgs& a, int in_dtype, int out_dtype, hip
     const int e16 = in_dtype == FS2_BF16 ? 8 : 4;
     if (a.K % ke || a.Cin % ke || a.ldx % e16 || a.K != a.taps * a.Cin) return FS2_ERR_SHAPE;
     if (a.ldc % 4) return FS2_ERR_SHAPE;
+    if (a.zero_rows) {  // the mel head with zeroed pad rows: 128x128 kernel only
+        if (fused) return FS2_ERR_SHAPE;
+        if (in_dtype == FS2_F32 && out_dtype == FS2_F32) return launch_t<float, float, true>(a, stream);
+        if (in_dtype == FS2_BF16 && out_dtype == FS2_F32) return launch_t<bf16, float, true>(a, stream);
+        return FS2_ERR_SHAPE;
+    }
     const int variant = g_gemm_variant;  // 0 = auto, 1 = 128x128 register-staged, 2 = 128x256 DMA ring,
                                          // 3/4/5 = slab kernel with 128/192/256-row tiles
     const bool slab_ok = a.M % a.S == 0 && (a.taps & 1);
@@ -901,8 +1069,10 @@ static int launch_gemm_plain(const GemmArgs& a, int in_dtype, int out_dtype, hip
         for (int hi = 0; hi < 5; ++hi) {                  // (the encoder's) spread over all CUs
             const int mi = kHeights[hi];
             if (fused && mi > 6) continue;
-            const long bm = mi * 32, tm = (S + bm - 1) / bm, tiles = (long)nutt * tm * tn;
-            const long cost = ((tiles + 255) / 256) * (bm + 40);
+            const long bm = mi * 32, tm = (S + bm - 1) / bm;
+            const bool wide = fused && tn > 1;  // one workgroup per row tile walks all tn column tiles
+            const long tiles = (long)nutt * tm * (wide ? 1 : tn);
+            const long cost = ((tiles + 255) / 256) * (bm + 40) * (wide ? tn : 1);
             if (!best || cost < best_cost) { best = mi; best_cost = cost; best_rows = (long)nutt * tm * bm; }
         }
         if (best_rows <= 2L * a.M) {

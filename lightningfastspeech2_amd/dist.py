@@ -2,18 +2,28 @@
 
 The path shards naturally: utterances are independent (no cross-utterance math anywhere in
 ``FastSpeech2.forward`` — SURVEY.md §8e), weights are replicated, every rank runs the full forward
-on its own contiguous shard *as its own padded batch* (what the reference does per rank under
-Lightning DDP, or per ``--batch_size`` chunk in generate.py:186-195).  The only exchange is the
-final mel tensors: one all-gather of the per-rank frame counts (so ranks with different T_r can be
-padded to a common T) and one all-gather of the (B_r, T, n_mels) fp32 mels — RCCL over xGMI when
-the process group is "nccl", gloo in the CPU tests.  No collective touches the forward itself.
+on its own contiguous shard.  Two padding modes:
+
+* per-shard (default): a shard is *its own padded batch* — what the reference does per rank under
+  Lightning DDP, or per ``--batch_size`` chunk in generate.py:186-195.  Because the reference's convs
+  are unmasked, pad rows leak into valid frames, so the result equals the reference run
+  on that shard alone, not the whole-batch run.
+* global pad (``global_pad=True``): every shard keeps the whole batch's phone length and pads its frames
+  to the whole batch's T — one 8-byte all-reduce(MAX) between the two phases of the forward — and the
+  gathered result equals the whole-batch run exactly.
+
+The only bulk exchange is the final mel tensors: an all-gather of the (B_r, T, n_mels) fp32 mels plus
+the per-utterance frame counts — RCCL over xGMI when the process group is "nccl", gloo in the CPU
+tests.  No collective touches the forward's arithmetic.
 """
 from __future__ import annotations
 
-from typing import Callable, Dict, Tuple
+from typing import Callable, Dict, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
+
+PHONE_LEVEL_KEYS = ("phones", "duration")  # (B, L) entries of the collate format (datasets.py:852-882)
 
 
 def shard_bounds(B: int, world: int, rank: int) -> Tuple[int, int]:
@@ -23,26 +33,36 @@ def shard_bounds(B: int, world: int, rank: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def shard_batch(batch: Dict[str, torch.Tensor], world: int, rank: int) -> Dict[str, torch.Tensor]:
+def shard_batch(batch: Dict[str, torch.Tensor], world: int, rank: int, *, trim: bool = True,
+                phone_level_keys: Sequence[str] = PHONE_LEVEL_KEYS) -> Dict[str, torch.Tensor]:
+    """This rank's contiguous rows of every per-utterance entry.  ``trim``: cut the phone axis of
+    EVERY per-phone (B, L) entry (phones, duration, ...) to the shard's longest utterance, so that the
+    shard is its own padded batch and teacher-forced durations stay aligned with the phones."""
     B = batch["phones"].shape[0]
     lo, hi = shard_bounds(B, world, rank)
     out = {}
     for k, v in batch.items():
         out[k] = v[lo:hi] if hasattr(v, "shape") and len(v.shape) > 0 and v.shape[0] == B else v
-    # each shard is its own padded batch: trim the phone axis to the shard's longest utterance
     ph = out["phones"]
-    if ph.numel():
+    if trim and ph.numel():
         lens = (ph != 0).sum(dim=1)
         # pads are a suffix in the collate format (datasets.py:878-880)
         Lr = max(int(lens.max()), 1)
-        out["phones"] = ph[:, :Lr].contiguous()
+        L = ph.shape[1]
+        for k in phone_level_keys:
+            v = out.get(k)
+            if v is None or not hasattr(v, "shape") or len(v.shape) < 2 or v.shape[1] != L:
+                continue
+            if k != "phones" and bool((torch.as_tensor(v)[:, Lr:] != 0).any()):
+                raise ValueError(f"batch[{k!r}] has non-zero entries beyond the shard's longest utterance")
+            out[k] = v[:, :Lr].contiguous()
     return out
 
 
 class MelGather:
     """An all-gather of the final mels in flight (``gather_mels_async``); ``wait()`` -> (mel_all, frames).
     The exchange runs on the collective library's own stream, so a caller that keeps launching the next
-    forward overlaps it with compute; nothing here blocks the host except the tiny shape exchange."""
+    forward overlaps it with compute."""
 
     def __init__(self, works, all_mel, all_fr, Bs, B_max):
         self._works, self._all_mel, self._all_fr, self._Bs, self._B_max = works, all_mel, all_fr, Bs, B_max
@@ -51,38 +71,51 @@ class MelGather:
         for w in self._works:
             w.wait()   # nccl: the current stream waits for the collective's stream; gloo: host wait
         self._works = []
-        if all(b == self._B_max for b in self._Bs):
+        if self._Bs is None or all(b == self._B_max for b in self._Bs):
             return self._all_mel, self._all_fr
         dev = self._all_mel.device
         keep = torch.cat([torch.arange(r * self._B_max, r * self._B_max + b, device=dev) for r, b in enumerate(self._Bs)])
         return self._all_mel[keep], self._all_fr[keep]
 
 
-def gather_mels_async(mel: torch.Tensor, tgt_mask: torch.Tensor, group=None) -> MelGather:
+def gather_mels_async(mel: torch.Tensor, tgt_mask: torch.Tensor, group=None, *,
+                      shapes: Optional[Tuple[Sequence[int], int]] = None, zeroed: bool = False) -> MelGather:
     """Start the all-gather of every rank's final mels.
 
     mel (B_r, T_r, n_mels) fp32 and tgt_mask (B_r, T_r) bool (True = pad) of this rank; the result of
     ``wait()`` is ``(mel_all (B, T_max, n_mels), frames (B,) int64)`` on every rank, utterances in global
-    batch order, rows beyond an utterance's frame count zeroed.  Two steps: the per-rank (B_r, T_r)
-    pairs (16 bytes, read back on the host to size the buffers), then the padded mels and the frame
-    counts as asynchronous collectives.
+    batch order, rows beyond an utterance's frame count zero.
+
+    ``shapes = (Bs, T_max)``: every rank's utterance count and the common frame capacity are already known
+    to all ranks (a fixed batch split with global-pad mode or fixed-length inputs; ``forward_sharded``
+    passes it in global-pad mode) — then nothing is exchanged or read back on the host before the
+    collectives are queued.  Otherwise the per-rank (B_r, T_r) pairs are all-gathered and read back first
+    (16 bytes, one host sync).
+    ``zeroed``: the pad rows of ``mel`` are already zero (``Engine.set_zero_pad_mel``, fused into the mel
+    GEMM's store) — skips the masking pass over the mel.
     """
     world = dist.get_world_size(group)
     dev = mel.device
     B_r, T_r, n_mels = mel.shape
-    meta = torch.tensor([B_r, T_r], dtype=torch.int64, device=dev)
-    metas = torch.empty(world * 2, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(metas, meta, group=group)
-    metas = metas.cpu().view(world, 2)
-    Bs = [int(b) for b in metas[:, 0]]
-    T_max, B_max = int(metas[:, 1].max()), max(Bs)
+    if shapes is None:
+        meta = torch.tensor([B_r, T_r], dtype=torch.int64, device=dev)
+        metas = torch.empty(world * 2, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(metas, meta, group=group)
+        metas = metas.cpu().view(world, 2)
+        Bs = [int(b) for b in metas[:, 0]]
+        T_max = int(metas[:, 1].max())
+    else:
+        Bs, T_max = [int(b) for b in shapes[0]], int(shapes[1])
+        if len(Bs) != world or B_r != Bs[dist.get_rank(group)] or T_r > T_max:
+            raise ValueError(f"shapes={shapes} do not describe this rank's mel {tuple(mel.shape)}")
+    B_max = max(Bs)
     frames_r = (~tgt_mask).sum(dim=1).to(torch.int64)
+    src = mel if zeroed else mel * (~tgt_mask).unsqueeze(-1)
     if B_r == B_max and T_r == T_max:
-        buf = mel * (~tgt_mask).unsqueeze(-1)
-        fr = frames_r
+        buf, fr = src.contiguous(), frames_r
     else:
         buf = torch.zeros(B_max, T_max, n_mels, dtype=mel.dtype, device=dev)
-        buf[:B_r, :T_r] = mel * (~tgt_mask).unsqueeze(-1)
+        buf[:B_r, :T_r] = src
         fr = torch.zeros(B_max, dtype=torch.int64, device=dev)
         fr[:B_r] = frames_r
     all_mel = torch.empty(world * B_max, T_max, n_mels, dtype=mel.dtype, device=dev)
@@ -92,16 +125,59 @@ def gather_mels_async(mel: torch.Tensor, tgt_mask: torch.Tensor, group=None) -> 
     return MelGather(works, all_mel, all_fr, Bs, B_max)
 
 
-def gather_mels(mel: torch.Tensor, tgt_mask: torch.Tensor, group=None):
+def gather_mels(mel: torch.Tensor, tgt_mask: torch.Tensor, group=None, **kw):
     """Blocking form of :func:`gather_mels_async`."""
-    return gather_mels_async(mel, tgt_mask, group=group).wait()
+    return gather_mels_async(mel, tgt_mask, group=group, **kw).wait()
 
 
-def forward_sharded(forward_fn: Callable[[Dict[str, torch.Tensor]], Dict[str, torch.Tensor]],
-                    batch: Dict[str, torch.Tensor], group=None):
-    """Run ``forward_fn`` (e.g. ``lambda b: model(b, inference=True)``) on this rank's shard of
-    ``batch`` and gather every rank's mels.  Returns (mel_all, frames, local_result)."""
+def global_frames(T_local: int, device, group=None) -> int:
+    """max over the ranks of the local frame count: the T the whole batch would be padded to."""
+    t = torch.tensor([int(T_local)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return int(t.item())
+
+
+def forward_sharded(forward_fn: Callable[..., Dict[str, torch.Tensor]], batch: Dict[str, torch.Tensor], group=None, *,
+                    global_pad: bool = False, n_mels: Optional[int] = None, zeroed: bool = False):
+    """Run ``forward_fn`` on this rank's shard of ``batch`` and gather every rank's mels.
+
+    per-shard mode: ``forward_fn(shard)`` (e.g. ``lambda b: model(b, inference=True)``).
+    global-pad mode: ``forward_fn(shard, frames_hook)`` — the hook must be handed to the model's forward
+    (``model.forward(b, True, frames_hook=hook)``); it all-reduces the frame count between the two phases.
+    Ranks whose shard is empty (global batch smaller than the world) skip the forward and contribute an
+    empty mel.  Returns (mel_all, frames, local_result or None)."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    local = forward_fn(shard_batch(batch, world, rank))
-    mel_all, frames = gather_mels(local["mel"], local["tgt_mask"], group=group)
+    B = batch["phones"].shape[0]
+    Bs = [hi - lo for lo, hi in (shard_bounds(B, world, r) for r in range(world))]
+    local_batch = shard_batch(batch, world, rank, trim=not global_pad)
+    dev = None
+    t_glob = {}
+
+    def hook(T_local):
+        t_glob["T"] = global_frames(T_local, dev if dev is not None else torch.device("cpu"), group)
+        return t_glob["T"]
+
+    if Bs[rank] == 0:
+        local = None
+        if n_mels is None:
+            raise ValueError("a world larger than the batch leaves empty shards: pass n_mels so that they can join the gather")
+        ref = batch["speaker"] if isinstance(batch.get("speaker"), torch.Tensor) else torch.zeros(0)
+        dev = ref.device
+        if global_pad:
+            hook(0)  # the ranks that do have utterances are waiting in the all-reduce
+        mel = torch.zeros(0, 0, n_mels, dtype=torch.float32, device=dev)
+        mask = torch.zeros(0, 0, dtype=torch.bool, device=dev)
+    else:
+        if global_pad:
+            sp = local_batch["speaker"]
+            dev = sp.device if isinstance(sp, torch.Tensor) else torch.device("cpu")
+            local = forward_fn(local_batch, hook)
+        else:
+            local = forward_fn(local_batch)
+        mel, mask = local["mel"], local["tgt_mask"]
+        dev = mel.device
+        if mel.device != mask.device:
+            mask = mask.to(mel.device)
+    shapes = (Bs, t_glob["T"]) if global_pad else None
+    mel_all, frames = gather_mels(mel, mask, group=group, shapes=shapes, zeroed=zeroed)
     return mel_all, frames, local

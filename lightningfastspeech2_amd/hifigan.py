@@ -163,9 +163,13 @@ class HifiGan:
             raise RuntimeError("the HiFi-GAN generator runs on an MI355X only (no CPU fallback)")
         self.lib = _bind(_lib.load())
         self.dtype = {"bf16": _lib.FS2_BF16, "fp32": _lib.FS2_F32}[precision]
-        torch.cuda.set_device(self.device)
         self.handle = C.c_void_p()
         cc = _config_to_c(cfg, self.dtype)
+        with torch.cuda.device(self.device):  # no global set_device: the reference Synthesiser has no such side effect
+            self._init(cfg, cc, state_dict)
+        self._last = None
+
+    def _init(self, cfg, cc, state_dict):
         st = self.lib.fs2_voc_create(C.byref(cc), C.byref(self.handle))
         if st != 0:
             raise RuntimeError(f"fs2_voc_create: {_lib.load().fs2_status_string(st).decode()}")
@@ -181,7 +185,6 @@ class HifiGan:
                         f"load_weight {name}")
         self._check(self.lib.fs2_voc_finalize(self.handle), "finalize")
         self.hop = int(self.lib.fs2_voc_hop(self.handle))
-        self._last = None
 
     def _check(self, status, what):
         if status != 0:
@@ -206,9 +209,10 @@ class HifiGan:
         wav = torch.zeros(B, T * self.hop, dtype=torch.float32, device=self.device)
         ld = None if lengths is None else lengths.to(self.device, torch.int32).contiguous()
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        self._check(self.lib.fs2_voc_synthesize(self.handle, C.c_void_p(mel.data_ptr()),
-                                                None if ld is None else C.c_void_p(ld.data_ptr()), B, T,
-                                                C.c_void_p(wav.data_ptr()), stream), "synthesize")
+        with torch.cuda.device(self.device):  # arena hipMalloc + launches must hit the engine's device
+            self._check(self.lib.fs2_voc_synthesize(self.handle, C.c_void_p(mel.data_ptr()),
+                                                    None if ld is None else C.c_void_p(ld.data_ptr()), B, T,
+                                                    C.c_void_p(wav.data_ptr()), stream), "synthesize")
         self._last = (B, T)
         return wav
 
@@ -217,7 +221,8 @@ class HifiGan:
         up = int(np.prod(self.cfg.upsample_rates[:stage])) if stage else 1
         t = torch.empty(B, T * up, self.cfg.channels()[stage], dtype=torch.float32, device=self.device)
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        self._check(self.lib.fs2_voc_debug_copy(self.handle, stage, C.c_void_p(t.data_ptr()), stream), "debug_copy")
+        with torch.cuda.device(self.device):
+            self._check(self.lib.fs2_voc_debug_copy(self.handle, stage, C.c_void_p(t.data_ptr()), stream), "debug_copy")
         return t
 
 

@@ -48,15 +48,18 @@ class FastSpeech2Loss:
                 raise NotImplementedError(f"FastSpeech2Loss: this {what} configuration is outside the built path "
                                           "(frame-level 'none' variances, 'l1'/'mse', deterministic durations)")
         self.lib = _lib.load()  # raises if the HIP library is missing
-        self._ws: Dict[torch.device, torch.Tensor] = {}
+        # one workspace (partials + the "done" counter) per (device, stream): launches on two streams must not share it
+        self._ws: Dict[tuple, torch.Tensor] = {}
 
     def _masked_mean(self, pred: torch.Tensor, truth: torch.Tensor, truth_kind: int, pad_mask: torch.Tensor,
                      inner: int, kind: str) -> torch.Tensor:
         dev = pred.device
         if dev.type != "cuda":
             raise RuntimeError("FastSpeech2Loss runs on the GPU the forward ran on (no CPU path)")
-        if dev not in self._ws:
-            self._ws[dev] = torch.zeros(int(self.lib.fs2_op_masked_loss_ws_bytes()), dtype=torch.uint8, device=dev)
+        stream = torch.cuda.current_stream(dev)
+        key = (dev, stream.cuda_stream)
+        if key not in self._ws:
+            self._ws[key] = torch.zeros(int(self.lib.fs2_op_masked_loss_ws_bytes()), dtype=torch.uint8, device=dev)
         pred = pred.to(torch.float32).contiguous()
         truth = truth.to(device=dev).contiguous()
         truth = truth.to(torch.float32) if truth_kind == 0 else truth.to(torch.int64)
@@ -65,8 +68,9 @@ class FastSpeech2Loss:
         if pred.numel() != rows * inner or truth.numel() != rows * inner:
             raise ValueError(f"shape mismatch: pred {tuple(pred.shape)}, truth {tuple(truth.shape)}, mask {tuple(mask.shape)}")
         out = torch.empty(2, dtype=torch.float32, device=dev)
-        st = self.lib.fs2_op_masked_loss(_ptr(pred), _ptr(truth), truth_kind, _ptr(mask), rows, inner, _KIND[kind],
-                                         _ptr(self._ws[dev]), _ptr(out), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        with torch.cuda.device(dev):
+            st = self.lib.fs2_op_masked_loss(_ptr(pred), _ptr(truth), truth_kind, _ptr(mask), rows, inner, _KIND[kind],
+                                             _ptr(self._ws[key]), _ptr(out), C.c_void_p(stream.cuda_stream))
         _lib.check(st, None, "fs2_op_masked_loss")
         return out[0]
 

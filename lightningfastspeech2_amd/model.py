@@ -21,7 +21,9 @@ import torch
 from . import _lib
 from .config import Fs2Config
 
-_PRECISIONS = {"fp32": _lib.FS2_F32, "f32": _lib.FS2_F32, "bf16": _lib.FS2_BF16}
+# "mixed": fp32 for everything a discrete decision hangs on (encoder, durations, variance predictors / buckets),
+# bf16 for the decoder + mel head (include/fs2.h: FS2_MIXED)
+_PRECISIONS = {"fp32": _lib.FS2_F32, "f32": _lib.FS2_F32, "bf16": _lib.FS2_BF16, "mixed": _lib.FS2_MIXED}
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -31,8 +33,14 @@ def _ptr(t: Optional[torch.Tensor]):
 class Engine:
     """Thin owner of one ``fs2_engine`` handle (one per device)."""
 
-    def __init__(self, cfg: Fs2Config, state_dict, precision: str = "fp32", device="cuda:0"):
+    def __init__(self, cfg: Fs2Config, state_dict, precision: str = "fp32", device="cuda:0",
+                 torch_workspace: bool = True):
         self.lib = _lib.load()
+        # torch_workspace: the forward's device workspace comes from torch's caching allocator through
+        # fs2_workspace_bytes / fs2_set_workspace (SURVEY 8b: caller-owned memory); False = the
+        # engine's own grow-only hipMalloc arenas
+        self.torch_workspace = torch_workspace
+        self._ws_persist = self._ws_scratch = None
         if not torch.cuda.is_available():
             raise RuntimeError("lightningfastspeech2_amd needs an MI355X (no CPU fallback for the product path)")
         self.cfg = cfg
@@ -50,6 +58,7 @@ class Engine:
                 self.close()
                 raise
         self._last = None
+        self._t_hint = {}
 
     def _load(self, state_dict):
         from .weights import state_dict_spec
@@ -90,11 +99,46 @@ class Engine:
         if priors is not None:  # (n_priors, B) fp32 on the device
             _lib.check(self.lib.fs2_set_priors(self.handle, _ptr(priors), B), self.handle, "set_priors")
         with torch.cuda.device(self.device):
+            if self.torch_workspace:  # sized for the frame count this (B, L) produced last time, if any
+                self._ensure_workspace(B, L, self._t_hint.get((B, L), 0))
             st = self.lib.fs2_encode(self.handle, _ptr(phones), _ptr(speaker), B, L, _ptr(forced_durations),
                                      self._stream(), C.byref(T))
         _lib.check(st, self.handle, "encode")
         self._last = (B, L, T.value)
+        self._t_hint[(B, L)] = T.value
         return T.value
+
+    def workspace_bytes(self, B: int, L: int, T: int = 0):
+        """(persist_bytes, scratch_bytes) a (B, L) encode and a T-frame decode need (fs2_workspace_bytes)."""
+        pb, sb = C.c_size_t(), C.c_size_t()
+        _lib.check(self.lib.fs2_workspace_bytes(self.handle, B, L, T, C.byref(pb), C.byref(sb)), self.handle,
+                   "workspace_bytes")
+        return pb.value, sb.value
+
+    def _ensure_workspace(self, B: int, L: int, T: int):
+        pb, sb = self.workspace_bytes(B, L, T)
+        grow_p = self._ws_persist is None or self._ws_persist.numel() < pb
+        grow_s = self._ws_scratch is None or self._ws_scratch.numel() < sb
+        if not (grow_p or grow_s):
+            return
+        # torch's allocator returns >= 512-byte aligned blocks and keeps freed blocks alive until the
+        # work queued on their stream has run, so replacing a buffer is safe without a device sync
+        if grow_p:
+            self._ws_persist = torch.empty(pb + pb // 8, dtype=torch.uint8, device=self.device)
+        if grow_s:
+            self._ws_scratch = torch.empty(sb + sb // 8, dtype=torch.uint8, device=self.device)
+        _lib.check(self.lib.fs2_set_workspace(self.handle, _ptr(self._ws_persist), self._ws_persist.numel(),
+                                              _ptr(self._ws_scratch), self._ws_scratch.numel()), self.handle,
+                   "set_workspace")
+
+    def set_frames(self, T: int):
+        """Pad this shard's decode to T frames (>= its own): the data-parallel global-pad mode."""
+        _lib.check(self.lib.fs2_set_frames(self.handle, int(T)), self.handle, "set_frames")
+        B, L, _ = self._last
+        self._last = (B, L, int(T))
+
+    def set_zero_pad_mel(self, on: bool):
+        _lib.check(self.lib.fs2_set_zero_pad_mel(self.handle, int(on)), self.handle, "set_zero_pad_mel")
 
     def totals(self):
         B = self._last[0]
@@ -130,6 +174,9 @@ class Engine:
 
     def decode(self, want_aux: bool = True, outputs: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
         B, L, T = self._last
+        if self.torch_workspace:
+            with torch.cuda.device(self.device):
+                self._ensure_workspace(B, L, T)  # only the scratch buffer can grow here
         res = outputs
         if res is None or tuple(res["mel"].shape) != (B, T, self.cfg.n_mels):
             res = self.alloc_outputs(B, L, T, want_aux)
@@ -235,7 +282,10 @@ class FastSpeech2:
     def __call__(self, targets, inference: bool = False):
         return self.forward(targets, inference)
 
-    def forward(self, targets: dict, inference: bool = False, *, force_durations=None, force_buckets=None) -> dict:
+    def forward(self, targets: dict, inference: bool = False, *, force_durations=None, force_buckets=None,
+                frames_hook=None) -> dict:
+        """``frames_hook(T_local) -> T`` (optional) runs between the two phases and may raise the frame count
+        this batch is padded to (data-parallel global-pad mode: an all-reduce MAX over the ranks)."""
         teacher = not inference and force_durations is None
         if teacher:
             # FastSpeech2.forward(batch) as the Lightning hooks call it (fastspeech2.py:787,800):
@@ -260,7 +310,14 @@ class FastSpeech2:
         speaker = speaker.to(self.device, dtype=torch.float32).contiguous()  # fastspeech2.py:641
         forced = None
         if force_durations is not None:
-            forced = torch.as_tensor(force_durations).to(self.device, dtype=torch.int32).contiguous()
+            forced = torch.as_tensor(force_durations)
+            if forced.dim() != 2 or forced.shape[0] != phones.shape[0] or forced.shape[1] < phones.shape[1]:
+                raise ValueError(f"durations must be (B, L) = {tuple(phones.shape)}, got {tuple(forced.shape)}")
+            if forced.shape[1] > phones.shape[1]:  # a wider target is fine only if the surplus is padding
+                if bool((forced[:, phones.shape[1]:] != 0).any()):
+                    raise ValueError(f"durations {tuple(forced.shape)} carry non-zero entries beyond phones' L={phones.shape[1]}")
+                forced = forced[:, :phones.shape[1]]
+            forced = forced.to(self.device, dtype=torch.int32).contiguous()
         # Output buffers are allocated BEFORE the forward's one host sync (inside fs2_encode), sized
         # with the frame count of the previous call: in steady state (same T) the allocator work
         # overlaps the encoder instead of sitting between the two phases; a different T just
@@ -270,9 +327,16 @@ class FastSpeech2:
         pre = self.engine.alloc_outputs(B, L, guess) if guess else None
         priors = None
         if self.cfg.priors:  # utterance-level priors, fastspeech2.py:687-692
-            rows = [torch.as_tensor(np.asarray(targets[f"priors_{pr}"], dtype=np.float32)).reshape(B) for pr in self.cfg.priors]
-            priors = torch.stack(rows).to(self.device, dtype=torch.float32).contiguous()
+            # generate_from_text hands these over as device tensors (generator.py:131-146), datasets as lists/arrays
+            rows = [(v if isinstance(v, torch.Tensor) else torch.as_tensor(np.asarray(v, dtype=np.float32)))
+                    .to(self.device, dtype=torch.float32).reshape(B) for v in (targets[f"priors_{pr}"] for pr in self.cfg.priors)]
+            priors = torch.stack(rows).contiguous()
         T = self.engine.encode(phones, speaker, forced, priors)
+        if frames_hook is not None:
+            Tg = int(frames_hook(T))
+            if Tg != T:
+                self.engine.set_frames(Tg)
+                T = Tg
         self._t_guess[(B, L)] = T
         if teacher:
             for vi, var in enumerate(self.cfg.variances):

@@ -55,7 +55,9 @@ class SpeechGenerator:
         result = self.model(batch, inference=True)                       # generator.py:158
         lengths = (~result["tgt_mask"]).sum(dim=1).to(torch.int32)       # frames the reference keeps, :163
         wav = self.synth.synthesize(result["mel"], lengths)               # (B, T*hop) fp32, device
-        i16 = (wav * 32768.0).to(torch.int16).cpu().numpy()               # Synthesiser.__call__, __init__.py:39-43
+        # the float -> int16 cast happens on the host with numpy, exactly as Synthesiser.__call__ does it
+        # (__init__.py:39-43): a device-side cast of tanh's +1.0 * 32768 is out of range (undefined)
+        i16 = (wav.cpu().numpy() * 32768.0).astype("int16")
         hop = self.synth.hop
         audios: List[np.ndarray] = [int16_samples_to_float32(i16[b, :int(n) * hop]) for b, n in enumerate(lengths.tolist())]
         out = {"fs": self.model.hparams.sampling_rate, "audios": audios}

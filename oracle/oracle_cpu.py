@@ -174,7 +174,7 @@ def prior_embedding(sd, cfg, prior: str, values: torch.Tensor) -> torch.Tensor:
 
 def forward(sd, cfg, phones, speaker, *, return_intermediates: bool = False,
             force_durations: Optional[torch.Tensor] = None, priors: Optional[dict] = None,
-            teacher_targets: Optional[dict] = None) -> Dict[str, torch.Tensor]:
+            teacher_targets: Optional[dict] = None, frames_hook=None) -> Dict[str, torch.Tensor]:
     """FastSpeech2.forward(targets, inference=True), fastspeech2.py:636-731 (mel path only; the
     fastdiff_var branch :733-736 is broken at HEAD and not part of mel — SURVEY §0.6)."""
     phones = torch.as_tensor(phones).long()
@@ -204,6 +204,11 @@ def forward(sd, cfg, phones, speaker, *, return_intermediates: bool = False,
     else:
         dur_rounded, guarded = torch.as_tensor(force_durations).int(), []
     x, tgt_mask = length_regulator(x, dur_rounded, cfg.max_length * cfg.sampling_rate / cfg.hop_length)
+    if frames_hook is not None:  # data-parallel global-pad mode: pad to the frame count of the whole batch
+        Tg = int(frames_hook(x.shape[1]))  # (what pad_sequence over ALL utterances would have produced)
+        if Tg > x.shape[1]:
+            x = F.pad(x, (0, 0, 0, Tg - x.shape[1]))
+            tgt_mask = F.pad(tgt_mask, (0, Tg - tgt_mask.shape[1]), value=True)
     inter["regulated"] = x
     result = {}
     for vi, var in enumerate(cfg.variances):                                  # model.py:315-333

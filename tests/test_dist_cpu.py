@@ -40,38 +40,106 @@ def test_shard_trims_to_its_own_padding():
     assert sh["phones"].tolist() == [[6, 7]] and sh["speaker"].shape == (1, 256)
 
 
-def _worker(rank, world, port, B, q):
+def _batch(B):
+    cfg = _cfg()
+    sd = synth_state_dict(cfg, 5, randomize_norm=True, duration_bias=1.0)
+    inp = synth_inputs(cfg, B, 9, seed=3, lengths=[9, 4, 7, 2, 6][:B])
+    return cfg, sd, {"phones": torch.from_numpy(inp["phones"]), "speaker": torch.from_numpy(inp["speaker"])}
+
+
+def _worker(rank, world, port, B, q, mode="shard"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
     from oracle import oracle_cpu
-    cfg = _cfg()
-    sd = synth_state_dict(cfg, 5, randomize_norm=True, duration_bias=1.0)
-    inp = synth_inputs(cfg, B, 9, seed=3, lengths=[9, 4, 7, 2, 6][:B])
-    batch = {"phones": torch.from_numpy(inp["phones"]), "speaker": torch.from_numpy(inp["speaker"])}
-    fwd = lambda b: oracle_cpu.forward(sd, cfg, b["phones"], b["speaker"])
-    mel_all, frames, _ = forward_sharded(fwd, batch)
+    cfg, sd, batch = _batch(B)
+    if mode == "global":
+        fwd = lambda b, hook: oracle_cpu.forward(sd, cfg, b["phones"], b["speaker"], frames_hook=hook)
+        mel_all, frames, _ = forward_sharded(fwd, batch, global_pad=True, n_mels=cfg.n_mels)
+    elif mode == "teacher":  # teacher-forced durations travel with their phones (shard_batch trims both)
+        ref = oracle_cpu.forward(sd, cfg, batch["phones"], batch["speaker"])
+        batch["duration"] = ref["duration_rounded"]
+
+        def fwd(b):
+            assert b["duration"].shape == b["phones"].shape
+            return oracle_cpu.forward(sd, cfg, b["phones"], b["speaker"], force_durations=b["duration"])
+        mel_all, frames, _ = forward_sharded(fwd, batch, n_mels=cfg.n_mels)
+    else:
+        fwd = lambda b: oracle_cpu.forward(sd, cfg, b["phones"], b["speaker"])
+        mel_all, frames, _ = forward_sharded(fwd, batch, n_mels=cfg.n_mels)
     if rank == 0:
         q.put((mel_all.numpy(), frames.numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("B", [4, 5])
-def test_two_rank_gather_equals_per_shard_oracle(B):
+def _run(world, B, mode):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, B, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, B, q, mode)) for r in range(world)]
     for p in procs:
         p.start()
-    mel_all, frames = q.get(timeout=120)
+    out = q.get(timeout=180)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    return out
+
+
+def test_global_pad_mode_equals_the_whole_batch():
+    """SURVEY 8e global-pad mode on a ragged batch: shards keep the batch's phone length and pad their frames to the
+    all-reduced maximum, so the gathered mels equal the single-process whole-batch run (pad leakage included)."""
+    from oracle import oracle_cpu
+    mel_all, frames = _run(2, 5, "global")
+    cfg, sd, batch = _batch(5)
+    ref = oracle_cpu.forward(sd, cfg, batch["phones"], batch["speaker"])
+    assert mel_all.shape == tuple(ref["mel"].shape)
+    for i in range(5):
+        n = int((~ref["tgt_mask"][i]).sum())
+        assert frames[i] == n
+        np.testing.assert_allclose(mel_all[i, :n], ref["mel"][i, :n].numpy(), rtol=0, atol=1e-6)
+        assert not mel_all[i, n:].any()
+
+
+def test_world_larger_than_batch_does_not_hang():
+    """B < world leaves empty shards; they must still join the gather."""
+    from oracle import oracle_cpu
+    mel_all, frames = _run(3, 2, "shard")
+    cfg, sd, batch = _batch(2)
+    assert mel_all.shape[0] == 2
+    for r in range(2):
+        ref = oracle_cpu.forward(sd, cfg, batch["phones"][r:r + 1, :int((batch["phones"][r] != 0).sum())], batch["speaker"][r:r + 1])
+        n = int((~ref["tgt_mask"][0]).sum())
+        assert frames[r] == n
+        np.testing.assert_allclose(mel_all[r, :n], ref["mel"][0, :n].numpy(), rtol=0, atol=1e-6)
+    mel_all, frames = _run(3, 2, "global")
+    ref = oracle_cpu.forward(sd, cfg, batch["phones"], batch["speaker"])
+    np.testing.assert_allclose(mel_all[0, :int(frames[0])], ref["mel"][0, :int(frames[0])].numpy(), rtol=0, atol=1e-6)
+
+
+def test_teacher_forced_sharded_keeps_durations_aligned():
+    from oracle import oracle_cpu
+    mel_all, frames = _run(2, 5, "teacher")
+    cfg, sd, batch = _batch(5)
+    whole = oracle_cpu.forward(sd, cfg, batch["phones"], batch["speaker"])
+    row = 0
+    for r in range(2):
+        sh = shard_batch({**batch, "duration": whole["duration_rounded"]}, 2, r)
+        assert sh["duration"].shape == sh["phones"].shape
+        ref = oracle_cpu.forward(sd, cfg, sh["phones"], sh["speaker"], force_durations=sh["duration"])
+        for i in range(ref["mel"].shape[0]):
+            n = int((~ref["tgt_mask"][i]).sum())
+            np.testing.assert_allclose(mel_all[row, :n], ref["mel"][i, :n].numpy(), rtol=0, atol=1e-6)
+            row += 1
+
+
+@pytest.mark.parametrize("B", [4, 5])
+def test_two_rank_gather_equals_per_shard_oracle(B):
+    mel_all, frames = _run(2, B, "shard")
     # expected: the oracle on each shard separately (each shard is its own padded batch — pad
     # leakage makes that differ from the whole-batch result, SURVEY §0.8 / §8e)
     from oracle import oracle_cpu

@@ -1,0 +1,147 @@
+"""Boundary behaviour on the GPU (`-m gpu`): caller-owned workspace (fs2_workspace_bytes / fs2_set_workspace),
+the data-parallel aids (zeroed pad rows in the mel store, global-pad frame count) and the host mirror's argument checks."""
+import ctypes as C
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from lightningfastspeech2_amd import _lib
+from lightningfastspeech2_amd.config import Fs2Config
+from lightningfastspeech2_amd.weights import synth_inputs, synth_state_dict
+from oracle import oracle_cpu
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _cfg(**kw):
+    base = dict(n_phones=40, encoder_hidden=128, decoder_hidden=128, encoder_head=2, decoder_head=2, encoder_layers=2,
+                decoder_layers=2, encoder_kernel_sizes=[5, 9], decoder_kernel_sizes=[9, 3], encoder_conv_filter_size=256,
+                decoder_conv_filter_size=256, encoder_depthwise_conv=False, decoder_depthwise_conv=True,
+                variance_filter_size=128, variance_nlayers=[2, 2, 2], duration_filter_size=128)
+    base.update(kw)
+    return Fs2Config(**base)
+
+
+def _case(B=4, L=24, lengths=(24, 17, 9, 3), seed=5, **cfgkw):
+    cfg = _cfg(**cfgkw)
+    sd = synth_state_dict(cfg, seed, randomize_norm=True, duration_bias=1.3)
+    inp = synth_inputs(cfg, B, L, seed=seed + 1, lengths=list(lengths))
+    batch = {"phones": torch.from_numpy(inp["phones"]), "speaker": torch.from_numpy(inp["speaker"])}
+    return cfg, sd, inp, batch
+
+
+def _model(cfg, sd, precision="fp32", **kw):
+    from lightningfastspeech2_amd.model import Engine, FastSpeech2
+    m = FastSpeech2(cfg, sd, precision=precision, device="cuda:0")
+    if kw:
+        m.engine = Engine(cfg, sd, precision=precision, device="cuda:0", **kw)
+    return m
+
+
+def test_caller_workspace_matches_engine_arenas_bitwise():
+    """The same forward out of torch-allocated workspace (the default of the host mirror) and out of the engine's own
+    hipMalloc arenas: bit-equal; and a too-small caller buffer is refused with the needed size, not overrun."""
+    cfg, sd, inp, batch = _case()
+    a = _model(cfg, sd, "bf16")                       # torch workspace
+    b = _model(cfg, sd, "bf16", torch_workspace=False)  # engine arenas
+    oa, ob = a(batch, inference=True), b(batch, inference=True)
+    assert a.engine._ws_persist is not None and b.engine._ws_persist is None
+    for k in oa:
+        assert torch.equal(oa[k], ob[k]), k
+    pb, sb = a.engine.workspace_bytes(4, 24, int(oa["mel"].shape[1]))
+    pb0, sb0 = a.engine.workspace_bytes(4, 24, 0)
+    assert pb == pb0 and sb >= sb0 > 0
+    small = torch.empty(4096, dtype=torch.uint8, device="cuda:0")
+    lib = _lib.load()
+    st = lib.fs2_set_workspace(a.engine.handle, C.c_void_p(small.data_ptr()), small.numel(), C.c_void_p(small.data_ptr()), small.numel())
+    assert st == 0
+    a.engine.torch_workspace = False  # stop the mirror from replacing it
+    with pytest.raises(RuntimeError, match="workspace too small"):
+        a(batch, inference=True)
+    assert lib.fs2_set_workspace(a.engine.handle, None, 0, None, 0) == 0
+    oc = a(batch, inference=True)
+    assert torch.equal(oc["mel"], ob["mel"])
+
+
+def test_zero_pad_mel_only_touches_pad_rows():
+    cfg, sd, inp, batch = _case()
+    m = _model(cfg, sd, "fp32")
+    ref = m(batch, inference=True)
+    m.engine.set_zero_pad_mel(True)
+    out = m(batch, inference=True)
+    pad = ref["tgt_mask"]
+    assert pad.any() and torch.equal(out["mel"][~pad], ref["mel"][~pad])
+    assert not out["mel"][pad].any()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_global_pad_shard_equals_whole_batch(precision):
+    """SURVEY 8e global-pad mode on the engine: a shard that keeps the batch's phone length and is padded to the whole
+    batch's frame count (frames_hook -> fs2_set_frames) reproduces its rows of the whole-batch run bit for bit."""
+    cfg, sd, inp, batch = _case(B=5, L=24, lengths=(11, 24, 9, 16, 3))
+    m = _model(cfg, sd, precision)
+    whole = m(batch, inference=True)
+    T = int(whole["mel"].shape[1])
+    for lo, hi in ((0, 1), (2, 5)):
+        sh = {k: v[lo:hi] for k, v in batch.items()}
+        out = m.forward(sh, True, frames_hook=lambda t: T)
+        assert out["mel"].shape[1] == T
+        for k in ("mel", "tgt_mask", "duration_rounded", "variances_pitch"):
+            assert torch.equal(out[k], whole[k][lo:hi]), (k, lo)
+    with pytest.raises(RuntimeError, match="can only pad"):
+        m.forward(batch, True, frames_hook=lambda t: t - 1)
+
+
+def test_forced_durations_shape_is_checked():
+    """a duration target whose shape does not match phones must raise, never be read out of bounds."""
+    cfg, sd, inp, batch = _case()
+    m = _model(cfg, sd, "fp32")
+    ref = oracle_cpu.forward(sd, cfg, inp["phones"], inp["speaker"])
+    d = ref["duration_rounded"]
+    with pytest.raises(ValueError, match="durations must be"):
+        m.forward(batch, force_durations=d[:, :-3])
+    wide = torch.nn.functional.pad(d, (0, 4))
+    out = m.forward(batch, force_durations=wide)  # zero-padded surplus is harmless
+    assert torch.equal(out["tgt_mask"].cpu(), ref["tgt_mask"])
+    wide[0, -1] = 2
+    with pytest.raises(ValueError, match="non-zero entries beyond"):
+        m.forward(batch, force_durations=wide)
+
+
+def test_priors_may_arrive_as_device_tensors():
+    """generate_from_text puts priors in the batch as tensors on the model's device (generator.py:131-146)."""
+    stats = {v: {"min": -3.0, "max": 3.0, "mean": 0.0, "std": 1.0} for v in ("pitch", "energy", "snr")}
+    stats.update({"pitch_prior": {"min": -2.0, "max": 2.0}, "energy_prior": {"min": -2.0, "max": 2.0}})
+    cfg, sd, inp, batch = _case(priors=["pitch", "energy"], stats=stats)
+    m = _model(cfg, sd, "fp32")
+    pr = {"priors_pitch": np.array([0.1, -0.4, 1.2, 0.0], np.float32), "priors_energy": np.array([-1.0, 0.3, 0.2, 2.0], np.float32)}
+    a = m({**batch, **pr}, inference=True)
+    b = m({**batch, **{k: torch.from_numpy(v).to("cuda:0") for k, v in pr.items()}}, inference=True)
+    assert torch.equal(a["mel"], b["mel"])
+    ref = oracle_cpu.forward(sd, cfg, inp["phones"], inp["speaker"], priors=pr)
+    assert float((a["mel"].cpu() - ref["mel"]).abs().max()) <= 1e-3
+
+
+def test_two_rank_bench_rehearsal_over_gloo():
+    """bench.py's multi-rank control flow (shape agreement once, sync-free gathers with zeroed pad rows, drain, max over
+    ranks) with both ranks on this box's one GPU over gloo - the RCCL run itself needs the 8-GPU node."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, FS2_BENCH_BACKEND="gloo", FS2_BENCH_DEVICE="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--config", "ref-default", "--batch", "4", "--phones", "32"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 8 and line["value"] > 0
+    assert line["config"]["frames_per_utterance"] == 32 * 6

@@ -150,6 +150,53 @@ def test_bf16_close_under_forced_durations(case):
     assert float(err.mean()) <= 0.03 and float(err.max()) <= 0.3  # bf16 tolerance, NOT the 1e-3 claim
 
 
+def _decisions(m, cfg, batch, ref):
+    """(duration flips, bucket flips under the oracle's durations, mel max-abs under all of the oracle's decisions)"""
+    m.engine.set_debug(True)
+    free = _cpu(m(batch, inference=True))
+    dflips = int((free["duration_rounded"] != ref["duration_rounded"]).sum())
+    _cpu(m.forward(batch, force_durations=ref["duration_rounded"]))
+    bflips = sum(int((m.engine.debug_tensor(f"bucket_{v}").cpu().long() != ref["_intermediates"][f"bucket_{v}"]).sum())
+                 for v in cfg.variances)
+    out = _cpu(m.forward(batch, force_durations=ref["duration_rounded"],
+                         force_buckets={v: ref["_intermediates"][f"bucket_{v}"] for v in cfg.variances}))
+    return dflips, bflips, float((out["mel"] - ref["mel"]).abs().max()), free
+
+
+@pytest.mark.parametrize("case", ["c2arch_ragged", "refdefault_dw", "ls_h768_2layer"])
+def test_mixed_precision_is_decision_safe(case):
+    """precision="mixed" (FS2_MIXED): the encoder -> duration path and the variance-predictor chain in fp32, the decoder in
+    bf16.  Its discrete decisions must be the fp32 path's: durations equal to the oracle's, bucket flips >= 10x rarer than
+    the all-bf16 mode's (SURVEY 7 "hard parts": keep every predictor head and what feeds it out of bf16)."""
+    mk, B, L, lengths, skw = CASES[case]
+    cfg = mk()
+    sd, inp, ref = _oracle_case(cfg, B, L, lengths, seed=3, **skw)
+    batch = {"phones": torch.from_numpy(inp["phones"]), "speaker": torch.from_numpy(inp["speaker"])}
+    d16, b16, e16, _ = _decisions(_model(cfg, sd, "bf16"), cfg, batch, ref)
+    dmx, bmx, emx, free = _decisions(_model(cfg, sd, "mixed"), cfg, batch, ref)
+    nb = sum(ref["_intermediates"][f"bucket_{v}"].numel() for v in cfg.variances)
+    _report(test="mixed_vs_bf16", case=case, buckets=nb, bf16=dict(duration_flips=d16, bucket_flips=b16, mel_forced=e16),
+            mixed=dict(duration_flips=dmx, bucket_flips=bmx, mel_forced=emx))
+    assert dmx == 0 and torch.equal(free["tgt_mask"], ref["tgt_mask"])
+    assert bmx <= max(2, b16 // 10)
+    assert emx <= 0.3  # the decoder is bf16: same tolerance as the all-bf16 mode under forced decisions
+    for v in cfg.variances[:1]:  # the first predictor sees fp32 inputs identical to the parity mode's
+        assert float((free[f"variances_{v}"] - ref[f"variances_{v}"]).abs().max()) <= 1e-3
+
+
+@pytest.mark.parametrize("name", [n for n in golden_names() if "teacher" not in n])
+def test_mixed_precision_decisions_on_goldens(name):
+    g = Golden(name)
+    m = _model(g.cfg, g.state_dict(), "mixed")
+    batch = {"phones": torch.from_numpy(g.phones), "speaker": torch.from_numpy(g.speaker), **g.priors}
+    out = _cpu(m(batch, inference=True))
+    for k in ("duration_rounded", "src_mask", "tgt_mask"):
+        assert np.array_equal(out[k].numpy(), g.out[k]), k
+    err = float(np.abs(out["mel"].numpy() - g.out["mel"]).max())
+    _report(test="golden_mixed", case=name, mel_max=err, mel_scale=float(np.abs(g.out["mel"]).max()))
+    assert np.isfinite(err)
+
+
 def test_full_size_properties_bf16():
     """BASELINE.json configs[1]: FS2-27M, batch 32 x 256 phonemes, 6 frames/phone -> T = 1536."""
     cfg = preset("c2")

@@ -81,13 +81,19 @@ def test_gemm_conv_same_padding_per_utterance(dtype, B, S, Cin, N, k, gemm_varia
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("wide", [False, True], ids=["twolaunch", "widefused"])
 @pytest.mark.parametrize("variant", [0, 1, 3, 4, 6, 7], ids=["auto", "unfused128x128", "slab128", "slab192", "slab32", "slab64"])
 @pytest.mark.parametrize("B,S,Cin,N,k,relu,use_res", [(3, 200, 256, 256, 3, True, False), (2, 333, 1024, 256, 1, False, True),
                                                      (2, 70, 64, 192, 5, True, True), (1, 1536, 256, 256, 9, False, True),
-                                                     (2, 50, 768, 768, 1, False, True)])
-def test_gemm_fused_layernorm_epilogue(dtype, variant, B, S, Cin, N, k, relu, use_res):
+                                                     (2, 50, 768, 768, 1, False, True), (2, 333, 768, 768, 1, False, True),
+                                                     (2, 300, 1024, 1024, 3, True, False), (1, 700, 3072, 768, 1, False, True),
+                                                     (3, 77, 128, 320, 3, True, True)])
+def test_gemm_fused_layernorm_epilogue(dtype, wide, variant, B, S, Cin, N, k, relu, use_res):
+    if wide and N <= 256:
+        pytest.skip("one column tile: the knob changes nothing")
     """conv/GEMM -> (+ReLU) -> (+residual) -> LayerNorm (-> predictor head), fused in the slab
-    kernel's epilogue when the row fits one workgroup (N <= 256), else GEMM + LayerNorm kernel."""
+    kernel's epilogue: rows of N <= 256 channels in one tile; wider rows (768 / 1024: BASELINE configs C3 / C5)
+    by a workgroup that walks the column tiles and normalises its own rows in place."""
     x = rnd(B, S, Cin, seed=50)
     w = rnd(N, Cin, k, seed=51, scale=(Cin * k) ** -0.5)
     b, res = rnd(N, seed=52), rnd(B * S, N, seed=53)
@@ -102,6 +108,7 @@ def test_gemm_fused_layernorm_epilogue(dtype, variant, B, S, Cin, N, k, relu, us
         z = z + G.rounded(res, dtype)
     ref = F.layer_norm(z, (N,), g, be, 1e-5)
     pref = (ref @ hw + 0.3).masked_fill(mask, 0)
+    G.lib().fs2_op_set_gemm_variant(301 if wide else 300)
     G.lib().fs2_op_set_gemm_variant(variant)
     try:
         y, pred = G.gemm_ln(dtype, x.reshape(B * S, Cin), G.pack_conv_weight(w), b, res if use_res else None, g, be,
@@ -110,10 +117,33 @@ def test_gemm_fused_layernorm_epilogue(dtype, variant, B, S, Cin, N, k, relu, us
                              taps=k, S=S, relu=relu, dot_w=hw, dot_b=0.3, mask=mask, want_y=False)
     finally:
         G.lib().fs2_op_set_gemm_variant(0)
+        G.lib().fs2_op_set_gemm_variant(300)
     assert float((y - ref).abs().max()) <= tol(dtype, ref, f32=5e-5, bf16=2.5e-2)
     ptol = 1e-4 if dtype == G.F32 else 3e-2
     assert float((pred - pref).abs().max()) <= ptol * (float(pref.abs().max()) + 1)
     assert torch.equal(pred, pred2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_wide_layernorm_fused_vs_two_launches(dtype):
+    """N = 768: the in-place fused epilogue against the round-1 path (GEMM launch + LayerNorm launch, knob 300) and
+    against torch; many reruns bit-identical (the workgroup re-reads rows other waves of it have just written)."""
+    B, S, Cin, N = 3, 413, 768, 768
+    x, w = rnd(B * S, Cin, seed=60), rnd(N, Cin, 1, seed=61, scale=Cin ** -0.5)
+    b, res = rnd(N, seed=62), 2.0 + rnd(B * S, N, seed=63)  # a row mean well away from 0: sum / sum-of-squares statistics
+    g, be = 1 + 0.2 * rnd(N, seed=64), 0.1 * rnd(N, seed=65)
+    z = G.rounded(x, dtype) @ G.rounded(w[:, :, 0], dtype).T + b + G.rounded(res, dtype)
+    ref = F.layer_norm(z, (N,), g, be, 1e-5)
+    G.lib().fs2_op_set_gemm_variant(301)
+    try:
+        runs = [G.gemm_ln(dtype, x, G.pack_conv_weight(w), b, res, g, be)[0] for _ in range(12)]
+    finally:
+        G.lib().fs2_op_set_gemm_variant(300)
+    two = G.gemm_ln(dtype, x, G.pack_conv_weight(w), b, res, g, be)[0]
+    assert float((runs[0] - ref).abs().max()) <= tol(dtype, ref, f32=5e-5, bf16=2.5e-2)
+    assert float((runs[0] - two).abs().max()) <= tol(dtype, ref, f32=2e-5, bf16=2.5e-2)
+    for r in runs[1:]:
+        assert torch.equal(r, runs[0])
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -229,6 +259,31 @@ def test_attention(dtype, B, S, H, heads, mask_kind):
     got = G.attention(dtype, qkv, mask, B, S, H, heads)
     err = float((got - ref).abs().max())
     assert err <= tol(dtype, ref, f32=5e-5, bf16=2e-2), (err, tol(dtype, ref))
+
+
+@pytest.mark.parametrize("B,S,heads,mask_kind", [(2, 1000, 2, "suffix"), (1, 1536, 2, "none"), (3, 333, 2, "scatter"), (2, 192, 6, "suffix")])
+def test_attention_six_wave_query_tiles(B, S, heads, mask_kind):
+    """192-query (6-wave) workgroups, bf16 d = 128 (knob 406): the same answers as the 128-query form and as torch,
+    incl. a tail tile (S not a multiple of 192), skipped tiles and scattered masks."""
+    H = 128 * heads
+    qkv = rnd(B * S, 3 * H, seed=12)
+    mask = torch.zeros(B, S, dtype=torch.bool)
+    if mask_kind == "suffix":
+        mask[0, S - S // 3:] = True
+        mask[-1, S - 5:] = True
+    elif mask_kind == "scatter":
+        mask = torch.rand(B, S, generator=torch.Generator().manual_seed(13)) < 0.3
+        mask[:, 0] = False
+    ref = _attn_ref(G.rounded(qkv, G.BF16), mask, B, S, H, heads)
+    G.lib().fs2_op_set_gemm_variant(404)
+    try:
+        four = G.attention(G.BF16, qkv, mask, B, S, H, heads)
+        G.lib().fs2_op_set_gemm_variant(406)
+        six = G.attention(G.BF16, qkv, mask, B, S, H, heads)
+    finally:
+        G.lib().fs2_op_set_gemm_variant(400)
+    assert float((six - ref).abs().max()) <= tol(G.BF16, ref, bf16=2e-2)
+    assert torch.equal(six, four)  # a query's arithmetic does not depend on which workgroup shape carries it
 
 
 def test_attention_spike_forces_rescale():

@@ -134,10 +134,30 @@ def main():
             gemm_ln_case("enc conv2 1x1 +res+LN", 8192, 256, 1024, 1, 8192, a.reps, v)
             gemm_ln_case("enc out_proj +res+LN", 8192, 256, 256, 1, 8192, a.reps, v)
             gemm_ln_case("dur-pred conv k=3 +LN", 8192, 256, 256, 3, 256, a.reps, v, res=False, relu=True)
+    if a.what in ("wide",):  # rows wider than one tile (C3 N = 768, C5 N = 1024): fused in-place LayerNorm vs GEMM + LayerNorm launches
+        for knob in (300, 301):
+            lib.fs2_op_set_gemm_variant(knob)
+            print("---- two launches (GEMM, LayerNorm)" if knob == 300 else "---- fused wide-row LayerNorm epilogue")
+            for v in ([0] if a.variant < 0 else [a.variant]):
+                gemm_ln_case("c3 dec out_proj +res+LN", 49152, 768, 768, 1, 49152, a.reps, v)
+                gemm_ln_case("c3 dec conv2 +res+LN", 49152, 768, 3072, 1, 49152, a.reps, v)
+                gemm_ln_case("c3 pred pw +relu+LN", 49152, 768, 768, 1, 1536, a.reps, v, res=False, relu=True)
+                gemm_ln_case("c3 enc out_proj +res+LN", 8192, 768, 768, 1, 8192, a.reps, v)
+                gemm_ln_case("c3 enc conv2 +res+LN", 8192, 768, 3072, 1, 8192, a.reps, v)
+                gemm_ln_case("c5 dec out_proj +res+LN", 12288, 1024, 1024, 1, 12288, a.reps, v)
+                gemm_ln_case("c5 dec conv2 +res+LN", 12288, 1024, 4096, 1, 12288, a.reps, v)
+                gemm_ln_case("c5 pred conv k=3 +relu+LN", 12288, 1024, 1024, 3, 1536, a.reps, v, res=False, relu=True)
+        lib.fs2_op_set_gemm_variant(301)
     if a.what in ("pred", "all"):
         predictor_case("variance predictor fused", 32, 1536, 5, a.reps)
         predictor_case("duration predictor fused", 32, 256, 2, a.reps)
     if a.what in ("attn", "all"):
+        for knob in (404, 406):
+            lib.fs2_op_set_gemm_variant(knob)
+            attn_case(f"decoder attention nw={knob - 400}", 32, 1536, 256, 2, a.reps)
+            attn_case(f"c3 decoder attention nw={knob - 400}", 32, 1536, 768, 6, a.reps)
+            attn_case(f"ragged-length S=1000 nw={knob - 400}", 32, 1000, 256, 2, a.reps)
+        lib.fs2_op_set_gemm_variant(400)
         attn_case("decoder attention", 32, 1536, 256, 2, a.reps)
         attn_case("encoder attention", 32, 256, 256, 2, a.reps)
 
