@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c2", help="c2 (FS2-27M) | c3 (LS-76M) | c5 (FS2-1B) | ref-default")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "mixed"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "mixed", "mixed3"])
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
     ap.add_argument("--phones", type=int, default=256)
     ap.add_argument("--frames-per-phone", type=int, default=6)

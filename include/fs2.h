@@ -48,7 +48,8 @@ enum fs2_status {
 enum fs2_dtype {
     FS2_F32 = 0,
     FS2_BF16 = 1,
-    FS2_MIXED = 2  /* engine mode only (fs2_config.dtype): fp32 "front" + bf16 "back", see fs2_config.dtype */
+    FS2_MIXED = 2,    /* engine modes only (fs2_config.dtype): fp32 "front" + bf16 "back", see fs2_config.dtype */
+    FS2_MIXED_X3 = 3  /* the same with the front's GEMMs / convs as bf16 x 3 split products of fp32 operands */
 };
 
 /* Mirrors the hparams that shape FastSpeech2.forward (fastspeech2.py:46-130). */
@@ -61,7 +62,11 @@ typedef struct fs2_config {
                               (embedding, encoder, duration predictor and rounding, length regulator, variance
                               predictors and bucketize - model.py:259,299-309,315-333,434-438) runs as in F32, the
                               decoder and the mel head (where an error stays an error of O(bf16 rounding) in the
-                              mel) as in BF16: durations / buckets follow the fp32 path's, at bf16 decoder speed */
+                              mel) as in BF16: durations / buckets follow the fp32 path's, at bf16 decoder speed;
+                              MIXED_X3 = MIXED with the front's matrix products evaluated as hi*hi + hi*lo + lo*hi of
+                              bf16 head/tail pairs split from the fp32 operands in registers (fp32 storage,
+                              accumulation, attention, LayerNorm, heads; ~1e-5 relative per product instead of fp32's
+                              6e-8 or bf16's 4e-3): 3 bf16 MFMAs per 32 k-values instead of 8 fp32 MFMAs */
     int32_t n_phones;      /* len(phone2id) */
     int32_t hidden;        /* encoder_hidden == decoder_hidden */
     int32_t n_mels;
@@ -183,7 +188,7 @@ int fs2_profile_read(fs2_engine* e, int32_t kernel_class, double* total_ms, int6
  *   3/4/5   slab kernel, 128/192/256-row tiles   6/7   slab kernel, 32/64-row tiles
  *   200/201 slab kernel tile order: plain / XCD-contiguous (default)
  *   300/301 LayerNorm epilogue for rows wider than 256: GEMM + stand-alone LayerNorm launch (default) / in-place fused
- *   400/404/406 attention query tile on long bf16 d=128 sequences: auto / 128 queries (4 waves) / 192 queries (6 waves) */
+ *   500/501 fp32 slab-kernel launches: fp32 MFMA (default) / bf16 x 3 split products (what FS2_MIXED_X3 uses in its front) */
 int fs2_op_set_gemm_variant(int32_t variant);
 /* tuning knob: cap (KiB) on the LDS operand slab of a vocoder conv workgroup; 0 = built-in heuristic */
 int fs2_op_set_vocoder_lds_limit(int32_t kib);

@@ -23,7 +23,7 @@ FS2_MAX_LAYERS = 32
 FS2_MAX_VARIANCES = 4
 FS2_NAME_LEN = 32
 FS2_OK = 0
-FS2_F32, FS2_BF16, FS2_MIXED = 0, 1, 2
+FS2_F32, FS2_BF16, FS2_MIXED, FS2_MIXED_X3 = 0, 1, 2, 3
 K_CONV_GEMM, K_GEMM, K_ATTENTION, K_ROWOPS, K_DEC_FFN_CONV1 = 0, 1, 2, 3, 4
 
 

@@ -86,7 +86,7 @@ __device__ inline float half_sum(float x) {
 }
 
 template <typename T, int D, int NW>
-__global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128) ? (NW == 6 ? 3 : 2) : 1) void attention_kernel(AttnArgs p) {
+__global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128) ? 2 : 1) void attention_kernel(AttnArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins exist in the device pass only
     constexpr int KVB = sizeof(T) == 2 ? 64 : 32;      // keys per tile
     constexpr int E16 = Num<T>::kPer16B;
@@ -403,25 +403,15 @@ static int launch_tv(const AttnArgs& a, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
 }
 
-int g_attn_nw = 0;  // A/B knob: 0 = auto, 4 / 6 = waves (x32 queries) per workgroup on long sequences
-
 template <typename T, int D>
 static int launch_td(const AttnArgs& a, hipStream_t stream) {
     const int BH = a.B * a.heads, BH8 = (BH + 7) / 8 * 8;
     // grid = ceil(BH/8)*8 * nq, decoded XCD-aware in the kernel.  Small sequences: 2-wave
     // workgroups so the grid still covers the 256 CUs.
     const long blocks4 = (long)((a.S + 127) / 128) * BH;
-    // Long sequences, bf16, d = 128: 192 queries (6 waves) per workgroup when that fills two workgroups per CU evenly -
-    // every workgroup streams ALL keys of its (utterance, head) through LDS, so fewer, taller query tiles cut that
-    // traffic by a third (C2 decoder: 512 workgroups x 786 KB instead of 768 x 786 KB).
-    const long blocks6 = (long)((a.S + 191) / 192) * BH;
-    const int nw = g_attn_nw ? g_attn_nw : ((sizeof(T) == 2 && D == 128 && blocks6 >= 384 && a.S >= 768) ? 6 : 4);
-    if constexpr (sizeof(T) == 2 && D == 128) {
-        if (nw == 6 && (g_attn_nw == 6 || blocks4 >= 512)) {
-            hipLaunchKernelGGL((attention_kernel<T, D, 6>), dim3(((a.S + 191) / 192) * BH8), dim3(384), 0, stream, a);
-            return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
-        }
-    }
+    // (192-query / 6-wave workgroups - 512 of them for the C2 decoder, two per CU, a third less K/V streamed - need three
+    // waves per SIMD, i.e. <= 168 VGPRs; this kernel holds 234 (O^T 64, S^T 32, Q 32, K/V/P fragments 56 ...) and with the cap
+    // spills 84 of them: 195 us against 101 us for the 128-query form.  Measured r02, removed.)
     if (blocks4 >= 512) {
         hipLaunchKernelGGL((attention_kernel<T, D, 4>), dim3(((a.S + 127) / 128) * BH8), dim3(256), 0, stream, a);
     } else {

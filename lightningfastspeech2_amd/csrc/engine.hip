@@ -120,6 +120,7 @@ struct fs2_engine {
     bool debug = false;
     bool fuse_predictor = true;
     bool zero_pad_mel = false;
+    bool front_split = false;  // FS2_MIXED_X3: the front's fp32 GEMMs / convs run as bf16 x 3 split products
     std::map<std::string, HostTensor> host;
     std::map<std::string, std::vector<int64_t>> spec;
     std::vector<void*> dev_allocs;
@@ -248,7 +249,7 @@ void build_spec(fs2_engine* e) {
 int check_config(fs2_engine* e) {
     const fs2_config& c = e->cfg;
     if (c.abi_version != FS2_ABI_VERSION) return fail(e, FS2_ERR_ARG, "abi_version %d != %d", c.abi_version, FS2_ABI_VERSION);
-    if (c.dtype != FS2_F32 && c.dtype != FS2_BF16 && c.dtype != FS2_MIXED) return fail(e, FS2_ERR_ARG, "bad dtype");
+    if (c.dtype != FS2_F32 && c.dtype != FS2_BF16 && c.dtype != FS2_MIXED && c.dtype != FS2_MIXED_X3) return fail(e, FS2_ERR_ARG, "bad dtype");
     const int H = c.hidden;
     if (H <= 0 || H % 64 || H > 1024) return fail(e, FS2_ERR_SHAPE, "hidden=%d must be a multiple of 64, <= 1024", H);
     if (c.enc_layers < 0 || c.enc_layers > FS2_MAX_LAYERS || c.dec_layers < 0 || c.dec_layers > FS2_MAX_LAYERS)
@@ -468,6 +469,7 @@ int gemm(fs2_engine* e, hipStream_t st, const ConvW& w, const void* x, void* c, 
          const LnFuse* ln = nullptr, int extra_class = -1, const uint8_t* zero_rows = nullptr) {
     GemmArgs a;
     a.zero_rows = zero_rows;
+    a.split = e->front_split && w.dt == FS2_F32;
     a.X = x;
     a.W = w.w;
     a.bias = w.b;
@@ -687,6 +689,7 @@ int fs2_create(const fs2_config* cfg, fs2_engine** out) {
     e->fdt = cfg->dtype == FS2_BF16 ? FS2_BF16 : FS2_F32;
     e->bdt = cfg->dtype == FS2_F32 ? FS2_F32 : FS2_BF16;
     e->esz = cfg->dtype == FS2_BF16 ? 2 : 4;
+    e->front_split = cfg->dtype == FS2_MIXED_X3;
     build_spec(e);
     return FS2_OK;
 }

@@ -182,6 +182,23 @@ template <> struct Mma32<float> {
     }
 };
 
+// Eight fp32 values (two 16-byte chunks of a lane's K slice) -> bf16 heads and bf16 tails, x = hi + lo (+ 2^-17 |x|):
+// hi = RNE(x) by v_cvt_pk_bf16_f32, lo = RNE(x - hi) with the subtraction exact in fp32.
+__device__ inline void split_bf16x3(const uint4& c0, const uint4& c1, uint4& hi, uint4& lo) {
+    const float f[8] = {__uint_as_float(c0.x), __uint_as_float(c0.y), __uint_as_float(c0.z), __uint_as_float(c0.w),
+                        __uint_as_float(c1.x), __uint_as_float(c1.y), __uint_as_float(c1.z), __uint_as_float(c1.w)};
+    uint32_t h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        h[j] = pack_bf16x2(f[2 * j], f[2 * j + 1]);
+        const float r0 = f[2 * j] - __uint_as_float(h[j] << 16);
+        const float r1 = f[2 * j + 1] - __uint_as_float(h[j] & 0xffff0000u);
+        l[j] = pack_bf16x2(r0, r1);
+    }
+    hi = make_uint4(h[0], h[1], h[2], h[3]);
+    lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
 // LDS-DMA completion is made explicit wherever a barrier publishes DMA'd operands: hipcc usually
 // puts a vmcnt(0) in front of such a barrier itself, but it may hoist that wait out of a loop (seen
 // when VGPR-returning loads sit ahead of the loop), which leaves the back-edge barrier unprotected

@@ -31,12 +31,13 @@ struct GemmArgs {
     float* pred = nullptr;          // (M)
     void* ln_tmp = nullptr;         // (M, ldc) scratch for the unfused fallback
     int xcd_remap = 0;              // set by the launcher
+    int split = 0;                  // fp32 operands only: 1 = bf16 x 3 split arithmetic in the slab kernel (gemm_mfma.hip)
     const uint8_t* zero_rows = nullptr;  // (M) 1 = store zeros for this row (128x128 kernel only: the mel head)
 };
 int launch_gemm(const GemmArgs& a, int in_dtype, int out_dtype, hipStream_t stream);
 extern int g_gemm_variant;
 extern int g_wide_ln;
-extern int g_attn_nw;
+extern int g_split_f32;
 extern int g_slab_xcd_remap;  // 1 = XCD-contiguous tile order in the slab kernel (A/B knob)  // test/bench knob: 0 auto, 1 force the 128x128 kernel, 2 force the DMA kernel
 
 struct AttnArgs {

@@ -368,8 +368,14 @@ template <bool B> struct BoolC { static constexpr bool value = B; };
 // normalises them in place and, for a predictor's last layer, evaluates the Linear(filter, 1) head.  That
 // replaces a GEMM launch + a stand-alone LayerNorm launch (one more HBM round trip of the (M, N) tensor and of
 // the residual) for hidden sizes 768 / 1024 (BASELINE configs C3 / C5).
-template <typename T, typename OutT, int MI, bool LN, bool WIDE = false>
+// SPLIT (T = float only): fp32 operands, bf16 x 3 arithmetic.  Each fp32 value is split in registers into a bf16 head
+// and a bf16 tail (x = hi + lo up to 2^-17 |x|) and a product becomes three bf16 MFMAs, hi*hi + hi*lo + lo*hi, accumulated
+// in fp32 (the dropped lo*lo term is 2^-16 of the product): ~1e-5 relative, ~400x closer to fp32 than bf16 storage, at
+// 3 x 16-cycle MFMAs per 32 k-values instead of the 8 x 32-cycle fp32 MFMAs - the arithmetic of the "front" (encoder +
+// variance adaptor) in the mixed precision mode, where a discrete decision hangs on every output.
+template <typename T, typename OutT, int MI, bool LN, bool WIDE = false, bool SPLIT = false>
 __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
+    static_assert(!SPLIT || sizeof(T) == 4, "the split arithmetic takes fp32 operands");
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-resource builtins only exist in the device pass
     using Cfg = SlabCfg<MI>;
     constexpr int BMs = Cfg::BM, SI = Cfg::SI;
@@ -468,6 +474,23 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
         }
 
     auto compute = [&](const unsigned char* sl, const unsigned char* wt, int tap) {
+        if constexpr (SPLIT) {
+            // both 16-byte chunks of the step = 8 k-values per lane = the k-group one bf16 16x16x32 MFMA takes from it
+            uint4 wh[4], wl[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) split_bf16x3(*(const uint4*)(wt + woff[i][0]), *(const uint4*)(wt + woff[i][1]), wh[i], wl[i]);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                uint4 xh, xl;
+                split_bf16x3(*(const uint4*)(sl + swz(xrow0 + mi * 16 + tap, fg)), *(const uint4*)(sl + swz(xrow0 + mi * 16 + tap, 4 + fg)), xh, xl);
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    Mma16<bf16>::step(wl[ni], xh, acc[ni][mi]);  // small terms first
+                    Mma16<bf16>::step(wh[ni], xl, acc[ni][mi]);
+                    Mma16<bf16>::step(wh[ni], xh, acc[ni][mi]);
+                }
+            }
+        } else {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             uint4 fw[4], fx[MI];
@@ -479,6 +502,7 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
             for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) Mma16<T>::step(fw[ni], fx[mi], acc[ni][mi]);
+        }
         }
     };
 
@@ -943,17 +967,18 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
 #endif
 }
 
-template <typename T, typename OutT, int MI, bool LN, bool WIDE = false>
+template <typename T, typename OutT, int MI, bool LN, bool WIDE = false, bool SPLIT = false>
 static int launch_slab_t(const GemmArgs& a0, hipStream_t stream) {
     GemmArgs a = a0;
     if (a.taps == 1) a.S = a.M;  // plain GEMM: one "utterance" of M rows
     a.xcd_remap = g_slab_xcd_remap;
     const int BMs = SlabCfg<MI>::BM;
     const int tiles = (a.M / a.S) * ((a.S + BMs - 1) / BMs) * (WIDE ? 1 : (a.N + S_BN - 1) / S_BN);
-    hipLaunchKernelGGL((gemm_conv_slab_kernel<T, OutT, MI, LN, WIDE>), dim3(tiles), dim3(512), 0, stream, a);
+    hipLaunchKernelGGL((gemm_conv_slab_kernel<T, OutT, MI, LN, WIDE, SPLIT>), dim3(tiles), dim3(512), 0, stream, a);
     return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
 }
 
+extern int g_split_f32;
 template <int MI>
 static int launch_slab(const GemmArgs& a, int in_dtype, int out_dtype, hipStream_t stream) {
     if (a.ln_g) {  // fused LayerNorm epilogue: whole rows per workgroup, tile heights 128 / 192 only
@@ -964,12 +989,14 @@ static int launch_slab(const GemmArgs& a, int in_dtype, int out_dtype, hipStream
                 if (in_dtype == FS2_BF16 && out_dtype == FS2_BF16) return launch_slab_t<bf16, bf16, MI, true, true>(a, stream);
                 return FS2_ERR_SHAPE;
             }
-            if (in_dtype == FS2_F32 && out_dtype == FS2_F32) return launch_slab_t<float, float, MI, true>(a, stream);
+            if (in_dtype == FS2_F32 && out_dtype == FS2_F32)
+                return (a.split || g_split_f32) ? launch_slab_t<float, float, MI, true, false, true>(a, stream) : launch_slab_t<float, float, MI, true>(a, stream);
             if (in_dtype == FS2_BF16 && out_dtype == FS2_BF16) return launch_slab_t<bf16, bf16, MI, true>(a, stream);
         }
         return FS2_ERR_SHAPE;
     }
-    if (in_dtype == FS2_F32 && out_dtype == FS2_F32) return launch_slab_t<float, float, MI, false>(a, stream);
+    if (in_dtype == FS2_F32 && out_dtype == FS2_F32)
+        return (a.split || g_split_f32) ? launch_slab_t<float, float, MI, false, false, true>(a, stream) : launch_slab_t<float, float, MI, false>(a, stream);
     if (in_dtype == FS2_BF16 && out_dtype == FS2_BF16) return launch_slab_t<bf16, bf16, MI, false>(a, stream);
     if (in_dtype == FS2_BF16 && out_dtype == FS2_F32) return launch_slab_t<bf16, float, MI, false>(a, stream);
     return FS2_ERR_SHAPE;
@@ -991,6 +1018,7 @@ static int launch_t(const GemmArgs& a, hipStream_t stream) {
 }
 
 int g_gemm_variant = 0;
+int g_split_f32 = 0;  // test knob: every fp32 slab launch in the bf16 x 3 split arithmetic
 int g_slab_xcd_remap = 1;
 // 1 = rows wider than 256 by the in-place WIDE epilogue, 0 = GEMM launch + stand-alone LayerNorm launch.  Measured on
 // MI355X (tools/bench_ops.py wide, r02): the WIDE form only ties at M = 49152, K = 768 (118 vs 120 us) and LOSES

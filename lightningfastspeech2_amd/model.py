@@ -23,7 +23,9 @@ from .config import Fs2Config
 
 # "mixed": fp32 for everything a discrete decision hangs on (encoder, durations, variance predictors / buckets),
 # bf16 for the decoder + mel head (include/fs2.h: FS2_MIXED)
-_PRECISIONS = {"fp32": _lib.FS2_F32, "f32": _lib.FS2_F32, "bf16": _lib.FS2_BF16, "mixed": _lib.FS2_MIXED}
+# "mixed3": the same with the front's matrix products as bf16 x 3 split products of the fp32 operands (FS2_MIXED_X3)
+_PRECISIONS = {"fp32": _lib.FS2_F32, "f32": _lib.FS2_F32, "bf16": _lib.FS2_BF16, "mixed": _lib.FS2_MIXED,
+               "mixed3": _lib.FS2_MIXED_X3}
 
 
 def _ptr(t: Optional[torch.Tensor]):

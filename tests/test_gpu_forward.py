@@ -163,8 +163,9 @@ def _decisions(m, cfg, batch, ref):
     return dflips, bflips, float((out["mel"] - ref["mel"]).abs().max()), free
 
 
+@pytest.mark.parametrize("mode", ["mixed", "mixed3"])
 @pytest.mark.parametrize("case", ["c2arch_ragged", "refdefault_dw", "ls_h768_2layer"])
-def test_mixed_precision_is_decision_safe(case):
+def test_mixed_precision_is_decision_safe(case, mode):
     """precision="mixed" (FS2_MIXED): the encoder -> duration path and the variance-predictor chain in fp32, the decoder in
     bf16.  Its discrete decisions must be the fp32 path's: durations equal to the oracle's, bucket flips >= 10x rarer than
     the all-bf16 mode's (SURVEY 7 "hard parts": keep every predictor head and what feeds it out of bf16)."""
@@ -173,9 +174,9 @@ def test_mixed_precision_is_decision_safe(case):
     sd, inp, ref = _oracle_case(cfg, B, L, lengths, seed=3, **skw)
     batch = {"phones": torch.from_numpy(inp["phones"]), "speaker": torch.from_numpy(inp["speaker"])}
     d16, b16, e16, _ = _decisions(_model(cfg, sd, "bf16"), cfg, batch, ref)
-    dmx, bmx, emx, free = _decisions(_model(cfg, sd, "mixed"), cfg, batch, ref)
+    dmx, bmx, emx, free = _decisions(_model(cfg, sd, mode), cfg, batch, ref)
     nb = sum(ref["_intermediates"][f"bucket_{v}"].numel() for v in cfg.variances)
-    _report(test="mixed_vs_bf16", case=case, buckets=nb, bf16=dict(duration_flips=d16, bucket_flips=b16, mel_forced=e16),
+    _report(test="mixed_vs_bf16", case=case, mode=mode, buckets=nb, bf16=dict(duration_flips=d16, bucket_flips=b16, mel_forced=e16),
             mixed=dict(duration_flips=dmx, bucket_flips=bmx, mel_forced=emx))
     assert dmx == 0 and torch.equal(free["tgt_mask"], ref["tgt_mask"])
     assert bmx <= max(2, b16 // 10)
@@ -184,16 +185,17 @@ def test_mixed_precision_is_decision_safe(case):
         assert float((free[f"variances_{v}"] - ref[f"variances_{v}"]).abs().max()) <= 1e-3
 
 
+@pytest.mark.parametrize("mode", ["mixed", "mixed3"])
 @pytest.mark.parametrize("name", [n for n in golden_names() if "teacher" not in n])
-def test_mixed_precision_decisions_on_goldens(name):
+def test_mixed_precision_decisions_on_goldens(name, mode):
     g = Golden(name)
-    m = _model(g.cfg, g.state_dict(), "mixed")
+    m = _model(g.cfg, g.state_dict(), mode)
     batch = {"phones": torch.from_numpy(g.phones), "speaker": torch.from_numpy(g.speaker), **g.priors}
     out = _cpu(m(batch, inference=True))
     for k in ("duration_rounded", "src_mask", "tgt_mask"):
         assert np.array_equal(out[k].numpy(), g.out[k]), k
     err = float(np.abs(out["mel"].numpy() - g.out["mel"]).max())
-    _report(test="golden_mixed", case=name, mel_max=err, mel_scale=float(np.abs(g.out["mel"]).max()))
+    _report(test="golden_mixed", case=name, mode=mode, mel_max=err, mel_scale=float(np.abs(g.out["mel"]).max()))
     assert np.isfinite(err)
 
 

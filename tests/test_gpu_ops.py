@@ -124,6 +124,31 @@ def test_gemm_fused_layernorm_epilogue(dtype, wide, variant, B, S, Cin, N, k, re
     assert torch.equal(pred, pred2)
 
 
+@pytest.mark.parametrize("B,S,Cin,N,k,ln", [(2, 300, 256, 1024, 9, False), (1, 1536, 256, 256, 3, True), (3, 100, 1024, 256, 1, True),
+                                             (2, 64, 256, 768, 1, False)])
+def test_gemm_split_bf16x3_arithmetic(B, S, Cin, N, k, ln):
+    """fp32 operands as bf16 head + tail, three bf16 MFMAs per product (knob 501; the front of FS2_MIXED_X3): against an
+    fp64 reference the error must sit ~2 orders of magnitude under plain bf16 operands' and within ~1e-5 relative."""
+    x, w, b = rnd(B, S, Cin, seed=70), rnd(N, Cin, k, seed=71, scale=(Cin * k) ** -0.5), rnd(N, seed=72)
+    z = F.conv1d(x.double().transpose(1, 2), w.double(), b.double(), padding="same").transpose(1, 2).reshape(B * S, N)
+    g, be = 1 + 0.2 * rnd(N, seed=74), 0.1 * rnd(N, seed=75)
+    ref = F.layer_norm(torch.relu(z), (N,), g.double(), be.double(), 1e-5) if ln else z
+    out = {}
+    for knob in (500, 501):
+        G.lib().fs2_op_set_gemm_variant(knob)
+        try:
+            if ln:
+                out[knob] = G.gemm_ln(G.F32, x.reshape(B * S, Cin), G.pack_conv_weight(w), b, None, g, be, taps=k, S=S, relu=True)[0]
+            else:
+                out[knob] = G.gemm(G.F32, x.reshape(B * S, Cin), G.pack_conv_weight(w), b, taps=k, S=S)
+        finally:
+            G.lib().fs2_op_set_gemm_variant(500)
+    scale = float(ref.abs().max())
+    e32, e3 = float((out[500].double() - ref).abs().max()) / scale, float((out[501].double() - ref).abs().max()) / scale
+    assert e32 <= 2e-6 and e3 <= 4e-5, (e32, e3)
+    assert not torch.equal(out[500], out[501])  # the knob did select another arithmetic
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_wide_layernorm_fused_vs_two_launches(dtype):
     """N = 768: the in-place fused epilogue against the round-1 path (GEMM launch + LayerNorm launch, knob 300) and
@@ -259,31 +284,6 @@ def test_attention(dtype, B, S, H, heads, mask_kind):
     got = G.attention(dtype, qkv, mask, B, S, H, heads)
     err = float((got - ref).abs().max())
     assert err <= tol(dtype, ref, f32=5e-5, bf16=2e-2), (err, tol(dtype, ref))
-
-
-@pytest.mark.parametrize("B,S,heads,mask_kind", [(2, 1000, 2, "suffix"), (1, 1536, 2, "none"), (3, 333, 2, "scatter"), (2, 192, 6, "suffix")])
-def test_attention_six_wave_query_tiles(B, S, heads, mask_kind):
-    """192-query (6-wave) workgroups, bf16 d = 128 (knob 406): the same answers as the 128-query form and as torch,
-    incl. a tail tile (S not a multiple of 192), skipped tiles and scattered masks."""
-    H = 128 * heads
-    qkv = rnd(B * S, 3 * H, seed=12)
-    mask = torch.zeros(B, S, dtype=torch.bool)
-    if mask_kind == "suffix":
-        mask[0, S - S // 3:] = True
-        mask[-1, S - 5:] = True
-    elif mask_kind == "scatter":
-        mask = torch.rand(B, S, generator=torch.Generator().manual_seed(13)) < 0.3
-        mask[:, 0] = False
-    ref = _attn_ref(G.rounded(qkv, G.BF16), mask, B, S, H, heads)
-    G.lib().fs2_op_set_gemm_variant(404)
-    try:
-        four = G.attention(G.BF16, qkv, mask, B, S, H, heads)
-        G.lib().fs2_op_set_gemm_variant(406)
-        six = G.attention(G.BF16, qkv, mask, B, S, H, heads)
-    finally:
-        G.lib().fs2_op_set_gemm_variant(400)
-    assert float((six - ref).abs().max()) <= tol(G.BF16, ref, bf16=2e-2)
-    assert torch.equal(six, four)  # a query's arithmetic does not depend on which workgroup shape carries it
 
 
 def test_attention_spike_forces_rescale():

@@ -152,12 +152,7 @@ def main():
         predictor_case("variance predictor fused", 32, 1536, 5, a.reps)
         predictor_case("duration predictor fused", 32, 256, 2, a.reps)
     if a.what in ("attn", "all"):
-        for knob in (404, 406):
-            lib.fs2_op_set_gemm_variant(knob)
-            attn_case(f"decoder attention nw={knob - 400}", 32, 1536, 256, 2, a.reps)
-            attn_case(f"c3 decoder attention nw={knob - 400}", 32, 1536, 768, 6, a.reps)
-            attn_case(f"ragged-length S=1000 nw={knob - 400}", 32, 1000, 256, 2, a.reps)
-        lib.fs2_op_set_gemm_variant(400)
+        attn_case("c3 decoder attention", 32, 1536, 768, 6, a.reps)
         attn_case("decoder attention", 32, 1536, 256, 2, a.reps)
         attn_case("encoder attention", 32, 256, 256, 2, a.reps)
 
