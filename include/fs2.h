@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FS2_ABI_VERSION 1
+#define FS2_ABI_VERSION 2
 #define FS2_MAX_LAYERS 32
 #define FS2_MAX_VARIANCES 4
 #define FS2_NAME_LEN 32
@@ -87,6 +87,9 @@ typedef struct fs2_config {
     int32_t dur_nlayers, dur_kernel, dur_filter, dur_depthwise;
     int32_t n_priors;      /* hparams.priors (default []): PriorEmbedding rows added after the encoder */
     char prior_names[FS2_MAX_VARIANCES][FS2_NAME_LEN];
+    int32_t var_cwt[FS2_MAX_VARIANCES];  /* variance_transforms[i] == "cwt" (the class default for pitch, fastspeech2.py:60):
+                              the CWT head of VarianceEncoder (model.py:412-431,445-461): predictor.linear is (10, filter),
+                              mean_std_linear (2, filter) exists, bins are log-spaced; var_mean/var_std must be 0 / 1 */
 } fs2_config;
 
 typedef struct fs2_engine fs2_engine;
@@ -99,7 +102,10 @@ typedef struct fs2_outputs {
     int32_t* duration_rounded;     /* (B, L) (model.py:299-309) */
     uint8_t* src_mask;             /* (B, L) phones == 0 (fastspeech2.py:651) */
     uint8_t* tgt_mask;             /* (B, T) t >= total_b (model.py:358-361) */
-    float* variances[FS2_MAX_VARIANCES];  /* (B, T) each, 0 at pads (model.py:328) */
+    float* variances[FS2_MAX_VARIANCES];  /* (B, T) each, 0 at pads (model.py:328); for a CWT variance the recomposed
+                                             log-domain signal (exp of it = the reference's "reconstructed_signal") */
+    float* var_spectrogram[FS2_MAX_VARIANCES];  /* CWT variances only: (B, T, 10) wavelet spectrogram, 0 at pads */
+    float* var_mean_std[FS2_MAX_VARIANCES];     /* CWT variances only: (B, 2) utterance-level mean, std (model.py:414-415) */
 } fs2_outputs;
 
 int fs2_abi_version(void);

@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FS2_LIB") or os.path.join(_HERE, "libfs2_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "fs2.h")
 
-FS2_ABI_VERSION = 1
+FS2_ABI_VERSION = 2
 FS2_MAX_LAYERS = 32
 FS2_MAX_VARIANCES = 4
 FS2_NAME_LEN = 32
@@ -45,6 +45,7 @@ class Fs2ConfigC(C.Structure):
         ("dur_nlayers", C.c_int32), ("dur_kernel", C.c_int32), ("dur_filter", C.c_int32), ("dur_depthwise", C.c_int32),
         ("n_priors", C.c_int32),
         ("prior_names", (C.c_char * FS2_NAME_LEN) * FS2_MAX_VARIANCES),
+        ("var_cwt", C.c_int32 * FS2_MAX_VARIANCES),
     ]
 
 
@@ -52,6 +53,7 @@ class Fs2OutputsC(C.Structure):
     _fields_ = [
         ("mel", C.c_void_p), ("duration_prediction", C.c_void_p), ("duration_rounded", C.c_void_p),
         ("src_mask", C.c_void_p), ("tgt_mask", C.c_void_p), ("variances", C.c_void_p * FS2_MAX_VARIANCES),
+        ("var_spectrogram", C.c_void_p * FS2_MAX_VARIANCES), ("var_mean_std", C.c_void_p * FS2_MAX_VARIANCES),
     ]
 
 
@@ -179,8 +181,10 @@ def config_to_c(cfg, dtype: int) -> Fs2ConfigC:
         c.var_names[i].value = name
         c.var_nlayers[i] = cfg.variance_nlayers[i]
         c.var_kernel[i] = cfg.variance_kernel_size[i]
-        c.var_mean[i] = cfg.stats[v]["mean"]
-        c.var_std[i] = cfg.stats[v]["std"]
+        cwt = cfg.is_cwt(i)  # the CWT head bucketises its recomposed log-domain signal directly (model.py:427-428)
+        c.var_cwt[i] = int(cwt)
+        c.var_mean[i] = 0.0 if cwt else cfg.stats[v]["mean"]
+        c.var_std[i] = 1.0 if cwt else cfg.stats[v]["std"]
     c.var_filter, c.var_nbins = cfg.variance_filter_size, cfg.variance_nbins
     c.var_depthwise = int(cfg.variance_depthwise_conv)
     if len(cfg.priors) > FS2_MAX_VARIANCES:

@@ -101,9 +101,12 @@ class Fs2Config:
             if self.variance_levels[i] != "frame":
                 raise ValueError("only frame-level variances are on the accelerated path "
                                  "(SURVEY §8a; phone-level loop model.py:276-294 is off-path)")
-            if self.variance_transforms[i] != "none":
-                raise ValueError("only variance_transforms='none' is on the accelerated path "
-                                 "(CWT pitch head model.py:412-431 is off-path)")
+            if self.variance_transforms[i] not in ("none", "cwt"):
+                raise ValueError(f"variance_transforms[{i}]={self.variance_transforms[i]!r}: the reference knows 'none' and 'cwt'")
+            if self.variance_transforms[i] == "cwt":  # VarianceEncoder takes log(min), log(max) (model.py:394-396)
+                st = self.stats.get(v, {})
+                if not (st.get("min", 0) > 0 and st.get("max", 0) > st.get("min", 0)):
+                    raise ValueError(f"variance {v!r} uses the CWT head: stats min/max must be positive (bins are log-spaced)")
             if self.variance_nlayers[i] > 1 and self.variance_filter_size != H:
                 raise ValueError("variance_filter_size must equal hidden when nlayers>1 "
                                  "(every layer is built in_channels->filter, model.py:497-501)")
@@ -118,6 +121,9 @@ class Fs2Config:
                 raise ValueError(f"stats['{pr}_prior'] with min/max is required for prior {pr!r}")
 
     # ---- (de)serialisation ----------------------------------------------------------------
+    def is_cwt(self, i: int) -> bool:
+        return self.variance_transforms[i] == "cwt"
+
     def to_dict(self) -> dict:
         return asdict(self)
 

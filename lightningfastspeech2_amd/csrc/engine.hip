@@ -86,6 +86,9 @@ struct PredLayerW {
 };
 struct PredictorW {
     int dt = FS2_F32;
+    bool cwt = false;   // CWT head: head_mat = Linear(filter, 10) padded to 12 rows, ms_w / ms_b = mean_std_linear
+    ConvW head_mat;
+    float *ms_w = nullptr, *ms_b = nullptr;
     std::vector<PredLayerW> layers;
     float* head_w = nullptr;
     float head_b = 0.f;
@@ -200,7 +203,7 @@ void conformer_spec(fs2_engine* e, const std::string& p, int H, int F, int k, bo
         s[p + ".conv2.bias"] = {H};
     }
 }
-void predictor_spec(fs2_engine* e, const std::string& p, int nl, int cin, int filt, int k, bool dw) {
+void predictor_spec(fs2_engine* e, const std::string& p, int nl, int cin, int filt, int k, bool dw, int n_out = 1) {
     auto& s = e->spec;
     for (int j = 0; j < nl; ++j) {
         const std::string q = p + ".layers." + std::to_string(j) + ".layers";
@@ -216,8 +219,8 @@ void predictor_spec(fs2_engine* e, const std::string& p, int nl, int cin, int fi
         s[q + ".2.weight"] = {filt};
         s[q + ".2.bias"] = {filt};
     }
-    s[p + ".linear.weight"] = {1, filt};
-    s[p + ".linear.bias"] = {1};
+    s[p + ".linear.weight"] = {n_out, filt};
+    s[p + ".linear.bias"] = {n_out};
 }
 void build_spec(fs2_engine* e) {
     const fs2_config& c = e->cfg;
@@ -233,7 +236,11 @@ void build_spec(fs2_engine* e) {
         const std::string p = std::string("variance_adaptor.encoders.") + c.var_names[v];
         e->spec[p + ".bins"] = {c.var_nbins - 1};
         e->spec[p + ".embedding.weight"] = {c.var_nbins, H};
-        predictor_spec(e, p + ".predictor", c.var_nlayers[v], H, c.var_filter, c.var_kernel[v], c.var_depthwise);
+        predictor_spec(e, p + ".predictor", c.var_nlayers[v], H, c.var_filter, c.var_kernel[v], c.var_depthwise, c.var_cwt[v] ? 10 : 1);
+        if (c.var_cwt[v]) {
+            e->spec[p + ".mean_std_linear.weight"] = {2, c.var_filter};
+            e->spec[p + ".mean_std_linear.bias"] = {2};
+        }
     }
     e->spec["linear.weight"] = {c.n_mels, H};
     e->spec["linear.bias"] = {c.n_mels};
@@ -280,6 +287,8 @@ int check_config(fs2_engine* e) {
     if (!(c.dur_kernel & 1) || c.dur_kernel > 31) return fail(e, FS2_ERR_SHAPE, "duration kernel must be odd, <= 31");
     for (int v = 0; v < c.n_variances; ++v) {
         if (c.var_nlayers[v] < 1) return fail(e, FS2_ERR_SHAPE, "variance_nlayers < 1");
+        if (c.var_cwt[v] && (c.var_mean[v] != 0.f || c.var_std[v] != 1.f))
+            return fail(e, FS2_ERR_ARG, "a CWT variance is bucketised as it is: var_mean / var_std must be 0 / 1");
         if (c.var_nlayers[v] > 1 && c.var_filter != H) return fail(e, FS2_ERR_SHAPE, "variance_filter_size != hidden with nlayers > 1");
         if (!(c.var_kernel[v] & 1) || c.var_kernel[v] > 31) return fail(e, FS2_ERR_SHAPE, "variance kernel must be odd, <= 31");
     }
@@ -387,9 +396,10 @@ int make_layer(fs2_engine* e, const std::string& p, int H, int F, bool dw, Layer
     }
     return FS2_OK;
 }
-int make_predictor(fs2_engine* e, const std::string& p, int nl, int filt, bool dw, PredictorW* P, int dt) {
+int make_predictor(fs2_engine* e, const std::string& p, int nl, int filt, bool dw, PredictorW* P, int dt, bool cwt = false) {
     P->filt = filt;
     P->dt = dt;
+    P->cwt = cwt;
     P->layers.resize(nl);
     for (int j = 0; j < nl; ++j) {
         const std::string q = p + ".layers." + std::to_string(j) + ".layers";
@@ -403,6 +413,17 @@ int make_predictor(fs2_engine* e, const std::string& p, int nl, int filt, bool d
         }
         CHK(up_vec(e, q + ".2.weight", &Lw.g));
         CHK(up_vec(e, q + ".2.bias", &Lw.b));
+    }
+    if (cwt) {  // Linear(filter, 10): a small GEMM (rows padded to 12 for 16-byte fp32 stores)
+        const HostTensor& hw = W(e, p + ".linear.weight");
+        const HostTensor& hb = W(e, p + ".linear.bias");
+        std::vector<float> wp((size_t)12 * filt, 0.f), bp(12, 0.f);
+        memcpy(wp.data(), hw.data.data(), (size_t)10 * filt * 4);
+        memcpy(bp.data(), hb.data.data(), 10 * 4);
+        P->head_mat.N = 12; P->head_mat.Cin = filt; P->head_mat.taps = 1; P->head_mat.dt = dt;
+        CHK(upload_mat(e, wp.data(), wp.size(), &P->head_mat.w, dt));
+        CHK(upload_f32(e, bp.data(), bp.size(), &P->head_mat.b));
+        return FS2_OK;  // never the single-launch kernel: its head is the scalar one
     }
     CHK(up_vec(e, p + ".linear.weight", &P->head_w));
     P->head_b = W(e, p + ".linear.bias").data[0];
@@ -555,9 +576,16 @@ int conformer(fs2_engine* e, hipStream_t st, const LayerW& w, void* x, void* tmp
 }
 
 // VariancePredictor.forward (model.py:510-522): pred (B*S) fp32, 0 where mask
+struct CwtOut {  // where the CWT head's by-products go (scratch or the caller's buffers)
+    float* spec12 = nullptr;    // (M, 12) scratch
+    float* mean_std = nullptr;  // (B, 2)
+    float* spec_out = nullptr;  // (B, S, 10) or null
+};
+
 int predictor(fs2_engine* e, hipStream_t st, const PredictorW& P, const void* x, int B, int S, const uint8_t* mask,
-              float* pred, const LayerScratch& sc) {
+              float* pred, const LayerScratch& sc, const CwtOut* cw = nullptr) {
     const int M = B * S;
+    if (P.cwt && !cw) return fail(e, FS2_ERR_STATE, "CWT predictor without its output buffers");
     if (P.wpk && e->fuse_predictor && predictor_fused_supported(P.dt, P.filt, P.layers[0].c.taps, (int)P.layers.size(), S)) {
         PredictorArgs a;
         a.x = x; a.wpk = P.wpk; a.bias = P.bias_all; a.ln_g = P.g_all; a.ln_b = P.b_all;
@@ -581,16 +609,22 @@ int predictor(fs2_engine* e, hipStream_t st, const PredictorW& P, const void* x,
         void* other = (j & 1) ? sc.att : sc.proj;
         LnFuse ln;
         ln.g = Lw.g; ln.b = Lw.b;
-        if (last) { ln.dot_w = P.head_w; ln.dot_b = P.head_b; ln.mask = mask; ln.pred = pred; }
+        const bool keep = !last || P.cwt;  // the CWT head needs the last layer's activations themselves
+        if (last && !P.cwt) { ln.dot_w = P.head_w; ln.dot_b = P.head_b; ln.mask = mask; ln.pred = pred; }
         if (Lw.depthwise) {
             CHK(dwconv(e, st, Lw.dw, src, sc.u, B, S, P.dt));
             ln.tmp = other;  // src (= other for j > 0) is dead once the depth-wise conv has run
-            CHK(gemm(e, st, Lw.c, sc.u, last ? nullptr : out, M, S, true, P.dt, &ln));
+            CHK(gemm(e, st, Lw.c, sc.u, keep ? out : nullptr, M, S, true, P.dt, &ln));
         } else {
             ln.tmp = sc.u;
-            CHK(gemm(e, st, Lw.c, src, last ? nullptr : out, M, S, true, P.dt, &ln));
+            CHK(gemm(e, st, Lw.c, src, keep ? out : nullptr, M, S, true, P.dt, &ln));
         }
         src = out;
+    }
+    if (P.cwt) {  // model.py:412-431: 10-scale head, utterance-level mean/std, recomposition
+        CHK(gemm(e, st, P.head_mat, src, cw->spec12, M, M, false, FS2_F32));
+        CwtArgs ca{src, cw->spec12, 12, mask, P.ms_w, P.ms_b, cw->mean_std, pred, cw->spec_out, B, S, P.filt};
+        if (launch_cwt_head(ca, P.dt, st) != FS2_OK) return fail(e, FS2_ERR_HIP, "cwt head launch failed");
     }
     return FS2_OK;
 }
@@ -633,7 +667,10 @@ size_t persist_bytes(const fs2_engine* e, int B, int L) {
 }
 size_t decode_scratch_bytes(const fs2_engine* e, int B, int T) {
     const size_t H = e->cfg.hidden, MT = (size_t)B * T, esz = e->esz;
-    return layer_scratch_bytes(e, B, T) + 2 * al(MT * H * esz) + al(MT) + (size_t)e->cfg.n_variances * al(MT * 4) + 4096;
+    size_t cw = 0;
+    for (int v = 0; v < e->cfg.n_variances; ++v)
+        if (e->cfg.var_cwt[v]) cw = al(MT * 12 * 4) + al((size_t)B * 8) + 512;  // the CWT head's spectrogram + (mean, std)
+    return layer_scratch_bytes(e, B, T) + 2 * al(MT * H * esz) + al(MT) + (size_t)e->cfg.n_variances * al(MT * 4) + cw + 4096;
 }
 // Grow-only engine arena, or the caller's buffer (fs2_set_workspace) which must already be large enough.
 int ensure_arena(fs2_engine* e, Arena& ar, size_t need, const char* what) {
@@ -747,7 +784,11 @@ int fs2_finalize(fs2_engine* e) {
     e->vars.resize(c.n_variances);
     for (int v = 0; v < c.n_variances; ++v) {
         const std::string p = std::string("variance_adaptor.encoders.") + c.var_names[v];
-        CHK(make_predictor(e, p + ".predictor", c.var_nlayers[v], c.var_filter, c.var_depthwise, &e->vars[v].pred, e->fdt));
+        CHK(make_predictor(e, p + ".predictor", c.var_nlayers[v], c.var_filter, c.var_depthwise, &e->vars[v].pred, e->fdt, c.var_cwt[v] != 0));
+        if (c.var_cwt[v]) {
+            CHK(up_vec(e, p + ".mean_std_linear.weight", &e->vars[v].pred.ms_w));
+            CHK(up_vec(e, p + ".mean_std_linear.bias", &e->vars[v].pred.ms_b));
+        }
         CHK(up_vec(e, p + ".bins", &e->vars[v].bins));
         CHK(up_vec(e, p + ".embedding.weight", &e->vars[v].emb));
     }
@@ -930,6 +971,13 @@ int fs2_decode(fs2_engine* e, const fs2_outputs* out, void* stream) {
     float* vpred[FS2_MAX_VARIANCES] = {nullptr, nullptr, nullptr, nullptr};
     for (int v = 0; v < c.n_variances; ++v)
         vpred[v] = out->variances[v] ? out->variances[v] : (float*)e->scratch.take(MT * 4);
+    float *cw_spec = nullptr, *cw_ms = nullptr;
+    for (int v = 0; v < c.n_variances; ++v)
+        if (c.var_cwt[v] && !cw_spec) {
+            cw_spec = (float*)e->scratch.take(MT * 12 * 4);
+            cw_ms = (float*)e->scratch.take((size_t)B * 8);
+            if (!cw_spec || !cw_ms) return fail(e, FS2_ERR_NOMEM, "scratch arena too small");
+        }
     LayerScratch sc;
     CHK(take_layer_scratch(e, e->scratch, B, T, &sc));
     if (!yA || !yB || !tmask) return fail(e, FS2_ERR_NOMEM, "scratch arena too small");
@@ -950,7 +998,13 @@ int fs2_decode(fs2_engine* e, const fs2_outputs* out, void* stream) {
     // frame-level variance encoders, sequential                            model.py:315-333
     const bool fuse_pe = !e->debug;
     for (int v = 0; v < c.n_variances; ++v) {
-        CHK(predictor(e, st, e->vars[v].pred, yA, B, T, tmask, vpred[v], sc));
+        CwtOut cwo;
+        if (c.var_cwt[v]) {
+            cwo.spec12 = cw_spec;
+            cwo.mean_std = out->var_mean_std[v] ? out->var_mean_std[v] : cw_ms;
+            cwo.spec_out = out->var_spectrogram[v];
+        }
+        CHK(predictor(e, st, e->vars[v].pred, yA, B, T, tmask, vpred[v], sc, c.var_cwt[v] ? &cwo : nullptr));
         const bool last = v + 1 == c.n_variances;
         int32_t* idx = nullptr;
         if (e->debug) {

@@ -158,6 +158,21 @@ struct DwConvArgs {
 };
 int launch_dwconv(const DwConvArgs& a, int dtype, hipStream_t stream);
 
+// CWT pitch head (VarianceEncoder.forward CWT branch, model.py:412-431 + CWT.recompose, dataset/cwt.py:18-21,49-50)
+struct CwtArgs {
+    const void* out_conv;   // (B*T, F) last predictor layer's LayerNorm output, engine dtype
+    const float* spec;      // (B*T, ld_spec) head output: the first 10 columns are the wavelet scales
+    int ld_spec;
+    const uint8_t* mask;    // (B*T) 1 = pad: spectrogram row := 0 (model.py:515-518)
+    const float* ms_w;      // (2, F) mean_std_linear
+    const float* ms_b;      // (2)
+    float* mean_std;        // (B, 2) out
+    float* pred;            // (B, T) out: z-normalised sum over the scales * std + mean (log domain)
+    float* spec_out;        // (B, T, 10) out or null
+    int B, T, F;
+};
+int launch_cwt_head(const CwtArgs& a, int dtype, hipStream_t stream);
+
 struct EmbedArgs {
     const int64_t* phones;  // (B, L)
     const float* table;     // (n_phones, H), row 0 == 0

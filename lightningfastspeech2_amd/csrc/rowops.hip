@@ -527,4 +527,72 @@ int launch_bucket_embed(const BucketArgs& a, int dtype, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
 }
 
+// =============================================================================================
+// CWT pitch head (model.py:412-431,445-461; dataset/cwt.py:18-21,49-50).  Two launches, one workgroup per utterance:
+//   mean_std[b] = mean_std_linear(mean_t out_conv[b, t, :])            (time mean over ALL T rows, pads included)
+//   s[b, t] = sum_j spec[b, t, j] (pads: 0);  pred = (s - mean_t s) / (std_t s + 1e-7) * std_b + mean_b  (unbiased std)
+// =============================================================================================
+__device__ inline float block_sum_256(float v, float* sh) {  // all 256 threads get the total; fixed order
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cwt_mean_std_kernel(CwtArgs p) {
+    __shared__ float sh[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const T* x = (const T*)p.out_conv + (size_t)b * p.T * p.F;
+    float d0 = 0.f, d1 = 0.f;
+    for (int c = tid; c < p.F; c += 256) {
+        float s = 0.f;
+        for (int t = 0; t < p.T; ++t) s += Num<T>::to_f32(x[(size_t)t * p.F + c]);
+        const float m = s / (float)p.T;
+        d0 = fmaf(m, p.ms_w[c], d0);
+        d1 = fmaf(m, p.ms_w[p.F + c], d1);
+    }
+    d0 = block_sum_256(d0, sh);
+    d1 = block_sum_256(d1, sh);
+    if (tid == 0) {
+        p.mean_std[2 * b] = d0 + p.ms_b[0];
+        p.mean_std[2 * b + 1] = d1 + p.ms_b[1];
+    }
+}
+
+__global__ __launch_bounds__(256) void cwt_recompose_kernel(CwtArgs p) {
+    __shared__ float sh[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float* pr = p.pred + (size_t)b * p.T;
+    float acc = 0.f;
+    for (int t = tid; t < p.T; t += 256) {
+        const size_t row = (size_t)b * p.T + t;
+        const bool pad = p.mask && p.mask[row];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            const float v = pad ? 0.f : p.spec[row * p.ld_spec + j];
+            if (p.spec_out) p.spec_out[row * 10 + j] = v;
+            s += v;
+        }
+        pr[t] = s;
+        acc += s;
+    }
+    const float m = block_sum_256(acc, sh) / (float)p.T;
+    float q = 0.f;
+    for (int t = tid; t < p.T; t += 256) { const float d = pr[t] - m; q = fmaf(d, d, q); }
+    const float sd = sqrtf(block_sum_256(q, sh) / (float)(p.T - 1));  // torch.std: unbiased (T = 1 -> NaN, as the reference)
+    const float mean_b = p.mean_std[2 * b], std_b = p.mean_std[2 * b + 1];
+    for (int t = tid; t < p.T; t += 256) pr[t] = __fadd_rn(__fmul_rn((pr[t] - m) / (sd + 1e-7f), std_b), mean_b);
+}
+
+int launch_cwt_head(const CwtArgs& a, int dtype, hipStream_t stream) {
+    if (a.B <= 0 || a.T <= 0) return FS2_OK;
+    if (dtype == FS2_BF16) hipLaunchKernelGGL(cwt_mean_std_kernel<bf16>, dim3(a.B), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(cwt_mean_std_kernel<float>, dim3(a.B), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(cwt_recompose_kernel, dim3(a.B), dim3(256), 0, stream, a);
+    return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
+}
+
 }  // namespace fs2

@@ -5,11 +5,15 @@
   ``<key>_lengths`` tensor for every array key, zero padding to the longest (``silence_mask`` keys pad
   with 1), and the ``pad_to_multiple_of`` quirk kept as is: only the FIRST sample is padded to the
   rounded-up length (``pad_sequence`` then stretches the rest).
-* ``LexiconG2P`` is the lexicon half of ``EnglishG2P`` (litfass/synthesis/g2p.py:22-65): NFKD + lower
-  case, split on spaces, trailing ``. , ! ?`` become ``[<unicode name>]`` tokens, every other word
-  boundary ``[SILENCE]``.  The reference's fallback for out-of-lexicon words is the third-party neural
-  ``g2p_en`` model and the ``phones`` ARPAbet->IPA tables; neither is part of the reference checkout
-  nor of this image, so out-of-lexicon words go to an optional ``fallback`` callable or raise.
+* ``LexiconG2P`` is ``EnglishG2P.__call__`` (litfass/synthesis/g2p.py:22-65): NFKD + lower case, split on
+  spaces, trailing ``. , ! ?`` become ``[<unicode name>]`` tokens, every other word boundary ``[SILENCE]``;
+  every phone of a word - lexicon entry or fallback output - loses its ``0`` / ``1`` stress digits (``2``
+  stays, g2p.py:44) and goes through the ARPAbet -> IPA converter, whose result EXTENDS the phone list
+  (g2p.py:45-46).  The reference's converter is the third-party ``phones`` package (pyproject.toml:15,
+  ``phones>=0.0.2``, not in the checkout, not in this image): ``ArpabetConverter`` restates the published
+  ARPAbet -> IPA correspondence (CMUdict's 39 phonemes) as a table.  Its out-of-lexicon fallback is the
+  neural ``g2p_en`` model (pyproject.toml:31), also absent: such words go to an optional ``fallback``
+  callable (ARPAbet with stress digits, what ``g2p_en.G2p`` returns) or raise.
 * ``text_to_batch`` is the tensor-building part of ``SpeechGenerator.generate_from_text``
   (litfass/synthesis/generator.py:96-150).
 """
@@ -63,18 +67,41 @@ def collate(samples: List[dict], pad_to_multiple_of: Optional[int] = None, load_
     return data
 
 
+# ARPAbet (CMUdict, stress digits removed) -> IPA.  One IPA symbol string per phoneme; diphthongs and affricates stay one
+# phone (the lexica the reference is used with list "oʊ", "tʃ" as single entries).
+ARPABET_TO_IPA = {
+    "AA": "ɑ", "AE": "æ", "AH": "ʌ", "AO": "ɔ", "AW": "aʊ", "AX": "ə", "AY": "aɪ", "B": "b", "CH": "tʃ", "D": "d",
+    "DH": "ð", "EH": "ɛ", "ER": "ɝ", "EY": "eɪ", "F": "f", "G": "ɡ", "HH": "h", "IH": "ɪ", "IY": "i", "JH": "dʒ",
+    "K": "k", "L": "l", "M": "m", "N": "n", "NG": "ŋ", "OW": "oʊ", "OY": "ɔɪ", "P": "p", "R": "ɹ", "S": "s", "SH": "ʃ",
+    "T": "t", "TH": "θ", "UH": "ʊ", "UW": "u", "V": "v", "W": "w", "Y": "j", "Z": "z", "ZH": "ʒ",
+}
+
+
+class ArpabetConverter:
+    """Table-driven stand-in for ``phones.convert.Converter()(phone, "arpabet", lang=None)`` (g2p.py:45): returns the
+    LIST of IPA phones of one ARPAbet symbol.  A secondary-stress digit the caller left on (``AH2``: g2p.py:44 strips only
+    0 and 1) is ignored; a symbol outside the table (a lexicon that already holds IPA, punctuation) passes through."""
+
+    def __call__(self, phone: str, source: str = "arpabet", lang=None) -> List[str]:
+        if source != "arpabet":
+            raise ValueError("only the ARPAbet -> IPA direction is on the synthesis path (g2p.py:45)")
+        key = phone.upper().rstrip("2")
+        return [ARPABET_TO_IPA.get(key, phone)]
+
+
 class LexiconG2P:
-    """``EnglishG2P.__call__`` for words a lexicon covers (g2p.py:29-52).  Lexicon file: one
-    ``word<TAB>p1 p2 ...`` per line (g2p.py:54-65); or pass a dict."""
+    """``EnglishG2P.__call__`` (g2p.py:28-52).  Lexicon file: one ``word<TAB>p1 p2 ...`` per line (g2p.py:54-65); or
+    pass a dict.  ``converter(phone, "arpabet", lang=None) -> list`` defaults to :class:`ArpabetConverter`."""
 
     PUNCTUATION = [".", ",", "!", "?"]
 
     def __init__(self, lexicon_path: Optional[str] = None, lexicon: Optional[Dict[str, List[str]]] = None,
-                 fallback: Optional[Callable[[str], Iterable[str]]] = None):
+                 fallback: Optional[Callable[[str], Iterable[str]]] = None, converter: Optional[Callable] = None):
         self.lexicon_path = lexicon_path
         self.lexicon = {k.lower(): list(v) for k, v in (lexicon or {}).items()}
         self.lexicon.update(self.load_lexicon())
         self.fallback = fallback
+        self.converter = converter if converter is not None else ArpabetConverter()
 
     def load_lexicon(self) -> Dict[str, List[str]]:
         lex = {}
@@ -99,12 +126,15 @@ class LexiconG2P:
             if word[-1] in self.PUNCTUATION:
                 punctuation, word = word[-1], word[:-1]
             if word in self.lexicon:
-                phones += self.lexicon[word]
+                add_phones = self.lexicon[word]
             elif self.fallback is not None:
-                phones += list(self.fallback(word))
+                add_phones = list(self.fallback(word))
             else:
                 raise KeyError(f"'{word}' is not in the lexicon and no fallback G2P is installed "
                                "(the reference uses the third-party g2p_en model here)")
+            for phone in add_phones:  # g2p.py:42-46
+                phone = phone.replace("0", "").replace("1", "")
+                phones += self.converter(phone, "arpabet", lang=None)
             phones.append("[" + unicodedata.name(punctuation) + "]" if punctuation else "[SILENCE]")
         return phones
 

@@ -164,8 +164,11 @@ class Engine:
             res["duration_rounded"] = torch.empty(B, L, dtype=torch.int32, device=dev)
             res["src_mask"] = torch.empty(B, L, dtype=torch.bool, device=dev)
             res["tgt_mask"] = torch.empty(B, T, dtype=torch.bool, device=dev)
-            for var in self.cfg.variances:
+            for i, var in enumerate(self.cfg.variances):
                 res[f"variances_{var}"] = torch.empty(B, T, dtype=torch.float32, device=dev)
+                if self.cfg.is_cwt(i):  # by-products of the CWT head (model.py:445-461)
+                    res[f"_cwt_spectrogram_{var}"] = torch.empty(B, T, 10, dtype=torch.float32, device=dev)
+                    res[f"_cwt_mean_std_{var}"] = torch.empty(B, 2, dtype=torch.float32, device=dev)
         return res
 
     def force_variance_targets(self, var_index: int, tgt: torch.Tensor):
@@ -191,6 +194,9 @@ class Engine:
             out.tgt_mask = res["tgt_mask"].data_ptr()
             for i, var in enumerate(self.cfg.variances):
                 out.variances[i] = res[f"variances_{var}"].data_ptr()
+                if self.cfg.is_cwt(i):
+                    out.var_spectrogram[i] = res[f"_cwt_spectrogram_{var}"].data_ptr()
+                    out.var_mean_std[i] = res[f"_cwt_mean_std_{var}"].data_ptr()
         with torch.cuda.device(self.device):
             st = self.lib.fs2_decode(self.handle, C.byref(out), self._stream())
         _lib.check(st, self.handle, "decode")
@@ -253,20 +259,21 @@ class FastSpeech2:
 
     # ---- reference-style construction from a Lightning checkpoint dict (fastspeech2.py:530-634) --
     @classmethod
-    def from_checkpoint(cls, checkpoint, *, precision: str = "fp32", device="cuda:0"):
+    def from_checkpoint(cls, checkpoint, *, precision: str = "fp32", device="cuda:0", tolerant: bool = False,
+                        init_seed: int = 0):
+        """``FastSpeech2.load_from_checkpoint(path)`` (generate.py:112) for a ``lit_model.ckpt`` path or an already
+        loaded checkpoint dict.  ``tolerant=True`` reproduces the reference's shape-mismatch-tolerant load
+        (fastspeech2.py:598-620; see checkpoint.resolve_state_dict), the default refuses a tensor that does not fit."""
+        from . import checkpoint as ck
         if isinstance(checkpoint, (str, bytes)) or hasattr(checkpoint, "__fspath__"):
-            checkpoint = torch.load(checkpoint, map_location="cpu", weights_only=False)
-        hparams = checkpoint["hyper_parameters"]
-        stats = checkpoint["stats"]
-        phone2id = checkpoint["phone2id"]
-        cfg = Fs2Config.from_hparams(hparams, stats=stats, n_phones=len(phone2id))
-        # keys of off-path modules (fastdiff_*, loss.*) are simply not asked for; a tensor of the wrong
-        # shape is an error naming it (the reference prints "Skip loading parameter" and keeps a random
-        # init, fastspeech2.py:598-617 - useless for inference, so it is not imitated)
-        model = cls(cfg, checkpoint["state_dict"], precision=precision, device=device, phone2id=phone2id,
+            checkpoint = ck.read_checkpoint(checkpoint)
+        cfg = ck.config_from_checkpoint(checkpoint)
+        sd, report = ck.resolve_state_dict(cfg, checkpoint["state_dict"], tolerant=tolerant, init_seed=init_seed)
+        model = cls(cfg, sd, precision=precision, device=device, phone2id=checkpoint["phone2id"],
                     speaker2dvector=checkpoint.get("speaker2dvector"))
-        for extra in ("speaker2id", "speaker2priors", "speaker_gmms", "dvector_gmms"):  # fastspeech2.py:571-587
-            if extra in checkpoint:
+        model.load_report = report
+        for extra in ck.EXTRA_KEYS:  # fastspeech2.py:571-587
+            if extra in checkpoint and extra != "speaker2dvector":
                 setattr(model, extra, checkpoint[extra])
         return model
 
@@ -281,6 +288,11 @@ class FastSpeech2:
                                "FastSpeech2(..., device=...) for another GPU")
         return self
 
+    def _target_key(self, vi: int) -> str:
+        """Teacher-forcing target of variance vi: the raw signal for a CWT variance (model.py:319-321)."""
+        var = self.cfg.variances[vi]
+        return f"variances_{var}_signal" if self.cfg.is_cwt(vi) else f"variances_{var}"
+
     def __call__(self, targets, inference: bool = False):
         return self.forward(targets, inference)
 
@@ -293,7 +305,7 @@ class FastSpeech2:
             # FastSpeech2.forward(batch) as the Lightning hooks call it (fastspeech2.py:787,800):
             # target durations (model.py:296-297) and target variances (model.py:317-325) are teacher
             # forced; forward only — the loss/backward of training_step stay with the caller.
-            missing = [k for k in ["duration"] + [f"variances_{v}" for v in self.cfg.variances] if k not in targets]
+            missing = [k for k in ["duration"] + [self._target_key(i) for i in range(len(self.cfg.variances))] if k not in targets]
             if missing:
                 raise KeyError(f"inference=False needs teacher-forcing targets {missing} (model.py:296-297,317-325)")
             force_durations = targets["duration"]
@@ -342,10 +354,13 @@ class FastSpeech2:
         self._t_guess[(B, L)] = T
         if teacher:
             for vi, var in enumerate(self.cfg.variances):
-                tgt = torch.as_tensor(np.asarray(targets[f"variances_{var}"]) if not isinstance(targets[f"variances_{var}"], torch.Tensor)
-                                      else targets[f"variances_{var}"]).to(self.device, dtype=torch.float32)
+                key = self._target_key(vi)
+                tgt = torch.as_tensor(np.asarray(targets[key]) if not isinstance(targets[key], torch.Tensor)
+                                      else targets[key]).to(self.device, dtype=torch.float32)
                 if tgt.dim() != 2 or tgt.shape[0] != B or tgt.shape[1] < T:
-                    raise ValueError(f"targets['variances_{var}'] must be (B, >= T) = ({B}, >= {T})")
+                    raise ValueError(f"targets[{key!r}] must be (B, >= T) = ({B}, >= {T})")
+                if self.cfg.is_cwt(vi):  # tgt = torch.log(tgt), bucketised as it is (model.py:418-419)
+                    tgt = torch.log(tgt)
                 self.engine.force_variance_targets(vi, tgt[:, :T].contiguous())
         for var, idx in (force_buckets or {}).items():
             idx = torch.as_tensor(idx).to(self.device, dtype=torch.int32).contiguous()
@@ -353,6 +368,12 @@ class FastSpeech2:
                 raise ValueError(f"force_buckets[{var!r}] must be (B, T)=({phones.shape[0]}, {T})")
             self.engine.force_buckets(self.cfg.variances.index(var), idx)
         res = self.engine.decode(outputs=pre)
+        for vi, var in enumerate(self.cfg.variances):  # the CWT head hands back a dict (model.py:445-461)
+            if self.cfg.is_cwt(vi):
+                ms = res.pop(f"_cwt_mean_std_{var}")
+                d = {"spectrogram": res.pop(f"_cwt_spectrogram_{var}"), "mean": ms[:, 0], "std": ms[:, 1]}
+                sig = res[f"variances_{var}"]
+                res[f"variances_{var}"] = d if teacher else {"reconstructed_signal": torch.exp(sig), **d}
         if teacher:  # the reference hands back the target tensor itself (model.py:297,337)
             d = targets["duration"]
             res["duration_rounded"] = d.to(self.device) if isinstance(d, torch.Tensor) else torch.as_tensor(np.asarray(d)).to(self.device)

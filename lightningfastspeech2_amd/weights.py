@@ -46,7 +46,10 @@ def _conformer_layer_spec(prefix, H, heads, F, k, depthwise, out):
         out[f"{prefix}.conv2.bias"] = (H,)
 
 
-def _predictor_spec(prefix, nlayers, cin, filt, k, depthwise, out):
+CWT_SCALES = 10  # VariancePredictor(cwt=True).linear = Linear(filter, 10) (model.py:505-508), CWT(n_scales=10) (dataset/cwt.py:25)
+
+
+def _predictor_spec(prefix, nlayers, cin, filt, k, depthwise, out, n_out=1):
     # VariancePredictor / VarianceConvolutionLayer, model.py:482-561
     for j in range(nlayers):
         p = f"{prefix}.layers.{j}.layers"
@@ -60,8 +63,8 @@ def _predictor_spec(prefix, nlayers, cin, filt, k, depthwise, out):
             out[f"{p}.0.module.bias"] = (filt,)
         out[f"{p}.2.weight"] = (filt,)
         out[f"{p}.2.bias"] = (filt,)
-    out[f"{prefix}.linear.weight"] = (1, filt)
-    out[f"{prefix}.linear.bias"] = (1,)
+    out[f"{prefix}.linear.weight"] = (n_out, filt)
+    out[f"{prefix}.linear.bias"] = (n_out,)
 
 
 def state_dict_spec(cfg: Fs2Config) -> "OrderedDict[str, tuple]":
@@ -79,7 +82,11 @@ def state_dict_spec(cfg: Fs2Config) -> "OrderedDict[str, tuple]":
         out[f"{p}.bins"] = (cfg.variance_nbins - 1,)
         out[f"{p}.embedding.weight"] = (cfg.variance_nbins, H)
         _predictor_spec(f"{p}.predictor", cfg.variance_nlayers[vi], H, cfg.variance_filter_size,
-                        cfg.variance_kernel_size[vi], cfg.variance_depthwise_conv, out)
+                        cfg.variance_kernel_size[vi], cfg.variance_depthwise_conv, out,
+                        n_out=CWT_SCALES if cfg.is_cwt(vi) else 1)
+        if cfg.is_cwt(vi):  # mean_std_linear = nn.Linear(filter_size, 2) (model.py:402-404)
+            out[f"{p}.mean_std_linear.weight"] = (2, cfg.variance_filter_size)
+            out[f"{p}.mean_std_linear.bias"] = (2,)
     for i in range(cfg.decoder_layers):
         _conformer_layer_spec(f"decoder.layers.{i}", H, cfg.decoder_head, cfg.decoder_conv_filter_size,
                               cfg.decoder_kernel_sizes[i], cfg.decoder_depthwise_conv, out)
@@ -114,6 +121,8 @@ def variance_bins(cfg: Fs2Config, var: str) -> np.ndarray:
     st = cfg.stats[var]
     n = cfg.variance_nbins - 1
     lo, hi = float(st["min"]), float(st["max"])
+    if var in cfg.variances and cfg.is_cwt(cfg.variances.index(var)):  # min = np.log(min), max = np.log(max) (model.py:394-396)
+        lo, hi = float(np.log(lo)), float(np.log(hi))
     if n == 1:
         return np.array([lo], np.float32)
     return (lo + (hi - lo) * (np.arange(n, dtype=np.float64) / (n - 1))).astype(np.float32)

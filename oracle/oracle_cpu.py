@@ -99,7 +99,7 @@ def conformer_layer(sd, prefix: str, x, heads: int, depthwise: bool, key_padding
     return x
 
 
-def variance_predictor(sd, prefix: str, x, nlayers: int, kernel: int, depthwise: bool, mask) -> torch.Tensor:
+def variance_predictor(sd, prefix: str, x, nlayers: int, kernel: int, depthwise: bool, mask, cwt: bool = False):
     """VariancePredictor.forward (model.py:510-522) over VarianceConvolutionLayer (model.py:524-561):
     n x [conv(k, pad (k-1)//2) (dense, or dw + pw 1x1) -> ReLU -> LayerNorm] -> Linear(.,1) ->
     squeeze -> masked_fill(mask, 0)."""
@@ -117,8 +117,10 @@ def variance_predictor(sd, prefix: str, x, nlayers: int, kernel: int, depthwise:
         z = torch.relu(z.transpose(1, 2))
         g = _t(sd, f"{p}.2.weight")
         y = F.layer_norm(z, (g.shape[0],), g, _t(sd, f"{p}.2.bias"), 1e-5)
-    out = F.linear(y, _t(sd, f"{prefix}.linear.weight"), _t(sd, f"{prefix}.linear.bias")).squeeze(-1)
-    return out.masked_fill(mask, 0)
+    out = F.linear(y, _t(sd, f"{prefix}.linear.weight"), _t(sd, f"{prefix}.linear.bias"))
+    if cwt:  # Linear(filter, 10), mask stacked over the 10 scales, out_conv handed back (model.py:505-522)
+        return out.masked_fill(mask[..., None], 0), y
+    return out.squeeze(-1).masked_fill(mask, 0)
 
 
 def round_durations(duration_pred: torch.Tensor, src_mask: torch.Tensor):
@@ -154,6 +156,8 @@ def variance_encoder(sd, cfg, var_index: int, x, mask, tgt=None):
     computed and returned."""
     var = cfg.variances[var_index]
     p = f"variance_adaptor.encoders.{var}"
+    if cfg.variance_transforms[var_index] == "cwt":
+        return _variance_encoder_cwt(sd, cfg, var_index, x, mask, tgt)
     pred = variance_predictor(sd, f"{p}.predictor", x, cfg.variance_nlayers[var_index],
                               cfg.variance_kernel_size[var_index], cfg.variance_depthwise_conv, mask)
     st = cfg.stats[var]
@@ -161,6 +165,30 @@ def variance_encoder(sd, cfg, var_index: int, x, mask, tgt=None):
     idx = torch.bucketize(bucket_value, _t(sd, f"{p}.bins"))  # right=False
     emb = F.embedding(idx, _t(sd, f"{p}.embedding.weight"))
     return pred, emb, idx
+
+
+def _variance_encoder_cwt(sd, cfg, var_index: int, x, mask, tgt=None):
+    """VarianceEncoder.forward, CWT branch (model.py:412-431,445-461) with CWT.recompose (dataset/cwt.py:18-21,49-50):
+    a 10-scale wavelet spectrogram per frame, utterance-level (mean, std) from the time-mean of the last conv layer,
+    signal = z-normalised (unbiased std, +1e-7) sum over the scales, * std + mean  -> log-domain pitch, bucketised against
+    log-spaced bins.  Returns (dict as the reference does, embedding, bucket indices); with ``tgt`` (the raw signal,
+    targets["variances_<var>_signal"]) the embedding comes from bucketize(log(tgt))."""
+    var = cfg.variances[var_index]
+    p = f"variance_adaptor.encoders.{var}"
+    spec, out_conv = variance_predictor(sd, f"{p}.predictor", x, cfg.variance_nlayers[var_index],
+                                        cfg.variance_kernel_size[var_index], cfg.variance_depthwise_conv, mask, cwt=True)
+    ms = F.linear(out_conv.mean(dim=1), _t(sd, f"{p}.mean_std_linear.weight"), _t(sd, f"{p}.mean_std_linear.bias"))
+    mean, std = ms[:, 0], ms[:, 1]
+    bins = _t(sd, f"{p}.bins")
+    if tgt is not None:
+        idx = torch.bucketize(torch.log(tgt), bins)
+        return {"spectrogram": spec, "mean": mean, "std": std}, F.embedding(idx, _t(sd, f"{p}.embedding.weight")), idx
+    sig = spec.sum(dim=-1)                                            # wavelet_recomposition: sum over the scales
+    sig = (sig - sig.mean(dim=1, keepdim=True)) / (sig.std(dim=1, keepdim=True) + 1e-7)  # torch .std(): unbiased
+    pred = sig * std[:, None] + mean[:, None]
+    idx = torch.bucketize(pred, bins)
+    res = {"reconstructed_signal": torch.exp(pred), "spectrogram": spec, "mean": mean, "std": std}
+    return res, F.embedding(idx, _t(sd, f"{p}.embedding.weight")), idx
 
 
 @torch.no_grad()
@@ -213,8 +241,9 @@ def forward(sd, cfg, phones, speaker, *, return_intermediates: bool = False,
     result = {}
     for vi, var in enumerate(cfg.variances):                                  # model.py:315-333
         tgt = None
-        if teacher_targets is not None:  # model.py:317-325
-            tgt = torch.as_tensor(np.asarray(teacher_targets[f"variances_{var}"])).float()
+        if teacher_targets is not None:  # model.py:317-325 (a CWT variance is forced with its raw signal)
+            key = f"variances_{var}_signal" if cfg.variance_transforms[vi] == "cwt" else f"variances_{var}"
+            tgt = torch.as_tensor(np.asarray(teacher_targets[key])).float()
         pred, emb, idx = variance_encoder(sd, cfg, vi, x, tgt_mask, tgt)
         result[f"variances_{var}"] = pred
         inter[f"bucket_{var}"] = idx

@@ -48,3 +48,11 @@ class Golden:
         sd = synth_state_dict(self.cfg, **self.synth)
         assert sd_digest(sd) == self.sd_sha256, "synthetic weight recipe drifted from the fixture"
         return sd
+
+
+def lookup(out, key):
+    """out["variances_pitch.mean"] -> out["variances_pitch"]["mean"]: the CWT head returns a dict per variance."""
+    if "." in key:
+        a, b = key.split(".", 1)
+        return out[a][b]
+    return out[key]

@@ -62,6 +62,22 @@ def test_lexicon_g2p_matches_reference():
     assert LexiconG2P(lexicon=lex, fallback=lambda w: ["?"])("hello zzz") == lex["hello"] + ["[SILENCE]", "?", "[SILENCE]"]
 
 
+def test_arpabet_g2p_matches_reference_call():
+    """Stress-digit stripping + ARPAbet -> IPA conversion: the fixture is what the reference's own EnglishG2P.__call__
+    returned with a NON-identity converter (the table) and ARPAbet lexicon / fallback phones carrying stress digits."""
+    from lightningfastspeech2_amd.frontend import ARPABET_TO_IPA, ArpabetConverter
+    lex, oov = json.loads(str(Z["g2p2_lexicon"])), json.loads(str(Z["g2p2_oov"]))
+    g = LexiconG2P(lexicon=lex, fallback=lambda w: oov[w])
+    for text, want in zip(json.loads(str(Z["g2p2_texts"])), json.loads(str(Z["g2p2_out"]))):
+        assert g(text) == want
+    out = g("hello everything")
+    assert out[:4] == ["h", "ʌ", "l", "oʊ"]           # AH0 -> AH -> ʌ, OW1 -> oʊ: digits gone before the table
+    assert "ɪ" in out and "IH2" not in out             # the '2' the reference leaves on is tolerated by the table
+    assert len(ARPABET_TO_IPA) == 40 and ArpabetConverter()("ZH") == ["ʒ"] and ArpabetConverter()("ə") == ["ə"]
+    with pytest.raises(ValueError):
+        ArpabetConverter()("a", "xsampa")
+
+
 def test_lexicon_file_and_text_to_batch(tmp_path):
     p = tmp_path / "lex.txt"
     p.write_text("hello\th ə l oʊ\n\nworld\tw ɜː l d\n", encoding="utf-8")

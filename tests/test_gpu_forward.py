@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-from _golden import Golden, golden_names
+from _golden import Golden, golden_names, lookup
 from lightningfastspeech2_amd.config import Fs2Config, preset
 from lightningfastspeech2_amd.weights import synth_inputs, synth_state_dict
 from oracle import oracle_cpu
@@ -40,7 +40,7 @@ def _model(cfg, sd, precision):
 
 
 def _cpu(d):
-    return {k: v.cpu() for k, v in d.items()}
+    return {k: ({kk: vv.cpu() for kk, vv in v.items()} if isinstance(v, dict) else v.cpu()) for k, v in d.items()}
 
 
 @pytest.mark.parametrize("name", golden_names())
@@ -62,7 +62,7 @@ def test_fp32_matches_reference_golden(name):
         assert np.array_equal(out[k].numpy(), g.out[k]), k
     for k, ref in g.out.items():
         if ref.dtype.kind == "f":
-            errs[k] = float(np.abs(out[k].numpy() - ref).max())
+            errs[k] = float(np.abs(lookup(out, k).numpy() - ref).max())
     for k, ref in g.mid.items():
         errs["mid_" + k] = float(np.abs(m.engine.debug_tensor(k).cpu().numpy() - ref).max())
     _report(test="golden_fp32", case=name, errs=errs)

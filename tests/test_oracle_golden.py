@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from _golden import Golden, golden_names
+from _golden import Golden, golden_names, lookup
 from lightningfastspeech2_amd.config import Fs2Config
 from lightningfastspeech2_amd.weights import synth_inputs, synth_state_dict
 from oracle import oracle_cpu
@@ -15,7 +15,7 @@ ORACLE_TOL = 2e-5  # fp32 restatement vs the reference's own fp32 forward (obser
 def test_fixtures_present():
     names = golden_names()
     for want in ("dense_small", "dw_small", "mixed_small", "guard_small", "clip_small", "priors_small", "teacher_small",
-                 "mid_dense_d128", "mid_dw_d64"):
+                 "mid_dense_d128", "mid_dw_d64", "cwt_small", "cwt_teacher_small"):
         assert want in names
 
 
@@ -30,7 +30,7 @@ def test_oracle_matches_reference_golden(name):
     assert out["duration_rounded"].dtype == (torch.int32 if g.teacher is None else torch.int64)
     for k, ref in g.out.items():
         if ref.dtype.kind == "f":
-            err = float(np.abs(out[k].numpy() - ref).max())
+            err = float(np.abs(lookup(out, k).numpy() - ref).max())
             assert err <= ORACLE_TOL, (k, err)
     for k, ref in g.mid.items():
         err = float(np.abs(out["_intermediates"][k].numpy() - ref).max())

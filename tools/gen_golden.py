@@ -76,6 +76,17 @@ CASES = {
                     {"guard": "some"}),
     "clip_small": (small(max_length=20.5 * 256 / 22050), 3, 12, [12, 12, 6], dict(duration_bias=1.3),
                    {"clip": True}),
+    # class default variance_transforms = [cwt, none, none] (fastspeech2.py:60): the CWT pitch head
+    "cwt_small": (small(variance_transforms=["cwt", "none", "none"],
+                        stats={"pitch": {"min": 0.2, "max": 5.0, "mean": 0.1, "std": 1.5},
+                               "energy": {"min": -3.0, "max": 3.0, "mean": 0.0, "std": 1.0},
+                               "snr": {"min": -1.0, "max": 4.0, "mean": 1.2, "std": 2.0}}),
+                  3, 11, [11, 7, 4], dict(duration_bias=1.2), {}),
+    "cwt_teacher_small": (small(variance_transforms=["cwt", "none", "none"],
+                                stats={"pitch": {"min": 0.2, "max": 5.0, "mean": 0.1, "std": 1.5},
+                                       "energy": {"min": -3.0, "max": 3.0, "mean": 0.0, "std": 1.0},
+                                       "snr": {"min": -1.0, "max": 4.0, "mean": 1.2, "std": 2.0}}),
+                          3, 11, [11, 7, 4], dict(duration_bias=1.2), {"teacher": True}),
     "mid_dense_d128": (Fs2Config(n_phones=80, encoder_hidden=256, decoder_hidden=256, encoder_head=2,
                                  decoder_head=2, encoder_layers=1, decoder_layers=2,
                                  encoder_kernel_sizes=[9], decoder_kernel_sizes=[9, 9],
@@ -113,12 +124,19 @@ def margins(cfg, out):
     frac = v - torch.floor(v)
     round_margin = float((frac - 0.5).abs().min()) if v.numel() else 1.0
     bucket_margin = 1.0
-    for var in cfg.variances:
+    for vi, var in enumerate(cfg.variances):
         st = cfg.stats[var]
-        bins = torch.linspace(st["min"], st["max"], cfg.variance_nbins - 1).double()
-        # pad frames carry pred == 0 exactly (masked_fill, model.py:518) -> value == mean in any
-        # implementation, so only valid frames can flip
-        val = (out[f"variances_{var}"].double() * st["std"] + st["mean"])[~out["tgt_mask"]]
+        if cfg.is_cwt(vi):  # log-spaced bins; the recomposed signal is bucketised at EVERY frame, pads included
+            bins = torch.linspace(float(np.log(st["min"])), float(np.log(st["max"])), cfg.variance_nbins - 1).double()
+            v = out[f"variances_{var}"]
+            if "reconstructed_signal" not in v:
+                continue  # teacher-forced: the embedding came from the target
+            val = torch.log(v["reconstructed_signal"].double())
+        else:
+            bins = torch.linspace(st["min"], st["max"], cfg.variance_nbins - 1).double()
+            # pad frames carry pred == 0 exactly (masked_fill, model.py:518) -> value == mean in any
+            # implementation, so only valid frames can flip
+            val = (out[f"variances_{var}"].double() * st["std"] + st["mean"])[~out["tgt_mask"]]
         bucket_margin = min(bucket_margin, float((val[..., None] - bins).abs().min()))
     return round_margin, bucket_margin
 
@@ -136,6 +154,9 @@ def make_case(name, cfg, B, L, lengths, skw, want):
                 dur[b, n:] = 0
             Tt = int(dur.sum(1).max())
             tt = {"duration": dur, **{f"variances_{v}": (1.2 * rs.randn(B, Tt)).astype(np.float32) for v in cfg.variances}}
+            for vi, v in enumerate(cfg.variances):
+                if cfg.is_cwt(vi):  # the raw (positive) signal; model.py:319-321 reads variances_<var>_signal
+                    tt[f"variances_{v}_signal"] = np.exp(0.8 * rs.randn(B, Tt)).astype(np.float32)
         out = run_reference(cfg, sd, inp["phones"], inp["speaker"], capture=True, priors=pri, teacher_targets=tt)
         rm, bm = margins(cfg, out)
         n_guard = out["_stdout"].count("Zero duration")
@@ -144,10 +165,14 @@ def make_case(name, cfg, B, L, lengths, skw, want):
         ok = rm > want.get("round_margin", ROUND_MARGIN) and bm > want.get("bucket_margin", BUCKET_MARGIN)
         if want.get("teacher"):
             st_ok = True
-            for v in cfg.variances:  # the forced targets must keep a margin from the bin edges too
+            for vi, v in enumerate(cfg.variances):  # the forced targets must keep a margin from the bin edges too
                 stv = cfg.stats[v]
-                bins = torch.linspace(stv["min"], stv["max"], cfg.variance_nbins - 1).double()
-                val = torch.as_tensor(tt[f"variances_{v}"]).double() * stv["std"] + stv["mean"]
+                if cfg.is_cwt(vi):
+                    bins = torch.linspace(float(np.log(stv["min"])), float(np.log(stv["max"])), cfg.variance_nbins - 1).double()
+                    val = torch.log(torch.as_tensor(tt[f"variances_{v}_signal"]).double())
+                else:
+                    bins = torch.linspace(stv["min"], stv["max"], cfg.variance_nbins - 1).double()
+                    val = torch.as_tensor(tt[f"variances_{v}"]).double() * stv["std"] + stv["mean"]
                 st_ok = st_ok and float((val[..., None] - bins).abs().min()) > 1e-4
             ok = st_ok
         if want.get("guard") == "some":
@@ -169,7 +194,11 @@ def make_case(name, cfg, B, L, lengths, skw, want):
         for k, v in out.items():
             if k.startswith("_"):
                 continue
-            arrays[f"out_{k}"] = v.numpy()
+            if isinstance(v, dict):  # the CWT head returns a dict per variance (model.py:445-461)
+                for kk, vv in v.items():
+                    arrays[f"out_{k}.{kk}"] = vv.numpy()
+            else:
+                arrays[f"out_{k}"] = v.numpy()
         if not want.get("slim"):
             for k, v in out["_intermediates"].items():
                 arrays[f"mid_{k}"] = v.numpy()

@@ -99,6 +99,26 @@ def main():
     fix["g2p_lexicon"] = np.asarray(json.dumps(lex))
     fix["g2p_texts"] = np.asarray(json.dumps(texts))
     fix["g2p_out"] = np.asarray(json.dumps([e(t) for t in texts]))
+    # EnglishG2P on ARPAbet: lexicon entries AND the (stubbed) g2p_en fallback carry stress digits; the converter is the
+    # table-driven ARPAbet -> IPA map (NOT an identity) - what the reference's own __call__ does with them is the fixture:
+    # 0 / 1 stripped, 2 kept (g2p.py:44), the converter's list EXTENDS the phone list (g2p.py:45-46)
+    from lightningfastspeech2_amd.frontend import ArpabetConverter
+    lex2 = {"hello": ["HH", "AH0", "L", "OW1"], "world": ["W", "ER1", "L", "D"], "choice": ["CH", "OY1", "S"]}
+    oov = {"thinking": ["TH", "IH1", "NG", "K", "IH0", "NG"], "about": ["AH0", "B", "AW1", "T"],
+           "everything": ["EH1", "V", "R", "IY0", "TH", "IH2", "NG"], "measure": ["M", "EH1", "ZH", "ER0"]}
+    with open(lex_path, "w", encoding="utf-8") as f:
+        for w, p in lex2.items():
+            f.write(w + "\t" + " ".join(p) + "\n")
+    e2 = g2p.EnglishG2P.__new__(g2p.EnglishG2P)
+    e2.lexicon_path = lex_path
+    e2.lexicon = g2p.EnglishG2P.load_lexicon(e2)
+    e2.g2p = lambda word: list(oov[word])          # stands in for g2p_en.G2p()(word): ARPAbet with stress digits
+    e2.converter = ArpabetConverter()
+    texts2 = ["Hello world, thinking about everything!", "choice measure. HELLO?", "about world"]
+    fix["g2p2_lexicon"] = np.asarray(json.dumps(lex2))
+    fix["g2p2_oov"] = np.asarray(json.dumps(oov))
+    fix["g2p2_texts"] = np.asarray(json.dumps(texts2))
+    fix["g2p2_out"] = np.asarray(json.dumps([e2(t) for t in texts2]))
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "frontend_collate.npz"), **fix)
     print({k: (v.shape if v.ndim else "json") for k, v in fix.items()})
 
