@@ -207,6 +207,8 @@ def main():
     model = FastSpeech2(cfg, sd, precision=args.precision, device=dev)
     if args.no_fused_predictor:
         model.engine.set_fused_predictor(False)
+    if os.environ.get("FS2_DEFER_LN") == "0":  # A/B: one launch per LayerNorm in the wide depth-wise blocks
+        model.engine.set_deferred_layernorm(False)
     if os.environ.get("FS2_XCD_REMAP"):  # A/B: 0 = plain tile order in the slab GEMM
         _lib.load().fs2_op_set_gemm_variant(200 + int(os.environ["FS2_XCD_REMAP"]))
     inp = synth_inputs(cfg, args.batch, args.phones, seed=1234 + 17 * rank)
@@ -253,9 +255,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # dominant kernel: the decoder FFN's dense k-tap conv (implicit GEMM); depth-wise configs have no
-    # dense conv, there the pointwise GEMM launches (aggregated) dominate
-    kcls = _lib.K_DEC_FFN_CONV1 if not cfg.decoder_depthwise_conv else _lib.K_GEMM
+    # dominant kernel: the decoder FFN's first GEMM - the dense k-tap conv (implicit GEMM), or in a depth-wise
+    # (LightSpeech) block the pointwise H -> F GEMM behind the depth-wise conv.  One launch shape, few events.
+    kcls = _lib.K_DEC_FFN_CONV1
     model.engine.profile_enable(kcls, True)
     sync()
     t0 = time.perf_counter()
@@ -310,7 +312,8 @@ def main():
                          "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": ("gemm_conv_slab_kernel: decoder FFN conv1, implicit-GEMM Conv1d "
                                     f"M={args.batch * T} N={cfg.decoder_conv_filter_size} K={cfg.decoder_kernel_sizes[0]}x{cfg.hidden}")
-                         if kcls == _lib.K_DEC_FFN_CONV1 else "gemm_conv_slab_kernel (pointwise GEMM launches, aggregated)",
+                         if not cfg.decoder_depthwise_conv else
+                         f"gemm_conv_slab_kernel: decoder FFN pointwise conv1.1 M={args.batch * T} N={cfg.decoder_conv_filter_size} K={cfg.hidden}",
                          "launches_timed": prof["launches"], "avg_launch_us": avg_s * 1e6,
                          "flops_per_launch": prof["flops"] / n},
         }

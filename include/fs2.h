@@ -161,6 +161,11 @@ int fs2_set_debug(fs2_engine* e, int32_t on);
 /* A/B and parity aid: on = 0 runs every VariancePredictor as per-layer conv+LayerNorm launches, 1
  * (default) as the single-launch kernel where the shape allows it (bf16, filter 256, k = 3, dense). */
 int fs2_set_fused_predictor(fs2_engine* e, int32_t on);
+/* A/B and parity aid: hidden sizes above 256 with depth-wise blocks (LightSpeech, model.py:73-93,541-558) run LayerNorm
+ * deferred (default 1): the GEMM in front of a LayerNorm leaves pre-norm rows + row statistics, the depth-wise conv / the
+ * next residual add normalise on load and the remaining LayerNorms are normalise-only passes; 0 = GEMM launch + LayerNorm
+ * launch everywhere (the round-1 path). */
+int fs2_set_deferred_layernorm(fs2_engine* e, int32_t on);
 /* Parity aid (the analogue of the reference's teacher forcing of variance targets,
  * model.py:417-422): the NEXT fs2_decode embeds these (B, T) int32 device bucket indices for
  * variance `variance_index` instead of bucketizing its own prediction.  One-shot. */

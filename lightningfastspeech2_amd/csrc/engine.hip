@@ -123,6 +123,7 @@ struct fs2_engine {
     bool debug = false;
     bool fuse_predictor = true;
     bool zero_pad_mel = false;
+    bool defer_ln = true;      // hidden > 256, depth-wise blocks: LayerNorm deferred into its consumers (A/B: fs2_set_deferred_layernorm)
     bool front_split = false;  // FS2_MIXED_X3: the front's fp32 GEMMs / convs run as bf16 x 3 split products
     std::map<std::string, HostTensor> host;
     std::map<std::string, std::vector<int64_t>> spec;
@@ -475,6 +476,15 @@ struct Bracket {
 };
 
 // ---- op wrappers used by the forward ------------------------------------------------------------
+struct Deferred {  // deferred-LayerNorm epilogue of a GEMM (rows wider than one 256-column tile; see GemmArgs)
+    const void* res = nullptr;        // residual added to the output ...
+    const float* res_stats = nullptr; // ... itself a pre-norm tensor if set: normalised on load with res_g / res_b
+    const float* res_g = nullptr;
+    const float* res_b = nullptr;
+    float* stats_out = nullptr;       // (M, parts) float2
+};
+inline int ln_parts(int N) { return (N + 255) / 256; }  // one (sum, sum of squares) per row per 256-column GEMM tile, <= 4
+
 struct LnFuse {  // optional fused epilogue: y = LN(act(gemm) [+ res]) [-> head]
     const void* res = nullptr;
     const float* g = nullptr;
@@ -487,9 +497,13 @@ struct LnFuse {  // optional fused epilogue: y = LN(act(gemm) [+ res]) [-> head]
 };
 
 int gemm(fs2_engine* e, hipStream_t st, const ConvW& w, const void* x, void* c, int M, int S, bool relu, int out_dt,
-         const LnFuse* ln = nullptr, int extra_class = -1, const uint8_t* zero_rows = nullptr) {
+         const LnFuse* ln = nullptr, int extra_class = -1, const uint8_t* zero_rows = nullptr, const Deferred* df = nullptr) {
     GemmArgs a;
     a.zero_rows = zero_rows;
+    if (df) {
+        a.epi_res = df->res; a.epi_res_stats = df->res_stats; a.epi_res_g = df->res_g; a.epi_res_b = df->res_b;
+        a.epi_res_parts = ln_parts(w.N); a.stats_out = df->stats_out; a.ln_eps = 1e-5f;
+    }
     a.split = e->front_split && w.dt == FS2_F32;
     a.X = x;
     a.W = w.w;
@@ -519,8 +533,12 @@ int gemm(fs2_engine* e, hipStream_t st, const ConvW& w, const void* x, void* c, 
     if (r != FS2_OK) return fail(e, r, "gemm launch failed (M=%d N=%d K=%d)", M, a.N, a.K);
     return FS2_OK;
 }
-int dwconv(fs2_engine* e, hipStream_t st, const DwW& w, const void* x, void* y, int B, int S, int dt) {
+struct LnOnLoad { const float* stats; const float* g; const float* b; };  // x of a dwconv is a pre-norm tensor
+
+int dwconv(fs2_engine* e, hipStream_t st, const DwW& w, const void* x, void* y, int B, int S, int dt,
+           const LnOnLoad* ln = nullptr) {
     DwConvArgs a;
+    if (ln) { a.ln_stats = ln->stats; a.ln_g = ln->g; a.ln_b = ln->b; a.ln_parts = ln_parts(w.C); }
     a.x = x; a.w = w.w; a.bias = w.b; a.y = y;
     a.B = B; a.S = S; a.C = w.C; a.k = w.k; a.pad = (w.k - 1) / 2;
     Bracket br(e, FS2_K_ROWOPS, st, 2.0 * B * S * (double)w.C * w.k, 2.0 * B * S * (double)w.C * (dt == FS2_BF16 ? 2 : 4));
@@ -529,7 +547,20 @@ int dwconv(fs2_engine* e, hipStream_t st, const DwW& w, const void* x, void* y, 
     return FS2_OK;
 }
 
+int norm_only(fs2_engine* e, hipStream_t st, int dt, const void* v, const float* stats, const float* g, const float* b, void* y,
+              int M, int H, const float* dot_w = nullptr, float dot_b = 0.f, const uint8_t* mask = nullptr, float* pred = nullptr) {
+    LayerNormArgs l;
+    l.pre_stats = stats; l.pre_parts = ln_parts(H);
+    l.x = v; l.res = nullptr; l.gamma = g; l.beta = b; l.y = y;
+    l.dot_w = dot_w; l.dot_b = dot_b; l.mask = mask; l.pred = pred;
+    l.M = M; l.H = H; l.eps = 1e-5f;
+    Bracket br(e, FS2_K_ROWOPS, st, 0, 2.0 * M * (double)H * (dt == FS2_BF16 ? 2 : 4));
+    if (launch_layernorm(l, dt, st) != FS2_OK) return fail(e, FS2_ERR_HIP, "normalise-only LayerNorm launch failed");
+    return FS2_OK;
+}
+
 struct LayerScratch {
+    float *st1, *st2;  // deferred-LayerNorm row statistics (M, ln_parts(max width)) float2 each
     void *qkv, *att, *proj, *hid, *u, *vt;
     uint64_t* bits;
     int Spad, nw64;
@@ -556,6 +587,22 @@ int conformer(fs2_engine* e, hipStream_t st, const LayerW& w, void* x, void* tmp
         const int r = launch_attention(a, dt, st);
         if (r != FS2_OK) return fail(e, r, "attention launch failed");
     }
+    if (w.depthwise && H > 256 && e->defer_ln) {
+        // Rows wider than one GEMM tile cannot have LayerNorm fused behind the GEMM, and in the depth-wise block every
+        // consumer of LN1's output is a row operation.  So LN1 is never materialised: the out-projection's epilogue
+        // leaves v1 = x + out_proj(att) and its row statistics, the depth-wise conv normalises v1 as it loads it, and
+        // conv2's epilogue normalises v1 once more for the residual; LN2 is a normalise-only pass over conv2's output.
+        Deferred d1;
+        d1.res = x; d1.stats_out = sc.st1;
+        CHK(gemm(e, st, w.out_proj, sc.att, tmp, M, M, false, dt, nullptr, -1, nullptr, &d1));       // tmp = v1
+        LnOnLoad l1{sc.st1, w.g1, w.b1};
+        CHK(dwconv(e, st, w.dw, tmp, sc.u, B, S, dt, &l1));
+        CHK(gemm(e, st, w.c1, sc.u, sc.hid, M, S, true, dt, nullptr, is_decoder ? FS2_K_DEC_FFN_CONV1 : -1));
+        Deferred d2;
+        d2.res = tmp; d2.res_stats = sc.st1; d2.res_g = w.g1; d2.res_b = w.b1; d2.stats_out = sc.st2;
+        CHK(gemm(e, st, w.c2, sc.hid, x, M, S, false, dt, nullptr, -1, nullptr, &d2));                // x = v2 (x is free by now)
+        return norm_only(e, st, dt, x, sc.st2, w.g2, w.b2, x, M, H);                                   // x = LN2(v2), in place
+    }
     {   // tmp = LN1(x + out_proj(att))
         LnFuse ln;
         ln.res = x; ln.g = w.g1; ln.b = w.b1; ln.tmp = sc.proj;
@@ -563,7 +610,7 @@ int conformer(fs2_engine* e, hipStream_t st, const LayerW& w, void* x, void* tmp
     }
     if (w.depthwise) {
         CHK(dwconv(e, st, w.dw, tmp, sc.u, B, S, dt));
-        CHK(gemm(e, st, w.c1, sc.u, sc.hid, M, S, true, dt));
+        CHK(gemm(e, st, w.c1, sc.u, sc.hid, M, S, true, dt, nullptr, is_decoder ? FS2_K_DEC_FFN_CONV1 : -1));
     } else {
         CHK(gemm(e, st, w.c1, tmp, sc.hid, M, S, true, dt, nullptr, is_decoder ? FS2_K_DEC_FFN_CONV1 : -1));
     }
@@ -596,6 +643,32 @@ int predictor(fs2_engine* e, hipStream_t st, const PredictorW& P, const void* x,
         Bracket br(e, FS2_K_CONV_GEMM, st, fl, by);
         const int r = launch_predictor_fused(a, st);
         if (r != FS2_OK) return fail(e, r, "fused predictor launch failed (B=%d S=%d)", B, S);
+        return FS2_OK;
+    }
+    if (P.layers[0].depthwise && P.filt > 256 && e->defer_ln) {
+        // depth-wise predictor, wide rows: [dw conv -> pointwise GEMM -> ReLU] leaves the pre-norm activations + row
+        // statistics; the NEXT layer's depth-wise conv normalises on load, the last layer's LayerNorm + head is a
+        // normalise-only pass that stores nothing but the prediction (or the activations, for the CWT head)
+        const void* src = x;
+        float* stats[2] = {sc.st1, sc.st2};
+        const PredLayerW* prev = nullptr;
+        for (size_t j = 0; j < P.layers.size(); ++j) {
+            const PredLayerW& Lw = P.layers[j];
+            void* out = (j & 1) ? sc.proj : sc.att;
+            LnOnLoad lp{stats[(j + 1) & 1], prev ? prev->g : nullptr, prev ? prev->b : nullptr};
+            CHK(dwconv(e, st, Lw.dw, src, sc.u, B, S, P.dt, prev ? &lp : nullptr));
+            Deferred d;
+            d.stats_out = stats[j & 1];
+            CHK(gemm(e, st, Lw.c, sc.u, out, M, S, true, P.dt, nullptr, -1, nullptr, &d));
+            src = out;
+            prev = &Lw;
+        }
+        float* stl = stats[(P.layers.size() - 1) & 1];
+        if (!P.cwt) return norm_only(e, st, P.dt, src, stl, prev->g, prev->b, nullptr, M, P.filt, P.head_w, P.head_b, mask, pred);
+        CHK(norm_only(e, st, P.dt, src, stl, prev->g, prev->b, (void*)src, M, P.filt));
+        CHK(gemm(e, st, P.head_mat, src, cw->spec12, M, M, false, FS2_F32));
+        CwtArgs ca{src, cw->spec12, 12, mask, P.ms_w, P.ms_b, cw->mean_std, pred, cw->spec_out, B, S, P.filt};
+        if (launch_cwt_head(ca, P.dt, st) != FS2_OK) return fail(e, FS2_ERR_HIP, "cwt head launch failed");
         return FS2_OK;
     }
     const void* src = x;
@@ -638,7 +711,7 @@ size_t layer_scratch_bytes(const fs2_engine* e, int B, int S) {
     if ((size_t)c.dur_filter > Pm) Pm = c.dur_filter;
     const size_t Spad = ((size_t)S + 63) / 64 * 64;
     return al(M * 3 * H * esz) + 3 * al(M * Pm * esz) + al(M * Fm * esz) + al((size_t)B * H * Spad * esz) +
-           al((size_t)B * (Spad / 64) * 8) + 4096;
+           al((size_t)B * (Spad / 64) * 8) + 2 * al(M * (size_t)ln_parts((int)Pm) * 8) + 4096;
 }
 int take_layer_scratch(fs2_engine* e, Arena& ar, int B, int S, LayerScratch* sc) {
     const fs2_config& c = e->cfg;
@@ -649,6 +722,8 @@ int take_layer_scratch(fs2_engine* e, Arena& ar, int B, int S, LayerScratch* sc)
     if ((size_t)c.dur_filter > Pm) Pm = c.dur_filter;
     sc->Spad = (S + 63) / 64 * 64;
     sc->nw64 = sc->Spad / 64;
+    sc->st1 = (float*)ar.take(M * (size_t)ln_parts((int)Pm) * 8);
+    sc->st2 = (float*)ar.take(M * (size_t)ln_parts((int)Pm) * 8);
     sc->qkv = ar.take(M * 3 * H * esz);
     sc->att = ar.take(M * Pm * esz);
     sc->proj = ar.take(M * Pm * esz);
@@ -656,7 +731,7 @@ int take_layer_scratch(fs2_engine* e, Arena& ar, int B, int S, LayerScratch* sc)
     sc->u = ar.take(M * Pm * esz);
     sc->vt = ar.take((size_t)B * H * sc->Spad * esz);
     sc->bits = (uint64_t*)ar.take((size_t)B * sc->nw64 * 8);
-    if (!sc->qkv || !sc->att || !sc->proj || !sc->hid || !sc->u || !sc->vt || !sc->bits)
+    if (!sc->st1 || !sc->st2 || !sc->qkv || !sc->att || !sc->proj || !sc->hid || !sc->u || !sc->vt || !sc->bits)
         return fail(e, FS2_ERR_NOMEM, "scratch arena too small");
     return FS2_OK;
 }
@@ -816,6 +891,12 @@ int fs2_set_fused_predictor(fs2_engine* e, int32_t on) {
 int fs2_set_debug(fs2_engine* e, int32_t on) {
     if (!e) return FS2_ERR_ARG;
     e->debug = on != 0;
+    return FS2_OK;
+}
+
+int fs2_set_deferred_layernorm(fs2_engine* e, int32_t on) {
+    if (!e) return FS2_ERR_ARG;
+    e->defer_ln = on != 0;
     return FS2_OK;
 }
 

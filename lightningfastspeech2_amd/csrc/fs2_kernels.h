@@ -31,6 +31,15 @@ struct GemmArgs {
     float* pred = nullptr;          // (M)
     void* ln_tmp = nullptr;         // (M, ldc) scratch for the unfused fallback
     int xcd_remap = 0;              // set by the launcher
+    // Deferred-LayerNorm epilogue of the slab kernel (no ln_g): C = v = act(acc + bias) + res, and per row the partial
+    // sums (sum v, sum v^2) of every 64-column wave slice -> stats_out (M, ceil(N/256)*4) float2.  epi_res_stats != null:
+    // the residual is a pre-norm tensor normalised on load from ITS parts (epi_res_parts per row) with epi_res_g / _b.
+    const void* epi_res = nullptr;
+    const float* epi_res_stats = nullptr;
+    const float* epi_res_g = nullptr;
+    const float* epi_res_b = nullptr;
+    int epi_res_parts = 0;
+    float* stats_out = nullptr;
     int split = 0;                  // fp32 operands only: 1 = bf16 x 3 split arithmetic in the slab kernel (gemm_mfma.hip)
     const uint8_t* zero_rows = nullptr;  // (M) 1 = store zeros for this row (128x128 kernel only: the mel head)
 };
@@ -146,6 +155,8 @@ struct LayerNormArgs {
     float* pred;          // (M)
     int M, H;
     float eps;
+    const float* pre_stats = nullptr;  // (M, pre_parts) float2 partial (sum, sum of squares) of x's rows: skip the reductions
+    int pre_parts = 0;
 };
 int launch_layernorm(const LayerNormArgs& a, int dtype, hipStream_t stream);
 
@@ -155,6 +166,12 @@ struct DwConvArgs {
     const float* bias;  // (C) or null
     void* y;            // (B*S, C)
     int B, S, C, k, pad;
+    // x is a pre-norm tensor: LayerNorm it on load from its row parts (ln_parts float2 per row), gamma / beta (C)
+    const float* ln_stats = nullptr;
+    const float* ln_g = nullptr;
+    const float* ln_b = nullptr;
+    int ln_parts = 0;
+    float ln_eps = 1e-5f;
 };
 int launch_dwconv(const DwConvArgs& a, int dtype, hipStream_t stream);
 

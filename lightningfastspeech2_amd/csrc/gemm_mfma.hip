@@ -463,7 +463,8 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
     // Residual without an activation in front of it: start the accumulators AT the residual, fetched
     // with 16-byte loads that land underneath the first operand DMAs instead of sitting, exposed,
     // between the K loop and the row statistics.
-    const bool res_in_acc = LN && p.res && !p.relu;
+    // (the deferred-LayerNorm epilogue does the same with ITS residual, normalised first if that is a pre-norm tensor)
+    const bool res_in_acc = !p.relu && (LN ? p.res != nullptr : p.epi_res != nullptr);
     int woff[4][2];                          // weight fragment byte offsets (tap independent)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -538,39 +539,55 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < MI; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    if constexpr (LN) {
-        if (res_in_acc) {
-            const T* R = (const T*)p.res + (size_t)ub * S * p.ldc;
+    if (res_in_acc) {
+        const T* R = (const T*)(LN ? p.res : p.epi_res) + (size_t)ub * S * p.ldc;
+        const bool rnorm = !LN && p.epi_res_stats != nullptr;
+        const size_t rowbase0 = (size_t)ub * S;
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                int t = t0 + wm * (MI * 16) + mi * 16 + fr;
-                if (t >= S) t = S - 1;  // rows past the utterance end are never stored
+        for (int mi = 0; mi < MI; ++mi) {
+            int t = t0 + wm * (MI * 16) + mi * 16 + fr;
+            if (t >= S) t = S - 1;  // rows past the utterance end are never stored
+            float rmean = 0.f, rrstd = 1.f;
+            if (rnorm) {
+                const float2* ps = (const float2*)p.epi_res_stats + (rowbase0 + t) * p.epi_res_parts;
+                float2 pq[4];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int n = n0 + wn * 64 + j * 32 + fg * 8;
-                    const T* src = R + (size_t)t * p.ldc + n;
-                    float rv[8];
-                    if (n + 7 < p.N) {
-                        if constexpr (sizeof(T) == 4) {
-                            const float4 q0 = *(const float4*)src, q1 = *(const float4*)(src + 4);
-                            rv[0] = q0.x; rv[1] = q0.y; rv[2] = q0.z; rv[3] = q0.w;
-                            rv[4] = q1.x; rv[5] = q1.y; rv[6] = q1.z; rv[7] = q1.w;
-                        } else {
-                            const uint4 q = *(const uint4*)src;
-                            const unsigned w4[4] = {q.x, q.y, q.z, q.w};
+                for (int q = 0; q < 4; ++q) pq[q] = q < p.epi_res_parts ? ps[q] : make_float2(0.f, 0.f);
+                const float s1 = (pq[0].x + pq[1].x) + (pq[2].x + pq[3].x), s2 = (pq[0].y + pq[1].y) + (pq[2].y + pq[3].y);
+                const float invn = 1.0f / (float)p.N;
+                rmean = s1 * invn;
+                rrstd = 1.0f / sqrtf(fmaxf(__builtin_fmaf(-rmean, rmean, s2 * invn), 0.f) + p.ln_eps);
+            }
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                rv[2 * e] = __uint_as_float(w4[e] << 16);
-                                rv[2 * e + 1] = __uint_as_float(w4[e] & 0xffff0000u);
-                            }
-                        }
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wn * 64 + j * 32 + fg * 8;
+                const T* src = R + (size_t)t * p.ldc + n;
+                float rv[8];
+                if (n + 7 < p.N) {
+                    if constexpr (sizeof(T) == 4) {
+                        const float4 q0 = *(const float4*)src, q1 = *(const float4*)(src + 4);
+                        rv[0] = q0.x; rv[1] = q0.y; rv[2] = q0.z; rv[3] = q0.w;
+                        rv[4] = q1.x; rv[5] = q1.y; rv[6] = q1.z; rv[7] = q1.w;
                     } else {
+                        const uint4 q = *(const uint4*)src;
+                        const unsigned w4[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) rv[r] = (n + r < p.N) ? Num<T>::to_f32(src[r]) : 0.f;
+                        for (int e = 0; e < 4; ++e) {
+                            rv[2 * e] = __uint_as_float(w4[e] << 16);
+                            rv[2 * e + 1] = __uint_as_float(w4[e] & 0xffff0000u);
+                        }
                     }
+                } else {
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) acc[2 * j + (r >> 2)][mi][r & 3] = rv[r];
+                    for (int r = 0; r < 8; ++r) rv[r] = (n + r < p.N) ? Num<T>::to_f32(src[r]) : 0.f;
                 }
+                if (rnorm) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r)
+                        rv[r] = n + r < p.N ? __builtin_fmaf((rv[r] - rmean) * rrstd, p.epi_res_g[n + r], p.epi_res_b[n + r]) : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 8; ++r) acc[2 * j + (r >> 2)][mi][r & 3] = rv[r];
             }
         }
     }
@@ -954,6 +971,118 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
         }
     }
     };
+    if (p.stats_out || p.epi_res) {
+        // Deferred-LayerNorm epilogue (rows wider than one tile): v = act(acc + bias) + res, stored as it is, plus this
+        // column tile's sum(v), sum(v^2) per row -> stats_out[row][column tile]; the consumers (depth-wise conv,
+        // normalise-only LayerNorm, the next epilogue's residual) finish mean / rstd from the tiles' parts.
+        // The residual may itself be such a pre-norm tensor: then it is normalised on load from ITS parts.
+        const T* R = (p.epi_res && !res_in_acc) ? (const T*)p.epi_res + (size_t)ub * S * p.ldc : nullptr;  // else: already in acc
+        const size_t rowbase = (size_t)ub * S;
+        const float lo = p.relu ? 0.f : -__builtin_inff();
+        const bool rnorm = R && p.epi_res_stats;
+        float rg[2][8], rb[2][8];  // gamma / beta of the residual's LayerNorm for this lane's 2 x 8 channels
+        if (rnorm) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wn * 64 + j * 32 + fg * 8;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    rg[j][r] = n + r < p.N ? p.epi_res_g[n + r] : 0.f;
+                    rb[j][r] = n + r < p.N ? p.epi_res_b[n + r] : 0.f;
+                }
+            }
+        }
+        float a1[MI], a2[MI];
+        auto body = [&](auto full_c) {
+            constexpr bool FULL = decltype(full_c)::value;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int t = t0 + wm * (MI * 16) + mi * 16 + fr;
+            const int tc = t < S ? t : S - 1;
+            float rmean = 0.f, rrstd = 1.f;
+            if (rnorm) {
+                const float2* ps = (const float2*)p.epi_res_stats + (rowbase + tc) * p.epi_res_parts;
+                float2 pq[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pq[q] = q < p.epi_res_parts ? ps[q] : make_float2(0.f, 0.f);
+                const float s1 = (pq[0].x + pq[1].x) + (pq[2].x + pq[3].x), s2 = (pq[0].y + pq[1].y) + (pq[2].y + pq[3].y);
+                const float invn = 1.0f / (float)p.N;
+                rmean = s1 * invn;
+                rrstd = 1.0f / sqrtf(fmaxf(__builtin_fmaf(-rmean, rmean, s2 * invn), 0.f) + p.ln_eps);
+            }
+            a1[mi] = a2[mi] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int n = n0 + wn * 64 + j * 32 + fg * 8;
+                float v[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] = fmaxf(acc[2 * j + (r >> 2)][mi][r & 3] + bv[j][r], lo);
+                if (R && (FULL || n < p.N)) {
+                    const T* src = R + (size_t)tc * p.ldc + n;
+                    float x[8];
+                    if (FULL || n + 7 < p.N) {
+                        if constexpr (sizeof(T) == 4) {
+                            const float4 q0 = *(const float4*)src, q1 = *(const float4*)(src + 4);
+                            x[0] = q0.x; x[1] = q0.y; x[2] = q0.z; x[3] = q0.w; x[4] = q1.x; x[5] = q1.y; x[6] = q1.z; x[7] = q1.w;
+                        } else {
+                            Vec16<T>::unpack(*(const uint4*)src, x);
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) x[r] = n + r < p.N ? Num<T>::to_f32(src[r]) : 0.f;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        if (rnorm) x[r] = __builtin_fmaf((x[r] - rmean) * rrstd, rg[j][r], rb[j][r]);
+                        v[r] += x[r];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    if (!FULL && n + r >= p.N) v[r] = 0.f;
+                    a1[mi] += v[r];
+                    a2[mi] = __builtin_fmaf(v[r], v[r], a2[mi]);
+                }
+                if (t < S && (FULL || n < p.N)) {
+                    OutT* dst = (OutT*)((char*)C + (unsigned)(t * p.ldc + n) * (unsigned)sizeof(OutT));
+                    if (FULL || n + 7 < p.N) {
+                        if constexpr (sizeof(OutT) == 4) {
+                            *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
+                            *(float4*)(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                        } else {
+                            *(uint4*)dst = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]),
+                                                      pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) if (n + r < p.N) dst[r] = Num<OutT>::from_f32(v[r]);
+                    }
+                }
+            }
+        }
+        };
+        if (n0 + S_BN <= p.N) body(BoolC<true>{});
+        else body(BoolC<false>{});
+        if (p.stats_out) {  // one (sum, sum of squares) per row per column TILE: the four column waves meet in LDS
+            __syncthreads();  // every wave is done with the operand buffers
+            float2* red = (float2*)slab0;  // [4 column waves][BMs rows]
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const float s1 = group4_sum(a1[mi]), s2 = group4_sum(a2[mi]);
+                if (fg == 0) red[wn * BMs + wm * (MI * 16) + mi * 16 + fr] = make_float2(s1, s2);
+            }
+            __syncthreads();
+            for (int row = tid; row < BMs; row += 512) {
+                const int t = t0 + row;
+                if (t < S) {
+                    const float2 q0 = red[row], q1 = red[BMs + row], q2 = red[2 * BMs + row], q3 = red[3 * BMs + row];
+                    ((float2*)p.stats_out)[(rowbase + t) * (size_t)tiles_n + bn] =
+                        make_float2((q0.x + q1.x) + (q2.x + q3.x), (q0.y + q1.y) + (q2.y + q3.y));
+                }
+            }
+        }
+        return;
+    }
     const bool fulln = n0 + S_BN <= p.N;  // this column tile lies wholly inside N
     if (fulln) {
         if (p.relu) store(BoolC<true>{}, BoolC<true>{});
@@ -1080,6 +1209,7 @@ static int launch_gemm_plain(const GemmArgs& a, int in_dtype, int out_dtype, hip
     }
     if (fused && variant != 0) return FS2_OK;  // forced non-slab kernel: caller falls back
     if (variant == 2) {
+        if (a.stats_out || a.epi_res) return FS2_ERR_SHAPE;
         if (in_dtype == FS2_F32 && out_dtype == FS2_F32) return launch_glds_t<float, float>(a, stream);
         if (in_dtype == FS2_BF16 && out_dtype == FS2_BF16) return launch_glds_t<bf16, bf16>(a, stream);
         if (in_dtype == FS2_BF16 && out_dtype == FS2_F32) return launch_glds_t<bf16, float>(a, stream);
@@ -1113,6 +1243,7 @@ static int launch_gemm_plain(const GemmArgs& a, int in_dtype, int out_dtype, hip
         }
     }
     if (fused) return FS2_OK;  // not the slab kernel: caller falls back to GEMM + LayerNorm kernel
+    if (a.stats_out || a.epi_res) return FS2_ERR_SHAPE;  // the deferred-LayerNorm epilogue lives in the slab kernel only
     if (in_dtype == FS2_F32 && out_dtype == FS2_F32) return launch_t<float, float>(a, stream);
     if (in_dtype == FS2_BF16 && out_dtype == FS2_BF16) return launch_t<bf16, bf16>(a, stream);
     if (in_dtype == FS2_BF16 && out_dtype == FS2_F32) return launch_t<bf16, float>(a, stream);

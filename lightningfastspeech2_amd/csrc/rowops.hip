@@ -56,7 +56,17 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LayerNormArgs p) {
         }
         s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     }
-    const float mean = wave_sum(s) / (float)p.H;
+    float mean, rstd;
+    if (p.pre_stats) {  // statistics left by the producing GEMM's epilogue: normalise only
+        const float2* ps = (const float2*)p.pre_stats + (size_t)row * p.pre_parts;
+        float2 pq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pq[q] = q < p.pre_parts ? ps[q] : make_float2(0.f, 0.f);
+        const float s1 = (pq[0].x + pq[1].x) + (pq[2].x + pq[3].x), s2 = (pq[0].y + pq[1].y) + (pq[2].y + pq[3].y);
+        mean = s1 / (float)p.H;
+        rstd = 1.0f / sqrtf(fmaxf(__builtin_fmaf(-mean, mean, s2 / (float)p.H), 0.f) + p.eps);
+    } else {
+    mean = wave_sum(s) / (float)p.H;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -66,7 +76,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LayerNormArgs p) {
             for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q += d * d; }
         }
     }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)p.H + p.eps);
+    rstd = 1.0f / sqrtf(wave_sum(q) / (float)p.H + p.eps);
+    }
     float dot = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -125,12 +136,38 @@ template <typename T>
 __global__ __launch_bounds__(256) void dwconv_kernel(DwConvArgs p) {
     __shared__ __attribute__((aligned(16))) float tile[(DW_TR + DW_KMAX - 1) * DW_CT];
     __shared__ __attribute__((aligned(16))) float wl[DW_KMAX * DW_CT];  // [tap][channel]
+    __shared__ float rstat[(DW_TR + DW_KMAX - 1) * 2];                   // LayerNorm-on-load: (mean, rstd) per slab row
     const int tid = threadIdx.x;
     const int t0 = blockIdx.x * DW_TR, c0 = blockIdx.y * DW_CT, b = blockIdx.z;
     const T* x = (const T*)p.x + (size_t)b * p.S * p.C;
     const int nch = (p.k + DW_TC - 1) / DW_TC, kp = nch * DW_TC;
     const int rows = DW_TR + kp - 1;
     const bool full_c = c0 + DW_CT <= p.C;
+    const bool lnl = p.ln_stats != nullptr;
+    float lg[4] = {1.f, 1.f, 1.f, 1.f}, lb[4] = {0.f, 0.f, 0.f, 0.f};
+    float2 pq[4] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f), make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
+    if (lnl) {  // this thread's slab row (rows <= 159 < 256): its row-statistic parts, issued with the fill loads below
+        const int t = t0 + tid - p.pad;
+        if (tid < rows && t >= 0 && t < p.S) {
+            const float2* ps = (const float2*)p.ln_stats + ((size_t)b * p.S + t) * p.ln_parts;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (q < p.ln_parts) pq[q] = ps[q];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = c0 + (tid & 15) * 4 + e;
+            if (c < p.C) { lg[e] = p.ln_g[c]; lb[e] = p.ln_b[c]; }
+        }
+    }
+    auto publish_rstat = [&]() {
+        const float s1 = (pq[0].x + pq[1].x) + (pq[2].x + pq[3].x), s2 = (pq[0].y + pq[1].y) + (pq[2].y + pq[3].y);
+        const float mean = s1 / (float)p.C;
+        if (tid < rows) {
+            rstat[2 * tid] = mean;
+            rstat[2 * tid + 1] = 1.0f / sqrtf(fmaxf(__builtin_fmaf(-mean, mean, s2 / (float)p.C), 0.f) + p.ln_eps);
+        }
+        __syncthreads();
+    };
     if (full_c) {
         // every load of the slab is issued before the first is used (unconditional, clamped row, zeroed afterwards):
         // ONE memory round trip for the fill instead of one per 256 pieces
@@ -143,6 +180,17 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwConvArgs p) {
             const int r = ii >> 4, cq = (ii & 15) * 4, t = t0 + r - p.pad;
             const int tc = t < 0 ? 0 : (t < p.S ? t : p.S - 1);
             load4<T>(x + (size_t)tc * p.C + c0 + cq, v[u]);
+        }
+        if (lnl) publish_rstat();
+#pragma unroll
+        for (int u = 0; u < FB; ++u) {
+            const int i = tid + u * 256, ii = i < npc ? i : npc - 1;
+            const int r = ii >> 4, t = t0 + r - p.pad;
+            if (lnl) {
+                const float mean = rstat[2 * r], rstd = rstat[2 * r + 1];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[u][e] = __builtin_fmaf((v[u][e] - mean) * rstd, lg[e], lb[e]);
+            }
             if (t < 0 || t >= p.S) v[u][0] = v[u][1] = v[u][2] = v[u][3] = 0.f;
         }
 #pragma unroll
@@ -151,6 +199,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwConvArgs p) {
             if (i < npc) *(float4*)(tile + (i >> 4) * DW_CT + (i & 15) * 4) = make_float4(v[u][0], v[u][1], v[u][2], v[u][3]);
         }
     } else {
+        if (lnl) publish_rstat();
         for (int i = tid; i < rows * (DW_CT / 4); i += 256) {  // channel tail tile: element by element
             const int r = i >> 4, cq = (i & 15) * 4;
             const int t = t0 + r - p.pad;
@@ -158,7 +207,10 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwConvArgs p) {
             if (t >= 0 && t < p.S) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    if (c0 + cq + e < p.C) v[e] = Num<T>::to_f32(x[(size_t)t * p.C + c0 + cq + e]);
+                    if (c0 + cq + e < p.C) {
+                        v[e] = Num<T>::to_f32(x[(size_t)t * p.C + c0 + cq + e]);
+                        if (lnl) v[e] = __builtin_fmaf((v[e] - rstat[2 * r]) * rstat[2 * r + 1], p.ln_g[c0 + cq + e], p.ln_b[c0 + cq + e]);
+                    }
             }
             *(float4*)(tile + r * DW_CT + cq) = make_float4(v[0], v[1], v[2], v[3]);
         }

@@ -216,6 +216,10 @@ class Engine:
                    f"debug_copy({what})")
         return t
 
+    def set_deferred_layernorm(self, on: bool):
+        """A/B: wide depth-wise blocks with LayerNorm deferred into its consumers (default) or as its own launches."""
+        _lib.check(self.lib.fs2_set_deferred_layernorm(self.handle, int(on)), self.handle, "set_deferred_layernorm")
+
     def set_fused_predictor(self, on: bool):
         """A/B: run the variance/duration predictors as one launch each (default) or layer by layer."""
         _lib.check(self.lib.fs2_set_fused_predictor(self.handle, int(on)), self.handle, "set_fused_predictor")

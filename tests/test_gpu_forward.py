@@ -199,6 +199,39 @@ def test_mixed_precision_decisions_on_goldens(name, mode):
     assert np.isfinite(err)
 
 
+@pytest.mark.parametrize("cwt", [False, True], ids=["plain", "cwt"])
+def test_deferred_layernorm_matches_its_own_launches(cwt):
+    """hidden 768, depth-wise blocks: LayerNorm deferred into its consumers (pre-norm rows + row statistics from the GEMM
+    epilogue; depth-wise conv / residual add normalise on load; normalise-only passes) against one launch per LayerNorm,
+    and against the oracle, in fp32; same decisions."""
+    mk, B, L, lengths, skw = CASES["ls_h768_2layer"]
+    cfg = mk()
+    if cwt:
+        d = cfg.to_dict()
+        d["variance_transforms"] = ["cwt", "none", "none"]
+        d["stats"] = {**d["stats"], "pitch": {"min": 0.2, "max": 5.0, "mean": 0.0, "std": 1.0}}
+        cfg = Fs2Config(**d)
+    sd, inp, ref = _oracle_case(cfg, B, L, lengths, seed=3, **skw)
+    batch = {"phones": torch.from_numpy(inp["phones"]), "speaker": torch.from_numpy(inp["speaker"])}
+    m = _model(cfg, sd, "fp32")
+    a = _cpu(m(batch, inference=True))
+    m.engine.set_deferred_layernorm(False)
+    b = _cpu(m(batch, inference=True))
+    assert torch.equal(a["duration_rounded"], b["duration_rounded"]) and torch.equal(a["duration_rounded"], ref["duration_rounded"])
+    d_ab = float((a["mel"] - b["mel"]).abs().max())
+    d_ref = float((a["mel"] - ref["mel"]).abs().max())
+    _report(test="deferred_ln", cwt=cwt, mel_deferred_vs_launches=d_ab, mel_deferred_vs_oracle=d_ref)
+    assert d_ab <= 2e-4 and d_ref <= MEL_TOL_FP32
+    if cwt:
+        for k in ("spectrogram", "mean", "std", "reconstructed_signal"):
+            assert float((a["variances_pitch"][k] - ref["variances_pitch"][k]).abs().max()) <= 1e-3, k
+    m16 = _model(cfg, sd, "bf16")
+    x = m16.forward(batch, force_durations=ref["duration_rounded"], force_buckets={v: ref["_intermediates"][f"bucket_{v}"] for v in cfg.variances})
+    m16.engine.set_deferred_layernorm(False)
+    y = m16.forward(batch, force_durations=ref["duration_rounded"], force_buckets={v: ref["_intermediates"][f"bucket_{v}"] for v in cfg.variances})
+    assert float((x["mel"] - y["mel"]).abs().max()) <= 0.15 and float((x["mel"].cpu() - ref["mel"]).abs().mean()) <= 0.03
+
+
 def test_full_size_properties_bf16():
     """BASELINE.json configs[1]: FS2-27M, batch 32 x 256 phonemes, 6 frames/phone -> T = 1536."""
     cfg = preset("c2")
@@ -252,6 +285,32 @@ def test_full_size_fp32_vs_oracle_one_utterance():
     assert bflips[cfg.variances[0]] <= 3  # first predictor sees identical inputs: only near-tie flips
 
 
+def test_full_size_full_batch_fp32_and_mixed_vs_oracle():
+    """BASELINE configs[1] at its FULL size - all 32 utterances x 256 phonemes -> T = 1536 - against the oracle:
+    fp32 parity mode holds mel <= 1e-3 on every entry of the (32, 1536, 80) tensor under the oracle's decisions (free-running
+    it differs from the oracle in a handful of near-tie buckets, counted); the mixed modes reproduce the durations exactly,
+    stay within a small multiple of the fp32 mode's bucket flips and hold the bf16-decoder tolerance."""
+    cfg = preset("c2")
+    sd = synth_state_dict(cfg, 0, duration_bias=float(np.log(7.0)), duration_weight_scale=0.0)
+    inp = synth_inputs(cfg, 32, 256, seed=1234)
+    ref = oracle_cpu.forward(sd, cfg, inp["phones"], inp["speaker"], return_intermediates=True)
+    batch = {"phones": torch.from_numpy(inp["phones"]), "speaker": torch.from_numpy(inp["speaker"])}
+    nb = sum(ref["_intermediates"][f"bucket_{v}"].numel() for v in cfg.variances)
+    rep = {"buckets": nb}
+    for mode in ("fp32", "mixed", "mixed3", "bf16"):
+        dfl, bfl, forced, free = _decisions(_model(cfg, sd, mode), cfg, batch, ref)
+        rep[mode] = dict(duration_flips=dfl, bucket_flips=bfl, mel_forced=forced)
+        assert dfl == 0 and tuple(free["mel"].shape) == (32, 1536, 80)
+        if mode == "fp32":
+            assert forced <= MEL_TOL_FP32 and bfl <= nb // 200   # ~0.3 % measured: near-tie buckets only
+        elif mode != "bf16":
+            assert forced <= 0.3 and bfl <= max(10 * rep["fp32"]["bucket_flips"], nb // 50)
+        else:
+            assert forced <= 0.3
+    _report(test="fullsize_fullbatch", **rep)
+    assert rep["mixed3"]["bucket_flips"] * 10 <= rep["bf16"]["bucket_flips"]
+
+
 def test_rejects_training_forward_and_bad_ids():
     g = Golden("dense_small")
     m = _model(g.cfg, g.state_dict(), "fp32")
@@ -292,9 +351,13 @@ def test_one_engine_many_shapes_and_checkpoint_roundtrip(tmp_path):
         ref = oracle_cpu.forward(sd, g.cfg, inp["phones"], inp["speaker"])
         o = _cpu(m({"phones": torch.from_numpy(inp["phones"]), "speaker": torch.from_numpy(inp["speaker"])}, inference=True))
         assert tuple(o["mel"].shape) == tuple(ref["mel"].shape)
-        if torch.equal(o["duration_rounded"], ref["duration_rounded"]):
-            mism = sum(int((o[f"variances_{v}"] - ref[f"variances_{v}"]).abs().max() > 1e-3) for v in g.cfg.variances)
-            if mism == 0:
-                assert float((o["mel"] - ref["mel"]).abs().max()) <= 5e-2  # free-running: a near-tie bucket may flip
+        # always compared: under the oracle's decisions (a near-tie duration / bucket may differ free-running) at 1e-3
+        ref = oracle_cpu.forward(sd, g.cfg, inp["phones"], inp["speaker"], return_intermediates=True)
+        b2 = {"phones": torch.from_numpy(inp["phones"]), "speaker": torch.from_numpy(inp["speaker"])}
+        f = _cpu(m.forward(b2, force_durations=ref["duration_rounded"],
+                           force_buckets={v: ref["_intermediates"][f"bucket_{v}"] for v in g.cfg.variances}))
+        assert torch.equal(f["tgt_mask"], ref["tgt_mask"])
+        assert float((f["mel"] - ref["mel"]).abs().max()) <= MEL_TOL_FP32
+        assert int((o["duration_rounded"] != ref["duration_rounded"]).sum()) <= 1
     again = _cpu(m({"phones": torch.from_numpy(g.phones), "speaker": torch.from_numpy(g.speaker)}, inference=True))
     assert torch.equal(again["mel"], out["mel"])

@@ -134,6 +134,12 @@ def main():
             gemm_ln_case("enc conv2 1x1 +res+LN", 8192, 256, 1024, 1, 8192, a.reps, v)
             gemm_ln_case("enc out_proj +res+LN", 8192, 256, 256, 1, 8192, a.reps, v)
             gemm_ln_case("dur-pred conv k=3 +LN", 8192, 256, 256, 3, 256, a.reps, v, res=False, relu=True)
+    if a.what in ("c3gemm",):  # the LS-76M decoder's pointwise GEMMs, by tile height
+        for v in ([3, 4, 5] if a.variant < 0 else [a.variant]):
+            gemm_case("c3 in_proj", 49152, 2304, 768, 1, 49152, a.reps, v)
+            gemm_case("c3 pw1", 49152, 3072, 768, 1, 49152, a.reps, v)
+            gemm_case("c3 conv2", 49152, 768, 3072, 1, 49152, a.reps, v)
+            gemm_case("c3 out_proj", 49152, 768, 768, 1, 49152, a.reps, v)
     if a.what in ("wide",):  # rows wider than one tile (C3 N = 768, C5 N = 1024): fused in-place LayerNorm vs GEMM + LayerNorm launches
         for knob in (300, 301):
             lib.fs2_op_set_gemm_variant(knob)
