@@ -2,7 +2,7 @@
 # tools/pmc_traffic.sh : HBM-side traffic of the decoder conv1 launch (bench.py's roofline.traffic).
 # Two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over tools/bench_ops.py gemm --only "dec conv1";
 # FETCH_SIZE is doubled (gfx950 counts 128-byte requests at 64 B, MI355X_MICROARCH.md HBM note); both are KiB.
-# Writes gpurun_out/pmc_traffic.json (copy to profiles/r01_pmc_traffic.json).
+# Writes gpurun_out/pmc_traffic.json (copy to profiles/r02_pmc_traffic.json).
 R=${GRAFT_REPO_ROOT:-$PWD}; OUT=$R/gpurun_out/pmc_t; mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
