@@ -167,6 +167,20 @@ def parity_block(cfg, sd, args, dev, timed_model):
                     "fp32_bucket_flips": bfl, "fp32_mel_maxabs_vs_oracle": forced if bfl else free,
                     "fp32_mel_maxabs_is": "under the oracle's decisions" if bfl else "free-running"})
         del m32
+    if args.precision == "bf16":  # the decision-safe throughput mode beside it: fp32-grade front, bf16 decoder
+        m3 = FastSpeech2(cfg, sd, precision="mixed3", device=dev)
+        dfl, bfl, free, forced = check(m3)
+        for _ in range(2):
+            m3(full, inference=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            m3(full, inference=True)
+        torch.cuda.synchronize()
+        res["decision_safe"] = {"mode": "mixed3 (front: fp32 storage, bf16 x 3 split products; decoder: bf16)",
+                                "ms_per_step": (time.perf_counter() - t0) / 5 * 1e3, "duration_flips": dfl, "bucket_flips": bfl,
+                                "mel_maxabs_forced": forced}
+        del m3
     dfl, bfl, free, forced = check(timed_model)
     p = args.precision
     res.update({f"{p}_duration_flips": dfl, f"{p}_bucket_flips": bfl, f"{p}_mel_maxabs_free": free,
