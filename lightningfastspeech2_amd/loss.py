@@ -46,7 +46,10 @@ class FastSpeech2Loss:
                          ("FastDiff terms", fastdiff_loss is None and not fastdiff_variances)):
             if not ok:
                 raise NotImplementedError(f"FastSpeech2Loss: this {what} configuration is outside the built path "
-                                          "(frame-level 'none' variances, 'l1'/'mse', deterministic durations)")
+                                          "(frame-level 'none' variances, 'l1'/'mse', deterministic durations).  Note: the "
+                                          "reference's own CWT loss branch cannot run at HEAD - it calls self.mse_loss, which "
+                                          "FastSpeech2Loss never defines (loss.py:141,148) - so there is nothing to pin a CWT "
+                                          "loss against; the CWT head itself is in the forward")
         self.lib = _lib.load()  # raises if the HIP library is missing
         # one workspace (partials + the "done" counter) per (device, stream): launches on two streams must not share it
         self._ws: Dict[tuple, torch.Tensor] = {}
