@@ -958,8 +958,8 @@ int fs2_encode(fs2_engine* e, const int64_t* phones, const float* speaker, int32
     e->dur_pred = (float*)e->persist.take(ML * 4);
     e->d_dur = (int32_t*)e->persist.take(ML * 4);
     e->d_cum = (int32_t*)e->persist.take(ML * 4);
-    e->d_totals = (int32_t*)e->persist.take((size_t)B * 4);
-    e->d_guard = (int32_t*)e->persist.take((size_t)B * 4);
+    e->d_totals = (int32_t*)e->persist.take((size_t)2 * B * 4);  // [totals | guard flags]: one read-back
+    e->d_guard = e->d_totals ? e->d_totals + B : nullptr;
     e->src_mask = (uint8_t*)e->persist.take(ML);
     if (!e->src_mask) return fail(e, FS2_ERR_NOMEM, "persist arena too small");
     LayerScratch sc;
@@ -1001,8 +1001,7 @@ int fs2_encode(fs2_engine* e, const int64_t* phones, const float* speaker, int32
     CHK(predictor(e, st, e->dur, e->xA, B, L, e->src_mask, e->dur_pred, sc));
     DurationArgs da{e->dur_pred, e->src_mask, forced, e->d_dur, e->d_cum, e->d_totals, e->d_guard, B, L};
     if (launch_durations(da, st) != FS2_OK) return fail(e, FS2_ERR_HIP, "durations launch failed");
-    HIPCHK(e, hipMemcpyAsync(e->h_pinned, e->d_totals, (size_t)B * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(e, hipMemcpyAsync(e->h_pinned + B, e->d_guard, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(e, hipMemcpyAsync(e->h_pinned, e->d_totals, (size_t)2 * B * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(e, hipStreamSynchronize(st));  // the one host sync of the forward (output shape)
     e->totals.assign(e->h_pinned, e->h_pinned + B);
     e->guard.assign(e->h_pinned + B, e->h_pinned + 2 * B);

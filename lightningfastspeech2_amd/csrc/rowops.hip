@@ -453,28 +453,53 @@ __global__ __launch_bounds__(256) void regulate_kernel(RegulateArgs p) {
         }
     }
     const int nc = (p.L + 63) / 64;
-    for (int r = 0; r < RG_ROWS; ++r) {
-        const int t = tb + r;
-        if (t >= p.T) break;
-        if (lane == 0) p.tgt_mask[(size_t)b * p.T + t] = t >= total;
-        uint4* dst = (uint4*)((T*)p.y + ((size_t)b * p.T + t) * p.H);
-        if (t < total) {
-            int lo = 0;
-            if (fast) {
+    // rows narrower than a wave's 1 KiB (H = 256 bf16: 512 B) are copied two at a time, one per half wave
+    const bool pair = nvec <= 32;
+    const int half = lane >> 5, hl = lane & 31;
+    for (int r = 0; r < RG_ROWS; r += pair ? 2 : 1) {
+        if (tb + r >= p.T) break;
+        int lo_of[2] = {0, 0};
+        bool in_of[2] = {false, false};
 #pragma unroll
-                for (int k = 0; k < RG_MAXC; ++k)
-                    if (k < nc) lo += __popcll(__ballot(cl[k] <= t));
-            } else {
-                int hi = p.L;
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (cum[mid] > t) hi = mid; else lo = mid + 1;
+        for (int q = 0; q < 2; ++q) {  // the owner search is a whole-wave ballot: done for both rows by all lanes
+            const int t = tb + r + q;
+            if (q == 1 && !pair) break;
+            if (t >= p.T) break;
+            in_of[q] = t < total;
+            if (lane == 0) p.tgt_mask[(size_t)b * p.T + t] = t >= total;
+            if (t < total) {
+                int lo = 0;
+                if (fast) {
+#pragma unroll
+                    for (int k = 0; k < RG_MAXC; ++k)
+                        if (k < nc) lo += __popcll(__ballot(cl[k] <= t));
+                } else {
+                    int hi = p.L;
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        if (cum[mid] > t) hi = mid; else lo = mid + 1;
+                    }
                 }
+                lo_of[q] = lo;
             }
-            const uint4* src = (const uint4*)((const T*)p.x + ((size_t)b * p.L + lo) * p.H);
-            for (int i = lane; i < nvec; i += 64) dst[i] = src[i];
+        }
+        if (pair) {
+            const int t = tb + r + half;
+            if (t < p.T && hl < nvec) {
+                uint4* dst = (uint4*)((T*)p.y + ((size_t)b * p.T + t) * p.H);
+                const bool in = half ? in_of[1] : in_of[0];
+                const int lo = half ? lo_of[1] : lo_of[0];
+                dst[hl] = in ? ((const uint4*)((const T*)p.x + ((size_t)b * p.L + lo) * p.H))[hl] : make_uint4(0, 0, 0, 0);
+            }
         } else {
-            for (int i = lane; i < nvec; i += 64) dst[i] = make_uint4(0, 0, 0, 0);
+            const int t = tb + r;
+            uint4* dst = (uint4*)((T*)p.y + ((size_t)b * p.T + t) * p.H);
+            if (in_of[0]) {
+                const uint4* src = (const uint4*)((const T*)p.x + ((size_t)b * p.L + lo_of[0]) * p.H);
+                for (int i = lane; i < nvec; i += 64) dst[i] = src[i];
+            } else {
+                for (int i = lane; i < nvec; i += 64) dst[i] = make_uint4(0, 0, 0, 0);
+            }
         }
     }
 }
