@@ -311,6 +311,70 @@ def test_full_size_full_batch_fp32_and_mixed_vs_oracle():
     assert rep["mixed3"]["bucket_flips"] * 10 <= rep["bf16"]["bucket_flips"]
 
 
+def _random_gpu_cfg(rs):
+    """Random hparams inside the engine's envelope (hidden a multiple of 64, head dim 32 / 64 / 128): dense / depth-wise
+    mixes, odd kernel sizes up to 25, 1-3 variances incl. the CWT head, predictor depths 1-4, with and without priors."""
+    H = int(rs.choice([64, 128, 192, 256, 320]))
+    heads = [h for h in (1, 2, 3, 4, 5, 6, 8, 10) if H % h == 0 and H // h in (32, 64, 128)]
+    he, hd = int(rs.choice(heads)), int(rs.choice(heads))
+    dw = [bool(rs.randint(2)) for _ in range(4)]
+    nl_e, nl_d = int(rs.randint(1, 3)), int(rs.randint(1, 4))
+    odd = lambda hi=25: int(rs.choice([k for k in (1, 3, 5, 7, 9, 13, 17, 21, 25) if k <= hi]))
+    variances = list(rs.permutation(["pitch", "energy", "snr"])[: rs.randint(1, 4)])
+    nv = len(variances)
+    cwt = [bool(rs.randint(3) == 0) for _ in range(nv)]
+    stats = {}
+    for v, c in zip(variances, cwt):
+        stats[v] = ({"min": 0.3, "max": 4.0, "mean": 0.0, "std": 1.0} if c else
+                    {"min": float(-1 - rs.rand()), "max": float(1 + 2 * rs.rand()), "mean": float(rs.randn() * .3), "std": float(.5 + rs.rand())})
+    priors = ["pitch"] if rs.randint(4) == 0 else []
+    if priors:
+        stats["pitch_prior"] = {"min": -1.0, "max": 1.0}
+    return Fs2Config(
+        n_phones=int(rs.randint(5, 60)), encoder_hidden=H, decoder_hidden=H, encoder_head=he, decoder_head=hd,
+        encoder_layers=nl_e, decoder_layers=nl_d, encoder_kernel_sizes=[odd() for _ in range(nl_e)],
+        decoder_kernel_sizes=[odd() for _ in range(nl_d)], encoder_depthwise_conv=dw[0], decoder_depthwise_conv=dw[1],
+        encoder_conv_filter_size=H * int(rs.choice([1, 2, 4])), decoder_conv_filter_size=H * int(rs.choice([1, 2, 4])),
+        variances=variances, variance_levels=["frame"] * nv, variance_transforms=["cwt" if c else "none" for c in cwt],
+        variance_nlayers=[int(rs.randint(1, 5)) for _ in range(nv)], variance_kernel_size=[odd(9) for _ in range(nv)],
+        variance_filter_size=H, variance_nbins=int(rs.choice([8, 33, 256])), variance_depthwise_conv=dw[2],
+        duration_nlayers=int(rs.randint(1, 3)), duration_kernel_size=odd(9), duration_filter_size=H,
+        duration_depthwise_conv=dw[3], n_mels=int(rs.choice([8, 80])), priors=priors, stats=stats)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fp32_random_configs_vs_oracle(seed):
+    """Fuzz: random architectures x ragged batches, fp32 engine vs the oracle under the oracle's decisions (<= 1e-3 on mel and
+    on every intermediate), free-running decision flips counted; the same batch through the bf16 engine stays finite."""
+    rs = np.random.RandomState(500 + seed)
+    cfg = _random_gpu_cfg(rs)
+    B, L = int(rs.randint(1, 6)), int(rs.randint(3, 70))
+    lengths = [L] + [int(rs.randint(1, L + 1)) for _ in range(B - 1)]
+    sd = synth_state_dict(cfg, seed, randomize_norm=True, duration_bias=float(rs.uniform(0.4, 1.6)))
+    inp = synth_inputs(cfg, B, L, seed=seed, lengths=lengths)
+    pri = {k: v for k, v in inp.items() if k.startswith("priors_")}
+    ref = oracle_cpu.forward(sd, cfg, inp["phones"], inp["speaker"], return_intermediates=True, priors=pri)
+    batch = {"phones": torch.from_numpy(inp["phones"]), "speaker": torch.from_numpy(inp["speaker"]), **pri}
+    m = _model(cfg, sd, "fp32")
+    m.engine.set_debug(True)
+    free = _cpu(m(batch, inference=True))
+    dfl = int((free["duration_rounded"] != ref["duration_rounded"]).sum())
+    out = _cpu(m.forward(batch, force_durations=ref["duration_rounded"],
+                         force_buckets={v: ref["_intermediates"][f"bucket_{v}"] for v in cfg.variances}))
+    assert torch.equal(out["tgt_mask"], ref["tgt_mask"]) and torch.equal(out["src_mask"], ref["src_mask"])
+    errs = {"mel": float((out["mel"] - ref["mel"]).abs().max()),
+            "duration_prediction": float((out["duration_prediction"] - ref["duration_prediction"]).abs().max())}
+    for k in ("encoder_out", "regulated", "adaptor_out", "decoder_out"):
+        errs[k] = float((m.engine.debug_tensor(k).cpu() - ref["_intermediates"][k]).abs().max())
+    _report(test="fuzz_fp32", seed=seed, H=cfg.hidden, dw=[cfg.encoder_depthwise_conv, cfg.decoder_depthwise_conv,
+            cfg.variance_depthwise_conv, cfg.duration_depthwise_conv], transforms=cfg.variance_transforms[:len(cfg.variances)],
+            B=B, L=L, T=int(ref["mel"].shape[1]), duration_flips_free=dfl, errs=errs)
+    assert dfl <= 1 and all(e <= MEL_TOL_FP32 for e in errs.values()), errs
+    if ref["mel"].shape[1] > 0:
+        o16 = _model(cfg, sd, "bf16").forward(batch, force_durations=ref["duration_rounded"])
+        assert bool(torch.isfinite(o16["mel"]).all())
+
+
 def test_rejects_training_forward_and_bad_ids():
     g = Golden("dense_small")
     m = _model(g.cfg, g.state_dict(), "fp32")
