@@ -248,6 +248,13 @@ int fs2_op_predictor(int32_t dtype, const void* x, const void* w, const float* b
 size_t fs2_op_masked_loss_ws_bytes(void);
 int fs2_op_masked_loss(const float* pred, const void* truth, int32_t truth_kind, const uint8_t* pad_mask, int64_t rows,
                        int32_t inner, int32_t kind, void* ws, float* out2, void* hip_stream);
+/* Soft-DTW value of B sequence pairs (litfass/third_party/softdtw/__init__.py:8-24,110-117 = the validation metric of
+ * fastspeech2.py:1149-1156; the same recursion is the arithmetic of the "soft_dtw" loss kind, loss.py:57-81):
+ * out[b] = R[N, M] with D[i,j] = |x[b,i] - y[b,j]|^2 (fp32), the recursion in fp64.  x (B, N, D), y (B, M, D), out (B): fp32
+ * device pointers.  One workgroup per pair; the sequences are staged in LDS when both fit beside the three fp64
+ * anti-diagonals (e.g. 2 x 240 frames of an 80-bin mel), else read through the caches; FS2_ERR_SHAPE for N > 6800. */
+int fs2_op_soft_dtw(const float* x, const float* y, int32_t B, int32_t N, int32_t M, int32_t D, float gamma, float* out,
+                    void* hip_stream);
 /* dtype conversion helpers for tests: fp32 <-> engine dtype, n elements, device pointers */
 int fs2_op_convert(int32_t src_dtype, int32_t dst_dtype, const void* src, void* dst, size_t n, void* hip_stream);
 

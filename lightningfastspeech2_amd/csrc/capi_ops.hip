@@ -55,6 +55,13 @@ int fs2_op_predictor(int32_t dtype, const void* x, const void* w, const float* b
     return launch_predictor_fused(a, (hipStream_t)stream);
 }
 
+int fs2_op_soft_dtw(const float* x, const float* y, int32_t B, int32_t N, int32_t M, int32_t D, float gamma, float* out,
+                    void* stream) {
+    if (!x || !y || !out) return FS2_ERR_ARG;
+    SoftDtwArgs a{x, y, out, B, N, M, D, gamma};
+    return launch_soft_dtw(a, (hipStream_t)stream);
+}
+
 size_t fs2_op_masked_loss_ws_bytes(void) { return fs2::masked_loss_ws_bytes(); }
 
 int fs2_op_masked_loss(const float* pred, const void* truth, int32_t truth_kind, const uint8_t* pad_mask, int64_t rows,

@@ -128,6 +128,15 @@ struct LossArgs {
     int64_t rows;
     int inner, kind, truth_kind;  // kind 0 = l1, 1 = mse
 };
+struct SoftDtwArgs {
+    const float* x;   // (B, N, D) fp32
+    const float* y;   // (B, M, D) fp32
+    float* out;       // (B) soft-DTW value R[N, M]
+    int B, N, M, D;
+    float gamma;
+};
+size_t soft_dtw_lds_bytes(int N, int M, int D);
+int launch_soft_dtw(const SoftDtwArgs& a, hipStream_t stream);
 size_t masked_loss_ws_bytes();
 int launch_masked_loss(const LossArgs& a, hipStream_t stream);
 int voc_resblock_mi16(const VocResblockArgs& a, int dtype);  // 0 = shape not covered

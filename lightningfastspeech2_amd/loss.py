@@ -41,7 +41,7 @@ class FastSpeech2Loss:
             "mel": 1.0, "pitch": 1e-1, "energy": 1e-1, "snr": 1e-1, "duration": 1e-4, "fastdiff": 1e-1, "speakers": 1}
         for what, ok in (("variance level", all(l == "frame" for l in self.variance_levels)),
                          ("variance transform", all(t == "none" for t in self.variance_transforms)),
-                         ("loss kind", all(k in _KIND for k in self.variance_losses + [mel_loss, duration_loss])),
+                         ("loss kind", all(k in _KIND or k == "soft_dtw" for k in self.variance_losses + [mel_loss, duration_loss])),
                          ("stochastic durations", not duration_stochastic),
                          ("FastDiff terms", fastdiff_loss is None and not fastdiff_variances)):
             if not ok:
@@ -50,6 +50,7 @@ class FastSpeech2Loss:
                                           "reference's own CWT loss branch cannot run at HEAD - it calls self.mse_loss, which "
                                           "FastSpeech2Loss never defines (loss.py:141,148) - so there is nothing to pin a CWT "
                                           "loss against; the CWT head itself is in the forward")
+        self.soft_dtw_gamma, self.soft_dtw_chunk_size = soft_dtw_gamma, soft_dtw_chunk_size
         self.lib = _lib.load()  # raises if the HIP library is missing
         # one workspace (partials + the "done" counter) per (device, stream): launches on two streams must not share it
         self._ws: Dict[tuple, torch.Tensor] = {}
@@ -77,6 +78,29 @@ class FastSpeech2Loss:
         _lib.check(st, None, "fs2_op_masked_loss")
         return out[0]
 
+    def _get_loss(self, pred, truth, truth_kind, pad_mask, inner, kind):
+        if kind != "soft_dtw":
+            return self._masked_mean(pred, truth, truth_kind, pad_mask, inner, kind)
+        # get_loss, loss.py:60-78: pads zero-filled, the time axis cut into chunks of soft_dtw_chunk_size, the soft-DTW
+        # value of every (pred chunk, truth chunk) pair summed over chunks and batch.  The reference evaluates the pairs
+        # with the third-party pysdtw package (pyproject.toml: pysdtw, not in the checkout, not in this image); its
+        # published recursion on squared Euclidean frame distances is the one of the vendored third_party/softdtw module,
+        # which pins csrc/softdtw.hip (tests/golden/softdtw_small.npz).
+        from .softdtw import soft_dtw_values
+        dev = pred.device
+        valid = (~pad_mask.to(dev).bool()).unsqueeze(-1)
+        pred = pred.to(torch.float32)
+        truth = truth.to(dev)
+        truth = truth.to(torch.float32) if truth_kind == 0 else torch.log(truth.to(torch.float32) + 1)
+        if pred.dim() == 2:
+            pred, truth = pred.unsqueeze(-1), truth.unsqueeze(-1)
+        pred, truth = pred * valid, truth * valid
+        total = None
+        for pc, tc in zip(pred.split(self.soft_dtw_chunk_size, dim=1), truth.split(self.soft_dtw_chunk_size, dim=1)):
+            v = soft_dtw_values(pc.contiguous(), tc.contiguous(), self.soft_dtw_gamma)
+            total = v if total is None else total + v
+        return total.sum()
+
     def __call__(self, result, target, frozen_components=()):
         return self.forward(result, target, frozen_components)
 
@@ -88,11 +112,11 @@ class FastSpeech2Loss:
                 raise AssertionError("target mel longer than max_length (loss.py:101)")
             for var, kind in zip(self.variances, self.variance_losses):
                 tgt = target[f"variances_{var}"][:, :int(self.max_length)]
-                losses[var] = self._masked_mean(result[f"variances_{var}"], tgt, 0, tgt_pad, 1, kind)
+                losses[var] = self._get_loss(result[f"variances_{var}"], tgt, 0, tgt_pad, 1, kind)
         n_mels = result["mel"].shape[-1]
-        losses["mel"] = self._masked_mean(result["mel"], target["mel"], 0, tgt_pad, n_mels, self.mel_loss)
-        losses["duration"] = self._masked_mean(result["duration_prediction"], target["duration"], 1, src_pad, 1,
-                                               self.duration_loss)
+        losses["mel"] = self._get_loss(result["mel"], target["mel"], 0, tgt_pad, n_mels, self.mel_loss)
+        losses["duration"] = self._get_loss(result["duration_prediction"], target["duration"], 1, src_pad, 1,
+                                            self.duration_loss)
         total = sum(v * self.loss_alphas[k] for k, v in losses.items() if not any(f in k for f in frozen_components))
         losses["total"] = total
         return losses

@@ -85,7 +85,7 @@ def test_loss_pad_rows_do_not_count_and_empty_is_nan():
 
 def test_loss_rejects_configurations_outside_the_path():
     from lightningfastspeech2_amd.loss import FastSpeech2Loss
-    for kw in (dict(mel_loss="soft_dtw"), dict(variance_transforms=["cwt", "none", "none"]),
+    for kw in (dict(mel_loss="huber"), dict(variance_transforms=["cwt", "none", "none"]),
                dict(variance_levels=["phone"] * 3), dict(duration_stochastic=True), dict(fastdiff_loss="mse")):
         with pytest.raises(NotImplementedError):
             FastSpeech2Loss(**kw)
@@ -109,3 +109,28 @@ def test_validation_step_forward_plus_loss():
     want = loss_cpu.fastspeech2_loss(ref_res, {k: v.numpy() for k, v in batch.items()}, g.cfg.variances)
     for k, w in want.items():
         assert abs(float(got[k]) - w) <= 2e-4 * max(1.0, abs(w)), (k, float(got[k]), w)  # mel parity 1e-3 abs -> loss
+
+
+def test_soft_dtw_loss_kind_chunked():
+    """mel_loss = "soft_dtw" (loss.py:60-78): zero-filled pads, chunks of soft_dtw_chunk_size frames, soft-DTW value of every
+    chunk pair summed over chunks and batch - against the oracle's soft-DTW (pinned on the reference's vendored module)."""
+    from lightningfastspeech2_amd.loss import FastSpeech2Loss
+    from oracle import softdtw_cpu
+    res, tgt = _synthetic(3, 9, 150, 80, seed=77)
+    gamma, chunk = 0.05, 64
+    loss = FastSpeech2Loss(variance_levels=["frame"] * 3, variance_transforms=["none"] * 3, variance_losses=["mse", "soft_dtw", "mse"],
+                           mel_loss="soft_dtw", soft_dtw_gamma=gamma, soft_dtw_chunk_size=chunk)
+    got = loss(_cuda(res), _cuda(tgt))
+    valid = ~res["tgt_mask"]
+
+    def want(pred, truth):
+        if pred.ndim == 2:
+            pred, truth = pred[..., None], truth[..., None]
+        p, t = pred * valid[..., None], truth * valid[..., None]
+        tot = 0.0
+        for s in range(0, p.shape[1], chunk):
+            tot += float(softdtw_cpu.soft_dtw(p[:, s:s + chunk], t[:, s:s + chunk], gamma).astype(np.float64).sum())
+        return tot
+    for key, (pr, tr) in {"mel": (res["mel"], tgt["mel"]), "pitch": (res["variances_pitch"], tgt["variances_pitch"])}.items():
+        w = want(pr, tr)
+        assert abs(float(got[key]) - w) <= 2e-5 * abs(w), (key, float(got[key]), w)

@@ -1,0 +1,30 @@
+"""The soft-DTW oracle against what the reference's vendored third_party/softdtw module returned (tests/golden/softdtw_small.npz)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import softdtw_cpu
+
+Z = np.load(os.path.join(os.path.dirname(__file__), "golden", "softdtw_small.npz"))
+CASES = json.loads(str(Z["cases_json"]))
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_oracle_matches_reference_fixture(case):
+    n = case["name"]
+    got = softdtw_cpu.soft_dtw(Z[f"{n}__x"], Z[f"{n}__y"], gamma=case["gamma"], normalize=case["normalize"])
+    ref = Z[f"{n}__out"]
+    assert np.shape(got) == ref.shape
+    np.testing.assert_allclose(got, ref, rtol=2e-6, atol=2e-4)
+
+
+def test_identical_sequences_normalise_to_zero_and_plain_value_is_a_soft_minimum():
+    rs = np.random.RandomState(0)
+    x = rs.randn(2, 12, 6).astype(np.float32)
+    assert np.abs(softdtw_cpu.soft_dtw(x, x, 0.5, True)).max() <= 1e-4
+    y = rs.randn(2, 9, 6).astype(np.float32)
+    hard = softdtw_cpu.soft_dtw(x, y, 1e-4)          # gamma -> 0: the DTW alignment cost
+    soft = softdtw_cpu.soft_dtw(x, y, 1.0)
+    assert (soft <= hard + 1e-3).all()                # a soft minimum never exceeds the hard one
