@@ -373,9 +373,12 @@ template <bool B> struct BoolC { static constexpr bool value = B; };
 // in fp32 (the dropped lo*lo term is 2^-16 of the product): ~1e-5 relative, ~400x closer to fp32 than bf16 storage, at
 // 3 x 16-cycle MFMAs per 32 k-values instead of the 8 x 32-cycle fp32 MFMAs - the arithmetic of the "front" (encoder +
 // variance adaptor) in the mixed precision mode, where a discrete decision hangs on every output.
-template <typename T, typename OutT, int MI, bool LN, bool WIDE = false, bool SPLIT = false>
+// DEFER (LN = false only): the deferred-LayerNorm epilogue (residual preload + pre-norm store + row statistics); its own
+// instantiation so that the plain GEMM launches do not carry its registers (the in-projection measured +9 % with both in one).
+template <typename T, typename OutT, int MI, bool LN, bool WIDE = false, bool SPLIT = false, bool DEFER = false>
 __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
     static_assert(!SPLIT || sizeof(T) == 4, "the split arithmetic takes fp32 operands");
+    static_assert(!(DEFER && LN), "deferred LayerNorm is what a launch WITHOUT the fused epilogue leaves behind");
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-resource builtins only exist in the device pass
     using Cfg = SlabCfg<MI>;
     constexpr int BMs = Cfg::BM, SI = Cfg::SI;
@@ -464,7 +467,7 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
     // with 16-byte loads that land underneath the first operand DMAs instead of sitting, exposed,
     // between the K loop and the row statistics.
     // (the deferred-LayerNorm epilogue does the same with ITS residual, normalised first if that is a pre-norm tensor)
-    const bool res_in_acc = !p.relu && (LN ? p.res != nullptr : p.epi_res != nullptr);
+    const bool res_in_acc = !p.relu && (LN ? p.res != nullptr : (DEFER && p.epi_res != nullptr));
     int woff[4][2];                          // weight fragment byte offsets (tap independent)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -539,9 +542,9 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < MI; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    if (res_in_acc) {
+    if ((LN || DEFER) && res_in_acc) {
         const T* R = (const T*)(LN ? p.res : p.epi_res) + (size_t)ub * S * p.ldc;
-        const bool rnorm = !LN && p.epi_res_stats != nullptr;
+        const bool rnorm = DEFER && p.epi_res_stats != nullptr;
         const size_t rowbase0 = (size_t)ub * S;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
@@ -971,7 +974,7 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
         }
     }
     };
-    if (p.stats_out || p.epi_res) {
+    if constexpr (DEFER) {
         // Deferred-LayerNorm epilogue (rows wider than one tile): v = act(acc + bias) + res, stored as it is, plus this
         // column tile's sum(v), sum(v^2) per row -> stats_out[row][column tile]; the consumers (depth-wise conv,
         // normalise-only LayerNorm, the next epilogue's residual) finish mean / rstd from the tiles' parts.
@@ -980,18 +983,6 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
         const size_t rowbase = (size_t)ub * S;
         const float lo = p.relu ? 0.f : -__builtin_inff();
         const bool rnorm = R && p.epi_res_stats;
-        float rg[2][8], rb[2][8];  // gamma / beta of the residual's LayerNorm for this lane's 2 x 8 channels
-        if (rnorm) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int n = n0 + wn * 64 + j * 32 + fg * 8;
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    rg[j][r] = n + r < p.N ? p.epi_res_g[n + r] : 0.f;
-                    rb[j][r] = n + r < p.N ? p.epi_res_b[n + r] : 0.f;
-                }
-            }
-        }
         float a1[MI], a2[MI];
         auto body = [&](auto full_c) {
             constexpr bool FULL = decltype(full_c)::value;
@@ -1033,7 +1024,7 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
                     }
 #pragma unroll
                     for (int r = 0; r < 8; ++r) {
-                        if (rnorm) x[r] = __builtin_fmaf((x[r] - rmean) * rrstd, rg[j][r], rb[j][r]);
+                        if (rnorm) x[r] = (FULL || n + r < p.N) ? __builtin_fmaf((x[r] - rmean) * rrstd, p.epi_res_g[n + r], p.epi_res_b[n + r]) : 0.f;
                         v[r] += x[r];
                     }
                 }
@@ -1096,14 +1087,14 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
 #endif
 }
 
-template <typename T, typename OutT, int MI, bool LN, bool WIDE = false, bool SPLIT = false>
+template <typename T, typename OutT, int MI, bool LN, bool WIDE = false, bool SPLIT = false, bool DEFER = false>
 static int launch_slab_t(const GemmArgs& a0, hipStream_t stream) {
     GemmArgs a = a0;
     if (a.taps == 1) a.S = a.M;  // plain GEMM: one "utterance" of M rows
     a.xcd_remap = g_slab_xcd_remap;
     const int BMs = SlabCfg<MI>::BM;
     const int tiles = (a.M / a.S) * ((a.S + BMs - 1) / BMs) * (WIDE ? 1 : (a.N + S_BN - 1) / S_BN);
-    hipLaunchKernelGGL((gemm_conv_slab_kernel<T, OutT, MI, LN, WIDE, SPLIT>), dim3(tiles), dim3(512), 0, stream, a);
+    hipLaunchKernelGGL((gemm_conv_slab_kernel<T, OutT, MI, LN, WIDE, SPLIT, DEFER>), dim3(tiles), dim3(512), 0, stream, a);
     return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
 }
 
@@ -1122,6 +1113,13 @@ static int launch_slab(const GemmArgs& a, int in_dtype, int out_dtype, hipStream
                 return (a.split || g_split_f32) ? launch_slab_t<float, float, MI, true, false, true>(a, stream) : launch_slab_t<float, float, MI, true>(a, stream);
             if (in_dtype == FS2_BF16 && out_dtype == FS2_BF16) return launch_slab_t<bf16, bf16, MI, true>(a, stream);
         }
+        return FS2_ERR_SHAPE;
+    }
+    if (a.stats_out || a.epi_res) {  // deferred-LayerNorm epilogue
+        if (in_dtype == FS2_F32 && out_dtype == FS2_F32)
+            return (a.split || g_split_f32) ? launch_slab_t<float, float, MI, false, false, true, true>(a, stream)
+                                            : launch_slab_t<float, float, MI, false, false, false, true>(a, stream);
+        if (in_dtype == FS2_BF16 && out_dtype == FS2_BF16) return launch_slab_t<bf16, bf16, MI, false, false, false, true>(a, stream);
         return FS2_ERR_SHAPE;
     }
     if (in_dtype == FS2_F32 && out_dtype == FS2_F32)
@@ -1204,7 +1202,7 @@ static int launch_gemm_plain(const GemmArgs& a, int in_dtype, int out_dtype, hip
     if (variant >= 3 && variant <= 5 && slab_ok && !(fused && variant == 5)) {
         if (fused) *fused = true;
         if (variant == 3) return launch_slab<4>(a, in_dtype, out_dtype, stream);
-        if (variant == 4) return launch_slab<6>(a, in_dtype, out_dtype, stream);
+        if (variant == 4 || a.stats_out || a.epi_res) return launch_slab<6>(a, in_dtype, out_dtype, stream);
         return launch_slab<8>(a, in_dtype, out_dtype, stream);
     }
     if (fused && variant != 0) return FS2_OK;  // forced non-slab kernel: caller falls back
@@ -1226,7 +1224,7 @@ static int launch_gemm_plain(const GemmArgs& a, int in_dtype, int out_dtype, hip
         static const int kHeights[5] = {1, 2, 4, 6, 8};  // x32 rows; 32/64-row tiles keep small-M launches
         for (int hi = 0; hi < 5; ++hi) {                  // (the encoder's) spread over all CUs
             const int mi = kHeights[hi];
-            if (fused && mi > 6) continue;
+            if ((fused || a.stats_out || a.epi_res) && mi > 6) continue;  // 256-row tiles spill with either LayerNorm epilogue
             const long bm = mi * 32, tm = (S + bm - 1) / bm;
             const bool wide = fused && tn > 1;  // one workgroup per row tile walks all tn column tiles
             const long tiles = (long)nutt * tm * (wide ? 1 : tn);
