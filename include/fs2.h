@@ -259,6 +259,73 @@ int fs2_op_soft_dtw(const float* x, const float* y, int32_t B, int32_t N, int32_
 int fs2_op_convert(int32_t src_dtype, int32_t dst_dtype, const void* src, void* dst, size_t n, void* hip_stream);
 
 /* ================================================================================================
+ * Training step: the operators the reference gets from autograd in
+ * FastSpeech2.training_step (litfass/fastspeech2/fastspeech2.py:786-797: loss.backward()) and from
+ * torch.optim.AdamW + gradient_clip_val (fastspeech2.py:1166-1182, scripts/train.sh:16).  The tape itself
+ * (which tensor feeds which gradient) lives in the host mirror, lightningfastspeech2_amd/training.py.
+ * All device pointers; fp32 (FS2_F32) arithmetic on the exact fp32 MFMA.
+ * ================================================================================================ */
+/* C[b1][b2](m, n) = alpha * sum_k A(m, k) B(k, n) + bias[n] + beta * C, operands by element strides (one stride of each
+ * operand is 1), two batch levels, optional deterministic split-K, and the two implicit 'same'-padded Conv1d forms over
+ * (B*S, C) time-major rows with utterances of `seg` rows:
+ *   data gradient (taps > 1):  K = taps * Kin; the k-tiles of tap j read A rows m + a_shift0 + j * a_shift_step
+ *                              (zero outside the row's utterance) and B from + j * sBtap;
+ *   weight gradient (taps <= 1, seg > 0): batch index b2 reads B's k rows at k + b_shift0 + b2 * b_shift_step. */
+typedef struct fs2_bgemm_desc {
+    int32_t M, N, K;
+    int64_t sAm, sAk, sBk, sBn, ldc;
+    int32_t nb1, nb2;
+    int64_t sA1, sA2, sB1, sB2, sC1, sC2;
+    float alpha, beta;
+    int32_t splitk;
+    int32_t seg, taps, Kin, a_shift0, a_shift_step;
+    int64_t sBtap;
+    int32_t b_shift0, b_shift_step;
+} fs2_bgemm_desc;
+size_t fs2_op_bgemm_ws_bytes(const fs2_bgemm_desc* d);  /* split-K slabs (0 when splitk <= 1) */
+int fs2_op_bgemm(int32_t dtype, const fs2_bgemm_desc* d, const void* A, const void* B, void* C, const float* bias,
+                 float* ws, void* hip_stream);
+/* LayerNorm backward of y = LN(z [+ res]) * gamma + beta: dz (M, H); part = (fs2_op_layernorm_bwd_parts(M), 2, H) partial
+ * column sums of dy * zhat and dy, to be reduced with fs2_op_col_sum over the parts -> dgamma, dbeta */
+int32_t fs2_op_layernorm_bwd_parts(int32_t M);
+int fs2_op_layernorm_bwd(int32_t dtype, const void* z, const void* res, const void* dy, const float* gamma, void* dz,
+                         float* part, int32_t M, int32_t H, void* hip_stream);
+/* out[s][n] (+)= scale * sum over the rows of segment s of x[row][n]; seg = rows per segment (0: one segment) */
+size_t fs2_op_col_sum_ws_bytes(int32_t M, int32_t N, int32_t seg);
+int fs2_op_col_sum(const float* x, float* out, float* ws, int32_t M, int32_t N, int32_t ldx, int32_t seg,
+                   int32_t accumulate, float scale, void* hip_stream);
+/* masked softmax over the key axis of (B, heads, S, S) scores, in place (the training path materialises the
+ * probabilities), and its backward dS = scale * P o (dP - sum_k dP o P), in place on dP */
+int fs2_op_softmax_fwd(int32_t dtype, void* s, const uint8_t* key_pad, int32_t B, int32_t heads, int32_t S, float scale,
+                       void* hip_stream);
+int fs2_op_softmax_bwd(int32_t dtype, void* dp, const void* p, int32_t B, int32_t heads, int32_t S, float scale,
+                       void* hip_stream);
+/* elementwise: op 0: out = alpha*a + beta*b (b may be NULL)   1: out = a where b > 0 else 0 (ReLU backward)   2: out = alpha*a */
+int fs2_op_ew(int32_t op, const float* a, const float* b, float* out, size_t n, float alpha, float beta, void* hip_stream);
+/* embedding backward: table[idx[r]] += x[r] for r < R (int32 or int64 indices), row skip_row untouched (padding_idx) */
+int fs2_op_scatter_rows(const float* x, const int32_t* idx32, const int64_t* idx64, float* table, int32_t R, int32_t H,
+                        int32_t V, int32_t skip_row, void* hip_stream);
+/* LengthRegulator backward: dx[b][p] = sum of dy[b][t] over the frames phone p was repeated to (truncated at T) */
+int fs2_op_regulate_bwd(const float* dy, const int32_t* cum, float* dx, int32_t B, int32_t L, int32_t T, int32_t H,
+                        void* hip_stream);
+/* gradient of alpha * fs2_op_masked_loss(...) with respect to pred; stat = that call's out2 (the count is read on device) */
+int fs2_op_masked_loss_bwd(const float* pred, const void* truth, int32_t truth_kind, const uint8_t* pad_mask,
+                           const float* stat, float* dpred, int64_t rows, int32_t inner, int32_t kind, float alpha,
+                           void* hip_stream);
+/* out[0] = sum of squares of x (fp64 partials, fixed order) */
+size_t fs2_op_sum_sq_ws_bytes(size_t n);
+int fs2_op_sum_sq(const float* x, size_t n, float* ws, float* out, void* hip_stream);
+/* torch.optim.AdamW step over flat fp32 buffers; g is scaled by grad_scale and, when gnorm_sq (device scalar, sum of
+ * squares of g) is given, by the clip_grad_norm_ coefficient min(1, max_norm / (grad_scale * sqrt(gnorm_sq) + 1e-6)) */
+int fs2_op_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+                 float weight_decay, int32_t step, const float* gnorm_sq, float max_norm, float grad_scale,
+                 void* hip_stream);
+/* teacher-forced VarianceEncoder embedding (model.py:417-422): y = x + Emb[bucketize(target * std + mean)] (+ pe + spk) */
+int fs2_op_bucket_embed_target(int32_t dtype, const void* x, const float* target, const float* bins, const float* emb,
+                               int32_t nbins, float std, float mean, const float* pe, const float* spk, void* y,
+                               int32_t* idx_out, int32_t B, int32_t T, int32_t H, void* hip_stream);
+
+/* ================================================================================================
  * HiFi-GAN generator: the step right after the mel forward.  Replaces
  * litfass.third_party.hifigan.Synthesiser.__call__ -> Generator.forward
  * (litfass/third_party/hifigan/__init__.py:19-43, models.py:112-165), resblock type "1".

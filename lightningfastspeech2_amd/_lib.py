@@ -57,6 +57,18 @@ class Fs2OutputsC(C.Structure):
     ]
 
 
+class BGemmDescC(C.Structure):
+    _fields_ = [
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("sAm", C.c_int64), ("sAk", C.c_int64), ("sBk", C.c_int64), ("sBn", C.c_int64), ("ldc", C.c_int64),
+        ("nb1", C.c_int32), ("nb2", C.c_int32),
+        ("sA1", C.c_int64), ("sA2", C.c_int64), ("sB1", C.c_int64), ("sB2", C.c_int64), ("sC1", C.c_int64), ("sC2", C.c_int64),
+        ("alpha", C.c_float), ("beta", C.c_float), ("splitk", C.c_int32),
+        ("seg", C.c_int32), ("taps", C.c_int32), ("Kin", C.c_int32), ("a_shift0", C.c_int32), ("a_shift_step", C.c_int32),
+        ("sBtap", C.c_int64), ("b_shift0", C.c_int32), ("b_shift_step", C.c_int32),
+    ]
+
+
 def declared_symbols(header_path: str = HEADER_PATH):
     """Every function include/fs2.h declares (used to verify the library exports the full ABI)."""
     with open(header_path) as f:
@@ -133,6 +145,27 @@ def load():
     lib.fs2_op_bucket_embed.argtypes = [i32, vp, vp, vp, vp, i32, C.c_float, C.c_float, vp, vp, vp, vp, i32, i32, i32, vp]
     lib.fs2_op_embed.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     lib.fs2_op_spk_proj.argtypes = [vp, vp, vp, vp, i32, i32, i32, vp]
+    f32, sz = C.c_float, C.c_size_t
+    lib.fs2_op_bgemm_ws_bytes.restype = sz
+    lib.fs2_op_bgemm_ws_bytes.argtypes = [C.POINTER(BGemmDescC)]
+    lib.fs2_op_bgemm.argtypes = [i32, C.POINTER(BGemmDescC), vp, vp, vp, vp, vp, vp]
+    lib.fs2_op_layernorm_bwd_parts.restype = i32
+    lib.fs2_op_layernorm_bwd_parts.argtypes = [i32]
+    lib.fs2_op_layernorm_bwd.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32, i32, vp]
+    lib.fs2_op_col_sum_ws_bytes.restype = sz
+    lib.fs2_op_col_sum_ws_bytes.argtypes = [i32, i32, i32]
+    lib.fs2_op_col_sum.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, f32, vp]
+    lib.fs2_op_softmax_fwd.argtypes = [i32, vp, vp, i32, i32, i32, f32, vp]
+    lib.fs2_op_softmax_bwd.argtypes = [i32, vp, vp, i32, i32, i32, f32, vp]
+    lib.fs2_op_ew.argtypes = [i32, vp, vp, vp, sz, f32, f32, vp]
+    lib.fs2_op_scatter_rows.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.fs2_op_regulate_bwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.fs2_op_masked_loss_bwd.argtypes = [vp, vp, i32, vp, vp, vp, C.c_int64, i32, i32, f32, vp]
+    lib.fs2_op_sum_sq_ws_bytes.restype = sz
+    lib.fs2_op_sum_sq_ws_bytes.argtypes = [sz]
+    lib.fs2_op_sum_sq.argtypes = [vp, sz, vp, vp, vp]
+    lib.fs2_op_adamw.argtypes = [vp, vp, vp, vp, sz, f32, f32, f32, f32, f32, i32, vp, f32, f32, vp]
+    lib.fs2_op_bucket_embed_target.argtypes = [i32, vp, vp, vp, vp, i32, f32, f32, vp, vp, vp, vp, i32, i32, i32, vp]
     if lib.fs2_abi_version() != FS2_ABI_VERSION:
         raise Fs2LibraryError("libfs2_hip.so ABI version mismatch")
     _lib = lib

@@ -1,0 +1,387 @@
+// Row / column kernels of the training step's backward (the reference gets them from autograd,
+// fastspeech2.py:786-797): LayerNorm backward, column sums (bias / gamma / beta / speaker gradients), masked softmax
+// forward + backward for the materialised attention of the training path, ReLU mask, embedding scatter, length-regulator
+// segment sums, masked-mean loss gradients, global gradient norm and the AdamW update (fastspeech2.py:1166-1173).
+// All HBM-bound: 16-byte accesses, one wave per row for the row kernels, fixed-order reductions (bit-equal reruns).
+#include "fs2_common.h"
+#include "fs2_kernels.h"
+
+namespace fs2 {
+
+namespace {
+
+// ---- LayerNorm backward -------------------------------------------------------------------------------------------
+// y = (z - mean) * rstd * gamma + beta.  dz = rstd * (g - mean(g) - zhat * mean(g * zhat)), g = dy * gamma.
+// One wave per row, 4 waves per workgroup, LN_ROWS rows per workgroup; the column sums of dy * zhat and dy are kept
+// per lane in registers over the workgroup's rows and leave as one partial per workgroup.
+constexpr int LN_ROWS = 64;
+constexpr int LN_MAXC = 16;  // columns per lane: H <= 64 * 16
+
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(LayerNormBwdArgs p) {
+    __shared__ float red[4][2][64 * LN_MAXC];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const float* z = (const float*)p.z;
+    const float* zr = (const float*)p.res;
+    const float* dy = (const float*)p.dy;
+    float* dz = (float*)p.dz;
+    const int H = p.H;
+    const int nc = (H + 63) / 64;
+    float dg[LN_MAXC], db[LN_MAXC], gam[LN_MAXC];
+#pragma unroll
+    for (int j = 0; j < LN_MAXC; ++j) {
+        dg[j] = db[j] = 0.f;
+        const int c = lane + 64 * j;
+        gam[j] = (j < nc && c < H) ? p.gamma[c] : 0.f;
+    }
+    const int row0 = blockIdx.x * LN_ROWS;
+    for (int rr = wid; rr < LN_ROWS; rr += 4) {
+        const int row = row0 + rr;
+        if (row >= p.M) break;
+        float zv[LN_MAXC], dv[LN_MAXC];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < LN_MAXC; ++j) {
+            const int c = lane + 64 * j;
+            const bool ok = j < nc && c < H;
+            zv[j] = ok ? z[(long)row * H + c] + (zr ? zr[(long)row * H + c] : 0.f) : 0.f;
+            dv[j] = ok ? dy[(long)row * H + c] : 0.f;
+            s += zv[j];
+        }
+        const float mean = wave_sum(s) / H;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < LN_MAXC; ++j) {
+            const int c = lane + 64 * j;
+            const float d = (j < nc && c < H) ? zv[j] - mean : 0.f;
+            zv[j] = d;
+            q += d * d;
+        }
+        const float rstd = rsqrtf(wave_sum(q) / H + p.eps);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < LN_MAXC; ++j) {
+            zv[j] *= rstd;  // zhat
+            const float g = dv[j] * gam[j];
+            s1 += g;
+            s2 += g * zv[j];
+            dg[j] += dv[j] * zv[j];
+            db[j] += dv[j];
+        }
+        s1 = wave_sum(s1) / H;
+        s2 = wave_sum(s2) / H;
+#pragma unroll
+        for (int j = 0; j < LN_MAXC; ++j) {
+            const int c = lane + 64 * j;
+            if (j < nc && c < H) dz[(long)row * H + c] = rstd * (dv[j] * gam[j] - s1 - zv[j] * s2);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < LN_MAXC; ++j) {
+        red[wid][0][lane + 64 * j] = dg[j];
+        red[wid][1][lane + 64 * j] = db[j];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < H; c += 256) {
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            a += red[w][0][c];
+            b += red[w][1][c];
+        }
+        p.part[((long)blockIdx.x * 2 + 0) * H + c] = a;
+        p.part[((long)blockIdx.x * 2 + 1) * H + c] = b;
+    }
+}
+
+// ---- column sums ----------------------------------------------------------------------------------------------------
+// out[s][n] (+)= scale * sum_{rows of segment s} x[row][n].  Pass 1: a workgroup owns 64 columns x one row chunk of one
+// segment (4 row groups x 64 lanes, fixed order), partials to ws; pass 2 adds the chunks in index order.
+constexpr int CS_CHUNK = 512;  // rows per pass-1 workgroup
+
+__global__ __launch_bounds__(256) void col_sum_pass1(ColSumArgs p, int nchunk) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    const int chunk = blockIdx.y, s = blockIdx.z;
+    const int seg = p.seg > 0 ? p.seg : p.M;
+    const int r0 = chunk * CS_CHUNK, r1 = min(seg, r0 + CS_CHUNK);
+    float a = 0.f;
+    if (c < p.N)
+        for (int r = r0 + g; r < r1; r += 4) a += p.x[((long)s * seg + r) * p.ldx + c];
+    red[g][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (g == 0 && c < p.N) {
+        const int l = threadIdx.x;
+        p.ws[((long)s * nchunk + chunk) * p.N + c] = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+    }
+}
+__global__ void col_sum_pass2(ColSumArgs p, int nchunk) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
+    if (c >= p.N) return;
+    float a = 0.f;
+    for (int k = 0; k < nchunk; ++k) a += p.ws[((long)s * nchunk + k) * p.N + c];
+    a *= p.scale;
+    float* o = p.out + (long)s * p.N + c;
+    *o = p.accumulate ? *o + a : a;
+}
+
+// ---- masked softmax over the key axis (training path: probabilities are materialised; HBM is 288 GB) --------------
+// one wave per (b, head, query) row
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(SoftmaxArgs p) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long rows = (long)p.B * p.heads * p.S;
+    if (row >= rows) return;
+    const int b = (int)(row / ((long)p.heads * p.S));
+    float* s = (float*)p.s + row * p.S;
+    const uint8_t* pad = p.key_pad ? p.key_pad + (long)b * p.S : nullptr;
+    float mx = -INFINITY;
+    for (int k = lane; k < p.S; k += 64) {
+        const float v = (pad && pad[k]) ? -INFINITY : s[k] * p.scale;
+        mx = fmaxf(mx, v);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int k = lane; k < p.S; k += 64) {
+        const float v = (pad && pad[k]) ? 0.f : expf(s[k] * p.scale - mx);
+        s[k] = v;
+        sum += v;
+    }
+    const float inv = 1.f / wave_sum(sum);
+    for (int k = lane; k < p.S; k += 64) s[k] *= inv;
+}
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(SoftmaxArgs p) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long rows = (long)p.B * p.heads * p.S;
+    if (row >= rows) return;
+    float* d = (float*)p.s + row * p.S;
+    const float* pr = (const float*)p.p + row * p.S;
+    float dot = 0.f;
+    for (int k = lane; k < p.S; k += 64) dot += d[k] * pr[k];
+    dot = wave_sum(dot);
+    for (int k = lane; k < p.S; k += 64) d[k] = p.scale * pr[k] * (d[k] - dot);
+}
+
+__global__ void ew_kernel(EwArgs p) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t e = i; e < p.n; e += stride) {
+        float v;
+        if (p.op == 0) v = p.alpha * p.a[e] + (p.b ? p.beta * p.b[e] : 0.f);
+        else if (p.op == 1) v = p.b[e] > 0.f ? p.a[e] : 0.f;
+        else v = p.alpha * p.a[e];
+        p.out[e] = v;
+    }
+}
+
+// ---- embedding backward: one workgroup per table row, source rows visited in index order --------------------------
+__global__ __launch_bounds__(256) void scatter_rows_kernel(ScatterRowsArgs p) {
+    const int v = blockIdx.x;
+    if (v == p.skip_row) return;
+    __shared__ int hits[1024];
+    __shared__ int nhit;
+    for (int c0 = 0; c0 < p.H; c0 += 256 * 8) {  // register accumulators for up to 8 columns per thread per sweep
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        for (int r0 = 0; r0 < p.R; r0 += 1024) {
+            if (threadIdx.x == 0) nhit = 0;
+            __syncthreads();
+            // ordered compaction of the matching rows of this block of 1024 (order = row index: deterministic sums)
+            for (int q = 0; q < 4; ++q) {
+                const int r = r0 + q * 256 + threadIdx.x;
+                const bool m = r < p.R && (p.idx32 ? p.idx32[r] : (int)p.idx64[r]) == v;
+                const unsigned long long bal = __ballot(m);
+                __shared__ int wcnt[4];
+                const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+                if (lane == 0) wcnt[w] = __popcll(bal);
+                __syncthreads();
+                int base = nhit;
+                for (int k = 0; k < w; ++k) base += wcnt[k];
+                if (m) hits[base + __popcll(bal & ((1ull << lane) - 1))] = r;
+                __syncthreads();
+                if (threadIdx.x == 0) nhit += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+                __syncthreads();
+            }
+            const int n = nhit;
+            for (int h = 0; h < n; ++h) {
+                const float* src = p.x + (long)hits[h] * p.H;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int c = c0 + j * 256 + threadIdx.x;
+                    if (c < p.H) acc[j] += src[c];
+                }
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = c0 + j * 256 + threadIdx.x;
+            if (c < p.H) p.table[(long)v * p.H + c] += acc[j];
+        }
+    }
+}
+
+// ---- length regulator backward: one wave per (b, phone) -----------------------------------------------------------
+__global__ __launch_bounds__(256) void regulate_bwd_kernel(RegulateBwdArgs p) {
+    const int lane = threadIdx.x & 63;
+    const long idx = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (idx >= (long)p.B * p.L) return;
+    const int b = (int)(idx / p.L), ph = (int)(idx % p.L);
+    const int t1 = min(p.cum[idx], p.T), t0 = min(ph ? p.cum[idx - 1] : 0, p.T);
+    for (int c = lane; c < p.H; c += 64) {
+        float a = 0.f;
+        for (int t = t0; t < t1; ++t) a += p.dy[((long)b * p.T + t) * p.H + c];
+        p.dx[idx * p.H + c] = a;
+    }
+}
+
+__global__ void masked_loss_bwd_kernel(LossBwdArgs p) {
+    const int64_t total = p.rows * (int64_t)p.inner;
+    const float cnt = p.stat[1];
+    const float k = p.alpha / cnt;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / p.inner;
+        float g = 0.f;
+        if (!p.mask[r]) {
+            float t;
+            if (p.truth_kind == 0) t = ((const float*)p.truth)[e];
+            else t = logf((float)((const int64_t*)p.truth)[e] + 1.0f);
+            const float d = p.pred[e] - t;
+            g = p.kind == 0 ? (d > 0.f ? k : (d < 0.f ? -k : 0.f)) : 2.f * d * k;
+        }
+        p.dpred[e] = g;
+    }
+}
+
+// ---- global gradient norm + AdamW ------------------------------------------------------------------------------------
+constexpr int SS_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void sum_sq_pass1(const float* x, size_t n, float* ws) {
+    __shared__ double red[256];
+    double a = 0.0;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) a += (double)x[e] * x[e];
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) ((double*)ws)[blockIdx.x] = red[0];
+}
+__global__ void sum_sq_pass2(const float* ws, int nb, float* out) {
+    if (threadIdx.x || blockIdx.x) return;
+    double a = 0.0;
+    for (int b = 0; b < nb; ++b) a += ((const double*)ws)[b];
+    *out = (float)a;
+}
+
+// torch.optim.AdamW (fastspeech2.py:1166-1173): decoupled weight decay, bias-corrected moments; the gradient is first
+// scaled by grad_scale and by the global-norm clip coefficient min(1, max_norm / (norm + 1e-6)) (clip_grad_norm_).
+__global__ void adamw_kernel(AdamWArgs p) {
+    float gs = p.grad_scale;
+    if (p.gnorm_sq) {
+        const float norm = sqrtf(*p.gnorm_sq) * p.grad_scale;
+        const float coef = p.max_norm / (norm + 1e-6f);
+        if (coef < 1.f) gs *= coef;
+    }
+    const float bc1 = 1.f - powf(p.beta1, (float)p.step), bc2 = 1.f - powf(p.beta2, (float)p.step);
+    const float step_size = p.lr / bc1, inv_sqrt_bc2 = 1.f / sqrtf(bc2);
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < p.n; e += (size_t)gridDim.x * blockDim.x) {
+        const float g = p.g[e] * gs;
+        float w = p.p[e] * (1.f - p.lr * p.weight_decay);
+        const float m = p.beta1 * p.m[e] + (1.f - p.beta1) * g;
+        const float v = p.beta2 * p.v[e] + (1.f - p.beta2) * g * g;
+        p.m[e] = m;
+        p.v[e] = v;
+        w -= step_size * m / (sqrtf(v) * inv_sqrt_bc2 + p.eps);
+        p.p[e] = w;
+    }
+}
+
+inline int ok() { return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP; }
+
+}  // namespace
+
+int layernorm_bwd_parts(int M) { return (M + LN_ROWS - 1) / LN_ROWS; }
+
+int launch_layernorm_bwd(const LayerNormBwdArgs& a, int dtype, hipStream_t stream) {
+    if (dtype != FS2_F32 || a.H > 64 * LN_MAXC || a.M <= 0) return FS2_ERR_SHAPE;
+    if (a.nparts != layernorm_bwd_parts(a.M)) return FS2_ERR_ARG;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(a.nparts), dim3(256), 0, stream, a);
+    return ok();
+}
+
+static int cs_chunks(int M, int seg) { return ((seg > 0 ? seg : M) + CS_CHUNK - 1) / CS_CHUNK; }
+size_t col_sum_ws_bytes(int M, int N, int seg) {
+    const int nseg = seg > 0 ? M / seg : 1;
+    return (size_t)nseg * cs_chunks(M, seg) * N * sizeof(float);
+}
+int launch_col_sum(const ColSumArgs& a, hipStream_t stream) {
+    if (a.M <= 0 || a.N <= 0 || (a.seg > 0 && a.M % a.seg)) return FS2_ERR_SHAPE;
+    const int nseg = a.seg > 0 ? a.M / a.seg : 1, nchunk = cs_chunks(a.M, a.seg);
+    hipLaunchKernelGGL(col_sum_pass1, dim3((a.N + 63) / 64, nchunk, nseg), dim3(256), 0, stream, a, nchunk);
+    hipLaunchKernelGGL(col_sum_pass2, dim3((a.N + 255) / 256, nseg), dim3(256), 0, stream, a, nchunk);
+    return ok();
+}
+
+int launch_softmax_fwd(const SoftmaxArgs& a, int dtype, hipStream_t stream) {
+    if (dtype != FS2_F32) return FS2_ERR_SHAPE;
+    const long rows = (long)a.B * a.heads * a.S;
+    hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, a);
+    return ok();
+}
+int launch_softmax_bwd(const SoftmaxArgs& a, int dtype, hipStream_t stream) {
+    if (dtype != FS2_F32) return FS2_ERR_SHAPE;
+    const long rows = (long)a.B * a.heads * a.S;
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, a);
+    return ok();
+}
+
+int launch_ew(const EwArgs& a, hipStream_t stream) {
+    if (!a.n) return FS2_OK;
+    size_t blocks = (a.n + 1023) / 1024;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(ew_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    return ok();
+}
+
+int launch_scatter_rows(const ScatterRowsArgs& a, hipStream_t stream) {
+    if (a.R <= 0 || a.V <= 0 || (!a.idx32 && !a.idx64)) return FS2_ERR_ARG;
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(a.V), dim3(256), 0, stream, a);
+    return ok();
+}
+
+int launch_regulate_bwd(const RegulateBwdArgs& a, hipStream_t stream) {
+    const long n = (long)a.B * a.L;
+    hipLaunchKernelGGL(regulate_bwd_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, a);
+    return ok();
+}
+
+int launch_masked_loss_bwd(const LossBwdArgs& a, hipStream_t stream) {
+    const int64_t total = a.rows * (int64_t)a.inner;
+    int64_t blocks = (total + 1023) / 1024;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(masked_loss_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    return ok();
+}
+
+size_t sum_sq_ws_bytes(size_t) { return SS_BLOCKS * sizeof(double); }
+int launch_sum_sq(const float* x, size_t n, float* ws, float* out, hipStream_t stream) {
+    int nb = (int)((n + 256 * 16 - 1) / (256 * 16));
+    if (nb < 1) nb = 1;
+    if (nb > SS_BLOCKS) nb = SS_BLOCKS;
+    hipLaunchKernelGGL(sum_sq_pass1, dim3(nb), dim3(256), 0, stream, x, n, ws);
+    hipLaunchKernelGGL(sum_sq_pass2, dim3(1), dim3(64), 0, stream, ws, nb, out);
+    return ok();
+}
+
+int launch_adamw(const AdamWArgs& a, hipStream_t stream) {
+    if (!a.n || a.step < 1) return FS2_ERR_ARG;
+    size_t blocks = (a.n + 1023) / 1024;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    return ok();
+}
+
+}  // namespace fs2

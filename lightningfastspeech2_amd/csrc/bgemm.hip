@@ -1,0 +1,280 @@
+// General strided-batched GEMM for the training step's backward:
+//   C[b][m][n] = alpha * sum_k A[b](m, k) * B[b](k, n)  (+ bias[n])  (+ beta * C[b][m][n])
+// with every operand addressed by element strides, so one kernel covers
+//   NT  (both operands k-contiguous)        attention scores  S = Q K^T,   dP = dO V^T
+//   NN  (B n-contiguous)                    linear / conv dgrad  dX = dY W,  O = P V,  dQ = dS K
+//   TN  (both operands k-strided)           weight gradients  dW = dY^T X,  dV = P^T dO,  dK = dS^T Q
+// plus the two implicit-conv forms of a 'same'-padded Conv1d over (B*S, C) time-major activations:
+//   dgrad: K = taps * Kin, k-tile `tap` reads A rows m + a_shift0 + tap * a_shift_step (zero outside the row's
+//          utterance of `seg` rows) and B from + tap * sBtap;
+//   wgrad: batch index b2 = tap, B's k index (a time row) is read at k + b_shift0 + b2 * b_shift_step, zero outside
+//          the utterance.
+// fp32 operands on the exact fp32 MFMA (16x16x4), fp32 accumulation; 128 x 128 x 16 tiles, 4 waves (2 x 2),
+// register-prefetched double-buffered LDS.  Split-K (deterministic: per-split slabs + a reduce pass) for the
+// weight gradients, whose reduction runs over all B*T rows while the output is only N x K.
+// The reference gets all of these from autograd (fastspeech2.py:786-797 training_step -> loss.backward()).
+#include "fs2_common.h"
+#include "fs2_kernels.h"
+
+namespace fs2 {
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int LDK = 20;    // k-contiguous LDS image: [128][20] floats (16-B aligned rows)
+constexpr int LDM = 144;   // m/n-contiguous LDS image: [16][144] floats (rows 16 banks apart)
+constexpr int OPSZ = BM * LDK;  // 2560 floats >= BK * LDM = 2304
+
+struct Operand {
+    const float* p;
+    long s_mn, s_k;  // element strides of the tile's outer (m or n) index and of k
+    int mn0, MN;     // tile origin and extent of the outer index
+    int shift_mn;    // rows of the outer index are read at +shift (dgrad), zero outside the segment
+    int shift_k;     // k rows are read at +shift (wgrad)
+    int seg;
+    bool vec;
+};
+
+// One tile (128 outer x 16 k) -> two float4 per thread.  kc: vectors run along k; else along the outer index.
+__device__ inline void load_tile(const Operand& o, int k0, int Kend, float4 (&r)[2]) {
+    const int tid = threadIdx.x;
+    const bool kc = o.s_k == 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int v = tid + 256 * i;
+        int mn, k;
+        if (kc) { mn = v >> 2; k = (v & 3) * 4; } else { k = v >> 5; mn = (v & 31) * 4; }
+        const int gmn = o.mn0 + mn, gk = k0 + k;
+        float f[4] = {0.f, 0.f, 0.f, 0.f};
+        if (kc) {
+            bool ok = gmn < o.MN;
+            long row = gmn;
+            if (o.seg && ok) {
+                const int in = gmn % o.seg + o.shift_mn;
+                ok = in >= 0 && in < o.seg;
+                row = gmn + o.shift_mn;
+            }
+            if (ok) {
+                const float* src = o.p + row * o.s_mn + gk;
+                if (o.vec && gk + 3 < Kend) {
+                    const float4 t = *(const float4*)src;
+                    f[0] = t.x; f[1] = t.y; f[2] = t.z; f[3] = t.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (gk + e < Kend) f[e] = src[e];
+                }
+            }
+        } else {
+            bool ok = gk < Kend;
+            long krow = gk;
+            if (o.seg && ok) {
+                const int in = gk % o.seg + o.shift_k;
+                ok = in >= 0 && in < o.seg;
+                krow = gk + o.shift_k;
+            }
+            if (ok) {
+                const float* src = o.p + krow * o.s_k + gmn;
+                if (o.vec && gmn + 3 < o.MN) {
+                    const float4 t = *(const float4*)src;
+                    f[0] = t.x; f[1] = t.y; f[2] = t.z; f[3] = t.w;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (gmn + e < o.MN) f[e] = src[e];
+                }
+            }
+        }
+        r[i] = make_float4(f[0], f[1], f[2], f[3]);
+    }
+}
+
+__device__ inline void store_tile(float* s, bool kc, const float4 (&r)[2]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int v = tid + 256 * i;
+        if (kc) *(float4*)(s + (v >> 2) * LDK + (v & 3) * 4) = r[i];
+        else *(float4*)(s + (v >> 5) * LDM + (v & 31) * 4) = r[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void bgemm_f32_kernel(BGemmArgs p) {
+    __shared__ __attribute__((aligned(16))) float lds[2][2][OPSZ];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int splitk = p.splitk > 1 ? p.splitk : 1;
+    int z = blockIdx.z;
+    const int split = z % splitk;
+    z /= splitk;
+    const int b2 = z % p.nb2, b1 = z / p.nb2;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+    Operand A, B;
+    A.p = (const float*)p.A + b1 * p.sA1 + b2 * p.sA2;
+    A.s_mn = p.sAm; A.s_k = p.sAk; A.mn0 = m0; A.MN = p.M;
+    A.shift_mn = 0; A.shift_k = 0; A.seg = 0; A.vec = p.vecA;
+    B.p = (const float*)p.B + b1 * p.sB1 + b2 * p.sB2;
+    B.s_mn = p.sBn; B.s_k = p.sBk; B.mn0 = n0; B.MN = p.N;
+    B.shift_mn = 0; B.shift_k = 0; B.seg = 0; B.vec = p.vecB;
+    if (p.seg && p.taps <= 1) {  // wgrad form: B's k rows shifted by the tap this batch index stands for
+        B.seg = p.seg;
+        B.shift_k = p.b_shift0 + b2 * p.b_shift_step;
+    }
+    const bool akc = A.s_k == 1, bkc = B.s_k == 1;
+
+    // k range of this split, in whole k-tiles; in the dgrad form K = taps * Kin and tiles never straddle a tap
+    const int Kin = p.taps > 1 ? p.Kin : p.K;
+    const int tiles_per_tap = (Kin + BK - 1) / BK;
+    const int ntiles = tiles_per_tap * (p.taps > 1 ? p.taps : 1);
+    const int per = (ntiles + splitk - 1) / splitk;
+    const int t_begin = split * per, t_end = min(ntiles, t_begin + per);
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const float* Ap0 = A.p;
+    const float* Bp0 = B.p;
+    auto fetch = [&](int t, float4 (&ra)[2], float4 (&rb)[2]) {
+        int k0 = t * BK, kend = p.K;
+        if (p.taps > 1) {
+            const int tap = t / tiles_per_tap;
+            k0 = (t - tap * tiles_per_tap) * BK;
+            kend = Kin;
+            A.seg = p.seg;
+            A.shift_mn = p.a_shift0 + tap * p.a_shift_step;
+            A.p = Ap0;
+            B.p = Bp0 + tap * p.sBtap;
+        }
+        load_tile(A, k0, kend, ra);
+        load_tile(B, k0, kend, rb);
+    };
+
+    float4 ra[2], rb[2];
+    if (t_begin < t_end) {
+        fetch(t_begin, ra, rb);
+        store_tile(lds[0][0], akc, ra);
+        store_tile(lds[0][1], bkc, rb);
+    }
+    __syncthreads();
+    for (int t = t_begin; t < t_end; ++t) {
+        const int cur = (t - t_begin) & 1;
+        const bool more = t + 1 < t_end;
+        if (more) fetch(t + 1, ra, rb);
+        const float* sa = lds[cur][0];
+        const float* sb = lds[cur][1];
+#pragma unroll
+        for (int ks = 0; ks < BK / 4; ++ks) {
+            const int k = ks * 4 + fg;
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = wm * 64 + i * 16 + fr;
+                a[i] = akc ? sa[m * LDK + k] : sa[k * LDM + m];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = wn * 64 + j * 16 + fr;
+                b[j] = bkc ? sb[n * LDK + k] : sb[k * LDM + n];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            store_tile(lds[cur ^ 1][0], akc, ra);
+            store_tile(lds[cur ^ 1][1], bkc, rb);
+        }
+        __syncthreads();
+    }
+
+    // D: lane holds column fr, rows fg * 4 + r of each 16 x 16 block
+    if (splitk > 1) {
+        float* ws = p.ws + ((long)(b1 * p.nb2 + b2) * splitk + split) * (long)p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm * 64 + i * 16 + fg * 4 + r, n = n0 + wn * 64 + j * 16 + fr;
+                    if (m < p.M && n < p.N) ws[(long)m * p.N + n] = acc[i][j][r];
+                }
+        return;
+    }
+    float* C = (float*)p.C + b1 * p.sC1 + b2 * p.sC2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + fr;
+            if (n >= p.N) continue;
+            const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 64 + i * 16 + fg * 4 + r;
+                if (m >= p.M) continue;
+                float v = p.alpha * acc[i][j][r] + bv;
+                float* dst = C + (long)m * p.ldc + n;
+                if (p.beta != 0.f) v += p.beta * *dst;
+                *dst = v;
+            }
+        }
+}
+
+// C = alpha * sum over splits + bias + beta * C, one thread per output element
+__global__ void bgemm_reduce_kernel(BGemmArgs p) {
+    const long per = (long)p.M * p.N;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int bz = blockIdx.y;  // batch
+    if (i >= per) return;
+    const int b2 = bz % p.nb2, b1 = bz / p.nb2;
+    const float* ws = p.ws + (long)bz * p.splitk * per + i;
+    float s = 0.f;
+    for (int k = 0; k < p.splitk; ++k) s += ws[(long)k * per];
+    const int m = (int)(i / p.N), n = (int)(i % p.N);
+    float v = p.alpha * s + (p.bias ? p.bias[n] : 0.f);
+    float* dst = (float*)p.C + b1 * p.sC1 + b2 * p.sC2 + (long)m * p.ldc + n;
+    if (p.beta != 0.f) v += p.beta * *dst;
+    *dst = v;
+}
+
+inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+}  // namespace
+
+size_t bgemm_ws_bytes(const BGemmArgs& a) {
+    return a.splitk > 1 ? (size_t)a.nb1 * a.nb2 * a.splitk * a.M * a.N * sizeof(float) : 0;
+}
+
+int launch_bgemm(const BGemmArgs& a0, int dtype, hipStream_t stream) {
+    if (dtype != FS2_F32) return FS2_ERR_SHAPE;
+    BGemmArgs a = a0;
+    if (a.M <= 0 || a.N <= 0 || a.K <= 0 || a.nb1 <= 0 || a.nb2 <= 0) return FS2_ERR_SHAPE;
+    if ((a.sAm != 1 && a.sAk != 1) || (a.sBk != 1 && a.sBn != 1)) return FS2_ERR_SHAPE;
+    if (a.taps > 1 && (a.Kin <= 0 || a.K != a.taps * a.Kin)) return FS2_ERR_SHAPE;
+    if (a.splitk > 1 && !a.ws) return FS2_ERR_ARG;
+    // 16-byte vector loads need every row start (and batch / tap base) on a 16-byte boundary
+    auto vec_ok = [](const void* p, long s_outer, long s1, long s2, long s3) {
+        return aligned16(p) && s_outer % 4 == 0 && s1 % 4 == 0 && s2 % 4 == 0 && s3 % 4 == 0;
+    };
+    a.vecA = vec_ok(a.A, a.sAk == 1 ? a.sAm : a.sAk, a.sA1, a.sA2, 0) ? 1 : 0;
+    a.vecB = vec_ok(a.B, a.sBk == 1 ? a.sBn : a.sBk, a.sB1, a.sB2, a.taps > 1 ? a.sBtap : 0) ? 1 : 0;
+    const int splitk = a.splitk > 1 ? a.splitk : 1;
+    dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, a.nb1 * a.nb2 * splitk);
+    hipLaunchKernelGGL(bgemm_f32_kernel, grid, dim3(256), 0, stream, a);
+    if (splitk > 1) {
+        const long per = (long)a.M * a.N;
+        dim3 g2((unsigned)((per + 255) / 256), a.nb1 * a.nb2);
+        hipLaunchKernelGGL(bgemm_reduce_kernel, g2, dim3(256), 0, stream, a);
+    }
+    return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
+}
+
+}  // namespace fs2

@@ -184,4 +184,85 @@ int fs2_op_spk_proj(const float* dvec, const float* w, const float* b, float* sp
     return launch_spk_proj(a, (hipStream_t)stream);
 }
 
+// ---- training step (f4): backward operators -------------------------------------------------------------------------
+static BGemmArgs bgemm_args(const fs2_bgemm_desc* d, const void* A, const void* B, void* C, const float* bias, float* ws) {
+    BGemmArgs a;
+    a.A = A; a.B = B; a.C = C; a.bias = bias; a.ws = ws;
+    a.M = d->M; a.N = d->N; a.K = d->K;
+    a.sAm = d->sAm; a.sAk = d->sAk; a.sBk = d->sBk; a.sBn = d->sBn; a.ldc = d->ldc;
+    a.nb1 = d->nb1 > 0 ? d->nb1 : 1; a.nb2 = d->nb2 > 0 ? d->nb2 : 1;
+    a.sA1 = d->sA1; a.sA2 = d->sA2; a.sB1 = d->sB1; a.sB2 = d->sB2; a.sC1 = d->sC1; a.sC2 = d->sC2;
+    a.alpha = d->alpha; a.beta = d->beta; a.splitk = d->splitk > 1 ? d->splitk : 1;
+    a.seg = d->seg; a.taps = d->taps > 1 ? d->taps : 1; a.Kin = d->Kin;
+    a.a_shift0 = d->a_shift0; a.a_shift_step = d->a_shift_step; a.sBtap = d->sBtap;
+    a.b_shift0 = d->b_shift0; a.b_shift_step = d->b_shift_step;
+    return a;
+}
+size_t fs2_op_bgemm_ws_bytes(const fs2_bgemm_desc* d) {
+    return d ? bgemm_ws_bytes(bgemm_args(d, nullptr, nullptr, nullptr, nullptr, nullptr)) : 0;
+}
+int fs2_op_bgemm(int32_t dtype, const fs2_bgemm_desc* d, const void* A, const void* B, void* C, const float* bias,
+                 float* ws, void* stream) {
+    if (!d || !A || !B || !C) return FS2_ERR_ARG;
+    return launch_bgemm(bgemm_args(d, A, B, C, bias, ws), dtype, (hipStream_t)stream);
+}
+int32_t fs2_op_layernorm_bwd_parts(int32_t M) { return layernorm_bwd_parts(M); }
+int fs2_op_layernorm_bwd(int32_t dtype, const void* z, const void* res, const void* dy, const float* gamma, void* dz,
+                         float* part, int32_t M, int32_t H, void* stream) {
+    LayerNormBwdArgs a{z, res, dy, gamma, dz, part, M, H, layernorm_bwd_parts(M), 1e-5f};
+    return launch_layernorm_bwd(a, dtype, (hipStream_t)stream);
+}
+size_t fs2_op_col_sum_ws_bytes(int32_t M, int32_t N, int32_t seg) { return col_sum_ws_bytes(M, N, seg); }
+int fs2_op_col_sum(const float* x, float* out, float* ws, int32_t M, int32_t N, int32_t ldx, int32_t seg,
+                   int32_t accumulate, float scale, void* stream) {
+    ColSumArgs a{x, out, ws, M, N, ldx, seg, accumulate, scale};
+    return launch_col_sum(a, (hipStream_t)stream);
+}
+int fs2_op_softmax_fwd(int32_t dtype, void* s, const uint8_t* key_pad, int32_t B, int32_t heads, int32_t S, float scale,
+                       void* stream) {
+    SoftmaxArgs a{s, nullptr, key_pad, B, heads, S, scale};
+    return launch_softmax_fwd(a, dtype, (hipStream_t)stream);
+}
+int fs2_op_softmax_bwd(int32_t dtype, void* dp, const void* p, int32_t B, int32_t heads, int32_t S, float scale,
+                       void* stream) {
+    SoftmaxArgs a{dp, p, nullptr, B, heads, S, scale};
+    return launch_softmax_bwd(a, dtype, (hipStream_t)stream);
+}
+int fs2_op_ew(int32_t op, const float* a_, const float* b, float* out, size_t n, float alpha, float beta, void* stream) {
+    EwArgs a{a_, b, out, n, alpha, beta, op};
+    return launch_ew(a, (hipStream_t)stream);
+}
+int fs2_op_scatter_rows(const float* x, const int32_t* idx32, const int64_t* idx64, float* table, int32_t R, int32_t H,
+                        int32_t V, int32_t skip_row, void* stream) {
+    ScatterRowsArgs a{x, idx32, idx64, table, R, H, V, skip_row};
+    return launch_scatter_rows(a, (hipStream_t)stream);
+}
+int fs2_op_regulate_bwd(const float* dy, const int32_t* cum, float* dx, int32_t B, int32_t L, int32_t T, int32_t H,
+                        void* stream) {
+    RegulateBwdArgs a{dy, cum, dx, B, L, T, H};
+    return launch_regulate_bwd(a, (hipStream_t)stream);
+}
+int fs2_op_masked_loss_bwd(const float* pred, const void* truth, int32_t truth_kind, const uint8_t* pad_mask,
+                           const float* stat, float* dpred, int64_t rows, int32_t inner, int32_t kind, float alpha,
+                           void* stream) {
+    LossBwdArgs a{pred, truth, pad_mask, stat, dpred, rows, inner, kind, truth_kind, alpha};
+    return launch_masked_loss_bwd(a, (hipStream_t)stream);
+}
+size_t fs2_op_sum_sq_ws_bytes(size_t n) { return sum_sq_ws_bytes(n); }
+int fs2_op_sum_sq(const float* x, size_t n, float* ws, float* out, void* stream) {
+    return launch_sum_sq(x, n, ws, out, (hipStream_t)stream);
+}
+int fs2_op_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
+                 float weight_decay, int32_t step, const float* gnorm_sq, float max_norm, float grad_scale, void* stream) {
+    AdamWArgs a{p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, gnorm_sq, max_norm, grad_scale};
+    return launch_adamw(a, (hipStream_t)stream);
+}
+int fs2_op_bucket_embed_target(int32_t dtype, const void* x, const float* target, const float* bins, const float* emb,
+                               int32_t nbins, float std, float mean, const float* pe, const float* spk, void* y,
+                               int32_t* idx_out, int32_t B, int32_t T, int32_t H, void* stream) {
+    BucketArgs a{x, target, bins, emb, nbins, std, mean, pe, spk, y, idx_out, B, T, H, nullptr};
+    a.bucket_src = target;
+    return launch_bucket_embed(a, dtype, (hipStream_t)stream);
+}
+
 }  // extern "C"

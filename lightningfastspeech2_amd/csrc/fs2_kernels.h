@@ -266,4 +266,120 @@ struct BucketArgs {
 };
 int launch_bucket_embed(const BucketArgs& a, int dtype, hipStream_t stream);
 
+// ---- training step: backward kernels ------------------------------------------------------------
+// General strided-batched GEMM (bgemm.hip): C[b1][b2](m, n) = alpha * sum_k A(m, k) B(k, n) + bias[n] + beta * C.
+struct BGemmArgs {
+    const void* A;
+    const void* B;
+    void* C;
+    const float* bias = nullptr;  // (N) or null
+    int M = 0, N = 0, K = 0;
+    long sAm = 0, sAk = 0;        // element strides of A(m, k); one of them is 1
+    long sBk = 0, sBn = 0;        // element strides of B(k, n); one of them is 1
+    long ldc = 0;                 // C is n-contiguous
+    int nb1 = 1, nb2 = 1;         // two batch levels (e.g. utterance, head)
+    long sA1 = 0, sA2 = 0, sB1 = 0, sB2 = 0, sC1 = 0, sC2 = 0;
+    float alpha = 1.f, beta = 0.f;
+    int splitk = 1;               // > 1: per-split slabs in ws (bgemm_ws_bytes) + a reduce pass; deterministic
+    float* ws = nullptr;
+    // implicit 'same'-padded Conv1d over (B*S, C) time-major rows, utterances of `seg` rows (0 = plain GEMM):
+    int seg = 0;
+    int taps = 1, Kin = 0;        // dgrad form: K = taps * Kin; k-tile of tap j reads A rows m + a_shift0 + j * a_shift_step
+    int a_shift0 = 0, a_shift_step = 0;
+    long sBtap = 0;               //             ... and B from + j * sBtap
+    int b_shift0 = 0, b_shift_step = 0;  // wgrad form (taps == 1): batch index b2 reads B's k rows at k + b_shift0 + b2 * b_shift_step
+    int vecA = 0, vecB = 0;       // set by the launcher
+};
+size_t bgemm_ws_bytes(const BGemmArgs& a);
+int launch_bgemm(const BGemmArgs& a, int dtype, hipStream_t stream);
+
+// Row / column kernels of the backward (backward.hip).  T = activation dtype; gradients of parameters are fp32.
+struct LayerNormBwdArgs {
+    const void* z;        // (M, H) the tensor that was normalised ...
+    const void* res;      // (M, H) or null: ... plus this (the forward's y = LN(x + res))
+    const void* dy;       // (M, H)
+    const float* gamma;   // (H)
+    void* dz;             // (M, H) out
+    float* part;          // (nparts, 2, H) out: per-workgroup partial sums of dy * zhat and dy (-> col_sum -> dgamma, dbeta)
+    int M, H, nparts;
+    float eps;
+};
+int layernorm_bwd_parts(int M);
+int launch_layernorm_bwd(const LayerNormBwdArgs& a, int dtype, hipStream_t stream);
+
+struct ColSumArgs {
+    const float* x;   // (M, N) fp32, row stride ldx
+    float* out;       // (nseg, N): out[s][n] (+)= scale * sum over the rows of segment s
+    float* ws;        // col_sum_ws_bytes
+    int M, N, ldx;
+    int seg;          // rows per segment (0 or M: one segment)
+    int accumulate;   // 1: out += ...
+    float scale;
+};
+size_t col_sum_ws_bytes(int M, int N, int seg);
+int launch_col_sum(const ColSumArgs& a, hipStream_t stream);
+
+struct SoftmaxArgs {
+    void* s;                // (B, heads, S, S) scores in place -> probabilities (fwd); dP in place -> dS (bwd)
+    const void* p;          // bwd: the probabilities
+    const uint8_t* key_pad; // (B, S) 1 = pad key -> probability 0; fwd only
+    int B, heads, S;
+    float scale;            // fwd: softmax(scale * s); bwd: dS = scale * P o (dP - sum(dP o P))
+};
+int launch_softmax_fwd(const SoftmaxArgs& a, int dtype, hipStream_t stream);
+int launch_softmax_bwd(const SoftmaxArgs& a, int dtype, hipStream_t stream);
+
+struct EwArgs {   // elementwise helpers over n fp32 elements
+    const float* a;
+    const float* b;
+    float* out;
+    size_t n;
+    float alpha, beta;
+    int op;       // 0: out = alpha*a + beta*b   1: out = a * (b > 0)  (ReLU backward: b = the ReLU output)   2: out = alpha * a
+};
+int launch_ew(const EwArgs& a, hipStream_t stream);
+
+struct ScatterRowsArgs {     // table[idx[r]] += scale * x[r]  (embedding backward), deterministic: one workgroup per table row
+    const float* x;          // (R, H)
+    const int32_t* idx32;    // (R) or null
+    const int64_t* idx64;    // (R) or null
+    float* table;            // (V, H) accumulated into
+    int R, H, V;
+    int skip_row;            // table row that receives no gradient (padding_idx), -1 = none
+};
+int launch_scatter_rows(const ScatterRowsArgs& a, hipStream_t stream);
+
+struct RegulateBwdArgs {     // d_phone[b][p] = sum of d_frame[b][t] over the frames phone p was repeated to (t < T)
+    const float* dy;         // (B*T, H)
+    const int32_t* cum;      // (B, L) inclusive prefix sums of the durations
+    float* dx;               // (B*L, H)
+    int B, L, T, H;
+};
+int launch_regulate_bwd(const RegulateBwdArgs& a, hipStream_t stream);
+
+struct LossBwdArgs {         // gradient of alpha * mean over selected elements of |p - t| or (p - t)^2
+    const float* pred;       // (rows, inner)
+    const void* truth;       // as LossArgs
+    const uint8_t* mask;     // (rows) 1 = pad
+    const float* stat;       // the forward's [mean, count] (device): count is read here, no host round trip
+    float* dpred;            // (rows, inner)
+    int64_t rows;
+    int inner, kind, truth_kind;
+    float alpha;
+};
+int launch_masked_loss_bwd(const LossBwdArgs& a, hipStream_t stream);
+
+struct AdamWArgs {
+    float* p; const float* g; float* m; float* v;   // flat fp32 buffers of n elements
+    size_t n;
+    float lr, beta1, beta2, eps, weight_decay;
+    int step;                // 1-based
+    const float* gnorm_sq;   // device scalar: sum of squares of g (null = no clipping)
+    float max_norm;          // clip the global norm to this (gradient_clip_val)
+    float grad_scale;        // g is multiplied by this first (1 / accumulated micro-batches)
+};
+int launch_adamw(const AdamWArgs& a, hipStream_t stream);
+size_t sum_sq_ws_bytes(size_t n);
+int launch_sum_sq(const float* x, size_t n, float* ws, float* out, hipStream_t stream);
+
 }  // namespace fs2

@@ -1,0 +1,257 @@
+"""GPU: the backward operators of the training step (csrc/bgemm.hip, csrc/backward.hip) one by one through
+the C ABI against plain fp32/fp64 torch CPU references of the same op (autograd where the op is a derivative).
+Tolerances: GEMM-shaped ops 2e-5 relative to the result's scale (fp32 MFMA, different summation order); row ops 1e-5."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from lightningfastspeech2_amd import _lib
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+F32 = _lib.FS2_F32
+
+
+def p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def bgemm(desc_kw, A, B, Cout, bias=None):
+    lib = _lib.load()
+    d = _lib.BGemmDescC()
+    base = dict(nb1=1, nb2=1, alpha=1.0, beta=0.0, splitk=1, taps=1)
+    base.update(desc_kw)
+    for k, v in base.items():
+        setattr(d, k, v)
+    ws = None
+    nbytes = lib.fs2_op_bgemm_ws_bytes(C.byref(d))
+    if nbytes:
+        ws = torch.empty(nbytes // 4, device=DEV)
+    _lib.check(lib.fs2_op_bgemm(F32, C.byref(d), p(A), p(B), p(Cout), p(bias), p(ws), st()), what="bgemm")
+    return Cout
+
+
+def close(got, want, rel=2e-5):
+    want = want.float()
+    scale = float(want.abs().max()) + 1e-30
+    err = float((got.cpu().float() - want).abs().max())
+    assert err <= rel * scale, (err, scale)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 16), (200, 72, 50), (1, 1, 1), (513, 259, 131), (64, 300, 7)])
+def test_bgemm_nt_nn_tn_layouts(M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    a, b = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g)
+    want = a.double() @ b.double()
+    bias = torch.randn(N, generator=g)
+    # NT: A (M, K) k-contiguous, B stored (N, K)
+    c = torch.empty(M, N, device=DEV)
+    bgemm(dict(M=M, N=N, K=K, sAm=K, sAk=1, sBk=1, sBn=K, ldc=N), a.to(DEV), b.t().contiguous().to(DEV), c, bias.to(DEV))
+    close(c, want + bias.double())
+    # NN: B stored (K, N)
+    c = torch.full((M, N), 3.0, device=DEV)
+    bgemm(dict(M=M, N=N, K=K, sAm=K, sAk=1, sBk=N, sBn=1, ldc=N, alpha=0.5, beta=2.0), a.to(DEV), b.to(DEV), c)
+    close(c, 0.5 * want + 6.0)
+    # TN: A stored (K, M), B stored (K, N), split-K
+    for sk in (1, 3):
+        c = torch.empty(M, N, device=DEV)
+        bgemm(dict(M=M, N=N, K=K, sAm=1, sAk=M, sBk=N, sBn=1, ldc=N, splitk=sk), a.t().contiguous().to(DEV), b.to(DEV), c)
+        close(c, want)
+
+
+def test_bgemm_batched_attention_shapes():
+    """S = Q K^T and O = P V straight out of / into the (B*S, 3H) / (B*S, H) projections' layout, and the TN products of
+    the attention backward (dV = P^T dO, dK = dS^T Q)."""
+    B, S, H, heads = 3, 37, 64, 2
+    d = H // heads
+    g = torch.Generator().manual_seed(5)
+    qkv = torch.randn(B * S, 3 * H, generator=g)
+    q, k, v = (t.view(B, S, heads, d).transpose(1, 2) for t in qkv.view(B, S, 3 * H).split(H, dim=-1))
+    scores = torch.empty(B, heads, S, S, device=DEV)
+    dq = qkv.to(DEV)
+    bgemm(dict(M=S, N=S, K=d, sAm=3 * H, sAk=1, sBk=1, sBn=3 * H, ldc=S, nb1=B, nb2=heads, sA1=S * 3 * H, sA2=d,
+               sB1=S * 3 * H, sB2=d, sC1=heads * S * S, sC2=S * S, alpha=0.25), dq, dq[:, H:], scores)
+    close(scores, 0.25 * (q.double() @ k.double().transpose(-1, -2)))
+    P = torch.softmax(torch.randn(B, heads, S, S, generator=g), dim=-1)
+    o = torch.empty(B * S, H, device=DEV)
+    bgemm(dict(M=S, N=d, K=S, sAm=S, sAk=1, sBk=3 * H, sBn=1, ldc=H, nb1=B, nb2=heads, sA1=heads * S * S, sA2=S * S,
+               sB1=S * 3 * H, sB2=d, sC1=S * H, sC2=d), P.to(DEV), dq[:, 2 * H:], o)
+    close(o, (P.double() @ v.double()).transpose(1, 2).reshape(B * S, H))
+    do = torch.randn(B * S, H, generator=g)
+    dqkv = torch.zeros(B * S, 3 * H, device=DEV)
+    bgemm(dict(M=S, N=d, K=S, sAm=1, sAk=S, sBk=H, sBn=1, ldc=3 * H, nb1=B, nb2=heads, sA1=heads * S * S, sA2=S * S,
+               sB1=S * H, sB2=d, sC1=S * 3 * H, sC2=d), P.to(DEV), do.to(DEV), dqkv[:, 2 * H:])
+    dov = do.view(B, S, heads, d).transpose(1, 2).double()
+    want_dv = (P.double().transpose(-1, -2) @ dov).transpose(1, 2).reshape(B * S, H)
+    close(dqkv[:, 2 * H:], want_dv)
+    assert not dqkv[:, :2 * H].any()
+
+
+@pytest.mark.parametrize("taps,Cin,N,S,B", [(9, 32, 48, 40, 3), (3, 20, 17, 11, 2), (1, 16, 16, 8, 2), (5, 64, 130, 150, 2)])
+def test_bgemm_conv_dgrad_and_wgrad(taps, Cin, N, S, B):
+    """The implicit-conv forms against autograd of F.conv1d(padding='same') over (B, C, S)."""
+    g = torch.Generator().manual_seed(taps * 100 + Cin)
+    x = torch.randn(B, S, Cin, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(N, Cin, taps, generator=g, dtype=torch.float64, requires_grad=True)
+    y = F.conv1d(x.transpose(1, 2), w, padding="same").transpose(1, 2)  # (B, S, N)
+    dy = torch.randn(B, S, N, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    pad = (taps - 1) // 2
+    w_tm = w.detach().permute(0, 2, 1).reshape(N, taps * Cin).float().contiguous().to(DEV)  # tap-major rows, as the engine holds them
+    dyd = dy.float().reshape(B * S, N).contiguous().to(DEV)
+    xd = x.detach().float().reshape(B * S, Cin).contiguous().to(DEV)
+    dx = torch.empty(B * S, Cin, device=DEV)
+    bgemm(dict(M=B * S, N=Cin, K=taps * N, sAm=N, sAk=1, sBk=taps * Cin, sBn=1, ldc=Cin, seg=S, taps=taps, Kin=N,
+               a_shift0=pad, a_shift_step=-1, sBtap=Cin), dyd, w_tm, dx)
+    close(dx, x.grad.reshape(B * S, Cin))
+    for sk in (1, 4):
+        dw = torch.zeros(N, taps * Cin, device=DEV)
+        bgemm(dict(M=N, N=Cin, K=B * S, sAm=1, sAk=N, sBk=Cin, sBn=1, ldc=taps * Cin, nb2=taps, sC2=Cin, seg=S,
+                   b_shift0=-pad, b_shift_step=1, splitk=sk), dyd, xd, dw)
+        close(dw, w.grad.permute(0, 2, 1).reshape(N, taps * Cin))
+
+
+@pytest.mark.parametrize("M,H,res", [(100, 256, True), (7, 48, False), (257, 768, True), (64, 1024, False)])
+def test_layernorm_bwd(M, H, res):
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + H)
+    z = torch.randn(M, H, generator=g, dtype=torch.float64, requires_grad=True)
+    r = torch.randn(M, H, generator=g, dtype=torch.float64) if res else None
+    gam = torch.randn(H, generator=g, dtype=torch.float64, requires_grad=True)
+    bet = torch.randn(H, generator=g, dtype=torch.float64, requires_grad=True)
+    dy = torch.randn(M, H, generator=g, dtype=torch.float64)
+    F.layer_norm(z + r if res else z, (H,), gam, bet, 1e-5).backward(dy)
+    nparts = lib.fs2_op_layernorm_bwd_parts(M)
+    dz = torch.empty(M, H, device=DEV)
+    part = torch.empty(nparts, 2, H, device=DEV)
+    zd, rd, dyd, gd = z.detach().float().to(DEV), r.float().to(DEV) if res else None, dy.float().to(DEV), gam.detach().float().to(DEV)
+    _lib.check(lib.fs2_op_layernorm_bwd(F32, p(zd), p(rd), p(dyd), p(gd), p(dz), p(part), M, H, st()))
+    close(dz, z.grad, 2e-5)
+    out = torch.full((1, 2 * H), 1.0, device=DEV)
+    ws = torch.empty(max(1, lib.fs2_op_col_sum_ws_bytes(nparts, 2 * H, 0) // 4), device=DEV)
+    _lib.check(lib.fs2_op_col_sum(p(part), p(out), p(ws), nparts, 2 * H, 2 * H, 0, 1, 1.0, st()))
+    close(out[0, :H] - 1.0, gam.grad, 2e-5)
+    close(out[0, H:] - 1.0, bet.grad, 2e-5)
+
+
+def test_col_sum_segments():
+    lib = _lib.load()
+    x = torch.randn(6 * 700, 100)
+    out = torch.empty(6, 100, device=DEV)
+    ws = torch.empty(lib.fs2_op_col_sum_ws_bytes(6 * 700, 100, 700) // 4, device=DEV)
+    xd = x.to(DEV)
+    _lib.check(lib.fs2_op_col_sum(p(xd), p(out), p(ws), 6 * 700, 100, 100, 700, 0, 0.5, st()))
+    close(out, 0.5 * x.double().view(6, 700, 100).sum(1), 1e-5)
+
+
+@pytest.mark.parametrize("B,heads,S", [(2, 2, 37), (1, 1, 1), (3, 2, 200)])
+def test_softmax_fwd_bwd(B, heads, S):
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(S)
+    s = torch.randn(B, heads, S, S, generator=g, dtype=torch.float64, requires_grad=True)
+    lens = torch.randint(1, S + 1, (B,), generator=g)
+    pad = torch.arange(S)[None, :] >= lens[:, None]
+    pr = torch.softmax((0.3 * s).masked_fill(pad[:, None, None, :], float("-inf")), dim=-1)
+    dp = torch.randn(B, heads, S, S, generator=g, dtype=torch.float64)
+    pr.backward(dp)
+    sd = s.detach().float().to(DEV)
+    padd = pad.to(torch.uint8).to(DEV)
+    _lib.check(lib.fs2_op_softmax_fwd(F32, p(sd), p(padd), B, heads, S, 0.3, st()))
+    close(sd, pr.detach(), 1e-5)
+    dd = dp.float().to(DEV)
+    _lib.check(lib.fs2_op_softmax_bwd(F32, p(dd), p(sd), B, heads, S, 0.3, st()))
+    close(dd, s.grad, 2e-5)
+
+
+def test_scatter_rows_and_regulate_bwd():
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(3)
+    R, H, V = 3000, 72, 40
+    idx = torch.randint(0, V, (R,), generator=g)
+    x = torch.randn(R, H, generator=g)
+    for kind in ("i32", "i64"):
+        table = torch.ones(V, H, device=DEV)
+        i32 = idx.int().to(DEV) if kind == "i32" else None
+        i64 = idx.to(DEV) if kind == "i64" else None
+        xd = x.to(DEV)
+        _lib.check(lib.fs2_op_scatter_rows(p(xd), p(i32), p(i64), p(table), R, H, V, 0, st()))
+        want = torch.ones(V, H, dtype=torch.float64).index_add_(0, idx, x.double())
+        want[0] = 1.0
+        close(table, want, 1e-5)
+    B, L, T, H = 3, 9, 31, 40
+    dur = torch.randint(0, 6, (B, L), generator=g)
+    dur[0, :] = 5  # 45 frames > T: truncated
+    cum = dur.cumsum(1).int()
+    dy = torch.randn(B * T, H, generator=g)
+    dx = torch.empty(B * L, H, device=DEV)
+    dyd, cumd = dy.to(DEV), cum.to(DEV)
+    _lib.check(lib.fs2_op_regulate_bwd(p(dyd), p(cumd), p(dx), B, L, T, H, st()))
+    want = torch.zeros(B, L, H, dtype=torch.float64)
+    for b in range(B):
+        t = 0
+        for ph in range(L):
+            for _ in range(int(dur[b, ph])):
+                if t < T:
+                    want[b, ph] += dy[b * T + t].double()
+                t += 1
+    close(dx, want.view(B * L, H), 1e-5)
+
+
+@pytest.mark.parametrize("kind,inner", [(0, 80), (1, 1)])
+def test_masked_loss_bwd(kind, inner):
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(kind)
+    rows = 500
+    pred = torch.randn(rows, inner, generator=g, dtype=torch.float64, requires_grad=True)
+    truth = torch.randn(rows, inner, generator=g, dtype=torch.float64)
+    mask = torch.rand(rows, generator=g) < 0.3
+    sel = ~mask
+    loss = (pred[sel] - truth[sel]).abs().mean() if kind == 0 else ((pred[sel] - truth[sel]) ** 2).mean()
+    (1.7 * loss).backward()
+    ws = torch.zeros(lib.fs2_op_masked_loss_ws_bytes(), dtype=torch.uint8, device=DEV)
+    stat = torch.empty(2, device=DEV)
+    pd, td, md = pred.detach().float().to(DEV), truth.float().to(DEV), mask.to(torch.uint8).to(DEV)
+    _lib.check(lib.fs2_op_masked_loss(p(pd), p(td), 0, p(md), rows, inner, kind, p(ws), p(stat), st()))
+    dpred = torch.empty(rows, inner, device=DEV)
+    _lib.check(lib.fs2_op_masked_loss_bwd(p(pd), p(td), 0, p(md), p(stat), p(dpred), rows, inner, kind, 1.7, st()))
+    close(dpred, pred.grad, 1e-5)
+
+
+def test_adamw_matches_torch_with_clipping():
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(11)
+    n = 10000
+    w = torch.randn(n, generator=g)
+    ref = torch.nn.Parameter(w.clone().double())
+    opt = torch.optim.AdamW([ref], lr=2e-4, betas=(0.9, 0.98), eps=1e-8, weight_decay=0.01)
+    wd, m, v = w.to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    ws = torch.empty(lib.fs2_op_sum_sq_ws_bytes(n) // 4, device=DEV)
+    nsq = torch.empty(1, device=DEV)
+    for step in range(1, 4):
+        grad = torch.randn(n, generator=g) * (3.0 if step == 2 else 0.001)  # step 2 clips, the others do not
+        ref.grad = grad.double().clone()
+        torch.nn.utils.clip_grad_norm_([ref], 1.0)
+        opt.step()
+        gd = grad.to(DEV)
+        _lib.check(lib.fs2_op_sum_sq(p(gd), n, p(ws), p(nsq), st()))
+        assert abs(float(nsq) - float((grad.double() ** 2).sum())) <= 1e-5 * float((grad.double() ** 2).sum())
+        _lib.check(lib.fs2_op_adamw(p(wd), p(gd), p(m), p(v), n, 2e-4, 0.9, 0.98, 1e-8, 0.01, step, p(nsq), 1.0, 1.0, st()))
+        close(wd, ref.detach(), 1e-6)
+
+
+def test_ew_ops():
+    lib = _lib.load()
+    a, b = torch.randn(5000), torch.randn(5000)
+    out = torch.empty(5000, device=DEV)
+    ad, bd = a.to(DEV), b.to(DEV)
+    _lib.check(lib.fs2_op_ew(0, p(ad), p(bd), p(out), 5000, 2.0, -1.0, st()))
+    assert torch.equal(out.cpu(), 2.0 * a - b)
+    _lib.check(lib.fs2_op_ew(1, p(ad), p(bd), p(out), 5000, 0.0, 0.0, st()))
+    assert torch.equal(out.cpu(), torch.where(b > 0, a, torch.zeros(())))

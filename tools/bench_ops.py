@@ -47,6 +47,19 @@ def gemm_case(name, M, N, Cin, taps, S, reps, variant):
     fl = 2.0 * M * N * Cin * taps
     print(f"{name:28s} M={M:6d} N={N:5d} K={taps*Cin:5d} variant={variant}  {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TF  ({fl/t/2.5e15*100:4.1f}% of 2.5 PF)")
     lib.fs2_op_set_gemm_variant(0)
+    if taps == 1 and os.environ.get("FS2_BENCH_BLASLT"):  # the vendor library on the same operands: a yardstick, not a product path
+        wt = w
+        for _ in range(3):
+            torch.nn.functional.linear(x, wt)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            torch.nn.functional.linear(x, wt)
+        e1.record()
+        torch.cuda.synchronize()
+        tl = e0.elapsed_time(e1) / reps * 1e-3
+        print(f"{'  (hipBLASLt via torch, no bias)':28s} {'':40s} {tl*1e6:8.1f} us  {fl/tl/1e12:7.1f} TF")
 
 
 def gemm_ln_case(name, M, N, Cin, taps, S, reps, variant, res=True, relu=False):
@@ -140,6 +153,13 @@ def main():
             gemm_case("c3 pw1", 49152, 3072, 768, 1, 49152, a.reps, v)
             gemm_case("c3 conv2", 49152, 768, 3072, 1, 49152, a.reps, v)
             gemm_case("c3 out_proj", 49152, 768, 768, 1, 49152, a.reps, v)
+            gemm_case("c5 in_proj", 12288, 3072, 1024, 1, 12288, a.reps, v)
+            gemm_case("c5 pw1", 12288, 4096, 1024, 1, 12288, a.reps, v)
+            gemm_case("c5 conv2", 12288, 1024, 4096, 1, 12288, a.reps, v)
+            gemm_case("c5 out_proj", 12288, 1024, 1024, 1, 12288, a.reps, v)
+            gemm_case("c5 conv1 k=9", 12288, 4096, 1024, 9, 1536, a.reps, v)
+            gemm_case("c5 conv1 as plain GEMM", 12288, 4096, 9216, 1, 12288, a.reps, v)
+            gemm_case("square 4096^3", 4096, 4096, 4096, 1, 4096, a.reps, v)
     if a.what in ("wide",):  # rows wider than one tile (C3 N = 768, C5 N = 1024): fused in-place LayerNorm vs GEMM + LayerNorm launches
         for knob in (300, 301):
             lib.fs2_op_set_gemm_variant(knob)

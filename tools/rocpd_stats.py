@@ -6,6 +6,23 @@ import sqlite3
 import sys
 
 
+def by_grid(db, title=""):
+    """One row per (kernel, grid) - the launch classes of a forward, for configs whose step is many shapes of one kernel."""
+    con = sqlite3.connect(db)
+    cols = [r[1] for r in con.execute("pragma table_info(kernels)")]
+    g = [c for c in ("grid_x", "grid_y", "grid_z", "grid_size_x", "grid_size_y", "grid_size_z") if c in cols][:3]
+    rows = con.execute(f"select name, {', '.join(g)}, count(*), sum(end-start), avg(end-start), min(end-start) from kernels "
+                       f"group by name, {', '.join(g)} order by {len(g) + 3} desc").fetchall()
+    tot = sum(r[len(g) + 2] for r in rows)
+    print(f"# {title or db} (by launch class)\n")
+    print("| kernel | grid | calls | total ms | avg us | min us | % |")
+    print("|---|---|---|---|---|---|---|")
+    for r in rows[:40]:
+        n = re.sub(r"fs2::", "", r[0])[:90]
+        c, s_, a, mn = r[len(g) + 1:]
+        print(f"| `{n}` | {'x'.join(str(x) for x in r[1:len(g) + 1])} | {c} | {s_ / 1e6:.3f} | {a / 1e3:.1f} | {mn / 1e3:.1f} | {100 * s_ / tot:.1f} |")
+
+
 def main(db, title=""):
     con = sqlite3.connect(db)
     rows = con.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start), "
@@ -22,4 +39,7 @@ def main(db, title=""):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], " ".join(sys.argv[2:]))
+    if sys.argv[1] == "--by-grid":
+        by_grid(sys.argv[2], " ".join(sys.argv[3:]))
+    else:
+        main(sys.argv[1], " ".join(sys.argv[2:]))
