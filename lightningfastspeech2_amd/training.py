@@ -1,0 +1,465 @@
+"""Host mirror of the reference's training step:
+
+    FastSpeech2.training_step (litfass/fastspeech2/fastspeech2.py:786-797):  result = self(batch); losses = self.loss(result, batch)
+    -> loss.backward() (Lightning) -> clip_grad_norm_(gradient_clip_val, scripts/train.sh:16)
+    -> torch.optim.AdamW(lr, betas=[0.9, 0.98], eps=1e-8, weight_decay=0.01) + NoamLR (fastspeech2.py:1166-1182, noam.py:4-25)
+
+built on the HIP operators behind the C ABI (include/fs2.h, "Training step" section): the teacher-forced forward keeps
+every tensor the backward needs in HBM (288 GB: nothing is recomputed, the attention probabilities are materialised),
+the backward is a hand-written tape over fs2_op_bgemm / fs2_op_layernorm_bwd / fs2_op_softmax_bwd / ..., parameters,
+gradients and both Adam moments live in ONE flat fp32 buffer each so the optimizer is a single launch and a data-parallel
+job all-reduces one contiguous gradient buffer.  torch supplies device memory and streams only; there is no autograd and
+no CPU path - without libfs2_hip.so the constructor raises.
+
+Covered: the dense-convolution architecture family (C1/C2/C5 of BASELINE.json and the test-size configs), frame-level
+'none' variances, 'l1' / 'mse' losses, fp32 arithmetic (exact fp32 MFMA).  Dropout is 0 (the reference's dropouts are
+random per step and cannot be pinned; p = 0 is what the parity tests compare).  Rejected loudly: depth-wise convolutions,
+phone-level / CWT variances, priors, stochastic durations.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from collections import OrderedDict
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import Fs2Config
+from .weights import state_dict_spec
+
+F32 = _lib.FS2_F32
+_KIND = {"l1": 0, "mse": 1}
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class _Ops:
+    """Thin typed wrappers: torch tensors in, C ABI launches on torch's current stream."""
+
+    def __init__(self, device):
+        self.lib = _lib.load()
+        self.dev = torch.device(device)
+        if self.dev.type != "cuda":
+            raise RuntimeError("the training step runs on the GPU (no CPU path)")
+        self._ws: Dict[str, torch.Tensor] = {}
+
+    def st(self):
+        return C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def empty(self, *shape, dtype=torch.float32):
+        return torch.empty(*shape, dtype=dtype, device=self.dev)
+
+    def ws(self, key: str, nbytes: int) -> Optional[torch.Tensor]:
+        if nbytes <= 0:
+            return None
+        t = self._ws.get(key)
+        if t is None or t.numel() * 4 < nbytes:
+            t = self.empty((nbytes + 3) // 4)
+            self._ws[key] = t
+        return t
+
+    def ck(self, status, what):
+        _lib.check(status, None, what)
+
+    # ---- forward operators (the inference path's own launches, fp32) ----
+    def gemm(self, x, w, bias, M, N, Cin, taps=1, S=None, relu=False):
+        y = self.empty(M, N)
+        self.ck(self.lib.fs2_op_gemm(F32, F32, _p(x), _p(w), _p(bias), _p(y), M, N, Cin, taps, S or M, int(relu), self.st()), "gemm")
+        return y
+
+    def layernorm(self, x, res, g, b, M, H, dot_w=None, dot_b=0.0, mask=None, want_y=True):
+        y = self.empty(M, H) if want_y else None
+        pred = self.empty(M) if dot_w is not None else None
+        self.ck(self.lib.fs2_op_layernorm(F32, _p(x), _p(res), _p(g), _p(b), _p(y), _p(dot_w), C.c_float(dot_b), _p(mask),
+                                          _p(pred), M, H, self.st()), "layernorm")
+        return y, pred
+
+    # ---- backward operators ----
+    def bgemm(self, A, B, Cout, bias=None, **kw):
+        d = _lib.BGemmDescC()
+        base = dict(nb1=1, nb2=1, alpha=1.0, beta=0.0, splitk=1, taps=1)
+        base.update(kw)
+        for k, v in base.items():
+            setattr(d, k, v)
+        ws = self.ws("bgemm", int(self.lib.fs2_op_bgemm_ws_bytes(C.byref(d))))
+        self.ck(self.lib.fs2_op_bgemm(F32, C.byref(d), _p(A), _p(B), _p(Cout), _p(bias), _p(ws), self.st()), "bgemm")
+        return Cout
+
+    def col_sum(self, x, out, M, N, seg=0, accumulate=True, scale=1.0, ldx=None):
+        ws = self.ws("colsum", int(self.lib.fs2_op_col_sum_ws_bytes(M, N, seg)))
+        self.ck(self.lib.fs2_op_col_sum(_p(x), _p(out), _p(ws), M, N, ldx or N, seg, int(accumulate), C.c_float(scale), self.st()), "col_sum")
+
+    def relu_bwd(self, dy, y):
+        """in place: dy *= (y > 0)"""
+        self.ck(self.lib.fs2_op_ew(1, _p(dy), _p(y), _p(dy), dy.numel(), C.c_float(0), C.c_float(0), self.st()), "relu_bwd")
+        return dy
+
+    def add_(self, a, b):
+        self.ck(self.lib.fs2_op_ew(0, _p(a), _p(b), _p(a), a.numel(), C.c_float(1), C.c_float(1), self.st()), "add")
+        return a
+
+    # y = x W^T + b backward pieces.  w is (N, taps*Cin) tap-major; x (M, Cin); dy (M, N); rows in utterances of S.
+    def dgrad(self, dy, w, M, N, Cin, taps=1, S=None, out=None, accumulate=False):
+        dx = out if out is not None else self.empty(M, Cin)
+        beta = 1.0 if accumulate else 0.0
+        if taps == 1:
+            return self.bgemm(dy, w, dx, M=M, N=Cin, K=N, sAm=N, sAk=1, sBk=Cin, sBn=1, ldc=Cin, beta=beta)
+        pad = (taps - 1) // 2
+        return self.bgemm(dy, w, dx, M=M, N=Cin, K=taps * N, sAm=N, sAk=1, sBk=taps * Cin, sBn=1, ldc=Cin, seg=S or M,
+                          taps=taps, Kin=N, a_shift0=pad, a_shift_step=-1, sBtap=Cin, beta=beta)
+
+    def wgrad(self, dy, x, dw, db, M, N, Cin, taps=1, S=None):
+        """dw (N, taps*Cin) += dy^T x (per tap, rows shifted inside their utterance); db (N) += column sums of dy."""
+        pad = (taps - 1) // 2
+        tiles = ((N + 127) // 128) * ((Cin + 127) // 128) * taps
+        splitk = max(1, min(64, 512 // tiles, M // 2048))
+        self.bgemm(dy, x, dw, M=N, N=Cin, K=M, sAm=1, sAk=N, sBk=Cin, sBn=1, ldc=taps * Cin, nb2=taps, sC2=Cin,
+                   seg=(S or M) if taps > 1 else 0, b_shift0=-pad, b_shift_step=1, splitk=splitk, beta=1.0)
+        if db is not None:
+            self.col_sum(dy, db, M, N)
+
+
+class Trainer:
+    """One process per GPU.  ``training_step(batch)`` = teacher-forced forward + losses + backward into the flat gradient
+    buffer (accumulating, as Lightning's accumulate_grad_batches does); ``optimizer_step()`` = clip + AdamW + Noam."""
+
+    def __init__(self, cfg: Fs2Config, state_dict, *, lr=2e-4, warmup_steps=4000, betas=(0.9, 0.98), eps=1e-8,
+                 weight_decay=0.01, gradient_clip_val: Optional[float] = 1.0, variance_losses=None, mel_loss="l1",
+                 duration_loss="mse", loss_alphas=None, device="cuda:0"):
+        if cfg.encoder_depthwise_conv or cfg.decoder_depthwise_conv or cfg.variance_depthwise_conv or cfg.duration_depthwise_conv:
+            raise NotImplementedError("training step: depth-wise convolution variants are not built yet (dense family only)")
+        if any(l != "frame" for l in cfg.variance_levels[:len(cfg.variances)]) or any(cfg.is_cwt(i) for i in range(len(cfg.variances))):
+            raise NotImplementedError("training step: frame-level 'none' variances only")
+        if cfg.priors:
+            raise NotImplementedError("training step: priors are not built")
+        self.cfg = cfg
+        self.ops = _Ops(device)
+        self.dev = self.ops.dev
+        self.lr, self.warmup_steps, self.betas, self.eps, self.weight_decay = lr, warmup_steps, betas, eps, weight_decay
+        self.gradient_clip_val = gradient_clip_val
+        self.variance_losses = list(variance_losses) if variance_losses is not None else ["mse"] * len(cfg.variances)
+        self.mel_loss, self.duration_loss = mel_loss, duration_loss
+        self.loss_alphas = dict(loss_alphas) if loss_alphas is not None else {
+            "mel": 1.0, "pitch": 1e-1, "energy": 1e-1, "snr": 1e-1, "duration": 1e-4}
+        for k in self.variance_losses + [mel_loss, duration_loss]:
+            if k not in _KIND:
+                raise NotImplementedError(f"training step: loss kind {k!r} has no gradient kernel ('l1' / 'mse' only)")
+        # ---- flat parameter / gradient / moment buffers, named views in KERNEL layout (conv weights tap-major) ----
+        spec = state_dict_spec(cfg)
+        self._layout: "OrderedDict[str, tuple]" = OrderedDict()   # name -> (offset, kernel shape, reference shape)
+        off = 0
+        for name, shape in spec.items():
+            if name == "positional_encoding.pe" or name.endswith(".bins"):
+                continue
+            kshape = (shape[0], shape[2] * shape[1]) if len(shape) == 3 else tuple(shape)
+            n = int(np.prod(shape))
+            self._layout[name] = (off, kshape, tuple(shape))
+            off += (n + 3) // 4 * 4  # every tensor starts on a 16-byte boundary
+        self.n_flat = off
+        self.flat_p = torch.zeros(off, device=self.dev)
+        self.flat_g = torch.zeros(off, device=self.dev)
+        self.flat_m = torch.zeros(off, device=self.dev)
+        self.flat_v = torch.zeros(off, device=self.dev)
+        self.P = {n: self.flat_p[o:o + int(np.prod(ks))].view(ks) for n, (o, ks, _) in self._layout.items()}
+        self.G = {n: self.flat_g[o:o + int(np.prod(ks))].view(ks) for n, (o, ks, _) in self._layout.items()}
+        self.buffers: Dict[str, torch.Tensor] = {}
+        self.load_state_dict(state_dict)
+        self.steps = 0          # optimizer steps taken
+        self._accum = 0         # micro-batches in the gradient buffer
+        self._loss_ws = torch.zeros(int(self.ops.lib.fs2_op_masked_loss_ws_bytes()), dtype=torch.uint8, device=self.dev)
+        self._nsq = torch.zeros(1, device=self.dev)
+        self._nsq_ws = self.ops.empty(int(self.ops.lib.fs2_op_sum_sq_ws_bytes(off)) // 4 + 1)
+
+    # ---- state ----
+    def load_state_dict(self, sd):
+        for name, (o, ks, rs) in self._layout.items():
+            v = sd[name]
+            t = torch.as_tensor(np.asarray(v) if not isinstance(v, torch.Tensor) else v).to(torch.float32)
+            if tuple(t.shape) != rs:
+                raise ValueError(f"{name}: shape {tuple(t.shape)} != {rs}")
+            if len(rs) == 3:
+                t = t.permute(0, 2, 1).reshape(ks)
+            self.P[name].copy_(t.contiguous())
+        for name in state_dict_spec(self.cfg):
+            if name == "positional_encoding.pe" or name.endswith(".bins"):
+                v = sd[name]
+                t = torch.as_tensor(np.asarray(v) if not isinstance(v, torch.Tensor) else v).to(torch.float32)
+                self.buffers[name] = t.reshape(-1, t.shape[-1]).contiguous().to(self.dev) if name.endswith(".pe") else t.contiguous().to(self.dev)
+
+    def _to_ref_layout(self, name, t):
+        _, ks, rs = self._layout[name]
+        t = t.detach().cpu()
+        if len(rs) == 3:
+            t = t.view(rs[0], rs[2], rs[1]).permute(0, 2, 1)
+        return t.reshape(rs).contiguous()
+
+    def state_dict(self):
+        """Reference key names and layouts (feeds FastSpeech2(...) of this package or the reference's load_state_dict)."""
+        out = OrderedDict((n, self._to_ref_layout(n, self.P[n])) for n in self._layout)
+        for n, b in self.buffers.items():
+            out[n] = b.cpu().reshape(1, *b.shape) if n.endswith(".pe") else b.cpu()
+        return out
+
+    def gradients(self):
+        return OrderedDict((n, self._to_ref_layout(n, self.G[n])) for n in self._layout)
+
+    def zero_grad(self):
+        self.flat_g.zero_()
+        self._accum = 0
+
+    def current_lr(self) -> float:
+        """NoamLR.get_lr (noam.py:19-25) for the optimizer step about to be taken: last_epoch = steps taken so far."""
+        e = max(1, self.steps)
+        return self.lr * self.warmup_steps ** 0.5 * min(e ** -0.5, e * self.warmup_steps ** -1.5)
+
+    # ---- forward / backward of one ConformerEncoderLayer (model.py:65-122, post-norm) ----
+    def _layer_fwd(self, x, prefix, B, S, heads, F_, k, key_pad):
+        o, P, H = self.ops, self.P, self.cfg.hidden
+        M, d = B * S, H // heads
+        t = {"x": x}
+        qkv = o.gemm(x, P[f"{prefix}.self_attn.in_proj_weight"], P[f"{prefix}.self_attn.in_proj_bias"], M, 3 * H, H)
+        prob = o.empty(B, heads, S, S)
+        o.bgemm(qkv, qkv[:, H:], prob, M=S, N=S, K=d, sAm=3 * H, sAk=1, sBk=1, sBn=3 * H, ldc=S, nb1=B, nb2=heads,
+                sA1=S * 3 * H, sA2=d, sB1=S * 3 * H, sB2=d, sC1=heads * S * S, sC2=S * S)
+        scale = 1.0 / math.sqrt(d)
+        o.ck(o.lib.fs2_op_softmax_fwd(F32, _p(prob), _p(key_pad), B, heads, S, C.c_float(scale), o.st()), "softmax")
+        attn = o.empty(M, H)
+        o.bgemm(prob, qkv[:, 2 * H:], attn, M=S, N=d, K=S, sAm=S, sAk=1, sBk=3 * H, sBn=1, ldc=H, nb1=B, nb2=heads,
+                sA1=heads * S * S, sA2=S * S, sB1=S * 3 * H, sB2=d, sC1=S * H, sC2=d)
+        proj = o.gemm(attn, P[f"{prefix}.self_attn.out_proj.weight"], P[f"{prefix}.self_attn.out_proj.bias"], M, H, H)
+        x1, _ = o.layernorm(proj, x, P[f"{prefix}.norm1.weight"], P[f"{prefix}.norm1.bias"], M, H)
+        h = o.gemm(x1, P[f"{prefix}.conv1.weight"], P[f"{prefix}.conv1.bias"], M, F_, H, taps=k, S=S, relu=True)
+        c2 = o.gemm(h, P[f"{prefix}.conv2.weight"], P[f"{prefix}.conv2.bias"], M, H, F_)
+        x2, _ = o.layernorm(c2, x1, P[f"{prefix}.norm2.weight"], P[f"{prefix}.norm2.bias"], M, H)
+        t.update(qkv=qkv, prob=prob, attn=attn, proj=proj, x1=x1, h=h, c2=c2, scale=scale)
+        return x2, t
+
+    def _ln_bwd(self, z, res, dy, gname, bname, M, H):
+        o = self.ops
+        nparts = int(o.lib.fs2_op_layernorm_bwd_parts(M))
+        dz, part = o.empty(M, H), o.empty(nparts, 2 * H)
+        o.ck(o.lib.fs2_op_layernorm_bwd(F32, _p(z), _p(res), _p(dy), _p(self.P[gname]), _p(dz), _p(part), M, H, o.st()), "layernorm_bwd")
+        o.col_sum(part, self.G[gname], nparts, H, ldx=2 * H)
+        o.col_sum(part[:, H:], self.G[bname], nparts, H, ldx=2 * H)
+        return dz
+
+    def _layer_bwd(self, dx2, t, prefix, B, S, heads, F_, k):
+        o, P, G, H = self.ops, self.P, self.G, self.cfg.hidden
+        M, d = B * S, H // heads
+        dx1 = self._ln_bwd(t["c2"], t["x1"], dx2, f"{prefix}.norm2.weight", f"{prefix}.norm2.bias", M, H)  # = dc2 too
+        o.wgrad(dx1, t["h"], G[f"{prefix}.conv2.weight"], G[f"{prefix}.conv2.bias"], M, H, F_)
+        dh = o.relu_bwd(o.dgrad(dx1, P[f"{prefix}.conv2.weight"], M, H, F_), t["h"])
+        o.wgrad(dh, t["x1"], G[f"{prefix}.conv1.weight"], G[f"{prefix}.conv1.bias"], M, F_, H, taps=k, S=S)
+        o.dgrad(dh, P[f"{prefix}.conv1.weight"], M, F_, H, taps=k, S=S, out=dx1, accumulate=True)
+        dx = self._ln_bwd(t["proj"], t["x"], dx1, f"{prefix}.norm1.weight", f"{prefix}.norm1.bias", M, H)  # = dproj too
+        o.wgrad(dx, t["attn"], G[f"{prefix}.self_attn.out_proj.weight"], G[f"{prefix}.self_attn.out_proj.bias"], M, H, H)
+        dattn = o.dgrad(dx, P[f"{prefix}.self_attn.out_proj.weight"], M, H, H)
+        qkv, prob = t["qkv"], t["prob"]
+        dqkv = o.empty(M, 3 * H)
+        bat = dict(nb1=B, nb2=heads)
+        sP = dict(sA1=heads * S * S, sA2=S * S)
+        # dV = P^T dO
+        o.bgemm(prob, dattn, dqkv[:, 2 * H:], M=S, N=d, K=S, sAm=1, sAk=S, sBk=H, sBn=1, ldc=3 * H, sB1=S * H, sB2=d,
+                sC1=S * 3 * H, sC2=d, **bat, **sP)
+        # dP = dO V^T
+        dp = o.empty(B, heads, S, S)
+        o.bgemm(dattn, qkv[:, 2 * H:], dp, M=S, N=S, K=d, sAm=H, sAk=1, sBk=1, sBn=3 * H, ldc=S, sA1=S * H, sA2=d,
+                sB1=S * 3 * H, sB2=d, sC1=heads * S * S, sC2=S * S, **bat)
+        o.ck(o.lib.fs2_op_softmax_bwd(F32, _p(dp), _p(prob), B, heads, S, C.c_float(t["scale"]), o.st()), "softmax_bwd")
+        # dQ = dS K ; dK = dS^T Q
+        o.bgemm(dp, qkv[:, H:], dqkv, M=S, N=d, K=S, sAm=S, sAk=1, sBk=3 * H, sBn=1, ldc=3 * H, sB1=S * 3 * H, sB2=d,
+                sC1=S * 3 * H, sC2=d, **bat, **sP)
+        o.bgemm(dp, qkv, dqkv[:, H:], M=S, N=d, K=S, sAm=1, sAk=S, sBk=3 * H, sBn=1, ldc=3 * H, sB1=S * 3 * H, sB2=d,
+                sC1=S * 3 * H, sC2=d, **bat, **sP)
+        o.wgrad(dqkv, t["x"], G[f"{prefix}.self_attn.in_proj_weight"], G[f"{prefix}.self_attn.in_proj_bias"], M, 3 * H, H)
+        o.dgrad(dqkv, P[f"{prefix}.self_attn.in_proj_weight"], M, 3 * H, H, out=dx, accumulate=True)
+        return dx
+
+    # ---- VariancePredictor (model.py:482-561, dense) ----
+    def _predictor_fwd(self, x, prefix, nlayers, filt, k, B, S, mask):
+        o, P, H = self.ops, self.P, self.cfg.hidden
+        M = B * S
+        tape, y, cin = [], x, H
+        for j in range(nlayers):
+            p = f"{prefix}.layers.{j}.layers"
+            c = o.gemm(y, P[f"{p}.0.module.weight"], P[f"{p}.0.module.bias"], M, filt, cin, taps=k, S=S, relu=True)
+            last = j == nlayers - 1
+            yn, pred = o.layernorm(c, None, P[f"{p}.2.weight"], P[f"{p}.2.bias"], M, filt,
+                                   dot_w=P[f"{prefix}.linear.weight"] if last else None,
+                                   dot_b=float(P[f"{prefix}.linear.bias"][0]) if last else 0.0, mask=mask if last else None)
+            tape.append({"xin": y, "c": c, "cin": cin})
+            y, cin = yn, filt
+        return pred, {"layers": tape, "y": y}
+
+    def _predictor_bwd(self, dpred, t, prefix, nlayers, filt, k, B, S, dx_out):
+        """dpred (M) -> gradients of the predictor's parameters, and dx_out (M, H) += d/dx."""
+        o, P, G = self.ops, self.P, self.G
+        M = B * S
+        # pred = y . w + b  (masked rows carry dpred = 0 already)
+        o.bgemm(dpred, t["y"], G[f"{prefix}.linear.weight"], M=1, N=filt, K=M, sAm=1, sAk=1, sBk=filt, sBn=1, ldc=filt,
+                splitk=max(1, min(64, M // 1024)), beta=1.0)
+        o.col_sum(dpred, G[f"{prefix}.linear.bias"], M, 1)
+        dy = o.empty(M, filt)
+        o.bgemm(dpred, P[f"{prefix}.linear.weight"], dy, M=M, N=filt, K=1, sAm=1, sAk=1, sBk=filt, sBn=1, ldc=filt)
+        for j in reversed(range(nlayers)):
+            p = f"{prefix}.layers.{j}.layers"
+            lt = t["layers"][j]
+            dc = o.relu_bwd(self._ln_bwd(lt["c"], None, dy, f"{p}.2.weight", f"{p}.2.bias", M, filt), lt["c"])
+            o.wgrad(dc, lt["xin"], G[f"{p}.0.module.weight"], G[f"{p}.0.module.bias"], M, filt, lt["cin"], taps=k, S=S)
+            if j == 0:
+                o.dgrad(dc, P[f"{p}.0.module.weight"], M, filt, lt["cin"], taps=k, S=S, out=dx_out, accumulate=True)
+            else:
+                dy = o.dgrad(dc, P[f"{p}.0.module.weight"], M, filt, lt["cin"], taps=k, S=S)
+
+    def _loss(self, name, pred, truth, truth_kind, mask, rows, inner, kind, want_grad=True):
+        o = self.ops
+        stat = o.empty(2)
+        o.ck(o.lib.fs2_op_masked_loss(_p(pred), _p(truth), truth_kind, _p(mask), rows, inner, _KIND[kind], _p(self._loss_ws),
+                                      _p(stat), o.st()), "masked_loss")
+        dpred = None
+        if want_grad:
+            dpred = o.empty(rows, inner) if inner > 1 else o.empty(rows)
+            o.ck(o.lib.fs2_op_masked_loss_bwd(_p(pred), _p(truth), truth_kind, _p(mask), _p(stat), _p(dpred), rows, inner,
+                                              _KIND[kind], C.c_float(self.loss_alphas[name]), o.st()), "masked_loss_bwd")
+        return stat, dpred
+
+    # ---- the step ----
+    def training_step(self, batch: dict) -> Dict[str, torch.Tensor]:
+        """forward(targets, inference=False) + FastSpeech2Loss + backward; gradients are ADDED to the flat buffer.
+        Returns the losses as 0-dim device tensors (same keys as the reference's loss dict)."""
+        cfg, o, P, G, dev = self.cfg, self.ops, self.P, self.G, self.dev
+        H = cfg.hidden
+        phones = batch["phones"].to(dev, torch.int64).contiguous()
+        dvec = batch["speaker"].to(dev, torch.float32).contiguous()
+        dur_t = batch["duration"].to(dev, torch.int64).contiguous()
+        mel_t = batch["mel"].to(dev, torch.float32).contiguous()
+        B, L = phones.shape
+        T = int(mel_t.shape[1])
+        if tuple(dur_t.shape) != (B, L):
+            raise ValueError(f"duration must be {(B, L)}, got {tuple(dur_t.shape)}")
+        var_t = {}
+        for v in cfg.variances:
+            t = batch[f"variances_{v}"].to(dev, torch.float32).contiguous()
+            if tuple(t.shape) != (B, T):
+                raise ValueError(f"variances_{v} must be {(B, T)}, got {tuple(t.shape)}")
+            var_t[v] = t
+        pe = self.buffers["positional_encoding.pe"]
+        with torch.cuda.device(dev):
+            # ---------------- forward ----------------
+            spk = o.empty(B, H)
+            o.ck(o.lib.fs2_op_spk_proj(_p(dvec), _p(P["speaker_embedding.projection.weight"]), _p(P["speaker_embedding.projection.bias"]),
+                                       _p(spk), B, H, dvec.shape[1], o.st()), "spk_proj")
+            x = o.empty(B * L, H)
+            src_mask = o.empty(B, L, dtype=torch.uint8)
+            o.ck(o.lib.fs2_op_embed(F32, _p(phones), _p(P["phone_embedding.weight"]), _p(pe), _p(spk), _p(x), _p(src_mask), B, L, H,
+                                    cfg.n_phones, o.st()), "embed")
+            enc_t = []
+            for i in range(cfg.encoder_layers):
+                x, t = self._layer_fwd(x, f"encoder.layers.{i}", B, L, cfg.encoder_head, cfg.encoder_conv_filter_size,
+                                       cfg.encoder_kernel_sizes[i], src_mask)
+                enc_t.append(t)
+            dur_pred, dur_tape = self._predictor_fwd(x, "variance_adaptor.duration_predictor", cfg.duration_nlayers,
+                                                     cfg.duration_filter_size, cfg.duration_kernel_size, B, L, src_mask)
+            forced = dur_t.to(torch.int32)
+            dur, cum, totals, guard = (o.empty(B, L, dtype=torch.int32), o.empty(B, L, dtype=torch.int32),
+                                       o.empty(B, dtype=torch.int32), o.empty(B, dtype=torch.int32))
+            o.ck(o.lib.fs2_op_durations(_p(dur_pred), _p(src_mask), _p(forced), _p(dur), _p(cum), _p(totals), _p(guard), B, L, o.st()), "durations")
+            xr = o.empty(B * T, H)
+            tgt_mask = o.empty(B, T, dtype=torch.uint8)
+            o.ck(o.lib.fs2_op_regulate(F32, _p(x), _p(cum), _p(totals), _p(xr), _p(tgt_mask), B, L, T, H, o.st()), "regulate")
+            var_pred, var_tape, var_idx = {}, {}, {}
+            xa = xr
+            nv = len(cfg.variances)
+            for vi, v in enumerate(cfg.variances):
+                pfx = f"variance_adaptor.encoders.{v}"
+                var_pred[v], var_tape[v] = self._predictor_fwd(xa, f"{pfx}.predictor", cfg.variance_nlayers[vi], cfg.variance_filter_size,
+                                                               cfg.variance_kernel_size[vi], B, T, tgt_mask)
+                idx = o.empty(B * T, dtype=torch.int32)
+                xn = o.empty(B * T, H)
+                last = vi == nv - 1
+                st_ = cfg.stats[v]
+                o.ck(o.lib.fs2_op_bucket_embed_target(F32, _p(xa), _p(var_t[v]), _p(self.buffers[f"{pfx}.bins"]), _p(P[f"{pfx}.embedding.weight"]),
+                                                      cfg.variance_nbins, C.c_float(st_["std"]), C.c_float(st_["mean"]),
+                                                      _p(pe) if last else None, _p(spk) if last else None, _p(xn), _p(idx), B, T, H, o.st()),
+                     "bucket_embed_target")
+                var_idx[v] = idx
+                xa = xn
+            if nv == 0:
+                xn = o.empty(B * T, H)
+                o.ck(o.lib.fs2_op_bucket_embed(F32, _p(xa), None, None, None, 0, C.c_float(1), C.c_float(0), _p(pe), _p(spk), _p(xn), None,
+                                               B, T, H, o.st()), "pe_spk")
+                xa = xn
+            y = xa
+            dec_t = []
+            for i in range(cfg.decoder_layers):
+                y, t = self._layer_fwd(y, f"decoder.layers.{i}", B, T, cfg.decoder_head, cfg.decoder_conv_filter_size,
+                                       cfg.decoder_kernel_sizes[i], tgt_mask)
+                dec_t.append(t)
+            mel = o.gemm(y, P["linear.weight"], P["linear.bias"], B * T, cfg.n_mels, H)
+            # ---------------- losses + their gradients (loss.py:83-213) ----------------
+            losses = {}
+            dvar = {}
+            for v, kind in zip(cfg.variances, self.variance_losses):
+                stat, dvar[v] = self._loss(v, var_pred[v], var_t[v], 0, tgt_mask, B * T, 1, kind)
+                losses[v] = stat[0]
+            stat, dmel = self._loss("mel", mel, mel_t, 0, tgt_mask, B * T, cfg.n_mels, self.mel_loss)
+            losses["mel"] = stat[0]
+            stat, ddur = self._loss("duration", dur_pred, dur_t, 1, src_mask, B * L, 1, self.duration_loss)
+            losses["duration"] = stat[0]
+            losses["total"] = sum(v * self.loss_alphas[k] for k, v in losses.items())
+            # ---------------- backward ----------------
+            o.wgrad(dmel, y, G["linear.weight"], G["linear.bias"], B * T, cfg.n_mels, H)
+            dy = o.dgrad(dmel, P["linear.weight"], B * T, cfg.n_mels, H)
+            for i in reversed(range(cfg.decoder_layers)):
+                dy = self._layer_bwd(dy, dec_t[i], f"decoder.layers.{i}", B, T, cfg.decoder_head, cfg.decoder_conv_filter_size,
+                                     cfg.decoder_kernel_sizes[i])
+            dspk = torch.zeros(B, H, device=dev)
+            o.col_sum(dy, dspk, B * T, H, seg=T)  # decoder input = adaptor out + pe + spk (fastspeech2.py:705-718)
+            dx = dy
+            for vi in reversed(range(nv)):
+                v = cfg.variances[vi]
+                pfx = f"variance_adaptor.encoders.{v}"
+                o.ck(o.lib.fs2_op_scatter_rows(_p(dx), _p(var_idx[v]), None, _p(G[f"{pfx}.embedding.weight"]), B * T, H, cfg.variance_nbins,
+                                               -1, o.st()), "scatter_rows")
+                self._predictor_bwd(dvar[v], var_tape[v], f"{pfx}.predictor", cfg.variance_nlayers[vi], cfg.variance_filter_size,
+                                    cfg.variance_kernel_size[vi], B, T, dx)
+            dxe = o.empty(B * L, H)
+            o.ck(o.lib.fs2_op_regulate_bwd(_p(dx), _p(cum), _p(dxe), B, L, T, H, o.st()), "regulate_bwd")
+            self._predictor_bwd(ddur, dur_tape, "variance_adaptor.duration_predictor", cfg.duration_nlayers, cfg.duration_filter_size,
+                                cfg.duration_kernel_size, B, L, dxe)
+            for i in reversed(range(cfg.encoder_layers)):
+                dxe = self._layer_bwd(dxe, enc_t[i], f"encoder.layers.{i}", B, L, cfg.encoder_head, cfg.encoder_conv_filter_size,
+                                      cfg.encoder_kernel_sizes[i])
+            o.ck(o.lib.fs2_op_scatter_rows(_p(dxe), None, _p(phones), _p(G["phone_embedding.weight"]), B * L, H, cfg.n_phones, 0, o.st()),
+                 "scatter_rows")
+            o.col_sum(dxe, dspk, B * L, H, seg=L)
+            o.relu_bwd(dspk, spk)  # spk = relu(W dvec + b), model.py:137-143
+            o.wgrad(dspk, dvec, G["speaker_embedding.projection.weight"], G["speaker_embedding.projection.bias"], B, H, dvec.shape[1])
+        self._accum += 1
+        self.last = {"mel": mel.view(B, T, cfg.n_mels), "duration_prediction": dur_pred.view(B, L), "tgt_mask": tgt_mask.bool(),
+                     "src_mask": src_mask.bool(), **{f"variances_{v}": var_pred[v].view(B, T) for v in cfg.variances}}
+        return losses
+
+    def optimizer_step(self):
+        """clip_grad_norm_(gradient_clip_val) on the mean of the accumulated micro-batch gradients, AdamW, NoamLR."""
+        if self._accum == 0:
+            raise RuntimeError("optimizer_step before any training_step")
+        o = self.ops
+        lr = self.current_lr()
+        with torch.cuda.device(self.dev):
+            nsq = None
+            if self.gradient_clip_val is not None:
+                o.ck(o.lib.fs2_op_sum_sq(_p(self.flat_g), self.n_flat, _p(self._nsq_ws), _p(self._nsq), o.st()), "sum_sq")
+                nsq = self._nsq
+            o.ck(o.lib.fs2_op_adamw(_p(self.flat_p), _p(self.flat_g), _p(self.flat_m), _p(self.flat_v), self.n_flat, C.c_float(lr),
+                                    C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps), C.c_float(self.weight_decay),
+                                    self.steps + 1, _p(nsq), C.c_float(self.gradient_clip_val or 0.0), C.c_float(1.0 / self._accum), o.st()),
+                 "adamw")
+        self.steps += 1
+        self.zero_grad()
+        return lr

@@ -32,6 +32,8 @@ import torch.nn.functional as F
 
 def _t(sd, name) -> torch.Tensor:
     v = sd[name]
+    if isinstance(v, torch.Tensor) and v.requires_grad:  # oracle/train_cpu.py: leaves of the autograd restatement of the training step
+        return v
     if isinstance(v, np.ndarray):
         v = torch.from_numpy(v)
     return v.detach().to(torch.float32) if v.is_floating_point() else v

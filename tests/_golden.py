@@ -15,7 +15,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 def golden_names():
     names = sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
     # vocoder / front-end fixtures have their own tests (test_hifigan_oracle.py, test_frontend_cpu.py)
-    return [n for n in names if not n.startswith(("hifigan_", "frontend_", "loss_", "softdtw_"))]
+    return [n for n in names if not n.startswith(("hifigan_", "frontend_", "loss_", "softdtw_", "train_"))]
 
 
 def sd_digest(sd) -> str:

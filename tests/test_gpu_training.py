@@ -1,0 +1,131 @@
+"""GPU: the HIP training step (lightningfastspeech2_amd/training.py over the backward operators of include/fs2.h) against
+(a) the fixture the REAL reference produced (tests/golden/train_small.npz: losses, every parameter's gradient, the weights
+after three clipped AdamW + Noam steps) and (b) the CPU oracle (oracle/train_cpu.py) on other shapes: ragged lengths, odd
+kernel sizes, gradient accumulation.  fp32 arithmetic; tolerances: gradients 1e-4 of the tensor's largest entry
+(the chain is ~40 fp32 GEMMs deep), losses 1e-5 relative, weights 2e-5 where Adam is well conditioned."""
+import numpy as np
+import pytest
+import torch
+
+from lightningfastspeech2_amd.config import Fs2Config
+from lightningfastspeech2_amd.weights import synth_inputs, synth_state_dict
+from oracle import train_cpu
+from test_train_oracle import assert_params_close, load
+
+pytestmark = pytest.mark.gpu
+GRAD_TOL = 1e-4
+
+
+def _dev(batch):
+    return {k: torch.as_tensor(v).cuda() for k, v in batch.items()}
+
+
+def _check_grads(got, want, tol=GRAD_TOL):
+    assert sorted(got) == sorted(want)
+    worst = ("", 0.0)
+    for n, w in want.items():
+        w = torch.as_tensor(w).float()
+        err = float((got[n] - w).abs().max()) / (float(w.abs().max()) + 1e-3)
+        if err > worst[1]:
+            worst = (n, err)
+    assert worst[1] <= tol, worst
+
+
+def test_training_step_matches_reference_fixture():
+    from lightningfastspeech2_amd.training import Trainer
+    z, cfg, sd, batch, hyper = load()
+    tr = Trainer(cfg, sd, **hyper)
+    for step in (1, 2, 3):
+        losses = tr.training_step(_dev(batch))
+        if step == 1:
+            for k, v in losses.items():
+                w = float(z[f"loss_{k}"])
+                assert abs(float(v) - w) <= 1e-5 * max(1.0, abs(w)), (k, float(v), w)
+            _check_grads(tr.gradients(), {k[5:]: z[k] for k in z.files if k.startswith("grad_")})
+        norm = float(torch.sqrt((tr.flat_g.double() ** 2).sum()))
+        assert abs(norm - float(z[f"gradnorm_{step}"])) <= 2e-4 * float(z[f"gradnorm_{step}"])
+        lr = tr.optimizer_step()
+        assert abs(lr - float(z[f"lr_{step}"])) <= 1e-12
+    after = tr.state_dict()
+    for k in z.files:
+        if k.startswith("after3_"):
+            assert_params_close(z, k[7:], after[k[7:]], 2e-5)
+
+
+def _case(seed, B, L, lengths, **kw):
+    base = dict(n_phones=30, encoder_hidden=64, decoder_hidden=64, encoder_head=2, decoder_head=4, encoder_layers=1,
+                decoder_layers=2, encoder_kernel_sizes=[5], decoder_kernel_sizes=[9, 3], encoder_conv_filter_size=96,
+                decoder_conv_filter_size=160, encoder_depthwise_conv=False, decoder_depthwise_conv=False,
+                variance_filter_size=64, variance_depthwise_conv=False, variance_nlayers=[2, 1], variances=["pitch", "energy"],
+                variance_levels=["frame", "frame"], variance_transforms=["none", "none"], variance_kernel_size=[3, 5],
+                duration_filter_size=64, duration_depthwise_conv=False, duration_nlayers=2, variance_nbins=24, n_mels=20,
+                stats={"pitch": {"min": -2.0, "max": 2.5, "mean": 0.1, "std": 1.5},
+                       "energy": {"min": -3.0, "max": 3.0, "mean": 0.0, "std": 1.0}})
+    base.update(kw)
+    cfg = Fs2Config(**base)
+    sd = synth_state_dict(cfg, seed, randomize_norm=True, duration_bias=1.0)
+    inp = synth_inputs(cfg, B, L, seed=seed + 1, lengths=lengths)
+    rs = np.random.RandomState(seed + 2)
+    dur = rs.randint(0, 5, size=(B, L)).astype(np.int64)
+    for b, n in enumerate(lengths):
+        dur[b, n:] = 0
+    dur[0, 0] = max(1, dur[0, 0])
+    T = int(dur.sum(1).max())
+    batch = {"phones": inp["phones"], "speaker": inp["speaker"], "duration": dur,
+             "mel": (rs.randn(B, T, cfg.n_mels) - 1.5).astype(np.float32)}
+    for v in cfg.variances:
+        batch[f"variances_{v}"] = (1.1 * rs.randn(B, T)).astype(np.float32)
+    return cfg, sd, batch
+
+
+@pytest.mark.parametrize("seed,B,L,lengths", [(3, 4, 13, [13, 9, 5, 1]), (8, 2, 37, [37, 20])])
+def test_training_step_matches_oracle_on_ragged_batches(seed, B, L, lengths):
+    from lightningfastspeech2_amd.training import Trainer
+    cfg, sd, batch = _case(seed, B, L, lengths)
+    kw = dict(lr=1e-3, warmup_steps=2, gradient_clip_val=0.5, variance_losses=["l1", "mse"], mel_loss="mse", duration_loss="l1")
+    ref = train_cpu.OracleTrainer(cfg, sd, **kw)
+    want_l, _ = ref.training_step(batch)
+    tr = Trainer(cfg, sd, **kw)
+    got_l = tr.training_step(_dev(batch))
+    for k, w in want_l.items():
+        assert abs(float(got_l[k]) - w) <= 1e-5 * max(1.0, abs(w)), (k, float(got_l[k]), w)
+    _check_grads(tr.gradients(), ref.gradients())
+
+
+def test_gradient_accumulation_and_bit_equal_reruns():
+    """Two micro-batches accumulate as Lightning's accumulate_grad_batches does (mean of the two gradients feeds the clip
+    and AdamW); the same step twice from the same state gives bit-equal gradients (fixed-order reductions everywhere)."""
+    from lightningfastspeech2_amd.training import Trainer
+    cfg, sd, b1 = _case(21, 3, 11, [11, 6, 2])
+    _, _, b2 = _case(22, 3, 11, [11, 10, 7])
+    kw = dict(lr=1e-3, warmup_steps=2, gradient_clip_val=1.0)
+    ref = train_cpu.OracleTrainer(cfg, sd, **kw)
+    ref.training_step(b1)
+    ref.training_step(b2)
+    want = ref.gradients()
+    tr = Trainer(cfg, sd, **kw)
+    tr.training_step(_dev(b1))
+    g1 = tr.flat_g.clone()
+    tr.training_step(_dev(b2))
+    _check_grads(tr.gradients(), want)
+    ref.optimizer_step(accum=2)
+    tr.optimizer_step()
+    after = tr.state_dict()
+    for n, t in ref.sd.items():
+        if t.requires_grad:
+            g = want[n].abs()
+            solid = g > 1e-5 * max(1.0, float(g.max()))
+            d = (after[n] - t.detach().float()).abs()
+            assert float(d[solid].max()) <= 2e-5, n
+    tr2 = Trainer(cfg, sd, **kw)
+    tr2.training_step(_dev(b1))
+    assert torch.equal(tr2.flat_g, g1)
+
+
+def test_trainer_rejects_what_is_not_built():
+    from lightningfastspeech2_amd.training import Trainer
+    cfg, sd, _ = _case(1, 2, 5, [5, 3])
+    with pytest.raises(NotImplementedError):
+        Trainer(Fs2Config(**{**cfg.__dict__, "decoder_depthwise_conv": True, "decoder_conv_filter_size": 128}), sd)
+    with pytest.raises(NotImplementedError):
+        Trainer(cfg, sd, mel_loss="soft_dtw")

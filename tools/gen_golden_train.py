@@ -1,0 +1,85 @@
+#!/usr/bin/env python
+"""Golden vectors for the training step: runs the REFERENCE itself (imported from /root/reference, build
+container only) - its FastSpeech2.forward(batch) in teacher-forced mode, its FastSpeech2Loss, loss.backward(),
+torch.nn.utils.clip_grad_norm_(1.0) (scripts/train.sh:16), torch.optim.AdamW as configure_optimizers builds it
+(fastspeech2.py:1166-1173) and its own NoamLR (noam.py) - on the batch of tests/golden/teacher_small.npz plus a seeded mel
+target, dropout off (eval mode: the reference's dropouts are random per step and cannot be pinned).
+
+    python tools/gen_golden_train.py      ->  tests/golden/train_small.npz
+
+The fixture holds the batch, the losses and per-parameter gradients of step 1, and every parameter after three optimizer
+steps (lr 2e-3, warmup 4: the third step runs at a different Noam rate; every step clips, the gradient norms are stored)."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from lightningfastspeech2_amd.config import Fs2Config  # noqa: E402
+from lightningfastspeech2_amd.weights import synth_state_dict  # noqa: E402
+from tools import ref_import  # noqa: E402
+
+LR, WARMUP, CLIP = 2e-3, 4, 1.0
+
+
+def main():
+    assert ref_import.reference_available(), "needs /root/reference (build container only)"
+    ref_import._install_stubs()
+    sys.modules["pysdtw"].SoftDTW = lambda *a, **k: None
+    from litfass.fastspeech2.loss import FastSpeech2Loss
+    from litfass.fastspeech2.noam import NoamLR
+
+    z = np.load(os.path.join(ROOT, "tests", "golden", "teacher_small.npz"))
+    cfg = Fs2Config.from_json(str(z["config_json"]))
+    skw = json.loads(str(z["synth_json"]))
+    sd = synth_state_dict(cfg, skw.pop("seed"), **skw)
+    model = ref_import.build_reference_model(cfg, sd)  # eval mode: dropout off
+    B, T = z["out_mel"].shape[:2]
+    rs = np.random.RandomState(777)
+    batch = {"phones": torch.from_numpy(z["phones"]), "speaker": torch.from_numpy(z["speaker"]),
+             "duration": torch.from_numpy(z["tf_duration"]),
+             "mel": torch.from_numpy((rs.randn(B, T, cfg.n_mels) * 1.3 - 2.0).astype(np.float32))}
+    for v in cfg.variances:
+        batch[f"variances_{v}"] = torch.from_numpy(z[f"tf_variances_{v}"])
+    nv = len(cfg.variances)
+    loss = FastSpeech2Loss(variances=list(cfg.variances), variance_levels=["frame"] * nv, variance_transforms=["none"] * nv,
+                           variance_losses=["mse"] * nv, mel_loss="l1", duration_loss="mse", max_length=4096)
+    params = [p for n, p in model.named_parameters() if not n.startswith("fastdiff_linear")]
+    opt = torch.optim.AdamW(model.parameters(), lr=LR, betas=[0.9, 0.98], eps=1e-8, weight_decay=0.01)
+    sched = NoamLR(opt, WARMUP)
+    out = {"config_json": np.array(cfg.to_json()), "synth_json": z["synth_json"], "hyper_json": np.array(json.dumps(
+        dict(lr=LR, warmup_steps=WARMUP, gradient_clip_val=CLIP)))}
+    for k, v in batch.items():
+        out["in_" + k] = v.numpy()
+    for step in (1, 2, 3):
+        np.random.seed(0)
+        result = model(batch)
+        losses = loss(result, batch)
+        opt.zero_grad()
+        losses["total"].backward()
+        if step == 1:
+            for k, v in losses.items():
+                out[f"loss_{k}"] = np.float64(v.item())
+            for n, p in model.named_parameters():
+                if n.startswith("fastdiff_linear") or not p.requires_grad:
+                    continue
+                out["grad_" + n] = (p.grad if p.grad is not None else torch.zeros_like(p)).numpy().copy()
+        norm = torch.nn.utils.clip_grad_norm_(model.parameters(), CLIP)
+        out[f"gradnorm_{step}"] = np.float64(float(norm))
+        out[f"lr_{step}"] = np.float64(opt.param_groups[0]["lr"])
+        opt.step()
+        sched.step()
+        print(f"step {step}: total={float(losses['total']):.6f} grad norm={float(norm):.4f} lr={out[f'lr_{step}']:.3e}")
+    for n, p in model.named_parameters():
+        if not n.startswith("fastdiff_linear") and p.requires_grad:
+            out["after3_" + n] = p.detach().numpy().copy()
+    path = os.path.join(ROOT, "tests", "golden", "train_small.npz")
+    np.savez_compressed(path, **out)
+    print(path, f"{os.path.getsize(path) / 1024:.1f} KiB")
+
+
+if __name__ == "__main__":
+    main()
