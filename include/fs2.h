@@ -281,6 +281,7 @@ typedef struct fs2_bgemm_desc {
     int32_t seg, taps, Kin, a_shift0, a_shift_step;
     int64_t sBtap;
     int32_t b_shift0, b_shift_step;
+    int32_t c_dtype;   /* fs2_dtype of C: FS2_F32 operands write fp32; FS2_BF16 operands write bf16 or fp32 */
 } fs2_bgemm_desc;
 size_t fs2_op_bgemm_ws_bytes(const fs2_bgemm_desc* d);  /* split-K slabs (0 when splitk <= 1) */
 int fs2_op_bgemm(int32_t dtype, const fs2_bgemm_desc* d, const void* A, const void* B, void* C, const float* bias,
@@ -292,22 +293,24 @@ int fs2_op_layernorm_bwd(int32_t dtype, const void* z, const void* res, const vo
                          float* part, int32_t M, int32_t H, void* hip_stream);
 /* out[s][n] (+)= scale * sum over the rows of segment s of x[row][n]; seg = rows per segment (0: one segment) */
 size_t fs2_op_col_sum_ws_bytes(int32_t M, int32_t N, int32_t seg);
-int fs2_op_col_sum(const float* x, float* out, float* ws, int32_t M, int32_t N, int32_t ldx, int32_t seg,
+int fs2_op_col_sum(int32_t dtype, const void* x, float* out, float* ws, int32_t M, int32_t N, int32_t ldx, int32_t seg,
                    int32_t accumulate, float scale, void* hip_stream);
-/* masked softmax over the key axis of (B, heads, S, S) scores, in place (the training path materialises the
- * probabilities), and its backward dS = scale * P o (dP - sum_k dP o P), in place on dP */
-int fs2_op_softmax_fwd(int32_t dtype, void* s, const uint8_t* key_pad, int32_t B, int32_t heads, int32_t S, float scale,
-                       void* hip_stream);
-int fs2_op_softmax_bwd(int32_t dtype, void* dp, const void* p, int32_t B, int32_t heads, int32_t S, float scale,
-                       void* hip_stream);
-/* elementwise: op 0: out = alpha*a + beta*b (b may be NULL)   1: out = a where b > 0 else 0 (ReLU backward)   2: out = alpha*a */
-int fs2_op_ew(int32_t op, const float* a, const float* b, float* out, size_t n, float alpha, float beta, void* hip_stream);
+/* masked softmax over the key axis of (B, heads, S, S) fp32 scores -> probabilities p in the activation dtype (the training
+ * path materialises them; p may alias s for FS2_F32), and its backward ds = scale * P o (dP - sum_k dP o P) from fp32 dP */
+int fs2_op_softmax_fwd(int32_t dtype, const float* s, const uint8_t* key_pad, void* p, int32_t B, int32_t heads, int32_t S,
+                       float scale, void* hip_stream);
+int fs2_op_softmax_bwd(int32_t dtype, const float* dp, const void* p, void* ds, int32_t B, int32_t heads, int32_t S,
+                       float scale, void* hip_stream);
+/* elementwise over the activation dtype: op 0: out = alpha*a + beta*b (b may be NULL)   1: out = a where b > 0 else 0
+ * (ReLU backward)   2: out = alpha*a */
+int fs2_op_ew(int32_t dtype, int32_t op, const void* a, const void* b, void* out, size_t n, float alpha, float beta,
+              void* hip_stream);
 /* embedding backward: table[idx[r]] += x[r] for r < R (int32 or int64 indices), row skip_row untouched (padding_idx) */
-int fs2_op_scatter_rows(const float* x, const int32_t* idx32, const int64_t* idx64, float* table, int32_t R, int32_t H,
-                        int32_t V, int32_t skip_row, void* hip_stream);
+int fs2_op_scatter_rows(int32_t dtype, const void* x, const int32_t* idx32, const int64_t* idx64, float* table, int32_t R,
+                        int32_t H, int32_t V, int32_t skip_row, void* hip_stream);
 /* LengthRegulator backward: dx[b][p] = sum of dy[b][t] over the frames phone p was repeated to (truncated at T) */
-int fs2_op_regulate_bwd(const float* dy, const int32_t* cum, float* dx, int32_t B, int32_t L, int32_t T, int32_t H,
-                        void* hip_stream);
+int fs2_op_regulate_bwd(int32_t dtype, const void* dy, const int32_t* cum, void* dx, int32_t B, int32_t L, int32_t T,
+                        int32_t H, void* hip_stream);
 /* gradient of alpha * fs2_op_masked_loss(...) with respect to pred; stat = that call's out2 (the count is read on device) */
 int fs2_op_masked_loss_bwd(const float* pred, const void* truth, int32_t truth_kind, const uint8_t* pad_mask,
                            const float* stat, float* dpred, int64_t rows, int32_t inner, int32_t kind, float alpha,

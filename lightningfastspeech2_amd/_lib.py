@@ -65,7 +65,7 @@ class BGemmDescC(C.Structure):
         ("sA1", C.c_int64), ("sA2", C.c_int64), ("sB1", C.c_int64), ("sB2", C.c_int64), ("sC1", C.c_int64), ("sC2", C.c_int64),
         ("alpha", C.c_float), ("beta", C.c_float), ("splitk", C.c_int32),
         ("seg", C.c_int32), ("taps", C.c_int32), ("Kin", C.c_int32), ("a_shift0", C.c_int32), ("a_shift_step", C.c_int32),
-        ("sBtap", C.c_int64), ("b_shift0", C.c_int32), ("b_shift_step", C.c_int32),
+        ("sBtap", C.c_int64), ("b_shift0", C.c_int32), ("b_shift_step", C.c_int32), ("c_dtype", C.c_int32),
     ]
 
 
@@ -154,12 +154,12 @@ def load():
     lib.fs2_op_layernorm_bwd.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32, i32, vp]
     lib.fs2_op_col_sum_ws_bytes.restype = sz
     lib.fs2_op_col_sum_ws_bytes.argtypes = [i32, i32, i32]
-    lib.fs2_op_col_sum.argtypes = [vp, vp, vp, i32, i32, i32, i32, i32, f32, vp]
-    lib.fs2_op_softmax_fwd.argtypes = [i32, vp, vp, i32, i32, i32, f32, vp]
-    lib.fs2_op_softmax_bwd.argtypes = [i32, vp, vp, i32, i32, i32, f32, vp]
-    lib.fs2_op_ew.argtypes = [i32, vp, vp, vp, sz, f32, f32, vp]
-    lib.fs2_op_scatter_rows.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
-    lib.fs2_op_regulate_bwd.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.fs2_op_col_sum.argtypes = [i32, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp]
+    lib.fs2_op_softmax_fwd.argtypes = [i32, vp, vp, vp, i32, i32, i32, f32, vp]
+    lib.fs2_op_softmax_bwd.argtypes = [i32, vp, vp, vp, i32, i32, i32, f32, vp]
+    lib.fs2_op_ew.argtypes = [i32, i32, vp, vp, vp, sz, f32, f32, vp]
+    lib.fs2_op_scatter_rows.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.fs2_op_regulate_bwd.argtypes = [i32, vp, vp, vp, i32, i32, i32, i32, vp]
     lib.fs2_op_masked_loss_bwd.argtypes = [vp, vp, i32, vp, vp, vp, C.c_int64, i32, i32, f32, vp]
     lib.fs2_op_sum_sq_ws_bytes.restype = sz
     lib.fs2_op_sum_sq_ws_bytes.argtypes = [sz]

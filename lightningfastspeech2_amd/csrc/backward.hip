@@ -17,13 +17,14 @@ namespace {
 constexpr int LN_ROWS = 64;
 constexpr int LN_MAXC = 16;  // columns per lane: H <= 64 * 16
 
+template <typename T>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(LayerNormBwdArgs p) {
     __shared__ float red[4][2][64 * LN_MAXC];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const float* z = (const float*)p.z;
-    const float* zr = (const float*)p.res;
-    const float* dy = (const float*)p.dy;
-    float* dz = (float*)p.dz;
+    const T* z = (const T*)p.z;
+    const T* zr = (const T*)p.res;
+    const T* dy = (const T*)p.dy;
+    T* dz = (T*)p.dz;
     const int H = p.H;
     const int nc = (H + 63) / 64;
     float dg[LN_MAXC], db[LN_MAXC], gam[LN_MAXC];
@@ -43,8 +44,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(LayerNormBwdArgs p) 
         for (int j = 0; j < LN_MAXC; ++j) {
             const int c = lane + 64 * j;
             const bool ok = j < nc && c < H;
-            zv[j] = ok ? z[(long)row * H + c] + (zr ? zr[(long)row * H + c] : 0.f) : 0.f;
-            dv[j] = ok ? dy[(long)row * H + c] : 0.f;
+            zv[j] = ok ? Num<T>::to_f32(z[(long)row * H + c]) + (zr ? Num<T>::to_f32(zr[(long)row * H + c]) : 0.f) : 0.f;
+            dv[j] = ok ? Num<T>::to_f32(dy[(long)row * H + c]) : 0.f;
             s += zv[j];
         }
         const float mean = wave_sum(s) / H;
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(LayerNormBwdArgs p) 
 #pragma unroll
         for (int j = 0; j < LN_MAXC; ++j) {
             const int c = lane + 64 * j;
-            if (j < nc && c < H) dz[(long)row * H + c] = rstd * (dv[j] * gam[j] - s1 - zv[j] * s2);
+            if (j < nc && c < H) dz[(long)row * H + c] = Num<T>::from_f32(rstd * (dv[j] * gam[j] - s1 - zv[j] * s2));
         }
     }
 #pragma unroll
@@ -98,6 +99,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(LayerNormBwdArgs p) 
 // segment (4 row groups x 64 lanes, fixed order), partials to ws; pass 2 adds the chunks in index order.
 constexpr int CS_CHUNK = 512;  // rows per pass-1 workgroup
 
+template <typename T>
 __global__ __launch_bounds__(256) void col_sum_pass1(ColSumArgs p, int nchunk) {
     __shared__ float red[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(256) void col_sum_pass1(ColSumArgs p, int nchunk) {
     const int r0 = chunk * CS_CHUNK, r1 = min(seg, r0 + CS_CHUNK);
     float a = 0.f;
     if (c < p.N)
-        for (int r = r0 + g; r < r1; r += 4) a += p.x[((long)s * seg + r) * p.ldx + c];
+        for (int r = r0 + g; r < r1; r += 4) a += Num<T>::to_f32(((const T*)p.x)[((long)s * seg + r) * p.ldx + c]);
     red[g][threadIdx.x & 63] = a;
     __syncthreads();
     if (g == 0 && c < p.N) {
@@ -125,14 +127,17 @@ __global__ void col_sum_pass2(ColSumArgs p, int nchunk) {
 }
 
 // ---- masked softmax over the key axis (training path: probabilities are materialised; HBM is 288 GB) --------------
-// one wave per (b, head, query) row
+// one wave per (b, head, query) row.  Scores and dP are fp32 (the GEMM that makes them writes fp32 in either precision
+// mode); probabilities and dS are in the activation dtype T (they are MFMA operands next).  p / out may alias s for fp32.
+template <typename T>
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(SoftmaxArgs p) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long rows = (long)p.B * p.heads * p.S;
     if (row >= rows) return;
     const int b = (int)(row / ((long)p.heads * p.S));
-    float* s = (float*)p.s + row * p.S;
+    const float* s = (const float*)p.s + row * p.S;
+    T* out = (T*)p.out + row * p.S;
     const uint8_t* pad = p.key_pad ? p.key_pad + (long)b * p.S : nullptr;
     float mx = -INFINITY;
     for (int k = lane; k < p.S; k += 64) {
@@ -141,40 +146,43 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(SoftmaxArgs p) {
     }
     mx = wave_max(mx);
     float sum = 0.f;
-    for (int k = lane; k < p.S; k += 64) {
-        const float v = (pad && pad[k]) ? 0.f : expf(s[k] * p.scale - mx);
-        s[k] = v;
-        sum += v;
-    }
+    for (int k = lane; k < p.S; k += 64) sum += (pad && pad[k]) ? 0.f : expf(s[k] * p.scale - mx);
     const float inv = 1.f / wave_sum(sum);
-    for (int k = lane; k < p.S; k += 64) s[k] *= inv;
+    for (int k = lane; k < p.S; k += 64) out[k] = Num<T>::from_f32((pad && pad[k]) ? 0.f : expf(s[k] * p.scale - mx) * inv);
 }
+template <typename T>
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(SoftmaxArgs p) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long rows = (long)p.B * p.heads * p.S;
     if (row >= rows) return;
-    float* d = (float*)p.s + row * p.S;
-    const float* pr = (const float*)p.p + row * p.S;
+    const float* d = (const float*)p.s + row * p.S;
+    const T* pr = (const T*)p.p + row * p.S;
+    T* out = (T*)p.out + row * p.S;
     float dot = 0.f;
-    for (int k = lane; k < p.S; k += 64) dot += d[k] * pr[k];
+    for (int k = lane; k < p.S; k += 64) dot += d[k] * Num<T>::to_f32(pr[k]);
     dot = wave_sum(dot);
-    for (int k = lane; k < p.S; k += 64) d[k] = p.scale * pr[k] * (d[k] - dot);
+    for (int k = lane; k < p.S; k += 64) out[k] = Num<T>::from_f32(p.scale * Num<T>::to_f32(pr[k]) * (d[k] - dot));
 }
 
+template <typename T>
 __global__ void ew_kernel(EwArgs p) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const T* a = (const T*)p.a;
+    const T* b = (const T*)p.b;
+    T* out = (T*)p.out;
     for (size_t e = i; e < p.n; e += stride) {
         float v;
-        if (p.op == 0) v = p.alpha * p.a[e] + (p.b ? p.beta * p.b[e] : 0.f);
-        else if (p.op == 1) v = p.b[e] > 0.f ? p.a[e] : 0.f;
-        else v = p.alpha * p.a[e];
-        p.out[e] = v;
+        if (p.op == 0) v = p.alpha * Num<T>::to_f32(a[e]) + (b ? p.beta * Num<T>::to_f32(b[e]) : 0.f);
+        else if (p.op == 1) v = Num<T>::to_f32(b[e]) > 0.f ? Num<T>::to_f32(a[e]) : 0.f;
+        else v = p.alpha * Num<T>::to_f32(a[e]);
+        out[e] = Num<T>::from_f32(v);
     }
 }
 
 // ---- embedding backward: one workgroup per table row, source rows visited in index order --------------------------
+template <typename T>
 __global__ __launch_bounds__(256) void scatter_rows_kernel(ScatterRowsArgs p) {
     const int v = blockIdx.x;
     if (v == p.skip_row) return;
@@ -205,11 +213,11 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(ScatterRowsArgs p) {
             }
             const int n = nhit;
             for (int h = 0; h < n; ++h) {
-                const float* src = p.x + (long)hits[h] * p.H;
+                const T* src = (const T*)p.x + (long)hits[h] * p.H;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int c = c0 + j * 256 + threadIdx.x;
-                    if (c < p.H) acc[j] += src[c];
+                    if (c < p.H) acc[j] += Num<T>::to_f32(src[c]);
                 }
             }
             __syncthreads();
@@ -223,6 +231,7 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(ScatterRowsArgs p) {
 }
 
 // ---- length regulator backward: one wave per (b, phone) -----------------------------------------------------------
+template <typename T>
 __global__ __launch_bounds__(256) void regulate_bwd_kernel(RegulateBwdArgs p) {
     const int lane = threadIdx.x & 63;
     const long idx = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -231,8 +240,8 @@ __global__ __launch_bounds__(256) void regulate_bwd_kernel(RegulateBwdArgs p) {
     const int t1 = min(p.cum[idx], p.T), t0 = min(ph ? p.cum[idx - 1] : 0, p.T);
     for (int c = lane; c < p.H; c += 64) {
         float a = 0.f;
-        for (int t = t0; t < t1; ++t) a += p.dy[((long)b * p.T + t) * p.H + c];
-        p.dx[idx * p.H + c] = a;
+        for (int t = t0; t < t1; ++t) a += Num<T>::to_f32(((const T*)p.dy)[((long)b * p.T + t) * p.H + c]);
+        ((T*)p.dx)[idx * p.H + c] = Num<T>::from_f32(a);
     }
 }
 
@@ -305,9 +314,10 @@ inline int ok() { return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
 int layernorm_bwd_parts(int M) { return (M + LN_ROWS - 1) / LN_ROWS; }
 
 int launch_layernorm_bwd(const LayerNormBwdArgs& a, int dtype, hipStream_t stream) {
-    if (dtype != FS2_F32 || a.H > 64 * LN_MAXC || a.M <= 0) return FS2_ERR_SHAPE;
+    if ((dtype != FS2_F32 && dtype != FS2_BF16) || a.H > 64 * LN_MAXC || a.M <= 0) return FS2_ERR_SHAPE;
     if (a.nparts != layernorm_bwd_parts(a.M)) return FS2_ERR_ARG;
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(a.nparts), dim3(256), 0, stream, a);
+    if (dtype == FS2_F32) hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(a.nparts), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(layernorm_bwd_kernel<bf16>, dim3(a.nparts), dim3(256), 0, stream, a);
     return ok();
 }
 
@@ -316,44 +326,54 @@ size_t col_sum_ws_bytes(int M, int N, int seg) {
     const int nseg = seg > 0 ? M / seg : 1;
     return (size_t)nseg * cs_chunks(M, seg) * N * sizeof(float);
 }
-int launch_col_sum(const ColSumArgs& a, hipStream_t stream) {
+int launch_col_sum(const ColSumArgs& a, int dtype, hipStream_t stream) {
     if (a.M <= 0 || a.N <= 0 || (a.seg > 0 && a.M % a.seg)) return FS2_ERR_SHAPE;
     const int nseg = a.seg > 0 ? a.M / a.seg : 1, nchunk = cs_chunks(a.M, a.seg);
-    hipLaunchKernelGGL(col_sum_pass1, dim3((a.N + 63) / 64, nchunk, nseg), dim3(256), 0, stream, a, nchunk);
+    const dim3 g1((a.N + 63) / 64, nchunk, nseg);
+    if (dtype == FS2_BF16) hipLaunchKernelGGL(col_sum_pass1<bf16>, g1, dim3(256), 0, stream, a, nchunk);
+    else hipLaunchKernelGGL(col_sum_pass1<float>, g1, dim3(256), 0, stream, a, nchunk);
     hipLaunchKernelGGL(col_sum_pass2, dim3((a.N + 255) / 256, nseg), dim3(256), 0, stream, a, nchunk);
     return ok();
 }
 
 int launch_softmax_fwd(const SoftmaxArgs& a, int dtype, hipStream_t stream) {
-    if (dtype != FS2_F32) return FS2_ERR_SHAPE;
+    if (dtype != FS2_F32 && dtype != FS2_BF16) return FS2_ERR_SHAPE;
     const long rows = (long)a.B * a.heads * a.S;
-    hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, a);
+    const dim3 g((unsigned)((rows + 3) / 4));
+    if (dtype == FS2_F32) hipLaunchKernelGGL(softmax_fwd_kernel<float>, g, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(softmax_fwd_kernel<bf16>, g, dim3(256), 0, stream, a);
     return ok();
 }
 int launch_softmax_bwd(const SoftmaxArgs& a, int dtype, hipStream_t stream) {
-    if (dtype != FS2_F32) return FS2_ERR_SHAPE;
+    if (dtype != FS2_F32 && dtype != FS2_BF16) return FS2_ERR_SHAPE;
     const long rows = (long)a.B * a.heads * a.S;
-    hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, a);
+    const dim3 g((unsigned)((rows + 3) / 4));
+    if (dtype == FS2_F32) hipLaunchKernelGGL(softmax_bwd_kernel<float>, g, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(softmax_bwd_kernel<bf16>, g, dim3(256), 0, stream, a);
     return ok();
 }
 
-int launch_ew(const EwArgs& a, hipStream_t stream) {
+int launch_ew(const EwArgs& a, int dtype, hipStream_t stream) {
     if (!a.n) return FS2_OK;
     size_t blocks = (a.n + 1023) / 1024;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(ew_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    if (dtype == FS2_BF16) hipLaunchKernelGGL(ew_kernel<bf16>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(ew_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
     return ok();
 }
 
-int launch_scatter_rows(const ScatterRowsArgs& a, hipStream_t stream) {
+int launch_scatter_rows(const ScatterRowsArgs& a, int dtype, hipStream_t stream) {
     if (a.R <= 0 || a.V <= 0 || (!a.idx32 && !a.idx64)) return FS2_ERR_ARG;
-    hipLaunchKernelGGL(scatter_rows_kernel, dim3(a.V), dim3(256), 0, stream, a);
+    if (dtype == FS2_BF16) hipLaunchKernelGGL(scatter_rows_kernel<bf16>, dim3(a.V), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(scatter_rows_kernel<float>, dim3(a.V), dim3(256), 0, stream, a);
     return ok();
 }
 
-int launch_regulate_bwd(const RegulateBwdArgs& a, hipStream_t stream) {
+int launch_regulate_bwd(const RegulateBwdArgs& a, int dtype, hipStream_t stream) {
     const long n = (long)a.B * a.L;
-    hipLaunchKernelGGL(regulate_bwd_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, a);
+    const dim3 g((unsigned)((n + 3) / 4));
+    if (dtype == FS2_BF16) hipLaunchKernelGGL(regulate_bwd_kernel<bf16>, g, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(regulate_bwd_kernel<float>, g, dim3(256), 0, stream, a);
     return ok();
 }
 

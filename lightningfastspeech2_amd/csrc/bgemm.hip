@@ -245,6 +245,226 @@ __global__ void bgemm_reduce_kernel(BGemmArgs p) {
     *dst = v;
 }
 
+
+// ---- bf16 operands (the mixed-precision training path): MFMA 16x16x32, fp32 accumulation ---------------------------
+// 128 x 128 x 32 tiles, 4 waves (2 x 2).  Both operands live in LDS k-contiguous, [128 rows][32 k] bf16 with 80-byte
+// rows and the row's four 16-byte chunks XOR-ed with (row / 8) & 3, whatever their layout in memory: a k-contiguous
+// operand is copied chunk by chunk; an operand whose OUTER index is contiguous (the k-strided side of NN / TN products)
+// is transposed on the way in - a thread takes 8 outer positions of two consecutive k rows and writes eight packed
+// (k, k+1) pairs.  Fragments are then plain ds_read_b128.
+constexpr int HBK = 32, HLD = 40;
+constexpr int HOPSZ = BM * HLD;  // bf16 elements per operand buffer (10 KB)
+
+struct OperandH {
+    const unsigned short* p;
+    long s_mn, s_k;
+    int mn0, MN, shift_mn, shift_k, seg;
+    bool vec;
+};
+
+__device__ inline uint4 load8(const unsigned short* src, bool vec, int nvalid) {  // nvalid of 8 elements in range
+    if (vec && nvalid >= 8) return *(const uint4*)src;
+    unsigned short e[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) e[i] = i < nvalid ? src[i] : (unsigned short)0;
+    return make_uint4(e[0] | ((uint32_t)e[1] << 16), e[2] | ((uint32_t)e[3] << 16), e[4] | ((uint32_t)e[5] << 16),
+                      e[6] | ((uint32_t)e[7] << 16));
+}
+
+__device__ inline void load_tile_h(const OperandH& o, int k0, int Kend, uint4 (&r)[2]) {
+    const int tid = threadIdx.x;
+    if (o.s_k == 1) {  // k-contiguous: (row, 8-k chunk)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int v = tid + 256 * i, mn = v >> 2, gk = k0 + (v & 3) * 8;
+            const int gmn = o.mn0 + mn;
+            bool ok = gmn < o.MN && gk < Kend;
+            long row = gmn;
+            if (o.seg && ok) {
+                const int in = gmn % o.seg + o.shift_mn;
+                ok = in >= 0 && in < o.seg;
+                row = gmn + o.shift_mn;
+            }
+            r[i] = ok ? load8(o.p + row * o.s_mn + gk, o.vec, Kend - gk) : make_uint4(0, 0, 0, 0);
+        }
+    } else {  // outer-contiguous: k rows 2*kp, 2*kp + 1, outer positions mq*8 .. +7
+        const int kp = tid >> 4, mq = tid & 15;
+        const int gmn = o.mn0 + mq * 8;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int gk = k0 + 2 * kp + i;
+            bool ok = gk < Kend && gmn < o.MN;
+            long krow = gk;
+            if (o.seg && ok) {
+                const int in = gk % o.seg + o.shift_k;
+                ok = in >= 0 && in < o.seg;
+                krow = gk + o.shift_k;
+            }
+            r[i] = ok ? load8(o.p + krow * o.s_k + gmn, o.vec, o.MN - gmn) : make_uint4(0, 0, 0, 0);
+        }
+    }
+}
+
+__device__ inline void store_tile_h(unsigned short* s, bool kc, const uint4 (&r)[2]) {
+    const int tid = threadIdx.x;
+    if (kc) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int v = tid + 256 * i, row = v >> 2, ch = v & 3;
+            *(uint4*)(s + row * HLD + ((ch ^ ((row >> 3) & 3)) << 3)) = r[i];
+        }
+    } else {
+        const int kp = tid >> 4, mq = tid & 15;
+        const uint32_t a[4] = {r[0].x, r[0].y, r[0].z, r[0].w}, b[4] = {r[1].x, r[1].y, r[1].z, r[1].w};
+        const int col = (((kp >> 2) ^ (mq & 3)) << 3) + (kp & 3) * 2;  // (row >> 3) & 3 == mq & 3 for the 8 rows of this thread
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t lo = a[i >> 1], hi = b[i >> 1];
+            const uint32_t w = (i & 1) ? ((lo >> 16) | (hi & 0xffff0000u)) : ((lo & 0xffffu) | (hi << 16));
+            *(uint32_t*)(s + (mq * 8 + i) * HLD + col) = w;
+        }
+    }
+}
+
+template <typename OutT>
+__global__ __launch_bounds__(256) void bgemm_bf16_kernel(BGemmArgs p) {
+    __shared__ __attribute__((aligned(16))) unsigned short lds[2][2][HOPSZ];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int splitk = p.splitk > 1 ? p.splitk : 1;
+    int z = blockIdx.z;
+    const int split = z % splitk;
+    z /= splitk;
+    const int b2 = z % p.nb2, b1 = z / p.nb2;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+    OperandH A, B;
+    A.p = (const unsigned short*)p.A + b1 * p.sA1 + b2 * p.sA2;
+    A.s_mn = p.sAm; A.s_k = p.sAk; A.mn0 = m0; A.MN = p.M;
+    A.shift_mn = 0; A.shift_k = 0; A.seg = 0; A.vec = p.vecA;
+    B.p = (const unsigned short*)p.B + b1 * p.sB1 + b2 * p.sB2;
+    B.s_mn = p.sBn; B.s_k = p.sBk; B.mn0 = n0; B.MN = p.N;
+    B.shift_mn = 0; B.shift_k = 0; B.seg = 0; B.vec = p.vecB;
+    if (p.seg && p.taps <= 1) {
+        B.seg = p.seg;
+        B.shift_k = p.b_shift0 + b2 * p.b_shift_step;
+    }
+    const bool akc = A.s_k == 1, bkc = B.s_k == 1;
+    const int Kin = p.taps > 1 ? p.Kin : p.K;
+    const int tiles_per_tap = (Kin + HBK - 1) / HBK;
+    const int ntiles = tiles_per_tap * (p.taps > 1 ? p.taps : 1);
+    const int per = (ntiles + splitk - 1) / splitk;
+    const int t_begin = split * per, t_end = min(ntiles, t_begin + per);
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const unsigned short* Ap0 = A.p;
+    const unsigned short* Bp0 = B.p;
+    auto fetch = [&](int t, uint4 (&ra)[2], uint4 (&rb)[2]) {
+        int k0 = t * HBK, kend = p.K;
+        if (p.taps > 1) {
+            const int tap = t / tiles_per_tap;
+            k0 = (t - tap * tiles_per_tap) * HBK;
+            kend = Kin;
+            A.seg = p.seg;
+            A.shift_mn = p.a_shift0 + tap * p.a_shift_step;
+            A.p = Ap0;
+            B.p = Bp0 + tap * p.sBtap;
+        }
+        load_tile_h(A, k0, kend, ra);
+        load_tile_h(B, k0, kend, rb);
+    };
+
+    uint4 ra[2], rb[2];
+    if (t_begin < t_end) {
+        fetch(t_begin, ra, rb);
+        store_tile_h(lds[0][0], akc, ra);
+        store_tile_h(lds[0][1], bkc, rb);
+    }
+    __syncthreads();
+    for (int t = t_begin; t < t_end; ++t) {
+        const int cur = (t - t_begin) & 1;
+        const bool more = t + 1 < t_end;
+        if (more) fetch(t + 1, ra, rb);
+        const unsigned short* sa = lds[cur][0];
+        const unsigned short* sb = lds[cur][1];
+        uint4 a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = wm * 64 + i * 16 + fr;
+            a[i] = *(const uint4*)(sa + row * HLD + ((fg ^ ((row >> 3) & 3)) << 3));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = wn * 64 + j * 16 + fr;
+            b[j] = *(const uint4*)(sb + row * HLD + ((fg ^ ((row >> 3) & 3)) << 3));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Mma16<bf16>::step(a[i], b[j], acc[i][j]);
+        if (more) {
+            store_tile_h(lds[cur ^ 1][0], akc, ra);
+            store_tile_h(lds[cur ^ 1][1], bkc, rb);
+        }
+        __syncthreads();
+    }
+
+    if (splitk > 1) {
+        float* ws = p.ws + ((long)(b1 * p.nb2 + b2) * splitk + split) * (long)p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm * 64 + i * 16 + fg * 4 + r, n = n0 + wn * 64 + j * 16 + fr;
+                    if (m < p.M && n < p.N) ws[(long)m * p.N + n] = acc[i][j][r];
+                }
+        return;
+    }
+    OutT* C = (OutT*)p.C + b1 * p.sC1 + b2 * p.sC2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + fr;
+            if (n >= p.N) continue;
+            const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 64 + i * 16 + fg * 4 + r;
+                if (m >= p.M) continue;
+                float v = p.alpha * acc[i][j][r] + bv;
+                OutT* dst = C + (long)m * p.ldc + n;
+                if (p.beta != 0.f) v += p.beta * Num<OutT>::to_f32(*dst);
+                *dst = Num<OutT>::from_f32(v);
+            }
+        }
+}
+
+template <typename OutT>
+__global__ void bgemm_reduce_t_kernel(BGemmArgs p) {
+    const long per = (long)p.M * p.N;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int bz = blockIdx.y;
+    if (i >= per) return;
+    const int b2 = bz % p.nb2, b1 = bz / p.nb2;
+    const float* ws = p.ws + (long)bz * p.splitk * per + i;
+    float s = 0.f;
+    for (int k = 0; k < p.splitk; ++k) s += ws[(long)k * per];
+    const int m = (int)(i / p.N), n = (int)(i % p.N);
+    float v = p.alpha * s + (p.bias ? p.bias[n] : 0.f);
+    OutT* dst = (OutT*)p.C + b1 * p.sC1 + b2 * p.sC2 + (long)m * p.ldc + n;
+    if (p.beta != 0.f) v += p.beta * Num<OutT>::to_f32(*dst);
+    *dst = Num<OutT>::from_f32(v);
+}
+
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
@@ -254,25 +474,33 @@ size_t bgemm_ws_bytes(const BGemmArgs& a) {
 }
 
 int launch_bgemm(const BGemmArgs& a0, int dtype, hipStream_t stream) {
-    if (dtype != FS2_F32) return FS2_ERR_SHAPE;
+    if (dtype != FS2_F32 && dtype != FS2_BF16) return FS2_ERR_SHAPE;
     BGemmArgs a = a0;
+    if (dtype == FS2_F32 && a.c_dtype != FS2_F32) return FS2_ERR_SHAPE;
     if (a.M <= 0 || a.N <= 0 || a.K <= 0 || a.nb1 <= 0 || a.nb2 <= 0) return FS2_ERR_SHAPE;
     if ((a.sAm != 1 && a.sAk != 1) || (a.sBk != 1 && a.sBn != 1)) return FS2_ERR_SHAPE;
     if (a.taps > 1 && (a.Kin <= 0 || a.K != a.taps * a.Kin)) return FS2_ERR_SHAPE;
     if (a.splitk > 1 && !a.ws) return FS2_ERR_ARG;
     // 16-byte vector loads need every row start (and batch / tap base) on a 16-byte boundary
-    auto vec_ok = [](const void* p, long s_outer, long s1, long s2, long s3) {
-        return aligned16(p) && s_outer % 4 == 0 && s1 % 4 == 0 && s2 % 4 == 0 && s3 % 4 == 0;
+    const int per16 = dtype == FS2_F32 ? 4 : 8;
+    auto vec_ok = [per16](const void* p, long s_outer, long s1, long s2, long s3) {
+        return aligned16(p) && s_outer % per16 == 0 && s1 % per16 == 0 && s2 % per16 == 0 && s3 % per16 == 0;
     };
     a.vecA = vec_ok(a.A, a.sAk == 1 ? a.sAm : a.sAk, a.sA1, a.sA2, 0) ? 1 : 0;
     a.vecB = vec_ok(a.B, a.sBk == 1 ? a.sBn : a.sBk, a.sB1, a.sB2, a.taps > 1 ? a.sBtap : 0) ? 1 : 0;
     const int splitk = a.splitk > 1 ? a.splitk : 1;
     dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, a.nb1 * a.nb2 * splitk);
-    hipLaunchKernelGGL(bgemm_f32_kernel, grid, dim3(256), 0, stream, a);
-    if (splitk > 1) {
-        const long per = (long)a.M * a.N;
-        dim3 g2((unsigned)((per + 255) / 256), a.nb1 * a.nb2);
-        hipLaunchKernelGGL(bgemm_reduce_kernel, g2, dim3(256), 0, stream, a);
+    const long per = (long)a.M * a.N;
+    dim3 g2((unsigned)((per + 255) / 256), a.nb1 * a.nb2);
+    if (dtype == FS2_F32) {
+        hipLaunchKernelGGL(bgemm_f32_kernel, grid, dim3(256), 0, stream, a);
+        if (splitk > 1) hipLaunchKernelGGL(bgemm_reduce_kernel, g2, dim3(256), 0, stream, a);
+    } else if (a.c_dtype == FS2_F32) {
+        hipLaunchKernelGGL(bgemm_bf16_kernel<float>, grid, dim3(256), 0, stream, a);
+        if (splitk > 1) hipLaunchKernelGGL(bgemm_reduce_t_kernel<float>, g2, dim3(256), 0, stream, a);
+    } else {
+        hipLaunchKernelGGL(bgemm_bf16_kernel<bf16>, grid, dim3(256), 0, stream, a);
+        if (splitk > 1) hipLaunchKernelGGL(bgemm_reduce_t_kernel<bf16>, g2, dim3(256), 0, stream, a);
     }
     return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
 }

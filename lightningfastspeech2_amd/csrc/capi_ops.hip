@@ -195,7 +195,7 @@ static BGemmArgs bgemm_args(const fs2_bgemm_desc* d, const void* A, const void* 
     a.alpha = d->alpha; a.beta = d->beta; a.splitk = d->splitk > 1 ? d->splitk : 1;
     a.seg = d->seg; a.taps = d->taps > 1 ? d->taps : 1; a.Kin = d->Kin;
     a.a_shift0 = d->a_shift0; a.a_shift_step = d->a_shift_step; a.sBtap = d->sBtap;
-    a.b_shift0 = d->b_shift0; a.b_shift_step = d->b_shift_step;
+    a.b_shift0 = d->b_shift0; a.b_shift_step = d->b_shift_step; a.c_dtype = d->c_dtype;
     return a;
 }
 size_t fs2_op_bgemm_ws_bytes(const fs2_bgemm_desc* d) {
@@ -213,34 +213,35 @@ int fs2_op_layernorm_bwd(int32_t dtype, const void* z, const void* res, const vo
     return launch_layernorm_bwd(a, dtype, (hipStream_t)stream);
 }
 size_t fs2_op_col_sum_ws_bytes(int32_t M, int32_t N, int32_t seg) { return col_sum_ws_bytes(M, N, seg); }
-int fs2_op_col_sum(const float* x, float* out, float* ws, int32_t M, int32_t N, int32_t ldx, int32_t seg,
+int fs2_op_col_sum(int32_t dtype, const void* x, float* out, float* ws, int32_t M, int32_t N, int32_t ldx, int32_t seg,
                    int32_t accumulate, float scale, void* stream) {
     ColSumArgs a{x, out, ws, M, N, ldx, seg, accumulate, scale};
-    return launch_col_sum(a, (hipStream_t)stream);
+    return launch_col_sum(a, dtype, (hipStream_t)stream);
 }
-int fs2_op_softmax_fwd(int32_t dtype, void* s, const uint8_t* key_pad, int32_t B, int32_t heads, int32_t S, float scale,
-                       void* stream) {
-    SoftmaxArgs a{s, nullptr, key_pad, B, heads, S, scale};
+int fs2_op_softmax_fwd(int32_t dtype, const float* s, const uint8_t* key_pad, void* p, int32_t B, int32_t heads, int32_t S,
+                       float scale, void* stream) {
+    SoftmaxArgs a{s, nullptr, p, key_pad, B, heads, S, scale};
     return launch_softmax_fwd(a, dtype, (hipStream_t)stream);
 }
-int fs2_op_softmax_bwd(int32_t dtype, void* dp, const void* p, int32_t B, int32_t heads, int32_t S, float scale,
-                       void* stream) {
-    SoftmaxArgs a{dp, p, nullptr, B, heads, S, scale};
+int fs2_op_softmax_bwd(int32_t dtype, const float* dp, const void* p, void* ds, int32_t B, int32_t heads, int32_t S,
+                       float scale, void* stream) {
+    SoftmaxArgs a{dp, p, ds, nullptr, B, heads, S, scale};
     return launch_softmax_bwd(a, dtype, (hipStream_t)stream);
 }
-int fs2_op_ew(int32_t op, const float* a_, const float* b, float* out, size_t n, float alpha, float beta, void* stream) {
+int fs2_op_ew(int32_t dtype, int32_t op, const void* a_, const void* b, void* out, size_t n, float alpha, float beta,
+              void* stream) {
     EwArgs a{a_, b, out, n, alpha, beta, op};
-    return launch_ew(a, (hipStream_t)stream);
+    return launch_ew(a, dtype, (hipStream_t)stream);
 }
-int fs2_op_scatter_rows(const float* x, const int32_t* idx32, const int64_t* idx64, float* table, int32_t R, int32_t H,
-                        int32_t V, int32_t skip_row, void* stream) {
+int fs2_op_scatter_rows(int32_t dtype, const void* x, const int32_t* idx32, const int64_t* idx64, float* table, int32_t R,
+                        int32_t H, int32_t V, int32_t skip_row, void* stream) {
     ScatterRowsArgs a{x, idx32, idx64, table, R, H, V, skip_row};
-    return launch_scatter_rows(a, (hipStream_t)stream);
+    return launch_scatter_rows(a, dtype, (hipStream_t)stream);
 }
-int fs2_op_regulate_bwd(const float* dy, const int32_t* cum, float* dx, int32_t B, int32_t L, int32_t T, int32_t H,
-                        void* stream) {
+int fs2_op_regulate_bwd(int32_t dtype, const void* dy, const int32_t* cum, void* dx, int32_t B, int32_t L, int32_t T,
+                        int32_t H, void* stream) {
     RegulateBwdArgs a{dy, cum, dx, B, L, T, H};
-    return launch_regulate_bwd(a, (hipStream_t)stream);
+    return launch_regulate_bwd(a, dtype, (hipStream_t)stream);
 }
 int fs2_op_masked_loss_bwd(const float* pred, const void* truth, int32_t truth_kind, const uint8_t* pad_mask,
                            const float* stat, float* dpred, int64_t rows, int32_t inner, int32_t kind, float alpha,

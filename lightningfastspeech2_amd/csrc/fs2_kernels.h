@@ -288,6 +288,7 @@ struct BGemmArgs {
     int a_shift0 = 0, a_shift_step = 0;
     long sBtap = 0;               //             ... and B from + j * sBtap
     int b_shift0 = 0, b_shift_step = 0;  // wgrad form (taps == 1): batch index b2 reads B's k rows at k + b_shift0 + b2 * b_shift_step
+    int c_dtype = FS2_F32;        // dtype of C: bf16 operands may write bf16 (activations) or fp32 (weight gradients, scores)
     int vecA = 0, vecB = 0;       // set by the launcher
 };
 size_t bgemm_ws_bytes(const BGemmArgs& a);
@@ -308,7 +309,7 @@ int layernorm_bwd_parts(int M);
 int launch_layernorm_bwd(const LayerNormBwdArgs& a, int dtype, hipStream_t stream);
 
 struct ColSumArgs {
-    const float* x;   // (M, N) fp32, row stride ldx
+    const void* x;    // (M, N) in the launch dtype, row stride ldx
     float* out;       // (nseg, N): out[s][n] (+)= scale * sum over the rows of segment s
     float* ws;        // col_sum_ws_bytes
     int M, N, ldx;
@@ -317,11 +318,12 @@ struct ColSumArgs {
     float scale;
 };
 size_t col_sum_ws_bytes(int M, int N, int seg);
-int launch_col_sum(const ColSumArgs& a, hipStream_t stream);
+int launch_col_sum(const ColSumArgs& a, int dtype, hipStream_t stream);
 
 struct SoftmaxArgs {
-    void* s;                // (B, heads, S, S) scores in place -> probabilities (fwd); dP in place -> dS (bwd)
-    const void* p;          // bwd: the probabilities
+    const float* s;         // (B, heads, S, S) fp32: scores (fwd) / dP (bwd)
+    const void* p;          // bwd: the probabilities, activation dtype
+    void* out;              // fwd: probabilities; bwd: dS; activation dtype (may alias s when that is fp32)
     const uint8_t* key_pad; // (B, S) 1 = pad key -> probability 0; fwd only
     int B, heads, S;
     float scale;            // fwd: softmax(scale * s); bwd: dS = scale * P o (dP - sum(dP o P))
@@ -329,33 +331,33 @@ struct SoftmaxArgs {
 int launch_softmax_fwd(const SoftmaxArgs& a, int dtype, hipStream_t stream);
 int launch_softmax_bwd(const SoftmaxArgs& a, int dtype, hipStream_t stream);
 
-struct EwArgs {   // elementwise helpers over n fp32 elements
-    const float* a;
-    const float* b;
-    float* out;
+struct EwArgs {   // elementwise helpers over n elements of the launch dtype
+    const void* a;
+    const void* b;
+    void* out;
     size_t n;
     float alpha, beta;
     int op;       // 0: out = alpha*a + beta*b   1: out = a * (b > 0)  (ReLU backward: b = the ReLU output)   2: out = alpha * a
 };
-int launch_ew(const EwArgs& a, hipStream_t stream);
+int launch_ew(const EwArgs& a, int dtype, hipStream_t stream);
 
 struct ScatterRowsArgs {     // table[idx[r]] += scale * x[r]  (embedding backward), deterministic: one workgroup per table row
-    const float* x;          // (R, H)
+    const void* x;           // (R, H) launch dtype
     const int32_t* idx32;    // (R) or null
     const int64_t* idx64;    // (R) or null
     float* table;            // (V, H) accumulated into
     int R, H, V;
     int skip_row;            // table row that receives no gradient (padding_idx), -1 = none
 };
-int launch_scatter_rows(const ScatterRowsArgs& a, hipStream_t stream);
+int launch_scatter_rows(const ScatterRowsArgs& a, int dtype, hipStream_t stream);
 
 struct RegulateBwdArgs {     // d_phone[b][p] = sum of d_frame[b][t] over the frames phone p was repeated to (t < T)
-    const float* dy;         // (B*T, H)
+    const void* dy;          // (B*T, H) launch dtype
     const int32_t* cum;      // (B, L) inclusive prefix sums of the durations
-    float* dx;               // (B*L, H)
+    void* dx;                // (B*L, H)
     int B, L, T, H;
 };
-int launch_regulate_bwd(const RegulateBwdArgs& a, hipStream_t stream);
+int launch_regulate_bwd(const RegulateBwdArgs& a, int dtype, hipStream_t stream);
 
 struct LossBwdArgs {         // gradient of alpha * mean over selected elements of |p - t| or (p - t)^2
     const float* pred;       // (rows, inner)

@@ -12,7 +12,9 @@ job all-reduces one contiguous gradient buffer.  torch supplies device memory an
 no CPU path - without libfs2_hip.so the constructor raises.
 
 Covered: the dense-convolution architecture family (C1/C2/C5 of BASELINE.json and the test-size configs), frame-level
-'none' variances, 'l1' / 'mse' losses, fp32 arithmetic (exact fp32 MFMA).  Dropout is 0 (the reference's dropouts are
+'none' variances, 'l1' / 'mse' losses; precision "fp32" (exact fp32 MFMA, the parity mode) or "bf16" (bf16 activations,
+activation gradients and GEMM operands on the bf16 MFMA with fp32 accumulation; fp32 master weights, weight gradients,
+Adam moments, LayerNorm / softmax statistics and losses - what the reference's `--precision 16` recipe does with fp16).  Dropout is 0 (the reference's dropouts are
 random per step and cannot be pinned; p = 0 is what the parity tests compare).  Rejected loudly: depth-wise convolutions,
 phone-level / CWT variances, priors, stochastic durations.
 """
@@ -30,8 +32,9 @@ from . import _lib
 from .config import Fs2Config
 from .weights import state_dict_spec
 
-F32 = _lib.FS2_F32
+F32, BF16 = _lib.FS2_F32, _lib.FS2_BF16
 _KIND = {"l1": 0, "mse": 1}
+_PRECISIONS = {"fp32": (F32, torch.float32), "bf16": (BF16, torch.bfloat16)}
 
 
 def _p(t: Optional[torch.Tensor]):
@@ -41,8 +44,9 @@ def _p(t: Optional[torch.Tensor]):
 class _Ops:
     """Thin typed wrappers: torch tensors in, C ABI launches on torch's current stream."""
 
-    def __init__(self, device):
+    def __init__(self, device, precision="fp32"):
         self.lib = _lib.load()
+        self.dt, self.tdt = _PRECISIONS[precision]   # activation dtype (C ABI enum, torch dtype)
         self.dev = torch.device(device)
         if self.dev.type != "cuda":
             raise RuntimeError("the training step runs on the GPU (no CPU path)")
@@ -53,6 +57,17 @@ class _Ops:
 
     def empty(self, *shape, dtype=torch.float32):
         return torch.empty(*shape, dtype=dtype, device=self.dev)
+
+    def act(self, *shape):
+        return torch.empty(*shape, dtype=self.tdt, device=self.dev)
+
+    def to_act(self, x):
+        """fp32 -> activation dtype (loss gradients enter the backward chain through this)"""
+        if self.dt == F32:
+            return x
+        y = self.act(*x.shape)
+        self.ck(self.lib.fs2_op_convert(F32, self.dt, _p(x), _p(y), x.numel(), self.st()), "convert")
+        return y
 
     def ws(self, key: str, nbytes: int) -> Optional[torch.Tensor]:
         if nbytes <= 0:
@@ -67,45 +82,51 @@ class _Ops:
         _lib.check(status, None, what)
 
     # ---- forward operators (the inference path's own launches, fp32) ----
-    def gemm(self, x, w, bias, M, N, Cin, taps=1, S=None, relu=False):
-        y = self.empty(M, N)
-        self.ck(self.lib.fs2_op_gemm(F32, F32, _p(x), _p(w), _p(bias), _p(y), M, N, Cin, taps, S or M, int(relu), self.st()), "gemm")
+    def gemm(self, x, w, bias, M, N, Cin, taps=1, S=None, relu=False, out_f32=False):
+        y = self.empty(M, N) if out_f32 else self.act(M, N)
+        self.ck(self.lib.fs2_op_gemm(self.dt, F32 if out_f32 else self.dt, _p(x), _p(w), _p(bias), _p(y), M, N, Cin, taps, S or M,
+                                     int(relu), self.st()), "gemm")
         return y
 
     def layernorm(self, x, res, g, b, M, H, dot_w=None, dot_b=0.0, mask=None, want_y=True):
-        y = self.empty(M, H) if want_y else None
+        y = self.act(M, H) if want_y else None
         pred = self.empty(M) if dot_w is not None else None
-        self.ck(self.lib.fs2_op_layernorm(F32, _p(x), _p(res), _p(g), _p(b), _p(y), _p(dot_w), C.c_float(dot_b), _p(mask),
+        self.ck(self.lib.fs2_op_layernorm(self.dt, _p(x), _p(res), _p(g), _p(b), _p(y), _p(dot_w), C.c_float(dot_b), _p(mask),
                                           _p(pred), M, H, self.st()), "layernorm")
         return y, pred
 
     # ---- backward operators ----
     def bgemm(self, A, B, Cout, bias=None, **kw):
+        """operands in A's dtype (both fp32 or both bf16); C fp32 or the activation dtype, by Cout's dtype"""
         d = _lib.BGemmDescC()
-        base = dict(nb1=1, nb2=1, alpha=1.0, beta=0.0, splitk=1, taps=1)
+        base = dict(nb1=1, nb2=1, alpha=1.0, beta=0.0, splitk=1, taps=1, c_dtype=F32 if Cout.dtype == torch.float32 else BF16)
         base.update(kw)
         for k, v in base.items():
             setattr(d, k, v)
+        if A.dtype != B.dtype:
+            raise TypeError(f"bgemm operands differ: {A.dtype} vs {B.dtype}")
         ws = self.ws("bgemm", int(self.lib.fs2_op_bgemm_ws_bytes(C.byref(d))))
-        self.ck(self.lib.fs2_op_bgemm(F32, C.byref(d), _p(A), _p(B), _p(Cout), _p(bias), _p(ws), self.st()), "bgemm")
+        self.ck(self.lib.fs2_op_bgemm(F32 if A.dtype == torch.float32 else BF16, C.byref(d), _p(A), _p(B), _p(Cout), _p(bias), _p(ws),
+                                      self.st()), "bgemm")
         return Cout
+
+    @staticmethod
+    def _dt(t):
+        return F32 if t.dtype == torch.float32 else BF16
 
     def col_sum(self, x, out, M, N, seg=0, accumulate=True, scale=1.0, ldx=None):
         ws = self.ws("colsum", int(self.lib.fs2_op_col_sum_ws_bytes(M, N, seg)))
-        self.ck(self.lib.fs2_op_col_sum(_p(x), _p(out), _p(ws), M, N, ldx or N, seg, int(accumulate), C.c_float(scale), self.st()), "col_sum")
+        self.ck(self.lib.fs2_op_col_sum(self._dt(x), _p(x), _p(out), _p(ws), M, N, ldx or N, seg, int(accumulate), C.c_float(scale),
+                                        self.st()), "col_sum")
 
     def relu_bwd(self, dy, y):
         """in place: dy *= (y > 0)"""
-        self.ck(self.lib.fs2_op_ew(1, _p(dy), _p(y), _p(dy), dy.numel(), C.c_float(0), C.c_float(0), self.st()), "relu_bwd")
+        self.ck(self.lib.fs2_op_ew(self._dt(dy), 1, _p(dy), _p(y), _p(dy), dy.numel(), C.c_float(0), C.c_float(0), self.st()), "relu_bwd")
         return dy
-
-    def add_(self, a, b):
-        self.ck(self.lib.fs2_op_ew(0, _p(a), _p(b), _p(a), a.numel(), C.c_float(1), C.c_float(1), self.st()), "add")
-        return a
 
     # y = x W^T + b backward pieces.  w is (N, taps*Cin) tap-major; x (M, Cin); dy (M, N); rows in utterances of S.
     def dgrad(self, dy, w, M, N, Cin, taps=1, S=None, out=None, accumulate=False):
-        dx = out if out is not None else self.empty(M, Cin)
+        dx = out if out is not None else self.act(M, Cin)
         beta = 1.0 if accumulate else 0.0
         if taps == 1:
             return self.bgemm(dy, w, dx, M=M, N=Cin, K=N, sAm=N, sAk=1, sBk=Cin, sBn=1, ldc=Cin, beta=beta)
@@ -130,15 +151,17 @@ class Trainer:
 
     def __init__(self, cfg: Fs2Config, state_dict, *, lr=2e-4, warmup_steps=4000, betas=(0.9, 0.98), eps=1e-8,
                  weight_decay=0.01, gradient_clip_val: Optional[float] = 1.0, variance_losses=None, mel_loss="l1",
-                 duration_loss="mse", loss_alphas=None, device="cuda:0"):
+                 duration_loss="mse", loss_alphas=None, precision="fp32", device="cuda:0"):
         if cfg.encoder_depthwise_conv or cfg.decoder_depthwise_conv or cfg.variance_depthwise_conv or cfg.duration_depthwise_conv:
             raise NotImplementedError("training step: depth-wise convolution variants are not built yet (dense family only)")
         if any(l != "frame" for l in cfg.variance_levels[:len(cfg.variances)]) or any(cfg.is_cwt(i) for i in range(len(cfg.variances))):
             raise NotImplementedError("training step: frame-level 'none' variances only")
         if cfg.priors:
             raise NotImplementedError("training step: priors are not built")
-        self.cfg = cfg
-        self.ops = _Ops(device)
+        if precision not in _PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
+        self.cfg, self.precision = cfg, precision
+        self.ops = _Ops(device, precision)
         self.dev = self.ops.dev
         self.lr, self.warmup_steps, self.betas, self.eps, self.weight_decay = lr, warmup_steps, betas, eps, weight_decay
         self.gradient_clip_val = gradient_clip_val
@@ -167,6 +190,12 @@ class Trainer:
         self.flat_v = torch.zeros(off, device=self.dev)
         self.P = {n: self.flat_p[o:o + int(np.prod(ks))].view(ks) for n, (o, ks, _) in self._layout.items()}
         self.G = {n: self.flat_g[o:o + int(np.prod(ks))].view(ks) for n, (o, ks, _) in self._layout.items()}
+        # GEMM operands: the fp32 masters themselves, or their bf16 shadow (refreshed after every optimizer step)
+        if self.ops.dt == F32:
+            self.W = self.P
+        else:
+            self.flat_w = torch.zeros(off, device=self.dev, dtype=torch.bfloat16)
+            self.W = {n: self.flat_w[o:o + int(np.prod(ks))].view(ks) for n, (o, ks, _) in self._layout.items()}
         self.buffers: Dict[str, torch.Tensor] = {}
         self.load_state_dict(state_dict)
         self.steps = 0          # optimizer steps taken
@@ -190,6 +219,13 @@ class Trainer:
                 v = sd[name]
                 t = torch.as_tensor(np.asarray(v) if not isinstance(v, torch.Tensor) else v).to(torch.float32)
                 self.buffers[name] = t.reshape(-1, t.shape[-1]).contiguous().to(self.dev) if name.endswith(".pe") else t.contiguous().to(self.dev)
+        self._refresh_shadow()
+
+    def _refresh_shadow(self):
+        if self.ops.dt != F32:
+            o = self.ops
+            with torch.cuda.device(self.dev):
+                o.ck(o.lib.fs2_op_convert(F32, o.dt, _p(self.flat_p), _p(self.flat_w), self.n_flat, o.st()), "convert")
 
     def _to_ref_layout(self, name, t):
         _, ks, rs = self._layout[name]
@@ -219,22 +255,24 @@ class Trainer:
 
     # ---- forward / backward of one ConformerEncoderLayer (model.py:65-122, post-norm) ----
     def _layer_fwd(self, x, prefix, B, S, heads, F_, k, key_pad):
-        o, P, H = self.ops, self.P, self.cfg.hidden
+        o, P, W, H = self.ops, self.P, self.W, self.cfg.hidden
         M, d = B * S, H // heads
         t = {"x": x}
-        qkv = o.gemm(x, P[f"{prefix}.self_attn.in_proj_weight"], P[f"{prefix}.self_attn.in_proj_bias"], M, 3 * H, H)
-        prob = o.empty(B, heads, S, S)
-        o.bgemm(qkv, qkv[:, H:], prob, M=S, N=S, K=d, sAm=3 * H, sAk=1, sBk=1, sBn=3 * H, ldc=S, nb1=B, nb2=heads,
+        qkv = o.gemm(x, W[f"{prefix}.self_attn.in_proj_weight"], P[f"{prefix}.self_attn.in_proj_bias"], M, 3 * H, H)
+        scores = o.empty(B, heads, S, S)  # fp32 in either mode; the probabilities are kept in the activation dtype
+        o.bgemm(qkv, qkv[:, H:], scores, M=S, N=S, K=d, sAm=3 * H, sAk=1, sBk=1, sBn=3 * H, ldc=S, nb1=B, nb2=heads,
                 sA1=S * 3 * H, sA2=d, sB1=S * 3 * H, sB2=d, sC1=heads * S * S, sC2=S * S)
         scale = 1.0 / math.sqrt(d)
-        o.ck(o.lib.fs2_op_softmax_fwd(F32, _p(prob), _p(key_pad), B, heads, S, C.c_float(scale), o.st()), "softmax")
-        attn = o.empty(M, H)
+        prob = scores if o.dt == F32 else o.act(B, heads, S, S)
+        o.ck(o.lib.fs2_op_softmax_fwd(o.dt, _p(scores), _p(key_pad), _p(prob), B, heads, S, C.c_float(scale), o.st()), "softmax")
+        del scores
+        attn = o.act(M, H)
         o.bgemm(prob, qkv[:, 2 * H:], attn, M=S, N=d, K=S, sAm=S, sAk=1, sBk=3 * H, sBn=1, ldc=H, nb1=B, nb2=heads,
                 sA1=heads * S * S, sA2=S * S, sB1=S * 3 * H, sB2=d, sC1=S * H, sC2=d)
-        proj = o.gemm(attn, P[f"{prefix}.self_attn.out_proj.weight"], P[f"{prefix}.self_attn.out_proj.bias"], M, H, H)
+        proj = o.gemm(attn, W[f"{prefix}.self_attn.out_proj.weight"], P[f"{prefix}.self_attn.out_proj.bias"], M, H, H)
         x1, _ = o.layernorm(proj, x, P[f"{prefix}.norm1.weight"], P[f"{prefix}.norm1.bias"], M, H)
-        h = o.gemm(x1, P[f"{prefix}.conv1.weight"], P[f"{prefix}.conv1.bias"], M, F_, H, taps=k, S=S, relu=True)
-        c2 = o.gemm(h, P[f"{prefix}.conv2.weight"], P[f"{prefix}.conv2.bias"], M, H, F_)
+        h = o.gemm(x1, W[f"{prefix}.conv1.weight"], P[f"{prefix}.conv1.bias"], M, F_, H, taps=k, S=S, relu=True)
+        c2 = o.gemm(h, W[f"{prefix}.conv2.weight"], P[f"{prefix}.conv2.bias"], M, H, F_)
         x2, _ = o.layernorm(c2, x1, P[f"{prefix}.norm2.weight"], P[f"{prefix}.norm2.bias"], M, H)
         t.update(qkv=qkv, prob=prob, attn=attn, proj=proj, x1=x1, h=h, c2=c2, scale=scale)
         return x2, t
@@ -242,25 +280,25 @@ class Trainer:
     def _ln_bwd(self, z, res, dy, gname, bname, M, H):
         o = self.ops
         nparts = int(o.lib.fs2_op_layernorm_bwd_parts(M))
-        dz, part = o.empty(M, H), o.empty(nparts, 2 * H)
-        o.ck(o.lib.fs2_op_layernorm_bwd(F32, _p(z), _p(res), _p(dy), _p(self.P[gname]), _p(dz), _p(part), M, H, o.st()), "layernorm_bwd")
+        dz, part = o.act(M, H), o.empty(nparts, 2 * H)
+        o.ck(o.lib.fs2_op_layernorm_bwd(o.dt, _p(z), _p(res), _p(dy), _p(self.P[gname]), _p(dz), _p(part), M, H, o.st()), "layernorm_bwd")
         o.col_sum(part, self.G[gname], nparts, H, ldx=2 * H)
         o.col_sum(part[:, H:], self.G[bname], nparts, H, ldx=2 * H)
         return dz
 
     def _layer_bwd(self, dx2, t, prefix, B, S, heads, F_, k):
-        o, P, G, H = self.ops, self.P, self.G, self.cfg.hidden
+        o, P, W, G, H = self.ops, self.P, self.W, self.G, self.cfg.hidden
         M, d = B * S, H // heads
         dx1 = self._ln_bwd(t["c2"], t["x1"], dx2, f"{prefix}.norm2.weight", f"{prefix}.norm2.bias", M, H)  # = dc2 too
         o.wgrad(dx1, t["h"], G[f"{prefix}.conv2.weight"], G[f"{prefix}.conv2.bias"], M, H, F_)
-        dh = o.relu_bwd(o.dgrad(dx1, P[f"{prefix}.conv2.weight"], M, H, F_), t["h"])
+        dh = o.relu_bwd(o.dgrad(dx1, W[f"{prefix}.conv2.weight"], M, H, F_), t["h"])
         o.wgrad(dh, t["x1"], G[f"{prefix}.conv1.weight"], G[f"{prefix}.conv1.bias"], M, F_, H, taps=k, S=S)
-        o.dgrad(dh, P[f"{prefix}.conv1.weight"], M, F_, H, taps=k, S=S, out=dx1, accumulate=True)
+        o.dgrad(dh, W[f"{prefix}.conv1.weight"], M, F_, H, taps=k, S=S, out=dx1, accumulate=True)
         dx = self._ln_bwd(t["proj"], t["x"], dx1, f"{prefix}.norm1.weight", f"{prefix}.norm1.bias", M, H)  # = dproj too
         o.wgrad(dx, t["attn"], G[f"{prefix}.self_attn.out_proj.weight"], G[f"{prefix}.self_attn.out_proj.bias"], M, H, H)
-        dattn = o.dgrad(dx, P[f"{prefix}.self_attn.out_proj.weight"], M, H, H)
+        dattn = o.dgrad(dx, W[f"{prefix}.self_attn.out_proj.weight"], M, H, H)
         qkv, prob = t["qkv"], t["prob"]
-        dqkv = o.empty(M, 3 * H)
+        dqkv = o.act(M, 3 * H)
         bat = dict(nb1=B, nb2=heads)
         sP = dict(sA1=heads * S * S, sA2=S * S)
         # dV = P^T dO
@@ -270,24 +308,26 @@ class Trainer:
         dp = o.empty(B, heads, S, S)
         o.bgemm(dattn, qkv[:, 2 * H:], dp, M=S, N=S, K=d, sAm=H, sAk=1, sBk=1, sBn=3 * H, ldc=S, sA1=S * H, sA2=d,
                 sB1=S * 3 * H, sB2=d, sC1=heads * S * S, sC2=S * S, **bat)
-        o.ck(o.lib.fs2_op_softmax_bwd(F32, _p(dp), _p(prob), B, heads, S, C.c_float(t["scale"]), o.st()), "softmax_bwd")
+        ds = dp if o.dt == F32 else o.act(B, heads, S, S)
+        o.ck(o.lib.fs2_op_softmax_bwd(o.dt, _p(dp), _p(prob), _p(ds), B, heads, S, C.c_float(t["scale"]), o.st()), "softmax_bwd")
+        dp = ds
         # dQ = dS K ; dK = dS^T Q
         o.bgemm(dp, qkv[:, H:], dqkv, M=S, N=d, K=S, sAm=S, sAk=1, sBk=3 * H, sBn=1, ldc=3 * H, sB1=S * 3 * H, sB2=d,
                 sC1=S * 3 * H, sC2=d, **bat, **sP)
         o.bgemm(dp, qkv, dqkv[:, H:], M=S, N=d, K=S, sAm=1, sAk=S, sBk=3 * H, sBn=1, ldc=3 * H, sB1=S * 3 * H, sB2=d,
                 sC1=S * 3 * H, sC2=d, **bat, **sP)
         o.wgrad(dqkv, t["x"], G[f"{prefix}.self_attn.in_proj_weight"], G[f"{prefix}.self_attn.in_proj_bias"], M, 3 * H, H)
-        o.dgrad(dqkv, P[f"{prefix}.self_attn.in_proj_weight"], M, 3 * H, H, out=dx, accumulate=True)
+        o.dgrad(dqkv, W[f"{prefix}.self_attn.in_proj_weight"], M, 3 * H, H, out=dx, accumulate=True)
         return dx
 
     # ---- VariancePredictor (model.py:482-561, dense) ----
     def _predictor_fwd(self, x, prefix, nlayers, filt, k, B, S, mask):
-        o, P, H = self.ops, self.P, self.cfg.hidden
+        o, P, W, H = self.ops, self.P, self.W, self.cfg.hidden
         M = B * S
         tape, y, cin = [], x, H
         for j in range(nlayers):
             p = f"{prefix}.layers.{j}.layers"
-            c = o.gemm(y, P[f"{p}.0.module.weight"], P[f"{p}.0.module.bias"], M, filt, cin, taps=k, S=S, relu=True)
+            c = o.gemm(y, W[f"{p}.0.module.weight"], P[f"{p}.0.module.bias"], M, filt, cin, taps=k, S=S, relu=True)
             last = j == nlayers - 1
             yn, pred = o.layernorm(c, None, P[f"{p}.2.weight"], P[f"{p}.2.bias"], M, filt,
                                    dot_w=P[f"{prefix}.linear.weight"] if last else None,
@@ -298,23 +338,24 @@ class Trainer:
 
     def _predictor_bwd(self, dpred, t, prefix, nlayers, filt, k, B, S, dx_out):
         """dpred (M) -> gradients of the predictor's parameters, and dx_out (M, H) += d/dx."""
-        o, P, G = self.ops, self.P, self.G
+        o, P, W, G = self.ops, self.P, self.W, self.G
         M = B * S
+        dpred = o.to_act(dpred)
         # pred = y . w + b  (masked rows carry dpred = 0 already)
         o.bgemm(dpred, t["y"], G[f"{prefix}.linear.weight"], M=1, N=filt, K=M, sAm=1, sAk=1, sBk=filt, sBn=1, ldc=filt,
                 splitk=max(1, min(64, M // 1024)), beta=1.0)
         o.col_sum(dpred, G[f"{prefix}.linear.bias"], M, 1)
-        dy = o.empty(M, filt)
-        o.bgemm(dpred, P[f"{prefix}.linear.weight"], dy, M=M, N=filt, K=1, sAm=1, sAk=1, sBk=filt, sBn=1, ldc=filt)
+        dy = o.act(M, filt)
+        o.bgemm(dpred, W[f"{prefix}.linear.weight"], dy, M=M, N=filt, K=1, sAm=1, sAk=1, sBk=filt, sBn=1, ldc=filt)
         for j in reversed(range(nlayers)):
             p = f"{prefix}.layers.{j}.layers"
             lt = t["layers"][j]
             dc = o.relu_bwd(self._ln_bwd(lt["c"], None, dy, f"{p}.2.weight", f"{p}.2.bias", M, filt), lt["c"])
             o.wgrad(dc, lt["xin"], G[f"{p}.0.module.weight"], G[f"{p}.0.module.bias"], M, filt, lt["cin"], taps=k, S=S)
             if j == 0:
-                o.dgrad(dc, P[f"{p}.0.module.weight"], M, filt, lt["cin"], taps=k, S=S, out=dx_out, accumulate=True)
+                o.dgrad(dc, W[f"{p}.0.module.weight"], M, filt, lt["cin"], taps=k, S=S, out=dx_out, accumulate=True)
             else:
-                dy = o.dgrad(dc, P[f"{p}.0.module.weight"], M, filt, lt["cin"], taps=k, S=S)
+                dy = o.dgrad(dc, W[f"{p}.0.module.weight"], M, filt, lt["cin"], taps=k, S=S)
 
     def _loss(self, name, pred, truth, truth_kind, mask, rows, inner, kind, want_grad=True):
         o = self.ops
@@ -332,7 +373,7 @@ class Trainer:
     def training_step(self, batch: dict) -> Dict[str, torch.Tensor]:
         """forward(targets, inference=False) + FastSpeech2Loss + backward; gradients are ADDED to the flat buffer.
         Returns the losses as 0-dim device tensors (same keys as the reference's loss dict)."""
-        cfg, o, P, G, dev = self.cfg, self.ops, self.P, self.G, self.dev
+        cfg, o, P, W, G, dev = self.cfg, self.ops, self.P, self.W, self.G, self.dev
         H = cfg.hidden
         phones = batch["phones"].to(dev, torch.int64).contiguous()
         dvec = batch["speaker"].to(dev, torch.float32).contiguous()
@@ -354,9 +395,9 @@ class Trainer:
             spk = o.empty(B, H)
             o.ck(o.lib.fs2_op_spk_proj(_p(dvec), _p(P["speaker_embedding.projection.weight"]), _p(P["speaker_embedding.projection.bias"]),
                                        _p(spk), B, H, dvec.shape[1], o.st()), "spk_proj")
-            x = o.empty(B * L, H)
+            x = o.act(B * L, H)
             src_mask = o.empty(B, L, dtype=torch.uint8)
-            o.ck(o.lib.fs2_op_embed(F32, _p(phones), _p(P["phone_embedding.weight"]), _p(pe), _p(spk), _p(x), _p(src_mask), B, L, H,
+            o.ck(o.lib.fs2_op_embed(o.dt, _p(phones), _p(P["phone_embedding.weight"]), _p(pe), _p(spk), _p(x), _p(src_mask), B, L, H,
                                     cfg.n_phones, o.st()), "embed")
             enc_t = []
             for i in range(cfg.encoder_layers):
@@ -369,9 +410,9 @@ class Trainer:
             dur, cum, totals, guard = (o.empty(B, L, dtype=torch.int32), o.empty(B, L, dtype=torch.int32),
                                        o.empty(B, dtype=torch.int32), o.empty(B, dtype=torch.int32))
             o.ck(o.lib.fs2_op_durations(_p(dur_pred), _p(src_mask), _p(forced), _p(dur), _p(cum), _p(totals), _p(guard), B, L, o.st()), "durations")
-            xr = o.empty(B * T, H)
+            xr = o.act(B * T, H)
             tgt_mask = o.empty(B, T, dtype=torch.uint8)
-            o.ck(o.lib.fs2_op_regulate(F32, _p(x), _p(cum), _p(totals), _p(xr), _p(tgt_mask), B, L, T, H, o.st()), "regulate")
+            o.ck(o.lib.fs2_op_regulate(o.dt, _p(x), _p(cum), _p(totals), _p(xr), _p(tgt_mask), B, L, T, H, o.st()), "regulate")
             var_pred, var_tape, var_idx = {}, {}, {}
             xa = xr
             nv = len(cfg.variances)
@@ -380,18 +421,18 @@ class Trainer:
                 var_pred[v], var_tape[v] = self._predictor_fwd(xa, f"{pfx}.predictor", cfg.variance_nlayers[vi], cfg.variance_filter_size,
                                                                cfg.variance_kernel_size[vi], B, T, tgt_mask)
                 idx = o.empty(B * T, dtype=torch.int32)
-                xn = o.empty(B * T, H)
+                xn = o.act(B * T, H)
                 last = vi == nv - 1
                 st_ = cfg.stats[v]
-                o.ck(o.lib.fs2_op_bucket_embed_target(F32, _p(xa), _p(var_t[v]), _p(self.buffers[f"{pfx}.bins"]), _p(P[f"{pfx}.embedding.weight"]),
+                o.ck(o.lib.fs2_op_bucket_embed_target(o.dt, _p(xa), _p(var_t[v]), _p(self.buffers[f"{pfx}.bins"]), _p(P[f"{pfx}.embedding.weight"]),
                                                       cfg.variance_nbins, C.c_float(st_["std"]), C.c_float(st_["mean"]),
                                                       _p(pe) if last else None, _p(spk) if last else None, _p(xn), _p(idx), B, T, H, o.st()),
                      "bucket_embed_target")
                 var_idx[v] = idx
                 xa = xn
             if nv == 0:
-                xn = o.empty(B * T, H)
-                o.ck(o.lib.fs2_op_bucket_embed(F32, _p(xa), None, None, None, 0, C.c_float(1), C.c_float(0), _p(pe), _p(spk), _p(xn), None,
+                xn = o.act(B * T, H)
+                o.ck(o.lib.fs2_op_bucket_embed(o.dt, _p(xa), None, None, None, 0, C.c_float(1), C.c_float(0), _p(pe), _p(spk), _p(xn), None,
                                                B, T, H, o.st()), "pe_spk")
                 xa = xn
             y = xa
@@ -400,7 +441,7 @@ class Trainer:
                 y, t = self._layer_fwd(y, f"decoder.layers.{i}", B, T, cfg.decoder_head, cfg.decoder_conv_filter_size,
                                        cfg.decoder_kernel_sizes[i], tgt_mask)
                 dec_t.append(t)
-            mel = o.gemm(y, P["linear.weight"], P["linear.bias"], B * T, cfg.n_mels, H)
+            mel = o.gemm(y, W["linear.weight"], P["linear.bias"], B * T, cfg.n_mels, H, out_f32=True)
             # ---------------- losses + their gradients (loss.py:83-213) ----------------
             losses = {}
             dvar = {}
@@ -413,8 +454,9 @@ class Trainer:
             losses["duration"] = stat[0]
             losses["total"] = sum(v * self.loss_alphas[k] for k, v in losses.items())
             # ---------------- backward ----------------
+            dmel = o.to_act(dmel)
             o.wgrad(dmel, y, G["linear.weight"], G["linear.bias"], B * T, cfg.n_mels, H)
-            dy = o.dgrad(dmel, P["linear.weight"], B * T, cfg.n_mels, H)
+            dy = o.dgrad(dmel, W["linear.weight"], B * T, cfg.n_mels, H)
             for i in reversed(range(cfg.decoder_layers)):
                 dy = self._layer_bwd(dy, dec_t[i], f"decoder.layers.{i}", B, T, cfg.decoder_head, cfg.decoder_conv_filter_size,
                                      cfg.decoder_kernel_sizes[i])
@@ -424,18 +466,18 @@ class Trainer:
             for vi in reversed(range(nv)):
                 v = cfg.variances[vi]
                 pfx = f"variance_adaptor.encoders.{v}"
-                o.ck(o.lib.fs2_op_scatter_rows(_p(dx), _p(var_idx[v]), None, _p(G[f"{pfx}.embedding.weight"]), B * T, H, cfg.variance_nbins,
+                o.ck(o.lib.fs2_op_scatter_rows(o.dt, _p(dx), _p(var_idx[v]), None, _p(G[f"{pfx}.embedding.weight"]), B * T, H, cfg.variance_nbins,
                                                -1, o.st()), "scatter_rows")
                 self._predictor_bwd(dvar[v], var_tape[v], f"{pfx}.predictor", cfg.variance_nlayers[vi], cfg.variance_filter_size,
                                     cfg.variance_kernel_size[vi], B, T, dx)
-            dxe = o.empty(B * L, H)
-            o.ck(o.lib.fs2_op_regulate_bwd(_p(dx), _p(cum), _p(dxe), B, L, T, H, o.st()), "regulate_bwd")
+            dxe = o.act(B * L, H)
+            o.ck(o.lib.fs2_op_regulate_bwd(o.dt, _p(dx), _p(cum), _p(dxe), B, L, T, H, o.st()), "regulate_bwd")
             self._predictor_bwd(ddur, dur_tape, "variance_adaptor.duration_predictor", cfg.duration_nlayers, cfg.duration_filter_size,
                                 cfg.duration_kernel_size, B, L, dxe)
             for i in reversed(range(cfg.encoder_layers)):
                 dxe = self._layer_bwd(dxe, enc_t[i], f"encoder.layers.{i}", B, L, cfg.encoder_head, cfg.encoder_conv_filter_size,
                                       cfg.encoder_kernel_sizes[i])
-            o.ck(o.lib.fs2_op_scatter_rows(_p(dxe), None, _p(phones), _p(G["phone_embedding.weight"]), B * L, H, cfg.n_phones, 0, o.st()),
+            o.ck(o.lib.fs2_op_scatter_rows(o.dt, _p(dxe), None, _p(phones), _p(G["phone_embedding.weight"]), B * L, H, cfg.n_phones, 0, o.st()),
                  "scatter_rows")
             o.col_sum(dxe, dspk, B * L, H, seg=L)
             o.relu_bwd(dspk, spk)  # spk = relu(W dvec + b), model.py:137-143
@@ -462,4 +504,5 @@ class Trainer:
                  "adamw")
         self.steps += 1
         self.zero_grad()
+        self._refresh_shadow()
         return lr

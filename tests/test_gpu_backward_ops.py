@@ -23,10 +23,11 @@ def st():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-def bgemm(desc_kw, A, B, Cout, bias=None):
+def bgemm(desc_kw, A, B, Cout, bias=None, dtype=F32):
     lib = _lib.load()
     d = _lib.BGemmDescC()
-    base = dict(nb1=1, nb2=1, alpha=1.0, beta=0.0, splitk=1, taps=1)
+    base = dict(nb1=1, nb2=1, alpha=1.0, beta=0.0, splitk=1, taps=1,
+                c_dtype=_lib.FS2_BF16 if Cout.dtype == torch.bfloat16 else F32)
     base.update(desc_kw)
     for k, v in base.items():
         setattr(d, k, v)
@@ -34,7 +35,7 @@ def bgemm(desc_kw, A, B, Cout, bias=None):
     nbytes = lib.fs2_op_bgemm_ws_bytes(C.byref(d))
     if nbytes:
         ws = torch.empty(nbytes // 4, device=DEV)
-    _lib.check(lib.fs2_op_bgemm(F32, C.byref(d), p(A), p(B), p(Cout), p(bias), p(ws), st()), what="bgemm")
+    _lib.check(lib.fs2_op_bgemm(dtype, C.byref(d), p(A), p(B), p(Cout), p(bias), p(ws), st()), what="bgemm")
     return Cout
 
 
@@ -136,7 +137,7 @@ def test_layernorm_bwd(M, H, res):
     close(dz, z.grad, 2e-5)
     out = torch.full((1, 2 * H), 1.0, device=DEV)
     ws = torch.empty(max(1, lib.fs2_op_col_sum_ws_bytes(nparts, 2 * H, 0) // 4), device=DEV)
-    _lib.check(lib.fs2_op_col_sum(p(part), p(out), p(ws), nparts, 2 * H, 2 * H, 0, 1, 1.0, st()))
+    _lib.check(lib.fs2_op_col_sum(F32, p(part), p(out), p(ws), nparts, 2 * H, 2 * H, 0, 1, 1.0, st()))
     close(out[0, :H] - 1.0, gam.grad, 2e-5)
     close(out[0, H:] - 1.0, bet.grad, 2e-5)
 
@@ -147,7 +148,7 @@ def test_col_sum_segments():
     out = torch.empty(6, 100, device=DEV)
     ws = torch.empty(lib.fs2_op_col_sum_ws_bytes(6 * 700, 100, 700) // 4, device=DEV)
     xd = x.to(DEV)
-    _lib.check(lib.fs2_op_col_sum(p(xd), p(out), p(ws), 6 * 700, 100, 100, 700, 0, 0.5, st()))
+    _lib.check(lib.fs2_op_col_sum(F32, p(xd), p(out), p(ws), 6 * 700, 100, 100, 700, 0, 0.5, st()))
     close(out, 0.5 * x.double().view(6, 700, 100).sum(1), 1e-5)
 
 
@@ -163,10 +164,10 @@ def test_softmax_fwd_bwd(B, heads, S):
     pr.backward(dp)
     sd = s.detach().float().to(DEV)
     padd = pad.to(torch.uint8).to(DEV)
-    _lib.check(lib.fs2_op_softmax_fwd(F32, p(sd), p(padd), B, heads, S, 0.3, st()))
+    _lib.check(lib.fs2_op_softmax_fwd(F32, p(sd), p(padd), p(sd), B, heads, S, 0.3, st()))
     close(sd, pr.detach(), 1e-5)
     dd = dp.float().to(DEV)
-    _lib.check(lib.fs2_op_softmax_bwd(F32, p(dd), p(sd), B, heads, S, 0.3, st()))
+    _lib.check(lib.fs2_op_softmax_bwd(F32, p(dd), p(sd), p(dd), B, heads, S, 0.3, st()))
     close(dd, s.grad, 2e-5)
 
 
@@ -181,7 +182,7 @@ def test_scatter_rows_and_regulate_bwd():
         i32 = idx.int().to(DEV) if kind == "i32" else None
         i64 = idx.to(DEV) if kind == "i64" else None
         xd = x.to(DEV)
-        _lib.check(lib.fs2_op_scatter_rows(p(xd), p(i32), p(i64), p(table), R, H, V, 0, st()))
+        _lib.check(lib.fs2_op_scatter_rows(F32, p(xd), p(i32), p(i64), p(table), R, H, V, 0, st()))
         want = torch.ones(V, H, dtype=torch.float64).index_add_(0, idx, x.double())
         want[0] = 1.0
         close(table, want, 1e-5)
@@ -192,7 +193,7 @@ def test_scatter_rows_and_regulate_bwd():
     dy = torch.randn(B * T, H, generator=g)
     dx = torch.empty(B * L, H, device=DEV)
     dyd, cumd = dy.to(DEV), cum.to(DEV)
-    _lib.check(lib.fs2_op_regulate_bwd(p(dyd), p(cumd), p(dx), B, L, T, H, st()))
+    _lib.check(lib.fs2_op_regulate_bwd(F32, p(dyd), p(cumd), p(dx), B, L, T, H, st()))
     want = torch.zeros(B, L, H, dtype=torch.float64)
     for b in range(B):
         t = 0
@@ -251,7 +252,105 @@ def test_ew_ops():
     a, b = torch.randn(5000), torch.randn(5000)
     out = torch.empty(5000, device=DEV)
     ad, bd = a.to(DEV), b.to(DEV)
-    _lib.check(lib.fs2_op_ew(0, p(ad), p(bd), p(out), 5000, 2.0, -1.0, st()))
+    _lib.check(lib.fs2_op_ew(F32, 0, p(ad), p(bd), p(out), 5000, 2.0, -1.0, st()))
     assert torch.equal(out.cpu(), 2.0 * a - b)
-    _lib.check(lib.fs2_op_ew(1, p(ad), p(bd), p(out), 5000, 0.0, 0.0, st()))
+    _lib.check(lib.fs2_op_ew(F32, 1, p(ad), p(bd), p(out), 5000, 0.0, 0.0, st()))
     assert torch.equal(out.cpu(), torch.where(b > 0, a, torch.zeros(())))
+
+
+# ---- bf16 operands (the mixed-precision training path): same products, inputs rounded to bf16, fp32 accumulation ----
+BF = _lib.FS2_BF16
+
+
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (200, 72, 50), (1, 1, 1), (513, 264, 136), (64, 300, 7)])
+def test_bgemm_bf16_layouts(M, N, K):
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    a, b = _bf(torch.randn(M, K, generator=g)), _bf(torch.randn(K, N, generator=g))
+    want = a.double() @ b.double()
+    bias = torch.randn(N, generator=g)
+    c = torch.empty(M, N, device=DEV)  # fp32 out
+    bgemm(dict(M=M, N=N, K=K, sAm=K, sAk=1, sBk=1, sBn=K, ldc=N), a.to(DEV), b.t().contiguous().to(DEV), c, bias.to(DEV), dtype=BF)
+    close(c, want + bias.double(), 1e-5)
+    c = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)  # bf16 out, NN
+    bgemm(dict(M=M, N=N, K=K, sAm=K, sAk=1, sBk=N, sBn=1, ldc=N), a.to(DEV), b.to(DEV), c, dtype=BF)
+    close(c, want, 5e-3)
+    for sk in (1, 3):  # TN
+        c = torch.full((M, N), 2.0, device=DEV)
+        bgemm(dict(M=M, N=N, K=K, sAm=1, sAk=M, sBk=N, sBn=1, ldc=N, splitk=sk, beta=1.0), a.t().contiguous().to(DEV), b.to(DEV), c, dtype=BF)
+        close(c, want + 2.0, 1e-5)
+
+
+@pytest.mark.parametrize("taps,Cin,N,S,B", [(9, 32, 48, 40, 3), (3, 24, 16, 11, 2), (5, 64, 136, 150, 2), (3, 20, 17, 11, 2)])
+def test_bgemm_bf16_conv_forms(taps, Cin, N, S, B):
+    g = torch.Generator().manual_seed(taps * 100 + Cin)
+    x = _bf(torch.randn(B, S, Cin, generator=g)).double().requires_grad_(True)
+    w = _bf(torch.randn(N, Cin, taps, generator=g)).double().requires_grad_(True)
+    y = F.conv1d(x.transpose(1, 2), w, padding="same").transpose(1, 2)
+    dy = _bf(torch.randn(B, S, N, generator=g)).double()
+    y.backward(dy)
+    pad = (taps - 1) // 2
+    w_tm = _bf(w.detach().permute(0, 2, 1).reshape(N, taps * Cin)).contiguous().to(DEV)
+    dyd = _bf(dy.reshape(B * S, N)).contiguous().to(DEV)
+    xd = _bf(x.detach().reshape(B * S, Cin)).contiguous().to(DEV)
+    dx = torch.empty(B * S, Cin, device=DEV)
+    bgemm(dict(M=B * S, N=Cin, K=taps * N, sAm=N, sAk=1, sBk=taps * Cin, sBn=1, ldc=Cin, seg=S, taps=taps, Kin=N,
+               a_shift0=pad, a_shift_step=-1, sBtap=Cin), dyd, w_tm, dx, dtype=BF)
+    close(dx, x.grad.reshape(B * S, Cin), 1e-5)
+    for sk in (1, 4):
+        dw = torch.zeros(N, taps * Cin, device=DEV)
+        bgemm(dict(M=N, N=Cin, K=B * S, sAm=1, sAk=N, sBk=Cin, sBn=1, ldc=taps * Cin, nb2=taps, sC2=Cin, seg=S,
+                   b_shift0=-pad, b_shift_step=1, splitk=sk), dyd, xd, dw, dtype=BF)
+        close(dw, w.grad.permute(0, 2, 1).reshape(N, taps * Cin), 1e-5)
+
+
+def test_row_ops_bf16():
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(9)
+    M, H = 300, 256
+    z, r, dy = (_bf(torch.randn(M, H, generator=g)) for _ in range(3))
+    gam = torch.randn(H, generator=g)
+    zz = (z.double() + r.double()).requires_grad_(True)
+    gg = gam.double().requires_grad_(True)
+    F.layer_norm(zz, (H,), gg, torch.zeros(H, dtype=torch.float64), 1e-5).backward(dy.double())
+    nparts = lib.fs2_op_layernorm_bwd_parts(M)
+    dz = torch.empty(M, H, device=DEV, dtype=torch.bfloat16)
+    part = torch.empty(nparts, 2, H, device=DEV)
+    zd, rd, dyd, gd = z.to(DEV), r.to(DEV), dy.to(DEV), gam.to(DEV)
+    _lib.check(lib.fs2_op_layernorm_bwd(BF, p(zd), p(rd), p(dyd), p(gd), p(dz), p(part), M, H, st()))
+    close(dz, zz.grad, 5e-3)
+    close(part.sum(0)[0], gg.grad, 1e-4)
+    # softmax: fp32 scores -> bf16 probabilities; fp32 dP + bf16 P -> bf16 dS
+    B, heads, S = 2, 2, 70
+    s = torch.randn(B, heads, S, S, generator=g)
+    pr = torch.softmax(0.5 * s.double(), dim=-1)
+    sd = s.to(DEV)
+    pd = torch.empty(B, heads, S, S, device=DEV, dtype=torch.bfloat16)
+    _lib.check(lib.fs2_op_softmax_fwd(BF, p(sd), None, p(pd), B, heads, S, 0.5, st()))
+    close(pd, pr, 5e-3)
+    dp = torch.randn(B, heads, S, S, generator=g)
+    prb = pd.cpu().double()
+    want = 0.5 * prb * (dp.double() - (dp.double() * prb).sum(-1, keepdim=True))
+    dpd = dp.to(DEV)
+    ds = torch.empty_like(pd)
+    _lib.check(lib.fs2_op_softmax_bwd(BF, p(dpd), p(pd), p(ds), B, heads, S, 0.5, st()))
+    close(ds, want, 5e-3)
+    # column sums / scatter / regulate / relu on bf16 inputs
+    x = _bf(torch.randn(1000, 72, generator=g))
+    xd = x.to(DEV)
+    out = torch.empty(1, 72, device=DEV)
+    ws = torch.empty(lib.fs2_op_col_sum_ws_bytes(1000, 72, 0) // 4, device=DEV)
+    _lib.check(lib.fs2_op_col_sum(BF, p(xd), p(out), p(ws), 1000, 72, 72, 0, 0, 1.0, st()))
+    close(out[0], x.double().sum(0), 1e-5)
+    idx = torch.randint(0, 20, (1000,), generator=g).int()
+    table = torch.zeros(20, 72, device=DEV)
+    idxd = idx.to(DEV)
+    _lib.check(lib.fs2_op_scatter_rows(BF, p(xd), p(idxd), None, p(table), 1000, 72, 20, -1, st()))
+    close(table, torch.zeros(20, 72, dtype=torch.float64).index_add_(0, idx.long(), x.double()), 1e-5)
+    y = _bf(torch.randn(1000, 72, generator=g)).to(DEV)
+    o2 = torch.empty_like(xd)
+    _lib.check(lib.fs2_op_ew(BF, 1, p(xd), p(y), p(o2), 1000 * 72, 0.0, 0.0, st()))
+    assert torch.equal(o2.cpu(), torch.where(y.cpu() > 0, x, torch.zeros((), dtype=torch.bfloat16)))
