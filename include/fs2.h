@@ -286,11 +286,13 @@ typedef struct fs2_bgemm_desc {
 size_t fs2_op_bgemm_ws_bytes(const fs2_bgemm_desc* d);  /* split-K slabs (0 when splitk <= 1) */
 int fs2_op_bgemm(int32_t dtype, const fs2_bgemm_desc* d, const void* A, const void* B, void* C, const float* bias,
                  float* ws, void* hip_stream);
-/* LayerNorm backward of y = LN(z [+ res]) * gamma + beta: dz (M, H); part = (fs2_op_layernorm_bwd_parts(M), 2, H) partial
- * column sums of dy * zhat and dy, to be reduced with fs2_op_col_sum over the parts -> dgamma, dbeta */
+/* LayerNorm backward of y = LN(z [+ res]) * gamma + beta: dz (M, H); relu_mask = 1 when z is a ReLU output and dz should be
+ * the gradient of the pre-activation (dz zeroed where z <= 0).  part = (fs2_op_layernorm_bwd_parts(M), 3, H) partial column
+ * sums of dy * zhat, dy and dz, to be reduced with fs2_op_col_sum over the parts -> dgamma, dbeta and the bias gradient of
+ * the layer that produced z.  H % 4 == 0, H <= 1024. */
 int32_t fs2_op_layernorm_bwd_parts(int32_t M);
 int fs2_op_layernorm_bwd(int32_t dtype, const void* z, const void* res, const void* dy, const float* gamma, void* dz,
-                         float* part, int32_t M, int32_t H, void* hip_stream);
+                         float* part, int32_t M, int32_t H, int32_t relu_mask, void* hip_stream);
 /* out[s][n] (+)= scale * sum over the rows of segment s of x[row][n]; seg = rows per segment (0: one segment) */
 size_t fs2_op_col_sum_ws_bytes(int32_t M, int32_t N, int32_t seg);
 int fs2_op_col_sum(int32_t dtype, const void* x, float* out, float* ws, int32_t M, int32_t N, int32_t ldx, int32_t seg,

@@ -10,125 +10,261 @@ namespace fs2 {
 
 namespace {
 
+template <typename T> __device__ inline void ld4(const T* p, float* f);
+template <> __device__ inline void ld4<float>(const float* p, float* f) {
+    const float4 v = *(const float4*)p;
+    f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+}
+template <> __device__ inline void ld4<bf16>(const bf16* p, float* f) {
+    const uint2 v = *(const uint2*)p;
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+template <typename T> __device__ inline void st4(T* p, const float* f);
+template <> __device__ inline void st4<float>(float* p, const float* f) { *(float4*)p = make_float4(f[0], f[1], f[2], f[3]); }
+template <> __device__ inline void st4<bf16>(bf16* p, const float* f) {
+    *(uint2*)p = make_uint2(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]));
+}
+
 // ---- LayerNorm backward -------------------------------------------------------------------------------------------
 // y = (z - mean) * rstd * gamma + beta.  dz = rstd * (g - mean(g) - zhat * mean(g * zhat)), g = dy * gamma.
-// One wave per row, 4 waves per workgroup, LN_ROWS rows per workgroup; the column sums of dy * zhat and dy are kept
-// per lane in registers over the workgroup's rows and leave as one partial per workgroup.
-constexpr int LN_ROWS = 64;
-constexpr int LN_MAXC = 16;  // columns per lane: H <= 64 * 16
+// One wave per row, 4 waves per workgroup, LN_ROWS rows per workgroup, a lane owns 4 consecutive columns of every
+// 256-column chunk (8- / 16-byte accesses); the column sums of dy * zhat, dy and (optionally ReLU-masked) dz are kept in
+// registers over the workgroup's rows and leave as one partial per workgroup: (dgamma, dbeta, dbias of the layer below).
+constexpr int LN_ROWS = 32;
+constexpr int LN_MAXC = 4;  // 256-column chunks: H <= 1024
 
-template <typename T>
+template <typename T, int NC>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(LayerNormBwdArgs p) {
-    __shared__ float red[4][2][64 * LN_MAXC];
+    __shared__ float red[4][3][256 * NC];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const T* z = (const T*)p.z;
     const T* zr = (const T*)p.res;
     const T* dy = (const T*)p.dy;
     T* dz = (T*)p.dz;
     const int H = p.H;
-    const int nc = (H + 63) / 64;
-    float dg[LN_MAXC], db[LN_MAXC], gam[LN_MAXC];
+    float dg[NC][4], db[NC][4], dc[NC][4], gam[NC][4];
 #pragma unroll
-    for (int j = 0; j < LN_MAXC; ++j) {
-        dg[j] = db[j] = 0.f;
-        const int c = lane + 64 * j;
-        gam[j] = (j < nc && c < H) ? p.gamma[c] : 0.f;
-    }
+    for (int j = 0; j < NC; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            dg[j][e] = db[j][e] = dc[j][e] = 0.f;
+            const int c = j * 256 + lane * 4 + e;
+            gam[j][e] = c < H ? p.gamma[c] : 0.f;
+        }
     const int row0 = blockIdx.x * LN_ROWS;
+    const float invH = 1.f / H;
     for (int rr = wid; rr < LN_ROWS; rr += 4) {
         const int row = row0 + rr;
         if (row >= p.M) break;
-        float zv[LN_MAXC], dv[LN_MAXC];
+        float zv[NC][4], dv[NC][4];
         float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < LN_MAXC; ++j) {
-            const int c = lane + 64 * j;
-            const bool ok = j < nc && c < H;
-            zv[j] = ok ? Num<T>::to_f32(z[(long)row * H + c]) + (zr ? Num<T>::to_f32(zr[(long)row * H + c]) : 0.f) : 0.f;
-            dv[j] = ok ? Num<T>::to_f32(dy[(long)row * H + c]) : 0.f;
-            s += zv[j];
-        }
-        const float mean = wave_sum(s) / H;
-        float q = 0.f;
+        for (int j = 0; j < NC; ++j) {
+            const int c = j * 256 + lane * 4;
+            if (c < H) {
+                ld4<T>(z + (long)row * H + c, zv[j]);
+                ld4<T>(dy + (long)row * H + c, dv[j]);
+                if (zr) {
+                    float r[4];
+                    ld4<T>(zr + (long)row * H + c, r);
 #pragma unroll
-        for (int j = 0; j < LN_MAXC; ++j) {
-            const int c = lane + 64 * j;
-            const float d = (j < nc && c < H) ? zv[j] - mean : 0.f;
-            zv[j] = d;
-            q += d * d;
+                    for (int e = 0; e < 4; ++e) zv[j][e] += r[e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) zv[j][e] = dv[j][e] = 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s += zv[j][e];
         }
-        const float rstd = rsqrtf(wave_sum(q) / H + p.eps);
+        const float mean = wave_sum(s) * invH;
+        float q = 0.f;
+        bool pos[NC][4];
+#pragma unroll
+        for (int j = 0; j < NC; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                pos[j][e] = zv[j][e] > 0.f;  // z is a ReLU output when relu_mask is set
+                const float d = (j * 256 + lane * 4 + e < H) ? zv[j][e] - mean : 0.f;
+                zv[j][e] = d;
+                q += d * d;
+            }
+        const float rstd = rsqrtf(wave_sum(q) * invH + p.eps);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < LN_MAXC; ++j) {
-            zv[j] *= rstd;  // zhat
-            const float g = dv[j] * gam[j];
-            s1 += g;
-            s2 += g * zv[j];
-            dg[j] += dv[j] * zv[j];
-            db[j] += dv[j];
-        }
-        s1 = wave_sum(s1) / H;
-        s2 = wave_sum(s2) / H;
+        for (int j = 0; j < NC; ++j)
 #pragma unroll
-        for (int j = 0; j < LN_MAXC; ++j) {
-            const int c = lane + 64 * j;
-            if (j < nc && c < H) dz[(long)row * H + c] = Num<T>::from_f32(rstd * (dv[j] * gam[j] - s1 - zv[j] * s2));
+            for (int e = 0; e < 4; ++e) {
+                zv[j][e] *= rstd;  // zhat
+                const float g = dv[j][e] * gam[j][e];
+                s1 += g;
+                s2 += g * zv[j][e];
+                dg[j][e] += dv[j][e] * zv[j][e];
+                db[j][e] += dv[j][e];
+            }
+        s1 = wave_sum(s1) * invH;
+        s2 = wave_sum(s2) * invH;
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = rstd * (dv[j][e] * gam[j][e] - s1 - zv[j][e] * s2);
+                if (p.relu_mask && !pos[j][e]) v = 0.f;
+                v = Num<T>::to_f32(Num<T>::from_f32(v));  // the column sum is of the stored value
+                o[e] = v;
+                dc[j][e] += v;
+            }
+            const int c = j * 256 + lane * 4;
+            if (c < H) st4<T>(dz + (long)row * H + c, o);
         }
     }
 #pragma unroll
-    for (int j = 0; j < LN_MAXC; ++j) {
-        red[wid][0][lane + 64 * j] = dg[j];
-        red[wid][1][lane + 64 * j] = db[j];
-    }
+    for (int j = 0; j < NC; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            red[wid][0][j * 256 + lane * 4 + e] = dg[j][e];
+            red[wid][1][j * 256 + lane * 4 + e] = db[j][e];
+            red[wid][2][j * 256 + lane * 4 + e] = dc[j][e];
+        }
     __syncthreads();
-    for (int c = threadIdx.x; c < H; c += 256) {
-        float a = 0.f, b = 0.f;
+    for (int c = threadIdx.x; c < H; c += 256)
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            a += red[w][0][c];
-            b += red[w][1][c];
-        }
-        p.part[((long)blockIdx.x * 2 + 0) * H + c] = a;
-        p.part[((long)blockIdx.x * 2 + 1) * H + c] = b;
-    }
+        for (int k = 0; k < 3; ++k)
+            p.part[((long)blockIdx.x * 3 + k) * H + c] = (red[0][k][c] + red[1][k][c]) + (red[2][k][c] + red[3][k][c]);
 }
 
 // ---- column sums ----------------------------------------------------------------------------------------------------
-// out[s][n] (+)= scale * sum_{rows of segment s} x[row][n].  Pass 1: a workgroup owns 64 columns x one row chunk of one
-// segment (4 row groups x 64 lanes, fixed order), partials to ws; pass 2 adds the chunks in index order.
-constexpr int CS_CHUNK = 512;  // rows per pass-1 workgroup
+// out[s][n] (+)= scale * sum_{rows of segment s} x[row][n].  Pass 1: a workgroup owns 64 columns x one chunk of CS_CHUNK
+// rows of one segment (4 row groups x 64 lanes, 8 loads in flight per thread, fixed order), partials to ws; pass 2: one
+// workgroup per (64 columns, segment) adds the chunk partials the same way.
+constexpr int CS_CHUNK = 128;
+
+template <typename T>
+__device__ inline float cs_accumulate(const T* x, long ldx, int c, int r0, int r1, int g) {
+    float a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = 0.f;
+    int r = r0 + g;
+    for (; r + 28 < r1; r += 32)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] += Num<T>::to_f32(x[(long)(r + 4 * u) * ldx + c]);
+    for (; r < r1; r += 4) a[0] += Num<T>::to_f32(x[(long)r * ldx + c]);
+    return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void col_sum_pass1(ColSumArgs p, int nchunk) {
     __shared__ float red[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    const int l = threadIdx.x & 63, c = blockIdx.x * 64 + l, g = threadIdx.x >> 6;
     const int chunk = blockIdx.y, s = blockIdx.z;
     const int seg = p.seg > 0 ? p.seg : p.M;
     const int r0 = chunk * CS_CHUNK, r1 = min(seg, r0 + CS_CHUNK);
-    float a = 0.f;
-    if (c < p.N)
-        for (int r = r0 + g; r < r1; r += 4) a += Num<T>::to_f32(((const T*)p.x)[((long)s * seg + r) * p.ldx + c]);
-    red[g][threadIdx.x & 63] = a;
+    red[g][l] = c < p.N ? cs_accumulate<T>((const T*)p.x + (long)s * seg * p.ldx, p.ldx, c, r0, r1, g) : 0.f;
+    __syncthreads();
+    if (g == 0 && c < p.N) p.ws[((long)s * nchunk + chunk) * p.N + c] = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+}
+__global__ __launch_bounds__(256) void col_sum_pass2(ColSumArgs p, int nchunk) {
+    __shared__ float red[4][64];
+    const int l = threadIdx.x & 63, c = blockIdx.x * 64 + l, g = threadIdx.x >> 6, s = blockIdx.y;
+    red[g][l] = c < p.N ? cs_accumulate<float>(p.ws + (long)s * nchunk * p.N, p.N, c, 0, nchunk, g) : 0.f;
     __syncthreads();
     if (g == 0 && c < p.N) {
-        const int l = threadIdx.x;
-        p.ws[((long)s * nchunk + chunk) * p.N + c] = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+        const float a = ((red[0][l] + red[1][l]) + (red[2][l] + red[3][l])) * p.scale;
+        float* o = p.out + (long)s * p.N + c;
+        *o = p.accumulate ? *o + a : a;
     }
-}
-__global__ void col_sum_pass2(ColSumArgs p, int nchunk) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x, s = blockIdx.y;
-    if (c >= p.N) return;
-    float a = 0.f;
-    for (int k = 0; k < nchunk; ++k) a += p.ws[((long)s * nchunk + k) * p.N + c];
-    a *= p.scale;
-    float* o = p.out + (long)s * p.N + c;
-    *o = p.accumulate ? *o + a : a;
 }
 
 // ---- masked softmax over the key axis (training path: probabilities are materialised; HBM is 288 GB) --------------
 // one wave per (b, head, query) row.  Scores and dP are fp32 (the GEMM that makes them writes fp32 in either precision
 // mode); probabilities and dS are in the activation dtype T (they are MFMA operands next).  p / out may alias s for fp32.
+// single pass: the row (S <= 256 * NV floats, S % 4 == 0) stays in registers, 16-byte loads
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void softmax_fwd_row_kernel(SoftmaxArgs p) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long rows = (long)p.B * p.heads * p.S;
+    if (row >= rows) return;
+    const int b = (int)(row / ((long)p.heads * p.S));
+    const float* s = p.s + row * p.S;
+    T* out = (T*)p.out + row * p.S;
+    const uint8_t* pad = p.key_pad ? p.key_pad + (long)b * p.S : nullptr;
+    float v[NV][4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int k = j * 256 + lane * 4;
+        if (k < p.S) {
+            ld4<float>(s + k, v[j]);
+            const uint32_t pm = pad ? *(const uint32_t*)(pad + k) : 0u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[j][e] = ((pm >> (8 * e)) & 0xffu) ? -INFINITY : v[j][e] * p.scale;
+                mx = fmaxf(mx, v[j][e]);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[j][e] = -INFINITY;
+        }
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[j][e] = v[j][e] == -INFINITY ? 0.f : expf(v[j][e] - mx);
+            sum += v[j][e];
+        }
+    const float inv = 1.f / wave_sum(sum);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int k = j * 256 + lane * 4;
+        if (k < p.S) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[j][e] *= inv;
+            st4<T>(out + k, v[j]);
+        }
+    }
+}
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void softmax_bwd_row_kernel(SoftmaxArgs p) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long rows = (long)p.B * p.heads * p.S;
+    if (row >= rows) return;
+    const float* d = p.s + row * p.S;
+    const T* pr = (const T*)p.p + row * p.S;
+    T* out = (T*)p.out + row * p.S;
+    float dv[NV][4], pv[NV][4];
+    float dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int k = j * 256 + lane * 4;
+        if (k < p.S) {
+            ld4<float>(d + k, dv[j]);
+            ld4<T>(pr + k, pv[j]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dv[j][e] = pv[j][e] = 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dot += dv[j][e] * pv[j][e];
+    }
+    dot = wave_sum(dot);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int k = j * 256 + lane * 4;
+        if (k < p.S) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dv[j][e] = p.scale * pv[j][e] * (dv[j][e] - dot);
+            st4<T>(out + k, dv[j]);
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(SoftmaxArgs p) {
     const int lane = threadIdx.x & 63;
@@ -314,10 +450,13 @@ inline int ok() { return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
 int layernorm_bwd_parts(int M) { return (M + LN_ROWS - 1) / LN_ROWS; }
 
 int launch_layernorm_bwd(const LayerNormBwdArgs& a, int dtype, hipStream_t stream) {
-    if ((dtype != FS2_F32 && dtype != FS2_BF16) || a.H > 64 * LN_MAXC || a.M <= 0) return FS2_ERR_SHAPE;
-    if (a.nparts != layernorm_bwd_parts(a.M)) return FS2_ERR_ARG;
-    if (dtype == FS2_F32) hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(a.nparts), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(layernorm_bwd_kernel<bf16>, dim3(a.nparts), dim3(256), 0, stream, a);
+    if ((dtype != FS2_F32 && dtype != FS2_BF16) || a.H > 256 * LN_MAXC || a.M <= 0) return FS2_ERR_SHAPE;
+    if (a.nparts != layernorm_bwd_parts(a.M) || a.H % 4) return FS2_ERR_ARG;
+    const int nc = (a.H + 255) / 256;
+#define FS2_LNB(T, NC) hipLaunchKernelGGL((layernorm_bwd_kernel<T, NC>), dim3(a.nparts), dim3(256), 0, stream, a)
+    if (dtype == FS2_F32) { if (nc == 1) FS2_LNB(float, 1); else if (nc == 2) FS2_LNB(float, 2); else if (nc == 3) FS2_LNB(float, 3); else FS2_LNB(float, 4); }
+    else { if (nc == 1) FS2_LNB(bf16, 1); else if (nc == 2) FS2_LNB(bf16, 2); else if (nc == 3) FS2_LNB(bf16, 3); else FS2_LNB(bf16, 4); }
+#undef FS2_LNB
     return ok();
 }
 
@@ -332,7 +471,7 @@ int launch_col_sum(const ColSumArgs& a, int dtype, hipStream_t stream) {
     const dim3 g1((a.N + 63) / 64, nchunk, nseg);
     if (dtype == FS2_BF16) hipLaunchKernelGGL(col_sum_pass1<bf16>, g1, dim3(256), 0, stream, a, nchunk);
     else hipLaunchKernelGGL(col_sum_pass1<float>, g1, dim3(256), 0, stream, a, nchunk);
-    hipLaunchKernelGGL(col_sum_pass2, dim3((a.N + 255) / 256, nseg), dim3(256), 0, stream, a, nchunk);
+    hipLaunchKernelGGL(col_sum_pass2, dim3((a.N + 63) / 64, nseg), dim3(256), 0, stream, a, nchunk);
     return ok();
 }
 
@@ -340,7 +479,12 @@ int launch_softmax_fwd(const SoftmaxArgs& a, int dtype, hipStream_t stream) {
     if (dtype != FS2_F32 && dtype != FS2_BF16) return FS2_ERR_SHAPE;
     const long rows = (long)a.B * a.heads * a.S;
     const dim3 g((unsigned)((rows + 3) / 4));
-    if (dtype == FS2_F32) hipLaunchKernelGGL(softmax_fwd_kernel<float>, g, dim3(256), 0, stream, a);
+    const bool row_ok = a.S % 4 == 0 && a.S <= 2048 && ((uintptr_t)a.s & 15) == 0 && ((uintptr_t)a.out & 7) == 0;
+#define FS2_SMF(T, NV) hipLaunchKernelGGL((softmax_fwd_row_kernel<T, NV>), g, dim3(256), 0, stream, a)
+    if (row_ok && dtype == FS2_F32) { if (a.S <= 256) FS2_SMF(float, 1); else if (a.S <= 512) FS2_SMF(float, 2); else if (a.S <= 1024) FS2_SMF(float, 4); else FS2_SMF(float, 8); }
+    else if (row_ok) { if (a.S <= 256) FS2_SMF(bf16, 1); else if (a.S <= 512) FS2_SMF(bf16, 2); else if (a.S <= 1024) FS2_SMF(bf16, 4); else FS2_SMF(bf16, 8); }
+#undef FS2_SMF
+    else if (dtype == FS2_F32) hipLaunchKernelGGL(softmax_fwd_kernel<float>, g, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(softmax_fwd_kernel<bf16>, g, dim3(256), 0, stream, a);
     return ok();
 }
@@ -348,7 +492,12 @@ int launch_softmax_bwd(const SoftmaxArgs& a, int dtype, hipStream_t stream) {
     if (dtype != FS2_F32 && dtype != FS2_BF16) return FS2_ERR_SHAPE;
     const long rows = (long)a.B * a.heads * a.S;
     const dim3 g((unsigned)((rows + 3) / 4));
-    if (dtype == FS2_F32) hipLaunchKernelGGL(softmax_bwd_kernel<float>, g, dim3(256), 0, stream, a);
+    const bool row_ok = a.S % 4 == 0 && a.S <= 2048 && ((uintptr_t)a.s & 15) == 0 && ((uintptr_t)a.out & 7) == 0 && ((uintptr_t)a.p & 7) == 0;
+#define FS2_SMB(T, NV) hipLaunchKernelGGL((softmax_bwd_row_kernel<T, NV>), g, dim3(256), 0, stream, a)
+    if (row_ok && dtype == FS2_F32) { if (a.S <= 256) FS2_SMB(float, 1); else if (a.S <= 512) FS2_SMB(float, 2); else if (a.S <= 1024) FS2_SMB(float, 4); else FS2_SMB(float, 8); }
+    else if (row_ok) { if (a.S <= 256) FS2_SMB(bf16, 1); else if (a.S <= 512) FS2_SMB(bf16, 2); else if (a.S <= 1024) FS2_SMB(bf16, 4); else FS2_SMB(bf16, 8); }
+#undef FS2_SMB
+    else if (dtype == FS2_F32) hipLaunchKernelGGL(softmax_bwd_kernel<float>, g, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(softmax_bwd_kernel<bf16>, g, dim3(256), 0, stream, a);
     return ok();
 }

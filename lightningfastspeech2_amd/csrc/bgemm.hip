@@ -247,13 +247,16 @@ __global__ void bgemm_reduce_kernel(BGemmArgs p) {
 
 
 // ---- bf16 operands (the mixed-precision training path): MFMA 16x16x32, fp32 accumulation ---------------------------
-// 128 x 128 x 32 tiles, 4 waves (2 x 2).  Both operands live in LDS k-contiguous, [128 rows][32 k] bf16 with 80-byte
-// rows and the row's four 16-byte chunks XOR-ed with (row / 8) & 3, whatever their layout in memory: a k-contiguous
-// operand is copied chunk by chunk; an operand whose OUTER index is contiguous (the k-strided side of NN / TN products)
-// is transposed on the way in - a thread takes 8 outer positions of two consecutive k rows and writes eight packed
-// (k, k+1) pairs.  Fragments are then plain ds_read_b128.
-constexpr int HBK = 32, HLD = 40;
-constexpr int HOPSZ = BM * HLD;  // bf16 elements per operand buffer (10 KB)
+// 128 x 128 x 32 tiles, 4 waves (2 x 2).  Each operand is copied to LDS in its memory order with 16-byte vectors:
+//   k-contiguous operand  -> [128 rows][32 k] bf16, 80-byte rows, the row's four 16-byte chunks XOR-ed with (row / 8) & 3;
+//                            fragments by ds_read_b128;
+//   outer-contiguous operand (the k-strided side of NN / TN products) -> [32 k][128 outer] bf16, 288-byte rows; fragments by
+//                            two ds_read_b64_tr_b16 each: inside a 16-lane group lane i hands in the address of
+//                            [k0 + i/4][col0 + 4*(i%4)] and receives column col0 + i of that 4 x 16 block
+//                            (tools/probes/tr_read_probe.hip), i.e. four consecutive k of its own MFMA row / column.
+constexpr int HBK = 32, HLD = 40, HLDT = 144;
+constexpr int HOPSZ = BM * HLD;  // bf16 elements per operand buffer (10 KB; the transposed image needs 32 * 144)
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 
 struct OperandH {
     const unsigned short* p;
@@ -287,12 +290,10 @@ __device__ inline void load_tile_h(const OperandH& o, int k0, int Kend, uint4 (&
             }
             r[i] = ok ? load8(o.p + row * o.s_mn + gk, o.vec, Kend - gk) : make_uint4(0, 0, 0, 0);
         }
-    } else {  // outer-contiguous: k rows 2*kp, 2*kp + 1, outer positions mq*8 .. +7
-        const int kp = tid >> 4, mq = tid & 15;
-        const int gmn = o.mn0 + mq * 8;
+    } else {  // outer-contiguous: (k row, 8 outer positions)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int gk = k0 + 2 * kp + i;
+            const int v = tid + 256 * i, gk = k0 + (v >> 4), gmn = o.mn0 + (v & 15) * 8;
             bool ok = gk < Kend && gmn < o.MN;
             long krow = gk;
             if (o.seg && ok) {
@@ -314,16 +315,28 @@ __device__ inline void store_tile_h(unsigned short* s, bool kc, const uint4 (&r)
             *(uint4*)(s + row * HLD + ((ch ^ ((row >> 3) & 3)) << 3)) = r[i];
         }
     } else {
-        const int kp = tid >> 4, mq = tid & 15;
-        const uint32_t a[4] = {r[0].x, r[0].y, r[0].z, r[0].w}, b[4] = {r[1].x, r[1].y, r[1].z, r[1].w};
-        const int col = (((kp >> 2) ^ (mq & 3)) << 3) + (kp & 3) * 2;  // (row >> 3) & 3 == mq & 3 for the 8 rows of this thread
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const uint32_t lo = a[i >> 1], hi = b[i >> 1];
-            const uint32_t w = (i & 1) ? ((lo >> 16) | (hi & 0xffff0000u)) : ((lo & 0xffffu) | (hi << 16));
-            *(uint32_t*)(s + (mq * 8 + i) * HLD + col) = w;
+        for (int i = 0; i < 2; ++i) {
+            const int v = tid + 256 * i;
+            *(uint4*)(s + (v >> 4) * HLDT + (v & 15) * 8) = r[i];
         }
     }
+}
+
+// 8 consecutive k (k = 8*fg .. 8*fg + 7) of MFMA row / column `mn0 + fr`, from either LDS image
+__device__ inline uint4 frag_h(const unsigned short* s, bool kc, int mn0, int fr, int fg) {
+    if (kc) {
+        const int row = mn0 + fr;
+        return *(const uint4*)(s + row * HLD + ((fg ^ ((row >> 3) & 3)) << 3));
+    }
+    typedef __attribute__((address_space(3))) s16x4_t* lds_v4;
+    const unsigned short* a = s + (fg * 8 + (fr >> 2)) * HLDT + mn0 + (fr & 3) * 4;
+    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)a);
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(a + 4 * HLDT));
+    union { s16x4_t v[2]; uint4 u; } c;
+    c.v[0] = lo;
+    c.v[1] = hi;
+    return c.u;
 }
 
 template <typename OutT>
@@ -395,15 +408,9 @@ __global__ __launch_bounds__(256) void bgemm_bf16_kernel(BGemmArgs p) {
         const unsigned short* sb = lds[cur][1];
         uint4 a[4], b[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = wm * 64 + i * 16 + fr;
-            a[i] = *(const uint4*)(sa + row * HLD + ((fg ^ ((row >> 3) & 3)) << 3));
-        }
+        for (int i = 0; i < 4; ++i) a[i] = frag_h(sa, akc, wm * 64 + i * 16, fr, fg);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int row = wn * 64 + j * 16 + fr;
-            b[j] = *(const uint4*)(sb + row * HLD + ((fg ^ ((row >> 3) & 3)) << 3));
-        }
+        for (int j = 0; j < 4; ++j) b[j] = frag_h(sb, bkc, wn * 64 + j * 16, fr, fg);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll

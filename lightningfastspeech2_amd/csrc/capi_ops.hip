@@ -208,8 +208,8 @@ int fs2_op_bgemm(int32_t dtype, const fs2_bgemm_desc* d, const void* A, const vo
 }
 int32_t fs2_op_layernorm_bwd_parts(int32_t M) { return layernorm_bwd_parts(M); }
 int fs2_op_layernorm_bwd(int32_t dtype, const void* z, const void* res, const void* dy, const float* gamma, void* dz,
-                         float* part, int32_t M, int32_t H, void* stream) {
-    LayerNormBwdArgs a{z, res, dy, gamma, dz, part, M, H, layernorm_bwd_parts(M), 1e-5f};
+                         float* part, int32_t M, int32_t H, int32_t relu_mask, void* stream) {
+    LayerNormBwdArgs a{z, res, dy, gamma, dz, part, M, H, layernorm_bwd_parts(M), 1e-5f, relu_mask};
     return launch_layernorm_bwd(a, dtype, (hipStream_t)stream);
 }
 size_t fs2_op_col_sum_ws_bytes(int32_t M, int32_t N, int32_t seg) { return col_sum_ws_bytes(M, N, seg); }

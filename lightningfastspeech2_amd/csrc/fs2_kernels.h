@@ -301,9 +301,11 @@ struct LayerNormBwdArgs {
     const void* dy;       // (M, H)
     const float* gamma;   // (H)
     void* dz;             // (M, H) out
-    float* part;          // (nparts, 2, H) out: per-workgroup partial sums of dy * zhat and dy (-> col_sum -> dgamma, dbeta)
+    float* part;          // (nparts, 3, H) out: per-workgroup partial column sums of dy * zhat, dy and dz (-> col_sum -> dgamma,
+                          // dbeta, and the bias gradient of the linear / conv layer whose output z is)
     int M, H, nparts;
     float eps;
+    int relu_mask;        // 1: z is a ReLU output; dz := dz where z > 0 else 0 (the gradient of the PRE-activation)
 };
 int layernorm_bwd_parts(int M);
 int launch_layernorm_bwd(const LayerNormBwdArgs& a, int dtype, hipStream_t stream);

@@ -277,25 +277,36 @@ class Trainer:
         t.update(qkv=qkv, prob=prob, attn=attn, proj=proj, x1=x1, h=h, c2=c2, scale=scale)
         return x2, t
 
-    def _ln_bwd(self, z, res, dy, gname, bname, M, H):
+    def _ln_bwd(self, z, res, dy, gname, bname, M, H, bias_name=None, relu_mask=False):
+        """dz of y = LN(z [+ res]); dgamma / dbeta (adjacent in the flat buffer: one column-sum launch) and, when asked, the
+        bias gradient of the layer that produced z (= column sums of dz; with relu_mask dz is the pre-activation gradient)."""
         o = self.ops
         nparts = int(o.lib.fs2_op_layernorm_bwd_parts(M))
-        dz, part = o.act(M, H), o.empty(nparts, 2 * H)
-        o.ck(o.lib.fs2_op_layernorm_bwd(o.dt, _p(z), _p(res), _p(dy), _p(self.P[gname]), _p(dz), _p(part), M, H, o.st()), "layernorm_bwd")
-        o.col_sum(part, self.G[gname], nparts, H, ldx=2 * H)
-        o.col_sum(part[:, H:], self.G[bname], nparts, H, ldx=2 * H)
+        dz, part = o.act(M, H), o.empty(nparts, 3 * H)
+        o.ck(o.lib.fs2_op_layernorm_bwd(o.dt, _p(z), _p(res), _p(dy), _p(self.P[gname]), _p(dz), _p(part), M, H, int(relu_mask), o.st()),
+             "layernorm_bwd")
+        gw, gb = self.G[gname], self.G[bname]
+        if gb.data_ptr() == gw.data_ptr() + 4 * H:
+            o.col_sum(part, gw, nparts, 2 * H, ldx=3 * H)
+        else:
+            o.col_sum(part, gw, nparts, H, ldx=3 * H)
+            o.col_sum(part[:, H:], gb, nparts, H, ldx=3 * H)
+        if bias_name is not None:
+            o.col_sum(part[:, 2 * H:], self.G[bias_name], nparts, H, ldx=3 * H)
         return dz
 
     def _layer_bwd(self, dx2, t, prefix, B, S, heads, F_, k):
         o, P, W, G, H = self.ops, self.P, self.W, self.G, self.cfg.hidden
         M, d = B * S, H // heads
-        dx1 = self._ln_bwd(t["c2"], t["x1"], dx2, f"{prefix}.norm2.weight", f"{prefix}.norm2.bias", M, H)  # = dc2 too
-        o.wgrad(dx1, t["h"], G[f"{prefix}.conv2.weight"], G[f"{prefix}.conv2.bias"], M, H, F_)
+        dx1 = self._ln_bwd(t["c2"], t["x1"], dx2, f"{prefix}.norm2.weight", f"{prefix}.norm2.bias", M, H,
+                           bias_name=f"{prefix}.conv2.bias")  # = dc2 too
+        o.wgrad(dx1, t["h"], G[f"{prefix}.conv2.weight"], None, M, H, F_)
         dh = o.relu_bwd(o.dgrad(dx1, W[f"{prefix}.conv2.weight"], M, H, F_), t["h"])
         o.wgrad(dh, t["x1"], G[f"{prefix}.conv1.weight"], G[f"{prefix}.conv1.bias"], M, F_, H, taps=k, S=S)
         o.dgrad(dh, W[f"{prefix}.conv1.weight"], M, F_, H, taps=k, S=S, out=dx1, accumulate=True)
-        dx = self._ln_bwd(t["proj"], t["x"], dx1, f"{prefix}.norm1.weight", f"{prefix}.norm1.bias", M, H)  # = dproj too
-        o.wgrad(dx, t["attn"], G[f"{prefix}.self_attn.out_proj.weight"], G[f"{prefix}.self_attn.out_proj.bias"], M, H, H)
+        dx = self._ln_bwd(t["proj"], t["x"], dx1, f"{prefix}.norm1.weight", f"{prefix}.norm1.bias", M, H,
+                          bias_name=f"{prefix}.self_attn.out_proj.bias")  # = dproj too
+        o.wgrad(dx, t["attn"], G[f"{prefix}.self_attn.out_proj.weight"], None, M, H, H)
         dattn = o.dgrad(dx, W[f"{prefix}.self_attn.out_proj.weight"], M, H, H)
         qkv, prob = t["qkv"], t["prob"]
         dqkv = o.act(M, 3 * H)
@@ -350,8 +361,8 @@ class Trainer:
         for j in reversed(range(nlayers)):
             p = f"{prefix}.layers.{j}.layers"
             lt = t["layers"][j]
-            dc = o.relu_bwd(self._ln_bwd(lt["c"], None, dy, f"{p}.2.weight", f"{p}.2.bias", M, filt), lt["c"])
-            o.wgrad(dc, lt["xin"], G[f"{p}.0.module.weight"], G[f"{p}.0.module.bias"], M, filt, lt["cin"], taps=k, S=S)
+            dc = self._ln_bwd(lt["c"], None, dy, f"{p}.2.weight", f"{p}.2.bias", M, filt, bias_name=f"{p}.0.module.bias", relu_mask=True)
+            o.wgrad(dc, lt["xin"], G[f"{p}.0.module.weight"], None, M, filt, lt["cin"], taps=k, S=S)
             if j == 0:
                 o.dgrad(dc, W[f"{p}.0.module.weight"], M, filt, lt["cin"], taps=k, S=S, out=dx_out, accumulate=True)
             else:

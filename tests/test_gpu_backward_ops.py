@@ -119,7 +119,7 @@ def test_bgemm_conv_dgrad_and_wgrad(taps, Cin, N, S, B):
         close(dw, w.grad.permute(0, 2, 1).reshape(N, taps * Cin))
 
 
-@pytest.mark.parametrize("M,H,res", [(100, 256, True), (7, 48, False), (257, 768, True), (64, 1024, False)])
+@pytest.mark.parametrize("M,H,res", [(100, 256, True), (7, 48, False), (257, 768, True), (64, 1024, False), (33, 300, False)])
 def test_layernorm_bwd(M, H, res):
     lib = _lib.load()
     g = torch.Generator().manual_seed(M + H)
@@ -131,15 +131,21 @@ def test_layernorm_bwd(M, H, res):
     F.layer_norm(z + r if res else z, (H,), gam, bet, 1e-5).backward(dy)
     nparts = lib.fs2_op_layernorm_bwd_parts(M)
     dz = torch.empty(M, H, device=DEV)
-    part = torch.empty(nparts, 2, H, device=DEV)
+    part = torch.empty(nparts, 3, H, device=DEV)
     zd, rd, dyd, gd = z.detach().float().to(DEV), r.float().to(DEV) if res else None, dy.float().to(DEV), gam.detach().float().to(DEV)
-    _lib.check(lib.fs2_op_layernorm_bwd(F32, p(zd), p(rd), p(dyd), p(gd), p(dz), p(part), M, H, st()))
+    _lib.check(lib.fs2_op_layernorm_bwd(F32, p(zd), p(rd), p(dyd), p(gd), p(dz), p(part), M, H, 0, st()))
     close(dz, z.grad, 2e-5)
-    out = torch.full((1, 2 * H), 1.0, device=DEV)
-    ws = torch.empty(max(1, lib.fs2_op_col_sum_ws_bytes(nparts, 2 * H, 0) // 4), device=DEV)
-    _lib.check(lib.fs2_op_col_sum(F32, p(part), p(out), p(ws), nparts, 2 * H, 2 * H, 0, 1, 1.0, st()))
+    out = torch.full((1, 3 * H), 1.0, device=DEV)
+    ws = torch.empty(max(1, lib.fs2_op_col_sum_ws_bytes(nparts, 3 * H, 0) // 4), device=DEV)
+    _lib.check(lib.fs2_op_col_sum(F32, p(part), p(out), p(ws), nparts, 3 * H, 3 * H, 0, 1, 1.0, st()))
     close(out[0, :H] - 1.0, gam.grad, 2e-5)
-    close(out[0, H:] - 1.0, bet.grad, 2e-5)
+    close(out[0, H:2 * H] - 1.0, bet.grad, 2e-5)
+    close(out[0, 2 * H:] - 1.0, z.grad.sum(0), 5e-5)
+    if not res:  # relu_mask: z doubles as a ReLU output - dz is zeroed where z <= 0, and so is its column sum
+        _lib.check(lib.fs2_op_layernorm_bwd(F32, p(zd), None, p(dyd), p(gd), p(dz), p(part), M, H, 1, st()))
+        want = torch.where(z.detach() > 0, z.grad, torch.zeros((), dtype=torch.float64))
+        close(dz, want, 2e-5)
+        close(part.sum(0)[2], want.sum(0), 5e-5)
 
 
 def test_col_sum_segments():
@@ -318,9 +324,9 @@ def test_row_ops_bf16():
     F.layer_norm(zz, (H,), gg, torch.zeros(H, dtype=torch.float64), 1e-5).backward(dy.double())
     nparts = lib.fs2_op_layernorm_bwd_parts(M)
     dz = torch.empty(M, H, device=DEV, dtype=torch.bfloat16)
-    part = torch.empty(nparts, 2, H, device=DEV)
+    part = torch.empty(nparts, 3, H, device=DEV)
     zd, rd, dyd, gd = z.to(DEV), r.to(DEV), dy.to(DEV), gam.to(DEV)
-    _lib.check(lib.fs2_op_layernorm_bwd(BF, p(zd), p(rd), p(dyd), p(gd), p(dz), p(part), M, H, st()))
+    _lib.check(lib.fs2_op_layernorm_bwd(BF, p(zd), p(rd), p(dyd), p(gd), p(dz), p(part), M, H, 0, st()))
     close(dz, zz.grad, 5e-3)
     close(part.sum(0)[0], gg.grad, 1e-4)
     # softmax: fp32 scores -> bf16 probabilities; fp32 dP + bf16 P -> bf16 dS

@@ -82,6 +82,55 @@ def gemm_ln_case(name, M, N, Cin, taps, S, reps, variant, res=True, relu=False):
     lib.fs2_op_set_gemm_variant(0)
 
 
+def bgemm_case(name, dims, A, Bm, Cout, reps, **kw):
+    """One fs2_op_bgemm launch class of the training step's backward (bf16 operands unless the tensors are fp32)."""
+    d = _lib.BGemmDescC()
+    base = dict(nb1=1, nb2=1, alpha=1.0, beta=0.0, splitk=1, taps=1, c_dtype=_lib.FS2_F32 if Cout.dtype == torch.float32 else BF16)
+    base.update(kw)
+    for k, v in base.items():
+        setattr(d, k, v)
+    nb = lib.fs2_op_bgemm_ws_bytes(C.byref(d))
+    ws = torch.empty(max(1, nb // 4), device=DEV)
+    dt = _lib.FS2_F32 if A.dtype == torch.float32 else BF16
+    t = timeit(lambda st: lib.fs2_op_bgemm(dt, C.byref(d), p(A), p(Bm), p(Cout), None, p(ws), st), reps)
+    fl = 2.0 * dims
+    print(f"{name:34s} {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TF  ({fl/t/2.5e15*100:4.1f}% of 2.5 PF)")
+
+
+def bwd_cases(reps):
+    bf = torch.bfloat16
+    M, H, F, k = 49152, 256, 1024, 9
+    dy = torch.randn(M, F, device=DEV).to(bf)
+    x = torch.randn(M, H, device=DEV).to(bf)
+    w = torch.randn(F, k * H, device=DEV).to(bf)
+    dx = torch.empty(M, H, device=DEV, dtype=bf)
+    bgemm_case("conv1 k=9 dgrad (M,1024)->(M,256)", M * H * k * F, dy, w, dx, reps, M=M, N=H, K=k * F, sAm=F, sAk=1, sBk=k * H, sBn=1,
+               ldc=H, seg=1536, taps=k, Kin=F, a_shift0=4, a_shift_step=-1, sBtap=H)
+    dw = torch.zeros(F, k * H, device=DEV)
+    for sk in (1, 4, 16):
+        bgemm_case(f"conv1 k=9 wgrad splitk={sk}", M * H * k * F, dy, x, dw, reps, M=F, N=H, K=M, sAm=1, sAk=F, sBk=H, sBn=1, ldc=k * H,
+                   nb2=k, sC2=H, seg=1536, b_shift0=-4, b_shift_step=1, splitk=sk, beta=1.0)
+    dy2 = torch.randn(M, H, device=DEV).to(bf)
+    w2 = torch.randn(H, F, device=DEV).to(bf)
+    dh = torch.empty(M, F, device=DEV, dtype=bf)
+    bgemm_case("conv2 1x1 dgrad (M,256)->(M,1024)", M * H * F, dy2, w2, dh, reps, M=M, N=F, K=H, sAm=H, sAk=1, sBk=F, sBn=1, ldc=F)
+    dw2 = torch.zeros(H, F, device=DEV)
+    bgemm_case("conv2 1x1 wgrad splitk=16", M * H * F, dy2, dy, dw2, reps, M=H, N=F, K=M, sAm=1, sAk=H, sBk=F, sBn=1, ldc=F, splitk=16, beta=1.0)
+    B, S, heads, d = 32, 1536, 2, 128
+    qkv = torch.randn(B * S, 3 * H, device=DEV).to(bf)
+    sc = torch.empty(B, heads, S, S, device=DEV)
+    bat = dict(nb1=B, nb2=heads)
+    bgemm_case("attn scores QK^T -> fp32", B * heads * S * S * d, qkv, qkv[:, H:], sc, reps, M=S, N=S, K=d, sAm=3 * H, sAk=1, sBk=1, sBn=3 * H,
+               ldc=S, sA1=S * 3 * H, sA2=d, sB1=S * 3 * H, sB2=d, sC1=heads * S * S, sC2=S * S, **bat)
+    P = torch.randn(B, heads, S, S, device=DEV).to(bf)
+    o = torch.empty(B * S, H, device=DEV, dtype=bf)
+    bgemm_case("attn O = P V", B * heads * S * S * d, P, qkv[:, 2 * H:], o, reps, M=S, N=d, K=S, sAm=S, sAk=1, sBk=3 * H, sBn=1, ldc=H,
+               sA1=heads * S * S, sA2=S * S, sB1=S * 3 * H, sB2=d, sC1=S * H, sC2=d, **bat)
+    dqkv = torch.empty(B * S, 3 * H, device=DEV, dtype=bf)
+    bgemm_case("attn dV = P^T dO", B * heads * S * S * d, P, o, dqkv[:, 2 * H:], reps, M=S, N=d, K=S, sAm=1, sAk=S, sBk=H, sBn=1, ldc=3 * H,
+               sA1=heads * S * S, sA2=S * S, sB1=S * H, sB2=d, sC1=S * 3 * H, sC2=d, **bat)
+
+
 def predictor_case(name, B, S, nl, reps):
     """Whole dense VariancePredictor (nl x conv k=3 + ReLU + LN, head) as one launch."""
     H, k = 256, 3
@@ -174,6 +223,8 @@ def main():
                 gemm_ln_case("c5 dec conv2 +res+LN", 12288, 1024, 4096, 1, 12288, a.reps, v)
                 gemm_ln_case("c5 pred conv k=3 +relu+LN", 12288, 1024, 1024, 3, 1536, a.reps, v, res=False, relu=True)
         lib.fs2_op_set_gemm_variant(301)
+    if a.what in ("bwd",):
+        bwd_cases(a.reps)
     if a.what in ("pred", "all"):
         predictor_case("variance predictor fused", 32, 1536, 5, a.reps)
         predictor_case("duration predictor fused", 32, 256, 2, a.reps)
