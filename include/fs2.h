@@ -317,6 +317,9 @@ int fs2_op_regulate_bwd(int32_t dtype, const void* dy, const int32_t* cum, void*
 int fs2_op_masked_loss_bwd(const float* pred, const void* truth, int32_t truth_kind, const uint8_t* pad_mask,
                            const float* stat, float* dpred, int64_t rows, int32_t inner, int32_t kind, float alpha,
                            void* hip_stream);
+/* the data-gradient kernel of a Conv1d / Linear: dst (Cin, taps*N), dst[ci][j'*N + n] = src[n][(taps-1-j')*Cin + ci] for
+ * src (N, taps*Cin) tap-major, so that dX = fs2_op_gemm(x = dY, w = dst, M, N = Cin, Cin = N, taps, S) */
+int fs2_op_transpose_weight(int32_t dtype, const void* src, void* dst, int32_t N, int32_t Cin, int32_t taps, void* hip_stream);
 /* out[0] = sum of squares of x (fp64 partials, fixed order) */
 size_t fs2_op_sum_sq_ws_bytes(size_t n);
 int fs2_op_sum_sq(const float* x, size_t n, float* ws, float* out, void* hip_stream);

@@ -161,6 +161,7 @@ def load():
     lib.fs2_op_scatter_rows.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     lib.fs2_op_regulate_bwd.argtypes = [i32, vp, vp, vp, i32, i32, i32, i32, vp]
     lib.fs2_op_masked_loss_bwd.argtypes = [vp, vp, i32, vp, vp, vp, C.c_int64, i32, i32, f32, vp]
+    lib.fs2_op_transpose_weight.argtypes = [i32, vp, vp, i32, i32, i32, vp]
     lib.fs2_op_sum_sq_ws_bytes.restype = sz
     lib.fs2_op_sum_sq_ws_bytes.argtypes = [sz]
     lib.fs2_op_sum_sq.argtypes = [vp, sz, vp, vp, vp]

@@ -443,9 +443,34 @@ __global__ void adamw_kernel(AdamWArgs p) {
     }
 }
 
+// ---- weights for the data-gradient convolution: dst[ci][j' * N + n] = src[n][(taps - 1 - j') * Cin + ci] -------------
+// (the transposed, tap-flipped kernel: dX = conv(dY, dst) with the forward GEMM / slab-conv kernels).  32 x 32 LDS tiles.
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_weight_kernel(TransposeWeightArgs p) {
+    __shared__ T tile[32][33];
+    const int tap = blockIdx.z, n0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const T* src = (const T*)p.src + (long)tap * p.Cin;
+    T* dst = (T*)p.dst + (long)(p.taps - 1 - tap) * p.N;
+    for (int r = ty; r < 32; r += 8)
+        if (n0 + r < p.N && c0 + tx < p.Cin) tile[r][tx] = src[(long)(n0 + r) * p.taps * p.Cin + c0 + tx];
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8)
+        if (c0 + r < p.Cin && n0 + tx < p.N) dst[(long)(c0 + r) * p.taps * p.N + n0 + tx] = tile[tx][r];
+}
+
 inline int ok() { return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP; }
 
 }  // namespace
+
+int launch_transpose_weight(const TransposeWeightArgs& a, int dtype, hipStream_t stream) {
+    if (a.N <= 0 || a.Cin <= 0 || a.taps <= 0) return FS2_ERR_SHAPE;
+    const dim3 g((a.Cin + 31) / 32, (a.N + 31) / 32, a.taps);
+    if (dtype == FS2_BF16) hipLaunchKernelGGL(transpose_weight_kernel<bf16>, g, dim3(256), 0, stream, a);
+    else if (dtype == FS2_F32) hipLaunchKernelGGL(transpose_weight_kernel<float>, g, dim3(256), 0, stream, a);
+    else return FS2_ERR_SHAPE;
+    return ok();
+}
 
 int layernorm_bwd_parts(int M) { return (M + LN_ROWS - 1) / LN_ROWS; }
 

@@ -249,6 +249,10 @@ int fs2_op_masked_loss_bwd(const float* pred, const void* truth, int32_t truth_k
     LossBwdArgs a{pred, truth, pad_mask, stat, dpred, rows, inner, kind, truth_kind, alpha};
     return launch_masked_loss_bwd(a, (hipStream_t)stream);
 }
+int fs2_op_transpose_weight(int32_t dtype, const void* src, void* dst, int32_t N, int32_t Cin, int32_t taps, void* stream) {
+    TransposeWeightArgs a{src, dst, N, Cin, taps};
+    return launch_transpose_weight(a, dtype, (hipStream_t)stream);
+}
 size_t fs2_op_sum_sq_ws_bytes(size_t n) { return sum_sq_ws_bytes(n); }
 int fs2_op_sum_sq(const float* x, size_t n, float* ws, float* out, void* stream) {
     return launch_sum_sq(x, n, ws, out, (hipStream_t)stream);

@@ -373,6 +373,13 @@ struct LossBwdArgs {         // gradient of alpha * mean over selected elements 
 };
 int launch_masked_loss_bwd(const LossBwdArgs& a, hipStream_t stream);
 
+struct TransposeWeightArgs {   // dst (Cin, taps*N) [ci][j'*N + n] = src (N, taps*Cin) [n][(taps-1-j')*Cin + ci]
+    const void* src;
+    void* dst;
+    int N, Cin, taps;
+};
+int launch_transpose_weight(const TransposeWeightArgs& a, int dtype, hipStream_t stream);
+
 struct AdamWArgs {
     float* p; const float* g; float* m; float* v;   // flat fp32 buffers of n elements
     size_t n;

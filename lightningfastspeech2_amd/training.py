@@ -22,6 +22,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from collections import OrderedDict
 from typing import Dict, Optional
 
@@ -125,7 +126,18 @@ class _Ops:
         return dy
 
     # y = x W^T + b backward pieces.  w is (N, taps*Cin) tap-major; x (M, Cin); dy (M, N); rows in utterances of S.
-    def dgrad(self, dy, w, M, N, Cin, taps=1, S=None, out=None, accumulate=False):
+    def dgrad(self, dy, w, M, N, Cin, taps=1, S=None, out=None, accumulate=False, wt=None):
+        """dX (M, Cin) = dY (M, N) . W: with the transposed / tap-flipped copy wt (Cin, taps*N) through the forward
+        GEMM / slab-conv kernel (dX is a 'same' conv of dY with wt), else through the strided-batched GEMM."""
+        if wt is not None and N % 64 == 0 and Cin % 64 == 0 and dy.dtype == wt.dtype:
+            dx = self.gemm(dy, wt, None, M, Cin, N, taps=taps, S=S)
+            if out is None:
+                return dx
+            if accumulate:
+                self.ck(self.lib.fs2_op_ew(self._dt(out), 0, _p(out), _p(dx), _p(out), out.numel(), C.c_float(1), C.c_float(1), self.st()), "add")
+            else:
+                out.copy_(dx)
+            return out
         dx = out if out is not None else self.act(M, Cin)
         beta = 1.0 if accumulate else 0.0
         if taps == 1:
@@ -196,6 +208,14 @@ class Trainer:
         else:
             self.flat_w = torch.zeros(off, device=self.dev, dtype=torch.bfloat16)
             self.W = {n: self.flat_w[o:o + int(np.prod(ks))].view(ks) for n, (o, ks, _) in self._layout.items()}
+        # transposed, tap-flipped copies of every GEMM weight (activation dtype): the data gradients run on the forward kernels
+        self.use_forward_dgrad = os.environ.get("FS2_TRAIN_DGRAD", "forward") == "forward"
+        self.flat_wt = torch.zeros(off, device=self.dev, dtype=self.ops.tdt)
+        self.WT = {}
+        for n, (o, ks, rs) in self._layout.items():
+            if n.endswith("weight") and len(ks) == 2 and ("embedding" not in n) and ("norm" not in n) and not n.endswith(".2.weight"):
+                taps = rs[2] if len(rs) == 3 else 1
+                self.WT[n] = self.flat_wt[o:o + int(np.prod(ks))].view(rs[1], taps * rs[0])
         self.buffers: Dict[str, torch.Tensor] = {}
         self.load_state_dict(state_dict)
         self.steps = 0          # optimizer steps taken
@@ -222,10 +242,18 @@ class Trainer:
         self._refresh_shadow()
 
     def _refresh_shadow(self):
-        if self.ops.dt != F32:
-            o = self.ops
-            with torch.cuda.device(self.dev):
+        o = self.ops
+        with torch.cuda.device(self.dev):
+            if o.dt != F32:
                 o.ck(o.lib.fs2_op_convert(F32, o.dt, _p(self.flat_p), _p(self.flat_w), self.n_flat, o.st()), "convert")
+            if self.use_forward_dgrad:
+                for n, wt in self.WT.items():
+                    _, _, rs = self._layout[n]
+                    taps = rs[2] if len(rs) == 3 else 1
+                    o.ck(o.lib.fs2_op_transpose_weight(o.dt, _p(self.W[n]), _p(wt), rs[0], rs[1], taps, o.st()), "transpose_weight")
+
+    def _wt(self, name):
+        return self.WT.get(name) if self.use_forward_dgrad else None
 
     def _to_ref_layout(self, name, t):
         _, ks, rs = self._layout[name]
@@ -301,13 +329,13 @@ class Trainer:
         dx1 = self._ln_bwd(t["c2"], t["x1"], dx2, f"{prefix}.norm2.weight", f"{prefix}.norm2.bias", M, H,
                            bias_name=f"{prefix}.conv2.bias")  # = dc2 too
         o.wgrad(dx1, t["h"], G[f"{prefix}.conv2.weight"], None, M, H, F_)
-        dh = o.relu_bwd(o.dgrad(dx1, W[f"{prefix}.conv2.weight"], M, H, F_), t["h"])
+        dh = o.relu_bwd(o.dgrad(dx1, W[f"{prefix}.conv2.weight"], M, H, F_, wt=self._wt(f"{prefix}.conv2.weight")), t["h"])
         o.wgrad(dh, t["x1"], G[f"{prefix}.conv1.weight"], G[f"{prefix}.conv1.bias"], M, F_, H, taps=k, S=S)
-        o.dgrad(dh, W[f"{prefix}.conv1.weight"], M, F_, H, taps=k, S=S, out=dx1, accumulate=True)
+        o.dgrad(dh, W[f"{prefix}.conv1.weight"], M, F_, H, taps=k, S=S, out=dx1, accumulate=True, wt=self._wt(f"{prefix}.conv1.weight"))
         dx = self._ln_bwd(t["proj"], t["x"], dx1, f"{prefix}.norm1.weight", f"{prefix}.norm1.bias", M, H,
                           bias_name=f"{prefix}.self_attn.out_proj.bias")  # = dproj too
         o.wgrad(dx, t["attn"], G[f"{prefix}.self_attn.out_proj.weight"], None, M, H, H)
-        dattn = o.dgrad(dx, W[f"{prefix}.self_attn.out_proj.weight"], M, H, H)
+        dattn = o.dgrad(dx, W[f"{prefix}.self_attn.out_proj.weight"], M, H, H, wt=self._wt(f"{prefix}.self_attn.out_proj.weight"))
         qkv, prob = t["qkv"], t["prob"]
         dqkv = o.act(M, 3 * H)
         bat = dict(nb1=B, nb2=heads)
@@ -328,7 +356,7 @@ class Trainer:
         o.bgemm(dp, qkv, dqkv[:, H:], M=S, N=d, K=S, sAm=1, sAk=S, sBk=3 * H, sBn=1, ldc=3 * H, sB1=S * 3 * H, sB2=d,
                 sC1=S * 3 * H, sC2=d, **bat, **sP)
         o.wgrad(dqkv, t["x"], G[f"{prefix}.self_attn.in_proj_weight"], G[f"{prefix}.self_attn.in_proj_bias"], M, 3 * H, H)
-        o.dgrad(dqkv, W[f"{prefix}.self_attn.in_proj_weight"], M, 3 * H, H, out=dx, accumulate=True)
+        o.dgrad(dqkv, W[f"{prefix}.self_attn.in_proj_weight"], M, 3 * H, H, out=dx, accumulate=True, wt=self._wt(f"{prefix}.self_attn.in_proj_weight"))
         return dx
 
     # ---- VariancePredictor (model.py:482-561, dense) ----
@@ -364,9 +392,9 @@ class Trainer:
             dc = self._ln_bwd(lt["c"], None, dy, f"{p}.2.weight", f"{p}.2.bias", M, filt, bias_name=f"{p}.0.module.bias", relu_mask=True)
             o.wgrad(dc, lt["xin"], G[f"{p}.0.module.weight"], None, M, filt, lt["cin"], taps=k, S=S)
             if j == 0:
-                o.dgrad(dc, W[f"{p}.0.module.weight"], M, filt, lt["cin"], taps=k, S=S, out=dx_out, accumulate=True)
+                o.dgrad(dc, W[f"{p}.0.module.weight"], M, filt, lt["cin"], taps=k, S=S, out=dx_out, accumulate=True, wt=self._wt(f"{p}.0.module.weight"))
             else:
-                dy = o.dgrad(dc, W[f"{p}.0.module.weight"], M, filt, lt["cin"], taps=k, S=S)
+                dy = o.dgrad(dc, W[f"{p}.0.module.weight"], M, filt, lt["cin"], taps=k, S=S, wt=self._wt(f"{p}.0.module.weight"))
 
     def _loss(self, name, pred, truth, truth_kind, mask, rows, inner, kind, want_grad=True):
         o = self.ops
