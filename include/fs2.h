@@ -317,6 +317,21 @@ int fs2_op_regulate_bwd(int32_t dtype, const void* dy, const int32_t* cum, void*
 int fs2_op_masked_loss_bwd(const float* pred, const void* truth, int32_t truth_kind, const uint8_t* pad_mask,
                            const float* stat, float* dpred, int64_t rows, int32_t inner, int32_t kind, float alpha,
                            void* hip_stream);
+/* depth-wise Conv1d (model.py:75-81, 545-551) backward: data gradient = the same conv with the taps reversed and no bias;
+ * weight / bias gradient as per-chunk partials part (fs2_op_dwconv_wgrad_parts(B, S), C * (k + 1)): [c * k + j] then [C * k + c],
+ * reduced with fs2_op_col_sum into the adjacent (C, k) weight and (C) bias gradients */
+int fs2_op_dwconv_dgrad(int32_t dtype, const void* dy, const float* w, void* dx, int32_t B, int32_t S, int32_t C, int32_t k,
+                        void* hip_stream);
+int32_t fs2_op_dwconv_wgrad_parts(int32_t B, int32_t S);
+int fs2_op_dwconv_wgrad(int32_t dtype, const void* dy, const void* x, float* part, int32_t B, int32_t S, int32_t C, int32_t k,
+                        void* hip_stream);
+/* the depth-wise layer's conv2 = Sequential(grouped 1x1 conv, groups = H over F channels; pointwise F -> H) (model.py:84-93)
+ * as one linear map Wf (H, F) = W21 blockdiag(G), bf = b21 + W21 bg (what the inference engine folds once at load time), and
+ * the chain rule from (dWf, dbf) back to the four parameter gradients (accumulated) */
+int fs2_op_fold_conv2(int32_t wf_dtype, const float* G, const float* bg, const float* W21, const float* b21, void* Wf, float* bf,
+                      int32_t H, int32_t F, void* hip_stream);
+int fs2_op_unfold_conv2(const float* dWf, const float* dbf, const float* G, const float* bg, const float* W21, float* dG,
+                        float* dbg, float* dW21, float* db21, int32_t H, int32_t F, void* hip_stream);
 /* the data-gradient kernel of a Conv1d / Linear: dst (Cin, taps*N), dst[ci][j'*N + n] = src[n][(taps-1-j')*Cin + ci] for
  * src (N, taps*Cin) tap-major, so that dX = fs2_op_gemm(x = dY, w = dst, M, N = Cin, Cin = N, taps, S) */
 int fs2_op_transpose_weight(int32_t dtype, const void* src, void* dst, int32_t N, int32_t Cin, int32_t taps, void* hip_stream);

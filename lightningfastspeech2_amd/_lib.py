@@ -161,6 +161,12 @@ def load():
     lib.fs2_op_scatter_rows.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     lib.fs2_op_regulate_bwd.argtypes = [i32, vp, vp, vp, i32, i32, i32, i32, vp]
     lib.fs2_op_masked_loss_bwd.argtypes = [vp, vp, i32, vp, vp, vp, C.c_int64, i32, i32, f32, vp]
+    lib.fs2_op_dwconv_dgrad.argtypes = [i32, vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.fs2_op_dwconv_wgrad_parts.restype = i32
+    lib.fs2_op_dwconv_wgrad_parts.argtypes = [i32, i32]
+    lib.fs2_op_dwconv_wgrad.argtypes = [i32, vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.fs2_op_fold_conv2.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32, i32, vp]
+    lib.fs2_op_unfold_conv2.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]
     lib.fs2_op_transpose_weight.argtypes = [i32, vp, vp, i32, i32, i32, vp]
     lib.fs2_op_sum_sq_ws_bytes.restype = sz
     lib.fs2_op_sum_sq_ws_bytes.argtypes = [sz]

@@ -459,9 +459,124 @@ __global__ __launch_bounds__(256) void transpose_weight_kernel(TransposeWeightAr
         if (c0 + r < p.Cin && n0 + tx < p.N) dst[(long)(c0 + r) * p.taps * p.N + n0 + tx] = tile[tx][r];
 }
 
+// ---- depth-wise conv weight gradient -------------------------------------------------------------------------------
+// Workgroup = DWG_R rows x 64 channels of one utterance: dy tile and the (DWG_R + k - 1)-row x slab in LDS (fp32), a thread
+// owns one channel and every 4th row and keeps all k taps (+ the bias sum) in registers; the 4 row groups meet in LDS.
+constexpr int DWG_R = 128, DWG_KMAX = 32;
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_wgrad_kernel(DwConvWgradArgs p) {
+    __shared__ float xs[(DWG_R + DWG_KMAX - 1) * 64];
+    __shared__ float ds[DWG_R * 64];
+    const int tid = threadIdx.x, c = tid & 63, g = tid >> 6;
+    const int t0 = blockIdx.x * DWG_R, c0 = blockIdx.y * 64, b = blockIdx.z;
+    const int nchunk = gridDim.x;
+    const T* x = (const T*)p.x + (size_t)b * p.S * p.C;
+    const T* dy = (const T*)p.dy + (size_t)b * p.S * p.C;
+    const int rows = DWG_R + p.k - 1;
+    for (int i = tid; i < rows * 64; i += 256) {
+        const int r = i >> 6, cc = i & 63, t = t0 + r - p.pad;
+        xs[i] = (t >= 0 && t < p.S && c0 + cc < p.C) ? Num<T>::to_f32(x[(size_t)t * p.C + c0 + cc]) : 0.f;
+    }
+    for (int i = tid; i < DWG_R * 64; i += 256) {
+        const int r = i >> 6, cc = i & 63, t = t0 + r;
+        ds[i] = (t < p.S && c0 + cc < p.C) ? Num<T>::to_f32(dy[(size_t)t * p.C + c0 + cc]) : 0.f;
+    }
+    __syncthreads();
+    float acc[DWG_KMAX + 1];
+#pragma unroll
+    for (int j = 0; j <= DWG_KMAX; ++j) acc[j] = 0.f;
+    for (int r = g; r < DWG_R; r += 4) {
+        const float d = ds[r * 64 + c];
+        acc[DWG_KMAX] += d;
+#pragma unroll
+        for (int j = 0; j < DWG_KMAX; ++j)
+            if (j < p.k) acc[j] = fmaf(d, xs[(r + j) * 64 + c], acc[j]);
+    }
+    __syncthreads();
+    // reduce the 4 row groups through LDS (reusing xs): [g][j][c]
+#pragma unroll
+    for (int j = 0; j <= DWG_KMAX; ++j)
+        if (j < p.k || j == DWG_KMAX) xs[(g * (DWG_KMAX + 1) + j) * 64 + c] = acc[j];
+    __syncthreads();
+    float* part = p.part + ((size_t)b * nchunk + blockIdx.x) * (size_t)p.C * (p.k + 1);
+    for (int i = tid; i < (p.k + 1) * 64; i += 256) {
+        const int j = i >> 6, cc = i & 63;
+        if (c0 + cc >= p.C) continue;
+        const int jj = j < p.k ? j : DWG_KMAX;
+        const float v = (xs[(0 * (DWG_KMAX + 1) + jj) * 64 + cc] + xs[(1 * (DWG_KMAX + 1) + jj) * 64 + cc]) +
+                        (xs[(2 * (DWG_KMAX + 1) + jj) * 64 + cc] + xs[(3 * (DWG_KMAX + 1) + jj) * 64 + cc]);
+        if (j < p.k) part[(size_t)(c0 + cc) * p.k + j] = v;
+        else part[(size_t)p.C * p.k + c0 + cc] = v;
+    }
+}
+
+template <typename T>
+__global__ void fold_conv2_kernel(FoldConv2Args p) {
+    const int gs = p.F / p.H;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (long)p.H * p.F) {
+        const int o = (int)(i / p.F), f = (int)(i % p.F), g = f / gs, j = f % gs;
+        float a = 0.f;
+        for (int ii = 0; ii < gs; ++ii) a = fmaf(p.W21[(long)o * p.F + g * gs + ii], p.G[(long)(g * gs + ii) * gs + j], a);
+        ((T*)p.Wf)[i] = Num<T>::from_f32(a);
+    }
+    if (i < p.H) {
+        float a = p.b21[i];
+        for (int f = 0; f < p.F; ++f) a = fmaf(p.W21[i * p.F + f], p.bg[f], a);
+        p.bf[i] = a;
+    }
+}
+__global__ void unfold_conv2_kernel(UnfoldConv2Args p) {
+    const int gs = p.F / p.H;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (long)p.H * p.F) {  // dW21[o][f], f = g*gs + ii
+        const int o = (int)(i / p.F), f = (int)(i % p.F), g = f / gs;
+        float a = p.dbf[o] * p.bg[f];
+        for (int j = 0; j < gs; ++j) a = fmaf(p.dWf[(long)o * p.F + g * gs + j], p.G[(long)f * gs + j], a);
+        p.dW21[i] += a;
+    }
+    if (i < (long)p.F * gs) {  // dG[f][j]
+        const int f = (int)(i / gs), j = (int)(i % gs), g = f / gs;
+        float a = 0.f;
+        for (int o = 0; o < p.H; ++o) a = fmaf(p.W21[(long)o * p.F + f], p.dWf[(long)o * p.F + g * gs + j], a);
+        p.dG[i] += a;
+    }
+    if (i < p.F) {
+        float a = 0.f;
+        for (int o = 0; o < p.H; ++o) a = fmaf(p.W21[(long)o * p.F + i], p.dbf[o], a);
+        p.dbg[i] += a;
+    }
+    if (i < p.H) p.db21[i] += p.dbf[i];
+}
+
 inline int ok() { return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP; }
 
 }  // namespace
+
+int dwconv_wgrad_parts(int B, int S) { return B * ((S + DWG_R - 1) / DWG_R); }
+int launch_dwconv_wgrad(const DwConvWgradArgs& a, int dtype, hipStream_t stream) {
+    if (a.k > DWG_KMAX || a.k < 1 || a.B <= 0 || a.S <= 0) return FS2_ERR_SHAPE;
+    const dim3 g((a.S + DWG_R - 1) / DWG_R, (a.C + 63) / 64, a.B);
+    if (dtype == FS2_BF16) hipLaunchKernelGGL(dwconv_wgrad_kernel<bf16>, g, dim3(256), 0, stream, a);
+    else if (dtype == FS2_F32) hipLaunchKernelGGL(dwconv_wgrad_kernel<float>, g, dim3(256), 0, stream, a);
+    else return FS2_ERR_SHAPE;
+    return ok();
+}
+int launch_fold_conv2(const FoldConv2Args& a, int wf_dtype, hipStream_t stream) {
+    if (a.H <= 0 || a.F % a.H) return FS2_ERR_SHAPE;
+    const long n = (long)a.H * a.F;
+    const dim3 g((unsigned)((n + 255) / 256));
+    if (wf_dtype == FS2_BF16) hipLaunchKernelGGL(fold_conv2_kernel<bf16>, g, dim3(256), 0, stream, a);
+    else if (wf_dtype == FS2_F32) hipLaunchKernelGGL(fold_conv2_kernel<float>, g, dim3(256), 0, stream, a);
+    else return FS2_ERR_SHAPE;
+    return ok();
+}
+int launch_unfold_conv2(const UnfoldConv2Args& a, hipStream_t stream) {
+    if (a.H <= 0 || a.F % a.H) return FS2_ERR_SHAPE;
+    const long n = (long)a.H * a.F;  // >= F * gs, F, H
+    hipLaunchKernelGGL(unfold_conv2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
+    return ok();
+}
 
 int launch_transpose_weight(const TransposeWeightArgs& a, int dtype, hipStream_t stream) {
     if (a.N <= 0 || a.Cin <= 0 || a.taps <= 0) return FS2_ERR_SHAPE;

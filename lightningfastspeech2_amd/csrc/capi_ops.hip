@@ -249,6 +249,28 @@ int fs2_op_masked_loss_bwd(const float* pred, const void* truth, int32_t truth_k
     LossBwdArgs a{pred, truth, pad_mask, stat, dpred, rows, inner, kind, truth_kind, alpha};
     return launch_masked_loss_bwd(a, (hipStream_t)stream);
 }
+int fs2_op_dwconv_dgrad(int32_t dtype, const void* dy, const float* w, void* dx, int32_t B, int32_t S, int32_t C, int32_t k,
+                        void* stream) {
+    DwConvArgs a{dy, w, nullptr, dx, B, S, C, k, (k - 1) / 2};
+    a.flip = 1;
+    return launch_dwconv(a, dtype, (hipStream_t)stream);
+}
+int32_t fs2_op_dwconv_wgrad_parts(int32_t B, int32_t S) { return dwconv_wgrad_parts(B, S); }
+int fs2_op_dwconv_wgrad(int32_t dtype, const void* dy, const void* x, float* part, int32_t B, int32_t S, int32_t C, int32_t k,
+                        void* stream) {
+    DwConvWgradArgs a{dy, x, part, B, S, C, k, (k - 1) / 2};
+    return launch_dwconv_wgrad(a, dtype, (hipStream_t)stream);
+}
+int fs2_op_fold_conv2(int32_t wf_dtype, const float* G, const float* bg, const float* W21, const float* b21, void* Wf, float* bf,
+                      int32_t H, int32_t F, void* stream) {
+    FoldConv2Args a{G, bg, W21, b21, Wf, bf, H, F};
+    return launch_fold_conv2(a, wf_dtype, (hipStream_t)stream);
+}
+int fs2_op_unfold_conv2(const float* dWf, const float* dbf, const float* G, const float* bg, const float* W21, float* dG,
+                        float* dbg, float* dW21, float* db21, int32_t H, int32_t F, void* stream) {
+    UnfoldConv2Args a{dWf, dbf, G, bg, W21, dG, dbg, dW21, db21, H, F};
+    return launch_unfold_conv2(a, (hipStream_t)stream);
+}
 int fs2_op_transpose_weight(int32_t dtype, const void* src, void* dst, int32_t N, int32_t Cin, int32_t taps, void* stream) {
     TransposeWeightArgs a{src, dst, N, Cin, taps};
     return launch_transpose_weight(a, dtype, (hipStream_t)stream);

@@ -181,6 +181,7 @@ struct DwConvArgs {
     const float* ln_b = nullptr;
     int ln_parts = 0;
     float ln_eps = 1e-5f;
+    int flip = 0;        // 1: taps in reverse order (the data gradient of the same conv: dx = dwconv(dy, flipped w), no bias)
 };
 int launch_dwconv(const DwConvArgs& a, int dtype, hipStream_t stream);
 
@@ -372,6 +373,39 @@ struct LossBwdArgs {         // gradient of alpha * mean over selected elements 
     float alpha;
 };
 int launch_masked_loss_bwd(const LossBwdArgs& a, hipStream_t stream);
+
+// depth-wise Conv1d weight / bias gradient: part[chunk][c * k + j] = sum_t dy[t][c] x[t + j - pad][c], part[chunk][C * k + c] =
+// sum_t dy[t][c] over the chunk's rows (dwconv_wgrad_parts(B, S) chunks; -> col_sum -> dw (C, k), db (C))
+struct DwConvWgradArgs {
+    const void* dy;   // (B*S, C)
+    const void* x;    // (B*S, C)
+    float* part;      // (nparts, C * (k + 1))
+    int B, S, C, k, pad;
+};
+int dwconv_wgrad_parts(int B, int S);
+int launch_dwconv_wgrad(const DwConvWgradArgs& a, int dtype, hipStream_t stream);
+
+// conv2 = Sequential(grouped 1x1 conv over F channels in H groups, pointwise F -> H) of the depth-wise ConformerEncoderLayer
+// (model.py:84-93) as ONE linear map: Wf[o][g*gs + j] = sum_i W21[o][g*gs + i] G[g*gs + i][j], bf = b21 + W21 bg; and the
+// chain rule back from (dWf, dbf) to the four parameter gradients (accumulating).
+struct FoldConv2Args {
+    const float* G;    // (F, gs)
+    const float* bg;   // (F)
+    const float* W21;  // (H, F)
+    const float* b21;  // (H)
+    void* Wf;          // (H, F) in wf_dtype
+    float* bf;         // (H)
+    int H, F;
+};
+int launch_fold_conv2(const FoldConv2Args& a, int wf_dtype, hipStream_t stream);
+struct UnfoldConv2Args {
+    const float* dWf;  // (H, F) fp32
+    const float* dbf;  // (H)
+    const float* G; const float* bg; const float* W21;
+    float* dG; float* dbg; float* dW21; float* db21;   // accumulated into
+    int H, F;
+};
+int launch_unfold_conv2(const UnfoldConv2Args& a, hipStream_t stream);
 
 struct TransposeWeightArgs {   // dst (Cin, taps*N) [ci][j'*N + n] = src (N, taps*Cin) [n][(taps-1-j')*Cin + ci]
     const void* src;

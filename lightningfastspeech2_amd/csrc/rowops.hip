@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwConvArgs p) {
     }
     for (int i = tid; i < DW_CT * kp; i += 256) {
         const int tap = i / DW_CT, c = i % DW_CT;
-        wl[tap * DW_CT + c] = (tap < p.k && c0 + c < p.C) ? p.w[(size_t)(c0 + c) * p.k + tap] : 0.f;
+        wl[tap * DW_CT + c] = (tap < p.k && c0 + c < p.C) ? p.w[(size_t)(c0 + c) * p.k + (p.flip ? p.k - 1 - tap : tap)] : 0.f;
     }
     __syncthreads();
     const int cq = (tid & 15) * 4, r0 = (tid >> 4) * DW_RR;

@@ -11,12 +11,13 @@ gradients and both Adam moments live in ONE flat fp32 buffer each so the optimiz
 job all-reduces one contiguous gradient buffer.  torch supplies device memory and streams only; there is no autograd and
 no CPU path - without libfs2_hip.so the constructor raises.
 
-Covered: the dense-convolution architecture family (C1/C2/C5 of BASELINE.json and the test-size configs), frame-level
+Covered: dense and depth-wise convolution variants of every block (C1-C5 of BASELINE.json, the reference's class defaults
+and the test-size configs; the depth-wise layer's conv2 pair is trained through its folded (H, F) map), frame-level
 'none' variances, 'l1' / 'mse' losses; precision "fp32" (exact fp32 MFMA, the parity mode) or "bf16" (bf16 activations,
 activation gradients and GEMM operands on the bf16 MFMA with fp32 accumulation; fp32 master weights, weight gradients,
 Adam moments, LayerNorm / softmax statistics and losses - what the reference's `--precision 16` recipe does with fp16).  Dropout is 0 (the reference's dropouts are
-random per step and cannot be pinned; p = 0 is what the parity tests compare).  Rejected loudly: depth-wise convolutions,
-phone-level / CWT variances, priors, stochastic durations.
+random per step and cannot be pinned; p = 0 is what the parity tests compare).  Rejected loudly: phone-level / CWT
+variances, priors, stochastic durations.
 """
 from __future__ import annotations
 
@@ -125,6 +126,29 @@ class _Ops:
         self.ck(self.lib.fs2_op_ew(self._dt(dy), 1, _p(dy), _p(y), _p(dy), dy.numel(), C.c_float(0), C.c_float(0), self.st()), "relu_bwd")
         return dy
 
+    def dwconv(self, x, w, bias, B, S, Cc, k):
+        y = self.act(B * S, Cc)
+        self.ck(self.lib.fs2_op_dwconv(self.dt, _p(x), _p(w), _p(bias), _p(y), B, S, Cc, k, self.st()), "dwconv")
+        return y
+
+    def dwconv_bwd(self, du, x, w, gw, gb, B, S, Cc, k):
+        """depth-wise conv backward: (gw (C, k), gb (C)) += the weight / bias gradients; returns d/dx (B*S, C)."""
+        nparts = int(self.lib.fs2_op_dwconv_wgrad_parts(B, S))
+        part = self.empty(nparts, Cc * (k + 1))
+        self.ck(self.lib.fs2_op_dwconv_wgrad(self.dt, _p(du), _p(x), _p(part), B, S, Cc, k, self.st()), "dwconv_wgrad")
+        if gb.data_ptr() == gw.data_ptr() + 4 * Cc * k:
+            self.col_sum(part, gw, nparts, Cc * (k + 1))
+        else:
+            self.col_sum(part, gw, nparts, Cc * k, ldx=Cc * (k + 1))
+            self.col_sum(part[:, Cc * k:], gb, nparts, Cc, ldx=Cc * (k + 1))
+        dx = self.act(B * S, Cc)
+        self.ck(self.lib.fs2_op_dwconv_dgrad(self.dt, _p(du), _p(w), _p(dx), B, S, Cc, k, self.st()), "dwconv_dgrad")
+        return dx
+
+    def add_(self, a, b):
+        self.ck(self.lib.fs2_op_ew(self._dt(a), 0, _p(a), _p(b), _p(a), a.numel(), C.c_float(1), C.c_float(1), self.st()), "add")
+        return a
+
     # y = x W^T + b backward pieces.  w is (N, taps*Cin) tap-major; x (M, Cin); dy (M, N); rows in utterances of S.
     def dgrad(self, dy, w, M, N, Cin, taps=1, S=None, out=None, accumulate=False, wt=None):
         """dX (M, Cin) = dY (M, N) . W: with the transposed / tap-flipped copy wt (Cin, taps*N) through the forward
@@ -164,8 +188,6 @@ class Trainer:
     def __init__(self, cfg: Fs2Config, state_dict, *, lr=2e-4, warmup_steps=4000, betas=(0.9, 0.98), eps=1e-8,
                  weight_decay=0.01, gradient_clip_val: Optional[float] = 1.0, variance_losses=None, mel_loss="l1",
                  duration_loss="mse", loss_alphas=None, precision="fp32", device="cuda:0"):
-        if cfg.encoder_depthwise_conv or cfg.decoder_depthwise_conv or cfg.variance_depthwise_conv or cfg.duration_depthwise_conv:
-            raise NotImplementedError("training step: depth-wise convolution variants are not built yet (dense family only)")
         if any(l != "frame" for l in cfg.variance_levels[:len(cfg.variances)]) or any(cfg.is_cwt(i) for i in range(len(cfg.variances))):
             raise NotImplementedError("training step: frame-level 'none' variances only")
         if cfg.priors:
@@ -213,9 +235,19 @@ class Trainer:
         self.flat_wt = torch.zeros(off, device=self.dev, dtype=self.ops.tdt)
         self.WT = {}
         for n, (o, ks, rs) in self._layout.items():
-            if n.endswith("weight") and len(ks) == 2 and ("embedding" not in n) and ("norm" not in n) and not n.endswith(".2.weight"):
+            gemm_w = n.endswith("weight") and "embedding" not in n and (
+                len(rs) == 2 or (len(rs) == 3 and rs[1] > 1 and ".conv2.0." not in n))  # not LayerNorm (1-D), depth-wise or grouped convs
+            if gemm_w:
                 taps = rs[2] if len(rs) == 3 else 1
                 self.WT[n] = self.flat_wt[o:o + int(np.prod(ks))].view(rs[1], taps * rs[0])
+        # depth-wise ConformerEncoderLayer: conv2 = grouped 1x1 + pointwise folded into one (H, F) map per optimizer step
+        self.fold: Dict[str, dict] = {}
+        H_ = cfg.hidden
+        for side, nl, dw, F_ in (("encoder", cfg.encoder_layers, cfg.encoder_depthwise_conv, cfg.encoder_conv_filter_size),
+                                 ("decoder", cfg.decoder_layers, cfg.decoder_depthwise_conv, cfg.decoder_conv_filter_size)):
+            if dw:
+                for i in range(nl):
+                    self.fold[f"{side}.layers.{i}"] = {"Wf": self.ops.act(H_, F_), "bf": self.ops.empty(H_), "WfT": self.ops.act(F_, H_)}
         self.buffers: Dict[str, torch.Tensor] = {}
         self.load_state_dict(state_dict)
         self.steps = 0          # optimizer steps taken
@@ -246,6 +278,12 @@ class Trainer:
         with torch.cuda.device(self.dev):
             if o.dt != F32:
                 o.ck(o.lib.fs2_op_convert(F32, o.dt, _p(self.flat_p), _p(self.flat_w), self.n_flat, o.st()), "convert")
+            for pfx, f in self.fold.items():
+                Hh, Ff = f["Wf"].shape
+                o.ck(o.lib.fs2_op_fold_conv2(o.dt, _p(self.P[f"{pfx}.conv2.0.weight"]), _p(self.P[f"{pfx}.conv2.0.bias"]),
+                                             _p(self.P[f"{pfx}.conv2.1.weight"]), _p(self.P[f"{pfx}.conv2.1.bias"]), _p(f["Wf"]), _p(f["bf"]),
+                                             Hh, Ff, o.st()), "fold_conv2")
+                o.ck(o.lib.fs2_op_transpose_weight(o.dt, _p(f["Wf"]), _p(f["WfT"]), Hh, Ff, 1, o.st()), "transpose_weight")
             if self.use_forward_dgrad:
                 for n, wt in self.WT.items():
                     _, _, rs = self._layout[n]
@@ -299,13 +337,18 @@ class Trainer:
                 sA1=heads * S * S, sA2=S * S, sB1=S * 3 * H, sB2=d, sC1=S * H, sC2=d)
         proj = o.gemm(attn, W[f"{prefix}.self_attn.out_proj.weight"], P[f"{prefix}.self_attn.out_proj.bias"], M, H, H)
         x1, _ = o.layernorm(proj, x, P[f"{prefix}.norm1.weight"], P[f"{prefix}.norm1.bias"], M, H)
-        h = o.gemm(x1, W[f"{prefix}.conv1.weight"], P[f"{prefix}.conv1.bias"], M, F_, H, taps=k, S=S, relu=True)
-        c2 = o.gemm(h, W[f"{prefix}.conv2.weight"], P[f"{prefix}.conv2.bias"], M, H, F_)
+        if prefix in self.fold:  # depth-wise FFN (model.py:73-93): dw(k) -> pw H->F -> ReLU -> [grouped 1x1 . pw F->H] folded
+            t["u"] = o.dwconv(x1, P[f"{prefix}.conv1.0.weight"], P[f"{prefix}.conv1.0.bias"], B, S, H, k)
+            h = o.gemm(t["u"], W[f"{prefix}.conv1.1.weight"], P[f"{prefix}.conv1.1.bias"], M, F_, H, relu=True)
+            c2 = o.gemm(h, self.fold[prefix]["Wf"], self.fold[prefix]["bf"], M, H, F_)
+        else:
+            h = o.gemm(x1, W[f"{prefix}.conv1.weight"], P[f"{prefix}.conv1.bias"], M, F_, H, taps=k, S=S, relu=True)
+            c2 = o.gemm(h, W[f"{prefix}.conv2.weight"], P[f"{prefix}.conv2.bias"], M, H, F_)
         x2, _ = o.layernorm(c2, x1, P[f"{prefix}.norm2.weight"], P[f"{prefix}.norm2.bias"], M, H)
         t.update(qkv=qkv, prob=prob, attn=attn, proj=proj, x1=x1, h=h, c2=c2, scale=scale)
         return x2, t
 
-    def _ln_bwd(self, z, res, dy, gname, bname, M, H, bias_name=None, relu_mask=False):
+    def _ln_bwd(self, z, res, dy, gname, bname, M, H, bias_name=None, relu_mask=False, bias_out=None):
         """dz of y = LN(z [+ res]); dgamma / dbeta (adjacent in the flat buffer: one column-sum launch) and, when asked, the
         bias gradient of the layer that produced z (= column sums of dz; with relu_mask dz is the pre-activation gradient)."""
         o = self.ops
@@ -321,17 +364,34 @@ class Trainer:
             o.col_sum(part[:, H:], gb, nparts, H, ldx=3 * H)
         if bias_name is not None:
             o.col_sum(part[:, 2 * H:], self.G[bias_name], nparts, H, ldx=3 * H)
+        if bias_out is not None:
+            o.col_sum(part[:, 2 * H:], bias_out, nparts, H, ldx=3 * H, accumulate=False)
         return dz
 
     def _layer_bwd(self, dx2, t, prefix, B, S, heads, F_, k):
         o, P, W, G, H = self.ops, self.P, self.W, self.G, self.cfg.hidden
         M, d = B * S, H // heads
-        dx1 = self._ln_bwd(t["c2"], t["x1"], dx2, f"{prefix}.norm2.weight", f"{prefix}.norm2.bias", M, H,
-                           bias_name=f"{prefix}.conv2.bias")  # = dc2 too
-        o.wgrad(dx1, t["h"], G[f"{prefix}.conv2.weight"], None, M, H, F_)
-        dh = o.relu_bwd(o.dgrad(dx1, W[f"{prefix}.conv2.weight"], M, H, F_, wt=self._wt(f"{prefix}.conv2.weight")), t["h"])
-        o.wgrad(dh, t["x1"], G[f"{prefix}.conv1.weight"], G[f"{prefix}.conv1.bias"], M, F_, H, taps=k, S=S)
-        o.dgrad(dh, W[f"{prefix}.conv1.weight"], M, F_, H, taps=k, S=S, out=dx1, accumulate=True, wt=self._wt(f"{prefix}.conv1.weight"))
+        if prefix in self.fold:
+            f = self.fold[prefix]
+            dbf = o.empty(H)
+            dx1 = self._ln_bwd(t["c2"], t["x1"], dx2, f"{prefix}.norm2.weight", f"{prefix}.norm2.bias", M, H, bias_out=dbf)
+            dWf = torch.zeros(H, F_, device=self.dev)
+            o.wgrad(dx1, t["h"], dWf, None, M, H, F_)
+            o.ck(o.lib.fs2_op_unfold_conv2(_p(dWf), _p(dbf), _p(P[f"{prefix}.conv2.0.weight"]), _p(P[f"{prefix}.conv2.0.bias"]),
+                                           _p(P[f"{prefix}.conv2.1.weight"]), _p(G[f"{prefix}.conv2.0.weight"]), _p(G[f"{prefix}.conv2.0.bias"]),
+                                           _p(G[f"{prefix}.conv2.1.weight"]), _p(G[f"{prefix}.conv2.1.bias"]), H, F_, o.st()), "unfold_conv2")
+            dh = o.relu_bwd(o.dgrad(dx1, f["Wf"], M, H, F_, wt=f["WfT"] if self.use_forward_dgrad else None), t["h"])
+            o.wgrad(dh, t["u"], G[f"{prefix}.conv1.1.weight"], G[f"{prefix}.conv1.1.bias"], M, F_, H)
+            du = o.dgrad(dh, W[f"{prefix}.conv1.1.weight"], M, F_, H, wt=self._wt(f"{prefix}.conv1.1.weight"))
+            o.add_(dx1, o.dwconv_bwd(du, t["x1"], P[f"{prefix}.conv1.0.weight"], G[f"{prefix}.conv1.0.weight"], G[f"{prefix}.conv1.0.bias"],
+                                     B, S, H, k))
+        else:
+            dx1 = self._ln_bwd(t["c2"], t["x1"], dx2, f"{prefix}.norm2.weight", f"{prefix}.norm2.bias", M, H,
+                               bias_name=f"{prefix}.conv2.bias")  # = dc2 too
+            o.wgrad(dx1, t["h"], G[f"{prefix}.conv2.weight"], None, M, H, F_)
+            dh = o.relu_bwd(o.dgrad(dx1, W[f"{prefix}.conv2.weight"], M, H, F_, wt=self._wt(f"{prefix}.conv2.weight")), t["h"])
+            o.wgrad(dh, t["x1"], G[f"{prefix}.conv1.weight"], G[f"{prefix}.conv1.bias"], M, F_, H, taps=k, S=S)
+            o.dgrad(dh, W[f"{prefix}.conv1.weight"], M, F_, H, taps=k, S=S, out=dx1, accumulate=True, wt=self._wt(f"{prefix}.conv1.weight"))
         dx = self._ln_bwd(t["proj"], t["x"], dx1, f"{prefix}.norm1.weight", f"{prefix}.norm1.bias", M, H,
                           bias_name=f"{prefix}.self_attn.out_proj.bias")  # = dproj too
         o.wgrad(dx, t["attn"], G[f"{prefix}.self_attn.out_proj.weight"], None, M, H, H)
@@ -360,22 +420,27 @@ class Trainer:
         return dx
 
     # ---- VariancePredictor (model.py:482-561, dense) ----
-    def _predictor_fwd(self, x, prefix, nlayers, filt, k, B, S, mask):
+    def _predictor_fwd(self, x, prefix, nlayers, filt, k, B, S, mask, dw=False):
         o, P, W, H = self.ops, self.P, self.W, self.cfg.hidden
         M = B * S
         tape, y, cin = [], x, H
         for j in range(nlayers):
             p = f"{prefix}.layers.{j}.layers"
-            c = o.gemm(y, W[f"{p}.0.module.weight"], P[f"{p}.0.module.bias"], M, filt, cin, taps=k, S=S, relu=True)
+            u = None
+            if dw:  # VarianceConvolutionLayer, depth-wise form (model.py:541-558): dw(k) -> pw 1x1 -> ReLU -> LN
+                u = o.dwconv(y, P[f"{p}.0.module.0.weight"], P[f"{p}.0.module.0.bias"], B, S, cin, k)
+                c = o.gemm(u, W[f"{p}.0.module.1.weight"], P[f"{p}.0.module.1.bias"], M, filt, cin, relu=True)
+            else:
+                c = o.gemm(y, W[f"{p}.0.module.weight"], P[f"{p}.0.module.bias"], M, filt, cin, taps=k, S=S, relu=True)
             last = j == nlayers - 1
             yn, pred = o.layernorm(c, None, P[f"{p}.2.weight"], P[f"{p}.2.bias"], M, filt,
                                    dot_w=P[f"{prefix}.linear.weight"] if last else None,
                                    dot_b=float(P[f"{prefix}.linear.bias"][0]) if last else 0.0, mask=mask if last else None)
-            tape.append({"xin": y, "c": c, "cin": cin})
+            tape.append({"xin": y, "c": c, "cin": cin, "u": u})
             y, cin = yn, filt
         return pred, {"layers": tape, "y": y}
 
-    def _predictor_bwd(self, dpred, t, prefix, nlayers, filt, k, B, S, dx_out):
+    def _predictor_bwd(self, dpred, t, prefix, nlayers, filt, k, B, S, dx_out, dw=False):
         """dpred (M) -> gradients of the predictor's parameters, and dx_out (M, H) += d/dx."""
         o, P, W, G = self.ops, self.P, self.W, self.G
         M = B * S
@@ -389,6 +454,17 @@ class Trainer:
         for j in reversed(range(nlayers)):
             p = f"{prefix}.layers.{j}.layers"
             lt = t["layers"][j]
+            if dw:
+                dc = self._ln_bwd(lt["c"], None, dy, f"{p}.2.weight", f"{p}.2.bias", M, filt, bias_name=f"{p}.0.module.1.bias", relu_mask=True)
+                o.wgrad(dc, lt["u"], G[f"{p}.0.module.1.weight"], None, M, filt, lt["cin"])
+                du = o.dgrad(dc, W[f"{p}.0.module.1.weight"], M, filt, lt["cin"], wt=self._wt(f"{p}.0.module.1.weight"))
+                dxin = o.dwconv_bwd(du, lt["xin"], P[f"{p}.0.module.0.weight"], G[f"{p}.0.module.0.weight"], G[f"{p}.0.module.0.bias"],
+                                    B, S, lt["cin"], k)
+                if j == 0:
+                    o.add_(dx_out, dxin)
+                else:
+                    dy = dxin
+                continue
             dc = self._ln_bwd(lt["c"], None, dy, f"{p}.2.weight", f"{p}.2.bias", M, filt, bias_name=f"{p}.0.module.bias", relu_mask=True)
             o.wgrad(dc, lt["xin"], G[f"{p}.0.module.weight"], None, M, filt, lt["cin"], taps=k, S=S)
             if j == 0:
@@ -444,7 +520,8 @@ class Trainer:
                                        cfg.encoder_kernel_sizes[i], src_mask)
                 enc_t.append(t)
             dur_pred, dur_tape = self._predictor_fwd(x, "variance_adaptor.duration_predictor", cfg.duration_nlayers,
-                                                     cfg.duration_filter_size, cfg.duration_kernel_size, B, L, src_mask)
+                                                     cfg.duration_filter_size, cfg.duration_kernel_size, B, L, src_mask,
+                                                     dw=cfg.duration_depthwise_conv)
             forced = dur_t.to(torch.int32)
             dur, cum, totals, guard = (o.empty(B, L, dtype=torch.int32), o.empty(B, L, dtype=torch.int32),
                                        o.empty(B, dtype=torch.int32), o.empty(B, dtype=torch.int32))
@@ -458,7 +535,7 @@ class Trainer:
             for vi, v in enumerate(cfg.variances):
                 pfx = f"variance_adaptor.encoders.{v}"
                 var_pred[v], var_tape[v] = self._predictor_fwd(xa, f"{pfx}.predictor", cfg.variance_nlayers[vi], cfg.variance_filter_size,
-                                                               cfg.variance_kernel_size[vi], B, T, tgt_mask)
+                                                               cfg.variance_kernel_size[vi], B, T, tgt_mask, dw=cfg.variance_depthwise_conv)
                 idx = o.empty(B * T, dtype=torch.int32)
                 xn = o.act(B * T, H)
                 last = vi == nv - 1
@@ -508,11 +585,11 @@ class Trainer:
                 o.ck(o.lib.fs2_op_scatter_rows(o.dt, _p(dx), _p(var_idx[v]), None, _p(G[f"{pfx}.embedding.weight"]), B * T, H, cfg.variance_nbins,
                                                -1, o.st()), "scatter_rows")
                 self._predictor_bwd(dvar[v], var_tape[v], f"{pfx}.predictor", cfg.variance_nlayers[vi], cfg.variance_filter_size,
-                                    cfg.variance_kernel_size[vi], B, T, dx)
+                                    cfg.variance_kernel_size[vi], B, T, dx, dw=cfg.variance_depthwise_conv)
             dxe = o.act(B * L, H)
             o.ck(o.lib.fs2_op_regulate_bwd(o.dt, _p(dx), _p(cum), _p(dxe), B, L, T, H, o.st()), "regulate_bwd")
             self._predictor_bwd(ddur, dur_tape, "variance_adaptor.duration_predictor", cfg.duration_nlayers, cfg.duration_filter_size,
-                                cfg.duration_kernel_size, B, L, dxe)
+                                cfg.duration_kernel_size, B, L, dxe, dw=cfg.duration_depthwise_conv)
             for i in reversed(range(cfg.encoder_layers)):
                 dxe = self._layer_bwd(dxe, enc_t[i], f"encoder.layers.{i}", B, L, cfg.encoder_head, cfg.encoder_conv_filter_size,
                                       cfg.encoder_kernel_sizes[i])

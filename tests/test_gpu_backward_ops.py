@@ -360,3 +360,60 @@ def test_row_ops_bf16():
     o2 = torch.empty_like(xd)
     _lib.check(lib.fs2_op_ew(BF, 1, p(xd), p(y), p(o2), 1000 * 72, 0.0, 0.0, st()))
     assert torch.equal(o2.cpu(), torch.where(y.cpu() > 0, x, torch.zeros((), dtype=torch.bfloat16)))
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("B,S,Cc,k", [(3, 40, 64, 9), (2, 150, 72, 3), (1, 7, 8, 25), (2, 300, 132, 17)])
+def test_dwconv_backward(B, S, Cc, k, dtype):
+    """depth-wise Conv1d: data gradient (the forward kernel with reversed taps) and weight / bias gradient against autograd."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(B * S + k)
+    bf = dtype == "bf16"
+    cast = (lambda t: _bf(t).double()) if bf else (lambda t: t.double())
+    x = cast(torch.randn(B, S, Cc, generator=g)).requires_grad_(True)
+    w = torch.randn(Cc, 1, k, generator=g).double().requires_grad_(True)
+    bias = torch.randn(Cc, generator=g).double().requires_grad_(True)
+    dy = cast(torch.randn(B, S, Cc, generator=g))
+    F.conv1d(x.transpose(1, 2), w, bias, padding=(k - 1) // 2, groups=Cc).transpose(1, 2).backward(dy)
+    tdt = torch.bfloat16 if bf else torch.float32
+    dt = BF if bf else F32
+    dyd, xd, wd = dy.to(tdt).to(DEV).contiguous(), x.detach().to(tdt).to(DEV).contiguous(), w.detach().float().view(Cc, k).to(DEV).contiguous()
+    dx = torch.empty(B * S, Cc, device=DEV, dtype=tdt)
+    _lib.check(lib.fs2_op_dwconv_dgrad(dt, p(dyd), p(wd), p(dx), B, S, Cc, k, st()))
+    close(dx, x.grad.reshape(B * S, Cc), 5e-3 if bf else 2e-5)
+    nparts = lib.fs2_op_dwconv_wgrad_parts(B, S)
+    part = torch.empty(nparts, Cc * (k + 1), device=DEV)
+    _lib.check(lib.fs2_op_dwconv_wgrad(dt, p(dyd), p(xd), p(part), B, S, Cc, k, st()))
+    tot = part.sum(0).cpu().double()
+    close(tot[:Cc * k].view(Cc, k), w.grad.view(Cc, k), 2e-5)
+    close(tot[Cc * k:], bias.grad, 2e-5)
+
+
+def test_fold_unfold_conv2():
+    """conv2 of the depth-wise layer as one folded linear map, and the chain rule back to its four parameters."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(4)
+    H, Fc, M = 16, 64, 50
+    gs = Fc // H
+    G = torch.randn(Fc, gs, 1, generator=g, dtype=torch.float64, requires_grad=True)
+    bg = torch.randn(Fc, generator=g, dtype=torch.float64, requires_grad=True)
+    W21 = torch.randn(H, Fc, 1, generator=g, dtype=torch.float64, requires_grad=True)
+    b21 = torch.randn(H, generator=g, dtype=torch.float64, requires_grad=True)
+    x = torch.randn(1, Fc, M, generator=g, dtype=torch.float64)
+    y = F.conv1d(F.conv1d(x, G, bg, groups=H), W21, b21)  # (1, H, M)
+    dy = torch.randn(1, H, M, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    Gd, bgd, Wd, bd = (t.detach().float().reshape(t.shape[0], -1).squeeze(-1).contiguous().to(DEV) if t.dim() > 1 else t.detach().float().to(DEV)
+                       for t in (G, bg, W21, b21))
+    Wf, bf_ = torch.empty(H, Fc, device=DEV), torch.empty(H, device=DEV)
+    _lib.check(lib.fs2_op_fold_conv2(F32, p(Gd), p(bgd), p(Wd), p(bd), p(Wf), p(bf_), H, Fc, st()))
+    yf = Wf.cpu().double() @ x[0] + bf_.cpu().double()[:, None]
+    close(yf, y[0].detach(), 1e-5)
+    dWf = (dy[0] @ x[0].t()).float().to(DEV).contiguous()  # gradient of the folded map
+    dbf = dy[0].sum(1).float().to(DEV)
+    dG, dbg, dW, db = (torch.ones_like(t) for t in (Gd, bgd, Wd, bd))
+    _lib.check(lib.fs2_op_unfold_conv2(p(dWf), p(dbf), p(Gd), p(bgd), p(Wd), p(dG), p(dbg), p(dW), p(db), H, Fc, st()))
+    close(dG - 1, G.grad.view(Fc, gs), 1e-5)
+    close(dbg - 1, bg.grad, 1e-5)
+    close(dW - 1, W21.grad.view(H, Fc), 1e-5)
+    close(db - 1, b21.grad, 1e-5)

@@ -10,7 +10,7 @@ import torch
 from lightningfastspeech2_amd.config import Fs2Config
 from lightningfastspeech2_amd.weights import synth_inputs, synth_state_dict
 from oracle import train_cpu
-from test_train_oracle import assert_params_close, load
+from test_train_oracle import CASES, assert_params_close, load
 
 pytestmark = pytest.mark.gpu
 GRAD_TOL = 1e-4
@@ -31,9 +31,10 @@ def _check_grads(got, want, tol=GRAD_TOL):
     assert worst[1] <= tol, worst
 
 
-def test_training_step_matches_reference_fixture():
+@pytest.mark.parametrize("name", CASES)
+def test_training_step_matches_reference_fixture(name):
     from lightningfastspeech2_amd.training import Trainer
-    z, cfg, sd, batch, hyper = load()
+    z, cfg, sd, batch, hyper = load(name)
     tr = Trainer(cfg, sd, **hyper)
     for step in (1, 2, 3):
         losses = tr.training_step(_dev(batch))
@@ -78,10 +79,15 @@ def _case(seed, B, L, lengths, **kw):
     return cfg, sd, batch
 
 
-@pytest.mark.parametrize("seed,B,L,lengths", [(3, 4, 13, [13, 9, 5, 1]), (8, 2, 37, [37, 20])])
-def test_training_step_matches_oracle_on_ragged_batches(seed, B, L, lengths):
+DW = dict(encoder_depthwise_conv=True, decoder_depthwise_conv=True, variance_depthwise_conv=True, duration_depthwise_conv=True,
+          encoder_conv_filter_size=128, decoder_conv_filter_size=192, decoder_kernel_sizes=[17, 3])
+
+
+@pytest.mark.parametrize("seed,B,L,lengths,kw", [(3, 4, 13, [13, 9, 5, 1], {}), (8, 2, 37, [37, 20], {}), (5, 3, 21, [21, 8, 2], DW),
+                                                 (6, 2, 9, [9, 4], dict(DW, decoder_depthwise_conv=False, variance_depthwise_conv=False))])
+def test_training_step_matches_oracle_on_ragged_batches(seed, B, L, lengths, kw):
     from lightningfastspeech2_amd.training import Trainer
-    cfg, sd, batch = _case(seed, B, L, lengths)
+    cfg, sd, batch = _case(seed, B, L, lengths, **kw)
     kw = dict(lr=1e-3, warmup_steps=2, gradient_clip_val=0.5, variance_losses=["l1", "mse"], mel_loss="mse", duration_loss="l1")
     ref = train_cpu.OracleTrainer(cfg, sd, **kw)
     want_l, _ = ref.training_step(batch)
@@ -125,8 +131,6 @@ def test_gradient_accumulation_and_bit_equal_reruns():
 def test_trainer_rejects_what_is_not_built():
     from lightningfastspeech2_amd.training import Trainer
     cfg, sd, _ = _case(1, 2, 5, [5, 3])
-    with pytest.raises(NotImplementedError):
-        Trainer(Fs2Config(**{**cfg.__dict__, "decoder_depthwise_conv": True, "decoder_conv_filter_size": 128}), sd)
     with pytest.raises(NotImplementedError):
         Trainer(cfg, sd, mel_loss="soft_dtw")
 

@@ -5,17 +5,19 @@ import json
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from lightningfastspeech2_amd.config import Fs2Config
 from lightningfastspeech2_amd.weights import synth_state_dict
 from oracle import train_cpu
 
-GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "train_small.npz")
+GOLD_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = ["train_small", "train_dw_small"]  # dense family / the reference's depth-wise class defaults
 
 
-def load():
-    z = np.load(GOLD)
+def load(name="train_small"):
+    z = np.load(os.path.join(GOLD_DIR, f"{name}.npz"))
     cfg = Fs2Config.from_json(str(z["config_json"]))
     skw = json.loads(str(z["synth_json"]))
     sd = synth_state_dict(cfg, skw.pop("seed"), **skw)
@@ -34,8 +36,9 @@ def assert_params_close(z, name, got, tol):
     assert float(diff.max()) <= 2.5e-3, (name, float(diff.max()))
 
 
-def test_oracle_training_matches_reference_fixture():
-    z, cfg, sd, batch, hyper = load()
+@pytest.mark.parametrize("name", CASES)
+def test_oracle_training_matches_reference_fixture(name):
+    z, cfg, sd, batch, hyper = load(name)
     tr = train_cpu.OracleTrainer(cfg, sd, **hyper)
     for step in (1, 2, 3):
         ls, _ = tr.training_step(batch)

@@ -25,32 +25,14 @@ from tools import ref_import  # noqa: E402
 LR, WARMUP, CLIP = 2e-3, 4, 1.0
 
 
-def main():
-    assert ref_import.reference_available(), "needs /root/reference (build container only)"
-    ref_import._install_stubs()
-    sys.modules["pysdtw"].SoftDTW = lambda *a, **k: None
-    from litfass.fastspeech2.loss import FastSpeech2Loss
-    from litfass.fastspeech2.noam import NoamLR
-
-    z = np.load(os.path.join(ROOT, "tests", "golden", "teacher_small.npz"))
-    cfg = Fs2Config.from_json(str(z["config_json"]))
-    skw = json.loads(str(z["synth_json"]))
-    sd = synth_state_dict(cfg, skw.pop("seed"), **skw)
+def run_case(name, cfg, sd, synth_json, batch, FastSpeech2Loss, NoamLR):
     model = ref_import.build_reference_model(cfg, sd)  # eval mode: dropout off
-    B, T = z["out_mel"].shape[:2]
-    rs = np.random.RandomState(777)
-    batch = {"phones": torch.from_numpy(z["phones"]), "speaker": torch.from_numpy(z["speaker"]),
-             "duration": torch.from_numpy(z["tf_duration"]),
-             "mel": torch.from_numpy((rs.randn(B, T, cfg.n_mels) * 1.3 - 2.0).astype(np.float32))}
-    for v in cfg.variances:
-        batch[f"variances_{v}"] = torch.from_numpy(z[f"tf_variances_{v}"])
     nv = len(cfg.variances)
     loss = FastSpeech2Loss(variances=list(cfg.variances), variance_levels=["frame"] * nv, variance_transforms=["none"] * nv,
                            variance_losses=["mse"] * nv, mel_loss="l1", duration_loss="mse", max_length=4096)
-    params = [p for n, p in model.named_parameters() if not n.startswith("fastdiff_linear")]
     opt = torch.optim.AdamW(model.parameters(), lr=LR, betas=[0.9, 0.98], eps=1e-8, weight_decay=0.01)
     sched = NoamLR(opt, WARMUP)
-    out = {"config_json": np.array(cfg.to_json()), "synth_json": z["synth_json"], "hyper_json": np.array(json.dumps(
+    out = {"config_json": np.array(cfg.to_json()), "synth_json": np.array(synth_json), "hyper_json": np.array(json.dumps(
         dict(lr=LR, warmup_steps=WARMUP, gradient_clip_val=CLIP)))}
     for k, v in batch.items():
         out["in_" + k] = v.numpy()
@@ -72,13 +54,60 @@ def main():
         out[f"lr_{step}"] = np.float64(opt.param_groups[0]["lr"])
         opt.step()
         sched.step()
-        print(f"step {step}: total={float(losses['total']):.6f} grad norm={float(norm):.4f} lr={out[f'lr_{step}']:.3e}")
+        print(f"{name} step {step}: total={float(losses['total'].detach()):.6f} grad norm={float(norm):.4f} lr={out[f'lr_{step}']:.3e}")
     for n, p in model.named_parameters():
         if not n.startswith("fastdiff_linear") and p.requires_grad:
             out["after3_" + n] = p.detach().numpy().copy()
-    path = os.path.join(ROOT, "tests", "golden", "train_small.npz")
+    path = os.path.join(ROOT, "tests", "golden", f"{name}.npz")
     np.savez_compressed(path, **out)
     print(path, f"{os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def main():
+    assert ref_import.reference_available(), "needs /root/reference (build container only)"
+    ref_import._install_stubs()
+    sys.modules["pysdtw"].SoftDTW = lambda *a, **k: None
+    from litfass.fastspeech2.loss import FastSpeech2Loss
+    from litfass.fastspeech2.noam import NoamLR
+
+    # dense family: the batch of teacher_small.npz
+    z = np.load(os.path.join(ROOT, "tests", "golden", "teacher_small.npz"))
+    cfg = Fs2Config.from_json(str(z["config_json"]))
+    skw = json.loads(str(z["synth_json"]))
+    sd = synth_state_dict(cfg, skw.pop("seed"), **skw)
+    B, T = z["out_mel"].shape[:2]
+    rs = np.random.RandomState(777)
+    batch = {"phones": torch.from_numpy(z["phones"]), "speaker": torch.from_numpy(z["speaker"]),
+             "duration": torch.from_numpy(z["tf_duration"]),
+             "mel": torch.from_numpy((rs.randn(B, T, cfg.n_mels) * 1.3 - 2.0).astype(np.float32))}
+    for v in cfg.variances:
+        batch[f"variances_{v}"] = torch.from_numpy(z[f"tf_variances_{v}"])
+    run_case("train_small", cfg, sd, str(z["synth_json"]), batch, FastSpeech2Loss, NoamLR)
+
+    # depth-wise family (the reference's class defaults, fastspeech2.py:68,76,98,107): every conv depth-wise, odd kernel mix
+    from lightningfastspeech2_amd.weights import synth_inputs
+    cfg = Fs2Config(n_phones=40, encoder_hidden=64, decoder_hidden=64, encoder_head=2, decoder_head=2, encoder_layers=2,
+                    decoder_layers=2, encoder_kernel_sizes=[5, 9], decoder_kernel_sizes=[7, 3], encoder_conv_filter_size=256,
+                    decoder_conv_filter_size=128, encoder_depthwise_conv=True, decoder_depthwise_conv=True,
+                    variance_filter_size=64, variance_depthwise_conv=True, variance_nlayers=[2, 2, 2], variance_kernel_size=[3, 5, 3],
+                    duration_filter_size=64, duration_depthwise_conv=True, duration_nlayers=2, variance_nbins=16, n_mels=8,
+                    stats={"pitch": {"min": -2.0, "max": 2.5, "mean": 0.1, "std": 1.5},
+                           "energy": {"min": -3.0, "max": 3.0, "mean": 0.0, "std": 1.0},
+                           "snr": {"min": -1.0, "max": 4.0, "mean": 1.2, "std": 2.0}})
+    skw = dict(seed=11, randomize_norm=True, duration_bias=1.0)
+    sd = synth_state_dict(cfg, 11, randomize_norm=True, duration_bias=1.0)
+    B, L, lengths = 3, 13, [13, 9, 5]
+    inp = synth_inputs(cfg, B, L, seed=2011, lengths=lengths)
+    rs = np.random.RandomState(8011)
+    dur = rs.randint(0, 6, size=(B, L)).astype(np.int64)
+    for b, n in enumerate(lengths):
+        dur[b, n:] = 0
+    T = int(dur.sum(1).max())
+    batch = {"phones": torch.from_numpy(inp["phones"]), "speaker": torch.from_numpy(inp["speaker"]), "duration": torch.from_numpy(dur),
+             "mel": torch.from_numpy((rs.randn(B, T, cfg.n_mels) * 1.3 - 2.0).astype(np.float32))}
+    for v in cfg.variances:
+        batch[f"variances_{v}"] = torch.from_numpy((1.2 * rs.randn(B, T)).astype(np.float32))
+    run_case("train_dw_small", cfg, sd, json.dumps(skw, sort_keys=True), batch, FastSpeech2Loss, NoamLR)
 
 
 if __name__ == "__main__":
