@@ -317,6 +317,14 @@ int fs2_op_regulate_bwd(int32_t dtype, const void* dy, const int32_t* cum, void*
 int fs2_op_masked_loss_bwd(const float* pred, const void* truth, int32_t truth_kind, const uint8_t* pad_mask,
                            const float* stat, float* dpred, int64_t rows, int32_t inner, int32_t kind, float alpha,
                            void* hip_stream);
+/* nn.Dropout in training mode: y = x * keep / (1 - p) (y may alias x).  The mask is a counter-based hash of (seed, key, element
+ * index) - nothing is stored; the backward applies the same call to the gradient.  Not the reference's random stream (torch's
+ * Philox), the same distribution. */
+int fs2_op_dropout(int32_t dtype, const void* x, void* y, size_t n, float p, uint64_t seed, uint64_t key, void* hip_stream);
+/* pred[m] = mask[m] ? 0 : y[m] . w + b[0]: the VariancePredictor head (model.py:512-518) when a dropout layer sits between the
+ * last LayerNorm and the Linear (otherwise fs2_op_layernorm's fused head does it) */
+int fs2_op_row_dot(int32_t dtype, const void* y, const float* w, const float* b, const uint8_t* mask, float* pred, int64_t M,
+                   int32_t H, void* hip_stream);
 /* depth-wise Conv1d (model.py:75-81, 545-551) backward: data gradient = the same conv with the taps reversed and no bias;
  * weight / bias gradient as per-chunk partials part (fs2_op_dwconv_wgrad_parts(B, S), C * (k + 1)): [c * k + j] then [C * k + c],
  * reduced with fs2_op_col_sum into the adjacent (C, k) weight and (C) bias gradients */

@@ -317,6 +317,40 @@ __global__ void ew_kernel(EwArgs p) {
     }
 }
 
+// ---- dropout: counter-based mask (splitmix64 of seed, site key, element index), regenerated - never stored -------------
+// y = x * keep / (1 - p); the same (seed, key) gives the same mask, so the backward applies the same launch to the gradient.
+__device__ inline uint32_t dropout_bits(uint64_t seed, uint64_t key, uint64_t i) {
+    uint64_t z = seed + key * 0x9E3779B97F4A7C15ull + i * 0xD1B54A32D192ED03ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (uint32_t)(z >> 40);  // 24 bits
+}
+template <typename T>
+__global__ void dropout_kernel(DropoutArgs p) {
+    const uint32_t thr = (uint32_t)(p.p * 16777216.0f);  // drop when bits < thr
+    const float scale = 1.f / (1.f - p.p);
+    const T* x = (const T*)p.x;
+    T* y = (T*)p.y;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < p.n; e += (size_t)gridDim.x * blockDim.x) {
+        const bool keep = dropout_bits(p.seed, p.key, e) >= thr;
+        y[e] = Num<T>::from_f32(keep ? Num<T>::to_f32(x[e]) * scale : 0.f);
+    }
+}
+
+// pred[m] = mask[m] ? 0 : y[m] . w + b   (the predictor head after a dropout layer; one wave per row)
+template <typename T>
+__global__ __launch_bounds__(256) void row_dot_kernel(RowDotArgs p) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.M) return;
+    const T* y = (const T*)p.y + row * p.H;
+    float a = 0.f;
+    for (int c = lane; c < p.H; c += 64) a = fmaf(Num<T>::to_f32(y[c]), p.w[c], a);
+    a = wave_sum(a);
+    if (lane == 0) p.pred[row] = (p.mask && p.mask[row]) ? 0.f : a + p.b[0];
+}
+
 // ---- embedding backward: one workgroup per table row, source rows visited in index order --------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void scatter_rows_kernel(ScatterRowsArgs p) {
@@ -552,6 +586,25 @@ __global__ void unfold_conv2_kernel(UnfoldConv2Args p) {
 inline int ok() { return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP; }
 
 }  // namespace
+
+int launch_dropout(const DropoutArgs& a, int dtype, hipStream_t stream) {
+    if (!(a.p >= 0.f && a.p < 1.f)) return FS2_ERR_ARG;
+    if (!a.n) return FS2_OK;
+    size_t blocks = (a.n + 2047) / 2048;
+    if (blocks > 8192) blocks = 8192;
+    if (dtype == FS2_BF16) hipLaunchKernelGGL(dropout_kernel<bf16>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    else if (dtype == FS2_F32) hipLaunchKernelGGL(dropout_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    else return FS2_ERR_SHAPE;
+    return ok();
+}
+int launch_row_dot(const RowDotArgs& a, int dtype, hipStream_t stream) {
+    if (a.M <= 0 || a.H <= 0) return FS2_ERR_SHAPE;
+    const dim3 g((unsigned)((a.M + 3) / 4));
+    if (dtype == FS2_BF16) hipLaunchKernelGGL(row_dot_kernel<bf16>, g, dim3(256), 0, stream, a);
+    else if (dtype == FS2_F32) hipLaunchKernelGGL(row_dot_kernel<float>, g, dim3(256), 0, stream, a);
+    else return FS2_ERR_SHAPE;
+    return ok();
+}
 
 int dwconv_wgrad_parts(int B, int S) { return B * ((S + DWG_R - 1) / DWG_R); }
 int launch_dwconv_wgrad(const DwConvWgradArgs& a, int dtype, hipStream_t stream) {

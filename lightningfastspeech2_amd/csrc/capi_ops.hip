@@ -249,6 +249,15 @@ int fs2_op_masked_loss_bwd(const float* pred, const void* truth, int32_t truth_k
     LossBwdArgs a{pred, truth, pad_mask, stat, dpred, rows, inner, kind, truth_kind, alpha};
     return launch_masked_loss_bwd(a, (hipStream_t)stream);
 }
+int fs2_op_dropout(int32_t dtype, const void* x, void* y, size_t n, float prob, uint64_t seed, uint64_t key, void* stream) {
+    DropoutArgs a{x, y, n, prob, seed, key};
+    return launch_dropout(a, dtype, (hipStream_t)stream);
+}
+int fs2_op_row_dot(int32_t dtype, const void* y, const float* w, const float* b, const uint8_t* mask, float* pred, int64_t M,
+                   int32_t H, void* stream) {
+    RowDotArgs a{y, w, b, mask, pred, (long)M, H};
+    return launch_row_dot(a, dtype, (hipStream_t)stream);
+}
 int fs2_op_dwconv_dgrad(int32_t dtype, const void* dy, const float* w, void* dx, int32_t B, int32_t S, int32_t C, int32_t k,
                         void* stream) {
     DwConvArgs a{dy, w, nullptr, dx, B, S, C, k, (k - 1) / 2};

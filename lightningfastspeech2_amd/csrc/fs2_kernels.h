@@ -407,6 +407,25 @@ struct UnfoldConv2Args {
 };
 int launch_unfold_conv2(const UnfoldConv2Args& a, hipStream_t stream);
 
+struct DropoutArgs {   // y = x * keep / (1 - p), keep from a counter-based hash of (seed, key, element index); y may alias x
+    const void* x;
+    void* y;
+    size_t n;
+    float p;
+    uint64_t seed, key;
+};
+int launch_dropout(const DropoutArgs& a, int dtype, hipStream_t stream);
+struct RowDotArgs {    // pred[m] = mask[m] ? 0 : y[m] . w + b[0]
+    const void* y;
+    const float* w;
+    const float* b;
+    const uint8_t* mask;
+    float* pred;
+    long M;
+    int H;
+};
+int launch_row_dot(const RowDotArgs& a, int dtype, hipStream_t stream);
+
 struct TransposeWeightArgs {   // dst (Cin, taps*N) [ci][j'*N + n] = src (N, taps*Cin) [n][(taps-1-j')*Cin + ci]
     const void* src;
     void* dst;

@@ -15,8 +15,10 @@ Covered: dense and depth-wise convolution variants of every block (C1-C5 of BASE
 and the test-size configs; the depth-wise layer's conv2 pair is trained through its folded (H, F) map), frame-level
 'none' variances, 'l1' / 'mse' losses; precision "fp32" (exact fp32 MFMA, the parity mode) or "bf16" (bf16 activations,
 activation gradients and GEMM operands on the bf16 MFMA with fp32 accumulation; fp32 master weights, weight gradients,
-Adam moments, LayerNorm / softmax statistics and losses - what the reference's `--precision 16` recipe does with fp16).  Dropout is 0 (the reference's dropouts are
-random per step and cannot be pinned; p = 0 is what the parity tests compare).  Rejected loudly: phone-level / CWT
+Adam moments, LayerNorm / softmax statistics and losses - what the reference's `--precision 16` recipe does with fp16).  Dropout: every nn.Dropout site of the reference in
+training mode (encoder / decoder incl. the attention weights and both positional encodings, variance / duration predictors)
+with a counter-based mask that is regenerated, not stored; 0 by default, which is what the parity fixtures pin (the
+reference's masks come from torch's random stream and cannot be reproduced).  Rejected loudly: phone-level / CWT
 variances, priors, stochastic durations.
 """
 from __future__ import annotations
@@ -53,6 +55,12 @@ class _Ops:
         if self.dev.type != "cuda":
             raise RuntimeError("the training step runs on the GPU (no CPU path)")
         self._ws: Dict[str, torch.Tensor] = {}
+        self.seed = 0       # dropout: set per micro-step by the trainer
+        self._site = 0      # dropout site counter of the current forward
+
+    def site(self):
+        self._site += 1
+        return self._site
 
     def st(self):
         return C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
@@ -145,6 +153,16 @@ class _Ops:
         self.ck(self.lib.fs2_op_dwconv_dgrad(self.dt, _p(du), _p(w), _p(dx), B, S, Cc, k, self.st()), "dwconv_dgrad")
         return dx
 
+    def dropout(self, x, p, key, out=None):
+        """nn.Dropout (training): in place unless `out` is given; mask = f(self.seed, key, element index), so calling it again
+        with the same key on a gradient is the backward."""
+        if p <= 0.0:
+            return x
+        y = x if out is None else out
+        self.ck(self.lib.fs2_op_dropout(self._dt(x), _p(x), _p(y), x.numel(), C.c_float(p), C.c_uint64(self.seed), C.c_uint64(key),
+                                        self.st()), "dropout")
+        return y
+
     def add_(self, a, b):
         self.ck(self.lib.fs2_op_ew(self._dt(a), 0, _p(a), _p(b), _p(a), a.numel(), C.c_float(1), C.c_float(1), self.st()), "add")
         return a
@@ -187,7 +205,8 @@ class Trainer:
 
     def __init__(self, cfg: Fs2Config, state_dict, *, lr=2e-4, warmup_steps=4000, betas=(0.9, 0.98), eps=1e-8,
                  weight_decay=0.01, gradient_clip_val: Optional[float] = 1.0, variance_losses=None, mel_loss="l1",
-                 duration_loss="mse", loss_alphas=None, precision="fp32", device="cuda:0"):
+                 duration_loss="mse", loss_alphas=None, precision="fp32", encoder_dropout=0.0, decoder_dropout=0.0,
+                 variance_dropout=0.0, duration_dropout=0.0, seed=0, device="cuda:0"):
         if any(l != "frame" for l in cfg.variance_levels[:len(cfg.variances)]) or any(cfg.is_cwt(i) for i in range(len(cfg.variances))):
             raise NotImplementedError("training step: frame-level 'none' variances only")
         if cfg.priors:
@@ -199,6 +218,13 @@ class Trainer:
         self.dev = self.ops.dev
         self.lr, self.warmup_steps, self.betas, self.eps, self.weight_decay = lr, warmup_steps, betas, eps, weight_decay
         self.gradient_clip_val = gradient_clip_val
+        # nn.Dropout sites of the reference in training mode (fastspeech2.py:94,103 encoder/decoder_dropout incl. the attention
+        # weights and both PositionalEncoding calls; :65,74 variance / duration predictors).  Reference defaults 0.1 / 0.1 / 0.5 /
+        # 0.5, the shipped recipe 0.1 everywhere (scripts/train.sh:12-13); 0 here unless asked, which is what parity pins.
+        nv_ = len(cfg.variances)
+        self.p_enc, self.p_dec, self.p_dur = float(encoder_dropout), float(decoder_dropout), float(duration_dropout)
+        self.p_var = [float(v) for v in variance_dropout][:nv_] if isinstance(variance_dropout, (list, tuple)) else [float(variance_dropout)] * nv_
+        self.seed, self._micro = int(seed), 0
         self.variance_losses = list(variance_losses) if variance_losses is not None else ["mse"] * len(cfg.variances)
         self.mel_loss, self.duration_loss = mel_loss, duration_loss
         self.loss_alphas = dict(loss_alphas) if loss_alphas is not None else {
@@ -320,10 +346,10 @@ class Trainer:
         return self.lr * self.warmup_steps ** 0.5 * min(e ** -0.5, e * self.warmup_steps ** -1.5)
 
     # ---- forward / backward of one ConformerEncoderLayer (model.py:65-122, post-norm) ----
-    def _layer_fwd(self, x, prefix, B, S, heads, F_, k, key_pad):
+    def _layer_fwd(self, x, prefix, B, S, heads, F_, k, key_pad, pd=0.0):
         o, P, W, H = self.ops, self.P, self.W, self.cfg.hidden
         M, d = B * S, H // heads
-        t = {"x": x}
+        t = {"x": x, "pd": pd, "k_attn": o.site(), "k_sa": o.site(), "k_h": o.site(), "k_ff": o.site()}
         qkv = o.gemm(x, W[f"{prefix}.self_attn.in_proj_weight"], P[f"{prefix}.self_attn.in_proj_bias"], M, 3 * H, H)
         scores = o.empty(B, heads, S, S)  # fp32 in either mode; the probabilities are kept in the activation dtype
         o.bgemm(qkv, qkv[:, H:], scores, M=S, N=S, K=d, sAm=3 * H, sAk=1, sBk=1, sBn=3 * H, ldc=S, nb1=B, nb2=heads,
@@ -332,20 +358,22 @@ class Trainer:
         prob = scores if o.dt == F32 else o.act(B, heads, S, S)
         o.ck(o.lib.fs2_op_softmax_fwd(o.dt, _p(scores), _p(key_pad), _p(prob), B, heads, S, C.c_float(scale), o.st()), "softmax")
         del scores
+        prob_d = o.dropout(prob, pd, t["k_attn"], out=o.act(B, heads, S, S)) if pd > 0 else prob  # MHA drops attention weights
         attn = o.act(M, H)
-        o.bgemm(prob, qkv[:, 2 * H:], attn, M=S, N=d, K=S, sAm=S, sAk=1, sBk=3 * H, sBn=1, ldc=H, nb1=B, nb2=heads,
+        o.bgemm(prob_d, qkv[:, 2 * H:], attn, M=S, N=d, K=S, sAm=S, sAk=1, sBk=3 * H, sBn=1, ldc=H, nb1=B, nb2=heads,
                 sA1=heads * S * S, sA2=S * S, sB1=S * 3 * H, sB2=d, sC1=S * H, sC2=d)
-        proj = o.gemm(attn, W[f"{prefix}.self_attn.out_proj.weight"], P[f"{prefix}.self_attn.out_proj.bias"], M, H, H)
+        proj = o.dropout(o.gemm(attn, W[f"{prefix}.self_attn.out_proj.weight"], P[f"{prefix}.self_attn.out_proj.bias"], M, H, H),
+                         pd, t["k_sa"])  # dropout1
         x1, _ = o.layernorm(proj, x, P[f"{prefix}.norm1.weight"], P[f"{prefix}.norm1.bias"], M, H)
         if prefix in self.fold:  # depth-wise FFN (model.py:73-93): dw(k) -> pw H->F -> ReLU -> [grouped 1x1 . pw F->H] folded
             t["u"] = o.dwconv(x1, P[f"{prefix}.conv1.0.weight"], P[f"{prefix}.conv1.0.bias"], B, S, H, k)
-            h = o.gemm(t["u"], W[f"{prefix}.conv1.1.weight"], P[f"{prefix}.conv1.1.bias"], M, F_, H, relu=True)
-            c2 = o.gemm(h, self.fold[prefix]["Wf"], self.fold[prefix]["bf"], M, H, F_)
+            h = o.dropout(o.gemm(t["u"], W[f"{prefix}.conv1.1.weight"], P[f"{prefix}.conv1.1.bias"], M, F_, H, relu=True), pd, t["k_h"])
+            c2 = o.dropout(o.gemm(h, self.fold[prefix]["Wf"], self.fold[prefix]["bf"], M, H, F_), pd, t["k_ff"])
         else:
-            h = o.gemm(x1, W[f"{prefix}.conv1.weight"], P[f"{prefix}.conv1.bias"], M, F_, H, taps=k, S=S, relu=True)
-            c2 = o.gemm(h, W[f"{prefix}.conv2.weight"], P[f"{prefix}.conv2.bias"], M, H, F_)
+            h = o.dropout(o.gemm(x1, W[f"{prefix}.conv1.weight"], P[f"{prefix}.conv1.bias"], M, F_, H, taps=k, S=S, relu=True), pd, t["k_h"])
+            c2 = o.dropout(o.gemm(h, W[f"{prefix}.conv2.weight"], P[f"{prefix}.conv2.bias"], M, H, F_), pd, t["k_ff"])  # dropout2
         x2, _ = o.layernorm(c2, x1, P[f"{prefix}.norm2.weight"], P[f"{prefix}.norm2.bias"], M, H)
-        t.update(qkv=qkv, prob=prob, attn=attn, proj=proj, x1=x1, h=h, c2=c2, scale=scale)
+        t.update(qkv=qkv, prob=prob, prob_d=prob_d, attn=attn, proj=proj, x1=x1, h=h, c2=c2, scale=scale)
         return x2, t
 
     def _ln_bwd(self, z, res, dy, gname, bname, M, H, bias_name=None, relu_mask=False, bias_out=None):
@@ -371,42 +399,57 @@ class Trainer:
     def _layer_bwd(self, dx2, t, prefix, B, S, heads, F_, k):
         o, P, W, G, H = self.ops, self.P, self.W, self.G, self.cfg.hidden
         M, d = B * S, H // heads
-        if prefix in self.fold:
+        pd, folded = t["pd"], prefix in self.fold
+        dbf = o.empty(H) if folded else None
+        # x2 = LN2(x1 + dropout2(c2)): dz2 is the gradient of x1 (residual) and, through dropout2, of c2
+        dx1 = self._ln_bwd(t["c2"], t["x1"], dx2, f"{prefix}.norm2.weight", f"{prefix}.norm2.bias", M, H,
+                           bias_name=f"{prefix}.conv2.bias" if (pd <= 0 and not folded) else None,
+                           bias_out=dbf if (pd <= 0 and folded) else None)
+        dc2 = dx1
+        if pd > 0:
+            dc2 = o.dropout(dx1, pd, t["k_ff"], out=o.act(M, H))
+            o.col_sum(dc2, dbf if folded else G[f"{prefix}.conv2.bias"], M, H, accumulate=not folded)
+        if folded:
             f = self.fold[prefix]
-            dbf = o.empty(H)
-            dx1 = self._ln_bwd(t["c2"], t["x1"], dx2, f"{prefix}.norm2.weight", f"{prefix}.norm2.bias", M, H, bias_out=dbf)
             dWf = torch.zeros(H, F_, device=self.dev)
-            o.wgrad(dx1, t["h"], dWf, None, M, H, F_)
+            o.wgrad(dc2, t["h"], dWf, None, M, H, F_)
             o.ck(o.lib.fs2_op_unfold_conv2(_p(dWf), _p(dbf), _p(P[f"{prefix}.conv2.0.weight"]), _p(P[f"{prefix}.conv2.0.bias"]),
                                            _p(P[f"{prefix}.conv2.1.weight"]), _p(G[f"{prefix}.conv2.0.weight"]), _p(G[f"{prefix}.conv2.0.bias"]),
                                            _p(G[f"{prefix}.conv2.1.weight"]), _p(G[f"{prefix}.conv2.1.bias"]), H, F_, o.st()), "unfold_conv2")
-            dh = o.relu_bwd(o.dgrad(dx1, f["Wf"], M, H, F_, wt=f["WfT"] if self.use_forward_dgrad else None), t["h"])
+            dh = o.dgrad(dc2, f["Wf"], M, H, F_, wt=f["WfT"] if self.use_forward_dgrad else None)
+        else:
+            o.wgrad(dc2, t["h"], G[f"{prefix}.conv2.weight"], None, M, H, F_)
+            dh = o.dgrad(dc2, W[f"{prefix}.conv2.weight"], M, H, F_, wt=self._wt(f"{prefix}.conv2.weight"))
+        dh = o.relu_bwd(o.dropout(dh, pd, t["k_h"]), t["h"])  # h (post-dropout) > 0  <=>  kept and pre-activation > 0
+        if folded:
             o.wgrad(dh, t["u"], G[f"{prefix}.conv1.1.weight"], G[f"{prefix}.conv1.1.bias"], M, F_, H)
             du = o.dgrad(dh, W[f"{prefix}.conv1.1.weight"], M, F_, H, wt=self._wt(f"{prefix}.conv1.1.weight"))
             o.add_(dx1, o.dwconv_bwd(du, t["x1"], P[f"{prefix}.conv1.0.weight"], G[f"{prefix}.conv1.0.weight"], G[f"{prefix}.conv1.0.bias"],
                                      B, S, H, k))
         else:
-            dx1 = self._ln_bwd(t["c2"], t["x1"], dx2, f"{prefix}.norm2.weight", f"{prefix}.norm2.bias", M, H,
-                               bias_name=f"{prefix}.conv2.bias")  # = dc2 too
-            o.wgrad(dx1, t["h"], G[f"{prefix}.conv2.weight"], None, M, H, F_)
-            dh = o.relu_bwd(o.dgrad(dx1, W[f"{prefix}.conv2.weight"], M, H, F_, wt=self._wt(f"{prefix}.conv2.weight")), t["h"])
             o.wgrad(dh, t["x1"], G[f"{prefix}.conv1.weight"], G[f"{prefix}.conv1.bias"], M, F_, H, taps=k, S=S)
             o.dgrad(dh, W[f"{prefix}.conv1.weight"], M, F_, H, taps=k, S=S, out=dx1, accumulate=True, wt=self._wt(f"{prefix}.conv1.weight"))
+        # x1 = LN1(x + dropout1(proj))
         dx = self._ln_bwd(t["proj"], t["x"], dx1, f"{prefix}.norm1.weight", f"{prefix}.norm1.bias", M, H,
-                          bias_name=f"{prefix}.self_attn.out_proj.bias")  # = dproj too
-        o.wgrad(dx, t["attn"], G[f"{prefix}.self_attn.out_proj.weight"], None, M, H, H)
-        dattn = o.dgrad(dx, W[f"{prefix}.self_attn.out_proj.weight"], M, H, H, wt=self._wt(f"{prefix}.self_attn.out_proj.weight"))
+                          bias_name=f"{prefix}.self_attn.out_proj.bias" if pd <= 0 else None)
+        dproj = dx
+        if pd > 0:
+            dproj = o.dropout(dx, pd, t["k_sa"], out=o.act(M, H))
+            o.col_sum(dproj, G[f"{prefix}.self_attn.out_proj.bias"], M, H)
+        o.wgrad(dproj, t["attn"], G[f"{prefix}.self_attn.out_proj.weight"], None, M, H, H)
+        dattn = o.dgrad(dproj, W[f"{prefix}.self_attn.out_proj.weight"], M, H, H, wt=self._wt(f"{prefix}.self_attn.out_proj.weight"))
         qkv, prob = t["qkv"], t["prob"]
         dqkv = o.act(M, 3 * H)
         bat = dict(nb1=B, nb2=heads)
         sP = dict(sA1=heads * S * S, sA2=S * S)
-        # dV = P^T dO
-        o.bgemm(prob, dattn, dqkv[:, 2 * H:], M=S, N=d, K=S, sAm=1, sAk=S, sBk=H, sBn=1, ldc=3 * H, sB1=S * H, sB2=d,
+        # dV = dropout(P)^T dO
+        o.bgemm(t["prob_d"], dattn, dqkv[:, 2 * H:], M=S, N=d, K=S, sAm=1, sAk=S, sBk=H, sBn=1, ldc=3 * H, sB1=S * H, sB2=d,
                 sC1=S * 3 * H, sC2=d, **bat, **sP)
         # dP = dO V^T
         dp = o.empty(B, heads, S, S)
         o.bgemm(dattn, qkv[:, 2 * H:], dp, M=S, N=S, K=d, sAm=H, sAk=1, sBk=1, sBn=3 * H, ldc=S, sA1=S * H, sA2=d,
                 sB1=S * 3 * H, sB2=d, sC1=heads * S * S, sC2=S * S, **bat)
+        o.dropout(dp, pd, t["k_attn"])  # back through the attention-weight dropout (fp32 buffer, same element order as P)
         ds = dp if o.dt == F32 else o.act(B, heads, S, S)
         o.ck(o.lib.fs2_op_softmax_bwd(o.dt, _p(dp), _p(prob), _p(ds), B, heads, S, C.c_float(t["scale"]), o.st()), "softmax_bwd")
         dp = ds
@@ -420,7 +463,7 @@ class Trainer:
         return dx
 
     # ---- VariancePredictor (model.py:482-561, dense) ----
-    def _predictor_fwd(self, x, prefix, nlayers, filt, k, B, S, mask, dw=False):
+    def _predictor_fwd(self, x, prefix, nlayers, filt, k, B, S, mask, dw=False, pd=0.0):
         o, P, W, H = self.ops, self.P, self.W, self.cfg.hidden
         M = B * S
         tape, y, cin = [], x, H
@@ -433,12 +476,19 @@ class Trainer:
             else:
                 c = o.gemm(y, W[f"{p}.0.module.weight"], P[f"{p}.0.module.bias"], M, filt, cin, taps=k, S=S, relu=True)
             last = j == nlayers - 1
+            fused_head = last and pd <= 0
             yn, pred = o.layernorm(c, None, P[f"{p}.2.weight"], P[f"{p}.2.bias"], M, filt,
-                                   dot_w=P[f"{prefix}.linear.weight"] if last else None,
-                                   dot_b=float(P[f"{prefix}.linear.bias"][0]) if last else 0.0, mask=mask if last else None)
-            tape.append({"xin": y, "c": c, "cin": cin, "u": u})
+                                   dot_w=P[f"{prefix}.linear.weight"] if fused_head else None,
+                                   dot_b=float(P[f"{prefix}.linear.bias"][0]) if fused_head else 0.0, mask=mask if fused_head else None)
+            kd = o.site()
+            o.dropout(yn, pd, kd)  # VarianceConvolutionLayer ends in nn.Dropout (model.py:539,557)
+            if last and pd > 0:
+                pred = o.empty(M)
+                o.ck(o.lib.fs2_op_row_dot(o.dt, _p(yn), _p(P[f"{prefix}.linear.weight"]), _p(P[f"{prefix}.linear.bias"]), _p(mask), _p(pred),
+                                          M, filt, o.st()), "row_dot")
+            tape.append({"xin": y, "c": c, "cin": cin, "u": u, "kd": kd})
             y, cin = yn, filt
-        return pred, {"layers": tape, "y": y}
+        return pred, {"layers": tape, "y": y, "pd": pd}
 
     def _predictor_bwd(self, dpred, t, prefix, nlayers, filt, k, B, S, dx_out, dw=False):
         """dpred (M) -> gradients of the predictor's parameters, and dx_out (M, H) += d/dx."""
@@ -454,6 +504,7 @@ class Trainer:
         for j in reversed(range(nlayers)):
             p = f"{prefix}.layers.{j}.layers"
             lt = t["layers"][j]
+            o.dropout(dy, t["pd"], lt["kd"])
             if dw:
                 dc = self._ln_bwd(lt["c"], None, dy, f"{p}.2.weight", f"{p}.2.bias", M, filt, bias_name=f"{p}.0.module.1.bias", relu_mask=True)
                 o.wgrad(dc, lt["u"], G[f"{p}.0.module.1.weight"], None, M, filt, lt["cin"])
@@ -507,21 +558,30 @@ class Trainer:
         pe = self.buffers["positional_encoding.pe"]
         with torch.cuda.device(dev):
             # ---------------- forward ----------------
+            o.seed, o._site = (self.seed * 1000003 + self._micro) & 0xFFFFFFFFFFFFFFFF, 0
+            self._micro += 1
+            pe_drop = self.p_enc > 0  # PositionalEncoding(dropout=encoder_dropout) serves both stacks (fastspeech2.py:296-298)
+            k_pe_enc, k_pe_dec = o.site(), o.site()
             spk = o.empty(B, H)
             o.ck(o.lib.fs2_op_spk_proj(_p(dvec), _p(P["speaker_embedding.projection.weight"]), _p(P["speaker_embedding.projection.bias"]),
                                        _p(spk), B, H, dvec.shape[1], o.st()), "spk_proj")
             x = o.act(B * L, H)
             src_mask = o.empty(B, L, dtype=torch.uint8)
-            o.ck(o.lib.fs2_op_embed(o.dt, _p(phones), _p(P["phone_embedding.weight"]), _p(pe), _p(spk), _p(x), _p(src_mask), B, L, H,
-                                    cfg.n_phones, o.st()), "embed")
+            zero_spk = torch.zeros(B, H, device=dev) if pe_drop else None
+            o.ck(o.lib.fs2_op_embed(o.dt, _p(phones), _p(P["phone_embedding.weight"]), _p(pe), _p(zero_spk if pe_drop else spk), _p(x),
+                                    _p(src_mask), B, L, H, cfg.n_phones, o.st()), "embed")
+            if pe_drop:  # x = dropout(E[phones] + pe) + spk   (model.py:53-55, fastspeech2.py:655-660)
+                o.dropout(x, self.p_enc, k_pe_enc)
+                o.ck(o.lib.fs2_op_bucket_embed(o.dt, _p(x), None, None, None, 0, C.c_float(1), C.c_float(0), None, _p(spk), _p(x), None,
+                                               B, L, H, o.st()), "add_spk")
             enc_t = []
             for i in range(cfg.encoder_layers):
                 x, t = self._layer_fwd(x, f"encoder.layers.{i}", B, L, cfg.encoder_head, cfg.encoder_conv_filter_size,
-                                       cfg.encoder_kernel_sizes[i], src_mask)
+                                       cfg.encoder_kernel_sizes[i], src_mask, pd=self.p_enc)
                 enc_t.append(t)
             dur_pred, dur_tape = self._predictor_fwd(x, "variance_adaptor.duration_predictor", cfg.duration_nlayers,
                                                      cfg.duration_filter_size, cfg.duration_kernel_size, B, L, src_mask,
-                                                     dw=cfg.duration_depthwise_conv)
+                                                     dw=cfg.duration_depthwise_conv, pd=self.p_dur)
             forced = dur_t.to(torch.int32)
             dur, cum, totals, guard = (o.empty(B, L, dtype=torch.int32), o.empty(B, L, dtype=torch.int32),
                                        o.empty(B, dtype=torch.int32), o.empty(B, dtype=torch.int32))
@@ -535,27 +595,32 @@ class Trainer:
             for vi, v in enumerate(cfg.variances):
                 pfx = f"variance_adaptor.encoders.{v}"
                 var_pred[v], var_tape[v] = self._predictor_fwd(xa, f"{pfx}.predictor", cfg.variance_nlayers[vi], cfg.variance_filter_size,
-                                                               cfg.variance_kernel_size[vi], B, T, tgt_mask, dw=cfg.variance_depthwise_conv)
+                                                               cfg.variance_kernel_size[vi], B, T, tgt_mask, dw=cfg.variance_depthwise_conv,
+                                                               pd=self.p_var[vi])
                 idx = o.empty(B * T, dtype=torch.int32)
                 xn = o.act(B * T, H)
                 last = vi == nv - 1
                 st_ = cfg.stats[v]
                 o.ck(o.lib.fs2_op_bucket_embed_target(o.dt, _p(xa), _p(var_t[v]), _p(self.buffers[f"{pfx}.bins"]), _p(P[f"{pfx}.embedding.weight"]),
                                                       cfg.variance_nbins, C.c_float(st_["std"]), C.c_float(st_["mean"]),
-                                                      _p(pe) if last else None, _p(spk) if last else None, _p(xn), _p(idx), B, T, H, o.st()),
-                     "bucket_embed_target")
+                                                      _p(pe) if last else None, _p(spk) if (last and not pe_drop) else None, _p(xn), _p(idx),
+                                                      B, T, H, o.st()), "bucket_embed_target")
                 var_idx[v] = idx
                 xa = xn
             if nv == 0:
                 xn = o.act(B * T, H)
-                o.ck(o.lib.fs2_op_bucket_embed(o.dt, _p(xa), None, None, None, 0, C.c_float(1), C.c_float(0), _p(pe), _p(spk), _p(xn), None,
-                                               B, T, H, o.st()), "pe_spk")
+                o.ck(o.lib.fs2_op_bucket_embed(o.dt, _p(xa), None, None, None, 0, C.c_float(1), C.c_float(0), _p(pe),
+                                               None if pe_drop else _p(spk), _p(xn), None, B, T, H, o.st()), "pe_spk")
                 xa = xn
             y = xa
+            if pe_drop:  # y = dropout(x + pe) + spk   (fastspeech2.py:705-718)
+                o.dropout(y, self.p_enc, k_pe_dec)
+                o.ck(o.lib.fs2_op_bucket_embed(o.dt, _p(y), None, None, None, 0, C.c_float(1), C.c_float(0), None, _p(spk), _p(y), None,
+                                               B, T, H, o.st()), "add_spk")
             dec_t = []
             for i in range(cfg.decoder_layers):
                 y, t = self._layer_fwd(y, f"decoder.layers.{i}", B, T, cfg.decoder_head, cfg.decoder_conv_filter_size,
-                                       cfg.decoder_kernel_sizes[i], tgt_mask)
+                                       cfg.decoder_kernel_sizes[i], tgt_mask, pd=self.p_dec)
                 dec_t.append(t)
             mel = o.gemm(y, W["linear.weight"], P["linear.bias"], B * T, cfg.n_mels, H, out_f32=True)
             # ---------------- losses + their gradients (loss.py:83-213) ----------------
@@ -577,8 +642,8 @@ class Trainer:
                 dy = self._layer_bwd(dy, dec_t[i], f"decoder.layers.{i}", B, T, cfg.decoder_head, cfg.decoder_conv_filter_size,
                                      cfg.decoder_kernel_sizes[i])
             dspk = torch.zeros(B, H, device=dev)
-            o.col_sum(dy, dspk, B * T, H, seg=T)  # decoder input = adaptor out + pe + spk (fastspeech2.py:705-718)
-            dx = dy
+            o.col_sum(dy, dspk, B * T, H, seg=T)  # decoder input = dropout(adaptor out + pe) + spk (fastspeech2.py:705-718)
+            dx = o.dropout(dy, self.p_enc, k_pe_dec)
             for vi in reversed(range(nv)):
                 v = cfg.variances[vi]
                 pfx = f"variance_adaptor.encoders.{v}"
@@ -593,9 +658,10 @@ class Trainer:
             for i in reversed(range(cfg.encoder_layers)):
                 dxe = self._layer_bwd(dxe, enc_t[i], f"encoder.layers.{i}", B, L, cfg.encoder_head, cfg.encoder_conv_filter_size,
                                       cfg.encoder_kernel_sizes[i])
+            o.col_sum(dxe, dspk, B * L, H, seg=L)
+            o.dropout(dxe, self.p_enc, k_pe_enc)
             o.ck(o.lib.fs2_op_scatter_rows(o.dt, _p(dxe), None, _p(phones), _p(G["phone_embedding.weight"]), B * L, H, cfg.n_phones, 0, o.st()),
                  "scatter_rows")
-            o.col_sum(dxe, dspk, B * L, H, seg=L)
             o.relu_bwd(dspk, spk)  # spk = relu(W dvec + b), model.py:137-143
             o.wgrad(dspk, dvec, G["speaker_embedding.projection.weight"], G["speaker_embedding.projection.bias"], B, H, dvec.shape[1])
         self._accum += 1

@@ -164,3 +164,63 @@ def test_bf16_mixed_precision_step_tracks_the_fp32_gradients():
         last = float(tr.training_step(_dev(batch))["total"])
         tr.optimizer_step()
     assert last < first
+
+
+def test_dropout_op_statistics_and_determinism():
+    import ctypes as C
+    from lightningfastspeech2_amd import _lib
+    lib = _lib.load()
+    n, p = 1 << 20, 0.3
+    x = torch.ones(n, device="cuda:0")
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    outs = []
+    for seed, key in ((5, 1), (5, 1), (5, 2), (6, 1)):
+        y = torch.empty_like(x)
+        _lib.check(lib.fs2_op_dropout(_lib.FS2_F32, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), n, C.c_float(p), C.c_uint64(seed), C.c_uint64(key), st))
+        outs.append(y.cpu())
+    a, b, c, d = outs
+    assert torch.equal(a, b) and not torch.equal(a, c) and not torch.equal(a, d)
+    keep = float((a != 0).float().mean())
+    assert abs(keep - (1 - p)) <= 4 * (p * (1 - p) / n) ** 0.5
+    assert torch.allclose(a[a != 0], torch.tensor(1 / (1 - p)))
+    both = float(((a != 0) & (c != 0)).float().mean())   # two sites: independent masks
+    assert abs(both - (1 - p) ** 2) <= 5e-3
+    xb = torch.ones(n, device="cuda:0", dtype=torch.bfloat16)
+    yb = torch.empty_like(xb)
+    _lib.check(lib.fs2_op_dropout(_lib.FS2_BF16, C.c_void_p(xb.data_ptr()), C.c_void_p(yb.data_ptr()), n, C.c_float(p), C.c_uint64(5), C.c_uint64(1), st))
+    assert torch.equal(yb.cpu() != 0, a != 0)  # the mask depends on (seed, key, index) only: an fp32 gradient meets the bf16 mask
+
+
+@pytest.mark.parametrize("kw", [{}, DW])
+def test_backward_is_the_derivative_of_the_forward_under_dropout(kw):
+    """With every dropout site switched on (fixed seed, so the step is a deterministic function of the weights) the gradient
+    buffer must be the directional derivative of the total loss: (L(w + eps v) - L(w - eps v)) / (2 eps) = g . v.  The
+    directions are the gradient itself re-weighted element by element (v = g * u, u ~ U(0.5, 1.5)), so g . v = sum g^2 u is far
+    above the fp32 noise of a loss difference and a wrong mask, scale or position in the chain at any site shows up in it;
+    tools/probes/fd_check.py does the same with random directions, site by site."""
+    from lightningfastspeech2_amd.training import Trainer
+    cfg, sd, batch = _case(31, 3, 12, [12, 7, 3], **kw)
+    drop = dict(encoder_dropout=0.2, decoder_dropout=0.15, variance_dropout=[0.3, 0.25], duration_dropout=0.3, seed=9)
+    tr = Trainer(cfg, sd, gradient_clip_val=None, **drop)
+    bd = _dev(batch)
+    l0 = float(tr.training_step(bd)["total"])
+    g = tr.flat_g.clone().double()
+    tr.zero_grad()
+    tr0 = Trainer(cfg, sd, gradient_clip_val=None)
+    assert abs(float(tr0.training_step(bd)["total"]) - l0) > 1e-3  # dropout really is on
+    w0 = tr.flat_p.clone()
+    gen = torch.Generator(device="cuda:0").manual_seed(3)
+    for trial in range(3):
+        v = g.float() * (0.5 + torch.rand(tr.n_flat, device="cuda:0", generator=gen))
+        eps = 1e-4 / float(v.norm()) * float(w0.norm())  # |eps v| = 1e-4 |w|: few ReLU / L1 kinks are crossed
+        vals = []
+        for sgn in (1.0, -1.0):
+            tr.flat_p.copy_(w0 + sgn * eps * v)
+            tr._refresh_shadow()
+            tr._micro = 0  # same masks as the step whose gradient is checked
+            vals.append(float(tr.training_step(bd)["total"].double()))
+            tr.zero_grad()
+        fd = (vals[0] - vals[1]) / (2 * eps)
+        an = float((g * v.double()).sum())
+        assert an > 0 and abs(fd - an) <= 3e-2 * an, (trial, fd, an)
+    tr.flat_p.copy_(w0)
