@@ -181,3 +181,22 @@ def forward_sharded(forward_fn: Callable[..., Dict[str, torch.Tensor]], batch: D
     shapes = (Bs, t_glob["T"]) if global_pad else None
     mel_all, frames = gather_mels(mel, mask, group=group, shapes=shapes, zeroed=zeroed)
     return mel_all, frames, local
+
+
+# ---- training: gradient averaging over the data-parallel ranks (what Lightning's DDP strategy does, scripts/train.sh "--strategy ddp") ----
+def all_reduce_gradients(flat_g: torch.Tensor, group=None, *, bucket_bytes: int = 256 << 20, async_op: bool = False):
+    """SUM the flat fp32 gradient buffer of ``training.Trainer`` over the ranks, in place.
+
+    All parameters' gradients live in one contiguous buffer, so this is a handful of large all-reduces (``bucket_bytes`` each;
+    xGMI rings are per-link bound, big messages keep every link busy) instead of one per tensor.  The 1 / world factor is folded
+    into the optimizer's gradient scale by the caller (``Trainer.optimizer_step``).  ``async_op``: returns the work handles;
+    the collectives run on the collective library's stream (RCCL) and overlap whatever the caller launches next.
+    """
+    n = flat_g.numel()
+    per = max(1, bucket_bytes // flat_g.element_size())
+    works = []
+    for lo in range(0, n, per):
+        w = dist.all_reduce(flat_g[lo:min(n, lo + per)], op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+        if async_op:
+            works.append(w)
+    return works

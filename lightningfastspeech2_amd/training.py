@@ -669,12 +669,20 @@ class Trainer:
                      "src_mask": src_mask.bool(), **{f"variances_{v}": var_pred[v].view(B, T) for v in cfg.variances}}
         return losses
 
-    def optimizer_step(self):
-        """clip_grad_norm_(gradient_clip_val) on the mean of the accumulated micro-batch gradients, AdamW, NoamLR."""
+    def optimizer_step(self, group=None):
+        """clip_grad_norm_(gradient_clip_val) on the mean of the accumulated micro-batch gradients, AdamW, NoamLR.  With an
+        initialised torch.distributed process group (one process per GPU, "nccl" = RCCL) the flat gradient buffer is summed
+        over the ranks first and the 1 / world factor joins the gradient scale - DDP's gradient averaging."""
         if self._accum == 0:
             raise RuntimeError("optimizer_step before any training_step")
         o = self.ops
         lr = self.current_lr()
+        world = 1
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            from .dist import all_reduce_gradients
+            world = torch.distributed.get_world_size(group)
+            if world > 1:
+                all_reduce_gradients(self.flat_g, group)
         with torch.cuda.device(self.dev):
             nsq = None
             if self.gradient_clip_val is not None:
@@ -682,7 +690,7 @@ class Trainer:
                 nsq = self._nsq
             o.ck(o.lib.fs2_op_adamw(_p(self.flat_p), _p(self.flat_g), _p(self.flat_m), _p(self.flat_v), self.n_flat, C.c_float(lr),
                                     C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps), C.c_float(self.weight_decay),
-                                    self.steps + 1, _p(nsq), C.c_float(self.gradient_clip_val or 0.0), C.c_float(1.0 / self._accum), o.st()),
+                                    self.steps + 1, _p(nsq), C.c_float(self.gradient_clip_val or 0.0), C.c_float(1.0 / (self._accum * world)), o.st()),
                  "adamw")
         self.steps += 1
         self.zero_grad()

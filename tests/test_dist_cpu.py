@@ -158,3 +158,37 @@ def test_two_rank_gather_equals_per_shard_oracle(B):
             np.testing.assert_allclose(mel_all[row, :n], ref["mel"][i, :n].numpy(), rtol=0, atol=1e-6)
             assert not mel_all[row, n:].any()
             row += 1
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lightningfastspeech2_amd.dist import all_reduce_gradients
+    g = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    all_reduce_gradients(g, bucket_bytes=4 * 300)          # 4 buckets, the last one short
+    h = torch.full((77,), float(rank))
+    for w in all_reduce_gradients(h, async_op=True):
+        w.wait()
+    q.put((rank, g.clone(), h.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_flat_gradient_all_reduce_two_ranks():
+    """The training step's data-parallel exchange: the flat gradient buffer summed over the ranks in buckets."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in ps:
+        p_.start()
+    res = sorted((q.get(timeout=120) for _ in ps), key=lambda t: t[0])
+    for p_ in ps:
+        p_.join(timeout=60)
+    for _, g, h in res:
+        assert torch.equal(g, torch.arange(1000, dtype=torch.float32) * 3)
+        assert torch.equal(h, torch.full((77,), 1.0))

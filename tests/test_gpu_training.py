@@ -224,3 +224,43 @@ def test_backward_is_the_derivative_of_the_forward_under_dropout(kw):
         an = float((g * v.double()).sum())
         assert an > 0 and abs(fd - an) <= 3e-2 * an, (trial, fd, an)
     tr.flat_p.copy_(w0)
+
+
+def test_two_rank_data_parallel_step(tmp_path):
+    """Two ranks (both on this box's one GPU, gloo), each with its shard of a ragged batch: per-rank step, the flat gradient
+    buffer all-reduced inside optimizer_step.  The result must equal the oracle that accumulates the two shards' gradients
+    and steps with their mean (DDP averages per-rank mean losses) - and be identical on both ranks."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    from lightningfastspeech2_amd.dist import shard_batch
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = tmp_path / "after.npz"
+    here = os.path.dirname(os.path.abspath(__file__))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(here, "_dist_train_worker.py"), str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = np.load(out)
+    cfg, sd, batch = _case(41, 4, 11, [11, 9, 6, 2])
+    ref = train_cpu.OracleTrainer(cfg, sd, lr=1e-3, warmup_steps=2, gradient_clip_val=1.0)
+    full = {k: torch.as_tensor(v) for k, v in batch.items()}
+    for rank in range(2):
+        mine = shard_batch(full, 2, rank, trim=True)
+        T = int(mine["duration"].sum(1).max())
+        for k in list(mine):
+            if k == "mel" or k.startswith("variances_"):
+                mine[k] = mine[k][:, :T].contiguous()
+        ref.training_step({k: v.numpy() for k, v in mine.items()})
+    grads = ref.gradients()
+    ref.optimizer_step(accum=2)
+    for n, t in ref.sd.items():
+        if t.requires_grad:
+            g = grads[n].abs()
+            solid = g > 1e-5 * max(1.0, float(g.max()))
+            d = (torch.from_numpy(got[n]) - t.detach().float()).abs()
+            assert float(d[solid].max()) <= 2e-5, n
