@@ -317,6 +317,10 @@ int fs2_op_regulate_bwd(int32_t dtype, const void* dy, const int32_t* cum, void*
 int fs2_op_masked_loss_bwd(const float* pred, const void* truth, int32_t truth_kind, const uint8_t* pad_mask,
                            const float* stat, float* dpred, int64_t rows, int32_t inner, int32_t kind, float alpha,
                            void* hip_stream);
+/* PriorEmbedding (model.py:146-164) on the training path: y[b, t] = x[b, t] + emb[bucketize(values[b], bins)] for every row of
+ * utterance b; emb is the caller's relu(embedding.weight) (relu(E[i]) == relu(E)[i]); idx_out (B*T) receives the bucket per row */
+int fs2_op_bucket_embed_utt(int32_t dtype, const void* x, const float* values, const float* bins, const float* emb, int32_t nbins,
+                            void* y, int32_t* idx_out, int32_t B, int32_t T, int32_t H, void* hip_stream);
 /* nn.Dropout in training mode: y = x * keep / (1 - p) (y may alias x).  The mask is a counter-based hash of (seed, key, element
  * index) - nothing is stored; the backward applies the same call to the gradient.  Not the reference's random stream (torch's
  * Philox), the same distribution. */

@@ -161,6 +161,7 @@ def load():
     lib.fs2_op_scatter_rows.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     lib.fs2_op_regulate_bwd.argtypes = [i32, vp, vp, vp, i32, i32, i32, i32, vp]
     lib.fs2_op_masked_loss_bwd.argtypes = [vp, vp, i32, vp, vp, vp, C.c_int64, i32, i32, f32, vp]
+    lib.fs2_op_bucket_embed_utt.argtypes = [i32, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, vp]
     lib.fs2_op_dropout.argtypes = [i32, vp, vp, sz, f32, C.c_uint64, C.c_uint64, vp]
     lib.fs2_op_row_dot.argtypes = [i32, vp, vp, vp, vp, vp, C.c_int64, i32, vp]
     lib.fs2_op_dwconv_dgrad.argtypes = [i32, vp, vp, vp, i32, i32, i32, i32, vp]

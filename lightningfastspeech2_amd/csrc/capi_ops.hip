@@ -249,6 +249,12 @@ int fs2_op_masked_loss_bwd(const float* pred, const void* truth, int32_t truth_k
     LossBwdArgs a{pred, truth, pad_mask, stat, dpred, rows, inner, kind, truth_kind, alpha};
     return launch_masked_loss_bwd(a, (hipStream_t)stream);
 }
+int fs2_op_bucket_embed_utt(int32_t dtype, const void* x, const float* values, const float* bins, const float* emb, int32_t nbins,
+                            void* y, int32_t* idx_out, int32_t B, int32_t T, int32_t H, void* stream) {
+    BucketArgs a{x, values, bins, emb, nbins, 1.f, 0.f, nullptr, nullptr, y, idx_out, B, T, H, nullptr};
+    a.pred_per_utt = 1;
+    return launch_bucket_embed(a, dtype, (hipStream_t)stream);
+}
 int fs2_op_dropout(int32_t dtype, const void* x, void* y, size_t n, float prob, uint64_t seed, uint64_t key, void* stream) {
     DropoutArgs a{x, y, n, prob, seed, key};
     return launch_dropout(a, dtype, (hipStream_t)stream);

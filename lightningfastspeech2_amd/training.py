@@ -18,8 +18,8 @@ activation gradients and GEMM operands on the bf16 MFMA with fp32 accumulation; 
 Adam moments, LayerNorm / softmax statistics and losses - what the reference's `--precision 16` recipe does with fp16).  Dropout: every nn.Dropout site of the reference in
 training mode (encoder / decoder incl. the attention weights and both positional encodings, variance / duration predictors)
 with a counter-based mask that is regenerated, not stored; 0 by default, which is what the parity fixtures pin (the
-reference's masks come from torch's random stream and cannot be reproduced).  Rejected loudly: phone-level / CWT
-variances, priors, stochastic durations.
+reference's masks come from torch's random stream and cannot be reproduced).  Priors (PriorEmbedding) are trained.  Rejected loudly:
+phone-level / CWT variances, stochastic durations.
 """
 from __future__ import annotations
 
@@ -209,8 +209,6 @@ class Trainer:
                  variance_dropout=0.0, duration_dropout=0.0, seed=0, device="cuda:0"):
         if any(l != "frame" for l in cfg.variance_levels[:len(cfg.variances)]) or any(cfg.is_cwt(i) for i in range(len(cfg.variances))):
             raise NotImplementedError("training step: frame-level 'none' variances only")
-        if cfg.priors:
-            raise NotImplementedError("training step: priors are not built")
         if precision not in _PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
         self.cfg, self.precision = cfg, precision
@@ -579,6 +577,22 @@ class Trainer:
                 x, t = self._layer_fwd(x, f"encoder.layers.{i}", B, L, cfg.encoder_head, cfg.encoder_conv_filter_size,
                                        cfg.encoder_kernel_sizes[i], src_mask, pd=self.p_enc)
                 enc_t.append(t)
+            prior_idx = {}
+            for pr in cfg.priors:  # output = output + relu(Emb[bucketize(prior)]) per utterance (fastspeech2.py:687-692, model.py:160-164)
+                pfx = f"prior_embeddings.{pr}"
+                vals = torch.as_tensor(np.asarray(batch[f"priors_{pr}"].cpu() if isinstance(batch[f"priors_{pr}"], torch.Tensor)
+                                                  else batch[f"priors_{pr}"]), dtype=torch.float32).to(dev).contiguous()
+                if vals.numel() != B:
+                    raise ValueError(f"priors_{pr} must hold one value per utterance")
+                remb = o.empty(cfg.variance_nbins, H)
+                o.ck(o.lib.fs2_op_ew(F32, 1, _p(P[f"{pfx}.embedding.weight"]), _p(P[f"{pfx}.embedding.weight"]), _p(remb), remb.numel(),
+                                     C.c_float(0), C.c_float(0), o.st()), "relu")
+                idx = o.empty(B * L, dtype=torch.int32)
+                xn = o.act(B * L, H)
+                o.ck(o.lib.fs2_op_bucket_embed_utt(o.dt, _p(x), _p(vals), _p(self.buffers[f"{pfx}.bins"]), _p(remb), cfg.variance_nbins,
+                                                   _p(xn), _p(idx), B, L, H, o.st()), "prior_embed")
+                prior_idx[pr] = idx.view(B, L)[:, 0].contiguous()
+                x = xn
             dur_pred, dur_tape = self._predictor_fwd(x, "variance_adaptor.duration_predictor", cfg.duration_nlayers,
                                                      cfg.duration_filter_size, cfg.duration_kernel_size, B, L, src_mask,
                                                      dw=cfg.duration_depthwise_conv, pd=self.p_dur)
@@ -655,6 +669,16 @@ class Trainer:
             o.ck(o.lib.fs2_op_regulate_bwd(o.dt, _p(dx), _p(cum), _p(dxe), B, L, T, H, o.st()), "regulate_bwd")
             self._predictor_bwd(ddur, dur_tape, "variance_adaptor.duration_predictor", cfg.duration_nlayers, cfg.duration_filter_size,
                                 cfg.duration_kernel_size, B, L, dxe, dw=cfg.duration_depthwise_conv)
+            if cfg.priors:
+                seg = o.empty(B, H)
+                o.col_sum(dxe, seg, B * L, H, seg=L, accumulate=False)
+                for pr in cfg.priors:
+                    pfx = f"prior_embeddings.{pr}"
+                    tmp = torch.zeros(cfg.variance_nbins, H, device=dev)
+                    o.ck(o.lib.fs2_op_scatter_rows(F32, _p(seg), _p(prior_idx[pr]), None, _p(tmp), B, H, cfg.variance_nbins, -1, o.st()),
+                         "scatter_rows")
+                    o.relu_bwd(tmp, P[f"{pfx}.embedding.weight"])
+                    o.add_(G[f"{pfx}.embedding.weight"], tmp)
             for i in reversed(range(cfg.encoder_layers)):
                 dxe = self._layer_bwd(dxe, enc_t[i], f"encoder.layers.{i}", B, L, cfg.encoder_head, cfg.encoder_conv_filter_size,
                                       cfg.encoder_kernel_sizes[i])

@@ -193,7 +193,6 @@ def _variance_encoder_cwt(sd, cfg, var_index: int, x, mask, tgt=None):
     return res, F.embedding(idx, _t(sd, f"{p}.embedding.weight")), idx
 
 
-@torch.no_grad()
 def prior_embedding(sd, cfg, prior: str, values: torch.Tensor) -> torch.Tensor:
     """PriorEmbedding.forward, model.py:160-164 — relu(Emb[bucketize(prior, bins)]), one row per
     utterance, broadcast over time by the caller."""

@@ -62,7 +62,8 @@ class OracleTrainer:
 
     def training_step(self, batch):
         tt = {k: batch[k] for k in batch if k == "duration" or k.startswith("variances_")}
-        res = oracle_cpu.forward(self.sd, self.cfg, batch["phones"], batch["speaker"], teacher_targets=tt)
+        pri = {k: batch[k] for k in batch if k.startswith("priors_")}
+        res = oracle_cpu.forward(self.sd, self.cfg, batch["phones"], batch["speaker"], teacher_targets=tt, priors=pri or None)
         ls = losses(self.cfg, res, batch, **self.loss_kw)
         ls["total"].backward()
         return {k: float(v.detach()) for k, v in ls.items()}, res
