@@ -254,7 +254,7 @@ __global__ void bgemm_reduce_kernel(BGemmArgs p) {
 //                            two ds_read_b64_tr_b16 each: inside a 16-lane group lane i hands in the address of
 //                            [k0 + i/4][col0 + 4*(i%4)] and receives column col0 + i of that 4 x 16 block
 //                            (tools/probes/tr_read_probe.hip), i.e. four consecutive k of its own MFMA row / column.
-constexpr int HBK = 32, HLD = 40, HLDT = 144;
+constexpr int HBK = 32, HLD = 40;
 constexpr int HOPSZ = BM * HLD;  // bf16 elements per operand buffer (10 KB; the transposed image needs 32 * 144)
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 
@@ -274,11 +274,13 @@ __device__ inline uint4 load8(const unsigned short* src, bool vec, int nvalid) {
                       e[6] | ((uint32_t)e[7] << 16));
 }
 
-__device__ inline void load_tile_h(const OperandH& o, int k0, int Kend, uint4 (&r)[2]) {
+// R = rows of the operand's outer index in the tile (128, or 256 for the A side of the 256-row tile)
+template <int R>
+__device__ inline void load_tile_h(const OperandH& o, int k0, int Kend, uint4 (&r)[R / 64]) {
     const int tid = threadIdx.x;
     if (o.s_k == 1) {  // k-contiguous: (row, 8-k chunk)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < R / 64; ++i) {
             const int v = tid + 256 * i, mn = v >> 2, gk = k0 + (v & 3) * 8;
             const int gmn = o.mn0 + mn;
             bool ok = gmn < o.MN && gk < Kend;
@@ -291,9 +293,10 @@ __device__ inline void load_tile_h(const OperandH& o, int k0, int Kend, uint4 (&
             r[i] = ok ? load8(o.p + row * o.s_mn + gk, o.vec, Kend - gk) : make_uint4(0, 0, 0, 0);
         }
     } else {  // outer-contiguous: (k row, 8 outer positions)
+        constexpr int VR = R / 8;  // vectors per k row
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int v = tid + 256 * i, gk = k0 + (v >> 4), gmn = o.mn0 + (v & 15) * 8;
+        for (int i = 0; i < R / 64; ++i) {
+            const int v = tid + 256 * i, gk = k0 + v / VR, gmn = o.mn0 + (v % VR) * 8;
             bool ok = gk < Kend && gmn < o.MN;
             long krow = gk;
             if (o.seg && ok) {
@@ -306,51 +309,131 @@ __device__ inline void load_tile_h(const OperandH& o, int k0, int Kend, uint4 (&
     }
 }
 
-__device__ inline void store_tile_h(unsigned short* s, bool kc, const uint4 (&r)[2]) {
+template <int R>
+__device__ inline void store_tile_h(unsigned short* s, bool kc, const uint4 (&r)[R / 64]) {
     const int tid = threadIdx.x;
     if (kc) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < R / 64; ++i) {
             const int v = tid + 256 * i, row = v >> 2, ch = v & 3;
             *(uint4*)(s + row * HLD + ((ch ^ ((row >> 3) & 3)) << 3)) = r[i];
         }
     } else {
+        constexpr int VR = R / 8;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < R / 64; ++i) {
             const int v = tid + 256 * i;
-            *(uint4*)(s + (v >> 4) * HLDT + (v & 15) * 8) = r[i];
+            *(uint4*)(s + (v / VR) * (R + 16) + (v % VR) * 8) = r[i];
         }
     }
 }
 
-// 8 consecutive k (k = 8*fg .. 8*fg + 7) of MFMA row / column `mn0 + fr`, from either LDS image
-__device__ inline uint4 frag_h(const unsigned short* s, bool kc, int mn0, int fr, int fg) {
+// Per-thread cursor over an operand's k-tiles for the plain (taps <= 1) forms: everything that does not change from one
+// k-tile to the next (the thread's rows / columns, their bounds, the 64-bit addresses) is worked out once; a step is a
+// pointer bump, a compare and the 16-byte load.  (The generic loader above spends ~10x the MFMA issue slots of a k-step on
+// address arithmetic - integer modulo, 64-bit multiplies - and made the kernel VALU-bound.)
+template <int R>
+struct TileCursor {
+    static constexpr int NV = R / 64;
+    const unsigned short* ptr[NV];
+    int gk[NV];        // k index of the vector (kc: its first element; else: its k row)
+    int pos[NV];       // outer-contiguous + seg: gk % seg
+    int nmn[NV];       // valid elements along the vector's own direction that do not depend on k (outer-contiguous: MN - gmn)
+    bool ok[NV];
+    bool kc, vec;
+    int seg, shift, Kend;
+    long step;
+
+    __device__ inline void init(const OperandH& o, int k0, int Kend_) {
+        const int tid = threadIdx.x;
+        kc = o.s_k == 1; vec = o.vec; seg = o.seg; shift = o.shift_k; Kend = Kend_;
+        step = kc ? HBK : (long)HBK * o.s_k;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = tid + 256 * i;
+            if (kc) {
+                const int gmn = o.mn0 + (v >> 2);
+                gk[i] = k0 + (v & 3) * 8;
+                ok[i] = gmn < o.MN;
+                ptr[i] = o.p + (long)gmn * o.s_mn + gk[i];
+                nmn[i] = 0; pos[i] = 0;
+            } else {
+                constexpr int VR = R / 8;
+                const int gmn = o.mn0 + (v % VR) * 8;
+                gk[i] = k0 + v / VR;
+                ok[i] = gmn < o.MN;
+                nmn[i] = o.MN - gmn;
+                pos[i] = seg ? gk[i] % seg : 0;
+                ptr[i] = o.p + ((long)gk[i] + shift) * o.s_k + gmn;
+            }
+        }
+    }
+    __device__ inline void load(uint4 (&r)[NV]) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            bool v = ok[i] && gk[i] < Kend;
+            if (!kc && seg) v = v && (unsigned)(pos[i] + shift) < (unsigned)seg;
+            r[i] = v ? load8(ptr[i], vec, kc ? Kend - gk[i] : nmn[i]) : make_uint4(0, 0, 0, 0);
+        }
+    }
+    __device__ inline void next() {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            ptr[i] += step;
+            gk[i] += HBK;
+            if (!kc && seg) {
+                pos[i] += HBK;
+                while (pos[i] >= seg) pos[i] -= seg;
+            }
+        }
+    }
+};
+
+// 8 consecutive k (k = 8*fg .. 8*fg + 7) of MFMA row / column `mn0 + fr`, from either LDS image (ldt = row stride of the
+// transposed image)
+__device__ inline uint4 frag_h(const unsigned short* s, bool kc, int mn0, int fr, int fg, int ldt) {
     if (kc) {
         const int row = mn0 + fr;
         return *(const uint4*)(s + row * HLD + ((fg ^ ((row >> 3) & 3)) << 3));
     }
     typedef __attribute__((address_space(3))) s16x4_t* lds_v4;
-    const unsigned short* a = s + (fg * 8 + (fr >> 2)) * HLDT + mn0 + (fr & 3) * 4;
+    const unsigned short* a = s + (fg * 8 + (fr >> 2)) * ldt + mn0 + (fr & 3) * 4;
     const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)a);
-    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(a + 4 * HLDT));
+    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(a + 4 * ldt));
     union { s16x4_t v[2]; uint4 u; } c;
     c.v[0] = lo;
     c.v[1] = hi;
     return c.u;
 }
 
-template <typename OutT>
-__global__ __launch_bounds__(256) void bgemm_bf16_kernel(BGemmArgs p) {
-    __shared__ __attribute__((aligned(16))) unsigned short lds[2][2][HOPSZ];
+// WM = 16-row fragments per wave along m: 4 -> 128 x 128 tile, 8 -> 256 x 128 tile (4 waves as 2 x 2 either way: a wave
+// owns WM*16 rows x 64 columns; the taller tile halves the LDS fragment reads per MFMA)
+template <typename OutT, int WM>
+__global__ __launch_bounds__(256, 3) void bgemm_bf16_kernel(const BGemmArgs p) {
+    constexpr int BMT = WM * 32;
+    constexpr int ASZ = BMT * HLD > HBK * (BMT + 16) ? BMT * HLD : HBK * (BMT + 16);
+    __shared__ __attribute__((aligned(16))) unsigned short lds[2][ASZ + HOPSZ];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
     const int fr = lane & 15, fg = lane >> 4;
     const int splitk = p.splitk > 1 ? p.splitk : 1;
-    int z = blockIdx.z;
-    const int split = z % splitk;
-    z /= splitk;
-    const int b2 = z % p.nb2, b1 = z / p.nb2;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // XCD-aware order: the hardware deals consecutive workgroup ids to the 8 XCDs in turn; remapped so that each XCD (its own
+    // L2) walks a CONTIGUOUS range of tiles, with the tiles that share operand rows next to each other: column tile fastest,
+    // then row tile, then the tap / head index, then the k split, then the outer batch.
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (p.xcd_remap) {
+        const unsigned gx = gridDim.x, gy = gridDim.y, nwg = gx * gy * gridDim.z;
+        const unsigned L = bx + gx * (by + gy * bz);
+        const unsigned q = nwg >> 3, r = nwg & 7, xcd = L & 7, idx = L >> 3;
+        const unsigned lg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        bx = lg % gx;
+        by = (lg / gx) % gy;
+        bz = lg / (gx * gy);
+    }
+    const int b2 = bz % p.nb2;
+    const int split = (bz / p.nb2) % splitk;
+    const int b1 = bz / (p.nb2 * splitk);
+    const int m0 = by * BMT, n0 = bx * BN;
 
     OperandH A, B;
     A.p = (const unsigned short*)p.A + b1 * p.sA1 + b2 * p.sA2;
@@ -370,15 +453,15 @@ __global__ __launch_bounds__(256) void bgemm_bf16_kernel(BGemmArgs p) {
     const int per = (ntiles + splitk - 1) / splitk;
     const int t_begin = split * per, t_end = min(ntiles, t_begin + per);
 
-    f32x4_t acc[4][4];
+    f32x4_t acc[WM][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < WM; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     const unsigned short* Ap0 = A.p;
     const unsigned short* Bp0 = B.p;
-    auto fetch = [&](int t, uint4 (&ra)[2], uint4 (&rb)[2]) {
+    auto fetch = [&](int t, uint4 (&ra)[BMT / 64], uint4 (&rb)[2]) {
         int k0 = t * HBK, kend = p.K;
         if (p.taps > 1) {
             const int tap = t / tiles_per_tap;
@@ -389,35 +472,47 @@ __global__ __launch_bounds__(256) void bgemm_bf16_kernel(BGemmArgs p) {
             A.p = Ap0;
             B.p = Bp0 + tap * p.sBtap;
         }
-        load_tile_h(A, k0, kend, ra);
-        load_tile_h(B, k0, kend, rb);
+        load_tile_h<BMT>(A, k0, kend, ra);
+        load_tile_h<128>(B, k0, kend, rb);
     };
 
-    uint4 ra[2], rb[2];
+    auto compute = [&](int cur) {
+        const unsigned short* sa = lds[cur];
+        const unsigned short* sb = lds[cur] + ASZ;
+        uint4 b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = frag_h(sb, bkc, wn * 64 + j * 16, fr, fg, 128 + 16);
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+            const uint4 a = frag_h(sa, akc, wm * (WM * 16) + i * 16, fr, fg, BMT + 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) Mma16<bf16>::step(a, b[j], acc[i][j]);
+        }
+    };
+    uint4 ra[BMT / 64], rb[2];
+    const bool plain = p.taps <= 1;  // wave-uniform: cursors for the plain forms, the generic loader for the implicit-conv dgrad
+    TileCursor<BMT> ca;
+    TileCursor<128> cb;
+    if (plain) {
+        ca.init(A, t_begin * HBK, p.K);
+        cb.init(B, t_begin * HBK, p.K);
+    }
     if (t_begin < t_end) {
-        fetch(t_begin, ra, rb);
-        store_tile_h(lds[0][0], akc, ra);
-        store_tile_h(lds[0][1], bkc, rb);
+        if (plain) { ca.load(ra); cb.load(rb); } else fetch(t_begin, ra, rb);
+        store_tile_h<BMT>(lds[0], akc, ra);
+        store_tile_h<128>(lds[0] + ASZ, bkc, rb);
     }
     __syncthreads();
     for (int t = t_begin; t < t_end; ++t) {
         const int cur = (t - t_begin) & 1;
         const bool more = t + 1 < t_end;
-        if (more) fetch(t + 1, ra, rb);
-        const unsigned short* sa = lds[cur][0];
-        const unsigned short* sb = lds[cur][1];
-        uint4 a[4], b[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = frag_h(sa, akc, wm * 64 + i * 16, fr, fg);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = frag_h(sb, bkc, wn * 64 + j * 16, fr, fg);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) Mma16<bf16>::step(a[i], b[j], acc[i][j]);
         if (more) {
-            store_tile_h(lds[cur ^ 1][0], akc, ra);
-            store_tile_h(lds[cur ^ 1][1], bkc, rb);
+            if (plain) { ca.next(); cb.next(); ca.load(ra); cb.load(rb); } else fetch(t + 1, ra, rb);
+        }
+        compute(cur);
+        if (more) {
+            store_tile_h<BMT>(lds[cur ^ 1], akc, ra);
+            store_tile_h<128>(lds[cur ^ 1] + ASZ, bkc, rb);
         }
         __syncthreads();
     }
@@ -425,19 +520,19 @@ __global__ __launch_bounds__(256) void bgemm_bf16_kernel(BGemmArgs p) {
     if (splitk > 1) {
         float* ws = p.ws + ((long)(b1 * p.nb2 + b2) * splitk + split) * (long)p.M * p.N;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < WM; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int m = m0 + wm * 64 + i * 16 + fg * 4 + r, n = n0 + wn * 64 + j * 16 + fr;
+                    const int m = m0 + wm * (WM * 16) + i * 16 + fg * 4 + r, n = n0 + wn * 64 + j * 16 + fr;
                     if (m < p.M && n < p.N) ws[(long)m * p.N + n] = acc[i][j][r];
                 }
         return;
     }
     OutT* C = (OutT*)p.C + b1 * p.sC1 + b2 * p.sC2;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < WM; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int n = n0 + wn * 64 + j * 16 + fr;
@@ -445,7 +540,7 @@ __global__ __launch_bounds__(256) void bgemm_bf16_kernel(BGemmArgs p) {
             const float bv = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm * 64 + i * 16 + fg * 4 + r;
+                const int m = m0 + wm * (WM * 16) + i * 16 + fg * 4 + r;
                 if (m >= p.M) continue;
                 float v = p.alpha * acc[i][j][r] + bv;
                 OutT* dst = C + (long)m * p.ldc + n;
@@ -476,6 +571,9 @@ inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
 
+int g_bgemm_xcd = 1;   // A/B knob: XCD-contiguous tile order of the bf16 kernel
+int g_bgemm_tile = 0;  // A/B knob: 0 auto, 1 force 128-row tiles, 2 force 256-row tiles (bf16)
+
 size_t bgemm_ws_bytes(const BGemmArgs& a) {
     return a.splitk > 1 ? (size_t)a.nb1 * a.nb2 * a.splitk * a.M * a.N * sizeof(float) : 0;
 }
@@ -495,18 +593,26 @@ int launch_bgemm(const BGemmArgs& a0, int dtype, hipStream_t stream) {
     };
     a.vecA = vec_ok(a.A, a.sAk == 1 ? a.sAm : a.sAk, a.sA1, a.sA2, 0) ? 1 : 0;
     a.vecB = vec_ok(a.B, a.sBk == 1 ? a.sBn : a.sBk, a.sB1, a.sB2, a.taps > 1 ? a.sBtap : 0) ? 1 : 0;
+    a.xcd_remap = g_bgemm_xcd;
     const int splitk = a.splitk > 1 ? a.splitk : 1;
     dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, a.nb1 * a.nb2 * splitk);
+    // bf16: the 256-row tile when it still leaves every CU a workgroup or two
+    const long tiles256 = (long)((a.N + BN - 1) / BN) * ((a.M + 255) / 256) * a.nb1 * a.nb2 * splitk;
+    (void)tiles256;
+    const bool tall = dtype == FS2_BF16 && g_bgemm_tile == 2;  // 256-row tiles measured slower on every training shape: knob only
+    if (tall) grid.y = (a.M + 255) / 256;
     const long per = (long)a.M * a.N;
     dim3 g2((unsigned)((per + 255) / 256), a.nb1 * a.nb2);
     if (dtype == FS2_F32) {
         hipLaunchKernelGGL(bgemm_f32_kernel, grid, dim3(256), 0, stream, a);
         if (splitk > 1) hipLaunchKernelGGL(bgemm_reduce_kernel, g2, dim3(256), 0, stream, a);
     } else if (a.c_dtype == FS2_F32) {
-        hipLaunchKernelGGL(bgemm_bf16_kernel<float>, grid, dim3(256), 0, stream, a);
+        if (tall) hipLaunchKernelGGL((bgemm_bf16_kernel<float, 8>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((bgemm_bf16_kernel<float, 4>), grid, dim3(256), 0, stream, a);
         if (splitk > 1) hipLaunchKernelGGL(bgemm_reduce_t_kernel<float>, g2, dim3(256), 0, stream, a);
     } else {
-        hipLaunchKernelGGL(bgemm_bf16_kernel<bf16>, grid, dim3(256), 0, stream, a);
+        if (tall) hipLaunchKernelGGL((bgemm_bf16_kernel<bf16, 8>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((bgemm_bf16_kernel<bf16, 4>), grid, dim3(256), 0, stream, a);
         if (splitk > 1) hipLaunchKernelGGL(bgemm_reduce_t_kernel<bf16>, g2, dim3(256), 0, stream, a);
     }
     return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;

@@ -291,8 +291,11 @@ struct BGemmArgs {
     int b_shift0 = 0, b_shift_step = 0;  // wgrad form (taps == 1): batch index b2 reads B's k rows at k + b_shift0 + b2 * b_shift_step
     int c_dtype = FS2_F32;        // dtype of C: bf16 operands may write bf16 (activations) or fp32 (weight gradients, scores)
     int vecA = 0, vecB = 0;       // set by the launcher
+    int xcd_remap = 0;            // set by the launcher
 };
 size_t bgemm_ws_bytes(const BGemmArgs& a);
+extern int g_bgemm_tile;
+extern int g_bgemm_xcd;
 int launch_bgemm(const BGemmArgs& a, int dtype, hipStream_t stream);
 
 // Row / column kernels of the backward (backward.hip).  T = activation dtype; gradients of parameters are fp32.

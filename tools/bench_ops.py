@@ -108,7 +108,7 @@ def bwd_cases(reps):
                ldc=H, seg=1536, taps=k, Kin=F, a_shift0=4, a_shift_step=-1, sBtap=H)
     dw = torch.zeros(F, k * H, device=DEV)
     for sk in (1, 4, 16):
-        bgemm_case(f"conv1 k=9 wgrad splitk={sk}", M * H * k * F, dy, x, dw, reps, M=F, N=H, K=M, sAm=1, sAk=F, sBk=H, sBn=1, ldc=k * H,
+        bgemm_case(f"conv1 k=9 wgrad_splitk={sk}", M * H * k * F, dy, x, dw, reps, M=F, N=H, K=M, sAm=1, sAk=F, sBk=H, sBn=1, ldc=k * H,
                    nb2=k, sC2=H, seg=1536, b_shift0=-4, b_shift_step=1, splitk=sk, beta=1.0)
     dy2 = torch.randn(M, H, device=DEV).to(bf)
     w2 = torch.randn(H, F, device=DEV).to(bf)
@@ -167,9 +167,10 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default="", help="substring filter on the case name")
     a = ap.parse_args()
-    global gemm_case, attn_case, gemm_ln_case
+    global gemm_case, attn_case, gemm_ln_case, bgemm_case
     if a.only:
-        g0, a0, l0 = gemm_case, attn_case, gemm_ln_case
+        g0, a0, l0, b0 = gemm_case, attn_case, gemm_ln_case, bgemm_case
+        bgemm_case = lambda name, *r, **k: b0(name, *r, **k) if a.only in name else None
         gemm_ln_case = lambda name, *r, **k: l0(name, *r, **k) if a.only in name else None
         gemm_case = lambda name, *r: g0(name, *r) if a.only in name else None
         attn_case = lambda name, *r: a0(name, *r) if a.only in name else None

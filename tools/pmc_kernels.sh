@@ -6,6 +6,7 @@
 CFG=${1:-c2}; B=32; [ $CFG = c5 ] && B=8
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/pmc_ks; mkdir -p $O
 CMD="python $R/bench.py --config $CFG --batch $B --steps 2 --warmup 1 --no-cpu-baseline --no-parity"
+[ -n "$PMC_CMD" ] && CMD="$PMC_CMD"   # any other command (e.g. tools/bench_ops.py bwd --only ...); CFG then only names the output
 cd /tmp && export TMPDIR=/tmp
 rm -rf $O/*
 timeout 400 rocprofv3 --kernel-trace --output-format csv -d $O/t -o p -- $CMD > /dev/null 2>&1
