@@ -200,7 +200,6 @@ int fs2_profile_read(fs2_engine* e, int32_t kernel_class, double* total_ms, int6
  *   200/201 slab kernel tile order: plain / XCD-contiguous (default)
  *   300/301 LayerNorm epilogue for rows wider than 256: GEMM + stand-alone LayerNorm launch (default) / in-place fused
  *   500/501 fp32 slab-kernel launches: fp32 MFMA (default) / bf16 x 3 split products (what FS2_MIXED_X3 uses in its front)
- *   600/601/602 bf16 fs2_op_bgemm tile height: auto / 128 rows / 256 rows
  *   700/701 bf16 fs2_op_bgemm tile order: plain / XCD-contiguous (default) */
 int fs2_op_set_gemm_variant(int32_t variant);
 /* tuning knob: cap (KiB) on the LDS operand slab of a vocoder conv workgroup; 0 = built-in heuristic */
@@ -288,6 +287,13 @@ typedef struct fs2_bgemm_desc {
 size_t fs2_op_bgemm_ws_bytes(const fs2_bgemm_desc* d);  /* split-K slabs (0 when splitk <= 1) */
 int fs2_op_bgemm(int32_t dtype, const fs2_bgemm_desc* d, const void* A, const void* B, void* C, const float* bias,
                  float* ws, void* hip_stream);
+/* attention backward without a dP tensor: C = dS = alpha * P o (dropout(A B) - delta) where A B = dO V^T is the product the
+ * descriptor states, P (C's layout and dtype) are the forward's probabilities, delta (nb1, nb2, M) = fs2_op_attn_delta(dO, O)
+ * (= sum_k dP P) and the dropout is the forward's attention-weight dropout (drop_p = 0: none), regenerated from (seed, key) */
+int fs2_op_bgemm_softmax_bwd(int32_t dtype, const fs2_bgemm_desc* d, const void* A, const void* B, void* C, const void* P,
+                             const float* delta, float drop_p, uint64_t drop_seed, uint64_t drop_key, void* hip_stream);
+int fs2_op_attn_delta(int32_t dtype, const void* dout, const void* out, float* delta, int32_t B, int32_t S, int32_t H,
+                      int32_t heads, void* hip_stream);
 /* LayerNorm backward of y = LN(z [+ res]) * gamma + beta: dz (M, H); relu_mask = 1 when z is a ReLU output and dz should be
  * the gradient of the pre-activation (dz zeroed where z <= 0).  part = (fs2_op_layernorm_bwd_parts(M), 3, H) partial column
  * sums of dy * zhat, dy and dz, to be reduced with fs2_op_col_sum over the parts -> dgamma, dbeta and the bias gradient of

@@ -319,13 +319,6 @@ __global__ void ew_kernel(EwArgs p) {
 
 // ---- dropout: counter-based mask (splitmix64 of seed, site key, element index), regenerated - never stored -------------
 // y = x * keep / (1 - p); the same (seed, key) gives the same mask, so the backward applies the same launch to the gradient.
-__device__ inline uint32_t dropout_bits(uint64_t seed, uint64_t key, uint64_t i) {
-    uint64_t z = seed + key * 0x9E3779B97F4A7C15ull + i * 0xD1B54A32D192ED03ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    return (uint32_t)(z >> 40);  // 24 bits
-}
 template <typename T>
 __global__ void dropout_kernel(DropoutArgs p) {
     const uint32_t thr = (uint32_t)(p.p * 16777216.0f);  // drop when bits < thr
@@ -336,6 +329,23 @@ __global__ void dropout_kernel(DropoutArgs p) {
         const bool keep = dropout_bits(p.seed, p.key, e) >= thr;
         y[e] = Num<T>::from_f32(keep ? Num<T>::to_f32(x[e]) * scale : 0.f);
     }
+}
+
+// delta[b][h][q] = sum_d dO[b*S + q][h*d .. ] * O[...]  (= sum_k dP P of the attention backward); one wave per (row, head)
+template <typename T>
+__global__ __launch_bounds__(256) void attn_delta_kernel(AttnDeltaArgs p) {
+    const int lane = threadIdx.x & 63;
+    const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long rows = (long)p.B * p.S;
+    if (w >= rows * p.heads) return;
+    const long row = w / p.heads;
+    const int h = (int)(w % p.heads), d = p.H / p.heads;
+    const T* a = (const T*)p.dout + row * p.H + h * d;
+    const T* o = (const T*)p.out + row * p.H + h * d;
+    float s = 0.f;
+    for (int c = lane; c < d; c += 64) s = fmaf(Num<T>::to_f32(a[c]), Num<T>::to_f32(o[c]), s);
+    s = wave_sum(s);
+    if (lane == 0) p.delta[((row / p.S) * p.heads + h) * p.S + row % p.S] = s;
 }
 
 // pred[m] = mask[m] ? 0 : y[m] . w + b   (the predictor head after a dropout layer; one wave per row)
@@ -594,6 +604,15 @@ int launch_dropout(const DropoutArgs& a, int dtype, hipStream_t stream) {
     if (blocks > 8192) blocks = 8192;
     if (dtype == FS2_BF16) hipLaunchKernelGGL(dropout_kernel<bf16>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
     else if (dtype == FS2_F32) hipLaunchKernelGGL(dropout_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    else return FS2_ERR_SHAPE;
+    return ok();
+}
+int launch_attn_delta(const AttnDeltaArgs& a, int dtype, hipStream_t stream) {
+    if (a.B <= 0 || a.S <= 0 || a.heads <= 0 || a.H % a.heads) return FS2_ERR_SHAPE;
+    const long n = (long)a.B * a.S * a.heads;
+    const dim3 g((unsigned)((n + 3) / 4));
+    if (dtype == FS2_BF16) hipLaunchKernelGGL(attn_delta_kernel<bf16>, g, dim3(256), 0, stream, a);
+    else if (dtype == FS2_F32) hipLaunchKernelGGL(attn_delta_kernel<float>, g, dim3(256), 0, stream, a);
     else return FS2_ERR_SHAPE;
     return ok();
 }

@@ -25,6 +25,19 @@ constexpr int LDK = 20;    // k-contiguous LDS image: [128][20] floats (16-B ali
 constexpr int LDM = 144;   // m/n-contiguous LDS image: [16][144] floats (rows 16 banks apart)
 constexpr int OPSZ = BM * LDK;  // 2560 floats >= BK * LDM = 2304
 
+// dS = alpha * P * (dropout(dP) - delta[row]) for one element of the dP = dO V^T product (alpha = 1 / sqrt(d); the identity
+// sum_k dP P = sum_d dO O = delta holds with the attention-weight dropout in place because O was formed from the dropped P)
+template <typename OutT>
+__device__ inline float softmax_bwd_epilogue(const BGemmArgs& p, float dp, int b1, int b2, int m, int n) {
+    const long bidx = (long)b1 * p.nb2 + b2;
+    if (p.drop_p > 0.f) {
+        const uint32_t thr = (uint32_t)(p.drop_p * 16777216.0f);
+        dp = dropout_bits(p.drop_seed, p.drop_key, ((uint64_t)bidx * p.M + m) * p.N + n) >= thr ? dp * (1.f / (1.f - p.drop_p)) : 0.f;
+    }
+    const float pv = Num<OutT>::to_f32(((const OutT*)p.epi_p)[b1 * p.sC1 + b2 * p.sC2 + (long)m * p.ldc + n]);
+    return p.alpha * pv * (dp - p.epi_delta[bidx * p.M + m]);
+}
+
 struct Operand {
     const float* p;
     long s_mn, s_k;  // element strides of the tile's outer (m or n) index and of k
@@ -222,6 +235,7 @@ __global__ __launch_bounds__(256) void bgemm_f32_kernel(BGemmArgs p) {
                 if (m >= p.M) continue;
                 float v = p.alpha * acc[i][j][r] + bv;
                 float* dst = C + (long)m * p.ldc + n;
+                if (p.epi_p) v = softmax_bwd_epilogue<float>(p, acc[i][j][r], b1, b2, m, n);
                 if (p.beta != 0.f) v += p.beta * *dst;
                 *dst = v;
             }
@@ -255,6 +269,21 @@ __global__ void bgemm_reduce_kernel(BGemmArgs p) {
 //                            [k0 + i/4][col0 + 4*(i%4)] and receives column col0 + i of that 4 x 16 block
 //                            (tools/probes/tr_read_probe.hip), i.e. four consecutive k of its own MFMA row / column.
 constexpr int HBK = 32, HLD = 40;
+template <typename T> __device__ inline void ld4(const T* p, float* f);
+template <> __device__ inline void ld4<float>(const float* p, float* f) {
+    const float4 v = *(const float4*)p;
+    f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+}
+template <> __device__ inline void ld4<bf16>(const bf16* p, float* f) {
+    const uint2 v = *(const uint2*)p;
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+template <typename T> __device__ inline void st4(T* p, const float* f);
+template <> __device__ inline void st4<float>(float* p, const float* f) { *(float4*)p = make_float4(f[0], f[1], f[2], f[3]); }
+template <> __device__ inline void st4<bf16>(bf16* p, const float* f) {
+    *(uint2*)p = make_uint2(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]));
+}
 constexpr int HOPSZ = BM * HLD;  // bf16 elements per operand buffer (10 KB; the transposed image needs 32 * 144)
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 
@@ -406,8 +435,8 @@ __device__ inline uint4 frag_h(const unsigned short* s, bool kc, int mn0, int fr
     return c.u;
 }
 
-// WM = 16-row fragments per wave along m: 4 -> 128 x 128 tile, 8 -> 256 x 128 tile (4 waves as 2 x 2 either way: a wave
-// owns WM*16 rows x 64 columns; the taller tile halves the LDS fragment reads per MFMA)
+// WM = 16-row fragments per wave along m: 4 -> the 128 x 128 tile in use (4 waves as 2 x 2, a wave owns 64 x 64).  WM = 8
+// (256 x 128) was measured slower on every training shape - it drops the kernel to 1-2 waves per SIMD - and is not built.
 template <typename OutT, int WM>
 __global__ __launch_bounds__(256, 3) void bgemm_bf16_kernel(const BGemmArgs p) {
     constexpr int BMT = WM * 32;
@@ -530,24 +559,74 @@ __global__ __launch_bounds__(256, 3) void bgemm_bf16_kernel(const BGemmArgs p) {
                 }
         return;
     }
+    // Epilogue through LDS (free after the last barrier): the MFMA layout gives a lane one column and four rows, i.e. 2- / 4-byte
+    // accesses in 32- / 64-byte runs; staged per wave (32 x 64 fp32 at a time, rows padded to 68) a lane gets four consecutive
+    // columns of one row, so C, the old C (beta) and the softmax-backward epilogue's P move in 8- / 16-byte pieces, 128 / 256
+    // contiguous bytes per row.
     OutT* C = (OutT*)p.C + b1 * p.sC1 + b2 * p.sC2;
+    constexpr int SLD = 68;
+    static_assert(4 * 32 * SLD * 4 <= 2 * (ASZ + HOPSZ) * 2, "stage does not fit the operand buffers");
+    float* stage = (float*)&lds[0][0] + wid * (32 * SLD);
+    const bool vec_c = p.ldc % 4 == 0 && ((uintptr_t)C & 15) == 0 && (!p.epi_p || ((uintptr_t)p.epi_p & 15) == 0) &&
+                       p.sC1 % 4 == 0 && p.sC2 % 4 == 0;
+    const long bidx = (long)b1 * p.nb2 + b2;
 #pragma unroll
-    for (int i = 0; i < WM; ++i)
+    for (int half = 0; half < WM / 2; ++half) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + fr;
-            if (n >= p.N) continue;
-            const float bv = p.bias ? p.bias[n] : 0.f;
+        for (int i2 = 0; i2 < 2; ++i2)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm * (WM * 16) + i * 16 + fg * 4 + r;
-                if (m >= p.M) continue;
-                float v = p.alpha * acc[i][j][r] + bv;
-                OutT* dst = C + (long)m * p.ldc + n;
-                if (p.beta != 0.f) v += p.beta * Num<OutT>::to_f32(*dst);
-                *dst = Num<OutT>::from_f32(v);
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) stage[(i2 * 16 + fg * 4 + r) * SLD + j * 16 + fr] = acc[half * 2 + i2][j][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int rl = it * 4 + (lane >> 4), cl = (lane & 15) * 4;
+            const int m = m0 + wm * (WM * 16) + half * 32 + rl, n = n0 + wn * 64 + cl;
+            if (m >= p.M || n >= p.N) continue;
+            const float4 a4 = *(const float4*)(stage + rl * SLD + cl);
+            float v[4] = {a4.x, a4.y, a4.z, a4.w};
+            OutT* dst = C + (long)m * p.ldc + n;
+            const bool full = vec_c && n + 3 < p.N;
+            if (p.epi_p) {
+                const OutT* pp = (const OutT*)p.epi_p + b1 * p.sC1 + b2 * p.sC2 + (long)m * p.ldc + n;
+                float pv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (full) ld4<OutT>(pp, pv);
+                else
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (n + e < p.N) pv[e] = Num<OutT>::to_f32(pp[e]);
+                const float dl = p.epi_delta[bidx * p.M + m];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float dp = v[e];
+                    if (p.drop_p > 0.f) {
+                        const uint32_t thr = (uint32_t)(p.drop_p * 16777216.0f);
+                        dp = dropout_bits(p.drop_seed, p.drop_key, ((uint64_t)bidx * p.M + m) * p.N + n + e) >= thr ? dp * (1.f / (1.f - p.drop_p)) : 0.f;
+                    }
+                    v[e] = p.alpha * pv[e] * (dp - dl);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = p.alpha * v[e] + ((p.bias && n + e < p.N) ? p.bias[n + e] : 0.f);
             }
+            if (p.beta != 0.f) {
+                float old[4] = {0.f, 0.f, 0.f, 0.f};
+                if (full) ld4<OutT>(dst, old);
+                else
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (n + e < p.N) old[e] = Num<OutT>::to_f32(dst[e]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += p.beta * old[e];
+            }
+            if (full) st4<OutT>(dst, v);
+            else
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (n + e < p.N) dst[e] = Num<OutT>::from_f32(v[e]);
         }
+        __builtin_amdgcn_wave_barrier();
+    }
 }
 
 template <typename OutT>
@@ -572,7 +651,6 @@ inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 }  // namespace
 
 int g_bgemm_xcd = 1;   // A/B knob: XCD-contiguous tile order of the bf16 kernel
-int g_bgemm_tile = 0;  // A/B knob: 0 auto, 1 force 128-row tiles, 2 force 256-row tiles (bf16)
 
 size_t bgemm_ws_bytes(const BGemmArgs& a) {
     return a.splitk > 1 ? (size_t)a.nb1 * a.nb2 * a.splitk * a.M * a.N * sizeof(float) : 0;
@@ -586,6 +664,7 @@ int launch_bgemm(const BGemmArgs& a0, int dtype, hipStream_t stream) {
     if ((a.sAm != 1 && a.sAk != 1) || (a.sBk != 1 && a.sBn != 1)) return FS2_ERR_SHAPE;
     if (a.taps > 1 && (a.Kin <= 0 || a.K != a.taps * a.Kin)) return FS2_ERR_SHAPE;
     if (a.splitk > 1 && !a.ws) return FS2_ERR_ARG;
+    if (a.epi_p && (a.splitk > 1 || !a.epi_delta || a.bias)) return FS2_ERR_ARG;
     // 16-byte vector loads need every row start (and batch / tap base) on a 16-byte boundary
     const int per16 = dtype == FS2_F32 ? 4 : 8;
     auto vec_ok = [per16](const void* p, long s_outer, long s1, long s2, long s3) {
@@ -596,23 +675,16 @@ int launch_bgemm(const BGemmArgs& a0, int dtype, hipStream_t stream) {
     a.xcd_remap = g_bgemm_xcd;
     const int splitk = a.splitk > 1 ? a.splitk : 1;
     dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, a.nb1 * a.nb2 * splitk);
-    // bf16: the 256-row tile when it still leaves every CU a workgroup or two
-    const long tiles256 = (long)((a.N + BN - 1) / BN) * ((a.M + 255) / 256) * a.nb1 * a.nb2 * splitk;
-    (void)tiles256;
-    const bool tall = dtype == FS2_BF16 && g_bgemm_tile == 2;  // 256-row tiles measured slower on every training shape: knob only
-    if (tall) grid.y = (a.M + 255) / 256;
     const long per = (long)a.M * a.N;
     dim3 g2((unsigned)((per + 255) / 256), a.nb1 * a.nb2);
     if (dtype == FS2_F32) {
         hipLaunchKernelGGL(bgemm_f32_kernel, grid, dim3(256), 0, stream, a);
         if (splitk > 1) hipLaunchKernelGGL(bgemm_reduce_kernel, g2, dim3(256), 0, stream, a);
     } else if (a.c_dtype == FS2_F32) {
-        if (tall) hipLaunchKernelGGL((bgemm_bf16_kernel<float, 8>), grid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((bgemm_bf16_kernel<float, 4>), grid, dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((bgemm_bf16_kernel<float, 4>), grid, dim3(256), 0, stream, a);
         if (splitk > 1) hipLaunchKernelGGL(bgemm_reduce_t_kernel<float>, g2, dim3(256), 0, stream, a);
     } else {
-        if (tall) hipLaunchKernelGGL((bgemm_bf16_kernel<bf16, 8>), grid, dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL((bgemm_bf16_kernel<bf16, 4>), grid, dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((bgemm_bf16_kernel<bf16, 4>), grid, dim3(256), 0, stream, a);
         if (splitk > 1) hipLaunchKernelGGL(bgemm_reduce_t_kernel<bf16>, g2, dim3(256), 0, stream, a);
     }
     return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;

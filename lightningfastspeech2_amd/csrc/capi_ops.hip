@@ -86,7 +86,6 @@ int fs2_op_set_vocoder_lds_limit(int32_t kib) {
 
 int fs2_op_set_gemm_variant(int32_t variant) {
     if (variant >= 700) { fs2::g_bgemm_xcd = variant - 700; return FS2_OK; }        // 700 / 701: bf16 strided-batched GEMM tile order plain / XCD-contiguous
-    if (variant >= 600) { fs2::g_bgemm_tile = variant - 600; return FS2_OK; }       // 600 / 601 / 602: bf16 strided-batched GEMM tile auto / 128 / 256 rows
     if (variant >= 500) { fs2::g_split_f32 = variant - 500; return FS2_OK; }       // 500 / 501: fp32 slab launches as fp32 MFMA / bf16 x 3 split
     if (variant >= 300) { fs2::g_wide_ln = variant - 300; return FS2_OK; }         // 300 / 301: fused LayerNorm for N > 256 off / on
     if (variant >= 200) { fs2::g_slab_xcd_remap = variant - 200; return FS2_OK; }  // 200 / 201: tile order knob
@@ -207,6 +206,18 @@ int fs2_op_bgemm(int32_t dtype, const fs2_bgemm_desc* d, const void* A, const vo
                  float* ws, void* stream) {
     if (!d || !A || !B || !C) return FS2_ERR_ARG;
     return launch_bgemm(bgemm_args(d, A, B, C, bias, ws), dtype, (hipStream_t)stream);
+}
+int fs2_op_bgemm_softmax_bwd(int32_t dtype, const fs2_bgemm_desc* d, const void* A, const void* B, void* C, const void* P,
+                             const float* delta, float drop_p, uint64_t drop_seed, uint64_t drop_key, void* stream) {
+    if (!d || !A || !B || !C || !P || !delta) return FS2_ERR_ARG;
+    BGemmArgs a = bgemm_args(d, A, B, C, nullptr, nullptr);
+    a.epi_p = P; a.epi_delta = delta; a.drop_p = drop_p; a.drop_seed = drop_seed; a.drop_key = drop_key;
+    return launch_bgemm(a, dtype, (hipStream_t)stream);
+}
+int fs2_op_attn_delta(int32_t dtype, const void* dout, const void* out, float* delta, int32_t B, int32_t S, int32_t H,
+                      int32_t heads, void* stream) {
+    AttnDeltaArgs a{dout, out, delta, B, S, H, heads};
+    return launch_attn_delta(a, dtype, (hipStream_t)stream);
 }
 int32_t fs2_op_layernorm_bwd_parts(int32_t M) { return layernorm_bwd_parts(M); }
 int fs2_op_layernorm_bwd(int32_t dtype, const void* z, const void* res, const void* dy, const float* gamma, void* dz,

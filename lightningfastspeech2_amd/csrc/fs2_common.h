@@ -199,6 +199,16 @@ __device__ inline void split_bf16x3(const uint4& c0, const uint4& c1, uint4& hi,
     lo = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
+// nn.Dropout mask bits of element i at a site: counter-based (splitmix64 of seed, site key, element index), 24 bits; an
+// element is dropped when bits < p * 2^24.  Regenerated wherever the mask is needed, never stored.
+__host__ __device__ inline uint32_t dropout_bits(uint64_t seed, uint64_t key, uint64_t i) {
+    uint64_t z = seed + key * 0x9E3779B97F4A7C15ull + i * 0xD1B54A32D192ED03ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (uint32_t)(z >> 40);
+}
+
 // LDS-DMA completion is made explicit wherever a barrier publishes DMA'd operands: hipcc usually
 // puts a vmcnt(0) in front of such a barrier itself, but it may hoist that wait out of a loop (seen
 // when VGPR-returning loads sit ahead of the loop), which leaves the back-edge barrier unprotected

@@ -289,12 +289,16 @@ struct BGemmArgs {
     int a_shift0 = 0, a_shift_step = 0;
     long sBtap = 0;               //             ... and B from + j * sBtap
     int b_shift0 = 0, b_shift_step = 0;  // wgrad form (taps == 1): batch index b2 reads B's k rows at k + b_shift0 + b2 * b_shift_step
+    // fused softmax backward (attention): C = alpha * P * (dropout(acc) - delta[b1][b2][m]); P has C's layout and dtype
+    const void* epi_p = nullptr;
+    const float* epi_delta = nullptr;   // (nb1, nb2, M)
+    float drop_p = 0.f;                 // attention-weight dropout of the forward (mask over the (nb1, nb2, M, N) index)
+    uint64_t drop_seed = 0, drop_key = 0;
     int c_dtype = FS2_F32;        // dtype of C: bf16 operands may write bf16 (activations) or fp32 (weight gradients, scores)
     int vecA = 0, vecB = 0;       // set by the launcher
     int xcd_remap = 0;            // set by the launcher
 };
 size_t bgemm_ws_bytes(const BGemmArgs& a);
-extern int g_bgemm_tile;
 extern int g_bgemm_xcd;
 int launch_bgemm(const BGemmArgs& a, int dtype, hipStream_t stream);
 
@@ -418,6 +422,13 @@ struct DropoutArgs {   // y = x * keep / (1 - p), keep from a counter-based hash
     uint64_t seed, key;
 };
 int launch_dropout(const DropoutArgs& a, int dtype, hipStream_t stream);
+struct AttnDeltaArgs {   // delta (B, heads, S) = per-head row dot of dout and out, both (B*S, H)
+    const void* dout;
+    const void* out;
+    float* delta;
+    int B, S, H, heads;
+};
+int launch_attn_delta(const AttnDeltaArgs& a, int dtype, hipStream_t stream);
 struct RowDotArgs {    // pred[m] = mask[m] ? 0 : y[m] . w + b[0]
     const void* y;
     const float* w;

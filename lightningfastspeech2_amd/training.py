@@ -443,14 +443,17 @@ class Trainer:
         # dV = dropout(P)^T dO
         o.bgemm(t["prob_d"], dattn, dqkv[:, 2 * H:], M=S, N=d, K=S, sAm=1, sAk=S, sBk=H, sBn=1, ldc=3 * H, sB1=S * H, sB2=d,
                 sC1=S * 3 * H, sC2=d, **bat, **sP)
-        # dP = dO V^T
-        dp = o.empty(B, heads, S, S)
-        o.bgemm(dattn, qkv[:, 2 * H:], dp, M=S, N=S, K=d, sAm=H, sAk=1, sBk=1, sBn=3 * H, ldc=S, sA1=S * H, sA2=d,
-                sB1=S * 3 * H, sB2=d, sC1=heads * S * S, sC2=S * S, **bat)
-        o.dropout(dp, pd, t["k_attn"])  # back through the attention-weight dropout (fp32 buffer, same element order as P)
-        ds = dp if o.dt == F32 else o.act(B, heads, S, S)
-        o.ck(o.lib.fs2_op_softmax_bwd(o.dt, _p(dp), _p(prob), _p(ds), B, heads, S, C.c_float(t["scale"]), o.st()), "softmax_bwd")
-        dp = ds
+        # dS = P o (dropout(dO V^T) - delta) / sqrt(d) in the product's epilogue: no dP tensor, no softmax-backward pass
+        delta = o.empty(B, heads, S)
+        o.ck(o.lib.fs2_op_attn_delta(o.dt, _p(dattn), _p(t["attn"]), _p(delta), B, S, H, heads, o.st()), "attn_delta")
+        dp = o.act(B, heads, S, S)
+        dsc = _lib.BGemmDescC()
+        for k_, v_ in dict(M=S, N=S, K=d, sAm=H, sAk=1, sBk=1, sBn=3 * H, ldc=S, sA1=S * H, sA2=d, sB1=S * 3 * H, sB2=d,
+                           sC1=heads * S * S, sC2=S * S, alpha=t["scale"], beta=0.0, splitk=1, taps=1, nb1=B, nb2=heads,
+                           c_dtype=o.dt).items():
+            setattr(dsc, k_, v_)
+        o.ck(o.lib.fs2_op_bgemm_softmax_bwd(o.dt, C.byref(dsc), _p(dattn), _p(qkv[:, 2 * H:]), _p(dp), _p(prob), _p(delta),
+                                            C.c_float(pd), C.c_uint64(o.seed), C.c_uint64(t["k_attn"]), o.st()), "bgemm_softmax_bwd")
         # dQ = dS K ; dK = dS^T Q
         o.bgemm(dp, qkv[:, H:], dqkv, M=S, N=d, K=S, sAm=S, sAk=1, sBk=3 * H, sBn=1, ldc=3 * H, sB1=S * 3 * H, sB2=d,
                 sC1=S * 3 * H, sC2=d, **bat, **sP)

@@ -417,3 +417,42 @@ def test_fold_unfold_conv2():
     close(dbg - 1, bg.grad, 1e-5)
     close(dW - 1, W21.grad.view(H, Fc), 1e-5)
     close(db - 1, b21.grad, 1e-5)
+
+
+@pytest.mark.parametrize("dtype,drop", [("fp32", 0.0), ("bf16", 0.0), ("fp32", 0.25)])
+def test_fused_softmax_backward_epilogue(dtype, drop):
+    """dS = P o (dropout(dO V^T) - delta) / sqrt(d) straight out of the product (no dP tensor), delta from fs2_op_attn_delta,
+    against autograd of softmax(QK^T / sqrt(d)) -> dropout -> @ V with the mask the dropout op itself produces."""
+    lib = _lib.load()
+    B, S, H, heads = 2, 40, 64, 2
+    d = H // heads
+    bf = dtype == "bf16"
+    tdt, dt = (torch.bfloat16, BF) if bf else (torch.float32, F32)
+    g = torch.Generator().manual_seed(12)
+    qkv = torch.randn(B * S, 3 * H, generator=g).to(tdt)
+    q, k, v = (t.double().view(B, S, heads, d).transpose(1, 2) for t in qkv.view(B, S, 3 * H).split(H, dim=-1))
+    scores = (q @ k.transpose(-1, -2) / d ** 0.5).requires_grad_(True)
+    P = torch.softmax(scores, dim=-1)
+    Pd = P.detach().to(tdt).to(DEV).contiguous()
+    seed, key = 77, 5
+    if drop > 0:  # the mask the op regenerates: run it on ones
+        ones = torch.ones(B, heads, S, S, device=DEV)
+        m = torch.empty_like(ones)
+        _lib.check(lib.fs2_op_dropout(F32, p(ones), p(m), ones.numel(), C.c_float(drop), C.c_uint64(seed), C.c_uint64(key), st()))
+        mask = m.cpu().double()
+    else:
+        mask = torch.ones(B, heads, S, S, dtype=torch.float64)
+    out = ((P * mask) @ v).transpose(1, 2).reshape(B * S, H)
+    dout = torch.randn(B * S, H, generator=g).to(tdt)
+    out.backward(dout.double())
+    od, dod, qkvd = out.detach().to(tdt).to(DEV).contiguous(), dout.to(DEV), qkv.to(DEV)
+    delta = torch.empty(B, heads, S, device=DEV)
+    _lib.check(lib.fs2_op_attn_delta(dt, p(dod), p(od), p(delta), B, S, H, heads, st()))
+    ds = torch.empty(B, heads, S, S, device=DEV, dtype=tdt)
+    dsc = _lib.BGemmDescC()
+    for kk, vv in dict(M=S, N=S, K=d, sAm=H, sAk=1, sBk=1, sBn=3 * H, ldc=S, sA1=S * H, sA2=d, sB1=S * 3 * H, sB2=d, sC1=heads * S * S,
+                       sC2=S * S, alpha=1.0 / d ** 0.5, beta=0.0, splitk=1, taps=1, nb1=B, nb2=heads, c_dtype=dt).items():
+        setattr(dsc, kk, vv)
+    _lib.check(lib.fs2_op_bgemm_softmax_bwd(dt, C.byref(dsc), p(dod), p(qkvd[:, 2 * H:]), p(ds), p(Pd), p(delta), C.c_float(drop),
+                                            C.c_uint64(seed), C.c_uint64(key), st()))
+    close(ds, scores.grad / d ** 0.5, 2e-2 if bf else 3e-5)  # gradient of the RAW product Q K^T (what dQ = dS K and dK = dS^T Q consume)
