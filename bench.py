@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--frames-per-phone", type=int, default=6)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the training-step side measurement")
     ap.add_argument("--no-fused-predictor", action="store_true", help="A/B: variance predictors layer by layer")
     ap.add_argument("--parity-sample", type=int, default=2, help="utterances of the workload the parity block checks")
     return ap.parse_args()
@@ -186,6 +187,35 @@ def parity_block(cfg, sd, args, dev, timed_model):
     res.update({f"{p}_duration_flips": dfl, f"{p}_bucket_flips": bfl, f"{p}_mel_maxabs_free": free,
                 f"{p}_mel_maxabs_forced": forced, "mel_scale": float(ref["mel"].abs().max())})
     return res
+
+
+def training_block(cfg, sd, args, inp, T):
+    """The same synthetic batch through `Trainer.training_step` + `optimizer_step` (teacher-forced forward, losses, backward,
+    clip, AdamW): 2 warm-up + 5 timed steps.  Reported beside the forward metric, never as `value`."""
+    from lightningfastspeech2_amd.training import Trainer
+    del_model_mem = torch.cuda.memory_allocated()
+    rs = np.random.RandomState(5)
+    B, L = args.batch, args.phones
+    batch = {"phones": torch.from_numpy(inp["phones"]).cuda(), "speaker": torch.from_numpy(inp["speaker"]).cuda(),
+             "duration": torch.full((B, L), args.frames_per_phone, dtype=torch.int64).cuda(),
+             "mel": torch.from_numpy((rs.randn(B, T, cfg.n_mels) - 2).astype(np.float32)).cuda()}
+    for v in cfg.variances:
+        batch[f"variances_{v}"] = torch.from_numpy(rs.randn(B, T).astype(np.float32)).cuda()
+    tr = Trainer(cfg, sd, precision=args.precision)
+    for _ in range(2):
+        tr.training_step(batch)
+        tr.optimizer_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    k = 5
+    for _ in range(k):
+        losses = tr.training_step(batch)
+        tr.optimizer_step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / k
+    return {"what": "teacher-forced forward + FastSpeech2Loss + backward + clip + AdamW/Noam on the same batch (lightningfastspeech2_amd.training)",
+            "precision": args.precision, "ms_per_step": dt * 1e3, "mel_frames_per_s": B * T / dt, "steps": k,
+            "loss_total": float(losses["total"]), "extra_mem_GB": (torch.cuda.max_memory_allocated() - del_model_mem) / 2**30}
 
 
 def main():
@@ -360,6 +390,11 @@ def main():
                 line["parity"] = parity_block(cfg, sd, args, dev, model)
             except Exception as ex:  # never lose the timed line to the checker
                 line["parity"] = {"error": repr(ex)}
+        if world == 1 and not args.no_train and args.precision in ("bf16", "fp32"):
+            try:  # side measurement, never `value`: the same workload through the training step
+                line["training_step"] = training_block(cfg, sd, args, inp, T)
+            except Exception as ex:
+                line["training_step"] = {"error": repr(ex)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, sd, args)
         print(json.dumps(line), flush=True)
