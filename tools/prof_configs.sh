@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for cfg in c2 c3 c5; do
   B=32; [ $cfg = c5 ] && B=8
-  EXTRA="--no-cpu-baseline --no-parity"
+  EXTRA="--no-cpu-baseline --no-parity --no-train"
   timeout 600 python $R/bench.py --config $cfg --batch $B --steps 10 --warmup 3 $EXTRA > $O/${TAG}_${cfg}_bench.json 2> $O/${TAG}_${cfg}_bench.err
   rm -rf $O/prof_$cfg
   timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof_$cfg -o p -- python $R/bench.py --config $cfg --batch $B --steps 10 --warmup 3 $EXTRA > $O/${TAG}_${cfg}_prof_bench.json 2> $O/${TAG}_${cfg}_prof.err
