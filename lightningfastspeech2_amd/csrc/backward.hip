@@ -366,38 +366,56 @@ template <typename T>
 __global__ __launch_bounds__(256) void scatter_rows_kernel(ScatterRowsArgs p) {
     const int v = blockIdx.x;
     if (v == p.skip_row) return;
-    __shared__ int hits[1024];
-    __shared__ int nhit;
+    // Blocks of 4096 source rows: wave w scans its own 1024 of them (64 at a time, ballot + popcount compaction into its own
+    // list, no workgroup barrier), then all threads add the listed rows wave list by wave list - ascending row order, so the
+    // sums do not depend on scheduling.
+    __shared__ int hits[4][1024];
+    __shared__ int cnt[4];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int c0 = 0; c0 < p.H; c0 += 256 * 8) {  // register accumulators for up to 8 columns per thread per sweep
         float acc[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-        for (int r0 = 0; r0 < p.R; r0 += 1024) {
-            if (threadIdx.x == 0) nhit = 0;
-            __syncthreads();
-            // ordered compaction of the matching rows of this block of 1024 (order = row index: deterministic sums)
-            for (int q = 0; q < 4; ++q) {
-                const int r = r0 + q * 256 + threadIdx.x;
-                const bool m = r < p.R && (p.idx32 ? p.idx32[r] : (int)p.idx64[r]) == v;
-                const unsigned long long bal = __ballot(m);
-                __shared__ int wcnt[4];
-                const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-                if (lane == 0) wcnt[w] = __popcll(bal);
-                __syncthreads();
-                int base = nhit;
-                for (int k = 0; k < w; ++k) base += wcnt[k];
-                if (m) hits[base + __popcll(bal & ((1ull << lane) - 1))] = r;
-                __syncthreads();
-                if (threadIdx.x == 0) nhit += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-                __syncthreads();
-            }
-            const int n = nhit;
-            for (int h = 0; h < n; ++h) {
-                const T* src = (const T*)p.x + (long)hits[h] * p.H;
+        for (int r0 = 0; r0 < p.R; r0 += 4096) {
+            int n = 0;
+            int iv[16];  // all 16 index loads in flight before the first is looked at
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int c = c0 + j * 256 + threadIdx.x;
-                    if (c < p.H) acc[j] += Num<T>::to_f32(src[c]);
+            for (int q = 0; q < 16; ++q) {
+                const int r = r0 + w * 1024 + q * 64 + lane;
+                iv[q] = r < p.R ? (p.idx32 ? p.idx32[r] : (int)p.idx64[r]) : -1;
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int r = r0 + w * 1024 + q * 64 + lane;
+                const bool m = iv[q] == v;
+                const unsigned long long bal = __ballot(m);
+                if (m) hits[w][n + __popcll(bal & ((1ull << lane) - 1))] = r;
+                n += __popcll(bal);
+            }
+            if (lane == 0) cnt[w] = n;
+            __syncthreads();
+#pragma unroll 1
+            for (int ww = 0; ww < 4; ++ww) {
+                const int nh = cnt[ww];
+                if (p.H <= 256) {  // the usual width: eight rows' loads in flight, added in list order
+                    const int c = c0 + threadIdx.x;
+                    for (int h = 0; h < nh; h += 8) {
+                        float vv[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            vv[u] = (h + u < nh && c < p.H) ? Num<T>::to_f32(((const T*)p.x)[(long)hits[ww][h + u] * p.H + c]) : 0.f;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) acc[0] += vv[u];
+                    }
+                    continue;
+                }
+                for (int h = 0; h < nh; ++h) {
+                    const T* src = (const T*)p.x + (long)hits[ww][h] * p.H;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int c = c0 + j * 256 + threadIdx.x;
+                        if (c < p.H) acc[j] += Num<T>::to_f32(src[c]);
+                    }
                 }
             }
             __syncthreads();

@@ -19,17 +19,35 @@ __global__ __launch_bounds__(LOSS_THREADS) void masked_loss_kernel(LossArgs p) {
     __shared__ bool is_last;
     const int tid = threadIdx.x;
     double sum = 0.0, cnt = 0.0;
+    // a thread walks (row, column) pairs with a fixed column stride: one 64-bit division per thread, none per element
     const int64_t total = p.rows * (int64_t)p.inner;
-    for (int64_t e = (int64_t)blockIdx.x * LOSS_THREADS + tid; e < total; e += (int64_t)gridDim.x * LOSS_THREADS) {
-        const int64_t r = e / p.inner;
-        if (p.mask[r]) continue;  // True = pad
-        float t;
-        if (p.truth_kind == 0) t = ((const float*)p.truth)[e];
-        else t = logf((float)((const int64_t*)p.truth)[e] + 1.0f);  // duration target: log(d + 1), loss.py:176
-        const float d = p.pred[e] - t;
-        sum += p.kind == 0 ? (double)fabsf(d) : (double)(d * d);
-        cnt += 1.0;
+    const int64_t stride = (int64_t)gridDim.x * LOSS_THREADS;
+    int64_t e = (int64_t)blockIdx.x * LOSS_THREADS + tid;
+    int64_t r = e / p.inner;
+    int c = (int)(e - r * p.inner);
+    const int64_t dr = stride / p.inner;
+    const int dc = (int)(stride - dr * p.inner);
+    float fsum = 0.f;
+    int fcnt = 0, run = 0;
+    for (; e < total; e += stride) {
+        if (!p.mask[r]) {  // True = pad
+            float t;
+            if (p.truth_kind == 0) t = ((const float*)p.truth)[e];
+            else t = logf((float)((const int64_t*)p.truth)[e] + 1.0f);  // duration target: log(d + 1), loss.py:176
+            const float d = p.pred[e] - t;
+            fsum += p.kind == 0 ? fabsf(d) : d * d;
+            ++fcnt;
+        }
+        if (++run == 64) {  // fp32 runs of at most 64 terms, fp64 across runs
+            sum += (double)fsum; cnt += (double)fcnt;
+            fsum = 0.f; fcnt = 0; run = 0;
+        }
+        r += dr;
+        c += dc;
+        if (c >= p.inner) { c -= p.inner; ++r; }
     }
+    sum += (double)fsum;
+    cnt += (double)fcnt;
     ssum[tid] = sum;
     scnt[tid] = cnt;
     __syncthreads();
@@ -52,14 +70,25 @@ __global__ __launch_bounds__(LOSS_THREADS) void masked_loss_kernel(LossArgs p) {
     __syncthreads();
     if (!is_last) return;
     __threadfence();
-    if (tid == 0) {
-        double s = 0.0, c = 0.0;
-        for (unsigned b = 0; b < gridDim.x; ++b) {
-            s += ((volatile double*)psum)[b];
-            c += ((volatile double*)pcnt)[b];
+    // the last block adds the block partials: each thread a fixed subset in index order, then the same LDS tree
+    double ts = 0.0, tc = 0.0;
+    for (unsigned b = tid; b < gridDim.x; b += LOSS_THREADS) {
+        ts += ((volatile double*)psum)[b];
+        tc += ((volatile double*)pcnt)[b];
+    }
+    ssum[tid] = ts;
+    scnt[tid] = tc;
+    __syncthreads();
+    for (int st = LOSS_THREADS / 2; st > 0; st >>= 1) {
+        if (tid < st) {
+            ssum[tid] += ssum[tid + st];
+            scnt[tid] += scnt[tid + st];
         }
-        p.out[0] = c > 0.0 ? (float)(s / c) : __builtin_nanf("");  // torch: mean of an empty selection is nan
-        p.out[1] = (float)c;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        p.out[0] = scnt[0] > 0.0 ? (float)(ssum[0] / scnt[0]) : __builtin_nanf("");  // torch: mean of an empty selection is nan
+        p.out[1] = (float)scnt[0];
         *done = 0u;  // ready for the next launch on this workspace
     }
 }
