@@ -287,6 +287,18 @@ typedef struct fs2_bgemm_desc {
 size_t fs2_op_bgemm_ws_bytes(const fs2_bgemm_desc* d);  /* split-K slabs (0 when splitk <= 1) */
 int fs2_op_bgemm(int32_t dtype, const fs2_bgemm_desc* d, const void* A, const void* B, void* C, const float* bias,
                  float* ws, void* hip_stream);
+/* The fused (flash) attention of the inference path on the training path: also writes lse2 (B, heads, S) - per query, log2 of
+ * the softmax denominator in the scaled scores' log2 units - and applies nn.MultiheadAttention's attention-weight dropout
+ * (drop_p = 0: none; mask regenerated from (seed, key) over the (b, head, query, key) index); and its recomputing backward
+ * (bf16, head dim 128: fs2_op_attention_bwd_supported): dqkv (B*S, 3H) from dout (B*S, H), qkv, lse2 and
+ * delta = fs2_op_attn_delta(dout, out); neither the probabilities nor their gradients reach HBM.  Two launches, no atomics. */
+int fs2_op_attention_train(int32_t dtype, const void* qkv, const uint8_t* key_pad_mask, void* out, void* vt_scratch,
+                           uint64_t* bits_scratch, float* lse2, int32_t B, int32_t S, int32_t H, int32_t heads, float drop_p,
+                           uint64_t drop_seed, uint64_t drop_key, void* hip_stream);
+int32_t fs2_op_attention_bwd_supported(int32_t dtype, int32_t H, int32_t heads);
+int fs2_op_attention_bwd(int32_t dtype, const void* qkv, const void* dout, const float* lse2, const float* delta,
+                         const uint8_t* key_pad_mask, void* dqkv, int32_t B, int32_t S, int32_t H, int32_t heads, float drop_p,
+                         uint64_t drop_seed, uint64_t drop_key, void* hip_stream);
 /* attention backward without a dP tensor: C = dS = alpha * P o (dropout(A B) - delta) where A B = dO V^T is the product the
  * descriptor states, P (C's layout and dtype) are the forward's probabilities, delta (nb1, nb2, M) = fs2_op_attn_delta(dO, O)
  * (= sum_k dP P) and the dropout is the forward's attention-weight dropout (drop_p = 0: none), regenerated from (seed, key) */

@@ -149,6 +149,10 @@ def load():
     lib.fs2_op_bgemm_ws_bytes.restype = sz
     lib.fs2_op_bgemm_ws_bytes.argtypes = [C.POINTER(BGemmDescC)]
     lib.fs2_op_bgemm.argtypes = [i32, C.POINTER(BGemmDescC), vp, vp, vp, vp, vp, vp]
+    lib.fs2_op_attention_train.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, C.c_uint64, C.c_uint64, vp]
+    lib.fs2_op_attention_bwd_supported.restype = i32
+    lib.fs2_op_attention_bwd_supported.argtypes = [i32, i32, i32]
+    lib.fs2_op_attention_bwd.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, C.c_uint64, C.c_uint64, vp]
     lib.fs2_op_bgemm_softmax_bwd.argtypes = [i32, C.POINTER(BGemmDescC), vp, vp, vp, vp, vp, f32, C.c_uint64, C.c_uint64, vp]
     lib.fs2_op_attn_delta.argtypes = [i32, vp, vp, vp, i32, i32, i32, i32, vp]
     lib.fs2_op_layernorm_bwd_parts.restype = i32

@@ -282,6 +282,20 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128) ? 2 : 1) void
             rs = half_sum(rs);
             l_run += rs;
 
+            // ---- attention-weight dropout (training): after the row sum, before P.V (the softmax normalisation is of the
+            // undropped weights); mask = f(seed, key, ((b*heads + h)*S + query)*S + key index) ----
+            if (p.drop_p > 0.f) {
+                const uint32_t thr = (uint32_t)(p.drop_p * 16777216.0f);
+                const float dsc = 1.f / (1.f - p.drop_p);
+                const uint64_t rowbase = ((uint64_t)(b * p.heads + h) * p.S + (q0 + wave * 32 + li)) * p.S + (uint64_t)j * KVB;
+    #pragma unroll
+                for (int kb = 0; kb < NKB; ++kb)
+    #pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ko = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        sacc[kb][r] = dropout_bits(p.drop_seed, p.drop_key, rowbase + ko) >= thr ? sacc[kb][r] * dsc : 0.f;
+                    }
+            }
             // ---- P fragments (column operand), straight from the lane's own registers ----
     #pragma unroll
             for (int ch = 0; ch < 4; ++ch) {
@@ -346,6 +360,7 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128) ? 2 : 1) void
     // ---- normalise and store: lane owns query li, dv = nd*32 + (r&3) + 8*(r>>2) + 4*hi ----
     const int qrow = q0 + wave * 32 + li;
     if (qrow < p.S) {
+        if (p.lse2 && hi == 0) p.lse2[(size_t)(b * p.heads + h) * p.S + qrow] = m_run + __builtin_amdgcn_logf(l_run);  // v_log_f32 = log2
         const float inv = 1.f / l_run;  // all keys padded -> NaN, as the reference's softmax gives
         T* dst = (T*)p.out + (size_t)(b * p.S + qrow) * p.H + h * D;
 #pragma unroll

@@ -138,6 +138,32 @@ int fs2_op_attention(int32_t dtype, const void* qkv, const uint8_t* key_pad_mask
     return launch_attention(a, dtype, st);
 }
 
+int fs2_op_attention_train(int32_t dtype, const void* qkv, const uint8_t* key_pad_mask, void* out, void* vt_scratch,
+                           uint64_t* bits_scratch, float* lse2, int32_t B, int32_t S, int32_t H, int32_t heads, float drop_p,
+                           uint64_t drop_seed, uint64_t drop_key, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    const int Spad = (S + 63) / 64 * 64;
+    MaskBitsArgs mb{key_pad_mask, bits_scratch, B, S, Spad / 64};
+    int r = launch_mask_bits(mb, st);
+    if (r != FS2_OK) return r;
+    AttnArgs a;
+    a.qkv = qkv; a.vt = vt_scratch; a.kbits = bits_scratch; a.out = out;
+    a.B = B; a.S = S; a.H = H; a.heads = heads; a.Spad = Spad; a.nw64 = Spad / 64;
+    a.scale_log2e = (float)(1.4426950408889634 / sqrt((double)(H / heads)));
+    a.lse2 = lse2; a.drop_p = drop_p; a.drop_seed = drop_seed; a.drop_key = drop_key;
+    r = launch_transpose_v(a, dtype, st);
+    if (r != FS2_OK) return r;
+    return launch_attention(a, dtype, st);
+}
+int32_t fs2_op_attention_bwd_supported(int32_t dtype, int32_t H, int32_t heads) { return attention_bwd_supported(dtype, H, heads) ? 1 : 0; }
+int fs2_op_attention_bwd(int32_t dtype, const void* qkv, const void* dout, const float* lse2, const float* delta,
+                         const uint8_t* key_pad_mask, void* dqkv, int32_t B, int32_t S, int32_t H, int32_t heads, float drop_p,
+                         uint64_t drop_seed, uint64_t drop_key, void* stream) {
+    AttnBwdArgs a{qkv, dout, lse2, delta, key_pad_mask, dqkv, B, S, H, heads,
+                  (float)(1.4426950408889634 / sqrt((double)(H / heads))), (float)(1.0 / sqrt((double)(H / heads))), drop_p, drop_seed, drop_key};
+    return launch_attention_bwd(a, dtype, (hipStream_t)stream);
+}
+
 int fs2_op_layernorm(int32_t dtype, const void* x, const void* res, const float* gamma, const float* beta, void* y,
                      const float* dot_w, float dot_b, const uint8_t* mask, float* pred, int32_t M, int32_t H,
                      void* stream) {

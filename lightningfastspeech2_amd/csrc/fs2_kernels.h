@@ -56,7 +56,28 @@ struct AttnArgs {
     void* out;              // (B*S, H)
     int B, S, H, heads, Spad, nw64;
     float scale_log2e;      // log2(e) / sqrt(d)
+    // training path: per-query log-sum-exp in log2 units of the scaled scores (lse2 = m + log2(l); P = exp2(s - lse2)) for the
+    // recomputing backward, and the attention-weight dropout of nn.MultiheadAttention (mask over the (b, head, q, key) index)
+    float* lse2 = nullptr;  // (B, heads, S) or null
+    float drop_p = 0.f;
+    uint64_t drop_seed = 0, drop_key = 0;
 };
+// Recomputing (flash) backward of the same attention, bf16, head dim 128 (attention_bwd.hip): dqkv (B*S, 3H) from dout (B*S, H),
+// the forward's qkv / lse2 and delta = fs2 attn_delta(dout, out).  Two launches: (dK, dV) per key block, dQ per query block.
+struct AttnBwdArgs {
+    const void* qkv;
+    const void* dout;
+    const float* lse2;       // (B, heads, S)
+    const float* delta;      // (B, heads, S)
+    const uint8_t* key_pad;  // (B, S) 1 = pad
+    void* dqkv;              // (B*S, 3H) out: every element written
+    int B, S, H, heads;
+    float scale_log2e, scale;
+    float drop_p;
+    uint64_t drop_seed, drop_key;
+};
+bool attention_bwd_supported(int dtype, int H, int heads);
+int launch_attention_bwd(const AttnBwdArgs& a, int dtype, hipStream_t stream);
 int launch_transpose_v(const AttnArgs& a, int dtype, hipStream_t stream);  // fills a.vt from a.qkv
 int launch_attention(const AttnArgs& a, int dtype, hipStream_t stream);    // needs a.vt filled
 

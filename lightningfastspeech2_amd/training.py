@@ -206,7 +206,7 @@ class Trainer:
     def __init__(self, cfg: Fs2Config, state_dict, *, lr=2e-4, warmup_steps=4000, betas=(0.9, 0.98), eps=1e-8,
                  weight_decay=0.01, gradient_clip_val: Optional[float] = 1.0, variance_losses=None, mel_loss="l1",
                  duration_loss="mse", loss_alphas=None, precision="fp32", encoder_dropout=0.0, decoder_dropout=0.0,
-                 variance_dropout=0.0, duration_dropout=0.0, seed=0, device="cuda:0"):
+                 variance_dropout=0.0, duration_dropout=0.0, seed=0, attention="auto", device="cuda:0"):
         if any(l != "frame" for l in cfg.variance_levels[:len(cfg.variances)]) or any(cfg.is_cwt(i) for i in range(len(cfg.variances))):
             raise NotImplementedError("training step: frame-level 'none' variances only")
         if precision not in _PRECISIONS:
@@ -223,6 +223,9 @@ class Trainer:
         self.p_enc, self.p_dec, self.p_dur = float(encoder_dropout), float(decoder_dropout), float(duration_dropout)
         self.p_var = [float(v) for v in variance_dropout][:nv_] if isinstance(variance_dropout, (list, tuple)) else [float(variance_dropout)] * nv_
         self.seed, self._micro = int(seed), 0
+        if attention not in ("auto", "materialized"):
+            raise ValueError("attention must be 'auto' or 'materialized'")
+        self.attention = attention  # auto: the fused forward + recomputing backward where built (bf16, head dim 128)
         self.variance_losses = list(variance_losses) if variance_losses is not None else ["mse"] * len(cfg.variances)
         self.mel_loss, self.duration_loss = mel_loss, duration_loss
         self.loss_alphas = dict(loss_alphas) if loss_alphas is not None else {
@@ -349,17 +352,27 @@ class Trainer:
         M, d = B * S, H // heads
         t = {"x": x, "pd": pd, "k_attn": o.site(), "k_sa": o.site(), "k_h": o.site(), "k_ff": o.site()}
         qkv = o.gemm(x, W[f"{prefix}.self_attn.in_proj_weight"], P[f"{prefix}.self_attn.in_proj_bias"], M, 3 * H, H)
-        scores = o.empty(B, heads, S, S)  # fp32 in either mode; the probabilities are kept in the activation dtype
-        o.bgemm(qkv, qkv[:, H:], scores, M=S, N=S, K=d, sAm=3 * H, sAk=1, sBk=1, sBn=3 * H, ldc=S, nb1=B, nb2=heads,
-                sA1=S * 3 * H, sA2=d, sB1=S * 3 * H, sB2=d, sC1=heads * S * S, sC2=S * S)
+        flash = self.attention == "auto" and bool(o.lib.fs2_op_attention_bwd_supported(o.dt, H, heads))
         scale = 1.0 / math.sqrt(d)
-        prob = scores if o.dt == F32 else o.act(B, heads, S, S)
-        o.ck(o.lib.fs2_op_softmax_fwd(o.dt, _p(scores), _p(key_pad), _p(prob), B, heads, S, C.c_float(scale), o.st()), "softmax")
-        del scores
-        prob_d = o.dropout(prob, pd, t["k_attn"], out=o.act(B, heads, S, S)) if pd > 0 else prob  # MHA drops attention weights
         attn = o.act(M, H)
-        o.bgemm(prob_d, qkv[:, 2 * H:], attn, M=S, N=d, K=S, sAm=S, sAk=1, sBk=3 * H, sBn=1, ldc=H, nb1=B, nb2=heads,
-                sA1=heads * S * S, sA2=S * S, sB1=S * 3 * H, sB2=d, sC1=S * H, sC2=d)
+        prob = prob_d = lse = None
+        if flash:  # fused attention (scores never reach HBM) + lse2 for the recomputing backward
+            bb = C.c_size_t()
+            vb = int(o.lib.fs2_op_attention_scratch_bytes(o.dt, B, S, H, heads, C.byref(bb)))
+            vt, bits = o.ws("attn_vt", vb), o.ws("attn_bits", int(bb.value))
+            lse = o.empty(B, heads, S)
+            o.ck(o.lib.fs2_op_attention_train(o.dt, _p(qkv), _p(key_pad), _p(attn), _p(vt), _p(bits), _p(lse), B, S, H, heads,
+                                              C.c_float(pd), C.c_uint64(o.seed), C.c_uint64(t["k_attn"]), o.st()), "attention_train")
+        else:
+            scores = o.empty(B, heads, S, S)  # fp32 in either mode; the probabilities are kept in the activation dtype
+            o.bgemm(qkv, qkv[:, H:], scores, M=S, N=S, K=d, sAm=3 * H, sAk=1, sBk=1, sBn=3 * H, ldc=S, nb1=B, nb2=heads,
+                    sA1=S * 3 * H, sA2=d, sB1=S * 3 * H, sB2=d, sC1=heads * S * S, sC2=S * S)
+            prob = scores if o.dt == F32 else o.act(B, heads, S, S)
+            o.ck(o.lib.fs2_op_softmax_fwd(o.dt, _p(scores), _p(key_pad), _p(prob), B, heads, S, C.c_float(scale), o.st()), "softmax")
+            del scores
+            prob_d = o.dropout(prob, pd, t["k_attn"], out=o.act(B, heads, S, S)) if pd > 0 else prob  # MHA drops attention weights
+            o.bgemm(prob_d, qkv[:, 2 * H:], attn, M=S, N=d, K=S, sAm=S, sAk=1, sBk=3 * H, sBn=1, ldc=H, nb1=B, nb2=heads,
+                    sA1=heads * S * S, sA2=S * S, sB1=S * 3 * H, sB2=d, sC1=S * H, sC2=d)
         proj = o.dropout(o.gemm(attn, W[f"{prefix}.self_attn.out_proj.weight"], P[f"{prefix}.self_attn.out_proj.bias"], M, H, H),
                          pd, t["k_sa"])  # dropout1
         x1, _ = o.layernorm(proj, x, P[f"{prefix}.norm1.weight"], P[f"{prefix}.norm1.bias"], M, H)
@@ -371,7 +384,7 @@ class Trainer:
             h = o.dropout(o.gemm(x1, W[f"{prefix}.conv1.weight"], P[f"{prefix}.conv1.bias"], M, F_, H, taps=k, S=S, relu=True), pd, t["k_h"])
             c2 = o.dropout(o.gemm(h, W[f"{prefix}.conv2.weight"], P[f"{prefix}.conv2.bias"], M, H, F_), pd, t["k_ff"])  # dropout2
         x2, _ = o.layernorm(c2, x1, P[f"{prefix}.norm2.weight"], P[f"{prefix}.norm2.bias"], M, H)
-        t.update(qkv=qkv, prob=prob, prob_d=prob_d, attn=attn, proj=proj, x1=x1, h=h, c2=c2, scale=scale)
+        t.update(qkv=qkv, prob=prob, prob_d=prob_d, lse=lse, key_pad=key_pad, attn=attn, proj=proj, x1=x1, h=h, c2=c2, scale=scale)
         return x2, t
 
     def _ln_bwd(self, z, res, dy, gname, bname, M, H, bias_name=None, relu_mask=False, bias_out=None):
@@ -438,27 +451,31 @@ class Trainer:
         dattn = o.dgrad(dproj, W[f"{prefix}.self_attn.out_proj.weight"], M, H, H, wt=self._wt(f"{prefix}.self_attn.out_proj.weight"))
         qkv, prob = t["qkv"], t["prob"]
         dqkv = o.act(M, 3 * H)
-        bat = dict(nb1=B, nb2=heads)
-        sP = dict(sA1=heads * S * S, sA2=S * S)
-        # dV = dropout(P)^T dO
-        o.bgemm(t["prob_d"], dattn, dqkv[:, 2 * H:], M=S, N=d, K=S, sAm=1, sAk=S, sBk=H, sBn=1, ldc=3 * H, sB1=S * H, sB2=d,
-                sC1=S * 3 * H, sC2=d, **bat, **sP)
-        # dS = P o (dropout(dO V^T) - delta) / sqrt(d) in the product's epilogue: no dP tensor, no softmax-backward pass
         delta = o.empty(B, heads, S)
         o.ck(o.lib.fs2_op_attn_delta(o.dt, _p(dattn), _p(t["attn"]), _p(delta), B, S, H, heads, o.st()), "attn_delta")
-        dp = o.act(B, heads, S, S)
-        dsc = _lib.BGemmDescC()
-        for k_, v_ in dict(M=S, N=S, K=d, sAm=H, sAk=1, sBk=1, sBn=3 * H, ldc=S, sA1=S * H, sA2=d, sB1=S * 3 * H, sB2=d,
-                           sC1=heads * S * S, sC2=S * S, alpha=t["scale"], beta=0.0, splitk=1, taps=1, nb1=B, nb2=heads,
-                           c_dtype=o.dt).items():
-            setattr(dsc, k_, v_)
-        o.ck(o.lib.fs2_op_bgemm_softmax_bwd(o.dt, C.byref(dsc), _p(dattn), _p(qkv[:, 2 * H:]), _p(dp), _p(prob), _p(delta),
-                                            C.c_float(pd), C.c_uint64(o.seed), C.c_uint64(t["k_attn"]), o.st()), "bgemm_softmax_bwd")
-        # dQ = dS K ; dK = dS^T Q
-        o.bgemm(dp, qkv[:, H:], dqkv, M=S, N=d, K=S, sAm=S, sAk=1, sBk=3 * H, sBn=1, ldc=3 * H, sB1=S * 3 * H, sB2=d,
-                sC1=S * 3 * H, sC2=d, **bat, **sP)
-        o.bgemm(dp, qkv, dqkv[:, H:], M=S, N=d, K=S, sAm=1, sAk=S, sBk=3 * H, sBn=1, ldc=3 * H, sB1=S * 3 * H, sB2=d,
-                sC1=S * 3 * H, sC2=d, **bat, **sP)
+        if t["lse"] is not None:  # recomputing backward: P, dP, dS live in registers only
+            o.ck(o.lib.fs2_op_attention_bwd(o.dt, _p(qkv), _p(dattn), _p(t["lse"]), _p(delta), _p(t["key_pad"]), _p(dqkv), B, S, H, heads,
+                                            C.c_float(pd), C.c_uint64(o.seed), C.c_uint64(t["k_attn"]), o.st()), "attention_bwd")
+        else:
+            bat = dict(nb1=B, nb2=heads)
+            sP = dict(sA1=heads * S * S, sA2=S * S)
+            # dV = dropout(P)^T dO
+            o.bgemm(t["prob_d"], dattn, dqkv[:, 2 * H:], M=S, N=d, K=S, sAm=1, sAk=S, sBk=H, sBn=1, ldc=3 * H, sB1=S * H, sB2=d,
+                    sC1=S * 3 * H, sC2=d, **bat, **sP)
+            # dS = P o (dropout(dO V^T) - delta) / sqrt(d) in the product's epilogue: no dP tensor, no softmax-backward pass
+            dp = o.act(B, heads, S, S)
+            dsc = _lib.BGemmDescC()
+            for k_, v_ in dict(M=S, N=S, K=d, sAm=H, sAk=1, sBk=1, sBn=3 * H, ldc=S, sA1=S * H, sA2=d, sB1=S * 3 * H, sB2=d,
+                               sC1=heads * S * S, sC2=S * S, alpha=t["scale"], beta=0.0, splitk=1, taps=1, nb1=B, nb2=heads,
+                               c_dtype=o.dt).items():
+                setattr(dsc, k_, v_)
+            o.ck(o.lib.fs2_op_bgemm_softmax_bwd(o.dt, C.byref(dsc), _p(dattn), _p(qkv[:, 2 * H:]), _p(dp), _p(prob), _p(delta),
+                                                C.c_float(pd), C.c_uint64(o.seed), C.c_uint64(t["k_attn"]), o.st()), "bgemm_softmax_bwd")
+            # dQ = dS K ; dK = dS^T Q
+            o.bgemm(dp, qkv[:, H:], dqkv, M=S, N=d, K=S, sAm=S, sAk=1, sBk=3 * H, sBn=1, ldc=3 * H, sB1=S * 3 * H, sB2=d,
+                    sC1=S * 3 * H, sC2=d, **bat, **sP)
+            o.bgemm(dp, qkv, dqkv[:, H:], M=S, N=d, K=S, sAm=1, sAk=S, sBk=3 * H, sBn=1, ldc=3 * H, sB1=S * 3 * H, sB2=d,
+                    sC1=S * 3 * H, sC2=d, **bat, **sP)
         o.wgrad(dqkv, t["x"], G[f"{prefix}.self_attn.in_proj_weight"], G[f"{prefix}.self_attn.in_proj_bias"], M, 3 * H, H)
         o.dgrad(dqkv, W[f"{prefix}.self_attn.in_proj_weight"], M, 3 * H, H, out=dx, accumulate=True, wt=self._wt(f"{prefix}.self_attn.in_proj_weight"))
         return dx

@@ -456,3 +456,57 @@ def test_fused_softmax_backward_epilogue(dtype, drop):
     _lib.check(lib.fs2_op_bgemm_softmax_bwd(dt, C.byref(dsc), p(dod), p(qkvd[:, 2 * H:]), p(ds), p(Pd), p(delta), C.c_float(drop),
                                             C.c_uint64(seed), C.c_uint64(key), st()))
     close(ds, scores.grad / d ** 0.5, 2e-2 if bf else 3e-5)  # gradient of the RAW product Q K^T (what dQ = dS K and dK = dS^T Q consume)
+
+
+@pytest.mark.parametrize("B,S,heads,drop", [(2, 150, 2, 0.0), (3, 64, 1, 0.0), (2, 200, 2, 0.2), (1, 37, 2, 0.0)])
+def test_flash_attention_training_forward_and_backward(B, S, heads, drop):
+    """The fused attention on the training path: output + lse2 (+ attention-weight dropout) and the recomputing backward
+    (dQ, dK, dV with neither P nor dP in HBM), against autograd of softmax(q k^T / sqrt(d) + key padding) -> dropout -> @ v
+    in float64 on the same bf16 inputs, with the mask the dropout op regenerates."""
+    lib = _lib.load()
+    d = 128
+    H = heads * d
+    g = torch.Generator().manual_seed(S + heads)
+    qkv = (0.5 * torch.randn(B * S, 3 * H, generator=g)).to(torch.bfloat16)
+    lens = torch.randint(max(1, S // 2), S + 1, (B,), generator=g)
+    lens[0] = S
+    pad = torch.arange(S)[None, :] >= lens[:, None]
+    q, k, v = (t.double().view(B, S, heads, d).transpose(1, 2) for t in qkv.view(B, S, 3 * H).split(H, dim=-1))
+    q = q.clone().requires_grad_(True); k = k.clone().requires_grad_(True); v = v.clone().requires_grad_(True)
+    scores = (q @ k.transpose(-1, -2) / d ** 0.5).masked_fill(pad[:, None, None, :], float("-inf"))
+    P = torch.softmax(scores, dim=-1)
+    seed, key = 123, 7
+    if drop > 0:
+        ones = torch.ones(B, heads, S, S, device=DEV)
+        m = torch.empty_like(ones)
+        _lib.check(lib.fs2_op_dropout(F32, p(ones), p(m), ones.numel(), C.c_float(drop), C.c_uint64(seed), C.c_uint64(key), st()))
+        mask = m.cpu().double()
+    else:
+        mask = torch.ones(B, heads, S, S, dtype=torch.float64)
+    out = ((P * mask) @ v).transpose(1, 2).reshape(B * S, H)
+    dout = torch.randn(B * S, H, generator=g).to(torch.bfloat16)
+    out.backward(dout.double())
+    # forward
+    qd, padd = qkv.to(DEV), pad.to(torch.uint8).to(DEV)
+    od = torch.empty(B * S, H, device=DEV, dtype=torch.bfloat16)
+    bb = C.c_size_t()
+    vb = lib.fs2_op_attention_scratch_bytes(BF, B, S, H, heads, C.byref(bb))
+    vt, bits = torch.empty(vb, dtype=torch.uint8, device=DEV), torch.empty(bb.value, dtype=torch.uint8, device=DEV)
+    lse = torch.empty(B, heads, S, device=DEV)
+    _lib.check(lib.fs2_op_attention_train(BF, p(qd), p(padd), p(od), p(vt), p(bits), p(lse), B, S, H, heads, C.c_float(drop),
+                                          C.c_uint64(seed), C.c_uint64(key), st()))
+    close(od, out.detach(), 2e-2)
+    want_lse = torch.logsumexp(scores.detach(), dim=-1) / np.log(2.0)
+    assert float((lse.cpu().double() - want_lse).abs().max()) <= 2e-2
+    # backward
+    assert lib.fs2_op_attention_bwd_supported(BF, H, heads) == 1
+    dod = dout.to(DEV)
+    delta = torch.empty(B, heads, S, device=DEV)
+    _lib.check(lib.fs2_op_attn_delta(BF, p(dod), p(od), p(delta), B, S, H, heads, st()))
+    dqkv = torch.full((B * S, 3 * H), float("nan"), device=DEV, dtype=torch.bfloat16)
+    _lib.check(lib.fs2_op_attention_bwd(BF, p(qd), p(dod), p(lse), p(delta), p(padd), p(dqkv), B, S, H, heads, C.c_float(drop),
+                                        C.c_uint64(seed), C.c_uint64(key), st()))
+    want = torch.cat([t.grad.transpose(1, 2).reshape(B * S, H) for t in (q, k, v)], dim=1)
+    assert bool(torch.isfinite(dqkv.float()).all())
+    for name, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
+        close(dqkv[:, sl], want[:, sl], 3e-2)
