@@ -34,13 +34,20 @@ __device__ inline s16x4_t pack4(const float* f) {
 }
 __device__ inline f32x4_t mma16(s16x4_t a, s16x4_t b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
 
-// 64 rows x 128 columns of a (rows, ld) bf16 matrix -> LDS tile, rows >= nrows zero
-__device__ inline void load_tile(unsigned short* s, const unsigned short* g, long ld, int row0, int nrows) {
+// 64 rows x 128 columns of a (rows, ld) bf16 matrix: global -> registers (issued a whole block ahead of its use) -> LDS tile;
+// rows >= nrows are zero
+__device__ inline void fetch_tile(uint4 (&x)[4], const unsigned short* g, long ld, int row0, int nrows) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int v = threadIdx.x + 256 * i, r = v >> 4, c = (v & 15) * 8;
-        const uint4 x = row0 + r < nrows ? *(const uint4*)(g + (long)(row0 + r) * ld + c) : make_uint4(0, 0, 0, 0);
-        *(uint4*)(s + r * LDT + c) = x;
+        x[i] = row0 + r < nrows ? *(const uint4*)(g + (long)(row0 + r) * ld + c) : make_uint4(0, 0, 0, 0);
+    }
+}
+__device__ inline void stash_tile(unsigned short* s, const uint4 (&x)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int v = threadIdx.x + 256 * i;
+        *(uint4*)(s + (v >> 4) * LDT + (v & 15) * 8) = x[i];
     }
 }
 // this lane's four 16-byte fragments (k = ks*32 + fg*8 .. +7) of row `row` of a (rows, ld) matrix, zero past nrows
@@ -71,16 +78,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
     const uint32_t thr = (uint32_t)(p.drop_p * 16777216.0f);
     const float dsc = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
 
+    uint4 xq[4], xo[4];
+    float xl = 0.f, xd = 0.f;
+    fetch_tile(xq, Q, ldq, 0, p.S);
+    fetch_tile(xo, dO, p.H, 0, p.S);
+    if (tid < TB) { xl = tid < p.S ? lse[tid] : 0.f; xd = tid < p.S ? dl[tid] : 0.f; }
     for (int q0 = 0; q0 < p.S; q0 += TB) {
         __syncthreads();  // everyone is done with the previous tiles
-        load_tile(sQ, Q, ldq, q0, p.S);
-        load_tile(sO, dO, p.H, q0, p.S);
-        if (tid < TB) {
-            sL[tid] = q0 + tid < p.S ? lse[q0 + tid] : 0.f;
-            sD[tid] = q0 + tid < p.S ? dl[q0 + tid] : 0.f;
-        }
+        stash_tile(sQ, xq);
+        stash_tile(sO, xo);
+        if (tid < TB) { sL[tid] = xl; sD[tid] = xd; }
         __syncthreads();
-#pragma unroll 1
+        if (q0 + TB < p.S) {  // the next block's loads fly while this one is computed
+            fetch_tile(xq, Q, ldq, q0 + TB, p.S);
+            fetch_tile(xo, dO, p.H, q0 + TB, p.S);
+            if (tid < TB) { xl = q0 + TB + tid < p.S ? lse[q0 + TB + tid] : 0.f; xd = q0 + TB + tid < p.S ? dl[q0 + TB + tid] : 0.f; }
+        }
+#pragma unroll 1  // unrolling by 2 costs 24 VGPRs and a wave per SIMD: 323 -> 515 us
         for (int qs = 0; qs < 4; ++qs) {
             f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -151,13 +165,23 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs p) {
     const uint32_t thr = (uint32_t)(p.drop_p * 16777216.0f);
     const float dsc = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
 
+    uint4 xk[4], xv[4];
+    unsigned char xok = 0;
+    fetch_tile(xk, Q + p.H, ldq, 0, p.S);
+    fetch_tile(xv, Q + 2 * p.H, ldq, 0, p.S);
+    if (tid < TB) xok = (tid < p.S && !(p.key_pad && p.key_pad[(long)b * p.S + tid])) ? 1 : 0;
     for (int k0 = 0; k0 < p.S; k0 += TB) {
         __syncthreads();
-        load_tile(sK, Q + p.H, ldq, k0, p.S);
-        load_tile(sV, Q + 2 * p.H, ldq, k0, p.S);
-        if (tid < TB) sOk[tid] = (k0 + tid < p.S && !(p.key_pad && p.key_pad[(long)b * p.S + k0 + tid])) ? 1 : 0;
+        stash_tile(sK, xk);
+        stash_tile(sV, xv);
+        if (tid < TB) sOk[tid] = xok;
         __syncthreads();
-#pragma unroll 1
+        if (k0 + TB < p.S) {
+            fetch_tile(xk, Q + p.H, ldq, k0 + TB, p.S);
+            fetch_tile(xv, Q + 2 * p.H, ldq, k0 + TB, p.S);
+            if (tid < TB) xok = (k0 + TB + tid < p.S && !(p.key_pad && p.key_pad[(long)b * p.S + k0 + TB + tid])) ? 1 : 0;
+        }
+#pragma unroll 2
         for (int ks4 = 0; ks4 < 4; ++ks4) {
             f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
