@@ -304,10 +304,10 @@ __device__ inline uint4 load8(const unsigned short* src, bool vec, int nvalid) {
 }
 
 // R = rows of the operand's outer index in the tile (128, or 256 for the A side of the 256-row tile)
-template <int R>
+template <int R, bool KC>
 __device__ inline void load_tile_h(const OperandH& o, int k0, int Kend, uint4 (&r)[R / 64]) {
     const int tid = threadIdx.x;
-    if (o.s_k == 1) {  // k-contiguous: (row, 8-k chunk)
+    if (KC) {  // k-contiguous: (row, 8-k chunk)
 #pragma unroll
         for (int i = 0; i < R / 64; ++i) {
             const int v = tid + 256 * i, mn = v >> 2, gk = k0 + (v & 3) * 8;
@@ -361,7 +361,7 @@ __device__ inline void store_tile_h(unsigned short* s, bool kc, const uint4 (&r)
 // k-tile to the next (the thread's rows / columns, their bounds, the 64-bit addresses) is worked out once; a step is a
 // pointer bump, a compare and the 16-byte load.  (The generic loader above spends ~10x the MFMA issue slots of a k-step on
 // address arithmetic - integer modulo, 64-bit multiplies - and made the kernel VALU-bound.)
-template <int R>
+template <int R, bool KC>
 struct TileCursor {
     static constexpr int NV = R / 64;
     const unsigned short* ptr[NV];
@@ -369,13 +369,14 @@ struct TileCursor {
     int pos[NV];       // outer-contiguous + seg: gk % seg
     int nmn[NV];       // valid elements along the vector's own direction that do not depend on k (outer-contiguous: MN - gmn)
     bool ok[NV];
-    bool kc, vec;
+    static constexpr bool kc = KC;
+    bool vec;
     int seg, shift, Kend;
     long step;
 
     __device__ inline void init(const OperandH& o, int k0, int Kend_) {
         const int tid = threadIdx.x;
-        kc = o.s_k == 1; vec = o.vec; seg = o.seg; shift = o.shift_k; Kend = Kend_;
+        vec = o.vec; seg = o.seg; shift = o.shift_k; Kend = Kend_;
         step = kc ? HBK : (long)HBK * o.s_k;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -403,6 +404,21 @@ struct TileCursor {
             bool v = ok[i] && gk[i] < Kend;
             if (!kc && seg) v = v && (unsigned)(pos[i] + shift) < (unsigned)seg;
             r[i] = v ? load8(ptr[i], vec, kc ? Kend - gk[i] : nmn[i]) : make_uint4(0, 0, 0, 0);
+        }
+    }
+    // full tiles of an aligned operand: unconditional 16-byte loads (no per-lane branch may sit around a load - hipcc waits
+    // for it where the branch ends, i.e. before the MFMAs); a k row of another utterance (wgrad form) is read from a safe
+    // address and zeroed by a select
+    __device__ inline void load_full(uint4 (&r)[NV], const unsigned short* safe) const {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if (!kc && seg) {
+                const bool v = (unsigned)(pos[i] + shift) < (unsigned)seg;
+                const uint4 x = *(const uint4*)(v ? ptr[i] : safe);
+                r[i] = v ? x : make_uint4(0, 0, 0, 0);
+            } else {
+                r[i] = *(const uint4*)ptr[i];
+            }
         }
     }
     __device__ inline void next() {
@@ -437,7 +453,11 @@ __device__ inline uint4 frag_h(const unsigned short* s, bool kc, int mn0, int fr
 
 // WM = 16-row fragments per wave along m: 4 -> the 128 x 128 tile in use (4 waves as 2 x 2, a wave owns 64 x 64).  WM = 8
 // (256 x 128) was measured slower on every training shape - it drops the kernel to 1-2 waves per SIMD - and is not built.
-template <typename OutT, int WM>
+// AKC / BKC: the operand is k-contiguous in memory (compile time: with run-time flags hipcc put a branch and a full
+// s_waitcnt lgkmcnt(0) around every fragment read - eight serialised LDS round trips per k-step)
+// FULL: M % tile == 0, N % 128 == 0, K % 32 == 0, aligned operands, plain form (taps <= 1): the loop then holds no bounds
+// logic and no scalar fallback at all (the generic instantiation carries ~100 exec-mask branches and its SGPR spills).
+template <typename OutT, int WM, bool AKC, bool BKC, bool FULL>
 __global__ __launch_bounds__(256, 3) void bgemm_bf16_kernel(const BGemmArgs p) {
     constexpr int BMT = WM * 32;
     constexpr int ASZ = BMT * HLD > HBK * (BMT + 16) ? BMT * HLD : HBK * (BMT + 16);
@@ -475,7 +495,7 @@ __global__ __launch_bounds__(256, 3) void bgemm_bf16_kernel(const BGemmArgs p) {
         B.seg = p.seg;
         B.shift_k = p.b_shift0 + b2 * p.b_shift_step;
     }
-    const bool akc = A.s_k == 1, bkc = B.s_k == 1;
+    constexpr bool akc = AKC, bkc = BKC;
     const int Kin = p.taps > 1 ? p.Kin : p.K;
     const int tiles_per_tap = (Kin + HBK - 1) / HBK;
     const int ntiles = tiles_per_tap * (p.taps > 1 ? p.taps : 1);
@@ -501,8 +521,8 @@ __global__ __launch_bounds__(256, 3) void bgemm_bf16_kernel(const BGemmArgs p) {
             A.p = Ap0;
             B.p = Bp0 + tap * p.sBtap;
         }
-        load_tile_h<BMT>(A, k0, kend, ra);
-        load_tile_h<128>(B, k0, kend, rb);
+        load_tile_h<BMT, AKC>(A, k0, kend, ra);
+        load_tile_h<128, BKC>(B, k0, kend, rb);
     };
 
     auto compute = [&](int cur) {
@@ -519,15 +539,18 @@ __global__ __launch_bounds__(256, 3) void bgemm_bf16_kernel(const BGemmArgs p) {
         }
     };
     uint4 ra[BMT / 64], rb[2];
-    const bool plain = p.taps <= 1;  // wave-uniform: cursors for the plain forms, the generic loader for the implicit-conv dgrad
-    TileCursor<BMT> ca;
-    TileCursor<128> cb;
+    const bool plain = FULL || p.taps <= 1;  // wave-uniform: cursors for the plain forms, the generic loader for the implicit-conv dgrad
+    TileCursor<BMT, AKC> ca;
+    TileCursor<128, BKC> cb;
     if (plain) {
         ca.init(A, t_begin * HBK, p.K);
         cb.init(B, t_begin * HBK, p.K);
     }
+    const unsigned short* safeB = (const unsigned short*)p.B;
     if (t_begin < t_end) {
-        if (plain) { ca.load(ra); cb.load(rb); } else fetch(t_begin, ra, rb);
+        if constexpr (FULL) { ca.load_full(ra, safeB); cb.load_full(rb, safeB); }
+        else if (plain) { ca.load(ra); cb.load(rb); }
+        else fetch(t_begin, ra, rb);
         store_tile_h<BMT>(lds[0], akc, ra);
         store_tile_h<128>(lds[0] + ASZ, bkc, rb);
     }
@@ -536,7 +559,9 @@ __global__ __launch_bounds__(256, 3) void bgemm_bf16_kernel(const BGemmArgs p) {
         const int cur = (t - t_begin) & 1;
         const bool more = t + 1 < t_end;
         if (more) {
-            if (plain) { ca.next(); cb.next(); ca.load(ra); cb.load(rb); } else fetch(t + 1, ra, rb);
+            if constexpr (FULL) { ca.next(); cb.next(); ca.load_full(ra, safeB); cb.load_full(rb, safeB); }
+            else if (plain) { ca.next(); cb.next(); ca.load(ra); cb.load(rb); }
+            else fetch(t + 1, ra, rb);
         }
         compute(cur);
         if (more) {
@@ -650,6 +675,7 @@ inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
 
+int g_bgemm_full = 1;  // A/B knob: the bounds-free instantiation for full, aligned tiles
 int g_bgemm_xcd = 1;   // A/B knob: XCD-contiguous tile order of the bf16 kernel
 
 size_t bgemm_ws_bytes(const BGemmArgs& a) {
@@ -680,12 +706,29 @@ int launch_bgemm(const BGemmArgs& a0, int dtype, hipStream_t stream) {
     if (dtype == FS2_F32) {
         hipLaunchKernelGGL(bgemm_f32_kernel, grid, dim3(256), 0, stream, a);
         if (splitk > 1) hipLaunchKernelGGL(bgemm_reduce_kernel, g2, dim3(256), 0, stream, a);
-    } else if (a.c_dtype == FS2_F32) {
-        hipLaunchKernelGGL((bgemm_bf16_kernel<float, 4>), grid, dim3(256), 0, stream, a);
-        if (splitk > 1) hipLaunchKernelGGL(bgemm_reduce_t_kernel<float>, g2, dim3(256), 0, stream, a);
     } else {
-        hipLaunchKernelGGL((bgemm_bf16_kernel<bf16, 4>), grid, dim3(256), 0, stream, a);
-        if (splitk > 1) hipLaunchKernelGGL(bgemm_reduce_t_kernel<bf16>, g2, dim3(256), 0, stream, a);
+        const bool akc = a.sAk == 1, bkc = a.sBk == 1;
+        // (measured: a win for the TN products - weight gradients, dV, dK: conv1 wgrad 377 -> 350 us, conv2 wgrad 86 -> 67 - and a
+        // loss with a k-contiguous A - P V 87 -> 136 us - where the fourth wave per SIMD only adds LDS pressure: TN only)
+        const bool full = g_bgemm_full && !akc && a.M % BM == 0 && a.N % BN == 0 && a.K % HBK == 0 && a.vecA && a.vecB && a.taps <= 1 &&
+                          (a.seg == 0 || (a.seg >= HBK && !bkc));
+#define FS2_BG2(OT, FL) \
+        do { \
+            if (akc && bkc) hipLaunchKernelGGL((bgemm_bf16_kernel<OT, 4, true, true, FL>), grid, dim3(256), 0, stream, a); \
+            else if (akc) hipLaunchKernelGGL((bgemm_bf16_kernel<OT, 4, true, false, FL>), grid, dim3(256), 0, stream, a); \
+            else if (bkc) hipLaunchKernelGGL((bgemm_bf16_kernel<OT, 4, false, true, FL>), grid, dim3(256), 0, stream, a); \
+            else hipLaunchKernelGGL((bgemm_bf16_kernel<OT, 4, false, false, FL>), grid, dim3(256), 0, stream, a); \
+        } while (0)
+#define FS2_BG(OT) do { if (full) FS2_BG2(OT, true); else FS2_BG2(OT, false); } while (0)
+        if (a.c_dtype == FS2_F32) {
+            FS2_BG(float);
+            if (splitk > 1) hipLaunchKernelGGL(bgemm_reduce_t_kernel<float>, g2, dim3(256), 0, stream, a);
+        } else {
+            FS2_BG(bf16);
+            if (splitk > 1) hipLaunchKernelGGL(bgemm_reduce_t_kernel<bf16>, g2, dim3(256), 0, stream, a);
+        }
+#undef FS2_BG
+#undef FS2_BG2
     }
     return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
 }

@@ -321,6 +321,7 @@ struct BGemmArgs {
 };
 size_t bgemm_ws_bytes(const BGemmArgs& a);
 extern int g_bgemm_xcd;
+extern int g_bgemm_full;
 int launch_bgemm(const BGemmArgs& a, int dtype, hipStream_t stream);
 
 // Row / column kernels of the backward (backward.hip).  T = activation dtype; gradients of parameters are fp32.

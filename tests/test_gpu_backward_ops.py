@@ -510,3 +510,30 @@ def test_flash_attention_training_forward_and_backward(B, S, heads, drop):
     assert bool(torch.isfinite(dqkv.float()).all())
     for name, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
         close(dqkv[:, sl], want[:, sl], 3e-2)
+
+
+@pytest.mark.parametrize("M,N,K,splitk", [(256, 128, 64, 1), (128, 256, 320, 3), (384, 128, 4096, 8)])
+def test_bgemm_bf16_full_tile_instantiation(M, N, K, splitk):
+    """Shapes that take the bounds-free instantiation (full 128 x 128 x 32 tiles, aligned operands): all four layouts, plus the
+    weight-gradient form with utterance boundaries, against float64."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a, b = _bf(torch.randn(M, K, generator=g)), _bf(torch.randn(K, N, generator=g))
+    want = a.double() @ b.double()
+    for akc in (True, False):
+        for bkc in (True, False):
+            A = (a if akc else a.t().contiguous()).to(DEV)
+            Bm = (b.t().contiguous() if bkc else b).to(DEV)
+            c = torch.empty(M, N, device=DEV)
+            bgemm(dict(M=M, N=N, K=K, sAm=K if akc else 1, sAk=1 if akc else M, sBk=1 if bkc else N, sBn=K if bkc else 1, ldc=N,
+                       splitk=splitk), A, Bm, c, dtype=BF)
+            close(c, want, 1e-5)
+    taps, Cin, Nn, S, B = 5, 128, 128, 64, 4  # wgrad form on full tiles: K = B*S = 256
+    x = _bf(torch.randn(B, S, Cin, generator=g)).double().requires_grad_(True)
+    w = _bf(torch.randn(Nn, Cin, taps, generator=g)).double().requires_grad_(True)
+    dy = _bf(torch.randn(B, S, Nn, generator=g)).double()
+    F.conv1d(x.transpose(1, 2), w, padding="same").transpose(1, 2).backward(dy)
+    dyd, xd = _bf(dy.reshape(B * S, Nn)).contiguous().to(DEV), _bf(x.detach().reshape(B * S, Cin)).contiguous().to(DEV)
+    dw = torch.zeros(Nn, taps * Cin, device=DEV)
+    bgemm(dict(M=Nn, N=Cin, K=B * S, sAm=1, sAk=Nn, sBk=Cin, sBn=1, ldc=taps * Cin, nb2=taps, sC2=Cin, seg=S, b_shift0=-2, b_shift_step=1,
+               splitk=2), dyd, xd, dw, dtype=BF)
+    close(dw, w.grad.permute(0, 2, 1).reshape(Nn, taps * Cin), 1e-5)

@@ -225,7 +225,10 @@ def main():
                 gemm_ln_case("c5 pred conv k=3 +relu+LN", 12288, 1024, 1024, 3, 1536, a.reps, v, res=False, relu=True)
         lib.fs2_op_set_gemm_variant(301)
     if a.what in ("bwd",):
-        bwd_cases(a.reps)
+        for knob in (800, 801):
+            print("---- bf16 bgemm:", "generic instantiation" if knob == 800 else "bounds-free instantiation for full tiles")
+            lib.fs2_op_set_gemm_variant(knob)
+            bwd_cases(a.reps)
     if a.what in ("pred", "all"):
         predictor_case("variance predictor fused", 32, 1536, 5, a.reps)
         predictor_case("duration predictor fused", 32, 256, 2, a.reps)
