@@ -7,5 +7,5 @@ timeout 900 python $R/tools/bench_train.py --config $CFG --batch $B "$@" > $O/${
 rm -rf $O/proft_$CFG
 timeout 900 rocprofv3 --kernel-trace --stats -d $O/proft_$CFG -o p -- python $R/tools/bench_train.py --config $CFG --batch $B --steps 2 --warmup 1 "$@" > /dev/null 2> $O/${TAG}_train_${CFG}_prof.err
 DB=$(find $O/proft_$CFG -name '*results.db' | head -1)
-python $R/tools/rocpd_stats.py $DB "$TAG training step $CFG B=$B $* (3 steps: forward + loss + backward + AdamW)" > $O/${TAG}_train_${CFG}_kernel_stats.md
+python $R/tools/rocpd_stats.py $DB "$TAG training step $CFG B=$B $* (warm-up + timed steps of the command; forward + loss + backward + AdamW)" > $O/${TAG}_train_${CFG}_kernel_stats.md
 find $O/proft_$CFG -name '*.db' -delete
