@@ -192,7 +192,7 @@ class _Ops:
         """dw (N, taps*Cin) += dy^T x (per tap, rows shifted inside their utterance); db (N) += column sums of dy."""
         pad = (taps - 1) // 2
         tiles = ((N + 127) // 128) * ((Cin + 127) // 128) * taps
-        splitk = max(1, min(64, 512 // tiles, M // 2048))
+        splitk = max(1, min(32, -(-2304 // tiles), M // 1024))  # ~9 workgroups per CU (measured: conv1 16, conv2 / in-proj 32)
         self.bgemm(dy, x, dw, M=N, N=Cin, K=M, sAm=1, sAk=N, sBk=Cin, sBn=1, ldc=taps * Cin, nb2=taps, sC2=Cin,
                    seg=(S or M) if taps > 1 else 0, b_shift0=-pad, b_shift_step=1, splitk=splitk, beta=1.0)
         if db is not None:

@@ -107,7 +107,7 @@ def bwd_cases(reps):
     bgemm_case("conv1 k=9 dgrad (M,1024)->(M,256)", M * H * k * F, dy, w, dx, reps, M=M, N=H, K=k * F, sAm=F, sAk=1, sBk=k * H, sBn=1,
                ldc=H, seg=1536, taps=k, Kin=F, a_shift0=4, a_shift_step=-1, sBtap=H)
     dw = torch.zeros(F, k * H, device=DEV)
-    for sk in (1, 4, 16):
+    for sk in (1, 4, 8, 16, 32):
         bgemm_case(f"conv1 k=9 wgrad_splitk={sk}", M * H * k * F, dy, x, dw, reps, M=F, N=H, K=M, sAm=1, sAk=F, sBk=H, sBn=1, ldc=k * H,
                    nb2=k, sC2=H, seg=1536, b_shift0=-4, b_shift_step=1, splitk=sk, beta=1.0)
     dy2 = torch.randn(M, H, device=DEV).to(bf)
@@ -115,7 +115,13 @@ def bwd_cases(reps):
     dh = torch.empty(M, F, device=DEV, dtype=bf)
     bgemm_case("conv2 1x1 dgrad (M,256)->(M,1024)", M * H * F, dy2, w2, dh, reps, M=M, N=F, K=H, sAm=H, sAk=1, sBk=F, sBn=1, ldc=F)
     dw2 = torch.zeros(H, F, device=DEV)
-    bgemm_case("conv2 1x1 wgrad splitk=16", M * H * F, dy2, dy, dw2, reps, M=H, N=F, K=M, sAm=1, sAk=H, sBk=F, sBn=1, ldc=F, splitk=16, beta=1.0)
+    for sk in (16, 32, 64):
+        bgemm_case(f"conv2 1x1 wgrad splitk={sk}", M * H * F, dy2, dy, dw2, reps, M=H, N=F, K=M, sAm=1, sAk=H, sBk=F, sBn=1, ldc=F, splitk=sk, beta=1.0)
+    x3 = torch.randn(M, H, device=DEV).to(bf)
+    dw3 = torch.zeros(3 * H, H, device=DEV)
+    dy3 = torch.randn(M, 3 * H, device=DEV).to(bf)
+    for sk in (8, 32, 64):
+        bgemm_case(f"in_proj wgrad splitk={sk}", M * H * 3 * H, dy3, x3, dw3, reps, M=3 * H, N=H, K=M, sAm=1, sAk=3 * H, sBk=H, sBn=1, ldc=H, splitk=sk, beta=1.0)
     B, S, heads, d = 32, 1536, 2, 128
     qkv = torch.randn(B * S, 3 * H, device=DEV).to(bf)
     sc = torch.empty(B, heads, S, S, device=DEV)
@@ -225,10 +231,7 @@ def main():
                 gemm_ln_case("c5 pred conv k=3 +relu+LN", 12288, 1024, 1024, 3, 1536, a.reps, v, res=False, relu=True)
         lib.fs2_op_set_gemm_variant(301)
     if a.what in ("bwd",):
-        for knob in (800, 801):
-            print("---- bf16 bgemm:", "generic instantiation" if knob == 800 else "bounds-free instantiation for full tiles")
-            lib.fs2_op_set_gemm_variant(knob)
-            bwd_cases(a.reps)
+        bwd_cases(a.reps)
     if a.what in ("pred", "all"):
         predictor_case("variance predictor fused", 32, 1536, 5, a.reps)
         predictor_case("duration predictor fused", 32, 256, 2, a.reps)
