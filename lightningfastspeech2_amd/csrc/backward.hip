@@ -301,6 +301,28 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(SoftmaxArgs p) {
     for (int k = lane; k < p.S; k += 64) out[k] = Num<T>::from_f32(p.scale * Num<T>::to_f32(pr[k]) * (d[k] - dot));
 }
 
+// 16 bytes per thread and operand when everything is 16-byte aligned (the activation tensors are); scalar tail / fallback
+template <typename T>
+__global__ void ew_vec_kernel(EwArgs p) {
+    constexpr int NE = Vec16<T>::N;
+    const size_t nv = p.n / NE;
+    const uint4* a = (const uint4*)p.a;
+    const uint4* b = (const uint4*)p.b;
+    uint4* out = (uint4*)p.out;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < nv; e += (size_t)gridDim.x * blockDim.x) {
+        float fa[NE], fb[NE];
+        Vec16<T>::unpack(a[e], fa);
+        if (b) Vec16<T>::unpack(b[e], fb);
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            if (p.op == 0) fa[i] = p.alpha * fa[i] + (b ? p.beta * fb[i] : 0.f);
+            else if (p.op == 1) fa[i] = fb[i] > 0.f ? fa[i] : 0.f;
+            else fa[i] = p.alpha * fa[i];
+        }
+        out[e] = Vec16<T>::pack(fa);
+    }
+}
+
 template <typename T>
 __global__ void ew_kernel(EwArgs p) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -732,8 +754,24 @@ int launch_softmax_bwd(const SoftmaxArgs& a, int dtype, hipStream_t stream) {
     return ok();
 }
 
-int launch_ew(const EwArgs& a, int dtype, hipStream_t stream) {
-    if (!a.n) return FS2_OK;
+int launch_ew(const EwArgs& a0, int dtype, hipStream_t stream) {
+    if (!a0.n) return FS2_OK;
+    EwArgs a = a0;
+    const size_t ne = dtype == FS2_BF16 ? 8 : 4, esz = dtype == FS2_BF16 ? 2 : 4;
+    const bool al = (((uintptr_t)a.a | (uintptr_t)a.b | (uintptr_t)a.out) & 15) == 0;
+    if (al && a.n >= ne) {
+        EwArgs v = a;
+        v.n = a.n / ne * ne;
+        size_t blocks = (v.n / ne + 255) / 256;
+        if (blocks > 8192) blocks = 8192;
+        if (dtype == FS2_BF16) hipLaunchKernelGGL(ew_vec_kernel<bf16>, dim3((unsigned)blocks), dim3(256), 0, stream, v);
+        else hipLaunchKernelGGL(ew_vec_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, v);
+        a.a = (const char*)a.a + v.n * esz;
+        if (a.b) a.b = (const char*)a.b + v.n * esz;
+        a.out = (char*)a.out + v.n * esz;
+        a.n -= v.n;
+        if (!a.n) return ok();
+    }
     size_t blocks = (a.n + 1023) / 1024;
     if (blocks > 4096) blocks = 4096;
     if (dtype == FS2_BF16) hipLaunchKernelGGL(ew_kernel<bf16>, dim3((unsigned)blocks), dim3(256), 0, stream, a);

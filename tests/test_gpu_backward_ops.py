@@ -255,13 +255,20 @@ def test_adamw_matches_torch_with_clipping():
 
 def test_ew_ops():
     lib = _lib.load()
-    a, b = torch.randn(5000), torch.randn(5000)
+    a, b = torch.randn(5003), torch.randn(5003)  # vector body + scalar tail
+    a, b = a[:5000], b[:5000]
     out = torch.empty(5000, device=DEV)
     ad, bd = a.to(DEV), b.to(DEV)
     _lib.check(lib.fs2_op_ew(F32, 0, p(ad), p(bd), p(out), 5000, 2.0, -1.0, st()))
     assert torch.equal(out.cpu(), 2.0 * a - b)
     _lib.check(lib.fs2_op_ew(F32, 1, p(ad), p(bd), p(out), 5000, 0.0, 0.0, st()))
     assert torch.equal(out.cpu(), torch.where(b > 0, a, torch.zeros(())))
+    n = 4099  # odd length: body of 4096 + tail of 3; and an unaligned view (scalar path only)
+    ad, bd, out = torch.randn(n + 1, device=DEV), torch.randn(n + 1, device=DEV), torch.empty(n + 1, device=DEV)
+    _lib.check(lib.fs2_op_ew(F32, 0, p(ad), p(bd), p(out), n, 1.5, 0.5, st()))
+    assert torch.allclose(out[:n].cpu(), (1.5 * ad[:n] + 0.5 * bd[:n]).cpu(), rtol=1e-6, atol=1e-6)  # fma vs two roundings
+    _lib.check(lib.fs2_op_ew(F32, 1, p(ad[1:]), p(bd[1:]), p(out[1:]), n, 0.0, 0.0, st()))
+    assert torch.equal(out[1:].cpu(), torch.where(bd[1:] > 0, ad[1:], torch.zeros((), device=DEV)).cpu())
 
 
 # ---- bf16 operands (the mixed-precision training path): same products, inputs rounded to bf16, fp32 accumulation ----
