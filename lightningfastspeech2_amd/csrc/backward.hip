@@ -547,48 +547,64 @@ __global__ __launch_bounds__(256) void transpose_weight_kernel(TransposeWeightAr
 // Workgroup = DWG_R rows x 64 channels of one utterance: dy tile and the (DWG_R + k - 1)-row x slab in LDS (fp32), a thread
 // owns one channel and every 4th row and keeps all k taps (+ the bias sum) in registers; the 4 row groups meet in LDS.
 constexpr int DWG_R = 128, DWG_KMAX = 32;
-template <typename T>
+template <typename T, int KB>  // KB = taps rounded up to 4 / 8 / 16 / 32: the tap loops are unrolled to KB
 __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(DwConvWgradArgs p) {
-    __shared__ float xs[(DWG_R + DWG_KMAX - 1) * 64];
-    __shared__ float ds[DWG_R * 64];
+    __shared__ __attribute__((aligned(16))) float xs[(DWG_R + KB - 1) * 64];
+    __shared__ __attribute__((aligned(16))) float ds[DWG_R * 64];
     const int tid = threadIdx.x, c = tid & 63, g = tid >> 6;
     const int t0 = blockIdx.x * DWG_R, c0 = blockIdx.y * 64, b = blockIdx.z;
     const int nchunk = gridDim.x;
     const T* x = (const T*)p.x + (size_t)b * p.S * p.C;
     const T* dy = (const T*)p.dy + (size_t)b * p.S * p.C;
     const int rows = DWG_R + p.k - 1;
-    for (int i = tid; i < rows * 64; i += 256) {
-        const int r = i >> 6, cc = i & 63, t = t0 + r - p.pad;
-        xs[i] = (t >= 0 && t < p.S && c0 + cc < p.C) ? Num<T>::to_f32(x[(size_t)t * p.C + c0 + cc]) : 0.f;
-    }
-    for (int i = tid; i < DWG_R * 64; i += 256) {
-        const int r = i >> 6, cc = i & 63, t = t0 + r;
-        ds[i] = (t < p.S && c0 + cc < p.C) ? Num<T>::to_f32(dy[(size_t)t * p.C + c0 + cc]) : 0.f;
+    const bool quad = (p.C & 3) == 0 && c0 + 64 <= p.C;  // 8- / 16-byte loads of four channels
+    if (quad) {
+        for (int i = tid; i < rows * 16; i += 256) {
+            const int r = i >> 4, cq = (i & 15) * 4, t = t0 + r - p.pad;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (t >= 0 && t < p.S) ld4<T>(x + (size_t)t * p.C + c0 + cq, v);
+            *(float4*)(xs + r * 64 + cq) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        for (int i = tid; i < DWG_R * 16; i += 256) {
+            const int r = i >> 4, cq = (i & 15) * 4, t = t0 + r;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (t < p.S) ld4<T>(dy + (size_t)t * p.C + c0 + cq, v);
+            *(float4*)(ds + r * 64 + cq) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    } else {
+        for (int i = tid; i < rows * 64; i += 256) {
+            const int r = i >> 6, cc = i & 63, t = t0 + r - p.pad;
+            xs[i] = (t >= 0 && t < p.S && c0 + cc < p.C) ? Num<T>::to_f32(x[(size_t)t * p.C + c0 + cc]) : 0.f;
+        }
+        for (int i = tid; i < DWG_R * 64; i += 256) {
+            const int r = i >> 6, cc = i & 63, t = t0 + r;
+            ds[i] = (t < p.S && c0 + cc < p.C) ? Num<T>::to_f32(dy[(size_t)t * p.C + c0 + cc]) : 0.f;
+        }
     }
     __syncthreads();
-    float acc[DWG_KMAX + 1];
+    float acc[KB], bsum = 0.f;
 #pragma unroll
-    for (int j = 0; j <= DWG_KMAX; ++j) acc[j] = 0.f;
+    for (int j = 0; j < KB; ++j) acc[j] = 0.f;
     for (int r = g; r < DWG_R; r += 4) {
         const float d = ds[r * 64 + c];
-        acc[DWG_KMAX] += d;
+        bsum += d;
 #pragma unroll
-        for (int j = 0; j < DWG_KMAX; ++j)
+        for (int j = 0; j < KB; ++j)
             if (j < p.k) acc[j] = fmaf(d, xs[(r + j) * 64 + c], acc[j]);
     }
     __syncthreads();
-    // reduce the 4 row groups through LDS (reusing xs): [g][j][c]
+    // reduce the 4 row groups through LDS (reusing xs): [g][j][c], j = KB holds the bias sum
 #pragma unroll
-    for (int j = 0; j <= DWG_KMAX; ++j)
-        if (j < p.k || j == DWG_KMAX) xs[(g * (DWG_KMAX + 1) + j) * 64 + c] = acc[j];
+    for (int j = 0; j < KB; ++j) xs[(g * (KB + 1) + j) * 64 + c] = acc[j];
+    xs[(g * (KB + 1) + KB) * 64 + c] = bsum;
     __syncthreads();
     float* part = p.part + ((size_t)b * nchunk + blockIdx.x) * (size_t)p.C * (p.k + 1);
     for (int i = tid; i < (p.k + 1) * 64; i += 256) {
         const int j = i >> 6, cc = i & 63;
         if (c0 + cc >= p.C) continue;
-        const int jj = j < p.k ? j : DWG_KMAX;
-        const float v = (xs[(0 * (DWG_KMAX + 1) + jj) * 64 + cc] + xs[(1 * (DWG_KMAX + 1) + jj) * 64 + cc]) +
-                        (xs[(2 * (DWG_KMAX + 1) + jj) * 64 + cc] + xs[(3 * (DWG_KMAX + 1) + jj) * 64 + cc]);
+        const int jj = j < p.k ? j : KB;
+        const float v = (xs[(0 * (KB + 1) + jj) * 64 + cc] + xs[(1 * (KB + 1) + jj) * 64 + cc]) +
+                        (xs[(2 * (KB + 1) + jj) * 64 + cc] + xs[(3 * (KB + 1) + jj) * 64 + cc]);
         if (j < p.k) part[(size_t)(c0 + cc) * p.k + j] = v;
         else part[(size_t)p.C * p.k + c0 + cc] = v;
     }
@@ -604,33 +620,54 @@ __global__ void fold_conv2_kernel(FoldConv2Args p) {
         for (int ii = 0; ii < gs; ++ii) a = fmaf(p.W21[(long)o * p.F + g * gs + ii], p.G[(long)(g * gs + ii) * gs + j], a);
         ((T*)p.Wf)[i] = Num<T>::from_f32(a);
     }
-    if (i < p.H) {
-        float a = p.b21[i];
-        for (int f = 0; f < p.F; ++f) a = fmaf(p.W21[i * p.F + f], p.bg[f], a);
-        p.bf[i] = a;
-    }
 }
-__global__ void unfold_conv2_kernel(UnfoldConv2Args p) {
+// bf[o] = b21[o] + W21[o] . bg : one wave per output row
+__global__ __launch_bounds__(256) void fold_conv2_bias_kernel(FoldConv2Args p) {
+    const int lane = threadIdx.x & 63, o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= p.H) return;
+    float a = 0.f;
+    for (int f = lane; f < p.F; f += 64) a = fmaf(p.W21[(long)o * p.F + f], p.bg[f], a);
+    a = wave_sum(a);
+    if (lane == 0) p.bf[o] = p.b21[o] + a;
+}
+__global__ void unfold_conv2_w_kernel(UnfoldConv2Args p) {  // dW21[o][f] += dbf[o] bg[f] + sum_j dWf[o][g*gs + j] G[f][j]
     const int gs = p.F / p.H;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < (long)p.H * p.F) {  // dW21[o][f], f = g*gs + ii
+    if (i < (long)p.H * p.F) {
         const int o = (int)(i / p.F), f = (int)(i % p.F), g = f / gs;
         float a = p.dbf[o] * p.bg[f];
         for (int j = 0; j < gs; ++j) a = fmaf(p.dWf[(long)o * p.F + g * gs + j], p.G[(long)f * gs + j], a);
         p.dW21[i] += a;
     }
-    if (i < (long)p.F * gs) {  // dG[f][j]
-        const int f = (int)(i / gs), j = (int)(i % gs), g = f / gs;
-        float a = 0.f;
-        for (int o = 0; o < p.H; ++o) a = fmaf(p.W21[(long)o * p.F + f], p.dWf[(long)o * p.F + g * gs + j], a);
-        p.dG[i] += a;
-    }
-    if (i < p.F) {
-        float a = 0.f;
-        for (int o = 0; o < p.H; ++o) a = fmaf(p.W21[(long)o * p.F + i], p.dbf[o], a);
-        p.dbg[i] += a;
-    }
     if (i < p.H) p.db21[i] += p.dbf[i];
+}
+// dG[f][j] += sum_o W21[o][f] dWf[o][g*gs + j], dbg[f] += sum_o W21[o][f] dbf[o]: a workgroup per input channel f, the 256
+// threads share the output rows, fixed-order LDS tree
+constexpr int UF_GS = 8;  // group sizes up to 8 (F / H; 4 in every BASELINE config)
+__global__ __launch_bounds__(256) void unfold_conv2_g_kernel(UnfoldConv2Args p) {
+    __shared__ float red[256][UF_GS + 1];
+    const int gs = p.F / p.H, f = blockIdx.x, g = f / gs, tid = threadIdx.x;
+    float a[UF_GS + 1];
+#pragma unroll
+    for (int j = 0; j <= UF_GS; ++j) a[j] = 0.f;
+    for (int o = tid; o < p.H; o += 256) {
+        const float w = p.W21[(long)o * p.F + f];
+#pragma unroll
+        for (int j = 0; j < UF_GS; ++j)
+            if (j < gs) a[j] = fmaf(w, p.dWf[(long)o * p.F + g * gs + j], a[j]);
+        a[UF_GS] = fmaf(w, p.dbf[o], a[UF_GS]);
+    }
+#pragma unroll
+    for (int j = 0; j <= UF_GS; ++j) red[tid][j] = a[j];
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (tid < st)
+#pragma unroll
+            for (int j = 0; j <= UF_GS; ++j) red[tid][j] += red[tid + st][j];
+        __syncthreads();
+    }
+    if (tid < gs) p.dG[(long)f * gs + tid] += red[0][tid];
+    if (tid == 0) p.dbg[f] += red[0][UF_GS];
 }
 
 inline int ok() { return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP; }
@@ -667,11 +704,15 @@ int launch_row_dot(const RowDotArgs& a, int dtype, hipStream_t stream) {
 
 int dwconv_wgrad_parts(int B, int S) { return B * ((S + DWG_R - 1) / DWG_R); }
 int launch_dwconv_wgrad(const DwConvWgradArgs& a, int dtype, hipStream_t stream) {
-    if (a.k > DWG_KMAX || a.k < 1 || a.B <= 0 || a.S <= 0) return FS2_ERR_SHAPE;
+    if (a.k > DWG_KMAX || a.k < 1 || a.B <= 0 || a.S <= 0 || (dtype != FS2_BF16 && dtype != FS2_F32)) return FS2_ERR_SHAPE;
     const dim3 g((a.S + DWG_R - 1) / DWG_R, (a.C + 63) / 64, a.B);
-    if (dtype == FS2_BF16) hipLaunchKernelGGL(dwconv_wgrad_kernel<bf16>, g, dim3(256), 0, stream, a);
-    else if (dtype == FS2_F32) hipLaunchKernelGGL(dwconv_wgrad_kernel<float>, g, dim3(256), 0, stream, a);
-    else return FS2_ERR_SHAPE;
+#define FS2_DWG(KB) \
+    do { \
+        if (dtype == FS2_BF16) hipLaunchKernelGGL((dwconv_wgrad_kernel<bf16, KB>), g, dim3(256), 0, stream, a); \
+        else hipLaunchKernelGGL((dwconv_wgrad_kernel<float, KB>), g, dim3(256), 0, stream, a); \
+    } while (0)
+    if (a.k <= 4) FS2_DWG(4); else if (a.k <= 8) FS2_DWG(8); else if (a.k <= 16) FS2_DWG(16); else FS2_DWG(32);
+#undef FS2_DWG
     return ok();
 }
 int launch_fold_conv2(const FoldConv2Args& a, int wf_dtype, hipStream_t stream) {
@@ -681,12 +722,14 @@ int launch_fold_conv2(const FoldConv2Args& a, int wf_dtype, hipStream_t stream) 
     if (wf_dtype == FS2_BF16) hipLaunchKernelGGL(fold_conv2_kernel<bf16>, g, dim3(256), 0, stream, a);
     else if (wf_dtype == FS2_F32) hipLaunchKernelGGL(fold_conv2_kernel<float>, g, dim3(256), 0, stream, a);
     else return FS2_ERR_SHAPE;
+    hipLaunchKernelGGL(fold_conv2_bias_kernel, dim3((a.H + 3) / 4), dim3(256), 0, stream, a);
     return ok();
 }
 int launch_unfold_conv2(const UnfoldConv2Args& a, hipStream_t stream) {
-    if (a.H <= 0 || a.F % a.H) return FS2_ERR_SHAPE;
-    const long n = (long)a.H * a.F;  // >= F * gs, F, H
-    hipLaunchKernelGGL(unfold_conv2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
+    if (a.H <= 0 || a.F % a.H || a.F / a.H > UF_GS) return FS2_ERR_SHAPE;
+    const long n = (long)a.H * a.F;
+    hipLaunchKernelGGL(unfold_conv2_w_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(unfold_conv2_g_kernel, dim3(a.F), dim3(256), 0, stream, a);
     return ok();
 }
 
