@@ -201,7 +201,8 @@ int fs2_profile_read(fs2_engine* e, int32_t kernel_class, double* total_ms, int6
  *   300/301 LayerNorm epilogue for rows wider than 256: GEMM + stand-alone LayerNorm launch (default) / in-place fused
  *   500/501 fp32 slab-kernel launches: fp32 MFMA (default) / bf16 x 3 split products (what FS2_MIXED_X3 uses in its front)
  *   700/701 bf16 fs2_op_bgemm tile order: plain / XCD-contiguous (default)
- *   800/801 bf16 fs2_op_bgemm: generic instantiation only / the bounds-free one for full, aligned tiles (default) */
+ *   800/801 bf16 fs2_op_bgemm: generic instantiation only / the bounds-free one for full, aligned tiles (default)
+ *   900/901 fs2_op_attention_bwd: one (default) / two 16-row blocks per wave */
 int fs2_op_set_gemm_variant(int32_t variant);
 /* tuning knob: cap (KiB) on the LDS operand slab of a vocoder conv workgroup; 0 = built-in heuristic */
 int fs2_op_set_vocoder_lds_limit(int32_t kib);

@@ -56,23 +56,31 @@ __device__ inline void load_frags(uint4 (&f)[4], const unsigned short* g, long l
     for (int ks = 0; ks < 4; ++ks) f[ks] = row < nrows ? *(const uint4*)(g + (long)row * ld + ks * 32 + fg * 8) : make_uint4(0, 0, 0, 0);
 }
 
+// NB = 16-key (dK/dV) or 16-query (dQ) blocks per wave: 2 halves the LDS fragment / transpose reads per MFMA and the number of
+// times the walked tiles are fetched, for 2x the accumulators
+template <int NB>
 __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned short sQ[TB * LDT], sO[TB * LDT];
     __shared__ float sL[TB], sD[TB];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fr = lane & 15, fg = lane >> 4;
     const int bh = blockIdx.y, b = bh / p.heads, h = bh % p.heads;
-    const int k0 = blockIdx.x * TB;
+    const int k0 = blockIdx.x * (TB * NB);
     const long ldq = 3L * p.H;
     const unsigned short* Q = (const unsigned short*)p.qkv + (long)b * p.S * ldq + h * D;
     const unsigned short* dO = (const unsigned short*)p.dout + (long)b * p.S * p.H + h * D;
-    const int key = k0 + 16 * w + fr;  // the key of this lane's column in the S / dP blocks
-    const bool kvalid = key < p.S && !(p.key_pad && p.key_pad[(long)b * p.S + key]);
-    uint4 Kf[4], Vf[4];
-    load_frags(Kf, Q + p.H, ldq, key, p.S, fg);
-    load_frags(Vf, Q + 2 * p.H, ldq, key, p.S, fg);
-    f32x4_t dK[8], dV[8];
+    int key[NB];       // the key of this lane's column in the S / dP blocks
+    bool kvalid[NB];
+    uint4 Kf[NB][4], Vf[NB][4];
+    f32x4_t dK[NB][8], dV[NB][8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) dK[i] = dV[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int kb = 0; kb < NB; ++kb) {
+        key[kb] = k0 + (16 * NB) * w + 16 * kb + fr;
+        kvalid[kb] = key[kb] < p.S && !(p.key_pad && p.key_pad[(long)b * p.S + key[kb]]);
+        load_frags(Kf[kb], Q + p.H, ldq, key[kb], p.S, fg);
+        load_frags(Vf[kb], Q + 2 * p.H, ldq, key[kb], p.S, fg);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dK[kb][i] = dV[kb][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
     const float* lse = p.lse2 + (long)bh * p.S;
     const float* dl = p.delta + (long)bh * p.S;
     const uint32_t thr = (uint32_t)(p.drop_p * 16777216.0f);
@@ -94,74 +102,96 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
             fetch_tile(xo, dO, p.H, q0 + TB, p.S);
             if (tid < TB) { xl = q0 + TB + tid < p.S ? lse[q0 + TB + tid] : 0.f; xd = q0 + TB + tid < p.S ? dl[q0 + TB + tid] : 0.f; }
         }
-#pragma unroll 1  // unrolling by 2 costs 24 VGPRs and a wave per SIMD: 323 -> 515 us
+#pragma unroll 1
         for (int qs = 0; qs < 4; ++qs) {
-            f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            f32x4_t s[NB], dp[NB];
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) s[kb] = dp[kb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const uint4 qa = *(const uint4*)(sQ + (qs * 16 + fr) * LDT + ks * 32 + fg * 8);
                 const uint4 oa = *(const uint4*)(sO + (qs * 16 + fr) * LDT + ks * 32 + fg * 8);
-                Mma16<bf16>::step(qa, Kf[ks], s);    // S[q = fg*4 + r][key = fr]
-                Mma16<bf16>::step(oa, Vf[ks], dp);   // dP, same layout
-            }
-            float pv[4], dsv[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ql = qs * 16 + fg * 4 + r, q = q0 + ql;
-                float pr = (kvalid && q < p.S) ? __builtin_amdgcn_exp2f(s[r] * p.scale_log2e - sL[ql]) : 0.f;
-                float dpe = dp[r];
-                float pd = pr;
-                if (p.drop_p > 0.f) {
-                    const bool keep = dropout_bits(p.drop_seed, p.drop_key, ((uint64_t)bh * p.S + q) * p.S + key) >= thr;
-                    pd = keep ? pr * dsc : 0.f;
-                    dpe = keep ? dpe * dsc : 0.f;
+                for (int kb = 0; kb < NB; ++kb) {
+                    Mma16<bf16>::step(qa, Kf[kb][ks], s[kb]);    // S[q = fg*4 + r][key = fr]
+                    Mma16<bf16>::step(oa, Vf[kb][ks], dp[kb]);   // dP, same layout
                 }
-                pv[r] = pd;
-                dsv[r] = pr * (dpe - sD[ql]) * p.scale;
             }
-            const s16x4_t pa = pack4(pv), da = pack4(dsv);  // A operands: row = key (fr), k = the four queries fg*4 ..
+            s16x4_t pa[NB], da[NB];  // A operands: row = key (fr), k = the four queries fg*4 ..
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb) {
+                float pv[4], dsv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ql = qs * 16 + fg * 4 + r, q = q0 + ql;
+                    const float pr = (kvalid[kb] && q < p.S) ? __builtin_amdgcn_exp2f(s[kb][r] * p.scale_log2e - sL[ql]) : 0.f;
+                    float dpe = dp[kb][r], pd = pr;
+                    if (p.drop_p > 0.f) {
+                        const bool keep = dropout_bits(p.drop_seed, p.drop_key, ((uint64_t)bh * p.S + q) * p.S + key[kb]) >= thr;
+                        pd = keep ? pr * dsc : 0.f;
+                        dpe = keep ? dpe * dsc : 0.f;
+                    }
+                    pv[r] = pd;
+                    dsv[r] = pr * (dpe - sD[ql]) * p.scale;
+                }
+                pa[kb] = pack4(pv);
+                da[kb] = pack4(dsv);
+            }
             const unsigned short* tq = sQ + (qs * 16 + fg * 4 + (fr >> 2)) * LDT + (fr & 3) * 4;
             const unsigned short* to = sO + (qs * 16 + fg * 4 + (fr >> 2)) * LDT + (fr & 3) * 4;
 #pragma unroll
             for (int dt = 0; dt < 8; ++dt) {
-                dV[dt] = mma16(pa, tr4(to + dt * 16), dV[dt]);   // += P^T dO
-                dK[dt] = mma16(da, tr4(tq + dt * 16), dK[dt]);   // += dS^T Q
+                const s16x4_t bo = tr4(to + dt * 16), bq = tr4(tq + dt * 16);
+#pragma unroll
+                for (int kb = 0; kb < NB; ++kb) {
+                    dV[kb][dt] = mma16(pa[kb], bo, dV[kb][dt]);   // += P^T dO
+                    dK[kb][dt] = mma16(da[kb], bq, dK[kb][dt]);   // += dS^T Q
+                }
             }
         }
     }
-    // D: lane holds column d = dt*16 + fr, rows key = fg*4 + r of this wave's 16 keys
+    // D: lane holds column d = dt*16 + fr, rows key = fg*4 + r of each 16-key block
     unsigned short* out = (unsigned short*)p.dqkv + (long)b * p.S * ldq + h * D;
 #pragma unroll
-    for (int dt = 0; dt < 8; ++dt)
+    for (int kb = 0; kb < NB; ++kb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int kk = k0 + 16 * w + fg * 4 + r;
-            if (kk < p.S) {
-                out[(long)kk * ldq + p.H + dt * 16 + fr] = Num<bf16>::from_f32(dK[dt][r]).v;
-                out[(long)kk * ldq + 2 * p.H + dt * 16 + fr] = Num<bf16>::from_f32(dV[dt][r]).v;
+        for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int kk = k0 + (16 * NB) * w + 16 * kb + fg * 4 + r;
+                if (kk < p.S) {
+                    out[(long)kk * ldq + p.H + dt * 16 + fr] = Num<bf16>::from_f32(dK[kb][dt][r]).v;
+                    out[(long)kk * ldq + 2 * p.H + dt * 16 + fr] = Num<bf16>::from_f32(dV[kb][dt][r]).v;
+                }
             }
-        }
 }
 
+template <int NB>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned short sK[TB * LDT], sV[TB * LDT];
     __shared__ unsigned char sOk[TB];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fr = lane & 15, fg = lane >> 4;
     const int bh = blockIdx.y, b = bh / p.heads, h = bh % p.heads;
-    const int q0 = blockIdx.x * TB;
+    const int q0 = blockIdx.x * (TB * NB);
     const long ldq = 3L * p.H;
     const unsigned short* Q = (const unsigned short*)p.qkv + (long)b * p.S * ldq + h * D;
     const unsigned short* dO = (const unsigned short*)p.dout + (long)b * p.S * p.H + h * D;
-    const int q = q0 + 16 * w + fr;  // the query of this lane's column in the S^T / dP^T blocks
-    const bool qvalid = q < p.S;
-    uint4 Qf[4], Of[4];
-    load_frags(Qf, Q, ldq, q, p.S, fg);
-    load_frags(Of, dO, p.H, q, p.S, fg);
-    const float lse = qvalid ? p.lse2[(long)bh * p.S + q] : 0.f;
-    const float dl = qvalid ? p.delta[(long)bh * p.S + q] : 0.f;
-    f32x4_t dQ[8];
+    int q[NB];  // the query of this lane's column in the S^T / dP^T blocks
+    bool qvalid[NB];
+    uint4 Qf[NB][4], Of[NB][4];
+    float lse[NB], dl[NB];
+    f32x4_t dQ[NB][8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) dQ[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int qb = 0; qb < NB; ++qb) {
+        q[qb] = q0 + (16 * NB) * w + 16 * qb + fr;
+        qvalid[qb] = q[qb] < p.S;
+        load_frags(Qf[qb], Q, ldq, q[qb], p.S, fg);
+        load_frags(Of[qb], dO, p.H, q[qb], p.S, fg);
+        lse[qb] = qvalid[qb] ? p.lse2[(long)bh * p.S + q[qb]] : 0.f;
+        dl[qb] = qvalid[qb] ? p.delta[(long)bh * p.S + q[qb]] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dQ[qb][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
     const uint32_t thr = (uint32_t)(p.drop_p * 16777216.0f);
     const float dsc = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
 
@@ -181,52 +211,78 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs p) {
             fetch_tile(xv, Q + 2 * p.H, ldq, k0 + TB, p.S);
             if (tid < TB) xok = (k0 + TB + tid < p.S && !(p.key_pad && p.key_pad[(long)b * p.S + k0 + TB + tid])) ? 1 : 0;
         }
-#pragma unroll 2
+#pragma unroll 1
         for (int ks4 = 0; ks4 < 4; ++ks4) {
-            f32x4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+            f32x4_t s[NB], dp[NB];
+#pragma unroll
+            for (int qb = 0; qb < NB; ++qb) s[qb] = dp[qb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const uint4 ka = *(const uint4*)(sK + (ks4 * 16 + fr) * LDT + ks * 32 + fg * 8);
                 const uint4 va = *(const uint4*)(sV + (ks4 * 16 + fr) * LDT + ks * 32 + fg * 8);
-                Mma16<bf16>::step(ka, Qf[ks], s);    // S^T[key = fg*4 + r][q = fr]
-                Mma16<bf16>::step(va, Of[ks], dp);   // dP^T
-            }
-            float dsv[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int kl = ks4 * 16 + fg * 4 + r, key = k0 + kl;
-                const float pr = (qvalid && sOk[kl]) ? __builtin_amdgcn_exp2f(s[r] * p.scale_log2e - lse) : 0.f;
-                float dpe = dp[r];
-                if (p.drop_p > 0.f)
-                    dpe = dropout_bits(p.drop_seed, p.drop_key, ((uint64_t)bh * p.S + q) * p.S + key) >= thr ? dpe * dsc : 0.f;
-                dsv[r] = pr * (dpe - dl) * p.scale;
+                for (int qb = 0; qb < NB; ++qb) {
+                    Mma16<bf16>::step(ka, Qf[qb][ks], s[qb]);    // S^T[key = fg*4 + r][q = fr]
+                    Mma16<bf16>::step(va, Of[qb][ks], dp[qb]);   // dP^T
+                }
             }
-            const s16x4_t da = pack4(dsv);  // A operand: row = query (fr), k = the four keys fg*4 ..
+            s16x4_t da[NB];  // A operand: row = query (fr), k = the four keys fg*4 ..
+#pragma unroll
+            for (int qb = 0; qb < NB; ++qb) {
+                float dsv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int kl = ks4 * 16 + fg * 4 + r, key = k0 + kl;
+                    const float pr = (qvalid[qb] && sOk[kl]) ? __builtin_amdgcn_exp2f(s[qb][r] * p.scale_log2e - lse[qb]) : 0.f;
+                    float dpe = dp[qb][r];
+                    if (p.drop_p > 0.f)
+                        dpe = dropout_bits(p.drop_seed, p.drop_key, ((uint64_t)bh * p.S + q[qb]) * p.S + key) >= thr ? dpe * dsc : 0.f;
+                    dsv[r] = pr * (dpe - dl[qb]) * p.scale;
+                }
+                da[qb] = pack4(dsv);
+            }
             const unsigned short* tk = sK + (ks4 * 16 + fg * 4 + (fr >> 2)) * LDT + (fr & 3) * 4;
 #pragma unroll
-            for (int dt = 0; dt < 8; ++dt) dQ[dt] = mma16(da, tr4(tk + dt * 16), dQ[dt]);  // += dS K
+            for (int dt = 0; dt < 8; ++dt) {
+                const s16x4_t bk = tr4(tk + dt * 16);
+#pragma unroll
+                for (int qb = 0; qb < NB; ++qb) dQ[qb][dt] = mma16(da[qb], bk, dQ[qb][dt]);  // += dS K
+            }
         }
     }
     unsigned short* out = (unsigned short*)p.dqkv + (long)b * p.S * ldq + h * D;
 #pragma unroll
-    for (int dt = 0; dt < 8; ++dt)
+    for (int qb = 0; qb < NB; ++qb)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int qq = q0 + 16 * w + fg * 4 + r;
-            if (qq < p.S) out[(long)qq * ldq + dt * 16 + fr] = Num<bf16>::from_f32(dQ[dt][r]).v;
-        }
+        for (int dt = 0; dt < 8; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qq = q0 + (16 * NB) * w + 16 * qb + fg * 4 + r;
+                if (qq < p.S) out[(long)qq * ldq + dt * 16 + fr] = Num<bf16>::from_f32(dQ[qb][dt][r]).v;
+            }
 }
 
+int g_attn_bwd_nb = 1;  // measured (tools/bench_ops.py flash): 2 blocks per wave is 5-11 % slower (C2 590 -> 620 us, C3 1469 -> 1634 us):
+                        // the extra accumulators cost a wave per SIMD and these kernels live on occupancy
+
 }  // namespace
+
+void attention_bwd_set_blocks(int nb) { g_attn_bwd_nb = nb == 2 ? 2 : 1; }
 
 bool attention_bwd_supported(int dtype, int H, int heads) { return dtype == FS2_BF16 && heads > 0 && H == heads * D; }
 
 int launch_attention_bwd(const AttnBwdArgs& a, int dtype, hipStream_t stream) {
     if (!attention_bwd_supported(dtype, a.H, a.heads) || a.B <= 0 || a.S <= 0) return FS2_ERR_SHAPE;
     if (!a.qkv || !a.dout || !a.lse2 || !a.delta || !a.dqkv) return FS2_ERR_ARG;
-    const dim3 grid((a.S + TB - 1) / TB, a.B * a.heads);
-    hipLaunchKernelGGL(attn_bwd_dkdv_kernel, grid, dim3(256), 0, stream, a);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, stream, a);
+    if (g_attn_bwd_nb == 2) {
+        const dim3 grid((a.S + 2 * TB - 1) / (2 * TB), a.B * a.heads);
+        hipLaunchKernelGGL(attn_bwd_dkdv_kernel<2>, grid, dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<2>, grid, dim3(256), 0, stream, a);
+    } else {
+        const dim3 grid((a.S + TB - 1) / TB, a.B * a.heads);
+        hipLaunchKernelGGL(attn_bwd_dkdv_kernel<1>, grid, dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<1>, grid, dim3(256), 0, stream, a);
+    }
     return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
 }
 

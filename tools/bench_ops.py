@@ -137,6 +137,22 @@ def bwd_cases(reps):
                sA1=heads * S * S, sA2=S * S, sB1=S * H, sB2=d, sC1=S * 3 * H, sC2=d, **bat)
 
 
+def flash_bwd_case(name, B, S, H, heads, reps):
+    bf = torch.bfloat16
+    qkv = (0.5 * torch.randn(B * S, 3 * H, device=DEV)).to(bf)
+    dout = torch.randn(B * S, H, device=DEV).to(bf)
+    lse = torch.zeros(B, heads, S, device=DEV) + 5.0
+    delta = torch.zeros(B, heads, S, device=DEV)
+    dqkv = torch.empty(B * S, 3 * H, device=DEV, dtype=bf)
+    for knob in (900, 901):
+        lib.fs2_op_set_gemm_variant(knob)
+        t = timeit(lambda st: lib.fs2_op_attention_bwd(BF16, p(qkv), p(dout), p(lse), p(delta), None, p(dqkv), B, S, H, heads,
+                                                       C.c_float(0.0), C.c_uint64(0), C.c_uint64(0), st), reps)
+        fl = 5 * 2.0 * B * S * S * H  # dV, dP, dS-products: five S x S x d GEMMs are the useful work
+        print(f"{name:30s} blocks/wave={knob - 899}  {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TF useful ({fl/t/2.5e15*100:4.1f}% of 2.5 PF)")
+    lib.fs2_op_set_gemm_variant(900)
+
+
 def predictor_case(name, B, S, nl, reps):
     """Whole dense VariancePredictor (nl x conv k=3 + ReLU + LN, head) as one launch."""
     H, k = 256, 3
@@ -230,6 +246,10 @@ def main():
                 gemm_ln_case("c5 dec conv2 +res+LN", 12288, 1024, 4096, 1, 12288, a.reps, v)
                 gemm_ln_case("c5 pred conv k=3 +relu+LN", 12288, 1024, 1024, 3, 1536, a.reps, v, res=False, relu=True)
         lib.fs2_op_set_gemm_variant(301)
+    if a.what in ("flash",):
+        flash_bwd_case("c2 decoder attention backward", 32, 1536, 256, 2, a.reps)
+        flash_bwd_case("c3 decoder attention backward", 32, 1536, 768, 6, a.reps)
+        flash_bwd_case("c2 encoder attention backward", 32, 256, 256, 2, a.reps)
     if a.what in ("bwd",):
         bwd_cases(a.reps)
     if a.what in ("pred", "all"):
