@@ -559,17 +559,31 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(DwConvWgradArgs p) {
     const int rows = DWG_R + p.k - 1;
     const bool quad = (p.C & 3) == 0 && c0 + 64 <= p.C;  // 8- / 16-byte loads of four channels
     if (quad) {
-        for (int i = tid; i < rows * 16; i += 256) {
-            const int r = i >> 4, cq = (i & 15) * 4, t = t0 + r - p.pad;
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (t >= 0 && t < p.S) ld4<T>(x + (size_t)t * p.C + c0 + cq, v);
-            *(float4*)(xs + r * 64 + cq) = make_float4(v[0], v[1], v[2], v[3]);
+        // every load of both tiles is issued before the first is used (clamped row, zeroed afterwards): one memory round trip
+        // per workgroup instead of one per 16 rows
+        constexpr int NX = ((DWG_R + KB - 1) * 16 + 255) / 256, ND = DWG_R * 16 / 256;
+        float vx[NX][4], vd[ND][4];
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int i = tid + u * 256, r = i >> 4, cq = (i & 15) * 4, t = t0 + r - p.pad;
+            const int tc = t < 0 ? 0 : (t < p.S ? t : p.S - 1);
+            ld4<T>(x + (size_t)tc * p.C + c0 + cq, vx[u]);
         }
-        for (int i = tid; i < DWG_R * 16; i += 256) {
-            const int r = i >> 4, cq = (i & 15) * 4, t = t0 + r;
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (t < p.S) ld4<T>(dy + (size_t)t * p.C + c0 + cq, v);
-            *(float4*)(ds + r * 64 + cq) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+        for (int u = 0; u < ND; ++u) {
+            const int i = tid + u * 256, r = i >> 4, cq = (i & 15) * 4, t = t0 + r;
+            ld4<T>(dy + (size_t)(t < p.S ? t : p.S - 1) * p.C + c0 + cq, vd[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const int i = tid + u * 256, r = i >> 4, cq = (i & 15) * 4, t = t0 + r - p.pad;
+            const bool v = t >= 0 && t < p.S;
+            if (r < rows) *(float4*)(xs + r * 64 + cq) = v ? make_float4(vx[u][0], vx[u][1], vx[u][2], vx[u][3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < ND; ++u) {
+            const int i = tid + u * 256, r = i >> 4, cq = (i & 15) * 4, t = t0 + r;
+            *(float4*)(ds + r * 64 + cq) = t < p.S ? make_float4(vd[u][0], vd[u][1], vd[u][2], vd[u][3]) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     } else {
         for (int i = tid; i < rows * 64; i += 256) {
