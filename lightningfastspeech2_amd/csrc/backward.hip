@@ -419,24 +419,18 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(ScatterRowsArgs p) {
 #pragma unroll 1
             for (int ww = 0; ww < 4; ++ww) {
                 const int nh = cnt[ww];
-                if (p.H <= 256) {  // the usual width: eight rows' loads in flight, added in list order
-                    const int c = c0 + threadIdx.x;
+                // eight rows' loads in flight per column group, added in list order
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int c = c0 + j * 256 + threadIdx.x;
+                    if (c0 + j * 256 >= p.H) break;  // uniform
                     for (int h = 0; h < nh; h += 8) {
                         float vv[8];
 #pragma unroll
                         for (int u = 0; u < 8; ++u)
                             vv[u] = (h + u < nh && c < p.H) ? Num<T>::to_f32(((const T*)p.x)[(long)hits[ww][h + u] * p.H + c]) : 0.f;
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) acc[0] += vv[u];
-                    }
-                    continue;
-                }
-                for (int h = 0; h < nh; ++h) {
-                    const T* src = (const T*)p.x + (long)hits[ww][h] * p.H;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int c = c0 + j * 256 + threadIdx.x;
-                        if (c < p.H) acc[j] += Num<T>::to_f32(src[c]);
+                        for (int u = 0; u < 8; ++u) acc[j] += vv[u];
                     }
                 }
             }
