@@ -2,7 +2,7 @@
 from .config import Fs2Config, preset  # noqa: F401
 from .weights import state_dict_spec, synth_state_dict, synth_inputs  # noqa: F401
 
-__all__ = ["Fs2Config", "preset", "state_dict_spec", "synth_state_dict", "synth_inputs", "FastSpeech2"]
+__all__ = ["Fs2Config", "preset", "state_dict_spec", "synth_state_dict", "synth_inputs", "FastSpeech2", "Trainer"]
 
 
 def __getattr__(name):
@@ -10,4 +10,7 @@ def __getattr__(name):
     if name == "FastSpeech2":
         from .model import FastSpeech2
         return FastSpeech2
+    if name == "Trainer":  # the training step: forward tape + backward + clip + AdamW / Noam
+        from .training import Trainer
+        return Trainer
     raise AttributeError(name)

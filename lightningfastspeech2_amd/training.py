@@ -5,8 +5,9 @@
     -> torch.optim.AdamW(lr, betas=[0.9, 0.98], eps=1e-8, weight_decay=0.01) + NoamLR (fastspeech2.py:1166-1182, noam.py:4-25)
 
 built on the HIP operators behind the C ABI (include/fs2.h, "Training step" section): the teacher-forced forward keeps
-every tensor the backward needs in HBM (288 GB: nothing is recomputed, the attention probabilities are materialised),
-the backward is a hand-written tape over fs2_op_bgemm / fs2_op_layernorm_bwd / fs2_op_softmax_bwd / ..., parameters,
+every tensor the backward needs in HBM (288 GB: nothing is recomputed except the attention probabilities where the fused
+attention + recomputing backward applies - bf16, head dim 128; elsewhere they are materialised),
+the backward is a hand-written tape over fs2_op_bgemm / fs2_op_layernorm_bwd / fs2_op_attention_bwd / ..., parameters,
 gradients and both Adam moments live in ONE flat fp32 buffer each so the optimizer is a single launch and a data-parallel
 job all-reduces one contiguous gradient buffer.  torch supplies device memory and streams only; there is no autograd and
 no CPU path - without libfs2_hip.so the constructor raises.
@@ -15,8 +16,8 @@ Covered: dense and depth-wise convolution variants of every block (C1-C5 of BASE
 and the test-size configs; the depth-wise layer's conv2 pair is trained through its folded (H, F) map), frame-level
 'none' variances, 'l1' / 'mse' losses; precision "fp32" (exact fp32 MFMA, the parity mode) or "bf16" (bf16 activations,
 activation gradients and GEMM operands on the bf16 MFMA with fp32 accumulation; fp32 master weights, weight gradients,
-Adam moments, LayerNorm / softmax statistics and losses - what the reference's `--precision 16` recipe does with fp16).  Dropout: every nn.Dropout site of the reference in
-training mode (encoder / decoder incl. the attention weights and both positional encodings, variance / duration predictors)
+Adam moments, LayerNorm / softmax statistics and losses - what the reference's `--precision 16` recipe does with fp16).
+Dropout: every nn.Dropout site of the reference in training mode (encoder / decoder incl. the attention weights and both positional encodings, variance / duration predictors)
 with a counter-based mask that is regenerated, not stored; 0 by default, which is what the parity fixtures pin (the
 reference's masks come from torch's random stream and cannot be reproduced).  Priors (PriorEmbedding) are trained.  Rejected loudly:
 phone-level / CWT variances, stochastic durations.
