@@ -481,8 +481,19 @@ __global__ void masked_loss_bwd_kernel(LossBwdArgs p) {
 constexpr int SS_BLOCKS = 1024;
 __global__ __launch_bounds__(256) void sum_sq_pass1(const float* x, size_t n, float* ws) {
     __shared__ double red[256];
+    // 16-byte loads, fp32 partial sums of at most 64 squares, fp64 across them (x is 16-byte aligned: a flat buffer)
     double a = 0.0;
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) a += (double)x[e] * x[e];
+    const size_t nv = ((uintptr_t)x & 15) == 0 ? n / 4 : 0;
+    const float4* xv = (const float4*)x;
+    float f = 0.f;
+    int run = 0;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < nv; e += (size_t)gridDim.x * 256) {
+        const float4 v = xv[e];
+        f += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        if (++run == 16) { a += (double)f; f = 0.f; run = 0; }
+    }
+    a += (double)f;
+    for (size_t e = nv * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) a += (double)x[e] * x[e];
     red[threadIdx.x] = a;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
