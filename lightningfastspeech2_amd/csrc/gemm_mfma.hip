@@ -1228,7 +1228,12 @@ static int launch_gemm_plain(const GemmArgs& a, int in_dtype, int out_dtype, hip
             const long bm = mi * 32, tm = (S + bm - 1) / bm;
             const bool wide = fused && tn > 1;  // one workgroup per row tile walks all tn column tiles
             const long tiles = (long)nutt * tm * (wide ? 1 : tn);
-            const long cost = ((tiles + 255) / 256) * (bm + 40) * (wide ? tn : 1);
+            long cost = ((tiles + 255) / 256) * (bm + 40) * (wide ? tn : 1);
+            // long reductions (K >= 4096: the data-gradient convs of the training step, K = taps * filter): every workgroup
+            // streams the whole K x 256 weight panel out of L2, and tiles x panel bytes over the ~10 TB/s the L2s deliver
+            // together becomes the bound before the CUs fill - in the same units (one row of MFMA work per K) that is ~1 per
+            // tile.  C5 encoder conv1 dgrad (M = 2048, N = 1024, K = 36864): 256 x 32-row tiles 500 us -> 128 x 64-row tiles.
+            if (a.K >= 4096 && !wide) cost = cost > tiles ? cost : tiles;
             if (!best || cost < best_cost) { best = mi; best_cost = cost; best_rows = (long)nutt * tm * bm; }
         }
         if (best_rows <= 2L * a.M) {
