@@ -335,6 +335,26 @@ class Trainer:
             out[n] = b.cpu().reshape(1, *b.shape) if n.endswith(".pe") else b.cpu()
         return out
 
+    def optimizer_state(self):
+        """Adam moments under the reference's parameter names and layouts + the step counter (what a Lightning checkpoint keeps
+        as ``optimizer_states`` / ``lr_schedulers``): ``{"step": n, "exp_avg": {name: tensor}, "exp_avg_sq": {name: tensor}}``.
+        Together with ``state_dict()`` this resumes a run exactly."""
+        def views(flat):
+            return OrderedDict((n, self._to_ref_layout(n, flat[o:o + int(np.prod(ks))].view(ks))) for n, (o, ks, _) in self._layout.items())
+        return {"step": self.steps, "micro_step": self._micro, "exp_avg": views(self.flat_m), "exp_avg_sq": views(self.flat_v)}
+
+    def load_optimizer_state(self, st):
+        for key, flat in (("exp_avg", self.flat_m), ("exp_avg_sq", self.flat_v)):
+            for n, (o, ks, rs) in self._layout.items():
+                t = torch.as_tensor(st[key][n]).to(torch.float32)
+                if tuple(t.shape) != rs:
+                    raise ValueError(f"{key}[{n}]: shape {tuple(t.shape)} != {rs}")
+                if len(rs) == 3:
+                    t = t.permute(0, 2, 1).reshape(ks)
+                flat[o:o + int(np.prod(ks))].view(ks).copy_(t.contiguous())
+        self.steps = int(st["step"])
+        self._micro = int(st.get("micro_step", 0))
+
     def gradients(self):
         return OrderedDict((n, self._to_ref_layout(n, self.G[n])) for n in self._layout)
 

@@ -309,3 +309,22 @@ def test_flash_attention_path_matches_the_materialised_path(drop):
                 continue
             cos = float((ga[n].double() * w.double()).sum() / (ga[n].double().norm() * w.double().norm() + 1e-30))
             assert cos >= 0.99, (n, cos)
+
+
+def test_checkpoint_resume_is_exact():
+    """state_dict() + optimizer_state() of a run after two steps, loaded into a fresh Trainer: the third step (with dropout on,
+    so the mask counter matters too) leaves bit-identical weights in both."""
+    from lightningfastspeech2_amd.training import Trainer
+    cfg, sd, batch = _case(61, 3, 12, [12, 8, 3])
+    kw = dict(lr=1e-3, warmup_steps=2, encoder_dropout=0.1, decoder_dropout=0.1, variance_dropout=0.2, duration_dropout=0.2, seed=5)
+    a = Trainer(cfg, sd, **kw)
+    bd = _dev(batch)
+    for _ in range(2):
+        a.training_step(bd)
+        a.optimizer_step()
+    b = Trainer(cfg, a.state_dict(), **kw)
+    b.load_optimizer_state(a.optimizer_state())
+    for t in (a, b):
+        t.training_step(bd)
+        t.optimizer_step()
+    assert torch.equal(a.flat_p, b.flat_p) and torch.equal(a.flat_m, b.flat_m) and a.steps == b.steps == 3
