@@ -112,6 +112,7 @@ __device__ inline void store_tile(float* s, bool kc, const float4 (&r)[2]) {
     }
 }
 
+template <bool AKC, bool BKC>  // operand layouts at compile time: the fragment reads are straight-line code (see the bf16 kernel)
 __global__ __launch_bounds__(256) void bgemm_f32_kernel(BGemmArgs p) {
     __shared__ __attribute__((aligned(16))) float lds[2][2][OPSZ];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256) void bgemm_f32_kernel(BGemmArgs p) {
         B.seg = p.seg;
         B.shift_k = p.b_shift0 + b2 * p.b_shift_step;
     }
-    const bool akc = A.s_k == 1, bkc = B.s_k == 1;
+    constexpr bool akc = AKC, bkc = BKC;
 
     // k range of this split, in whole k-tiles; in the dgrad form K = taps * Kin and tiles never straddle a tap
     const int Kin = p.taps > 1 ? p.Kin : p.K;
@@ -704,7 +705,11 @@ int launch_bgemm(const BGemmArgs& a0, int dtype, hipStream_t stream) {
     const long per = (long)a.M * a.N;
     dim3 g2((unsigned)((per + 255) / 256), a.nb1 * a.nb2);
     if (dtype == FS2_F32) {
-        hipLaunchKernelGGL(bgemm_f32_kernel, grid, dim3(256), 0, stream, a);
+        const bool akc = a.sAk == 1, bkc = a.sBk == 1;
+        if (akc && bkc) hipLaunchKernelGGL((bgemm_f32_kernel<true, true>), grid, dim3(256), 0, stream, a);
+        else if (akc) hipLaunchKernelGGL((bgemm_f32_kernel<true, false>), grid, dim3(256), 0, stream, a);
+        else if (bkc) hipLaunchKernelGGL((bgemm_f32_kernel<false, true>), grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((bgemm_f32_kernel<false, false>), grid, dim3(256), 0, stream, a);
         if (splitk > 1) hipLaunchKernelGGL(bgemm_reduce_kernel, g2, dim3(256), 0, stream, a);
     } else {
         const bool akc = a.sAk == 1, bkc = a.sBk == 1;
