@@ -328,3 +328,38 @@ def test_checkpoint_resume_is_exact():
         t.training_step(bd)
         t.optimizer_step()
     assert torch.equal(a.flat_p, b.flat_p) and torch.equal(a.flat_m, b.flat_m) and a.steps == b.steps == 3
+
+
+def test_full_length_utterance_gradients_vs_oracle():
+    """BASELINE configs[1] architecture (FS2-27M: H = 256, F = 1024, k = 9, 4 + 4 layers) on one full-length utterance
+    (256 phonemes -> 1536 frames), fp32: losses and every parameter's gradient against the autograd oracle.  At this length a
+    gradient entry is a sum over 1536 frames of cancelling fp32 terms on BOTH sides (the oracle is fp32 too): per tensor the
+    direction must agree to cosine >= 0.99999 and no entry may differ by more than 2 % of the tensor's largest (measured:
+    cosine >= 0.999997, worst entry 1.0 %; tools/probes/full_len_grad_check.py prints the table)."""
+    import math
+    from lightningfastspeech2_amd.config import preset
+    from lightningfastspeech2_amd.training import Trainer
+    cfg = preset("c2")
+    sd = synth_state_dict(cfg, 0, duration_bias=math.log(7.0), duration_weight_scale=0.0)
+    inp = synth_inputs(cfg, 1, 256, seed=1234)
+    rs = np.random.RandomState(5)
+    T = 256 * 6
+    batch = {"phones": inp["phones"], "speaker": inp["speaker"], "duration": np.full((1, 256), 6, np.int64),
+             "mel": (rs.randn(1, T, cfg.n_mels) - 2).astype(np.float32)}
+    for v in cfg.variances:
+        batch[f"variances_{v}"] = rs.randn(1, T).astype(np.float32)
+    ref = train_cpu.OracleTrainer(cfg, sd, gradient_clip_val=None)
+    want_l, _ = ref.training_step(batch)
+    tr = Trainer(cfg, sd, gradient_clip_val=None)
+    got_l = tr.training_step(_dev(batch))
+    for k, w in want_l.items():
+        assert abs(float(got_l[k]) - w) <= 2e-5 * max(1.0, abs(w)), (k, float(got_l[k]), w)
+    got, want = tr.gradients(), ref.gradients()
+    gmax = max(float(w.abs().max()) for w in want.values())
+    for n, w in want.items():
+        w = w.float()
+        if float(w.abs().max()) < 1e-5 * gmax:
+            continue
+        cos = float((got[n].double() * w.double()).sum() / (got[n].double().norm() * w.double().norm() + 1e-30))
+        rel = float((got[n] - w).abs().max()) / float(w.abs().max())
+        assert cos >= 0.99999 and rel <= 2e-2, (n, cos, rel)
