@@ -287,6 +287,9 @@ typedef struct fs2_bgemm_desc {
     int32_t c_dtype;   /* fs2_dtype of C: FS2_F32 operands write fp32; FS2_BF16 operands write bf16 or fp32 */
 } fs2_bgemm_desc;
 size_t fs2_op_bgemm_ws_bytes(const fs2_bgemm_desc* d);  /* split-K slabs (0 when splitk <= 1) */
+/* 1 when bf16 operands of this shape run on the 256 x 256 tile kernel (TN product, M % 256 == N % 256 == K % 32 == 0, fp32 C):
+ * the caller sizes splitk for 4x fewer, 512-thread workgroups (one per CU) then */
+int32_t fs2_op_bgemm_tn256(const fs2_bgemm_desc* d);
 int fs2_op_bgemm(int32_t dtype, const fs2_bgemm_desc* d, const void* A, const void* B, void* C, const float* bias,
                  float* ws, void* hip_stream);
 /* The fused (flash) attention of the inference path on the training path: also writes lse2 (B, heads, S) - per query, log2 of

@@ -148,6 +148,8 @@ def load():
     f32, sz = C.c_float, C.c_size_t
     lib.fs2_op_bgemm_ws_bytes.restype = sz
     lib.fs2_op_bgemm_ws_bytes.argtypes = [C.POINTER(BGemmDescC)]
+    lib.fs2_op_bgemm_tn256.restype = i32
+    lib.fs2_op_bgemm_tn256.argtypes = [C.POINTER(BGemmDescC)]
     lib.fs2_op_bgemm.argtypes = [i32, C.POINTER(BGemmDescC), vp, vp, vp, vp, vp, vp]
     lib.fs2_op_attention_train.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, C.c_uint64, C.c_uint64, vp]
     lib.fs2_op_attention_bwd_supported.restype = i32

@@ -672,12 +672,202 @@ __global__ void bgemm_reduce_t_kernel(BGemmArgs p) {
     *dst = Num<OutT>::from_f32(v);
 }
 
+// ---- TN products with a long reduction (weight gradients): 256 x 256 x 32 tiles by LDS-DMA --------------------------------
+// dW = dY^T X reduces over all B*T rows into a small output, both operands k-strided ("natural": a k row is contiguous
+// along m / n).  The 128 x 128 tile above moves 64 flop per operand byte, i.e. it needs ~20 TB/s out of L2 at half the
+// MFMA peak; this kernel's 256 x 256 tile needs half of that and, as the forward slab kernel does, keeps its operands off the
+// VGPRs: 8 waves (2 x 4, a wave owns 128 x 64 = 8 x 4 accumulator fragments), three 32 KiB LDS stages ([32 k][256 m] of A,
+// then of B), `buffer_load ... lds` 16 B per lane (one instruction = two k rows), a counted vmcnt and ONE barrier per
+// k-step.  A DMA writes LDS lane-linearly, so the bank swizzle lives on the global side: LDS 32-byte position q of row k
+// holds global columns 16 * (q ^ f(k)), f(k) = (k & 3) | ((k >> 3) & 1) << 2, which makes the 32 lanes of a
+// ds_read_b64_tr_b16 half (k rows 0-3 and 8-11 of one 16-column block) cover all 64 banks once.  Rows that must read as
+// zero (the wgrad form's shifted time rows outside their utterance) carry an out-of-range buffer offset.
+constexpr int GT = 256, GK = 32;
+constexpr int GOP = GK * GT * 2;   // bytes per operand per stage
+constexpr int GSTAGE = 2 * GOP;
+
+__global__ __launch_bounds__(512) void bgemm_tn256_kernel(const BGemmArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ __attribute__((aligned(16))) unsigned char st0[GSTAGE];
+    __shared__ __attribute__((aligned(16))) unsigned char st1[GSTAGE];
+    __shared__ __attribute__((aligned(16))) unsigned char st2[GSTAGE];
+    typedef __attribute__((address_space(3))) s16x4_t* lds_v4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int splitk = p.splitk > 1 ? p.splitk : 1;
+    const int tn = p.N / GT, tm = p.M / GT;
+    // XCD-contiguous order (workgroup i runs on XCD i % 8): column tile fastest, then tap, row tile, k split, outer batch - the
+    // workgroups that share an A panel (one row tile, one split, every tap / column tile) sit in one XCD's L2 together
+    unsigned lg = blockIdx.x;
+    {
+        const unsigned nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = lg & 7, idx = lg >> 3;
+        lg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int bn = lg % tn; lg /= tn;
+    const int b2 = lg % p.nb2; lg /= p.nb2;
+    const int bm = lg % tm; lg /= tm;
+    const int split = lg % splitk;
+    const int b1 = lg / splitk;
+    const int m0 = bm * GT, n0 = bn * GT;
+    const int ntiles = p.K / GK, per = ntiles / splitk, rem = ntiles % splitk;
+    const int t_begin = split * per + (split < rem ? split : rem), nk = per + (split < rem ? 1 : 0);
+
+    const unsigned short* Ab = (const unsigned short*)p.A + b1 * p.sA1 + b2 * p.sA2;
+    const unsigned short* Bb = (const unsigned short*)p.B + b1 * p.sB1 + b2 * p.sB2;
+    constexpr unsigned OOB = 0xFFFFF000u;
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc((void*)Ab, 0, (unsigned)(((long)(p.K - 1) * p.sAk + p.M) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void*)Bb, 0, (unsigned)(((long)(p.K - 1) * p.sBk + p.N) * 2), 0x00020000);
+    const int shift = p.seg ? p.b_shift0 + b2 * p.b_shift_step : 0;
+    const int seg = p.seg ? p.seg : 0x7fffffff;
+    const unsigned stepA = (unsigned)(GK * p.sAk * 2), stepB = (unsigned)(GK * p.sBk * 2);
+    unsigned voffA[2], voffB[2];
+    int rsB[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = 2 * (wave + 8 * j) + (lane >> 5), pos = lane & 31;
+        const int f = (r & 3) | (((r >> 3) & 1) << 2);
+        const int c = (((pos >> 1) ^ f) << 1) | (pos & 1);   // global 16-byte chunk of the row that lands at LDS position pos
+        voffA[j] = (unsigned)(((long)r * p.sAk + m0 + c * 8) * 2);
+        voffB[j] = (unsigned)(((long)(t_begin * GK + r + shift) * p.sBk + n0 + c * 8) * 2);  // wraps when the row is negative: never used then
+        rsB[j] = r + shift;
+    }
+    int t_next = t_begin;  // the k-step the next issue() fetches
+    int kq = p.seg ? (t_begin * GK) % p.seg : 0;  // position of the next stage's first k row inside its utterance
+    auto issue = [&](unsigned char* dst) {
+        const unsigned soA = __builtin_amdgcn_readfirstlane((unsigned)t_next * stepA);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (__attribute__((address_space(3))) void*)(dst + (wave + 8 * j) * 1024), 16, voffA[j], soA, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const unsigned v = (unsigned)(kq + rsB[j]) < (unsigned)seg ? voffB[j] : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (__attribute__((address_space(3))) void*)(dst + GOP + (wave + 8 * j) * 1024), 16, v, 0, 0, 0);
+            voffB[j] += stepB;
+        }
+        ++t_next;
+        if (p.seg) { kq += GK; if (kq >= p.seg) kq -= p.seg; }
+    };
+
+    const int wm = wave >> 2, wn = wave & 3;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int fl = (fr >> 2) | ((fg & 1) << 2);
+    const int rowoff = (fg * 8 + (fr >> 2)) * (GT * 2) + (fr & 3) * 8;
+    int aoff[8], boff[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) aoff[i] = rowoff + (((wm * 8 + i) ^ fl) << 5);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) boff[j] = GOP + rowoff + (((wn * 4 + j) ^ fl) << 5);
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](const unsigned char* st) {
+        union Frag { s16x4_t v[2]; bf16x8_t h; };
+        Frag fb[4], fa[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            fb[j].v[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(st + boff[j]));
+            fb[j].v[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(st + boff[j] + 4 * GT * 2));
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            fa[i].v[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(st + aoff[i]));
+            fa[i].v[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(st + aoff[i] + 4 * GT * 2));
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i].h, fb[j].h, acc[i][j], 0, 0, 0);
+    };
+    // stage t has landed once at most the 4 DMAs of stage t+1 are still outstanding; the barrier also frees the stage that
+    // step t-1 was multiplied from, which is where stage t+2 goes
+#define FS2_TN_STEP(cur, nxt2, tv)                                                \
+    {                                                                             \
+        if ((tv) + 1 < nk) __builtin_amdgcn_s_waitcnt(0x0F74); /* vmcnt(4) */      \
+        else __builtin_amdgcn_s_waitcnt(0x0F70);               /* vmcnt(0) */      \
+        __builtin_amdgcn_s_barrier();                                             \
+        if ((tv) + 2 < nk) issue(nxt2);                                           \
+        compute(cur);                                                             \
+    }
+    // steady state with nothing conditional in it (the compiler's own LDS-DMA scoreboard then sees that vmcnt(4) retires the
+    // stage about to be read, and adds no vmcnt(0) of its own in front of the fragment reads); the last 2-4 steps take the
+    // guarded form
+#define FS2_TN_FULL(cur, nxt2)                                                    \
+    {                                                                             \
+        __builtin_amdgcn_s_waitcnt(0x0F74);                                       \
+        __builtin_amdgcn_s_barrier();                                             \
+        issue(nxt2);                                                              \
+        compute(cur);                                                             \
+    }
+    int t = 0;
+    if (nk >= 5) {
+        issue(st0);
+        issue(st1);
+        for (; t + 5 <= nk; t += 3) {
+            FS2_TN_FULL(st0, st2)
+            FS2_TN_FULL(st1, st0)
+            FS2_TN_FULL(st2, st1)
+        }
+    } else {
+        if (nk > 0) issue(st0);
+        if (nk > 1) issue(st1);
+    }
+    for (; t < nk; t += 3) {
+        FS2_TN_STEP(st0, st2, t)
+        if (t + 1 < nk) FS2_TN_STEP(st1, st0, t + 1)
+        if (t + 2 < nk) FS2_TN_STEP(st2, st1, t + 2)
+    }
+#undef FS2_TN_FULL
+#undef FS2_TN_STEP
+
+    if (splitk > 1) {
+        float* ws = p.ws + ((long)(b1 * p.nb2 + b2) * splitk + split) * (long)p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm * 128 + i * 16 + fg * 4 + r, n = n0 + wn * 64 + j * 16 + fr;
+                    ws[(long)m * p.N + n] = acc[i][j][r];
+                }
+        return;
+    }
+    float* C = (float*)p.C + b1 * p.sC1 + b2 * p.sC2;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * 128 + i * 16 + fg * 4 + r, n = n0 + wn * 64 + j * 16 + fr;
+                float* dst = C + (long)m * p.ldc + n;
+                float v = p.alpha * acc[i][j][r] + (p.bias ? p.bias[n] : 0.f);
+                if (p.beta != 0.f) v += p.beta * *dst;
+                *dst = v;
+            }
+#endif
+}
+
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
 
 int g_bgemm_full = 1;  // A/B knob: the bounds-free instantiation for full, aligned tiles
 int g_bgemm_xcd = 1;   // A/B knob: XCD-contiguous tile order of the bf16 kernel
+int g_bgemm_tn256 = 1; // A/B knob: the 256 x 256 LDS-DMA kernel for eligible TN products (fs2_op_bgemm_tn256)
+
+// bf16 TN product in the plain or wgrad form, whole 256 x 256 x 32 tiles, fp32 output, operands inside 32-bit buffer offsets
+bool bgemm_tn256_eligible(const BGemmArgs& a) {
+    if (!g_bgemm_tn256 || a.sAm != 1 || a.sBn != 1 || a.sAk == 1 || a.sBk == 1) return false;
+    if (a.M % GT || a.N % GT || a.K % GK || a.taps > 1 || a.c_dtype != FS2_F32 || a.epi_p) return false;
+    if (a.seg ? (a.seg % GK != 0 || a.K % a.seg != 0) : (a.b_shift0 != 0 || a.b_shift_step != 0)) return false;
+    if (!aligned16(a.A) || !aligned16(a.B) || a.sAk % 8 || a.sBk % 8 || a.sA1 % 8 || a.sA2 % 8 || a.sB1 % 8 || a.sB2 % 8) return false;
+    const long abytes = ((long)(a.K - 1) * a.sAk + a.M) * 2, bbytes = ((long)(a.K - 1) * a.sBk + a.N) * 2;
+    return abytes < 0xFFFFF000L && bbytes < 0xFFFFF000L;
+}
 
 size_t bgemm_ws_bytes(const BGemmArgs& a) {
     return a.splitk > 1 ? (size_t)a.nb1 * a.nb2 * a.splitk * a.M * a.N * sizeof(float) : 0;
@@ -713,6 +903,12 @@ int launch_bgemm(const BGemmArgs& a0, int dtype, hipStream_t stream) {
         if (splitk > 1) hipLaunchKernelGGL(bgemm_reduce_kernel, g2, dim3(256), 0, stream, a);
     } else {
         const bool akc = a.sAk == 1, bkc = a.sBk == 1;
+        if (bgemm_tn256_eligible(a)) {
+            const unsigned nwg = (unsigned)((a.M / GT) * (a.N / GT) * a.nb1 * a.nb2 * splitk);
+            hipLaunchKernelGGL(bgemm_tn256_kernel, dim3(nwg), dim3(512), 0, stream, a);
+            if (splitk > 1) hipLaunchKernelGGL(bgemm_reduce_t_kernel<float>, g2, dim3(256), 0, stream, a);
+            return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
+        }
         // (measured: a win for the TN products - weight gradients, dV, dK: conv1 wgrad 377 -> 350 us, conv2 wgrad 86 -> 67 - and a
         // loss with a k-contiguous A - P V 87 -> 136 us - where the fourth wave per SIMD only adds LDS pressure: TN only)
         const bool full = g_bgemm_full && !akc && a.M % BM == 0 && a.N % BN == 0 && a.K % HBK == 0 && a.vecA && a.vecB && a.taps <= 1 &&

@@ -85,6 +85,7 @@ int fs2_op_set_vocoder_lds_limit(int32_t kib) {
 }
 
 int fs2_op_set_gemm_variant(int32_t variant) {
+    if (variant >= 1000) { fs2::g_bgemm_tn256 = variant - 1000; return FS2_OK; }    // 1000 / 1001: 256 x 256 LDS-DMA kernel for eligible bf16 TN products off / on
     if (variant >= 900) { fs2::attention_bwd_set_blocks(variant - 900 + 1); return FS2_OK; }  // 900 / 901: attention backward, 1 / 2 blocks per wave
     if (variant >= 800) { fs2::g_bgemm_full = variant - 800; return FS2_OK; }       // 800 / 801: bf16 strided-batched GEMM generic instantiation only / bounds-free one for full aligned tiles
     if (variant >= 700) { fs2::g_bgemm_xcd = variant - 700; return FS2_OK; }        // 700 / 701: bf16 strided-batched GEMM tile order plain / XCD-contiguous
@@ -229,6 +230,9 @@ static BGemmArgs bgemm_args(const fs2_bgemm_desc* d, const void* A, const void* 
 }
 size_t fs2_op_bgemm_ws_bytes(const fs2_bgemm_desc* d) {
     return d ? bgemm_ws_bytes(bgemm_args(d, nullptr, nullptr, nullptr, nullptr, nullptr)) : 0;
+}
+int32_t fs2_op_bgemm_tn256(const fs2_bgemm_desc* d) {
+    return d && bgemm_tn256_eligible(bgemm_args(d, nullptr, nullptr, nullptr, nullptr, nullptr)) ? 1 : 0;
 }
 int fs2_op_bgemm(int32_t dtype, const fs2_bgemm_desc* d, const void* A, const void* B, void* C, const float* bias,
                  float* ws, void* stream) {

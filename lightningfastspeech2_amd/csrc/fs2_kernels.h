@@ -323,6 +323,8 @@ struct BGemmArgs {
 size_t bgemm_ws_bytes(const BGemmArgs& a);
 extern int g_bgemm_xcd;
 extern int g_bgemm_full;
+extern int g_bgemm_tn256;
+bool bgemm_tn256_eligible(const BGemmArgs& a);  // bf16 operands only
 int launch_bgemm(const BGemmArgs& a, int dtype, hipStream_t stream);
 
 // Row / column kernels of the backward (backward.hip).  T = activation dtype; gradients of parameters are fp32.

@@ -121,6 +121,15 @@ class _Ops:
                                       self.st()), "bgemm")
         return Cout
 
+    def tn256(self, **kw):
+        """does this bf16 product run on the 256 x 256 tile kernel (include/fs2.h fs2_op_bgemm_tn256)"""
+        d = _lib.BGemmDescC()
+        base = dict(nb1=1, nb2=1, alpha=1.0, beta=0.0, splitk=1, taps=1, c_dtype=F32)
+        base.update(kw)
+        for k, v in base.items():
+            setattr(d, k, v)
+        return bool(self.lib.fs2_op_bgemm_tn256(C.byref(d)))
+
     @staticmethod
     def _dt(t):
         return F32 if t.dtype == torch.float32 else BF16
@@ -192,10 +201,17 @@ class _Ops:
     def wgrad(self, dy, x, dw, db, M, N, Cin, taps=1, S=None):
         """dw (N, taps*Cin) += dy^T x (per tap, rows shifted inside their utterance); db (N) += column sums of dy."""
         pad = (taps - 1) // 2
-        tiles = ((N + 127) // 128) * ((Cin + 127) // 128) * taps
-        splitk = max(1, min(32, -(-2304 // tiles), M // 1024))  # ~9 workgroups per CU (measured: conv1 16, conv2 / in-proj 32)
-        self.bgemm(dy, x, dw, M=N, N=Cin, K=M, sAm=1, sAk=N, sBk=Cin, sBn=1, ldc=taps * Cin, nb2=taps, sC2=Cin,
-                   seg=(S or M) if taps > 1 else 0, b_shift0=-pad, b_shift_step=1, splitk=splitk, beta=1.0)
+        kw = dict(M=N, N=Cin, K=M, sAm=1, sAk=N, sBk=Cin, sBn=1, ldc=taps * Cin, nb2=taps, sC2=Cin,
+                  seg=(S or M) if taps > 1 else 0, b_shift0=-pad, b_shift_step=1, beta=1.0)
+        if dy.dtype == torch.bfloat16 and self.tn256(**kw):
+            # 256 x 256 tiles, one 512-thread workgroup per CU: fill the 256 CUs once (measured: conv1 7 splits = 252 workgroups,
+            # 199 us against 335 on the 128 x 128 kernel; a second, part-filled round costs more than it brings)
+            tiles = (N // 256) * (Cin // 256) * taps
+            splitk = max(1, min(256 // tiles, 48, M // 256))
+        else:
+            tiles = ((N + 127) // 128) * ((Cin + 127) // 128) * taps
+            splitk = max(1, min(32, -(-2304 // tiles), M // 1024))  # ~9 workgroups per CU (measured: conv1 16, conv2 / in-proj 32)
+        self.bgemm(dy, x, dw, splitk=splitk, **kw)
         if db is not None:
             self.col_sum(dy, db, M, N)
 

@@ -544,3 +544,74 @@ def test_bgemm_bf16_full_tile_instantiation(M, N, K, splitk):
     bgemm(dict(M=Nn, N=Cin, K=B * S, sAm=1, sAk=Nn, sBk=Cin, sBn=1, ldc=taps * Cin, nb2=taps, sC2=Cin, seg=S, b_shift0=-2, b_shift_step=1,
                splitk=2), dyd, xd, dw, dtype=BF)
     close(dw, w.grad.permute(0, 2, 1).reshape(Nn, taps * Cin), 1e-5)
+
+
+def _tn256(desc_kw):
+    lib = _lib.load()
+    d = _lib.BGemmDescC()
+    base = dict(nb1=1, nb2=1, alpha=1.0, beta=0.0, splitk=1, taps=1, c_dtype=F32)
+    base.update(desc_kw)
+    for k, v in base.items():
+        setattr(d, k, v)
+    return int(lib.fs2_op_bgemm_tn256(C.byref(d)))
+
+
+@pytest.mark.parametrize("M,N,K,sk", [(256, 256, 32, 1), (256, 512, 96, 1), (512, 256, 160, 2), (256, 256, 1024, 7), (768, 256, 2048, 5),
+                                       (256, 256, 64, 3)])
+def test_bgemm_tn256_plain(M, N, K, sk):
+    """The 256 x 256 LDS-DMA kernel of the bf16 TN products (csrc/bgemm.hip bgemm_tn256_kernel): plain form, direct and
+    split-K (uneven splits, more splits than k-steps), alpha / beta; against fp64 of the bf16-rounded operands, and against
+    the 128 x 128 kernel (knob 1000) on the same inputs."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + N + K + sk)
+    a = torch.randn(K, M, generator=g).to(torch.bfloat16)
+    b = torch.randn(K, N, generator=g).to(torch.bfloat16)
+    want = a.double().t() @ b.double()
+    kw = dict(M=M, N=N, K=K, sAm=1, sAk=M, sBk=N, sBn=1, ldc=N, splitk=sk)
+    assert _tn256(kw) == 1
+    c = torch.full((M, N), 2.0, device=DEV)
+    bgemm(dict(kw, alpha=0.5, beta=3.0), a.to(DEV), b.to(DEV), c, dtype=_lib.FS2_BF16)
+    close(c, 0.5 * want + 6.0, rel=1e-5)
+    try:
+        lib.fs2_op_set_gemm_variant(1000)
+        assert _tn256(kw) == 0
+        c2 = torch.full((M, N), 2.0, device=DEV)
+        bgemm(dict(kw, alpha=0.5, beta=3.0), a.to(DEV), b.to(DEV), c2, dtype=_lib.FS2_BF16)
+    finally:
+        lib.fs2_op_set_gemm_variant(1001)
+    close(c, c2.cpu(), rel=1e-5)
+
+
+@pytest.mark.parametrize("taps,Cin,N,S,B,sk", [(9, 256, 256, 96, 4, 1), (9, 256, 512, 64, 3, 5), (3, 512, 256, 32, 5, 2), (5, 256, 256, 160, 2, 10)])
+def test_bgemm_tn256_wgrad_form(taps, Cin, N, S, B, sk):
+    """... and the wgrad form (tap = batch index, shifted time rows that read as zero outside their utterance, utterance
+    boundaries inside and at the edges of a k-step, splits that start inside an utterance) against autograd of F.conv1d."""
+    g = torch.Generator().manual_seed(taps * 100 + Cin + S)
+    x = torch.randn(B, S, Cin, generator=g).to(torch.bfloat16)
+    dy = torch.randn(B, S, N, generator=g).to(torch.bfloat16)
+    xd64 = x.double().requires_grad_(True)
+    w = torch.zeros(N, Cin, taps, dtype=torch.float64, requires_grad=True)
+    y = F.conv1d(xd64.transpose(1, 2), w, padding="same").transpose(1, 2)
+    y.backward(dy.double())
+    pad = (taps - 1) // 2
+    kw = dict(M=N, N=Cin, K=B * S, sAm=1, sAk=N, sBk=Cin, sBn=1, ldc=taps * Cin, nb2=taps, sC2=Cin, seg=S,
+              b_shift0=-pad, b_shift_step=1, splitk=sk)
+    assert _tn256(kw) == 1
+    dw = torch.zeros(N, taps * Cin, device=DEV)
+    bgemm(kw, dy.reshape(B * S, N).contiguous().to(DEV), x.reshape(B * S, Cin).contiguous().to(DEV), dw, dtype=_lib.FS2_BF16)
+    close(dw, w.grad.permute(0, 2, 1).reshape(N, taps * Cin), rel=1e-5)
+
+
+def test_bgemm_tn256_eligibility():
+    """Shapes the 256-tile kernel must leave to the general one: partial tiles, k-contiguous operands, bf16 output, utterances
+    that are not whole k-steps."""
+    ok = dict(M=256, N=256, K=64, sAm=1, sAk=256, sBk=256, sBn=1, ldc=256)
+    assert _tn256(ok) == 1
+    assert _tn256(dict(ok, M=128)) == 0
+    assert _tn256(dict(ok, N=384, sBk=384, ldc=384)) == 0
+    assert _tn256(dict(ok, K=48)) == 0
+    assert _tn256(dict(ok, sAm=64, sAk=1)) == 0
+    assert _tn256(dict(ok, c_dtype=_lib.FS2_BF16)) == 0
+    assert _tn256(dict(ok, seg=48, K=96)) == 0
+    assert _tn256(dict(ok, seg=32, K=64, nb2=3, b_shift0=-1, b_shift_step=1)) == 1
+    assert _tn256(dict(ok, b_shift0=-1)) == 0

@@ -107,6 +107,30 @@ def bwd_cases(reps):
     bgemm_case("conv1 k=9 dgrad (M,1024)->(M,256)", M * H * k * F, dy, w, dx, reps, M=M, N=H, K=k * F, sAm=F, sAk=1, sBk=k * H, sBn=1,
                ldc=H, seg=1536, taps=k, Kin=F, a_shift0=4, a_shift_step=-1, sBtap=H)
     dw = torch.zeros(F, k * H, device=DEV)
+    # the 256 x 256 LDS-DMA kernel (knob 1001, default) next to the 128 x 128 one (1000) at each one's split counts
+    for sk in (3, 7, 14):
+        bgemm_case(f"conv1 k=9 wgrad tn256 splitk={sk}", M * H * k * F, dy, x, dw, reps, M=F, N=H, K=M, sAm=1, sAk=F, sBk=H, sBn=1, ldc=k * H,
+                   nb2=k, sC2=H, seg=1536, b_shift0=-4, b_shift_step=1, splitk=sk, beta=1.0)
+    dw2_ = torch.zeros(H, F, device=DEV)
+    dyq = torch.randn(M, H, device=DEV).to(bf)
+    for sk in (16, 32, 64):
+        bgemm_case(f"conv2 1x1 wgrad tn256 splitk={sk}", M * H * F, dyq, dy, dw2_, reps, M=H, N=F, K=M, sAm=1, sAk=H, sBk=F, sBn=1, ldc=F, splitk=sk, beta=1.0)
+    dw3_ = torch.zeros(3 * H, H, device=DEV)
+    dy3_ = torch.randn(M, 3 * H, device=DEV).to(bf)
+    for sk in (21, 42, 85):
+        bgemm_case(f"in_proj wgrad tn256 splitk={sk}", M * H * 3 * H, dy3_, x, dw3_, reps, M=3 * H, N=H, K=M, sAm=1, sAk=3 * H, sBk=H, sBn=1, ldc=H, splitk=sk, beta=1.0)
+    # C5 shapes (H 1536, F 6144, 8 x 1536 rows): conv2 1x1 and in-proj weight gradients
+    M5, H5, F5 = 12288, 1536, 6144
+    dy5 = torch.randn(M5, H5, device=DEV).to(bf)
+    x5 = torch.randn(M5, F5, device=DEV).to(bf)
+    dw5 = torch.zeros(H5, F5, device=DEV)
+    for knob in (1001, 1000):
+        lib.fs2_op_set_gemm_variant(knob)
+        for sk in (1, 2, 4):
+            bgemm_case(f"C5 conv2 1x1 wgrad knob={knob} splitk={sk}", M5 * H5 * F5, dy5, x5, dw5, reps, M=H5, N=F5, K=M5, sAm=1, sAk=H5, sBk=F5, sBn=1, ldc=F5, splitk=sk, beta=1.0)
+    lib.fs2_op_set_gemm_variant(1001)
+    del dy5, x5, dw5
+    lib.fs2_op_set_gemm_variant(1000)
     for sk in (1, 4, 8, 16, 32):
         bgemm_case(f"conv1 k=9 wgrad_splitk={sk}", M * H * k * F, dy, x, dw, reps, M=F, N=H, K=M, sAm=1, sAk=F, sBk=H, sBn=1, ldc=k * H,
                    nb2=k, sC2=H, seg=1536, b_shift0=-4, b_shift_step=1, splitk=sk, beta=1.0)
@@ -122,6 +146,7 @@ def bwd_cases(reps):
     dy3 = torch.randn(M, 3 * H, device=DEV).to(bf)
     for sk in (8, 32, 64):
         bgemm_case(f"in_proj wgrad splitk={sk}", M * H * 3 * H, dy3, x3, dw3, reps, M=3 * H, N=H, K=M, sAm=1, sAk=3 * H, sBk=H, sBn=1, ldc=H, splitk=sk, beta=1.0)
+    lib.fs2_op_set_gemm_variant(1001)
     B, S, heads, d = 32, 1536, 2, 128
     qkv = torch.randn(B * S, 3 * H, device=DEV).to(bf)
     sc = torch.empty(B, heads, S, S, device=DEV)
