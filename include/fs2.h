@@ -318,10 +318,16 @@ int fs2_op_attn_delta(int32_t dtype, const void* dout, const void* out, float* d
 int32_t fs2_op_layernorm_bwd_parts(int32_t M);
 int fs2_op_layernorm_bwd(int32_t dtype, const void* z, const void* res, const void* dy, const float* gamma, void* dz,
                          float* part, int32_t M, int32_t H, int32_t relu_mask, void* hip_stream);
-/* out[s][n] (+)= scale * sum over the rows of segment s of x[row][n]; seg = rows per segment (0: one segment) */
+/* out[s][n] (+)= scale * sum over the rows of segment s of x[row][n]; seg = rows per segment (0: one segment).  Per-chunk
+ * partials in ws (fs2_op_col_sum_ws_bytes), added in chunk order (deterministic).  ws starts with 8192 32-bit counters for the
+ * one-launch variant (fs2_op_set_gemm_variant 1101; off by default, measured slower): the caller zeroes them ONCE, when it
+ * allocates ws; every launch leaves them zero again.
+ * fs2_op_col_sum2: one segment, columns [0, n1) to out and [n1, N) to out2, each with its own accumulate flag. */
 size_t fs2_op_col_sum_ws_bytes(int32_t M, int32_t N, int32_t seg);
 int fs2_op_col_sum(int32_t dtype, const void* x, float* out, float* ws, int32_t M, int32_t N, int32_t ldx, int32_t seg,
                    int32_t accumulate, float scale, void* hip_stream);
+int fs2_op_col_sum2(int32_t dtype, const void* x, float* out, float* out2, int32_t n1, float* ws, int32_t M, int32_t N,
+                    int32_t ldx, int32_t accumulate, int32_t accumulate2, float scale, void* hip_stream);
 /* masked softmax over the key axis of (B, heads, S, S) fp32 scores -> probabilities p in the activation dtype (the training
  * path materialises them; p may alias s for FS2_F32), and its backward ds = scale * P o (dP - sum_k dP o P) from fp32 dP */
 int fs2_op_softmax_fwd(int32_t dtype, const float* s, const uint8_t* key_pad, void* p, int32_t B, int32_t heads, int32_t S,

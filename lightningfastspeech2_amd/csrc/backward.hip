@@ -136,10 +136,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(LayerNormBwdArgs p) 
 }
 
 // ---- column sums ----------------------------------------------------------------------------------------------------
-// out[s][n] (+)= scale * sum_{rows of segment s} x[row][n].  Pass 1: a workgroup owns 64 columns x one chunk of CS_CHUNK
-// rows of one segment (4 row groups x 64 lanes, 8 loads in flight per thread, fixed order), partials to ws; pass 2: one
-// workgroup per (64 columns, segment) adds the chunk partials the same way.
+// out[s][n] (+)= scale * sum_{rows of segment s} x[row][n].  Pass 1: a workgroup owns 64 columns x one chunk of CS_CHUNK rows
+// of one segment (4 row groups x 64 lanes, 8 loads in flight per thread, fixed order) and leaves its partial in ws; pass 2:
+// one workgroup per (64 columns, segment) adds the chunk partials the same way.  A one-launch form exists behind a knob
+// (g_colsum_fused: the workgroup that takes the last ticket of its (64 columns, segment) counter does pass 2's work, in chunk
+// order, and returns the counter to zero; the counters are the first CS_CTR words of ws) - measured slower, see the knob.  Columns n >= n1 may go to a second destination (LayerNorm backward: dgamma|dbeta and the
+// producing layer's bias gradient out of one (parts, 3H) array).
 constexpr int CS_CHUNK = 128;
+constexpr int CS_CTR = 8192;
 
 template <typename T>
 __device__ inline float cs_accumulate(const T* x, long ldx, int c, int r0, int r1, int g) {
@@ -154,27 +158,53 @@ __device__ inline float cs_accumulate(const T* x, long ldx, int c, int r0, int r
     return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
 }
 
-template <typename T>
+__device__ inline void cs_store(const ColSumArgs& p, int s, int c, float a) {
+    a *= p.scale;
+    if (p.out2 && c >= p.n1) {
+        float* o = p.out2 + (long)s * (p.N - p.n1) + (c - p.n1);
+        *o = p.accumulate2 ? *o + a : a;
+    } else {
+        float* o = p.out + (long)s * (p.out2 ? p.n1 : p.N) + c;
+        *o = p.accumulate ? *o + a : a;
+    }
+}
+
+// FUSED: the last workgroup of a (column block, segment) finishes the sum; otherwise col_sum_pass2 does
+template <typename T, bool FUSED>
 __global__ __launch_bounds__(256) void col_sum_pass1(ColSumArgs p, int nchunk) {
     __shared__ float red[4][64];
+    __shared__ int last;
     const int l = threadIdx.x & 63, c = blockIdx.x * 64 + l, g = threadIdx.x >> 6;
     const int chunk = blockIdx.y, s = blockIdx.z;
     const int seg = p.seg > 0 ? p.seg : p.M;
     const int r0 = chunk * CS_CHUNK, r1 = min(seg, r0 + CS_CHUNK);
+    float* part = p.ws + CS_CTR;
     red[g][l] = c < p.N ? cs_accumulate<T>((const T*)p.x + (long)s * seg * p.ldx, p.ldx, c, r0, r1, g) : 0.f;
     __syncthreads();
-    if (g == 0 && c < p.N) p.ws[((long)s * nchunk + chunk) * p.N + c] = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+    if (g == 0 && c < p.N) {
+        const float a = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+        if (FUSED && nchunk == 1) cs_store(p, s, c, a);
+        else part[((long)s * nchunk + chunk) * p.N + c] = a;
+    }
+    if (!FUSED || nchunk == 1) return;
+    __threadfence();   // this workgroup's partial is visible device-wide before its ticket is
+    __syncthreads();
+    unsigned* ctr = (unsigned*)p.ws + (s * gridDim.x + blockIdx.x);
+    if (threadIdx.x == 0) last = atomicAdd(ctr, 1u) == (unsigned)(nchunk - 1);
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    red[g][l] = c < p.N ? cs_accumulate<float>(part + (long)s * nchunk * p.N, p.N, c, 0, nchunk, g) : 0.f;
+    __syncthreads();
+    if (g == 0 && c < p.N) cs_store(p, s, c, (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]));
+    if (threadIdx.x == 0) *ctr = 0u;
 }
 __global__ __launch_bounds__(256) void col_sum_pass2(ColSumArgs p, int nchunk) {
     __shared__ float red[4][64];
     const int l = threadIdx.x & 63, c = blockIdx.x * 64 + l, g = threadIdx.x >> 6, s = blockIdx.y;
-    red[g][l] = c < p.N ? cs_accumulate<float>(p.ws + (long)s * nchunk * p.N, p.N, c, 0, nchunk, g) : 0.f;
+    red[g][l] = c < p.N ? cs_accumulate<float>(p.ws + CS_CTR + (long)s * nchunk * p.N, p.N, c, 0, nchunk, g) : 0.f;
     __syncthreads();
-    if (g == 0 && c < p.N) {
-        const float a = ((red[0][l] + red[1][l]) + (red[2][l] + red[3][l])) * p.scale;
-        float* o = p.out + (long)s * p.N + c;
-        *o = p.accumulate ? *o + a : a;
-    }
+    if (g == 0 && c < p.N) cs_store(p, s, c, (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]));
 }
 
 // ---- masked softmax over the key axis (training path: probabilities are materialised; HBM is 288 GB) --------------
@@ -774,17 +804,28 @@ int launch_layernorm_bwd(const LayerNormBwdArgs& a, int dtype, hipStream_t strea
     return ok();
 }
 
+// A/B knob: one-launch column sums (last workgroup reduces) / two launches.  OFF: measured on MI355X the one-launch form costs
+// ~50 us per launch more than it saves (C2 training step 13.5 -> 18.0 ms over its 90 column sums): each workgroup's device-scope
+// __threadfence() is an L2 write-back + invalidate on this 8-XCD part, thousands of them per launch.
+int g_colsum_fused = 0;
 static int cs_chunks(int M, int seg) { return ((seg > 0 ? seg : M) + CS_CHUNK - 1) / CS_CHUNK; }
 size_t col_sum_ws_bytes(int M, int N, int seg) {
     const int nseg = seg > 0 ? M / seg : 1;
-    return (size_t)nseg * cs_chunks(M, seg) * N * sizeof(float);
+    return (size_t)CS_CTR * sizeof(unsigned) + (size_t)nseg * cs_chunks(M, seg) * N * sizeof(float);
 }
 int launch_col_sum(const ColSumArgs& a, int dtype, hipStream_t stream) {
-    if (a.M <= 0 || a.N <= 0 || (a.seg > 0 && a.M % a.seg)) return FS2_ERR_SHAPE;
+    if (a.M <= 0 || a.N <= 0 || (a.seg > 0 && a.M % a.seg) || !a.ws) return FS2_ERR_SHAPE;
+    if (a.out2 && (a.n1 <= 0 || a.n1 >= a.N)) return FS2_ERR_ARG;
     const int nseg = a.seg > 0 ? a.M / a.seg : 1, nchunk = cs_chunks(a.M, a.seg);
     const dim3 g1((a.N + 63) / 64, nchunk, nseg);
-    if (dtype == FS2_BF16) hipLaunchKernelGGL(col_sum_pass1<bf16>, g1, dim3(256), 0, stream, a, nchunk);
-    else hipLaunchKernelGGL(col_sum_pass1<float>, g1, dim3(256), 0, stream, a, nchunk);
+    const bool fused = g_colsum_fused && (long)g1.x * nseg <= CS_CTR;
+    if (fused) {
+        if (dtype == FS2_BF16) hipLaunchKernelGGL((col_sum_pass1<bf16, true>), g1, dim3(256), 0, stream, a, nchunk);
+        else hipLaunchKernelGGL((col_sum_pass1<float, true>), g1, dim3(256), 0, stream, a, nchunk);
+        return ok();
+    }
+    if (dtype == FS2_BF16) hipLaunchKernelGGL((col_sum_pass1<bf16, false>), g1, dim3(256), 0, stream, a, nchunk);
+    else hipLaunchKernelGGL((col_sum_pass1<float, false>), g1, dim3(256), 0, stream, a, nchunk);
     hipLaunchKernelGGL(col_sum_pass2, dim3((a.N + 63) / 64, nseg), dim3(256), 0, stream, a, nchunk);
     return ok();
 }

@@ -684,13 +684,12 @@ __global__ void bgemm_reduce_t_kernel(BGemmArgs p) {
 // zero (the wgrad form's shifted time rows outside their utterance) carry an out-of-range buffer offset.
 constexpr int GT = 256, GK = 32;
 constexpr int GOP = GK * GT * 2;   // bytes per operand per stage
-constexpr int GSTAGE = 2 * GOP;
 
 __global__ __launch_bounds__(512) void bgemm_tn256_kernel(const BGemmArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __shared__ __attribute__((aligned(16))) unsigned char st0[GSTAGE];
-    __shared__ __attribute__((aligned(16))) unsigned char st1[GSTAGE];
-    __shared__ __attribute__((aligned(16))) unsigned char st2[GSTAGE];
+    __shared__ __attribute__((aligned(16))) unsigned char st0[2 * GOP];
+    __shared__ __attribute__((aligned(16))) unsigned char st1[2 * GOP];
+    __shared__ __attribute__((aligned(16))) unsigned char st2[2 * GOP];
     typedef __attribute__((address_space(3))) s16x4_t* lds_v4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -85,6 +85,7 @@ int fs2_op_set_vocoder_lds_limit(int32_t kib) {
 }
 
 int fs2_op_set_gemm_variant(int32_t variant) {
+    if (variant >= 1100) { fs2::g_colsum_fused = variant - 1100; return FS2_OK; }   // 1100 / 1101: column sums in two launches / one
     if (variant >= 1000) { fs2::g_bgemm_tn256 = variant - 1000; return FS2_OK; }    // 1000 / 1001: 256 x 256 LDS-DMA kernel for eligible bf16 TN products off / on
     if (variant >= 900) { fs2::attention_bwd_set_blocks(variant - 900 + 1); return FS2_OK; }  // 900 / 901: attention backward, 1 / 2 blocks per wave
     if (variant >= 800) { fs2::g_bgemm_full = variant - 800; return FS2_OK; }       // 800 / 801: bf16 strided-batched GEMM generic instantiation only / bounds-free one for full aligned tiles
@@ -261,6 +262,13 @@ size_t fs2_op_col_sum_ws_bytes(int32_t M, int32_t N, int32_t seg) { return col_s
 int fs2_op_col_sum(int32_t dtype, const void* x, float* out, float* ws, int32_t M, int32_t N, int32_t ldx, int32_t seg,
                    int32_t accumulate, float scale, void* stream) {
     ColSumArgs a{x, out, ws, M, N, ldx, seg, accumulate, scale};
+    return launch_col_sum(a, dtype, (hipStream_t)stream);
+}
+int fs2_op_col_sum2(int32_t dtype, const void* x, float* out, float* out2, int32_t n1, float* ws, int32_t M, int32_t N, int32_t ldx,
+                    int32_t accumulate, int32_t accumulate2, float scale, void* stream) {
+    ColSumArgs a{x, out, ws, M, N, ldx, 0, accumulate, scale};
+    a.out2 = out2; a.n1 = n1; a.accumulate2 = accumulate2;
+    if (!out2) return FS2_ERR_ARG;
     return launch_col_sum(a, dtype, (hipStream_t)stream);
 }
 int fs2_op_softmax_fwd(int32_t dtype, const float* s, const uint8_t* key_pad, void* p, int32_t B, int32_t heads, int32_t S,

@@ -346,12 +346,16 @@ int launch_layernorm_bwd(const LayerNormBwdArgs& a, int dtype, hipStream_t strea
 struct ColSumArgs {
     const void* x;    // (M, N) in the launch dtype, row stride ldx
     float* out;       // (nseg, N): out[s][n] (+)= scale * sum over the rows of segment s
-    float* ws;        // col_sum_ws_bytes
+    float* ws;        // col_sum_ws_bytes; its first 8192 words are counters: zero before the first launch, left zero by every launch
     int M, N, ldx;
     int seg;          // rows per segment (0 or M: one segment)
     int accumulate;   // 1: out += ...
     float scale;
+    float* out2 = nullptr;  // columns n >= n1 go to out2[s][n - n1] instead (out is then n1 wide)
+    int n1 = 0;
+    int accumulate2 = 0;
 };
+extern int g_colsum_fused;
 size_t col_sum_ws_bytes(int M, int N, int seg);
 int launch_col_sum(const ColSumArgs& a, int dtype, hipStream_t stream);
 

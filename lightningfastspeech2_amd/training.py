@@ -85,7 +85,8 @@ class _Ops:
             return None
         t = self._ws.get(key)
         if t is None or t.numel() * 4 < nbytes:
-            t = self.empty((nbytes + 3) // 4)
+            # zeroed: the column-sum workspace starts with ticket counters that every launch returns to zero (include/fs2.h)
+            t = torch.zeros((nbytes + 3) // 4, dtype=torch.float32, device=self.dev)
             self._ws[key] = t
         return t
 
@@ -138,6 +139,12 @@ class _Ops:
         ws = self.ws("colsum", int(self.lib.fs2_op_col_sum_ws_bytes(M, N, seg)))
         self.ck(self.lib.fs2_op_col_sum(self._dt(x), _p(x), _p(out), _p(ws), M, N, ldx or N, seg, int(accumulate), C.c_float(scale),
                                         self.st()), "col_sum")
+
+    def col_sum2(self, x, out, out2, n1, M, N, ldx=None, accumulate=True, accumulate2=True):
+        """columns [0, n1) of the sums to out, [n1, N) to out2"""
+        ws = self.ws("colsum", int(self.lib.fs2_op_col_sum_ws_bytes(M, N, 0)))
+        self.ck(self.lib.fs2_op_col_sum2(self._dt(x), _p(x), _p(out), _p(out2), n1, _p(ws), M, N, ldx or N, int(accumulate),
+                                         int(accumulate2), C.c_float(1.0), self.st()), "col_sum2")
 
     def relu_bwd(self, dy, y):
         """in place: dy *= (y > 0)"""
@@ -433,6 +440,11 @@ class Trainer:
         o.ck(o.lib.fs2_op_layernorm_bwd(o.dt, _p(z), _p(res), _p(dy), _p(self.P[gname]), _p(dz), _p(part), M, H, int(relu_mask), o.st()),
              "layernorm_bwd")
         gw, gb = self.G[gname], self.G[bname]
+        if gb.data_ptr() == gw.data_ptr() + 4 * H and (bias_name is None) != (bias_out is None):
+            # dgamma | dbeta (adjacent in the flat buffer) and the bias gradient out of one launch
+            o.col_sum2(part, gw, self.G[bias_name] if bias_name is not None else bias_out, 2 * H, nparts, 3 * H,
+                       accumulate2=bias_name is not None)
+            return dz
         if gb.data_ptr() == gw.data_ptr() + 4 * H:
             o.col_sum(part, gw, nparts, 2 * H, ldx=3 * H)
         else:

@@ -136,7 +136,7 @@ def test_layernorm_bwd(M, H, res):
     _lib.check(lib.fs2_op_layernorm_bwd(F32, p(zd), p(rd), p(dyd), p(gd), p(dz), p(part), M, H, 0, st()))
     close(dz, z.grad, 2e-5)
     out = torch.full((1, 3 * H), 1.0, device=DEV)
-    ws = torch.empty(max(1, lib.fs2_op_col_sum_ws_bytes(nparts, 3 * H, 0) // 4), device=DEV)
+    ws = torch.zeros(max(1, lib.fs2_op_col_sum_ws_bytes(nparts, 3 * H, 0) // 4), device=DEV)
     _lib.check(lib.fs2_op_col_sum(F32, p(part), p(out), p(ws), nparts, 3 * H, 3 * H, 0, 1, 1.0, st()))
     close(out[0, :H] - 1.0, gam.grad, 2e-5)
     close(out[0, H:2 * H] - 1.0, bet.grad, 2e-5)
@@ -152,7 +152,7 @@ def test_col_sum_segments():
     lib = _lib.load()
     x = torch.randn(6 * 700, 100)
     out = torch.empty(6, 100, device=DEV)
-    ws = torch.empty(lib.fs2_op_col_sum_ws_bytes(6 * 700, 100, 700) // 4, device=DEV)
+    ws = torch.zeros(lib.fs2_op_col_sum_ws_bytes(6 * 700, 100, 700) // 4, device=DEV)
     xd = x.to(DEV)
     _lib.check(lib.fs2_op_col_sum(F32, p(xd), p(out), p(ws), 6 * 700, 100, 100, 700, 0, 0.5, st()))
     close(out, 0.5 * x.double().view(6, 700, 100).sum(1), 1e-5)
@@ -355,7 +355,7 @@ def test_row_ops_bf16():
     x = _bf(torch.randn(1000, 72, generator=g))
     xd = x.to(DEV)
     out = torch.empty(1, 72, device=DEV)
-    ws = torch.empty(lib.fs2_op_col_sum_ws_bytes(1000, 72, 0) // 4, device=DEV)
+    ws = torch.zeros(lib.fs2_op_col_sum_ws_bytes(1000, 72, 0) // 4, device=DEV)
     _lib.check(lib.fs2_op_col_sum(BF, p(xd), p(out), p(ws), 1000, 72, 72, 0, 0, 1.0, st()))
     close(out[0], x.double().sum(0), 1e-5)
     idx = torch.randint(0, 20, (1000,), generator=g).int()
@@ -615,3 +615,48 @@ def test_bgemm_tn256_eligibility():
     assert _tn256(dict(ok, seg=48, K=96)) == 0
     assert _tn256(dict(ok, seg=32, K=64, nb2=3, b_shift0=-1, b_shift_step=1)) == 1
     assert _tn256(dict(ok, b_shift0=-1)) == 0
+
+
+@pytest.mark.parametrize("fused", [0, 1])
+def test_col_sum_two_destinations_and_one_launch_variant(fused):
+    """Column sums with two destinations and their own accumulate flags, several chunks per column block, bit-equal reruns; in
+    the default two-launch form and the one-launch variant (knob 1101: repeated launches on one workspace - the ticket
+    counters must come back to zero - and the fallback for shapes with more (column block, segment) pairs than counters)."""
+    lib = _lib.load()
+    lib.fs2_op_set_gemm_variant(1100 + fused)
+    try:
+        _col_sum_cases(lib)
+    finally:
+        lib.fs2_op_set_gemm_variant(1100)
+
+
+def _col_sum_cases(lib):
+    g = torch.Generator().manual_seed(11)
+    M, N, n1 = 1000, 3 * 200, 2 * 200
+    x = torch.randn(M, N, generator=g)
+    xd = x.to(DEV)
+    ws = torch.zeros(lib.fs2_op_col_sum_ws_bytes(M, N, 0) // 4, device=DEV)
+    want = x.double().sum(0)
+    first = None
+    for it in range(4):
+        out = torch.ones(n1, device=DEV)
+        out2 = torch.full((N - n1,), 5.0, device=DEV)
+        _lib.check(lib.fs2_op_col_sum2(F32, p(xd), p(out), p(out2), n1, p(ws), M, N, N, 1, 0, 1.0, st()))
+        close(out, want[:n1] + 1.0, 1e-5)
+        close(out2, want[n1:], 1e-5)
+        both = torch.cat([out, out2]).cpu()
+        if first is None:
+            first = both
+        assert torch.equal(both, first)
+        assert not ws[:8192].any()
+        # a different shape on the same workspace in between
+        o3 = torch.empty(72, device=DEV)
+        _lib.check(lib.fs2_op_col_sum(F32, p(xd), p(o3), p(ws), M, 72, N, 0, 0, 2.0, st()))
+        close(o3, 2.0 * want[:72], 1e-5)
+    # more (column block, segment) pairs than counters: 70 column blocks x 120 segments
+    nseg, seg, N2 = 120, 130, 64 * 70
+    x2 = torch.randn(nseg * seg, N2, generator=g)
+    ws2 = torch.zeros(lib.fs2_op_col_sum_ws_bytes(nseg * seg, N2, seg) // 4, device=DEV)
+    out = torch.empty(nseg, N2, device=DEV)
+    _lib.check(lib.fs2_op_col_sum(F32, p(x2.to(DEV)), p(out), p(ws2), nseg * seg, N2, N2, seg, 0, 1.0, st()))
+    close(out, x2.double().view(nseg, seg, N2).sum(1), 1e-5)

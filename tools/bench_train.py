@@ -27,7 +27,11 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--precision", default="fp32")
+    ap.add_argument("--knob", type=int, action="append", default=[], help="fs2_op_set_gemm_variant values (A/B switches)")
     a = ap.parse_args()
+    for k in a.knob:
+        from lightningfastspeech2_amd import _lib
+        _lib.load().fs2_op_set_gemm_variant(k)
     cfg = preset(a.config)
     sd = synth_state_dict(cfg, 0, duration_bias=math.log(7.0), duration_weight_scale=0.0)
     B, L = a.batch, a.phones
