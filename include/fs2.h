@@ -338,9 +338,13 @@ int fs2_op_softmax_bwd(int32_t dtype, const float* dp, const void* p, void* ds, 
  * (ReLU backward)   2: out = alpha*a */
 int fs2_op_ew(int32_t dtype, int32_t op, const void* a, const void* b, void* out, size_t n, float alpha, float beta,
               void* hip_stream);
-/* embedding backward: table[idx[r]] += x[r] for r < R (int32 or int64 indices), row skip_row untouched (padding_idx) */
-int fs2_op_scatter_rows(int32_t dtype, const void* x, const int32_t* idx32, const int64_t* idx64, float* table, int32_t R,
-                        int32_t H, int32_t V, int32_t skip_row, void* hip_stream);
+/* embedding backward: table[idx[r]] += x[r] for r < R (int32 or int64 indices), row skip_row untouched (padding_idx).
+ * ws: fs2_op_scatter_rows_ws_bytes(R, H, V) bytes when that is non-zero (long index lists over tables of <= 256 rows take a
+ * chunked two-phase form; ws follows fs2_op_col_sum's zero-once rule), else NULL; NULL always selects the one-launch kernel.
+ * Either form is deterministic. */
+size_t fs2_op_scatter_rows_ws_bytes(int32_t R, int32_t H, int32_t V);
+int fs2_op_scatter_rows(int32_t dtype, const void* x, const int32_t* idx32, const int64_t* idx64, float* table, float* ws,
+                        int32_t R, int32_t H, int32_t V, int32_t skip_row, void* hip_stream);
 /* LengthRegulator backward: dx[b][p] = sum of dy[b][t] over the frames phone p was repeated to (truncated at T) */
 int fs2_op_regulate_bwd(int32_t dtype, const void* dy, const int32_t* cum, void* dx, int32_t B, int32_t L, int32_t T,
                         int32_t H, void* hip_stream);

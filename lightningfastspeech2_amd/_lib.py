@@ -167,7 +167,9 @@ def load():
     lib.fs2_op_softmax_fwd.argtypes = [i32, vp, vp, vp, i32, i32, i32, f32, vp]
     lib.fs2_op_softmax_bwd.argtypes = [i32, vp, vp, vp, i32, i32, i32, f32, vp]
     lib.fs2_op_ew.argtypes = [i32, i32, vp, vp, vp, sz, f32, f32, vp]
-    lib.fs2_op_scatter_rows.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.fs2_op_scatter_rows_ws_bytes.restype = sz
+    lib.fs2_op_scatter_rows_ws_bytes.argtypes = [i32, i32, i32]
+    lib.fs2_op_scatter_rows.argtypes = [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     lib.fs2_op_regulate_bwd.argtypes = [i32, vp, vp, vp, i32, i32, i32, i32, vp]
     lib.fs2_op_masked_loss_bwd.argtypes = [vp, vp, i32, vp, vp, vp, C.c_int64, i32, i32, f32, vp]
     lib.fs2_op_bucket_embed_utt.argtypes = [i32, vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, vp]

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void col_sum_pass1(ColSumArgs p, int nchunk) {
     __syncthreads();
     if (g == 0 && c < p.N) {
         const float a = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
-        if (FUSED && nchunk == 1) cs_store(p, s, c, a);
+        if (nchunk == 1) cs_store(p, s, c, a);
         else part[((long)s * nchunk + chunk) * p.N + c] = a;
     }
     if (!FUSED || nchunk == 1) return;
@@ -472,6 +472,55 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(ScatterRowsArgs p) {
             if (c < p.H) p.table[(long)v * p.H + c] += acc[j];
         }
     }
+}
+
+// Chunked form for long index lists over small tables (the variance embeddings: 49152 frames into 256 buckets): the
+// one-workgroup-per-table-row kernel above makes every workgroup scan ALL R indices and leaves 256 workgroups to gather
+// 25 MB (132-170 us).  Here a workgroup owns SR_CHUNK source rows x 64 columns and a V x 64 fp32 table in LDS; wave w lists,
+// in ascending order, the chunk's rows whose table row v has v % 4 == w (so every LDS cell has ONE writer, which adds its
+// rows in order: deterministic), gathers them 16 loads at a time and dumps the table as a partial; the partials are then
+// column-summed over the chunks into the table (launch_col_sum, fixed order).
+constexpr int SR_CHUNK = 512, SR_VMAX = 256;
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_rows_part_kernel(ScatterRowsArgs p) {
+    __shared__ float tab[SR_VMAX * 64];
+    __shared__ unsigned hits[4][SR_CHUNK];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int chunk = blockIdx.x, c = blockIdx.y * 64 + lane;
+    const int r0 = chunk * SR_CHUNK;
+    for (int i = threadIdx.x; i < p.V * 64; i += 256) tab[i] = 0.f;
+    int iv[SR_CHUNK / 64];
+#pragma unroll
+    for (int q = 0; q < SR_CHUNK / 64; ++q) {
+        const int r = r0 + q * 64 + lane;
+        iv[q] = r < p.R ? (p.idx32 ? p.idx32[r] : (int)p.idx64[r]) : -1;
+    }
+    int n = 0;
+#pragma unroll
+    for (int q = 0; q < SR_CHUNK / 64; ++q) {
+        const bool m = iv[q] >= 0 && iv[q] < p.V && iv[q] != p.skip_row && (iv[q] & 3) == w;
+        const unsigned long long bal = __ballot(m);
+        if (m) hits[w][n + __popcll(bal & ((1ull << lane) - 1))] = ((unsigned)iv[q] << 16) | (unsigned)(q * 64 + lane);
+        n += __popcll(bal);
+    }
+    __syncthreads();
+    const T* x = (const T*)p.x;
+    for (int h = 0; h < n; h += 16) {
+        float vv[16];
+        unsigned hv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            hv[u] = hits[w][min(h + u, n - 1)];
+            vv[u] = (h + u < n && c < p.H) ? Num<T>::to_f32(x[(long)(r0 + (int)(hv[u] & 0xffffu)) * p.H + c]) : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+            if (h + u < n) tab[(hv[u] >> 16) * 64 + lane] += vv[u];
+    }
+    __syncthreads();
+    float* part = p.ws + (long)chunk * p.V * p.H;
+    if (c < p.H)
+        for (int v = w; v < p.V; v += 4) part[(long)v * p.H + c] = tab[v * 64 + lane];
 }
 
 // ---- length regulator backward: one wave per (b, phone) -----------------------------------------------------------
@@ -826,7 +875,7 @@ int launch_col_sum(const ColSumArgs& a, int dtype, hipStream_t stream) {
     }
     if (dtype == FS2_BF16) hipLaunchKernelGGL((col_sum_pass1<bf16, false>), g1, dim3(256), 0, stream, a, nchunk);
     else hipLaunchKernelGGL((col_sum_pass1<float, false>), g1, dim3(256), 0, stream, a, nchunk);
-    hipLaunchKernelGGL(col_sum_pass2, dim3((a.N + 63) / 64, nseg), dim3(256), 0, stream, a, nchunk);
+    if (nchunk > 1) hipLaunchKernelGGL(col_sum_pass2, dim3((a.N + 63) / 64, nseg), dim3(256), 0, stream, a, nchunk);
     return ok();
 }
 
@@ -882,8 +931,22 @@ int launch_ew(const EwArgs& a0, int dtype, hipStream_t stream) {
     return ok();
 }
 
+static bool scatter_chunked(int R, int V) { return V <= SR_VMAX && R >= 4 * SR_CHUNK; }
+size_t scatter_rows_ws_bytes(int R, int H, int V) {
+    if (!scatter_chunked(R, V)) return 0;
+    const int nchunk = (R + SR_CHUNK - 1) / SR_CHUNK;
+    return (size_t)nchunk * V * H * sizeof(float) + col_sum_ws_bytes(nchunk, V * H, 0);
+}
 int launch_scatter_rows(const ScatterRowsArgs& a, int dtype, hipStream_t stream) {
     if (a.R <= 0 || a.V <= 0 || (!a.idx32 && !a.idx64)) return FS2_ERR_ARG;
+    if (a.ws && scatter_chunked(a.R, a.V)) {
+        const int nchunk = (a.R + SR_CHUNK - 1) / SR_CHUNK;
+        const dim3 g(nchunk, (a.H + 63) / 64);
+        if (dtype == FS2_BF16) hipLaunchKernelGGL(scatter_rows_part_kernel<bf16>, g, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL(scatter_rows_part_kernel<float>, g, dim3(256), 0, stream, a);
+        ColSumArgs cs{a.ws, a.table, a.ws + (size_t)nchunk * a.V * a.H, nchunk, a.V * a.H, a.V * a.H, 0, 1, 1.f};
+        return launch_col_sum(cs, FS2_F32, stream);
+    }
     if (dtype == FS2_BF16) hipLaunchKernelGGL(scatter_rows_kernel<bf16>, dim3(a.V), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL(scatter_rows_kernel<float>, dim3(a.V), dim3(256), 0, stream, a);
     return ok();

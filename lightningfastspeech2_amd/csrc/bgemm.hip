@@ -862,7 +862,7 @@ int g_bgemm_tn256 = 1; // A/B knob: the 256 x 256 LDS-DMA kernel for eligible TN
 bool bgemm_tn256_eligible(const BGemmArgs& a) {
     if (!g_bgemm_tn256 || a.sAm != 1 || a.sBn != 1 || a.sAk == 1 || a.sBk == 1) return false;
     if (a.M % GT || a.N % GT || a.K % GK || a.taps > 1 || a.c_dtype != FS2_F32 || a.epi_p) return false;
-    if (a.seg ? (a.seg % GK != 0 || a.K % a.seg != 0) : (a.b_shift0 != 0 || a.b_shift_step != 0)) return false;
+    if (a.seg && (a.seg % GK != 0 || a.K % a.seg != 0)) return false;  // (seg == 0: the k shifts are not applied, as in the general kernel)
     if (!aligned16(a.A) || !aligned16(a.B) || a.sAk % 8 || a.sBk % 8 || a.sA1 % 8 || a.sA2 % 8 || a.sB1 % 8 || a.sB2 % 8) return false;
     const long abytes = ((long)(a.K - 1) * a.sAk + a.M) * 2, bbytes = ((long)(a.K - 1) * a.sBk + a.N) * 2;
     return abytes < 0xFFFFF000L && bbytes < 0xFFFFF000L;

@@ -286,9 +286,10 @@ int fs2_op_ew(int32_t dtype, int32_t op, const void* a_, const void* b, void* ou
     EwArgs a{a_, b, out, n, alpha, beta, op};
     return launch_ew(a, dtype, (hipStream_t)stream);
 }
-int fs2_op_scatter_rows(int32_t dtype, const void* x, const int32_t* idx32, const int64_t* idx64, float* table, int32_t R,
+size_t fs2_op_scatter_rows_ws_bytes(int32_t R, int32_t H, int32_t V) { return scatter_rows_ws_bytes(R, H, V); }
+int fs2_op_scatter_rows(int32_t dtype, const void* x, const int32_t* idx32, const int64_t* idx64, float* table, float* ws, int32_t R,
                         int32_t H, int32_t V, int32_t skip_row, void* stream) {
-    ScatterRowsArgs a{x, idx32, idx64, table, R, H, V, skip_row};
+    ScatterRowsArgs a{x, idx32, idx64, table, R, H, V, skip_row, ws};
     return launch_scatter_rows(a, dtype, (hipStream_t)stream);
 }
 int fs2_op_regulate_bwd(int32_t dtype, const void* dy, const int32_t* cum, void* dx, int32_t B, int32_t L, int32_t T,

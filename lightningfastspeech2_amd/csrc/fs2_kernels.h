@@ -387,7 +387,9 @@ struct ScatterRowsArgs {     // table[idx[r]] += scale * x[r]  (embedding backwa
     float* table;            // (V, H) accumulated into
     int R, H, V;
     int skip_row;            // table row that receives no gradient (padding_idx), -1 = none
+    float* ws = nullptr;     // scatter_rows_ws_bytes (0: not needed) or null: the one-launch kernel
 };
+size_t scatter_rows_ws_bytes(int R, int H, int V);
 int launch_scatter_rows(const ScatterRowsArgs& a, int dtype, hipStream_t stream);
 
 struct RegulateBwdArgs {     // d_phone[b][p] = sum of d_frame[b][t] over the frames phone p was repeated to (t < T)

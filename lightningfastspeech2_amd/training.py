@@ -146,6 +146,12 @@ class _Ops:
         self.ck(self.lib.fs2_op_col_sum2(self._dt(x), _p(x), _p(out), _p(out2), n1, _p(ws), M, N, ldx or N, int(accumulate),
                                          int(accumulate2), C.c_float(1.0), self.st()), "col_sum2")
 
+    def scatter_rows(self, x, idx32, idx64, table, R, H, V, skip_row):
+        """embedding backward: table[idx[r]] += x[r]"""
+        ws = self.ws("scatter", int(self.lib.fs2_op_scatter_rows_ws_bytes(R, H, V)))
+        self.ck(self.lib.fs2_op_scatter_rows(self._dt(x), _p(x), _p(idx32), _p(idx64), _p(table), _p(ws), R, H, V, skip_row, self.st()),
+                "scatter_rows")
+
     def relu_bwd(self, dy, y):
         """in place: dy *= (y > 0)"""
         self.ck(self.lib.fs2_op_ew(self._dt(dy), 1, _p(dy), _p(y), _p(dy), dy.numel(), C.c_float(0), C.c_float(0), self.st()), "relu_bwd")
@@ -730,8 +736,7 @@ class Trainer:
             for vi in reversed(range(nv)):
                 v = cfg.variances[vi]
                 pfx = f"variance_adaptor.encoders.{v}"
-                o.ck(o.lib.fs2_op_scatter_rows(o.dt, _p(dx), _p(var_idx[v]), None, _p(G[f"{pfx}.embedding.weight"]), B * T, H, cfg.variance_nbins,
-                                               -1, o.st()), "scatter_rows")
+                o.scatter_rows(dx, var_idx[v], None, G[f"{pfx}.embedding.weight"], B * T, H, cfg.variance_nbins, -1)
                 self._predictor_bwd(dvar[v], var_tape[v], f"{pfx}.predictor", cfg.variance_nlayers[vi], cfg.variance_filter_size,
                                     cfg.variance_kernel_size[vi], B, T, dx, dw=cfg.variance_depthwise_conv)
             dxe = o.act(B * L, H)
@@ -744,8 +749,7 @@ class Trainer:
                 for pr in cfg.priors:
                     pfx = f"prior_embeddings.{pr}"
                     tmp = torch.zeros(cfg.variance_nbins, H, device=dev)
-                    o.ck(o.lib.fs2_op_scatter_rows(F32, _p(seg), _p(prior_idx[pr]), None, _p(tmp), B, H, cfg.variance_nbins, -1, o.st()),
-                         "scatter_rows")
+                    o.scatter_rows(seg, prior_idx[pr], None, tmp, B, H, cfg.variance_nbins, -1)
                     o.relu_bwd(tmp, P[f"{pfx}.embedding.weight"])
                     o.add_(G[f"{pfx}.embedding.weight"], tmp)
             for i in reversed(range(cfg.encoder_layers)):
@@ -753,8 +757,7 @@ class Trainer:
                                       cfg.encoder_kernel_sizes[i])
             o.col_sum(dxe, dspk, B * L, H, seg=L)
             o.dropout(dxe, self.p_enc, k_pe_enc)
-            o.ck(o.lib.fs2_op_scatter_rows(o.dt, _p(dxe), None, _p(phones), _p(G["phone_embedding.weight"]), B * L, H, cfg.n_phones, 0, o.st()),
-                 "scatter_rows")
+            o.scatter_rows(dxe, None, phones, G["phone_embedding.weight"], B * L, H, cfg.n_phones, 0)
             o.relu_bwd(dspk, spk)  # spk = relu(W dvec + b), model.py:137-143
             o.wgrad(dspk, dvec, G["speaker_embedding.projection.weight"], G["speaker_embedding.projection.bias"], B, H, dvec.shape[1])
         self._accum += 1

@@ -188,7 +188,7 @@ def test_scatter_rows_and_regulate_bwd():
         i32 = idx.int().to(DEV) if kind == "i32" else None
         i64 = idx.to(DEV) if kind == "i64" else None
         xd = x.to(DEV)
-        _lib.check(lib.fs2_op_scatter_rows(F32, p(xd), p(i32), p(i64), p(table), R, H, V, 0, st()))
+        _lib.check(lib.fs2_op_scatter_rows(F32, p(xd), p(i32), p(i64), p(table), None, R, H, V, 0, st()))
         want = torch.ones(V, H, dtype=torch.float64).index_add_(0, idx, x.double())
         want[0] = 1.0
         close(table, want, 1e-5)
@@ -361,7 +361,7 @@ def test_row_ops_bf16():
     idx = torch.randint(0, 20, (1000,), generator=g).int()
     table = torch.zeros(20, 72, device=DEV)
     idxd = idx.to(DEV)
-    _lib.check(lib.fs2_op_scatter_rows(BF, p(xd), p(idxd), None, p(table), 1000, 72, 20, -1, st()))
+    _lib.check(lib.fs2_op_scatter_rows(BF, p(xd), p(idxd), None, p(table), None, 1000, 72, 20, -1, st()))
     close(table, torch.zeros(20, 72, dtype=torch.float64).index_add_(0, idx.long(), x.double()), 1e-5)
     y = _bf(torch.randn(1000, 72, generator=g)).to(DEV)
     o2 = torch.empty_like(xd)
@@ -614,7 +614,7 @@ def test_bgemm_tn256_eligibility():
     assert _tn256(dict(ok, c_dtype=_lib.FS2_BF16)) == 0
     assert _tn256(dict(ok, seg=48, K=96)) == 0
     assert _tn256(dict(ok, seg=32, K=64, nb2=3, b_shift0=-1, b_shift_step=1)) == 1
-    assert _tn256(dict(ok, b_shift0=-1)) == 0
+    assert _tn256(dict(ok, b_shift0=0, b_shift_step=1)) == 1   # no utterance length: the shifts are not applied
 
 
 @pytest.mark.parametrize("fused", [0, 1])
@@ -660,3 +660,36 @@ def _col_sum_cases(lib):
     out = torch.empty(nseg, N2, device=DEV)
     _lib.check(lib.fs2_op_col_sum(F32, p(x2.to(DEV)), p(out), p(ws2), nseg * seg, N2, N2, seg, 0, 1.0, st()))
     close(out, x2.double().view(nseg, seg, N2).sum(1), 1e-5)
+
+
+@pytest.mark.parametrize("R,H,V,skip,dtype", [(5000, 72, 40, 0, "fp32"), (2048, 256, 256, -1, "bf16"), (9000, 200, 3, 2, "bf16"),
+                                              (4097, 64, 255, -1, "fp32")])
+def test_scatter_rows_chunked_form(R, H, V, skip, dtype):
+    """The two-phase embedding backward (chunk x 64-column LDS tables, then a column sum over the chunks): ragged last chunk,
+    column tail, skewed and out-of-range indices, padding row, int32 / int64 indices; bit-equal reruns; against index_add_."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(R + V)
+    idx = torch.randint(0, V, (R,), generator=g)
+    idx[::7] = V - 1                       # one heavy table row
+    idx[5] = -1
+    idx[6] = V + 3                         # ignored, as the one-launch kernel does (no workgroup owns them)
+    x = torch.randn(R, H, generator=g)
+    if dtype == "bf16":
+        x = x.to(torch.bfloat16)
+    xd = x.to(DEV)
+    nbytes = lib.fs2_op_scatter_rows_ws_bytes(R, H, V)
+    assert nbytes > 0
+    ws = torch.zeros(nbytes // 4, device=DEV)
+    keep = (idx >= 0) & (idx < V) & (idx != skip)
+    want = torch.ones(V, H, dtype=torch.float64).index_add_(0, idx[keep], x.double()[keep])
+    first = None
+    for kind in ("i32", "i64", "i32"):
+        table = torch.ones(V, H, device=DEV)
+        i32 = idx.int().to(DEV) if kind == "i32" else None
+        i64 = idx.to(DEV) if kind == "i64" else None
+        _lib.check(lib.fs2_op_scatter_rows(_lib.FS2_BF16 if dtype == "bf16" else F32, p(xd), p(i32), p(i64), p(table), p(ws), R, H, V, skip, st()))
+        close(table, want, 1e-5)
+        if first is None:
+            first = table.clone()
+        assert torch.equal(table, first)
+    assert lib.fs2_op_scatter_rows_ws_bytes(100, H, V) == 0 and lib.fs2_op_scatter_rows_ws_bytes(R, H, 300) == 0
