@@ -382,6 +382,10 @@ int fs2_op_unfold_conv2(const float* dWf, const float* dbf, const float* G, cons
 /* the data-gradient kernel of a Conv1d / Linear: dst (Cin, taps*N), dst[ci][j'*N + n] = src[n][(taps-1-j')*Cin + ci] for
  * src (N, taps*Cin) tap-major, so that dX = fs2_op_gemm(x = dY, w = dst, M, N = Cin, Cin = N, taps, S) */
 int fs2_op_transpose_weight(int32_t dtype, const void* src, void* dst, int32_t N, int32_t Cin, int32_t taps, void* hip_stream);
+/* ... for many bf16 weights in one launch: table_dev = n rows of 6 int64 ON THE DEVICE, {src, dst, N, Cin, taps, first tile},
+ * a weight owning fs2_op_transpose_weight_tiles(N, Cin, taps) consecutive tiles from its first tile; tiles = their total */
+int64_t fs2_op_transpose_weight_tiles(int32_t N, int32_t Cin, int32_t taps);
+int fs2_op_transpose_weight_batch(const int64_t* table_dev, int32_t n, int64_t tiles, void* hip_stream);
 /* out[0] = sum of squares of x (fp64 partials, fixed order) */
 size_t fs2_op_sum_sq_ws_bytes(size_t n);
 int fs2_op_sum_sq(const float* x, size_t n, float* ws, float* out, void* hip_stream);
@@ -390,6 +394,10 @@ int fs2_op_sum_sq(const float* x, size_t n, float* ws, float* out, void* hip_str
 int fs2_op_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps,
                  float weight_decay, int32_t step, const float* gnorm_sq, float max_norm, float grad_scale,
                  void* hip_stream);
+/* ... that also writes the updated weights rounded to bf16 (shadow_bf16, n elements: the mixed-precision path's operands) */
+int fs2_op_adamw_shadow(float* p, const float* g, float* m, float* v, void* shadow_bf16, size_t n, float lr, float beta1,
+                        float beta2, float eps, float weight_decay, int32_t step, const float* gnorm_sq, float max_norm,
+                        float grad_scale, void* hip_stream);
 /* teacher-forced VarianceEncoder embedding (model.py:417-422): y = x + Emb[bucketize(target * std + mean)] (+ pe + spk) */
 int fs2_op_bucket_embed_target(int32_t dtype, const void* x, const float* target, const float* bins, const float* emb,
                                int32_t nbins, float std, float mean, const float* pe, const float* spk, void* y,

@@ -186,6 +186,10 @@ def load():
     lib.fs2_op_sum_sq_ws_bytes.argtypes = [sz]
     lib.fs2_op_sum_sq.argtypes = [vp, sz, vp, vp, vp]
     lib.fs2_op_adamw.argtypes = [vp, vp, vp, vp, sz, f32, f32, f32, f32, f32, i32, vp, f32, f32, vp]
+    lib.fs2_op_adamw_shadow.argtypes = [vp, vp, vp, vp, vp, sz, f32, f32, f32, f32, f32, i32, vp, f32, f32, vp]
+    lib.fs2_op_transpose_weight_tiles.restype = C.c_int64
+    lib.fs2_op_transpose_weight_tiles.argtypes = [i32, i32, i32]
+    lib.fs2_op_transpose_weight_batch.argtypes = [vp, i32, C.c_int64, vp]
     lib.fs2_op_bucket_embed_target.argtypes = [i32, vp, vp, vp, vp, i32, f32, f32, vp, vp, vp, vp, i32, i32, i32, vp]
     if lib.fs2_abi_version() != FS2_ABI_VERSION:
         raise Fs2LibraryError("libfs2_hip.so ABI version mismatch")

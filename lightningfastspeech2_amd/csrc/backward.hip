@@ -590,7 +590,18 @@ __global__ void sum_sq_pass2(const float* ws, int nb, float* out) {
 
 // torch.optim.AdamW (fastspeech2.py:1166-1173): decoupled weight decay, bias-corrected moments; the gradient is first
 // scaled by grad_scale and by the global-norm clip coefficient min(1, max_norm / (norm + 1e-6)) (clip_grad_norm_).
-__global__ void adamw_kernel(AdamWArgs p) {
+__device__ inline float adamw_one(const AdamWArgs& p, float& w, float g, float& m, float& v, float gs, float step_size, float inv_sqrt_bc2) {
+    g *= gs;
+    w *= 1.f - p.lr * p.weight_decay;
+    m = p.beta1 * m + (1.f - p.beta1) * g;
+    v = p.beta2 * v + (1.f - p.beta2) * g * g;
+    w -= step_size * m / (sqrtf(v) * inv_sqrt_bc2 + p.eps);
+    return w;
+}
+// Four elements per thread per pass (16-byte accesses; the buffers are torch allocations, n's tail goes element by element);
+// with `shadow` the new weights are also written in bf16 - the mixed-precision path's MFMA operands - instead of a separate
+// convert pass re-reading all of p.
+__global__ __launch_bounds__(256) void adamw_kernel(AdamWArgs p) {
     float gs = p.grad_scale;
     if (p.gnorm_sq) {
         const float norm = sqrtf(*p.gnorm_sq) * p.grad_scale;
@@ -599,15 +610,30 @@ __global__ void adamw_kernel(AdamWArgs p) {
     }
     const float bc1 = 1.f - powf(p.beta1, (float)p.step), bc2 = 1.f - powf(p.beta2, (float)p.step);
     const float step_size = p.lr / bc1, inv_sqrt_bc2 = 1.f / sqrtf(bc2);
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < p.n; e += (size_t)gridDim.x * blockDim.x) {
-        const float g = p.g[e] * gs;
-        float w = p.p[e] * (1.f - p.lr * p.weight_decay);
-        const float m = p.beta1 * p.m[e] + (1.f - p.beta1) * g;
-        const float v = p.beta2 * p.v[e] + (1.f - p.beta2) * g * g;
+    const size_t n4 = p.n / 4, stride = (size_t)gridDim.x * blockDim.x, tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bf16* sh = (bf16*)p.shadow;
+    for (size_t q = tid; q < n4; q += stride) {
+        float4 w = ((float4*)p.p)[q], m = ((float4*)p.m)[q], v = ((float4*)p.v)[q];
+        const float4 g = ((const float4*)p.g)[q];
+        adamw_one(p, w.x, g.x, m.x, v.x, gs, step_size, inv_sqrt_bc2);
+        adamw_one(p, w.y, g.y, m.y, v.y, gs, step_size, inv_sqrt_bc2);
+        adamw_one(p, w.z, g.z, m.z, v.z, gs, step_size, inv_sqrt_bc2);
+        adamw_one(p, w.w, g.w, m.w, v.w, gs, step_size, inv_sqrt_bc2);
+        ((float4*)p.p)[q] = w;
+        ((float4*)p.m)[q] = m;
+        ((float4*)p.v)[q] = v;
+        if (sh) {
+            const float o[4] = {w.x, w.y, w.z, w.w};
+            *(uint2*)(sh + 4 * q) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+        }
+    }
+    for (size_t e = 4 * n4 + tid; e < p.n; e += stride) {
+        float w = p.p[e], m = p.m[e], v = p.v[e];
+        adamw_one(p, w, p.g[e], m, v, gs, step_size, inv_sqrt_bc2);
+        p.p[e] = w;
         p.m[e] = m;
         p.v[e] = v;
-        w -= step_size * m / (sqrtf(v) * inv_sqrt_bc2 + p.eps);
-        p.p[e] = w;
+        if (sh) sh[e] = Num<bf16>::from_f32(w);
     }
 }
 
@@ -625,6 +651,54 @@ __global__ __launch_bounds__(256) void transpose_weight_kernel(TransposeWeightAr
     __syncthreads();
     for (int r = ty; r < 32; r += 8)
         if (c0 + r < p.Cin && n0 + tx < p.N) dst[(long)(c0 + r) * p.taps * p.N + n0 + tx] = tile[tx][r];
+}
+
+// All of a model's data-gradient weights in ONE launch (the per-weight launches above are 72 per optimizer step at C2, 157 at
+// C5): tab = n rows of {src, dst, N, Cin, taps, first tile}, 64 x 64 tiles moved as bf16 pairs.
+__global__ __launch_bounds__(256) void transpose_weight_batch_kernel(const long long* __restrict__ tab, int n) {
+    __shared__ unsigned short tile[64][66];
+    int lo = 0, hi = n - 1;
+    const long long b = blockIdx.x;
+    while (lo < hi) {  // last row whose first tile is <= b
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[mid * 6 + 5] <= b) lo = mid; else hi = mid - 1;
+    }
+    const long long* d = tab + lo * 6;
+    const unsigned short* src = (const unsigned short*)d[0];
+    unsigned short* dst = (unsigned short*)d[1];
+    const int N = (int)d[2], Cin = (int)d[3], taps = (int)d[4];
+    int t = (int)(b - d[5]);
+    const int tc = (Cin + 63) / 64, tn = (N + 63) / 64;
+    const int c0 = (t % tc) * 64; t /= tc;
+    const int n0 = (t % tn) * 64, tap = t / tn;
+    src += (long)tap * Cin;
+    dst += (long)(taps - 1 - tap) * N;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const bool pair_in = (Cin & 1) == 0 && (((uintptr_t)src) & 3) == 0, pair_out = (N & 1) == 0 && (((uintptr_t)dst) & 3) == 0;
+    for (int r = ty; r < 64; r += 8) {
+        const int nn = n0 + r, c = c0 + 2 * tx;
+        if (nn >= N) continue;
+        const unsigned short* s = src + (long)nn * taps * Cin + c;
+        if (pair_in && c + 1 < Cin) {
+            const unsigned v = *(const unsigned*)s;
+            tile[r][2 * tx] = (unsigned short)v;
+            tile[r][2 * tx + 1] = (unsigned short)(v >> 16);
+        } else {
+            if (c < Cin) tile[r][2 * tx] = s[0];
+            if (c + 1 < Cin) tile[r][2 * tx + 1] = s[1];
+        }
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 8) {
+        const int c = c0 + r, nn = n0 + 2 * tx;
+        if (c >= Cin) continue;
+        unsigned short* o = dst + (long)c * taps * N + nn;
+        if (pair_out && nn + 1 < N) *(unsigned*)o = (unsigned)tile[2 * tx][r] | ((unsigned)tile[2 * tx + 1][r] << 16);
+        else {
+            if (nn < N) o[0] = tile[2 * tx][r];
+            if (nn + 1 < N) o[1] = tile[2 * tx + 1][r];
+        }
+    }
 }
 
 // ---- depth-wise conv weight gradient -------------------------------------------------------------------------------
@@ -837,6 +911,12 @@ int launch_transpose_weight(const TransposeWeightArgs& a, int dtype, hipStream_t
     if (dtype == FS2_BF16) hipLaunchKernelGGL(transpose_weight_kernel<bf16>, g, dim3(256), 0, stream, a);
     else if (dtype == FS2_F32) hipLaunchKernelGGL(transpose_weight_kernel<float>, g, dim3(256), 0, stream, a);
     else return FS2_ERR_SHAPE;
+    return ok();
+}
+
+int launch_transpose_weight_batch(const long long* tab, int n, long long tiles, hipStream_t stream) {
+    if (!tab || n <= 0 || tiles <= 0 || tiles > 0x7fffffffLL) return FS2_ERR_ARG;
+    hipLaunchKernelGGL(transpose_weight_batch_kernel, dim3((unsigned)tiles), dim3(256), 0, stream, tab, n);
     return ok();
 }
 

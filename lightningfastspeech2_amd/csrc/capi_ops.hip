@@ -353,6 +353,18 @@ int fs2_op_adamw(float* p, const float* g, float* m, float* v, size_t n, float l
     AdamWArgs a{p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, gnorm_sq, max_norm, grad_scale};
     return launch_adamw(a, (hipStream_t)stream);
 }
+int fs2_op_adamw_shadow(float* p, const float* g, float* m, float* v, void* shadow_bf16, size_t n, float lr, float beta1, float beta2,
+                        float eps, float weight_decay, int32_t step, const float* gnorm_sq, float max_norm, float grad_scale,
+                        void* stream) {
+    AdamWArgs a{p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, gnorm_sq, max_norm, grad_scale, shadow_bf16};
+    return launch_adamw(a, (hipStream_t)stream);
+}
+int64_t fs2_op_transpose_weight_tiles(int32_t N, int32_t Cin, int32_t taps) {
+    return (int64_t)((N + 63) / 64) * ((Cin + 63) / 64) * taps;
+}
+int fs2_op_transpose_weight_batch(const int64_t* table_dev, int32_t n, int64_t tiles, void* stream) {
+    return launch_transpose_weight_batch((const long long*)table_dev, n, tiles, (hipStream_t)stream);
+}
 int fs2_op_bucket_embed_target(int32_t dtype, const void* x, const float* target, const float* bins, const float* emb,
                                int32_t nbins, float std, float mean, const float* pe, const float* spk, void* y,
                                int32_t* idx_out, int32_t B, int32_t T, int32_t H, void* stream) {

@@ -477,6 +477,7 @@ struct TransposeWeightArgs {   // dst (Cin, taps*N) [ci][j'*N + n] = src (N, tap
     int N, Cin, taps;
 };
 int launch_transpose_weight(const TransposeWeightArgs& a, int dtype, hipStream_t stream);
+int launch_transpose_weight_batch(const long long* tab, int n, long long tiles, hipStream_t stream);  // bf16; tab on the device
 
 struct AdamWArgs {
     float* p; const float* g; float* m; float* v;   // flat fp32 buffers of n elements
@@ -486,6 +487,7 @@ struct AdamWArgs {
     const float* gnorm_sq;   // device scalar: sum of squares of g (null = no clipping)
     float max_norm;          // clip the global norm to this (gradient_clip_val)
     float grad_scale;        // g is multiplied by this first (1 / accumulated micro-batches)
+    void* shadow = nullptr;  // (n) bf16 or null: the updated weights again, rounded to bf16
 };
 int launch_adamw(const AdamWArgs& a, hipStream_t stream);
 size_t sum_sq_ws_bytes(size_t n);

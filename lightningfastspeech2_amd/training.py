@@ -291,6 +291,7 @@ class Trainer:
         self.use_forward_dgrad = os.environ.get("FS2_TRAIN_DGRAD", "forward") == "forward"
         self.flat_wt = torch.zeros(off, device=self.dev, dtype=self.ops.tdt)
         self.WT = {}
+        self._tw_table = None
         for n, (o, ks, rs) in self._layout.items():
             gemm_w = n.endswith("weight") and "embedding" not in n and (
                 len(rs) == 2 or (len(rs) == 3 and rs[1] > 1 and ".conv2.0." not in n))  # not LayerNorm (1-D), depth-wise or grouped convs
@@ -330,22 +331,37 @@ class Trainer:
                 self.buffers[name] = t.reshape(-1, t.shape[-1]).contiguous().to(self.dev) if name.endswith(".pe") else t.contiguous().to(self.dev)
         self._refresh_shadow()
 
-    def _refresh_shadow(self):
+    def _refresh_shadow(self, converted=False):
+        """bf16 weight shadow (unless the optimizer step has just written it), folded depth-wise conv2 maps, and the transposed
+        tap-flipped weights the data gradients run on - all of those in one launch for bf16."""
         o = self.ops
         with torch.cuda.device(self.dev):
-            if o.dt != F32:
+            if o.dt != F32 and not converted:
                 o.ck(o.lib.fs2_op_convert(F32, o.dt, _p(self.flat_p), _p(self.flat_w), self.n_flat, o.st()), "convert")
             for pfx, f in self.fold.items():
                 Hh, Ff = f["Wf"].shape
                 o.ck(o.lib.fs2_op_fold_conv2(o.dt, _p(self.P[f"{pfx}.conv2.0.weight"]), _p(self.P[f"{pfx}.conv2.0.bias"]),
                                              _p(self.P[f"{pfx}.conv2.1.weight"]), _p(self.P[f"{pfx}.conv2.1.bias"]), _p(f["Wf"]), _p(f["bf"]),
                                              Hh, Ff, o.st()), "fold_conv2")
-                o.ck(o.lib.fs2_op_transpose_weight(o.dt, _p(f["Wf"]), _p(f["WfT"]), Hh, Ff, 1, o.st()), "transpose_weight")
+            jobs = [(f["Wf"], f["WfT"], f["Wf"].shape[0], f["Wf"].shape[1], 1) for f in self.fold.values()]
             if self.use_forward_dgrad:
                 for n, wt in self.WT.items():
                     _, _, rs = self._layout[n]
-                    taps = rs[2] if len(rs) == 3 else 1
-                    o.ck(o.lib.fs2_op_transpose_weight(o.dt, _p(self.W[n]), _p(wt), rs[0], rs[1], taps, o.st()), "transpose_weight")
+                    jobs.append((self.W[n], wt, rs[0], rs[1], rs[2] if len(rs) == 3 else 1))
+            if not jobs:
+                return
+            if o.dt == F32 or os.environ.get("FS2_TRAIN_TW_BATCH", "1") == "0":  # (A/B switch)
+                for src, dst, N, Cin, taps in jobs:
+                    o.ck(o.lib.fs2_op_transpose_weight(o.dt, _p(src), _p(dst), N, Cin, taps, o.st()), "transpose_weight")
+                return
+            if self._tw_table is None:  # the buffers never move: build the device table once
+                rows, tiles = [], 0
+                for src, dst, N, Cin, taps in jobs:
+                    rows.append([src.data_ptr(), dst.data_ptr(), N, Cin, taps, tiles])
+                    tiles += int(o.lib.fs2_op_transpose_weight_tiles(N, Cin, taps))
+                self._tw_table = (torch.tensor(rows, dtype=torch.int64, device=self.dev), len(rows), tiles)
+            tab, n, tiles = self._tw_table
+            o.ck(o.lib.fs2_op_transpose_weight_batch(_p(tab), n, tiles, o.st()), "transpose_weight_batch")
 
     def _wt(self, name):
         return self.WT.get(name) if self.use_forward_dgrad else None
@@ -784,11 +800,12 @@ class Trainer:
             if self.gradient_clip_val is not None:
                 o.ck(o.lib.fs2_op_sum_sq(_p(self.flat_g), self.n_flat, _p(self._nsq_ws), _p(self._nsq), o.st()), "sum_sq")
                 nsq = self._nsq
-            o.ck(o.lib.fs2_op_adamw(_p(self.flat_p), _p(self.flat_g), _p(self.flat_m), _p(self.flat_v), self.n_flat, C.c_float(lr),
-                                    C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps), C.c_float(self.weight_decay),
-                                    self.steps + 1, _p(nsq), C.c_float(self.gradient_clip_val or 0.0), C.c_float(1.0 / (self._accum * world)), o.st()),
-                 "adamw")
+            shadow = self.flat_w if o.dt != F32 and os.environ.get("FS2_TRAIN_ADAMW_SHADOW", "1") != "0" else None  # (A/B switch)
+            o.ck(o.lib.fs2_op_adamw_shadow(_p(self.flat_p), _p(self.flat_g), _p(self.flat_m), _p(self.flat_v), _p(shadow), self.n_flat,
+                                           C.c_float(lr), C.c_float(self.betas[0]), C.c_float(self.betas[1]), C.c_float(self.eps),
+                                           C.c_float(self.weight_decay), self.steps + 1, _p(nsq), C.c_float(self.gradient_clip_val or 0.0),
+                                           C.c_float(1.0 / (self._accum * world)), o.st()), "adamw")
         self.steps += 1
         self.zero_grad()
-        self._refresh_shadow()
+        self._refresh_shadow(converted=shadow is not None)
         return lr
