@@ -238,6 +238,7 @@ class Trainer:
                  duration_loss="mse", loss_alphas=None, precision="fp32", encoder_dropout=0.0, decoder_dropout=0.0,
                  variance_dropout=0.0, duration_dropout=0.0, seed=0, attention="auto", device="cuda:0"):
         if any(l != "frame" for l in cfg.variance_levels[:len(cfg.variances)]) or any(cfg.is_cwt(i) for i in range(len(cfg.variances))):
+            # (the reference cannot train the CWT head either: loss.py:141,148 read self.mse_loss, which its __init__ never sets)
             raise NotImplementedError("training step: frame-level 'none' variances only")
         if precision not in _PRECISIONS:
             raise ValueError(f"precision must be one of {sorted(_PRECISIONS)}")
