@@ -671,6 +671,37 @@ __global__ void bgemm_reduce_t_kernel(BGemmArgs p) {
     if (p.beta != 0.f) v += p.beta * Num<OutT>::to_f32(*dst);
     *dst = Num<OutT>::from_f32(v);
 }
+// ... four columns per thread, four slabs' loads in flight (fp32 C with N, ldc, the batch strides % 4 == 0 and 16-byte bases)
+__global__ __launch_bounds__(256) void bgemm_reduce_v4_kernel(BGemmArgs p) {
+    const long per4 = (long)p.M * p.N / 4;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int bz = blockIdx.y;
+    if (i >= per4) return;
+    const int b2 = bz % p.nb2, b1 = bz / p.nb2;
+    const float4* ws = (const float4*)(p.ws + (long)bz * p.splitk * per4 * 4) + i;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int k = 0;
+    for (; k + 4 <= p.splitk; k += 4) {
+        const float4 a = ws[(long)k * per4], b = ws[(long)(k + 1) * per4], c = ws[(long)(k + 2) * per4], d = ws[(long)(k + 3) * per4];
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+        s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w;
+        s.x += d.x; s.y += d.y; s.z += d.z; s.w += d.w;
+    }
+    for (; k < p.splitk; ++k) {
+        const float4 a = ws[(long)k * per4];
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
+    const int n4 = p.N / 4, m = (int)(i / n4), n = (int)(i % n4) * 4;
+    float4 v = make_float4(p.alpha * s.x, p.alpha * s.y, p.alpha * s.z, p.alpha * s.w);
+    if (p.bias) { v.x += p.bias[n]; v.y += p.bias[n + 1]; v.z += p.bias[n + 2]; v.w += p.bias[n + 3]; }
+    float4* dst = (float4*)((float*)p.C + b1 * p.sC1 + b2 * p.sC2 + (long)m * p.ldc + n);
+    if (p.beta != 0.f) {
+        const float4 o = *dst;
+        v.x += p.beta * o.x; v.y += p.beta * o.y; v.z += p.beta * o.z; v.w += p.beta * o.w;
+    }
+    *dst = v;
+}
 
 // ---- TN products with a long reduction (weight gradients): 256 x 256 x 32 tiles by LDS-DMA --------------------------------
 // dW = dY^T X reduces over all B*T rows into a small output, both operands k-strided ("natural": a k row is contiguous
@@ -872,6 +903,18 @@ size_t bgemm_ws_bytes(const BGemmArgs& a) {
     return a.splitk > 1 ? (size_t)a.nb1 * a.nb2 * a.splitk * a.M * a.N * sizeof(float) : 0;
 }
 
+// the split-K reduce pass of the bf16 kernels into an fp32 C: the 16-byte form when the layout allows it (same sums, same order)
+static void launch_reduce_f32(const BGemmArgs& a, dim3 g2, hipStream_t stream) {
+    const bool v4 = a.N % 4 == 0 && a.ldc % 4 == 0 && a.sC1 % 4 == 0 && a.sC2 % 4 == 0 && aligned16(a.C) && aligned16(a.ws) &&
+                    (!a.bias || aligned16(a.bias));
+    if (v4) {
+        const long per4 = (long)a.M * a.N / 4;
+        hipLaunchKernelGGL(bgemm_reduce_v4_kernel, dim3((unsigned)((per4 + 255) / 256), g2.y), dim3(256), 0, stream, a);
+    } else {
+        hipLaunchKernelGGL(bgemm_reduce_t_kernel<float>, g2, dim3(256), 0, stream, a);
+    }
+}
+
 int launch_bgemm(const BGemmArgs& a0, int dtype, hipStream_t stream) {
     if (dtype != FS2_F32 && dtype != FS2_BF16) return FS2_ERR_SHAPE;
     BGemmArgs a = a0;
@@ -905,7 +948,7 @@ int launch_bgemm(const BGemmArgs& a0, int dtype, hipStream_t stream) {
         if (bgemm_tn256_eligible(a)) {
             const unsigned nwg = (unsigned)((a.M / GT) * (a.N / GT) * a.nb1 * a.nb2 * splitk);
             hipLaunchKernelGGL(bgemm_tn256_kernel, dim3(nwg), dim3(512), 0, stream, a);
-            if (splitk > 1) hipLaunchKernelGGL(bgemm_reduce_t_kernel<float>, g2, dim3(256), 0, stream, a);
+            if (splitk > 1) launch_reduce_f32(a, g2, stream);
             return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
         }
         // (measured: a win for the TN products - weight gradients, dV, dK: conv1 wgrad 377 -> 350 us, conv2 wgrad 86 -> 67 - and a
@@ -922,7 +965,7 @@ int launch_bgemm(const BGemmArgs& a0, int dtype, hipStream_t stream) {
 #define FS2_BG(OT) do { if (full) FS2_BG2(OT, true); else FS2_BG2(OT, false); } while (0)
         if (a.c_dtype == FS2_F32) {
             FS2_BG(float);
-            if (splitk > 1) hipLaunchKernelGGL(bgemm_reduce_t_kernel<float>, g2, dim3(256), 0, stream, a);
+            if (splitk > 1) launch_reduce_f32(a, g2, stream);
         } else {
             FS2_BG(bf16);
             if (splitk > 1) hipLaunchKernelGGL(bgemm_reduce_t_kernel<bf16>, g2, dim3(256), 0, stream, a);

@@ -220,7 +220,7 @@ class _Ops:
             # 256 x 256 tiles, one 512-thread workgroup per CU: fill the 256 CUs once (measured: conv1 7 splits = 252 workgroups,
             # 199 us against 335 on the 128 x 128 kernel; a second, part-filled round costs more than it brings)
             tiles = (N // 256) * (Cin // 256) * taps
-            splitk = max(1, min(256 // tiles, 48, M // 256))
+            splitk = max(1, min(256 // tiles, 64, M // 256))
         else:
             tiles = ((N + 127) // 128) * ((Cin + 127) // 128) * taps
             splitk = max(1, min(32, -(-2304 // tiles), M // 1024))  # ~9 workgroups per CU (measured: conv1 16, conv2 / in-proj 32)

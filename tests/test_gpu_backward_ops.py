@@ -721,3 +721,20 @@ def test_transpose_weight_batch_matches_single_launches():
         assert torch.equal(got, want), (N, Cin, taps)
         ref = src.view(N, taps, Cin).flip(1).permute(2, 1, 0).reshape(Cin, taps * N)
         assert torch.equal(got, ref)
+
+
+def test_bgemm_tn256_two_batch_levels():
+    """Both batch levels with their own operand / output strides (operands interleaved per head the way the attention tensors
+    are), direct and split-K."""
+    g = torch.Generator().manual_seed(77)
+    nb1, nb2, K, M, N = 2, 3, 96, 256, 256
+    a = torch.randn(nb1, K, nb2 * M, generator=g).to(torch.bfloat16)   # (b1, k, [b2][m])
+    b = torch.randn(nb1, K, nb2 * N, generator=g).to(torch.bfloat16)
+    want = torch.einsum("bkhm,bkhn->bhmn", a.double().view(nb1, K, nb2, M), b.double().view(nb1, K, nb2, N))
+    for sk in (1, 2):
+        kw = dict(M=M, N=N, K=K, sAm=1, sAk=nb2 * M, sBk=nb2 * N, sBn=1, ldc=N, nb1=nb1, nb2=nb2, sA1=K * nb2 * M, sA2=M,
+                  sB1=K * nb2 * N, sB2=N, sC1=nb2 * M * N, sC2=M * N, splitk=sk)
+        assert _tn256(kw) == 1
+        c = torch.zeros(nb1, nb2, M, N, device=DEV)
+        bgemm(kw, a.to(DEV), b.to(DEV), c, dtype=_lib.FS2_BF16)
+        close(c, want, rel=1e-5)
