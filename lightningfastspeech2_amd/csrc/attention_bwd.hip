@@ -22,7 +22,11 @@ namespace fs2 {
 
 namespace {
 
-constexpr int D = 128, TB = 64, LDT = D + 8;  // tile rows of 272 bytes: b128 fragment reads conflict-free
+// Tile rows of 288 bytes: the 8 rows x 32 bytes of a ds_read_b64_tr_b16 phase land on 8 different bank groups (272-byte rows -
+// conflict-free for the b128 fragment reads instead - left every transpose read 2-way conflicted: 469 -> 452 us per C2 decoder
+// layer; an XOR-swizzled unpadded layout that frees BOTH kinds of read measured 495: its 12 per-lane offsets cost more address
+// arithmetic and registers than the conflicts it removes).
+constexpr int D = 128, TB = 64, LDT = D + 16;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((address_space(3))) s16x4_t* lds_v4;
 
@@ -58,10 +62,11 @@ __device__ inline void load_frags(uint4 (&f)[4], const unsigned short* g, long l
 
 // NB = 16-key (dK/dV) or 16-query (dQ) blocks per wave: 2 halves the LDS fragment / transpose reads per MFMA and the number of
 // times the walked tiles are fetched, for 2x the accumulators
-template <int NB>
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
+// DROP: the attention-weight dropout of the forward is regenerated (a run-time test put four branches into every block epilogue)
+template <int NB, bool DROP>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned short sQ[TB * LDT], sO[TB * LDT];
-    __shared__ float sL[TB], sD[TB];
+    __shared__ __attribute__((aligned(16))) float sL[TB], sD[TB];  // sL = +inf past the last query: exp2(.. - inf) = 0, no select
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fr = lane & 15, fg = lane >> 4;
     const int bh = blockIdx.y, b = bh / p.heads, h = bh % p.heads;
     const int k0 = blockIdx.x * (TB * NB);
@@ -90,7 +95,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
     float xl = 0.f, xd = 0.f;
     fetch_tile(xq, Q, ldq, 0, p.S);
     fetch_tile(xo, dO, p.H, 0, p.S);
-    if (tid < TB) { xl = tid < p.S ? lse[tid] : 0.f; xd = tid < p.S ? dl[tid] : 0.f; }
+    if (tid < TB) { xl = tid < p.S ? lse[tid] : __builtin_inff(); xd = tid < p.S ? dl[tid] : 0.f; }
     for (int q0 = 0; q0 < p.S; q0 += TB) {
         __syncthreads();  // everyone is done with the previous tiles
         stash_tile(sQ, xq);
@@ -100,11 +105,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
         if (q0 + TB < p.S) {  // the next block's loads fly while this one is computed
             fetch_tile(xq, Q, ldq, q0 + TB, p.S);
             fetch_tile(xo, dO, p.H, q0 + TB, p.S);
-            if (tid < TB) { xl = q0 + TB + tid < p.S ? lse[q0 + TB + tid] : 0.f; xd = q0 + TB + tid < p.S ? dl[q0 + TB + tid] : 0.f; }
+            if (tid < TB) { xl = q0 + TB + tid < p.S ? lse[q0 + TB + tid] : __builtin_inff(); xd = q0 + TB + tid < p.S ? dl[q0 + TB + tid] : 0.f; }
         }
 #pragma unroll 1
         for (int qs = 0; qs < 4; ++qs) {
             f32x4_t s[NB], dp[NB];
+            // this lane's four queries' statistics in two 16-byte reads, issued ahead of the products (they were four serialised
+            // LDS round trips inside exec-masked branches)
+            const float4 l4 = *(const float4*)(sL + qs * 16 + fg * 4), d4 = *(const float4*)(sD + qs * 16 + fg * 4);
+            const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq4[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
             for (int kb = 0; kb < NB; ++kb) s[kb] = dp[kb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -123,16 +132,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
                 float pv[4], dsv[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int ql = qs * 16 + fg * 4 + r, q = q0 + ql;
-                    const float pr = (kvalid[kb] && q < p.S) ? __builtin_amdgcn_exp2f(s[kb][r] * p.scale_log2e - sL[ql]) : 0.f;
+                    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], p.scale_log2e, -lq[r]));
+                    const float pr = kvalid[kb] ? e : 0.f;
                     float dpe = dp[kb][r], pd = pr;
-                    if (p.drop_p > 0.f) {
+                    if constexpr (DROP) {
+                        const int q = q0 + qs * 16 + fg * 4 + r;
                         const bool keep = dropout_bits(p.drop_seed, p.drop_key, ((uint64_t)bh * p.S + q) * p.S + key[kb]) >= thr;
                         pd = keep ? pr * dsc : 0.f;
                         dpe = keep ? dpe * dsc : 0.f;
                     }
                     pv[r] = pd;
-                    dsv[r] = pr * (dpe - sD[ql]) * p.scale;
+                    dsv[r] = (pr * p.scale) * (dpe - dq4[r]);
                 }
                 pa[kb] = pack4(pv);
                 da[kb] = pack4(dsv);
@@ -166,10 +176,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
             }
 }
 
-template <int NB>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs p) {
+template <int NB, bool DROP>
+__global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void attn_bwd_dq_kernel(AttnBwdArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned short sK[TB * LDT], sV[TB * LDT];
-    __shared__ unsigned char sOk[TB];
+    __shared__ __attribute__((aligned(16))) float sOk[TB];  // 0 for a key that takes part, -inf otherwise (added to the exponent)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fr = lane & 15, fg = lane >> 4;
     const int bh = blockIdx.y, b = bh / p.heads, h = bh % p.heads;
     const int q0 = blockIdx.x * (TB * NB);
@@ -187,7 +197,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs p) {
         qvalid[qb] = q[qb] < p.S;
         load_frags(Qf[qb], Q, ldq, q[qb], p.S, fg);
         load_frags(Of[qb], dO, p.H, q[qb], p.S, fg);
-        lse[qb] = qvalid[qb] ? p.lse2[(long)bh * p.S + q[qb]] : 0.f;
+        lse[qb] = qvalid[qb] ? p.lse2[(long)bh * p.S + q[qb]] : __builtin_inff();  // exp2(.. - inf) = 0: no select per element
         dl[qb] = qvalid[qb] ? p.delta[(long)bh * p.S + q[qb]] : 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) dQ[qb][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -196,10 +206,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs p) {
     const float dsc = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
 
     uint4 xk[4], xv[4];
-    unsigned char xok = 0;
+    float xok = 0.f;
     fetch_tile(xk, Q + p.H, ldq, 0, p.S);
     fetch_tile(xv, Q + 2 * p.H, ldq, 0, p.S);
-    if (tid < TB) xok = (tid < p.S && !(p.key_pad && p.key_pad[(long)b * p.S + tid])) ? 1 : 0;
+    if (tid < TB) xok = (tid < p.S && !(p.key_pad && p.key_pad[(long)b * p.S + tid])) ? 0.f : -__builtin_inff();
     for (int k0 = 0; k0 < p.S; k0 += TB) {
         __syncthreads();
         stash_tile(sK, xk);
@@ -209,11 +219,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs p) {
         if (k0 + TB < p.S) {
             fetch_tile(xk, Q + p.H, ldq, k0 + TB, p.S);
             fetch_tile(xv, Q + 2 * p.H, ldq, k0 + TB, p.S);
-            if (tid < TB) xok = (k0 + TB + tid < p.S && !(p.key_pad && p.key_pad[(long)b * p.S + k0 + TB + tid])) ? 1 : 0;
+            if (tid < TB) xok = (k0 + TB + tid < p.S && !(p.key_pad && p.key_pad[(long)b * p.S + k0 + TB + tid])) ? 0.f : -__builtin_inff();
         }
 #pragma unroll 1
         for (int ks4 = 0; ks4 < 4; ++ks4) {
             f32x4_t s[NB], dp[NB];
+            const float4 o4 = *(const float4*)(sOk + ks4 * 16 + fg * 4);  // this lane's four keys, one read ahead of the products
+            const float ok4[4] = {o4.x, o4.y, o4.z, o4.w};
 #pragma unroll
             for (int qb = 0; qb < NB; ++qb) s[qb] = dp[qb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -232,12 +244,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs p) {
                 float dsv[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int kl = ks4 * 16 + fg * 4 + r, key = k0 + kl;
-                    const float pr = (qvalid[qb] && sOk[kl]) ? __builtin_amdgcn_exp2f(s[qb][r] * p.scale_log2e - lse[qb]) : 0.f;
+                    const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][r], p.scale_log2e, ok4[r] - lse[qb]));
                     float dpe = dp[qb][r];
-                    if (p.drop_p > 0.f)
+                    if constexpr (DROP) {
+                        const int key = k0 + ks4 * 16 + fg * 4 + r;
                         dpe = dropout_bits(p.drop_seed, p.drop_key, ((uint64_t)bh * p.S + q[qb]) * p.S + key) >= thr ? dpe * dsc : 0.f;
-                    dsv[r] = pr * (dpe - dl[qb]) * p.scale;
+                    }
+                    dsv[r] = (pr * p.scale) * (dpe - dl[qb]);
                 }
                 da[qb] = pack4(dsv);
             }
@@ -274,15 +287,16 @@ bool attention_bwd_supported(int dtype, int H, int heads) { return dtype == FS2_
 int launch_attention_bwd(const AttnBwdArgs& a, int dtype, hipStream_t stream) {
     if (!attention_bwd_supported(dtype, a.H, a.heads) || a.B <= 0 || a.S <= 0) return FS2_ERR_SHAPE;
     if (!a.qkv || !a.dout || !a.lse2 || !a.delta || !a.dqkv) return FS2_ERR_ARG;
-    if (g_attn_bwd_nb == 2) {
-        const dim3 grid((a.S + 2 * TB - 1) / (2 * TB), a.B * a.heads);
-        hipLaunchKernelGGL(attn_bwd_dkdv_kernel<2>, grid, dim3(256), 0, stream, a);
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<2>, grid, dim3(256), 0, stream, a);
-    } else {
-        const dim3 grid((a.S + TB - 1) / TB, a.B * a.heads);
-        hipLaunchKernelGGL(attn_bwd_dkdv_kernel<1>, grid, dim3(256), 0, stream, a);
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<1>, grid, dim3(256), 0, stream, a);
-    }
+    const bool drop = a.drop_p > 0.f;
+#define FS2_AB(NBV, DR) \
+    do { \
+        const dim3 grid((a.S + NBV * TB - 1) / (NBV * TB), a.B * a.heads); \
+        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<NBV, DR>), grid, dim3(256), 0, stream, a); \
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<NBV, DR>), grid, dim3(256), 0, stream, a); \
+    } while (0)
+    if (g_attn_bwd_nb == 2) { if (drop) FS2_AB(2, true); else FS2_AB(2, false); }
+    else { if (drop) FS2_AB(1, true); else FS2_AB(1, false); }
+#undef FS2_AB
     return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
 }
 
