@@ -65,8 +65,9 @@ __device__ inline void load_frags(uint4 (&f)[4], const unsigned short* g, long l
 // DROP: the attention-weight dropout of the forward is regenerated (a run-time test put four branches into every block epilogue)
 template <int NB, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
-    __shared__ __attribute__((aligned(16))) unsigned short sQ[TB * LDT], sO[TB * LDT];
-    __shared__ __attribute__((aligned(16))) float sL[TB], sD[TB];  // sL = +inf past the last query: exp2(.. - inf) = 0, no select
+    // two buffers: the next block's tiles are written while this one is multiplied - one barrier per block instead of two
+    __shared__ __attribute__((aligned(16))) unsigned short sQ2[2][TB * LDT], sO2[2][TB * LDT];
+    __shared__ __attribute__((aligned(16))) float sL2[2][TB], sD2[2][TB];  // sL = +inf past the last query: exp2(.. - inf) = 0, no select
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fr = lane & 15, fg = lane >> 4;
     const int bh = blockIdx.y, b = bh / p.heads, h = bh % p.heads;
     const int k0 = blockIdx.x * (TB * NB);
@@ -96,13 +97,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
     fetch_tile(xq, Q, ldq, 0, p.S);
     fetch_tile(xo, dO, p.H, 0, p.S);
     if (tid < TB) { xl = tid < p.S ? lse[tid] : __builtin_inff(); xd = tid < p.S ? dl[tid] : 0.f; }
-    for (int q0 = 0; q0 < p.S; q0 += TB) {
-        __syncthreads();  // everyone is done with the previous tiles
-        stash_tile(sQ, xq);
-        stash_tile(sO, xo);
-        if (tid < TB) { sL[tid] = xl; sD[tid] = xd; }
-        __syncthreads();
-        if (q0 + TB < p.S) {  // the next block's loads fly while this one is computed
+    stash_tile(sQ2[0], xq);
+    stash_tile(sO2[0], xo);
+    if (tid < TB) { sL2[0][tid] = xl; sD2[0][tid] = xd; }
+    __syncthreads();
+    for (int q0 = 0, cur = 0; q0 < p.S; q0 += TB, cur ^= 1) {
+        const unsigned short* sQ = sQ2[cur];
+        const unsigned short* sO = sO2[cur];
+        const float* sL = sL2[cur];
+        const float* sD = sD2[cur];
+        const bool more = q0 + TB < p.S;
+        if (more) {  // the next block's loads fly while this one is computed
             fetch_tile(xq, Q, ldq, q0 + TB, p.S);
             fetch_tile(xo, dO, p.H, q0 + TB, p.S);
             if (tid < TB) { xl = q0 + TB + tid < p.S ? lse[q0 + TB + tid] : __builtin_inff(); xd = q0 + TB + tid < p.S ? dl[q0 + TB + tid] : 0.f; }
@@ -159,6 +164,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
                 }
             }
         }
+        if (more) {  // the other buffer was last read before the previous barrier
+            stash_tile(sQ2[cur ^ 1], xq);
+            stash_tile(sO2[cur ^ 1], xo);
+            if (tid < TB) { sL2[cur ^ 1][tid] = xl; sD2[cur ^ 1][tid] = xd; }
+        }
+        __syncthreads();
     }
     // D: lane holds column d = dt*16 + fr, rows key = fg*4 + r of each 16-key block
     unsigned short* out = (unsigned short*)p.dqkv + (long)b * p.S * ldq + h * D;
