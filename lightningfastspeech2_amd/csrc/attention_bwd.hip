@@ -286,12 +286,17 @@ __global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void attn_bwd_dq_kernel(AttnB
             }
 }
 
-int g_attn_bwd_nb = 1;  // measured (tools/bench_ops.py flash): 2 blocks per wave is 5-11 % slower (C2 590 -> 620 us, C3 1469 -> 1634 us):
-                        // the extra accumulators cost a wave per SIMD and these kernels live on occupancy
+// 16-row blocks per wave, per launch (tools/bench_ops.py flash, PMC in profiles/r02_pmc_attention_bwd.md): the dK / dV launch
+// stays at 1 (2 doubles its 128 accumulator registers and spills at two waves per SIMD), the dQ launch takes 2 (half the LDS
+// fragment / transpose reads per MFMA, 234 registers, no spill: MFMA pipe 45 -> 51 % busy)
+int g_attn_bwd_nb = 1, g_attn_bwd_nb_dq = 0;  // dQ: 0 = by size (2 when that still leaves two workgroups per CU: C2 encoder 24 us at 1, 28 at 2)
 
 }  // namespace
 
-void attention_bwd_set_blocks(int nb) { g_attn_bwd_nb = nb == 2 ? 2 : 1; }
+void attention_bwd_set_blocks(int which, int nb) {
+    if (which) g_attn_bwd_nb_dq = nb >= 0 && nb <= 2 ? nb : 0;
+    else g_attn_bwd_nb = nb == 2 ? 2 : 1;
+}
 
 bool attention_bwd_supported(int dtype, int H, int heads) { return dtype == FS2_BF16 && heads > 0 && H == heads * D; }
 
@@ -299,14 +304,13 @@ int launch_attention_bwd(const AttnBwdArgs& a, int dtype, hipStream_t stream) {
     if (!attention_bwd_supported(dtype, a.H, a.heads) || a.B <= 0 || a.S <= 0) return FS2_ERR_SHAPE;
     if (!a.qkv || !a.dout || !a.lse2 || !a.delta || !a.dqkv) return FS2_ERR_ARG;
     const bool drop = a.drop_p > 0.f;
-#define FS2_AB(NBV, DR) \
-    do { \
-        const dim3 grid((a.S + NBV * TB - 1) / (NBV * TB), a.B * a.heads); \
-        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<NBV, DR>), grid, dim3(256), 0, stream, a); \
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<NBV, DR>), grid, dim3(256), 0, stream, a); \
-    } while (0)
-    if (g_attn_bwd_nb == 2) { if (drop) FS2_AB(2, true); else FS2_AB(2, false); }
-    else { if (drop) FS2_AB(1, true); else FS2_AB(1, false); }
+#define FS2_AB(KERNEL, NBV, DR) \
+    hipLaunchKernelGGL((KERNEL<NBV, DR>), dim3((a.S + NBV * TB - 1) / (NBV * TB), a.B * a.heads), dim3(256), 0, stream, a)
+    if (g_attn_bwd_nb == 2) { if (drop) FS2_AB(attn_bwd_dkdv_kernel, 2, true); else FS2_AB(attn_bwd_dkdv_kernel, 2, false); }
+    else { if (drop) FS2_AB(attn_bwd_dkdv_kernel, 1, true); else FS2_AB(attn_bwd_dkdv_kernel, 1, false); }
+    const int nb_dq = g_attn_bwd_nb_dq ? g_attn_bwd_nb_dq : ((long)((a.S + 2 * TB - 1) / (2 * TB)) * a.B * a.heads >= 512 ? 2 : 1);
+    if (nb_dq == 2) { if (drop) FS2_AB(attn_bwd_dq_kernel, 2, true); else FS2_AB(attn_bwd_dq_kernel, 2, false); }
+    else { if (drop) FS2_AB(attn_bwd_dq_kernel, 1, true); else FS2_AB(attn_bwd_dq_kernel, 1, false); }
 #undef FS2_AB
     return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
 }

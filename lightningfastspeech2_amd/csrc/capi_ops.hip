@@ -87,7 +87,7 @@ int fs2_op_set_vocoder_lds_limit(int32_t kib) {
 int fs2_op_set_gemm_variant(int32_t variant) {
     if (variant >= 1100) { fs2::g_colsum_fused = variant - 1100; return FS2_OK; }   // 1100 / 1101: column sums in two launches / one
     if (variant >= 1000) { fs2::g_bgemm_tn256 = variant - 1000; return FS2_OK; }    // 1000 / 1001: 256 x 256 LDS-DMA kernel for eligible bf16 TN products off / on
-    if (variant >= 900) { fs2::attention_bwd_set_blocks(variant - 900 + 1); return FS2_OK; }  // 900 / 901: attention backward, 1 / 2 blocks per wave
+    if (variant >= 900) { if (variant == 904) fs2::attention_bwd_set_blocks(1, 0); else fs2::attention_bwd_set_blocks((variant - 900) >> 1, ((variant - 900) & 1) + 1); return FS2_OK; }  // 900 / 901: attention backward dK,dV launch 1 / 2 blocks per wave; 902 / 903: the dQ launch, 904: by size
     if (variant >= 800) { fs2::g_bgemm_full = variant - 800; return FS2_OK; }       // 800 / 801: bf16 strided-batched GEMM generic instantiation only / bounds-free one for full aligned tiles
     if (variant >= 700) { fs2::g_bgemm_xcd = variant - 700; return FS2_OK; }        // 700 / 701: bf16 strided-batched GEMM tile order plain / XCD-contiguous
     if (variant >= 500) { fs2::g_split_f32 = variant - 500; return FS2_OK; }       // 500 / 501: fp32 slab launches as fp32 MFMA / bf16 x 3 split

@@ -77,7 +77,7 @@ struct AttnBwdArgs {
     uint64_t drop_seed, drop_key;
 };
 bool attention_bwd_supported(int dtype, int H, int heads);
-void attention_bwd_set_blocks(int nb);  // A/B knob: 16-row blocks per wave (1 or 2)
+void attention_bwd_set_blocks(int which, int nb);  // A/B knob: 16-row blocks per wave (1 or 2) of the dK,dV (which = 0) / dQ (1) launch
 int launch_attention_bwd(const AttnBwdArgs& a, int dtype, hipStream_t stream);
 int launch_transpose_v(const AttnArgs& a, int dtype, hipStream_t stream);  // fills a.vt from a.qkv
 int launch_attention(const AttnArgs& a, int dtype, hipStream_t stream);    // needs a.vt filled
