@@ -113,54 +113,69 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
             if (tid < TB) { xl = q0 + TB + tid < p.S ? lse[q0 + TB + tid] : __builtin_inff(); xd = q0 + TB + tid < p.S ? dl[q0 + TB + tid] : 0.f; }
         }
 #pragma unroll 1
-        for (int qs = 0; qs < 4; ++qs) {
-            f32x4_t s[NB], dp[NB];
-            // this lane's four queries' statistics in two 16-byte reads, issued ahead of the products (they were four serialised
-            // LDS round trips inside exec-masked branches)
-            const float4 l4 = *(const float4*)(sL + qs * 16 + fg * 4), d4 = *(const float4*)(sD + qs * 16 + fg * 4);
-            const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq4[4] = {d4.x, d4.y, d4.z, d4.w};
+        for (int qp = 0; qp < 2; ++qp) {  // 32 queries per step: two 16-query S / dP blocks feed ONE 16x16x32 product each for dV and dK
+            f32x4_t s[2][NB], dp[2][NB];
+            float lq[2][4], dq4[2][4];
 #pragma unroll
-            for (int kb = 0; kb < NB; ++kb) s[kb] = dp[kb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int hb = 0; hb < 2; ++hb) {
+                // this lane's four queries' statistics in two 16-byte reads, issued ahead of the products (they were four serialised
+                // LDS round trips inside exec-masked branches)
+                const float4 l4 = *(const float4*)(sL + qp * 32 + hb * 16 + fg * 4), d4 = *(const float4*)(sD + qp * 32 + hb * 16 + fg * 4);
+                lq[hb][0] = l4.x; lq[hb][1] = l4.y; lq[hb][2] = l4.z; lq[hb][3] = l4.w;
+                dq4[hb][0] = d4.x; dq4[hb][1] = d4.y; dq4[hb][2] = d4.z; dq4[hb][3] = d4.w;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const uint4 qa = *(const uint4*)(sQ + (qs * 16 + fr) * LDT + ks * 32 + fg * 8);
-                const uint4 oa = *(const uint4*)(sO + (qs * 16 + fr) * LDT + ks * 32 + fg * 8);
-#pragma unroll
-                for (int kb = 0; kb < NB; ++kb) {
-                    Mma16<bf16>::step(qa, Kf[kb][ks], s[kb]);    // S[q = fg*4 + r][key = fr]
-                    Mma16<bf16>::step(oa, Vf[kb][ks], dp[kb]);   // dP, same layout
-                }
+                for (int kb = 0; kb < NB; ++kb) s[hb][kb] = dp[hb][kb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             }
-            s16x4_t pa[NB], da[NB];  // A operands: row = key (fr), k = the four queries fg*4 ..
 #pragma unroll
-            for (int kb = 0; kb < NB; ++kb) {
-                float pv[4], dsv[4];
+            for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kb][r], p.scale_log2e, -lq[r]));
-                    const float pr = kvalid[kb] ? e : 0.f;
-                    float dpe = dp[kb][r], pd = pr;
-                    if constexpr (DROP) {
-                        const int q = q0 + qs * 16 + fg * 4 + r;
-                        const bool keep = dropout_bits(p.drop_seed, p.drop_key, ((uint64_t)bh * p.S + q) * p.S + key[kb]) >= thr;
-                        pd = keep ? pr * dsc : 0.f;
-                        dpe = keep ? dpe * dsc : 0.f;
+                for (int ks = 0; ks < 4; ++ks) {
+                    const uint4 qa = *(const uint4*)(sQ + (qp * 32 + hb * 16 + fr) * LDT + ks * 32 + fg * 8);
+                    const uint4 oa = *(const uint4*)(sO + (qp * 32 + hb * 16 + fr) * LDT + ks * 32 + fg * 8);
+#pragma unroll
+                    for (int kb = 0; kb < NB; ++kb) {
+                        Mma16<bf16>::step(qa, Kf[kb][ks], s[hb][kb]);    // S[q = fg*4 + r][key = fr]
+                        Mma16<bf16>::step(oa, Vf[kb][ks], dp[hb][kb]);   // dP, same layout
                     }
-                    pv[r] = pd;
-                    dsv[r] = (pr * p.scale) * (dpe - dq4[r]);
                 }
-                pa[kb] = pack4(pv);
-                da[kb] = pack4(dsv);
-            }
-            const unsigned short* tq = sQ + (qs * 16 + fg * 4 + (fr >> 2)) * LDT + (fr & 3) * 4;
-            const unsigned short* to = sO + (qs * 16 + fg * 4 + (fr >> 2)) * LDT + (fr & 3) * 4;
+            // A operands of the 16x16x32 products: row = key (fr), reduction slot fg*8 + j <-> query fg*4 + j of the first block
+            // (j < 4) / fg*4 + j - 4 of the second: the D layout of the two S blocks, side by side - no cross-lane movement; the B
+            // operands pair the same queries (two transpose reads, one per block)
+            union AB { s16x4_t h[2]; bf16x8_t v; };
+            AB pa[NB], da[NB];
+#pragma unroll
+            for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb) {
+                    float pv[4], dsv[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[hb][kb][r], p.scale_log2e, -lq[hb][r]));
+                        const float pr = kvalid[kb] ? e : 0.f;
+                        float dpe = dp[hb][kb][r], pd = pr;
+                        if constexpr (DROP) {
+                            const int q = q0 + qp * 32 + hb * 16 + fg * 4 + r;
+                            const bool keep = dropout_bits(p.drop_seed, p.drop_key, ((uint64_t)bh * p.S + q) * p.S + key[kb]) >= thr;
+                            pd = keep ? pr * dsc : 0.f;
+                            dpe = keep ? dpe * dsc : 0.f;
+                        }
+                        pv[r] = pd;
+                        dsv[r] = (pr * p.scale) * (dpe - dq4[hb][r]);
+                    }
+                    pa[kb].h[hb] = pack4(pv);
+                    da[kb].h[hb] = pack4(dsv);
+                }
+            const unsigned short* tq = sQ + (qp * 32 + fg * 4 + (fr >> 2)) * LDT + (fr & 3) * 4;
+            const unsigned short* to = sO + (qp * 32 + fg * 4 + (fr >> 2)) * LDT + (fr & 3) * 4;
 #pragma unroll
             for (int dt = 0; dt < 8; ++dt) {
-                const s16x4_t bo = tr4(to + dt * 16), bq = tr4(tq + dt * 16);
+                AB bo, bq;
+                bo.h[0] = tr4(to + dt * 16); bo.h[1] = tr4(to + 16 * LDT + dt * 16);
+                bq.h[0] = tr4(tq + dt * 16); bq.h[1] = tr4(tq + 16 * LDT + dt * 16);
 #pragma unroll
                 for (int kb = 0; kb < NB; ++kb) {
-                    dV[kb][dt] = mma16(pa[kb], bo, dV[kb][dt]);   // += P^T dO
-                    dK[kb][dt] = mma16(da[kb], bq, dK[kb][dt]);   // += dS^T Q
+                    dV[kb][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa[kb].v, bo.v, dV[kb][dt], 0, 0, 0);   // += P^T dO
+                    dK[kb][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da[kb].v, bq.v, dK[kb][dt], 0, 0, 0);   // += dS^T Q
                 }
             }
         }
@@ -233,44 +248,54 @@ __global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void attn_bwd_dq_kernel(AttnB
             if (tid < TB) xok = (k0 + TB + tid < p.S && !(p.key_pad && p.key_pad[(long)b * p.S + k0 + TB + tid])) ? 0.f : -__builtin_inff();
         }
 #pragma unroll 1
-        for (int ks4 = 0; ks4 < 4; ++ks4) {
-            f32x4_t s[NB], dp[NB];
-            const float4 o4 = *(const float4*)(sOk + ks4 * 16 + fg * 4);  // this lane's four keys, one read ahead of the products
-            const float ok4[4] = {o4.x, o4.y, o4.z, o4.w};
+        for (int kp = 0; kp < 2; ++kp) {  // 32 keys per step: two 16-key S^T / dP^T blocks feed one 16x16x32 product for dQ
+            f32x4_t s[2][NB], dp[2][NB];
+            float ok4[2][4];
 #pragma unroll
-            for (int qb = 0; qb < NB; ++qb) s[qb] = dp[qb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            for (int hb = 0; hb < 2; ++hb) {
+                const float4 o4 = *(const float4*)(sOk + kp * 32 + hb * 16 + fg * 4);  // this lane's four keys, one read ahead of the products
+                ok4[hb][0] = o4.x; ok4[hb][1] = o4.y; ok4[hb][2] = o4.z; ok4[hb][3] = o4.w;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const uint4 ka = *(const uint4*)(sK + (ks4 * 16 + fr) * LDT + ks * 32 + fg * 8);
-                const uint4 va = *(const uint4*)(sV + (ks4 * 16 + fr) * LDT + ks * 32 + fg * 8);
-#pragma unroll
-                for (int qb = 0; qb < NB; ++qb) {
-                    Mma16<bf16>::step(ka, Qf[qb][ks], s[qb]);    // S^T[key = fg*4 + r][q = fr]
-                    Mma16<bf16>::step(va, Of[qb][ks], dp[qb]);   // dP^T
-                }
+                for (int qb = 0; qb < NB; ++qb) s[hb][qb] = dp[hb][qb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             }
-            s16x4_t da[NB];  // A operand: row = query (fr), k = the four keys fg*4 ..
 #pragma unroll
-            for (int qb = 0; qb < NB; ++qb) {
-                float dsv[4];
+            for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[qb][r], p.scale_log2e, ok4[r] - lse[qb]));
-                    float dpe = dp[qb][r];
-                    if constexpr (DROP) {
-                        const int key = k0 + ks4 * 16 + fg * 4 + r;
-                        dpe = dropout_bits(p.drop_seed, p.drop_key, ((uint64_t)bh * p.S + q[qb]) * p.S + key) >= thr ? dpe * dsc : 0.f;
+                for (int ks = 0; ks < 4; ++ks) {
+                    const uint4 ka = *(const uint4*)(sK + (kp * 32 + hb * 16 + fr) * LDT + ks * 32 + fg * 8);
+                    const uint4 va = *(const uint4*)(sV + (kp * 32 + hb * 16 + fr) * LDT + ks * 32 + fg * 8);
+#pragma unroll
+                    for (int qb = 0; qb < NB; ++qb) {
+                        Mma16<bf16>::step(ka, Qf[qb][ks], s[hb][qb]);    // S^T[key = fg*4 + r][q = fr]
+                        Mma16<bf16>::step(va, Of[qb][ks], dp[hb][qb]);   // dP^T
                     }
-                    dsv[r] = (pr * p.scale) * (dpe - dl[qb]);
                 }
-                da[qb] = pack4(dsv);
-            }
-            const unsigned short* tk = sK + (ks4 * 16 + fg * 4 + (fr >> 2)) * LDT + (fr & 3) * 4;
+            union AB { s16x4_t h[2]; bf16x8_t v; };
+            AB da[NB];  // A operand: row = query (fr), reduction slot fg*8 + j <-> key fg*4 + j of the first block / fg*4 + j - 4 of the second
+#pragma unroll
+            for (int qb = 0; qb < NB; ++qb)
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb) {
+                    float dsv[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[hb][qb][r], p.scale_log2e, ok4[hb][r] - lse[qb]));
+                        float dpe = dp[hb][qb][r];
+                        if constexpr (DROP) {
+                            const int key = k0 + kp * 32 + hb * 16 + fg * 4 + r;
+                            dpe = dropout_bits(p.drop_seed, p.drop_key, ((uint64_t)bh * p.S + q[qb]) * p.S + key) >= thr ? dpe * dsc : 0.f;
+                        }
+                        dsv[r] = (pr * p.scale) * (dpe - dl[qb]);
+                    }
+                    da[qb].h[hb] = pack4(dsv);
+                }
+            const unsigned short* tk = sK + (kp * 32 + fg * 4 + (fr >> 2)) * LDT + (fr & 3) * 4;
 #pragma unroll
             for (int dt = 0; dt < 8; ++dt) {
-                const s16x4_t bk = tr4(tk + dt * 16);
+                AB bk;
+                bk.h[0] = tr4(tk + dt * 16); bk.h[1] = tr4(tk + 16 * LDT + dt * 16);
 #pragma unroll
-                for (int qb = 0; qb < NB; ++qb) dQ[qb][dt] = mma16(da[qb], bk, dQ[qb][dt]);  // += dS K
+                for (int qb = 0; qb < NB; ++qb) dQ[qb][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da[qb].v, bk.v, dQ[qb][dt], 0, 0, 0);  // += dS K
             }
         }
     }
