@@ -943,7 +943,9 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
     }
     // ReLU and the N-tail checks are compiled out of the common case by workgroup-uniform dispatch (see the
     // LayerNorm epilogue above): at K = 256 this store loop is as many issue cycles as the K loop
-    auto store = [&](auto relu_c, auto full_c) {
+    // gate_c: out = gate[row][col] > 0 ? v : 0 with `gate` a tensor of C's layout and dtype - the ReLU backward of a data-gradient
+    // product (training step: dh = (dc2 . W2) o [h > 0]) folded into the store instead of a 3-tensor elementwise pass
+    auto store = [&](auto relu_c, auto full_c, auto gate_c) {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int t = t0 + wm * (MI * 16) + mi * 16 + fr;
@@ -957,6 +959,29 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
             for (int r = 0; r < 8; ++r) {
                 v[r] = acc[2 * j + (r >> 2)][mi][r & 3] + bv[j][r];
                 if constexpr (decltype(relu_c)::value) v[r] = fmaxf(v[r], 0.f);
+            }
+            if constexpr (decltype(gate_c)::value) {
+                const OutT* gt = (const OutT*)((const char*)p.gate + ((size_t)ub * S * p.ldc + (size_t)t * p.ldc + n) * sizeof(OutT));
+                if (decltype(full_c)::value || n + 7 < p.N) {
+                    float gv[8];
+                    if constexpr (sizeof(OutT) == 4) {
+                        const float4 q0 = *(const float4*)gt, q1 = *(const float4*)(gt + 4);
+                        gv[0] = q0.x; gv[1] = q0.y; gv[2] = q0.z; gv[3] = q0.w; gv[4] = q1.x; gv[5] = q1.y; gv[6] = q1.z; gv[7] = q1.w;
+                    } else {
+                        const uint4 q = *(const uint4*)gt;
+                        const unsigned w4[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            gv[2 * e] = __uint_as_float(w4[e] << 16);
+                            gv[2 * e + 1] = __uint_as_float(w4[e] & 0xffff0000u);
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] = gv[r] > 0.f ? v[r] : 0.f;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] = (n + r < p.N && Num<OutT>::to_f32(gt[r]) > 0.f) ? v[r] : 0.f;
+                }
             }
             OutT* dst = (OutT*)((char*)C + (unsigned)(t * p.ldc + n) * (unsigned)sizeof(OutT));  // one utterance < 4 GiB
             if (decltype(full_c)::value || n + 7 < p.N) {
@@ -1075,12 +1100,15 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
         return;
     }
     const bool fulln = n0 + S_BN <= p.N;  // this column tile lies wholly inside N
-    if (fulln) {
-        if (p.relu) store(BoolC<true>{}, BoolC<true>{});
-        else store(BoolC<false>{}, BoolC<true>{});
+    if (p.gate) {  // (the launcher admits a gate without ReLU only)
+        if (fulln) store(BoolC<false>{}, BoolC<true>{}, BoolC<true>{});
+        else store(BoolC<false>{}, BoolC<false>{}, BoolC<true>{});
+    } else if (fulln) {
+        if (p.relu) store(BoolC<true>{}, BoolC<true>{}, BoolC<false>{});
+        else store(BoolC<false>{}, BoolC<true>{}, BoolC<false>{});
     } else {
-        if (p.relu) store(BoolC<true>{}, BoolC<false>{});
-        else store(BoolC<false>{}, BoolC<false>{});
+        if (p.relu) store(BoolC<true>{}, BoolC<false>{}, BoolC<false>{});
+        else store(BoolC<false>{}, BoolC<false>{}, BoolC<false>{});
     }
 #else
     (void)p;
@@ -1191,6 +1219,9 @@ static int launch_gemm_plain(const GemmArgs& a, int in_dtype, int out_dtype, hip
         if (in_dtype == FS2_BF16 && out_dtype == FS2_F32) return launch_t<bf16, float, true>(a, stream);
         return FS2_ERR_SHAPE;
     }
+    if (a.gate && (fused || a.relu || a.stats_out || a.epi_res || g_gemm_variant != 0 || a.N < 192 || a.M % a.S || !(a.taps & 1) ||
+                   in_dtype != out_dtype))
+        return FS2_ERR_SHAPE;  // the gated store lives in the slab kernel's plain epilogue only
     const int variant = g_gemm_variant;  // 0 = auto, 1 = 128x128 register-staged, 2 = 128x256 DMA ring,
                                          // 3/4/5 = slab kernel with 128/192/256-row tiles
     const bool slab_ok = a.M % a.S == 0 && (a.taps & 1);
@@ -1246,7 +1277,7 @@ static int launch_gemm_plain(const GemmArgs& a, int in_dtype, int out_dtype, hip
         }
     }
     if (fused) return FS2_OK;  // not the slab kernel: caller falls back to GEMM + LayerNorm kernel
-    if (a.stats_out || a.epi_res) return FS2_ERR_SHAPE;  // the deferred-LayerNorm epilogue lives in the slab kernel only
+    if (a.stats_out || a.epi_res || a.gate) return FS2_ERR_SHAPE;  // the deferred-LayerNorm epilogue lives in the slab kernel only
     if (in_dtype == FS2_F32 && out_dtype == FS2_F32) return launch_t<float, float>(a, stream);
     if (in_dtype == FS2_BF16 && out_dtype == FS2_BF16) return launch_t<bf16, bf16>(a, stream);
     if (in_dtype == FS2_BF16 && out_dtype == FS2_F32) return launch_t<bf16, float>(a, stream);

@@ -94,8 +94,14 @@ class _Ops:
         _lib.check(status, None, what)
 
     # ---- forward operators (the inference path's own launches, fp32) ----
-    def gemm(self, x, w, bias, M, N, Cin, taps=1, S=None, relu=False, out_f32=False):
+    def gemm(self, x, w, bias, M, N, Cin, taps=1, S=None, relu=False, out_f32=False, gate=None):
         y = self.empty(M, N) if out_f32 else self.act(M, N)
+        if gate is not None:  # y = gate > 0 ? x w^T : 0 in the store, where the kernel has that epilogue
+            st_ = self.lib.fs2_op_gemm_gated(self.dt, _p(x), _p(w), _p(bias), _p(gate), _p(y), M, N, Cin, taps, S or M, self.st())
+            if st_ == 0:
+                return y
+            self.ck(self.lib.fs2_op_gemm(self.dt, self.dt, _p(x), _p(w), _p(bias), _p(y), M, N, Cin, taps, S or M, 0, self.st()), "gemm")
+            return self.relu_bwd(y, gate)
         self.ck(self.lib.fs2_op_gemm(self.dt, F32 if out_f32 else self.dt, _p(x), _p(w), _p(bias), _p(y), M, N, Cin, taps, S or M,
                                      int(relu), self.st()), "gemm")
         return y
@@ -191,11 +197,11 @@ class _Ops:
         return a
 
     # y = x W^T + b backward pieces.  w is (N, taps*Cin) tap-major; x (M, Cin); dy (M, N); rows in utterances of S.
-    def dgrad(self, dy, w, M, N, Cin, taps=1, S=None, out=None, accumulate=False, wt=None):
+    def dgrad(self, dy, w, M, N, Cin, taps=1, S=None, out=None, accumulate=False, wt=None, gate=None):
         """dX (M, Cin) = dY (M, N) . W: with the transposed / tap-flipped copy wt (Cin, taps*N) through the forward
         GEMM / slab-conv kernel (dX is a 'same' conv of dY with wt), else through the strided-batched GEMM."""
         if wt is not None and N % 64 == 0 and Cin % 64 == 0 and dy.dtype == wt.dtype:
-            dx = self.gemm(dy, wt, None, M, Cin, N, taps=taps, S=S)
+            dx = self.gemm(dy, wt, None, M, Cin, N, taps=taps, S=S, gate=gate)
             if out is None:
                 return dx
             if accumulate:
@@ -203,13 +209,17 @@ class _Ops:
             else:
                 out.copy_(dx)
             return out
+        if gate is not None and (out is not None or accumulate):
+            raise ValueError("dgrad: a gate goes with a fresh output only")
         dx = out if out is not None else self.act(M, Cin)
         beta = 1.0 if accumulate else 0.0
         if taps == 1:
-            return self.bgemm(dy, w, dx, M=M, N=Cin, K=N, sAm=N, sAk=1, sBk=Cin, sBn=1, ldc=Cin, beta=beta)
-        pad = (taps - 1) // 2
-        return self.bgemm(dy, w, dx, M=M, N=Cin, K=taps * N, sAm=N, sAk=1, sBk=taps * Cin, sBn=1, ldc=Cin, seg=S or M,
-                          taps=taps, Kin=N, a_shift0=pad, a_shift_step=-1, sBtap=Cin, beta=beta)
+            self.bgemm(dy, w, dx, M=M, N=Cin, K=N, sAm=N, sAk=1, sBk=Cin, sBn=1, ldc=Cin, beta=beta)
+        else:
+            pad = (taps - 1) // 2
+            self.bgemm(dy, w, dx, M=M, N=Cin, K=taps * N, sAm=N, sAk=1, sBk=taps * Cin, sBn=1, ldc=Cin, seg=S or M,
+                       taps=taps, Kin=N, a_shift0=pad, a_shift_step=-1, sBtap=Cin, beta=beta)
+        return self.relu_bwd(dx, gate) if gate is not None else dx
 
     def wgrad(self, dy, x, dw, db, M, N, Cin, taps=1, S=None):
         """dw (N, taps*Cin) += dy^T x (per tap, rows shifted inside their utterance); db (N) += column sums of dy."""
@@ -499,11 +509,15 @@ class Trainer:
             o.ck(o.lib.fs2_op_unfold_conv2(_p(dWf), _p(dbf), _p(P[f"{prefix}.conv2.0.weight"]), _p(P[f"{prefix}.conv2.0.bias"]),
                                            _p(P[f"{prefix}.conv2.1.weight"]), _p(G[f"{prefix}.conv2.0.weight"]), _p(G[f"{prefix}.conv2.0.bias"]),
                                            _p(G[f"{prefix}.conv2.1.weight"]), _p(G[f"{prefix}.conv2.1.bias"]), H, F_, o.st()), "unfold_conv2")
-            dh = o.dgrad(dc2, f["Wf"], M, H, F_, wt=f["WfT"] if self.use_forward_dgrad else None)
+        # dh = (dc2 . W2) o [h > 0]; without dropout the ReLU mask rides in the product's store (h is the ReLU output)
+        gate = t["h"] if pd <= 0 and os.environ.get("FS2_TRAIN_GATE", "1") != "0" else None  # (A/B switch)
+        if folded:
+            dh = o.dgrad(dc2, f["Wf"], M, H, F_, wt=f["WfT"] if self.use_forward_dgrad else None, gate=gate)
         else:
             o.wgrad(dc2, t["h"], G[f"{prefix}.conv2.weight"], None, M, H, F_)
-            dh = o.dgrad(dc2, W[f"{prefix}.conv2.weight"], M, H, F_, wt=self._wt(f"{prefix}.conv2.weight"))
-        dh = o.relu_bwd(o.dropout(dh, pd, t["k_h"]), t["h"])  # h (post-dropout) > 0  <=>  kept and pre-activation > 0
+            dh = o.dgrad(dc2, W[f"{prefix}.conv2.weight"], M, H, F_, wt=self._wt(f"{prefix}.conv2.weight"), gate=gate)
+        if gate is None:
+            dh = o.relu_bwd(o.dropout(dh, pd, t["k_h"]), t["h"])  # h (post-dropout) > 0  <=>  kept and pre-activation > 0
         if folded:
             o.wgrad(dh, t["u"], G[f"{prefix}.conv1.1.weight"], G[f"{prefix}.conv1.1.bias"], M, F_, H)
             du = o.dgrad(dh, W[f"{prefix}.conv1.1.weight"], M, F_, H, wt=self._wt(f"{prefix}.conv1.1.weight"))

@@ -738,3 +738,37 @@ def test_bgemm_tn256_two_batch_levels():
         c = torch.zeros(nb1, nb2, M, N, device=DEV)
         bgemm(kw, a.to(DEV), b.to(DEV), c, dtype=_lib.FS2_BF16)
         close(c, want, rel=1e-5)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("M,N,Cin,taps,S", [(512, 1024, 256, 1, 512), (384, 200, 64, 1, 384), (3 * 96, 256, 128, 3, 96), (256, 320, 64, 1, 256)])
+def test_gemm_gated_store(M, N, Cin, taps, S, dtype):
+    """fs2_op_gemm_gated: the ReLU backward folded into the data-gradient product's store (c = gate > 0 ? x w^T : 0), full and
+    partial column tiles, conv form; against the ungated launch + the elementwise mask (bit-equal) and fp64."""
+    lib = _lib.load()
+    bf = dtype == "bf16"
+    dt, td = (_lib.FS2_BF16, torch.bfloat16) if bf else (F32, torch.float32)
+    g = torch.Generator().manual_seed(M + N + taps)
+    x = torch.randn(M, Cin, generator=g).to(td)
+    w = (torch.randn(N, taps * Cin, generator=g) / (taps * Cin) ** 0.5).to(td)
+    gate = torch.relu(torch.randn(M, N, generator=g)).to(td)   # a ReLU output: zeros and positives
+    xd, wd, gd = x.to(DEV), w.to(DEV), gate.to(DEV)
+    c = torch.empty(M, N, device=DEV, dtype=td)
+    _lib.check(lib.fs2_op_gemm_gated(dt, p(xd), p(wd), None, p(gd), p(c), M, N, Cin, taps, S, st()))
+    c0 = torch.empty(M, N, device=DEV, dtype=td)
+    _lib.check(lib.fs2_op_gemm(dt, dt, p(xd), p(wd), None, p(c0), M, N, Cin, taps, S, 0, st()))
+    want = torch.where(gd > 0, c0, torch.zeros_like(c0))
+    assert torch.equal(c, want)
+    assert float((want != 0).float().mean()) > 0.3 and float((want == 0).float().mean()) > 0.3
+    if taps == 1:
+        ref = torch.where(gate.double() > 0, x.double() @ w.double().t(), torch.zeros(M, N, dtype=torch.float64))
+        close(c, ref, rel=2e-2 if bf else 2e-5)
+
+
+def test_gemm_gated_rejects_shapes_without_the_epilogue():
+    lib = _lib.load()
+    x = torch.zeros(256, 64, device=DEV)
+    w = torch.zeros(128, 64, device=DEV)
+    c = torch.zeros(256, 128, device=DEV)
+    assert lib.fs2_op_gemm_gated(F32, p(x), p(w), None, p(c), p(c), 256, 128, 64, 1, 256, st()) != 0   # N < 192: not the slab kernel
+    assert lib.fs2_op_gemm_gated(F32, p(x), p(w), None, None, p(c), 256, 128, 64, 1, 256, st()) != 0
