@@ -199,14 +199,25 @@ __device__ inline void split_bf16x3(const uint4& c0, const uint4& c1, uint4& hi,
     lo = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
-// nn.Dropout mask bits of element i at a site: counter-based (splitmix64 of seed, site key, element index), 24 bits; an
-// element is dropped when bits < p * 2^24.  Regenerated wherever the mask is needed, never stored.
+// nn.Dropout mask bits of element i at a site: counter-based, 24 bits; an element is dropped when bits < p * 2^24.
+// Regenerated wherever the mask is needed, never stored.  The site constant is a full splitmix64 of (seed, site key) - uniform
+// in a launch, so it runs on the scalar unit; per element a 32-bit integer finaliser (xorshift-multiply, two rounds) of the
+// index folded to 32 bits XOR that constant.  (The first version ran splitmix64 per element: three 64-bit multiplies = a dozen
+// quarter-rate v_mul_lo/hi_u32 - the attention backward with dropout 0.1 spent more cycles hashing than multiplying, and the
+// stand-alone dropout pass was VALU- instead of HBM-bound: 73 us for a 100 MB tensor.)
 __host__ __device__ inline uint32_t dropout_bits(uint64_t seed, uint64_t key, uint64_t i) {
-    uint64_t z = seed + key * 0x9E3779B97F4A7C15ull + i * 0xD1B54A32D192ED03ull;
+    uint64_t z = seed + key * 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     z ^= z >> 31;
-    return (uint32_t)(z >> 40);
+    const uint32_t hi = (uint32_t)(i >> 32);
+    uint32_t x = (uint32_t)i ^ (uint32_t)z ^ ((hi << 13) | (hi >> 19)) ^ (uint32_t)(z >> 32);
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x >> 8;
 }
 
 // LDS-DMA completion is made explicit wherever a barrier publishes DMA'd operands: hipcc usually

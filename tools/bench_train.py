@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--precision", default="fp32")
+    ap.add_argument("--dropout", type=float, default=0.0, help="every nn.Dropout site of the reference at this rate (the shipped recipe: 0.1)")
     ap.add_argument("--knob", type=int, action="append", default=[], help="fs2_op_set_gemm_variant values (A/B switches)")
     a = ap.parse_args()
     for k in a.knob:
@@ -44,6 +45,8 @@ def main():
     for v in cfg.variances:
         batch[f"variances_{v}"] = torch.from_numpy(rs.randn(B, T).astype(np.float32)).cuda()
     kw = {} if a.precision == "fp32" else {"precision": a.precision}
+    if a.dropout > 0:
+        kw.update(encoder_dropout=a.dropout, decoder_dropout=a.dropout, variance_dropout=a.dropout, duration_dropout=a.dropout)
     tr = Trainer(cfg, sd, **kw)
     for _ in range(a.warmup):
         losses = tr.training_step(batch)
