@@ -372,12 +372,23 @@ __global__ void ew_kernel(EwArgs p) {
 // ---- dropout: counter-based mask (splitmix64 of seed, site key, element index), regenerated - never stored -------------
 // y = x * keep / (1 - p); the same (seed, key) gives the same mask, so the backward applies the same launch to the gradient.
 template <typename T>
-__global__ void dropout_kernel(DropoutArgs p) {
+__global__ __launch_bounds__(256) void dropout_kernel(DropoutArgs p) {
     const uint32_t thr = (uint32_t)(p.p * 16777216.0f);  // drop when bits < thr
     const float scale = 1.f / (1.f - p.p);
     const T* x = (const T*)p.x;
     T* y = (T*)p.y;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < p.n; e += (size_t)gridDim.x * blockDim.x) {
+    constexpr int V = 16 / (int)sizeof(T);  // 16-byte accesses (the first version moved 2 bytes per thread: 73 us for 100 MB)
+    const size_t stride = (size_t)gridDim.x * blockDim.x, tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool vec = (((uintptr_t)x | (uintptr_t)y) & 15) == 0;
+    const size_t nv = vec ? p.n / V : 0;
+    for (size_t q = tid; q < nv; q += stride) {
+        float f[V];
+        Vec16<T>::unpack(((const uint4*)x)[q], f);
+#pragma unroll
+        for (int e = 0; e < V; ++e) f[e] = dropout_bits(p.seed, p.key, q * V + e) >= thr ? f[e] * scale : 0.f;
+        ((uint4*)y)[q] = Vec16<T>::pack(f);
+    }
+    for (size_t e = nv * V + tid; e < p.n; e += stride) {
         const bool keep = dropout_bits(p.seed, p.key, e) >= thr;
         y[e] = Num<T>::from_f32(keep ? Num<T>::to_f32(x[e]) * scale : 0.f);
     }
@@ -850,7 +861,7 @@ int launch_dropout(const DropoutArgs& a, int dtype, hipStream_t stream) {
     if (!(a.p >= 0.f && a.p < 1.f)) return FS2_ERR_ARG;
     if (!a.n) return FS2_OK;
     size_t blocks = (a.n + 2047) / 2048;
-    if (blocks > 8192) blocks = 8192;
+    if (blocks > 4096) blocks = 4096;
     if (dtype == FS2_BF16) hipLaunchKernelGGL(dropout_kernel<bf16>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
     else if (dtype == FS2_F32) hipLaunchKernelGGL(dropout_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, stream, a);
     else return FS2_ERR_SHAPE;
