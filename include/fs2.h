@@ -335,6 +335,9 @@ int fs2_op_col_sum(int32_t dtype, const void* x, float* out, float* ws, int32_t 
                    int32_t accumulate, float scale, void* hip_stream);
 int fs2_op_col_sum2(int32_t dtype, const void* x, float* out, float* out2, int32_t n1, float* ws, int32_t M, int32_t N,
                     int32_t ldx, int32_t accumulate, int32_t accumulate2, float scale, void* hip_stream);
+/* out[n] (+)= scale * sum_r row_w[r] * x[r][n]: the weight gradient of a Linear(H, 1) head (row_w = the loss gradient per row) */
+int fs2_op_col_sum_weighted(int32_t dtype, const void* x, const float* row_w, float* out, float* ws, int32_t M, int32_t N,
+                            int32_t ldx, int32_t accumulate, float scale, void* hip_stream);
 /* masked softmax over the key axis of (B, heads, S, S) fp32 scores -> probabilities p in the activation dtype (the training
  * path materialises them; p may alias s for FS2_F32), and its backward ds = scale * P o (dP - sum_k dP o P) from fp32 dP */
 int fs2_op_softmax_fwd(int32_t dtype, const float* s, const uint8_t* key_pad, void* p, int32_t B, int32_t heads, int32_t S,

@@ -165,6 +165,7 @@ def load():
     lib.fs2_op_col_sum_ws_bytes.argtypes = [i32, i32, i32]
     lib.fs2_op_col_sum.argtypes = [i32, vp, vp, vp, i32, i32, i32, i32, i32, f32, vp]
     lib.fs2_op_col_sum2.argtypes = [i32, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, f32, vp]
+    lib.fs2_op_col_sum_weighted.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, i32, f32, vp]
     lib.fs2_op_softmax_fwd.argtypes = [i32, vp, vp, vp, i32, i32, i32, f32, vp]
     lib.fs2_op_softmax_bwd.argtypes = [i32, vp, vp, vp, i32, i32, i32, f32, vp]
     lib.fs2_op_ew.argtypes = [i32, i32, vp, vp, vp, sz, f32, f32, vp]

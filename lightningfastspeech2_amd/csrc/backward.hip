@@ -146,15 +146,26 @@ constexpr int CS_CHUNK = 128;
 constexpr int CS_CTR = 8192;
 
 template <typename T>
-__device__ inline float cs_accumulate(const T* x, long ldx, int c, int r0, int r1, int g) {
+__device__ inline float cs_accumulate(const T* x, long ldx, int c, int r0, int r1, int g, const float* w = nullptr) {
     float a[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) a[u] = 0.f;
     int r = r0 + g;
-    for (; r + 28 < r1; r += 32)
+    if (w) {  // rows weighted: sum_r w[r] x[r][c] (a vector-matrix product whose vector is a loss gradient)
+        for (; r + 28 < r1; r += 32) {
+            float xv[8], wv[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) a[u] += Num<T>::to_f32(x[(long)(r + 4 * u) * ldx + c]);
-    for (; r < r1; r += 4) a[0] += Num<T>::to_f32(x[(long)r * ldx + c]);
+            for (int u = 0; u < 8; ++u) { xv[u] = Num<T>::to_f32(x[(long)(r + 4 * u) * ldx + c]); wv[u] = w[r + 4 * u]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] = fmaf(xv[u], wv[u], a[u]);
+        }
+        for (; r < r1; r += 4) a[0] = fmaf(Num<T>::to_f32(x[(long)r * ldx + c]), w[r], a[0]);
+    } else {
+        for (; r + 28 < r1; r += 32)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += Num<T>::to_f32(x[(long)(r + 4 * u) * ldx + c]);
+        for (; r < r1; r += 4) a[0] += Num<T>::to_f32(x[(long)r * ldx + c]);
+    }
     return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
 }
 
@@ -179,7 +190,7 @@ __global__ __launch_bounds__(256) void col_sum_pass1(ColSumArgs p, int nchunk) {
     const int seg = p.seg > 0 ? p.seg : p.M;
     const int r0 = chunk * CS_CHUNK, r1 = min(seg, r0 + CS_CHUNK);
     float* part = p.ws + CS_CTR;
-    red[g][l] = c < p.N ? cs_accumulate<T>((const T*)p.x + (long)s * seg * p.ldx, p.ldx, c, r0, r1, g) : 0.f;
+    red[g][l] = c < p.N ? cs_accumulate<T>((const T*)p.x + (long)s * seg * p.ldx, p.ldx, c, r0, r1, g, p.row_w ? p.row_w + (long)s * seg : nullptr) : 0.f;
     __syncthreads();
     if (g == 0 && c < p.N) {
         const float a = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);

@@ -282,6 +282,13 @@ int fs2_op_col_sum2(int32_t dtype, const void* x, float* out, float* out2, int32
     if (!out2) return FS2_ERR_ARG;
     return launch_col_sum(a, dtype, (hipStream_t)stream);
 }
+int fs2_op_col_sum_weighted(int32_t dtype, const void* x, const float* row_w, float* out, float* ws, int32_t M, int32_t N, int32_t ldx,
+                            int32_t accumulate, float scale, void* stream) {
+    if (!row_w) return FS2_ERR_ARG;
+    ColSumArgs a{x, out, ws, M, N, ldx, 0, accumulate, scale};
+    a.row_w = row_w;
+    return launch_col_sum(a, dtype, (hipStream_t)stream);
+}
 int fs2_op_softmax_fwd(int32_t dtype, const float* s, const uint8_t* key_pad, void* p, int32_t B, int32_t heads, int32_t S,
                        float scale, void* stream) {
     SoftmaxArgs a{s, nullptr, p, key_pad, B, heads, S, scale};

@@ -355,6 +355,7 @@ struct ColSumArgs {
     float* out2 = nullptr;  // columns n >= n1 go to out2[s][n - n1] instead (out is then n1 wide)
     int n1 = 0;
     int accumulate2 = 0;
+    const float* row_w = nullptr;  // (M) or null: rows are weighted, out[s][n] (+)= scale * sum_r row_w[r] x[r][n]
 };
 extern int g_colsum_fused;
 size_t col_sum_ws_bytes(int M, int N, int seg);

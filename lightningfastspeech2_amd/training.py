@@ -598,10 +598,12 @@ class Trainer:
         """dpred (M) -> gradients of the predictor's parameters, and dx_out (M, H) += d/dx."""
         o, P, W, G = self.ops, self.P, self.W, self.G
         M = B * S
+        # pred = y . w + b  (masked rows carry dpred = 0 already): dw = sum_m dpred[m] y[m] as a row-weighted column sum (fp32
+        # weights; as a 1 x filt x M product on the 128 x 128 GEMM tile it took 51 us per head)
+        ws = o.ws("colsum", int(o.lib.fs2_op_col_sum_ws_bytes(M, filt, 0)))
+        o.ck(o.lib.fs2_op_col_sum_weighted(o._dt(t["y"]), _p(t["y"]), _p(dpred), _p(G[f"{prefix}.linear.weight"]), _p(ws), M, filt, filt, 1,
+                                           C.c_float(1.0), o.st()), "col_sum_weighted")
         dpred = o.to_act(dpred)
-        # pred = y . w + b  (masked rows carry dpred = 0 already)
-        o.bgemm(dpred, t["y"], G[f"{prefix}.linear.weight"], M=1, N=filt, K=M, sAm=1, sAk=1, sBk=filt, sBn=1, ldc=filt,
-                splitk=max(1, min(64, M // 1024)), beta=1.0)
         o.col_sum(dpred, G[f"{prefix}.linear.bias"], M, 1)
         dy = o.act(M, filt)
         o.bgemm(dpred, W[f"{prefix}.linear.weight"], dy, M=M, N=filt, K=1, sAm=1, sAk=1, sBk=filt, sBn=1, ldc=filt)

@@ -772,3 +772,20 @@ def test_gemm_gated_rejects_shapes_without_the_epilogue():
     c = torch.zeros(256, 128, device=DEV)
     assert lib.fs2_op_gemm_gated(F32, p(x), p(w), None, p(c), p(c), 256, 128, 64, 1, 256, st()) != 0   # N < 192: not the slab kernel
     assert lib.fs2_op_gemm_gated(F32, p(x), p(w), None, None, p(c), 256, 128, 64, 1, 256, st()) != 0
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_col_sum_weighted(dtype):
+    """out[n] += sum_r w[r] x[r][n] (the weight gradient of a Linear(H, 1) head) against fp64."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(9)
+    M, N = 3000, 200
+    x = torch.randn(M, N, generator=g)
+    if dtype == "bf16":
+        x = x.to(torch.bfloat16)
+    w = torch.randn(M, generator=g)
+    ws = torch.zeros(lib.fs2_op_col_sum_ws_bytes(M, N, 0) // 4, device=DEV)
+    out = torch.ones(N, device=DEV)
+    _lib.check(lib.fs2_op_col_sum_weighted(_lib.FS2_BF16 if dtype == "bf16" else F32, p(x.to(DEV)), p(w.to(DEV)), p(out), p(ws), M, N, N, 1,
+                                           0.5, st()))
+    close(out, 1.0 + 0.5 * (w.double()[:, None] * x.double()).sum(0), 1e-5)
