@@ -212,11 +212,12 @@ int fs2_op_set_vocoder_lds_limit(int32_t kib);
 int fs2_op_set_vocoder_fused_resblock(int32_t on);
 int fs2_op_gemm(int32_t dtype, int32_t out_dtype, const void* x, const void* w, const float* bias, void* c,
                 int32_t M, int32_t N, int32_t Cin, int32_t taps, int32_t S, int32_t relu, void* hip_stream);
-/* ... with the ReLU backward of a data-gradient product folded into the store: c = gate > 0 ? x w^T + bias : 0, gate (M, N) in
- * the launch dtype (training step: dh = (dc2 . W2) o [h > 0], model.py:84-90 backwards).  FS2_ERR_SHAPE when the shape does not
- * run on the slab kernel (N < 192, M % S != 0, even tap count): the caller then uses fs2_op_gemm + fs2_op_ew(op 1). */
-int fs2_op_gemm_gated(int32_t dtype, const void* x, const void* w, const float* bias, const void* gate, void* c, int32_t M,
-                      int32_t N, int32_t Cin, int32_t taps, int32_t S, void* hip_stream);
+/* ... with the ReLU (and dropout) backward of a data-gradient product folded into the store: c = gate > 0 ? scale * (x w^T + bias)
+ * : 0, gate (M, N) in the launch dtype (training step: dh = (dc2 . W2) o [h > 0] / (1 - p), h = dropout(relu(.)) of the forward:
+ * h > 0 <=> kept and pre-activation > 0, model.py:84-90 backwards).  FS2_ERR_SHAPE when the shape does not run on the slab kernel
+ * (N < 192, M % S != 0, even tap count): the caller then uses fs2_op_gemm + fs2_op_dropout + fs2_op_ew(op 1). */
+int fs2_op_gemm_gated(int32_t dtype, const void* x, const void* w, const float* bias, const void* gate, float scale, void* c,
+                      int32_t M, int32_t N, int32_t Cin, int32_t taps, int32_t S, void* hip_stream);
 int fs2_op_attention(int32_t dtype, const void* qkv, const uint8_t* key_pad_mask, void* out, void* vt_scratch,
                      uint64_t* bits_scratch, int32_t B, int32_t S, int32_t H, int32_t heads, void* hip_stream);
 /* GEMM/conv with the fused row epilogue  y = LayerNorm(act(xW^T + b) [+ res]) [, pred = head(y)]

@@ -106,14 +106,14 @@ int fs2_op_gemm(int32_t dtype, int32_t out_dtype, const void* x, const void* w, 
     return launch_gemm(a, dtype, out_dtype, (hipStream_t)stream);
 }
 
-int fs2_op_gemm_gated(int32_t dtype, const void* x, const void* w, const float* bias, const void* gate, void* c, int32_t M,
+int fs2_op_gemm_gated(int32_t dtype, const void* x, const void* w, const float* bias, const void* gate, float scale, void* c, int32_t M,
                       int32_t N, int32_t Cin, int32_t taps, int32_t S, void* stream) {
     if (!gate) return FS2_ERR_ARG;
     GemmArgs a;
     a.X = x; a.W = w; a.bias = bias; a.C = c;
     a.M = M; a.N = N; a.K = taps * Cin; a.ldx = Cin; a.ldc = N;
     a.Cin = Cin; a.taps = taps; a.pad = (taps - 1) / 2; a.S = S; a.relu = 0;
-    a.gate = gate;
+    a.gate = gate; a.gate_scale = scale;
     return launch_gemm(a, dtype, dtype, (hipStream_t)stream);
 }
 

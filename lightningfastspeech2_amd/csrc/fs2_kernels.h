@@ -42,7 +42,8 @@ struct GemmArgs {
     float* stats_out = nullptr;
     int split = 0;                  // fp32 operands only: 1 = bf16 x 3 split arithmetic in the slab kernel (gemm_mfma.hip)
     const uint8_t* zero_rows = nullptr;  // (M) 1 = store zeros for this row (128x128 kernel only: the mel head)
-    const void* gate = nullptr;     // slab kernel, plain epilogue: C = gate > 0 ? acc + bias : 0; gate has C's shape, ldc and dtype
+    const void* gate = nullptr;     // slab kernel, plain epilogue: C = gate > 0 ? gate_scale * (acc + bias) : 0; gate has C's shape, ldc and dtype
+    float gate_scale = 1.f;
 };
 int launch_gemm(const GemmArgs& a, int in_dtype, int out_dtype, hipStream_t stream);
 extern int g_gemm_variant;

@@ -977,10 +977,10 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
                         }
                     }
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) v[r] = gv[r] > 0.f ? v[r] : 0.f;
+                    for (int r = 0; r < 8; ++r) v[r] = gv[r] > 0.f ? v[r] * p.gate_scale : 0.f;
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) v[r] = (n + r < p.N && Num<OutT>::to_f32(gt[r]) > 0.f) ? v[r] : 0.f;
+                    for (int r = 0; r < 8; ++r) v[r] = (n + r < p.N && Num<OutT>::to_f32(gt[r]) > 0.f) ? v[r] * p.gate_scale : 0.f;
                 }
             }
             OutT* dst = (OutT*)((char*)C + (unsigned)(t * p.ldc + n) * (unsigned)sizeof(OutT));  // one utterance < 4 GiB

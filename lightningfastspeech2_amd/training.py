@@ -94,14 +94,15 @@ class _Ops:
         _lib.check(status, None, what)
 
     # ---- forward operators (the inference path's own launches, fp32) ----
-    def gemm(self, x, w, bias, M, N, Cin, taps=1, S=None, relu=False, out_f32=False, gate=None):
+    def gemm(self, x, w, bias, M, N, Cin, taps=1, S=None, relu=False, out_f32=False, gate=None, gate_scale=1.0):
         y = self.empty(M, N) if out_f32 else self.act(M, N)
-        if gate is not None:  # y = gate > 0 ? x w^T : 0 in the store, where the kernel has that epilogue
-            st_ = self.lib.fs2_op_gemm_gated(self.dt, _p(x), _p(w), _p(bias), _p(gate), _p(y), M, N, Cin, taps, S or M, self.st())
+        if gate is not None:  # y = gate > 0 ? gate_scale * x w^T : 0 in the store, where the kernel has that epilogue
+            st_ = self.lib.fs2_op_gemm_gated(self.dt, _p(x), _p(w), _p(bias), _p(gate), C.c_float(gate_scale), _p(y), M, N, Cin, taps,
+                                             S or M, self.st())
             if st_ == 0:
                 return y
             self.ck(self.lib.fs2_op_gemm(self.dt, self.dt, _p(x), _p(w), _p(bias), _p(y), M, N, Cin, taps, S or M, 0, self.st()), "gemm")
-            return self.relu_bwd(y, gate)
+            return self.gate_(y, gate, gate_scale)
         self.ck(self.lib.fs2_op_gemm(self.dt, F32 if out_f32 else self.dt, _p(x), _p(w), _p(bias), _p(y), M, N, Cin, taps, S or M,
                                      int(relu), self.st()), "gemm")
         return y
@@ -163,6 +164,13 @@ class _Ops:
         self.ck(self.lib.fs2_op_ew(self._dt(dy), 1, _p(dy), _p(y), _p(dy), dy.numel(), C.c_float(0), C.c_float(0), self.st()), "relu_bwd")
         return dy
 
+    def gate_(self, dy, y, scale=1.0):
+        """in place: dy = y > 0 ? scale * dy : 0"""
+        self.relu_bwd(dy, y)
+        if scale != 1.0:
+            self.ck(self.lib.fs2_op_ew(self._dt(dy), 2, _p(dy), None, _p(dy), dy.numel(), C.c_float(scale), C.c_float(0), self.st()), "scale")
+        return dy
+
     def dwconv(self, x, w, bias, B, S, Cc, k):
         y = self.act(B * S, Cc)
         self.ck(self.lib.fs2_op_dwconv(self.dt, _p(x), _p(w), _p(bias), _p(y), B, S, Cc, k, self.st()), "dwconv")
@@ -197,11 +205,11 @@ class _Ops:
         return a
 
     # y = x W^T + b backward pieces.  w is (N, taps*Cin) tap-major; x (M, Cin); dy (M, N); rows in utterances of S.
-    def dgrad(self, dy, w, M, N, Cin, taps=1, S=None, out=None, accumulate=False, wt=None, gate=None):
+    def dgrad(self, dy, w, M, N, Cin, taps=1, S=None, out=None, accumulate=False, wt=None, gate=None, gate_scale=1.0):
         """dX (M, Cin) = dY (M, N) . W: with the transposed / tap-flipped copy wt (Cin, taps*N) through the forward
         GEMM / slab-conv kernel (dX is a 'same' conv of dY with wt), else through the strided-batched GEMM."""
         if wt is not None and N % 64 == 0 and Cin % 64 == 0 and dy.dtype == wt.dtype:
-            dx = self.gemm(dy, wt, None, M, Cin, N, taps=taps, S=S, gate=gate)
+            dx = self.gemm(dy, wt, None, M, Cin, N, taps=taps, S=S, gate=gate, gate_scale=gate_scale)
             if out is None:
                 return dx
             if accumulate:
@@ -219,7 +227,7 @@ class _Ops:
             pad = (taps - 1) // 2
             self.bgemm(dy, w, dx, M=M, N=Cin, K=taps * N, sAm=N, sAk=1, sBk=taps * Cin, sBn=1, ldc=Cin, seg=S or M,
                        taps=taps, Kin=N, a_shift0=pad, a_shift_step=-1, sBtap=Cin, beta=beta)
-        return self.relu_bwd(dx, gate) if gate is not None else dx
+        return self.gate_(dx, gate, gate_scale) if gate is not None else dx
 
     def wgrad(self, dy, x, dw, db, M, N, Cin, taps=1, S=None):
         """dw (N, taps*Cin) += dy^T x (per tap, rows shifted inside their utterance); db (N) += column sums of dy."""
@@ -509,13 +517,15 @@ class Trainer:
             o.ck(o.lib.fs2_op_unfold_conv2(_p(dWf), _p(dbf), _p(P[f"{prefix}.conv2.0.weight"]), _p(P[f"{prefix}.conv2.0.bias"]),
                                            _p(P[f"{prefix}.conv2.1.weight"]), _p(G[f"{prefix}.conv2.0.weight"]), _p(G[f"{prefix}.conv2.0.bias"]),
                                            _p(G[f"{prefix}.conv2.1.weight"]), _p(G[f"{prefix}.conv2.1.bias"]), H, F_, o.st()), "unfold_conv2")
-        # dh = (dc2 . W2) o [h > 0]; without dropout the ReLU mask rides in the product's store (h is the ReLU output)
-        gate = t["h"] if pd <= 0 and os.environ.get("FS2_TRAIN_GATE", "1") != "0" else None  # (A/B switch)
+        # dh = (dc2 . W2) o [h > 0] / (1 - p): h = dropout(relu(.)) of the forward is > 0 exactly where the element was kept AND the
+        # pre-activation was positive, so the ReLU backward and the dropout backward ride in the product's store together
+        gate = t["h"] if os.environ.get("FS2_TRAIN_GATE", "1") != "0" else None  # (A/B switch)
+        gs = 1.0 / (1.0 - pd) if pd > 0 else 1.0
         if folded:
-            dh = o.dgrad(dc2, f["Wf"], M, H, F_, wt=f["WfT"] if self.use_forward_dgrad else None, gate=gate)
+            dh = o.dgrad(dc2, f["Wf"], M, H, F_, wt=f["WfT"] if self.use_forward_dgrad else None, gate=gate, gate_scale=gs)
         else:
             o.wgrad(dc2, t["h"], G[f"{prefix}.conv2.weight"], None, M, H, F_)
-            dh = o.dgrad(dc2, W[f"{prefix}.conv2.weight"], M, H, F_, wt=self._wt(f"{prefix}.conv2.weight"), gate=gate)
+            dh = o.dgrad(dc2, W[f"{prefix}.conv2.weight"], M, H, F_, wt=self._wt(f"{prefix}.conv2.weight"), gate=gate, gate_scale=gs)
         if gate is None:
             dh = o.relu_bwd(o.dropout(dh, pd, t["k_h"]), t["h"])  # h (post-dropout) > 0  <=>  kept and pre-activation > 0
         if folded:

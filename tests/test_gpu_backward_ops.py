@@ -754,7 +754,7 @@ def test_gemm_gated_store(M, N, Cin, taps, S, dtype):
     gate = torch.relu(torch.randn(M, N, generator=g)).to(td)   # a ReLU output: zeros and positives
     xd, wd, gd = x.to(DEV), w.to(DEV), gate.to(DEV)
     c = torch.empty(M, N, device=DEV, dtype=td)
-    _lib.check(lib.fs2_op_gemm_gated(dt, p(xd), p(wd), None, p(gd), p(c), M, N, Cin, taps, S, st()))
+    _lib.check(lib.fs2_op_gemm_gated(dt, p(xd), p(wd), None, p(gd), 1.0, p(c), M, N, Cin, taps, S, st()))
     c0 = torch.empty(M, N, device=DEV, dtype=td)
     _lib.check(lib.fs2_op_gemm(dt, dt, p(xd), p(wd), None, p(c0), M, N, Cin, taps, S, 0, st()))
     want = torch.where(gd > 0, c0, torch.zeros_like(c0))
@@ -763,6 +763,8 @@ def test_gemm_gated_store(M, N, Cin, taps, S, dtype):
     if taps == 1:
         ref = torch.where(gate.double() > 0, x.double() @ w.double().t(), torch.zeros(M, N, dtype=torch.float64))
         close(c, ref, rel=2e-2 if bf else 2e-5)
+        _lib.check(lib.fs2_op_gemm_gated(dt, p(xd), p(wd), None, p(gd), 1.25, p(c), M, N, Cin, taps, S, st()))   # dropout's 1 / (1 - p)
+        close(c, 1.25 * ref, rel=2e-2 if bf else 2e-5)
 
 
 def test_gemm_gated_rejects_shapes_without_the_epilogue():
@@ -770,8 +772,8 @@ def test_gemm_gated_rejects_shapes_without_the_epilogue():
     x = torch.zeros(256, 64, device=DEV)
     w = torch.zeros(128, 64, device=DEV)
     c = torch.zeros(256, 128, device=DEV)
-    assert lib.fs2_op_gemm_gated(F32, p(x), p(w), None, p(c), p(c), 256, 128, 64, 1, 256, st()) != 0   # N < 192: not the slab kernel
-    assert lib.fs2_op_gemm_gated(F32, p(x), p(w), None, None, p(c), 256, 128, 64, 1, 256, st()) != 0
+    assert lib.fs2_op_gemm_gated(F32, p(x), p(w), None, p(c), 1.0, p(c), 256, 128, 64, 1, 256, st()) != 0   # N < 192: not the slab kernel
+    assert lib.fs2_op_gemm_gated(F32, p(x), p(w), None, None, 1.0, p(c), 256, 128, 64, 1, 256, st()) != 0
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
