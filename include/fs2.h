@@ -326,6 +326,14 @@ int fs2_op_attn_delta(int32_t dtype, const void* dout, const void* out, float* d
 int32_t fs2_op_layernorm_bwd_parts(int32_t M);
 int fs2_op_layernorm_bwd(int32_t dtype, const void* z, const void* res, const void* dy, const float* gamma, void* dz,
                          float* part, int32_t M, int32_t H, int32_t relu_mask, void* hip_stream);
+/* ... whose dy is the gradient of dropout(y) (VarianceConvolutionLayer: LayerNorm -> Dropout, model.py:538-539,556-557): the
+ * forward's mask (fs2_op_dropout / fs2_op_layernorm_dropout with the same seed, key) is applied to dy on load */
+int fs2_op_layernorm_bwd_dropout(int32_t dtype, const void* z, const void* res, const void* dy, const float* gamma, void* dz,
+                                 float* part, int32_t M, int32_t H, int32_t relu_mask, float drop_p, uint64_t seed, uint64_t key,
+                                 void* hip_stream);
+/* y = dropout(LayerNorm(x [+ res])) in one launch; the mask is fs2_op_dropout's over the (M, H) element index */
+int fs2_op_layernorm_dropout(int32_t dtype, const void* x, const void* res, const float* gamma, const float* beta, void* y,
+                             int32_t M, int32_t H, float drop_p, uint64_t seed, uint64_t key, void* hip_stream);
 /* out[s][n] (+)= scale * sum over the rows of segment s of x[row][n]; seg = rows per segment (0: one segment).  Per-chunk
  * partials in ws (fs2_op_col_sum_ws_bytes), added in chunk order (deterministic).  ws starts with 8192 32-bit counters for the
  * one-launch variant (fs2_op_set_gemm_variant 1101; off by default, measured slower): the caller zeroes them ONCE, when it

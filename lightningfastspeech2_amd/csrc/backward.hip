@@ -65,6 +65,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(LayerNormBwdArgs p) 
             if (c < H) {
                 ld4<T>(z + (long)row * H + c, zv[j]);
                 ld4<T>(dy + (long)row * H + c, dv[j]);
+                if (p.drop_p > 0.f) {  // dy arrives as the gradient of dropout(y): the forward's mask, regenerated
+                    const uint32_t thr = (uint32_t)(p.drop_p * 16777216.0f);
+                    const float sc = 1.f / (1.f - p.drop_p);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dv[j][e] = dropout_bits(p.drop_seed, p.drop_key, (uint64_t)row * H + c + e) >= thr ? dv[j][e] * sc : 0.f;
+                }
                 if (zr) {
                     float r[4];
                     ld4<T>(zr + (long)row * H + c, r);

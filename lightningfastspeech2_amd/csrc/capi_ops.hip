@@ -188,6 +188,16 @@ int fs2_op_layernorm(int32_t dtype, const void* x, const void* res, const float*
     a.M = M; a.H = H; a.eps = 1e-5f;
     return launch_layernorm(a, dtype, (hipStream_t)stream);
 }
+int fs2_op_layernorm_dropout(int32_t dtype, const void* x, const void* res, const float* gamma, const float* beta, void* y,
+                             int32_t M, int32_t H, float drop_p, uint64_t seed, uint64_t key, void* stream) {
+    if (!(drop_p >= 0.f && drop_p < 1.f) || !y) return FS2_ERR_ARG;
+    LayerNormArgs a;
+    a.x = x; a.res = res; a.gamma = gamma; a.beta = beta; a.y = y;
+    a.dot_w = nullptr; a.dot_b = 0.f; a.mask = nullptr; a.pred = nullptr;
+    a.M = M; a.H = H; a.eps = 1e-5f;
+    a.drop_p = drop_p; a.drop_seed = seed; a.drop_key = key;
+    return launch_layernorm(a, dtype, (hipStream_t)stream);
+}
 
 int fs2_op_dwconv(int32_t dtype, const void* x, const float* w, const float* bias, void* y, int32_t B, int32_t S,
                   int32_t C, int32_t k, void* stream) {
@@ -267,6 +277,14 @@ int32_t fs2_op_layernorm_bwd_parts(int32_t M) { return layernorm_bwd_parts(M); }
 int fs2_op_layernorm_bwd(int32_t dtype, const void* z, const void* res, const void* dy, const float* gamma, void* dz,
                          float* part, int32_t M, int32_t H, int32_t relu_mask, void* stream) {
     LayerNormBwdArgs a{z, res, dy, gamma, dz, part, M, H, layernorm_bwd_parts(M), 1e-5f, relu_mask};
+    return launch_layernorm_bwd(a, dtype, (hipStream_t)stream);
+}
+int fs2_op_layernorm_bwd_dropout(int32_t dtype, const void* z, const void* res, const void* dy, const float* gamma, void* dz,
+                                 float* part, int32_t M, int32_t H, int32_t relu_mask, float drop_p, uint64_t seed, uint64_t key,
+                                 void* stream) {
+    if (!(drop_p >= 0.f && drop_p < 1.f)) return FS2_ERR_ARG;
+    LayerNormBwdArgs a{z, res, dy, gamma, dz, part, M, H, layernorm_bwd_parts(M), 1e-5f, relu_mask};
+    a.drop_p = drop_p; a.drop_seed = seed; a.drop_key = key;
     return launch_layernorm_bwd(a, dtype, (hipStream_t)stream);
 }
 size_t fs2_op_col_sum_ws_bytes(int32_t M, int32_t N, int32_t seg) { return col_sum_ws_bytes(M, N, seg); }

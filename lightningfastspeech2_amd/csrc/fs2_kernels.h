@@ -190,6 +190,8 @@ struct LayerNormArgs {
     float eps;
     const float* pre_stats = nullptr;  // (M, pre_parts) float2 partial (sum, sum of squares) of x's rows: skip the reductions
     int pre_parts = 0;
+    float drop_p = 0.f;                // > 0: y = dropout(LN(.)), mask of fs2_op_dropout over the (M, H) element index
+    uint64_t drop_seed = 0, drop_key = 0;
 };
 int launch_layernorm(const LayerNormArgs& a, int dtype, hipStream_t stream);
 
@@ -341,6 +343,8 @@ struct LayerNormBwdArgs {
     int M, H, nparts;
     float eps;
     int relu_mask;        // 1: z is a ReLU output; dz := dz where z > 0 else 0 (the gradient of the PRE-activation)
+    float drop_p = 0.f;   // > 0: dy is the gradient of dropout(y): the mask of the forward (seed, key) is applied to dy on load
+    uint64_t drop_seed = 0, drop_key = 0;
 };
 int layernorm_bwd_parts(int M);
 int launch_layernorm_bwd(const LayerNormBwdArgs& a, int dtype, hipStream_t stream);

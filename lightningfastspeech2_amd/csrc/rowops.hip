@@ -88,6 +88,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LayerNormArgs p) {
             load4<float>(p.beta + c, bb);
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[e] = (v[i][e] - mean) * rstd * g[e] + bb[e];
+            if (p.drop_p > 0.f) {  // the layer's nn.Dropout behind the LayerNorm (model.py:539,557), same mask as the stand-alone pass
+                const uint32_t thr = (uint32_t)(p.drop_p * 16777216.0f);
+                const float sc = 1.f / (1.f - p.drop_p);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = dropout_bits(p.drop_seed, p.drop_key, (uint64_t)row * p.H + c + e) >= thr ? y[e] * sc : 0.f;
+            }
             if (p.y) store4<T>((T*)p.y + (size_t)row * p.H + c, y);
             if (p.dot_w) {
                 float w[4];

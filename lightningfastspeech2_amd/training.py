@@ -472,14 +472,18 @@ class Trainer:
         t.update(qkv=qkv, prob=prob, prob_d=prob_d, lse=lse, key_pad=key_pad, attn=attn, proj=proj, x1=x1, h=h, c2=c2, scale=scale)
         return x2, t
 
-    def _ln_bwd(self, z, res, dy, gname, bname, M, H, bias_name=None, relu_mask=False, bias_out=None):
+    def _ln_bwd(self, z, res, dy, gname, bname, M, H, bias_name=None, relu_mask=False, bias_out=None, drop=None):
         """dz of y = LN(z [+ res]); dgamma / dbeta (adjacent in the flat buffer: one column-sum launch) and, when asked, the
         bias gradient of the layer that produced z (= column sums of dz; with relu_mask dz is the pre-activation gradient)."""
         o = self.ops
         nparts = int(o.lib.fs2_op_layernorm_bwd_parts(M))
         dz, part = o.act(M, H), o.empty(nparts, 3 * H)
-        o.ck(o.lib.fs2_op_layernorm_bwd(o.dt, _p(z), _p(res), _p(dy), _p(self.P[gname]), _p(dz), _p(part), M, H, int(relu_mask), o.st()),
-             "layernorm_bwd")
+        if drop is not None and drop[0] > 0:  # dy is the gradient of dropout(y): the mask is applied on load, no separate pass
+            o.ck(o.lib.fs2_op_layernorm_bwd_dropout(o.dt, _p(z), _p(res), _p(dy), _p(self.P[gname]), _p(dz), _p(part), M, H, int(relu_mask),
+                                                    C.c_float(drop[0]), C.c_uint64(o.seed), C.c_uint64(drop[1]), o.st()), "layernorm_bwd")
+        else:
+            o.ck(o.lib.fs2_op_layernorm_bwd(o.dt, _p(z), _p(res), _p(dy), _p(self.P[gname]), _p(dz), _p(part), M, H, int(relu_mask),
+                                            o.st()), "layernorm_bwd")
         gw, gb = self.G[gname], self.G[bname]
         if gb.data_ptr() == gw.data_ptr() + 4 * H and (bias_name is None) != (bias_out is None):
             # dgamma | dbeta (adjacent in the flat buffer) and the bias gradient out of one launch
@@ -591,11 +595,17 @@ class Trainer:
                 c = o.gemm(y, W[f"{p}.0.module.weight"], P[f"{p}.0.module.bias"], M, filt, cin, taps=k, S=S, relu=True)
             last = j == nlayers - 1
             fused_head = last and pd <= 0
-            yn, pred = o.layernorm(c, None, P[f"{p}.2.weight"], P[f"{p}.2.bias"], M, filt,
-                                   dot_w=P[f"{prefix}.linear.weight"] if fused_head else None,
-                                   dot_b=float(P[f"{prefix}.linear.bias"][0]) if fused_head else 0.0, mask=mask if fused_head else None)
-            kd = o.site()
-            o.dropout(yn, pd, kd)  # VarianceConvolutionLayer ends in nn.Dropout (model.py:539,557)
+            kd = None
+            if pd > 0:  # VarianceConvolutionLayer ends in nn.Dropout (model.py:539,557): inside the LayerNorm launch
+                kd = o.site()
+                yn, pred = o.act(M, filt), None
+                o.ck(o.lib.fs2_op_layernorm_dropout(o.dt, _p(c), None, _p(P[f"{p}.2.weight"]), _p(P[f"{p}.2.bias"]), _p(yn), M, filt,
+                                                    C.c_float(pd), C.c_uint64(o.seed), C.c_uint64(kd), o.st()), "layernorm_dropout")
+            else:
+                yn, pred = o.layernorm(c, None, P[f"{p}.2.weight"], P[f"{p}.2.bias"], M, filt,
+                                       dot_w=P[f"{prefix}.linear.weight"] if fused_head else None,
+                                       dot_b=float(P[f"{prefix}.linear.bias"][0]) if fused_head else 0.0, mask=mask if fused_head else None)
+                kd = o.site()
             if last and pd > 0:
                 pred = o.empty(M)
                 o.ck(o.lib.fs2_op_row_dot(o.dt, _p(yn), _p(P[f"{prefix}.linear.weight"]), _p(P[f"{prefix}.linear.bias"]), _p(mask), _p(pred),
@@ -620,9 +630,10 @@ class Trainer:
         for j in reversed(range(nlayers)):
             p = f"{prefix}.layers.{j}.layers"
             lt = t["layers"][j]
-            o.dropout(dy, t["pd"], lt["kd"])
+            drop = (t["pd"], lt["kd"])  # the layer's Dropout behind its LayerNorm: undone inside the LayerNorm backward launch
             if dw:
-                dc = self._ln_bwd(lt["c"], None, dy, f"{p}.2.weight", f"{p}.2.bias", M, filt, bias_name=f"{p}.0.module.1.bias", relu_mask=True)
+                dc = self._ln_bwd(lt["c"], None, dy, f"{p}.2.weight", f"{p}.2.bias", M, filt, bias_name=f"{p}.0.module.1.bias", relu_mask=True,
+                                  drop=drop)
                 o.wgrad(dc, lt["u"], G[f"{p}.0.module.1.weight"], None, M, filt, lt["cin"])
                 du = o.dgrad(dc, W[f"{p}.0.module.1.weight"], M, filt, lt["cin"], wt=self._wt(f"{p}.0.module.1.weight"))
                 dxin = o.dwconv_bwd(du, lt["xin"], P[f"{p}.0.module.0.weight"], G[f"{p}.0.module.0.weight"], G[f"{p}.0.module.0.bias"],
@@ -632,7 +643,8 @@ class Trainer:
                 else:
                     dy = dxin
                 continue
-            dc = self._ln_bwd(lt["c"], None, dy, f"{p}.2.weight", f"{p}.2.bias", M, filt, bias_name=f"{p}.0.module.bias", relu_mask=True)
+            dc = self._ln_bwd(lt["c"], None, dy, f"{p}.2.weight", f"{p}.2.bias", M, filt, bias_name=f"{p}.0.module.bias", relu_mask=True,
+                              drop=drop)
             o.wgrad(dc, lt["xin"], G[f"{p}.0.module.weight"], None, M, filt, lt["cin"], taps=k, S=S)
             if j == 0:
                 o.dgrad(dc, W[f"{p}.0.module.weight"], M, filt, lt["cin"], taps=k, S=S, out=dx_out, accumulate=True, wt=self._wt(f"{p}.0.module.weight"))

@@ -791,3 +791,36 @@ def test_col_sum_weighted(dtype):
     _lib.check(lib.fs2_op_col_sum_weighted(_lib.FS2_BF16 if dtype == "bf16" else F32, p(x.to(DEV)), p(w.to(DEV)), p(out), p(ws), M, N, N, 1,
                                            0.5, st()))
     close(out, 1.0 + 0.5 * (w.double()[:, None] * x.double()).sum(0), 1e-5)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_layernorm_with_dropout_matches_the_two_pass_form(dtype):
+    """fs2_op_layernorm_dropout == fs2_op_layernorm then fs2_op_dropout (same mask: the element index over (M, H)), and
+    fs2_op_layernorm_bwd_dropout == fs2_op_dropout on dy then fs2_op_layernorm_bwd (fp32: bit-equal; bf16: one rounding fewer)."""
+    lib = _lib.load()
+    bf = dtype == "bf16"
+    dt, td = (_lib.FS2_BF16, torch.bfloat16) if bf else (F32, torch.float32)
+    g = torch.Generator().manual_seed(4)
+    M, H, pdrop, seed, key = 300, 264, 0.3, 12345, 7
+    x = torch.randn(M, H, generator=g).to(td).to(DEV)
+    gam, bet = (1 + 0.1 * torch.randn(H, generator=g)).to(DEV), (0.1 * torch.randn(H, generator=g)).to(DEV)
+    y1 = torch.empty(M, H, device=DEV, dtype=td)
+    _lib.check(lib.fs2_op_layernorm_dropout(dt, p(x), None, p(gam), p(bet), p(y1), M, H, pdrop, seed, key, st()))
+    y0 = torch.empty(M, H, device=DEV, dtype=td)
+    _lib.check(lib.fs2_op_layernorm(dt, p(x), None, p(gam), p(bet), p(y0), None, 0.0, None, None, M, H, st()))
+    _lib.check(lib.fs2_op_dropout(dt, p(y0), p(y0), M * H, pdrop, seed, key, st()))
+    assert torch.equal(y1 == 0, y0 == 0) and 0.25 < float((y1 == 0).float().mean()) < 0.35
+    close(y1, y0.cpu(), rel=1e-2 if bf else 1e-6)
+    dy = torch.randn(M, H, generator=g).to(td).to(DEV)
+    nparts = lib.fs2_op_layernorm_bwd_parts(M)
+    dz1, part1 = torch.empty(M, H, device=DEV, dtype=td), torch.empty(nparts, 3 * H, device=DEV)
+    _lib.check(lib.fs2_op_layernorm_bwd_dropout(dt, p(x), None, p(dy), p(gam), p(dz1), p(part1), M, H, 0, pdrop, seed, key, st()))
+    dyd = dy.clone()
+    _lib.check(lib.fs2_op_dropout(dt, p(dyd), p(dyd), M * H, pdrop, seed, key, st()))
+    dz0, part0 = torch.empty(M, H, device=DEV, dtype=td), torch.empty(nparts, 3 * H, device=DEV)
+    _lib.check(lib.fs2_op_layernorm_bwd(dt, p(x), None, p(dyd), p(gam), p(dz0), p(part0), M, H, 0, st()))
+    if bf:
+        close(dz1, dz0.cpu(), rel=2e-2)
+        close(part1, part0.cpu(), rel=1e-2)
+    else:
+        assert torch.equal(dz1, dz0) and torch.equal(part1, part0)
