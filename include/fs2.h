@@ -161,6 +161,13 @@ int fs2_set_debug(fs2_engine* e, int32_t on);
 /* A/B and parity aid: on = 0 runs every VariancePredictor as per-layer conv+LayerNorm launches, 1
  * (default) as the single-launch kernel where the shape allows it (bf16, filter 256, k = 3, dense). */
 int fs2_set_fused_predictor(fs2_engine* e, int32_t on);
+/* 1: fs2_decode replays its launches (~50: variance adaptor after the length regulator, decoder, mel head) as a hipGraph once
+ * the same shape AND buffer addresses (outputs, arenas) are seen again - first sight runs plainly, second captures, later calls
+ * are one hipGraphLaunch on an engine-owned stream ordered against the caller's with events.  Same kernels, same arguments:
+ * results are bit-identical.  Off by default; debug taps, per-class profiling and forced buckets always take the
+ * plain path; a caller workspace (fs2_set_workspace) is part of the signature.  fs2_graph_replays: how many decodes were replays (tests, diagnostics). */
+int fs2_set_graphs(fs2_engine* e, int32_t on);
+int64_t fs2_graph_replays(const fs2_engine* e);
 /* A/B and parity aid: hidden sizes above 256 with depth-wise blocks (LightSpeech, model.py:73-93,541-558) run LayerNorm
  * deferred (default 1): the GEMM in front of a LayerNorm leaves pre-norm rows + row statistics, the depth-wise conv / the
  * next residual add normalise on load and the remaining LayerNorms are normalise-only passes; 0 = GEMM launch + LayerNorm

@@ -117,6 +117,9 @@ def load():
     lib.fs2_set_frames.argtypes = [vp, i32]
     lib.fs2_set_zero_pad_mel.argtypes = [vp, i32]
     lib.fs2_set_fused_predictor.argtypes = [vp, i32]
+    lib.fs2_set_graphs.argtypes = [vp, i32]
+    lib.fs2_graph_replays.restype = C.c_int64
+    lib.fs2_graph_replays.argtypes = [vp]
     lib.fs2_set_deferred_layernorm.argtypes = [vp, i32]
     lib.fs2_debug_copy.argtypes = [vp, C.c_char_p, vp, vp]
     lib.fs2_force_buckets.argtypes = [vp, i32, vp]

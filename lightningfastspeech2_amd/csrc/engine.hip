@@ -122,6 +122,14 @@ struct fs2_engine {
     bool finalized = false;
     bool debug = false;
     bool fuse_predictor = true;
+    // fs2_set_graphs: the decode phase replayed as a hipGraph (one launch instead of ~50) once a shape / buffer signature repeats
+    bool use_graph = false;
+    struct GraphEntry { std::vector<uint64_t> key; hipGraphExec_t exec = nullptr; uint64_t stamp = 0; bool bad = false; };
+    std::vector<GraphEntry> dgraphs;
+    hipStream_t gstream = nullptr;
+    hipEvent_t gev_in = nullptr, gev_out = nullptr;
+    uint64_t gclock = 0;
+    long graph_replays = 0;
     bool zero_pad_mel = false;
     bool defer_ln = true;      // hidden > 256, depth-wise blocks: LayerNorm deferred into its consumers (A/B: fs2_set_deferred_layernorm)
     bool front_split = false;  // FS2_MIXED_X3: the front's fp32 GEMMs / convs run as bf16 x 3 split products
@@ -815,6 +823,10 @@ int fs2_destroy(fs2_engine* e) {
     e->dbg.release();
     e->dbg_enc.release();
     if (e->h_pinned) (void)hipHostFree(e->h_pinned);
+    for (auto& g : e->dgraphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    if (e->gev_in) (void)hipEventDestroy(e->gev_in);
+    if (e->gev_out) (void)hipEventDestroy(e->gev_out);
+    if (e->gstream) (void)hipStreamDestroy(e->gstream);
     for (auto& s : e->prof)
         for (auto& ev : s.ev) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     delete e;
@@ -1030,10 +1042,7 @@ int fs2_last_totals(const fs2_engine* e, int32_t* totals, int32_t* guard, int32_
     return FS2_OK;
 }
 
-int fs2_decode(fs2_engine* e, const fs2_outputs* out, void* stream) {
-    if (!e || !out) return FS2_ERR_ARG;
-    if (!e->encoded) return fail(e, FS2_ERR_STATE, "fs2_decode without a preceding successful fs2_encode");
-    hipStream_t st = (hipStream_t)stream;
+static int decode_body(fs2_engine* e, const fs2_outputs* out, hipStream_t st) {
     const fs2_config& c = e->cfg;
     const int B = e->B, L = e->L, T = e->T;
     const size_t H = c.hidden, MT = (size_t)B * T, ML = (size_t)B * L, esz = e->esz;
@@ -1116,6 +1125,101 @@ int fs2_decode(fs2_engine* e, const fs2_outputs* out, void* stream) {
     for (int v = 0; v < FS2_MAX_VARIANCES; ++v) e->forced_idx[v] = nullptr, e->forced_tgt[v] = nullptr;  // one-shot
     return FS2_OK;
 }
+
+static void drop_graphs(fs2_engine* e) {
+    for (auto& g : e->dgraphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    e->dgraphs.clear();
+}
+
+// The decode phase (variance adaptor after the length regulator, decoder, mel head: ~50 launches on one stream, no host
+// decision in between) as a hipGraph.  A signature = shape + every buffer address a launch sees (the caller's outputs, the
+// arenas).  First sight of a signature: plain launches (lazy initialisation happens there); second sight: the same code path
+// runs under stream capture on an engine-owned non-blocking stream, is instantiated and launched; from then on one
+// hipGraphLaunch.  The caller's stream (the legacy null stream included, which cannot be captured itself) is ordered around it
+// with two events.  Anything the capture cannot hold (debug taps, per-class profiling, one-shot forced buckets) takes the plain path.
+int fs2_decode(fs2_engine* e, const fs2_outputs* out, void* stream) {
+    if (!e || !out) return FS2_ERR_ARG;
+    if (!e->encoded) return fail(e, FS2_ERR_STATE, "fs2_decode without a preceding successful fs2_encode");
+    hipStream_t st = (hipStream_t)stream;
+    bool plain = !e->use_graph || e->debug || e->T == 0;
+    for (int k = 0; k < FS2_K_COUNT && !plain; ++k) plain = e->prof[k].enabled;
+    for (int v = 0; v < FS2_MAX_VARIANCES && !plain; ++v) plain = e->forced_idx[v] || e->forced_tgt[v];
+    static const bool gdbg = getenv("FS2_GRAPH_DEBUG") != nullptr;
+    if (plain) { if (gdbg && e->use_graph) fprintf(stderr, "fs2 graph: plain path (debug %d, T %d, external %d)\n", (int)e->debug, e->T, (int)e->scratch.external); return decode_body(e, out, st); }
+    // the arena may grow (device sync + hipMalloc) only outside a capture; the body's own call is then a no-op
+    const char* base0 = e->scratch.base;
+    CHK(ensure_arena(e, e->scratch, decode_scratch_bytes(e, e->B, e->T), "scratch"));
+    if (e->scratch.base != base0) drop_graphs(e);
+    std::vector<uint64_t> key = {(uint64_t)e->B, (uint64_t)e->L, (uint64_t)e->T, (uint64_t)e->scratch.base, (uint64_t)e->persist.base,
+                                 (uint64_t)e->xA, (uint64_t)e->d_cum, (uint64_t)e->spk, (uint64_t)e->zero_pad_mel, (uint64_t)e->fuse_predictor,
+                                 (uint64_t)e->defer_ln, (uint64_t)e->front_split, (uint64_t)out->mel, (uint64_t)out->tgt_mask,
+                                 (uint64_t)out->duration_prediction, (uint64_t)out->duration_rounded, (uint64_t)out->src_mask};
+    for (int v = 0; v < FS2_MAX_VARIANCES; ++v) {
+        key.push_back((uint64_t)out->variances[v]);
+        key.push_back((uint64_t)out->var_mean_std[v]);
+        key.push_back((uint64_t)out->var_spectrogram[v]);
+    }
+    fs2_engine::GraphEntry* g = nullptr;
+    for (auto& c : e->dgraphs) if (c.key == key) { g = &c; break; }
+    if (!g) {  // first sight: remember it, run plainly
+        if (e->dgraphs.size() >= 8) {
+            size_t old = 0;
+            for (size_t i = 1; i < e->dgraphs.size(); ++i) if (e->dgraphs[i].stamp < e->dgraphs[old].stamp) old = i;
+            if (e->dgraphs[old].exec) (void)hipGraphExecDestroy(e->dgraphs[old].exec);
+            e->dgraphs.erase(e->dgraphs.begin() + old);
+        }
+        e->dgraphs.emplace_back();
+        e->dgraphs.back().key = key;
+        e->dgraphs.back().stamp = ++e->gclock;
+        if (gdbg) fprintf(stderr, "fs2 graph: new signature (%zu cached) mel %p\n", e->dgraphs.size(), (void*)out->mel);
+        return decode_body(e, out, st);
+    }
+    g->stamp = ++e->gclock;
+    if (g->bad) { if (gdbg) fprintf(stderr, "fs2 graph: signature marked bad\n"); return decode_body(e, out, st); }
+    if (!e->gstream) {
+        if (hipStreamCreateWithFlags(&e->gstream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&e->gev_in, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&e->gev_out, hipEventDisableTiming) != hipSuccess) {
+            e->use_graph = false;
+            return decode_body(e, out, st);
+        }
+    }
+    if (!g->exec) {  // second sight: capture the same code path
+        if (hipStreamBeginCapture(e->gstream, hipStreamCaptureModeThreadLocal) != hipSuccess) { g->bad = true; return decode_body(e, out, st); }
+        const bool enc = e->encoded, mid = e->mid_forward;
+        const int r = decode_body(e, out, e->gstream);
+        hipGraph_t graph = nullptr;
+        const hipError_t ce = hipStreamEndCapture(e->gstream, &graph);
+        hipError_t ie = hipSuccess;
+        if (r != FS2_OK || ce != hipSuccess || !graph || (ie = hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0)) != hipSuccess) {
+            if (gdbg) fprintf(stderr, "fs2 graph: capture failed (body %d, end %d %s, instantiate %d)\n", r, (int)ce, hipGetErrorString(ce), (int)ie);
+            if (graph) (void)hipGraphDestroy(graph);
+            (void)hipGetLastError();
+            g->exec = nullptr;
+            g->bad = true;
+            e->encoded = enc; e->mid_forward = mid;
+            return decode_body(e, out, st);  // nothing was executed during the capture
+        }
+        (void)hipGraphDestroy(graph);
+    }
+    HIPCHK(e, hipEventRecord(e->gev_in, st));
+    HIPCHK(e, hipStreamWaitEvent(e->gstream, e->gev_in, 0));
+    HIPCHK(e, hipGraphLaunch(g->exec, e->gstream));
+    HIPCHK(e, hipEventRecord(e->gev_out, e->gstream));
+    HIPCHK(e, hipStreamWaitEvent(st, e->gev_out, 0));
+    e->mid_forward = false;
+    e->graph_replays++;
+    return FS2_OK;
+}
+
+int fs2_set_graphs(fs2_engine* e, int32_t on) {
+    if (!e) return FS2_ERR_ARG;
+    e->use_graph = on != 0;
+    if (!on) drop_graphs(e);
+    return FS2_OK;
+}
+
+int64_t fs2_graph_replays(const fs2_engine* e) { return e ? e->graph_replays : -1; }
 
 int fs2_force_buckets(fs2_engine* e, int32_t variance_index, const int32_t* idx) {
     if (!e || variance_index < 0 || variance_index >= e->cfg.n_variances) return FS2_ERR_ARG;

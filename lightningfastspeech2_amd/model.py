@@ -220,6 +220,15 @@ class Engine:
         """A/B: wide depth-wise blocks with LayerNorm deferred into its consumers (default) or as its own launches."""
         _lib.check(self.lib.fs2_set_deferred_layernorm(self.handle, int(on)), self.handle, "set_deferred_layernorm")
 
+    def set_graphs(self, on: bool):
+        """Replay the decode phase (~50 launches) as a hipGraph once a shape + buffer signature repeats (include/fs2.h
+        fs2_set_graphs); bit-identical results, one launch instead of ~50 - the forward stops depending on how fast the host
+        can issue launches.  Off by default."""
+        _lib.check(self.lib.fs2_set_graphs(self.handle, int(on)), self.handle, "set_graphs")
+
+    def graph_replays(self) -> int:
+        return int(self.lib.fs2_graph_replays(self.handle))
+
     def set_fused_predictor(self, on: bool):
         """A/B: run the variance/duration predictors as one launch each (default) or layer by layer."""
         _lib.check(self.lib.fs2_set_fused_predictor(self.handle, int(on)), self.handle, "set_fused_predictor")

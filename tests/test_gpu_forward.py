@@ -425,3 +425,47 @@ def test_one_engine_many_shapes_and_checkpoint_roundtrip(tmp_path):
         assert int((o["duration_rounded"] != ref["duration_rounded"]).sum()) <= 1
     again = _cpu(m({"phones": torch.from_numpy(g.phones), "speaker": torch.from_numpy(g.speaker)}, inference=True))
     assert torch.equal(again["mel"], out["mel"])
+
+
+@pytest.mark.gpu
+def test_decode_graph_replay_is_bit_identical():
+    """fs2_set_graphs: the decode phase replayed as a hipGraph (first sight plain, second captured, then replays) gives the
+    plain path's outputs bit for bit, for two alternating output-buffer sets and after a shape change."""
+    import numpy as np
+    import torch
+    from lightningfastspeech2_amd.config import preset
+    from lightningfastspeech2_amd.model import FastSpeech2
+    from lightningfastspeech2_amd.weights import synth_inputs, synth_state_dict
+    cfg = preset("ref-default")
+    sd = synth_state_dict(cfg, 3, duration_bias=float(np.log(4.0)), duration_weight_scale=0.0)
+    model = FastSpeech2(cfg, sd, precision="bf16", device="cuda:0")
+
+    def run(B, L, seed):
+        inp = synth_inputs(cfg, B, L, seed=seed)
+        batch = {"phones": torch.from_numpy(inp["phones"]).cuda(), "speaker": torch.from_numpy(inp["speaker"]).cuda()}
+        out = model(batch, inference=True)
+        torch.cuda.synchronize()
+        return {k: v.clone() for k, v in out.items() if isinstance(v, torch.Tensor)}
+
+    want_a, want_b = run(3, 40, 1), run(2, 24, 2)
+    model.engine.set_graphs(True)
+    n0 = model.engine.graph_replays()
+    keep = []
+    for it in range(6):
+        got = run(3, 40, 1)
+        keep.append(got)  # hold the outputs: the allocator hands out different buffers, more than one signature is cached
+        keep = keep[-2:]
+        for k, v in want_a.items():
+            assert torch.equal(got[k], v), (it, k)
+    assert model.engine.graph_replays() > n0
+    for it in range(4):
+        got = run(2, 24, 2)
+        for k, v in want_b.items():
+            assert torch.equal(got[k], v), (it, k)
+    got = run(3, 40, 1)
+    for k, v in want_a.items():
+        assert torch.equal(got[k], v), k
+    model.engine.set_graphs(False)
+    got = run(3, 40, 1)
+    for k, v in want_a.items():
+        assert torch.equal(got[k], v), k
