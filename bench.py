@@ -309,14 +309,25 @@ def main():
     # dominant kernel: the decoder FFN's first GEMM - the dense k-tap conv (implicit GEMM), or in a depth-wise
     # (LightSpeech) block the pointwise H -> F GEMM behind the depth-wise conv.  One launch shape, few events.
     kcls = _lib.K_DEC_FFN_CONV1
+    # the events the timed region records into exist before it starts (event creation is a driver call of its own)
+    model.engine.profile_reserve(kcls, args.steps * (cfg.encoder_layers + cfg.decoder_layers) * 2 + 16)
     model.engine.profile_enable(kcls, True)
     sync()
+    trace = [] if os.environ.get("FS2_BENCH_TRACE") else None  # host-side time of each step() call (diagnostics)
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        if trace is not None:
+            ts = time.perf_counter()
         step()
+        if trace is not None:
+            trace.append(time.perf_counter() - ts)
     drain()
+    t_sync = time.perf_counter()
     sync()
     elapsed = time.perf_counter() - t0
+    if trace is not None and rank == 0:
+        print(f"closing sync: {(time.perf_counter() - t_sync) * 1e3:.2f} ms", file=sys.stderr)
+        print("host ms per step():", " ".join(f"{t * 1e3:.2f}" for t in trace), file=sys.stderr)
     prof = model.engine.profile_read(kcls)
     model.engine.profile_enable(kcls, False)
 

@@ -195,6 +195,8 @@ enum fs2_kernel_class {
     FS2_K_COUNT = 5
 };
 int fs2_profile_enable(fs2_engine* e, int32_t kernel_class, int32_t enable);
+/* pre-create the event pairs of `pairs` bracketed launches (otherwise they are created on first use, inside the caller's timed region) */
+int fs2_profile_reserve(fs2_engine* e, int32_t kernel_class, int32_t pairs);
 /* Sums elapsed ms / launches / algorithmic flops / algorithmic bytes since enable; syncs the events. */
 int fs2_profile_read(fs2_engine* e, int32_t kernel_class, double* total_ms, int64_t* launches,
                      double* flops, double* bytes);

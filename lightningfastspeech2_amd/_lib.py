@@ -125,6 +125,7 @@ def load():
     lib.fs2_force_buckets.argtypes = [vp, i32, vp]
     lib.fs2_force_variance_targets.argtypes = [vp, i32, vp]
     lib.fs2_profile_enable.argtypes = [vp, i32, i32]
+    lib.fs2_profile_reserve.argtypes = [vp, i32, i32]
     lib.fs2_profile_read.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_int64),
                                      C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.fs2_op_convert.argtypes = [i32, i32, vp, vp, C.c_size_t, vp]

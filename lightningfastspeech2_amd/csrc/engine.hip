@@ -1250,6 +1250,21 @@ int fs2_profile_enable(fs2_engine* e, int32_t cls, int32_t enable) {
     return FS2_OK;
 }
 
+// Create the event pairs of `pairs` bracketed launches now, so that a timed region with profiling on records into existing
+// events only (hipEventCreate is an ioctl that was seen to take tens of microseconds on hosts whose other GPUs are busy - 160
+// of them inside bench.py's timed region turned 2.4 ms forwards into 4.5 ms ones).
+int fs2_profile_reserve(fs2_engine* e, int32_t cls, int32_t pairs) {
+    if (!e || cls < 0 || cls >= FS2_K_COUNT || pairs < 0) return FS2_ERR_ARG;
+    ProfSlot& s = e->prof[cls];
+    while ((int)s.ev.size() < pairs) {
+        hipEvent_t a, b;
+        HIPCHK(e, hipEventCreate(&a));
+        if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); return fail(e, FS2_ERR_HIP, "hipEventCreate failed"); }
+        s.ev.emplace_back(a, b);
+    }
+    return FS2_OK;
+}
+
 int fs2_profile_read(fs2_engine* e, int32_t cls, double* total_ms, int64_t* launches, double* flops, double* bytes) {
     if (!e || cls < 0 || cls >= FS2_K_COUNT) return FS2_ERR_ARG;
     ProfSlot& s = e->prof[cls];

@@ -236,6 +236,10 @@ class Engine:
     def profile_enable(self, kernel_class: int, on: bool = True):
         _lib.check(self.lib.fs2_profile_enable(self.handle, kernel_class, int(on)), self.handle, "profile_enable")
 
+    def profile_reserve(self, kernel_class: int, pairs: int):
+        """create the event pairs of `pairs` bracketed launches ahead of a timed region"""
+        _lib.check(self.lib.fs2_profile_reserve(self.handle, kernel_class, int(pairs)), self.handle, "profile_reserve")
+
     def profile_read(self, kernel_class: int):
         ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
         _lib.check(self.lib.fs2_profile_read(self.handle, kernel_class, C.byref(ms), C.byref(n), C.byref(fl),
