@@ -340,6 +340,11 @@ int fs2_op_layernorm_bwd(int32_t dtype, const void* z, const void* res, const vo
 int fs2_op_layernorm_bwd_dropout(int32_t dtype, const void* z, const void* res, const void* dy, const float* gamma, void* dz,
                                  float* part, int32_t M, int32_t H, int32_t relu_mask, float drop_p, uint64_t seed, uint64_t key,
                                  void* hip_stream);
+/* fs2_op_layernorm with its fused Linear(H, 1) head reading the bias from DEVICE memory (a parameter being trained: the host
+ * copy would cost a read-back + stream sync per step) */
+int fs2_op_layernorm_head(int32_t dtype, const void* x, const void* res, const float* gamma, const float* beta, void* y,
+                          const float* dot_w, const float* dot_b_dev, const uint8_t* mask, float* pred, int32_t M, int32_t H,
+                          void* hip_stream);
 /* y = dropout(LayerNorm(x [+ res])) in one launch; the mask is fs2_op_dropout's over the (M, H) element index */
 int fs2_op_layernorm_dropout(int32_t dtype, const void* x, const void* res, const float* gamma, const float* beta, void* y,
                              int32_t M, int32_t H, float drop_p, uint64_t seed, uint64_t key, void* hip_stream);

@@ -188,6 +188,17 @@ int fs2_op_layernorm(int32_t dtype, const void* x, const void* res, const float*
     a.M = M; a.H = H; a.eps = 1e-5f;
     return launch_layernorm(a, dtype, (hipStream_t)stream);
 }
+int fs2_op_layernorm_head(int32_t dtype, const void* x, const void* res, const float* gamma, const float* beta, void* y,
+                          const float* dot_w, const float* dot_b_dev, const uint8_t* mask, float* pred, int32_t M, int32_t H,
+                          void* stream) {
+    if (!dot_w || !dot_b_dev || !pred) return FS2_ERR_ARG;
+    LayerNormArgs a;
+    a.x = x; a.res = res; a.gamma = gamma; a.beta = beta; a.y = y;
+    a.dot_w = dot_w; a.dot_b = 0.f; a.mask = mask; a.pred = pred;
+    a.M = M; a.H = H; a.eps = 1e-5f;
+    a.dot_b_dev = dot_b_dev;
+    return launch_layernorm(a, dtype, (hipStream_t)stream);
+}
 int fs2_op_layernorm_dropout(int32_t dtype, const void* x, const void* res, const float* gamma, const float* beta, void* y,
                              int32_t M, int32_t H, float drop_p, uint64_t seed, uint64_t key, void* stream) {
     if (!(drop_p >= 0.f && drop_p < 1.f) || !y) return FS2_ERR_ARG;

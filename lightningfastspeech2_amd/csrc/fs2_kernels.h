@@ -190,6 +190,7 @@ struct LayerNormArgs {
     float eps;
     const float* pre_stats = nullptr;  // (M, pre_parts) float2 partial (sum, sum of squares) of x's rows: skip the reductions
     int pre_parts = 0;
+    const float* dot_b_dev = nullptr;  // device scalar used instead of dot_b when given (a trained bias: no host read-back)
     float drop_p = 0.f;                // > 0: y = dropout(LN(.)), mask of fs2_op_dropout over the (M, H) element index
     uint64_t drop_seed = 0, drop_key = 0;
 };

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LayerNormArgs p) {
         }
     }
     if (p.dot_w) {
-        dot = wave_sum(dot) + p.dot_b;
+        dot = wave_sum(dot) + (p.dot_b_dev ? *p.dot_b_dev : p.dot_b);
         if (lane == 0) p.pred[row] = (p.mask && p.mask[row]) ? 0.f : dot;
     }
 }

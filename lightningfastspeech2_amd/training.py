@@ -602,9 +602,13 @@ class Trainer:
                 o.ck(o.lib.fs2_op_layernorm_dropout(o.dt, _p(c), None, _p(P[f"{p}.2.weight"]), _p(P[f"{p}.2.bias"]), _p(yn), M, filt,
                                                     C.c_float(pd), C.c_uint64(o.seed), C.c_uint64(kd), o.st()), "layernorm_dropout")
             else:
-                yn, pred = o.layernorm(c, None, P[f"{p}.2.weight"], P[f"{p}.2.bias"], M, filt,
-                                       dot_w=P[f"{prefix}.linear.weight"] if fused_head else None,
-                                       dot_b=float(P[f"{prefix}.linear.bias"][0]) if fused_head else 0.0, mask=mask if fused_head else None)
+                if fused_head:  # LayerNorm + the Linear(filter, 1) head + mask in one launch, the head's bias read on the device
+                    yn, pred = o.act(M, filt), o.empty(M)
+                    o.ck(o.lib.fs2_op_layernorm_head(o.dt, _p(c), None, _p(P[f"{p}.2.weight"]), _p(P[f"{p}.2.bias"]), _p(yn),
+                                                     _p(P[f"{prefix}.linear.weight"]), _p(P[f"{prefix}.linear.bias"]), _p(mask), _p(pred),
+                                                     M, filt, o.st()), "layernorm_head")
+                else:
+                    yn, pred = o.layernorm(c, None, P[f"{p}.2.weight"], P[f"{p}.2.bias"], M, filt)
                 kd = o.site()
             if last and pd > 0:
                 pred = o.empty(M)
