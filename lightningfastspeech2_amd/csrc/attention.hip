@@ -449,9 +449,22 @@ int launch_transpose_v(const AttnArgs& a, int dtype, hipStream_t stream) {
     return FS2_ERR_SHAPE;
 }
 
+int g_attn_pipe = 3;
+
 int launch_attention(const AttnArgs& a, int dtype, hipStream_t stream) {
     if (a.B <= 0 || a.S <= 0) return FS2_OK;
     if (a.Spad % 64 || a.Spad < a.S || a.H % a.heads) return FS2_ERR_SHAPE;
+    if (g_attn_pipe && attention_pipe_supported(a, dtype)) {
+        // WHICH kernel family computes an utterance may depend on the utterance only (its length, the head count), never on the
+        // batch around it: a shard run alone must be bit-equal to its rows of the whole batch (the data-parallel invariant,
+        // tests/test_gpu_configs.py).  The two pipelined variants are bit-identical per row (same per-row instruction sequence),
+        // so the choice between THEM may follow the launch size: one workgroup per CU with 64 queries per wave from about two
+        // 128-query units per CU (measured, r03: C2 / C3 / C5 decoder 90 / 296 / 90 us against 98 / 315 / 93 for the kernel
+        // below), two 4 x 32-query workgroups per CU under that.  Short sequences (the encoder's 256 phonemes) stay below.
+        const long long per_utt = (long long)a.heads * ((a.S + 127) / 128), units = per_utt * a.B;
+        if (g_attn_pipe == 1 || g_attn_pipe == 2) return launch_attention_pipe(a, g_attn_pipe, stream);
+        if (per_utt >= 16) return launch_attention_pipe(a, units >= 512 ? 2 : 1, stream);
+    }
     const int d = a.H / a.heads;
 #define FS2_ATTN_CASE(DD)                                                        \
     if (d == DD) return dtype == FS2_BF16 ? launch_td<bf16, DD>(a, stream) : launch_td<float, DD>(a, stream);

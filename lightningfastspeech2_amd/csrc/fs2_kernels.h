@@ -83,6 +83,10 @@ void attention_bwd_set_blocks(int which, int nb);  // A/B knob: 16-row blocks pe
 int launch_attention_bwd(const AttnBwdArgs& a, int dtype, hipStream_t stream);
 int launch_transpose_v(const AttnArgs& a, int dtype, hipStream_t stream);  // fills a.vt from a.qkv
 int launch_attention(const AttnArgs& a, int dtype, hipStream_t stream);    // needs a.vt filled
+// attention_pipe.hip: the software-pipelined kernel for the MFMA-bound instance (bf16, head dim 128, no attention dropout)
+bool attention_pipe_supported(const AttnArgs& a, int dtype);
+int launch_attention_pipe(const AttnArgs& a, int variant, hipStream_t stream);
+extern int g_attn_pipe;
 
 // Whole dense VariancePredictor (n x [conv k=3 -> ReLU -> LN] -> Linear(H,1) -> mask) in one launch;
 // bf16, H = 256, k = 3 (predictor_fused.hip).  wpk = per-layer weights in MFMA fragment order

@@ -297,6 +297,92 @@ def test_attention_spike_forces_rescale():
     assert float((got - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
 
 
+@pytest.fixture
+def pipe_kernel(request):
+    """Force the software-pipelined attention kernel (attention_pipe.hip) for shapes of any size; 1203 = by size again."""
+    G.lib().fs2_op_set_gemm_variant(1200 + request.param)
+    yield request.param
+    G.lib().fs2_op_set_gemm_variant(1203)
+
+
+def _mask(kind, B, S):
+    mask = torch.zeros(B, S, dtype=torch.bool)
+    if kind == "suffix":
+        for b in range(B):
+            mask[b, S - (7 + 13 * b) % S:] = True
+        mask[0, :] = False
+        mask[0, S - S // 2:] = True   # a long padded tail: whole tiles are never visited
+    elif kind == "scatter":
+        mask = torch.rand(B, S, generator=torch.Generator().manual_seed(11)) < 0.3
+        mask[:, 0] = False
+    elif kind == "prefix":            # valid keys only at the END: leading all-padded tiles, a first tile whose first half is padded
+        mask[:, :S - min(S, 40)] = True
+    elif kind == "holes":             # whole 64-key tiles padded in the middle of the valid range
+        mask[:, 64:192] = True
+        mask[1 % B, 200:S - 3] = True
+    return mask
+
+
+@pytest.mark.parametrize("pipe_kernel", [1, 2], indirect=True)
+@pytest.mark.parametrize("B,S,H,heads,mask_kind", [
+    (2, 200, 256, 2, "suffix"), (2, 64, 256, 2, "none"), (2, 257, 256, 2, "scatter"), (1, 700, 256, 2, "suffix"),
+    (3, 130, 128, 1, "suffix"), (2, 33, 384, 3, "scatter"), (2, 300, 256, 2, "prefix"), (2, 450, 256, 2, "holes"),
+    (1, 1536, 256, 2, "none"), (5, 129, 256, 2, "suffix"), (1, 1, 128, 1, "none")])
+def test_attention_pipelined(pipe_kernel, B, S, H, heads, mask_kind):
+    """The MFMA-bound instance's kernel (bf16, head dim 128) against the fp32 reference of the same op: every work-split shape
+    (one / several 128-query units per head, ragged last unit, more workgroup slots than units), every mask shape."""
+    qkv = rnd(B * S, 3 * H, seed=10)
+    mask = _mask(mask_kind, B, S)
+    ref = _attn_ref(G.rounded(qkv, G.BF16), mask, B, S, H, heads)
+    got = G.attention(G.BF16, qkv, mask, B, S, H, heads)
+    assert torch.isfinite(got).all()
+    err = float((got - ref).abs().max())
+    assert err <= tol(G.BF16, ref, f32=5e-5, bf16=2e-2), (err, tol(G.BF16, ref))
+    G.lib().fs2_op_set_gemm_variant(1200)
+    old = G.attention(G.BF16, qkv, mask, B, S, H, heads)   # the phase-serial kernel: same arithmetic contract
+    assert float((got - old).abs().max()) <= tol(G.BF16, ref, f32=5e-5, bf16=2e-2)
+    # 32 or 64 queries per wave: the same instruction sequence per query row - bit-identical, whatever the launch size picks
+    G.lib().fs2_op_set_gemm_variant(1200 + (3 - pipe_kernel))
+    other = G.attention(G.BF16, qkv, mask, B, S, H, heads)
+    assert torch.equal(got, other)
+
+
+@pytest.mark.parametrize("pipe_kernel", [1, 2], indirect=True)
+def test_attention_pipelined_spike_and_all_padded(pipe_kernel):
+    # (i) one key dominates late in the sequence: the running max jumps at a late half tile, in one query block only (rule 26:
+    # the deferred rescale must scale O, l and nothing else exactly once); (ii) an utterance whose every key is padded gives NaN
+    # rows, as the reference's softmax over all -inf does, and leaves its neighbours alone
+    B, S, H, heads = 2, 512, 256, 2
+    qkv = rnd(B * S, 3 * H, seed=12)
+    qkv[300, H:H + 128] = 8.0 * qkv[5, :128]          # key 300 aligned with query 5 (utterance 0, head 0)
+    qkv[S + 450, H + 128:H + 256] = -9.0 * qkv[S + 77, 128:256]
+    mask = torch.zeros(B, S, dtype=torch.bool)
+    x = G.rounded(qkv, G.BF16)
+    ref = _attn_ref(x, mask, B, S, H, heads)
+    got = G.attention(G.BF16, qkv, mask, B, S, H, heads)
+    assert float((got - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+    mask[1, :] = True
+    got = G.attention(G.BF16, qkv, mask, B, S, H, heads)
+    assert torch.isnan(got[S:]).all()
+    assert float((got[:S] - ref[:S]).abs().max()) <= 2e-2 * float(ref.abs().max())
+
+
+def test_attention_by_size_picks_the_pipelined_kernel_and_agrees():
+    # the dispatch the engine uses (knob 1203): a decoder-sized problem goes to the pipelined kernel, same answers as the
+    # phase-serial one up to bf16 rounding of P
+    B, S, H, heads = 8, 1536, 256, 2
+    qkv = rnd(B * S, 3 * H, seed=19)
+    mask = _mask("suffix", B, S)
+    got = G.attention(G.BF16, qkv, mask, B, S, H, heads)
+    G.lib().fs2_op_set_gemm_variant(1200)
+    try:
+        old = G.attention(G.BF16, qkv, mask, B, S, H, heads)
+    finally:
+        G.lib().fs2_op_set_gemm_variant(1203)
+    assert torch.isfinite(got).all()
+    assert float((got - old).abs().max()) <= 2e-2 * float(old.abs().max())
+
+
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,H", [(37, 64), (100, 256), (9, 768), (130, 1024), (5, 128)])

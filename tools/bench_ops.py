@@ -213,6 +213,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("what", nargs="?", default="all")
     ap.add_argument("--variant", type=int, default=-1)
+    ap.add_argument("--shape", default="", help="attn: one extra case B,S,H,heads")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default="", help="substring filter on the case name")
     a = ap.parse_args()
@@ -283,9 +284,13 @@ def main():
         predictor_case("variance predictor fused", 32, 1536, 5, a.reps)
         predictor_case("duration predictor fused", 32, 256, 2, a.reps)
     if a.what in ("attn", "all"):
+        if a.variant >= 1200: lib.fs2_op_set_gemm_variant(a.variant)   # 1200 phase-serial kernel, 1201 / 1202 pipelined, 1203 by size
+        if a.shape: attn_case("custom attention", *[int(x) for x in a.shape.split(",")], a.reps)
         attn_case("c3 decoder attention", 32, 1536, 768, 6, a.reps)
-        attn_case("decoder attention", 32, 1536, 256, 2, a.reps)
-        attn_case("encoder attention", 32, 256, 256, 2, a.reps)
+        attn_case("c2 decoder attention", 32, 1536, 256, 2, a.reps)
+        attn_case("c5 decoder attention", 8, 1536, 1024, 8, a.reps)
+        attn_case("c2 encoder attention", 32, 256, 256, 2, a.reps)
+        lib.fs2_op_set_gemm_variant(1203)
 
 
 if __name__ == "__main__":

@@ -2,7 +2,7 @@
 # tools/pmc_kernels.sh [config] : per-kernel MFMA utilisation and HBM-side traffic of one bench.py forward (north_star:
 # "evidenced by rocprof HBM GB/s and MFMA utilisation against gfx950 peak").  Three separate rocprofv3 --pmc passes
 # (SQ set, FETCH_SIZE, WRITE_SIZE - MI355X_MICROARCH.md: they do not fit one pass) + a plain --kernel-trace pass for the
-# un-profiled durations.  FETCH_SIZE is doubled (gfx950 tallies 128-B requests at 64 B).  Writes gpurun_out/r02_pmc_kernels_<cfg>.md
+# un-profiled durations.  FETCH_SIZE is doubled (gfx950 tallies 128-B requests at 64 B).  Writes gpurun_out/${ROUND:-r03}_pmc_kernels_<cfg>.md
 CFG=${1:-c2}; B=32; [ $CFG = c5 ] && B=8
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/pmc_ks; mkdir -p $O
 CMD="python $R/bench.py --config $CFG --batch $B --steps 2 --warmup 1 --no-cpu-baseline --no-parity"
@@ -13,7 +13,7 @@ timeout 400 rocprofv3 --kernel-trace --output-format csv -d $O/t -o p -- $CMD > 
 timeout 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $O/s -o p -- $CMD > /dev/null 2>&1
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/f -o p -- $CMD > /dev/null 2>&1
 timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/w -o p -- $CMD > /dev/null 2>&1
-python3 - "$O" "$CFG" <<'PY' > $R/gpurun_out/r02_pmc_kernels_$CFG.md
+python3 - "$O" "$CFG" <<'PY' > $R/gpurun_out/${ROUND:-r03}_pmc_kernels_$CFG.md
 import csv, collections, glob, re, sys
 O, cfg = sys.argv[1], sys.argv[2]
 def rd(sub, name):
@@ -28,7 +28,7 @@ for sub in ("s", "f", "w"):
     for r in rd(sub, "counter_collection"):
         cnt[short(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"])
         if r["Counter_Name"] in ("SQ_INSTS_MFMA", "FETCH_SIZE", "WRITE_SIZE"): n[(short(r["Kernel_Name"]), r["Counter_Name"])] += 1
-print(f"# r02 per-kernel PMC summary, {cfg} bf16 (3 forwards of bench.py; tools/pmc_kernels.sh)\n")
+print(f"# per-kernel PMC summary, {cfg} bf16 (tools/pmc_kernels.sh)\n")
 print("MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES): share of SIMD cycles the matrix pipe is busy (in the profiled pass's own clock). "
       "waits = SQ_WAIT_ANY / SQ_WAVE_CYCLES (waves parked at s_waitcnt / barriers), issue stalls = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES. "
       "HBM-side bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB counters; Infinity-Cache hits included), per launch; GB/s over the un-profiled launch duration.\n")
