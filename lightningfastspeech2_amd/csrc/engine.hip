@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -125,7 +126,7 @@ struct fs2_engine {
     // fs2_set_graphs: the decode phase replayed as a hipGraph (one launch instead of ~50) once a shape / buffer signature repeats
     bool use_graph = false;
     struct GraphEntry { std::vector<uint64_t> key; hipGraphExec_t exec = nullptr; uint64_t stamp = 0; bool bad = false; };
-    std::vector<GraphEntry> dgraphs;
+    std::vector<GraphEntry> dgraphs, egraphs;  // decode phase / encode phase
     hipStream_t gstream = nullptr;
     hipEvent_t gev_in = nullptr, gev_out = nullptr;
     uint64_t gclock = 0;
@@ -824,6 +825,7 @@ int fs2_destroy(fs2_engine* e) {
     e->dbg_enc.release();
     if (e->h_pinned) (void)hipHostFree(e->h_pinned);
     for (auto& g : e->dgraphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    for (auto& g : e->egraphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     if (e->gev_in) (void)hipEventDestroy(e->gev_in);
     if (e->gev_out) (void)hipEventDestroy(e->gev_out);
     if (e->gstream) (void)hipStreamDestroy(e->gstream);
@@ -947,6 +949,11 @@ int fs2_set_frames(fs2_engine* e, int32_t T) {
     return FS2_OK;
 }
 
+static void drop_graphs(fs2_engine* e);
+static int encode_body(fs2_engine* e, const int64_t* phones, const float* speaker, const int32_t* forced, LayerScratch& sc, hipStream_t st);
+static int run_phase(fs2_engine* e, std::vector<fs2_engine::GraphEntry>& cache, const std::vector<uint64_t>& key, bool plain,
+                     hipStream_t st, const std::function<int(hipStream_t)>& body);
+
 int fs2_encode(fs2_engine* e, const int64_t* phones, const float* speaker, int32_t B, int32_t L,
                const int32_t* forced, void* stream, int32_t* T_out) {
     if (!e || !phones || !speaker || !T_out || B <= 0 || L <= 0) return e ? fail(e, FS2_ERR_ARG, "bad encode argument") : FS2_ERR_ARG;
@@ -981,8 +988,33 @@ int fs2_encode(fs2_engine* e, const int64_t* phones, const float* speaker, int32
         e->h_pinned = nullptr;
         HIPCHK(e, hipHostMalloc((void**)&e->h_pinned, (size_t)2 * B * 4, hipHostMallocDefault));
         e->h_pinned_cap = 2 * B;
+        drop_graphs(e);  // captured copies point at the old pinned block
     }
+    // every launch of the phase (no host decision among them), plainly or as a replayed hipGraph (fs2_set_graphs)
+    {
+        std::vector<uint64_t> key = {(uint64_t)B, (uint64_t)L, (uint64_t)e->persist.base, (uint64_t)e->scratch.base, (uint64_t)phones,
+                                     (uint64_t)speaker, (uint64_t)forced, (uint64_t)e->h_pinned, (uint64_t)e->fuse_predictor,
+                                     (uint64_t)e->defer_ln, (uint64_t)e->front_split};
+        const bool plain = c.n_priors != 0;  // a prior tensor is a one-shot pointer of the call
+        CHK(run_phase(e, e->egraphs, key, plain, st, [&](hipStream_t s2) { return encode_body(e, phones, speaker, forced, sc, s2); }));
+    }
+    HIPCHK(e, hipStreamSynchronize(st));  // the one host sync of the forward (output shape)
+    e->totals.assign(e->h_pinned, e->h_pinned + B);
+    e->guard.assign(e->h_pinned + B, e->h_pinned + 2 * B);
+    int mx = 0;
+    for (int b = 0; b < B; ++b) mx = e->totals[b] > mx ? e->totals[b] : mx;
+    e->T = mx < c.max_frames ? mx : c.max_frames;                            // model.py:355
+    if (e->T > c.pe_len) return fail(e, FS2_ERR_SHAPE, "T=%d exceeds positional table %d", e->T, c.pe_len);
+    *T_out = e->T;
+    e->encoded = true;
+    e->mid_forward = true;
+    return FS2_OK;
+}
 
+static int encode_body(fs2_engine* e, const int64_t* phones, const float* speaker, const int32_t* forced, LayerScratch& sc, hipStream_t st) {
+    const fs2_config& c = e->cfg;
+    const int B = e->B, L = e->L;
+    const size_t H = c.hidden, ML = (size_t)B * L, esz = e->esz;
     {   // speaker projection + phone embedding + PE                       fastspeech2.py:651-660
         Bracket br(e, FS2_K_ROWOPS, st, 0, ML * H * esz);
         SpkProjArgs sp{speaker, e->spk_w, e->spk_b, e->spk, B, (int)H, c.dvec_dim};
@@ -1014,16 +1046,6 @@ int fs2_encode(fs2_engine* e, const int64_t* phones, const float* speaker, int32
     DurationArgs da{e->dur_pred, e->src_mask, forced, e->d_dur, e->d_cum, e->d_totals, e->d_guard, B, L};
     if (launch_durations(da, st) != FS2_OK) return fail(e, FS2_ERR_HIP, "durations launch failed");
     HIPCHK(e, hipMemcpyAsync(e->h_pinned, e->d_totals, (size_t)2 * B * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(e, hipStreamSynchronize(st));  // the one host sync of the forward (output shape)
-    e->totals.assign(e->h_pinned, e->h_pinned + B);
-    e->guard.assign(e->h_pinned + B, e->h_pinned + 2 * B);
-    int mx = 0;
-    for (int b = 0; b < B; ++b) mx = e->totals[b] > mx ? e->totals[b] : mx;
-    e->T = mx < c.max_frames ? mx : c.max_frames;                            // model.py:355
-    if (e->T > c.pe_len) return fail(e, FS2_ERR_SHAPE, "T=%d exceeds positional table %d", e->T, c.pe_len);
-    *T_out = e->T;
-    e->encoded = true;
-    e->mid_forward = true;
     return FS2_OK;
 }
 
@@ -1128,24 +1150,83 @@ static int decode_body(fs2_engine* e, const fs2_outputs* out, hipStream_t st) {
 
 static void drop_graphs(fs2_engine* e) {
     for (auto& g : e->dgraphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    for (auto& g : e->egraphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
     e->dgraphs.clear();
+    e->egraphs.clear();
 }
 
-// The decode phase (variance adaptor after the length regulator, decoder, mel head: ~50 launches on one stream, no host
-// decision in between) as a hipGraph.  A signature = shape + every buffer address a launch sees (the caller's outputs, the
-// arenas).  First sight of a signature: plain launches (lazy initialisation happens there); second sight: the same code path
-// runs under stream capture on an engine-owned non-blocking stream, is instantiated and launched; from then on one
-// hipGraphLaunch.  The caller's stream (the legacy null stream included, which cannot be captured itself) is ordered around it
-// with two events.  Anything the capture cannot hold (debug taps, per-class profiling, one-shot forced buckets) takes the plain path.
+// A phase of the forward (encode: embedding .. durations + the totals' copy to pinned memory; decode: length regulator .. mel head:
+// ~100 / ~50 launches on one stream, no host decision inside) as a hipGraph.  A signature = shape + every buffer address a launch
+// sees (the caller's tensors, the arenas).  First sight of a signature: plain launches (lazy initialisation happens there); second
+// sight: the same code path runs under stream capture on an engine-owned non-blocking stream, is instantiated and launched; from
+// then on one hipGraphLaunch.  The caller's stream (the legacy null stream included, which cannot be captured itself) is ordered
+// around it with two events.  Anything a capture cannot hold (debug taps, per-class profiling events, one-shot forced buckets or
+// priors) takes the plain path.
+static int run_phase(fs2_engine* e, std::vector<fs2_engine::GraphEntry>& cache, const std::vector<uint64_t>& key, bool plain,
+                     hipStream_t st, const std::function<int(hipStream_t)>& body) {
+    static const bool gdbg = getenv("FS2_GRAPH_DEBUG") != nullptr;
+    plain = plain || !e->use_graph || e->debug;
+    for (int k = 0; k < FS2_K_COUNT && !plain; ++k) plain = e->prof[k].enabled;
+    if (plain) return body(st);
+    fs2_engine::GraphEntry* g = nullptr;
+    for (auto& c : cache) if (c.key == key) { g = &c; break; }
+    if (!g) {  // first sight: remember it, run plainly
+        if (cache.size() >= 8) {
+            size_t old = 0;
+            for (size_t i = 1; i < cache.size(); ++i) if (cache[i].stamp < cache[old].stamp) old = i;
+            if (cache[old].exec) (void)hipGraphExecDestroy(cache[old].exec);
+            cache.erase(cache.begin() + old);
+        }
+        cache.emplace_back();
+        cache.back().key = key;
+        cache.back().stamp = ++e->gclock;
+        if (gdbg) fprintf(stderr, "fs2 graph: new signature (%zu cached)\n", cache.size());
+        return body(st);
+    }
+    g->stamp = ++e->gclock;
+    if (g->bad) { if (gdbg) fprintf(stderr, "fs2 graph: signature marked bad\n"); return body(st); }
+    if (!e->gstream) {
+        if (hipStreamCreateWithFlags(&e->gstream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&e->gev_in, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&e->gev_out, hipEventDisableTiming) != hipSuccess) {
+            e->use_graph = false;
+            return body(st);
+        }
+    }
+    if (!g->exec) {  // second sight: capture the same code path
+        if (hipStreamBeginCapture(e->gstream, hipStreamCaptureModeThreadLocal) != hipSuccess) { g->bad = true; return body(st); }
+        const bool enc = e->encoded, mid = e->mid_forward;
+        const int r = body(e->gstream);
+        hipGraph_t graph = nullptr;
+        const hipError_t ce = hipStreamEndCapture(e->gstream, &graph);
+        hipError_t ie = hipSuccess;
+        if (r != FS2_OK || ce != hipSuccess || !graph || (ie = hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0)) != hipSuccess) {
+            if (gdbg) fprintf(stderr, "fs2 graph: capture failed (body %d, end %d %s, instantiate %d)\n", r, (int)ce, hipGetErrorString(ce), (int)ie);
+            if (graph) (void)hipGraphDestroy(graph);
+            (void)hipGetLastError();
+            g->exec = nullptr;
+            g->bad = true;
+            e->encoded = enc; e->mid_forward = mid;
+            return body(st);  // nothing was executed during the capture
+        }
+        (void)hipGraphDestroy(graph);
+    }
+    HIPCHK(e, hipEventRecord(e->gev_in, st));
+    HIPCHK(e, hipStreamWaitEvent(e->gstream, e->gev_in, 0));
+    HIPCHK(e, hipGraphLaunch(g->exec, e->gstream));
+    HIPCHK(e, hipEventRecord(e->gev_out, e->gstream));
+    HIPCHK(e, hipStreamWaitEvent(st, e->gev_out, 0));
+    e->graph_replays++;
+    return FS2_OK;
+}
+
 int fs2_decode(fs2_engine* e, const fs2_outputs* out, void* stream) {
     if (!e || !out) return FS2_ERR_ARG;
     if (!e->encoded) return fail(e, FS2_ERR_STATE, "fs2_decode without a preceding successful fs2_encode");
     hipStream_t st = (hipStream_t)stream;
     bool plain = !e->use_graph || e->debug || e->T == 0;
-    for (int k = 0; k < FS2_K_COUNT && !plain; ++k) plain = e->prof[k].enabled;
     for (int v = 0; v < FS2_MAX_VARIANCES && !plain; ++v) plain = e->forced_idx[v] || e->forced_tgt[v];
-    static const bool gdbg = getenv("FS2_GRAPH_DEBUG") != nullptr;
-    if (plain) { if (gdbg && e->use_graph) fprintf(stderr, "fs2 graph: plain path (debug %d, T %d, external %d)\n", (int)e->debug, e->T, (int)e->scratch.external); return decode_body(e, out, st); }
+    if (plain) return decode_body(e, out, st);
     // the arena may grow (device sync + hipMalloc) only outside a capture; the body's own call is then a no-op
     const char* base0 = e->scratch.base;
     CHK(ensure_arena(e, e->scratch, decode_scratch_bytes(e, e->B, e->T), "scratch"));
@@ -1159,57 +1240,9 @@ int fs2_decode(fs2_engine* e, const fs2_outputs* out, void* stream) {
         key.push_back((uint64_t)out->var_mean_std[v]);
         key.push_back((uint64_t)out->var_spectrogram[v]);
     }
-    fs2_engine::GraphEntry* g = nullptr;
-    for (auto& c : e->dgraphs) if (c.key == key) { g = &c; break; }
-    if (!g) {  // first sight: remember it, run plainly
-        if (e->dgraphs.size() >= 8) {
-            size_t old = 0;
-            for (size_t i = 1; i < e->dgraphs.size(); ++i) if (e->dgraphs[i].stamp < e->dgraphs[old].stamp) old = i;
-            if (e->dgraphs[old].exec) (void)hipGraphExecDestroy(e->dgraphs[old].exec);
-            e->dgraphs.erase(e->dgraphs.begin() + old);
-        }
-        e->dgraphs.emplace_back();
-        e->dgraphs.back().key = key;
-        e->dgraphs.back().stamp = ++e->gclock;
-        if (gdbg) fprintf(stderr, "fs2 graph: new signature (%zu cached) mel %p\n", e->dgraphs.size(), (void*)out->mel);
-        return decode_body(e, out, st);
-    }
-    g->stamp = ++e->gclock;
-    if (g->bad) { if (gdbg) fprintf(stderr, "fs2 graph: signature marked bad\n"); return decode_body(e, out, st); }
-    if (!e->gstream) {
-        if (hipStreamCreateWithFlags(&e->gstream, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&e->gev_in, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&e->gev_out, hipEventDisableTiming) != hipSuccess) {
-            e->use_graph = false;
-            return decode_body(e, out, st);
-        }
-    }
-    if (!g->exec) {  // second sight: capture the same code path
-        if (hipStreamBeginCapture(e->gstream, hipStreamCaptureModeThreadLocal) != hipSuccess) { g->bad = true; return decode_body(e, out, st); }
-        const bool enc = e->encoded, mid = e->mid_forward;
-        const int r = decode_body(e, out, e->gstream);
-        hipGraph_t graph = nullptr;
-        const hipError_t ce = hipStreamEndCapture(e->gstream, &graph);
-        hipError_t ie = hipSuccess;
-        if (r != FS2_OK || ce != hipSuccess || !graph || (ie = hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0)) != hipSuccess) {
-            if (gdbg) fprintf(stderr, "fs2 graph: capture failed (body %d, end %d %s, instantiate %d)\n", r, (int)ce, hipGetErrorString(ce), (int)ie);
-            if (graph) (void)hipGraphDestroy(graph);
-            (void)hipGetLastError();
-            g->exec = nullptr;
-            g->bad = true;
-            e->encoded = enc; e->mid_forward = mid;
-            return decode_body(e, out, st);  // nothing was executed during the capture
-        }
-        (void)hipGraphDestroy(graph);
-    }
-    HIPCHK(e, hipEventRecord(e->gev_in, st));
-    HIPCHK(e, hipStreamWaitEvent(e->gstream, e->gev_in, 0));
-    HIPCHK(e, hipGraphLaunch(g->exec, e->gstream));
-    HIPCHK(e, hipEventRecord(e->gev_out, e->gstream));
-    HIPCHK(e, hipStreamWaitEvent(st, e->gev_out, 0));
-    e->mid_forward = false;
-    e->graph_replays++;
-    return FS2_OK;
+    const int r = run_phase(e, e->dgraphs, key, false, st, [&](hipStream_t s2) { return decode_body(e, out, s2); });
+    if (r == FS2_OK) e->mid_forward = false;
+    return r;
 }
 
 int fs2_set_graphs(fs2_engine* e, int32_t on) {

@@ -12,6 +12,7 @@ only.  There is no CPU fallback: without the HIP library or a GPU this module ra
 from __future__ import annotations
 
 import ctypes as C
+import os
 from types import SimpleNamespace
 from typing import Dict, Optional
 
@@ -36,7 +37,7 @@ class Engine:
     """Thin owner of one ``fs2_engine`` handle (one per device)."""
 
     def __init__(self, cfg: Fs2Config, state_dict, precision: str = "fp32", device="cuda:0",
-                 torch_workspace: bool = True):
+                 torch_workspace: bool = True, graphs: Optional[bool] = None):
         self.lib = _lib.load()
         # torch_workspace: the forward's device workspace comes from torch's caching allocator through
         # fs2_workspace_bytes / fs2_set_workspace (SURVEY 8b: caller-owned memory); False = the
@@ -61,6 +62,15 @@ class Engine:
                 raise
         self._last = None
         self._t_hint = {}
+        # Both phases of the forward can replay as hipGraphs once a shape + buffer signature repeats (first sight plain, second
+        # captured): the step then costs the host two graph launches around its one sync instead of ~150 kernel launches, so a
+        # busy host no longer shows up as GPU idle time.  Measured on a quiet host (r03, C2 batch 32): eager 2.37 ms / step =
+        # the forward's GPU time to 0.4 %, replay 2.48 (ROCm's graph launch costs ~0.7 us per node) - so eager is the default
+        # and graphs are the caller's choice (graphs=True / FS2_GRAPHS=1); bench.py times a few steps of both during warm-up
+        # and runs the timed region in the faster mode of the box it is on.
+        if graphs is None:
+            graphs = os.environ.get("FS2_GRAPHS", "0") == "1"
+        self.set_graphs(graphs)
 
     def _load(self, state_dict):
         from .weights import state_dict_spec
@@ -221,9 +231,9 @@ class Engine:
         _lib.check(self.lib.fs2_set_deferred_layernorm(self.handle, int(on)), self.handle, "set_deferred_layernorm")
 
     def set_graphs(self, on: bool):
-        """Replay the decode phase (~50 launches) as a hipGraph once a shape + buffer signature repeats (include/fs2.h
-        fs2_set_graphs); bit-identical results, one launch instead of ~50 - the forward stops depending on how fast the host
-        can issue launches.  Off by default."""
+        """Replay the encode and the decode phase (~100 / ~50 launches) as hipGraphs once a shape + buffer signature repeats
+        (include/fs2.h fs2_set_graphs); bit-identical results, the forward stops depending on how fast the host can issue
+        launches.  Off by default (constructor argument graphs=True / FS2_GRAPHS=1)."""
         _lib.check(self.lib.fs2_set_graphs(self.handle, int(on)), self.handle, "set_graphs")
 
     def graph_replays(self) -> int:
