@@ -30,9 +30,10 @@
 extern "C" {
 #endif
 
-#define FS2_ABI_VERSION 2
+#define FS2_ABI_VERSION 3
 #define FS2_MAX_LAYERS 32
 #define FS2_MAX_VARIANCES 4
+#define FS2_MAX_PRIORS 8   /* hparams.priors: the shipped recipe lists five (scripts/train.sh:49: energy duration snr pitch srmr) */
 #define FS2_NAME_LEN 32
 
 enum fs2_status {
@@ -86,7 +87,7 @@ typedef struct fs2_config {
     int32_t var_filter, var_nbins, var_depthwise;
     int32_t dur_nlayers, dur_kernel, dur_filter, dur_depthwise;
     int32_t n_priors;      /* hparams.priors (default []): PriorEmbedding rows added after the encoder */
-    char prior_names[FS2_MAX_VARIANCES][FS2_NAME_LEN];
+    char prior_names[FS2_MAX_PRIORS][FS2_NAME_LEN];
     int32_t var_cwt[FS2_MAX_VARIANCES];  /* variance_transforms[i] == "cwt" (the class default for pitch, fastspeech2.py:60):
                               the CWT head of VarianceEncoder (model.py:412-431,445-461): predictor.linear is (10, filter),
                               mean_std_linear (2, filter) exists, bins are log-spaced; var_mean/var_std must be 0 / 1 */

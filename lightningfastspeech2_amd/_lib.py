@@ -18,11 +18,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FS2_LIB") or os.path.join(_HERE, "libfs2_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "fs2.h")
 
-FS2_ABI_VERSION = 2
+FS2_ABI_VERSION = 3
 FS2_MAX_LAYERS = 32
 FS2_MAX_VARIANCES = 4
+FS2_MAX_PRIORS = 8
 FS2_NAME_LEN = 32
 FS2_OK = 0
+FS2_ERR_HIP, FS2_ERR_SHAPE, FS2_ERR_ARG, FS2_ERR_WEIGHT, FS2_ERR_STATE, FS2_ERR_NOMEM = 1, 2, 3, 4, 5, 6
 FS2_F32, FS2_BF16, FS2_MIXED, FS2_MIXED_X3 = 0, 1, 2, 3
 K_CONV_GEMM, K_GEMM, K_ATTENTION, K_ROWOPS, K_DEC_FFN_CONV1 = 0, 1, 2, 3, 4
 
@@ -44,7 +46,7 @@ class Fs2ConfigC(C.Structure):
         ("var_filter", C.c_int32), ("var_nbins", C.c_int32), ("var_depthwise", C.c_int32),
         ("dur_nlayers", C.c_int32), ("dur_kernel", C.c_int32), ("dur_filter", C.c_int32), ("dur_depthwise", C.c_int32),
         ("n_priors", C.c_int32),
-        ("prior_names", (C.c_char * FS2_NAME_LEN) * FS2_MAX_VARIANCES),
+        ("prior_names", (C.c_char * FS2_NAME_LEN) * FS2_MAX_PRIORS),
         ("var_cwt", C.c_int32 * FS2_MAX_VARIANCES),
     ]
 
@@ -256,7 +258,7 @@ def config_to_c(cfg, dtype: int) -> Fs2ConfigC:
         c.var_std[i] = 1.0 if cwt else cfg.stats[v]["std"]
     c.var_filter, c.var_nbins = cfg.variance_filter_size, cfg.variance_nbins
     c.var_depthwise = int(cfg.variance_depthwise_conv)
-    if len(cfg.priors) > FS2_MAX_VARIANCES:
+    if len(cfg.priors) > FS2_MAX_PRIORS:
         raise ValueError("too many priors for the C ABI")
     c.n_priors = len(cfg.priors)
     for i, pr in enumerate(cfg.priors):

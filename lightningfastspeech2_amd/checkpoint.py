@@ -37,13 +37,51 @@ class AttributeDict(dict):
         self[k] = v
 
 
+class _Opaque:
+    """Stand-in for any OTHER Lightning class a checkpoint references (enum members rebuilt as ``cls("fit")``, callback /
+    loop / progress state objects of some Lightning versions): accepts whatever the pickle hands it - constructor
+    arguments, ``__setstate__`` of any shape, item / attribute assignment - and keeps it for inspection.  Nothing on the
+    forward path reads these objects."""
+
+    def __init__(self, *args, **kwargs):
+        self.__dict__["_args"], self.__dict__["_kwargs"], self.__dict__["_state"] = args, kwargs, None
+
+    def __setstate__(self, state):
+        self.__dict__["_state"] = state
+        if isinstance(state, dict):
+            self.__dict__.update({k: v for k, v in state.items() if isinstance(k, str)})
+
+    def __setitem__(self, k, v):
+        self.__dict__.setdefault("_items", {})[k] = v
+
+    def __call__(self, *args, **kwargs):  # an enum CLASS stand-in called with a value
+        return _Opaque(*args, **kwargs)
+
+    def append(self, v):
+        self.__dict__.setdefault("_list", []).append(v)
+
+    def extend(self, vs):
+        self.__dict__.setdefault("_list", []).extend(vs)
+
+    def __repr__(self):
+        return f"<opaque Lightning object args={self._args!r}>"
+
+
+_OPAQUE_CLASSES: Dict[Tuple[str, str], type] = {}
+
+
 class _Unpickler(pickle.Unpickler):
     def find_class(self, module, name):
         try:
             return super().find_class(module, name)
         except (ImportError, AttributeError):
-            if module.split(".")[0] in ("pytorch_lightning", "lightning", "lightning_fabric"):
-                return AttributeDict
+            if module.split(".")[0] in ("pytorch_lightning", "lightning", "lightning_fabric", "lightning_lite"):
+                if name == "AttributeDict":
+                    return AttributeDict
+                key = (module, name)  # one class per pickled name, so that NEWOBJ / REDUCE / BUILD all find a real type
+                if key not in _OPAQUE_CLASSES:
+                    _OPAQUE_CLASSES[key] = type(name, (_Opaque,), {"__module__": __name__, "_pickled_as": f"{module}.{name}"})
+                return _OPAQUE_CLASSES[key]
             raise
 
 
@@ -109,3 +147,80 @@ def resolve_state_dict(cfg: Fs2Config, state_dict: Dict[str, object], *, toleran
 
 
 EXTRA_KEYS = ("speaker2id", "speaker2dvector", "speaker2priors", "speaker_gmms", "dvector_gmms")  # fastspeech2.py:571-587
+
+
+# ---- optimizer state <-> Lightning's checkpoint layout -------------------------------------------------------------------
+def parameter_order(cfg: Fs2Config) -> list:
+    """Names of the trainable tensors in the order ``FastSpeech2.parameters()`` yields them in the reference - what
+    ``torch.optim.AdamW(self.parameters())`` (fastspeech2.py:1166-1173) numbers 0..n-1 in ``optimizer.state_dict()``.
+    Module registration order in ``FastSpeech2.__init__``: phone_embedding (fastspeech2.py:243), encoder (:249),
+    positional_encoding (:296, a buffer only), variance_adaptor (:301-341), decoder (:347), linear (:385),
+    prior_embeddings (:417-424), speaker_embedding (:428); inside a module, ``state_dict`` order minus the buffers
+    (``pe``, ``bins``).  (FastDiff modules, when configured, would follow ``linear``; they are off this path.)"""
+    names = [n for n in state_dict_spec(cfg) if n != "positional_encoding.pe" and not n.endswith(".bins")]
+    top = ["phone_embedding", "encoder", "variance_adaptor", "decoder", "linear", "prior_embeddings", "speaker_embedding"]
+    rank = {t: i for i, t in enumerate(top)}
+    unknown = [n for n in names if n.split(".")[0] not in rank]
+    if unknown:
+        raise ValueError(f"parameter_order: no place for {unknown[:3]}")
+    return sorted(names, key=lambda n: rank[n.split(".")[0]])  # stable: keeps the in-module order
+
+
+def to_lightning_optimizer_state(cfg: Fs2Config, opt_state: dict, *, lr: float, warmup_steps: int, betas=(0.9, 0.98), eps=1e-8,
+                                 weight_decay=0.01) -> dict:
+    """``Trainer.optimizer_state()`` -> the two checkpoint entries Lightning writes for the reference's optimizer and scheduler:
+    ``{"optimizer_states": [AdamW.state_dict()], "lr_schedulers": [NoamLR.state_dict()]}`` - parameters numbered in
+    ``parameter_order``, tensors in the reference's shapes, ``step`` per parameter as torch >= 1.12 keeps it (a 0-d fp32
+    tensor; torch 1.10's int is accepted on the way back).  The current rate is NoamLR's for ``last_epoch`` = steps taken
+    (noam.py:19-25)."""
+    names = parameter_order(cfg)
+    step = int(opt_state["step"])
+    state = {}
+    for i, n in enumerate(names):
+        if step == 0:
+            continue  # AdamW holds no state for a parameter before its first step
+        state[i] = {"step": torch.tensor(float(step)), "exp_avg": torch.as_tensor(opt_state["exp_avg"][n]).detach().cpu().clone(),
+                    "exp_avg_sq": torch.as_tensor(opt_state["exp_avg_sq"][n]).detach().cpu().clone()}
+    e = max(1, step)
+    cur = lr * warmup_steps ** 0.5 * min(e ** -0.5, e * warmup_steps ** -1.5)
+    group = {"lr": cur, "betas": list(betas), "eps": eps, "weight_decay": weight_decay, "amsgrad": False, "maximize": False,
+             "foreach": None, "capturable": False, "differentiable": False, "fused": None, "initial_lr": lr,
+             "params": list(range(len(names)))}
+    sched = {"warmup_steps": warmup_steps, "base_lrs": [lr], "last_epoch": step, "_step_count": step + 1, "verbose": False,
+             "_get_lr_called_within_step": False, "_last_lr": [cur]}
+    return {"optimizer_states": [{"state": state, "param_groups": [group]}], "lr_schedulers": [sched]}
+
+
+def from_lightning_optimizer_state(cfg: Fs2Config, checkpoint: dict) -> dict:
+    """The inverse: a reference checkpoint's ``optimizer_states[0]`` (+ ``lr_schedulers[0]`` / ``global_step`` for the
+    step count) -> what ``Trainer.load_optimizer_state`` takes.  Shapes are checked against the architecture; a checkpoint
+    whose optimizer covers other parameters (FastDiff attached) is refused by count."""
+    names = parameter_order(cfg)
+    spec = state_dict_spec(cfg)
+    osd = checkpoint["optimizer_states"][0]
+    n_ckpt = sum(len(g["params"]) for g in osd["param_groups"])
+    if n_ckpt != len(names):
+        raise ValueError(f"the checkpoint's optimizer holds {n_ckpt} parameters, this architecture has {len(names)} "
+                         "(a FastDiff vocoder attached to the model adds its own)")
+    st = osd["state"]
+    steps = set()
+    out = {"exp_avg": {}, "exp_avg_sq": {}}
+    for i, n in enumerate(names):
+        ent = st.get(i, st.get(str(i)))
+        if ent is None:  # no step taken for this parameter yet
+            out["exp_avg"][n] = torch.zeros(spec[n])
+            out["exp_avg_sq"][n] = torch.zeros(spec[n])
+            continue
+        for key in ("exp_avg", "exp_avg_sq"):
+            t = torch.as_tensor(ent[key]).detach().cpu().to(torch.float32)
+            if tuple(t.shape) != tuple(spec[n]):
+                raise ValueError(f"optimizer state {key}[{i}] has shape {tuple(t.shape)}; parameter {i} of this architecture is "
+                                 f"{n} {tuple(spec[n])}")
+            out[key][n] = t
+        steps.add(int(float(ent["step"])))
+    if len(steps) > 1:
+        raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): not a state this optimizer can resume")
+    sched = (checkpoint.get("lr_schedulers") or [None])[0]
+    out["step"] = steps.pop() if steps else int((sched or {}).get("last_epoch", checkpoint.get("global_step", 0)))
+    out["micro_step"] = 0
+    return out

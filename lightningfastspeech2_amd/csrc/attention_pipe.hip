@@ -35,7 +35,8 @@ namespace {
 
 // Probe builds (tools/probes/attn_pipe_probe.py compiles this file with -DFS2_ATTN_PROBE=bits into throw-away libraries and times
 // them): 1 = no exp / sum / pack, 2 = no row max / decision, 4 = no fragment reads in the loop, 8 = no tile DMA in the loop,
-// 16 = no Q.K^T MFMAs, 32 = no P.V MFMAs.  The product is always built with 0.
+// 16 = no Q.K^T MFMAs, 32 = no P.V MFMAs, 128 = 32-query items only, 256 = no per-tile drain + barrier (racy), 512 = no key-mask
+// test.  The product is always built with 0.
 #ifndef FS2_ATTN_PROBE
 #define FS2_ATTN_PROBE 0
 #endif
@@ -95,14 +96,21 @@ __device__ __forceinline__ void mma_pv(f32x16_t& o, const u32x4_t& v, const u32x
 // Per-wave state of one item (NQB query blocks of 32)
 template <int NQB>
 struct PipeState {
-    f32x16_t S0[NQB], S1[NQB];   // two live half tiles of scores (minus the running max), log2 units
-    f32x16_t minit[NQB];         // -(running max), sixteen copies: the C operand that starts a Q.K^T chain
+    f32x16_t S0[NQB], S1[NQB];   // two live half tiles of scores (minus the reference max), log2 units
+    f32x16_t minit[NQB];         // -(reference max), sixteen copies: the C operand that starts a Q.K^T chain
     f32x16_t oacc[NQB][4];       // O^T: dv block nd, lane = query
-    uint32_t pfw[NQB][8];        // P of the half tile in flight, bf16 pairs: words 0-3 = 16-key chunk 0, 4-7 = chunk 1
+    uint32_t P0[NQB][8], P1[NQB][8];  // P of the two half tiles in flight, bf16 pairs: words 0-3 = 16-key chunk 0, 4-7 = chunk 1
     float lsum[NQB][2];          // this lane's share of the denominator (its 16 keys of every 32), two chains
-    float thr[NQB];              // -inf until the row has a finite max, then kThr
-    float mref[NQB];             // the running max the exponentials refer to
+    float mref[NQB];             // the reference the exponentials refer to: the row max over the first 32 valid keys
+    float mnext[NQB];            // a row whose sums ran over: the reference its next pass starts from
 };
+
+// No running max: p = exp2(s - reference) with the reference fixed at the row max of the first half tile.  bf16 keeps its 8
+// bits at any scale and O / the denominator accumulate in fp32, so a score above the reference costs no accuracy - only a row
+// whose denominator leaves [.., kBound] (a score ~100 log2 units = 69 nats above its reference, inf, NaN) is wrong, and that row
+// alone runs again from a higher reference (the pass loop in run_item).  The per-element max, the rescale decision and its branch
+// were a fifth of the loop's issue slots and the only VALU use of the output accumulators.
+constexpr float kBound = 0x1p100f;
 
 template <int NQB, bool ACC>
 __device__ __forceinline__ void run_item(const AttnArgs& p, unsigned char* smem, int bh, int q0, int wave, int lane) {
@@ -140,8 +148,7 @@ __device__ __forceinline__ void run_item(const AttnArgs& p, unsigned char* smem,
         return;
     }
 
-    // smem: two K slots, then two V slots
-    __syncthreads();  // every wave is done with the previous item's tiles
+    // smem: two V slots (0, 16 KiB), then three K slots (32, 48, 64 KiB)
 
     // ---- Q fragments first (they return to registers; the DMAs behind them are counted separately) ----
     uint4 qraw[NQB][8];
@@ -164,7 +171,7 @@ __device__ __forceinline__ void run_item(const AttnArgs& p, unsigned char* smem,
         vvo = (unsigned)((row * ld + 2 * p.H + h * kD) * 2 + ((ps ^ ((row & 3) << 2)) << 4));
     }
     const unsigned ktile = (unsigned)(64 * ld * 2), kpiece = (unsigned)(16 * ld * 2);
-    // The DMA is issued from an asm statement: hipcc's own scoreboard for buffer_load ... lds cannot tell the four slots of one
+    // The DMA is issued from an asm statement: hipcc's own scoreboard for buffer_load ... lds cannot tell the slots of one
     // LDS array apart and puts a vmcnt(0) in front of the next ds_read - i.e. right behind the issue.  Completion is counted
     // here instead: dma_drain() ahead of the one barrier per tile.
     typedef __attribute__((ext_vector_type(4))) int rsrc_words_t;
@@ -175,31 +182,25 @@ __device__ __forceinline__ void run_item(const AttnArgs& p, unsigned char* smem,
     qrw[2] = __builtin_amdgcn_readfirstlane((int)utt_bytes);
     qrw[3] = 0x00020000;
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem + wave * 1024;
-    auto issue_tile = [&](unsigned slot_off, unsigned vo, int t) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const unsigned voff = vo + ((unsigned)t * ktile + i * kpiece);
-            const unsigned m0v = lds0 + slot_off + i * 4096;
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(m0v), "v"(voff), "s"(qrw) : "memory");
-        }
-    };
-    // one piece (1 KiB) of a tile: inside the loop the four pieces of a tile ride between the MFMAs of a phase, one per step - a
-    // burst of eight behind the barrier keeps the matrix pipe idle for its whole issue time (~100 cycles a piece)
     auto issue_piece = [&](unsigned slot_off, unsigned vo, unsigned tile_off, int i) {
         const unsigned voff = vo + (tile_off + i * kpiece);
         const unsigned m0v = lds0 + slot_off + i * 4096;
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(m0v), "v"(voff), "s"(qrw) : "memory");
     };
-    issue_tile(0, kvo, jb);
-    issue_tile(2 * kTileB, vvo, jb);
-    if (jb + 1 < je) issue_tile(kTileB, kvo, jb + 1);
+    auto issue_tile = [&](unsigned slot_off, unsigned vo, int t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) issue_piece(slot_off, vo, (unsigned)t * ktile, i);
+    };
+    constexpr unsigned kK0 = 2 * kTileB;  // first K slot
 
-    // ---- LDS fragment addresses (slot 0; XOR kTileB toggles the slot) ----
+    // ---- LDS fragment addresses ----
     // K fragment (key block kb, chunk c): row kb*32 + li, 16-byte slot (2c + hi) ^ (li & 15)  ==  kaddr ^ (c << 5), + kb * 8192
-    // (chunks 4..7 = kaddr[c - 4] ^ 128, formed at the read: four registers less in a kernel that sits at the 256 cap)
+    // (chunks 4..7 = kaddr[c - 4] ^ 128, formed at the read); kaddr carries the base of the slot being read and moves by a scalar
+    // delta when the loop turns to the next tile's slot (three slots: a tile's fragments are still being read while the DMA of
+    // the tile after next is in flight, and a fragment ring of four registers replaces a phase's eight)
     unsigned kaddr[4];
     {
-        const unsigned base0 = (unsigned)(li * kRB + ((hi ^ (li & 15)) << 4));
+        const unsigned base0 = kK0 + (unsigned)(li * kRB + ((hi ^ (li & 15)) << 4));
 #pragma unroll
         for (int c = 0; c < 4; ++c) kaddr[c] = base0 ^ (unsigned)(c << 5);
     }
@@ -211,7 +212,7 @@ __device__ __forceinline__ void run_item(const AttnArgs& p, unsigned char* smem,
         const int rowb = (4 * hi + rsub) * kRB + (i16 & 1) * 8;
 #pragma unroll
         for (int nd = 0; nd < 4; ++nd)
-            vaddr[nd] = (unsigned)(2 * kTileB + rowb + (((nd * 4 + g1 * 2 + ((i16 & 3) >> 1)) ^ (rsub << 2)) << 4));
+            vaddr[nd] = (unsigned)(rowb + (((nd * 4 + g1 * 2 + ((i16 & 3) >> 1)) ^ (rsub << 2)) << 4));
     }
 
     PipeState<NQB> st;
@@ -228,18 +229,14 @@ __device__ __forceinline__ void run_item(const AttnArgs& p, unsigned char* smem,
             qf[qb][c] = u32x4_t{pk.x, pk.y, pk.z, pk.w};
             if (ACC) asm volatile("" : "+a"(qf[qb][c]));  // one 128-bit accumulator-file tuple from here on (else: four scalars + copies per use)
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) st.minit[qb][r] = 0.f;
-#pragma unroll
-        for (int nd = 0; nd < 4; ++nd)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) st.oacc[qb][nd][r] = 0.f;
-        st.lsum[qb][0] = st.lsum[qb][1] = 0.f;
-        st.thr[qb] = -INFINITY;
-        st.mref[qb] = 0.f;
+        st.mnext[qb] = 0.f;
     }
+    bool done[NQB];         // this row's result has been stored by an earlier pass
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb) done[qb] = false;
+    unsigned ks_cur = kK0, ks_nxt = kK0 + kTileB, ks_fre = kK0 + 2 * kTileB;  // K(t), K(t+1), K(t+2)
 
-    u32x4_t kf[8], vf[4];  // K: a phase's eight fragments, read under the P.V phase before it; V: a four-deep ring
+    u32x4_t kf[4], vf[4];  // fragment rings: a K / V fragment is requested about eight MFMAs ahead of its use
     auto kload = [&](int kb, int c) { return *(const u32x4_t*)(smem + (c < 4 ? kaddr[c] : (kaddr[c - 4] ^ 128u)) + kb * 8192); };
     auto vload = [&](int ch, int nd) {
         const unsigned char* vb = smem + vaddr[nd] + ch * (16 * kRB);
@@ -247,25 +244,18 @@ __device__ __forceinline__ void run_item(const AttnArgs& p, unsigned char* smem,
         const uint2 hi2 = tr_read64(vb + 8 * kRB);
         return u32x4_t{lo.x, lo.y, hi2.x, hi2.y};
     };
-    auto toggle_slots = [&]() {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) kaddr[c] ^= (unsigned)kTileB;
-#pragma unroll
-        for (int nd = 0; nd < 4; ++nd) vaddr[nd] ^= (unsigned)kTileB;
-    };
-    // pair k of a half tile: accumulator registers 2k, 2k+1 -> exp2, row sums, one packed bf16 word
-    auto fin_pair = [&](f32x16_t (&S)[NQB], int k) {
+    // unit u of a half tile (U = 8 NQB of them): pair k = u / NQB of query block u % NQB: accumulator registers 2k, 2k+1 ->
+    // exp2, row sums, one packed bf16 word.  Five instructions: what one MFMA hides (MI355X_MICROARCH.md, one wave per SIMD)
+    auto unit = [&](f32x16_t (&S)[NQB], uint32_t (&P)[NQB][8], int u) {
         if (kProbe & 1) return;
-#pragma unroll
-        for (int qb = 0; qb < NQB; ++qb) {
-            const float e0 = __builtin_amdgcn_exp2f(S[qb][2 * k]);
-            const float e1 = __builtin_amdgcn_exp2f(S[qb][2 * k + 1]);
-            st.lsum[qb][0] += e0;
-            st.lsum[qb][1] += e1;
-            st.pfw[qb][k] = pack_bf16x2(e0, e1);
-            // anchor: without it the optimiser sinks the whole slice below the phase (its results are used a phase later)
-            asm volatile("" : "+v"(st.pfw[qb][k]), "+v"(st.lsum[qb][0]), "+v"(st.lsum[qb][1]));
-        }
+        const int k = u / NQB, qb = u % NQB;
+        const float e0 = __builtin_amdgcn_exp2f(S[qb][2 * k]);
+        const float e1 = __builtin_amdgcn_exp2f(S[qb][2 * k + 1]);
+        st.lsum[qb][0] += e0;
+        st.lsum[qb][1] += e1;
+        P[qb][k] = pack_bf16x2(e0, e1);
+        // anchor: without it the optimiser sinks the whole slice below the phase (its results are used a phase later)
+        asm volatile("" : "+v"(P[qb][k]), "+v"(st.lsum[qb][0]), "+v"(st.lsum[qb][1]));
     };
     auto mask_half = [&](f32x16_t (&S)[NQB], unsigned bits32) {  // keys of this 32-key block that are padded -> -inf
         if (ACC) {  // S left the matrix pipe just now: MFMA D -> VALU write needs the wait states hipcc does not insert for asm
@@ -279,206 +269,275 @@ __device__ __forceinline__ void run_item(const AttnArgs& p, unsigned char* smem,
             for (int r = 0; r < 16; ++r)
                 if (!((w >> ((r & 3) + 8 * (r >> 2))) & 1u)) S[qb][r] = -INFINITY;
     };
-    // the decision for a freshly scored half tile whose row max (relative to the running max) is mx: only when a row's max grew
-    // past the threshold (or the row has no finite max yet) is anything rescaled
-    auto decide = [&](f32x16_t (&S)[NQB], float (&mx)[NQB]) {
-        bool fire = false;
+    constexpr int G = 8 * NQB;      // MFMAs (= gaps) per phase
+    constexpr int UH = 4 * NQB;     // units per half of a half tile's finishing
+    // Q.K^T of the next half tile into Sn || second half of the units of Sc -> Pc || K ring refill (fragments 4..7 of block kb
+    // of the tile kaddr points at) || the first four V fragments of the coming P.V phase (chunk vch) || tile DMA pieces (hook).
+    // One MFMA, then at most about five other instructions, then the next MFMA: an in-order wave gets VALU issue slots only in
+    // the shadow of ITS OWN last MFMA - two MFMAs back to back waste the first one's (MI355X_MICROARCH.md, "two waves per SIMD" 1).
+    auto phase_qk = [&](f32x16_t (&Sn)[NQB], f32x16_t (&Sc)[NQB], uint32_t (&Pc)[NQB][8], int kb, int vch, auto DO_MMA, auto&& hook) {
 #pragma unroll
-        for (int qb = 0; qb < NQB; ++qb) {
-            mx[qb] = xhalf_max(mx[qb]);
-            fire = fire || (mx[qb] > st.thr[qb]);
-        }
-        if (__any(fire)) {
-            if (ACC) asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");  // the phase's last P.V MFMAs -> O read below
-#pragma unroll
-            for (int qb = 0; qb < NQB; ++qb) {
-                const bool f = mx[qb] > st.thr[qb];
-                const float d = f ? mx[qb] : 0.f;
-                const float alpha = st.thr[qb] == -INFINITY ? 1.f : __builtin_amdgcn_exp2f(-d);
-                st.thr[qb] = f ? kThr : st.thr[qb];
-                st.mref[qb] += d;
-                st.lsum[qb][0] *= alpha;
-                st.lsum[qb][1] *= alpha;
-#pragma unroll
-                for (int nd = 0; nd < 4; ++nd)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) st.oacc[qb][nd][r] *= alpha;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    S[qb][r] -= d;
-                    st.minit[qb][r] = -st.mref[qb];
-                }
-            }
-            if (ACC) {  // VALU / accvgpr writes -> MFMA operands of the next phase
-#pragma unroll
-                for (int qb = 0; qb < NQB; ++qb) {
-                    asm volatile("s_nop 3" : "+v"(S[qb]), "+v"(st.minit[qb]));
-#pragma unroll
-                    for (int nd = 0; nd < 4; ++nd) asm volatile("" : "+a"(st.oacc[qb][nd]));
-                }
-            }
-        }
-    };
-
-#ifndef FS2_ATTN_FQ
-#define FS2_ATTN_FQ 6
-#endif
-    constexpr int FQ = FS2_ATTN_FQ;  // pairs of a half tile finished under the Q.K^T phase; the other 8 - FQ open the P.V phase
-
-    // Q.K^T of the next half tile into Sn (K fragments in kf) || finish Sc || first four V fragments of the coming P.V phase
-    auto phase_qk = [&](f32x16_t (&Sn)[NQB], f32x16_t (&Sc)[NQB], int ch_next, auto DO_MMA, auto&& step_hook) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int g = 0; g < G; ++g) {
+            const int i = g / NQB, qb = g % NQB;
             if (decltype(DO_MMA)::value && !(kProbe & 16)) {
-#pragma unroll
-                for (int qb = 0; qb < NQB; ++qb) {
-                    if (i == 0) mma_qk_first<ACC>(Sn[qb], kf[i], qf[qb][i], st.minit[qb]);
-                    else mma_qk<ACC>(Sn[qb], kf[i], qf[qb][i]);
-                }
+                if (i == 0) mma_qk_first<ACC>(Sn[qb], kf[0], qf[qb][0], st.minit[qb]);
+                else mma_qk<ACC>(Sn[qb], kf[i & 3], qf[qb][i]);
             }
-            if (i < FQ) fin_pair(Sc, i);
-            if (i >= 4 && !(kProbe & 4)) vf[i - 4] = vload(ch_next, i - 4);
-            step_hook(i);
+            if (g & 1) {
+                unit(Sc, Pc, UH + (g >> 1));
+            } else if (NQB == 2) {
+                const int e = g >> 1;  // 0..7
+                if (e == 0 && !(kProbe & 4)) vf[0] = vload(vch, 0);
+                if (e >= 1 && e <= 4) {
+                    if (decltype(DO_MMA)::value && !(kProbe & 4)) kf[e - 1] = kload(kb, e + 3);
+                    hook(e - 1);
+                }
+                if (e >= 5 && !(kProbe & 4)) vf[e - 4] = vload(vch, e - 4);
+            } else {
+                const int e = g >> 1;  // 0..3
+                if (decltype(DO_MMA)::value && !(kProbe & 4)) {
+                    if (e == 0) kf[0] = kload(kb, 4);
+                    if (e == 1) { kf[1] = kload(kb, 5); kf[2] = kload(kb, 6); }
+                    if (e == 2) kf[3] = kload(kb, 7);
+                }
+                if (!(kProbe & 4)) vf[e] = vload(vch, e);
+                hook(e);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    // P.V of the finished half tile (16-key chunks ch0, ch0 + 1) || row max of Sn || K fragments of key block kb_next -> kf
-    auto phase_pv = [&](f32x16_t (&Sc)[NQB], f32x16_t (&Sn)[NQB], int ch0, int kb_next, auto DO_MAX, auto DO_KLOAD, float (&mx)[NQB],
-                        auto&& step_hook) {
+    // P.V of the finished half tile Pc (16-key chunks ch0, ch0 + 1) || first half of the units of Sn -> Pn || V ring refill (chunk
+    // ch0 + 1) || fragments 0..3 of key block kbn of the tile kaddr points at, for the coming Q.K^T phase || tile DMA pieces
+    auto phase_pv = [&](uint32_t (&Pc)[NQB][8], f32x16_t (&Sn)[NQB], uint32_t (&Pn)[NQB][8], int ch0, int kbn, auto DO_UNITS, auto DO_KLOAD,
+                        auto&& hook) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (i < 8 - FQ) fin_pair(Sc, FQ + i);
-#pragma unroll
-            for (int qb = 0; qb < NQB; ++qb) {
-                const u32x4_t pf = (i >> 2) == 0 ? u32x4_t{st.pfw[qb][0], st.pfw[qb][1], st.pfw[qb][2], st.pfw[qb][3]}
-                                                 : u32x4_t{st.pfw[qb][4], st.pfw[qb][5], st.pfw[qb][6], st.pfw[qb][7]};
+        for (int g = 0; g < G; ++g) {
+            const int i = g / NQB, qb = g % NQB;
+            {
+                const u32x4_t pf = (i >> 2) == 0 ? u32x4_t{Pc[qb][0], Pc[qb][1], Pc[qb][2], Pc[qb][3]}
+                                                 : u32x4_t{Pc[qb][4], Pc[qb][5], Pc[qb][6], Pc[qb][7]};
                 if (!(kProbe & 32)) mma_pv<ACC>(st.oacc[qb][i & 3], vf[i & 3], pf);
             }
-            if (ACC && i == 0 && decltype(DO_MAX)::value) {
-                // the scores this phase takes the row max of left the matrix pipe with the LAST MFMAs of the phase before: no
-                // VALU may read them until two more MFMAs (16 wait states) have been issued - asm statements keep their order
-#pragma unroll
-                for (int qb = 0; qb < NQB; ++qb) asm volatile("" : "+v"(Sn[qb]));
-            }
-            if (i < 4 && !(kProbe & 4)) vf[i] = vload(ch0 + 1, i);
-            if (decltype(DO_MAX)::value && !(kProbe & 2)) {
-#pragma unroll
-                for (int qb = 0; qb < NQB; ++qb) {
-                    mx[qb] = fmaxf(fmaxf(mx[qb], Sn[qb][2 * i]), Sn[qb][2 * i + 1]);
-                    asm volatile("" : "+v"(mx[qb]));
+            if (g & 1) {
+                // the scores these units read left the matrix pipe with the LAST MFMAs of the phase before; the first unit (query
+                // block 0) sits behind three later MFMAs, the second (block NQB - 1) behind four or more: asm statements keep order
+                if (decltype(DO_UNITS)::value) unit(Sn, Pn, g >> 1);
+            } else if (NQB == 2) {
+                const int e = g >> 1;  // 0..7
+                if (e >= 1 && e <= 4 && !(kProbe & 4)) vf[e - 1] = vload(ch0 + 1, e - 1);
+                if (e == 0 || e >= 5) {
+                    const int j = e == 0 ? 0 : e - 4;
+                    if (decltype(DO_KLOAD)::value && !(kProbe & 4)) kf[j] = kload(kbn, j);
+                    hook(j);
                 }
+            } else {
+                const int e = g >> 1;  // 0..3
+                if (!(kProbe & 4)) {
+                    if (e == 1) { vf[0] = vload(ch0 + 1, 0); vf[1] = vload(ch0 + 1, 1); }
+                    if (e == 2) { vf[2] = vload(ch0 + 1, 2); vf[3] = vload(ch0 + 1, 3); }
+                    if (decltype(DO_KLOAD)::value) {
+                        if (e == 0) kf[0] = kload(kbn, 0);
+                        if (e == 3) { kf[1] = kload(kbn, 1); kf[2] = kload(kbn, 2); kf[3] = kload(kbn, 3); }
+                    }
+                }
+                hook(e);
             }
-            if (decltype(DO_KLOAD)::value && !(kProbe & 4)) kf[i] = kload(kb_next, i);
-            step_hook(i);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
 
-    // ---- prologue: first half tile of tile jb ----
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // Q and K(jb): everything but the two youngest tile DMAs (4 pieces each)
-    if (jb + 1 >= je) dma_drain();                    // (only two tiles were issued: wait for both)
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 8; ++i) kf[i] = kload(0, i);
-    {
-        float mx[NQB];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-#pragma unroll
-            for (int qb = 0; qb < NQB; ++qb) {
-                if (i == 0) mma_qk_first<ACC>(st.S0[qb], kf[i], qf[qb][i], st.minit[qb]);
-                else mma_qk<ACC>(st.S0[qb], kf[i], qf[qb][i]);
-            }
-            kf[i] = kload(1, i);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (ACC) asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");  // MFMA D -> VALU read (prologue only)
-        const unsigned bits = tile_lo(jb);
-        if (bits != 0xffffffffu) mask_half(st.S0, bits);
-#pragma unroll
-        for (int qb = 0; qb < NQB; ++qb) {
-            mx[qb] = st.S0[qb][0];
-#pragma unroll
-            for (int r = 1; r < 16; ++r) mx[qb] = fmaxf(mx[qb], st.S0[qb][r]);
-        }
-        decide(st.S0, mx);
-    }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) kaddr[c] ^= (unsigned)kTileB;  // kaddr -> slot of K(jb+1); vaddr stays on V(jb)'s
-
-    // ---- main loop: one barrier per 64-key tile ----
-    auto tile_step = [&](int t, auto HN) {
-        constexpr bool has_next = decltype(HN)::value;
+    // One tile of the main loop: one barrier per 64-key tile
+    auto tile_step = [&](int t, auto HN, auto MK) {
+        constexpr bool has_next = decltype(HN)::value, masked = decltype(MK)::value && !(kProbe & 512);
         const int rel = t - jb;
-        dma_drain();
-        __syncthreads();  // V(t), K(t+1) landed for everyone; K(t) and V(t-1) are dead
+        if (!(kProbe & 256)) {
+            dma_drain();
+            __syncthreads();  // V(t), K(t+1) landed for everyone; K(t-1) and V(t-1) are dead
+        }
         auto no_hook = [](int) {};
-        // K(t+2) rides in phase C, V(t+1) in phase D, a piece per step.  No branch in a step: a K tile past the end is issued
+        // K(t+2) rides in phase C, V(t+1) in phase D, a piece per even gap.  No branch in a gap: a K tile past the end is issued
         // with an offset beyond the descriptor's range (zeros land in a slot nobody reads again)
         constexpr bool dma = has_next && !(kProbe & 8);
         const unsigned koff = t + 2 < je ? (unsigned)(t + 2) * ktile : 0x80000000u, voff = (unsigned)(t + 1) * ktile;
-        const unsigned kslot = (rel & 1) * kTileB, vslot = (2 + ((rel + 1) & 1)) * kTileB;
-        auto hook_k = [&](int i) { if (dma && i >= 4) issue_piece(kslot, kvo, koff, i - 4); };
-        auto hook_v = [&](int i) { if (dma && i >= 2 && i < 6) issue_piece(vslot, vvo, voff, i - 2); };
-        float mx[NQB];
+        const unsigned vslot = ((rel + 1) & 1) * kTileB;
+        auto hook_k = [&](int i) { if (dma) issue_piece(ks_fre, kvo, koff, i); };
+        auto hook_v = [&](int i) { if (dma) issue_piece(vslot, vvo, voff, i); };
 
-        // C: Q.K^T(t, keys 32..63) || finish S0 || V(t) chunks 0, 1
-        phase_qk(st.S1, st.S0, 0, std::true_type{}, hook_k);
-        {
+        // C: Q.K^T(t, keys 32..63) -> S1 || units of S0, second half || V(t) chunk 0 || K(t) block 1, fragments 4..7
+        phase_qk(st.S1, st.S0, st.P0, 1, 0, std::true_type{}, hook_k);
+        if (masked) {
             const unsigned bits = tile_hi(t);
             if (bits != 0xffffffffu) mask_half(st.S1, bits);
         }
-        // D: P.V(t, keys 0..31) || max S1 || K(t+1) keys 0..31
+        if (has_next) {  // fragment reads turn to K(t+1)'s slot
+            const unsigned dk = ks_nxt - ks_cur;
 #pragma unroll
-        for (int qb = 0; qb < NQB; ++qb) mx[qb] = -INFINITY;
-        phase_pv(st.S0, st.S1, 0, 0, std::true_type{}, HN, mx, hook_v);
-        if (!(kProbe & 2)) decide(st.S1, mx);
-        // A': Q.K^T(t+1, keys 0..31) || finish S1 || V(t) chunks 2, 3
-        phase_qk(st.S0, st.S1, 2, HN, no_hook);
-        if (has_next) {
+            for (int c = 0; c < 4; ++c) kaddr[c] += dk;
+        }
+        // D: P.V(t, keys 0..31) || units of S1, first half || V(t) chunk 1 || K(t+1) block 0, fragments 0..3
+        phase_pv(st.P0, st.S1, st.P1, 0, 0, std::true_type{}, HN, hook_v);
+        // A': Q.K^T(t+1, keys 0..31) -> S0 || units of S1, second half || V(t) chunk 2 || K(t+1) block 0, fragments 4..7
+        phase_qk(st.S0, st.S1, st.P1, 0, 2, HN, no_hook);
+        if (has_next && masked) {
             const unsigned bitsn = tile_lo(t + 1);
             if (bitsn != 0xffffffffu) mask_half(st.S0, bitsn);
         }
-        // B': P.V(t, keys 32..63) || max S0 || K(t+1) keys 32..63
+        // B': P.V(t, keys 32..63) || units of S0, first half || V(t) chunk 3 || K(t+1) block 1, fragments 0..3
+        phase_pv(st.P1, st.S0, st.P0, 2, 1, HN, HN, no_hook);
 #pragma unroll
-        for (int qb = 0; qb < NQB; ++qb) mx[qb] = -INFINITY;
-        phase_pv(st.S1, st.S0, 2, 1, HN, HN, mx, no_hook);
-        if (has_next && !(kProbe & 2)) decide(st.S0, mx);
-        toggle_slots();
-    };
-    for (int t = jb; t + 1 < je; ++t) tile_step(t, std::true_type{});
-    tile_step(je - 1, std::false_type{});
-
-    // ---- normalise and store: lane (li, hi) owns query li, dv = nd*32 + 8g + 4hi + 0..3; the two halves of a row trade
-    // 8-byte groups (v_permlane32_swap) so that every lane stores 16 contiguous bytes ----
-    if (ACC) asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");  // last P.V MFMAs -> O read
-#pragma unroll
-    for (int qb = 0; qb < NQB; ++qb) {
-        const float l = xhalf_sum(st.lsum[qb][0] + st.lsum[qb][1]);
-        const float inv = 1.f / l;
-        if (qrow[qb] < p.S) {
-            if (p.lse2 && hi == 0) p.lse2[(size_t)bh * p.S + qrow[qb]] = st.mref[qb] + __builtin_amdgcn_logf(l);  // v_log_f32 = log2
+        for (int nd = 0; nd < 4; ++nd) vaddr[nd] ^= (unsigned)kTileB;
+        if (has_next) {
+            const unsigned tmp = ks_cur;
+            ks_cur = ks_nxt; ks_nxt = ks_fre; ks_fre = tmp;
         }
-        bf16* dst = outp + (size_t)(b * p.S + (qrow[qb] < p.S ? qrow[qb] : 0)) * p.H + h * kD + hi * 8;
+    };
+
+    // tiles jb .. jb + nfull - 1 have all 64 keys valid: their steps carry no mask test (a test is a v_readlane, a compare and a
+    // branch that ends the scheduling region - ~50 cycles each, twice per tile)
+    int nfull;
+    {
+        const unsigned long long notfull = __ballot(myword != ~0ull) >> jb;
+        nfull = notfull ? __builtin_ctzll(notfull) : 64 - jb;
+    }
+    constexpr int kMaxPass = 64;
+
+    // ---- passes over the item: one, unless a row's sums ran over kBound; bounded (NaN / inf scores never settle) ----
+    for (int pass = 0; pass < kMaxPass; ++pass) {
+        __syncthreads();  // every wave is done with the previous item's / pass's tiles (and has read its flags)
+        {   // fragment addresses back to the first slots
+            const unsigned dk = kK0 - ks_cur;
 #pragma unroll
-        for (int nd = 0; nd < 4; ++nd)
+            for (int c = 0; c < 4; ++c) kaddr[c] += dk;
 #pragma unroll
-            for (int g = 0; g < 4; g += 2) {
-                const f32x16_t& o = st.oacc[qb][nd];
-                uint32_t a0 = pack_bf16x2(o[4 * g + 0] * inv, o[4 * g + 1] * inv), a1 = pack_bf16x2(o[4 * g + 2] * inv, o[4 * g + 3] * inv);
-                uint32_t b0 = pack_bf16x2(o[4 * g + 4] * inv, o[4 * g + 5] * inv), b1 = pack_bf16x2(o[4 * g + 6] * inv, o[4 * g + 7] * inv);
-                const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
-                const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-                // lower half: [own g | upper's g] = dv 8g .. 8g+7; upper half: [lower's g+1 | own g+1] = dv 8g+8 .. 8g+15
-                if (qrow[qb] < p.S) *(uint4*)(dst + nd * 32 + 8 * g) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+            for (int nd = 0; nd < 4; ++nd) vaddr[nd] &= ~(unsigned)kTileB;
+            ks_cur = kK0; ks_nxt = kK0 + kTileB; ks_fre = kK0 + 2 * kTileB;
+        }
+        issue_tile(kK0, kvo, jb);
+        issue_tile(0, vvo, jb);
+        if (jb + 1 < je) issue_tile(kK0 + kTileB, kvo, jb + 1);
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb) {
+            st.mref[qb] = pass == 0 ? 0.f : st.mnext[qb];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st.minit[qb][r] = -st.mref[qb];
+#pragma unroll
+            for (int nd = 0; nd < 4; ++nd)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) st.oacc[qb][nd][r] = 0.f;
+            if (ACC) {
+                asm volatile("" : "+v"(st.minit[qb]));
+#pragma unroll
+                for (int nd = 0; nd < 4; ++nd) asm volatile("" : "+a"(st.oacc[qb][nd]));
             }
+            st.lsum[qb][0] = st.lsum[qb][1] = 0.f;
+        }
+
+        // ---- prologue: scores of the first half tile of tile jb (nothing to overlap with); in the first pass their row max
+        // becomes the row's reference; the first half of their units ----
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // Q and K(jb): everything but the two youngest tile DMAs (4 pieces each)
+        if (jb + 1 >= je) dma_drain();                    // (only two tiles were issued: wait for both)
+        __syncthreads();
+        const unsigned bits0 = tile_lo(jb);
+        // the first pass takes the reference from the first half tile that holds a valid key: keys 0..31 of tile jb, or - masks
+        // whose first 32 keys there are all padded - keys 32..63 (scored twice then: here for the max, again in the loop)
+        const int nscore = (pass == 0 && bits0 == 0u) ? 2 : 1;
+        for (int sc = nscore - 1; sc >= 0; --sc) {   // sc = 1: block 1 for its max only; sc = 0: block 0, the scores the loop continues from
+#pragma unroll
+            for (int c = 0; c < 4; ++c) kf[c] = kload(sc, c);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+#pragma unroll
+                for (int qb = 0; qb < NQB; ++qb) {
+                    if (i == 0) mma_qk_first<ACC>(st.S0[qb], kf[0], qf[qb][0], st.minit[qb]);
+                    else mma_qk<ACC>(st.S0[qb], kf[i & 3], qf[qb][i]);
+                }
+                // this block's fragments 4..7, then block 1's 0..3 for the first phase C
+                kf[i & 3] = kload(i < 4 ? sc : 1, i < 4 ? i + 4 : i - 4);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (ACC) asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");  // MFMA D -> VALU read (prologue only)
+            const unsigned bits = sc == 0 ? bits0 : tile_hi(jb);
+            if (bits != 0xffffffffu) mask_half(st.S0, bits);
+            if (pass == 0 && bits != 0u) {  // a valid key in this half tile: every row has a finite max
+#pragma unroll
+                for (int qb = 0; qb < NQB; ++qb) {
+                    float mx = st.S0[qb][0];
+#pragma unroll
+                    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st.S0[qb][r]);
+                    mx = xhalf_max(mx);
+                    st.mref[qb] = mx;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        st.S0[qb][r] -= mx;
+                        st.minit[qb][r] = -mx;
+                    }
+                    if (ACC) asm volatile("s_nop 3" : "+v"(st.minit[qb]));
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UH; ++u) unit(st.S0, st.P0, u);
+
+        // ---- main loop ----
+        {
+            int t = jb;
+            const int tu = jb + nfull - 1 < je - 1 ? jb + nfull - 1 : je - 1;
+            for (; t < tu; ++t) tile_step(t, std::true_type{}, std::false_type{});
+            for (; t + 1 < je; ++t) tile_step(t, std::true_type{}, std::true_type{});
+            tile_step(je - 1, std::false_type{}, std::true_type{});
+        }
+
+        // ---- normalise and store: lane (li, hi) owns query li, dv = nd*32 + 8g + 4hi + 0..3; the two halves of a row trade
+        // 8-byte groups (v_permlane32_swap) so that every lane stores 16 contiguous bytes ----
+        if (ACC) asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");  // last P.V MFMAs -> O read
+        bool more = false;
+#pragma unroll
+        for (int qb = 0; qb < NQB; ++qb) {
+            const float l = xhalf_sum(st.lsum[qb][0] + st.lsum[qb][1]);
+            const float inv = 1.f / l;
+            const bool ok = l <= kBound;  // false for inf and NaN too
+            const bool mine = qrow[qb] < p.S && !done[qb] && (ok || pass == kMaxPass - 1);
+            // a row that ran over starts again from about its largest score: log2(l) is within log2(S) of (max - reference)
+            st.mnext[qb] = st.mref[qb] + (l < INFINITY ? __builtin_amdgcn_logf(l) : 100.f);
+            if ((kProbe & 1024) && p.lse2 && hi == 0 && qrow[qb] < p.S)  // debug dump: one record per (row, pass)
+                ((float4*)p.lse2)[(size_t)qrow[qb] * 4 + (pass < 4 ? pass : 3)] = make_float4(l, st.mref[qb], ok ? 1.f : 0.f, (mine ? 1.f : 0.f) + (done[qb] ? 2.f : 0.f) + 10.f * pass);
+            if (mine) {
+                if (p.lse2 && hi == 0) p.lse2[(size_t)bh * p.S + qrow[qb]] = st.mref[qb] + __builtin_amdgcn_logf(l);  // v_log_f32 = log2
+            }
+            bf16* dst = outp + (size_t)(b * p.S + (qrow[qb] < p.S ? qrow[qb] : 0)) * p.H + h * kD + hi * 8;
+#pragma unroll
+            for (int nd = 0; nd < 4; ++nd)
+#pragma unroll
+                for (int g = 0; g < 4; g += 2) {
+                    const f32x16_t& o = st.oacc[qb][nd];
+                    uint32_t a0 = pack_bf16x2(o[4 * g + 0] * inv, o[4 * g + 1] * inv), a1 = pack_bf16x2(o[4 * g + 2] * inv, o[4 * g + 3] * inv);
+                    uint32_t b0 = pack_bf16x2(o[4 * g + 4] * inv, o[4 * g + 5] * inv), b1 = pack_bf16x2(o[4 * g + 6] * inv, o[4 * g + 7] * inv);
+                    const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+                    const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+                    // lower half: [own g | upper's g] = dv 8g .. 8g+7; upper half: [lower's g+1 | own g+1] = dv 8g+8 .. 8g+15
+                    if (mine) *(uint4*)(dst + nd * 32 + 8 * g) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+                }
+            done[qb] = done[qb] || ok;
+            more = more || !done[qb];
+        }
+        // does any row of the workgroup need another pass?  The waves trade a word each through a K slot nobody has read or
+        // written since the barrier of the last tile (K(t+1)'s: the last tile has no next); the barrier at the top of the next
+        // pass / item keeps the next DMA away from it until every wave has read
+        {
+            int* flags = (int*)(smem + ks_nxt);
+            const int wave_more = __any(more) ? 1 : 0;
+            if (lane == 0) flags[wave] = wave_more;
+            __syncthreads();
+            const int4 f = *(const int4*)flags;
+            if (!__builtin_amdgcn_readfirstlane(f.x | f.y | f.z | f.w)) break;
+        }
     }
 }
 
 template <int NQBMAX>
 __global__ __launch_bounds__(256, NQBMAX == 2 ? 1 : 2) void attention_pipe_kernel(AttnArgs p, int nu, int U) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __shared__ __attribute__((aligned(32768))) unsigned char smem[4 * kTileB];
+    __shared__ __attribute__((aligned(32768))) unsigned char smem[5 * kTileB];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int G = gridDim.x;  // a multiple of 8: slot = XCD-major so that an XCD's workgroups own neighbouring units
@@ -522,6 +581,13 @@ int launch_attention_pipe(const AttnArgs& a, int variant, hipStream_t stream) {
 }  // namespace fs2
 
 #if FS2_ATTN_PROBE
+extern "C" int attn_pipe_probe_dbg(const void* qkv, const uint64_t* kbits, void* out, float* dbg, int B, int S, int H, int heads, int variant, void* stream) {
+    fs2::AttnArgs a;
+    a.qkv = qkv; a.vt = nullptr; a.kbits = kbits; a.out = out; a.lse2 = dbg;
+    a.B = B; a.S = S; a.H = H; a.heads = heads; a.Spad = (S + 63) / 64 * 64; a.nw64 = a.Spad / 64;
+    a.scale_log2e = 1.4426950408889634f / 11.313708f;
+    return fs2::launch_attention_pipe(a, variant, (hipStream_t)stream);
+}
 extern "C" int attn_pipe_probe(const void* qkv, const uint64_t* kbits, void* out, int B, int S, int H, int heads, int variant, void* stream) {
     fs2::AttnArgs a;
     a.qkv = qkv; a.vt = nullptr; a.kbits = kbits; a.out = out;

@@ -272,7 +272,7 @@ int check_config(fs2_engine* e) {
     if (c.enc_layers < 0 || c.enc_layers > FS2_MAX_LAYERS || c.dec_layers < 0 || c.dec_layers > FS2_MAX_LAYERS)
         return fail(e, FS2_ERR_SHAPE, "layer count out of range");
     if (c.n_variances < 0 || c.n_variances > FS2_MAX_VARIANCES) return fail(e, FS2_ERR_SHAPE, "n_variances out of range");
-    if (c.n_priors < 0 || c.n_priors > FS2_MAX_VARIANCES) return fail(e, FS2_ERR_SHAPE, "n_priors out of range");
+    if (c.n_priors < 0 || c.n_priors > FS2_MAX_PRIORS) return fail(e, FS2_ERR_SHAPE, "n_priors out of range");
     if (c.n_priors && c.var_nbins < 2) return fail(e, FS2_ERR_SHAPE, "variance_nbins < 2");
     const int heads[2] = {c.enc_heads, c.dec_heads};
     for (int i = 0; i < 2; ++i) {

@@ -26,6 +26,20 @@ import torch.distributed as dist
 PHONE_LEVEL_KEYS = ("phones", "duration")  # (B, L) entries of the collate format (datasets.py:852-882)
 
 
+def _is_frame_level(key: str) -> bool:
+    """(B, T, ...) entries of the collate format: the mel and the frame-level variance targets (datasets.py:866-877)."""
+    return key == "mel" or key.startswith("variances_")
+
+
+def collective_device(group=None, like=None) -> torch.device:
+    """Where a small control tensor of a collective must live: the process group's backend decides (nccl = RCCL wants
+    device memory on every rank - also on ranks that hold no utterance and therefore no device tensor to copy from)."""
+    backend = str(dist.get_backend(group)).lower()
+    if "nccl" in backend:
+        return torch.device("cuda", torch.cuda.current_device())
+    return like.device if isinstance(like, torch.Tensor) else torch.device("cpu")
+
+
 def shard_bounds(B: int, world: int, rank: int) -> Tuple[int, int]:
     """Contiguous, near-equal split of B utterances: rank r gets [lo, hi)."""
     base, rem = divmod(B, world)
@@ -37,7 +51,10 @@ def shard_batch(batch: Dict[str, torch.Tensor], world: int, rank: int, *, trim: 
                 phone_level_keys: Sequence[str] = PHONE_LEVEL_KEYS) -> Dict[str, torch.Tensor]:
     """This rank's contiguous rows of every per-utterance entry.  ``trim``: cut the phone axis of
     EVERY per-phone (B, L) entry (phones, duration, ...) to the shard's longest utterance, so that the
-    shard is its own padded batch and teacher-forced durations stay aligned with the phones."""
+    shard is its own padded batch and teacher-forced durations stay aligned with the phones; when the batch carries
+    target durations, the frame axis of the frame-level entries (``mel``, ``variances_*``) is cut to the shard's longest
+    utterance in frames (max over its rows of sum(duration)) as well - a training shard is then padded to ITS T, which is
+    what a DataLoader under DDP would have collated for that rank."""
     B = batch["phones"].shape[0]
     lo, hi = shard_bounds(B, world, rank)
     out = {}
@@ -56,6 +73,12 @@ def shard_batch(batch: Dict[str, torch.Tensor], world: int, rank: int, *, trim: 
             if k != "phones" and bool((torch.as_tensor(v)[:, Lr:] != 0).any()):
                 raise ValueError(f"batch[{k!r}] has non-zero entries beyond the shard's longest utterance")
             out[k] = v[:, :Lr].contiguous()
+        dur = out.get("duration")
+        if dur is not None and hasattr(dur, "shape") and len(dur.shape) == 2:
+            Tr = max(int(torch.as_tensor(dur).sum(dim=1).max()), 1)
+            for k, v in list(out.items()):
+                if _is_frame_level(k) and hasattr(v, "shape") and len(v.shape) >= 2 and v.shape[1] > Tr:
+                    out[k] = v[:, :Tr].contiguous()
     return out
 
 
@@ -138,44 +161,43 @@ def global_frames(T_local: int, device, group=None) -> int:
 
 
 def forward_sharded(forward_fn: Callable[..., Dict[str, torch.Tensor]], batch: Dict[str, torch.Tensor], group=None, *,
-                    global_pad: bool = False, n_mels: Optional[int] = None, zeroed: bool = False):
+                    global_pad: bool = False, n_mels: Optional[int] = None, zeroed: bool = False,
+                    device: Optional[torch.device] = None):
     """Run ``forward_fn`` on this rank's shard of ``batch`` and gather every rank's mels.
 
     per-shard mode: ``forward_fn(shard)`` (e.g. ``lambda b: model(b, inference=True)``).
     global-pad mode: ``forward_fn(shard, frames_hook)`` — the hook must be handed to the model's forward
     (``model.forward(b, True, frames_hook=hook)``); it all-reduces the frame count between the two phases.
     Ranks whose shard is empty (global batch smaller than the world) skip the forward and contribute an
-    empty mel.  Returns (mel_all, frames, local_result or None)."""
+    empty mel.  ``device``: where the control tensors of the collectives (and an empty shard's mel) live; default =
+    what the group's backend needs (``collective_device``: the current GPU under nccl, also for a host-side batch).
+    Returns (mel_all, frames, local_result or None)."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     B = batch["phones"].shape[0]
     Bs = [hi - lo for lo, hi in (shard_bounds(B, world, r) for r in range(world))]
     local_batch = shard_batch(batch, world, rank, trim=not global_pad)
-    dev = None
+    sp_ = batch.get("speaker")
+    dev = torch.device(device) if device is not None else collective_device(group, sp_ if isinstance(sp_, torch.Tensor) else None)
     t_glob = {}
 
     def hook(T_local):
-        t_glob["T"] = global_frames(T_local, dev if dev is not None else torch.device("cpu"), group)
+        t_glob["T"] = global_frames(T_local, dev, group)
         return t_glob["T"]
 
     if Bs[rank] == 0:
         local = None
         if n_mels is None:
             raise ValueError("a world larger than the batch leaves empty shards: pass n_mels so that they can join the gather")
-        ref = batch["speaker"] if isinstance(batch.get("speaker"), torch.Tensor) else torch.zeros(0)
-        dev = ref.device
         if global_pad:
             hook(0)  # the ranks that do have utterances are waiting in the all-reduce
         mel = torch.zeros(0, 0, n_mels, dtype=torch.float32, device=dev)
         mask = torch.zeros(0, 0, dtype=torch.bool, device=dev)
     else:
         if global_pad:
-            sp = local_batch["speaker"]
-            dev = sp.device if isinstance(sp, torch.Tensor) else torch.device("cpu")
             local = forward_fn(local_batch, hook)
         else:
             local = forward_fn(local_batch)
         mel, mask = local["mel"], local["tgt_mask"]
-        dev = mel.device
         if mel.device != mask.device:
             mask = mask.to(mel.device)
     shapes = (Bs, t_glob["T"]) if global_pad else None

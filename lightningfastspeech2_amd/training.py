@@ -101,6 +101,8 @@ class _Ops:
                                              S or M, self.st())
             if st_ == 0:
                 return y
+            if st_ != _lib.FS2_ERR_SHAPE:  # only "no such epilogue for this shape" falls back; a launch failure is raised
+                self.ck(st_, "gemm_gated")
             self.ck(self.lib.fs2_op_gemm(self.dt, self.dt, _p(x), _p(w), _p(bias), _p(y), M, N, Cin, taps, S or M, 0, self.st()), "gemm")
             return self.gate_(y, gate, gate_scale)
         self.ck(self.lib.fs2_op_gemm(self.dt, F32 if out_f32 else self.dt, _p(x), _p(w), _p(bias), _p(y), M, N, Cin, taps, S or M,
@@ -264,7 +266,17 @@ class Trainer:
         self.ops = _Ops(device, precision)
         self.dev = self.ops.dev
         self.lr, self.warmup_steps, self.betas, self.eps, self.weight_decay = lr, warmup_steps, betas, eps, weight_decay
-        self.gradient_clip_val = gradient_clip_val
+        # Lightning (>= 1.5, what the reference pins) reads gradient_clip_val None or 0 as "no clipping"; negative is an error there too
+        if gradient_clip_val is not None and float(gradient_clip_val) < 0:
+            raise ValueError(f"gradient_clip_val must be >= 0, got {gradient_clip_val}")
+        self.gradient_clip_val = float(gradient_clip_val) if gradient_clip_val else None
+        # 'same' padding of an even kernel is asymmetric (left (k-1)//2, right k-1-left): the data gradients run on the forward
+        # kernels with tap-flipped weights, which is the transpose only for odd k (and the inference engine rejects even k too)
+        for what, ks in (("encoder_kernel_sizes", cfg.encoder_kernel_sizes[:cfg.encoder_layers]),
+                         ("decoder_kernel_sizes", cfg.decoder_kernel_sizes[:cfg.decoder_layers]),
+                         ("variance_kernel_size", list(cfg.variance_kernel_size)), ("duration_kernel_size", [cfg.duration_kernel_size])):
+            if any(int(k) % 2 == 0 for k in ks):
+                raise ValueError(f"training step: {what} = {list(ks)} holds an even kernel size (odd sizes only, as in the inference engine)")
         # nn.Dropout sites of the reference in training mode (fastspeech2.py:94,103 encoder/decoder_dropout incl. the attention
         # weights and both PositionalEncoding calls; :65,74 variance / duration predictors).  Reference defaults 0.1 / 0.1 / 0.5 /
         # 0.5, the shipped recipe 0.1 everywhere (scripts/train.sh:12-13); 0 here unless asked, which is what parity pins.
@@ -279,6 +291,9 @@ class Trainer:
         self.mel_loss, self.duration_loss = mel_loss, duration_loss
         self.loss_alphas = dict(loss_alphas) if loss_alphas is not None else {
             "mel": 1.0, "pitch": 1e-1, "energy": 1e-1, "snr": 1e-1, "duration": 1e-4}
+        missing = [k for k in ["mel", "duration"] + list(cfg.variances) if k not in self.loss_alphas]
+        if missing:
+            raise ValueError(f"loss_alphas has no entry for {missing} (the default covers mel / pitch / energy / snr / duration)")
         for k in self.variance_losses + [mel_loss, duration_loss]:
             if k not in _KIND:
                 raise NotImplementedError(f"training step: loss kind {k!r} has no gradient kernel ('l1' / 'mse' only)")
@@ -418,6 +433,18 @@ class Trainer:
                 flat[o:o + int(np.prod(ks))].view(ks).copy_(t.contiguous())
         self.steps = int(st["step"])
         self._micro = int(st.get("micro_step", 0))
+
+    def lightning_optimizer_state(self):
+        """``{"optimizer_states": [...], "lr_schedulers": [...]}`` in the layout Lightning writes for the reference's
+        ``AdamW`` + ``NoamLR`` (fastspeech2.py:1166-1182): a checkpoint made of ``state_dict()`` + these two entries resumes in
+        the reference, and ``load_lightning_optimizer_state`` resumes a reference checkpoint here."""
+        from .checkpoint import to_lightning_optimizer_state
+        return to_lightning_optimizer_state(self.cfg, self.optimizer_state(), lr=self.lr, warmup_steps=self.warmup_steps,
+                                            betas=self.betas, eps=self.eps, weight_decay=self.weight_decay)
+
+    def load_lightning_optimizer_state(self, checkpoint):
+        from .checkpoint import from_lightning_optimizer_state
+        self.load_optimizer_state(from_lightning_optimizer_state(self.cfg, checkpoint))
 
     def gradients(self):
         return OrderedDict((n, self._to_ref_layout(n, self.G[n])) for n in self._layout)

@@ -27,8 +27,10 @@ def test_library_exports_every_declared_symbol(lib):
 
 
 def test_struct_layout_matches_header():
-    # sizes follow from include/fs2.h: 8 + (4+32)*2 ints, 1 int, 4*32 chars, 2*4 ints, 2*4 floats, 7 ints
-    assert C.sizeof(_lib.Fs2ConfigC) == 4 * (8 + 36 + 36 + 1) + 4 * 32 + 4 * (4 + 4) + 4 * (4 + 4) + 4 * 7 + 4 + 4 * 32 + 4 * 4
+    # sizes follow from include/fs2.h: 8 + (4+32)*2 ints, 1 int, 4*32 chars, 2*4 ints, 2*4 floats, 7 ints, n_priors,
+    # FS2_MAX_PRIORS names (ABI v3: the shipped recipe lists five priors, scripts/train.sh:49), var_cwt
+    assert _lib.FS2_ABI_VERSION == 3 and _lib.FS2_MAX_PRIORS == 8
+    assert C.sizeof(_lib.Fs2ConfigC) == 4 * (8 + 36 + 36 + 1) + 4 * 32 + 4 * (4 + 4) + 4 * (4 + 4) + 4 * 7 + 4 + 8 * 32 + 4 * 4
     assert C.sizeof(_lib.Fs2OutputsC) == 8 * (5 + 3 * _lib.FS2_MAX_VARIANCES)
 
 
@@ -52,6 +54,20 @@ def test_create_validates_config(lib):
     st, h = _create(lib, Fs2Config(encoder_head=16, decoder_head=16))  # head dim 16 unsupported
     assert st == 2
     lib.fs2_destroy(h)
+
+
+def test_recipe_with_five_priors_fits_the_abi(lib):
+    # scripts/train.sh:27,49 of the reference: four variances, five priors
+    cfg = Fs2Config(variances=["pitch", "energy", "snr", "srmr"], variance_levels=["frame"] * 4, variance_transforms=["none"] * 4,
+                    variance_nlayers=[5] * 4, variance_kernel_size=[3] * 4, priors=["energy", "duration", "snr", "pitch", "srmr"],
+                    decoder_layers=6, decoder_kernel_sizes=[9] * 6, duration_nlayers=5,
+                    encoder_depthwise_conv=False, decoder_depthwise_conv=False)
+    st, h = _create(lib, cfg, _lib.FS2_BF16)
+    assert st == 0, lib.fs2_last_error(h)
+    lib.fs2_destroy(h)
+    cfg.priors = [f"p{i}" for i in range(9)]
+    with pytest.raises(ValueError, match="too many priors"):
+        _lib.config_to_c(cfg, _lib.FS2_BF16)
 
 
 def test_load_weight_checks_names_and_shapes(lib):
