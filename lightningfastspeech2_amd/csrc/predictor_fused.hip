@@ -259,6 +259,8 @@ __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(Predict
 #endif
 }
 
+int g_pred_tall = 1;
+
 bool predictor_fused_supported(int dtype, int H, int taps, int nlayers, int S) {
     return dtype == FS2_BF16 && H == PF_H && taps == PF_TAPS && nlayers >= 1 && nlayers <= 16 && S >= 1 &&
            (size_t)S * PF_ROWB < 0xFFFFF000ull;
@@ -281,7 +283,9 @@ int launch_predictor_fused(const PredictorArgs& a, hipStream_t stream) {
     auto tiles = [&](int R) { return (long)a.B * ((a.S + (R - halo2) - 1) / (R - halo2)); };
     // the tile HEIGHT does not enter the arithmetic (rows are independent), the wave layout does: one
     // layout for everything, shorter tiles when 112-row tiles would leave most CUs without work
-    if (tiles(112) < 200 && 64 - halo2 >= 32) {
+    if (g_pred_tall && tiles(208) >= 200) {
+        hipLaunchKernelGGL((predictor_fused_kernel<13, 4, 1>), dim3((unsigned)tiles(208)), dim3(256), 0, stream, a);
+    } else if (tiles(112) < 200 && 64 - halo2 >= 32) {
         hipLaunchKernelGGL((predictor_fused_kernel<4, 4, 2>), dim3((unsigned)tiles(64)), dim3(256), 0, stream, a);
     } else {
         hipLaunchKernelGGL((predictor_fused_kernel<7, 4, 2>), dim3((unsigned)tiles(112)), dim3(256), 0, stream, a);

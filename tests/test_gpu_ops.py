@@ -230,6 +230,32 @@ def test_predictor_single_launch(B, S, nl):
     assert torch.equal(again, got)
 
 
+def test_predictor_tile_heights_are_bit_identical():
+    """Which tile height runs (208 rows, one workgroup per CU, when the launch fills the chip; 112 / 64 rows otherwise) follows the
+    launch size, so it must not enter the arithmetic: same wave layout, same reduction tree - bit-equal outputs."""
+    B, S, nl, H = 26, 1536, 5, 256   # 26 x 8 = 208 tall tiles: the tall kernel runs by default
+    x = rnd(B, S, H, seed=170)
+    ws = [rnd(H, H, 3, seed=171 + j, scale=(3 * H) ** -0.5) for j in range(nl)]
+    bs = [0.3 * rnd(H, seed=180 + j) for j in range(nl)]
+    gs = [1 + 0.2 * rnd(H, seed=190 + j) for j in range(nl)]
+    bes = [0.1 * rnd(H, seed=200 + j) for j in range(nl)]
+    hw, hb = rnd(H, seed=210, scale=H ** -0.5), 0.25
+    mask = torch.zeros(B, S, dtype=torch.bool)
+    for b in range(B):
+        mask[b, S - 11 * b:] = True
+    tall = G.predictor(x, ws, bs, gs, bes, hw, hb, mask, B, S)
+    G.lib().fs2_op_set_gemm_variant(1300)
+    try:
+        short = G.predictor(x, ws, bs, gs, bes, hw, hb, mask, B, S)
+    finally:
+        G.lib().fs2_op_set_gemm_variant(1301)
+    assert torch.equal(tall, short)
+    ref = _predictor_ref(x[:3], ws, bs, gs, bes, hw, hb, mask[:3])
+    assert float((tall[:3] - ref).abs().max()) <= 2e-2 * (float(ref.abs().max()) + 1)
+    one = G.predictor(x[5:6], ws, bs, gs, bes, hw, hb, mask[5:6], 1, S)   # a single utterance (short tiles) == its row of the batch
+    assert torch.equal(one[0], tall[5])
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_dma_pipeline_large_and_repeatable(dtype):
     """Full-size decoder conv tile stream (K = 9*256 -> 36 chunks through the 3-stage DMA ring),
