@@ -236,8 +236,14 @@ def main():
     if "FS2_BENCH_DEVICE" in os.environ:
         local_rank = int(os.environ["FS2_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # FS2_BENCH_FORCE_DIST=1: take the multi-rank path (process group, sync-free mel gathers on the collective stream, closing
+    # barrier, max over ranks) also at WORLD_SIZE 1 - how the RCCL branch gets exercised on a one-GPU box (tests/test_gpu_boundary.py)
+    multi = world > 1 or os.environ.get("FS2_BENCH_FORCE_DIST") == "1"
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
         else:
@@ -271,12 +277,12 @@ def main():
     # collectives without any exchange or host read-back; pad rows are zeroed by the mel GEMM's own store.
     pending = []
     shapes = [None]
-    if world > 1:
+    if multi:
         model.engine.set_zero_pad_mel(True)
 
     def step():
         out = model(batch, inference=True)
-        if world > 1:
+        if multi:
             if pending:
                 pending.pop().wait()
             if shapes[0] is None:
@@ -293,9 +299,9 @@ def main():
             mel_all, frames = pending.pop().wait()
             assert mel_all.shape[0] == frames.numel()
 
-    for _ in range(max(args.warmup, 1) if world > 1 else args.warmup):
+    for _ in range(max(args.warmup, 1) if multi else args.warmup):
         out = step()
-    if args.warmup == 0 and world == 1:
+    if args.warmup == 0 and not multi:
         out = model(batch, inference=True)
     drain()
     frames_rank = int((~out["tgt_mask"]).sum())
@@ -322,7 +328,7 @@ def main():
         timed_steps(3)  # first sight, capture
         tune[mode] = min(timed_steps(5), timed_steps(5)) * 1e3
     pick = min(tune, key=tune.get)
-    if world > 1:
+    if multi:
         flag = torch.tensor([1 if pick == "graphs" else 0], device=dev if backend == "nccl" else torch.device("cpu"))
         dist.broadcast(flag, 0)
         pick = "graphs" if int(flag.item()) else "eager"
@@ -330,7 +336,7 @@ def main():
     timed_steps(2)
 
     def sync():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -385,7 +391,7 @@ def main():
     cdev = dev if backend == "nccl" else torch.device("cpu")
     t_max = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     frames_all = torch.tensor([frames_rank], dtype=torch.int64, device=cdev)
-    if world > 1:
+    if multi:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
         dist.all_reduce(frames_all, op=dist.ReduceOp.SUM)
     elapsed = float(t_max.item())
@@ -420,7 +426,7 @@ def main():
                        + f", batch {args.batch}/GPU x {args.phones} phonemes, {args.frames_per_phone} frames/phone "
                          f"-> T={T}, random-init weights", "batch_per_gpu": args.batch, "phonemes": args.phones,
                        "frames_per_utterance": T, "global_batch": args.batch * world,
-                       "parallelism": f"dp{world} (utterance shards, RCCL all-gather of mels only)" if world > 1 else "single GPU",
+                       "parallelism": f"dp{world} (utterance shards, RCCL all-gather of mels only)" if multi else "single GPU",
                        "params": cfg.param_count()},
             "roofline": {"bound": "mfma", "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
                          "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
@@ -440,7 +446,7 @@ def main():
                                     "around the one host sync; a few untimed steps of each after warm-up, the faster mode of this host "
                                     "runs the timed region (FS2_BENCH_MODE pins it)"},
         }
-        if world == 1:
+        if not multi:
             # the boundary takes device pointers; a host caller also pays H2D of phones + speaker and D2H of the
             # fp32 mels + mask per batch (SURVEY 8d's metric definition): timed separately, never `value`
             hp = torch.from_numpy(inp["phones"]).pin_memory()
@@ -464,20 +470,20 @@ def main():
             line["value_incl_pcie"] = {"value": frames_rank * k2 / el2, "ms_per_step": el2 / k2 * 1e3, "steps": k2,
                                        "what": "inputs from / mels + mask to pinned host memory every step (66 KB H2D, "
                                                f"{hmel.numel() * 4 / 1e6:.1f} MB D2H)"}
-        if world == 1 and not args.no_parity:
+        if not multi and not args.no_parity:
             try:
                 line["parity"] = parity_block(cfg, sd, args, dev, model)
             except Exception as ex:  # never lose the timed line to the checker
                 line["parity"] = {"error": repr(ex)}
-        if world == 1 and not args.no_train and args.precision in ("bf16", "fp32"):
+        if not multi and not args.no_train and args.precision in ("bf16", "fp32"):
             try:  # side measurement, never `value`: the same workload through the training step
                 line["training_step"] = training_block(cfg, sd, args, inp, T)
             except Exception as ex:
                 line["training_step"] = {"error": repr(ex)}
-        if world == 1 and not args.no_cpu_baseline:
+        if not multi and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, sd, args)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -155,15 +155,41 @@ def parameter_order(cfg: Fs2Config) -> list:
     ``torch.optim.AdamW(self.parameters())`` (fastspeech2.py:1166-1173) numbers 0..n-1 in ``optimizer.state_dict()``.
     Module registration order in ``FastSpeech2.__init__``: phone_embedding (fastspeech2.py:243), encoder (:249),
     positional_encoding (:296, a buffer only), variance_adaptor (:301-341), decoder (:347), linear (:385),
-    prior_embeddings (:417-424), speaker_embedding (:428); inside a module, ``state_dict`` order minus the buffers
-    (``pe``, ``bins``).  (FastDiff modules, when configured, would follow ``linear``; they are off this path.)"""
-    names = [n for n in state_dict_spec(cfg) if n != "positional_encoding.pe" and not n.endswith(".bins")]
+    prior_embeddings (:417-424), speaker_embedding (:428); inside a module, ``state_dict`` order minus the one buffer
+    (``pe``).  The bucket edges ``bins`` of VarianceEncoder / PriorEmbedding ARE ``nn.Parameter(requires_grad=False)``
+    (model.py:150,397): they take a slot in the optimizer's numbering and never get any state.  (FastDiff modules, when
+    configured, would follow ``linear``; they are off this path.)"""
+    names = [n for n in state_dict_spec(cfg) if n != "positional_encoding.pe"]
     top = ["phone_embedding", "encoder", "variance_adaptor", "decoder", "linear", "prior_embeddings", "speaker_embedding"]
     rank = {t: i for i, t in enumerate(top)}
     unknown = [n for n in names if n.split(".")[0] not in rank]
     if unknown:
         raise ValueError(f"parameter_order: no place for {unknown[:3]}")
-    return sorted(names, key=lambda n: rank[n.split(".")[0]])  # stable: keeps the in-module order
+
+    def key(n):
+        # a module's own parameters come before its children's: VarianceEncoder = bins, predictor (registered first,
+        # model.py:391-393), embedding, mean_std_linear (model.py:397-404); state_dict_spec lists the embedding before the predictor
+        parts = n.split(".")
+        sub = 0
+        if parts[0] == "variance_adaptor" and parts[1] == "encoders":
+            sub = {"bins": 0, "predictor": 1, "embedding": 2, "mean_std_linear": 3}[parts[3]]
+        return (rank[parts[0]], sub if parts[0] == "variance_adaptor" and parts[1] == "encoders" else 0)
+
+    out, i = [], 0
+    # stable sort inside one variance encoder only: everything else keeps the spec's (= the modules') order
+    while i < len(names):
+        n = names[i]
+        parts = n.split(".")
+        if parts[0] == "variance_adaptor" and parts[1] == "encoders":
+            j = i
+            while j < len(names) and names[j].split(".")[:3] == parts[:3]:
+                j += 1
+            out += sorted(names[i:j], key=key)
+            i = j
+        else:
+            out.append(n)
+            i += 1
+    return sorted(out, key=lambda n: rank[n.split(".")[0]])  # stable: keeps the in-module order
 
 
 def to_lightning_optimizer_state(cfg: Fs2Config, opt_state: dict, *, lr: float, warmup_steps: int, betas=(0.9, 0.98), eps=1e-8,
@@ -177,8 +203,8 @@ def to_lightning_optimizer_state(cfg: Fs2Config, opt_state: dict, *, lr: float, 
     step = int(opt_state["step"])
     state = {}
     for i, n in enumerate(names):
-        if step == 0:
-            continue  # AdamW holds no state for a parameter before its first step
+        if step == 0 or n.endswith(".bins"):
+            continue  # AdamW holds no state for a parameter before its first step, nor ever for the frozen bucket edges
         state[i] = {"step": torch.tensor(float(step)), "exp_avg": torch.as_tensor(opt_state["exp_avg"][n]).detach().cpu().clone(),
                     "exp_avg_sq": torch.as_tensor(opt_state["exp_avg_sq"][n]).detach().cpu().clone()}
     e = max(1, step)
@@ -206,6 +232,8 @@ def from_lightning_optimizer_state(cfg: Fs2Config, checkpoint: dict) -> dict:
     steps = set()
     out = {"exp_avg": {}, "exp_avg_sq": {}}
     for i, n in enumerate(names):
+        if n.endswith(".bins"):
+            continue  # frozen: a slot in the numbering, no state
         ent = st.get(i, st.get(str(i)))
         if ent is None:  # no step taken for this parameter yet
             out["exp_avg"][n] = torch.zeros(spec[n])

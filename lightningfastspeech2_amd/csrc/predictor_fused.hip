@@ -126,22 +126,47 @@ __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(Predict
             const int i0 = fr + tp;
             const unsigned char* arow_p = slab + i0 * PF_ROWB;
             const int acx = (((fg & 1) << 3) | ((fg >> 1) ^ (i0 & 7))) << 4;  // SlabSwizzle::slot(fg, i0); + kb below
+            constexpr int HFB = MI16 - HFA;
+            auto loadA = [&](uint4 (&fx)[HFA], int kb, int hf) {
+                const int m0 = hf * HFA, cnt = hf ? HFB : HFA;
 #pragma unroll
-            for (int kb = 0; kb < PF_KB; ++kb) {
-                loadB(bw[(kb + 3) & 3], (l * PF_TAPS + tp) * PF_KB + kb + 3);
+                for (int mi = 0; mi < HFA; ++mi)
+                    if (mi < cnt) fx[mi] = *(const uint4*)(arow_p + (m0 + mi) * 16 * PF_ROWB + (acx ^ ((((kb & 3) << 1) | ((kb >> 2) << 4)) << 4)));
+            };
+            if constexpr (MINW == 1) {
+                // one wave per SIMD: nobody covers an LDS round trip, so the next half's activation fragments are requested before
+                // this half's MFMAs (two fragment sets alive; a 512-register wave has room)
+                uint4 fxa[HFA], fxb[HFA];
+                loadA(fxa, 0, 0);
 #pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    constexpr int HFB = MI16 - HFA;
-                    const int m0 = hf * HFA, cnt = hf ? HFB : HFA;
-                    uint4 fx[HFA];
-#pragma unroll
-                    for (int mi = 0; mi < HFA; ++mi)
-                        if (mi < cnt) fx[mi] = *(const uint4*)(arow_p + (m0 + mi) * 16 * PF_ROWB + (acx ^ ((((kb & 3) << 1) | ((kb >> 2) << 4)) << 4)));
+                for (int kb = 0; kb < PF_KB; ++kb) {
+                    loadB(bw[(kb + 3) & 3], (l * PF_TAPS + tp) * PF_KB + kb + 3);
+                    loadA(fxb, kb, 1);
 #pragma unroll
                     for (int ni = 0; ni < NFR; ++ni)
 #pragma unroll
-                        for (int mi = 0; mi < HFA; ++mi)
-                            if (mi < cnt) Mma16<bf16>::step(bw[kb & 3][ni], fx[mi], acc[ni][m0 + mi]);
+                        for (int mi = 0; mi < HFA; ++mi) Mma16<bf16>::step(bw[kb & 3][ni], fxa[mi], acc[ni][mi]);
+                    if (kb + 1 < PF_KB) loadA(fxa, kb + 1, 0);
+#pragma unroll
+                    for (int ni = 0; ni < NFR; ++ni)
+#pragma unroll
+                        for (int mi = 0; mi < HFB; ++mi) Mma16<bf16>::step(bw[kb & 3][ni], fxb[mi], acc[ni][HFA + mi]);
+                }
+            } else {
+#pragma unroll
+                for (int kb = 0; kb < PF_KB; ++kb) {
+                    loadB(bw[(kb + 3) & 3], (l * PF_TAPS + tp) * PF_KB + kb + 3);
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        const int m0 = hf * HFA, cnt = hf ? HFB : HFA;
+                        uint4 fx[HFA];
+                        loadA(fx, kb, hf);
+#pragma unroll
+                        for (int ni = 0; ni < NFR; ++ni)
+#pragma unroll
+                            for (int mi = 0; mi < HFA; ++mi)
+                                if (mi < cnt) Mma16<bf16>::step(bw[kb & 3][ni], fx[mi], acc[ni][m0 + mi]);
+                    }
                 }
             }
         }
@@ -259,7 +284,10 @@ __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(Predict
 #endif
 }
 
-int g_pred_tall = 1;
+// 208-row tiles, one 4-wave workgroup per CU (knob 1301): measured r03 148-152 us against 112 us for two 112-row workgroups per CU
+// on the C2 variance predictor - with one wave per SIMD nothing runs under the LayerNorm epilogue, whose VALU stream (~2.9 k
+// instructions per layer and wave) is as long as the layer's MFMA stream.  Off by default; bit-identical outputs either way.
+int g_pred_tall = 0;
 
 bool predictor_fused_supported(int dtype, int H, int taps, int nlayers, int S) {
     return dtype == FS2_BF16 && H == PF_H && taps == PF_TAPS && nlayers >= 1 && nlayers <= 16 && S >= 1 &&

@@ -1,6 +1,7 @@
 """Lightning-style checkpoints: a pickle written by torch.save of the dict Lightning writes - hyper_parameters
 as pytorch_lightning's AttributeDict, state_dict of tensors, the on_save_checkpoint extras (fastspeech2.py:622-634) - read
 back without Lightning installed, the class-default CWT pitch transform included, strict and tolerant loads."""
+import os
 import sys
 import types
 
@@ -89,3 +90,121 @@ def test_strict_and_tolerant_loads(tmp_path, capsys):
     fresh = synth_state_dict(cfg, 9)
     np.testing.assert_array_equal(w["linear.weight"], fresh["linear.weight"])  # keeps a fresh initialisation, as the reference
     np.testing.assert_array_equal(w["linear.bias"], sd["linear.bias"])
+
+
+def test_opaque_lightning_objects_do_not_break_the_load(tmp_path):
+    """a checkpoint may pickle instances of Lightning classes other than AttributeDict - enum members rebuilt as
+    cls('fit'), callback / loop state objects with __setstate__.  Without Lightning they resolve to tolerant stand-ins."""
+    import enum
+    import pickle
+    names = ["pytorch_lightning", "pytorch_lightning.trainer", "pytorch_lightning.trainer.states", "pytorch_lightning.callbacks"]
+    saved = {n: sys.modules.get(n) for n in names}
+    mods = [types.ModuleType(n) for n in names]
+    Stage = enum.Enum("RunningStage", {"TRAINING": "train", "FITTING": "fit"}, module=names[2])
+    mods[2].RunningStage = Stage
+
+    class ProgressState:
+        def __init__(self, a, b=2):
+            self.a, self.b = a, b
+
+        def __reduce__(self):
+            return (ProgressState, (self.a,), {"b": self.b, "extra": [1, 2, 3]})
+    ProgressState.__module__, ProgressState.__qualname__ = names[3], "ProgressState"
+    mods[3].ProgressState = ProgressState
+    for n, m in zip(names, mods):
+        sys.modules[n] = m
+    path = tmp_path / "odd.ckpt"
+    try:
+        torch.save({"state_dict": {"w": torch.ones(2)}, "stage": Stage.FITTING, "callbacks": {"progress": ProgressState(7)},
+                    "loops": [ProgressState(1), ProgressState(2)]}, path)
+    finally:
+        for n in names:
+            if saved[n] is None:
+                sys.modules.pop(n, None)
+            else:
+                sys.modules[n] = saved[n]
+    c = ck.read_checkpoint(path)
+    assert torch.equal(c["state_dict"]["w"], torch.ones(2))
+    assert c["stage"]._args == ("fit",)                      # the enum member's value survives for inspection
+    assert c["callbacks"]["progress"]._args == (7,) and c["callbacks"]["progress"].b == 2
+    assert [o._args for o in c["loops"]] == [(1,), (2,)]
+    del pickle
+
+
+def _reference_order_or_skip(cfg):
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import ref_import
+    if not ref_import.reference_available():
+        pytest.skip("reference checkout absent")
+    m, _ = ref_import.load_reference()
+    return m
+
+
+def test_parameter_order_follows_the_reference_modules():
+    """optimizer.state_dict() numbers parameters in FastSpeech2.parameters() order: module registration order of
+    fastspeech2.py:242-438 (phone_embedding, encoder, variance_adaptor, decoder, linear, prior_embeddings, speaker_embedding),
+    in-module order = the real modules' named_parameters()."""
+    cfg = _cfg(priors=["energy", "duration"], encoder_depthwise_conv=True, decoder_depthwise_conv=False,
+               stats={"pitch": {"min": 60.0, "max": 400.0, "mean": 180.0, "std": 40.0},
+                      "energy": {"min": -3.0, "max": 3.0, "mean": 0.0, "std": 1.0}, "snr": {"min": -1.0, "max": 4.0, "mean": 1.2, "std": 2.0},
+                      "energy_prior": {"min": -1.0, "max": 1.0, "mean": 0.0, "std": 1.0},
+                      "duration_prior": {"min": 0.0, "max": 9.0, "mean": 3.0, "std": 1.0}})
+    order = ck.parameter_order(cfg)
+    tops = [n.split(".")[0] for n in order]
+    firsts = [t for i, t in enumerate(tops) if i == 0 or tops[i - 1] != t]
+    assert firsts == ["phone_embedding", "encoder", "variance_adaptor", "decoder", "linear", "prior_embeddings", "speaker_embedding"]
+    assert "positional_encoding.pe" not in order and "variance_adaptor.encoders.pitch.bins" in order  # bins are frozen Parameters
+    m = _reference_order_or_skip(cfg)
+    nv = len(cfg.variances)
+    va = m.VarianceAdaptor(cfg.stats, list(cfg.variances), list(cfg.variance_levels[:nv]), list(cfg.variance_transforms[:nv]),
+                           list(cfg.variance_nlayers[:nv]), list(cfg.variance_kernel_size[:nv]), [0.5] * nv, cfg.variance_filter_size,
+                           cfg.variance_nbins, cfg.variance_depthwise_conv, cfg.duration_nlayers, False, cfg.duration_kernel_size, 0.5,
+                           cfg.duration_filter_size, cfg.duration_depthwise_conv, cfg.hidden, 2756.25)
+    assert [n for n in order if n.startswith("variance_adaptor.")] == ["variance_adaptor." + n for n, _ in va.named_parameters()]
+    for side, heads, F, k, dw in (("encoder", cfg.encoder_head, cfg.encoder_conv_filter_size, cfg.encoder_kernel_sizes[0], True),
+                                  ("decoder", cfg.decoder_head, cfg.decoder_conv_filter_size, cfg.decoder_kernel_sizes[0], False)):
+        layer = m.ConformerEncoderLayer(cfg.hidden, heads, conv_in=cfg.hidden, conv_filter_size=F, conv_kernel=(k, 1), batch_first=True,
+                                        dropout=0.1, conv_depthwise=dw)
+        assert [n for n in order if n.startswith(f"{side}.layers.0.")] == [f"{side}.layers.0." + n for n, _ in layer.named_parameters()]
+    pe = m.PriorEmbedding(cfg.hidden, cfg.variance_nbins, cfg.stats["energy_prior"])
+    assert [n for n in order if n.startswith("prior_embeddings.energy.")] == ["prior_embeddings.energy." + n for n, _ in pe.named_parameters()]
+    se = m.SpeakerEmbedding(cfg.hidden, "dvector")
+    assert [n for n in order if n.startswith("speaker_embedding.")] == ["speaker_embedding." + n for n, _ in se.named_parameters()]
+
+
+def test_optimizer_state_round_trips_through_lightning_layout():
+    """Trainer.optimizer_state() -> Lightning's optimizer_states / lr_schedulers -> a REAL torch.optim.AdamW over parameters in
+    parameter_order accepts it, steps, and its state comes back unchanged through the inverse."""
+    cfg = _cfg(variance_transforms=["none", "none", "none"])
+    names = ck.parameter_order(cfg)
+    spec = state_dict_spec(cfg)
+    g = torch.Generator().manual_seed(0)
+    train = [n for n in names if not n.endswith(".bins")]
+    st = {"step": 17, "micro_step": 0, "exp_avg": {n: torch.randn(spec[n], generator=g) for n in train},
+          "exp_avg_sq": {n: torch.rand(spec[n], generator=g) for n in train}}
+    lit = ck.to_lightning_optimizer_state(cfg, st, lr=1e-3, warmup_steps=4000)
+    params = [torch.nn.Parameter(torch.zeros(spec[n]), requires_grad=not n.endswith(".bins")) for n in names]
+    opt = torch.optim.AdamW(params, lr=1e-3, betas=[0.9, 0.98], eps=1e-8, weight_decay=0.01)
+    opt.load_state_dict(lit["optimizer_states"][0])          # torch's own shape / group validation
+    for i, n in enumerate(names):
+        if n.endswith(".bins"):
+            assert params[i] not in opt.state
+            continue
+        assert torch.equal(opt.state[params[i]]["exp_avg"], st["exp_avg"][n])
+        assert int(opt.state[params[i]]["step"]) == 17
+    assert abs(opt.param_groups[0]["lr"] - 1e-3 * 4000 ** 0.5 * min(17 ** -0.5, 17 * 4000 ** -1.5)) < 1e-12   # noam.py:19-25
+    assert lit["lr_schedulers"][0]["last_epoch"] == 17 and lit["lr_schedulers"][0]["warmup_steps"] == 4000
+    back = ck.from_lightning_optimizer_state(cfg, {"optimizer_states": [opt.state_dict()], "lr_schedulers": lit["lr_schedulers"]})
+    assert back["step"] == 17
+    assert set(back["exp_avg"]) == set(train)
+    for n in train:
+        assert torch.equal(back["exp_avg"][n], st["exp_avg"][n]) and torch.equal(back["exp_avg_sq"][n], st["exp_avg_sq"][n])
+    # torch 1.10 (what the reference pins) keeps `step` as an int
+    old = opt.state_dict()
+    for v in old["state"].values():
+        v["step"] = int(v["step"])
+    assert ck.from_lightning_optimizer_state(cfg, {"optimizer_states": [old], "lr_schedulers": []})["step"] == 17
+    wrong = opt.state_dict()
+    wrong["param_groups"][0]["params"] = wrong["param_groups"][0]["params"][:-1]
+    with pytest.raises(ValueError, match="optimizer holds"):
+        ck.from_lightning_optimizer_state(cfg, {"optimizer_states": [wrong]})

@@ -90,6 +90,39 @@ def _run(world, B, mode):
     return out
 
 
+def test_shard_trims_frame_level_targets_to_its_own_frames():
+    """a training shard carries mel / variances_* padded to the WHOLE batch's T; with trim they are cut to the
+    shard's longest utterance in frames (max over its rows of sum(duration)) - what that rank's DataLoader would have collated."""
+    ph = torch.tensor([[3, 4, 5, 6], [7, 8, 0, 0], [9, 0, 0, 0]])
+    dur = torch.tensor([[2, 3, 1, 4], [5, 1, 0, 0], [2, 0, 0, 0]])
+    T = 10
+    batch = {"phones": ph, "duration": dur, "speaker": torch.zeros(3, 256), "mel": torch.arange(3 * T * 2.0).reshape(3, T, 2),
+             "variances_pitch": torch.arange(3 * T * 1.0).reshape(3, T), "priors_energy": torch.tensor([0.1, 0.2, 0.3])}
+    sh = shard_batch(batch, 2, 1)   # rank 1: the last utterance alone (2 frames, 1 phone)
+    assert sh["phones"].shape == (1, 1) and sh["duration"].shape == (1, 1)
+    assert sh["mel"].shape == (1, 2, 2) and torch.equal(sh["mel"], batch["mel"][2:, :2])
+    assert sh["variances_pitch"].shape == (1, 2) and sh["priors_energy"].shape == (1,)
+    sh0 = shard_batch(batch, 2, 0)  # rank 0: utterances 0, 1 -> 10 and 6 frames
+    assert sh0["mel"].shape == (2, 10, 2) and sh0["variances_pitch"].shape == (2, 10)
+    keep = shard_batch(batch, 2, 1, trim=False)
+    assert keep["mel"].shape == (1, T, 2) and keep["phones"].shape == (1, 4)
+
+
+def test_collective_device_follows_the_backend():
+    from lightningfastspeech2_amd import dist as D
+    import torch.distributed as td
+    td.init_process_group("gloo", rank=0, world_size=1, init_method="tcp://127.0.0.1:29533")
+    try:
+        assert D.collective_device(None, None) == torch.device("cpu")          # host-side batch under gloo
+        assert D.collective_device(None, torch.zeros(1)) == torch.device("cpu")
+        # an explicit device wins in forward_sharded; an empty shard no longer guesses from batch["speaker"]
+        out = D.forward_sharded(lambda b: {"mel": torch.zeros(1, 3, 4), "tgt_mask": torch.zeros(1, 3, dtype=torch.bool)},
+                                {"phones": torch.ones(1, 2, dtype=torch.long), "speaker": [[0.0] * 256]}, n_mels=4, device="cpu")
+        assert out[0].shape == (1, 3, 4)
+    finally:
+        td.destroy_process_group()
+
+
 def test_global_pad_mode_equals_the_whole_batch():
     """SURVEY 8e global-pad mode on a ragged batch: shards keep the batch's phone length and pad their frames to the
     all-reduced maximum, so the gathered mels equal the single-process whole-batch run (pad leakage included)."""

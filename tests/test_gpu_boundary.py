@@ -145,3 +145,66 @@ def test_two_rank_bench_rehearsal_over_gloo():
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 8 and line["value"] > 0
     assert line["config"]["frames_per_utterance"] == 32 * 6
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_rccl_branch_runs_at_world_size_one():
+    """The backend == "nccl" paths (= RCCL on ROCm) of dist.py on the hardware that exists: librccl loads, the process group
+    comes up with device_id=, the mel gather queues on the collective stream and MelGather.wait orders the caller's stream
+    behind it, global_frames / all_reduce_gradients run - before an 8-GPU node ever sees them.  In a child process: a process
+    group in the pytest process would outlive the test."""
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["FS2_ROOT"])
+from lightningfastspeech2_amd.dist import gather_mels_async, global_frames, all_reduce_gradients, forward_sharded, collective_device
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+assert dist.get_backend() == "nccl"
+assert collective_device(None, None) == torch.device("cuda", 0)           # a host-side batch still gets device control tensors
+mel = torch.randn(3, 40, 80, device="cuda")
+mask = torch.zeros(3, 40, dtype=torch.bool, device="cuda"); mask[1, 25:] = True; mask[2, 10:] = True
+mel[mask] = 0
+g = gather_mels_async(mel, mask, zeroed=True)                               # general path: exchanges (B_r, T) first
+all_mel, frames = g.wait()
+torch.cuda.synchronize()
+assert torch.equal(all_mel, mel) and frames.tolist() == [40, 25, 10]
+g2 = gather_mels_async(mel, mask, shapes=([3], 40), zeroed=True)            # sync-free path (bench.py's steady state)
+all2, fr2 = g2.wait(); torch.cuda.synchronize()
+assert torch.equal(all2, mel) and fr2.tolist() == [40, 25, 10]
+assert global_frames(123, torch.device("cuda", 0)) == 123
+flat = torch.arange(1000, dtype=torch.float32, device="cuda")
+all_reduce_gradients(flat, bucket_bytes=1024)                               # four buckets
+works = all_reduce_gradients(flat, bucket_bytes=2048, async_op=True)
+for w in works: w.wait()
+torch.cuda.synchronize()
+assert torch.equal(flat.cpu(), torch.arange(1000, dtype=torch.float32))
+out = forward_sharded(lambda b: {"mel": mel[:b["phones"].shape[0]], "tgt_mask": mask[:b["phones"].shape[0]]},
+                      {"phones": torch.ones(3, 5, dtype=torch.long), "speaker": torch.zeros(3, 256)}, n_mels=80)
+assert out[0].shape == (3, 40, 80) and out[0].is_cuda
+dist.destroy_process_group()
+print("RCCL-OK")
+'''
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), FS2_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL-OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+
+
+def test_bench_under_torchrun_over_rccl_one_rank():
+    """bench.py exactly as the driver launches it for N > 1 (torch.distributed.run, one rank per GPU, backend nccl), with the
+    multi-rank path forced at world size 1 (FS2_BENCH_FORCE_DIST): init with device_id=, shape agreement, gathers in flight under
+    the next forward, drain, closing barrier, max over ranks."""
+    env = dict(os.environ, FS2_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--config", "ref-default", "--batch", "4", "--phones", "32"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and "RCCL" in line["config"]["parallelism"]

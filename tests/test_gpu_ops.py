@@ -231,9 +231,9 @@ def test_predictor_single_launch(B, S, nl):
 
 
 def test_predictor_tile_heights_are_bit_identical():
-    """Which tile height runs (208 rows, one workgroup per CU, when the launch fills the chip; 112 / 64 rows otherwise) follows the
-    launch size, so it must not enter the arithmetic: same wave layout, same reduction tree - bit-equal outputs."""
-    B, S, nl, H = 26, 1536, 5, 256   # 26 x 8 = 208 tall tiles: the tall kernel runs by default
+    """Which tile height runs (112 / 64 rows by launch size; 208 rows with one workgroup per CU behind knob 1301) must not enter
+    the arithmetic: same wave layout, same reduction tree - bit-equal outputs."""
+    B, S, nl, H = 26, 1536, 5, 256   # 26 x 8 = 208 tall tiles: enough for the tall kernel to be picked under knob 1301
     x = rnd(B, S, H, seed=170)
     ws = [rnd(H, H, 3, seed=171 + j, scale=(3 * H) ** -0.5) for j in range(nl)]
     bs = [0.3 * rnd(H, seed=180 + j) for j in range(nl)]
@@ -243,12 +243,12 @@ def test_predictor_tile_heights_are_bit_identical():
     mask = torch.zeros(B, S, dtype=torch.bool)
     for b in range(B):
         mask[b, S - 11 * b:] = True
-    tall = G.predictor(x, ws, bs, gs, bes, hw, hb, mask, B, S)
-    G.lib().fs2_op_set_gemm_variant(1300)
+    short = G.predictor(x, ws, bs, gs, bes, hw, hb, mask, B, S)
+    G.lib().fs2_op_set_gemm_variant(1301)
     try:
-        short = G.predictor(x, ws, bs, gs, bes, hw, hb, mask, B, S)
+        tall = G.predictor(x, ws, bs, gs, bes, hw, hb, mask, B, S)
     finally:
-        G.lib().fs2_op_set_gemm_variant(1301)
+        G.lib().fs2_op_set_gemm_variant(1300)
     assert torch.equal(tall, short)
     ref = _predictor_ref(x[:3], ws, bs, gs, bes, hw, hb, mask[:3])
     assert float((tall[:3] - ref).abs().max()) <= 2e-2 * (float(ref.abs().max()) + 1)

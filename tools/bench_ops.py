@@ -281,6 +281,7 @@ def main():
     if a.what in ("bwd",):
         bwd_cases(a.reps)
     if a.what in ("pred", "all"):
+        if a.variant >= 1300: lib.fs2_op_set_gemm_variant(a.variant)   # 1300: 112-row tiles only, 1301: 208-row tiles where they fill the chip
         predictor_case("variance predictor fused", 32, 1536, 5, a.reps)
         predictor_case("duration predictor fused", 32, 256, 2, a.reps)
     if a.what in ("attn", "all"):
