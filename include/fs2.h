@@ -280,6 +280,14 @@ int fs2_op_masked_loss(const float* pred, const void* truth, int32_t truth_kind,
  * anti-diagonals (e.g. 2 x 240 frames of an 80-bin mel), else read through the caches; FS2_ERR_SHAPE for N > 6800. */
 int fs2_op_soft_dtw(const float* x, const float* y, int32_t B, int32_t N, int32_t M, int32_t D, float gamma, float* out,
                     void* hip_stream);
+/* The same value plus its gradient with respect to x - what loss.backward() yields through the reference's vendored module
+ * (third_party/softdtw/__init__.py:27-52 compute_softdtw_backward on the float32 R / D that _SoftDTW.forward saves, :56-77;
+ * autograd through calc_distance_matrix :85-92): grad_x[b,i,:] = 2 sum_j E[b,i,j] (x[b,i,:] - y[b,j,:]).  The "soft_dtw" loss
+ * kind of loss.py:36,62-81 differentiates exactly this, chunk by chunk, with respect to the prediction only.  scratch: device
+ * memory of fs2_op_soft_dtw_grad_scratch_bytes(B, N, M) bytes (R, D and E of every pair).  Deterministic. */
+size_t fs2_op_soft_dtw_grad_scratch_bytes(int32_t B, int32_t N, int32_t M);
+int fs2_op_soft_dtw_grad(const float* x, const float* y, int32_t B, int32_t N, int32_t M, int32_t D, float gamma, float* out,
+                         float* grad_x, void* scratch, size_t scratch_bytes, void* hip_stream);
 /* dtype conversion helpers for tests: fp32 <-> engine dtype, n elements, device pointers */
 int fs2_op_convert(int32_t src_dtype, int32_t dst_dtype, const void* src, void* dst, size_t n, void* hip_stream);
 

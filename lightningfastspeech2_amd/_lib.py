@@ -136,6 +136,9 @@ def load():
     lib.fs2_op_masked_loss_ws_bytes.argtypes = []
     lib.fs2_op_masked_loss.argtypes = [vp, vp, i32, vp, C.c_int64, i32, i32, vp, vp, vp]
     lib.fs2_op_soft_dtw.argtypes = [vp, vp, i32, i32, i32, i32, C.c_float, vp, vp]
+    lib.fs2_op_soft_dtw_grad_scratch_bytes.argtypes = [i32, i32, i32]
+    lib.fs2_op_soft_dtw_grad_scratch_bytes.restype = C.c_size_t
+    lib.fs2_op_soft_dtw_grad.argtypes = [vp, vp, i32, i32, i32, i32, C.c_float, vp, vp, vp, C.c_size_t, vp]
     lib.fs2_op_set_gemm_variant.argtypes = [i32]
     lib.fs2_op_set_vocoder_lds_limit.argtypes = [i32]
     lib.fs2_op_set_vocoder_fused_resblock.argtypes = [i32]

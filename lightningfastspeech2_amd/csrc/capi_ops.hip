@@ -61,6 +61,13 @@ int fs2_op_soft_dtw(const float* x, const float* y, int32_t B, int32_t N, int32_
     SoftDtwArgs a{x, y, out, B, N, M, D, gamma};
     return launch_soft_dtw(a, (hipStream_t)stream);
 }
+size_t fs2_op_soft_dtw_grad_scratch_bytes(int32_t B, int32_t N, int32_t M) { return soft_dtw_grad_scratch_bytes(B, N, M); }
+int fs2_op_soft_dtw_grad(const float* x, const float* y, int32_t B, int32_t N, int32_t M, int32_t D, float gamma, float* out,
+                         float* grad_x, void* scratch, size_t scratch_bytes, void* stream) {
+    if (!x || !y || !out) return FS2_ERR_ARG;
+    SoftDtwArgs a{x, y, out, B, N, M, D, gamma};
+    return launch_soft_dtw_grad(a, grad_x, scratch, scratch_bytes, (hipStream_t)stream);
+}
 
 size_t fs2_op_masked_loss_ws_bytes(void) { return fs2::masked_loss_ws_bytes(); }
 

@@ -166,6 +166,8 @@ struct SoftDtwArgs {
 };
 size_t soft_dtw_lds_bytes(int N, int M, int D);
 int launch_soft_dtw(const SoftDtwArgs& a, hipStream_t stream);
+size_t soft_dtw_grad_scratch_bytes(int B, int N, int M);
+int launch_soft_dtw_grad(const SoftDtwArgs& a, float* grad_x, void* scratch, size_t scratch_bytes, hipStream_t stream);
 size_t masked_loss_ws_bytes();
 int launch_masked_loss(const LossArgs& a, hipStream_t stream);
 int voc_resblock_mi16(const VocResblockArgs& a, int dtype);  // 0 = shape not covered

@@ -256,7 +256,8 @@ class Trainer:
     def __init__(self, cfg: Fs2Config, state_dict, *, lr=2e-4, warmup_steps=4000, betas=(0.9, 0.98), eps=1e-8,
                  weight_decay=0.01, gradient_clip_val: Optional[float] = 1.0, variance_losses=None, mel_loss="l1",
                  duration_loss="mse", loss_alphas=None, precision="fp32", encoder_dropout=0.0, decoder_dropout=0.0,
-                 variance_dropout=0.0, duration_dropout=0.0, seed=0, attention="auto", device="cuda:0"):
+                 variance_dropout=0.0, duration_dropout=0.0, seed=0, attention="auto", device="cuda:0",
+                 soft_dtw_gamma=0.01, soft_dtw_chunk_size=256):
         if any(l != "frame" for l in cfg.variance_levels[:len(cfg.variances)]) or any(cfg.is_cwt(i) for i in range(len(cfg.variances))):
             # (the reference cannot train the CWT head either: loss.py:141,148 read self.mse_loss, which its __init__ never sets)
             raise NotImplementedError("training step: frame-level 'none' variances only")
@@ -295,8 +296,9 @@ class Trainer:
         if missing:
             raise ValueError(f"loss_alphas has no entry for {missing} (the default covers mel / pitch / energy / snr / duration)")
         for k in self.variance_losses + [mel_loss, duration_loss]:
-            if k not in _KIND:
-                raise NotImplementedError(f"training step: loss kind {k!r} has no gradient kernel ('l1' / 'mse' only)")
+            if k not in _KIND and k != "soft_dtw":
+                raise NotImplementedError(f"training step: loss kind {k!r} has no gradient kernel ('l1' / 'mse' / 'soft_dtw')")
+        self.soft_dtw_gamma, self.soft_dtw_chunk_size = float(soft_dtw_gamma), int(soft_dtw_chunk_size)
         # ---- flat parameter / gradient / moment buffers, named views in KERNEL layout (conv weights tap-major) ----
         spec = state_dict_spec(cfg)
         self._layout: "OrderedDict[str, tuple]" = OrderedDict()   # name -> (offset, kernel shape, reference shape)
@@ -682,8 +684,31 @@ class Trainer:
             else:
                 dy = o.dgrad(dc, W[f"{p}.0.module.weight"], M, filt, lt["cin"], taps=k, S=S, wt=self._wt(f"{p}.0.module.weight"))
 
+    def _loss_soft_dtw(self, name, pred, truth, truth_kind, mask, rows, inner):
+        """get_loss with loss == "soft_dtw" (loss.py:62-81): pads zero-filled in prediction and target, the time axis cut into
+        chunks of soft_dtw_chunk_size frames, soft-DTW of every (prediction chunk, target chunk) pair summed over chunks and batch;
+        the gradient reaches the prediction only (truth.requires_grad = False, :63) and not its zero-filled pads.  Value and
+        gradient of a chunk: fs2_op_soft_dtw_grad (csrc/softdtw.hip), pinned on the reference's vendored module."""
+        from .softdtw import soft_dtw_value_and_grad
+        Bm, Tm = mask.shape
+        valid = (mask.view(Bm, Tm) == 0).unsqueeze(-1).to(torch.float32)
+        p3 = pred.view(Bm, Tm, inner).to(torch.float32) * valid
+        t3 = truth.view(Bm, Tm, -1).to(torch.float32) if truth_kind == 0 else torch.log(truth.view(Bm, Tm, 1).to(torch.float32) + 1)
+        t3 = t3 * valid
+        total = None
+        grads = []
+        for pc, tc in zip(p3.split(self.soft_dtw_chunk_size, dim=1), t3.split(self.soft_dtw_chunk_size, dim=1)):
+            v, g = soft_dtw_value_and_grad(pc.contiguous(), tc.contiguous(), self.soft_dtw_gamma)
+            total = v.sum() if total is None else total + v.sum()
+            grads.append(g)
+        dpred = (torch.cat(grads, dim=1) * valid * float(self.loss_alphas[name])).reshape(rows, inner) if inner > 1 else \
+            (torch.cat(grads, dim=1) * valid * float(self.loss_alphas[name])).reshape(rows)
+        return torch.stack([total, valid.sum() * inner]), dpred.contiguous()
+
     def _loss(self, name, pred, truth, truth_kind, mask, rows, inner, kind, want_grad=True):
         o = self.ops
+        if kind == "soft_dtw":
+            return self._loss_soft_dtw(name, pred, truth, truth_kind, mask, rows, inner)
         stat = o.empty(2)
         o.ck(o.lib.fs2_op_masked_loss(_p(pred), _p(truth), truth_kind, _p(mask), rows, inner, _KIND[kind], _p(self._loss_ws),
                                       _p(stat), o.st()), "masked_loss")

@@ -23,24 +23,59 @@ from . import oracle_cpu
 DEFAULT_ALPHAS = {"mel": 1.0, "pitch": 1e-1, "energy": 1e-1, "snr": 1e-1, "duration": 1e-4}
 
 
-def _masked(pred, truth, kind, valid):
+class _SoftDtwChunk(torch.autograd.Function):
+    """One (prediction chunk, target chunk) batch through oracle.softdtw_cpu: value forward, d value / d prediction backward
+    (= the reference's vendored _SoftDTW + calc_distance_matrix, pinned on tests/golden/softdtw_grad_small.npz)."""
+
+    @staticmethod
+    def forward(ctx, x, y, gamma):
+        from . import softdtw_cpu
+        val, grad = softdtw_cpu.soft_dtw_value_and_grad(x.detach().numpy(), y.detach().numpy(), gamma)
+        ctx.save_for_backward(torch.from_numpy(grad))
+        return torch.from_numpy(val)
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return g.view(-1, 1, 1) * grad, None, None
+
+
+def _soft_dtw(pred, truth, valid, gamma, chunk):
+    """get_loss with loss == "soft_dtw" (loss.py:62-81): zero-filled pads, chunks of `chunk` frames, summed over chunks and batch."""
+    if pred.dim() == 2:
+        pred, truth = pred.unsqueeze(-1), truth.unsqueeze(-1)
+    v = valid.unsqueeze(-1)
+    pred, truth = pred.masked_fill(~v, 0), truth.masked_fill(~v, 0)
+    total = None
+    for pc, tc in zip(pred.split(chunk, dim=1), truth.split(chunk, dim=1)):
+        val = _SoftDtwChunk.apply(pc.contiguous(), tc.contiguous(), gamma)
+        total = val if total is None else total + val
+    return total.sum()
+
+
+def _masked(pred, truth, kind, valid, soft_dtw_gamma=0.01, soft_dtw_chunk_size=256):
     """get_loss, loss.py:57-81: masked_select by the valid mask, then nn.L1Loss / nn.MSELoss (mean)."""
+    if kind == "soft_dtw":
+        return _soft_dtw(pred, truth, valid, soft_dtw_gamma, soft_dtw_chunk_size)
     if pred.dim() == 3:
         valid = valid.unsqueeze(-1).expand_as(pred)
     d = pred[valid] - truth[valid]
     return d.abs().mean() if kind == "l1" else (d * d).mean()
 
 
-def losses(cfg, result, batch, variance_losses=None, mel_loss="l1", duration_loss="mse", alphas=None):
+def losses(cfg, result, batch, variance_losses=None, mel_loss="l1", duration_loss="mse", alphas=None, soft_dtw_gamma=0.01,
+           soft_dtw_chunk_size=256):
     alphas = dict(DEFAULT_ALPHAS if alphas is None else alphas)
     variance_losses = variance_losses or ["mse"] * len(cfg.variances)
     tgt_valid, src_valid = ~result["tgt_mask"], ~result["src_mask"]
     out = OrderedDict()
     for v, kind in zip(cfg.variances, variance_losses):
-        out[v] = _masked(result[f"variances_{v}"], torch.as_tensor(np.asarray(batch[f"variances_{v}"])).float(), kind, tgt_valid)
-    out["mel"] = _masked(result["mel"], torch.as_tensor(np.asarray(batch["mel"])).float(), mel_loss, tgt_valid)
+        out[v] = _masked(result[f"variances_{v}"], torch.as_tensor(np.asarray(batch[f"variances_{v}"])).float(), kind, tgt_valid,
+                         soft_dtw_gamma, soft_dtw_chunk_size)
+    out["mel"] = _masked(result["mel"], torch.as_tensor(np.asarray(batch["mel"])).float(), mel_loss, tgt_valid, soft_dtw_gamma,
+                         soft_dtw_chunk_size)
     dur_t = torch.log(torch.as_tensor(np.asarray(batch["duration"])).float() + 1)
-    out["duration"] = _masked(result["duration_prediction"], dur_t, duration_loss, src_valid)
+    out["duration"] = _masked(result["duration_prediction"], dur_t, duration_loss, src_valid, soft_dtw_gamma, soft_dtw_chunk_size)
     out["total"] = sum(v * alphas[k] for k, v in out.items())
     return out
 

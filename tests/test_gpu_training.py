@@ -137,7 +137,13 @@ def test_trainer_rejects_what_is_not_built():
     from lightningfastspeech2_amd.training import Trainer
     cfg, sd, _ = _case(1, 2, 5, [5, 3])
     with pytest.raises(NotImplementedError):
-        Trainer(cfg, sd, mel_loss="soft_dtw")
+        Trainer(cfg, sd, mel_loss="huber")
+    with pytest.raises(ValueError, match="even kernel size"):   # 'same' padding of an even kernel is asymmetric
+        import dataclasses
+        Trainer(dataclasses.replace(cfg, decoder_kernel_sizes=[4, 3]), sd)
+    with pytest.raises(ValueError, match="loss_alphas"):
+        Trainer(cfg, sd, loss_alphas={"mel": 1.0, "duration": 1.0})
+    assert Trainer(cfg, sd, gradient_clip_val=0).gradient_clip_val is None   # Lightning: 0 = no clipping
 
 
 def test_bf16_mixed_precision_step_tracks_the_fp32_gradients():
@@ -400,3 +406,85 @@ def test_baseline_configs_train_in_bf16(name):
         tr.optimizer_step()
         last = tr.training_step(bd)
     assert float(last["total"]) < float(l0["total"])
+
+
+@pytest.mark.parametrize("name,dropout", [("c2", 0.0), ("c2", 0.1), ("ref-default", 0.0), ("ref-default", 0.1)])
+def test_bf16_step_tracks_the_fp32_step_at_a_baseline_size(name, dropout):
+    """bf16 training parity beyond the tiny fixture.  Full BASELINE configs[1] architecture (FS2-27M dense)
+    and the reference-default depth-wise family, B = 4 utterances x 256 phonemes x 3 frames, ragged: the bf16 step against the
+    fp32 HIP step from the same weights (the fp32 step is what the reference-produced fixtures pin to 1e-4) - every loss term
+    within 2 % (measured: 1e-4 .. 1e-3), every parameter tensor's gradient cosine >= 0.98 and >= 0.99 for at least 90 % of the
+    tensors (tensors whose gradient is numerical noise excepted), with the recipe's dropout too (same counter-based masks in
+    both precisions).  Measured r03, C2 without dropout: 163 of 172 tensors >= 0.99; the nine below are the first conv layers of
+    the variance predictors and the embedding tables they feed back into (0.986 .. 0.99), the same with materialised attention
+    and with either data-gradient path - a property of the bf16 predictor chain, not of one kernel."""
+    import math
+    from lightningfastspeech2_amd.config import preset
+    from lightningfastspeech2_amd.training import Trainer
+    cfg = preset(name)
+    sd = synth_state_dict(cfg, 0, duration_bias=math.log(4.0), duration_weight_scale=0.0)
+    B, L, f = 4, 256, 3
+    lens = [L, L - 37, L - 90, L // 2]
+    inp = synth_inputs(cfg, B, L, seed=91, lengths=lens)
+    rs = np.random.RandomState(5)
+    dur = np.zeros((B, L), np.int64)
+    for b, n in enumerate(lens):
+        dur[b, :n] = rs.randint(1, 2 * f, size=n)
+    T = int(dur.sum(axis=1).max())
+    batch = {"phones": inp["phones"], "speaker": inp["speaker"], "duration": dur, "mel": (rs.randn(B, T, cfg.n_mels) - 2).astype(np.float32)}
+    for v in cfg.variances:
+        batch[f"variances_{v}"] = rs.randn(B, T).astype(np.float32)
+    bd = _dev(batch)
+    kw = dict(lr=1e-3, warmup_steps=1, seed=11, encoder_dropout=dropout, decoder_dropout=dropout, duration_dropout=dropout,
+              variance_dropout=dropout)
+    ref = Trainer(cfg, sd, precision="fp32", **kw)
+    want_l = {k: float(v) for k, v in ref.training_step(bd).items()}
+    want = {n: g.double().cpu() for n, g in ref.gradients().items()}
+    del ref
+    torch.cuda.empty_cache()
+    tr = Trainer(cfg, sd, precision="bf16", **kw)
+    got_l = {k: float(v) for k, v in tr.training_step(bd).items()}
+    for k, w in want_l.items():
+        assert abs(got_l[k] - w) <= 2e-2 * max(1.0, abs(w)), (k, got_l[k], w)
+    got = tr.gradients()
+    gmax = max(float(w.abs().max()) for w in want.values())
+    worst = ("", 1.0)
+    checked = good = 0
+    for n, w in want.items():
+        if float(w.abs().max()) < 1e-4 * gmax:
+            continue  # numerically-zero gradients (attention key biases): direction is noise
+        g = got[n].double().cpu()
+        cos = float((g * w).sum() / (g.norm() * w.norm() + 1e-30))
+        checked += 1
+        good += cos >= 0.99
+        if cos < worst[1]:
+            worst = (n, cos)
+    assert checked >= 0.8 * len(want) and worst[1] >= 0.98 and good >= 0.9 * checked, (worst, good, checked, len(want))
+
+
+def test_soft_dtw_loss_kind_trains():
+    """mel_loss = "soft_dtw" and a soft-DTW variance loss (loss.py:36,62-81): zero-filled pads, chunks of soft_dtw_chunk_size
+    frames, value summed over chunks and batch, the gradient through fs2_op_soft_dtw_grad - losses and every parameter's gradient
+    against the oracle (torch autograd over the forward oracle with oracle.softdtw_cpu's value / gradient, itself pinned on the
+    reference's vendored module); a chunk size below T exercises the chunk seam."""
+    from lightningfastspeech2_amd.training import Trainer
+    cfg, sd, batch = _case(2, 2, 9, [9, 6])
+    kw = dict(mel_loss="soft_dtw", variance_losses=["soft_dtw", "mse"], soft_dtw_gamma=0.5, soft_dtw_chunk_size=16,
+              lr=1e-3, warmup_steps=10)
+    ref = train_cpu.OracleTrainer(cfg, sd, **kw)
+    want_l, _ = ref.training_step(batch)
+    want = ref.gradients()
+    tr = Trainer(cfg, sd, **kw)
+    got_l = tr.training_step(_dev(batch))
+    for k, w in want_l.items():
+        assert abs(float(got_l[k]) - w) <= 2e-4 * max(1.0, abs(w)), (k, float(got_l[k]), w)
+    got = tr.gradients()
+    for n, w in want.items():
+        scale = float(w.abs().max()) + 1e-3 * max(float(v.abs().max()) for v in want.values())
+        assert float((got[n].cpu() - w).abs().max()) <= 2e-3 * scale, n
+    first = float(got_l["total"])
+    tr.optimizer_step()
+    for _ in range(3):
+        last = float(tr.training_step(_dev(batch))["total"])
+        tr.optimizer_step()
+    assert last < first

@@ -28,3 +28,18 @@ def test_identical_sequences_normalise_to_zero_and_plain_value_is_a_soft_minimum
     hard = softdtw_cpu.soft_dtw(x, y, 1e-4)          # gamma -> 0: the DTW alignment cost
     soft = softdtw_cpu.soft_dtw(x, y, 1.0)
     assert (soft <= hard + 1e-3).all()                # a soft minimum never exceeds the hard one
+
+
+def test_gradient_oracle_matches_the_reference_backward():
+    """oracle.softdtw_cpu.soft_dtw_value_and_grad against what loss.backward() left in x.grad through the reference's own
+    _SoftDTW Function + calc_distance_matrix (tools/gen_golden_softdtw.py -> tests/golden/softdtw_grad_small.npz)."""
+    import json
+    import os
+    zg = np.load(os.path.join(os.path.dirname(__file__), "golden", "softdtw_grad_small.npz"))
+    for c in json.loads(str(zg["cases_json"])):
+        n = c["name"]
+        val, grad = softdtw_cpu.soft_dtw_value_and_grad(zg[f"{n}__x"], zg[f"{n}__y"], c["gamma"])
+        np.testing.assert_allclose(val, zg[f"{n}__out"], rtol=3e-6, atol=3e-4)
+        want = zg[f"{n}__grad"]
+        # the backward exponentiates float32-rounded R differences divided by gamma: last-ulp differences in D move E by ~1e-4
+        assert float(np.abs(grad - want).max()) <= 1e-3 * float(np.abs(want).max()), n
