@@ -129,18 +129,20 @@ int launch_layernorm(const LayerNormArgs& a, int dtype, hipStream_t stream) {
 // LightSpeech FFN (model.py:75-81) and module.0 of the depth-wise predictor layer
 // (model.py:545-551).  LDS-staged (TR + k - 1) x 64 slab, one output channel per lane.
 // =============================================================================================
-static constexpr int DW_TR = 128, DW_CT = 64, DW_KMAX = 32, DW_RR = 8, DW_TC = 8;
+static constexpr int DW_TR = 256, DW_CT = 64, DW_KMAX = 32, DW_RR = 16, DW_TC = 8;
 
-// Workgroup = 128 rows x 64 channels of one utterance; a thread owns 8 consecutive rows x 4 channels.  The
-// (128 + k' - 1) x 64 input slab (k' = k rounded up to a multiple of 8; zeros outside the utterance) and the
-// k' x 64 weights (zeros past k) are staged in LDS as fp32.  Taps go in chunks of 8: the chunk's 8 x 4 weights sit
+// Workgroup = 256 rows x 64 channels of one utterance; a thread owns 16 consecutive rows x 4 channels.  The
+// (256 + k' - 1) x 64 input slab (k' = k rounded up to a multiple of 8; zeros outside the utterance) sits in LDS in the
+// activation dtype, the k' x 64 weights (zeros past k) as fp32.  (r03: with 8 rows per thread and an fp32 slab the kernel moved
+// 1.44 LDS bytes per multiply-add - 368 B of slab + weight reads per 256 - against a CU's 128 B and 128 multiply-adds per
+// cycle: LDS-bound at 42 % of the HBM rate; 16 rows on a bf16 slab move 0.61.)  Taps go in chunks of 8: the chunk's 8 x 4 weights sit
 // in registers and the thread walks the 15 input rows the chunk touches ONCE - one 16-byte LDS read feeds up
 // to 8 x 4 multiply-adds (input row o + j contributes tap c*8 + j to output row o).  The previous kernel read an
 // input row per output row per tap (5 LDS reads per 16 MACs) and sat on the LDS port at k = 17..25, 2.6x off
 // the HBM time of its 0.15 GB.  Per output the taps are still added in ascending order: bit-identical results.
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv_kernel(DwConvArgs p) {
-    __shared__ __attribute__((aligned(16))) float tile[(DW_TR + DW_KMAX - 1) * DW_CT];
+    __shared__ __attribute__((aligned(16))) T tile[(DW_TR + DW_KMAX - 1) * DW_CT];
     __shared__ __attribute__((aligned(16))) float wl[DW_KMAX * DW_CT];  // [tap][channel]
     __shared__ float rstat[(DW_TR + DW_KMAX - 1) * 2];                   // LayerNorm-on-load: (mean, rstd) per slab row
     const int tid = threadIdx.x;
@@ -151,13 +153,20 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwConvArgs p) {
     const bool full_c = c0 + DW_CT <= p.C;
     const bool lnl = p.ln_stats != nullptr;
     float lg[4] = {1.f, 1.f, 1.f, 1.f}, lb[4] = {0.f, 0.f, 0.f, 0.f};
-    float2 pq[4] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f), make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
-    if (lnl) {  // this thread's slab row (rows <= 159 < 256): its row-statistic parts, issued with the fill loads below
-        const int t = t0 + tid - p.pad;
-        if (tid < rows && t >= 0 && t < p.S) {
-            const float2* ps = (const float2*)p.ln_stats + ((size_t)b * p.S + t) * p.ln_parts;
+    float2 pq[2][4];  // row-statistic parts of slab rows tid and tid + 256 (rows <= 287)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) if (q < p.ln_parts) pq[q] = ps[q];
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pq[h][q] = make_float2(0.f, 0.f);
+    if (lnl) {  // issued with the fill loads below
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = tid + 256 * h, t = t0 + r - p.pad;
+            if (r < rows && t >= 0 && t < p.S) {
+                const float2* ps = (const float2*)p.ln_stats + ((size_t)b * p.S + t) * p.ln_parts;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (q < p.ln_parts) pq[h][q] = ps[q];
+            }
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -166,11 +175,15 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwConvArgs p) {
         }
     }
     auto publish_rstat = [&]() {
-        const float s1 = (pq[0].x + pq[1].x) + (pq[2].x + pq[3].x), s2 = (pq[0].y + pq[1].y) + (pq[2].y + pq[3].y);
-        const float mean = s1 / (float)p.C;
-        if (tid < rows) {
-            rstat[2 * tid] = mean;
-            rstat[2 * tid + 1] = 1.0f / sqrtf(fmaxf(__builtin_fmaf(-mean, mean, s2 / (float)p.C), 0.f) + p.ln_eps);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = tid + 256 * h;
+            const float s1 = (pq[h][0].x + pq[h][1].x) + (pq[h][2].x + pq[h][3].x), s2 = (pq[h][0].y + pq[h][1].y) + (pq[h][2].y + pq[h][3].y);
+            const float mean = s1 / (float)p.C;
+            if (r < rows) {
+                rstat[2 * r] = mean;
+                rstat[2 * r + 1] = 1.0f / sqrtf(fmaxf(__builtin_fmaf(-mean, mean, s2 / (float)p.C), 0.f) + p.ln_eps);
+            }
         }
         __syncthreads();
     };
@@ -202,7 +215,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwConvArgs p) {
 #pragma unroll
         for (int u = 0; u < FB; ++u) {
             const int i = tid + u * 256;
-            if (i < npc) *(float4*)(tile + (i >> 4) * DW_CT + (i & 15) * 4) = make_float4(v[u][0], v[u][1], v[u][2], v[u][3]);
+            if (i < npc) store4<T>(tile + (i >> 4) * DW_CT + (i & 15) * 4, v[u]);
         }
     } else {
         if (lnl) publish_rstat();
@@ -218,7 +231,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwConvArgs p) {
                         if (lnl) v[e] = __builtin_fmaf((v[e] - rstat[2 * r]) * rstat[2 * r + 1], p.ln_g[c0 + cq + e], p.ln_b[c0 + cq + e]);
                     }
             }
-            *(float4*)(tile + r * DW_CT + cq) = make_float4(v[0], v[1], v[2], v[3]);
+            store4<T>(tile + r * DW_CT + cq, v);
         }
     }
     for (int i = tid; i < DW_CT * kp; i += 256) {
@@ -237,18 +250,19 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwConvArgs p) {
         float4 w[DW_TC];
 #pragma unroll
         for (int j = 0; j < DW_TC; ++j) w[j] = *(const float4*)(wl + (c * DW_TC + j) * DW_CT + cq);
-        const float* trow = tile + (r0 + c * DW_TC) * DW_CT + cq;
+        const T* trow = tile + (r0 + c * DW_TC) * DW_CT + cq;
 #pragma unroll
         for (int rr = 0; rr < DW_RR + DW_TC - 1; ++rr) {
-            const float4 x4 = *(const float4*)(trow + rr * DW_CT);
+            float x4[4];
+            load4<T>(trow + rr * DW_CT, x4);
 #pragma unroll
             for (int o = 0; o < DW_RR; ++o) {
                 const int j = rr - o;  // compile-time after unrolling: tap c*8 + j of output row o
                 if (j >= 0 && j < DW_TC) {
-                    acc[o][0] = fmaf(w[j].x, x4.x, acc[o][0]);
-                    acc[o][1] = fmaf(w[j].y, x4.y, acc[o][1]);
-                    acc[o][2] = fmaf(w[j].z, x4.z, acc[o][2]);
-                    acc[o][3] = fmaf(w[j].w, x4.w, acc[o][3]);
+                    acc[o][0] = fmaf(w[j].x, x4[0], acc[o][0]);
+                    acc[o][1] = fmaf(w[j].y, x4[1], acc[o][1]);
+                    acc[o][2] = fmaf(w[j].z, x4[2], acc[o][2]);
+                    acc[o][3] = fmaf(w[j].w, x4[3], acc[o][3]);
                 }
             }
         }
