@@ -36,7 +36,8 @@ namespace {
 // Probe builds (tools/probes/attn_pipe_probe.py compiles this file with -DFS2_ATTN_PROBE=bits into throw-away libraries and times
 // them): 1 = no exp / sum / pack, 2 = no row max / decision, 4 = no fragment reads in the loop, 8 = no tile DMA in the loop,
 // 16 = no Q.K^T MFMAs, 32 = no P.V MFMAs, 128 = 32-query items only, 256 = no per-tile drain + barrier (racy), 512 = no key-mask
-// test.  The product is always built with 0.
+// test, 1024 = per-row decision dump into lse2, 4096 = s_memtime phase stamps of workgroup 0 behind lse2 (tools/probes/
+// attn_pipe_stamps.py).  The product is always built with 0.
 #ifndef FS2_ATTN_PROBE
 #define FS2_ATTN_PROBE 0
 #endif
@@ -401,8 +402,11 @@ __device__ __forceinline__ void run_item(const AttnArgs& p, unsigned char* smem,
     }
     constexpr int kMaxPass = 64;
 
+    long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto stamp = [&](int i) { if (kProbe & 4096) stamps[i] = (long long)__builtin_amdgcn_s_memtime(); };
     // ---- passes over the item: one, unless a row's sums ran over kBound; bounded (NaN / inf scores never settle) ----
     for (int pass = 0; pass < kMaxPass; ++pass) {
+        stamp(0);
         __syncthreads();  // every wave is done with the previous item's / pass's tiles (and has read its flags)
         {   // fragment addresses back to the first slots
             const unsigned dk = kK0 - ks_cur;
@@ -437,6 +441,7 @@ __device__ __forceinline__ void run_item(const AttnArgs& p, unsigned char* smem,
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // Q and K(jb): everything but the two youngest tile DMAs (4 pieces each)
         if (jb + 1 >= je) dma_drain();                    // (only two tiles were issued: wait for both)
         __syncthreads();
+        stamp(1);
         const unsigned bits0 = tile_lo(jb);
         // the first pass takes the reference from the first half tile that holds a valid key: keys 0..31 of tile jb, or - masks
         // whose first 32 keys there are all padded - keys 32..63 (scored twice then: here for the max, again in the loop)
@@ -478,6 +483,7 @@ __device__ __forceinline__ void run_item(const AttnArgs& p, unsigned char* smem,
 #pragma unroll
         for (int u = 0; u < UH; ++u) unit(st.S0, st.P0, u);
 
+        stamp(2);
         // ---- main loop ----
         {
             int t = jb;
@@ -489,6 +495,7 @@ __device__ __forceinline__ void run_item(const AttnArgs& p, unsigned char* smem,
 
         // ---- normalise and store: lane (li, hi) owns query li, dv = nd*32 + 8g + 4hi + 0..3; the two halves of a row trade
         // 8-byte groups (v_permlane32_swap) so that every lane stores 16 contiguous bytes ----
+        stamp(3);
         if (ACC) asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");  // last P.V MFMAs -> O read
         bool more = false;
 #pragma unroll
@@ -523,6 +530,16 @@ __device__ __forceinline__ void run_item(const AttnArgs& p, unsigned char* smem,
         // does any row of the workgroup need another pass?  The waves trade a word each through a K slot nobody has read or
         // written since the barrier of the last tile (K(t+1)'s: the last tile has no next); the barrier at the top of the next
         // pass / item keeps the next DMA away from it until every wave has read
+        stamp(4);
+        if ((kProbe & 4096) && p.lse2 && blockIdx.x == 0 && wave == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            stamp(5);
+            if (lane == 0) {
+                float* o = p.lse2 + (size_t)p.B * p.heads * p.S + (size_t)(q0 / 128) * 8;   // one record per unit index of this workgroup's items
+                for (int i = 0; i < 6; ++i) o[i] = (float)(stamps[i] - stamps[0]);
+                o[6] = (float)NQB; o[7] = (float)(stamps[0] & 0xffffff);
+            }
+        }
         {
             int* flags = (int*)(smem + ks_nxt);
             const int wave_more = __any(more) ? 1 : 0;
