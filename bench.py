@@ -37,7 +37,7 @@ import torch.distributed as dist
 
 MFMA_PEAK = {"bf16": 2.5e15, "fp32": 157.3e12}  # dense, /opt/skills/guides/MI355X_MICROARCH.md
 HOP, SR = 256, 22050
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")  # regenerated every round: tools/pmc_traffic.sh
 
 
 def parse():
@@ -407,9 +407,11 @@ def main():
         traffic, traffic_src = None, None
         if os.path.exists(TRAFFIC_FILE) and args.config == "c2" and args.precision == "bf16" and args.batch == 32:
             try:
-                traffic = json.load(open(TRAFFIC_FILE)).get("conv_gemm_hbm_bytes_per_launch")
-                traffic_src = ("profiles/r02_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + --pmc WRITE_SIZE, "
-                               "separate passes over this launch shape (tools/pmc_traffic.sh), this round's kernel")
+                tj = json.load(open(TRAFFIC_FILE))
+                traffic = tj.get("conv_gemm_hbm_bytes_per_launch")
+                traffic_src = (f"profiles/{os.path.basename(TRAFFIC_FILE)}: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + --pmc WRITE_SIZE, "
+                               "separate passes over this launch shape (tools/pmc_traffic.sh); kernel source at commit "
+                               f"{tj.get('kernel_commit', '?')} (git log -1 -- csrc/gemm_mfma.hip), measured at {tj.get('measured_at_commit', '?')}")
             except Exception:
                 traffic = None
         line = {

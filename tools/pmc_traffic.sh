@@ -2,7 +2,8 @@
 # tools/pmc_traffic.sh : HBM-side traffic of the decoder conv1 launch (bench.py's roofline.traffic).
 # Two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over tools/bench_ops.py gemm --only "dec conv1";
 # FETCH_SIZE is doubled (gfx950 counts 128-byte requests at 64 B, MI355X_MICROARCH.md HBM note); both are KiB.
-# Writes gpurun_out/pmc_traffic.json (copy to profiles/r02_pmc_traffic.json).
+# Writes gpurun_out/pmc_traffic.json (copy to profiles/rNN_pmc_traffic.json); KERNEL_COMMIT / HEAD_COMMIT (passed in from the
+# build container: the GPU box has no .git) key the numbers to the kernel source they were measured on.
 R=${GRAFT_REPO_ROOT:-$PWD}; OUT=$R/gpurun_out/pmc_t; mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
@@ -18,6 +19,7 @@ import json
 f=float(open("$R/gpurun_out/pmc_FETCH_SIZE.txt").read()); w=float(open("$R/gpurun_out/pmc_WRITE_SIZE.txt").read())
 d={"kernel":"gemm_conv_slab_kernel<bf16,bf16,8,false> decoder conv1 (M=49152,N=1024,K=2304)","FETCH_SIZE_KiB_per_launch":f,"WRITE_SIZE_KiB_per_launch":w,
    "fetch_bytes_corrected_x2":f*1024*2,"write_bytes":w*1024,"conv_gemm_hbm_bytes_per_launch":f*1024*2+w*1024,"algorithmic_bytes_per_launch":130547712,
+   "kernel_commit":"${KERNEL_COMMIT:-unknown}","measured_at_commit":"${HEAD_COMMIT:-unknown}",
    "note":"tools/pmc_traffic.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over tools/bench_ops.py gemm --only 'dec conv1' (mean of the 3 timed launches); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B requests at 64 B); L2<->fabric traffic, Infinity-Cache hits included"}
 json.dump(d,open("$R/gpurun_out/pmc_traffic.json","w"),indent=1); print(d)
 PY
