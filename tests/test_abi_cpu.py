@@ -58,8 +58,12 @@ def test_create_validates_config(lib):
 
 def test_recipe_with_five_priors_fits_the_abi(lib):
     # scripts/train.sh:27,49 of the reference: four variances, five priors
-    cfg = Fs2Config(variances=["pitch", "energy", "snr", "srmr"], variance_levels=["frame"] * 4, variance_transforms=["none"] * 4,
-                    variance_nlayers=[5] * 4, variance_kernel_size=[3] * 4, priors=["energy", "duration", "snr", "pitch", "srmr"],
+    names = ["pitch", "energy", "snr", "srmr"]
+    priors = ["energy", "duration", "snr", "pitch", "srmr"]
+    stats = {v: {"min": -3.0, "max": 3.0, "mean": 0.0, "std": 1.0} for v in names}
+    stats.update({f"{p}_prior": {"min": -2.0, "max": 2.0, "mean": 0.0, "std": 1.0} for p in priors})
+    cfg = Fs2Config(variances=names, variance_levels=["frame"] * 4, variance_transforms=["none"] * 4,
+                    variance_nlayers=[5] * 4, variance_kernel_size=[3] * 4, priors=priors, stats=stats,
                     decoder_layers=6, decoder_kernel_sizes=[9] * 6, duration_nlayers=5,
                     encoder_depthwise_conv=False, decoder_depthwise_conv=False)
     st, h = _create(lib, cfg, _lib.FS2_BF16)
