@@ -240,6 +240,14 @@ int fs2_op_gemm_ln(int32_t dtype, const void* x, const void* w, const float* bia
                    const float* ln_g, const float* ln_b, const float* dot_w, float dot_b, const uint8_t* mask,
                    float* pred, void* y, void* tmp, int32_t M, int32_t N, int32_t Cin, int32_t taps, int32_t S,
                    int32_t relu, void* hip_stream);
+/* The same fused launch for the training tape: y = LayerNorm(z) * g + b with z = act(x W^T + bias) [+ res], and z itself stored
+ * too (z_out, (M, N), the activation dtype) - what LayerNorm's backward needs (the forward of ConformerEncoderLayer's
+ * x = norm(x + sublayer(x)), model.py:114-115, and of a predictor layer's conv -> ReLU -> LayerNorm, model.py:528-538, without a
+ * stand-alone LayerNorm launch).  FS2_ERR_SHAPE (nothing launched) where the epilogue does not apply (N > 256, shapes the slab
+ * kernel does not take): the caller keeps its GEMM + LayerNorm launches. */
+int fs2_op_gemm_ln_tape(int32_t dtype, const void* x, const void* w, const float* bias, const void* res, const float* ln_g,
+                        const float* ln_b, void* y, void* z_out, int32_t M, int32_t N, int32_t Cin, int32_t taps, int32_t S,
+                        int32_t relu, void* hip_stream);
 size_t fs2_op_attention_scratch_bytes(int32_t dtype, int32_t B, int32_t S, int32_t H, int32_t heads, size_t* bits_bytes);
 int fs2_op_layernorm(int32_t dtype, const void* x, const void* res, const float* gamma, const float* beta, void* y,
                      const float* dot_w, float dot_b, const uint8_t* mask, float* pred, int32_t M, int32_t H,

@@ -144,6 +144,7 @@ def load():
     lib.fs2_op_set_vocoder_fused_resblock.argtypes = [i32]
     lib.fs2_op_gemm.argtypes = [i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.fs2_op_gemm_gated.argtypes = [i32, vp, vp, vp, vp, C.c_float, vp, i32, i32, i32, i32, i32, vp]
+    lib.fs2_op_gemm_ln_tape.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.fs2_op_gemm_ln.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.fs2_op_attention_scratch_bytes.restype = C.c_size_t
     lib.fs2_op_attention_scratch_bytes.argtypes = [i32, i32, i32, i32, i32, C.POINTER(C.c_size_t)]

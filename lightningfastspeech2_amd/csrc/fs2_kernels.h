@@ -30,6 +30,8 @@ struct GemmArgs {
     const uint8_t* mask = nullptr;  // (M) 1 = pad
     float* pred = nullptr;          // (M)
     void* ln_tmp = nullptr;         // (M, ldc) scratch for the unfused fallback
+    void* z_out = nullptr;          // (M, ldc), C's dtype: the fused epilogue also stores the PRE-norm rows act(acc + bias) [+ res] (the
+                                    // training tape: LayerNorm's backward needs them); slab kernel only, null otherwise
     int xcd_remap = 0;              // set by the launcher
     // Deferred-LayerNorm epilogue of the slab kernel (no ln_g): C = v = act(acc + bias) + res, and per row the partial
     // sums (sum v, sum v^2) of every 64-column wave slice -> stats_out (M, ceil(N/256)*4) float2.  epi_res_stats != null:

@@ -799,6 +799,34 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
                 }
             }
         }
+        if (p.z_out) {  // training tape: the pre-norm rows, in the output dtype, 8 consecutive channels per store
+            OutT* __restrict__ Zn = (OutT*)p.z_out + rowbase * p.ldc;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int t = t0 + wm * (MI * 16) + mi * 16 + fr;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int n = wn * 64 + j * 32 + fg * 8;
+                    if (t < S && n < p.N) {
+                        OutT* dst = Zn + (size_t)t * p.ldc + n;
+                        const f32x4_t a0 = acc[2 * j][mi], a1 = acc[2 * j + 1][mi];
+                        if (n + 7 < p.N) {
+                            if constexpr (sizeof(OutT) == 4) {
+                                *(float4*)dst = make_float4(a0[0], a0[1], a0[2], a0[3]);
+                                *(float4*)(dst + 4) = make_float4(a1[0], a1[1], a1[2], a1[3]);
+                            } else {
+                                *(uint4*)dst = make_uint4(pack_bf16x2(a0[0], a0[1]), pack_bf16x2(a0[2], a0[3]),
+                                                          pack_bf16x2(a1[0], a1[1]), pack_bf16x2(a1[2], a1[3]));
+                            }
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 8; ++r)
+                                if (n + r < p.N) dst[r] = Num<OutT>::from_f32(r < 4 ? a0[r] : a1[r - 4]);
+                        }
+                    }
+                }
+            }
+        }
         __syncthreads();  // every wave is done with the operand buffers: reuse them for the exchange
         float* red = (float*)slab0;  // [4 column waves][BMs rows]
         float* lnp = (float*)wt0;    // [gamma 256 | beta 256 | head weight 256]
@@ -1188,10 +1216,12 @@ int launch_gemm(const GemmArgs& a, int in_dtype, int out_dtype, hipStream_t stre
     // fused row epilogue requested: try the slab kernel (whole rows per workgroup), else GEMM -> ln_tmp
     // followed by the stand-alone LayerNorm kernel (same arithmetic, one more HBM round trip)
     bool fused = false;
+    if (a.z_out && a.N > S_BN) return FS2_ERR_SHAPE;  // the pre-norm store exists in the one-column-tile epilogue only
     if ((a.N <= S_BN || (g_wide_ln && a.N <= 1024 && (a.C || a.ln_tmp))) && in_dtype == out_dtype) {
         const int r = launch_gemm_plain(a, in_dtype, out_dtype, stream, &fused);
         if (r != FS2_OK || fused) return r;
     }
+    if (a.z_out) return FS2_ERR_SHAPE;  // not fusable for this shape: the caller takes its two-launch path (nothing was launched)
     if (!a.ln_tmp || in_dtype != out_dtype) return FS2_ERR_ARG;
     GemmArgs g = a;
     g.ln_g = nullptr;

@@ -58,6 +58,7 @@ class _Ops:
         self._ws: Dict[str, torch.Tensor] = {}
         self.seed = 0       # dropout: set per micro-step by the trainer
         self._site = 0      # dropout site counter of the current forward
+        self.fuse_ln = os.environ.get("FS2_TRAIN_FUSE_LN", "1") != "0"  # A/B switch: GEMM + LayerNorm as one launch where it applies
 
     def site(self):
         self._site += 1
@@ -108,6 +109,19 @@ class _Ops:
         self.ck(self.lib.fs2_op_gemm(self.dt, F32 if out_f32 else self.dt, _p(x), _p(w), _p(bias), _p(y), M, N, Cin, taps, S or M,
                                      int(relu), self.st()), "gemm")
         return y
+
+    def gemm_ln_tape(self, x, w, bias, res, g, b, M, N, Cin, taps=1, S=None, relu=False):
+        """y = LayerNorm(z), z = act(x W^T + bias) [+ res], both stored, in ONE launch (the inference engine's fused GEMM +
+        LayerNorm epilogue with a pre-norm store); None where that epilogue does not apply (N > 256, odd shapes, knob off)."""
+        if not self.fuse_ln or N > 256:
+            return None
+        y, z = self.act(M, N), self.act(M, N)
+        st_ = self.lib.fs2_op_gemm_ln_tape(self.dt, _p(x), _p(w), _p(bias), _p(res), _p(g), _p(b), _p(y), _p(z), M, N, Cin, taps,
+                                           S or M, int(relu), self.st())
+        if st_ == _lib.FS2_ERR_SHAPE:
+            return None
+        self.ck(st_, "gemm_ln_tape")
+        return y, z
 
     def layernorm(self, x, res, g, b, M, H, dot_w=None, dot_b=0.0, mask=None, want_y=True):
         y = self.act(M, H) if want_y else None
@@ -487,17 +501,32 @@ class Trainer:
             prob_d = o.dropout(prob, pd, t["k_attn"], out=o.act(B, heads, S, S)) if pd > 0 else prob  # MHA drops attention weights
             o.bgemm(prob_d, qkv[:, 2 * H:], attn, M=S, N=d, K=S, sAm=S, sAk=1, sBk=3 * H, sBn=1, ldc=H, nb1=B, nb2=heads,
                     sA1=heads * S * S, sA2=S * S, sB1=S * 3 * H, sB2=d, sC1=S * H, sC2=d)
-        proj = o.dropout(o.gemm(attn, W[f"{prefix}.self_attn.out_proj.weight"], P[f"{prefix}.self_attn.out_proj.bias"], M, H, H),
-                         pd, t["k_sa"])  # dropout1
-        x1, _ = o.layernorm(proj, x, P[f"{prefix}.norm1.weight"], P[f"{prefix}.norm1.bias"], M, H)
+        # without dropout the out-projection, the residual add and norm1 are ONE launch that also leaves the pre-norm sum for the
+        # tape (t["proj"] then holds x + proj and the backward's LayerNorm takes no separate residual)
+        f1 = o.gemm_ln_tape(attn, W[f"{prefix}.self_attn.out_proj.weight"], P[f"{prefix}.self_attn.out_proj.bias"], x,
+                            P[f"{prefix}.norm1.weight"], P[f"{prefix}.norm1.bias"], M, H, H) if pd <= 0 else None
+        if f1 is not None:
+            x1, proj = f1
+        else:
+            proj = o.dropout(o.gemm(attn, W[f"{prefix}.self_attn.out_proj.weight"], P[f"{prefix}.self_attn.out_proj.bias"], M, H, H),
+                             pd, t["k_sa"])  # dropout1
+            x1, _ = o.layernorm(proj, x, P[f"{prefix}.norm1.weight"], P[f"{prefix}.norm1.bias"], M, H)
+        t["sum1"] = f1 is not None
         if prefix in self.fold:  # depth-wise FFN (model.py:73-93): dw(k) -> pw H->F -> ReLU -> [grouped 1x1 . pw F->H] folded
             t["u"] = o.dwconv(x1, P[f"{prefix}.conv1.0.weight"], P[f"{prefix}.conv1.0.bias"], B, S, H, k)
             h = o.dropout(o.gemm(t["u"], W[f"{prefix}.conv1.1.weight"], P[f"{prefix}.conv1.1.bias"], M, F_, H, relu=True), pd, t["k_h"])
             c2 = o.dropout(o.gemm(h, self.fold[prefix]["Wf"], self.fold[prefix]["bf"], M, H, F_), pd, t["k_ff"])
         else:
             h = o.dropout(o.gemm(x1, W[f"{prefix}.conv1.weight"], P[f"{prefix}.conv1.bias"], M, F_, H, taps=k, S=S, relu=True), pd, t["k_h"])
-            c2 = o.dropout(o.gemm(h, W[f"{prefix}.conv2.weight"], P[f"{prefix}.conv2.bias"], M, H, F_), pd, t["k_ff"])  # dropout2
-        x2, _ = o.layernorm(c2, x1, P[f"{prefix}.norm2.weight"], P[f"{prefix}.norm2.bias"], M, H)
+            f2 = o.gemm_ln_tape(h, W[f"{prefix}.conv2.weight"], P[f"{prefix}.conv2.bias"], x1, P[f"{prefix}.norm2.weight"],
+                                P[f"{prefix}.norm2.bias"], M, H, F_) if pd <= 0 else None
+            if f2 is not None:
+                x2, c2 = f2
+            else:
+                c2 = o.dropout(o.gemm(h, W[f"{prefix}.conv2.weight"], P[f"{prefix}.conv2.bias"], M, H, F_), pd, t["k_ff"])  # dropout2
+        t["sum2"] = prefix not in self.fold and f2 is not None
+        if not t["sum2"]:
+            x2, _ = o.layernorm(c2, x1, P[f"{prefix}.norm2.weight"], P[f"{prefix}.norm2.bias"], M, H)
         t.update(qkv=qkv, prob=prob, prob_d=prob_d, lse=lse, key_pad=key_pad, attn=attn, proj=proj, x1=x1, h=h, c2=c2, scale=scale)
         return x2, t
 
@@ -536,7 +565,7 @@ class Trainer:
         pd, folded = t["pd"], prefix in self.fold
         dbf = o.empty(H) if folded else None
         # x2 = LN2(x1 + dropout2(c2)): dz2 is the gradient of x1 (residual) and, through dropout2, of c2
-        dx1 = self._ln_bwd(t["c2"], t["x1"], dx2, f"{prefix}.norm2.weight", f"{prefix}.norm2.bias", M, H,
+        dx1 = self._ln_bwd(t["c2"], None if t["sum2"] else t["x1"], dx2, f"{prefix}.norm2.weight", f"{prefix}.norm2.bias", M, H,
                            bias_name=f"{prefix}.conv2.bias" if (pd <= 0 and not folded) else None,
                            bias_out=dbf if (pd <= 0 and folded) else None)
         dc2 = dx1
@@ -570,7 +599,7 @@ class Trainer:
             o.wgrad(dh, t["x1"], G[f"{prefix}.conv1.weight"], G[f"{prefix}.conv1.bias"], M, F_, H, taps=k, S=S)
             o.dgrad(dh, W[f"{prefix}.conv1.weight"], M, F_, H, taps=k, S=S, out=dx1, accumulate=True, wt=self._wt(f"{prefix}.conv1.weight"))
         # x1 = LN1(x + dropout1(proj))
-        dx = self._ln_bwd(t["proj"], t["x"], dx1, f"{prefix}.norm1.weight", f"{prefix}.norm1.bias", M, H,
+        dx = self._ln_bwd(t["proj"], None if t["sum1"] else t["x"], dx1, f"{prefix}.norm1.weight", f"{prefix}.norm1.bias", M, H,
                           bias_name=f"{prefix}.self_attn.out_proj.bias" if pd <= 0 else None)
         dproj = dx
         if pd > 0:
@@ -620,9 +649,18 @@ class Trainer:
             if dw:  # VarianceConvolutionLayer, depth-wise form (model.py:541-558): dw(k) -> pw 1x1 -> ReLU -> LN
                 u = o.dwconv(y, P[f"{p}.0.module.0.weight"], P[f"{p}.0.module.0.bias"], B, S, cin, k)
                 c = o.gemm(u, W[f"{p}.0.module.1.weight"], P[f"{p}.0.module.1.bias"], M, filt, cin, relu=True)
-            else:
-                c = o.gemm(y, W[f"{p}.0.module.weight"], P[f"{p}.0.module.bias"], M, filt, cin, taps=k, S=S, relu=True)
             last = j == nlayers - 1
+            fl = None
+            if not dw and pd <= 0 and not last:  # conv -> ReLU -> LayerNorm in one launch, the ReLU output kept for the tape
+                fl = o.gemm_ln_tape(y, W[f"{p}.0.module.weight"], P[f"{p}.0.module.bias"], None, P[f"{p}.2.weight"], P[f"{p}.2.bias"],
+                                    M, filt, cin, taps=k, S=S, relu=True)
+            if fl is not None:
+                yn, c = fl
+                tape.append({"xin": y, "c": c, "cin": cin, "u": None, "kd": o.site()})
+                y, cin = yn, filt
+                continue
+            if not dw:
+                c = o.gemm(y, W[f"{p}.0.module.weight"], P[f"{p}.0.module.bias"], M, filt, cin, taps=k, S=S, relu=True)
             fused_head = last and pd <= 0
             kd = None
             if pd > 0:  # VarianceConvolutionLayer ends in nn.Dropout (model.py:539,557): inside the LayerNorm launch
