@@ -373,6 +373,15 @@ def main():
     torch.cuda.synchronize()
     prof = model.engine.profile_read(kcls)
     model.engine.profile_enable(kcls, False)
+    # the north star's attention figure (BASELINE.json: ">= 40 % of the bf16 MFMA roofline" on the attention GEMMs): the decoder
+    # stack's self-attention launches - the MFMA-bound instance (4 B T^2 H flops, AI = T / 2) - timed the same way, own pass
+    model.engine.profile_reserve(_lib.K_DEC_ATTENTION, psteps * cfg.decoder_layers + 16)
+    model.engine.profile_enable(_lib.K_DEC_ATTENTION, True)
+    for _ in range(psteps):
+        model(batch, inference=True)
+    torch.cuda.synchronize()
+    prof_att = model.engine.profile_read(_lib.K_DEC_ATTENTION)
+    model.engine.profile_enable(_lib.K_DEC_ATTENTION, False)
     # GPU time of one forward = the sum over every launch class (conv GEMMs, GEMMs, attention, row kernels) of the HIP-event
     # intervals around its launches, in a pass of its own (eager; the dominant class is a subset of the conv / GEMM class)
     all_cls = [_lib.K_CONV_GEMM, _lib.K_GEMM, _lib.K_ATTENTION, _lib.K_ROWOPS]
@@ -414,6 +423,9 @@ def main():
                                f"{tj.get('kernel_commit', '?')} (git log -1 -- csrc/gemm_mfma.hip), measured at {tj.get('measured_at_commit', '?')}")
             except Exception:
                 traffic = None
+        na = max(prof_att["launches"], 1)
+        att_s = prof_att["ms"] / na * 1e-3
+        att_tf = (prof_att["flops"] / na) / att_s / 1e12 if att_s > 0 else 0.0
         line = {
             "metric": "mel-frames/sec (whole node), 256-phoneme batch-32",
             "value": value, "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -440,6 +452,13 @@ def main():
                          "flops_per_launch": prof["flops"] / n,
                          "measured": f"HIP events on the launch stream around every launch of this class in {psteps} eager steps of the same "
                                      "workload right behind the timed region (the timed steps replay hipGraphs, which hold no event records)"},
+            "north_star_attention": {
+                "kernel": f"decoder self-attention (QK^T, softmax, PV fused): {args.batch * cfg.decoder_head} x {T} queries x {T} keys, head dim "
+                          f"{cfg.hidden // cfg.decoder_head}; attention_pipe_kernel where it applies (bf16, head dim 128)",
+                "achieved": att_tf, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": att_tf * 1e12 / peak,
+                "avg_launch_us": att_s * 1e6, "launches_timed": prof_att["launches"], "flops_per_launch": prof_att["flops"] / na,
+                "what": "BASELINE.json north_star: >= 40 % of the bf16 MFMA roofline on the attention GEMMs; the encoder's instance "
+                        "(256 keys) is ingest-bound (DESIGN 4), this is the MFMA-bound one; HIP events, own pass of eager steps"},
             "gpu_ms_per_step": gpu_ms,
             "gpu_ms_per_step_is": f"sum of HIP-event intervals around every kernel launch of a forward, {psteps} eager steps behind the timed region",
             "launch_mode": {"timed_region": pick, "warmup_ms_per_step": {k: round(v, 4) for k, v in tune.items()},

@@ -593,6 +593,7 @@ int conformer(fs2_engine* e, hipStream_t st, const LayerW& w, void* x, void* tmp
     }
     {
         Bracket br(e, FS2_K_ATTENTION, st, 4.0 * B * (double)S * S * H, 4.0 * M * H * dsz);
+        Bracket br2(e, FS2_K_DEC_ATTENTION, st, 4.0 * B * (double)S * S * H, 4.0 * M * H * dsz, is_decoder);
         const int r = launch_attention(a, dt, st);
         if (r != FS2_OK) return fail(e, r, "attention launch failed");
     }
