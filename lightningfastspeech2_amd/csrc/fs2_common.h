@@ -127,15 +127,40 @@ __device__ inline float group4_sum(float x) {
 #endif
 }
 
-__device__ inline float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Whole-wave reductions without LDS round trips: four DPP steps inside each row of 16 lanes (xor 1, xor 2, half-row mirror,
+// row mirror), then the four rows through v_permlane16_swap / v_permlane32_swap.  (r03: the __shfl_xor butterfly these
+// replace compiles to six dependent ds_bpermute round trips per reduction; the row kernels built on it - LayerNorm forward /
+// backward, softmax, row dots - spent their time in that chain, not on memory: with four rows in flight per wave and a
+// quarter of the waves they got SLOWER.)  Every lane receives the result.
+__device__ inline float row16_sum(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x141, 0xf, 0xf, false));  // row_half_mirror
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x140, 0xf, 0xf, false));  // row_mirror
+#endif
     return v;
 }
-__device__ inline float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+__device__ inline float row16_max(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    v = fmaxf(v, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0xB1, 0xf, 0xf, false)));
+    v = fmaxf(v, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x4E, 0xf, 0xf, false)));
+    v = fmaxf(v, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x141, 0xf, 0xf, false)));
+    v = fmaxf(v, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x140, 0xf, 0xf, false)));
+#endif
     return v;
+}
+__device__ inline float wave_sum(float v) { return group4_sum(row16_sum(v)); }
+__device__ inline float wave_max(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    v = row16_max(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    const float s = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+#else
+    return v;
+#endif
 }
 
 // ---- MFMA wrappers: one "16-byte K chunk per lane" step -------------------------------------
