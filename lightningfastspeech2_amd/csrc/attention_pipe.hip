@@ -512,6 +512,8 @@ __device__ __forceinline__ void run_item(const AttnArgs& p, unsigned char* smem,
                 if (p.lse2 && hi == 0) p.lse2[(size_t)bh * p.S + qrow[qb]] = st.mref[qb] + __builtin_amdgcn_logf(l);  // v_log_f32 = log2
             }
             bf16* dst = outp + (size_t)(b * p.S + (qrow[qb] < p.S ? qrow[qb] : 0)) * p.H + h * kD + hi * 8;
+            uint4 ov[8];  // all eight pieces first, then ONE predicated block of stores (a branch per store ends the scheduling region
+                          // sixteen times per block; staging the rows through LDS for whole-row stores measured no faster, r03)
 #pragma unroll
             for (int nd = 0; nd < 4; ++nd)
 #pragma unroll
@@ -522,8 +524,12 @@ __device__ __forceinline__ void run_item(const AttnArgs& p, unsigned char* smem,
                     const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
                     const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
                     // lower half: [own g | upper's g] = dv 8g .. 8g+7; upper half: [lower's g+1 | own g+1] = dv 8g+8 .. 8g+15
-                    if (mine) *(uint4*)(dst + nd * 32 + 8 * g) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+                    ov[nd * 2 + (g >> 1)] = make_uint4(r0[0], r1[0], r0[1], r1[1]);
                 }
+            if (mine) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) *(uint4*)(dst + (i >> 1) * 32 + 16 * (i & 1)) = ov[i];
+            }
             done[qb] = done[qb] || ok;
             more = more || !done[qb];
         }

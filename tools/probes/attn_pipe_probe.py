@@ -11,10 +11,10 @@ B, S, H, heads = [int(x) for x in os.environ.get("PROBE_SHAPE", "32,1536,256,2")
 qkv = (torch.randn(B * S, 3 * H, device="cuda")).to(torch.bfloat16)
 out = torch.empty(B * S, H, device="cuda", dtype=torch.bfloat16)
 bits = torch.full((B, (S + 63) // 64), -1, dtype=torch.int64, device="cuda")
-names = {1: "no exp/sum/pack", 2: "no overflow check", 4: "no fragment reads", 8: "no DMA", 16: "no QK MFMA", 32: "no PV MFMA", 64: "(full kernel)", 128: "32-query items only", 256: "no tile barrier", 512: "no mask test"}
+names = {1: "no exp/sum/pack", 2: "no overflow check", 4: "no fragment reads", 8: "no DMA", 16: "no QK MFMA", 32: "no PV MFMA", 64: "(full kernel)", 128: "32-query items only", 256: "no tile barrier", 512: "no mask test", 8192: "direct O stores (no LDS staging)"}
 for pb in probes:
     so = f"/tmp/attn_probe_{pb}.so"
-    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", f"-DFS2_ATTN_PROBE={pb & 4095}", f"-DFS2_ATTN_FQ={((pb >> 12) & 15) or 6}",
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", f"-DFS2_ATTN_PROBE={pb & 16383}", 
                     f"-I{R}/lightningfastspeech2_amd/csrc", f"-I{R}/include", "-o", so, src], check=True, stderr=subprocess.DEVNULL)
     lib = C.CDLL(so)
     lib.attn_pipe_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
