@@ -551,3 +551,35 @@ def test_slab_gemm_bits_do_not_depend_on_tile_height():
             assert torch.equal(outs[0], o), (K, N, taps, ln, relu)
         for q in preds[1:]:
             assert torch.equal(preds[0], q), (K, N, taps, "head")
+
+
+def test_attention_pipelined_rerun_pass_in_64_query_items():
+    """The rare path of the pipelined kernel at the size where workgroups run 256-query items (64 queries per wave, O in the
+    accumulator file): scores far above a row's reference (the max over its first 32 keys) - one row beyond 2^100 (its item
+    runs a second pass for that row alone), several rows by 2^20 .. 2^60 (no second pass: bf16 P keeps its 8 bits at any scale) -
+    next to ragged key masks; every row against the fp32 reference, and the other rows of the same item bit-equal to a launch
+    without the spike (a row's bits may not depend on its neighbours)."""
+    B, S, H, heads = 16, 1536, 256, 2
+    qkv = rnd(B * S, 3 * H, seed=21)
+    mask = torch.zeros(B, S, dtype=torch.bool)
+    for b in range(B):
+        mask[b, S - 37 * b:] = True
+    clean = G.attention(G.BF16, qkv, mask, B, S, H, heads)
+    spiked = qkv.clone()
+    u = 3 * S                                               # utterance 3
+    spiked[u + 700, H:H + 128] = 8.0 * qkv[u + 300, :128]   # key 700, head 0: ~130 log2 units above query 300's other scores
+    spiked[u + 900, H + 128:H + 256] = 2.5 * qkv[u + 1000, 128:256]  # head 1: ~40 log2 units for query 1000
+    ref = _attn_ref(G.rounded(spiked, G.BF16), mask, B, S, H, heads)
+    got = G.attention(G.BF16, spiked, mask, B, S, H, heads)
+    assert torch.isfinite(got).all()
+    assert float((got - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+    # utterances other than 3 see the same inputs: bit-equal; inside utterance 3 only rows whose own scores changed may differ
+    other = torch.ones(B * S, dtype=torch.bool)
+    other[u:u + S] = False
+    assert torch.equal(got[other], clean[other])
+    G.lib().fs2_op_set_gemm_variant(1201)                   # 32 queries per wave: the same rows, bit for bit
+    try:
+        small = G.attention(G.BF16, spiked, mask, B, S, H, heads)
+    finally:
+        G.lib().fs2_op_set_gemm_variant(1203)
+    assert torch.equal(got, small)
