@@ -102,16 +102,18 @@ struct PipeState {
     f32x16_t oacc[NQB][4];       // O^T: dv block nd, lane = query
     uint32_t P0[NQB][8], P1[NQB][8];  // P of the two half tiles in flight, bf16 pairs: words 0-3 = 16-key chunk 0, 4-7 = chunk 1
     float lsum[NQB][2];          // this lane's share of the denominator (its 16 keys of every 32), two chains
-    float mref[NQB];             // the reference the exponentials refer to: the row max over the first 32 valid keys
+    float mref[NQB];             // the reference the exponentials refer to: 0 in the first pass
     float mnext[NQB];            // a row whose sums ran over: the reference its next pass starts from
 };
 
-// No running max: p = exp2(s - reference) with the reference fixed at the row max of the first half tile.  bf16 keeps its 8
-// bits at any scale and O / the denominator accumulate in fp32, so a score above the reference costs no accuracy - only a row
-// whose denominator leaves [.., kBound] (a score ~100 log2 units = 69 nats above its reference, inf, NaN) is wrong, and that row
-// alone runs again from a higher reference (the pass loop in run_item).  The per-element max, the rescale decision and its branch
-// were a fifth of the loop's issue slots and the only VALU use of the output accumulators.
-constexpr float kBound = 0x1p100f;
+// No running max, and in the first pass no reference at all: p = exp2(s) with s the scaled score in log2 units (reference 0).
+// bf16 keeps its 8 bits at any scale and O / the denominator accumulate in fp32, so the scale of a row's scores costs no accuracy
+// - only a row whose denominator leaves [kLow, kBound] (scores beyond +-100 log2 units = 69 nats, inf, NaN) is wrong, and that row
+// alone runs again from the reference log2(denominator) (the pass loop in run_item), which then rides in the C operand of the first
+// MFMA of every chain.  The per-element max, the rescale decision and its branch were a fifth of the loop's issue slots and the
+// only VALU use of the output accumulators; the first half tile's row max (the first version's reference) was ~1.5 k unhidden
+// cycles per item.
+constexpr float kBound = 0x1p100f, kLow = 0x1p-100f;
 
 template <int NQB, bool ACC>
 __device__ __forceinline__ void run_item(const AttnArgs& p, unsigned char* smem, int bh, int q0, int wave, int lane) {
@@ -436,19 +438,14 @@ __device__ __forceinline__ void run_item(const AttnArgs& p, unsigned char* smem,
             st.lsum[qb][0] = st.lsum[qb][1] = 0.f;
         }
 
-        // ---- prologue: scores of the first half tile of tile jb (nothing to overlap with); in the first pass their row max
-        // becomes the row's reference; the first half of their units ----
+        // ---- prologue: scores of the first half tile of tile jb, the first half of their units ----
         asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // Q and K(jb): everything but the two youngest tile DMAs (4 pieces each)
         if (jb + 1 >= je) dma_drain();                    // (only two tiles were issued: wait for both)
         __syncthreads();
         stamp(1);
-        const unsigned bits0 = tile_lo(jb);
-        // the first pass takes the reference from the first half tile that holds a valid key: keys 0..31 of tile jb, or - masks
-        // whose first 32 keys there are all padded - keys 32..63 (scored twice then: here for the max, again in the loop)
-        const int nscore = (pass == 0 && bits0 == 0u) ? 2 : 1;
-        for (int sc = nscore - 1; sc >= 0; --sc) {   // sc = 1: block 1 for its max only; sc = 0: block 0, the scores the loop continues from
+        {   // scores of the first half tile (block 0 of tile jb): nothing to overlap with
 #pragma unroll
-            for (int c = 0; c < 4; ++c) kf[c] = kload(sc, c);
+            for (int c = 0; c < 4; ++c) kf[c] = kload(0, c);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
 #pragma unroll
@@ -457,28 +454,12 @@ __device__ __forceinline__ void run_item(const AttnArgs& p, unsigned char* smem,
                     else mma_qk<ACC>(st.S0[qb], kf[i & 3], qf[qb][i]);
                 }
                 // this block's fragments 4..7, then block 1's 0..3 for the first phase C
-                kf[i & 3] = kload(i < 4 ? sc : 1, i < 4 ? i + 4 : i - 4);
+                kf[i & 3] = kload(i < 4 ? 0 : 1, i < 4 ? i + 4 : i - 4);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (ACC) asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");  // MFMA D -> VALU read (prologue only)
-            const unsigned bits = sc == 0 ? bits0 : tile_hi(jb);
+            const unsigned bits = tile_lo(jb);
             if (bits != 0xffffffffu) mask_half(st.S0, bits);
-            if (pass == 0 && bits != 0u) {  // a valid key in this half tile: every row has a finite max
-#pragma unroll
-                for (int qb = 0; qb < NQB; ++qb) {
-                    float mx = st.S0[qb][0];
-#pragma unroll
-                    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, st.S0[qb][r]);
-                    mx = xhalf_max(mx);
-                    st.mref[qb] = mx;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        st.S0[qb][r] -= mx;
-                        st.minit[qb][r] = -mx;
-                    }
-                    if (ACC) asm volatile("s_nop 3" : "+v"(st.minit[qb]));
-                }
-            }
         }
 #pragma unroll
         for (int u = 0; u < UH; ++u) unit(st.S0, st.P0, u);
@@ -502,10 +483,11 @@ __device__ __forceinline__ void run_item(const AttnArgs& p, unsigned char* smem,
         for (int qb = 0; qb < NQB; ++qb) {
             const float l = xhalf_sum(st.lsum[qb][0] + st.lsum[qb][1]);
             const float inv = 1.f / l;
-            const bool ok = l <= kBound;  // false for inf and NaN too
+            const bool ok = l <= kBound && l >= kLow;  // false for inf and NaN too
             const bool mine = qrow[qb] < p.S && !done[qb] && (ok || pass == kMaxPass - 1);
-            // a row that ran over starts again from about its largest score: log2(l) is within log2(S) of (max - reference)
-            st.mnext[qb] = st.mref[qb] + (l < INFINITY ? __builtin_amdgcn_logf(l) : 100.f);
+            // a row that ran over (under) starts again from about its largest score: log2(l) is within log2(S) of (max - reference);
+            // an infinite (zero) denominator moves the reference by a fixed +-100 and tries again
+            st.mnext[qb] = st.mref[qb] + (l < INFINITY ? (l > 0.f ? __builtin_amdgcn_logf(l) : -100.f) : 100.f);
             if ((kProbe & 1024) && p.lse2 && hi == 0 && qrow[qb] < p.S)  // debug dump: one record per (row, pass)
                 ((float4*)p.lse2)[(size_t)qrow[qb] * 4 + (pass < 4 ? pass : 3)] = make_float4(l, st.mref[qb], ok ? 1.f : 0.f, (mine ? 1.f : 0.f) + (done[qb] ? 2.f : 0.f) + 10.f * pass);
             if (mine) {

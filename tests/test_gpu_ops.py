@@ -583,3 +583,26 @@ def test_attention_pipelined_rerun_pass_in_64_query_items():
     finally:
         G.lib().fs2_op_set_gemm_variant(1203)
     assert torch.equal(got, small)
+
+
+@pytest.mark.parametrize("pipe_kernel", [1, 2], indirect=True)
+def test_attention_pipelined_rows_far_below_and_above_zero(pipe_kernel):
+    """The first pass of the pipelined kernel exponentiates the scaled scores as they are (reference 0).  Rows whose scores all lie
+    ~160 log2 units BELOW zero (denominator underflows) and rows ~160 above (overflows) rerun from the reference log2(denominator);
+    rows in between do not.  All against the fp32 reference."""
+    B, S, H, heads = 1, 512, 128, 1
+    qkv = rnd(B * S, 3 * H, seed=31)
+    q = qkv[:, :H].clone()
+    qkv[:, H:2 * H] *= 0.3
+    # every key gets a large component along -q7 (query 7 sees all its scores ~ -160 log2) and along +q9 (query 9: ~ +160)
+    d7, d9 = q[7] / q[7].norm(), q[9] / q[9].norm()
+    qkv[:, H:2 * H] += (-1250.0 / float(q[7].norm())) * d7 + (1250.0 / float(q[9].norm())) * d9
+    mask = torch.zeros(B, S, dtype=torch.bool)
+    mask[0, S - 50:] = True
+    x = G.rounded(qkv, G.BF16)
+    ref = _attn_ref(x, mask, B, S, H, heads)
+    sc = (x[:, :H] @ x[:, H:2 * H].T) * (1.4426950408889634 / H ** 0.5)
+    assert float(sc[7, :S - 50].max()) < -120 and float(sc[9, :S - 50].min()) > 120   # the test really is on both far sides
+    got = G.attention(G.BF16, qkv, mask, B, S, H, heads)
+    assert torch.isfinite(got).all()
+    assert float((got - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
