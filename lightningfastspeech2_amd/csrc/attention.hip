@@ -449,7 +449,7 @@ int launch_transpose_v(const AttnArgs& a, int dtype, hipStream_t stream) {
     return FS2_ERR_SHAPE;
 }
 
-int g_attn_pipe = 3;
+int g_attn_pipe = 3;  // 0: attention_kernel only; 1 / 2 / 4: the pipelined kernel with 32 / 64 / 96 queries per wave where it applies; 3: by size
 
 int launch_attention(const AttnArgs& a, int dtype, hipStream_t stream) {
     if (a.B <= 0 || a.S <= 0) return FS2_OK;
@@ -463,7 +463,10 @@ int launch_attention(const AttnArgs& a, int dtype, hipStream_t stream) {
         // below), two 4 x 32-query workgroups per CU under that.  Short sequences (the encoder's 256 phonemes) stay below.
         const long long per_utt = (long long)a.heads * ((a.S + 127) / 128), units = per_utt * a.B;
         if (g_attn_pipe == 1 || g_attn_pipe == 2) return launch_attention_pipe(a, g_attn_pipe, stream);
-        if (per_utt >= 16) return launch_attention_pipe(a, units >= 512 ? 2 : 1, stream);
+        if (g_attn_pipe == 4) return launch_attention_pipe(a, 3, stream);
+        // 96 queries per wave (384-query items) where a workgroup's run of units is whole items: three or more units per workgroup
+        // and a multiple of three per head (T = 1536: 12 units per head, 3 per workgroup at C2 / C5, 9 at C3)
+        if (per_utt >= 16) return launch_attention_pipe(a, units >= 768 && ((a.S + 127) / 128) % 3 == 0 ? 3 : (units >= 512 ? 2 : 1), stream);
     }
     const int d = a.H / a.heads;
 #define FS2_ATTN_CASE(DD)                                                        \

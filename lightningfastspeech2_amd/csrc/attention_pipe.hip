@@ -85,6 +85,17 @@ __device__ __forceinline__ void mma_qk(f32x16_t& d, const u32x4_t& k, const u32x
         d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(k), as_bf(q), d, 0, 0, 0);
     }
 }
+// 96 queries per wave (NQB = 3): no reference tuple at all (the chain starts from the inline constant 0), and the third block's Q
+// fragments come from LDS into arch VGPRs (the accumulator file holds O of three blocks and Q of two: 256 registers)
+__device__ __forceinline__ void mma_qk_first0(f32x16_t& d, const u32x4_t& k, const u32x4_t& q) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(k), "a"(q));
+}
+__device__ __forceinline__ void mma_qk_first0_v(f32x16_t& d, const u32x4_t& k, const u32x4_t& q) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(k), "v"(q));
+}
+__device__ __forceinline__ void mma_qk_v(f32x16_t& d, const u32x4_t& k, const u32x4_t& q) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d) : "v"(k), "v"(q));
+}
 template <bool ACC>
 __device__ __forceinline__ void mma_pv(f32x16_t& o, const u32x4_t& v, const u32x4_t& pw) {
     if constexpr (ACC) {
@@ -116,7 +127,9 @@ struct PipeState {
 constexpr float kBound = 0x1p100f, kLow = 0x1p-100f;
 
 template <int NQB, bool ACC>
-__device__ __forceinline__ void run_item(const AttnArgs& p, unsigned char* smem, int bh, int q0, int wave, int lane) {
+__device__ __forceinline__ bool run_item(const AttnArgs& p, unsigned char* smem, int bh, int q0, int wave, int lane) {
+    static_assert(NQB != 3 || ACC, "96 queries per wave need the whole register file");
+    constexpr int NQR = NQB == 3 ? 2 : NQB;  // query blocks whose Q fragments stay in registers
     const int li = lane & 31, hi = lane >> 5;
     const int b = bh / p.heads, h = bh - b * p.heads;
     const int ld = 3 * p.H;
@@ -148,7 +161,7 @@ __device__ __forceinline__ void run_item(const AttnArgs& p, unsigned char* smem,
                 for (int e = 0; e < 64; ++e) dst[e] = nanv;
                 if (p.lse2 && hi == 0) p.lse2[(size_t)bh * p.S + qrow[qb]] = __builtin_nanf("");
             }
-        return;
+        return false;
     }
 
     // smem: two V slots (0, 16 KiB), then three K slots (32, 48, 64 KiB)
@@ -219,7 +232,12 @@ __device__ __forceinline__ void run_item(const AttnArgs& p, unsigned char* smem,
     }
 
     PipeState<NQB> st;
-    u32x4_t qf[NQB][8];
+    u32x4_t qf[NQR][8];
+    // NQB = 3: the third block's eight fragments live in LDS behind the tile slots, lane-linear (a lane reads back exactly the 16
+    // bytes it wrote: 1 KiB per fragment and wave, conflict-free), and pass through a four-deep register ring
+    unsigned char* const q2base = smem + 5 * kTileB + wave * 8192 + lane * 16;
+    u32x4_t q2[4];
+    auto q2load = [&](int c) { return *(const u32x4_t*)(q2base + c * 1024); };
 #pragma unroll
     for (int qb = 0; qb < NQB; ++qb) {
 #pragma unroll
@@ -229,8 +247,12 @@ __device__ __forceinline__ void run_item(const AttnArgs& p, unsigned char* smem,
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] *= p.scale_log2e;
             const uint4 pk = Vec16<bf16>::pack(f);
-            qf[qb][c] = u32x4_t{pk.x, pk.y, pk.z, pk.w};
-            if (ACC) asm volatile("" : "+a"(qf[qb][c]));  // one 128-bit accumulator-file tuple from here on (else: four scalars + copies per use)
+            if (qb < NQR) {
+                qf[qb < NQR ? qb : 0][c] = u32x4_t{pk.x, pk.y, pk.z, pk.w};
+                if (ACC) asm volatile("" : "+a"(qf[qb < NQR ? qb : 0][c]));  // one 128-bit accumulator-file tuple from here on (else: four scalars + copies per use)
+            } else {
+                *(uint4*)(q2base + c * 1024) = pk;
+            }
         }
         st.mnext[qb] = 0.f;
     }
@@ -272,6 +294,20 @@ __device__ __forceinline__ void run_item(const AttnArgs& p, unsigned char* smem,
             for (int r = 0; r < 16; ++r)
                 if (!((w >> ((r & 3) + 8 * (r >> 2))) & 1u)) S[qb][r] = -INFINITY;
     };
+    auto qk_mma = [&](f32x16_t (&Sn)[NQB], int i, int qb) {  // chunk i of Q.K^T for query block qb; K fragment in the ring
+        if constexpr (NQB == 3) {
+            if (qb < 2) {
+                if (i == 0) mma_qk_first0(Sn[qb], kf[0], qf[qb < 2 ? qb : 0][0]);
+                else mma_qk<true>(Sn[qb], kf[i & 3], qf[qb < 2 ? qb : 0][i]);
+            } else {
+                if (i == 0) mma_qk_first0_v(Sn[qb], kf[0], q2[0]);
+                else mma_qk_v(Sn[qb], kf[i & 3], q2[i & 3]);
+            }
+        } else {
+            if (i == 0) mma_qk_first<ACC>(Sn[qb], kf[0], qf[qb < NQR ? qb : 0][0], st.minit[qb]);
+            else mma_qk<ACC>(Sn[qb], kf[i & 3], qf[qb < NQR ? qb : 0][i]);
+        }
+    };
     constexpr int G = 8 * NQB;      // MFMAs (= gaps) per phase
     constexpr int UH = 4 * NQB;     // units per half of a half tile's finishing
     // Q.K^T of the next half tile into Sn || second half of the units of Sc -> Pc || K ring refill (fragments 4..7 of block kb
@@ -282,12 +318,28 @@ __device__ __forceinline__ void run_item(const AttnArgs& p, unsigned char* smem,
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             const int i = g / NQB, qb = g % NQB;
-            if (decltype(DO_MMA)::value && !(kProbe & 16)) {
-                if (i == 0) mma_qk_first<ACC>(Sn[qb], kf[0], qf[qb][0], st.minit[qb]);
-                else mma_qk<ACC>(Sn[qb], kf[i & 3], qf[qb][i]);
-            }
+            if (decltype(DO_MMA)::value && !(kProbe & 16)) qk_mma(Sn, i, qb);
             if (g & 1) {
                 unit(Sc, Pc, UH + (g >> 1));
+            } else if (NQB == 3) {
+                // twelve even gaps: chunk j's last MFMA (block 2) is gap 3j + 2 - its K ring slot is refilled in the next even gap,
+                // its Q ring slot two gaps on; the ring's chunks 0, 1 were requested at the end of the P.V phase before
+                const int e = g >> 1;  // 0..11
+                constexpr bool mm = decltype(DO_MMA)::value;
+                if (!(kProbe & 4)) {
+                    if (mm && e == 0) q2[2] = q2load(2);
+                    if (mm && e == 1) kf[0] = kload(kb, 4);
+                    if (mm && e == 2) q2[3] = q2load(3);
+                    if (mm && e == 3) { kf[1] = kload(kb, 5); q2[0] = q2load(4); }
+                    if (mm && e == 4) { kf[2] = kload(kb, 6); q2[1] = q2load(5); }
+                    if (mm && e == 5) q2[2] = q2load(6);
+                    if (mm && e == 6) { kf[3] = kload(kb, 7); q2[3] = q2load(7); }
+                    if (e >= 7 && e <= 10) vf[e - 7] = vload(vch, e - 7);
+                }
+                if (e == 1) hook(0);
+                if (e == 2) hook(1);
+                if (e == 5) hook(2);
+                if (e == 7) hook(3);
             } else if (NQB == 2) {
                 const int e = g >> 1;  // 0..7
                 if (e == 0 && !(kProbe & 4)) vf[0] = vload(vch, 0);
@@ -325,6 +377,25 @@ __device__ __forceinline__ void run_item(const AttnArgs& p, unsigned char* smem,
                 // the scores these units read left the matrix pipe with the LAST MFMAs of the phase before; the first unit (query
                 // block 0) sits behind three later MFMAs, the second (block NQB - 1) behind four or more: asm statements keep order
                 if (decltype(DO_UNITS)::value) unit(Sn, Pn, g >> 1);
+            } else if (NQB == 3) {
+                const int e = g >> 1;  // 0..11; step j's MFMAs are gaps 3j .. 3j + 2: its V ring slot is refilled from gap 3j + 3 on
+                constexpr bool kl = decltype(DO_KLOAD)::value;
+                if (!(kProbe & 4)) {
+                    if (kl && e == 0) kf[0] = kload(kbn, 0);
+                    if (kl && e == 1) kf[1] = kload(kbn, 1);
+                    if (e == 2) vf[0] = vload(ch0 + 1, 0);
+                    if (e == 3) vf[1] = vload(ch0 + 1, 1);
+                    if (e == 5) vf[2] = vload(ch0 + 1, 2);
+                    if (e == 6) vf[3] = vload(ch0 + 1, 3);
+                    if (kl && e == 7) kf[2] = kload(kbn, 2);
+                    if (kl && e == 8) kf[3] = kload(kbn, 3);
+                    if (kl && e == 10) q2[0] = q2load(0);  // the coming Q.K^T phase's first two fragments of block 2
+                    if (kl && e == 11) q2[1] = q2load(1);
+                }
+                if (e == 0) hook(0);
+                if (e == 4) hook(1);
+                if (e == 7) hook(2);
+                if (e == 9) hook(3);
             } else if (NQB == 2) {
                 const int e = g >> 1;  // 0..7
                 if (e >= 1 && e <= 4 && !(kProbe & 4)) vf[e - 1] = vload(ch0 + 1, e - 1);
@@ -402,7 +473,7 @@ __device__ __forceinline__ void run_item(const AttnArgs& p, unsigned char* smem,
         const unsigned long long notfull = __ballot(myword != ~0ull) >> jb;
         nfull = notfull ? __builtin_ctzll(notfull) : 64 - jb;
     }
-    constexpr int kMaxPass = 64;
+    constexpr int kMaxPass = NQB == 3 ? 1 : 64;  // 96 queries per wave: one pass, the caller reruns the units on the paths that carry a reference
 
     long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     auto stamp = [&](int i) { if (kProbe & 4096) stamps[i] = (long long)__builtin_amdgcn_s_memtime(); };
@@ -446,15 +517,17 @@ __device__ __forceinline__ void run_item(const AttnArgs& p, unsigned char* smem,
         {   // scores of the first half tile (block 0 of tile jb): nothing to overlap with
 #pragma unroll
             for (int c = 0; c < 4; ++c) kf[c] = kload(0, c);
+            if (NQB == 3) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) q2[c] = q2load(c);
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
 #pragma unroll
-                for (int qb = 0; qb < NQB; ++qb) {
-                    if (i == 0) mma_qk_first<ACC>(st.S0[qb], kf[0], qf[qb][0], st.minit[qb]);
-                    else mma_qk<ACC>(st.S0[qb], kf[i & 3], qf[qb][i]);
-                }
+                for (int qb = 0; qb < NQB; ++qb) qk_mma(st.S0, i, qb);
                 // this block's fragments 4..7, then block 1's 0..3 for the first phase C
                 kf[i & 3] = kload(i < 4 ? 0 : 1, i < 4 ? i + 4 : i - 4);
+                if (NQB == 3) q2[i & 3] = q2load(i < 4 ? i + 4 : i - 4);  // chunks 4..7, then 0..3 again for phase C (its first two are used)
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (ACC) asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");  // MFMA D -> VALU read (prologue only)
@@ -484,7 +557,7 @@ __device__ __forceinline__ void run_item(const AttnArgs& p, unsigned char* smem,
             const float l = xhalf_sum(st.lsum[qb][0] + st.lsum[qb][1]);
             const float inv = 1.f / l;
             const bool ok = l <= kBound && l >= kLow;  // false for inf and NaN too
-            const bool mine = qrow[qb] < p.S && !done[qb] && (ok || pass == kMaxPass - 1);
+            const bool mine = qrow[qb] < p.S && !done[qb] && (ok || (NQB != 3 && pass == kMaxPass - 1));
             // a row that ran over (under) starts again from about its largest score: log2(l) is within log2(S) of (max - reference);
             // an infinite (zero) denominator moves the reference by a fixed +-100 and tries again
             st.mnext[qb] = st.mref[qb] + (l < INFINITY ? (l > 0.f ? __builtin_amdgcn_logf(l) : -100.f) : 100.f);
@@ -534,15 +607,18 @@ __device__ __forceinline__ void run_item(const AttnArgs& p, unsigned char* smem,
             if (lane == 0) flags[wave] = wave_more;
             __syncthreads();
             const int4 f = *(const int4*)flags;
-            if (!__builtin_amdgcn_readfirstlane(f.x | f.y | f.z | f.w)) break;
+            const int again = __builtin_amdgcn_readfirstlane(f.x | f.y | f.z | f.w);
+            if (NQB == 3) return again != 0;
+            if (!again) break;
         }
     }
+    return false;
 }
 
 template <int NQBMAX>
-__global__ __launch_bounds__(256, NQBMAX == 2 ? 1 : 2) void attention_pipe_kernel(AttnArgs p, int nu, int U) {
+__global__ __launch_bounds__(256, NQBMAX >= 2 ? 1 : 2) void attention_pipe_kernel(AttnArgs p, int nu, int U) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __shared__ __attribute__((aligned(32768))) unsigned char smem[5 * kTileB];
+    __shared__ __attribute__((aligned(32768))) unsigned char smem[5 * kTileB + (NQBMAX == 3 ? 32768 : 0)];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int G = gridDim.x;  // a multiple of 8: slot = XCD-major so that an XCD's workgroups own neighbouring units
@@ -551,11 +627,22 @@ __global__ __launch_bounds__(256, NQBMAX == 2 ? 1 : 2) void attention_pipe_kerne
     const int u1 = (int)((long long)(slot + 1) * U / G);
     while (u < u1) {
         const int bh = u / nu, uu = u - bh * nu;
-        if (NQBMAX == 2 && !(kProbe & 128) && uu + 2 <= nu && u + 2 <= u1) {
-            run_item<NQBMAX, true>(p, smem, bh, uu * 128, wave, lane);
+        if constexpr (NQBMAX == 3) {
+            if (!(kProbe & 128) && uu + 3 <= nu && u + 3 <= u1) {
+                // 384 queries, 96 per wave, one pass; a row outside the reference-free range sends the three units to the paths below
+                if (run_item<3, true>(p, smem, bh, uu * 128, wave, lane)) {
+                    run_item<2, true>(p, smem, bh, uu * 128, wave, lane);
+                    run_item<1, true>(p, smem, bh, (uu + 2) * 128, wave, lane);
+                }
+                u += 3;
+                continue;
+            }
+        }
+        if (NQBMAX >= 2 && !(kProbe & 128) && uu + 2 <= nu && u + 2 <= u1) {
+            run_item<2, true>(p, smem, bh, uu * 128, wave, lane);
             u += 2;
         } else {
-            run_item<1, NQBMAX == 2>(p, smem, bh, uu * 128, wave, lane);
+            run_item<1, NQBMAX >= 2>(p, smem, bh, uu * 128, wave, lane);
             u += 1;
         }
     }
@@ -575,7 +662,14 @@ int launch_attention_pipe(const AttnArgs& a, int variant, hipStream_t stream) {
     const int nu = (a.S + 127) / 128;
     const long long U = (long long)a.B * a.heads * nu;
     if (U > 0x7fffffffll) return FS2_ERR_SHAPE;
-    if (variant == 2) {
+    if (variant == 3) {
+        static bool attr = false;  // 112 KiB of static LDS: above the 64 KiB a kernel gets without asking
+        if (!attr) {
+            (void)hipFuncSetAttribute((const void*)attention_pipe_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 0);
+            attr = true;
+        }
+        hipLaunchKernelGGL((attention_pipe_kernel<3>), dim3(256), dim3(256), 0, stream, a, nu, (int)U);
+    } else if (variant == 2) {
         hipLaunchKernelGGL((attention_pipe_kernel<2>), dim3(256), dim3(256), 0, stream, a, nu, (int)U);
     } else {
         hipLaunchKernelGGL((attention_pipe_kernel<1>), dim3(512), dim3(256), 0, stream, a, nu, (int)U);

@@ -349,7 +349,7 @@ def _mask(kind, B, S):
     return mask
 
 
-@pytest.mark.parametrize("pipe_kernel", [1, 2], indirect=True)
+@pytest.mark.parametrize("pipe_kernel", [1, 2, 4], indirect=True)
 @pytest.mark.parametrize("B,S,H,heads,mask_kind", [
     (2, 200, 256, 2, "suffix"), (2, 64, 256, 2, "none"), (2, 257, 256, 2, "scatter"), (1, 700, 256, 2, "suffix"),
     (3, 130, 128, 1, "suffix"), (2, 33, 384, 3, "scatter"), (2, 300, 256, 2, "prefix"), (2, 450, 256, 2, "holes"),
@@ -367,13 +367,13 @@ def test_attention_pipelined(pipe_kernel, B, S, H, heads, mask_kind):
     G.lib().fs2_op_set_gemm_variant(1200)
     old = G.attention(G.BF16, qkv, mask, B, S, H, heads)   # the phase-serial kernel: same arithmetic contract
     assert float((got - old).abs().max()) <= tol(G.BF16, ref, f32=5e-5, bf16=2e-2)
-    # 32 or 64 queries per wave: the same instruction sequence per query row - bit-identical, whatever the launch size picks
-    G.lib().fs2_op_set_gemm_variant(1200 + (3 - pipe_kernel))
+    # 32, 64 or 96 queries per wave: the same instruction sequence per query row - bit-identical, whatever the launch size picks
+    G.lib().fs2_op_set_gemm_variant(1200 + {1: 2, 2: 4, 4: 1}[pipe_kernel])
     other = G.attention(G.BF16, qkv, mask, B, S, H, heads)
     assert torch.equal(got, other)
 
 
-@pytest.mark.parametrize("pipe_kernel", [1, 2], indirect=True)
+@pytest.mark.parametrize("pipe_kernel", [1, 2, 4], indirect=True)
 def test_attention_pipelined_spike_and_all_padded(pipe_kernel):
     # (i) one key dominates late in the sequence: the running max jumps at a late half tile, in one query block only (rule 26:
     # the deferred rescale must scale O, l and nothing else exactly once); (ii) an utterance whose every key is padded gives NaN
@@ -577,15 +577,16 @@ def test_attention_pipelined_rerun_pass_in_64_query_items():
     other = torch.ones(B * S, dtype=torch.bool)
     other[u:u + S] = False
     assert torch.equal(got[other], clean[other])
-    G.lib().fs2_op_set_gemm_variant(1201)                   # 32 queries per wave: the same rows, bit for bit
-    try:
-        small = G.attention(G.BF16, spiked, mask, B, S, H, heads)
-    finally:
-        G.lib().fs2_op_set_gemm_variant(1203)
-    assert torch.equal(got, small)
+    for knob in (1201, 1202, 1204):                         # 32 / 64 / 96 queries per wave: the same rows, bit for bit
+        G.lib().fs2_op_set_gemm_variant(knob)
+        try:
+            other_shape = G.attention(G.BF16, spiked, mask, B, S, H, heads)
+        finally:
+            G.lib().fs2_op_set_gemm_variant(1203)
+        assert torch.equal(got, other_shape), knob
 
 
-@pytest.mark.parametrize("pipe_kernel", [1, 2], indirect=True)
+@pytest.mark.parametrize("pipe_kernel", [1, 2, 4], indirect=True)
 def test_attention_pipelined_rows_far_below_and_above_zero(pipe_kernel):
     """The first pass of the pipelined kernel exponentiates the scaled scores as they are (reference 0).  Rows whose scores all lie
     ~160 log2 units BELOW zero (denominator underflows) and rows ~160 above (overflows) rerun from the reference log2(denominator);
