@@ -17,7 +17,7 @@ dbg = torch.zeros(B * heads * S + 1024, device="cuda")
 lib.attn_pipe_probe_dbg.argtypes = [C.c_void_p] * 4 + [C.c_int] * 5 + [C.c_void_p]
 for it in range(3):
     dbg.zero_()
-    lib.attn_pipe_probe_dbg(qkv.data_ptr(), bits.data_ptr(), out.data_ptr(), dbg.data_ptr(), B, S, H, heads, 2, None)
+    lib.attn_pipe_probe_dbg(qkv.data_ptr(), bits.data_ptr(), out.data_ptr(), dbg.data_ptr(), B, S, H, heads, int(sys.argv[1]) if len(sys.argv) > 1 else 3, None)
     torch.cuda.synchronize()
 d = dbg.cpu()[B * heads * S:B * heads * S + 12 * 8].view(12, 8)
 print("per item of workgroup 0 (cycles since item start): [0, K landed + barrier, prologue done, loop done, epilogue issued, stores drained, NQB, t0 low bits]")
