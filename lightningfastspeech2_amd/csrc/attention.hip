@@ -464,9 +464,10 @@ int launch_attention(const AttnArgs& a, int dtype, hipStream_t stream) {
         const long long per_utt = (long long)a.heads * ((a.S + 127) / 128), units = per_utt * a.B;
         if (g_attn_pipe == 1 || g_attn_pipe == 2) return launch_attention_pipe(a, g_attn_pipe, stream);
         if (g_attn_pipe == 4) return launch_attention_pipe(a, 3, stream);
-        // 96 queries per wave (384-query items) where a workgroup's run of units is whole items: three or more units per workgroup
-        // and a multiple of three per head (T = 1536: 12 units per head, 3 per workgroup at C2 / C5, 9 at C3)
-        if (per_utt >= 16) return launch_attention_pipe(a, units >= 768 && ((a.S + 127) / 128) % 3 == 0 ? 3 : (units >= 512 ? 2 : 1), stream);
+        // 96 queries per wave (384-query items) from three units per workgroup on: at T = 1536 (12 units per head) a workgroup's
+        // run is whole items (one per CU at C2 / C5, three at C3); other lengths finish a head with a 256- or 128-query item and
+        // measured equal or faster than the 64-query-per-wave kernel (r03: T = 1400 66 vs 72 us, 1000 / 1664 / 2000 equal)
+        if (per_utt >= 16) return launch_attention_pipe(a, units >= 768 ? 3 : (units >= 512 ? 2 : 1), stream);
     }
     const int d = a.H / a.heads;
 #define FS2_ATTN_CASE(DD)                                                        \
