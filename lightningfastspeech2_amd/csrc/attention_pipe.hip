@@ -1,30 +1,32 @@
 // Software-pipelined fused attention for gfx950, bf16, head dim 128: the MFMA-bound instance of the attention inside
 // nn.MultiheadAttention (ConformerEncoderLayer.forward, /root/reference/litfass/fastspeech2/model.py:108-116) - the decoder's
-// self-attention over T frames.  Same arithmetic contract as attention.hip (padded KEYS masked, padded queries computed,
-// base-2 online softmax with a deferred rescale, fp32 statistics), different schedule:
+// self-attention over T frames.  Same contract as attention.hip (padded KEYS masked, padded queries computed, base-2 softmax,
+// fp32 statistics, bf16 P), different schedule and no running max:
 //
 //   attention.hip runs a KV tile as  [16 Q.K^T MFMAs] [softmax VALU] [16 P.V MFMAs]  per wave: the matrix pipe idles while the
 //   ~200 softmax instructions issue and the issue port idles while MFMAs drain (PMC: MFMA pipe 44 % busy, 5 VALU per MFMA), and
-//   a second wave on the SIMD does not fill the holes (the arbiter serves the oldest wave).  Here every MFMA phase
-//   carries the softmax of ANOTHER 32-key half tile of the same wave between its MFMAs:
+//   a second wave on the SIMD does not fill the holes (the arbiter serves the oldest wave).  Here one wave per SIMD
+//   runs [1 MFMA, <= 5 other instructions] over and over (an in-order wave gets issue slots only in the shadow of its own last
+//   MFMA; tools/probes/mfma_filler_cost.hip), and every MFMA phase carries the softmax "units" of ANOTHER 32-key half tile:
 //
-//     phase QK(h+1):  S(h+1) = K(h+1) Q^T  [8 K fragments x NQB MFMAs]  ||  finish(h): p = exp2(S(h)), row sums, bf16 pack
-//                                                                        ||  V(h) fragments -> registers (ds_read_b64_tr_b16)
-//     phase PV(h):    O^T += V(h)^T P(h)^T [8 V fragments x NQB MFMAs]  ||  start(h+1): row max of S(h+1)
-//                                                                        ||  K(h+2) fragments -> registers (ds_read_b128)
-//     then the (rare) rescale decision for S(h+1), after every P.V MFMA of the phase has been issued (a rescale of O may not
-//     split a pending P.V: cdna_hip_programming.md T13).
+//     phase QK(h+1):  S(h+1) = K(h+1) Q^T  [8 K fragments x NQB MFMAs]  ||  second half of the units of S(h): p = exp2(S), row
+//                                                                            sums, bf16 pack  ||  V(h) fragments (ds_read_b64_tr_b16)
+//     phase PV(h):    O^T += V(h)^T P(h)^T [8 V fragments x NQB MFMAs]  ||  first half of the units of S(h+1)
+//                                                                        ||  K(h+2) fragments (ds_read_b128)  ||  tile DMA pieces
 //
-//   A wave owns NQB 32-query blocks that share every K / V fragment it reads (NQB = 2: half the LDS reads per MFMA); two S
-//   half tiles (16 registers per block each) are alive at a time; the running max rides in a 16-register block that is the C
-//   operand of the first Q.K^T MFMA of a chain, so p = exp2(acc) needs no subtract and no accumulator initialisation.
-//   K / V tiles (64 keys) stream by buffer-load-to-LDS DMA into two slots each: ONE barrier per tile - at the top of tile t
-//   everything tile t reads (V(t), K(t+1)) has landed, K(t) / V(t-1) are dead and K(t+2) / V(t+1) are issued into their slots, a
-//   whole tile ahead of their first read.
+//   A wave owns NQB 32-query blocks that share every K / V fragment it reads; two S half tiles and two P half tiles are alive
+//   at a time.  p = exp2(scaled score) with no reference in the first pass (bf16 keeps 8 bits at any scale, O and the
+//   denominator accumulate in fp32); a row whose denominator leaves [2^-100, 2^100] is not stored and the item runs again for it
+//   from the reference log2(denominator), which then rides in the C operand of the first MFMA of each chain - so the loop has no
+//   max, no rescale, no branch, and no VALU access to O (run_item's pass loop; per-row, launch-shape independent).
+//   K / V tiles (64 keys) stream by buffer-load-to-LDS DMA into three K slots and two V slots: ONE barrier per tile - at the top of
+//   tile t everything tile t reads (V(t), K(t+1)) has landed, K(t-1) / V(t-1) are dead and K(t+2) / V(t+1) are issued into their
+//   slots, a whole tile ahead of their first read; fragments pass through 4-deep register rings.
 //
-// Work split: a unit is 128 queries of one (utterance, head); the grid is one workgroup per CU (NQB = 2, 512 registers, one wave
-// per SIMD) or two (NQB = 1), each owning a contiguous run of units - pairs of units of one head run as 256-query items (64 per
-// wave), leftovers as 128-query items - so 64 x 1536 queries (C2 decoder) are 3 units per workgroup, one round, no tail.
+// Work split: a unit is 128 queries of one (utterance, head); the grid is one workgroup per CU (NQB = 2 / 3, 512 registers, one
+// wave per SIMD) or two (NQB = 1), each owning a contiguous run of units - triples of units of one head run as 384-query items
+// (96 per wave, kernel<3>), pairs as 256-query items (64 per wave), leftovers as 128-query items - so 64 x 1536 queries (C2
+// decoder) are 3 units = one 384-query item per workgroup, one round, no tail.
 // Workgroups of one XCD own neighbouring units: a head's K / V stay in that XCD's L2.
 #include "fs2_common.h"
 #include "fs2_kernels.h"
@@ -663,11 +665,6 @@ int launch_attention_pipe(const AttnArgs& a, int variant, hipStream_t stream) {
     const long long U = (long long)a.B * a.heads * nu;
     if (U > 0x7fffffffll) return FS2_ERR_SHAPE;
     if (variant == 3) {
-        static bool attr = false;  // 112 KiB of static LDS: above the 64 KiB a kernel gets without asking
-        if (!attr) {
-            (void)hipFuncSetAttribute((const void*)attention_pipe_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 0);
-            attr = true;
-        }
         hipLaunchKernelGGL((attention_pipe_kernel<3>), dim3(256), dim3(256), 0, stream, a, nu, (int)U);
     } else if (variant == 2) {
         hipLaunchKernelGGL((attention_pipe_kernel<2>), dim3(256), dim3(256), 0, stream, a, nu, (int)U);
