@@ -243,13 +243,18 @@ def test_predictor_tile_heights_are_bit_identical():
     mask = torch.zeros(B, S, dtype=torch.bool)
     for b in range(B):
         mask[b, S - 11 * b:] = True
+    G.lib().fs2_op_set_gemm_variant(1300)
     short = G.predictor(x, ws, bs, gs, bes, hw, hb, mask, B, S)
-    G.lib().fs2_op_set_gemm_variant(1301)
     try:
+        G.lib().fs2_op_set_gemm_variant(1301)
         tall = G.predictor(x, ws, bs, gs, bes, hw, hb, mask, B, S)
+        G.lib().fs2_op_set_gemm_variant(1302)   # two tiles per workgroup, the epilogue of one between the MFMAs of the other
+        pair = G.predictor(x, ws, bs, gs, bes, hw, hb, mask, B, S)
+        pair_again = G.predictor(x, ws, bs, gs, bes, hw, hb, mask, B, S)
     finally:
         G.lib().fs2_op_set_gemm_variant(1300)
     assert torch.equal(tall, short)
+    assert torch.equal(pair, short) and torch.equal(pair_again, pair)
     ref = _predictor_ref(x[:3], ws, bs, gs, bes, hw, hb, mask[:3])
     assert float((tall[:3] - ref).abs().max()) <= 2e-2 * (float(ref.abs().max()) + 1)
     one = G.predictor(x[5:6], ws, bs, gs, bes, hw, hb, mask[5:6], 1, S)   # a single utterance (short tiles) == its row of the batch
