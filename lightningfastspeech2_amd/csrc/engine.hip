@@ -1069,10 +1069,15 @@ static int decode_body(fs2_engine* e, const fs2_outputs* out, hipStream_t st) {
     const fs2_config& c = e->cfg;
     const int B = e->B, L = e->L, T = e->T;
     const size_t H = c.hidden, MT = (size_t)B * T, ML = (size_t)B * L, esz = e->esz;
-    if (out->duration_prediction) HIPCHK(e, hipMemcpyAsync(out->duration_prediction, e->dur_pred, ML * 4, hipMemcpyDeviceToDevice, st));
-    if (out->duration_rounded) HIPCHK(e, hipMemcpyAsync(out->duration_rounded, e->d_dur, ML * 4, hipMemcpyDeviceToDevice, st));
-    if (out->src_mask) HIPCHK(e, hipMemcpyAsync(out->src_mask, e->src_mask, ML, hipMemcpyDeviceToDevice, st));
-    if (T == 0) { e->encoded = false; e->mid_forward = false; return FS2_OK; }
+    // the phone-level outputs live in the engine's persistent arena (decode does not touch it): copied out BEHIND the decode
+    // launches - three hipMemcpyAsync cost the host ~15 us each, which the GPU would otherwise spend idle at the seam
+    auto phone_outputs = [&]() -> int {
+        if (out->duration_prediction) HIPCHK(e, hipMemcpyAsync(out->duration_prediction, e->dur_pred, ML * 4, hipMemcpyDeviceToDevice, st));
+        if (out->duration_rounded) HIPCHK(e, hipMemcpyAsync(out->duration_rounded, e->d_dur, ML * 4, hipMemcpyDeviceToDevice, st));
+        if (out->src_mask) HIPCHK(e, hipMemcpyAsync(out->src_mask, e->src_mask, ML, hipMemcpyDeviceToDevice, st));
+        return FS2_OK;
+    };
+    if (T == 0) { e->encoded = false; e->mid_forward = false; return phone_outputs(); }
 
     CHK(ensure_arena(e, e->scratch, decode_scratch_bytes(e, B, T), "scratch"));  // too small: the caller may retry with more
     e->mid_forward = false;  // from here on the encoder state is consumed by this call
@@ -1146,7 +1151,7 @@ static int decode_body(fs2_engine* e, const fs2_outputs* out, hipStream_t st) {
     if (out->mel)                                                            // fastspeech2.py:723
         CHK(gemm(e, st, e->mel, yA, out->mel, (int)MT, (int)MT, false, FS2_F32, nullptr, -1, e->zero_pad_mel ? tmask : nullptr));
     for (int v = 0; v < FS2_MAX_VARIANCES; ++v) e->forced_idx[v] = nullptr, e->forced_tgt[v] = nullptr;  // one-shot
-    return FS2_OK;
+    return phone_outputs();
 }
 
 static void drop_graphs(fs2_engine* e) {

@@ -37,9 +37,31 @@ def main(db, title=""):
         n = re.sub(r"fs2::", "", n)[:100]
         print(f"| `{n}` | {c} | {s / 1e6:.3f} | {a / 1e3:.1f} | {mn / 1e3:.1f} | {mx / 1e3:.1f} | {100 * s / tot:.1f} | {vg} | {ag} | {lds} |")
 
+def timeline(db, title=""):
+    """The launch sequence of ONE forward (the last complete one in the trace): per launch its duration and the idle gap since the
+    previous launch ended - which launch is which GEMM, and where the GPU waits for the host."""
+    con = sqlite3.connect(db)
+    cols = [r[1] for r in con.execute("pragma table_info(kernels)")]
+    g = [c for c in ("grid_x", "grid_size_x") if c in cols][0]
+    rows = con.execute(f"select name, start, end, {g} from kernels order by start").fetchall()
+    idx = [i for i, r in enumerate(rows) if "embed_kernel<" in r[0] and "bucket" not in r[0]]  # the phone embedding opens a forward
+    a, b = idx[-2], idx[-1]
+    print(f"# {title or db}: launches of one forward ({b - a} launches, {(rows[b][1] - rows[a][1]) / 1e3:.1f} us start to start)\n")
+    print("| # | kernel | grid x | us | gap before, us |")
+    print("|---|---|---|---|---|")
+    busy = 0
+    for i in range(a, b):
+        n = re.sub(r"fs2::|\(anonymous namespace\)::|void ", "", rows[i][0])[:70]
+        busy += rows[i][2] - rows[i][1]
+        print(f"| {i - a} | `{n}` | {rows[i][3]} | {(rows[i][2] - rows[i][1]) / 1e3:.1f} | {(rows[i][1] - rows[i - 1][2]) / 1e3:.1f} |")
+    print(f"\nkernel time {busy / 1e3:.1f} us, idle {(rows[b][1] - rows[a][1] - busy) / 1e3:.1f} us")
+
+
 
 if __name__ == "__main__":
     if sys.argv[1] == "--by-grid":
         by_grid(sys.argv[2], " ".join(sys.argv[3:]))
+    elif sys.argv[1] == "--timeline":
+        timeline(sys.argv[2], " ".join(sys.argv[3:]))
     else:
         main(sys.argv[1], " ".join(sys.argv[2:]))
