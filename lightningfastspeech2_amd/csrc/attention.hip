@@ -85,8 +85,17 @@ __device__ inline float half_sum(float x) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-template <typename T, int D, int NW>
-__global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128) ? 2 : 1) void attention_kernel(AttnArgs p) {
+// RES > 0 (bf16, head dim 128, at most RES key tiles = 64 RES keys: the encoder's 256 phonemes): ALL of the (utterance, head)'s
+// K and V are requested at the top of the kernel - K tiles first, then V - into RES-tile LDS images (128 KiB at RES = 4, one
+// workgroup per CU), and the tile loop runs without DMA issue or barrier after its first iteration.  The streaming form pays a
+// DMA round trip (~1 us) at each of its two barriers per tile because a tile is requested only one phase ahead; with four tiles
+// in all there is nothing else to hide it under.  The arithmetic per row is the streaming kernel's, instruction for instruction.
+// (Knob 1211; measured no faster - see g_attn_resident below.)
+template <int N>
+__device__ inline void vm_wait() { __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14)); }
+
+template <typename T, int D, int NW, int RES = 0>
+__global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128 && RES == 0) ? 2 : 1) void attention_kernel(AttnArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins exist in the device pass only
     constexpr int KVB = sizeof(T) == 2 ? 64 : 32;      // keys per tile
     constexpr int E16 = Num<T>::kPer16B;
@@ -106,8 +115,9 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128) ? 2 : 1) void
     constexpr bool TRV = sizeof(T) == 2;  // bf16: V stays row-major (straight from qkv), hardware transpose read
     static_assert(TILE_B % (1024 * NDW) == 0 && NDW <= NW, "tile must split into whole wave DMAs");
 
-    __shared__ __attribute__((aligned(16))) unsigned char sKa[TILE_B];
-    __shared__ __attribute__((aligned(16))) unsigned char sVa[TILE_B];
+    static_assert(RES == 0 || (TRV && NINST * RES <= 32), "resident K / V: bf16 only, the counted wait must fit vmcnt");
+    __shared__ __attribute__((aligned(16))) unsigned char sKa[TILE_B * (RES ? RES : 1)];
+    __shared__ __attribute__((aligned(16))) unsigned char sVa[TILE_B * (RES ? RES : 1)];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // query group (also this wave's share of the tile DMAs)
@@ -197,16 +207,33 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128) ? 2 : 1) void
 
     // This half's tile range; all halves run the same number of (two-barrier) iterations.
     const int nhalf = ntiles, jbeg = 0, jend = ntiles;
-    auto run = [&](unsigned char* sK, unsigned char* sV) {
-        if (jbeg < jend && tile_bits(jbeg) != 0ull) issue_k(jbeg, sK);
+    auto run = [&](unsigned char* sK0, unsigned char* sV0) {
+        if constexpr (RES > 0) {  // everything in flight at once: K tiles, then V tiles (padded tiles too: the waits below count)
+            for (int j = 0; j < ntiles; ++j) issue_k(j, sK0 + j * TILE_B);
+            for (int j = 0; j < ntiles; ++j) issue_v(j, sV0 + j * TILE_B);
+        } else {
+            if (jbeg < jend && tile_bits(jbeg) != 0ull) issue_k(jbeg, sK0);
+        }
         for (int it = 0; it < nhalf; ++it) {
             const int j = jbeg + it;
             const unsigned long long bits = j < jend ? tile_bits(j) : 0ull;
             const bool valid = bits != 0ull;  // fully padded tiles cost two barriers, nothing else
+            unsigned char* const sK = sK0 + (RES > 0 ? j * TILE_B : 0);
+            unsigned char* const sV = sV0 + (RES > 0 ? j * TILE_B : 0);
+            if constexpr (RES > 0) {
+                if (it == 0) {  // this wave's share of every K tile has landed: all but the V requests (in issue order) are done
+                    if (ntiles == 1) vm_wait<NINST>();
+                    else if (ntiles == 2) vm_wait<2 * NINST>();
+                    else if (ntiles == 3) vm_wait<(RES >= 3 ? 3 : 1) * NINST>();
+                    else vm_wait<(RES >= 4 ? 4 : 1) * NINST>();
+                    __syncthreads();
+                }
+            } else {
             dma_drain();       // this wave's share of K_j has landed (explicit: never left to hipcc's
             __syncthreads();   // placement); after the barrier everyone's has, and every wave is
                                // done with P.V of the previous tile -> sV is free
             if (valid) issue_v(j, sV);  // V_j streams in underneath Q.K^T
+            }
             uint4 pf[4];
             if (valid) {
             // the running max rides in the accumulator's initial value, so the common path is
@@ -308,9 +335,16 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128) ? 2 : 1) void
                 pf[ch] = Vec16<T>::pack(f);
             }
             }
+            if constexpr (RES > 0) {
+                if (it == 0) {  // every V tile landed (they streamed in under the first tile's Q.K^T and softmax)
+                    dma_drain();
+                    __syncthreads();
+                }
+            } else {
             dma_drain();
             __syncthreads();   // V_j landed; every wave is done reading sK
             if (j + 1 < jend && tile_bits(j + 1) != 0ull) issue_k(j + 1, sK);  // next K under P.V
+            }
             if (valid) {
             // ---- O^T += V^T P^T ----
             if constexpr (TRV) {
@@ -412,6 +446,11 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(AttnArgs p) {
     }
 }
 
+// Measured r03 (rocprof, tools/probes/attn_resident_ab.sh): C2 encoder (64 heads x 256 keys) 13.1 us resident vs 13.6 streaming (min 12.0 vs
+// 10.1), C3 encoder (192 heads) 28.1 vs 19.3 - the 128 KiB a workgroup pulls before its first MFMA arrive at the CU's ~30 GB/s
+// whatever the request pattern, and the streaming form's two co-resident workgroups hide each other's round trips.  Off.
+int g_attn_resident = 0;  // 1: sequences of at most 256 keys (bf16, head dim 128) keep K and V resident in LDS; 0: streaming form
+
 template <typename T, int D>
 static int launch_tv(const AttnArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL((transpose_v_kernel<T, D>), dim3(a.Spad / 64, a.B * a.heads), dim3(256), 0, stream, a);
@@ -427,6 +466,16 @@ static int launch_td(const AttnArgs& a, hipStream_t stream) {
     // (192-query / 6-wave workgroups - 512 of them for the C2 decoder, two per CU, a third less K/V streamed - need three
     // waves per SIMD, i.e. <= 168 VGPRs; this kernel holds 234 (O^T 64, S^T 32, Q 32, K/V/P fragments 56 ...) and with the cap
     // spills 84 of them: 195 us against 101 us for the 128-query form.  Measured r02, removed.)
+    if constexpr (sizeof(T) == 2 && D == 128) {
+        // at most 256 keys: K and V resident (one 128-KiB workgroup per CU); 64-query workgroups while they fit one round
+        if (g_attn_resident && a.S <= 256) {
+            if ((long)((a.S + 63) / 64) * BH > 256)
+                hipLaunchKernelGGL((attention_kernel<T, D, 4, 4>), dim3(((a.S + 127) / 128) * BH8), dim3(256), 0, stream, a);
+            else
+                hipLaunchKernelGGL((attention_kernel<T, D, 2, 4>), dim3(((a.S + 63) / 64) * BH8), dim3(128), 0, stream, a);
+            return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
+        }
+    }
     if (blocks4 >= 512) {
         hipLaunchKernelGGL((attention_kernel<T, D, 4>), dim3(((a.S + 127) / 128) * BH8), dim3(256), 0, stream, a);
     } else {

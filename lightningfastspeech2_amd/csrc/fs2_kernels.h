@@ -89,6 +89,7 @@ int launch_attention(const AttnArgs& a, int dtype, hipStream_t stream);    // ne
 bool attention_pipe_supported(const AttnArgs& a, int dtype);
 int launch_attention_pipe(const AttnArgs& a, int variant, hipStream_t stream);
 extern int g_attn_pipe;
+extern int g_attn_resident;
 extern int g_pred_tall;  // predictor_fused.hip: 208-row tiles (one workgroup per CU) where they fill the chip
 
 // Whole dense VariancePredictor (n x [conv k=3 -> ReLU -> LN] -> Linear(H,1) -> mask) in one launch;

@@ -378,6 +378,32 @@ def test_attention_pipelined(pipe_kernel, B, S, H, heads, mask_kind):
     assert torch.equal(got, other)
 
 
+@pytest.mark.parametrize("B,S,H,heads,mask_kind", [
+    (2, 256, 256, 2, "none"), (3, 200, 256, 2, "suffix"), (2, 64, 256, 2, "none"), (2, 33, 384, 3, "scatter"),
+    (2, 250, 256, 2, "prefix"), (2, 256, 256, 2, "holes"), (48, 130, 768, 6, "suffix"), (1, 1, 128, 1, "none")])
+def test_attention_resident_kv_is_bit_identical(B, S, H, heads, mask_kind):
+    """Knob 1211: at most 256 keys, K and V of an (utterance, head) requested at once and held in LDS (both workgroup widths:
+    the 48 x 6-head case takes the 128-query one).  Same per-row instruction sequence as the streaming form - bit-equal,
+    padded tiles and NaN rows of fully padded utterances included."""
+    qkv = rnd(B * S, 3 * H, seed=12)
+    mask = _mask(mask_kind, B, S)
+    if mask_kind == "suffix" and B > 2:
+        mask[2, :] = True  # an utterance with no valid key at all
+    G.lib().fs2_op_set_gemm_variant(1200)
+    try:
+        G.lib().fs2_op_set_gemm_variant(1210)
+        old = G.attention(G.BF16, qkv, mask, B, S, H, heads)
+        G.lib().fs2_op_set_gemm_variant(1211)
+        got = G.attention(G.BF16, qkv, mask, B, S, H, heads)
+    finally:
+        G.lib().fs2_op_set_gemm_variant(1210)
+        G.lib().fs2_op_set_gemm_variant(1203)
+    assert torch.equal(torch.nan_to_num(got, nan=7.0), torch.nan_to_num(old, nan=7.0))
+    ref = _attn_ref(G.rounded(qkv, G.BF16), mask, B, S, H, heads)
+    ok = ~torch.isnan(ref)
+    assert float((got[ok] - ref[ok]).abs().max()) <= tol(G.BF16, ref[ok], f32=5e-5, bf16=2e-2)
+
+
 @pytest.mark.parametrize("pipe_kernel", [1, 2, 4], indirect=True)
 def test_attention_pipelined_spike_and_all_padded(pipe_kernel):
     # (i) one key dominates late in the sequence: the running max jumps at a late half tile, in one query block only (rule 26:
