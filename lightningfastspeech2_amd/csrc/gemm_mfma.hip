@@ -375,6 +375,17 @@ template <bool B> struct BoolC { static constexpr bool value = B; };
 // variance adaptor) in the mixed precision mode, where a discrete decision hangs on every output.
 // DEFER (LN = false only): the deferred-LayerNorm epilogue (residual preload + pre-norm store + row statistics); its own
 // instantiation so that the plain GEMM launches do not carry its registers (the in-projection measured +9 % with both in one).
+#ifdef FS2_SLAB_PROBE  // tools/probes/slab_phase_stamps.py: s_memtime of waves 0 and 7 of workgroups 0 and 128 at the phase boundaries
+__device__ unsigned long long g_slab_stamps[4][8];
+#define SLAB_STAMP(i)                                                                                                   \
+    do {                                                                                                                \
+        if ((blockIdx.x == 0 || blockIdx.x == 128) && (threadIdx.x == 0 || threadIdx.x == 448))                          \
+            g_slab_stamps[(blockIdx.x ? 2 : 0) + (threadIdx.x ? 1 : 0)][i] = __builtin_amdgcn_s_memtime();               \
+    } while (0)
+#else
+#define SLAB_STAMP(i) do { } while (0)
+#endif
+
 template <typename T, typename OutT, int MI, bool LN, bool WIDE = false, bool SPLIT = false, bool DEFER = false>
 __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
     static_assert(!SPLIT || sizeof(T) == 4, "the split arithmetic takes fp32 operands");
@@ -387,6 +398,7 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char wt0[S_BN * ROWB];  // 32 KiB weight tile per stage
     __shared__ __attribute__((aligned(16))) unsigned char wt1[S_BN * ROWB];
     constexpr int KE = ROWB / (int)sizeof(T);
+    SLAB_STAMP(0);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -538,6 +550,12 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
             set_wvoff();
         }
     }
+    // the first operand DMAs go out BEFORE the residual preload below: that preload waits for its own global loads (11 k of a
+    // 35 k-tick out-projection + LayerNorm launch sat in front of the first DMA, tools/probes/slab_phase_stamps.py) and the two
+    // round trips now overlap
+    SLAB_STAMP(1);
+    issue_slab(slab0, 0);
+    issue_w(wt0, 0, 0);
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -594,8 +612,7 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
             }
         }
     }
-    issue_slab(slab0, 0);
-    issue_w(wt0, 0, 0);
+    SLAB_STAMP(6);
     for (int cc = 0; cc < ncc; cc += 2) {
         for (int tap = 0; tap < ntap; tap += 2) {
             FS2_SLAB_STEP(slab0, slab1, wt0, wt1, cc, tap)
@@ -608,6 +625,7 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
             }
         }
     }
+    SLAB_STAMP(2);
     if constexpr (WIDE) {
         // this column tile's pre-norm values v = act(acc + bias) + res: row partial sums + one 16-byte store per
         // 8 consecutive channels (columns past N come out of the K loop as exact zeros and stay zero)
@@ -828,6 +846,7 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
             }
         }
         __syncthreads();  // every wave is done with the operand buffers: reuse them for the exchange
+        SLAB_STAMP(3);
         float* red = (float*)slab0;  // [4 column waves][BMs rows]
         float* lnp = (float*)wt0;    // [gamma 256 | beta 256 | head weight 256]
         if (tid < S_BN) {
@@ -886,6 +905,7 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
             rstd[mi] = 1.0f / sqrtf(var + p.ln_eps);
         }
         OutT* __restrict__ Cn = p.C ? (OutT*)p.C + rowbase * p.ldc : nullptr;
+        SLAB_STAMP(4);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const int t = t0 + wm * (MI * 16) + mi * 16 + fr;
@@ -917,6 +937,7 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
                 }
             }
         }
+        SLAB_STAMP(5);
         if (p.dot_w) {  // predictor head (rare): the normalised values once more, times the head weights
             float dsum[MI];
 #pragma unroll
@@ -1315,3 +1336,10 @@ static int launch_gemm_plain(const GemmArgs& a, int in_dtype, int out_dtype, hip
 }
 
 }  // namespace fs2
+
+#ifdef FS2_SLAB_PROBE
+extern "C" int fs2_dbg_slab_phase_stamps(unsigned long long* out /*4 x 8, host*/) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(fs2::g_slab_stamps), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -2;
+}
+#endif

@@ -8,6 +8,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$D $EXTRA"   # EXTRA="-DFOO"
 /opt/rocm/bin/hipcc $FLAGS -c $ATT -o $V/obj_$NAME/attention.o &
 /opt/rocm/bin/hipcc $FLAGS -c $GEMM -o $V/obj_$NAME/gemm_mfma.o &
 wait
-for f in rowops capi_ops engine predictor_fused vocoder_conv vocoder_resblock vocoder_engine loss; do [ -f $D/$f.o ] || /opt/rocm/bin/hipcc $FLAGS -c $D/$f.hip -o $D/$f.o; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $V/libfs2_$NAME.so $V/obj_$NAME/attention.o $V/obj_$NAME/gemm_mfma.o $D/rowops.o $D/capi_ops.o $D/engine.o $D/predictor_fused.o $D/vocoder_conv.o $D/vocoder_resblock.o $D/vocoder_engine.o $D/loss.o
+make -s -C $D -j6   # every other object as the in-tree library has it
+REST=$(ls $D/*.o | grep -v -e /attention.o -e /gemm_mfma.o)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $V/libfs2_$NAME.so $V/obj_$NAME/attention.o $V/obj_$NAME/gemm_mfma.o $REST
 echo built $V/libfs2_$NAME.so
