@@ -239,6 +239,12 @@ def main():
             gemm_case("enc in_proj", 8192, 768, 256, 1, 8192, a.reps, v)
             gemm_case("dur-pred conv k=3", 8192, 256, 256, 3, 256, a.reps, v)
             gemm_case("square 4096^3", 4096, 4096, 4096, 1, 4096, a.reps, v)
+    if a.what == "dgrad":  # data-gradient convs of the training step: long reductions (K = taps x filter) at few rows
+        for v in ([0, 6, 7, 3, 4, 5] if a.variant < 0 else [a.variant]):
+            gemm_case("c2 enc conv1 dgrad", 8192, 256, 1024, 9, 256, a.reps, v)
+            gemm_case("c2 dec conv1 dgrad", 49152, 256, 1024, 9, 1536, a.reps, v)
+            gemm_case("c2 enc conv2 dgrad", 8192, 1024, 256, 1, 8192, a.reps, v)
+            gemm_case("c5 enc conv1 dgrad", 2048, 1024, 4096, 9, 256, a.reps, v)
     if a.what in ("ln", "all"):
         for v in ([0, 6, 7, 3, 4] if a.variant < 0 else [a.variant]):
             gemm_ln_case("var-pred conv k=3 +LN", 49152, 256, 256, 3, 1536, a.reps, v, res=False, relu=True)

@@ -6,6 +6,7 @@
 //   MODE 2: global_load_dwordx4 -> VGPR -> ds_write_b128 (4 x 16 B per thread per step), loads of step s+1 issued before the
 //           barrier of step s, written after it
 //   MODE 3: as 2, two steps of loads in flight
+//   MODE 4 / 5: LDS-DMA by all 8 waves into a ring of 3 / 4 stages (2 / 3 steps in flight), counted vmcnt, one barrier per step
 // hipcc --offload-arch=gfx950 -O3 -o /tmp/cu_ingest tools/probes/cu_ingest.hip && /tmp/cu_ingest
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -39,7 +40,33 @@ __global__ __launch_bounds__(512, 1) void k(const unsigned char* w, int panel, i
         }
     };
     for (int r = 0; r < reps; ++r) {
-        if (MODE <= 1) {
+        if (MODE >= 4) {
+            constexpr int NST = MODE - 1;  // 3 or 4 stages
+            __shared__ __attribute__((aligned(16))) unsigned char ring[4][STEP];
+            unsigned char* const st0 = &ring[0][0];
+            auto dmar = [&](int slot, int s) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(st0 + slot * STEP + (i * 8 + wave) * 1024), 16,
+                                                             (unsigned)(s * STEP + (i * 8 + wave) * 1024 + lane * 16), 0, 0, 0);
+            };
+            for (int s = 0; s < NST - 1 && s < nsteps; ++s) dmar(s, s);
+            int slot = 0;
+            for (int s = 0; s < nsteps; ++s) {
+                // step s landed = all but the (NST - 2) younger steps' DMAs (4 instructions per step per wave) are done
+                if (s + NST - 2 < nsteps) {
+                    if (NST == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __syncthreads();
+                if (s + NST - 1 < nsteps) dmar((slot + NST - 1) % NST, s + NST - 1);
+                consume(st0 + slot * STEP);
+                slot = (slot + 1) % NST;
+            }
+            __syncthreads();
+        } else if (MODE <= 1) {
             dma(b0, 0);
             for (int s = 0; s < nsteps; ++s) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -93,6 +120,7 @@ int main() {
     (void)hipMalloc(&w, 8 << 20); (void)hipMemset(w, 1, 8 << 20); (void)hipMalloc(&o, 256 * 512 * 4);
     for (int panel : {512 << 10, 4 << 20}) {
         run<0>(w, o, panel, 256); run<1>(w, o, panel, 256); run<2>(w, o, panel, 256); run<3>(w, o, panel, 256);
+        run<4>(w, o, panel, 256); run<5>(w, o, panel, 256);
     }
     run<0>(w, o, 512 << 10, 32); run<2>(w, o, 512 << 10, 32);
     return 0;
