@@ -1233,7 +1233,11 @@ int g_wide_ln = 0;
 static int launch_gemm_plain(const GemmArgs& a, int in_dtype, int out_dtype, hipStream_t stream, bool* fused);
 
 int launch_gemm(const GemmArgs& a, int in_dtype, int out_dtype, hipStream_t stream) {
-    if (!a.ln_g) return launch_gemm_plain(a, in_dtype, out_dtype, stream, nullptr);
+    if (!a.ln_g) {
+        // K = 256 bf16: the column tile's weights live in registers, row tiles stream (gemm_wres.hip; bit-identical results)
+        if (g_gemm_wres && g_gemm_variant == 0 && gemm_wres_supported(a, in_dtype, out_dtype, g_gemm_wres == 2)) return launch_gemm_wres(a, stream);
+        return launch_gemm_plain(a, in_dtype, out_dtype, stream, nullptr);
+    }
     // fused row epilogue requested: try the slab kernel (whole rows per workgroup), else GEMM -> ln_tmp
     // followed by the stand-alone LayerNorm kernel (same arithmetic, one more HBM round trip)
     bool fused = false;

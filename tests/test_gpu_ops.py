@@ -51,6 +51,29 @@ def test_gemm_plain(dtype, M, N, K, relu, gemm_variant):
     assert err <= tol(dtype, ref), (err, tol(dtype, ref))
 
 
+@pytest.mark.parametrize("M,N,relu,bias", [(49152, 768, False, True), (8192, 768, False, True), (8192, 256, True, True), (1, 256, False, False),
+                                         (95, 512, False, True), (97, 256, True, True), (96 * 9 + 5, 1024, False, True), (300, 768, True, False)])
+def test_wres_gemm_is_bit_identical_to_the_slab_kernel(M, N, relu, bias):
+    """bf16 GEMMs with K = 256 take the weight-resident kernel (gemm_wres.hip: a column tile's weights in registers, 96-row
+    activation tiles streamed through LDS, one workgroup walking many tiles): bit-equal to the slab kernel it replaces (knob
+    1400) on every work split - one row, ragged last tiles, more row groups than tiles, several tiles per workgroup - and
+    within the bf16 tolerance of the fp32 reference."""
+    x, w = rnd(M, 256, seed=3), rnd(N, 256, seed=4) / 16
+    b = rnd(N, seed=5) if bias else None
+    try:
+        G.lib().fs2_op_set_gemm_variant(1400)
+        old = G.gemm(G.BF16, x, w, b, relu=relu)
+        G.lib().fs2_op_set_gemm_variant(1402)   # the weight-resident kernel at every size (1401, the default, picks it from three tiles per workgroup on)
+        got = G.gemm(G.BF16, x, w, b, relu=relu)
+        again = G.gemm(G.BF16, x, w, b, relu=relu)
+    finally:
+        G.lib().fs2_op_set_gemm_variant(1401)
+    assert torch.equal(got, old) and torch.equal(got, again)
+    ref = G.rounded(x, G.BF16) @ G.rounded(w, G.BF16).T + (0 if b is None else b)
+    ref = ref.clamp_min(0) if relu else ref
+    assert float((got - ref).abs().max()) <= tol(G.BF16, ref)
+
+
 def test_gemm_bf16_in_fp32_out(gemm_variant):
     x, w, b = rnd(150, 256, seed=4), rnd(80, 256, seed=5, scale=1 / 16), rnd(80, seed=6)
     ref = G.rounded(x, G.BF16) @ G.rounded(w, G.BF16).T + b
