@@ -25,6 +25,10 @@ namespace {
 constexpr int PF_H = 256, PF_TAPS = 3, PF_KB = PF_H / 32, PF_STEPS = PF_TAPS * PF_KB;  // 24 k-steps of 32
 constexpr int PF_STEP_U4 = 8 * 2 * 64;  // 16-byte fragments per k-step: [wave][fragment][lane]
 constexpr int PF_ROWB = PF_H * 2;       // slab row bytes (bf16)
+#ifndef FS2_PF_PREFETCH
+#define FS2_PF_PREFETCH 1
+#endif
+constexpr bool PF_PREFETCH = FS2_PF_PREFETCH;
 
 }  // namespace
 
@@ -46,11 +50,21 @@ __global__ void pack_predictor_weights_kernel(const bf16* __restrict__ W, uint4*
 // redundant loads inside the workgroup) and ride a 4-deep register ring: L2 latency under 256 CUs
 // pulling the same lines is ~2k cycles, a k-step is 450-900.  The activation fragments come from the
 // LDS slab in two halves so that they never hold more than 16-28 VGPRs.
-// The shipped form is 4 waves x 64 channels on 112-row tiles, TWO workgroups per CU: independent
-// workgroups run out of phase (one's LayerNorm epilogue under the other's K loop), and 15 x 112 rows
+// The shipped form is 4 waves x 64 channels on 112-row tiles, TWO workgroups per CU (while one wave of a SIMD waits for its
+// fragments the other issues), and 15 x 112 rows
 // cover 1536 frames with less halo waste than 8 x 224 (5 layers: 121 us vs 137 us for the 8-wave,
 // 224-row, one-workgroup-per-CU form).  One form for every shape keeps results independent of how an
 // utterance is batched (the cross-wave reduction tree is part of the arithmetic).
+//
+// Where the time goes (r03, C2 variance predictor, 32 x 1536 frames, 5 layers; probe builds -DFS2_PF_PROBE=1|2 through
+// tools/build_variant_files.sh, tools/bench_ops.py pred, kernel time = the printed figure minus ~15 us of weight packing):
+//   shipped r02 form 113 us | every k-step streaming the same two weight blocks (L1-hot) -9 | no ReLU / LayerNorm / slab rewrite
+//   -17 | both -35 (72 us: the K loops alone, 56 us of MFMA passes at ~1.9 GHz).  The parts ADD - the two workgroups of a CU
+//   (blockIdx i and i + 256, started within 40 ticks of each other: tools/probes/hwid_probe.hip) do not hide each other's epilogue:
+//   starting the second one 1-12 us late changes nothing (the delay is absorbed, no more), so the lever is instruction count.
+//   Taken: the epilogue on packed fp32 (~1400 -> ~750 VALU per layer and wave), the A-fragment halves requested one half ahead,
+//   the bias as the C operand of a chain's first MFMA: 113 -> 106 us.  The epilogue change alone measured nothing until the
+//   fragment prefetch was in (its LDS round trips sat in front of every half's MFMAs).
 template <int MI16, int NWV, int MINW>
 __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(PredictorArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins exist in the device pass only
@@ -93,6 +107,9 @@ __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(Predict
     const int total = nl * PF_STEPS;
     auto loadB = [&](uint4 (&b)[NFR], int g) {
         g = g < total ? g : total - 1;  // past the end: a harmless re-read instead of a branch
+#if defined(FS2_PF_PROBE) && (FS2_PF_PROBE & 1)
+        g &= 1;  // probe: every k-step streams the same two 16-KiB blocks (hot in the vector L1) - what does the L2 weight stream cost?
+#endif
 #pragma unroll
         for (int ni = 0; ni < NFR; ++ni) b[ni] = wbase[(size_t)g * PF_STEP_U4 + ni * 64];
     };
@@ -106,24 +123,29 @@ __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(Predict
 
     const int n0 = wv * (NFR * 16) + fg * 8;  // fragment pair j: this lane's channels n0 + 32*j .. +7
     for (int l = 0; l < nl; ++l) {
-        // bias rides in as the accumulators' initial value
+        // The bias rides in as the C operand of a chain's FIRST MFMA (k-block 0 of tap 0 names the bias quad, the accumulator is
+        // written, not read: no 112 v_mov per layer to seed the accumulators) - tap 0 is peeled for that.
         f32x4_t acc[NFR][MI16];
+        f32x4_t bq[NFR];
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             const float* bias = p.bias + l * PF_H + n0 + 32 * j;
             const float4 b0 = *(const float4*)bias, b1 = *(const float4*)(bias + 4);
-#pragma unroll
-            for (int b = 0; b < MI16; ++b) {
-                acc[2 * j][b] = (f32x4_t){b0.x, b0.y, b0.z, b0.w};
-                acc[2 * j + 1][b] = (f32x4_t){b1.x, b1.y, b1.z, b1.w};
-            }
+            bq[2 * j] = (f32x4_t){b0.x, b0.y, b0.z, b0.w};
+            bq[2 * j + 1] = (f32x4_t){b1.x, b1.y, b1.z, b1.w};
         }
         // tile row r at tap tp lives at slab index r + tp; its 16-byte slot (kb*4 + fg) is stored at
         // SlabSwizzle::slot(slot, index) (conflict-free fragment reads for every start row; the plain
-        // slot ^ (index & 15) map measured 20 % bank-conflict cycles).  Taps: a rolled loop (short live ranges); the 8 k-blocks of a tap are
-        // unrolled so that the ring index is static.
-#pragma unroll 1
-        for (int tp = 0; tp < PF_TAPS; ++tp) {
+        // slot ^ (index & 15) map measured 20 % bank-conflict cycles).  Taps 1.. : a rolled loop (short live ranges); the 8 k-blocks of
+        // a tap are unrolled so that the ring index is static.
+        auto mma = [&](auto FIRSTKB, const uint4& bfrag, const uint4& afrag, int ni, f32x4_t& a) {
+            if constexpr (decltype(FIRSTKB)::value)
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(const bf16x8_t*)&bfrag, *(const bf16x8_t*)&afrag, bq[ni], 0, 0, 0);
+            else
+                Mma16<bf16>::step(bfrag, afrag, a);
+        };
+        auto tap = [&](int tp, auto FIRST) {
+            constexpr bool first = decltype(FIRST)::value;
             const int i0 = fr + tp;
             const unsigned char* arow_p = slab + i0 * PF_ROWB;
             const int acx = (((fg & 1) << 3) | ((fg >> 1) ^ (i0 & 7))) << 4;  // SlabSwizzle::slot(fg, i0); + kb below
@@ -134,60 +156,76 @@ __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(Predict
                 for (int mi = 0; mi < HFA; ++mi)
                     if (mi < cnt) fx[mi] = *(const uint4*)(arow_p + (m0 + mi) * 16 * PF_ROWB + (acx ^ ((((kb & 3) << 1) | ((kb >> 2) << 4)) << 4)));
             };
-            if constexpr (MINW == 1) {
-                // one wave per SIMD: nobody covers an LDS round trip, so the next half's activation fragments are requested before
-                // this half's MFMAs (two fragment sets alive; a 512-register wave has room)
-                uint4 fxa[HFA], fxb[HFA];
-                loadA(fxa, 0, 0);
-#pragma unroll
-                for (int kb = 0; kb < PF_KB; ++kb) {
-                    loadB(bw[(kb + 3) & 3], (l * PF_TAPS + tp) * PF_KB + kb + 3);
+            auto kblock = [&](auto KB0, int kb, uint4 (&fxa)[HFA], uint4 (&fxb)[HFA]) {
+                loadB(bw[(kb + 3) & 3], (l * PF_TAPS + tp) * PF_KB + kb + 3);
+                if constexpr (MINW == 1 || PF_PREFETCH) {
+                    // the next half's activation fragments are requested before this half's MFMAs (two fragment sets alive): an LDS
+                    // round trip behind every half otherwise (r03: 113 -> 107 us for the C2 variance predictor with two workgroups per CU)
                     loadA(fxb, kb, 1);
 #pragma unroll
                     for (int ni = 0; ni < NFR; ++ni)
 #pragma unroll
-                        for (int mi = 0; mi < HFA; ++mi) Mma16<bf16>::step(bw[kb & 3][ni], fxa[mi], acc[ni][mi]);
+                        for (int mi = 0; mi < HFA; ++mi) mma(KB0, bw[kb & 3][ni], fxa[mi], ni, acc[ni][mi]);
                     if (kb + 1 < PF_KB) loadA(fxa, kb + 1, 0);
 #pragma unroll
                     for (int ni = 0; ni < NFR; ++ni)
 #pragma unroll
-                        for (int mi = 0; mi < HFB; ++mi) Mma16<bf16>::step(bw[kb & 3][ni], fxb[mi], acc[ni][HFA + mi]);
-                }
-            } else {
-#pragma unroll
-                for (int kb = 0; kb < PF_KB; ++kb) {
-                    loadB(bw[(kb + 3) & 3], (l * PF_TAPS + tp) * PF_KB + kb + 3);
+                        for (int mi = 0; mi < HFB; ++mi) mma(KB0, bw[kb & 3][ni], fxb[mi], ni, acc[ni][HFA + mi]);
+                } else {
 #pragma unroll
                     for (int hf = 0; hf < 2; ++hf) {
                         const int m0 = hf * HFA, cnt = hf ? HFB : HFA;
-                        uint4 fx[HFA];
-                        loadA(fx, kb, hf);
+                        loadA(fxa, kb, hf);
 #pragma unroll
                         for (int ni = 0; ni < NFR; ++ni)
 #pragma unroll
                             for (int mi = 0; mi < HFA; ++mi)
-                                if (mi < cnt) Mma16<bf16>::step(bw[kb & 3][ni], fx[mi], acc[ni][m0 + mi]);
+                                if (mi < cnt) mma(KB0, bw[kb & 3][ni], fxa[mi], ni, acc[ni][m0 + mi]);
                     }
                 }
-            }
-        }
+            };
+            uint4 fxa[HFA], fxb[HFA];
+            if constexpr (MINW == 1 || PF_PREFETCH) loadA(fxa, 0, 0);
+            kblock(std::integral_constant<bool, first>{}, 0, fxa, fxb);
+#pragma unroll
+            for (int kb = 1; kb < PF_KB; ++kb) kblock(std::false_type{}, kb, fxa, fxb);
+        };
+        tap(0, std::true_type{});
+#pragma unroll 1
+        for (int tp = 1; tp < PF_TAPS; ++tp) tap(tp, std::false_type{});
 
-        // ---- ReLU ----  lane: rows (m*16 + fr), channels n0 + 32*(ni>>1) + (ni&1)*4 + r
+        // ---- ReLU + LayerNorm (r03: packed fp32) ----  lane: rows (m*16 + fr), channels n0 + 32*(ni>>1) + (ni&1)*4 + r.
+        // The epilogue's VALU stream runs NEXT to the co-resident workgroup's MFMAs on the same SIMD and the two add up:
+        // before, ~1400 VALU per layer and wave against 672 MFMAs (fmaxf on an MFMA result = a canonicalising v_max + the v_max,
+        // scalar adds / subtracts / squares, an IEEE 1/sqrt of ~35 instructions per row).  Now: one v_max per element, the row
+        // sums / centring / squares on v_pk_add_f32 / v_pk_fma_f32 (two elements per instruction; the partial sums pair up as
+        // (even, odd) slots of a fragment), v_rsq_f32 for the reciprocal root (1 ulp; the per-layer path keeps the IEEE form).
+#if defined(FS2_PF_PROBE) && (FS2_PF_PROBE & 2)
+        {   // probe: no ReLU / LayerNorm / slab rewrite - the K loops alone (the sum keeps the MFMAs alive)
+            f32x4_t s4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ni = 0; ni < NFR; ++ni)
+            for (int ni = 0; ni < NFR; ++ni)
 #pragma unroll
-            for (int m = 0; m < MI16; ++m)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[ni][m][r] = fmaxf(acc[ni][m][r], 0.f);
-        // ---- LayerNorm statistics, two-pass: lane partial -> lane groups -> the column waves via LDS
+                for (int m = 0; m < MI16; ++m) s4 += acc[ni][m];
+            if (s4.x + s4.y + s4.z + s4.w == 12345.678f) red[0][tid] = s4.x;
+            __syncthreads();
+            continue;
+        }
+#endif
+        auto relu = [](float x) { float y; asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x)); return y; };
         const float invn = 1.0f / (float)PF_H;
         float mean[MI16], rstd[MI16];
 #pragma unroll
         for (int m = 0; m < MI16; ++m) {
-            float sm = 0.f;
+            f32x2_t s2 = {0.f, 0.f};
 #pragma unroll
-            for (int ni = 0; ni < NFR; ++ni) sm += (acc[ni][m][0] + acc[ni][m][1]) + (acc[ni][m][2] + acc[ni][m][3]);
-            sm = group4_sum(sm);
+            for (int ni = 0; ni < NFR; ++ni) {
+                f32x4_t& a = acc[ni][m];
+                a = (f32x4_t){relu(a[0]), relu(a[1]), relu(a[2]), relu(a[3])};
+                s2 += a.xy;
+                s2 += a.zw;
+            }
+            const float sm = group4_sum(s2.x + s2.y);
             if (fg == 0) red[0][wv * R + m * 16 + fr] = sm;
         }
         __syncthreads();  // also: every wave is past its K loop -> the slab may be rewritten below
@@ -198,16 +236,17 @@ __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(Predict
 #pragma unroll
             for (int w = 0; w < NWV; ++w) t8 += red[0][w * R + row];
             mean[m] = t8 * invn;
-            float q = 0.f;
+            const f32x2_t mn2 = {mean[m], mean[m]};
+            f32x2_t q2 = {0.f, 0.f};
 #pragma unroll
-            for (int ni = 0; ni < NFR; ++ni)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float d = acc[ni][m][r] - mean[m];
-                    acc[ni][m][r] = d;  // kept: the normalisation below needs the same difference
-                    q = __builtin_fmaf(d, d, q);
-                }
-            q = group4_sum(q);
+            for (int ni = 0; ni < NFR; ++ni) {
+                f32x4_t& a = acc[ni][m];
+                const f32x2_t d0 = a.xy - mn2, d1 = a.zw - mn2;  // kept: the normalisation below needs the same difference
+                a = (f32x4_t){d0.x, d0.y, d1.x, d1.y};
+                q2 = __builtin_elementwise_fma(d0, d0, q2);
+                q2 = __builtin_elementwise_fma(d1, d1, q2);
+            }
+            const float q = group4_sum(q2.x + q2.y);
             if (fg == 0) red[1][wv * R + row] = q;
         }
         __syncthreads();
@@ -217,7 +256,7 @@ __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(Predict
             float t8 = 0.f;
 #pragma unroll
             for (int w = 0; w < NWV; ++w) t8 += red[1][w * R + row];
-            rstd[m] = 1.0f / sqrtf(t8 * invn + p.eps);
+            rstd[m] = __builtin_amdgcn_rsqf(t8 * invn + p.eps);
         }
         const bool last = l + 1 == nl;
         float dsum[MI16];
@@ -226,33 +265,39 @@ __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(Predict
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             const int n = n0 + 32 * j;
-            float gg[8], ee[8], hw[8];
+            f32x2_t gg[4], ee[4], hw[4];
             {
                 const float* gam = p.ln_g + l * PF_H + n;
                 const float* bet = p.ln_b + l * PF_H + n;
                 const float4 g0 = *(const float4*)gam, g1 = *(const float4*)(gam + 4);
                 const float4 e0 = *(const float4*)bet, e1 = *(const float4*)(bet + 4);
-                gg[0] = g0.x; gg[1] = g0.y; gg[2] = g0.z; gg[3] = g0.w; gg[4] = g1.x; gg[5] = g1.y; gg[6] = g1.z; gg[7] = g1.w;
-                ee[0] = e0.x; ee[1] = e0.y; ee[2] = e0.z; ee[3] = e0.w; ee[4] = e1.x; ee[5] = e1.y; ee[6] = e1.z; ee[7] = e1.w;
+                gg[0] = (f32x2_t){g0.x, g0.y}; gg[1] = (f32x2_t){g0.z, g0.w}; gg[2] = (f32x2_t){g1.x, g1.y}; gg[3] = (f32x2_t){g1.z, g1.w};
+                ee[0] = (f32x2_t){e0.x, e0.y}; ee[1] = (f32x2_t){e0.z, e0.w}; ee[2] = (f32x2_t){e1.x, e1.y}; ee[3] = (f32x2_t){e1.z, e1.w};
                 if (last) {
                     const float4 h0 = *(const float4*)(p.head_w + n), h1 = *(const float4*)(p.head_w + n + 4);
-                    hw[0] = h0.x; hw[1] = h0.y; hw[2] = h0.z; hw[3] = h0.w; hw[4] = h1.x; hw[5] = h1.y; hw[6] = h1.z; hw[7] = h1.w;
+                    hw[0] = (f32x2_t){h0.x, h0.y}; hw[1] = (f32x2_t){h0.z, h0.w}; hw[2] = (f32x2_t){h1.x, h1.y}; hw[3] = (f32x2_t){h1.z, h1.w};
                 }
             }
 #pragma unroll
             for (int m = 0; m < MI16; ++m) {
                 const int row = m * 16 + fr, t = t0 + row, i = row + 1;
-                float y[8];
+                const f32x2_t rs2 = {rstd[m], rstd[m]};
+                f32x2_t y[4];
 #pragma unroll
-                for (int r = 0; r < 8; ++r) y[r] = __builtin_fmaf(acc[2 * j + (r >> 2)][m][r & 3] * rstd[m], gg[r], ee[r]);
+                for (int r = 0; r < 4; ++r) {
+                    const f32x4_t& a = acc[2 * j + (r >> 1)][m];
+                    y[r] = __builtin_elementwise_fma((r & 1 ? a.zw : a.xy) * rs2, gg[r], ee[r]);
+                }
                 if (last) {
+                    f32x2_t d2 = {dsum[m], 0.f};
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) dsum[m] = __builtin_fmaf(y[r], hw[r], dsum[m]);
+                    for (int r = 0; r < 4; ++r) d2 = __builtin_elementwise_fma(y[r], hw[r], d2);
+                    dsum[m] = d2.x + d2.y;
                 } else {
                     // next layer's input, in place; rows outside the utterance stay the conv's zero padding
                     const bool inside = t >= 0 && t < S;
-                    const uint4 o = inside ? make_uint4(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]),
-                                                        pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7]))
+                    const uint4 o = inside ? make_uint4(pack_bf16x2(y[0].x, y[0].y), pack_bf16x2(y[1].x, y[1].y),
+                                                        pack_bf16x2(y[2].x, y[2].y), pack_bf16x2(y[3].x, y[3].y))
                                            : make_uint4(0u, 0u, 0u, 0u);
                     *(uint4*)(slab + i * PF_ROWB + (SlabSwizzle(PF_ROWB / 16).slot(n >> 3, i) << 4)) = o;
                 }

@@ -7,7 +7,7 @@ set -e
 NAME=$1; shift
 D=lightningfastspeech2_amd/csrc; V=lightningfastspeech2_amd/variants; O=$V/obj_$NAME; mkdir -p $O
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$D $EXTRA"
-ALL="gemm_mfma attention predictor_fused rowops capi_ops engine vocoder_conv vocoder_resblock vocoder_engine loss"
+ALL=$(for f in $D/*.hip; do basename $f .hip; done)
 REPL=""
 for f in "$@"; do b=$(basename $f .hip); REPL="$REPL $b"; /opt/rocm/bin/hipcc $FLAGS -c $f -o $O/$b.o & done
 wait
