@@ -64,7 +64,9 @@ __global__ void pack_predictor_weights_kernel(const bf16* __restrict__ W, uint4*
 //   starting the second one 1-12 us late changes nothing (the delay is absorbed, no more), so the lever is instruction count.
 //   Taken: the epilogue on packed fp32 (~1400 -> ~750 VALU per layer and wave), the A-fragment halves requested one half ahead,
 //   the bias as the C operand of a chain's first MFMA: 113 -> 106 us.  The epilogue change alone measured nothing until the
-//   fragment prefetch was in (its LDS round trips sat in front of every half's MFMAs).
+//   fragment prefetch was in (its LDS round trips sat in front of every half's MFMAs).  hipcc still sinks most fragment reads to
+//   just before their first use (a __builtin_amdgcn_sched_group_barrier pattern per k-block made that worse, not better): what is
+//   left in the K loop needs the reads and their waits as asm statements, the attention_pipe.hip way - not done.
 template <int MI16, int NWV, int MINW>
 __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(PredictorArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins exist in the device pass only
