@@ -232,6 +232,13 @@ int fs2_op_set_vocoder_lds_limit(int32_t kib);
 int fs2_op_set_vocoder_fused_resblock(int32_t on);
 int fs2_op_gemm(int32_t dtype, int32_t out_dtype, const void* x, const void* w, const float* bias, void* c,
                 int32_t M, int32_t N, int32_t Cin, int32_t taps, int32_t S, int32_t relu, void* hip_stream);
+/* Split-K form for long reductions over few row tiles (training step: the encoder-side data-gradient convs, M = B L rows, K = taps x
+ * filter): ksplit (from fs2_op_gemm_splitk_choice; 1 = not worth it -> use fs2_op_gemm) slices of the input channels run as separate
+ * workgroups of ONE launch into fp32 planes part (ksplit, M, N), a second launch adds the planes in order:
+ * c (out_dtype) = [c +] sum_s part[s].  No bias / ReLU.  FS2_ERR_SHAPE when the shape does not run on the slab kernel. */
+int fs2_op_gemm_splitk_choice(int32_t dtype, int32_t M, int32_t N, int32_t Cin, int32_t taps, int32_t S);
+int fs2_op_gemm_splitk(int32_t dtype, int32_t out_dtype, const void* x, const void* w, void* c, float* part, int32_t M, int32_t N,
+                       int32_t Cin, int32_t taps, int32_t S, int32_t ksplit, int32_t accumulate, void* hip_stream);
 /* ... with the ReLU (and dropout) backward of a data-gradient product folded into the store: c = gate > 0 ? scale * (x w^T + bias)
  * : 0, gate (M, N) in the launch dtype (training step: dh = (dc2 . W2) o [h > 0] / (1 - p), h = dropout(relu(.)) of the forward:
  * h > 0 <=> kept and pre-activation > 0, model.py:84-90 backwards).  FS2_ERR_SHAPE when the shape does not run on the slab kernel

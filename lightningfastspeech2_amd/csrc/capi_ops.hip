@@ -117,6 +117,23 @@ int fs2_op_gemm(int32_t dtype, int32_t out_dtype, const void* x, const void* w, 
     return launch_gemm(a, dtype, out_dtype, (hipStream_t)stream);
 }
 
+int fs2_op_gemm_splitk_choice(int32_t dtype, int32_t M, int32_t N, int32_t Cin, int32_t taps, int32_t S) {
+    return gemm_splitk_choice(M, N, Cin, taps, S, dtype);
+}
+
+int fs2_op_gemm_splitk(int32_t dtype, int32_t out_dtype, const void* x, const void* w, void* c, float* part, int32_t M, int32_t N,
+                       int32_t Cin, int32_t taps, int32_t S, int32_t ksplit, int32_t accumulate, void* stream) {
+    if (ksplit < 2 || !part) return FS2_ERR_ARG;
+    GemmArgs a;
+    a.X = x; a.W = w; a.bias = nullptr; a.C = part;
+    a.M = M; a.N = N; a.K = taps * Cin; a.ldx = Cin; a.ldc = N;
+    a.Cin = Cin; a.taps = taps; a.pad = (taps - 1) / 2; a.S = S; a.relu = 0;
+    a.ksplit = ksplit;
+    const int r = launch_gemm(a, dtype, FS2_F32, (hipStream_t)stream);
+    if (r != FS2_OK) return r;
+    return launch_split_k_reduce(part, c, (size_t)M * N, ksplit, accumulate, out_dtype, (hipStream_t)stream);
+}
+
 int fs2_op_gemm_gated(int32_t dtype, const void* x, const void* w, const float* bias, const void* gate, float scale, void* c, int32_t M,
                       int32_t N, int32_t Cin, int32_t taps, int32_t S, void* stream) {
     if (!gate) return FS2_ERR_ARG;

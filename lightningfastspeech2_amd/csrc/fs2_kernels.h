@@ -46,8 +46,14 @@ struct GemmArgs {
     const uint8_t* zero_rows = nullptr;  // (M) 1 = store zeros for this row (128x128 kernel only: the mel head)
     const void* gate = nullptr;     // slab kernel, plain epilogue: C = gate > 0 ? gate_scale * (acc + bias) : 0; gate has C's shape, ldc and dtype
     float gate_scale = 1.f;
+    int ksplit = 0;                 // > 1: split-K on the slab kernel (plain epilogue, fp32 out, no bias / ReLU / gate): split s sums the channel
+                                    // blocks [s, s + 1) * Cin / ksplit of every tap into plane s of C (ksplit, M, ldc); launch_split_k_reduce adds them
 };
 int launch_gemm(const GemmArgs& a, int in_dtype, int out_dtype, hipStream_t stream);
+// out (M, N) in out_dtype = [out +] sum over s of part[s] (fp32 planes of n = M * N elements, n % 4 == 0), fixed order
+int launch_split_k_reduce(const float* part, void* out, size_t n, int ksplit, int accumulate, int out_dtype, hipStream_t stream);
+// the split a long-K, few-tile GEMM / conv is worth (1 = none): tools/bench_ops.py dgrad
+int gemm_splitk_choice(int M, int N, int Cin, int taps, int S, int in_dtype);
 extern int g_gemm_variant;
 extern int g_gemm_wres;  // 1 = bf16 K = 256 plain GEMMs on the weight-resident kernel (gemm_wres.hip)
 bool gemm_wres_supported(const GemmArgs& a, int in_dtype, int out_dtype, bool force);

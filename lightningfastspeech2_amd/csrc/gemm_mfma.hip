@@ -413,20 +413,31 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
         const int nt = gridDim.x, per = nt >> 3, rem = nt & 7, xcd = bid & 7;
         bid = xcd * per + (xcd < rem ? xcd : rem) + (bid >> 3);
     }
+    // Split-K launches (p.ksplit > 1; plain epilogue, OutT = float): split ks owns a contiguous range of the Cin / KE channel blocks (all
+    // taps) and stores its partial sums into plane ks of C, (ksplit, M, ldc); split_k_reduce_kernel adds the planes up.  ks is the
+    // SLOWEST tile index, so an XCD's contiguous tile range reads one or two weight slices, not the whole panel.
+    int ks = 0;
+    if constexpr (!LN && !WIDE && !DEFER) {
+        if (p.ksplit > 1) {
+            const int per_split = gridDim.x / p.ksplit;
+            ks = bid / per_split;
+            bid -= ks * per_split;
+        }
+    }
     int bn = 0;
     if constexpr (!WIDE) { bn = bid % tiles_n; bid /= tiles_n; }
     const int tm = bid % tiles_m, ub = bid / tiles_m;
     if (ub >= nutt) return;
     const int t0 = tm * BMs;
     int n0 = bn * S_BN;
-    const T* __restrict__ Xu = (const T*)p.X + (size_t)ub * S * p.ldx;  // this utterance's rows
-    const int ntap = p.taps, ncc = p.Cin / KE;
+    const int ntap = p.taps, ncc = p.Cin / KE / (p.ksplit > 1 ? p.ksplit : 1), cc0 = ks * ncc;
+    const T* __restrict__ Xu = (const T*)p.X + (size_t)ub * S * p.ldx + cc0 * KE;  // this utterance's rows (this split's channels)
     // Operands are fetched with buffer loads straight into LDS: a descriptor per operand in SGPRs,
     // one 32-bit byte offset per lane per DMA, the channel/tap advance in the scalar offset.  Lanes
     // whose row must read as zero (outside the utterance, M/N tails) carry an out-of-range offset:
     // the hardware bounds check returns zeros for them.
     constexpr unsigned OOB = 0xFFFFF000u;
-    const unsigned xbytes = (unsigned)(((size_t)(S - 1) * p.ldx + p.Cin) * sizeof(T));
+    const unsigned xbytes = (unsigned)(((size_t)(S - 1) * p.ldx + p.Cin - cc0 * KE) * sizeof(T));
     const unsigned wbytes = (unsigned)((size_t)p.N * p.K * sizeof(T));
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)Xu, 0, xbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, wbytes, 0x00020000);
@@ -464,7 +475,7 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
     };
     auto issue_w = [&](unsigned char* dst, int cc, int tap) {
         if (!dma_wave) return;
-        const int koff = (tap * p.Cin + cc * KE) * (int)sizeof(T);
+        const int koff = (tap * p.Cin + (cc0 + cc) * KE) * (int)sizeof(T);
 #pragma unroll
         for (int i = 0; i < DWI; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)(dst + (i * DW + wave) * 1024),
@@ -979,7 +990,7 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
         }
         return;
     }
-    OutT* __restrict__ C = (OutT*)p.C + (size_t)ub * S * p.ldc;
+    OutT* __restrict__ C = (OutT*)p.C + ((size_t)ks * p.M + (size_t)ub * S) * p.ldc;
     // lane (fr, fg) holds, for output row t, the 8 consecutive channels n .. n+7 of each fragment
     // pair (2j, 2j+1): one 16-byte (bf16) / two 16-byte (fp32) stores, 64 contiguous bytes per row
     // across the four lane groups; the two halves (j = 0, 1) of a row's 128-byte line go out back to back
@@ -1170,7 +1181,7 @@ static int launch_slab_t(const GemmArgs& a0, hipStream_t stream) {
     if (a.taps == 1) a.S = a.M;  // plain GEMM: one "utterance" of M rows
     a.xcd_remap = g_slab_xcd_remap;
     const int BMs = SlabCfg<MI>::BM;
-    const int tiles = (a.M / a.S) * ((a.S + BMs - 1) / BMs) * (WIDE ? 1 : (a.N + S_BN - 1) / S_BN);
+    const int tiles = (a.M / a.S) * ((a.S + BMs - 1) / BMs) * (WIDE ? 1 : (a.N + S_BN - 1) / S_BN) * (a.ksplit > 1 ? a.ksplit : 1);
     hipLaunchKernelGGL((gemm_conv_slab_kernel<T, OutT, MI, LN, WIDE, SPLIT, DEFER>), dim3(tiles), dim3(512), 0, stream, a);
     return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
 }
@@ -1235,7 +1246,7 @@ static int launch_gemm_plain(const GemmArgs& a, int in_dtype, int out_dtype, hip
 int launch_gemm(const GemmArgs& a, int in_dtype, int out_dtype, hipStream_t stream) {
     if (!a.ln_g) {
         // K = 256 bf16: the column tile's weights live in registers, row tiles stream (gemm_wres.hip; bit-identical results)
-        if (g_gemm_wres && g_gemm_variant == 0 && gemm_wres_supported(a, in_dtype, out_dtype, g_gemm_wres == 2)) return launch_gemm_wres(a, stream);
+        if (g_gemm_wres && g_gemm_variant == 0 && a.ksplit <= 1 && gemm_wres_supported(a, in_dtype, out_dtype, g_gemm_wres == 2)) return launch_gemm_wres(a, stream);
         return launch_gemm_plain(a, in_dtype, out_dtype, stream, nullptr);
     }
     // fused row epilogue requested: try the slab kernel (whole rows per workgroup), else GEMM -> ln_tmp
@@ -1280,6 +1291,10 @@ static int launch_gemm_plain(const GemmArgs& a, int in_dtype, int out_dtype, hip
     const int variant = g_gemm_variant;  // 0 = auto, 1 = 128x128 register-staged, 2 = 128x256 DMA ring,
                                          // 3/4/5 = slab kernel with 128/192/256-row tiles
     const bool slab_ok = a.M % a.S == 0 && (a.taps & 1);
+    const int ksp = a.ksplit > 1 ? a.ksplit : 1;
+    if (ksp > 1 && (fused || a.bias || a.relu || a.gate || a.stats_out || a.epi_res || a.zero_rows || out_dtype != FS2_F32 || !slab_ok ||
+                    a.N < 192 || (a.Cin / ke) % ksp || (variant != 0 && (variant < 3 || variant > 7))))
+        return FS2_ERR_SHAPE;  // split-K: the slab kernel's plain fp32 store only
     if (variant >= 6 && variant <= 7 && slab_ok) {  // 6/7 = slab kernel with 32/64-row tiles
         if (fused) *fused = true;
         if (variant == 6) return launch_slab<1>(a, in_dtype, out_dtype, stream);
@@ -1313,13 +1328,13 @@ static int launch_gemm_plain(const GemmArgs& a, int in_dtype, int out_dtype, hip
             if ((fused || a.stats_out || a.epi_res) && mi > 6) continue;  // 256-row tiles spill with either LayerNorm epilogue
             const long bm = mi * 32, tm = (S + bm - 1) / bm;
             const bool wide = fused && tn > 1;  // one workgroup per row tile walks all tn column tiles
-            const long tiles = (long)nutt * tm * (wide ? 1 : tn);
+            const long tiles = (long)nutt * tm * (wide ? 1 : tn) * ksp;
             long cost = ((tiles + 255) / 256) * (bm + 40) * (wide ? tn : 1);
             // long reductions (K >= 4096: the data-gradient convs of the training step, K = taps * filter): every workgroup
             // streams the whole K x 256 weight panel out of L2, and tiles x panel bytes over the ~10 TB/s the L2s deliver
             // together becomes the bound before the CUs fill - in the same units (one row of MFMA work per K) that is ~1 per
             // tile.  C5 encoder conv1 dgrad (M = 2048, N = 1024, K = 36864): 256 x 32-row tiles 500 us -> 128 x 64-row tiles.
-            if (a.K >= 4096 && !wide) cost = cost > tiles ? cost : tiles;
+            if (a.K / ksp >= 4096 && !wide) cost = cost > tiles ? cost : tiles;
             if (!best || cost < best_cost) { best = mi; best_cost = cost; best_rows = (long)nutt * tm * bm; }
         }
         if (best_rows <= 2L * a.M) {
@@ -1332,11 +1347,62 @@ static int launch_gemm_plain(const GemmArgs& a, int in_dtype, int out_dtype, hip
         }
     }
     if (fused) return FS2_OK;  // not the slab kernel: caller falls back to GEMM + LayerNorm kernel
-    if (a.stats_out || a.epi_res || a.gate) return FS2_ERR_SHAPE;  // the deferred-LayerNorm epilogue lives in the slab kernel only
+    if (a.stats_out || a.epi_res || a.gate || ksp > 1) return FS2_ERR_SHAPE;  // the deferred-LayerNorm epilogue lives in the slab kernel only
     if (in_dtype == FS2_F32 && out_dtype == FS2_F32) return launch_t<float, float>(a, stream);
     if (in_dtype == FS2_BF16 && out_dtype == FS2_BF16) return launch_t<bf16, bf16>(a, stream);
     if (in_dtype == FS2_BF16 && out_dtype == FS2_F32) return launch_t<bf16, float>(a, stream);
     return FS2_ERR_SHAPE;
+}
+
+// ---- split-K: planes -> output ----------------------------------------------------------------------------------------------
+// out[i] = [out[i] +] ((p0 + p1) + p2) + ... in plane order (deterministic), 4 elements per thread, 16-byte plane loads
+template <typename OutT>
+__global__ __launch_bounds__(256) void split_k_reduce_kernel(const float* __restrict__ part, OutT* __restrict__ out, size_t n, int ksplit,
+                                                             int accumulate) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    float4 a = *(const float4*)(part + i);
+    for (int s = 1; s < ksplit; ++s) {
+        const float4 b = *(const float4*)(part + (size_t)s * n + i);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    if constexpr (sizeof(OutT) == 4) {
+        float4* o = (float4*)(out + i);
+        if (accumulate) { const float4 c = *o; a.x += c.x; a.y += c.y; a.z += c.z; a.w += c.w; }
+        *o = a;
+    } else {
+        uint2* o = (uint2*)(out + i);
+        if (accumulate) {
+            const uint2 c = *o;
+            a.x += __uint_as_float(c.x << 16); a.y += __uint_as_float(c.x & 0xffff0000u);
+            a.z += __uint_as_float(c.y << 16); a.w += __uint_as_float(c.y & 0xffff0000u);
+        }
+        *o = make_uint2(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w));
+    }
+}
+
+int launch_split_k_reduce(const float* part, void* out, size_t n, int ksplit, int accumulate, int out_dtype, hipStream_t stream) {
+    if (!part || !out || ksplit < 1 || n % 4 || (out_dtype != FS2_F32 && out_dtype != FS2_BF16)) return FS2_ERR_ARG;
+    if (!n) return FS2_OK;
+    const dim3 g((unsigned)((n / 4 + 255) / 256));
+    if (out_dtype == FS2_F32) hipLaunchKernelGGL(split_k_reduce_kernel<float>, g, dim3(256), 0, stream, part, (float*)out, n, ksplit, accumulate);
+    else hipLaunchKernelGGL(split_k_reduce_kernel<bf16>, g, dim3(256), 0, stream, part, (bf16*)out, n, ksplit, accumulate);
+    return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
+}
+
+// A long reduction over few row tiles (the encoder-side data-gradient convs of the training step: M = 8192, N = 256, K = 9 x 1024)
+// leaves every workgroup streaming the whole K x 256 weight panel at the CU's ~64 GB/s ingest rate with half the CUs idle
+// (130 us at C2).  Split over K so that 128-row tiles fill the chip once: 1/ksplit of the panel per workgroup.
+int gemm_splitk_choice(int M, int N, int Cin, int taps, int S, int in_dtype) {
+    const int ke = in_dtype == FS2_BF16 ? 64 : 32;
+    if (taps < 1 || !(taps & 1) || N < 192 || Cin % ke || (long)taps * Cin < 2048) return 1;
+    if (taps == 1) S = M;
+    if (S <= 0 || M % S) return 1;
+    const long tiles = (long)(M / S) * ((S + 127) / 128) * ((N + S_BN - 1) / S_BN);
+    int best = 1;
+    for (int k = 2; k <= 8; k *= 2)
+        if ((Cin / ke) % k == 0 && tiles * k <= 256 && (long)taps * Cin / k >= 1024) best = k;
+    return best;
 }
 
 }  // namespace fs2

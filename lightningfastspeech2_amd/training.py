@@ -59,6 +59,7 @@ class _Ops:
         self.seed = 0       # dropout: set per micro-step by the trainer
         self._site = 0      # dropout site counter of the current forward
         self.fuse_ln = os.environ.get("FS2_TRAIN_FUSE_LN", "1") != "0"  # A/B switch: GEMM + LayerNorm as one launch where it applies
+        self.splitk = os.environ.get("FS2_TRAIN_SPLITK", "1") != "0"    # A/B switch: split-K data-gradient convs where fs2_op_gemm_splitk_choice says so
 
     def site(self):
         self._site += 1
@@ -225,6 +226,18 @@ class _Ops:
         """dX (M, Cin) = dY (M, N) . W: with the transposed / tap-flipped copy wt (Cin, taps*N) through the forward
         GEMM / slab-conv kernel (dX is a 'same' conv of dY with wt), else through the strided-batched GEMM."""
         if wt is not None and N % 64 == 0 and Cin % 64 == 0 and dy.dtype == wt.dtype:
+            # a long reduction over few row tiles (encoder conv1: M = B L, K = taps x filter): K slices as workgroups of one launch
+            # into fp32 planes, the plane sum folds the "+=" of an accumulating call (no separate add launch)
+            ks = int(self.lib.fs2_op_gemm_splitk_choice(self.dt, M, Cin, N, taps, S or M)) if (gate is None and self.splitk) else 1
+            if ks > 1:
+                dx = out if out is not None else self.act(M, Cin)
+                part = self.empty(ks, M, Cin)
+                st_ = self.lib.fs2_op_gemm_splitk(self.dt, self._dt(dx), _p(dy), _p(wt), _p(dx), _p(part), M, Cin, N, taps, S or M, ks,
+                                                  int(bool(accumulate and out is not None)), self.st())
+                if st_ == 0:
+                    return dx
+                if st_ != _lib.FS2_ERR_SHAPE:
+                    self.ck(st_, "gemm_splitk")
             dx = self.gemm(dy, wt, None, M, Cin, N, taps=taps, S=S, gate=gate, gate_scale=gate_scale)
             if out is None:
                 return dx

@@ -54,6 +54,21 @@ def gemm(dtype, x, w_packed, bias, taps=1, S=None, relu=False, out_dtype=None):
     return c.float().cpu()
 
 
+def gemm_splitk(dtype, x, w_packed, ksplit, taps=1, S=None, out_dtype=None, into=None):
+    """fs2_op_gemm_splitk: K slices as workgroups of one launch into fp32 planes + the plane sum; into = a tensor the result is
+    ADDED to (the accumulating data-gradient call of the training step)."""
+    M, Cin = x.shape
+    N = w_packed.shape[0]
+    out_dtype = dtype if out_dtype is None else out_dtype
+    xd, wd = to_dev(x, dtype), to_dev(w_packed, dtype)
+    c = torch.empty(M, N, dtype=tdt(out_dtype), device=DEV) if into is None else to_dev(into, out_dtype).clone()
+    part = torch.empty(ksplit, M, N, dtype=torch.float32, device=DEV)
+    ok(lib().fs2_op_gemm_splitk(dtype, out_dtype, p(xd), p(wd), p(c), p(part), M, N, Cin, taps, S or M, ksplit, int(into is not None),
+                                stream()), "gemm_splitk")
+    torch.cuda.synchronize()
+    return c.float().cpu()
+
+
 def gemm_ln(dtype, x, w_packed, bias, res, g, b, taps=1, S=None, relu=False, dot_w=None, dot_b=0.0, mask=None, want_y=True):
     M, Cin = x.shape
     N = w_packed.shape[0]

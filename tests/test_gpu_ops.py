@@ -289,6 +289,40 @@ def test_predictor_tile_heights_are_bit_identical():
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,S,Cin,N,k,ks", [(8, 256, 1024, 256, 9, 4), (3, 200, 512, 256, 3, 2), (1, 640, 512, 512, 1, 8), (5, 77, 256, 192, 5, 2)])
+def test_gemm_split_k_matches_the_one_pass_kernel(dtype, B, S, Cin, N, k, ks):
+    """Split-K on the slab kernel (the encoder-side data-gradient convs of the training step: few row tiles, a long reduction): K
+    slices of the input channels as workgroups of one launch, fp32 planes, plane sum.  Against torch, against the one-pass kernel
+    (same products, another summation order: fp32 rounding apart), accumulating into an existing tensor, repeatable."""
+    x = rnd(B, S, Cin, seed=300)
+    w = rnd(N, Cin, k, seed=301, scale=(Cin * k) ** -0.5)
+    ref = F.conv1d(G.rounded(x, dtype).transpose(1, 2), G.rounded(w, dtype), None, padding="same").transpose(1, 2).reshape(B * S, N)
+    xs, wp = x.reshape(B * S, Cin), G.pack_conv_weight(w)
+    one = G.gemm(dtype, xs, wp, None, taps=k, S=S, out_dtype=G.F32)
+    runs = [G.gemm_splitk(dtype, xs, wp, ks, taps=k, S=S, out_dtype=G.F32) for _ in range(2)]
+    assert torch.equal(runs[0], runs[1])
+    assert float((runs[0] - ref).abs().max()) <= tol(dtype, ref)
+    assert float((runs[0] - one).abs().max()) <= 1e-4 * (float(ref.abs().max()) + 1)
+    base = rnd(B * S, N, seed=302)
+    acc = G.gemm_splitk(dtype, xs, wp, ks, taps=k, S=S, into=base)   # out dtype = the activation dtype, out += product
+    want = G.rounded(base, dtype) + runs[0]
+    assert float((acc - want).abs().max()) <= (2e-2 if dtype == G.BF16 else 1e-5) * (float(want.abs().max()) + 1)
+    # what the launcher offers for this shape is a split the kernel accepts
+    c = int(G.lib().fs2_op_gemm_splitk_choice(dtype, B * S, N, Cin, k, S))
+    assert c >= 1 and (c == 1 or (Cin // (64 if dtype == G.BF16 else 32)) % c == 0)
+
+
+def test_gemm_split_k_rejects_what_it_cannot_run():
+    x, w = rnd(256, 256, seed=1), rnd(256, 256, seed=2)
+    xd, wd = G.to_dev(x, G.BF16), G.to_dev(w, G.BF16)
+    c = torch.empty(256, 256, dtype=torch.bfloat16, device=G.DEV)
+    part = torch.empty(3, 256, 256, dtype=torch.float32, device=G.DEV)
+    # 256 channels = 4 blocks of 64: 3 does not divide them
+    assert G.lib().fs2_op_gemm_splitk(G.BF16, G.BF16, G.p(xd), G.p(wd), G.p(c), G.p(part), 256, 256, 256, 1, 256, 3, 0, G.stream()) != 0
+    assert G.lib().fs2_op_gemm_splitk(G.BF16, G.BF16, G.p(xd), G.p(wd), G.p(c), None, 256, 256, 256, 1, 256, 2, 0, G.stream()) != 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_dma_pipeline_large_and_repeatable(dtype):
     """Full-size decoder conv tile stream (K = 9*256 -> 36 chunks through the 3-stage DMA ring),
     many workgroups per CU in flight: compare with torch and demand bit-identical reruns (a DMA /

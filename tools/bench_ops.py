@@ -62,6 +62,16 @@ def gemm_case(name, M, N, Cin, taps, S, reps, variant):
         print(f"{'  (hipBLASLt via torch, no bias)':28s} {'':40s} {tl*1e6:8.1f} us  {fl/tl/1e12:7.1f} TF")
 
 
+def splitk_case(name, M, N, Cin, taps, S, ks, reps):
+    x = torch.randn(M, Cin, device=DEV).to(torch.bfloat16)
+    w = (torch.randn(N, taps * Cin, device=DEV) * (taps * Cin) ** -0.5).to(torch.bfloat16)
+    c = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    part = torch.empty(ks, M, N, device=DEV)
+    t = timeit(lambda st: lib.fs2_op_gemm_splitk(BF16, BF16, p(x), p(w), p(c), p(part), M, N, Cin, taps, S, ks, 1, st), reps)
+    fl = 2.0 * M * N * Cin * taps
+    print(f"{name:34s} M={M} N={N} K={taps}x{Cin}  {t * 1e6:8.1f} us  {fl / t / 1e12:7.1f} TF  (launch + plane sum, accumulating)")
+
+
 def gemm_ln_case(name, M, N, Cin, taps, S, reps, variant, res=True, relu=False):
     """GEMM/conv + fused LayerNorm epilogue (the N=256 launches of the forward)."""
     lib.fs2_op_set_gemm_variant(variant)
@@ -239,6 +249,11 @@ def main():
             gemm_case("enc in_proj", 8192, 768, 256, 1, 8192, a.reps, v)
             gemm_case("dur-pred conv k=3", 8192, 256, 256, 3, 256, a.reps, v)
             gemm_case("square 4096^3", 4096, 4096, 4096, 1, 4096, a.reps, v)
+    if a.what == "splitk":  # the same data-gradient convs one pass vs split over K (fs2_op_gemm_splitk)
+        for name, M, N, Cin, taps, S in (("c2 enc conv1 dgrad", 8192, 256, 1024, 9, 256), ("c5 enc conv1 dgrad", 2048, 1024, 4096, 9, 256)):
+            gemm_case(name + " one pass", M, N, Cin, taps, S, a.reps, 0)
+            for ks in (2, 4, 8):
+                splitk_case(name + f" split {ks}", M, N, Cin, taps, S, ks, a.reps)
     if a.what == "dgrad":  # data-gradient convs of the training step: long reductions (K = taps x filter) at few rows
         for v in ([0, 6, 7, 3, 4, 5] if a.variant < 0 else [a.variant]):
             gemm_case("c2 enc conv1 dgrad", 8192, 256, 1024, 9, 256, a.reps, v)
