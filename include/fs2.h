@@ -232,6 +232,11 @@ int fs2_op_set_vocoder_lds_limit(int32_t kib);
 int fs2_op_set_vocoder_fused_resblock(int32_t on);
 int fs2_op_gemm(int32_t dtype, int32_t out_dtype, const void* x, const void* w, const float* bias, void* c,
                 int32_t M, int32_t N, int32_t Cin, int32_t taps, int32_t S, int32_t relu, void* hip_stream);
+/* c = x w^T + bias + addend, addend (M, N) in the launch dtype; addend == c is allowed (a workgroup reads its own tile of it before it
+ * writes it): the accumulating data-gradient products of the training step (dx += dy . W) without an elementwise pass behind them.
+ * FS2_ERR_SHAPE when the shape does not run on the slab kernel (N < 192, M % S != 0, even tap count). */
+int fs2_op_gemm_add(int32_t dtype, const void* x, const void* w, const float* bias, const void* addend, void* c, int32_t M, int32_t N,
+                    int32_t Cin, int32_t taps, int32_t S, void* hip_stream);
 /* Split-K form for long reductions over few row tiles (training step: the encoder-side data-gradient convs, M = B L rows, K = taps x
  * filter): ksplit (from fs2_op_gemm_splitk_choice; 1 = not worth it -> use fs2_op_gemm) slices of the input channels run as separate
  * workgroups of ONE launch into fp32 planes part (ksplit, M, N), a second launch adds the planes in order:

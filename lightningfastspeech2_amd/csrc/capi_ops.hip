@@ -117,6 +117,18 @@ int fs2_op_gemm(int32_t dtype, int32_t out_dtype, const void* x, const void* w, 
     return launch_gemm(a, dtype, out_dtype, (hipStream_t)stream);
 }
 
+int fs2_op_gemm_add(int32_t dtype, const void* x, const void* w, const float* bias, const void* addend, void* c, int32_t M, int32_t N,
+                    int32_t Cin, int32_t taps, int32_t S, void* stream) {
+    if (!addend) return FS2_ERR_ARG;
+    GemmArgs a;
+    a.X = x; a.W = w; a.bias = bias; a.C = c;
+    a.M = M; a.N = N; a.K = taps * Cin; a.ldx = Cin; a.ldc = N;
+    a.Cin = Cin; a.taps = taps; a.pad = (taps - 1) / 2; a.S = S; a.relu = 0;
+    a.epi_res = addend;  // the slab kernel's residual epilogue without statistics: the accumulators start AT the addend
+    if (N < 192 || M % S || !(taps & 1)) return FS2_ERR_SHAPE;  // slab kernel only
+    return launch_gemm(a, dtype, dtype, (hipStream_t)stream);
+}
+
 int fs2_op_gemm_splitk_choice(int32_t dtype, int32_t M, int32_t N, int32_t Cin, int32_t taps, int32_t S) {
     return gemm_splitk_choice(M, N, Cin, taps, S, dtype);
 }

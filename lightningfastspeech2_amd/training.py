@@ -59,6 +59,7 @@ class _Ops:
         self.seed = 0       # dropout: set per micro-step by the trainer
         self._site = 0      # dropout site counter of the current forward
         self.fuse_ln = os.environ.get("FS2_TRAIN_FUSE_LN", "1") != "0"  # A/B switch: GEMM + LayerNorm as one launch where it applies
+        self.fuse_add = os.environ.get("FS2_TRAIN_FUSE_ADD", "1") != "0"  # A/B switch: "dx +=" of a data-gradient product inside the GEMM launch
         self.splitk = os.environ.get("FS2_TRAIN_SPLITK", "1") != "0"    # A/B switch: split-K data-gradient convs where fs2_op_gemm_splitk_choice says so
 
     def site(self):
@@ -238,6 +239,13 @@ class _Ops:
                     return dx
                 if st_ != _lib.FS2_ERR_SHAPE:
                     self.ck(st_, "gemm_splitk")
+            if out is not None and accumulate and gate is None and self.fuse_add:
+                # out += dy . wt in the GEMM's own store (the accumulators start at out's tile)
+                st_ = self.lib.fs2_op_gemm_add(self.dt, _p(dy), _p(wt), None, _p(out), _p(out), M, Cin, N, taps, S or M, self.st())
+                if st_ == 0:
+                    return out
+                if st_ != _lib.FS2_ERR_SHAPE:
+                    self.ck(st_, "gemm_add")
             dx = self.gemm(dy, wt, None, M, Cin, N, taps=taps, S=S, gate=gate, gate_scale=gate_scale)
             if out is None:
                 return dx

@@ -54,6 +54,17 @@ def gemm(dtype, x, w_packed, bias, taps=1, S=None, relu=False, out_dtype=None):
     return c.float().cpu()
 
 
+def gemm_add(dtype, x, w_packed, bias, addend, taps=1, S=None, in_place=True):
+    M, Cin = x.shape
+    N = w_packed.shape[0]
+    xd, wd, ad = to_dev(x, dtype), to_dev(w_packed, dtype), to_dev(addend, dtype)
+    bd = None if bias is None else torch.as_tensor(bias).float().to(DEV)
+    c = ad if in_place else torch.empty(M, N, dtype=tdt(dtype), device=DEV)
+    ok(lib().fs2_op_gemm_add(dtype, p(xd), p(wd), p(bd), p(ad), p(c), M, N, Cin, taps, S or M, stream()), "gemm_add")
+    torch.cuda.synchronize()
+    return c.float().cpu()
+
+
 def gemm_splitk(dtype, x, w_packed, ksplit, taps=1, S=None, out_dtype=None, into=None):
     """fs2_op_gemm_splitk: K slices as workgroups of one launch into fp32 planes + the plane sum; into = a tensor the result is
     ADDED to (the accumulating data-gradient call of the training step)."""

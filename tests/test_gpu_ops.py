@@ -312,6 +312,24 @@ def test_gemm_split_k_matches_the_one_pass_kernel(dtype, B, S, Cin, N, k, ks):
     assert c >= 1 and (c == 1 or (Cin // (64 if dtype == G.BF16 else 32)) % c == 0)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,S,Cin,N,k", [(4, 300, 256, 768, 1), (3, 217, 1024, 256, 9), (2, 1536, 256, 256, 3), (5, 40, 128, 200, 3)])
+def test_gemm_with_addend_in_place(dtype, B, S, Cin, N, k):
+    """c = x w^T + bias + addend with addend == c (the accumulating data-gradient products of the training step)."""
+    x = rnd(B, S, Cin, seed=310)
+    w = rnd(N, Cin, k, seed=311, scale=(Cin * k) ** -0.5)
+    b = rnd(N, seed=312)
+    base = rnd(B * S, N, seed=313)
+    ref = F.conv1d(G.rounded(x, dtype).transpose(1, 2), G.rounded(w, dtype), b, padding="same").transpose(1, 2).reshape(B * S, N)
+    ref = ref + G.rounded(base, dtype)
+    xs, wp = x.reshape(B * S, Cin), G.pack_conv_weight(w)
+    got = G.gemm_add(dtype, xs, wp, b, base, taps=k, S=S)
+    again = G.gemm_add(dtype, xs, wp, b, base, taps=k, S=S)
+    other = G.gemm_add(dtype, xs, wp, b, base, taps=k, S=S, in_place=False)
+    assert torch.equal(got, again) and torch.equal(got, other)
+    assert float((got - ref).abs().max()) <= tol(dtype, ref)
+
+
 def test_gemm_split_k_rejects_what_it_cannot_run():
     x, w = rnd(256, 256, seed=1), rnd(256, 256, seed=2)
     xd, wd = G.to_dev(x, G.BF16), G.to_dev(w, G.BF16)
