@@ -29,6 +29,15 @@ constexpr int PF_ROWB = PF_H * 2;       // slab row bytes (bf16)
 #define FS2_PF_PREFETCH 1
 #endif
 constexpr bool PF_PREFETCH = FS2_PF_PREFETCH;
+// scheduling fence around the fragment reads of a half: hipcc otherwise sinks the reads to just before their first use
+#ifndef FS2_PF_FENCE
+#define FS2_PF_FENCE 1
+#endif
+#if FS2_PF_FENCE
+#define PF_FENCE() __builtin_amdgcn_sched_barrier(0)
+#else
+#define PF_FENCE() do { } while (0)
+#endif
 
 }  // namespace
 
@@ -67,6 +76,10 @@ __global__ void pack_predictor_weights_kernel(const bf16* __restrict__ W, uint4*
 //   fragment prefetch was in (its LDS round trips sat in front of every half's MFMAs).  hipcc still sinks most fragment reads to
 //   just before their first use (a __builtin_amdgcn_sched_group_barrier pattern per k-block made that worse, not better): what is
 //   left in the K loop needs the reads and their waits as asm statements, the attention_pipe.hip way - not done.
+//   What did work: __builtin_amdgcn_sched_barrier(0) fences around each half's fragment reads (PF_FENCE) - reads in a group, then the
+//   MFMAs, nothing moved across - once the epilogue's per-lane offsets were kept from being hoisted across the K loop (the laundered
+//   lane id below; 54 -> 34 spilled registers, none inside the loops).  64-row tiles (the duration predictor's launch): 33 -> 21 us;
+//   112-row tiles: 106 -> ~104 us (FS2_PF_FENCE=0 builds the unfenced form for A/B).
 template <int MI16, int NWV, int MINW>
 __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(PredictorArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins exist in the device pass only
@@ -164,15 +177,19 @@ __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(Predict
                     // the next half's activation fragments are requested before this half's MFMAs (two fragment sets alive): an LDS
                     // round trip behind every half otherwise (r03: 113 -> 107 us for the C2 variance predictor with two workgroups per CU)
                     loadA(fxb, kb, 1);
+                    PF_FENCE();
 #pragma unroll
                     for (int ni = 0; ni < NFR; ++ni)
 #pragma unroll
                         for (int mi = 0; mi < HFA; ++mi) mma(KB0, bw[kb & 3][ni], fxa[mi], ni, acc[ni][mi]);
+                    PF_FENCE();
                     if (kb + 1 < PF_KB) loadA(fxa, kb + 1, 0);
+                    PF_FENCE();
 #pragma unroll
                     for (int ni = 0; ni < NFR; ++ni)
 #pragma unroll
                         for (int mi = 0; mi < HFB; ++mi) mma(KB0, bw[kb & 3][ni], fxb[mi], ni, acc[ni][HFA + mi]);
+                    PF_FENCE();
                 } else {
 #pragma unroll
                     for (int hf = 0; hf < 2; ++hf) {
@@ -215,6 +232,13 @@ __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(Predict
         }
 #endif
         auto relu = [](float x) { float y; asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x)); return y; };
+        // The epilogue's per-lane offsets (slab slots, LayerNorm parameter columns, exchange rows) are re-derived from a laundered
+        // lane id: left to itself hipcc hoists them out of the layer loop and carries ~40 registers of addresses across the K loop,
+        // which at 256 registers is what spills once the fragment reads are pinned one half ahead (54 spilled, +4 us).
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int fr = lane_e & 15, fg = lane_e >> 4;
+        const int n0 = wv * (NFR * 16) + fg * 8;
         const float invn = 1.0f / (float)PF_H;
         float mean[MI16], rstd[MI16];
 #pragma unroll
