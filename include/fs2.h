@@ -213,7 +213,9 @@ int fs2_profile_read(fs2_engine* e, int32_t kernel_class, double* total_ms, int6
  *   500/501 fp32 slab-kernel launches: fp32 MFMA (default) / bf16 x 3 split products (what FS2_MIXED_X3 uses in its front)
  *   700/701 bf16 fs2_op_bgemm tile order: plain / XCD-contiguous (default)
  *   800/801 bf16 fs2_op_bgemm: generic instantiation only / the bounds-free one for full, aligned tiles (default)
- *   900/901 fs2_op_attention_bwd, dK / dV launch: one (default) / two 16-row blocks per wave;  902/903/904 the dQ launch: one / two / by size (default)
+ *   900/901 fs2_op_attention_bwd, dK / dV launch: one (default, also 909) / two 16-row blocks per wave, 905/906 three / four (one wave
+ *              per SIMD; measured no faster inside the training step);  902/903/904 the dQ launch: one / two / by size (default),
+ *              907/908 three / four
  *   1000/1001 bf16 fs2_op_bgemm: 256 x 256 LDS-DMA kernel for eligible TN products off / on (default)
  *   1100/1101 fs2_op_col_sum: two launches (default) / one (last workgroup reduces; measured slower)
  *   1200..1203 fused attention: 1200 = the phase-serial kernel only; 1201 / 1202 = the software-pipelined kernel (bf16, head dim

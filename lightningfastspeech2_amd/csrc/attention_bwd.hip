@@ -64,7 +64,7 @@ __device__ inline void load_frags(uint4 (&f)[4], const unsigned short* g, long l
 // times the walked tiles are fetched, for 2x the accumulators
 // DROP: the attention-weight dropout of the forward is regenerated (a run-time test put four branches into every block epilogue)
 template <int NB, bool DROP>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
+__global__ __launch_bounds__(256, NB <= 2 ? 2 : 1) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
     // two buffers: the next block's tiles are written while this one is multiplied - one barrier per block instead of two
     __shared__ __attribute__((aligned(16))) unsigned short sQ2[2][TB * LDT], sO2[2][TB * LDT];
     __shared__ __attribute__((aligned(16))) float sL2[2][TB], sD2[2][TB];  // sL = +inf past the last query: exp2(.. - inf) = 0, no select
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(AttnBwdArgs p) {
 }
 
 template <int NB, bool DROP>
-__global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void attn_bwd_dq_kernel(AttnBwdArgs p) {
+__global__ __launch_bounds__(256, NB == 1 ? 3 : (NB == 2 ? 2 : 1)) void attn_bwd_dq_kernel(AttnBwdArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned short sK[TB * LDT], sV[TB * LDT];
     __shared__ __attribute__((aligned(16))) float sOk[TB];  // 0 for a key that takes part, -inf otherwise (added to the exponent)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, fr = lane & 15, fg = lane >> 4;
@@ -314,13 +314,18 @@ __global__ __launch_bounds__(256, NB == 1 ? 3 : 2) void attn_bwd_dq_kernel(AttnB
 // 16-row blocks per wave, per launch (tools/bench_ops.py flash, PMC in profiles/r02_pmc_attention_bwd.md): the dK / dV launch
 // stays at 1 (2 doubles its 128 accumulator registers and spills at two waves per SIMD), the dQ launch takes 2 (half the LDS
 // fragment / transpose reads per MFMA, 234 registers, no spill: MFMA pipe 45 -> 51 % busy)
-int g_attn_bwd_nb = 1, g_attn_bwd_nb_dq = 0;  // dQ: 0 = by size (2 when that still leaves two workgroups per CU: C2 encoder 24 us at 1, 28 at 2)
+// r03: 3 / 4 blocks per wave (48 / 64 keys or queries per wave, ONE wave per SIMD with the 512-register file; dK dV at 3: 456
+// registers, no spill, a third of the LDS fragment / transpose reads per MFMA; at 4: 117 spilled) behind knobs 905-908.  On random
+// operands (tools/bench_ops.py flash) the C2 decoder pair goes 370 -> 329 us with the 3-block dK / dV launch; inside the training
+// step, on the model's own activations, that launch takes 221 us against 219 us at 1 block (rocprof, same box, both ways) - the
+// gain does not survive real data (the launch is power / clock limited there), so the default stays 1.
+int g_attn_bwd_nb = 1, g_attn_bwd_nb_dq = 0;  // dQ: 0 = by size (2 when that still leaves two workgroups per CU: C2 encoder 24 us at 1, 28 at 2)  // dQ: 0 = by size (2 when that still leaves two workgroups per CU: C2 encoder 24 us at 1, 28 at 2)
 
 }  // namespace
 
 void attention_bwd_set_blocks(int which, int nb) {
-    if (which) g_attn_bwd_nb_dq = nb >= 0 && nb <= 2 ? nb : 0;
-    else g_attn_bwd_nb = nb == 2 ? 2 : 1;
+    if (which) g_attn_bwd_nb_dq = nb >= 0 && nb <= 4 ? nb : 0;
+    else g_attn_bwd_nb = nb >= 1 && nb <= 4 ? nb : 1;
 }
 
 bool attention_bwd_supported(int dtype, int H, int heads) { return dtype == FS2_BF16 && heads > 0 && H == heads * D; }
@@ -331,10 +336,15 @@ int launch_attention_bwd(const AttnBwdArgs& a, int dtype, hipStream_t stream) {
     const bool drop = a.drop_p > 0.f;
 #define FS2_AB(KERNEL, NBV, DR) \
     hipLaunchKernelGGL((KERNEL<NBV, DR>), dim3((a.S + NBV * TB - 1) / (NBV * TB), a.B * a.heads), dim3(256), 0, stream, a)
-    if (g_attn_bwd_nb == 2) { if (drop) FS2_AB(attn_bwd_dkdv_kernel, 2, true); else FS2_AB(attn_bwd_dkdv_kernel, 2, false); }
+    const int nb_kv = g_attn_bwd_nb;
+    if (nb_kv == 4 && !drop) FS2_AB(attn_bwd_dkdv_kernel, 4, false);
+    else if (nb_kv == 3 && !drop) FS2_AB(attn_bwd_dkdv_kernel, 3, false);
+    else if (nb_kv == 2) { if (drop) FS2_AB(attn_bwd_dkdv_kernel, 2, true); else FS2_AB(attn_bwd_dkdv_kernel, 2, false); }
     else { if (drop) FS2_AB(attn_bwd_dkdv_kernel, 1, true); else FS2_AB(attn_bwd_dkdv_kernel, 1, false); }
     const int nb_dq = g_attn_bwd_nb_dq ? g_attn_bwd_nb_dq : ((long)((a.S + 2 * TB - 1) / (2 * TB)) * a.B * a.heads >= 512 ? 2 : 1);
-    if (nb_dq == 2) { if (drop) FS2_AB(attn_bwd_dq_kernel, 2, true); else FS2_AB(attn_bwd_dq_kernel, 2, false); }
+    if (nb_dq == 4 && !drop) FS2_AB(attn_bwd_dq_kernel, 4, false);
+    else if (nb_dq == 3 && !drop) FS2_AB(attn_bwd_dq_kernel, 3, false);
+    else if (nb_dq >= 2) { if (drop) FS2_AB(attn_bwd_dq_kernel, 2, true); else FS2_AB(attn_bwd_dq_kernel, 2, false); }
     else { if (drop) FS2_AB(attn_bwd_dq_kernel, 1, true); else FS2_AB(attn_bwd_dq_kernel, 1, false); }
 #undef FS2_AB
     return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;

@@ -98,6 +98,8 @@ int fs2_op_set_gemm_variant(int32_t variant) {
     if (variant >= 1200) { fs2::g_attn_pipe = variant - 1200; return FS2_OK; }      // 1200: attention.hip only; 1201 / 1202 / 1204: the software-pipelined kernel with 32 / 64 / 96 queries per wave where it applies; 1203: by size (default)
     if (variant >= 1100) { fs2::g_colsum_fused = variant - 1100; return FS2_OK; }   // 1100 / 1101: column sums in two launches / one
     if (variant >= 1000) { fs2::g_bgemm_tn256 = variant - 1000; return FS2_OK; }    // 1000 / 1001: 256 x 256 LDS-DMA kernel for eligible bf16 TN products off / on
+    if (variant >= 905 && variant <= 908) { fs2::attention_bwd_set_blocks(variant >= 907, 3 + ((variant - 905) & 1)); return FS2_OK; }  // 905 / 906: dK,dV launch 3 / 4 blocks per wave (one wave per SIMD); 907 / 908: the dQ launch
+    if (variant == 909) { fs2::attention_bwd_set_blocks(0, 1); return FS2_OK; }  // dK,dV launch back to its default (1 block per wave)
     if (variant >= 900) { if (variant == 904) fs2::attention_bwd_set_blocks(1, 0); else fs2::attention_bwd_set_blocks((variant - 900) >> 1, ((variant - 900) & 1) + 1); return FS2_OK; }  // 900 / 901: attention backward dK,dV launch 1 / 2 blocks per wave; 902 / 903: the dQ launch, 904: by size
     if (variant >= 800) { fs2::g_bgemm_full = variant - 800; return FS2_OK; }       // 800 / 801: bf16 strided-batched GEMM generic instantiation only / bounds-free one for full aligned tiles
     if (variant >= 700) { fs2::g_bgemm_xcd = variant - 700; return FS2_OK; }        // 700 / 701: bf16 strided-batched GEMM tile order plain / XCD-contiguous

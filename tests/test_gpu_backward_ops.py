@@ -470,8 +470,19 @@ def test_fused_softmax_backward_epilogue(dtype, drop):
     close(ds, scores.grad / d ** 0.5, 2e-2 if bf else 3e-5)  # gradient of the RAW product Q K^T (what dQ = dS K and dK = dS^T Q consume)
 
 
-@pytest.mark.parametrize("B,S,heads,drop", [(2, 150, 2, 0.0), (3, 64, 1, 0.0), (2, 200, 2, 0.2), (1, 37, 2, 0.0)])
-def test_flash_attention_training_forward_and_backward(B, S, heads, drop):
+@pytest.fixture(params=[(), (905, 907), (905, 908), (901, 903)], ids=["by-size", "dkdv3-dq3", "dkdv3-dq4", "dkdv2-dq2"])
+def attn_bwd_blocks(request):
+    """16-row blocks per wave of the (dK dV, dQ) launches: the default (1 / by size) or forced (3 / 4: one wave per SIMD)"""
+    lib = _lib.load()
+    for k in request.param:
+        lib.fs2_op_set_gemm_variant(k)
+    yield request.param
+    lib.fs2_op_set_gemm_variant(909)
+    lib.fs2_op_set_gemm_variant(904)
+
+
+@pytest.mark.parametrize("B,S,heads,drop", [(2, 150, 2, 0.0), (3, 64, 1, 0.0), (2, 200, 2, 0.2), (1, 37, 2, 0.0), (2, 700, 2, 0.0)])
+def test_flash_attention_training_forward_and_backward(B, S, heads, drop, attn_bwd_blocks):
     """The fused attention on the training path: output + lse2 (+ attention-weight dropout) and the recomputing backward
     (dQ, dK, dV with neither P nor dP in HBM), against autograd of softmax(q k^T / sqrt(d) + key padding) -> dropout -> @ v
     in float64 on the same bf16 inputs, with the mask the dropout op regenerates."""

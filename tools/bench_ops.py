@@ -179,14 +179,14 @@ def flash_bwd_case(name, B, S, H, heads, reps):
     lse = torch.zeros(B, heads, S, device=DEV) + 5.0
     delta = torch.zeros(B, heads, S, device=DEV)
     dqkv = torch.empty(B * S, 3 * H, device=DEV, dtype=bf)
-    for knobs in ((900, 902), (900, 903), (901, 902)):  # blocks per wave of the (dK dV, dQ) launches
+    for knobs in ((900, 902), (900, 903), (901, 902), (905, 903), (900, 907), (900, 908), (905, 907), (905, 908)):  # blocks per wave of the (dK dV, dQ) launches (905 / 907: 3, 908: 4)
         for knob in knobs:
             lib.fs2_op_set_gemm_variant(knob)
         t = timeit(lambda st: lib.fs2_op_attention_bwd(BF16, p(qkv), p(dout), p(lse), p(delta), None, p(dqkv), B, S, H, heads,
                                                        C.c_float(0.0), C.c_uint64(0), C.c_uint64(0), st), reps)
         fl = 5 * 2.0 * B * S * S * H  # dV, dP, dS-products: five S x S x d GEMMs are the useful work
-        print(f"{name:30s} blocks/wave={knobs[0] - 899},{knobs[1] - 901}  {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TF useful ({fl/t/2.5e15*100:4.1f}% of 2.5 PF)")
-    lib.fs2_op_set_gemm_variant(900)
+        print(f"{name:30s} knobs={knobs[0]},{knobs[1]}  {t*1e6:8.1f} us  {fl/t/1e12:7.1f} TF useful ({fl/t/2.5e15*100:4.1f}% of 2.5 PF)")
+    lib.fs2_op_set_gemm_variant(909)
     lib.fs2_op_set_gemm_variant(904)
 
 
