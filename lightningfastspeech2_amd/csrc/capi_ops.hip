@@ -93,6 +93,7 @@ int fs2_op_set_vocoder_lds_limit(int32_t kib) {
 
 int fs2_op_set_gemm_variant(int32_t variant) {
     if (variant >= 1400 && variant <= 1402) { fs2::g_gemm_wres = variant - 1400; return FS2_OK; }      // bf16 K = 256 plain GEMMs: slab kernel / weight-resident kernel where it pays (default) / wherever it applies
+    if (variant == 1320 || variant == 1321) { fs2::g_pred_fuse_embed = variant - 1320; return FS2_OK; }  // engine: variance encoder (bucketize + embedding add) as the tail of its predictor launch: off / on (default)
     if (variant >= 1300) { fs2::g_pred_tall = variant - 1300; return FS2_OK; }      // 1300 / 1301 / 1302: single-launch predictor on 112-row tiles only / 208-row tiles (one workgroup per CU) / two 112-row tiles per workgroup, when they fill the chip
     if (variant == 1210 || variant == 1211) { fs2::g_attn_resident = variant - 1210; return FS2_OK; }  // <= 256 keys: K / V streamed tile by tile (default) / resident in LDS
     if (variant >= 1200) { fs2::g_attn_pipe = variant - 1200; return FS2_OK; }      // 1200: attention.hip only; 1201 / 1202 / 1204: the software-pipelined kernel with 32 / 64 / 96 queries per wave where it applies; 1203: by size (default)

@@ -639,20 +639,37 @@ struct CwtOut {  // where the CWT head's by-products go (scratch or the caller's
     float* spec_out = nullptr;  // (B, S, 10) or null
 };
 
+struct EmbedTail {  // the VarianceEncoder's bucketize + embedding add (+ pe + spk) as the tail of the predictor launch (predictor_fused.hip)
+    void* y;
+    const float* bins;
+    const float* emb;
+    int nbins;
+    float std, mean;
+    const float* pe;
+    const float* spk;
+};
+
 int predictor(fs2_engine* e, hipStream_t st, const PredictorW& P, const void* x, int B, int S, const uint8_t* mask,
-              float* pred, const LayerScratch& sc, const CwtOut* cw = nullptr) {
+              float* pred, const LayerScratch& sc, const CwtOut* cw = nullptr, const EmbedTail* tail = nullptr, bool* tail_done = nullptr) {
     const int M = B * S;
+    if (tail_done) *tail_done = false;
     if (P.cwt && !cw) return fail(e, FS2_ERR_STATE, "CWT predictor without its output buffers");
     if (P.wpk && e->fuse_predictor && predictor_fused_supported(P.dt, P.filt, P.layers[0].c.taps, (int)P.layers.size(), S)) {
         PredictorArgs a;
         a.x = x; a.wpk = P.wpk; a.bias = P.bias_all; a.ln_g = P.g_all; a.ln_b = P.b_all;
         a.head_w = P.head_w; a.head_b = P.head_b; a.mask = mask; a.pred = pred;
         a.B = B; a.S = S; a.H = P.filt; a.nlayers = (int)P.layers.size(); a.taps = P.layers[0].c.taps; a.eps = 1e-5f;
+        const bool with_tail = tail && tail_done && !P.cwt && tail->y != x && tail->nbins >= 2 && tail->nbins - 1 <= 512;
+        if (with_tail) {
+            a.be_y = tail->y; a.be_bins = tail->bins; a.be_emb = tail->emb; a.be_nbins = tail->nbins;
+            a.be_std = tail->std; a.be_mean = tail->mean; a.be_pe = tail->pe; a.be_spk = tail->spk;
+        }
         const double fl = 2.0 * M * (double)P.filt * P.filt * a.taps * a.nlayers;
-        const double by = (double)M * P.filt * 2 + (double)M * 4;
+        const double by = (double)M * P.filt * 2 + (double)M * 4 + (with_tail ? 2.0 * M * P.filt * 2 : 0.0);
         Bracket br(e, FS2_K_CONV_GEMM, st, fl, by);
         const int r = launch_predictor_fused(a, st);
         if (r != FS2_OK) return fail(e, r, "fused predictor launch failed (B=%d S=%d)", B, S);
+        if (with_tail) *tail_done = true;
         return FS2_OK;
     }
     if (P.layers[0].depthwise && P.filt > 256 && e->defer_ln) {
@@ -994,7 +1011,7 @@ int fs2_encode(fs2_engine* e, const int64_t* phones, const float* speaker, int32
     // every launch of the phase (no host decision among them), plainly or as a replayed hipGraph (fs2_set_graphs)
     {
         std::vector<uint64_t> key = {(uint64_t)B, (uint64_t)L, (uint64_t)e->persist.base, (uint64_t)e->scratch.base, (uint64_t)phones,
-                                     (uint64_t)speaker, (uint64_t)forced, (uint64_t)e->h_pinned, (uint64_t)e->fuse_predictor,
+                                     (uint64_t)speaker, (uint64_t)forced, (uint64_t)e->h_pinned, (uint64_t)e->fuse_predictor + 2 * (uint64_t)g_pred_fuse_embed,
                                      (uint64_t)e->defer_ln, (uint64_t)e->front_split};
         const bool plain = c.n_priors != 0;  // a prior tensor is a one-shot pointer of the call
         CHK(run_phase(e, e->egraphs, key, plain, st, [&](hipStream_t s2) { return encode_body(e, phones, speaker, forced, sc, s2); }));
@@ -1121,8 +1138,20 @@ static int decode_body(fs2_engine* e, const fs2_outputs* out, hipStream_t st) {
             cwo.mean_std = out->var_mean_std[v] ? out->var_mean_std[v] : cw_ms;
             cwo.spec_out = out->var_spectrogram[v];
         }
-        CHK(predictor(e, st, e->vars[v].pred, yA, B, T, tmask, vpred[v], sc, c.var_cwt[v] ? &cwo : nullptr));
         const bool last = v + 1 == c.n_variances;
+        // the encoder's bucketize + embedding add rides in the predictor launch where nothing else wants its by-products
+        // (bucket indices for the debug taps, forced buckets / targets of the teacher-forced and oracle paths)
+        const bool tail_ok = g_pred_fuse_embed && !e->debug && !e->forced_idx[v] && !e->forced_tgt[v] && !c.var_cwt[v] &&
+                             e->fdt == FS2_BF16 && H == 256;
+        const EmbedTail tl{yB, e->vars[v].bins, e->vars[v].emb, c.var_nbins, c.var_std[v], c.var_mean[v],
+                           (last && fuse_pe) ? e->pe : nullptr, (last && fuse_pe) ? e->spk : nullptr};
+        bool tail_done = false;
+        CHK(predictor(e, st, e->vars[v].pred, yA, B, T, tmask, vpred[v], sc, c.var_cwt[v] ? &cwo : nullptr, tail_ok ? &tl : nullptr,
+                      &tail_done));
+        if (tail_done) {
+            std::swap(yA, yB);
+            continue;
+        }
         int32_t* idx = nullptr;
         if (e->debug) {
             idx = (int32_t*)e->dbg.take(MT * 4);
@@ -1238,7 +1267,7 @@ int fs2_decode(fs2_engine* e, const fs2_outputs* out, void* stream) {
     CHK(ensure_arena(e, e->scratch, decode_scratch_bytes(e, e->B, e->T), "scratch"));
     if (e->scratch.base != base0) drop_graphs(e);
     std::vector<uint64_t> key = {(uint64_t)e->B, (uint64_t)e->L, (uint64_t)e->T, (uint64_t)e->scratch.base, (uint64_t)e->persist.base,
-                                 (uint64_t)e->xA, (uint64_t)e->d_cum, (uint64_t)e->spk, (uint64_t)e->zero_pad_mel, (uint64_t)e->fuse_predictor,
+                                 (uint64_t)e->xA, (uint64_t)e->d_cum, (uint64_t)e->spk, (uint64_t)e->zero_pad_mel, (uint64_t)e->fuse_predictor + 2 * (uint64_t)g_pred_fuse_embed,
                                  (uint64_t)e->defer_ln, (uint64_t)e->front_split, (uint64_t)out->mel, (uint64_t)out->tgt_mask,
                                  (uint64_t)out->duration_prediction, (uint64_t)out->duration_rounded, (uint64_t)out->src_mask};
     for (int v = 0; v < FS2_MAX_VARIANCES; ++v) {

@@ -116,7 +116,18 @@ struct PredictorArgs {
     float* pred;            // (B*S)
     int B, S, H, nlayers, taps;
     float eps;
+    // Optional tail (inference engine): the VarianceEncoder's  y = x + Embedding[bucketize(pred * std + mean)] [+ pe] [+ spk]
+    // (model.py:434-438,333; rowops.hip bucket_embed_kernel, same arithmetic bit for bit) for the rows this workgroup finishes,
+    // instead of a launch of its own behind this one.  be_y != x (neighbouring workgroups still read x's rows as their halo).
+    void* be_y = nullptr;            // (B*S, H) bf16 out, or null: no tail
+    const float* be_bins = nullptr;  // (be_nbins - 1) sorted edges, be_nbins - 1 <= 512
+    const float* be_emb = nullptr;   // (be_nbins, H) fp32
+    int be_nbins = 0;
+    float be_std = 1.f, be_mean = 0.f;
+    const float* be_pe = nullptr;    // (>= S, H) fp32 or null
+    const float* be_spk = nullptr;   // (B, H) fp32 or null
 };
+extern int g_pred_fuse_embed;  // A/B knob (1320 / 1321): the engine's frame-level variance encoders as the tail of their predictor launch
 bool predictor_fused_supported(int dtype, int H, int taps, int nlayers, int S);
 size_t predictor_packed_bytes_per_layer();
 int launch_pack_predictor_weights(const void* w_layer /*(H, taps*H) tap-major bf16*/, void* out_layer, hipStream_t stream);

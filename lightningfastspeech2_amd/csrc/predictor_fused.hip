@@ -347,7 +347,70 @@ __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(Predict
 #pragma unroll
                 for (int w = 0; w < NWV; ++w) d += red[0][w * R + row];
                 const size_t o = (size_t)ub * S + t;
-                p.pred[o] = (p.mask && p.mask[o]) ? 0.f : d;
+                d = (p.mask && p.mask[o]) ? 0.f : d;
+                p.pred[o] = d;
+                red[1][row] = d;  // (red[1] was last read before the final layer's last barrier)
+            }
+        }
+    }
+    // (outside the layer loop: inside it hipcc carried the tail's addresses and edge registers across every K loop - 116 spilled)
+    int lane_t = lane;
+    asm volatile("" : "+v"(lane_t));
+    if (p.be_y) {
+        // ---- VarianceEncoder tail: y[t] = x[t] + Emb[bucketize(pred[t] * std + mean)] [+ pe[t]] [+ spk[b]] for the finished rows.
+        // bucketize = the number of edges < v: the wave holds the edges in registers (8 per lane) and counts by ballot; a lane
+        // owns 4 consecutive channels of a row; EB rows' loads are in flight at once (x comes back out of L2 / MALL).
+        __syncthreads();
+        constexpr int EB = 8;  // rows in flight per wave (13 - two even rounds of the 104 finished rows - measured no better)
+        const int nedge = p.be_nbins - 1, nb = (nedge + 63) >> 6;
+        float bl[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = lane_t + 64 * k;
+            bl[k] = i < nedge ? p.be_bins[i] : __builtin_inff();
+        }
+        const bf16* xg = (const bf16*)p.x + (size_t)ub * S * PF_H + lane_t * 4;
+        bf16* yg = (bf16*)p.be_y + (size_t)ub * S * PF_H + lane_t * 4;
+        const float* spr = p.be_spk ? p.be_spk + (size_t)ub * PF_H + lane_t * 4 : nullptr;
+        float4 sp4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (spr) sp4 = *(const float4*)spr;
+        for (int base = halo + wv * EB; base < R - halo; base += NWV * EB) {
+            uint2 xv[EB];
+            float4 ev[EB], pv[EB];
+            bool okr[EB];
+#pragma unroll
+            for (int j = 0; j < EB; ++j) {
+                const int row = base + j, t = t0 + row;
+                okr[j] = row < R - halo && t < S;
+                const int rc = okr[j] ? row : halo, tc = okr[j] ? t : t0 + halo;
+                const float v = __fadd_rn(__fmul_rn(red[1][rc], p.be_std), p.be_mean);
+                int lo = 0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (k < nb) lo += __popcll(__ballot(bl[k] < v));
+                xv[j] = *(const uint2*)(xg + (size_t)tc * PF_H);
+                ev[j] = *(const float4*)(p.be_emb + (size_t)lo * PF_H + lane_t * 4);
+                if (p.be_pe) pv[j] = *(const float4*)(p.be_pe + (size_t)tc * PF_H + lane_t * 4);
+            }
+#pragma unroll
+            for (int j = 0; j < EB; ++j) {
+                if (!okr[j]) continue;
+                float v[4] = {__uint_as_float(xv[j].x << 16), __uint_as_float(xv[j].x & 0xffff0000u), __uint_as_float(xv[j].y << 16),
+                              __uint_as_float(xv[j].y & 0xffff0000u)};
+                const float e4[4] = {ev[j].x, ev[j].y, ev[j].z, ev[j].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = __fadd_rn(v[i], e4[i]);
+                if (p.be_pe) {
+                    const float q4[4] = {pv[j].x, pv[j].y, pv[j].z, pv[j].w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = __fadd_rn(v[i], q4[i]);
+                }
+                if (spr) {
+                    const float q4[4] = {sp4.x, sp4.y, sp4.z, sp4.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = __fadd_rn(v[i], q4[i]);
+                }
+                *(uint2*)(yg + (size_t)(t0 + base + j) * PF_H) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
             }
         }
     }
@@ -666,6 +729,7 @@ __global__ __launch_bounds__(256, 1) void predictor_pair_kernel(PredictorArgs p,
 // 208-row tiles, one 4-wave workgroup per CU (knob 1301): measured r03 148-152 us against 112 us for two 112-row workgroups per CU
 // on the C2 variance predictor - with one wave per SIMD nothing runs under the LayerNorm epilogue, whose VALU stream (~2.9 k
 // instructions per layer and wave) is as long as the layer's MFMA stream.  Off by default; bit-identical outputs either way.
+int g_pred_fuse_embed = 1;
 int g_pred_tall = 0;  // 0: 112- / 64-row tiles, two workgroups per CU; 1: 208-row tiles; 2: two 112-row tiles per workgroup (predictor_pair_kernel)
 
 bool predictor_fused_supported(int dtype, int H, int taps, int nlayers, int S) {
@@ -690,7 +754,8 @@ int launch_predictor_fused(const PredictorArgs& a, hipStream_t stream) {
     auto tiles = [&](int R) { return (long)a.B * ((a.S + (R - halo2) - 1) / (R - halo2)); };
     // the tile HEIGHT does not enter the arithmetic (rows are independent), the wave layout does: one
     // layout for everything, shorter tiles when 112-row tiles would leave most CUs without work
-    if (g_pred_tall == 2 && tiles(112) >= 256) {  // two 112-row tiles per workgroup, one workgroup per CU
+    if (a.be_y && (a.be_y == a.x || !a.be_bins || !a.be_emb || a.be_nbins < 2 || a.be_nbins - 1 > 512)) return FS2_ERR_ARG;
+    if (g_pred_tall == 2 && tiles(112) >= 256 && !a.be_y) {  // two 112-row tiles per workgroup, one workgroup per CU
         const long n = tiles(112);
         hipLaunchKernelGGL((predictor_pair_kernel<7>), dim3((unsigned)((n + 1) / 2)), dim3(256), 0, stream, a, (int)n);
     } else if (g_pred_tall == 1 && tiles(208) >= 200) {

@@ -258,6 +258,41 @@ def test_full_size_properties_bf16():
     assert same.count(False) == 1 and not same[3]
 
 
+@pytest.mark.parametrize("case", ["c2arch_ragged", "c2_full", "c2_priorless_tail_rows"])
+def test_variance_encoder_in_the_predictor_launch_is_bit_identical(case):
+    """bf16 engine: bucketize + embedding add (+ pe + spk after the last variance) as the tail of the single-launch predictor
+    (predictor_fused.hip, knob 1321 = default) against the stand-alone bucket_embed launch (knob 1320): same arithmetic, same
+    bits - mel, every variance prediction, masks; ragged utterances (pad rows bucketize the masked 0), tile seams, T not a
+    multiple of the tile's finished rows."""
+    from lightningfastspeech2_amd import _lib
+    cfg = preset("c2")
+    if case == "c2_full":
+        sd = synth_state_dict(cfg, 0, duration_bias=float(np.log(7.0)), duration_weight_scale=0.0, randomize_norm=True)
+        inp = synth_inputs(cfg, 8, 256, seed=1234)
+    elif case == "c2arch_ragged":
+        sd = synth_state_dict(cfg, 3, randomize_norm=True, duration_bias=1.5)
+        inp = synth_inputs(cfg, 4, 64, seed=53, lengths=[64, 50, 33, 7])
+    else:
+        sd = synth_state_dict(cfg, 5, randomize_norm=True, duration_bias=1.2)
+        inp = synth_inputs(cfg, 3, 97, seed=77, lengths=[97, 61, 1])
+    m = _model(cfg, sd, "bf16")
+    batch = {"phones": torch.from_numpy(inp["phones"]), "speaker": torch.from_numpy(inp["speaker"])}
+    lib = _lib.load()
+    outs = {}
+    try:
+        for knob in (1320, 1321, 1320, 1321):
+            lib.fs2_op_set_gemm_variant(knob)
+            outs.setdefault(knob, []).append(_cpu(m(batch, inference=True)))
+    finally:
+        lib.fs2_op_set_gemm_variant(1321)
+    a, b = outs[1320][0], outs[1321][0]
+    assert torch.isfinite(b["mel"]).all() and b["mel"].shape[1] > 0
+    for k in a:
+        if torch.is_tensor(a[k]):
+            assert torch.equal(a[k], b[k]), k
+            assert torch.equal(outs[1321][1][k], b[k]), k
+
+
 def test_full_size_fp32_vs_oracle_one_utterance():
     """One full-length utterance (L=256 -> T=1536) of the FS2-27M config against the oracle."""
     cfg = preset("c2")
