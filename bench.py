@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c2", help="c2 (FS2-27M) | c3 (LS-76M) | c5 (FS2-1B) | ref-default")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "mixed", "mixed3"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "mixed", "mixed3", "fp32x3"])
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
     ap.add_argument("--phones", type=int, default=256)
     ap.add_argument("--frames-per-phone", type=int, default=6)
@@ -168,6 +168,21 @@ def parity_block(cfg, sd, args, dev, timed_model):
                     "fp32_bucket_flips": bfl, "fp32_mel_maxabs_vs_oracle": forced if bfl else free,
                     "fp32_mel_maxabs_is": "under the oracle's decisions" if bfl else "free-running"})
         del m32
+        # the parity mode's layout and row arithmetic with every GEMM / conv as bf16 x 3 split products (FS2_F32_X3)
+        mx = FastSpeech2(cfg, sd, precision="fp32x3", device=dev)
+        dfl, bfl, free, forced = check(mx)
+        for _ in range(2):
+            mx(full, inference=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            mx(full, inference=True)
+        torch.cuda.synchronize()
+        res["fp32x3"] = {"mode": "fp32 storage / attention / LayerNorm / heads, every GEMM and conv as bf16 x 3 split products of the fp32 operands",
+                         "ms_per_step": (time.perf_counter() - t0) / 3 * 1e3, "duration_flips": dfl, "bucket_flips": bfl,
+                         "mel_maxabs_vs_oracle": forced if bfl else free,
+                         "mel_maxabs_is": "under the oracle's decisions" if bfl else "free-running"}
+        del mx
     if args.precision == "bf16":  # the decision-safe throughput mode beside it: fp32-grade front, bf16 decoder
         m3 = FastSpeech2(cfg, sd, precision="mixed3", device=dev)
         dfl, bfl, free, forced = check(m3)

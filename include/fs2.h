@@ -50,7 +50,8 @@ enum fs2_dtype {
     FS2_F32 = 0,
     FS2_BF16 = 1,
     FS2_MIXED = 2,    /* engine modes only (fs2_config.dtype): fp32 "front" + bf16 "back", see fs2_config.dtype */
-    FS2_MIXED_X3 = 3  /* the same with the front's GEMMs / convs as bf16 x 3 split products of fp32 operands */
+    FS2_MIXED_X3 = 3, /* the same with the front's GEMMs / convs as bf16 x 3 split products of fp32 operands */
+    FS2_F32_X3 = 4    /* engine mode: F32 storage and row arithmetic everywhere, EVERY GEMM / conv as bf16 x 3 split products */
 };
 
 /* Mirrors the hparams that shape FastSpeech2.forward (fastspeech2.py:46-130). */
@@ -67,7 +68,10 @@ typedef struct fs2_config {
                               MIXED_X3 = MIXED with the front's matrix products evaluated as hi*hi + hi*lo + lo*hi of
                               bf16 head/tail pairs split from the fp32 operands in registers (fp32 storage,
                               accumulation, attention, LayerNorm, heads; ~1e-5 relative per product instead of fp32's
-                              6e-8 or bf16's 4e-3): 3 bf16 MFMAs per 32 k-values instead of 8 fp32 MFMAs */
+                              6e-8 or bf16's 4e-3): 3 bf16 MFMAs per 32 k-values instead of 8 fp32 MFMAs;
+                              F32_X3 = F32 with every GEMM / conv (both sides) evaluated that way: the parity mode's layout,
+                              attention, LayerNorm, heads and decisions logic at about half its time (C2: 8.1 vs 15.2 ms per
+                              forward); measured 1.4e-5 on the mel against F32 under equal decisions */
     int32_t n_phones;      /* len(phone2id) */
     int32_t hidden;        /* encoder_hidden == decoder_hidden */
     int32_t n_mels;

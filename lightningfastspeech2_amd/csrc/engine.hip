@@ -133,7 +133,7 @@ struct fs2_engine {
     long graph_replays = 0;
     bool zero_pad_mel = false;
     bool defer_ln = true;      // hidden > 256, depth-wise blocks: LayerNorm deferred into its consumers (A/B: fs2_set_deferred_layernorm)
-    bool front_split = false;  // FS2_MIXED_X3: the front's fp32 GEMMs / convs run as bf16 x 3 split products
+    bool front_split = false;  // FS2_MIXED_X3 / FS2_F32_X3: the fp32 GEMMs / convs (the front's / all of them) run as bf16 x 3 split products
     std::map<std::string, HostTensor> host;
     std::map<std::string, std::vector<int64_t>> spec;
     std::vector<void*> dev_allocs;
@@ -266,7 +266,8 @@ void build_spec(fs2_engine* e) {
 int check_config(fs2_engine* e) {
     const fs2_config& c = e->cfg;
     if (c.abi_version != FS2_ABI_VERSION) return fail(e, FS2_ERR_ARG, "abi_version %d != %d", c.abi_version, FS2_ABI_VERSION);
-    if (c.dtype != FS2_F32 && c.dtype != FS2_BF16 && c.dtype != FS2_MIXED && c.dtype != FS2_MIXED_X3) return fail(e, FS2_ERR_ARG, "bad dtype");
+    if (c.dtype != FS2_F32 && c.dtype != FS2_BF16 && c.dtype != FS2_MIXED && c.dtype != FS2_MIXED_X3 && c.dtype != FS2_F32_X3)
+        return fail(e, FS2_ERR_ARG, "bad dtype");
     const int H = c.hidden;
     if (H <= 0 || H % 64 || H > 1024) return fail(e, FS2_ERR_SHAPE, "hidden=%d must be a multiple of 64, <= 1024", H);
     if (c.enc_layers < 0 || c.enc_layers > FS2_MAX_LAYERS || c.dec_layers < 0 || c.dec_layers > FS2_MAX_LAYERS)
@@ -826,9 +827,9 @@ int fs2_create(const fs2_config* cfg, fs2_engine** out) {
     if (r != FS2_OK) return r;
     e->dt = cfg->dtype;
     e->fdt = cfg->dtype == FS2_BF16 ? FS2_BF16 : FS2_F32;
-    e->bdt = cfg->dtype == FS2_F32 ? FS2_F32 : FS2_BF16;
+    e->bdt = (cfg->dtype == FS2_F32 || cfg->dtype == FS2_F32_X3) ? FS2_F32 : FS2_BF16;
     e->esz = cfg->dtype == FS2_BF16 ? 2 : 4;
-    e->front_split = cfg->dtype == FS2_MIXED_X3;
+    e->front_split = cfg->dtype == FS2_MIXED_X3 || cfg->dtype == FS2_F32_X3;  // every fp32-weight GEMM / conv as bf16 x 3 split products
     build_spec(e);
     return FS2_OK;
 }

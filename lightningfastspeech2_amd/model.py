@@ -26,7 +26,9 @@ from .config import Fs2Config
 # bf16 for the decoder + mel head (include/fs2.h: FS2_MIXED)
 # "mixed3": the same with the front's matrix products as bf16 x 3 split products of the fp32 operands (FS2_MIXED_X3)
 _PRECISIONS = {"fp32": _lib.FS2_F32, "f32": _lib.FS2_F32, "bf16": _lib.FS2_BF16, "mixed": _lib.FS2_MIXED,
-               "mixed3": _lib.FS2_MIXED_X3}
+               "mixed3": _lib.FS2_MIXED_X3, "fp32x3": _lib.FS2_F32_X3}
+# "fp32x3": the fp32 mode's storage, attention, LayerNorm, heads and decision logic with EVERY GEMM / conv as bf16 x 3 split products
+# (FS2_F32_X3): ~1e-5 on the mel against "fp32" at about half its time
 
 
 def _ptr(t: Optional[torch.Tensor]):

@@ -120,6 +120,34 @@ def test_fp32_matches_oracle(case):
     assert errs["mel"] <= MEL_TOL_FP32, errs
 
 
+@pytest.mark.parametrize("case", list(CASES))
+def test_fp32x3_matches_oracle_at_the_fp32_tolerance(case):
+    """precision="fp32x3" (FS2_F32_X3): the fp32 mode with EVERY GEMM / conv as bf16 x 3 split products of the fp32 operands.  Held
+    to the fp32 mode's own bar against the oracle (MEL_TOL_FP32 = 1e-3 on the encoder output and on the mel under the oracle's
+    decisions); duration / bucket flips against the oracle are reported like the fp32 mode's."""
+    mk, B, L, lengths, skw = CASES[case]
+    cfg = mk()
+    sd, inp, ref = _oracle_case(cfg, B, L, lengths, seed=3, **skw)
+    m = _model(cfg, sd, "fp32x3")
+    m.engine.set_debug(True)
+    batch = {"phones": torch.from_numpy(inp["phones"]), "speaker": torch.from_numpy(inp["speaker"])}
+    out = _cpu(m(batch, inference=True))
+    dflips = int((out["duration_rounded"] != ref["duration_rounded"]).sum())
+    enc = float((m.engine.debug_tensor("encoder_out").cpu() - ref["_intermediates"]["encoder_out"]).abs().max())
+    assert enc <= MEL_TOL_FP32, enc
+    out = _cpu(m.forward(batch, force_durations=ref["duration_rounded"]))
+    assert torch.equal(out["tgt_mask"], ref["tgt_mask"]) and torch.equal(out["src_mask"], ref["src_mask"])
+    bflips = {v: int((m.engine.debug_tensor(f"bucket_{v}").cpu().long() != ref["_intermediates"][f"bucket_{v}"]).sum())
+              for v in cfg.variances}
+    out = _cpu(m.forward(batch, force_durations=ref["duration_rounded"],
+                         force_buckets={v: ref["_intermediates"][f"bucket_{v}"] for v in cfg.variances}))
+    errs = {f"variances_{v}": float((out[f"variances_{v}"] - ref[f"variances_{v}"]).abs().max()) for v in cfg.variances}
+    errs["mel"] = float((out["mel"] - ref["mel"]).abs().max())
+    _report(test="oracle_fp32x3", case=case, duration_flips=dflips, bucket_flips=bflips, encoder_out_max=enc, errs=errs)
+    assert errs["mel"] <= MEL_TOL_FP32, errs
+    assert dflips <= max(1, ref["duration_rounded"].numel() // 100) and sum(bflips.values()) <= max(2, sum(ref["_intermediates"][f"bucket_{v}"].numel() for v in cfg.variances) // 50)
+
+
 @pytest.mark.parametrize("case", ["c2arch_ragged", "refdefault_dw"])
 def test_bf16_close_under_forced_durations(case):
     mk, B, L, lengths, skw = CASES[case]
