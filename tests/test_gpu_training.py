@@ -336,9 +336,11 @@ def test_checkpoint_resume_is_exact():
     assert torch.equal(a.flat_p, b.flat_p) and torch.equal(a.flat_m, b.flat_m) and a.steps == b.steps == 3
 
 
-def test_full_length_utterance_gradients_vs_oracle():
+@pytest.mark.parametrize("case", ["one_full", "ragged3"])
+def test_full_length_utterance_gradients_vs_oracle(case):
     """BASELINE configs[1] architecture (FS2-27M: H = 256, F = 1024, k = 9, 4 + 4 layers) on one full-length utterance
-    (256 phonemes -> 1536 frames), fp32: losses and every parameter's gradient against the autograd oracle.  At this length a
+    (256 phonemes -> 1536 frames), and on a ragged batch of three (256 / 180 / 64 phonemes, durations 2..10 frames: pad phones, pad
+    frames and unequal T at the full length), fp32: losses and every parameter's gradient against the autograd oracle.  At this length a
     gradient entry is a sum over 1536 frames of cancelling fp32 terms on BOTH sides (the oracle is fp32 too): per tensor the
     direction must agree to cosine >= 0.99999 and no entry may differ by more than 2 % of the tensor's largest (measured:
     cosine >= 0.999997, worst entry 1.0 %; tools/probes/full_len_grad_check.py prints the table)."""
@@ -347,13 +349,22 @@ def test_full_length_utterance_gradients_vs_oracle():
     from lightningfastspeech2_amd.training import Trainer
     cfg = preset("c2")
     sd = synth_state_dict(cfg, 0, duration_bias=math.log(7.0), duration_weight_scale=0.0)
-    inp = synth_inputs(cfg, 1, 256, seed=1234)
     rs = np.random.RandomState(5)
-    T = 256 * 6
-    batch = {"phones": inp["phones"], "speaker": inp["speaker"], "duration": np.full((1, 256), 6, np.int64),
-             "mel": (rs.randn(1, T, cfg.n_mels) - 2).astype(np.float32)}
+    if case == "one_full":
+        B = 1
+        inp = synth_inputs(cfg, 1, 256, seed=1234)
+        dur = np.full((1, 256), 6, np.int64)
+    else:
+        B, lengths = 3, [256, 180, 64]
+        inp = synth_inputs(cfg, B, 256, seed=1234, lengths=lengths)
+        dur = rs.randint(2, 11, size=(B, 256)).astype(np.int64)
+        for b, n in enumerate(lengths):
+            dur[b, n:] = 0
+    T = int(dur.sum(1).max())
+    batch = {"phones": inp["phones"], "speaker": inp["speaker"], "duration": dur,
+             "mel": (rs.randn(B, T, cfg.n_mels) - 2).astype(np.float32)}
     for v in cfg.variances:
-        batch[f"variances_{v}"] = rs.randn(1, T).astype(np.float32)
+        batch[f"variances_{v}"] = rs.randn(B, T).astype(np.float32)
     ref = train_cpu.OracleTrainer(cfg, sd, gradient_clip_val=None)
     want_l, _ = ref.training_step(batch)
     tr = Trainer(cfg, sd, gradient_clip_val=None)
