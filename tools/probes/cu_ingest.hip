@@ -7,6 +7,10 @@
 //           barrier of step s, written after it
 //   MODE 3: as 2, two steps of loads in flight
 //   MODE 4 / 5: LDS-DMA by all 8 waves into a ring of 3 / 4 stages (2 / 3 steps in flight), counted vmcnt, one barrier per step
+//   MODE 6: global_load_dwordx4 -> VGPR only (no LDS stage: the single-launch predictor's weight path), a 4-deep register ring,
+//           every thread 64 B per step, consumed by adds; no barrier
+//   MODE 7: BOTH at once - the 32 KiB of a step by LDS-DMA (mode 0) and another 32 KiB by the register path (mode 6's ring): does a CU
+//           ingest more through two paths than through one?  (reported: the SUM of both streams)
 // hipcc --offload-arch=gfx950 -O3 -o /tmp/cu_ingest tools/probes/cu_ingest.hip && /tmp/cu_ingest
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -40,7 +44,35 @@ __global__ __launch_bounds__(512, 1) void k(const unsigned char* w, int panel, i
         }
     };
     for (int r = 0; r < reps; ++r) {
-        if (MODE >= 4) {
+        if (MODE == 6 || MODE == 7) {
+            uint4 q[4][4];
+            auto ld = [&](uint4 (&x)[4], int s) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) x[i] = *(const uint4*)(w + (MODE == 7 ? ((size_t)panel + (size_t)s * STEP) % (size_t)(8 << 20) : (size_t)s * STEP) + (i * 512 + tid) * 16);
+            };
+            auto use = [&](const uint4 (&x)[4]) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc += __uint_as_float(x[i].x) + __uint_as_float(x[i].w);
+            };
+            // (mode 7 reads its register stream from the bytes BEHIND the panel - another L2-resident region - so that the two streams
+            // do not hit the same lines)
+            ld(q[0], 0); if (nsteps > 1) ld(q[1], 1); if (nsteps > 2) ld(q[2], 2);
+            if (MODE == 7) dma(b0, 0);
+#pragma unroll 4
+            for (int s = 0; s < nsteps; ++s) {
+                if (MODE == 7) {
+                    // the DMA of step s must have landed; the register loads of steps s+1.. (4 per step, issued after it) may fly
+                    if (s + 2 < nsteps) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();
+                    if (s + 1 < nsteps) dma((s & 1) ? b0 : b1, s + 1);
+                }
+                if (s + 3 < nsteps) ld(q[(s + 3) & 3], s + 3);
+                use(q[s & 3]);
+                if (MODE == 7) consume((s & 1) ? b1 : b0);
+            }
+            if (MODE == 7) __syncthreads();
+        } else if (MODE >= 4) {
             constexpr int NST = MODE - 1;  // 3 or 4 stages
             __shared__ __attribute__((aligned(16))) unsigned char ring[4][STEP];
             unsigned char* const st0 = &ring[0][0];
@@ -113,14 +145,15 @@ template <int MODE> void run(const unsigned char* w, float* o, int panel, int gr
     (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
     float ms; (void)hipEventElapsedTime(&ms, e0, e1);
     const double per_cu = (double)panel * reps / (ms * 1e-3) / 1e9;
-    printf("mode %d  panel %5d KiB  %3d workgroups: %6.1f GB/s per CU, %5.2f TB/s chip\n", MODE, panel >> 10, grid, per_cu, per_cu * grid / 1e3);
+    const double mult = MODE == 7 ? 2.0 : 1.0;  // two 32-KiB streams per step
+    printf("mode %d  panel %5d KiB  %3d workgroups: %6.1f GB/s per CU, %5.2f TB/s chip\n", MODE, panel >> 10, grid, per_cu * mult, per_cu * mult * grid / 1e3);
 }
 int main() {
     unsigned char* w; float* o;
     (void)hipMalloc(&w, 8 << 20); (void)hipMemset(w, 1, 8 << 20); (void)hipMalloc(&o, 256 * 512 * 4);
     for (int panel : {512 << 10, 4 << 20}) {
         run<0>(w, o, panel, 256); run<1>(w, o, panel, 256); run<2>(w, o, panel, 256); run<3>(w, o, panel, 256);
-        run<4>(w, o, panel, 256); run<5>(w, o, panel, 256);
+        run<4>(w, o, panel, 256); run<5>(w, o, panel, 256); run<6>(w, o, panel, 256); run<7>(w, o, panel, 256);
     }
     run<0>(w, o, 512 << 10, 32); run<2>(w, o, 512 << 10, 32);
     return 0;
