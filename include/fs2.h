@@ -274,6 +274,12 @@ int fs2_op_gemm_ln(int32_t dtype, const void* x, const void* w, const float* bia
 int fs2_op_gemm_ln_tape(int32_t dtype, const void* x, const void* w, const float* bias, const void* res, const float* ln_g,
                         const float* ln_b, void* y, void* z_out, int32_t M, int32_t N, int32_t Cin, int32_t taps, int32_t S,
                         int32_t relu, void* hip_stream);
+/* ... with nn.Dropout between the product and the residual add (the residual sites of ConformerEncoderLayer in training mode, model.py:
+ * 117-121): z = dropout(act(x w^T + bias)) + res, y = LayerNorm(z); the mask is fs2_op_dropout's over the (M, N) product with this
+ * (p, seed, key), so fs2_op_dropout on the gradient regenerates it. */
+int fs2_op_gemm_ln_tape_dropout(int32_t dtype, const void* x, const void* w, const float* bias, const void* res, const float* ln_g,
+                                const float* ln_b, void* y, void* z_out, int32_t M, int32_t N, int32_t Cin, int32_t taps, int32_t S,
+                                int32_t relu, float p, uint64_t seed, uint64_t key, void* hip_stream);
 size_t fs2_op_attention_scratch_bytes(int32_t dtype, int32_t B, int32_t S, int32_t H, int32_t heads, size_t* bits_bytes);
 int fs2_op_layernorm(int32_t dtype, const void* x, const void* res, const float* gamma, const float* beta, void* y,
                      const float* dot_w, float dot_b, const uint8_t* mask, float* pred, int32_t M, int32_t H,

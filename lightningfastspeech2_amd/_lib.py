@@ -148,6 +148,7 @@ def load():
     lib.fs2_op_gemm_splitk.argtypes = [i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.fs2_op_gemm_gated.argtypes = [i32, vp, vp, vp, vp, C.c_float, vp, i32, i32, i32, i32, i32, vp]
     lib.fs2_op_gemm_ln_tape.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    lib.fs2_op_gemm_ln_tape_dropout.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, C.c_float, C.c_uint64, C.c_uint64, vp]
     lib.fs2_op_gemm_ln.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.fs2_op_attention_scratch_bytes.restype = C.c_size_t
     lib.fs2_op_attention_scratch_bytes.argtypes = [i32, i32, i32, i32, i32, C.POINTER(C.c_size_t)]

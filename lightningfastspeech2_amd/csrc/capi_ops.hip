@@ -185,6 +185,20 @@ int fs2_op_gemm_ln_tape(int32_t dtype, const void* x, const void* w, const float
     return launch_gemm(a, dtype, dtype, (hipStream_t)stream);
 }
 
+int fs2_op_gemm_ln_tape_dropout(int32_t dtype, const void* x, const void* w, const float* bias, const void* res, const float* ln_g,
+                                const float* ln_b, void* y, void* z_out, int32_t M, int32_t N, int32_t Cin, int32_t taps, int32_t S,
+                                int32_t relu, float p, uint64_t seed, uint64_t key, void* stream) {
+    if (!x || !w || !ln_g || !ln_b || !y || !z_out) return FS2_ERR_ARG;
+    if (!(p >= 0.f && p < 1.f)) return FS2_ERR_ARG;
+    GemmArgs a;
+    a.X = x; a.W = w; a.bias = bias; a.C = y;
+    a.M = M; a.N = N; a.K = taps * Cin; a.ldx = Cin; a.ldc = N;
+    a.Cin = Cin; a.taps = taps; a.pad = (taps - 1) / 2; a.S = S; a.relu = relu;
+    a.res = res; a.ln_g = ln_g; a.ln_b = ln_b; a.z_out = z_out;
+    a.drop_p = p; a.drop_seed = seed; a.drop_key = key;
+    return launch_gemm(a, dtype, dtype, (hipStream_t)stream);
+}
+
 size_t fs2_op_attention_scratch_bytes(int32_t dtype, int32_t B, int32_t S, int32_t H, int32_t heads, size_t* bits_bytes) {
     (void)heads;
     const size_t Spad = ((size_t)S + 63) / 64 * 64;

@@ -46,6 +46,8 @@ struct GemmArgs {
     const uint8_t* zero_rows = nullptr;  // (M) 1 = store zeros for this row (128x128 kernel only: the mel head)
     const void* gate = nullptr;     // slab kernel, plain epilogue: C = gate > 0 ? gate_scale * (acc + bias) : 0; gate has C's shape, ldc and dtype
     float gate_scale = 1.f;
+    float drop_p = 0.f;             // slab kernel, fused LayerNorm epilogue only: z = dropout(act(acc + bias)) [+ res] with the counter-based
+    uint64_t drop_seed = 0, drop_key = 0;  // mask of fs2_op_dropout over the (M, N) product (element index row * N + col) - the residual sites of the training step
     int ksplit = 0;                 // > 1: split-K on the slab kernel (plain epilogue, fp32 out, no bias / ReLU / gate): split s sums the channel
                                     // blocks [s, s + 1) * Cin / ksplit of every tap into plane s of C (ksplit, M, ldc); launch_split_k_reduce adds them
 };

@@ -490,7 +490,8 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
     // with 16-byte loads that land underneath the first operand DMAs instead of sitting, exposed,
     // between the K loop and the row statistics.
     // (the deferred-LayerNorm epilogue does the same with ITS residual, normalised first if that is a pre-norm tensor)
-    const bool res_in_acc = !p.relu && (LN ? p.res != nullptr : (DEFER && p.epi_res != nullptr));
+    // (with the epilogue's dropout the residual must stay OUT of the accumulators: the mask applies to the product alone)
+    const bool res_in_acc = !p.relu && !(LN && p.drop_p > 0.f) && (LN ? p.res != nullptr : (DEFER && p.epi_res != nullptr));
     int woff[4][2];                          // weight fragment byte offsets (tap independent)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -784,6 +785,25 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
                     const float bvv = (p.bias && n + r < p.N) ? p.bias[n + r] : 0.f;
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi) acc[ni][mi][r] = fmaxf(acc[ni][mi][r] + bvv, lo);
+                }
+            }
+            if (p.drop_p > 0.f) {
+                // nn.Dropout between the sub-layer and its residual add (model.py:117-121: x = norm(x + dropout(sublayer(x)))): the
+                // stand-alone kernel's mask (dropout_bits over the element index row * N + col of the (M, N) product), applied to the
+                // fp32 value before the residual - the backward regenerates it from the same (seed, key)
+                const uint32_t thr = (uint32_t)(p.drop_p * 16777216.0f);
+                const float dsc = 1.f / (1.f - p.drop_p);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const int t = t0 + wm * (MI * 16) + mi * 16 + fr;
+                    const uint64_t e0 = (uint64_t)(rowbase + (t < S ? t : S - 1)) * (uint64_t)p.N;
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) {
+                        const int n = wn * 64 + wcol(ni, fg);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            acc[ni][mi][r] = dropout_bits(p.drop_seed, p.drop_key, e0 + (uint64_t)(n + r)) >= thr ? acc[ni][mi][r] * dsc : 0.f;
+                    }
                 }
             }
             if (!full) {  // columns past N hold act(0 + 0): make them exact zeros for the row sums
@@ -1253,6 +1273,7 @@ int launch_gemm(const GemmArgs& a, int in_dtype, int out_dtype, hipStream_t stre
     // followed by the stand-alone LayerNorm kernel (same arithmetic, one more HBM round trip)
     bool fused = false;
     if (a.z_out && a.N > S_BN) return FS2_ERR_SHAPE;  // the pre-norm store exists in the one-column-tile epilogue only
+    if (a.drop_p > 0.f && (a.N > S_BN || !a.z_out)) return FS2_ERR_SHAPE;  // the epilogue's dropout: one-column-tile fused form only (training tape)
     if ((a.N <= S_BN || (g_wide_ln && a.N <= 1024 && (a.C || a.ln_tmp))) && in_dtype == out_dtype) {
         const int r = launch_gemm_plain(a, in_dtype, out_dtype, stream, &fused);
         if (r != FS2_OK || fused) return r;

@@ -59,6 +59,7 @@ class _Ops:
         self.seed = 0       # dropout: set per micro-step by the trainer
         self._site = 0      # dropout site counter of the current forward
         self.fuse_ln = os.environ.get("FS2_TRAIN_FUSE_LN", "1") != "0"  # A/B switch: GEMM + LayerNorm as one launch where it applies
+        self.fuse_ln_drop = os.environ.get("FS2_TRAIN_FUSE_LN_DROPOUT", "1") != "0"  # A/B switch: the residual-site dropout inside that launch
         self.fuse_add = os.environ.get("FS2_TRAIN_FUSE_ADD", "1") != "0"  # A/B switch: "dx +=" of a data-gradient product inside the GEMM launch
         self.splitk = os.environ.get("FS2_TRAIN_SPLITK", "1") != "0"    # A/B switch: split-K data-gradient convs where fs2_op_gemm_splitk_choice says so
 
@@ -112,14 +113,22 @@ class _Ops:
                                      int(relu), self.st()), "gemm")
         return y
 
-    def gemm_ln_tape(self, x, w, bias, res, g, b, M, N, Cin, taps=1, S=None, relu=False):
+    def gemm_ln_tape(self, x, w, bias, res, g, b, M, N, Cin, taps=1, S=None, relu=False, drop=None):
         """y = LayerNorm(z), z = act(x W^T + bias) [+ res], both stored, in ONE launch (the inference engine's fused GEMM +
-        LayerNorm epilogue with a pre-norm store); None where that epilogue does not apply (N > 256, odd shapes, knob off)."""
+        LayerNorm epilogue with a pre-norm store); None where that epilogue does not apply (N > 256, odd shapes, knob off).
+        drop = (p, key): z = dropout(act(.)) + res with the mask of ``dropout(., p, key)`` (the residual sites in training mode)."""
         if not self.fuse_ln or N > 256:
             return None
         y, z = self.act(M, N), self.act(M, N)
-        st_ = self.lib.fs2_op_gemm_ln_tape(self.dt, _p(x), _p(w), _p(bias), _p(res), _p(g), _p(b), _p(y), _p(z), M, N, Cin, taps,
-                                           S or M, int(relu), self.st())
+        if drop is not None and drop[0] > 0:
+            if not self.fuse_ln_drop:
+                return None
+            st_ = self.lib.fs2_op_gemm_ln_tape_dropout(self.dt, _p(x), _p(w), _p(bias), _p(res), _p(g), _p(b), _p(y), _p(z), M, N, Cin, taps,
+                                                       S or M, int(relu), C.c_float(drop[0]), C.c_uint64(self.seed), C.c_uint64(drop[1]),
+                                                       self.st())
+        else:
+            st_ = self.lib.fs2_op_gemm_ln_tape(self.dt, _p(x), _p(w), _p(bias), _p(res), _p(g), _p(b), _p(y), _p(z), M, N, Cin, taps,
+                                               S or M, int(relu), self.st())
         if st_ == _lib.FS2_ERR_SHAPE:
             return None
         self.ck(st_, "gemm_ln_tape")
@@ -525,7 +534,7 @@ class Trainer:
         # without dropout the out-projection, the residual add and norm1 are ONE launch that also leaves the pre-norm sum for the
         # tape (t["proj"] then holds x + proj and the backward's LayerNorm takes no separate residual)
         f1 = o.gemm_ln_tape(attn, W[f"{prefix}.self_attn.out_proj.weight"], P[f"{prefix}.self_attn.out_proj.bias"], x,
-                            P[f"{prefix}.norm1.weight"], P[f"{prefix}.norm1.bias"], M, H, H) if pd <= 0 else None
+                            P[f"{prefix}.norm1.weight"], P[f"{prefix}.norm1.bias"], M, H, H, drop=(pd, t["k_sa"]))  # (dropout1 inside)
         if f1 is not None:
             x1, proj = f1
         else:
@@ -540,7 +549,7 @@ class Trainer:
         else:
             h = o.dropout(o.gemm(x1, W[f"{prefix}.conv1.weight"], P[f"{prefix}.conv1.bias"], M, F_, H, taps=k, S=S, relu=True), pd, t["k_h"])
             f2 = o.gemm_ln_tape(h, W[f"{prefix}.conv2.weight"], P[f"{prefix}.conv2.bias"], x1, P[f"{prefix}.norm2.weight"],
-                                P[f"{prefix}.norm2.bias"], M, H, F_) if pd <= 0 else None
+                                P[f"{prefix}.norm2.bias"], M, H, F_, drop=(pd, t["k_ff"]))  # (dropout2 inside)
             if f2 is not None:
                 x2, c2 = f2
             else:
