@@ -393,6 +393,12 @@ int fs2_op_layernorm_bwd(int32_t dtype, const void* z, const void* res, const vo
 int fs2_op_layernorm_bwd_dropout(int32_t dtype, const void* z, const void* res, const void* dy, const float* gamma, void* dz,
                                  float* part, int32_t M, int32_t H, int32_t relu_mask, float drop_p, uint64_t seed, uint64_t key,
                                  void* hip_stream);
+/* ... for y = LayerNorm(res + dropout(u)) (the residual sites): dz as above (the residual's gradient) AND dzm = mask o dz / (1 - out_p),
+ * the gradient of u, as a second tensor (mask of fs2_op_dropout(., out_p, seed, out_key) over (M, H)); the third column sum of part is
+ * then dzm's (u's bias gradient). */
+int fs2_op_layernorm_bwd_masked(int32_t dtype, const void* z, const void* res, const void* dy, const float* gamma, void* dz, void* dzm,
+                                float* part, int32_t M, int32_t H, int32_t relu_mask, float out_p, uint64_t seed, uint64_t out_key,
+                                void* hip_stream);
 /* fs2_op_layernorm with its fused Linear(H, 1) head reading the bias from DEVICE memory (a parameter being trained: the host
  * copy would cost a read-back + stream sync per step) */
 int fs2_op_layernorm_head(int32_t dtype, const void* x, const void* res, const float* gamma, const float* beta, void* y,

@@ -176,6 +176,7 @@ def load():
     lib.fs2_op_layernorm_bwd_parts.argtypes = [i32]
     lib.fs2_op_layernorm_bwd.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]
     lib.fs2_op_layernorm_bwd_dropout.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, C.c_float, C.c_uint64, C.c_uint64, vp]
+    lib.fs2_op_layernorm_bwd_masked.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, C.c_float, C.c_uint64, C.c_uint64, vp]
     lib.fs2_op_layernorm_head.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]
     lib.fs2_op_layernorm_dropout.argtypes = [i32, vp, vp, vp, vp, vp, i32, i32, C.c_float, C.c_uint64, C.c_uint64, vp]
     lib.fs2_op_col_sum_ws_bytes.restype = sz

@@ -120,10 +120,23 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(LayerNormBwdArgs p) 
                 if (p.relu_mask && !pos[j][e]) v = 0.f;
                 v = Num<T>::to_f32(Num<T>::from_f32(v));  // the column sum is of the stored value
                 o[e] = v;
-                dc[j][e] += v;
+                if (!p.dzm) dc[j][e] += v;
             }
             const int c = j * 256 + lane * 4;
             if (c < H) st4<T>(dz + (long)row * H + c, o);
+            if (p.dzm) {  // the same gradient through the dropout on the sub-layer's summand: a second tensor instead of a pass of its own
+                const uint32_t thr = (uint32_t)(p.out_p * 16777216.0f);
+                const float sc = 1.f / (1.f - p.out_p);
+                float m[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = dropout_bits(p.drop_seed, p.out_key, (uint64_t)row * H + c + e) >= thr ? o[e] * sc : 0.f;
+                    v = Num<T>::to_f32(Num<T>::from_f32(v));
+                    m[e] = v;
+                    dc[j][e] += v;  // the third column sum is that of dzm
+                }
+                if (c < H) st4<T>((T*)p.dzm + (long)row * H + c, m);
+            }
         }
     }
 #pragma unroll

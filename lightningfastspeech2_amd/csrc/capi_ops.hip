@@ -367,6 +367,14 @@ int fs2_op_layernorm_bwd_dropout(int32_t dtype, const void* z, const void* res, 
     a.drop_p = drop_p; a.drop_seed = seed; a.drop_key = key;
     return launch_layernorm_bwd(a, dtype, (hipStream_t)stream);
 }
+int fs2_op_layernorm_bwd_masked(int32_t dtype, const void* z, const void* res, const void* dy, const float* gamma, void* dz, void* dzm,
+                                float* part, int32_t M, int32_t H, int32_t relu_mask, float out_p, uint64_t seed, uint64_t out_key,
+                                void* stream) {
+    if (!dzm || !(out_p > 0.f && out_p < 1.f)) return FS2_ERR_ARG;
+    LayerNormBwdArgs a{z, res, dy, gamma, dz, part, M, H, layernorm_bwd_parts(M), 1e-5f, relu_mask};
+    a.drop_seed = seed; a.dzm = dzm; a.out_p = out_p; a.out_key = out_key;
+    return launch_layernorm_bwd(a, dtype, (hipStream_t)stream);
+}
 size_t fs2_op_col_sum_ws_bytes(int32_t M, int32_t N, int32_t seg) { return col_sum_ws_bytes(M, N, seg); }
 int fs2_op_col_sum(int32_t dtype, const void* x, float* out, float* ws, int32_t M, int32_t N, int32_t ldx, int32_t seg,
                    int32_t accumulate, float scale, void* stream) {

@@ -378,6 +378,11 @@ struct LayerNormBwdArgs {
     int relu_mask;        // 1: z is a ReLU output; dz := dz where z > 0 else 0 (the gradient of the PRE-activation)
     float drop_p = 0.f;   // > 0: dy is the gradient of dropout(y): the mask of the forward (seed, key) is applied to dy on load
     uint64_t drop_seed = 0, drop_key = 0;
+    // second output: dz through the dropout that sat on ONE summand of z (z = res + dropout(u): dzm = mask o dz / (1 - p) = du, while dz
+    // itself is the residual's gradient).  With it the third column sum of `part` is that of dzm (u's bias gradient).
+    void* dzm = nullptr;  // (M, H) out or null
+    float out_p = 0.f;
+    uint64_t out_key = 0; // (seed = drop_seed is shared: one seed per micro-step)
 };
 int layernorm_bwd_parts(int M);
 int launch_layernorm_bwd(const LayerNormBwdArgs& a, int dtype, hipStream_t stream);

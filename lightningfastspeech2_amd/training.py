@@ -560,13 +560,21 @@ class Trainer:
         t.update(qkv=qkv, prob=prob, prob_d=prob_d, lse=lse, key_pad=key_pad, attn=attn, proj=proj, x1=x1, h=h, c2=c2, scale=scale)
         return x2, t
 
-    def _ln_bwd(self, z, res, dy, gname, bname, M, H, bias_name=None, relu_mask=False, bias_out=None, drop=None):
+    def _ln_bwd(self, z, res, dy, gname, bname, M, H, bias_name=None, relu_mask=False, bias_out=None, drop=None, out_drop=None):
         """dz of y = LN(z [+ res]); dgamma / dbeta (adjacent in the flat buffer: one column-sum launch) and, when asked, the
-        bias gradient of the layer that produced z (= column sums of dz; with relu_mask dz is the pre-activation gradient)."""
+        bias gradient of the layer that produced z (= column sums of dz; with relu_mask dz is the pre-activation gradient).
+        out_drop = (p, key): z = res + dropout(u) - returns (dz, dzm) with dzm = u's gradient (the mask applied in the same launch)
+        and the bias gradient asked for is u's."""
         o = self.ops
         nparts = int(o.lib.fs2_op_layernorm_bwd_parts(M))
         dz, part = o.act(M, H), o.empty(nparts, 3 * H)
-        if drop is not None and drop[0] > 0:  # dy is the gradient of dropout(y): the mask is applied on load, no separate pass
+        dzm = None
+        if out_drop is not None and out_drop[0] > 0:
+            dzm = o.act(M, H)
+            o.ck(o.lib.fs2_op_layernorm_bwd_masked(o.dt, _p(z), _p(res), _p(dy), _p(self.P[gname]), _p(dz), _p(dzm), _p(part), M, H,
+                                                   int(relu_mask), C.c_float(out_drop[0]), C.c_uint64(o.seed), C.c_uint64(out_drop[1]),
+                                                   o.st()), "layernorm_bwd")
+        elif drop is not None and drop[0] > 0:  # dy is the gradient of dropout(y): the mask is applied on load, no separate pass
             o.ck(o.lib.fs2_op_layernorm_bwd_dropout(o.dt, _p(z), _p(res), _p(dy), _p(self.P[gname]), _p(dz), _p(part), M, H, int(relu_mask),
                                                     C.c_float(drop[0]), C.c_uint64(o.seed), C.c_uint64(drop[1]), o.st()), "layernorm_bwd")
         else:
@@ -577,7 +585,7 @@ class Trainer:
             # dgamma | dbeta (adjacent in the flat buffer) and the bias gradient out of one launch
             o.col_sum2(part, gw, self.G[bias_name] if bias_name is not None else bias_out, 2 * H, nparts, 3 * H,
                        accumulate2=bias_name is not None)
-            return dz
+            return dz if dzm is None else (dz, dzm)
         if gb.data_ptr() == gw.data_ptr() + 4 * H:
             o.col_sum(part, gw, nparts, 2 * H, ldx=3 * H)
         else:
@@ -587,7 +595,7 @@ class Trainer:
             o.col_sum(part[:, 2 * H:], self.G[bias_name], nparts, H, ldx=3 * H)
         if bias_out is not None:
             o.col_sum(part[:, 2 * H:], bias_out, nparts, H, ldx=3 * H, accumulate=False)
-        return dz
+        return dz if dzm is None else (dz, dzm)
 
     def _layer_bwd(self, dx2, t, prefix, B, S, heads, F_, k):
         o, P, W, G, H = self.ops, self.P, self.W, self.G, self.cfg.hidden
@@ -595,11 +603,14 @@ class Trainer:
         pd, folded = t["pd"], prefix in self.fold
         dbf = o.empty(H) if folded else None
         # x2 = LN2(x1 + dropout2(c2)): dz2 is the gradient of x1 (residual) and, through dropout2, of c2
+        fm = pd > 0 and o.fuse_ln_drop  # the dropout backward of the sub-layer's summand as a second output of the LayerNorm backward
         dx1 = self._ln_bwd(t["c2"], None if t["sum2"] else t["x1"], dx2, f"{prefix}.norm2.weight", f"{prefix}.norm2.bias", M, H,
-                           bias_name=f"{prefix}.conv2.bias" if (pd <= 0 and not folded) else None,
-                           bias_out=dbf if (pd <= 0 and folded) else None)
+                           bias_name=f"{prefix}.conv2.bias" if ((pd <= 0 or fm) and not folded) else None,
+                           bias_out=dbf if ((pd <= 0 or fm) and folded) else None, out_drop=(pd, t["k_ff"]) if fm else None)
         dc2 = dx1
-        if pd > 0:
+        if fm:
+            dx1, dc2 = dx1
+        elif pd > 0:
             dc2 = o.dropout(dx1, pd, t["k_ff"], out=o.act(M, H))
             o.col_sum(dc2, dbf if folded else G[f"{prefix}.conv2.bias"], M, H, accumulate=not folded)
         if folded:
@@ -630,9 +641,12 @@ class Trainer:
             o.dgrad(dh, W[f"{prefix}.conv1.weight"], M, F_, H, taps=k, S=S, out=dx1, accumulate=True, wt=self._wt(f"{prefix}.conv1.weight"))
         # x1 = LN1(x + dropout1(proj))
         dx = self._ln_bwd(t["proj"], None if t["sum1"] else t["x"], dx1, f"{prefix}.norm1.weight", f"{prefix}.norm1.bias", M, H,
-                          bias_name=f"{prefix}.self_attn.out_proj.bias" if pd <= 0 else None)
+                          bias_name=f"{prefix}.self_attn.out_proj.bias" if (pd <= 0 or fm) else None,
+                          out_drop=(pd, t["k_sa"]) if fm else None)
         dproj = dx
-        if pd > 0:
+        if fm:
+            dx, dproj = dx
+        elif pd > 0:
             dproj = o.dropout(dx, pd, t["k_sa"], out=o.act(M, H))
             o.col_sum(dproj, G[f"{prefix}.self_attn.out_proj.bias"], M, H)
         o.wgrad(dproj, t["attn"], G[f"{prefix}.self_attn.out_proj.weight"], None, M, H, H)
