@@ -240,6 +240,10 @@ int fs2_op_set_vocoder_lds_limit(int32_t kib);
 int fs2_op_set_vocoder_fused_resblock(int32_t on);
 int fs2_op_gemm(int32_t dtype, int32_t out_dtype, const void* x, const void* w, const float* bias, void* c,
                 int32_t M, int32_t N, int32_t Cin, int32_t taps, int32_t S, int32_t relu, void* hip_stream);
+/* c = dropout(relu(x w^T + bias)) with fs2_op_dropout's mask over the (M, N) product in the store (the FFN's hidden tensor in training
+ * mode: no read-modify-write pass over the (M, filter) tensor).  FS2_ERR_SHAPE when the shape does not run on the slab kernel. */
+int fs2_op_gemm_relu_dropout(int32_t dtype, const void* x, const void* w, const float* bias, void* c, int32_t M, int32_t N, int32_t Cin,
+                             int32_t taps, int32_t S, float p, uint64_t seed, uint64_t key, void* hip_stream);
 /* c = x w^T + bias + addend, addend (M, N) in the launch dtype; addend == c is allowed (a workgroup reads its own tile of it before it
  * writes it): the accumulating data-gradient products of the training step (dx += dy . W) without an elementwise pass behind them.
  * FS2_ERR_SHAPE when the shape does not run on the slab kernel (N < 192, M % S != 0, even tap count). */

@@ -143,6 +143,7 @@ def load():
     lib.fs2_op_set_vocoder_lds_limit.argtypes = [i32]
     lib.fs2_op_set_vocoder_fused_resblock.argtypes = [i32]
     lib.fs2_op_gemm.argtypes = [i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    lib.fs2_op_gemm_relu_dropout.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, C.c_float, C.c_uint64, C.c_uint64, vp]
     lib.fs2_op_gemm_add.argtypes = [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.fs2_op_gemm_splitk_choice.argtypes = [i32, i32, i32, i32, i32, i32]
     lib.fs2_op_gemm_splitk.argtypes = [i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]

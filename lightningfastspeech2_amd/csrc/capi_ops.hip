@@ -120,6 +120,17 @@ int fs2_op_gemm(int32_t dtype, int32_t out_dtype, const void* x, const void* w, 
     return launch_gemm(a, dtype, out_dtype, (hipStream_t)stream);
 }
 
+int fs2_op_gemm_relu_dropout(int32_t dtype, const void* x, const void* w, const float* bias, void* c, int32_t M, int32_t N, int32_t Cin,
+                             int32_t taps, int32_t S, float p, uint64_t seed, uint64_t key, void* stream) {
+    if (!(p > 0.f && p < 1.f)) return FS2_ERR_ARG;
+    GemmArgs a;
+    a.X = x; a.W = w; a.bias = bias; a.C = c;
+    a.M = M; a.N = N; a.K = taps * Cin; a.ldx = Cin; a.ldc = N;
+    a.Cin = Cin; a.taps = taps; a.pad = (taps - 1) / 2; a.S = S; a.relu = 1;
+    a.drop_p = p; a.drop_seed = seed; a.drop_key = key;
+    return launch_gemm(a, dtype, dtype, (hipStream_t)stream);
+}
+
 int fs2_op_gemm_add(int32_t dtype, const void* x, const void* w, const float* bias, const void* addend, void* c, int32_t M, int32_t N,
                     int32_t Cin, int32_t taps, int32_t S, void* stream) {
     if (!addend) return FS2_ERR_ARG;

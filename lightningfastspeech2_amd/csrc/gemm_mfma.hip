@@ -1025,7 +1025,7 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
     // LayerNorm epilogue above): at K = 256 this store loop is as many issue cycles as the K loop
     // gate_c: out = gate[row][col] > 0 ? v : 0 with `gate` a tensor of C's layout and dtype - the ReLU backward of a data-gradient
     // product (training step: dh = (dc2 . W2) o [h > 0]) folded into the store instead of a 3-tensor elementwise pass
-    auto store = [&](auto relu_c, auto full_c, auto gate_c) {
+    auto store = [&](auto relu_c, auto full_c, auto gate_c, auto drop_c) {
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int t = t0 + wm * (MI * 16) + mi * 16 + fr;
@@ -1039,6 +1039,15 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
             for (int r = 0; r < 8; ++r) {
                 v[r] = acc[2 * j + (r >> 2)][mi][r & 3] + bv[j][r];
                 if constexpr (decltype(relu_c)::value) v[r] = fmaxf(v[r], 0.f);
+            }
+            if constexpr (decltype(drop_c)::value) {
+                // nn.Dropout behind the activation (the FFN's hidden tensor in training mode, model.py:94-106): fs2_op_dropout's mask over the
+                // (M, N) product, in the store instead of a read-modify-write pass over the (M, filter) tensor
+                const uint32_t thr = (uint32_t)(p.drop_p * 16777216.0f);
+                const float dsc = 1.f / (1.f - p.drop_p);
+                const uint64_t e0 = ((uint64_t)ub * S + (uint64_t)t) * (uint64_t)p.N + (uint64_t)n;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] = dropout_bits(p.drop_seed, p.drop_key, e0 + r) >= thr ? v[r] * dsc : 0.f;
             }
             if constexpr (decltype(gate_c)::value) {
                 const OutT* gt = (const OutT*)((const char*)p.gate + ((size_t)ub * S * p.ldc + (size_t)t * p.ldc + n) * sizeof(OutT));
@@ -1181,14 +1190,17 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
     }
     const bool fulln = n0 + S_BN <= p.N;  // this column tile lies wholly inside N
     if (p.gate) {  // (the launcher admits a gate without ReLU only)
-        if (fulln) store(BoolC<false>{}, BoolC<true>{}, BoolC<true>{});
-        else store(BoolC<false>{}, BoolC<false>{}, BoolC<true>{});
+        if (fulln) store(BoolC<false>{}, BoolC<true>{}, BoolC<true>{}, BoolC<false>{});
+        else store(BoolC<false>{}, BoolC<false>{}, BoolC<true>{}, BoolC<false>{});
+    } else if (p.drop_p > 0.f) {  // (the launcher admits the store's dropout with ReLU, bf16 / fp32 in = out, no gate)
+        if (fulln) store(BoolC<true>{}, BoolC<true>{}, BoolC<false>{}, BoolC<true>{});
+        else store(BoolC<true>{}, BoolC<false>{}, BoolC<false>{}, BoolC<true>{});
     } else if (fulln) {
-        if (p.relu) store(BoolC<true>{}, BoolC<true>{}, BoolC<false>{});
-        else store(BoolC<false>{}, BoolC<true>{}, BoolC<false>{});
+        if (p.relu) store(BoolC<true>{}, BoolC<true>{}, BoolC<false>{}, BoolC<false>{});
+        else store(BoolC<false>{}, BoolC<true>{}, BoolC<false>{}, BoolC<false>{});
     } else {
-        if (p.relu) store(BoolC<true>{}, BoolC<false>{}, BoolC<false>{});
-        else store(BoolC<false>{}, BoolC<false>{}, BoolC<false>{});
+        if (p.relu) store(BoolC<true>{}, BoolC<false>{}, BoolC<false>{}, BoolC<false>{});
+        else store(BoolC<false>{}, BoolC<false>{}, BoolC<false>{}, BoolC<false>{});
     }
 #else
     (void)p;
@@ -1264,6 +1276,12 @@ int g_wide_ln = 0;
 static int launch_gemm_plain(const GemmArgs& a, int in_dtype, int out_dtype, hipStream_t stream, bool* fused);
 
 int launch_gemm(const GemmArgs& a, int in_dtype, int out_dtype, hipStream_t stream) {
+    if (!a.ln_g && a.drop_p > 0.f) {  // the plain store's dropout: slab kernel, behind a ReLU (the FFN's hidden tensor)
+        if (!a.relu || a.gate || a.stats_out || a.epi_res || a.ksplit > 1 || a.zero_rows || g_gemm_variant != 0 || a.N < 192 || a.M % a.S ||
+            !(a.taps & 1) || in_dtype != out_dtype)
+            return FS2_ERR_SHAPE;
+        return launch_gemm_plain(a, in_dtype, out_dtype, stream, nullptr);  // (FS2_ERR_SHAPE there if it would take a flat kernel)
+    }
     if (!a.ln_g) {
         // K = 256 bf16: the column tile's weights live in registers, row tiles stream (gemm_wres.hip; bit-identical results)
         if (g_gemm_wres && g_gemm_variant == 0 && a.ksplit <= 1 && gemm_wres_supported(a, in_dtype, out_dtype, g_gemm_wres == 2)) return launch_gemm_wres(a, stream);
@@ -1368,7 +1386,7 @@ static int launch_gemm_plain(const GemmArgs& a, int in_dtype, int out_dtype, hip
         }
     }
     if (fused) return FS2_OK;  // not the slab kernel: caller falls back to GEMM + LayerNorm kernel
-    if (a.stats_out || a.epi_res || a.gate || ksp > 1) return FS2_ERR_SHAPE;  // the deferred-LayerNorm epilogue lives in the slab kernel only
+    if (a.stats_out || a.epi_res || a.gate || ksp > 1 || a.drop_p > 0.f) return FS2_ERR_SHAPE;  // the deferred-LayerNorm epilogue lives in the slab kernel only
     if (in_dtype == FS2_F32 && out_dtype == FS2_F32) return launch_t<float, float>(a, stream);
     if (in_dtype == FS2_BF16 && out_dtype == FS2_BF16) return launch_t<bf16, bf16>(a, stream);
     if (in_dtype == FS2_BF16 && out_dtype == FS2_F32) return launch_t<bf16, float>(a, stream);

@@ -113,6 +113,18 @@ class _Ops:
                                      int(relu), self.st()), "gemm")
         return y
 
+    def gemm_relu_dropout(self, x, w, bias, M, N, Cin, taps, S, p, key):
+        """dropout(relu(x W^T + bias)) - the mask of ``dropout(., p, key)`` - in one launch where the slab kernel runs the shape."""
+        if p > 0 and self.fuse_ln_drop:
+            y = self.act(M, N)
+            st_ = self.lib.fs2_op_gemm_relu_dropout(self.dt, _p(x), _p(w), _p(bias), _p(y), M, N, Cin, taps, S or M, C.c_float(p),
+                                                    C.c_uint64(self.seed), C.c_uint64(key), self.st())
+            if st_ == 0:
+                return y
+            if st_ != _lib.FS2_ERR_SHAPE:
+                self.ck(st_, "gemm_relu_dropout")
+        return self.dropout(self.gemm(x, w, bias, M, N, Cin, taps=taps, S=S, relu=True), p, key)
+
     def gemm_ln_tape(self, x, w, bias, res, g, b, M, N, Cin, taps=1, S=None, relu=False, drop=None):
         """y = LayerNorm(z), z = act(x W^T + bias) [+ res], both stored, in ONE launch (the inference engine's fused GEMM +
         LayerNorm epilogue with a pre-norm store); None where that epilogue does not apply (N > 256, odd shapes, knob off).
@@ -544,10 +556,10 @@ class Trainer:
         t["sum1"] = f1 is not None
         if prefix in self.fold:  # depth-wise FFN (model.py:73-93): dw(k) -> pw H->F -> ReLU -> [grouped 1x1 . pw F->H] folded
             t["u"] = o.dwconv(x1, P[f"{prefix}.conv1.0.weight"], P[f"{prefix}.conv1.0.bias"], B, S, H, k)
-            h = o.dropout(o.gemm(t["u"], W[f"{prefix}.conv1.1.weight"], P[f"{prefix}.conv1.1.bias"], M, F_, H, relu=True), pd, t["k_h"])
+            h = o.gemm_relu_dropout(t["u"], W[f"{prefix}.conv1.1.weight"], P[f"{prefix}.conv1.1.bias"], M, F_, H, 1, None, pd, t["k_h"])
             c2 = o.dropout(o.gemm(h, self.fold[prefix]["Wf"], self.fold[prefix]["bf"], M, H, F_), pd, t["k_ff"])
         else:
-            h = o.dropout(o.gemm(x1, W[f"{prefix}.conv1.weight"], P[f"{prefix}.conv1.bias"], M, F_, H, taps=k, S=S, relu=True), pd, t["k_h"])
+            h = o.gemm_relu_dropout(x1, W[f"{prefix}.conv1.weight"], P[f"{prefix}.conv1.bias"], M, F_, H, k, S, pd, t["k_h"])
             f2 = o.gemm_ln_tape(h, W[f"{prefix}.conv2.weight"], P[f"{prefix}.conv2.bias"], x1, P[f"{prefix}.norm2.weight"],
                                 P[f"{prefix}.norm2.bias"], M, H, F_, drop=(pd, t["k_ff"]))  # (dropout2 inside)
             if f2 is not None:

@@ -330,6 +330,35 @@ def test_gemm_with_addend_in_place(dtype, B, S, Cin, N, k):
     assert float((got - ref).abs().max()) <= tol(dtype, ref)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,S,Cin,N,k", [(2, 300, 256, 1024, 9), (3, 77, 128, 320, 3), (1, 512, 256, 256, 1)])
+def test_gemm_relu_dropout_store_uses_the_dropout_op_mask(dtype, B, S, Cin, N, k):
+    """c = dropout(relu(x w^T + b)) in the GEMM's store (training forward, the FFN's hidden tensor): the kept / dropped pattern is
+    fs2_op_dropout's for the same (p, seed, key) over the (M, N) tensor - so the backward's dropout call regenerates it - and kept
+    values are relu(.) / (1 - p)."""
+    import ctypes as C
+    pdrop, seed, key = 0.3, 99, 5
+    x = rnd(B, S, Cin, seed=320)
+    w = rnd(N, Cin, k, seed=321, scale=(Cin * k) ** -0.5)
+    b = rnd(N, seed=322) + 0.5
+    M = B * S
+    xd, wd = G.to_dev(x.reshape(M, Cin), dtype), G.to_dev(G.pack_conv_weight(w), dtype)
+    bd = b.float().to(G.DEV)
+    c = torch.empty(M, N, dtype=G.tdt(dtype), device=G.DEV)
+    G.ok(G.lib().fs2_op_gemm_relu_dropout(dtype, G.p(xd), G.p(wd), G.p(bd), G.p(c), M, N, Cin, k, S, C.c_float(pdrop), C.c_uint64(seed),
+                                          C.c_uint64(key), G.stream()), "gemm_relu_dropout")
+    ones = torch.ones(M, N, dtype=torch.float32, device=G.DEV)
+    mask = torch.empty_like(ones)
+    G.ok(G.lib().fs2_op_dropout(G.F32, G.p(ones), G.p(mask), M * N, C.c_float(pdrop), C.c_uint64(seed), C.c_uint64(key), G.stream()), "dropout")
+    torch.cuda.synchronize()
+    plain = G.gemm(dtype, x.reshape(M, Cin), G.pack_conv_weight(w), b, taps=k, S=S, relu=True)
+    got, mask = c.float().cpu(), mask.cpu()
+    want = plain * mask                     # mask holds 0 or 1 / (1 - p)
+    assert 0.2 < float((mask == 0).float().mean()) < 0.4
+    assert torch.equal(got == 0, want == 0) or float(((got == 0) != (want == 0)).float().mean()) < 1e-4   # (relu zeros aside, a value that rounds to 0)
+    assert float((got - want).abs().max()) <= (2e-2 if dtype == G.BF16 else 1e-5) * (float(want.abs().max()) + 1)
+
+
 def test_gemm_split_k_rejects_what_it_cannot_run():
     x, w = rnd(256, 256, seed=1), rnd(256, 256, seed=2)
     xd, wd = G.to_dev(x, G.BF16), G.to_dev(w, G.BF16)
