@@ -33,6 +33,13 @@ constexpr bool PF_PREFETCH = FS2_PF_PREFETCH;
 #ifndef FS2_PF_FENCE
 #define FS2_PF_FENCE 1
 #endif
+// weight-fragment ring depth: 4 (three k-steps ahead; taps 1.. in a rolled loop, 8 % 4 == 0 keeps the ring index static) or 3 (two
+// ahead, 16 registers fewer; the 24 k-steps of a layer fully unrolled, 24 % 3 == 0)
+#ifndef FS2_PF_RING
+#define FS2_PF_RING 3
+#endif
+constexpr int PF_RING = FS2_PF_RING;
+static_assert(PF_RING == 3 || PF_RING == 4, "ring depth 3 or 4");
 #if FS2_PF_FENCE
 #define PF_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
@@ -79,7 +86,9 @@ __global__ void pack_predictor_weights_kernel(const bf16* __restrict__ W, uint4*
 //   What did work: __builtin_amdgcn_sched_barrier(0) fences around each half's fragment reads (PF_FENCE) - reads in a group, then the
 //   MFMAs, nothing moved across - once the epilogue's per-lane offsets were kept from being hoisted across the K loop (the laundered
 //   lane id below; 54 -> 34 spilled registers, none inside the loops).  64-row tiles (the duration predictor's launch): 33 -> 21 us;
-//   112-row tiles: 106 -> ~104 us (FS2_PF_FENCE=0 builds the unfenced form for A/B).
+//   112-row tiles: 106 -> ~104 us (FS2_PF_FENCE=0 builds the unfenced form for A/B).  Then the weight ring at 3 stages instead of 4 (two
+//   k-steps ahead; 16 registers fewer: 34 -> 14 spilled; the layer's 24 k-steps unrolled so that the ring index stays static):
+//   ~103 -> ~98 us (-DFS2_PF_RING=4 builds the 4-stage form).
 template <int MI16, int NWV, int MINW>
 __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(PredictorArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins exist in the device pass only
@@ -128,10 +137,10 @@ __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(Predict
 #pragma unroll
         for (int ni = 0; ni < NFR; ++ni) b[ni] = wbase[(size_t)g * PF_STEP_U4 + ni * 64];
     };
-    uint4 bw[4][NFR];
+    uint4 bw[PF_RING][NFR];
     loadB(bw[0], 0);
     loadB(bw[1], 1);
-    loadB(bw[2], 2);
+    if constexpr (PF_RING == 4) loadB(bw[2], 2);
 
     dma_drain();
     __syncthreads();
@@ -172,7 +181,8 @@ __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(Predict
                     if (mi < cnt) fx[mi] = *(const uint4*)(arow_p + (m0 + mi) * 16 * PF_ROWB + (acx ^ ((((kb & 3) << 1) | ((kb >> 2) << 4)) << 4)));
             };
             auto kblock = [&](auto KB0, int kb, uint4 (&fxa)[HFA], uint4 (&fxb)[HFA]) {
-                loadB(bw[(kb + 3) & 3], (l * PF_TAPS + tp) * PF_KB + kb + 3);
+                const int rs = (tp * PF_KB + kb) % PF_RING, rn = (tp * PF_KB + kb + PF_RING - 1) % PF_RING;  // static after unrolling
+                loadB(bw[rn], (l * PF_TAPS + tp) * PF_KB + kb + PF_RING - 1);
                 if constexpr (MINW == 1 || PF_PREFETCH) {
                     // the next half's activation fragments are requested before this half's MFMAs (two fragment sets alive): an LDS
                     // round trip behind every half otherwise (r03: 113 -> 107 us for the C2 variance predictor with two workgroups per CU)
@@ -181,14 +191,14 @@ __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(Predict
 #pragma unroll
                     for (int ni = 0; ni < NFR; ++ni)
 #pragma unroll
-                        for (int mi = 0; mi < HFA; ++mi) mma(KB0, bw[kb & 3][ni], fxa[mi], ni, acc[ni][mi]);
+                        for (int mi = 0; mi < HFA; ++mi) mma(KB0, bw[rs][ni], fxa[mi], ni, acc[ni][mi]);
                     PF_FENCE();
                     if (kb + 1 < PF_KB) loadA(fxa, kb + 1, 0);
                     PF_FENCE();
 #pragma unroll
                     for (int ni = 0; ni < NFR; ++ni)
 #pragma unroll
-                        for (int mi = 0; mi < HFB; ++mi) mma(KB0, bw[kb & 3][ni], fxb[mi], ni, acc[ni][HFA + mi]);
+                        for (int mi = 0; mi < HFB; ++mi) mma(KB0, bw[rs][ni], fxb[mi], ni, acc[ni][HFA + mi]);
                     PF_FENCE();
                 } else {
 #pragma unroll
@@ -199,7 +209,7 @@ __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(Predict
                         for (int ni = 0; ni < NFR; ++ni)
 #pragma unroll
                             for (int mi = 0; mi < HFA; ++mi)
-                                if (mi < cnt) mma(KB0, bw[kb & 3][ni], fxa[mi], ni, acc[ni][m0 + mi]);
+                                if (mi < cnt) mma(KB0, bw[rs][ni], fxa[mi], ni, acc[ni][m0 + mi]);
                     }
                 }
             };
@@ -210,8 +220,13 @@ __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(Predict
             for (int kb = 1; kb < PF_KB; ++kb) kblock(std::false_type{}, kb, fxa, fxb);
         };
         tap(0, std::true_type{});
+        if constexpr (PF_RING == 4) {
 #pragma unroll 1
-        for (int tp = 1; tp < PF_TAPS; ++tp) tap(tp, std::false_type{});
+            for (int tp = 1; tp < PF_TAPS; ++tp) tap(tp, std::false_type{});
+        } else {
+            tap(1, std::false_type{});
+            tap(2, std::false_type{});
+        }
 
         // ---- ReLU + LayerNorm (r03: packed fp32) ----  lane: rows (m*16 + fr), channels n0 + 32*(ni>>1) + (ni&1)*4 + r.
         // The epilogue's VALU stream runs NEXT to the co-resident workgroup's MFMAs on the same SIMD and the two add up:
