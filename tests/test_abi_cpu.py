@@ -117,3 +117,20 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 text = open(os.path.join(dp, f)).read()
                 assert "oracle_cpu" not in text and "import oracle" not in text and "from oracle" not in text, f
+
+
+def test_split_k_choice_is_a_pure_shape_function(lib):
+    """fs2_op_gemm_splitk_choice runs on the host: the shapes the training step meets.  A long reduction over few row tiles
+    splits (the encoder-side data-gradient convs), launches that already fill the chip or reduce over a short K do not."""
+    BF16, F32 = 1, 0
+    f = lib.fs2_op_gemm_splitk_choice
+    assert f(BF16, 8192, 256, 1024, 9, 256) == 4      # C2 encoder conv1 data gradient: 64 row tiles x 4 = one round of 256 CUs
+    assert f(BF16, 2048, 1024, 4096, 9, 256) == 4     # C5, 8 utterances per GPU
+    assert f(BF16, 49152, 256, 1024, 9, 1536) == 1    # decoder: 384 row tiles already
+    assert f(BF16, 8192, 1024, 256, 1, 8192) == 1     # short reduction
+    assert f(BF16, 8192, 128, 1024, 9, 256) == 1      # narrower than the slab kernel's column tile
+    assert f(BF16, 8192, 256, 1024, 2, 256) == 1      # even tap count: not a slab-kernel conv
+    for dt in (F32, BF16):
+        for args in ((8192, 256, 1024, 9, 256), (2048, 1024, 4096, 9, 256), (300, 256, 2048, 1, 300)):
+            k = f(dt, *args)
+            assert k >= 1 and (args[2] // (64 if dt == BF16 else 32)) % k == 0
