@@ -281,6 +281,9 @@ def main():
         model.engine.set_fused_predictor(False)
     if os.environ.get("FS2_DEFER_LN") == "0":  # A/B: one launch per LayerNorm in the wide depth-wise blocks
         model.engine.set_deferred_layernorm(False)
+    if os.environ.get("FS2_GEMM_KNOBS"):  # A/B: comma-separated fs2_op_set_gemm_variant values (include/fs2.h)
+        for k in os.environ["FS2_GEMM_KNOBS"].split(","):
+            _lib.load().fs2_op_set_gemm_variant(int(k))
     if os.environ.get("FS2_XCD_REMAP"):  # A/B: 0 = plain tile order in the slab GEMM
         _lib.load().fs2_op_set_gemm_variant(200 + int(os.environ["FS2_XCD_REMAP"]))
     inp = synth_inputs(cfg, args.batch, args.phones, seed=1234 + 17 * rank)

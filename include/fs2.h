@@ -228,6 +228,7 @@ int fs2_profile_read(fs2_engine* e, int32_t kernel_class, double* total_ms, int6
  *              in LDS (measured no faster, kept for A/B); bit-identical outputs
  *   1400..1402 bf16 GEMMs with K = 256 (no fused epilogue): slab kernel / weight-resident kernel from three row tiles per
  *              workgroup on (default) / wherever it applies; bit-identical outputs
+ *   310/311    deferred-LayerNorm GEMM epilogue on 192-row tiles only (default) / 256-row tiles admitted (spills; measured no faster)
  *   1320/1321  inference engine, bf16: the VarianceEncoder's bucketize + embedding add as the tail of its predictor's launch: off / on (default;
  *              bit-identical either way)
  *   1300..1302 single-launch predictor: 112- / 64-row tiles only (default); 1301 = 208-row tiles, one workgroup per CU; 1302 = two

@@ -105,6 +105,7 @@ int fs2_op_set_gemm_variant(int32_t variant) {
     if (variant >= 800) { fs2::g_bgemm_full = variant - 800; return FS2_OK; }       // 800 / 801: bf16 strided-batched GEMM generic instantiation only / bounds-free one for full aligned tiles
     if (variant >= 700) { fs2::g_bgemm_xcd = variant - 700; return FS2_OK; }        // 700 / 701: bf16 strided-batched GEMM tile order plain / XCD-contiguous
     if (variant >= 500) { fs2::g_split_f32 = variant - 500; return FS2_OK; }       // 500 / 501: fp32 slab launches as fp32 MFMA / bf16 x 3 split
+    if (variant == 310 || variant == 311) { fs2::g_defer_mi8 = variant - 310; return FS2_OK; }  // deferred-LayerNorm GEMM epilogue: 192-row tiles only / 256-row tiles admitted
     if (variant >= 300) { fs2::g_wide_ln = variant - 300; return FS2_OK; }         // 300 / 301: fused LayerNorm for N > 256 off / on
     if (variant >= 200) { fs2::g_slab_xcd_remap = variant - 200; return FS2_OK; }  // 200 / 201: tile order knob
     fs2::g_gemm_variant = variant;

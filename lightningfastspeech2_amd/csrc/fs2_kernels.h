@@ -61,6 +61,7 @@ extern int g_gemm_wres;  // 1 = bf16 K = 256 plain GEMMs on the weight-resident 
 bool gemm_wres_supported(const GemmArgs& a, int in_dtype, int out_dtype, bool force);
 int launch_gemm_wres(const GemmArgs& a, hipStream_t stream);
 extern int g_wide_ln;
+extern int g_defer_mi8;
 extern int g_split_f32;
 extern int g_slab_xcd_remap;  // 1 = XCD-contiguous tile order in the slab kernel (A/B knob)  // test/bench knob: 0 auto, 1 force the 128x128 kernel, 2 force the DMA kernel
 

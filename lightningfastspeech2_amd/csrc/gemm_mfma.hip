@@ -1272,6 +1272,7 @@ int g_slab_xcd_remap = 1;
 // elsewhere (K = 3072: 357 vs 294 us - a workgroup re-streams its x tile once per column tile and 32 such tiles per XCD
 // do not fit the 4 MiB L2; M = 8192 / 12288: 1.5-2.2x slower - a third or a quarter of the workgroups), so it is OFF.
 int g_wide_ln = 0;
+int g_defer_mi8 = 0;  // 1: the deferred-LayerNorm epilogue may take 256-row tiles (spills ~600 registers, almost all outside the K loop)
 
 static int launch_gemm_plain(const GemmArgs& a, int in_dtype, int out_dtype, hipStream_t stream, bool* fused);
 
@@ -1364,7 +1365,8 @@ static int launch_gemm_plain(const GemmArgs& a, int in_dtype, int out_dtype, hip
         static const int kHeights[5] = {1, 2, 4, 6, 8};  // x32 rows; 32/64-row tiles keep small-M launches
         for (int hi = 0; hi < 5; ++hi) {                  // (the encoder's) spread over all CUs
             const int mi = kHeights[hi];
-            if ((fused || a.stats_out || a.epi_res) && mi > 6) continue;  // 256-row tiles spill with either LayerNorm epilogue
+            if (fused && mi > 6) continue;                                    // 256-row tiles spill with the fused LayerNorm epilogue
+            if ((a.stats_out || a.epi_res) && mi > 6 && !g_defer_mi8) continue;  // ... and with the deferred one (knob 311 admits them: A/B)
             const long bm = mi * 32, tm = (S + bm - 1) / bm;
             const bool wide = fused && tn > 1;  // one workgroup per row tile walks all tn column tiles
             const long tiles = (long)nutt * tm * (wide ? 1 : tn) * ksp;
