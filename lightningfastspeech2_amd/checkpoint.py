@@ -217,10 +217,11 @@ def to_lightning_optimizer_state(cfg: Fs2Config, opt_state: dict, *, lr: float, 
     return {"optimizer_states": [{"state": state, "param_groups": [group]}], "lr_schedulers": [sched]}
 
 
-def from_lightning_optimizer_state(cfg: Fs2Config, checkpoint: dict) -> dict:
+def from_lightning_optimizer_state(cfg: Fs2Config, checkpoint: dict, accumulate_grad_batches: int = 1) -> dict:
     """The inverse: a reference checkpoint's ``optimizer_states[0]`` (+ ``lr_schedulers[0]`` / ``global_step`` for the
     step count) -> what ``Trainer.load_optimizer_state`` takes.  Shapes are checked against the architecture; a checkpoint
-    whose optimizer covers other parameters (FastDiff attached) is refused by count."""
+    whose optimizer covers other parameters (FastDiff attached) is refused by count.  ``micro_step`` (the dropout-mask
+    counter) resumes at step x ``accumulate_grad_batches`` unless the checkpoint carries the extra key ``fs2_micro_step``."""
     names = parameter_order(cfg)
     spec = state_dict_spec(cfg)
     osd = checkpoint["optimizer_states"][0]
@@ -250,5 +251,7 @@ def from_lightning_optimizer_state(cfg: Fs2Config, checkpoint: dict) -> dict:
         raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): not a state this optimizer can resume")
     sched = (checkpoint.get("lr_schedulers") or [None])[0]
     out["step"] = steps.pop() if steps else int((sched or {}).get("last_epoch", checkpoint.get("global_step", 0)))
-    out["micro_step"] = 0
+    # the dropout seed of a micro-batch is seed * 1000003 + micro_step (training.Trainer): resuming at 0 would replay the
+    # masks of steps 0..N.  Lightning keeps no such counter; optimizer steps x accumulate_grad_batches is what it would be.
+    out["micro_step"] = int(checkpoint.get("fs2_micro_step", out["step"] * max(1, int(accumulate_grad_batches))))
     return out

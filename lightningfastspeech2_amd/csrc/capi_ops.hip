@@ -91,25 +91,36 @@ int fs2_op_set_vocoder_lds_limit(int32_t kib) {
     return FS2_OK;
 }
 
-int fs2_op_set_gemm_variant(int32_t variant) {
+
+
+// Process-global A/B knobs.  Every value is listed: an undefined one is FS2_ERR_ARG (a typo in FS2_GEMM_KNOBS must not pass
+// silently), and every accepted call bumps g_knob_gen, which is part of the engines' hipGraph keys - a captured phase is
+// never replayed with kernels chosen under other knobs.
+static int set_gemm_variant(int32_t variant) {
     if (variant >= 1400 && variant <= 1402) { fs2::g_gemm_wres = variant - 1400; return FS2_OK; }      // bf16 K = 256 plain GEMMs: slab kernel / weight-resident kernel where it pays (default) / wherever it applies
     if (variant == 1320 || variant == 1321) { fs2::g_pred_fuse_embed = variant - 1320; return FS2_OK; }  // engine: variance encoder (bucketize + embedding add) as the tail of its predictor launch: off / on (default)
-    if (variant >= 1300) { fs2::g_pred_tall = variant - 1300; return FS2_OK; }      // 1300 / 1301 / 1302: single-launch predictor on 112-row tiles only / 208-row tiles (one workgroup per CU) / two 112-row tiles per workgroup, when they fill the chip
+    if (variant >= 1300 && variant <= 1302) { fs2::g_pred_tall = variant - 1300; return FS2_OK; }      // 1300 / 1301 / 1302: single-launch predictor on 112-row tiles only / 208-row tiles (one workgroup per CU) / two 112-row tiles per workgroup, when they fill the chip
     if (variant == 1210 || variant == 1211) { fs2::g_attn_resident = variant - 1210; return FS2_OK; }  // <= 256 keys: K / V streamed tile by tile (default) / resident in LDS
-    if (variant >= 1200) { fs2::g_attn_pipe = variant - 1200; return FS2_OK; }      // 1200: attention.hip only; 1201 / 1202 / 1204: the software-pipelined kernel with 32 / 64 / 96 queries per wave where it applies; 1203: by size (default)
-    if (variant >= 1100) { fs2::g_colsum_fused = variant - 1100; return FS2_OK; }   // 1100 / 1101: column sums in two launches / one
-    if (variant >= 1000) { fs2::g_bgemm_tn256 = variant - 1000; return FS2_OK; }    // 1000 / 1001: 256 x 256 LDS-DMA kernel for eligible bf16 TN products off / on
+    if (variant >= 1200 && variant <= 1204) { fs2::g_attn_pipe = variant - 1200; return FS2_OK; }      // 1200: attention.hip only; 1201 / 1202 / 1204: the software-pipelined kernel with 32 / 64 / 96 queries per wave where it applies; 1203: by size (default)
+    if (variant == 1100 || variant == 1101) { fs2::g_colsum_fused = variant - 1100; return FS2_OK; }   // 1100 / 1101: column sums in two launches / one
+    if (variant == 1000 || variant == 1001) { fs2::g_bgemm_tn256 = variant - 1000; return FS2_OK; }    // 1000 / 1001: 256 x 256 LDS-DMA kernel for eligible bf16 TN products off / on
     if (variant >= 905 && variant <= 908) { fs2::attention_bwd_set_blocks(variant >= 907, 3 + ((variant - 905) & 1)); return FS2_OK; }  // 905 / 906: dK,dV launch 3 / 4 blocks per wave (one wave per SIMD); 907 / 908: the dQ launch
     if (variant == 909) { fs2::attention_bwd_set_blocks(0, 1); return FS2_OK; }  // dK,dV launch back to its default (1 block per wave)
-    if (variant >= 900) { if (variant == 904) fs2::attention_bwd_set_blocks(1, 0); else fs2::attention_bwd_set_blocks((variant - 900) >> 1, ((variant - 900) & 1) + 1); return FS2_OK; }  // 900 / 901: attention backward dK,dV launch 1 / 2 blocks per wave; 902 / 903: the dQ launch, 904: by size
-    if (variant >= 800) { fs2::g_bgemm_full = variant - 800; return FS2_OK; }       // 800 / 801: bf16 strided-batched GEMM generic instantiation only / bounds-free one for full aligned tiles
-    if (variant >= 700) { fs2::g_bgemm_xcd = variant - 700; return FS2_OK; }        // 700 / 701: bf16 strided-batched GEMM tile order plain / XCD-contiguous
-    if (variant >= 500) { fs2::g_split_f32 = variant - 500; return FS2_OK; }       // 500 / 501: fp32 slab launches as fp32 MFMA / bf16 x 3 split
+    if (variant >= 900 && variant <= 904) { if (variant == 904) fs2::attention_bwd_set_blocks(1, 0); else fs2::attention_bwd_set_blocks((variant - 900) >> 1, ((variant - 900) & 1) + 1); return FS2_OK; }  // 900 / 901: attention backward dK,dV launch 1 / 2 blocks per wave; 902 / 903: the dQ launch, 904: by size
+    if (variant == 800 || variant == 801) { fs2::g_bgemm_full = variant - 800; return FS2_OK; }       // 800 / 801: bf16 strided-batched GEMM generic instantiation only / bounds-free one for full aligned tiles
+    if (variant == 700 || variant == 701) { fs2::g_bgemm_xcd = variant - 700; return FS2_OK; }        // 700 / 701: bf16 strided-batched GEMM tile order plain / XCD-contiguous
+    if (variant == 500 || variant == 501) { fs2::g_split_f32 = variant - 500; return FS2_OK; }       // 500 / 501: fp32 slab launches as fp32 MFMA / bf16 x 3 split
     if (variant == 310 || variant == 311) { fs2::g_defer_mi8 = variant - 310; return FS2_OK; }  // deferred-LayerNorm GEMM epilogue: 192-row tiles only / 256-row tiles admitted
-    if (variant >= 300) { fs2::g_wide_ln = variant - 300; return FS2_OK; }         // 300 / 301: fused LayerNorm for N > 256 off / on
-    if (variant >= 200) { fs2::g_slab_xcd_remap = variant - 200; return FS2_OK; }  // 200 / 201: tile order knob
-    fs2::g_gemm_variant = variant;
-    return FS2_OK;
+    if (variant == 300 || variant == 301) { fs2::g_wide_ln = variant - 300; return FS2_OK; }         // 300 / 301: fused LayerNorm for N > 256 off / on
+    if (variant == 200 || variant == 201) { fs2::g_slab_xcd_remap = variant - 200; return FS2_OK; }  // 200 / 201: tile order knob
+    if (variant >= 0 && variant < 200) { fs2::g_gemm_variant = variant; return FS2_OK; }              // kernel family / forced tile height of the forward GEMM launcher (gemm_mfma.hip: launch_gemm)
+    return FS2_ERR_ARG;
+}
+
+int fs2_op_set_gemm_variant(int32_t variant) {
+    const int st = set_gemm_variant(variant);
+    if (st == FS2_OK) ++fs2::g_knob_gen;
+    return st;
 }
 
 int fs2_op_gemm(int32_t dtype, int32_t out_dtype, const void* x, const void* w, const float* bias, void* c,

@@ -1012,7 +1012,7 @@ int fs2_encode(fs2_engine* e, const int64_t* phones, const float* speaker, int32
     // every launch of the phase (no host decision among them), plainly or as a replayed hipGraph (fs2_set_graphs)
     {
         std::vector<uint64_t> key = {(uint64_t)B, (uint64_t)L, (uint64_t)e->persist.base, (uint64_t)e->scratch.base, (uint64_t)phones,
-                                     (uint64_t)speaker, (uint64_t)forced, (uint64_t)e->h_pinned, (uint64_t)e->fuse_predictor + 2 * (uint64_t)g_pred_fuse_embed,
+                                     (uint64_t)speaker, (uint64_t)forced, (uint64_t)e->h_pinned, (uint64_t)e->fuse_predictor, (uint64_t)g_knob_gen,
                                      (uint64_t)e->defer_ln, (uint64_t)e->front_split};
         const bool plain = c.n_priors != 0;  // a prior tensor is a one-shot pointer of the call
         CHK(run_phase(e, e->egraphs, key, plain, st, [&](hipStream_t s2) { return encode_body(e, phones, speaker, forced, sc, s2); }));
@@ -1268,7 +1268,7 @@ int fs2_decode(fs2_engine* e, const fs2_outputs* out, void* stream) {
     CHK(ensure_arena(e, e->scratch, decode_scratch_bytes(e, e->B, e->T), "scratch"));
     if (e->scratch.base != base0) drop_graphs(e);
     std::vector<uint64_t> key = {(uint64_t)e->B, (uint64_t)e->L, (uint64_t)e->T, (uint64_t)e->scratch.base, (uint64_t)e->persist.base,
-                                 (uint64_t)e->xA, (uint64_t)e->d_cum, (uint64_t)e->spk, (uint64_t)e->zero_pad_mel, (uint64_t)e->fuse_predictor + 2 * (uint64_t)g_pred_fuse_embed,
+                                 (uint64_t)e->xA, (uint64_t)e->d_cum, (uint64_t)e->spk, (uint64_t)e->zero_pad_mel, (uint64_t)e->fuse_predictor, (uint64_t)g_knob_gen,
                                  (uint64_t)e->defer_ln, (uint64_t)e->front_split, (uint64_t)out->mel, (uint64_t)out->tgt_mask,
                                  (uint64_t)out->duration_prediction, (uint64_t)out->duration_rounded, (uint64_t)out->src_mask};
     for (int v = 0; v < FS2_MAX_VARIANCES; ++v) {

@@ -1265,6 +1265,7 @@ static int launch_t(const GemmArgs& a, hipStream_t stream) {
 }
 
 int g_gemm_variant = 0;
+unsigned long long g_knob_gen = 0;  // bumped by every accepted fs2_op_set_gemm_variant call; part of the hipGraph keys
 int g_split_f32 = 0;  // test knob: every fp32 slab launch in the bf16 x 3 split arithmetic
 int g_slab_xcd_remap = 1;
 // 1 = rows wider than 256 by the in-place WIDE epilogue, 0 = GEMM launch + stand-alone LayerNorm launch.  Measured on

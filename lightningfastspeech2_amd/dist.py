@@ -36,6 +36,10 @@ def collective_device(group=None, like=None) -> torch.device:
     device memory on every rank - also on ranks that hold no utterance and therefore no device tensor to copy from)."""
     backend = str(dist.get_backend(group)).lower()
     if "nccl" in backend:
+        # a rank whose model and batch live on cuda:{local_rank} without torch.cuda.set_device() must not build its control
+        # tensors on cuda:0: take the device of the tensor the rank already holds, the current device only without one
+        if isinstance(like, torch.Tensor) and like.is_cuda:
+            return like.device
         return torch.device("cuda", torch.cuda.current_device())
     return like.device if isinstance(like, torch.Tensor) else torch.device("cpu")
 
@@ -74,11 +78,20 @@ def shard_batch(batch: Dict[str, torch.Tensor], world: int, rank: int, *, trim: 
                 raise ValueError(f"batch[{k!r}] has non-zero entries beyond the shard's longest utterance")
             out[k] = v[:, :Lr].contiguous()
         dur = out.get("duration")
+        mel_t = out.get("mel")
         if dur is not None and hasattr(dur, "shape") and len(dur.shape) == 2:
             Tr = max(int(torch.as_tensor(dur).sum(dim=1).max()), 1)
+            # the frame axis is the mel's: only entries that share it are frame-level (a phone-level (B, L) "variances_*"
+            # entry with L > Tr - zero-length durations - is left alone); without a mel, the longest such entry names it
+            T_b = mel_t.shape[1] if hasattr(mel_t, "shape") and len(mel_t.shape) >= 2 else max(
+                [v.shape[1] for k, v in out.items() if _is_frame_level(k) and hasattr(v, "shape") and len(v.shape) >= 2
+                 and v.shape[1] != L] or [0])
             for k, v in list(out.items()):
-                if _is_frame_level(k) and hasattr(v, "shape") and len(v.shape) >= 2 and v.shape[1] > Tr:
-                    out[k] = v[:, :Tr].contiguous()
+                if not (_is_frame_level(k) and hasattr(v, "shape") and len(v.shape) >= 2 and v.shape[1] == T_b and T_b > Tr):
+                    continue
+                if bool((torch.as_tensor(v)[:, Tr:] != 0).any()):
+                    raise ValueError(f"batch[{k!r}] has non-zero frames beyond the shard's sum(duration) = {Tr}")
+                out[k] = v[:, :Tr].contiguous()
     return out
 
 
@@ -200,6 +213,10 @@ def forward_sharded(forward_fn: Callable[..., Dict[str, torch.Tensor]], batch: D
         mel, mask = local["mel"], local["tgt_mask"]
         if mel.device != mask.device:
             mask = mask.to(mel.device)
+        if device is None and mel.is_cuda:
+            dev = mel.device   # the gather's tensors follow the local mel
+        if "nccl" in str(dist.get_backend(group)).lower() and mel.device != dev:
+            raise ValueError(f"local mel on {mel.device}, collective control tensors on {dev}: RCCL needs one device per rank")
     shapes = (Bs, t_glob["T"]) if global_pad else None
     mel_all, frames = gather_mels(mel, mask, group=group, shapes=shapes, zeroed=zeroed)
     return mel_all, frames, local

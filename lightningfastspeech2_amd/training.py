@@ -502,7 +502,7 @@ class Trainer:
 
     def load_lightning_optimizer_state(self, checkpoint):
         from .checkpoint import from_lightning_optimizer_state
-        self.load_optimizer_state(from_lightning_optimizer_state(self.cfg, checkpoint))
+        self.load_optimizer_state(from_lightning_optimizer_state(self.cfg, checkpoint, getattr(self, "accumulate_grad_batches", 1)))
 
     def gradients(self):
         return OrderedDict((n, self._to_ref_layout(n, self.G[n])) for n in self._layout)

@@ -134,3 +134,14 @@ def test_split_k_choice_is_a_pure_shape_function(lib):
         for args in ((8192, 256, 1024, 9, 256), (2048, 1024, 4096, 9, 256), (300, 256, 2048, 1, 300)):
             k = f(dt, *args)
             assert k >= 1 and (args[2] // (64 if dt == BF16 else 32)) % k == 0
+
+
+def test_knob_setter_rejects_undefined_values(lib):
+    """fs2_op_set_gemm_variant takes closed ranges - a typo in FS2_GEMM_KNOBS is an error, not a silent global."""
+    FS2_OK, FS2_ERR_ARG = 0, lib.fs2_op_set_gemm_variant(-1)
+    assert FS2_ERR_ARG != FS2_OK
+    for bad in (1303, 1319, 1322, 1399, 1403, 1205, 1209, 1212, 1299, 1102, 1002, 910, 802, 702, 502, 312, 302, 202, 100000):
+        assert lib.fs2_op_set_gemm_variant(bad) == FS2_ERR_ARG, bad
+    # the defaults (each is a defined value) leave the process as it was
+    for ok in (0, 201, 300, 310, 500, 701, 801, 909, 904, 1001, 1100, 1203, 1210, 1300, 1321, 1401):
+        assert lib.fs2_op_set_gemm_variant(ok) == FS2_OK, ok

@@ -196,6 +196,12 @@ def test_optimizer_state_round_trips_through_lightning_layout():
     assert lit["lr_schedulers"][0]["last_epoch"] == 17 and lit["lr_schedulers"][0]["warmup_steps"] == 4000
     back = ck.from_lightning_optimizer_state(cfg, {"optimizer_states": [opt.state_dict()], "lr_schedulers": lit["lr_schedulers"]})
     assert back["step"] == 17
+    # the dropout-mask counter must not restart at 0 (it would replay the masks of steps 0..N)
+    assert back["micro_step"] == 17
+    assert ck.from_lightning_optimizer_state(cfg, {"optimizer_states": [opt.state_dict()], "lr_schedulers": lit["lr_schedulers"]},
+                                             accumulate_grad_batches=3)["micro_step"] == 51
+    assert ck.from_lightning_optimizer_state(cfg, {"optimizer_states": [opt.state_dict()], "lr_schedulers": lit["lr_schedulers"],
+                                                   "fs2_micro_step": 40})["micro_step"] == 40
     assert set(back["exp_avg"]) == set(train)
     for n in train:
         assert torch.equal(back["exp_avg"][n], st["exp_avg"][n]) and torch.equal(back["exp_avg_sq"][n], st["exp_avg_sq"][n])

@@ -96,8 +96,10 @@ def test_shard_trims_frame_level_targets_to_its_own_frames():
     ph = torch.tensor([[3, 4, 5, 6], [7, 8, 0, 0], [9, 0, 0, 0]])
     dur = torch.tensor([[2, 3, 1, 4], [5, 1, 0, 0], [2, 0, 0, 0]])
     T = 10
-    batch = {"phones": ph, "duration": dur, "speaker": torch.zeros(3, 256), "mel": torch.arange(3 * T * 2.0).reshape(3, T, 2),
-             "variances_pitch": torch.arange(3 * T * 1.0).reshape(3, T), "priors_energy": torch.tensor([0.1, 0.2, 0.3])}
+    valid = (torch.arange(T)[None, :] < dur.sum(1)[:, None])   # the collate format zero-pads beyond an utterance's frames
+    batch = {"phones": ph, "duration": dur, "speaker": torch.zeros(3, 256),
+             "mel": (1 + torch.arange(3 * T * 2.0)).reshape(3, T, 2) * valid[..., None],
+             "variances_pitch": (1 + torch.arange(3 * T * 1.0)).reshape(3, T) * valid, "priors_energy": torch.tensor([0.1, 0.2, 0.3])}
     sh = shard_batch(batch, 2, 1)   # rank 1: the last utterance alone (2 frames, 1 phone)
     assert sh["phones"].shape == (1, 1) and sh["duration"].shape == (1, 1)
     assert sh["mel"].shape == (1, 2, 2) and torch.equal(sh["mel"], batch["mel"][2:, :2])
@@ -106,6 +108,18 @@ def test_shard_trims_frame_level_targets_to_its_own_frames():
     assert sh0["mel"].shape == (2, 10, 2) and sh0["variances_pitch"].shape == (2, 10)
     keep = shard_batch(batch, 2, 1, trim=False)
     assert keep["mel"].shape == (1, T, 2) and keep["phones"].shape == (1, 4)
+    # real frames beyond sum(duration) are an error, not silently dropped ...
+    bad = dict(batch, mel=batch["mel"].clone())
+    bad["duration"] = torch.tensor([[2, 3, 1, 4], [5, 1, 0, 0], [1, 0, 0, 0]])   # utterance 2 now claims 1 frame; its mel has 10
+    with pytest.raises(ValueError, match="non-zero frames"):
+        shard_batch(bad, 2, 1)
+    # ... and a phone-level (B, L) variances_* entry is not cut on the frame axis (zero-length durations make L > Tr possible)
+    ph2 = torch.tensor([[3, 4, 5, 6], [7, 8, 9, 1]])
+    dur2 = torch.tensor([[1, 0, 0, 0], [0, 1, 0, 0]])
+    b2 = {"phones": ph2, "duration": dur2, "speaker": torch.zeros(2, 256), "mel": torch.zeros(2, 6, 2),
+          "variances_energy": torch.arange(8.0).reshape(2, 4)}
+    s2 = shard_batch(b2, 1, 0)
+    assert s2["variances_energy"].shape == (2, 4) and s2["mel"].shape == (2, 1, 2)
 
 
 def test_collective_device_follows_the_backend():
@@ -115,6 +129,15 @@ def test_collective_device_follows_the_backend():
     try:
         assert D.collective_device(None, None) == torch.device("cpu")          # host-side batch under gloo
         assert D.collective_device(None, torch.zeros(1)) == torch.device("cpu")
+        # under nccl the control tensors follow the tensor the rank already holds (a rank that never called
+        # torch.cuda.set_device), the current device only without one
+        import unittest.mock as um
+        like = um.MagicMock(spec=torch.Tensor)
+        like.is_cuda, like.device = True, torch.device("cuda", 3)
+        with um.patch.object(D.dist, "get_backend", return_value="nccl"), um.patch.object(torch.cuda, "current_device", return_value=0):
+            assert D.collective_device(None, like) == torch.device("cuda", 3)
+            assert D.collective_device(None, None) == torch.device("cuda", 0)
+            assert D.collective_device(None, torch.zeros(1)) == torch.device("cuda", 0)
         # an explicit device wins in forward_sharded; an empty shard no longer guesses from batch["speaker"]
         out = D.forward_sharded(lambda b: {"mel": torch.zeros(1, 3, 4), "tgt_mask": torch.zeros(1, 3, dtype=torch.bool)},
                                 {"phones": torch.ones(1, 2, dtype=torch.long), "speaker": [[0.0] * 256]}, n_mels=4, device="cpu")
@@ -202,7 +225,8 @@ def _grad_worker(rank, world, port, q):
     h = torch.full((77,), float(rank))
     for w in all_reduce_gradients(h, async_op=True):
         w.wait()
-    q.put((rank, g.clone(), h.clone()))
+    # plain lists: a torch tensor on an mp.Queue travels as a shared-memory fd the parent may open after this worker is gone
+    q.put((rank, g.tolist(), h.tolist()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -223,5 +247,5 @@ def test_flat_gradient_all_reduce_two_ranks():
     for p_ in ps:
         p_.join(timeout=60)
     for _, g, h in res:
-        assert torch.equal(g, torch.arange(1000, dtype=torch.float32) * 3)
-        assert torch.equal(h, torch.full((77,), 1.0))
+        assert g == (torch.arange(1000, dtype=torch.float32) * 3).tolist()
+        assert h == [1.0] * 77
