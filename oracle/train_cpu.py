@@ -64,8 +64,10 @@ def _masked(pred, truth, kind, valid, soft_dtw_gamma=0.01, soft_dtw_chunk_size=2
 
 
 def losses(cfg, result, batch, variance_losses=None, mel_loss="l1", duration_loss="mse", alphas=None, soft_dtw_gamma=0.01,
-           soft_dtw_chunk_size=256):
-    alphas = dict(DEFAULT_ALPHAS if alphas is None else alphas)
+           soft_dtw_chunk_size=256, loss_alphas=None):
+    """``loss_alphas`` is the reference's keyword for ``alphas`` (loss.py:17-26; FastSpeech2.__init__ fills it from
+    mel_loss_weight / duration_loss_weight / variance_loss_weights, fastspeech2.py:445-451)."""
+    alphas = dict(DEFAULT_ALPHAS if (alphas is None and loss_alphas is None) else (alphas if alphas is not None else loss_alphas))
     variance_losses = variance_losses or ["mse"] * len(cfg.variances)
     tgt_valid, src_valid = ~result["tgt_mask"], ~result["src_mask"]
     out = OrderedDict()

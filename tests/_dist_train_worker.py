@@ -20,6 +20,13 @@ def main(out_path):
     torch.cuda.set_device(0)
     cfg, sd, batch = _case(41, 4, 11, [11, 9, 6, 2])
     full = {k: torch.as_tensor(v) for k, v in batch.items()}
+    # the collate format zero-pads every frame-level target beyond an utterance's own frames (datasets.py:866-877); the seeded
+    # batch is random there, and shard_batch refuses to cut non-zero frames
+    frames = full["duration"].sum(1)
+    for k in list(full):
+        if k == "mel" or k.startswith("variances_"):
+            keep = torch.arange(full[k].shape[1])[None, :] < frames[:, None]
+            full[k] = full[k] * (keep[..., None] if full[k].dim() == 3 else keep)
     mine = shard_batch(full, world, rank, trim=True)
     T = int(mine["duration"].sum(1).max())  # the shard is its own padded batch: frame-level targets cut to its longest utterance
     for k in list(mine):

@@ -13,7 +13,7 @@ from lightningfastspeech2_amd.weights import synth_state_dict
 from oracle import train_cpu
 
 GOLD_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-CASES = ["train_small", "train_dw_small"]  # dense family / the reference's depth-wise class defaults
+CASES = ["train_small", "train_dw_small", "train_recipe_small"]  # dense family / the reference's depth-wise class defaults / the shipped recipe's architecture (scripts/train.sh)
 
 
 def load(name="train_small"):

@@ -49,6 +49,22 @@ def small(**kw):
     return Fs2Config(**base)
 
 
+RECIPE_STATS = {"pitch": {"min": -2.0, "max": 2.5, "mean": 0.1, "std": 1.5},
+                "energy": {"min": -3.0, "max": 3.0, "mean": 0.0, "std": 1.0},
+                "snr": {"min": -1.0, "max": 4.0, "mean": 1.2, "std": 2.0},
+                "srmr": {"min": -2.5, "max": 3.5, "mean": 0.4, "std": 1.3},
+                "energy_prior": {"min": -1.0, "max": 1.0}, "duration_prior": {"min": 0.0, "max": 5.0},
+                "snr_prior": {"min": -2.0, "max": 3.0}, "pitch_prior": {"min": -1.0, "max": 1.0},
+                "srmr_prior": {"min": 0.0, "max": 2.0}}
+RECIPE = Fs2Config(n_phones=40, encoder_hidden=64, decoder_hidden=64, encoder_head=2, decoder_head=2,
+                   encoder_layers=4, decoder_layers=6, encoder_kernel_sizes=[5, 25, 13, 9], decoder_kernel_sizes=[9] * 6,
+                   encoder_conv_filter_size=128, decoder_conv_filter_size=128,
+                   encoder_depthwise_conv=True, decoder_depthwise_conv=True,
+                   variances=["pitch", "energy", "snr", "srmr"], variance_levels=["frame"] * 4, variance_transforms=["none"] * 4,
+                   variance_nlayers=[5, 5, 5, 5], variance_kernel_size=[3, 3, 3, 3], variance_filter_size=64,
+                   variance_depthwise_conv=True, duration_nlayers=5, duration_filter_size=64, duration_depthwise_conv=True,
+                   variance_nbins=32, n_mels=80, priors=["energy", "duration", "snr", "pitch", "srmr"], stats=RECIPE_STATS)
+
 CASES = {
     # name: (config, B, L, lengths, synth kwargs, want)
     "dense_small": (small(), 3, 11, [11, 7, 4], dict(duration_bias=1.2), {}),
@@ -87,6 +103,11 @@ CASES = {
                                        "energy": {"min": -3.0, "max": 3.0, "mean": 0.0, "std": 1.0},
                                        "snr": {"min": -1.0, "max": 4.0, "mean": 1.2, "std": 2.0}}),
                           3, 11, [11, 7, 4], dict(duration_bias=1.2), {"teacher": True}),
+    # the architecture the reference actually ships (scripts/train.sh:12-13,27-36,49): four frame-level "none" variances incl.
+    # srmr (FS2_MAX_VARIANCES full), five priors, duration_nlayers 5, six decoder layers of kernel 9, the class defaults'
+    # depth-wise blocks / encoder kernels [5, 25, 13, 9] / five-layer variance predictors, at a fixture-sized hidden width
+    "recipe_small": (RECIPE, 3, 12, [12, 8, 5], dict(duration_bias=1.1), {"slim": True, "bucket_margin": 5e-4}),
+    "recipe_teacher_small": (RECIPE, 3, 12, [12, 8, 5], dict(duration_bias=1.1), {"slim": True, "teacher": True}),
     "mid_dense_d128": (Fs2Config(n_phones=80, encoder_hidden=256, decoder_hidden=256, encoder_head=2,
                                  decoder_head=2, encoder_layers=1, decoder_layers=2,
                                  encoder_kernel_sizes=[9], decoder_kernel_sizes=[9, 9],

@@ -25,15 +25,17 @@ from tools import ref_import  # noqa: E402
 LR, WARMUP, CLIP = 2e-3, 4, 1.0
 
 
-def run_case(name, cfg, sd, synth_json, batch, FastSpeech2Loss, NoamLR):
+def run_case(name, cfg, sd, synth_json, batch, FastSpeech2Loss, NoamLR, loss_alphas=None):
     model = ref_import.build_reference_model(cfg, sd)  # eval mode: dropout off
     nv = len(cfg.variances)
+    kw = {} if loss_alphas is None else {"loss_alphas": dict(loss_alphas)}  # what FastSpeech2.__init__ builds, fastspeech2.py:445-451
     loss = FastSpeech2Loss(variances=list(cfg.variances), variance_levels=["frame"] * nv, variance_transforms=["none"] * nv,
-                           variance_losses=["mse"] * nv, mel_loss="l1", duration_loss="mse", max_length=4096)
+                           variance_losses=["mse"] * nv, mel_loss="l1", duration_loss="mse", max_length=4096, **kw)
     opt = torch.optim.AdamW(model.parameters(), lr=LR, betas=[0.9, 0.98], eps=1e-8, weight_decay=0.01)
     sched = NoamLR(opt, WARMUP)
     out = {"config_json": np.array(cfg.to_json()), "synth_json": np.array(synth_json), "hyper_json": np.array(json.dumps(
-        dict(lr=LR, warmup_steps=WARMUP, gradient_clip_val=CLIP)))}
+        dict(lr=LR, warmup_steps=WARMUP, gradient_clip_val=CLIP, **({} if loss_alphas is None else {"loss_alphas": {
+            k: v for k, v in loss_alphas.items() if k != "speakers"}}))))}
     for k, v in batch.items():
         out["in_" + k] = v.numpy()
     for step in (1, 2, 3):
@@ -70,6 +72,37 @@ def main():
     from litfass.fastspeech2.loss import FastSpeech2Loss
     from litfass.fastspeech2.noam import NoamLR
 
+    only = sys.argv[1:]
+    if not only or "train_small" in only:
+        _dense(FastSpeech2Loss, NoamLR)
+    _rest(FastSpeech2Loss, NoamLR, only)
+
+
+def _recipe(FastSpeech2Loss, NoamLR, only):
+    """The shipped recipe's architecture (scripts/train.sh:12-13,27-36,49: four variances incl. srmr, five priors, five-layer
+    duration predictor, six decoder layers, depth-wise blocks) on the batch of recipe_teacher_small.npz."""
+    if only and "train_recipe_small" not in only:
+        return
+    z = np.load(os.path.join(ROOT, "tests", "golden", "recipe_teacher_small.npz"))
+    cfg = Fs2Config.from_json(str(z["config_json"]))
+    skw = json.loads(str(z["synth_json"]))
+    sd = synth_state_dict(cfg, skw.pop("seed"), **skw)
+    B, T = z["out_mel"].shape[:2]
+    rs = np.random.RandomState(778)
+    batch = {"phones": torch.from_numpy(z["phones"]), "speaker": torch.from_numpy(z["speaker"]),
+             "duration": torch.from_numpy(z["tf_duration"]),
+             "mel": torch.from_numpy((rs.randn(B, T, cfg.n_mels) * 1.3 - 2.0).astype(np.float32))}
+    for v in cfg.variances:
+        batch[f"variances_{v}"] = torch.from_numpy(z[f"tf_variances_{v}"])
+    for k in z.files:
+        if k.startswith("in_priors_"):
+            batch[k[3:]] = torch.from_numpy(z[k])
+    # scripts/train.sh:25-26: --variance_loss_weights 1 1 1 1 --duration_loss_weight 1; mel_loss_weight's default is 1
+    alphas = {"mel": 1.0, "duration": 1.0, "speakers": 1.0, **{v: 1.0 for v in cfg.variances}}
+    run_case("train_recipe_small", cfg, sd, str(z["synth_json"]), batch, FastSpeech2Loss, NoamLR, loss_alphas=alphas)
+
+
+def _dense(FastSpeech2Loss, NoamLR):
     # dense family: the batch of teacher_small.npz
     z = np.load(os.path.join(ROOT, "tests", "golden", "teacher_small.npz"))
     cfg = Fs2Config.from_json(str(z["config_json"]))
@@ -84,6 +117,11 @@ def main():
         batch[f"variances_{v}"] = torch.from_numpy(z[f"tf_variances_{v}"])
     run_case("train_small", cfg, sd, str(z["synth_json"]), batch, FastSpeech2Loss, NoamLR)
 
+
+def _rest(FastSpeech2Loss, NoamLR, only):
+    _recipe(FastSpeech2Loss, NoamLR, only)
+    if only and "train_dw_small" not in only:
+        return
     # depth-wise family (the reference's class defaults, fastspeech2.py:68,76,98,107): every conv depth-wise, odd kernel mix
     from lightningfastspeech2_amd.weights import synth_inputs
     cfg = Fs2Config(n_phones=40, encoder_hidden=64, decoder_hidden=64, encoder_head=2, decoder_head=2, encoder_layers=2,
