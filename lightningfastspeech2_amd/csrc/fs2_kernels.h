@@ -130,6 +130,7 @@ struct PredictorArgs {
     const float* be_pe = nullptr;    // (>= S, H) fp32 or null
     const float* be_spk = nullptr;   // (B, H) fp32 or null
 };
+extern int g_slab_ring;  // A/B knob (210 / 211): the slab kernel's operand ring for pointwise launches on short tiles
 extern unsigned long long g_knob_gen;  // bumped by every accepted fs2_op_set_gemm_variant call; part of the hipGraph keys (capi_ops.hip)
 extern int g_pred_fuse_embed;  // A/B knob (1320 / 1321): the engine's frame-level variance encoders as the tail of their predictor launch
 bool predictor_fused_supported(int dtype, int H, int taps, int nlayers, int S);

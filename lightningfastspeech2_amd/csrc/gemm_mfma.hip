@@ -386,17 +386,32 @@ __device__ unsigned long long g_slab_stamps[4][8];
 #define SLAB_STAMP(i) do { } while (0)
 #endif
 
-template <typename T, typename OutT, int MI, bool LN, bool WIDE = false, bool SPLIT = false, bool DEFER = false>
+// NST > 2 (pointwise launches only, taps == 1; r04): the operand RING.  With two stages a step's DMAs are requested one step ahead;
+// where a step is short (32- / 64- / 128-row tiles: 256 .. 1100 MFMA cycles) that is less than the round trip of an L2 miss, and
+// inside a forward every launch finds its weights L2-cold (last touched a layer ago): the encoder's conv2 + LayerNorm launch took
+// 22 us in the forward against 13.9 us back to back on hot caches (tools/bench_ops.py --flush: 19.9 us with the L2s flushed, 26.1
+// with the Infinity Cache flushed too) - a latency-bound loop, PMC waits 0.74 of its wave cycles.  NST stages of (row tile x 64
+// channels, 256 x 64 weight tile), NST - 1 steps in flight, a COUNTED vmcnt per step (the builtin, so that hipcc's own LDS-DMA
+// scoreboard sees it) and the raw s_barrier (a __syncthreads() would drain every DMA in flight).  The slabs of this mode hold
+// the tile's rows only (no conv halo), so 4 stages fit at 32-row tiles (160 KiB) and 3 at 64 / 128 rows.
+template <typename T, typename OutT, int MI, bool LN, bool WIDE = false, bool SPLIT = false, bool DEFER = false, int NST = 2>
 __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
     static_assert(!SPLIT || sizeof(T) == 4, "the split arithmetic takes fp32 operands");
     static_assert(!(DEFER && LN), "deferred LayerNorm is what a launch WITHOUT the fused epilogue leaves behind");
+    static_assert(NST >= 2 && NST <= 4 && !(NST > 2 && WIDE), "operand ring: 2 (two-stage loop), 3 or 4 stages");
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-resource builtins only exist in the device pass
     using Cfg = SlabCfg<MI>;
-    constexpr int BMs = Cfg::BM, SI = Cfg::SI;
-    __shared__ __attribute__((aligned(16))) unsigned char slab0[Cfg::SLAB_BYTES];
-    __shared__ __attribute__((aligned(16))) unsigned char slab1[Cfg::SLAB_BYTES];
+    constexpr int BMs = Cfg::BM;
+    constexpr int SI = NST > 2 ? (BMs / 8 + 7) / 8 : Cfg::SI;                       // ring mode: the tile's own rows, no halo
+    constexpr int SLAB_B = NST > 2 ? SI * 8 * 1024 : Cfg::SLAB_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char slab0[SLAB_B];
+    __shared__ __attribute__((aligned(16))) unsigned char slab1[SLAB_B];
+    __shared__ __attribute__((aligned(16))) unsigned char slab2[NST > 2 ? SLAB_B : 16];
+    __shared__ __attribute__((aligned(16))) unsigned char slab3[NST > 3 ? SLAB_B : 16];
     __shared__ __attribute__((aligned(16))) unsigned char wt0[S_BN * ROWB];  // 32 KiB weight tile per stage
     __shared__ __attribute__((aligned(16))) unsigned char wt1[S_BN * ROWB];
+    __shared__ __attribute__((aligned(16))) unsigned char wt2[NST > 2 ? S_BN * ROWB : 16];
+    __shared__ __attribute__((aligned(16))) unsigned char wt3[NST > 3 ? S_BN * ROWB : 16];
     constexpr int KE = ROWB / (int)sizeof(T);
     SLAB_STAMP(0);
 
@@ -568,6 +583,10 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
     SLAB_STAMP(1);
     issue_slab(slab0, 0);
     issue_w(wt0, 0, 0);
+    if constexpr (NST > 2) {  // the ring's other NST - 2 leading steps: everything the first steps need is requested before any wait
+        if (ncc > 1) { issue_slab(slab1, 1); issue_w(wt1, 1, 0); }
+        if (NST > 3 && ncc > 2) { issue_slab(slab2, 2); issue_w(wt2, 2, 0); }
+    }
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -576,55 +595,139 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
         const T* R = (const T*)(LN ? p.res : p.epi_res) + (size_t)ub * S * p.ldc;
         const bool rnorm = DEFER && p.epi_res_stats != nullptr;
         const size_t rowbase0 = (size_t)ub * S;
+        // Every load of the preload is issued before the first one is waited for.  (Until r04 each 16-byte load sat under its own
+        // N-tail branch, and hipcc puts a vmcnt(0) behind a load it cannot move out of an exec-masked block: 2 * MI serial round
+        // trips - twelve at 192-row tiles, the "residual preload 11.2 k ticks" of tools/probes/slab_phase_stamps.py.)  The tile
+        // that lies wholly inside N - the common case - takes a branch-free path by workgroup-uniform dispatch.
+        auto preload = [&](auto full_c) {
+            constexpr bool FULL = decltype(full_c)::value;
+            float rmean[MI], rrstd[MI];
+            int tr[MI];
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            int t = t0 + wm * (MI * 16) + mi * 16 + fr;
-            if (t >= S) t = S - 1;  // rows past the utterance end are never stored
-            float rmean = 0.f, rrstd = 1.f;
-            if (rnorm) {
-                const float2* ps = (const float2*)p.epi_res_stats + (rowbase0 + t) * p.epi_res_parts;
-                float2 pq[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) pq[q] = q < p.epi_res_parts ? ps[q] : make_float2(0.f, 0.f);
-                const float s1 = (pq[0].x + pq[1].x) + (pq[2].x + pq[3].x), s2 = (pq[0].y + pq[1].y) + (pq[2].y + pq[3].y);
-                const float invn = 1.0f / (float)p.N;
-                rmean = s1 * invn;
-                rrstd = 1.0f / sqrtf(fmaxf(__builtin_fmaf(-rmean, rmean, s2 * invn), 0.f) + p.ln_eps);
+            for (int mi = 0; mi < MI; ++mi) {
+                const int t = t0 + wm * (MI * 16) + mi * 16 + fr;
+                tr[mi] = t >= S ? S - 1 : t;  // rows past the utterance end are never stored
+                rmean[mi] = 0.f;
+                rrstd[mi] = 1.f;
             }
+            if (rnorm) {
+                float2 pq[MI][4];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int n = n0 + wn * 64 + j * 32 + fg * 8;
-                const T* src = R + (size_t)t * p.ldc + n;
-                float rv[8];
-                if (n + 7 < p.N) {
-                    if constexpr (sizeof(T) == 4) {
-                        const float4 q0 = *(const float4*)src, q1 = *(const float4*)(src + 4);
-                        rv[0] = q0.x; rv[1] = q0.y; rv[2] = q0.z; rv[3] = q0.w;
-                        rv[4] = q1.x; rv[5] = q1.y; rv[6] = q1.z; rv[7] = q1.w;
-                    } else {
-                        const uint4 q = *(const uint4*)src;
-                        const unsigned w4[4] = {q.x, q.y, q.z, q.w};
+                for (int mi = 0; mi < MI; ++mi) {
+                    const float2* ps = (const float2*)p.epi_res_stats + (rowbase0 + tr[mi]) * p.epi_res_parts;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            rv[2 * e] = __uint_as_float(w4[e] << 16);
-                            rv[2 * e + 1] = __uint_as_float(w4[e] & 0xffff0000u);
+                    for (int q = 0; q < 4; ++q) pq[mi][q] = ps[q < p.epi_res_parts ? q : 0];  // unconditional: a clamped index, masked below
+                }
+                const float invn = 1.0f / (float)p.N;
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+                    for (int q = 1; q < 4; ++q) if (q >= p.epi_res_parts) pq[mi][q] = make_float2(0.f, 0.f);
+                    const float s1 = (pq[mi][0].x + pq[mi][1].x) + (pq[mi][2].x + pq[mi][3].x);
+                    const float s2 = (pq[mi][0].y + pq[mi][1].y) + (pq[mi][2].y + pq[mi][3].y);
+                    rmean[mi] = s1 * invn;
+                    rrstd[mi] = 1.0f / sqrtf(fmaxf(__builtin_fmaf(-rmean[mi], rmean[mi], s2 * invn), 0.f) + p.ln_eps);
+                }
+            }
+            if constexpr (FULL) {
+                if constexpr (sizeof(T) == 4) {
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const T* src = R + (size_t)tr[mi] * p.ldc + n0 + wn * 64 + j * 32 + fg * 8;
+                            const float4 q0 = *(const float4*)src, q1 = *(const float4*)(src + 4);
+                            acc[2 * j][mi] = (f32x4_t){q0.x, q0.y, q0.z, q0.w};
+                            acc[2 * j + 1][mi] = (f32x4_t){q1.x, q1.y, q1.z, q1.w};
                         }
-                    }
                 } else {
+                    uint4 rq[MI][2];
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) rv[r] = (n + r < p.N) ? Num<T>::to_f32(src[r]) : 0.f;
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) rq[mi][j] = *(const uint4*)(R + (size_t)tr[mi] * p.ldc + n0 + wn * 64 + j * 32 + fg * 8);
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const unsigned w4[4] = {rq[mi][j].x, rq[mi][j].y, rq[mi][j].z, rq[mi][j].w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                acc[2 * j + (e >> 1)][mi][(2 * e) & 3] = __uint_as_float(w4[e] << 16);
+                                acc[2 * j + (e >> 1)][mi][(2 * e + 1) & 3] = __uint_as_float(w4[e] & 0xffff0000u);
+                            }
+                        }
                 }
                 if (rnorm) {
 #pragma unroll
-                    for (int r = 0; r < 8; ++r)
-                        rv[r] = n + r < p.N ? __builtin_fmaf((rv[r] - rmean) * rrstd, p.epi_res_g[n + r], p.epi_res_b[n + r]) : 0.f;
-                }
+                    for (int j = 0; j < 2; ++j) {
+                        const int n = n0 + wn * 64 + j * 32 + fg * 8;
+                        float gv[8], bv8[8];
 #pragma unroll
-                for (int r = 0; r < 8; ++r) acc[2 * j + (r >> 2)][mi][r & 3] = rv[r];
+                        for (int r = 0; r < 8; ++r) { gv[r] = p.epi_res_g[n + r]; bv8[r] = p.epi_res_b[n + r]; }
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                            for (int r = 0; r < 8; ++r)
+                                acc[2 * j + (r >> 2)][mi][r & 3] = __builtin_fmaf((acc[2 * j + (r >> 2)][mi][r & 3] - rmean[mi]) * rrstd[mi], gv[r], bv8[r]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int n = n0 + wn * 64 + j * 32 + fg * 8;
+                        const T* src = R + (size_t)tr[mi] * p.ldc + n;
+                        float rv[8];
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) rv[r] = (n + r < p.N) ? Num<T>::to_f32(src[r]) : 0.f;
+                        if (rnorm) {
+#pragma unroll
+                            for (int r = 0; r < 8; ++r)
+                                rv[r] = n + r < p.N ? __builtin_fmaf((rv[r] - rmean[mi]) * rrstd[mi], p.epi_res_g[n + r], p.epi_res_b[n + r]) : 0.f;
+                        }
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) acc[2 * j + (r >> 2)][mi][r & 3] = rv[r];
+                    }
+                }
             }
-        }
+        };
+        if (n0 + S_BN <= p.N) preload(BoolC<true>{});
+        else preload(BoolC<false>{});
     }
     SLAB_STAMP(6);
+    if constexpr (NST > 2) {
+        // ---- operand ring (taps == 1): step cc multiplies stage cc % NST; steps cc + 1 .. cc + NST - 2 are in flight across its barrier,
+        // step cc + NST - 1 is requested right behind the barrier into the stage step cc - 1 has just left.  A DMA wave issues G
+        // instructions per step, in order, so "all but the youngest (NST - 2) G have landed" is this wave's share of step cc.
+        constexpr int G = DSI + DWI;
+#define FS2_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (7 << 4) | (15 << 8) | (((n) >> 4) << 14))
+#define FS2_RING_STEP(slab_cur, w_cur, slab_nxt, w_nxt, ccv)                                                   \
+    {                                                                                                          \
+        const int left = ncc - 1 - (ccv); /* steps requested behind this one */                               \
+        if (left >= NST - 2) FS2_VMCNT((NST - 2) * G);                                                         \
+        else if (NST == 4 && left == 1) FS2_VMCNT(G);                                                          \
+        else FS2_VMCNT(0);                                                                                     \
+        __builtin_amdgcn_s_barrier();                                                                          \
+        if ((ccv) + NST - 1 < ncc) { issue_slab(slab_nxt, (ccv) + NST - 1); issue_w(w_nxt, (ccv) + NST - 1, 0); } \
+        compute(slab_cur, w_cur, 0);                                                                           \
+    }
+        for (int cc = 0; cc < ncc; cc += NST) {
+            if constexpr (NST == 3) {
+                FS2_RING_STEP(slab0, wt0, slab2, wt2, cc)
+                if (cc + 1 < ncc) FS2_RING_STEP(slab1, wt1, slab0, wt0, cc + 1)
+                if (cc + 2 < ncc) FS2_RING_STEP(slab2, wt2, slab1, wt1, cc + 2)
+            } else {
+                FS2_RING_STEP(slab0, wt0, slab3, wt3, cc)
+                if (cc + 1 < ncc) FS2_RING_STEP(slab1, wt1, slab0, wt0, cc + 1)
+                if (cc + 2 < ncc) FS2_RING_STEP(slab2, wt2, slab1, wt1, cc + 2)
+                if (cc + 3 < ncc) FS2_RING_STEP(slab3, wt3, slab2, wt2, cc + 3)
+            }
+        }
+#undef FS2_RING_STEP
+#undef FS2_VMCNT
+    } else
     for (int cc = 0; cc < ncc; cc += 2) {
         for (int tap = 0; tap < ntap; tap += 2) {
             FS2_SLAB_STEP(slab0, slab1, wt0, wt1, cc, tap)
@@ -1207,20 +1310,39 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
 #endif
 }
 
-template <typename T, typename OutT, int MI, bool LN, bool WIDE = false, bool SPLIT = false, bool DEFER = false>
+template <typename T, typename OutT, int MI, bool LN, bool WIDE = false, bool SPLIT = false, bool DEFER = false, int NST = 2>
 static int launch_slab_t(const GemmArgs& a0, hipStream_t stream) {
     GemmArgs a = a0;
     if (a.taps == 1) a.S = a.M;  // plain GEMM: one "utterance" of M rows
     a.xcd_remap = g_slab_xcd_remap;
     const int BMs = SlabCfg<MI>::BM;
     const int tiles = (a.M / a.S) * ((a.S + BMs - 1) / BMs) * (WIDE ? 1 : (a.N + S_BN - 1) / S_BN) * (a.ksplit > 1 ? a.ksplit : 1);
-    hipLaunchKernelGGL((gemm_conv_slab_kernel<T, OutT, MI, LN, WIDE, SPLIT, DEFER>), dim3(tiles), dim3(512), 0, stream, a);
+    hipLaunchKernelGGL((gemm_conv_slab_kernel<T, OutT, MI, LN, WIDE, SPLIT, DEFER, NST>), dim3(tiles), dim3(512), 0, stream, a);
     return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
 }
 
 extern int g_split_f32;
+int g_slab_ring = 0;  // A/B knob (210 / 211): pointwise launches on 32- / 64- / 128-row tiles through the 4- / 4- / 3-stage operand ring.
+                      // OFF: measured neutral (tools/bench_ops.py ln / gemm --flush 48, r04: enc conv2 + LN 19.9 -> 21.6 us, conv2 plain 18.4 ->
+                      // 15.9, in-proj 12.9 -> 12.9) - these launches are bound by what a CU ingests per second, not by a step's round trip
 template <int MI>
 static int launch_slab(const GemmArgs& a, int in_dtype, int out_dtype, hipStream_t stream) {
+    if constexpr (MI <= 4) {
+        // short steps, long round trips: the operand ring (see the kernel).  Same MFMA order per element: bit-identical results.
+        constexpr int R = MI == 4 ? 3 : 4;
+        if (g_slab_ring && a.taps == 1 && a.ksplit <= 1 && !a.stats_out && !a.epi_res && (!a.ln_g || a.N <= S_BN) && in_dtype == out_dtype) {
+            const bool sp = a.split || g_split_f32;
+            if (a.ln_g) {
+                if (in_dtype == FS2_F32) return sp ? launch_slab_t<float, float, MI, true, false, true, false, R>(a, stream)
+                                                   : launch_slab_t<float, float, MI, true, false, false, false, R>(a, stream);
+                if (in_dtype == FS2_BF16) return launch_slab_t<bf16, bf16, MI, true, false, false, false, R>(a, stream);
+            } else {
+                if (in_dtype == FS2_F32) return sp ? launch_slab_t<float, float, MI, false, false, true, false, R>(a, stream)
+                                                   : launch_slab_t<float, float, MI, false, false, false, false, R>(a, stream);
+                if (in_dtype == FS2_BF16) return launch_slab_t<bf16, bf16, MI, false, false, false, false, R>(a, stream);
+            }
+        }
+    }
     if (a.ln_g) {  // fused LayerNorm epilogue: whole rows per workgroup, tile heights 128 / 192 only
         if constexpr (MI <= 6) {
             if (a.N > S_BN) {  // wide rows: column tiles walked inside the workgroup, normalised in place

@@ -52,16 +52,10 @@ def test_full_config_properties_bf16(name):
     out2 = m({"phones": batch["phones"], "speaker": spk2}, inference=True)
     same = [bool(torch.equal(out2["mel"][b], out["mel"][b])) for b in range(B)]
     assert same.count(False) == 1 and not same[1]
-    # the in-place wide-row LayerNorm epilogue (N = 768 / 1024; built, measured slower, off by default) against the
-    # GEMM + LayerNorm launches
-    m.engine.lib.fs2_op_set_gemm_variant(301)
-    try:
-        two = m(batch, inference=True)
-    finally:
-        m.engine.lib.fs2_op_set_gemm_variant(300)
-    d = (two["mel"] - out["mel"]).abs()
-    _report(test="full_config_bf16", case=name, wide_ln_vs_two_launch_mel_max=float(d.max()), mel_scale=float(out["mel"].abs().max()))
-    assert torch.equal(two["tgt_mask"], out["tgt_mask"])
+    # (the in-place wide-row LayerNorm epilogue - knob 301, off by default - has its own operator-level test with an asserted
+    # tolerance, tests/test_gpu_ops.py::test_wide_layernorm_fused_vs_two_launches; a free-running whole-model comparison flips
+    # buckets and asserted nothing)
+    _report(test="full_config_bf16", case=name, mel_scale=float(out["mel"].abs().max()))
 
 
 @pytest.mark.parametrize("name", ["c3", "c5"])

@@ -74,6 +74,34 @@ def test_wres_gemm_is_bit_identical_to_the_slab_kernel(M, N, relu, bias):
     assert float((got - ref).abs().max()) <= tol(G.BF16, ref)
 
 
+@pytest.mark.parametrize("dtype", [G.BF16, G.F32])
+@pytest.mark.parametrize("M,N,K,variant,ln", [(8192, 256, 1024, 6, True), (8192, 256, 256, 6, True), (2048, 768, 256, 7, False),
+                                              (1024, 256, 320, 6, True), (96 * 5 + 7, 512, 192, 3, False), (2048, 256, 1024, 3, True),
+                                              (40, 200, 64, 6, True)])
+def test_operand_ring_is_bit_identical_to_the_two_stage_loop(dtype, M, N, K, variant, ln):
+    """Knob 211 (r04; off by default - measured neutral): pointwise launches on 32- / 64- / 128-row tiles with 4 / 4 / 3
+    operand stages in flight (counted vmcnt + raw barrier) - the same MFMA order per element as the two-stage loop, so bit-equal
+    outputs, on K = 1 .. 16 steps (fewer steps than stages included), ragged row / column tails, plain and LayerNorm epilogues."""
+    ke = 64 if dtype == G.BF16 else 32
+    assert K % ke == 0
+    x, w, b = rnd(M, K, seed=21), rnd(N, K, seed=22) / K ** 0.5, rnd(N, seed=23)
+    res, g, be = rnd(M, N, seed=24), 1 + 0.1 * rnd(N, seed=25), rnd(N, seed=26)
+    outs = []
+    try:
+        G.lib().fs2_op_set_gemm_variant(variant)
+        for knob in (210, 211, 211):
+            G.lib().fs2_op_set_gemm_variant(knob)
+            if ln and N <= 256:
+                outs.append(G.gemm_ln(dtype, x, w, b, res, g, be)[0])
+            else:
+                outs.append(G.gemm(dtype, x, w, b, relu=True))
+    finally:
+        G.lib().fs2_op_set_gemm_variant(210)
+        G.lib().fs2_op_set_gemm_variant(0)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+    assert bool(torch.isfinite(outs[0]).all())
+
+
 def test_gemm_bf16_in_fp32_out(gemm_variant):
     x, w, b = rnd(150, 256, seed=4), rnd(80, 256, seed=5, scale=1 / 16), rnd(80, seed=6)
     ref = G.rounded(x, G.BF16) @ G.rounded(w, G.BF16).T + b

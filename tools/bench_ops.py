@@ -23,10 +23,25 @@ def p(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+FLUSH = [None]  # --flush MB: a torch pass over that many MB between reps (evicts the L2s, and the Infinity Cache from 256 MB on):
+                 # what a launch costs inside a forward, where its weights were last touched a whole layer ago
+
+
 def timeit(fn, reps):
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     for _ in range(3):
         fn(st)
+    if FLUSH[0] is not None:
+        tot = 0.0
+        for _ in range(reps):
+            FLUSH[0].add_(1.0)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn(st)
+            e1.record()
+            torch.cuda.synchronize()
+            tot += e0.elapsed_time(e1)
+        return tot / reps * 1e-3
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -226,7 +241,10 @@ def main():
     ap.add_argument("--shape", default="", help="attn: one extra case B,S,H,heads")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default="", help="substring filter on the case name")
+    ap.add_argument("--flush", type=int, default=0, help="MB of unrelated memory touched between reps (cold caches); 0 = back-to-back reps")
     a = ap.parse_args()
+    if a.flush:
+        FLUSH[0] = torch.zeros(a.flush * 1024 * 1024 // 4, device=DEV)
     global gemm_case, attn_case, gemm_ln_case, bgemm_case
     if a.only:
         g0, a0, l0, b0 = gemm_case, attn_case, gemm_ln_case, bgemm_case

@@ -11,6 +11,6 @@ for cfg in c2 c3 c5; do
   rm -rf $O/prof_$cfg
   timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof_$cfg -o p -- python $R/bench.py --config $cfg --batch $B --steps 10 --warmup 3 $EXTRA > $O/${TAG}_${cfg}_prof_bench.json 2> $O/${TAG}_${cfg}_prof.err
   DB=$(find $O/prof_$cfg -name '*results.db' | head -1)
-  python $R/tools/rocpd_stats.py $DB "$TAG $cfg: rocprofv3 --kernel-trace --stats -- python bench.py --config $cfg --batch $B --steps 10 --warmup 3 (13 forwards, bf16)" > $O/${TAG}_${cfg}_kernel_stats.md
+  python $R/tools/rocpd_stats.py $DB "$TAG $cfg: rocprofv3 --kernel-trace --stats -- python bench.py --config $cfg --batch $B --steps 10 --warmup 3 (bf16)" > $O/${TAG}_${cfg}_kernel_stats.md
   find $O/prof_$cfg -name '*.db' -delete
 done

@@ -30,7 +30,9 @@ def main(db, title=""):
                        "from kernels group by name order by 3 desc").fetchall()
     tot = sum(r[2] for r in rows)
     print(f"# {title or db}\n")
-    print(f"total kernel time {tot / 1e6:.3f} ms over {sum(r[1] for r in rows)} dispatches\n")
+    nfw = sum(r[1] for r in rows if "embed_kernel<" in r[0] and "bucket" not in r[0])  # the phone embedding opens a forward
+    print(f"total kernel time {tot / 1e6:.3f} ms over {sum(r[1] for r in rows)} dispatches"
+          + (f"; {nfw} forwards in the trace (warm-up, launch-mode tuning, the timed steps and bench.py's event-bracketed passes)\n" if nfw else "\n"))
     print("| kernel | calls | total ms | avg us | min us | max us | % | vgpr | agpr | lds B |")
     print("|---|---|---|---|---|---|---|---|---|---|")
     for n, c, s, a, mn, mx, vg, ag, lds in rows:
