@@ -265,6 +265,15 @@ int fs2_op_gemm_gated(int32_t dtype, const void* x, const void* w, const float* 
                       int32_t M, int32_t N, int32_t Cin, int32_t taps, int32_t S, void* hip_stream);
 int fs2_op_attention(int32_t dtype, const void* qkv, const uint8_t* key_pad_mask, void* out, void* vt_scratch,
                      uint64_t* bits_scratch, int32_t B, int32_t S, int32_t H, int32_t heads, void* hip_stream);
+/* The same attention (nn.MultiheadAttention inside ConformerEncoderLayer.forward, litfass/fastspeech2/model.py:108-116) in the
+ * split arithmetic of the fp32x3 / mixed3 modes: qkv fp32 (B*S, 3H) is split into bf16 heads and tails (split_scratch: 2 x B*S*3H
+ * bf16), every q.k and p.v product is three bf16 MFMAs (lo*hi + hi*lo + hi*hi, fp32 accumulate), softmax fp32; out fp32 (B*S, H). */
+int fs2_op_attention_x3(const float* qkv, const uint8_t* key_pad_mask, float* out, void* split_scratch, uint64_t* bits_scratch,
+                        int32_t B, int32_t S, int32_t H, int32_t heads, void* hip_stream);
+/* fp32 GEMM c = x w^T + bias (split != 0: bf16 x 3 split products) whose result leaves as TWO bf16 (M, N) tensors, c_hi + c_lo = c
+ * up to 2^-17 |c| - how the engine's in-projection feeds the split-arithmetic attention without an extra pass.  N >= 192. */
+int fs2_op_gemm_split_out(const void* x, const void* w, const float* bias, void* c_hi, void* c_lo, int32_t M, int32_t N, int32_t Cin,
+                          int32_t split, void* hip_stream);
 /* GEMM/conv with the fused row epilogue  y = LayerNorm(act(xW^T + b) [+ res]) [, pred = head(y)]
  * (y or pred may be NULL; tmp = (M, N) scratch used when the shape cannot be fused) */
 int fs2_op_gemm_ln(int32_t dtype, const void* x, const void* w, const float* bias, const void* res,

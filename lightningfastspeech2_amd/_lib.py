@@ -154,6 +154,8 @@ def load():
     lib.fs2_op_attention_scratch_bytes.restype = C.c_size_t
     lib.fs2_op_attention_scratch_bytes.argtypes = [i32, i32, i32, i32, i32, C.POINTER(C.c_size_t)]
     lib.fs2_op_attention.argtypes = [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.fs2_op_attention_x3.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.fs2_op_gemm_split_out.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     lib.fs2_op_layernorm.argtypes = [i32, vp, vp, vp, vp, vp, vp, C.c_float, vp, vp, i32, i32, vp]
     lib.fs2_op_dwconv.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     lib.fs2_op_durations.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp]

@@ -22,6 +22,8 @@
 //   two in flight and the wave runs at LDS latency).
 // Key padding arrives as a 64-bit valid mask per 64-key group (any mask shape, not only suffix
 // padding); fully padded tiles are skipped.
+#include <type_traits>
+
 #include "fs2_common.h"
 #include "fs2_kernels.h"
 
@@ -94,7 +96,13 @@ __device__ inline float half_sum(float x) {
 template <int N>
 __device__ inline void vm_wait() { __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14)); }
 
-template <typename T, int D, int NW, int RES = 0>
+// X3 (r04; T = bf16 operands, fp32 output): the parity-grade arithmetic of the fp32x3 / mixed3 modes.  q, k, v arrive as TWO bf16
+// tensors each - head and tail of the fp32 values, x = hi + lo up to 2^-17 |x|, written by the in-projection's own store
+// (GemmArgs::C_lo) or by split_hi_lo_kernel - and every product is three bf16 MFMAs, lo*hi + hi*lo + hi*hi in the fp32 accumulator
+// (small terms first; the dropped lo*lo is 2^-16 of the product), P split the same way in registers.  Softmax, running max, the
+// denominator and O stay fp32.  Against the fp32-MFMA form of this kernel (32x32x2, 1/16 of the bf16 rate): 3/16 of the matrix
+// time; the decoder launch at C2 went 714 us -> see DESIGN 5.
+template <typename T, int D, int NW, int RES = 0, bool X3 = false>
 __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128 && RES == 0) ? 2 : 1) void attention_kernel(AttnArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins exist in the device pass only
     constexpr int KVB = sizeof(T) == 2 ? 64 : 32;      // keys per tile
@@ -116,8 +124,11 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128 && RES == 0) ?
     static_assert(TILE_B % (1024 * NDW) == 0 && NDW <= NW, "tile must split into whole wave DMAs");
 
     static_assert(RES == 0 || (TRV && NINST * RES <= 32), "resident K / V: bf16 only, the counted wait must fit vmcnt");
+    static_assert(!X3 || (TRV && RES == 0), "split arithmetic: bf16 head / tail operands, streaming form");
     __shared__ __attribute__((aligned(16))) unsigned char sKa[TILE_B * (RES ? RES : 1)];
     __shared__ __attribute__((aligned(16))) unsigned char sVa[TILE_B * (RES ? RES : 1)];
+    __shared__ __attribute__((aligned(16))) unsigned char sKl[X3 ? TILE_B : 16];  // the tails' tiles, same layout
+    __shared__ __attribute__((aligned(16))) unsigned char sVl[X3 ? TILE_B : 16];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // query group (also this wave's share of the tile DMAs)
@@ -132,6 +143,7 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128 && RES == 0) ?
     const int q0 = (r8 % nq) * (NW * 32);
     const int ld = 3 * p.H;
     const T* __restrict__ qkv = (const T*)p.qkv;
+    const T* __restrict__ qkvl = (const T*)p.qkv_lo;  // X3 only
     const uint64_t* kbits = p.kbits + (size_t)b * p.nw64;
     const int ntiles = (p.S + KVB - 1) / KVB;
 
@@ -148,6 +160,8 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128 && RES == 0) ?
     const unsigned utt_bytes = (unsigned)((size_t)p.S * ld * sizeof(T));
     const __amdgpu_buffer_rsrc_t qrs =
         __builtin_amdgcn_make_buffer_rsrc((void*)(qkv + (size_t)b * p.S * ld), 0, utt_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t qrl =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((X3 ? qkvl : qkv) + (size_t)b * p.S * ld), 0, utt_bytes, 0x00020000);
     const unsigned vt_bytes = TRV ? 16u : (unsigned)((size_t)p.B * p.heads * D * p.Spad * sizeof(T));
     const __amdgpu_buffer_rsrc_t vrs =
         __builtin_amdgcn_make_buffer_rsrc(TRV ? (void*)p.qkv : (void*)p.vt, 0, vt_bytes, 0x00020000);
@@ -172,6 +186,10 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128 && RES == 0) ?
         if (NDW != NW && wave >= NDW) return;
 #pragma unroll
         for (int i = 0; i < NINST; ++i) dma16(qrs, sK + (i * NDW + wave) * 1024, kvo[i] + (unsigned)j * ktile);
+        if constexpr (X3) {
+#pragma unroll
+            for (int i = 0; i < NINST; ++i) dma16(qrl, sKl + (i * NDW + wave) * 1024, kvo[i] + (unsigned)j * ktile);
+        }
     };
     auto issue_v = [&](int j, unsigned char* sV) {
         if (NDW != NW && wave >= NDW) return;
@@ -180,10 +198,14 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128 && RES == 0) ?
             if constexpr (TRV) dma16(qrs, sV + (i * NDW + wave) * 1024, vvo[i] + (unsigned)j * ktile);
             else dma16(vrs, sV + (i * NDW + wave) * 1024, vvo[i] + (unsigned)(j * KVB * (int)sizeof(T)));
         }
+        if constexpr (X3) {
+#pragma unroll
+            for (int i = 0; i < NINST; ++i) dma16(qrl, sVl + (i * NDW + wave) * 1024, vvo[i] + (unsigned)j * ktile);
+        }
     };
 
     // ---- Q fragments (column operand of S^T = K Q^T) ----
-    uint4 qf[NQC];
+    uint4 qf[NQC], qfl[X3 ? NQC : 1];
     {
         int qrow = q0 + wave * 32 + li;
         if (qrow >= p.S) qrow = p.S - 1;
@@ -192,9 +214,21 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128 && RES == 0) ?
         for (int c = 0; c < NQC; ++c) {  // q * log2(e)/sqrt(d), once: scores come out of the MFMA in exp2 units
             float f[Vec16<T>::N];
             Vec16<T>::unpack(*(const uint4*)(src + c * KC), f);
+            if constexpr (X3) {  // the fp32 value back from its two halves, scaled in fp32, split again
+                float g[Vec16<T>::N], r[Vec16<T>::N];
+                Vec16<T>::unpack(*(const uint4*)(qkvl + (size_t)(b * p.S + qrow) * ld + h * D + hi * E16 + c * KC), g);
+#pragma unroll
+                for (int e = 0; e < Vec16<T>::N; ++e) f[e] = (f[e] + g[e]) * p.scale_log2e;
+                qf[c] = Vec16<T>::pack(f);
+                Vec16<T>::unpack(qf[c], g);
+#pragma unroll
+                for (int e = 0; e < Vec16<T>::N; ++e) r[e] = f[e] - g[e];
+                qfl[c] = Vec16<T>::pack(r);
+            } else {
 #pragma unroll
             for (int e = 0; e < Vec16<T>::N; ++e) f[e] *= p.scale_log2e;
             qf[c] = Vec16<T>::pack(f);
+            }
         }
     }
 
@@ -234,7 +268,7 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128 && RES == 0) ?
                                // done with P.V of the previous tile -> sV is free
             if (valid) issue_v(j, sV);  // V_j streams in underneath Q.K^T
             }
-            uint4 pf[4];
+            uint4 pf[4], pfl[X3 ? 4 : 1];
             if (valid) {
             // the running max rides in the accumulator's initial value, so the common path is
             // p = exp2(acc) with no per-element subtract
@@ -250,16 +284,27 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128 && RES == 0) ?
             // accumulate latency of one chain hides under the other
             {   // rolling prefetch: PD K fragments are in flight ahead of the MFMA that consumes them, so a
                 // wave's Q.K^T is paced by the matrix pipe, not by an LDS round trip per MFMA pair
-                constexpr int NF = NQC * NKB, PD = NF < 6 ? NF : 6;
-                uint4 kq[PD];
-                auto kaddr = [&](int i) { return sK + swz_row<KRB>((i % NKB) * 32 + li, (i / NKB) * 2 + hi); };
+                constexpr int NF = NQC * NKB, PD = X3 ? (NF < 3 ? NF : 3) : (NF < 6 ? NF : 6);
+                uint4 kq[PD], kql[X3 ? PD : 1];
+                auto koff = [&](int i) { return swz_row<KRB>((i % NKB) * 32 + li, (i / NKB) * 2 + hi); };
+                auto kaddr = [&](int i) { return sK + koff(i); };
     #pragma unroll
-                for (int i = 0; i < PD; ++i) kq[i] = *(const uint4*)kaddr(i);
+                for (int i = 0; i < PD; ++i) {
+                    kq[i] = *(const uint4*)kaddr(i);
+                    if constexpr (X3) kql[i] = *(const uint4*)(sKl + koff(i));
+                }
                 __builtin_amdgcn_sched_barrier(0);  // keep the issue order: hipcc otherwise re-serialises to 2 in flight
     #pragma unroll
                 for (int i = 0; i < NF; ++i) {
+                    if constexpr (X3) {  // small terms first
+                        Mma32<T>::step(kql[i % PD], qf[i / NKB], sacc[i % NKB]);
+                        Mma32<T>::step(kq[i % PD], qfl[i / NKB], sacc[i % NKB]);
+                    }
                     Mma32<T>::step(kq[i % PD], qf[i / NKB], sacc[i % NKB]);
-                    if (i + PD < NF) kq[i % PD] = *(const uint4*)kaddr(i + PD);
+                    if (i + PD < NF) {
+                        kq[i % PD] = *(const uint4*)kaddr(i + PD);
+                        if constexpr (X3) kql[i % PD] = *(const uint4*)(sKl + koff(i + PD));
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -333,6 +378,13 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128 && RES == 0) ?
                     f[e] = sacc[flat >> 4][flat & 15];
                 }
                 pf[ch] = Vec16<T>::pack(f);
+                if constexpr (X3) {  // p = head + tail
+                    float g[Vec16<T>::N];
+                    Vec16<T>::unpack(pf[ch], g);
+    #pragma unroll
+                    for (int e = 0; e < Vec16<T>::N; ++e) g[e] = f[e] - g[e];
+                    pfl[ch] = Vec16<T>::pack(g);
+                }
             }
             }
             if constexpr (RES > 0) {
@@ -359,21 +411,31 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128 && RES == 0) ?
                     vcol[nd] = rowb + (((nd * 4 + g1 * 2 + ((i16 & 3) >> 1)) ^ vswz<KRB>(rsub)) << 4);
                 // key-chunk outer / dv-block inner: consecutive MFMAs accumulate into different oacc[nd]
                 {   // same rolling prefetch for the transposed V fragments (two 8-byte reads each)
-                    constexpr int NF = 4 * ND, PD = 4;
-                    uint4 vq[PD];
-                    auto vload = [&](int i) {
-                        const unsigned char* vb = sV + vcol[i % ND] + (i / ND) * 16 * KRB;
+                    constexpr int NF = 4 * ND, PD = X3 ? 2 : 4;
+                    uint4 vq[PD], vql[X3 ? PD : 1];
+                    auto vload = [&](const unsigned char* base, int i) {
+                        const unsigned char* vb = base + vcol[i % ND] + (i / ND) * 16 * KRB;
                         const uint2 lo = tr_read_b64(vb);
                         const uint2 hi2 = tr_read_b64(vb + 8 * KRB);
                         return make_uint4(lo.x, lo.y, hi2.x, hi2.y);
                     };
     #pragma unroll
-                    for (int i = 0; i < PD; ++i) vq[i] = vload(i);
+                    for (int i = 0; i < PD; ++i) {
+                        vq[i] = vload(sV, i);
+                        if constexpr (X3) vql[i] = vload(sVl, i);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
     #pragma unroll
                     for (int i = 0; i < NF; ++i) {
+                        if constexpr (X3) {
+                            Mma32<T>::step(vql[i % PD], pf[i / ND], oacc[i % ND]);
+                            Mma32<T>::step(vq[i % PD], pfl[i / ND], oacc[i % ND]);
+                        }
                         Mma32<T>::step(vq[i % PD], pf[i / ND], oacc[i % ND]);
-                        if (i + PD < NF) vq[i % PD] = vload(i + PD);
+                        if (i + PD < NF) {
+                            vq[i % PD] = vload(sV, i + PD);
+                            if constexpr (X3) vql[i % PD] = vload(sVl, i + PD);
+                        }
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
@@ -396,7 +458,8 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128 && RES == 0) ?
     if (qrow < p.S) {
         if (p.lse2 && hi == 0) p.lse2[(size_t)(b * p.heads + h) * p.S + qrow] = m_run + __builtin_amdgcn_logf(l_run);  // v_log_f32 = log2
         const float inv = 1.f / l_run;  // all keys padded -> NaN, as the reference's softmax gives
-        T* dst = (T*)p.out + (size_t)(b * p.S + qrow) * p.H + h * D;
+        using OT = typename std::conditional<X3, float, T>::type;  // the split form hands back fp32 rows
+        OT* dst = (OT*)p.out + (size_t)(b * p.S + qrow) * p.H + h * D;
 #pragma unroll
         for (int nd = 0; nd < ND; ++nd)
 #pragma unroll
@@ -404,7 +467,7 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128 && RES == 0) ?
                 const int dv = nd * 32 + 8 * g + 4 * hi;
                 const float v0 = oacc[nd][4 * g + 0] * inv, v1 = oacc[nd][4 * g + 1] * inv;
                 const float v2 = oacc[nd][4 * g + 2] * inv, v3 = oacc[nd][4 * g + 3] * inv;
-                if constexpr (sizeof(T) == 4) {
+                if constexpr (sizeof(OT) == 4) {
                     *(float4*)(dst + dv) = make_float4(v0, v1, v2, v3);
                 } else {
                     *(uint2*)(dst + dv) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
@@ -498,11 +561,46 @@ int launch_transpose_v(const AttnArgs& a, int dtype, hipStream_t stream) {
     return FS2_ERR_SHAPE;
 }
 
+// fp32 (B*S, 3H) -> bf16 heads and tails, x = hi + lo (the X3 attention's operands when the in-projection did not write them itself)
+__global__ __launch_bounds__(256) void split_hi_lo_kernel(const float* __restrict__ x, bf16* __restrict__ hi, bf16* __restrict__ lo, size_t n8) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const uint4 c0 = *(const uint4*)(x + i * 8), c1 = *(const uint4*)(x + i * 8 + 4);
+    uint4 h, l;
+    split_bf16x3(c0, c1, h, l);
+    *(uint4*)(hi + i * 8) = h;
+    *(uint4*)(lo + i * 8) = l;
+}
+int launch_split_hi_lo(const float* x, void* hi, void* lo, size_t n, hipStream_t stream) {
+    if (n % 8) return FS2_ERR_SHAPE;
+    if (!n) return FS2_OK;
+    hipLaunchKernelGGL(split_hi_lo_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, stream, x, (bf16*)hi, (bf16*)lo, n / 8);
+    return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
+}
+
+template <int D>
+static int launch_x3(const AttnArgs& a, hipStream_t stream) {
+    const int BH = a.B * a.heads, BH8 = (BH + 7) / 8 * 8;
+    const long blocks4 = (long)((a.S + 127) / 128) * BH;
+    if (blocks4 >= 512) hipLaunchKernelGGL((attention_kernel<bf16, D, 4, 0, true>), dim3(((a.S + 127) / 128) * BH8), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((attention_kernel<bf16, D, 2, 0, true>), dim3(((a.S + 63) / 64) * BH8), dim3(128), 0, stream, a);
+    return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
+}
+
+int g_attn_x3 = 1;    // 1: the fp32-storage split modes (fp32x3 / mixed3) run attention on bf16 x 3 split products; 0: fp32 MFMA
 int g_attn_pipe = 3;  // 0: attention_kernel only; 1 / 2 / 4: the pipelined kernel with 32 / 64 / 96 queries per wave where it applies; 3: by size
 
 int launch_attention(const AttnArgs& a, int dtype, hipStream_t stream) {
     if (a.B <= 0 || a.S <= 0) return FS2_OK;
     if (a.Spad % 64 || a.Spad < a.S || a.H % a.heads) return FS2_ERR_SHAPE;
+    if (a.qkv_lo) {  // split arithmetic: bf16 head / tail operands, fp32 rows out (dtype names the STORAGE mode: fp32)
+        const int d3 = a.H / a.heads;
+        if (dtype != FS2_F32) return FS2_ERR_ARG;
+        if (d3 == 32) return launch_x3<32>(a, stream);
+        if (d3 == 64) return launch_x3<64>(a, stream);
+        if (d3 == 128) return launch_x3<128>(a, stream);
+        return FS2_ERR_SHAPE;
+    }
     if (g_attn_pipe && attention_pipe_supported(a, dtype)) {
         // WHICH kernel family computes an utterance may depend on the utterance only (its length, the head count), never on the
         // batch around it: a shard run alone must be bit-equal to its rows of the whole batch (the data-parallel invariant,

@@ -97,6 +97,7 @@ int fs2_op_set_vocoder_lds_limit(int32_t kib) {
 // silently), and every accepted call bumps g_knob_gen, which is part of the engines' hipGraph keys - a captured phase is
 // never replayed with kernels chosen under other knobs.
 static int set_gemm_variant(int32_t variant) {
+    if (variant == 1500 || variant == 1501) { fs2::g_attn_x3 = variant - 1500; return FS2_OK; }        // fp32-storage split modes: attention on fp32 MFMA / on bf16 x 3 split products (default)
     if (variant >= 1400 && variant <= 1402) { fs2::g_gemm_wres = variant - 1400; return FS2_OK; }      // bf16 K = 256 plain GEMMs: slab kernel / weight-resident kernel where it pays (default) / wherever it applies
     if (variant == 1320 || variant == 1321) { fs2::g_pred_fuse_embed = variant - 1320; return FS2_OK; }  // engine: variance encoder (bucketize + embedding add) as the tail of its predictor launch: off / on (default)
     if (variant >= 1300 && variant <= 1302) { fs2::g_pred_tall = variant - 1300; return FS2_OK; }      // 1300 / 1301 / 1302: single-launch predictor on 112-row tiles only / 208-row tiles (one workgroup per CU) / two 112-row tiles per workgroup, when they fill the chip
@@ -244,6 +245,38 @@ int fs2_op_attention(int32_t dtype, const void* qkv, const uint8_t* key_pad_mask
     r = launch_transpose_v(a, dtype, st);
     if (r != FS2_OK) return r;
     return launch_attention(a, dtype, st);
+}
+
+// The split-arithmetic attention on an fp32 (B*S, 3H) qkv tensor: head / tail split pass (the engine's in-projection writes the two
+// halves itself), then attention_kernel<bf16, .., X3>; out = fp32 (B*S, H).  split_scratch: 2 * B*S*3H bf16.
+int fs2_op_attention_x3(const float* qkv, const uint8_t* key_pad_mask, float* out, void* split_scratch, uint64_t* bits_scratch,
+                        int32_t B, int32_t S, int32_t H, int32_t heads, void* stream) {
+    if (!qkv || !key_pad_mask || !out || !split_scratch || !bits_scratch || B <= 0 || S <= 0 || H <= 0 || heads <= 0 || H % heads) return FS2_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int Spad = (S + 63) / 64 * 64;
+    MaskBitsArgs mb{key_pad_mask, bits_scratch, B, S, Spad / 64};
+    int r = launch_mask_bits(mb, st);
+    if (r != FS2_OK) return r;
+    const size_t n = (size_t)B * S * 3 * H;
+    void* lo = (char*)split_scratch + n * 2;
+    r = launch_split_hi_lo(qkv, split_scratch, lo, n, st);
+    if (r != FS2_OK) return r;
+    AttnArgs a;
+    a.qkv = split_scratch; a.qkv_lo = lo; a.vt = nullptr; a.kbits = bits_scratch; a.out = out;
+    a.B = B; a.S = S; a.H = H; a.heads = heads; a.Spad = Spad; a.nw64 = Spad / 64;
+    a.scale_log2e = (float)(1.4426950408889634 / sqrt((double)(H / heads)));
+    return launch_attention(a, FS2_F32, st);
+}
+
+// fp32 GEMM (bf16 x 3 split products when split != 0) whose result leaves as two bf16 tensors, head + tail
+int fs2_op_gemm_split_out(const void* x, const void* w, const float* bias, void* c_hi, void* c_lo, int32_t M, int32_t N, int32_t Cin,
+                          int32_t split, void* stream) {
+    if (!x || !w || !c_hi || !c_lo) return FS2_ERR_ARG;
+    GemmArgs a;
+    a.X = x; a.W = w; a.bias = bias; a.C = c_hi; a.C_lo = c_lo;
+    a.M = M; a.N = N; a.K = Cin; a.ldx = Cin; a.ldc = N;
+    a.Cin = Cin; a.taps = 1; a.pad = 0; a.S = M; a.relu = 0; a.split = split != 0;
+    return launch_gemm(a, FS2_F32, FS2_F32, (hipStream_t)stream);
 }
 
 int fs2_op_attention_train(int32_t dtype, const void* qkv, const uint8_t* key_pad_mask, void* out, void* vt_scratch,

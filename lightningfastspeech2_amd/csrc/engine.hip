@@ -66,6 +66,7 @@ struct ConvW {     // dense conv or pointwise: W (N, taps*Cin) in its side's dty
     float* b = nullptr;
     int N = 0, Cin = 0, taps = 1;
     int dt = FS2_F32;  // dtype of w and of the activations this layer reads
+    bool presplit = false;  // split-arithmetic modes: w holds bf16 heads + tails per 32-channel chunk (pack_presplit_weights), not fp32
 };
 struct DwW {       // depth-wise conv weights fp32 (C, k) + bias
     float* w = nullptr;
@@ -331,6 +332,18 @@ int upload_mat(fs2_engine* e, const float* h, size_t n, void** out, int dt) {
 const HostTensor& W(fs2_engine* e, const std::string& n) { return e->host.at(n); }
 
 // conv weight (N, Cin, k) -> (N, k*Cin) tap-major
+// GEMM weights of the split-arithmetic modes (FS2_F32_X3, the front of FS2_MIXED_X3): every launch of an fp32-weight layer splits each
+// value into a bf16 head and tail - a constant, so it is done here, once; same bytes as fp32.  Layers the slab kernel cannot take
+// (fewer than 192 output channels: the mel head, the CWT head) keep fp32 weights and the in-register split.
+int upload_gemm_w(fs2_engine* e, const float* h, int N, int K, ConvW* out, int dt) {
+    out->presplit = dt == FS2_F32 && e->front_split && gemm_presplit_eligible(N, K);
+    if (!out->presplit) return upload_mat(e, h, (size_t)N * K, &out->w, dt);
+    CHK(upload_f32(e, h, (size_t)N * K, (float**)&out->w));
+    if (launch_presplit_pack((const float*)out->w, out->w, (size_t)N * K, nullptr) != FS2_OK) return fail(e, FS2_ERR_HIP, "weight split launch failed");
+    HIPCHK(e, hipStreamSynchronize(nullptr));
+    return FS2_OK;
+}
+
 int make_conv(fs2_engine* e, const std::string& wname, const std::string& bname, ConvW* out, int dt) {
     out->dt = dt;
     const HostTensor& w = W(e, wname);
@@ -342,7 +355,7 @@ int make_conv(fs2_engine* e, const std::string& wname, const std::string& bname,
     out->N = N;
     out->Cin = Cin;
     out->taps = k;
-    CHK(upload_mat(e, packed.data(), packed.size(), &out->w, dt));
+    CHK(upload_gemm_w(e, packed.data(), N, Cin * k, out, dt));
     const HostTensor& b = W(e, bname);
     return upload_f32(e, b.data.data(), b.data.size(), &out->b);
 }
@@ -382,7 +395,7 @@ int make_folded_conv2(fs2_engine* e, const std::string& p, int H, int F, ConvW* 
     out->N = H;
     out->Cin = F;
     out->taps = 1;
-    CHK(upload_mat(e, Wf.data(), Wf.size(), &out->w, dt));
+    CHK(upload_gemm_w(e, Wf.data(), H, F, out, dt));
     return upload_f32(e, bf.data(), bf.size(), &out->b);
 }
 int up_vec(fs2_engine* e, const std::string& n, float** out) {
@@ -507,14 +520,17 @@ struct LnFuse {  // optional fused epilogue: y = LN(act(gemm) [+ res]) [-> head]
 };
 
 int gemm(fs2_engine* e, hipStream_t st, const ConvW& w, const void* x, void* c, int M, int S, bool relu, int out_dt,
-         const LnFuse* ln = nullptr, int extra_class = -1, const uint8_t* zero_rows = nullptr, const Deferred* df = nullptr) {
+         const LnFuse* ln = nullptr, int extra_class = -1, const uint8_t* zero_rows = nullptr, const Deferred* df = nullptr,
+         void* c_lo = nullptr) {
     GemmArgs a;
     a.zero_rows = zero_rows;
+    a.C_lo = c_lo;
     if (df) {
         a.epi_res = df->res; a.epi_res_stats = df->res_stats; a.epi_res_g = df->res_g; a.epi_res_b = df->res_b;
         a.epi_res_parts = ln_parts(w.N); a.stats_out = df->stats_out; a.ln_eps = 1e-5f;
     }
     a.split = e->front_split && w.dt == FS2_F32;
+    a.w_presplit = w.presplit;
     a.X = x;
     a.W = w.w;
     a.bias = w.b;
@@ -582,14 +598,20 @@ int conformer(fs2_engine* e, hipStream_t st, const LayerW& w, void* x, void* tmp
               const LayerScratch& sc, bool is_decoder) {
     const int H = e->cfg.hidden, M = B * S, dt = w.in_proj.dt;
     const double dsz = dt == FS2_BF16 ? 2 : 4;
-    CHK(gemm(e, st, w.in_proj, x, sc.qkv, M, M, false, dt));
+    // fp32 storage with the bf16 x 3 split products (FS2_F32_X3 / the front of FS2_MIXED_X3): the attention takes the split
+    // arithmetic too - the in-projection stores its fp32 result as bf16 head + tail (the same bytes, no extra pass), the attention
+    // multiplies them with three bf16 MFMAs per product and hands back fp32 rows (attention.hip, X3)
+    const bool x3 = e->front_split && dt == FS2_F32 && g_attn_x3;
+    void* qkv_lo = x3 ? (void*)((char*)sc.qkv + (size_t)M * 3 * H * 2) : nullptr;
+    CHK(gemm(e, st, w.in_proj, x, sc.qkv, M, M, false, dt, nullptr, -1, nullptr, nullptr, qkv_lo));
     AttnArgs a;
+    a.qkv_lo = qkv_lo;
     a.qkv = sc.qkv; a.vt = sc.vt; a.kbits = sc.bits; a.out = sc.att;
     a.B = B; a.S = S; a.H = H; a.heads = heads; a.Spad = sc.Spad; a.nw64 = sc.nw64;
     a.scale_log2e = (float)(1.4426950408889634 / sqrt((double)(H / heads)));
     {
         Bracket br(e, FS2_K_ROWOPS, st, 0, 2.0 * M * H * dsz);
-        const int r = launch_transpose_v(a, dt, st);
+        const int r = x3 ? FS2_OK : launch_transpose_v(a, dt, st);  // (the split form reads V row-major, like the bf16 one)
         if (r != FS2_OK) return fail(e, r, "transpose_v launch failed");
     }
     {

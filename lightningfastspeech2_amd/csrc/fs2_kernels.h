@@ -12,6 +12,8 @@ struct GemmArgs {
     const void* W;      // (N, K) weights, K = taps*Cin (tap-major)
     const float* bias;  // (N) or null
     void* C;            // (M, ldc)
+    void* C_lo = nullptr;  // fp32 launches only: C and C_lo receive the result as TWO bf16 (M, ldc) tensors, head and tail (x = hi + lo up
+                           // to 2^-17 |x|) - the operands of the split-arithmetic attention (attention.hip, X3); slab kernel, plain epilogue
     int M, N, K;
     int ldx, ldc;
     int Cin, taps, pad;  // implicit conv: K index = tap*Cin + c, source row = m + tap - pad
@@ -42,6 +44,7 @@ struct GemmArgs {
     const float* epi_res_b = nullptr;
     int epi_res_parts = 0;
     float* stats_out = nullptr;
+    int w_presplit = 0;             // split launches: W is NOT fp32 but heads + tails, packed per 32-channel chunk by pack_presplit_weights (gemm_mfma.hip)
     int split = 0;                  // fp32 operands only: 1 = bf16 x 3 split arithmetic in the slab kernel (gemm_mfma.hip)
     const uint8_t* zero_rows = nullptr;  // (M) 1 = store zeros for this row (128x128 kernel only: the mel head)
     const void* gate = nullptr;     // slab kernel, plain epilogue: C = gate > 0 ? gate_scale * (acc + bias) : 0; gate has C's shape, ldc and dtype
@@ -52,6 +55,11 @@ struct GemmArgs {
                                     // blocks [s, s + 1) * Cin / ksplit of every tap into plane s of C (ksplit, M, ldc); launch_split_k_reduce adds them
 };
 int launch_gemm(const GemmArgs& a, int in_dtype, int out_dtype, hipStream_t stream);
+// fp32 (N, K) weights, K % 32 == 0 -> the split arithmetic's load-time format, same size: per row and 32-channel chunk (128 bytes)
+// 16-byte slot s < 4 = bf16 heads of channels [4s, 4s + 4) and [16 + 4s, 16 + 4s + 4) of the chunk, slot 4 + s = their tails
+// (x = hi + lo up to 2^-17 |x|; the values split_bf16x3 produces).  Once per weight tensor, at fs2_finalize.
+int launch_presplit_pack(const float* w, void* out, size_t n_values, hipStream_t stream);  // device side; out == w packs in place
+bool gemm_presplit_eligible(int N, int K);
 // out (M, N) in out_dtype = [out +] sum over s of part[s] (fp32 planes of n = M * N elements, n % 4 == 0), fixed order
 int launch_split_k_reduce(const float* part, void* out, size_t n, int ksplit, int accumulate, int out_dtype, hipStream_t stream);
 // the split a long-K, few-tile GEMM / conv is worth (1 = none): tools/bench_ops.py dgrad
@@ -72,6 +80,8 @@ struct AttnArgs {
     void* out;              // (B*S, H)
     int B, S, H, heads, Spad, nw64;
     float scale_log2e;      // log2(e) / sqrt(d)
+    const void* qkv_lo = nullptr;  // split arithmetic (attention_kernel<.., X3>): qkv = the bf16 heads, qkv_lo = the bf16 tails of the fp32
+                                   // (B*S, 3H) tensor, out = fp32 rows
     // training path: per-query log-sum-exp in log2 units of the scaled scores (lse2 = m + log2(l); P = exp2(s - lse2)) for the
     // recomputing backward, and the attention-weight dropout of nn.MultiheadAttention (mask over the (b, head, q, key) index)
     float* lse2 = nullptr;  // (B, heads, S) or null
@@ -96,6 +106,7 @@ bool attention_bwd_supported(int dtype, int H, int heads);
 void attention_bwd_set_blocks(int which, int nb);  // A/B knob: 16-row blocks per wave (1 or 2) of the dK,dV (which = 0) / dQ (1) launch
 int launch_attention_bwd(const AttnBwdArgs& a, int dtype, hipStream_t stream);
 int launch_transpose_v(const AttnArgs& a, int dtype, hipStream_t stream);  // fills a.vt from a.qkv
+int launch_split_hi_lo(const float* x, void* hi, void* lo, size_t n, hipStream_t stream);  // fp32 -> bf16 head + bf16 tail, n % 8 == 0
 int launch_attention(const AttnArgs& a, int dtype, hipStream_t stream);    // needs a.vt filled
 // attention_pipe.hip: the software-pipelined kernel for the MFMA-bound instance (bf16, head dim 128, no attention dropout)
 bool attention_pipe_supported(const AttnArgs& a, int dtype);
@@ -130,6 +141,7 @@ struct PredictorArgs {
     const float* be_pe = nullptr;    // (>= S, H) fp32 or null
     const float* be_spk = nullptr;   // (B, H) fp32 or null
 };
+extern int g_attn_x3;   // A/B knob (1500 / 1501): fp32-storage split modes with fp32-MFMA attention / the bf16 x 3 split attention (default)
 extern int g_slab_ring;  // A/B knob (210 / 211): the slab kernel's operand ring for pointwise launches on short tiles
 extern unsigned long long g_knob_gen;  // bumped by every accepted fs2_op_set_gemm_variant call; part of the hipGraph keys (capi_ops.hip)
 extern int g_pred_fuse_embed;  // A/B knob (1320 / 1321): the engine's frame-level variance encoders as the tail of their predictor launch

@@ -16,6 +16,8 @@
 // written to the other LDS buffer afterwards (one barrier per chunk).  MFMA operands are swapped
 // (W is the row operand) so each lane ends up with 4 consecutive n of one output row: the
 // epilogue is one 8/16-byte store per fragment.
+#include <string.h>
+
 #include "fs2_common.h"
 #include "fs2_kernels.h"
 
@@ -394,11 +396,12 @@ __device__ unsigned long long g_slab_stamps[4][8];
 // channels, 256 x 64 weight tile), NST - 1 steps in flight, a COUNTED vmcnt per step (the builtin, so that hipcc's own LDS-DMA
 // scoreboard sees it) and the raw s_barrier (a __syncthreads() would drain every DMA in flight).  The slabs of this mode hold
 // the tile's rows only (no conv halo), so 4 stages fit at 32-row tiles (160 KiB) and 3 at 64 / 128 rows.
-template <typename T, typename OutT, int MI, bool LN, bool WIDE = false, bool SPLIT = false, bool DEFER = false, int NST = 2>
+template <typename T, typename OutT, int MI, bool LN, bool WIDE = false, bool SPLIT = false, bool DEFER = false, int NST = 2, bool XPRE = false>
 __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
+    static_assert(!XPRE || SPLIT, "XPRE: the split arithmetic's conv form (activation slab split in place when it lands)");
     static_assert(!SPLIT || sizeof(T) == 4, "the split arithmetic takes fp32 operands");
     static_assert(!(DEFER && LN), "deferred LayerNorm is what a launch WITHOUT the fused epilogue leaves behind");
-    static_assert(NST >= 2 && NST <= 4 && !(NST > 2 && WIDE), "operand ring: 2 (two-stage loop), 3 or 4 stages");
+    static_assert(NST >= 2 && NST <= 4 && !(NST > 2 && (WIDE || SPLIT)), "operand ring: 2 (two-stage loop), 3 or 4 stages");
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-resource builtins only exist in the device pass
     using Cfg = SlabCfg<MI>;
     constexpr int BMs = Cfg::BM;
@@ -516,21 +519,47 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
             woff[i][ks] = wrow * ROWB + (((ks * 4 + fg) ^ wswz(wrow)) << 4);
         }
 
+    // SPLIT: the weights ARRIVE as heads + tails (slot fg of a row's 128-byte chunk = the bf16 heads of lane group fg's eight k-values,
+    // slot 4 + fg their tails: presplit_pack_kernel, once per weight tensor); the activations are fp32 and are split either in
+    // registers as a fragment is read (pointwise launches) or - XPRE, conv launches - in place when the slab lands (split_rows
+    // below: once per element instead of once per column wave and tap).
     auto compute = [&](const unsigned char* sl, const unsigned char* wt, int tap) {
         if constexpr (SPLIT) {
             // both 16-byte chunks of the step = 8 k-values per lane = the k-group one bf16 16x16x32 MFMA takes from it
             uint4 wh[4], wl[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) split_bf16x3(*(const uint4*)(wt + woff[i][0]), *(const uint4*)(wt + woff[i][1]), wh[i], wl[i]);
+            for (int i = 0; i < 4; ++i) { wh[i] = *(const uint4*)(wt + woff[i][0]); wl[i] = *(const uint4*)(wt + woff[i][1]); }
+            if constexpr (XPRE) {
+                // no VALU between the fragment reads and the MFMAs: left alone hipcc hoists all 2 MI reads to the top (64 more live
+                // registers next to 128 accumulators) - one row block ahead, pinned
+                uint4 xh[2], xl[2];
+                xh[0] = *(const uint4*)(sl + swz(xrow0 + tap, fg));
+                xl[0] = *(const uint4*)(sl + swz(xrow0 + tap, 4 + fg));
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                uint4 xh, xl;
-                split_bf16x3(*(const uint4*)(sl + swz(xrow0 + mi * 16 + tap, fg)), *(const uint4*)(sl + swz(xrow0 + mi * 16 + tap, 4 + fg)), xh, xl);
+                for (int mi = 0; mi < MI; ++mi) {
+                    if (mi + 1 < MI) {
+                        xh[(mi + 1) & 1] = *(const uint4*)(sl + swz(xrow0 + (mi + 1) * 16 + tap, fg));
+                        xl[(mi + 1) & 1] = *(const uint4*)(sl + swz(xrow0 + (mi + 1) * 16 + tap, 4 + fg));
+                    }
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni) {
-                    Mma16<bf16>::step(wl[ni], xh, acc[ni][mi]);  // small terms first
-                    Mma16<bf16>::step(wh[ni], xl, acc[ni][mi]);
-                    Mma16<bf16>::step(wh[ni], xh, acc[ni][mi]);
+                    for (int ni = 0; ni < 4; ++ni) {
+                        Mma16<bf16>::step(wl[ni], xh[mi & 1], acc[ni][mi]);  // small terms first
+                        Mma16<bf16>::step(wh[ni], xl[mi & 1], acc[ni][mi]);
+                        Mma16<bf16>::step(wh[ni], xh[mi & 1], acc[ni][mi]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    uint4 xh, xl;
+                    split_bf16x3(*(const uint4*)(sl + swz(xrow0 + mi * 16 + tap, fg)), *(const uint4*)(sl + swz(xrow0 + mi * 16 + tap, 4 + fg)), xh, xl);
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) {
+                        Mma16<bf16>::step(wl[ni], xh, acc[ni][mi]);  // small terms first
+                        Mma16<bf16>::step(wh[ni], xl, acc[ni][mi]);
+                        Mma16<bf16>::step(wh[ni], xh, acc[ni][mi]);
+                    }
                 }
             }
         } else {
@@ -549,6 +578,24 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
         }
     };
 
+    // SPLIT, conv launches: head / tail split of a landed fp32 activation slab, in place, ONCE per element: the pair of 16-byte slots
+    // (s, 4 + s) of a row - the eight k-values lane group s feeds one bf16 MFMA - becomes (heads, tails).  Until r04 every wave split
+    // every fragment it read: a weight value twice (2 row waves), an activation four times (4 column waves) and again at every conv
+    // tap - (4 + MI) x ~24 VALU instructions per wave and step next to 12 MI MFMAs; the decoder conv1 ran 3.7x its bf16 launch.
+    // Same arithmetic per element (split_bf16x3): bit-identical results.  (Splitting the weight tile in LDS as well - one more
+    // barrier per step - measured slower on every pointwise launch: the weights are split once at load time instead.)
+    auto split_rows = [&](unsigned char* buf, int nrows) {
+        for (int i = tid; i < nrows * 4; i += 512) {
+            const int row = i >> 2, sl4 = i & 3;
+            const int x = row & 7;
+            unsigned char* a0 = buf + row * ROWB + ((sl4 ^ x) << 4);
+            unsigned char* a1 = buf + row * ROWB + (((4 + sl4) ^ x) << 4);
+            uint4 h, l;
+            split_bf16x3(*(const uint4*)a0, *(const uint4*)a1, h, l);
+            *(uint4*)a0 = h;
+            *(uint4*)a1 = l;
+        }
+    };
     // Step (cc, tap) uses slab[cc & 1] and wt[(cc*ntap + tap) & 1]; ntap is odd (the launcher checks),
     // so the weight parity is (cc + tap) & 1.  The steps are laid out as straight-line code with
     // STATIC buffer names (no pointer selects: hipcc then knows which LDS object each ds_read
@@ -561,6 +608,12 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
         if (ntp == ntap) { ntp = 0; ++ncb; }                                                \
         if (ncb < ncc) issue_w(w_nxt, ncb, ntp);                                            \
         if ((tapv) == 0 && (ccv) + 1 < ncc) issue_slab(slab_nxt, (ccv) + 1);                \
+        if constexpr (XPRE) {                                                               \
+            if ((tapv) == 0) {                                                              \
+                split_rows(slab_cur, BMs + ntap - 1);                                       \
+                __syncthreads();                                                            \
+            }                                                                               \
+        }                                                                                   \
         compute(slab_cur, w_cur, (tapv));                                                   \
     }
     float ws1[WIDE ? MI : 1], ws2[WIDE ? MI : 1];  // WIDE: this lane's share of sum(v), sum(v^2) per row, over all tiles
@@ -1175,6 +1228,29 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
                     for (int r = 0; r < 8; ++r) v[r] = (n + r < p.N && Num<OutT>::to_f32(gt[r]) > 0.f) ? v[r] * p.gate_scale : 0.f;
                 }
             }
+            if constexpr (sizeof(OutT) == 4) {
+                if (p.C_lo) {  // the fp32 result as two bf16 tensors, head + tail (the split-arithmetic attention's operands): same bytes
+                    const size_t off = ((size_t)ub * S + t) * p.ldc + n;
+                    uint4 hq, lq;
+                    split_bf16x3(make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])),
+                                 make_uint4(__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])), hq, lq);
+                    bf16* dh = (bf16*)p.C + off;
+                    bf16* dl = (bf16*)p.C_lo + off;
+                    if (decltype(full_c)::value || n + 7 < p.N) {
+                        *(uint4*)dh = hq;
+                        *(uint4*)dl = lq;
+                    } else {
+                        const unsigned hw[4] = {hq.x, hq.y, hq.z, hq.w}, lw[4] = {lq.x, lq.y, lq.z, lq.w};
+#pragma unroll
+                        for (int r = 0; r < 8; ++r)
+                            if (n + r < p.N) {
+                                ((unsigned short*)dh)[r] = (unsigned short)(hw[r >> 1] >> (16 * (r & 1)));
+                                ((unsigned short*)dl)[r] = (unsigned short)(lw[r >> 1] >> (16 * (r & 1)));
+                            }
+                    }
+                    continue;
+                }
+            }
             OutT* dst = (OutT*)((char*)C + (unsigned)(t * p.ldc + n) * (unsigned)sizeof(OutT));  // one utterance < 4 GiB
             if (decltype(full_c)::value || n + 7 < p.N) {
                 if constexpr (sizeof(OutT) == 4) {
@@ -1312,6 +1388,16 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
 
 template <typename T, typename OutT, int MI, bool LN, bool WIDE = false, bool SPLIT = false, bool DEFER = false, int NST = 2>
 static int launch_slab_t(const GemmArgs& a0, hipStream_t stream) {
+    if constexpr (SPLIT && NST == 2) {  // conv launches of the split arithmetic: the slab is split in place when it lands
+        if (a0.taps > 1) {
+            GemmArgs a = a0;
+            a.xcd_remap = g_slab_xcd_remap;
+            const int BMs = SlabCfg<MI>::BM;
+            const int tiles = (a.M / a.S) * ((a.S + BMs - 1) / BMs) * (WIDE ? 1 : (a.N + S_BN - 1) / S_BN) * (a.ksplit > 1 ? a.ksplit : 1);
+            hipLaunchKernelGGL((gemm_conv_slab_kernel<T, OutT, MI, LN, WIDE, SPLIT, DEFER, NST, true>), dim3(tiles), dim3(512), 0, stream, a);
+            return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
+        }
+    }
     GemmArgs a = a0;
     if (a.taps == 1) a.S = a.M;  // plain GEMM: one "utterance" of M rows
     a.xcd_remap = g_slab_xcd_remap;
@@ -1321,24 +1407,47 @@ static int launch_slab_t(const GemmArgs& a0, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
 }
 
-extern int g_split_f32;
+int g_split_f32 = 0;  // test knob: every fp32 slab launch in the bf16 x 3 split arithmetic
 int g_slab_ring = 0;  // A/B knob (210 / 211): pointwise launches on 32- / 64- / 128-row tiles through the 4- / 4- / 3-stage operand ring.
                       // OFF: measured neutral (tools/bench_ops.py ln / gemm --flush 48, r04: enc conv2 + LN 19.9 -> 21.6 us, conv2 plain 18.4 ->
                       // 15.9, in-proj 12.9 -> 12.9) - these launches are bound by what a CU ingests per second, not by a step's round trip
+// Split launches whose caller holds plain fp32 weights (the operator-level entry points, knob 501: tests): packed on the fly into a
+// process-wide grow-only buffer.  The engine never comes here - it packs its weights once at fs2_finalize (GemmArgs::w_presplit).
+static int presplit_on_the_fly(GemmArgs& a, hipStream_t stream) {
+    static void* buf = nullptr;
+    static size_t cap = 0;
+    const size_t bytes = (size_t)a.N * a.K * 4;
+    if (bytes > cap) {
+        if (hipDeviceSynchronize() != hipSuccess) return FS2_ERR_HIP;  // an earlier launch may still read the old block
+        if (buf) (void)hipFree(buf);
+        buf = nullptr;
+        cap = 0;
+        if (hipMalloc(&buf, bytes + bytes / 4) != hipSuccess) return FS2_ERR_NOMEM;
+        cap = bytes + bytes / 4;
+    }
+    const int r = launch_presplit_pack((const float*)a.W, buf, (size_t)a.N * a.K, stream);
+    a.W = buf;
+    a.w_presplit = 1;
+    return r;
+}
+
 template <int MI>
-static int launch_slab(const GemmArgs& a, int in_dtype, int out_dtype, hipStream_t stream) {
+static int launch_slab(const GemmArgs& a_in, int in_dtype, int out_dtype, hipStream_t stream) {
+    GemmArgs a = a_in;
+    if (in_dtype == FS2_F32 && out_dtype == FS2_F32 && (a.split || g_split_f32) && !a.w_presplit) {
+        const int r = presplit_on_the_fly(a, stream);
+        if (r != FS2_OK) return r;
+    }
     if constexpr (MI <= 4) {
         // short steps, long round trips: the operand ring (see the kernel).  Same MFMA order per element: bit-identical results.
         constexpr int R = MI == 4 ? 3 : 4;
         if (g_slab_ring && a.taps == 1 && a.ksplit <= 1 && !a.stats_out && !a.epi_res && (!a.ln_g || a.N <= S_BN) && in_dtype == out_dtype) {
             const bool sp = a.split || g_split_f32;
             if (a.ln_g) {
-                if (in_dtype == FS2_F32) return sp ? launch_slab_t<float, float, MI, true, false, true, false, R>(a, stream)
-                                                   : launch_slab_t<float, float, MI, true, false, false, false, R>(a, stream);
+                if (in_dtype == FS2_F32 && !sp) return launch_slab_t<float, float, MI, true, false, false, false, R>(a, stream);
                 if (in_dtype == FS2_BF16) return launch_slab_t<bf16, bf16, MI, true, false, false, false, R>(a, stream);
             } else {
-                if (in_dtype == FS2_F32) return sp ? launch_slab_t<float, float, MI, false, false, true, false, R>(a, stream)
-                                                   : launch_slab_t<float, float, MI, false, false, false, false, R>(a, stream);
+                if (in_dtype == FS2_F32 && !sp) return launch_slab_t<float, float, MI, false, false, false, false, R>(a, stream);
                 if (in_dtype == FS2_BF16) return launch_slab_t<bf16, bf16, MI, false, false, false, false, R>(a, stream);
             }
         }
@@ -1388,7 +1497,6 @@ static int launch_t(const GemmArgs& a, hipStream_t stream) {
 
 int g_gemm_variant = 0;
 unsigned long long g_knob_gen = 0;  // bumped by every accepted fs2_op_set_gemm_variant call; part of the hipGraph keys
-int g_split_f32 = 0;  // test knob: every fp32 slab launch in the bf16 x 3 split arithmetic
 int g_slab_xcd_remap = 1;
 // 1 = rows wider than 256 by the in-place WIDE epilogue, 0 = GEMM launch + stand-alone LayerNorm launch.  Measured on
 // MI355X (tools/bench_ops.py wide, r02): the WIDE form only ties at M = 49152, K = 768 (118 vs 120 us) and LOSES
@@ -1455,6 +1563,11 @@ static int launch_gemm_plain(const GemmArgs& a, int in_dtype, int out_dtype, hip
                                          // 3/4/5 = slab kernel with 128/192/256-row tiles
     const bool slab_ok = a.M % a.S == 0 && (a.taps & 1);
     const int ksp = a.ksplit > 1 ? a.ksplit : 1;
+    if (a.w_presplit && (!(a.split || g_split_f32) || variant != 0 || !slab_ok || a.N < 192 || in_dtype != FS2_F32 || a.ksplit > 1 || a.zero_rows))
+        return FS2_ERR_SHAPE;  // weights packed as heads + tails are the slab kernel's split arithmetic's own format
+    if (a.C_lo && (fused || a.gate || a.stats_out || a.epi_res || a.zero_rows || a.ksplit > 1 || a.drop_p > 0.f || variant != 0 || !slab_ok ||
+                   a.N < 192 || in_dtype != FS2_F32 || out_dtype != FS2_F32))
+        return FS2_ERR_SHAPE;  // the head + tail store lives in the slab kernel's plain fp32 epilogue only
     if (ksp > 1 && (fused || a.bias || a.relu || a.gate || a.stats_out || a.epi_res || a.zero_rows || out_dtype != FS2_F32 || !slab_ok ||
                     a.N < 192 || (a.Cin / ke) % ksp || (variant != 0 && (variant < 3 || variant > 7))))
         return FS2_ERR_SHAPE;  // split-K: the slab kernel's plain fp32 store only
@@ -1501,7 +1614,7 @@ static int launch_gemm_plain(const GemmArgs& a, int in_dtype, int out_dtype, hip
             if (a.K / ksp >= 4096 && !wide) cost = cost > tiles ? cost : tiles;
             if (!best || cost < best_cost) { best = mi; best_cost = cost; best_rows = (long)nutt * tm * bm; }
         }
-        if (best_rows <= 2L * a.M) {
+        if (best_rows <= 2L * a.M || a.C_lo || a.w_presplit) {  // (the head + tail store / pre-split weights exist in this kernel only)
             if (fused) *fused = true;
             if (best == 1) return launch_slab<1>(a, in_dtype, out_dtype, stream);
             if (best == 2) return launch_slab<2>(a, in_dtype, out_dtype, stream);
@@ -1516,6 +1629,29 @@ static int launch_gemm_plain(const GemmArgs& a, int in_dtype, int out_dtype, hip
     if (in_dtype == FS2_BF16 && out_dtype == FS2_BF16) return launch_t<bf16, bf16>(a, stream);
     if (in_dtype == FS2_BF16 && out_dtype == FS2_F32) return launch_t<bf16, float>(a, stream);
     return FS2_ERR_SHAPE;
+}
+
+bool gemm_presplit_eligible(int N, int K) { return N >= 192 && K % 32 == 0; }
+
+// fp32 (N, K) weights -> the split arithmetic's operand format, same size, in place or into `out`: per 32-channel chunk (128 bytes)
+// 16-byte slot s < 4 = the bf16 heads of channels [4s, 4s + 4) and [16 + 4s, 16 + 4s + 4), slot 4 + s = their tails
+__global__ __launch_bounds__(256) void presplit_pack_kernel(const float* w, unsigned char* out, size_t npairs) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npairs) return;
+    const size_t chunk = i >> 2;
+    const int sl = (int)(i & 3);
+    const uint4 c0 = *(const uint4*)(w + chunk * 32 + 4 * sl), c1 = *(const uint4*)(w + chunk * 32 + 16 + 4 * sl);
+    uint4 h, l;
+    split_bf16x3(c0, c1, h, l);
+    *(uint4*)(out + chunk * 128 + sl * 16) = h;        // (in place: a thread writes the two slots it has read)
+    *(uint4*)(out + chunk * 128 + (4 + sl) * 16) = l;
+}
+int launch_presplit_pack(const float* w, void* out, size_t n_values, hipStream_t stream) {
+    if (n_values % 32) return FS2_ERR_SHAPE;
+    if (!n_values) return FS2_OK;
+    const size_t np = n_values / 8;
+    hipLaunchKernelGGL(presplit_pack_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, stream, w, (unsigned char*)out, np);
+    return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
 }
 
 // ---- split-K: planes -> output ----------------------------------------------------------------------------------------------

@@ -133,6 +133,30 @@ def attention(dtype, qkv, key_pad_mask, B, S, H, heads):
     return out.float().cpu()
 
 
+def attention_x3(qkv, key_pad_mask, B, S, H, heads):
+    """fs2_op_attention_x3: fp32 qkv, bf16 x 3 split products, fp32 out."""
+    qd = torch.as_tensor(qkv).float().to(DEV).contiguous()
+    md = torch.as_tensor(key_pad_mask).to(torch.uint8).to(DEV).contiguous()
+    out = torch.empty(B * S, H, dtype=torch.float32, device=DEV)
+    split = torch.empty(2 * B * S * 3 * H, dtype=torch.bfloat16, device=DEV)
+    bits = torch.empty(B * ((S + 63) // 64) * 8, dtype=torch.uint8, device=DEV)
+    ok(lib().fs2_op_attention_x3(p(qd), p(md), p(out), p(split), p(bits), B, S, H, heads, stream()), "attention_x3")
+    torch.cuda.synchronize()
+    return out.cpu()
+
+
+def gemm_split_out(x, w, bias, split=True):
+    M, K = x.shape
+    N = w.shape[0]
+    xd, wd = torch.as_tensor(x).float().to(DEV).contiguous(), torch.as_tensor(w).float().to(DEV).contiguous()
+    bd = None if bias is None else torch.as_tensor(bias).float().to(DEV)
+    hi = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    lo = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ok(lib().fs2_op_gemm_split_out(p(xd), p(wd), p(bd), p(hi), p(lo), M, N, K, int(split), stream()), "gemm_split_out")
+    torch.cuda.synchronize()
+    return hi.float().cpu(), lo.float().cpu()
+
+
 def layernorm(dtype, x, res, gamma, beta, dot_w=None, dot_b=0.0, mask=None, want_y=True):
     M, H = x.shape
     xd = to_dev(x, dtype)

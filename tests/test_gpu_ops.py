@@ -453,6 +453,61 @@ def test_attention(dtype, B, S, H, heads, mask_kind):
     assert err <= tol(dtype, ref, f32=5e-5, bf16=2e-2), (err, tol(dtype, ref))
 
 
+@pytest.mark.parametrize("B,S,H,heads,mask_kind", [
+    (2, 40, 64, 2, "suffix"), (3, 130, 128, 2, "suffix"), (2, 200, 256, 2, "suffix"), (2, 64, 256, 2, "none"),
+    (2, 257, 256, 2, "scatter"), (1, 700, 256, 2, "suffix"), (2, 33, 128, 4, "scatter"), (4, 1536, 256, 2, "none")])
+def test_attention_split_bf16x3(B, S, H, heads, mask_kind):
+    """attention_kernel<bf16, .., X3> (r04): q, k, v as bf16 head + tail of the fp32 values, three bf16 MFMAs per q.k and p.v
+    product, fp32 softmax / accumulators / output - the attention of the fp32x3 and mixed3 modes.  Against the fp64 reference it
+    must sit where the fp32-MFMA kernel sits (bar 5e-5 of the output scale, the fp32 kernel's own), 400x inside the bf16 kernel's."""
+    qkv = rnd(B * S, 3 * H, seed=10)
+    mask = torch.zeros(B, S, dtype=torch.bool)
+    if mask_kind == "suffix":
+        for b in range(B):
+            mask[b, S - (7 + 13 * b) % S:] = True
+        mask[0, :] = False
+        mask[0, S - S // 2:] = True
+    elif mask_kind == "scatter":
+        g = torch.Generator().manual_seed(11)
+        mask = torch.rand(B, S, generator=g) < 0.3
+        mask[:, 0] = False
+    ref = _attn_ref(qkv.double(), mask, B, S, H, heads).float()
+    got = G.attention_x3(qkv, mask, B, S, H, heads)
+    again = G.attention_x3(qkv, mask, B, S, H, heads)
+    assert torch.equal(got, again)
+    err = float((got - ref).abs().max())
+    assert err <= 5e-5 * max(1.0, float(ref.abs().max())), (err, float(ref.abs().max()))
+
+
+def test_attention_split_bf16x3_spike():
+    B, S, H, heads = 1, 256, 256, 2
+    qkv = rnd(B * S, 3 * H, seed=12)
+    qkv[200, H:H + 128] = 6.0 * qkv[5, :128]  # a late, dominant key: the deferred rescale fires
+    mask = torch.zeros(B, S, dtype=torch.bool)
+    ref = _attn_ref(qkv.double(), mask, B, S, H, heads).float()
+    got = G.attention_x3(qkv, mask, B, S, H, heads)
+    assert float((got - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 768, 256), (1, 192, 64), (33, 200, 96), (8192, 768, 256)])
+@pytest.mark.parametrize("split", [True, False])
+def test_gemm_head_tail_store(M, N, K, split):
+    """GemmArgs::C_lo (r04): the fp32 in-projection leaves as two bf16 tensors, head + tail, hi + lo == the fp32 result up to
+    2^-17 - and hi is the RNE bf16 of it, so the pair is exactly what split_bf16x3 would make of the fp32 tensor."""
+    x, w, b = rnd(M, K, seed=31), rnd(N, K, seed=32) / K ** 0.5, rnd(N, seed=33)
+    hi, lo = G.gemm_split_out(x, w, b, split)
+    try:
+        if split:
+            G.lib().fs2_op_set_gemm_variant(501)
+        full = G.gemm(G.F32, x, w, b)
+    finally:
+        G.lib().fs2_op_set_gemm_variant(500)
+    # (the fp32 launch may run on another tile shape / kernel than the head + tail store's, so the sums agree to fp32 rounding only)
+    tot = hi + lo
+    assert bool((lo.abs() <= 2.0 ** -8 * hi.abs() + 1e-38).all())   # the tail is at most half an ulp of the head: hi = RNE(value)
+    assert float((tot - full).abs().max()) <= (2.0 ** -16 + 2e-6) * float(full.abs().max())
+
+
 def test_attention_spike_forces_rescale():
     # one key dominates late in the sequence: the running max jumps at a late tile (rule 26)
     B, S, H, heads = 1, 256, 256, 2
