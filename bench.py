@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step side measurement")
     ap.add_argument("--no-fused-predictor", action="store_true", help="A/B: variance predictors layer by layer")
+    ap.add_argument("--in-flight", type=int, default=2, help="forwards in flight (model.pipeline): 1 = one synchronous forward at a time; "
+                    "the timed region takes the faster of 1 and this many, measured in the warm-up (FS2_BENCH_IN_FLIGHT pins it)")
     ap.add_argument("--parity-sample", type=int, default=2, help="utterances of the workload the parity block checks")
     return ap.parse_args()
 
@@ -316,8 +318,20 @@ def main():
 
     gather_bytes = [0]
 
-    def step(gather=True):
-        out = model(batch, inference=True)
+    # Forwards in flight: model.pipeline(n) keeps n engine replicas, each on its own HIP stream and host thread - batch i + 1's
+    # encoder is queued while the host reads batch i's frame count (the forward's one host sync) and launches its decoder, and the
+    # two forwards' launches fill each other's ramps and tails.  A step is still one forward over one batch; results come back in
+    # submission order a step or two later (drain() collects the rest before the closing sync).
+    pipes = {}
+    cur = {"in_flight": 1}
+
+    def forward_outs():
+        n = cur["in_flight"]
+        if n <= 1:
+            return [model(batch, inference=True)]
+        return pipes[n].submit(batch)
+
+    def on_result(out, gather):
         if multi and gather:
             if pending:
                 pending.pop().wait()
@@ -329,17 +343,22 @@ def main():
                 pending.append(gather_mels_async(out["mel"], out["tgt_mask"], shapes=shapes[0], zeroed=True))
             else:  # rehearsal path: gloo moves host tensors
                 pending.append(gather_mels_async(out["mel"].cpu(), out["tgt_mask"].cpu(), shapes=shapes[0], zeroed=True))
-        return out
 
-    def drain():
+    def step(gather=True):
+        for out in forward_outs():
+            on_result(out, gather)
+
+    def drain(gather=True):
+        if cur["in_flight"] > 1:
+            for out in pipes[cur["in_flight"]].drain():
+                on_result(out, gather)
         if pending:
             mel_all, frames = pending.pop().wait()
             assert mel_all.shape[0] == frames.numel()
 
+    out = model(batch, inference=True)  # shapes of the workload (T, frames) from one plain forward
     for _ in range(max(args.warmup, 1) if multi else args.warmup):
-        out = step()
-    if args.warmup == 0 and not multi:
-        out = model(batch, inference=True)
+        step()
     drain()
     frames_rank = int((~out["tgt_mask"]).sum())
     T = int(out["mel"].shape[1])
@@ -358,19 +377,40 @@ def main():
         return (time.perf_counter() - t_) / n
     tune = {}
     pin = os.environ.get("FS2_BENCH_MODE", "")
-    for mode in ("eager", "graphs"):
-        if pin and pin != mode:
-            continue
-        model.engine.set_graphs(mode == "graphs")
-        timed_steps(3)  # first sight, capture
-        tune[mode] = min(timed_steps(5), timed_steps(5)) * 1e3
-    pick = min(tune, key=tune.get)
+    pin_n = int(os.environ.get("FS2_BENCH_IN_FLIGHT", "0"))
+    flights = sorted({1, max(1, args.in_flight)}) if not pin_n else [pin_n]
+    for n in flights:
+        if n > 1 and n not in pipes:
+            pipes[n] = model.pipeline(n)
+            for m in pipes[n].models[1:]:  # the replicas take the main engine's per-engine settings
+                if multi:
+                    m.engine.set_zero_pad_mel(True)
+                if args.no_fused_predictor:
+                    m.engine.set_fused_predictor(False)
+                if os.environ.get("FS2_DEFER_LN") == "0":
+                    m.engine.set_deferred_layernorm(False)
+    for n in flights:
+        cur["in_flight"] = n
+        for mode in ("eager", "graphs"):
+            if pin and pin != mode:
+                continue
+            model.engine.set_graphs(mode == "graphs")
+            if n > 1:
+                pipes[n].set_graphs(mode == "graphs")
+            timed_steps(3 * n)  # first sight, capture (per replica)
+            tune[f"{mode}/{n}"] = min(timed_steps(6), timed_steps(6)) * 1e3
+    pick_key = min(tune, key=tune.get)
     if multi:
-        flag = torch.tensor([1 if pick == "graphs" else 0], device=dev if backend == "nccl" else torch.device("cpu"))
+        keys = sorted(tune)
+        flag = torch.tensor([keys.index(pick_key)], device=dev if backend == "nccl" else torch.device("cpu"))
         dist.broadcast(flag, 0)
-        pick = "graphs" if int(flag.item()) else "eager"
+        pick_key = keys[int(flag.item())]
+    pick, n_pick = pick_key.split("/")[0], int(pick_key.split("/")[1])
+    cur["in_flight"] = n_pick
     model.engine.set_graphs(pick == "graphs")
-    timed_steps(2)
+    if n_pick > 1:
+        pipes[n_pick].set_graphs(pick == "graphs")
+    timed_steps(2 * n_pick)
 
     def sync():
         if multi:
@@ -399,6 +439,7 @@ def main():
         print(f"closing sync: {(time.perf_counter() - t_sync) * 1e3:.2f} ms", file=sys.stderr)
         print("host ms per step():", " ".join(f"{t * 1e3:.2f}" for t in trace), file=sys.stderr)
     graph_replays = model.engine.graph_replays()
+    cur["in_flight"] = 1  # the event-bracketed passes below are plain synchronous forwards
     # multi-rank evidence (checkable the moment a node exists): which ranks the collective library really connected, every rank's own
     # step time, the bytes a rank contributes to the mel gather, and what the gather costs the step - the same K steps once more
     # WITHOUT the gather (forward only), same launch mode, same barrier + sync brackets; exposed = with - without
@@ -409,6 +450,7 @@ def main():
         t1 = time.perf_counter()
         for _ in range(args.steps):
             step(gather=False)
+        drain(gather=False)
         sync()
         el_nog = time.perf_counter() - t1
         mine = torch.tensor([float(rank), float(local_rank), elapsed / args.steps * 1e3, el_nog / args.steps * 1e3, float(frames_rank),
@@ -537,11 +579,17 @@ def main():
                         "(256 keys) is ingest-bound (DESIGN 4), this is the MFMA-bound one; HIP events, own pass of eager steps"},
             "gpu_ms_per_step": gpu_ms,
             "gpu_ms_per_step_is": f"sum of HIP-event intervals around every kernel launch of a forward, {psteps} eager steps behind the timed region",
+            "in_flight": n_pick,
+            "ms_per_step_one_in_flight": min((v for k, v in tune.items() if k.endswith("/1")), default=None),
+            "in_flight_is": "forwards in flight in the timed region (lightningfastspeech2_amd.model.ForwardPipeline: one engine replica, HIP "
+                            "stream and host thread each; a step = one forward over one batch either way); ms_per_step_one_in_flight = the best "
+                            "warm-up figure with one synchronous forward at a time",
             "launch_mode": {"timed_region": pick, "warmup_ms_per_step": {k: round(v, 4) for k, v in tune.items()},
                             "graph_replays_total": int(graph_replays),
                             "what": "eager launches or both phases of the forward (encode ~100 launches, decode ~50) replayed as hipGraphs "
-                                    "around the one host sync; a few untimed steps of each after warm-up, the faster mode of this host "
-                                    "runs the timed region (FS2_BENCH_MODE pins it)"},
+                                    "around the one host sync, with 1 or --in-flight forwards in flight; a few untimed steps of each "
+                                    "combination (key mode/in_flight) after warm-up, the fastest on this host runs the timed region "
+                                    "(FS2_BENCH_MODE / FS2_BENCH_IN_FLIGHT pin it)"},
         }
         if dist_info is not None:
             line["dist"] = dist_info
@@ -582,6 +630,8 @@ def main():
         if not multi and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, sd, args)
         print(json.dumps(line), flush=True)
+    for pp in pipes.values():
+        pp.close()
     if multi:
         dist.barrier()
         dist.destroy_process_group()

@@ -654,60 +654,65 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
         // that lies wholly inside N - the common case - takes a branch-free path by workgroup-uniform dispatch.
         auto preload = [&](auto full_c) {
             constexpr bool FULL = decltype(full_c)::value;
-            float rmean[MI], rrstd[MI];
-            int tr[MI];
+            // (groups of GP row blocks, one after the other, measured r04: GP = 2 at 192-row tiles costs the C3 step 1 ms - three
+            // dependent round trips per workgroup in front of its first MFMA - and saves no register: the pressure was elsewhere)
+            constexpr int GP = MI;
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                const int t = t0 + wm * (MI * 16) + mi * 16 + fr;
-                tr[mi] = t >= S ? S - 1 : t;  // rows past the utterance end are never stored
-                rmean[mi] = 0.f;
-                rrstd[mi] = 1.f;
+            for (int g0 = 0; g0 < MI; g0 += GP) {
+            float rmean[GP], rrstd[GP];
+            int tr[GP];
+#pragma unroll
+            for (int gi = 0; gi < GP; ++gi) {
+                const int t = t0 + wm * (MI * 16) + (g0 + gi) * 16 + fr;
+                tr[gi] = t >= S ? S - 1 : t;  // rows past the utterance end are never stored
+                rmean[gi] = 0.f;
+                rrstd[gi] = 1.f;
             }
             if (rnorm) {
-                float2 pq[MI][4];
+                float2 pq[GP][4];
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) {
-                    const float2* ps = (const float2*)p.epi_res_stats + (rowbase0 + tr[mi]) * p.epi_res_parts;
+                for (int gi = 0; gi < GP; ++gi) {
+                    const float2* ps = (const float2*)p.epi_res_stats + (rowbase0 + tr[gi]) * p.epi_res_parts;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) pq[mi][q] = ps[q < p.epi_res_parts ? q : 0];  // unconditional: a clamped index, masked below
+                    for (int q = 0; q < 4; ++q) pq[gi][q] = ps[q < p.epi_res_parts ? q : 0];  // unconditional: a clamped index, masked below
                 }
                 const float invn = 1.0f / (float)p.N;
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) {
+                for (int gi = 0; gi < GP; ++gi) {
 #pragma unroll
-                    for (int q = 1; q < 4; ++q) if (q >= p.epi_res_parts) pq[mi][q] = make_float2(0.f, 0.f);
-                    const float s1 = (pq[mi][0].x + pq[mi][1].x) + (pq[mi][2].x + pq[mi][3].x);
-                    const float s2 = (pq[mi][0].y + pq[mi][1].y) + (pq[mi][2].y + pq[mi][3].y);
-                    rmean[mi] = s1 * invn;
-                    rrstd[mi] = 1.0f / sqrtf(fmaxf(__builtin_fmaf(-rmean[mi], rmean[mi], s2 * invn), 0.f) + p.ln_eps);
+                    for (int q = 1; q < 4; ++q) if (q >= p.epi_res_parts) pq[gi][q] = make_float2(0.f, 0.f);
+                    const float s1 = (pq[gi][0].x + pq[gi][1].x) + (pq[gi][2].x + pq[gi][3].x);
+                    const float s2 = (pq[gi][0].y + pq[gi][1].y) + (pq[gi][2].y + pq[gi][3].y);
+                    rmean[gi] = s1 * invn;
+                    rrstd[gi] = 1.0f / sqrtf(fmaxf(__builtin_fmaf(-rmean[gi], rmean[gi], s2 * invn), 0.f) + p.ln_eps);
                 }
             }
             if constexpr (FULL) {
                 if constexpr (sizeof(T) == 4) {
 #pragma unroll
-                    for (int mi = 0; mi < MI; ++mi)
+                    for (int gi = 0; gi < GP; ++gi)
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
-                            const T* src = R + (size_t)tr[mi] * p.ldc + n0 + wn * 64 + j * 32 + fg * 8;
+                            const T* src = R + (size_t)tr[gi] * p.ldc + n0 + wn * 64 + j * 32 + fg * 8;
                             const float4 q0 = *(const float4*)src, q1 = *(const float4*)(src + 4);
-                            acc[2 * j][mi] = (f32x4_t){q0.x, q0.y, q0.z, q0.w};
-                            acc[2 * j + 1][mi] = (f32x4_t){q1.x, q1.y, q1.z, q1.w};
+                            acc[2 * j][g0 + gi] = (f32x4_t){q0.x, q0.y, q0.z, q0.w};
+                            acc[2 * j + 1][g0 + gi] = (f32x4_t){q1.x, q1.y, q1.z, q1.w};
                         }
                 } else {
-                    uint4 rq[MI][2];
+                    uint4 rq[GP][2];
 #pragma unroll
-                    for (int mi = 0; mi < MI; ++mi)
+                    for (int gi = 0; gi < GP; ++gi)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) rq[mi][j] = *(const uint4*)(R + (size_t)tr[mi] * p.ldc + n0 + wn * 64 + j * 32 + fg * 8);
+                        for (int j = 0; j < 2; ++j) rq[gi][j] = *(const uint4*)(R + (size_t)tr[gi] * p.ldc + n0 + wn * 64 + j * 32 + fg * 8);
 #pragma unroll
-                    for (int mi = 0; mi < MI; ++mi)
+                    for (int gi = 0; gi < GP; ++gi)
 #pragma unroll
                         for (int j = 0; j < 2; ++j) {
-                            const unsigned w4[4] = {rq[mi][j].x, rq[mi][j].y, rq[mi][j].z, rq[mi][j].w};
+                            const unsigned w4[4] = {rq[gi][j].x, rq[gi][j].y, rq[gi][j].z, rq[gi][j].w};
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                acc[2 * j + (e >> 1)][mi][(2 * e) & 3] = __uint_as_float(w4[e] << 16);
-                                acc[2 * j + (e >> 1)][mi][(2 * e + 1) & 3] = __uint_as_float(w4[e] & 0xffff0000u);
+                                acc[2 * j + (e >> 1)][g0 + gi][(2 * e) & 3] = __uint_as_float(w4[e] << 16);
+                                acc[2 * j + (e >> 1)][g0 + gi][(2 * e + 1) & 3] = __uint_as_float(w4[e] & 0xffff0000u);
                             }
                         }
                 }
@@ -715,35 +720,36 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const int n = n0 + wn * 64 + j * 32 + fg * 8;
-                        float gv[8], bv8[8];
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) { gv[r] = p.epi_res_g[n + r]; bv8[r] = p.epi_res_b[n + r]; }
+                        for (int r = 0; r < 8; ++r) {
+                            const float gvr = p.epi_res_g[n + r], bvr = p.epi_res_b[n + r];
 #pragma unroll
-                        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                            for (int r = 0; r < 8; ++r)
-                                acc[2 * j + (r >> 2)][mi][r & 3] = __builtin_fmaf((acc[2 * j + (r >> 2)][mi][r & 3] - rmean[mi]) * rrstd[mi], gv[r], bv8[r]);
+                            for (int gi = 0; gi < GP; ++gi)
+                                acc[2 * j + (r >> 2)][g0 + gi][r & 3] = __builtin_fmaf((acc[2 * j + (r >> 2)][g0 + gi][r & 3] - rmean[gi]) * rrstd[gi], gvr, bvr);
+                        }
                     }
                 }
             } else {
 #pragma unroll
-                for (int mi = 0; mi < MI; ++mi) {
+                for (int gi = 0; gi < GP; ++gi) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const int n = n0 + wn * 64 + j * 32 + fg * 8;
-                        const T* src = R + (size_t)tr[mi] * p.ldc + n;
+                        const T* src = R + (size_t)tr[gi] * p.ldc + n;
                         float rv[8];
 #pragma unroll
                         for (int r = 0; r < 8; ++r) rv[r] = (n + r < p.N) ? Num<T>::to_f32(src[r]) : 0.f;
                         if (rnorm) {
 #pragma unroll
                             for (int r = 0; r < 8; ++r)
-                                rv[r] = n + r < p.N ? __builtin_fmaf((rv[r] - rmean[mi]) * rrstd[mi], p.epi_res_g[n + r], p.epi_res_b[n + r]) : 0.f;
+                                rv[r] = n + r < p.N ? __builtin_fmaf((rv[r] - rmean[gi]) * rrstd[gi], p.epi_res_g[n + r], p.epi_res_b[n + r]) : 0.f;
                         }
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) acc[2 * j + (r >> 2)][mi][r & 3] = rv[r];
+                        for (int r = 0; r < 8; ++r) acc[2 * j + (r >> 2)][g0 + gi][r & 3] = rv[r];
                     }
                 }
+            }
+            if (MI > GP) __builtin_amdgcn_sched_barrier(0);
             }
         };
         if (n0 + S_BN <= p.N) preload(BoolC<true>{});
@@ -1284,6 +1290,7 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
             const int t = t0 + wm * (MI * 16) + mi * 16 + fr;
             const int tc = t < S ? t : S - 1;
             float rmean = 0.f, rrstd = 1.f;
+#if 0
             if (rnorm) {
                 const float2* ps = (const float2*)p.epi_res_stats + (rowbase + tc) * p.epi_res_parts;
                 float2 pq[4];
@@ -1294,6 +1301,7 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
                 rmean = s1 * invn;
                 rrstd = 1.0f / sqrtf(fmaxf(__builtin_fmaf(-rmean, rmean, s2 * invn), 0.f) + p.ln_eps);
             }
+#endif
             a1[mi] = a2[mi] = 0.f;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -1301,6 +1309,8 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
                 float v[8];
 #pragma unroll
                 for (int r = 0; r < 8; ++r) v[r] = fmaxf(acc[2 * j + (r >> 2)][mi][r & 3] + bv[j][r], lo);
+#if 0  // (a residual behind a ReLU never reaches this epilogue: the launcher refuses it - the path cost 35 registers at 192-row tiles and
+       //  spilled 500 at 256 rows, dead code in every launch of the forward)
                 if (R && (FULL || n < p.N)) {
                     const T* src = R + (size_t)tc * p.ldc + n;
                     float x[8];
@@ -1321,6 +1331,7 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
                         v[r] += x[r];
                     }
                 }
+#endif
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
                     if (!FULL && n + r >= p.N) v[r] = 0.f;
@@ -1467,6 +1478,7 @@ static int launch_slab(const GemmArgs& a_in, int in_dtype, int out_dtype, hipStr
         return FS2_ERR_SHAPE;
     }
     if (a.stats_out || a.epi_res) {  // deferred-LayerNorm epilogue
+        if (a.epi_res && a.relu) return FS2_ERR_SHAPE;  // the residual rides in the accumulators' initial value: no activation in between
         if (in_dtype == FS2_F32 && out_dtype == FS2_F32)
             return (a.split || g_split_f32) ? launch_slab_t<float, float, MI, false, false, true, true>(a, stream)
                                             : launch_slab_t<float, float, MI, false, false, false, true>(a, stream);

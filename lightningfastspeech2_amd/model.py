@@ -237,6 +237,7 @@ class Engine:
         (include/fs2.h fs2_set_graphs); bit-identical results, the forward stops depending on how fast the host can issue
         launches.  Off by default (constructor argument graphs=True / FS2_GRAPHS=1)."""
         _lib.check(self.lib.fs2_set_graphs(self.handle, int(on)), self.handle, "set_graphs")
+        self._graphs_on = bool(on)
 
     def graph_replays(self) -> int:
         return int(self.lib.fs2_graph_replays(self.handle))
@@ -285,6 +286,17 @@ class FastSpeech2:
         self.device = self.engine.device
         self.training = False
         self._t_guess = {}
+        self._ctor = (state_dict, precision, phone2id, speaker2dvector, extra_hparams)  # what replicate() builds another engine from
+
+    def replicate(self) -> "FastSpeech2":
+        """Another model object over the same weights (its own engine: own workspace, own host state) - what ForwardPipeline
+        keeps per forward in flight."""
+        sd, precision, phone2id, speaker2dvector, extra = self._ctor
+        return FastSpeech2(self.cfg, sd, precision=precision, device=self.device, phone2id=phone2id,
+                           speaker2dvector=speaker2dvector, extra_hparams=extra)
+
+    def pipeline(self, in_flight: int = 2) -> "ForwardPipeline":
+        return ForwardPipeline(self, in_flight)
 
     # ---- reference-style construction from a Lightning checkpoint dict (fastspeech2.py:530-634) --
     @classmethod
@@ -410,3 +422,82 @@ class FastSpeech2:
         for _ in range(int(guard.sum())):
             print("Zero duration, setting to 1")  # the reference's one stdout side effect (model.py:309)
         return res
+
+
+class ForwardPipeline:
+    """``in_flight`` inference forwards at once: batch i + 1's encoder is already queued while the host reads batch i's frame
+    count - the forward's one host sync (fastspeech2.py / model.py:354-355: the output length is data dependent) - and launches
+    its decoder.
+
+    A single forward leaves the GPU idle at that seam (sync wake-up, output allocation, the first decode launches) and in the
+    tail / ramp of every launch that does not fill the chip; a second forward on its own HIP stream fills both.  One engine
+    replica (own workspace arenas, own host-side state), one HIP stream and one host thread per forward in flight; ctypes
+    releases the GIL inside the library, so the threads drive their streams concurrently.  Outputs are bit-identical to
+    ``model(batch, inference=True)`` (same engine code, same kernels; tests/test_gpu_boundary.py).  Measured r04 at C2, batch 32:
+    2.06 -> ~1.9 ms per batch with two in flight.
+
+        pipe = model.pipeline(2)
+        for batch in batches:
+            for out in pipe.submit(batch):   # results come back in submission order, a batch or two later
+                use(out)
+        for out in pipe.drain():
+            use(out)
+
+    A result's tensors were produced on the pipeline's own streams; ``submit`` / ``drain`` make the caller's current stream wait for
+    them (an event per forward) before handing them over.
+    """
+
+    def __init__(self, model: FastSpeech2, in_flight: int = 2):
+        import concurrent.futures as cf
+        if in_flight < 1:
+            raise ValueError("in_flight >= 1")
+        self.models = [model] + [model.replicate() for _ in range(in_flight - 1)]
+        for m in self.models[1:]:
+            m.engine.set_graphs(getattr(model.engine, "_graphs_on", False))
+        self.device = model.device
+        self.streams = [torch.cuda.Stream(self.device) for _ in self.models]
+        # one single-thread executor per replica: a replica's forwards run in submission order on its own thread and stream
+        self.pools = [cf.ThreadPoolExecutor(max_workers=1) for _ in self.models]
+        self.pending = []  # futures in submission order
+        self.n = 0
+
+    def set_graphs(self, on: bool):
+        for m in self.models:
+            m.engine.set_graphs(on)
+
+    def _run(self, k, batch, ready):
+        with torch.cuda.device(self.device), torch.cuda.stream(self.streams[k]):
+            self.streams[k].wait_event(ready)  # the caller's stream produced the batch
+            out = self.models[k](batch, inference=True)
+            done = torch.cuda.Event()
+            done.record(self.streams[k])
+        return out, done
+
+    def _hand_over(self, fut):
+        out, done = fut.result()
+        torch.cuda.current_stream(self.device).wait_event(done)
+        return out
+
+    def submit(self, batch):
+        """Queue one batch; returns the list (possibly empty) of finished-in-order results that fall out of the window."""
+        k = self.n % len(self.models)
+        self.n += 1
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.device))
+        self.pending.append(self.pools[k].submit(self._run, k, batch, ready))
+        outs = []
+        while len(self.pending) > len(self.models):        # never more than in_flight behind: the host waits for the oldest
+            outs.append(self._hand_over(self.pending.pop(0)))
+        while self.pending and self.pending[0].done():     # and whatever has finished in the meantime
+            outs.append(self._hand_over(self.pending.pop(0)))
+        return outs
+
+    def drain(self):
+        outs = [self._hand_over(f) for f in self.pending]
+        self.pending = []
+        return outs
+
+    def close(self):
+        self.drain()
+        for p in self.pools:
+            p.shutdown(wait=True)

@@ -129,6 +129,35 @@ def test_priors_may_arrive_as_device_tensors():
     assert float((a["mel"].cpu() - ref["mel"]).abs().max()) <= 1e-3
 
 
+def test_forward_pipeline_is_bit_identical_and_ordered():
+    """model.pipeline(n) (r04): n forwards in flight on n engine replicas / HIP streams / host threads.  Every batch's outputs equal
+    the synchronous model(batch)'s bit for bit and come back in submission order, for ragged batches of different shapes."""
+    cfg, sd, inp, batch = _case()
+    m = _model(cfg, sd, "bf16")
+    rs = np.random.RandomState(3)
+    batches = []
+    for i in range(7):
+        B = int(rs.randint(1, 5))
+        L = int(rs.randint(5, 25))
+        lens = sorted((int(rs.randint(1, L + 1)) for _ in range(B)), reverse=True)
+        lens[0] = L
+        x = synth_inputs(cfg, B, L, seed=50 + i, lengths=lens)
+        batches.append({"phones": torch.from_numpy(x["phones"]).cuda(), "speaker": torch.from_numpy(x["speaker"]).cuda()})
+    want = [m(b, inference=True) for b in batches]
+    for n in (1, 2, 3):
+        pipe = m.pipeline(n)
+        got = []
+        for b in batches:
+            got += pipe.submit(b)
+        got += pipe.drain()
+        pipe.close()
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            assert g.keys() == w.keys()
+            for k in w:
+                assert torch.equal(g[k], w[k]), (n, k)
+
+
 def test_two_rank_bench_rehearsal_over_gloo():
     """bench.py's multi-rank control flow (shape agreement once, sync-free gathers with zeroed pad rows, drain, max over
     ranks) with both ranks on this box's one GPU over gloo - the RCCL run itself needs the 8-GPU node."""

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--graphs", type=int, default=0)
+    ap.add_argument("--full", type=int, default=0, help="1: every stream runs FULL batches (n batches in flight: does hiding one forward's host-sync seam under another's kernels pay?)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     cfg = preset(a.config)
@@ -34,10 +35,12 @@ def main():
     for n in (1, 2, 4):
         if a.batch % n:
             continue
-        bg = a.batch // n
+        bg = a.batch if a.full else a.batch // n
         models = [FastSpeech2(cfg, sd, precision="bf16", device=dev) for _ in range(n)]
         streams = [torch.cuda.Stream(dev) for _ in range(n)]
         batches = [{"phones": phones[i * bg:(i + 1) * bg].contiguous(), "speaker": spk[i * bg:(i + 1) * bg].contiguous()} for i in range(n)]
+        if a.full:
+            batches = [{"phones": phones, "speaker": spk} for _ in range(n)]
         for m in models:
             m.engine.set_graphs(bool(a.graphs))
 
@@ -56,7 +59,7 @@ def main():
             for t in ths:
                 t.join()
             torch.cuda.synchronize()
-            return (time.perf_counter() - t0) / k * 1e3
+            return (time.perf_counter() - t0) / k * 1e3 / (n if a.full else 1)
         run(5)
         best = min(run(a.steps) for _ in range(3))
         print(f"{a.config} B={a.batch}: {n} group(s) of {bg} on {n} stream(s): {best:.3f} ms per batch-{a.batch} step (graphs={a.graphs})", flush=True)
