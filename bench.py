@@ -512,6 +512,15 @@ def main():
     torch.cuda.synchronize()
     prof_att = model.engine.profile_read(_lib.K_DEC_ATTENTION)
     model.engine.profile_enable(_lib.K_DEC_ATTENTION, False)
+    # the literal north-star instance: the ENCODER's self-attention block (in-projection + attention + out-projection + LayerNorm
+    # launches of ConformerEncoderLayer.forward, model.py:108-116) against SURVEY 8d's fused-MHA figure 8 B L H^2 + 4 B L^2 H
+    model.engine.profile_reserve(_lib.K_ENC_MHA, psteps * cfg.encoder_layers + 16)
+    model.engine.profile_enable(_lib.K_ENC_MHA, True)
+    for _ in range(psteps):
+        model(batch, inference=True)
+    torch.cuda.synchronize()
+    prof_mha = model.engine.profile_read(_lib.K_ENC_MHA)
+    model.engine.profile_enable(_lib.K_ENC_MHA, False)
     # GPU time of one forward = the sum over every launch class (conv GEMMs, GEMMs, attention, row kernels) of the HIP-event
     # intervals around its launches, in a pass of its own (eager; the dominant class is a subset of the conv / GEMM class)
     all_cls = [_lib.K_CONV_GEMM, _lib.K_GEMM, _lib.K_ATTENTION, _lib.K_ROWOPS]
@@ -594,6 +603,15 @@ def main():
                 "avg_launch_us": att_s * 1e6, "launches_timed": prof_att["launches"], "flops_per_launch": prof_att["flops"] / na,
                 "what": "BASELINE.json north_star: >= 40 % of the bf16 MFMA roofline on the attention GEMMs; the encoder's instance "
                         "(256 keys) is ingest-bound (DESIGN 4), this is the MFMA-bound one; HIP events, own pass of eager steps"},
+            "encoder_mha_block": (lambda n_, s_: {
+                "kernel": "encoder self-attention block = three launches per layer: in-projection GEMM, attention_kernel (256 keys: ingest-bound), "
+                          "out-projection + residual + LayerNorm (fused epilogue)",
+                "achieved": (prof_mha["flops"] / n_) / s_ / 1e12 if s_ > 0 else 0.0, "peak": peak / 1e12, "unit": "TFLOP/s",
+                "frac": (prof_mha["flops"] / n_) / s_ / peak if s_ > 0 else 0.0, "avg_block_us": s_ * 1e6, "blocks_timed": prof_mha["launches"],
+                "flops_per_block": prof_mha["flops"] / n_,
+                "what": "BASELINE.json north_star names the encoder attention; SURVEY 8d: only the fused block (8 B L H^2 + 4 B L^2 H, AI ~ 724) can "
+                        "be MFMA-bound.  NOT fused here (DESIGN 0 item 1: the block's three launches are bound by what a CU ingests for 32 / 64 "
+                        "rows); HIP events around the block, one forward at a time"})(max(prof_mha["launches"], 1), prof_mha["ms"] / max(prof_mha["launches"], 1) * 1e-3),
             "gpu_ms_per_step": gpu_ms,
             "gpu_ms_per_step_is": f"sum of HIP-event intervals around every kernel launch of a forward, {psteps} eager steps behind the timed region",
             "in_flight": n_pick,

@@ -198,7 +198,9 @@ enum fs2_kernel_class {
     FS2_K_ROWOPS = 3,
     FS2_K_DEC_FFN_CONV1 = 4, /* the decoder FFN's first conv only: the single dominant launch shape */
     FS2_K_DEC_ATTENTION = 5, /* the decoder stack's self-attention launches only: the MFMA-bound attention instance (north_star) */
-    FS2_K_COUNT = 6
+    FS2_K_ENC_MHA = 6,     /* the encoder stack's whole self-attention block: in-projection + attention + out-projection (+ residual +
+                            * LayerNorm) launches - nn.MultiheadAttention inside ConformerEncoderLayer.forward, model.py:108-116 */
+    FS2_K_COUNT = 7
 };
 int fs2_profile_enable(fs2_engine* e, int32_t kernel_class, int32_t enable);
 /* pre-create the event pairs of `pairs` bracketed launches (otherwise they are created on first use, inside the caller's timed region) */

@@ -601,6 +601,11 @@ int conformer(fs2_engine* e, hipStream_t st, const LayerW& w, void* x, void* tmp
     // fp32 storage with the bf16 x 3 split products (FS2_F32_X3 / the front of FS2_MIXED_X3): the attention takes the split
     // arithmetic too - the in-projection stores its fp32 result as bf16 head + tail (the same bytes, no extra pass), the attention
     // multiplies them with three bf16 MFMAs per product and hands back fp32 rows (attention.hip, X3)
+    // the encoder's whole self-attention block as one timed class (in-projection .. out-projection + LayerNorm): 8 S H^2 + 4 S^2 H flops
+    // per utterance (SURVEY 8d's fused-MHA figure), bytes: x in + out, the three weight matrices
+    Bracket* mha = is_decoder ? nullptr : new Bracket(e, FS2_K_ENC_MHA, st, 8.0 * M * (double)H * H + 4.0 * B * (double)S * S * H,
+                                                      2.0 * M * H * dsz + 4.0 * H * H * dsz);
+    struct MhaEnd { Bracket*& b; ~MhaEnd() { delete b; b = nullptr; } } mha_end{mha};
     const bool x3 = e->front_split && dt == FS2_F32 && g_attn_x3;
     void* qkv_lo = x3 ? (void*)((char*)sc.qkv + (size_t)M * 3 * H * 2) : nullptr;
     CHK(gemm(e, st, w.in_proj, x, sc.qkv, M, M, false, dt, nullptr, -1, nullptr, nullptr, qkv_lo));
@@ -628,6 +633,7 @@ int conformer(fs2_engine* e, hipStream_t st, const LayerW& w, void* x, void* tmp
         Deferred d1;
         d1.res = x; d1.stats_out = sc.st1;
         CHK(gemm(e, st, w.out_proj, sc.att, tmp, M, M, false, dt, nullptr, -1, nullptr, &d1));       // tmp = v1
+        delete mha; mha = nullptr;
         LnOnLoad l1{sc.st1, w.g1, w.b1};
         CHK(dwconv(e, st, w.dw, tmp, sc.u, B, S, dt, &l1));
         CHK(gemm(e, st, w.c1, sc.u, sc.hid, M, S, true, dt, nullptr, is_decoder ? FS2_K_DEC_FFN_CONV1 : -1));
@@ -640,6 +646,7 @@ int conformer(fs2_engine* e, hipStream_t st, const LayerW& w, void* x, void* tmp
         LnFuse ln;
         ln.res = x; ln.g = w.g1; ln.b = w.b1; ln.tmp = sc.proj;
         CHK(gemm(e, st, w.out_proj, sc.att, tmp, M, M, false, dt, &ln));
+        delete mha; mha = nullptr;
     }
     if (w.depthwise) {
         CHK(dwconv(e, st, w.dw, tmp, sc.u, B, S, dt));
