@@ -5,7 +5,8 @@
 # un-profiled durations.  FETCH_SIZE is doubled (gfx950 tallies 128-B requests at 64 B).  Writes gpurun_out/${ROUND:-r03}_pmc_kernels_<cfg>.md
 CFG=${1:-c2}; B=32; [ $CFG = c5 ] && B=8
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/pmc_ks; mkdir -p $O
-CMD="python $R/bench.py --config $CFG --batch $B --steps 2 --warmup 1 --no-cpu-baseline --no-parity"
+export FS2_BENCH_IN_FLIGHT=1 FS2_BENCH_MODE=eager   # one forward at a time, eager: a launch's counters and duration are its own
+CMD="python $R/bench.py --config $CFG --batch $B --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-train"
 [ -n "$PMC_CMD" ] && CMD="$PMC_CMD"   # any other command (e.g. tools/bench_ops.py bwd --only ...); CFG then only names the output
 cd /tmp && export TMPDIR=/tmp
 rm -rf $O/*
