@@ -119,6 +119,10 @@ const char* fs2_last_error(const fs2_engine* e);
 
 int fs2_create(const fs2_config* cfg, fs2_engine** out);
 int fs2_destroy(fs2_engine* e);
+/* A second engine over the same device weights (finalized engines only; the weights are freed with the last holder): own workspace,
+ * own host-side state.  One engine serves one caller thread at a time; an engine and its clones may run concurrently on different
+ * streams - several forwards of FastSpeech2.forward in flight (generate.py:186-195 feeds the model chunk after chunk). */
+int fs2_clone(const fs2_engine* src, fs2_engine** out);
 
 /* One call per state_dict entry, reference key names, fp32 HOST data, torch shape.
  * Unknown names that belong to off-path modules are rejected with FS2_ERR_WEIGHT. */

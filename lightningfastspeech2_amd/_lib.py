@@ -107,6 +107,7 @@ def load():
     lib.fs2_last_error.argtypes = [vp]
     lib.fs2_create.argtypes = [C.POINTER(Fs2ConfigC), C.POINTER(vp)]
     lib.fs2_destroy.argtypes = [vp]
+    lib.fs2_clone.argtypes = [vp, C.POINTER(vp)]
     lib.fs2_load_weight.argtypes = [vp, C.c_char_p, vp, i64p, i32]
     lib.fs2_finalize.argtypes = [vp]
     lib.fs2_encode.argtypes = [vp, vp, vp, i32, i32, vp, vp, C.POINTER(i32)]

@@ -11,6 +11,7 @@
 
 #include <functional>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -137,7 +138,12 @@ struct fs2_engine {
     bool front_split = false;  // FS2_MIXED_X3 / FS2_F32_X3: the fp32 GEMMs / convs (the front's / all of them) run as bf16 x 3 split products
     std::map<std::string, HostTensor> host;
     std::map<std::string, std::vector<int64_t>> spec;
-    std::vector<void*> dev_allocs;
+    // device weight blocks: owned jointly by an engine and its fs2_clone()s (freed with the last of them)
+    struct DevAllocs {
+        std::vector<void*> p;
+        ~DevAllocs() { for (void* q : p) (void)hipFree(q); }
+    };
+    std::shared_ptr<DevAllocs> dev_allocs = std::make_shared<DevAllocs>();
     // device weights
     float *phone_table = nullptr, *pe = nullptr, *spk_w = nullptr, *spk_b = nullptr;
     std::vector<LayerW> enc, dec;
@@ -313,7 +319,7 @@ int check_config(fs2_engine* e) {
 // ---- upload helpers ---------------------------------------------------------------------------
 int dev_alloc(fs2_engine* e, void** p, size_t bytes) {
     if (hipMalloc(p, bytes ? bytes : 256) != hipSuccess) return fail(e, FS2_ERR_NOMEM, "hipMalloc(%zu) failed", bytes);
-    e->dev_allocs.push_back(*p);
+    e->dev_allocs->p.push_back(*p);
     return FS2_OK;
 }
 int upload_f32(fs2_engine* e, const float* h, size_t n, float** out) {
@@ -863,10 +869,34 @@ int fs2_create(const fs2_config* cfg, fs2_engine** out) {
     return FS2_OK;
 }
 
+// A second engine over the SAME device weights (read-only after fs2_finalize): its own workspace arenas, host-side state, graphs,
+// profiling slots - what a second forward in flight needs (lightningfastspeech2_amd.model.ForwardPipeline).  One engine = one caller
+// thread at a time; an engine and its clones may run concurrently on different streams.
+int fs2_clone(const fs2_engine* src, fs2_engine** out) {
+    if (!src || !out) return FS2_ERR_ARG;
+    if (!src->finalized) return FS2_ERR_STATE;
+    fs2_engine* e = new fs2_engine();
+    e->cfg = src->cfg;
+    e->dt = src->dt; e->fdt = src->fdt; e->bdt = src->bdt; e->esz = src->esz;
+    e->err[0] = 0;
+    e->finalized = true;
+    e->fuse_predictor = src->fuse_predictor;
+    e->use_graph = src->use_graph;
+    e->zero_pad_mel = src->zero_pad_mel;
+    e->defer_ln = src->defer_ln;
+    e->front_split = src->front_split;
+    e->spec = src->spec;
+    e->dev_allocs = src->dev_allocs;
+    e->phone_table = src->phone_table; e->pe = src->pe; e->spk_w = src->spk_w; e->spk_b = src->spk_b;
+    e->enc = src->enc; e->dec = src->dec; e->dur = src->dur; e->vars = src->vars; e->mel = src->mel; e->priors_w = src->priors_w;
+    *out = e;
+    return FS2_OK;
+}
+
 int fs2_destroy(fs2_engine* e) {
     if (!e) return FS2_OK;
     (void)hipDeviceSynchronize();
-    for (void* p : e->dev_allocs) (void)hipFree(p);
+    e->dev_allocs.reset();  // frees the weights unless a clone still holds them
     e->persist.release();
     e->scratch.release();
     e->dbg.release();

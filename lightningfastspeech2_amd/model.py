@@ -74,6 +74,19 @@ class Engine:
             graphs = os.environ.get("FS2_GRAPHS", "0") == "1"
         self.set_graphs(graphs)
 
+    def clone(self) -> "Engine":
+        """Another engine over the same device weights (fs2_clone): own workspace and host-side state."""
+        other = Engine.__new__(Engine)
+        other.lib, other.torch_workspace = self.lib, self.torch_workspace
+        other._ws_persist = other._ws_scratch = None
+        other.cfg, other.precision, other.dtype, other.device = self.cfg, self.precision, self.dtype, self.device
+        other.handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.fs2_clone(self.handle, C.byref(other.handle)), self.handle, "clone")
+        other._last, other._t_hint = None, {}
+        other._graphs_on = getattr(self, "_graphs_on", False)
+        return other
+
     def _load(self, state_dict):
         from .weights import state_dict_spec
         spec = state_dict_spec(self.cfg)
@@ -286,14 +299,15 @@ class FastSpeech2:
         self.device = self.engine.device
         self.training = False
         self._t_guess = {}
-        self._ctor = (state_dict, precision, phone2id, speaker2dvector, extra_hparams)  # what replicate() builds another engine from
 
     def replicate(self) -> "FastSpeech2":
         """Another model object over the same weights (its own engine: own workspace, own host state) - what ForwardPipeline
         keeps per forward in flight."""
-        sd, precision, phone2id, speaker2dvector, extra = self._ctor
-        return FastSpeech2(self.cfg, sd, precision=precision, device=self.device, phone2id=phone2id,
-                           speaker2dvector=speaker2dvector, extra_hparams=extra)
+        import copy
+        other = copy.copy(self)            # hparams, stats, phone2id ...: shared, read-only
+        other.engine = self.engine.clone()  # the device weights too (fs2_clone)
+        other._t_guess = {}
+        return other
 
     def pipeline(self, in_flight: int = 2) -> "ForwardPipeline":
         return ForwardPipeline(self, in_flight)
