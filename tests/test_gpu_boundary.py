@@ -158,6 +158,23 @@ def test_forward_pipeline_is_bit_identical_and_ordered():
                 assert torch.equal(g[k], w[k]), (n, k)
 
 
+def test_engine_clone_shares_weights_and_outlives_its_parent():
+    """fs2_clone: a second engine over the same device weights; the weights are freed with the LAST holder, so a clone keeps working
+    after its parent is destroyed, and gives the parent's results bit for bit."""
+    cfg, sd, inp, batch = _case()
+    m = _model(cfg, sd, "bf16")
+    want = m(batch, inference=True)
+    before = torch.cuda.memory_allocated()
+    r = m.replicate()
+    got = r(batch, inference=True)
+    for k in want:
+        assert torch.equal(got[k], want[k]), k
+    m.engine.close()            # parent gone: the clone still holds the weight blocks
+    again = r(batch, inference=True)
+    assert torch.equal(again["mel"], want["mel"])
+    del before
+
+
 def test_two_rank_bench_rehearsal_over_gloo():
     """bench.py's multi-rank control flow (shape agreement once, sync-free gathers with zeroed pad rows, drain, max over
     ranks) with both ranks on this box's one GPU over gloo - the RCCL run itself needs the 8-GPU node."""
