@@ -62,6 +62,16 @@ class _Ops:
         self.fuse_ln_drop = os.environ.get("FS2_TRAIN_FUSE_LN_DROPOUT", "1") != "0"  # A/B switch: the residual-site dropout inside that launch
         self.fuse_add = os.environ.get("FS2_TRAIN_FUSE_ADD", "1") != "0"  # A/B switch: "dx +=" of a data-gradient product inside the GEMM launch
         self.splitk = os.environ.get("FS2_TRAIN_SPLITK", "1") != "0"    # A/B switch: split-K data-gradient convs where fs2_op_gemm_splitk_choice says so
+        # Weight gradients are leaves of the backward: nothing downstream reads them before the optimizer step.  With
+        # FS2_TRAIN_WGRAD_STREAM=1 they run on a second HIP stream (dW GEMM + split-K reduce + bias column sums: ~110 of a step's
+        # ~510 launches) beside the data-gradient chain, ordered by events: the side stream waits for dy, the main stream waits
+        # for the side stream before it overwrites a tensor a pending product still reads (_guard) and at the end of the step.
+        # Measured r04 at C2, bf16: 10.95 -> 10.5 ms per step (12.30 -> 11.7 with the recipe's dropout); fp32 (long MFMA-bound launches,
+        # nothing to fill) 63.2 -> 64.3, so the default follows the precision.  FS2_TRAIN_WGRAD_STREAM=0 / 1 overrides.
+        side_on = os.environ.get("FS2_TRAIN_WGRAD_STREAM", "1" if precision == "bf16" else "0") == "1"
+        self.side = torch.cuda.Stream(self.dev) if side_on else None
+        self._ws_tag = ""
+        self._pending: Dict[int, "torch.cuda.Event"] = {}
 
     def site(self):
         self._site += 1
@@ -84,9 +94,29 @@ class _Ops:
         self.ck(self.lib.fs2_op_convert(F32, self.dt, _p(x), _p(y), x.numel(), self.st()), "convert")
         return y
 
+    @staticmethod
+    def _base(t):
+        return t.untyped_storage().data_ptr()
+
+    def _guard(self, *tensors):
+        """about to WRITE these tensors on the current stream: wait for side-stream products that still read them"""
+        if not self._pending:
+            return
+        for t in tensors:
+            ev = self._pending.pop(self._base(t), None) if t is not None else None
+            if ev is not None:
+                torch.cuda.current_stream(self.dev).wait_event(ev)
+
+    def join_side(self):
+        """the current stream waits for everything queued on the weight-gradient stream"""
+        if self.side is not None:
+            torch.cuda.current_stream(self.dev).wait_stream(self.side)
+            self._pending.clear()
+
     def ws(self, key: str, nbytes: int) -> Optional[torch.Tensor]:
         if nbytes <= 0:
             return None
+        key = key + self._ws_tag  # the side stream's launches have workspaces of their own
         t = self._ws.get(key)
         if t is None or t.numel() * 4 < nbytes:
             # zeroed: the column-sum workspace starts with ticket counters that every launch returns to zero (include/fs2.h)
@@ -200,6 +230,7 @@ class _Ops:
 
     def relu_bwd(self, dy, y):
         """in place: dy *= (y > 0)"""
+        self._guard(dy)
         self.ck(self.lib.fs2_op_ew(self._dt(dy), 1, _p(dy), _p(y), _p(dy), dy.numel(), C.c_float(0), C.c_float(0), self.st()), "relu_bwd")
         return dy
 
@@ -218,13 +249,16 @@ class _Ops:
     def dwconv_bwd(self, du, x, w, gw, gb, B, S, Cc, k):
         """depth-wise conv backward: (gw (C, k), gb (C)) += the weight / bias gradients; returns d/dx (B*S, C)."""
         nparts = int(self.lib.fs2_op_dwconv_wgrad_parts(B, S))
-        part = self.empty(nparts, Cc * (k + 1))
-        self.ck(self.lib.fs2_op_dwconv_wgrad(self.dt, _p(du), _p(x), _p(part), B, S, Cc, k, self.st()), "dwconv_wgrad")
-        if gb.data_ptr() == gw.data_ptr() + 4 * Cc * k:
-            self.col_sum(part, gw, nparts, Cc * (k + 1))
-        else:
-            self.col_sum(part, gw, nparts, Cc * k, ldx=Cc * (k + 1))
-            self.col_sum(part[:, Cc * k:], gb, nparts, Cc, ldx=Cc * (k + 1))
+
+        def wg():  # parameter gradients: a leaf (side stream where there is one)
+            part = self.empty(nparts, Cc * (k + 1))
+            self.ck(self.lib.fs2_op_dwconv_wgrad(self.dt, _p(du), _p(x), _p(part), B, S, Cc, k, self.st()), "dwconv_wgrad")
+            if gb.data_ptr() == gw.data_ptr() + 4 * Cc * k:
+                self.col_sum(part, gw, nparts, Cc * (k + 1))
+            else:
+                self.col_sum(part, gw, nparts, Cc * k, ldx=Cc * (k + 1))
+                self.col_sum(part[:, Cc * k:], gb, nparts, Cc, ldx=Cc * (k + 1))
+        self.on_side((du, x), wg)
         dx = self.act(B * S, Cc)
         self.ck(self.lib.fs2_op_dwconv_dgrad(self.dt, _p(du), _p(w), _p(dx), B, S, Cc, k, self.st()), "dwconv_dgrad")
         return dx
@@ -235,11 +269,13 @@ class _Ops:
         if p <= 0.0:
             return x
         y = x if out is None else out
+        self._guard(y)
         self.ck(self.lib.fs2_op_dropout(self._dt(x), _p(x), _p(y), x.numel(), C.c_float(p), C.c_uint64(self.seed), C.c_uint64(key),
                                         self.st()), "dropout")
         return y
 
     def add_(self, a, b):
+        self._guard(a)
         self.ck(self.lib.fs2_op_ew(self._dt(a), 0, _p(a), _p(b), _p(a), a.numel(), C.c_float(1), C.c_float(1), self.st()), "add")
         return a
 
@@ -247,6 +283,8 @@ class _Ops:
     def dgrad(self, dy, w, M, N, Cin, taps=1, S=None, out=None, accumulate=False, wt=None, gate=None, gate_scale=1.0):
         """dX (M, Cin) = dY (M, N) . W: with the transposed / tap-flipped copy wt (Cin, taps*N) through the forward
         GEMM / slab-conv kernel (dX is a 'same' conv of dY with wt), else through the strided-batched GEMM."""
+        if out is not None:
+            self._guard(out)
         if wt is not None and N % 64 == 0 and Cin % 64 == 0 and dy.dtype == wt.dtype:
             # a long reduction over few row tiles (encoder conv1: M = B L, K = taps x filter): K slices as workgroups of one launch
             # into fp32 planes, the plane sum folds the "+=" of an accumulating call (no separate add launch)
@@ -287,8 +325,36 @@ class _Ops:
                        taps=taps, Kin=N, a_shift0=pad, a_shift_step=-1, sBtap=Cin, beta=beta)
         return self.gate_(dx, gate, gate_scale) if gate is not None else dx
 
-    def wgrad(self, dy, x, dw, db, M, N, Cin, taps=1, S=None):
-        """dw (N, taps*Cin) += dy^T x (per tap, rows shifted inside their utterance); db (N) += column sums of dy."""
+    def wgrad(self, dy, x, dw, db, M, N, Cin, taps=1, S=None, sync=False):
+        """dw (N, taps*Cin) += dy^T x (per tap, rows shifted inside their utterance); db (N) += column sums of dy.
+        ``sync``: the caller reads dw right away (the folded depth-wise conv2) - no side stream for this one."""
+        if sync:
+            return self._wgrad(dy, x, dw, db, M, N, Cin, taps, S)
+        self.on_side((dy, x), lambda: self._wgrad(dy, x, dw, db, M, N, Cin, taps, S))
+
+    def on_side(self, reads, fn):
+        """Run the launches of fn() - LEAF work of the backward: parameter gradients nothing reads before the optimizer step - on the
+        side stream, behind everything queued on the current stream so far; `reads` = the tensors they read."""
+        if self.side is None:
+            return fn()
+        cur = torch.cuda.current_stream(self.dev)
+        ready = torch.cuda.Event()
+        ready.record(cur)                      # the inputs are complete on the main stream here
+        self.side.wait_event(ready)
+        self._ws_tag = "@side"
+        try:
+            with torch.cuda.stream(self.side):
+                fn()
+                done = torch.cuda.Event()
+                done.record(self.side)
+        finally:
+            self._ws_tag = ""
+        for t in reads:
+            if t is not None:
+                t.record_stream(self.side)     # the allocator must not hand the block out again before the side stream is through
+                self._pending[self._base(t)] = done
+
+    def _wgrad(self, dy, x, dw, db, M, N, Cin, taps=1, S=None):
         pad = (taps - 1) // 2
         kw = dict(M=N, N=Cin, K=M, sAm=1, sAk=N, sBk=Cin, sBn=1, ldc=taps * Cin, nb2=taps, sC2=Cin,
                   seg=(S or M) if taps > 1 else 0, b_shift0=-pad, b_shift_step=1, beta=1.0)
@@ -593,20 +659,25 @@ class Trainer:
             o.ck(o.lib.fs2_op_layernorm_bwd(o.dt, _p(z), _p(res), _p(dy), _p(self.P[gname]), _p(dz), _p(part), M, H, int(relu_mask),
                                             o.st()), "layernorm_bwd")
         gw, gb = self.G[gname], self.G[bname]
-        if gb.data_ptr() == gw.data_ptr() + 4 * H and (bias_name is None) != (bias_out is None):
-            # dgamma | dbeta (adjacent in the flat buffer) and the bias gradient out of one launch
-            o.col_sum2(part, gw, self.G[bias_name] if bias_name is not None else bias_out, 2 * H, nparts, 3 * H,
-                       accumulate2=bias_name is not None)
-            return dz if dzm is None else (dz, dzm)
-        if gb.data_ptr() == gw.data_ptr() + 4 * H:
-            o.col_sum(part, gw, nparts, 2 * H, ldx=3 * H)
-        else:
-            o.col_sum(part, gw, nparts, H, ldx=3 * H)
-            o.col_sum(part[:, H:], gb, nparts, H, ldx=3 * H)
-        if bias_name is not None:
-            o.col_sum(part[:, 2 * H:], self.G[bias_name], nparts, H, ldx=3 * H)
-        if bias_out is not None:
-            o.col_sum(part[:, 2 * H:], bias_out, nparts, H, ldx=3 * H, accumulate=False)
+
+        def sums():
+            if gb.data_ptr() == gw.data_ptr() + 4 * H and (bias_name is None) != (bias_out is None):
+                # dgamma | dbeta (adjacent in the flat buffer) and the bias gradient out of one launch
+                o.col_sum2(part, gw, self.G[bias_name] if bias_name is not None else bias_out, 2 * H, nparts, 3 * H,
+                           accumulate2=bias_name is not None)
+                return
+            if gb.data_ptr() == gw.data_ptr() + 4 * H:
+                o.col_sum(part, gw, nparts, 2 * H, ldx=3 * H)
+            else:
+                o.col_sum(part, gw, nparts, H, ldx=3 * H)
+                o.col_sum(part[:, H:], gb, nparts, H, ldx=3 * H)
+            if bias_name is not None:
+                o.col_sum(part[:, 2 * H:], self.G[bias_name], nparts, H, ldx=3 * H)
+            if bias_out is not None:
+                o.col_sum(part[:, 2 * H:], bias_out, nparts, H, ldx=3 * H, accumulate=False)
+        # (these column sums are leaves too, but on the side stream they measured SLOWER - 10.6 -> 11.0 ms per step: ~125 launches of
+        # ~6 us each cost more in event records / waits than they free on the main chain; only the weight-gradient GEMMs go there)
+        sums()
         return dz if dzm is None else (dz, dzm)
 
     def _layer_bwd(self, dx2, t, prefix, B, S, heads, F_, k):
@@ -628,7 +699,7 @@ class Trainer:
         if folded:
             f = self.fold[prefix]
             dWf = torch.zeros(H, F_, device=self.dev)
-            o.wgrad(dc2, t["h"], dWf, None, M, H, F_)
+            o.wgrad(dc2, t["h"], dWf, None, M, H, F_, sync=True)
             o.ck(o.lib.fs2_op_unfold_conv2(_p(dWf), _p(dbf), _p(P[f"{prefix}.conv2.0.weight"]), _p(P[f"{prefix}.conv2.0.bias"]),
                                            _p(P[f"{prefix}.conv2.1.weight"]), _p(G[f"{prefix}.conv2.0.weight"]), _p(G[f"{prefix}.conv2.0.bias"]),
                                            _p(G[f"{prefix}.conv2.1.weight"]), _p(G[f"{prefix}.conv2.1.bias"]), H, F_, o.st()), "unfold_conv2")
@@ -668,6 +739,7 @@ class Trainer:
         delta = o.empty(B, heads, S)
         o.ck(o.lib.fs2_op_attn_delta(o.dt, _p(dattn), _p(t["attn"]), _p(delta), B, S, H, heads, o.st()), "attn_delta")
         if t["lse"] is not None:  # recomputing backward: P, dP, dS live in registers only
+        # (its two launches - (dK, dV) and dQ - side by side on two streams measured nothing: 10.4-10.5 ms either way, r04)
             o.ck(o.lib.fs2_op_attention_bwd(o.dt, _p(qkv), _p(dattn), _p(t["lse"]), _p(delta), _p(t["key_pad"]), _p(dqkv), B, S, H, heads,
                                             C.c_float(pd), C.c_uint64(o.seed), C.c_uint64(t["k_attn"]), o.st()), "attention_bwd")
         else:
@@ -747,9 +819,13 @@ class Trainer:
         M = B * S
         # pred = y . w + b  (masked rows carry dpred = 0 already): dw = sum_m dpred[m] y[m] as a row-weighted column sum (fp32
         # weights; as a 1 x filt x M product on the 128 x 128 GEMM tile it took 51 us per head)
-        ws = o.ws("colsum", int(o.lib.fs2_op_col_sum_ws_bytes(M, filt, 0)))
-        o.ck(o.lib.fs2_op_col_sum_weighted(o._dt(t["y"]), _p(t["y"]), _p(dpred), _p(G[f"{prefix}.linear.weight"]), _p(ws), M, filt, filt, 1,
-                                           C.c_float(1.0), o.st()), "col_sum_weighted")
+        dpred32 = dpred
+
+        def head_w():
+            ws = o.ws("colsum", int(o.lib.fs2_op_col_sum_ws_bytes(M, filt, 0)))
+            o.ck(o.lib.fs2_op_col_sum_weighted(o._dt(t["y"]), _p(t["y"]), _p(dpred32), _p(G[f"{prefix}.linear.weight"]), _p(ws), M, filt, filt, 1,
+                                               C.c_float(1.0), o.st()), "col_sum_weighted")
+        head_w()
         dpred = o.to_act(dpred)
         o.col_sum(dpred, G[f"{prefix}.linear.bias"], M, 1)
         dy = o.act(M, filt)
@@ -941,7 +1017,7 @@ class Trainer:
             for vi in reversed(range(nv)):
                 v = cfg.variances[vi]
                 pfx = f"variance_adaptor.encoders.{v}"
-                o.scatter_rows(dx, var_idx[v], None, G[f"{pfx}.embedding.weight"], B * T, H, cfg.variance_nbins, -1)
+                o.on_side((dx,), lambda: o.scatter_rows(dx, var_idx[v], None, G[f"{pfx}.embedding.weight"], B * T, H, cfg.variance_nbins, -1))
                 self._predictor_bwd(dvar[v], var_tape[v], f"{pfx}.predictor", cfg.variance_nlayers[vi], cfg.variance_filter_size,
                                     cfg.variance_kernel_size[vi], B, T, dx, dw=cfg.variance_depthwise_conv)
             dxe = o.act(B * L, H)
@@ -962,9 +1038,10 @@ class Trainer:
                                       cfg.encoder_kernel_sizes[i])
             o.col_sum(dxe, dspk, B * L, H, seg=L)
             o.dropout(dxe, self.p_enc, k_pe_enc)
-            o.scatter_rows(dxe, None, phones, G["phone_embedding.weight"], B * L, H, cfg.n_phones, 0)
+            o.on_side((dxe,), lambda: o.scatter_rows(dxe, None, phones, G["phone_embedding.weight"], B * L, H, cfg.n_phones, 0))
             o.relu_bwd(dspk, spk)  # spk = relu(W dvec + b), model.py:137-143
             o.wgrad(dspk, dvec, G["speaker_embedding.projection.weight"], G["speaker_embedding.projection.bias"], B, H, dvec.shape[1])
+        o.join_side()  # the weight gradients of this micro-step are in the flat buffer before anything reads it
         self._accum += 1
         self.last = {"mel": mel.view(B, T, cfg.n_mels), "duration_prediction": dur_pred.view(B, L), "tgt_mask": tgt_mask.bool(),
                      "src_mask": src_mask.bool(), **{f"variances_{v}": var_pred[v].view(B, T) for v in cfg.variances}}

@@ -237,6 +237,36 @@ def test_backward_is_the_derivative_of_the_forward_under_dropout(kw):
     tr.flat_p.copy_(w0)
 
 
+@pytest.mark.parametrize("dw", [False, True])
+def test_weight_gradient_stream_is_bit_identical(monkeypatch, dw):
+    """r04: the weight-gradient GEMMs (+ split-K reduce, bias column sums, embedding scatters, depth-wise weight gradients) - leaves of
+    the backward - run on a second HIP stream beside the data-gradient chain (FS2_TRAIN_WGRAD_STREAM, on for bf16).  Same kernels on
+    the same inputs, ordered by events: losses, every gradient and the weights after two steps are bit-equal to the one-stream run,
+    with dropout on (in-place mask passes over tensors the side stream still reads are guarded)."""
+    from lightningfastspeech2_amd.training import Trainer
+    cfg, sd, batch = _case(61, 3, 17, [17, 11, 4], encoder_depthwise_conv=dw, decoder_depthwise_conv=dw, variance_depthwise_conv=dw,
+                           duration_depthwise_conv=dw, encoder_conv_filter_size=128, decoder_conv_filter_size=128)
+    outs = []
+    for on in ("0", "1"):
+        monkeypatch.setenv("FS2_TRAIN_WGRAD_STREAM", on)
+        tr = Trainer(cfg, sd, precision="bf16", encoder_dropout=0.1, decoder_dropout=0.1, variance_dropout=0.1, duration_dropout=0.1, seed=5)
+        assert (tr.ops.side is not None) == (on == "1")
+        l1 = tr.training_step(_dev(batch))
+        g1 = {k: v.clone() for k, v in tr.gradients().items()}
+        tr.optimizer_step()
+        tr.training_step(_dev(batch))
+        tr.optimizer_step()
+        torch.cuda.synchronize()
+        outs.append((l1, g1, tr.state_dict()))
+    (la, ga, wa), (lb, gb, wb) = outs
+    for k in la:
+        assert float(la[k]) == float(lb[k]), k
+    for k in ga:
+        assert torch.equal(ga[k], gb[k]), k
+    for k in wa:
+        assert torch.equal(torch.as_tensor(wa[k]), torch.as_tensor(wb[k])), k
+
+
 def test_two_rank_data_parallel_step(tmp_path):
     """Two ranks (both on this box's one GPU, gloo), each with its shard of a ragged batch: per-rank step, the flat gradient
     buffer all-reduced inside optimizer_step.  The result must equal the oracle that accumulates the two shards' gradients
