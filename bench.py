@@ -463,15 +463,24 @@ def main():
     dist_info = None
     if multi:
         cdev_i = dev if backend == "nccl" else torch.device("cpu")
-        sync()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step(gather=False)
-        drain(gather=False)
-        sync()
-        el_nog = time.perf_counter() - t1
+        # alternating blocks (with / without the gather), medians: a single pass behind the timed region measured the clock
+        # drift of a warm GPU rather than the gather (r04: "exposed" came out negative)
+        import statistics as _st
+        nblk = max(4, args.steps // 2)
+        t_with, t_without = [], []
+        for _ in range(3):
+            for g_on, acc in ((True, t_with), (False, t_without)):
+                sync()
+                t1 = time.perf_counter()
+                for _ in range(nblk):
+                    step(gather=g_on)
+                drain(gather=g_on)
+                sync()
+                acc.append((time.perf_counter() - t1) / nblk)
+        el_nog = _st.median(t_without) * args.steps
+        el_wg = _st.median(t_with) * args.steps
         mine = torch.tensor([float(rank), float(local_rank), elapsed / args.steps * 1e3, el_nog / args.steps * 1e3, float(frames_rank),
-                             float(torch.cuda.current_device())], dtype=torch.float64, device=cdev_i)
+                             float(torch.cuda.current_device()), el_wg / args.steps * 1e3], dtype=torch.float64, device=cdev_i)
         allr = torch.empty(world * mine.numel(), dtype=torch.float64, device=cdev_i)
         dist.all_gather_into_tensor(allr, mine)
         allr = allr.cpu().view(world, -1)
@@ -486,11 +495,12 @@ def main():
             "per_rank_ms_per_step_without_gather": [round(float(v), 4) for v in allr[:, 3]],
             "per_rank_frames_per_step": [int(v) for v in allr[:, 4]],
             "gather_bytes_per_rank": int(gather_bytes[0]), "gather_bytes_total_per_step": int(gather_bytes[0]) * world,
-            "gather_ms_exposed": round(float(allr[:, 2].max() - allr[:, 3].max()), 4),
+            "per_rank_ms_per_step_with_gather_ab": [round(float(v), 4) for v in allr[:, 6]],
+            "gather_ms_exposed": round(float(allr[:, 6].max() - allr[:, 3].max()), 4),
             "rccl_version": ver if backend == "nccl" else None, "device_name": torch.cuda.get_device_name(dev),
             "forced_single_rank": world == 1,
-            "what": "all-gathered from every rank over the process group the mel gather uses; gather_ms_exposed = max-over-ranks ms_per_step "
-                    "with the asynchronous mel all-gather minus the same steps without it (the collective runs on the collective "
+            "what": "all-gathered from every rank over the process group the mel gather uses; gather_ms_exposed = max-over-ranks ms per step "
+                    "with the asynchronous mel all-gather minus without it, medians of three alternating blocks of steps behind the timed region (the collective runs on the collective "
                     "library's stream underneath the next forward)"}
     model.engine.set_graphs(False)
     # roofline pass: K eager steps with the events of the dominant launch class on; then the whole forward's kernel time from
