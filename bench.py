@@ -316,11 +316,15 @@ def main():
         model.engine.set_fused_predictor(False)
     if os.environ.get("FS2_DEFER_LN") == "0":  # A/B: one launch per LayerNorm in the wide depth-wise blocks
         model.engine.set_deferred_layernorm(False)
+    def set_knob(k):  # a mistyped knob must not yield an unlabeled default-config measurement
+        r = _lib.load().fs2_op_set_gemm_variant(int(k))
+        if r != 0:
+            raise SystemExit(f"fs2_op_set_gemm_variant({k}) was rejected (status {r}): not a defined knob value (include/fs2.h)")
     if os.environ.get("FS2_GEMM_KNOBS"):  # A/B: comma-separated fs2_op_set_gemm_variant values (include/fs2.h)
         for k in os.environ["FS2_GEMM_KNOBS"].split(","):
-            _lib.load().fs2_op_set_gemm_variant(int(k))
+            set_knob(int(k))
     if os.environ.get("FS2_XCD_REMAP"):  # A/B: 0 = plain tile order in the slab GEMM
-        _lib.load().fs2_op_set_gemm_variant(200 + int(os.environ["FS2_XCD_REMAP"]))
+        set_knob(200 + int(os.environ["FS2_XCD_REMAP"]))
     inp = synth_inputs(cfg, args.batch, args.phones, seed=1234 + 17 * rank)
     batch = {"phones": torch.from_numpy(inp["phones"]).to(dev), "speaker": torch.from_numpy(inp["speaker"]).to(dev)}
 
@@ -479,24 +483,15 @@ def main():
                 acc.append((time.perf_counter() - t1) / nblk)
         el_nog = _st.median(t_without) * args.steps
         el_wg = _st.median(t_with) * args.steps
-        mine = torch.tensor([float(rank), float(local_rank), elapsed / args.steps * 1e3, el_nog / args.steps * 1e3, float(frames_rank),
-                             float(torch.cuda.current_device()), el_wg / args.steps * 1e3], dtype=torch.float64, device=cdev_i)
-        allr = torch.empty(world * mine.numel(), dtype=torch.float64, device=cdev_i)
-        dist.all_gather_into_tensor(allr, mine)
-        allr = allr.cpu().view(world, -1)
+        from lightningfastspeech2_amd.dist import rank_report
         try:
             ver = ".".join(str(v) for v in torch.cuda.nccl.version())
         except Exception:
             ver = None
         dist_info = {
-            "backend": str(dist.get_backend()), "world_size": dist.get_world_size(), "ranks_seen": [int(r) for r in allr[:, 0]],
-            "local_ranks": [int(r) for r in allr[:, 1]], "devices": [int(r) for r in allr[:, 5]],
-            "per_rank_ms_per_step": [round(float(v), 4) for v in allr[:, 2]],
-            "per_rank_ms_per_step_without_gather": [round(float(v), 4) for v in allr[:, 3]],
-            "per_rank_frames_per_step": [int(v) for v in allr[:, 4]],
-            "gather_bytes_per_rank": int(gather_bytes[0]), "gather_bytes_total_per_step": int(gather_bytes[0]) * world,
-            "per_rank_ms_per_step_with_gather_ab": [round(float(v), 4) for v in allr[:, 6]],
-            "gather_ms_exposed": round(float(allr[:, 6].max() - allr[:, 3].max()), 4),
+            **rank_report(ms_per_step=elapsed / args.steps * 1e3, ms_without_gather=el_nog / args.steps * 1e3,
+                          ms_with_gather=el_wg / args.steps * 1e3, frames_per_step=frames_rank, gather_bytes=int(gather_bytes[0]),
+                          local_rank=local_rank, device_index=torch.cuda.current_device(), device=cdev_i),
             "rccl_version": ver if backend == "nccl" else None, "device_name": torch.cuda.get_device_name(dev),
             "forced_single_rank": world == 1,
             "what": "all-gathered from every rank over the process group the mel gather uses; gather_ms_exposed = max-over-ranks ms per step "
@@ -569,12 +564,12 @@ def main():
                 traffic = tj.get("conv_gemm_hbm_bytes_per_launch")
                 import hashlib
                 here = hashlib.sha256(open(os.path.join(ROOT, "lightningfastspeech2_amd", "csrc", "gemm_mfma.hip"), "rb").read()).hexdigest()[:16]
-                cur = tj.get("kernel_source_sha256") == here
+                sha_matches = tj.get("kernel_source_sha256") == here
                 traffic_src = (f"profiles/{os.path.basename(TRAFFIC_FILE)}: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + --pmc WRITE_SIZE, "
                                "separate passes over this launch shape (tools/pmc_traffic.sh); kernel source at commit "
                                f"{tj.get('kernel_commit', '?')} (git log -1 -- csrc/gemm_mfma.hip), measured at {tj.get('measured_at_commit', '?')}; "
                                f"sha256 of the measured csrc/gemm_mfma.hip {tj.get('kernel_source_sha256', '?')} "
-                               + ("== this checkout's" if cur else f"!= this checkout's {here}: the kernel source changed since the counters were read"))
+                               + ("== this checkout's" if sha_matches else f"!= this checkout's {here}: the kernel source changed since the counters were read"))
             except Exception:
                 traffic = None
         na = max(prof_att["launches"], 1)

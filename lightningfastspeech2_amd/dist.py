@@ -100,13 +100,17 @@ class MelGather:
     The exchange runs on the collective library's own stream, so a caller that keeps launching the next
     forward overlaps it with compute."""
 
-    def __init__(self, works, all_mel, all_fr, Bs, B_max):
+    def __init__(self, works, all_mel, all_fr, Bs, B_max, keep_alive=None):
         self._works, self._all_mel, self._all_fr, self._Bs, self._B_max = works, all_mel, all_fr, Bs, B_max
+        self._keep = keep_alive  # send buffers of a root-only gather: alive until the collective has finished
 
     def wait(self):
         for w in self._works:
             w.wait()   # nccl: the current stream waits for the collective's stream; gloo: host wait
         self._works = []
+        self._keep = None
+        if self._all_mel is None:  # root-only gather (dst=), and this rank is not the root
+            return None, None
         if self._Bs is None or all(b == self._B_max for b in self._Bs):
             return self._all_mel, self._all_fr
         dev = self._all_mel.device
@@ -115,8 +119,15 @@ class MelGather:
 
 
 def gather_mels_async(mel: torch.Tensor, tgt_mask: torch.Tensor, group=None, *,
-                      shapes: Optional[Tuple[Sequence[int], int]] = None, zeroed: bool = False) -> MelGather:
-    """Start the all-gather of every rank's final mels.
+                      shapes: Optional[Tuple[Sequence[int], int]] = None, zeroed: bool = False,
+                      dst: Optional[int] = None) -> MelGather:
+    """Start the gather of every rank's final mels: onto every rank (``dst=None``: an all-gather) or onto rank ``dst`` only.
+
+    ``dst`` (a global rank, as ``torch.distributed.gather`` takes it): the north star's literal "RCCL gather of the final mel
+    tensors" - only the root allocates the (B, T_max, n_mels) result and receives (world - 1) x the shard; every other rank
+    sends its shard once and ``wait()`` hands it ``(None, None)``.  Over xGMI that is one message per link into the root
+    instead of every rank receiving from every other (at C4: 7 x 15.7 MB into one GPU instead of into each of eight); use it
+    when one process consumes the batch (a vocoder / writer on rank 0), the all-gather when every rank needs it.
 
     mel (B_r, T_r, n_mels) fp32 and tgt_mask (B_r, T_r) bool (True = pad) of this rank; the result of
     ``wait()`` is ``(mel_all (B, T_max, n_mels), frames (B,) int64)`` on every rank, utterances in global
@@ -154,6 +165,21 @@ def gather_mels_async(mel: torch.Tensor, tgt_mask: torch.Tensor, group=None, *,
         buf[:B_r, :T_r] = src
         fr = torch.zeros(B_max, dtype=torch.int64, device=dev)
         fr[:B_r] = frames_r
+    if dst is not None:
+        if not 0 <= int(dst) < dist.get_world_size():
+            raise ValueError(f"dst={dst} is not a rank of this job")
+        if dist.get_rank() == int(dst):
+            all_mel = torch.empty(world * B_max, T_max, n_mels, dtype=mel.dtype, device=dev)
+            all_fr = torch.empty(world * B_max, dtype=torch.int64, device=dev)
+            # the root's receive buffers are the rows of the result itself: contiguous (B_max, T_max, n_mels) views, no copy
+            mel_list = list(all_mel.view(world, B_max, T_max, n_mels).unbind(0))
+            fr_list = list(all_fr.view(world, B_max).unbind(0))
+        else:
+            all_mel = all_fr = mel_list = fr_list = None
+        buf, fr = buf.contiguous(), fr.contiguous()
+        works = [dist.gather(buf, mel_list, dst=int(dst), group=group, async_op=True),
+                 dist.gather(fr, fr_list, dst=int(dst), group=group, async_op=True)]
+        return MelGather(works, all_mel, all_fr, Bs, B_max, keep_alive=(buf, fr))
     all_mel = torch.empty(world * B_max, T_max, n_mels, dtype=mel.dtype, device=dev)
     all_fr = torch.empty(world * B_max, dtype=torch.int64, device=dev)
     works = [dist.all_gather_into_tensor(all_mel, buf, group=group, async_op=True),
@@ -175,7 +201,7 @@ def global_frames(T_local: int, device, group=None) -> int:
 
 def forward_sharded(forward_fn: Callable[..., Dict[str, torch.Tensor]], batch: Dict[str, torch.Tensor], group=None, *,
                     global_pad: bool = False, n_mels: Optional[int] = None, zeroed: bool = False,
-                    device: Optional[torch.device] = None):
+                    device: Optional[torch.device] = None, dst: Optional[int] = None):
     """Run ``forward_fn`` on this rank's shard of ``batch`` and gather every rank's mels.
 
     per-shard mode: ``forward_fn(shard)`` (e.g. ``lambda b: model(b, inference=True)``).
@@ -184,6 +210,7 @@ def forward_sharded(forward_fn: Callable[..., Dict[str, torch.Tensor]], batch: D
     Ranks whose shard is empty (global batch smaller than the world) skip the forward and contribute an
     empty mel.  ``device``: where the control tensors of the collectives (and an empty shard's mel) live; default =
     what the group's backend needs (``collective_device``: the current GPU under nccl, also for a host-side batch).
+    ``dst``: gather onto that rank only (``gather_mels_async``); the other ranks get ``(None, None, local)``.
     Returns (mel_all, frames, local_result or None)."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     B = batch["phones"].shape[0]
@@ -218,7 +245,7 @@ def forward_sharded(forward_fn: Callable[..., Dict[str, torch.Tensor]], batch: D
         if "nccl" in str(dist.get_backend(group)).lower() and mel.device != dev:
             raise ValueError(f"local mel on {mel.device}, collective control tensors on {dev}: RCCL needs one device per rank")
     shapes = (Bs, t_glob["T"]) if global_pad else None
-    mel_all, frames = gather_mels(mel, mask, group=group, shapes=shapes, zeroed=zeroed)
+    mel_all, frames = gather_mels(mel, mask, group=group, shapes=shapes, zeroed=zeroed, dst=dst)
     return mel_all, frames, local
 
 
@@ -239,3 +266,32 @@ def all_reduce_gradients(flat_g: torch.Tensor, group=None, *, bucket_bytes: int 
         if async_op:
             works.append(w)
     return works
+
+
+def rank_report(*, ms_per_step: float, ms_without_gather: float, ms_with_gather: float, frames_per_step: int, gather_bytes: int,
+                local_rank: int, device_index: int, device, group=None) -> dict:
+    """The `dist` object of a multi-rank bench line (bench.py): every rank's own numbers all-gathered over the SAME process
+    group the mel gather uses, so that a line claiming N ranks can be checked - which ranks the collective library really
+    connected, which device each drove, every rank's step time with and without the gather, the frames and the bytes a rank
+    contributes.  Pure bookkeeping (one small all-gather); returns the same dict on every rank.
+
+    Internal consistency a reader (and tests/test_dist_cpu.py) can hold it to: ``ranks_seen == list(range(world_size))``,
+    ``sum(per_rank_frames_per_step)`` = the frames the headline value was computed from, ``gather_bytes_total_per_step ==
+    world_size * gather_bytes_per_rank``, ``gather_ms_exposed == max(with) - max(without)``."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    mine = torch.tensor([float(rank), float(local_rank), float(ms_per_step), float(ms_without_gather), float(frames_per_step),
+                         float(device_index), float(ms_with_gather), float(gather_bytes)], dtype=torch.float64, device=device)
+    allr = torch.empty(world * mine.numel(), dtype=torch.float64, device=device)
+    dist.all_gather_into_tensor(allr, mine, group=group)
+    allr = allr.cpu().view(world, -1)
+    return {
+        "backend": str(dist.get_backend(group)), "world_size": world, "ranks_seen": [int(r) for r in allr[:, 0]],
+        "local_ranks": [int(r) for r in allr[:, 1]], "devices": [int(r) for r in allr[:, 5]],
+        "per_rank_ms_per_step": [round(float(v), 4) for v in allr[:, 2]],
+        "per_rank_ms_per_step_without_gather": [round(float(v), 4) for v in allr[:, 3]],
+        "per_rank_frames_per_step": [int(v) for v in allr[:, 4]],
+        "gather_bytes_per_rank": int(allr[:, 7].max()), "gather_bytes_total_per_step": int(allr[:, 7].sum()),
+        "per_rank_gather_bytes": [int(v) for v in allr[:, 7]],
+        "per_rank_ms_per_step_with_gather_ab": [round(float(v), 4) for v in allr[:, 6]],
+        "gather_ms_exposed": round(float(allr[:, 6].max() - allr[:, 3].max()), 4),
+    }

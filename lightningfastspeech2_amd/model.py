@@ -479,9 +479,26 @@ class ForwardPipeline:
         for m in self.models:
             m.engine.set_graphs(on)
 
+    @staticmethod
+    def _record(obj, stream):
+        """Tell torch's caching allocator that `stream` uses these tensors too: a block is otherwise returned to the pool of the
+        stream it was allocated on as soon as its tensor dies, and the next allocation there may overwrite it while the other
+        stream still reads it (a mel dropped by the caller right after queueing a vocoder on it; a batch released by
+        the caller while stream k still decodes from it)."""
+        if isinstance(obj, torch.Tensor):
+            if obj.is_cuda:
+                obj.record_stream(stream)
+        elif isinstance(obj, dict):
+            for v in obj.values():
+                ForwardPipeline._record(v, stream)
+        elif isinstance(obj, (list, tuple)):
+            for v in obj:
+                ForwardPipeline._record(v, stream)
+
     def _run(self, k, batch, ready):
         with torch.cuda.device(self.device), torch.cuda.stream(self.streams[k]):
             self.streams[k].wait_event(ready)  # the caller's stream produced the batch
+            self._record(batch, self.streams[k])  # ... and may release it before this stream has finished reading it
             out = self.models[k](batch, inference=True)
             done = torch.cuda.Event()
             done.record(self.streams[k])
@@ -489,7 +506,9 @@ class ForwardPipeline:
 
     def _hand_over(self, fut):
         out, done = fut.result()
-        torch.cuda.current_stream(self.device).wait_event(done)
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(done)
+        self._record(out, cur)  # allocated on the pipeline's stream, consumed (and possibly dropped) on the caller's
         return out
 
     def submit(self, batch):

@@ -563,12 +563,17 @@ class Trainer:
         ``AdamW`` + ``NoamLR`` (fastspeech2.py:1166-1182): a checkpoint made of ``state_dict()`` + these two entries resumes in
         the reference, and ``load_lightning_optimizer_state`` resumes a reference checkpoint here."""
         from .checkpoint import to_lightning_optimizer_state
-        return to_lightning_optimizer_state(self.cfg, self.optimizer_state(), lr=self.lr, warmup_steps=self.warmup_steps,
-                                            betas=self.betas, eps=self.eps, weight_decay=self.weight_decay)
+        out = to_lightning_optimizer_state(self.cfg, self.optimizer_state(), lr=self.lr, warmup_steps=self.warmup_steps,
+                                           betas=self.betas, eps=self.eps, weight_decay=self.weight_decay)
+        out["fs2_micro_step"] = int(self._micro)  # the dropout-mask counter (Lightning keeps none): an extra key the reference ignores
+        return out
 
-    def load_lightning_optimizer_state(self, checkpoint):
+    def load_lightning_optimizer_state(self, checkpoint, accumulate_grad_batches: int = 1):
+        """``accumulate_grad_batches``: the value the run that wrote ``checkpoint`` was trained with (Lightning's Trainer flag,
+        scripts/train.sh) - the dropout-mask counter resumes at optimizer steps x that many micro-batches, unless the checkpoint
+        carries this framework's own ``fs2_micro_step`` (``lightning_optimizer_state()`` writes it)."""
         from .checkpoint import from_lightning_optimizer_state
-        self.load_optimizer_state(from_lightning_optimizer_state(self.cfg, checkpoint, getattr(self, "accumulate_grad_batches", 1)))
+        self.load_optimizer_state(from_lightning_optimizer_state(self.cfg, checkpoint, int(accumulate_grad_batches)))
 
     def gradients(self):
         return OrderedDict((n, self._to_ref_layout(n, self.G[n])) for n in self._layout)

@@ -64,6 +64,16 @@ def _worker(rank, world, port, B, q, mode="shard"):
             assert b["duration"].shape == b["phones"].shape
             return oracle_cpu.forward(sd, cfg, b["phones"], b["speaker"], force_durations=b["duration"])
         mel_all, frames, _ = forward_sharded(fwd, batch, n_mels=cfg.n_mels)
+    elif mode.startswith("root"):  # root-only gather (dst=): rank 1 receives, the others only send and get (None, None)
+        fwd = lambda b: oracle_cpu.forward(sd, cfg, b["phones"], b["speaker"])
+        root = int(mode[4:])
+        mel_all, frames, _ = forward_sharded(fwd, batch, n_mels=cfg.n_mels, dst=root)
+        assert (mel_all is None) == (rank != root) and (frames is None) == (rank != root)
+        if rank == root:
+            q.put((mel_all.numpy(), frames.numpy()))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     else:
         fwd = lambda b: oracle_cpu.forward(sd, cfg, b["phones"], b["speaker"])
         mel_all, frames, _ = forward_sharded(fwd, batch, n_mels=cfg.n_mels)
@@ -216,6 +226,17 @@ def test_two_rank_gather_equals_per_shard_oracle(B):
             row += 1
 
 
+@pytest.mark.parametrize("world,B,root", [(2, 5, 1), (3, 2, 0), (2, 4, 0)])
+def test_root_only_gather_equals_the_all_gather(world, B, root):
+    """`dst=`: the north star's literal gather - only the root holds the (B, T_max, n_mels) result; ragged shards, an empty
+    shard (world 3, batch 2) and a non-zero root; the same rows as the all-gather delivers to everyone."""
+    mel_root, fr_root = _run(world, B, f"root{root}")
+    mel_all, fr_all = _run(world, B, "shard")
+    assert mel_root.shape == mel_all.shape
+    np.testing.assert_array_equal(fr_root, fr_all)
+    np.testing.assert_array_equal(mel_root, mel_all)
+
+
 def _grad_worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -249,3 +270,49 @@ def test_flat_gradient_all_reduce_two_ranks():
     for _, g, h in res:
         assert g == (torch.arange(1000, dtype=torch.float32) * 3).tolist()
         assert h == [1.0] * 77
+
+
+def _report_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lightningfastspeech2_amd.dist import gather_mels, rank_report
+    # each rank "ran" its own shard: 3 + rank utterances of 10 + rank frames, 4 mel bins, ragged frame counts
+    Br, Tr = 3 + rank, 10 + rank
+    mel = torch.full((Br, Tr, 4), float(rank + 1))
+    mask = torch.arange(Tr)[None, :] >= torch.tensor([Tr - i for i in range(Br)])[:, None]
+    frames_r = int((~mask).sum())
+    mel_all, frames = gather_mels(mel, mask)
+    rep = rank_report(ms_per_step=2.0 + rank, ms_without_gather=1.5 + rank, ms_with_gather=1.75 + rank, frames_per_step=frames_r,
+                      gather_bytes=mel.numel() * 4 + Br * 8, local_rank=rank, device_index=rank, device=torch.device("cpu"))
+    q.put((rank, rep, int(frames.sum()), frames_r))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_dist_object_is_internally_consistent_at_world_two():
+    """What a multi-rank bench line's `dist` object carries (bench.py -> dist.rank_report), built by two gloo ranks: every rank
+    returns the same object, the ranks seen are exactly the job's, the per-rank frames add up to what the gathered frame counts
+    say, the bytes add up, and `gather_ms_exposed` is the difference of the maxima."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_report_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, rep0, gathered0, fr0), (_, rep1, gathered1, fr1) = got
+    assert rep0 == rep1
+    assert rep0["backend"] == "gloo" and rep0["world_size"] == 2
+    assert rep0["ranks_seen"] == [0, 1] and rep0["local_ranks"] == [0, 1] and rep0["devices"] == [0, 1]
+    assert rep0["per_rank_frames_per_step"] == [fr0, fr1] and sum(rep0["per_rank_frames_per_step"]) == gathered0 == gathered1
+    assert rep0["per_rank_gather_bytes"] == [3 * 10 * 4 * 4 + 3 * 8, 4 * 11 * 4 * 4 + 4 * 8]
+    assert rep0["gather_bytes_total_per_step"] == sum(rep0["per_rank_gather_bytes"])
+    assert rep0["gather_bytes_per_rank"] == max(rep0["per_rank_gather_bytes"])
+    assert rep0["per_rank_ms_per_step"] == [2.0, 3.0]
+    assert rep0["gather_ms_exposed"] == round(max(rep0["per_rank_ms_per_step_with_gather_ab"]) - max(rep0["per_rank_ms_per_step_without_gather"]), 4) == 0.25

@@ -22,6 +22,10 @@ from oracle import oracle_cpu
 pytestmark = pytest.mark.gpu
 
 MEL_TOL_FP32 = 1e-3
+# bf16 (throughput mode) under the oracle's decisions, measured r04 (gpurun_out/parity_report.jsonl): mel max-abs 0.014-0.018, mean
+# 0.0023-0.0030 on O(1)-scale mels (scale 2.5-2.8), encoder output 0.054-0.062.  Asserted at <= 3.5x the measurement (VERDICT r04 weak 2:
+# the bounds were 15-20x).
+BF16_MEL_MAX, BF16_MEL_MEAN, BF16_ENC_MAX = 0.06, 0.008, 0.15
 REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_report.jsonl")
 
 
@@ -174,8 +178,8 @@ def test_bf16_close_under_forced_durations(case):
             mel_max=float(err.max()), mel_mean=float(err.mean()), encoder_out_max=enc,
             mel_scale=float(ref["mel"].abs().max()))
     assert torch.isfinite(out["mel"]).all()
-    assert enc <= 0.15                      # bf16 rounding (2^-8) through 4 post-LN layers of O(1) activations
-    assert float(err.mean()) <= 0.03 and float(err.max()) <= 0.3  # bf16 tolerance, NOT the 1e-3 claim
+    assert enc <= BF16_ENC_MAX              # bf16 rounding (2^-8) through 4 post-LN layers of O(1) activations
+    assert float(err.mean()) <= BF16_MEL_MEAN and float(err.max()) <= BF16_MEL_MAX  # bf16 tolerance, NOT the 1e-3 claim
 
 
 def _decisions(m, cfg, batch, ref):
@@ -208,7 +212,7 @@ def test_mixed_precision_is_decision_safe(case, mode):
             mixed=dict(duration_flips=dmx, bucket_flips=bmx, mel_forced=emx))
     assert dmx == 0 and torch.equal(free["tgt_mask"], ref["tgt_mask"])
     assert bmx <= max(2, b16 // 10)
-    assert emx <= 0.3  # the decoder is bf16: same tolerance as the all-bf16 mode under forced decisions
+    assert emx <= BF16_MEL_MAX  # the decoder is bf16: same tolerance as the all-bf16 mode under forced decisions
     for v in cfg.variances[:1]:  # the first predictor sees fp32 inputs identical to the parity mode's
         assert float((free[f"variances_{v}"] - ref[f"variances_{v}"]).abs().max()) <= 1e-3
 
@@ -257,7 +261,7 @@ def test_deferred_layernorm_matches_its_own_launches(cwt):
     x = m16.forward(batch, force_durations=ref["duration_rounded"], force_buckets={v: ref["_intermediates"][f"bucket_{v}"] for v in cfg.variances})
     m16.engine.set_deferred_layernorm(False)
     y = m16.forward(batch, force_durations=ref["duration_rounded"], force_buckets={v: ref["_intermediates"][f"bucket_{v}"] for v in cfg.variances})
-    assert float((x["mel"] - y["mel"]).abs().max()) <= 0.15 and float((x["mel"].cpu() - ref["mel"]).abs().mean()) <= 0.03
+    assert float((x["mel"] - y["mel"]).abs().max()) <= BF16_MEL_MAX and float((x["mel"].cpu() - ref["mel"]).abs().mean()) <= BF16_MEL_MEAN
 
 
 def test_full_size_properties_bf16():
@@ -369,9 +373,9 @@ def test_full_size_full_batch_fp32_and_mixed_vs_oracle():
         elif mode == "fp32x3":  # the parity-grade mode at a third of the time: the fp32 bar on the whole tensor
             assert forced <= MEL_TOL_FP32 and bfl <= max(10 * rep["fp32"]["bucket_flips"], nb // 100)
         elif mode != "bf16":
-            assert forced <= 0.3 and bfl <= max(10 * rep["fp32"]["bucket_flips"], nb // 50)
+            assert forced <= BF16_MEL_MAX and bfl <= max(10 * rep["fp32"]["bucket_flips"], nb // 50)
         else:
-            assert forced <= 0.3
+            assert forced <= BF16_MEL_MAX
     _report(test="fullsize_fullbatch", **rep)
     assert rep["mixed3"]["bucket_flips"] * 10 <= rep["bf16"]["bucket_flips"]
 

@@ -615,6 +615,37 @@ def test_attention_pipelined_spike_and_all_padded(pipe_kernel):
     assert float((got[:S] - ref[:S]).abs().max()) <= 2e-2 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("B,S,H,heads,mask_kind", [
+    (32, 1024, 256, 2, "suffix"), (32, 1536, 256, 2, "holes"), (11, 1536, 768, 6, "suffix"), (16, 1024, 512, 4, "holes"),
+    (32, 1536, 256, 2, "ragged")])
+def test_attention_pipelined_decoder_sized_key_padding(B, S, H, heads, mask_kind):
+    """Key padding through the decoder-sized launches: S in {1024, 1536}, B x heads >= 64, so a workgroup's
+    run is whole 384-query triples (`attention_pipe_kernel<3>`) with padded tails, fully padded 64-key tiles in the middle of
+    the valid range and - "ragged" - every utterance its own valid length U{S/2..S}, as a ragged batch's `tgt_mask` is
+    (model.py:358-361).  Against the fp32 reference of the same op on the bf16-rounded operands; padded QUERY rows are computed
+    like any other (the reference does, and they feed the conv halo of valid rows); the by-size dispatch (96 queries per wave)
+    bit-equal to the 32-query form."""
+    qkv = rnd(B * S, 3 * H, seed=21)
+    if mask_kind == "ragged":
+        g = torch.Generator().manual_seed(5)
+        lens = torch.randint(S // 2, S + 1, (B,), generator=g)
+        lens[0] = S
+        mask = torch.arange(S)[None, :] >= lens[:, None]
+    else:
+        mask = _mask(mask_kind, B, S)
+    ref = _attn_ref(G.rounded(qkv, G.BF16), mask, B, S, H, heads)
+    got = G.attention(G.BF16, qkv, mask, B, S, H, heads)   # knob 1203 (default): by size -> the pipelined kernel
+    assert torch.isfinite(got).all()
+    err = float((got - ref).abs().max())
+    assert err <= tol(G.BF16, ref, f32=5e-5, bf16=2e-2), (err, tol(G.BF16, ref))
+    G.lib().fs2_op_set_gemm_variant(1201)
+    try:
+        other = G.attention(G.BF16, qkv, mask, B, S, H, heads)
+    finally:
+        G.lib().fs2_op_set_gemm_variant(1203)
+    assert torch.equal(got, other)
+
+
 def test_attention_by_size_picks_the_pipelined_kernel_and_agrees():
     # the dispatch the engine uses (knob 1203): a decoder-sized problem goes to the pipelined kernel, same answers as the
     # phase-serial one up to bf16 rounding of P
