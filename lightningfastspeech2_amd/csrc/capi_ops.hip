@@ -113,6 +113,7 @@ static int set_gemm_variant(int32_t variant) {
     if (variant == 500 || variant == 501) { fs2::g_split_f32 = variant - 500; return FS2_OK; }       // 500 / 501: fp32 slab launches as fp32 MFMA / bf16 x 3 split
     if (variant == 310 || variant == 311) { fs2::g_defer_mi8 = variant - 310; return FS2_OK; }  // deferred-LayerNorm GEMM epilogue: 192-row tiles only / 256-row tiles admitted
     if (variant == 300 || variant == 301) { fs2::g_wide_ln = variant - 300; return FS2_OK; }         // 300 / 301: fused LayerNorm for N > 256 off / on
+    if (variant == 220 || variant == 221) { fs2::g_gemm_persist = variant - 220; return FS2_OK; }    // 220 / 221: multi-round bf16 slab launches one tile per workgroup / on the persistent kernel (default)
     if (variant == 210 || variant == 211) { fs2::g_slab_ring = variant - 210; return FS2_OK; }       // 210 / 211: pointwise launches on <= 128-row tiles: two-stage loop (default) / operand ring
     if (variant == 200 || variant == 201) { fs2::g_slab_xcd_remap = variant - 200; return FS2_OK; }  // 200 / 201: tile order knob
     if (variant >= 0 && variant < 200) { fs2::g_gemm_variant = variant; return FS2_OK; }              // kernel family / forced tile height of the forward GEMM launcher (gemm_mfma.hip: launch_gemm)

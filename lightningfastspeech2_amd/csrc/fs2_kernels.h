@@ -68,6 +68,11 @@ extern int g_gemm_variant;
 extern int g_gemm_wres;  // 1 = bf16 K = 256 plain GEMMs on the weight-resident kernel (gemm_wres.hip)
 bool gemm_wres_supported(const GemmArgs& a, int in_dtype, int out_dtype, bool force);
 int launch_gemm_wres(const GemmArgs& a, hipStream_t stream);
+// gemm_persist.hip: the slab kernel's persistent form (one workgroup per CU walks its tiles; bit-identical results)
+extern int g_gemm_persist;
+bool gemm_persist_supported(const GemmArgs& a, int in_dtype, int out_dtype, int mi);
+bool gemm_persist_pays(const GemmArgs& a, int mi);
+int launch_gemm_persist(const GemmArgs& a, int mi, hipStream_t stream);
 extern int g_wide_ln;
 extern int g_defer_mi8;
 extern int g_split_f32;

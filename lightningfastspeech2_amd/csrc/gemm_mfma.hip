@@ -1627,6 +1627,10 @@ static int launch_gemm_plain(const GemmArgs& a, int in_dtype, int out_dtype, hip
             if (!best || cost < best_cost) { best = mi; best_cost = cost; best_rows = (long)nutt * tm * bm; }
         }
         if (best_rows <= 2L * a.M || a.C_lo || a.w_presplit) {  // (the head + tail store / pre-split weights exist in this kernel only)
+            // more tiles than CUs: one workgroup per CU walks them, the next tile's first operands under this tile's epilogue
+            // (gemm_persist.hip; same tile height, same arithmetic per element - bit-identical)
+            if (!fused && g_gemm_persist && gemm_persist_supported(a, in_dtype, out_dtype, best) && gemm_persist_pays(a, best))
+                return launch_gemm_persist(a, best, stream);
             if (fused) *fused = true;
             if (best == 1) return launch_slab<1>(a, in_dtype, out_dtype, stream);
             if (best == 2) return launch_slab<2>(a, in_dtype, out_dtype, stream);

@@ -74,6 +74,42 @@ def test_wres_gemm_is_bit_identical_to_the_slab_kernel(M, N, relu, bias):
     assert float((got - ref).abs().max()) <= tol(G.BF16, ref)
 
 
+@pytest.mark.parametrize("M,N,K,relu,add", [
+    (49152, 2304, 768, False, False),   # C3 decoder in-projection: 256-row tiles, 6.75 tiles per workgroup
+    (49152, 3072, 768, True, False),    # C3 FFN pointwise conv1.1 (+ ReLU): 9 tiles per workgroup
+    (49152, 768, 3072, False, True),    # C3 conv2 / out-projection shape with the residual in the accumulators (deferred epilogue, 192-row tiles)
+    (49152, 768, 768, False, True),
+    (36864, 768, 768, True, False),     # predictor-sized pointwise + ReLU
+    (50000, 712, 384, False, False),    # ragged last row tile AND a column tail (N = 2 x 256 + 200): the uncounted-wait path
+    (50000, 712, 384, False, True),
+    (70001, 256, 128, True, False),     # two K steps per tile (the shortest stream the kernel takes), one column tile, odd row count
+    (24576, 1024, 1024, False, False)])
+def test_persistent_gemm_is_bit_identical_to_the_slab_kernel(M, N, K, relu, add):
+    """gemm_persist.hip (knob 221, default): bf16 pointwise launches of more tiles than CUs on ONE workgroup per CU that walks its
+    tiles - the next tile's first operands requested inside this tile's last K step, the epilogue's stores left in flight behind
+    a counted wait - against the one-tile-per-workgroup slab kernel (knob 220): the same MFMA sequence per output element, so
+    the same bits; plain (bias, ReLU) epilogue and the residual-in-the-accumulators epilogue; twice (tile hand-over races would
+    show as run-to-run differences), and within the bf16 tolerance of the fp32 reference."""
+    x, w = rnd(M, K, seed=31), rnd(N, K, seed=32) / math.sqrt(K)
+    b = rnd(N, seed=33)
+    addend = rnd(M, N, seed=34) if add else None
+    run = (lambda: G.gemm_add(G.BF16, x, w, b, addend, in_place=False)) if add else (lambda: G.gemm(G.BF16, x, w, b, relu=relu))
+    try:
+        G.lib().fs2_op_set_gemm_variant(220)
+        old = run()
+        G.lib().fs2_op_set_gemm_variant(221)
+        got = run()
+        again = run()
+    finally:
+        G.lib().fs2_op_set_gemm_variant(221)
+    assert torch.equal(got, old) and torch.equal(got, again)
+    ref = G.rounded(x, G.BF16) @ G.rounded(w, G.BF16).T + b
+    ref = ref.clamp_min(0) if relu else ref
+    if add:
+        ref = ref + G.rounded(addend, G.BF16)
+    assert float((got - ref).abs().max()) <= tol(G.BF16, ref)
+
+
 @pytest.mark.parametrize("dtype", [G.BF16, G.F32])
 @pytest.mark.parametrize("M,N,K,variant,ln", [(8192, 256, 1024, 6, True), (8192, 256, 256, 6, True), (2048, 768, 256, 7, False),
                                               (1024, 256, 320, 6, True), (96 * 5 + 7, 512, 192, 3, False), (2048, 256, 1024, 3, True),

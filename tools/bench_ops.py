@@ -245,6 +245,9 @@ def main():
     a = ap.parse_args()
     if a.flush:
         FLUSH[0] = torch.zeros(a.flush * 1024 * 1024 // 4, device=DEV)
+    for k in [k for k in os.environ.get("FS2_GEMM_KNOBS", "").split(",") if k]:  # A/B knobs that are not kernel-family variants (210 / 211, 220 / 221 ...)
+        if lib.fs2_op_set_gemm_variant(int(k)) != 0:
+            raise SystemExit(f"knob {k} rejected")
     global gemm_case, attn_case, gemm_ln_case, bgemm_case
     if a.only:
         g0, a0, l0, b0 = gemm_case, attn_case, gemm_ln_case, bgemm_case
