@@ -316,6 +316,8 @@ def main():
         model.engine.set_fused_predictor(False)
     if os.environ.get("FS2_DEFER_LN") == "0":  # A/B: one launch per LayerNorm in the wide depth-wise blocks
         model.engine.set_deferred_layernorm(False)
+    if os.environ.get("FS2_FOLD_LN") == "0":  # A/B: a normalise-only pass per wide depth-wise block instead of folding norm2 into the next in-projection
+        model.engine.set_folded_layernorm(False)
     def set_knob(k):  # a mistyped knob must not yield an unlabeled default-config measurement
         r = _lib.load().fs2_op_set_gemm_variant(int(k))
         if r != 0:
@@ -410,6 +412,8 @@ def main():
                     m.engine.set_fused_predictor(False)
                 if os.environ.get("FS2_DEFER_LN") == "0":
                     m.engine.set_deferred_layernorm(False)
+                if os.environ.get("FS2_FOLD_LN") == "0":
+                    m.engine.set_folded_layernorm(False)
     for n in flights:
         cur["in_flight"] = n
         for mode in ("eager", "graphs"):

@@ -182,6 +182,10 @@ int64_t fs2_graph_replays(const fs2_engine* e);
  * next residual add normalise on load and the remaining LayerNorms are normalise-only passes; 0 = GEMM launch + LayerNorm
  * launch everywhere (the round-1 path). */
 int fs2_set_deferred_layernorm(fs2_engine* e, int32_t on);
+/* A/B: 1 (default) = inside a stack of wide depth-wise blocks (bf16) a block's closing LayerNorm is not materialised either: the
+ * next block's in-projection runs on the pre-norm rows with gamma / beta folded into its weights (fs2_op_gemm_rowscale) and its
+ * out-projection normalises the residual on load; 0 = one normalise-only pass per block.  Needs deferred LayerNorm on. */
+int fs2_set_folded_layernorm(fs2_engine* e, int32_t on);
 /* Parity aid (the analogue of the reference's teacher forcing of variance targets,
  * model.py:417-422): the NEXT fs2_decode embeds these (B, T) int32 device bucket indices for
  * variance `variance_index` instead of bucketizing its own prediction.  One-shot. */
@@ -256,6 +260,16 @@ int fs2_op_gemm_relu_dropout(int32_t dtype, const void* x, const void* w, const 
  * FS2_ERR_SHAPE when the shape does not run on the slab kernel (N < 192, M % S != 0, even tap count). */
 int fs2_op_gemm_add(int32_t dtype, const void* x, const void* w, const float* bias, const void* addend, void* c, int32_t M, int32_t N,
                     int32_t Cin, int32_t taps, int32_t S, void* hip_stream);
+/* c = LayerNorm(v) w0^T + bias0 evaluated on the PRE-norm rows v = x (bf16): the caller folds gamma / beta into the operands
+ * (w = w0 diag(gamma) as stored in bf16, bias = bias0 + w0 beta, wg[n] = sum_k w[n][k]) and hands over v's finished row
+ * statistics rowstats (M) float2 (rstd, rstd * mean) (fs2_op_rowstats_finish); the epilogue applies
+ * c[m][n] = rstd[m] * acc - rstd[m] * mean[m] * wg[n] + bias[n].  What the engine's in-projection does behind a deferred norm2
+ * (litfass/fastspeech2/model.py:113-115) instead of a normalise-only pass.  bf16 only, N >= 192; FS2_ERR_SHAPE otherwise. */
+int fs2_op_gemm_rowscale(const void* x, const void* w, const float* bias, const float* rowstats, const float* wg,
+                         void* c, int32_t M, int32_t N, int32_t Cin, void* hip_stream);
+/* parts (M, nparts) float2 partial (sum, sum of squares) over ncols columns per row - what the deferred-LayerNorm GEMM epilogue
+ * leaves, one per 256-column tile - -> out (M) float2 (rstd, rstd * mean) */
+int fs2_op_rowstats_finish(const float* parts, int32_t nparts, int32_t ncols, float eps, float* out, int32_t M, void* hip_stream);
 /* Split-K form for long reductions over few row tiles (training step: the encoder-side data-gradient convs, M = B L rows, K = taps x
  * filter): ksplit (from fs2_op_gemm_splitk_choice; 1 = not worth it -> use fs2_op_gemm) slices of the input channels run as separate
  * workgroups of ONE launch into fp32 planes part (ksplit, M, N), a second launch adds the planes in order:

@@ -124,6 +124,7 @@ def load():
     lib.fs2_graph_replays.restype = C.c_int64
     lib.fs2_graph_replays.argtypes = [vp]
     lib.fs2_set_deferred_layernorm.argtypes = [vp, i32]
+    lib.fs2_set_folded_layernorm.argtypes = [vp, i32]
     lib.fs2_debug_copy.argtypes = [vp, C.c_char_p, vp, vp]
     lib.fs2_force_buckets.argtypes = [vp, i32, vp]
     lib.fs2_force_variance_targets.argtypes = [vp, i32, vp]
@@ -146,6 +147,8 @@ def load():
     lib.fs2_op_gemm.argtypes = [i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     lib.fs2_op_gemm_relu_dropout.argtypes = [i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, C.c_float, C.c_uint64, C.c_uint64, vp]
     lib.fs2_op_gemm_add.argtypes = [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    lib.fs2_op_gemm_rowscale.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]
+    lib.fs2_op_rowstats_finish.argtypes = [vp, i32, i32, C.c_float, vp, i32, vp]
     lib.fs2_op_gemm_splitk_choice.argtypes = [i32, i32, i32, i32, i32, i32]
     lib.fs2_op_gemm_splitk.argtypes = [i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.fs2_op_gemm_gated.argtypes = [i32, vp, vp, vp, vp, C.c_float, vp, i32, i32, i32, i32, i32, vp]

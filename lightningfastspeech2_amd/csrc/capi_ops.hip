@@ -158,6 +158,21 @@ int fs2_op_gemm_add(int32_t dtype, const void* x, const void* w, const float* bi
     return launch_gemm(a, dtype, dtype, (hipStream_t)stream);
 }
 
+int fs2_op_gemm_rowscale(const void* x, const void* w, const float* bias, const float* rowstats, const float* wg,
+                         void* c, int32_t M, int32_t N, int32_t Cin, void* stream) {
+    if (!x || !w || !bias || !rowstats || !wg || !c) return FS2_ERR_ARG;
+    GemmArgs a;
+    a.X = x; a.W = w; a.bias = bias; a.C = c;
+    a.M = M; a.N = N; a.K = Cin; a.ldx = Cin; a.ldc = N;
+    a.Cin = Cin; a.taps = 1; a.pad = 0; a.S = M; a.relu = 0;
+    a.rs_stats = rowstats; a.rs_wg = wg;
+    if (N < 192) return FS2_ERR_SHAPE;
+    return launch_gemm(a, FS2_BF16, FS2_BF16, (hipStream_t)stream);
+}
+int fs2_op_rowstats_finish(const float* parts, int32_t nparts, int32_t ncols, float eps, float* out, int32_t M, void* stream) {
+    return launch_rowstats_finish(parts, nparts, ncols, eps, out, M, (hipStream_t)stream);
+}
+
 int fs2_op_gemm_splitk_choice(int32_t dtype, int32_t M, int32_t N, int32_t Cin, int32_t taps, int32_t S) {
     return gemm_splitk_choice(M, N, Cin, taps, S, dtype);
 }

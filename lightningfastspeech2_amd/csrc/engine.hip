@@ -80,6 +80,12 @@ struct LayerW {
     bool depthwise = false;
     DwW dw;          // conv1.0 (depth-wise only)
     ConvW c1, c2;    // dense: conv1 (k taps) / conv2; depth-wise: conv1.1 / folded conv2.0*conv2.1
+    // layer i >= 1 of a stack of wide depth-wise bf16 blocks: the in-projection with the PREVIOUS block's norm2 folded in -
+    // W' = W_in diag(gamma2), b' = b_in + W_in beta2, in_wg[n] = sum_k W'[n][k] (of the bf16 values as stored) - for
+    // fs2_op_gemm_rowscale's epilogue on the previous block's pre-norm output (no normalise-only pass in between)
+    ConvW in_proj_f;
+    float* in_wg = nullptr;
+    bool has_fold = false;
 };
 struct PredLayerW {
     bool depthwise = false;
@@ -135,6 +141,7 @@ struct fs2_engine {
     long graph_replays = 0;
     bool zero_pad_mel = false;
     bool defer_ln = true;      // hidden > 256, depth-wise blocks: LayerNorm deferred into its consumers (A/B: fs2_set_deferred_layernorm)
+    bool fold_ln = true;       // ... and a block's closing norm2 folded into the next block's in-projection (bf16; A/B: fs2_set_folded_layernorm)
     bool front_split = false;  // FS2_MIXED_X3 / FS2_F32_X3: the fp32 GEMMs / convs (the front's / all of them) run as bf16 x 3 split products
     std::map<std::string, HostTensor> host;
     std::map<std::string, std::vector<int64_t>> spec;
@@ -426,6 +433,34 @@ int make_layer(fs2_engine* e, const std::string& p, int H, int F, bool dw, Layer
     }
     return FS2_OK;
 }
+// The in-projection of block `p` with the previous block's norm2 (`pp`.norm2) folded in: see LayerW::in_proj_f.  bf16 stacks of wide
+// depth-wise blocks only (the blocks whose LayerNorms are deferred, conformer()).
+int make_folded_in_proj(fs2_engine* e, const std::string& p, const std::string& pp, int H, LayerW* L) {
+    const HostTensor& w = W(e, p + ".self_attn.in_proj_weight");   // (3H, H)
+    const HostTensor& b = W(e, p + ".self_attn.in_proj_bias");
+    const HostTensor& g = W(e, pp + ".norm2.weight");
+    const HostTensor& be = W(e, pp + ".norm2.bias");
+    const int N = 3 * H;
+    std::vector<float> wf((size_t)N * H), bf(N), wg(N);
+    for (int n = 0; n < N; ++n) {
+        double bacc = b.data[n], gacc = 0;
+        for (int k = 0; k < H; ++k) {
+            const float v = (float)((double)w.data[(size_t)n * H + k] * g.data[k]);
+            wf[(size_t)n * H + k] = v;
+            bacc += (double)w.data[(size_t)n * H + k] * be.data[k];
+            gacc += (double)bf16_to_f32(f32_to_bf16(v));  // of the values the MFMAs will multiply with
+        }
+        bf[n] = (float)bacc;
+        wg[n] = (float)gacc;
+    }
+    L->in_proj_f.N = N; L->in_proj_f.Cin = H; L->in_proj_f.taps = 1; L->in_proj_f.dt = FS2_BF16;
+    CHK(upload_mat(e, wf.data(), wf.size(), &L->in_proj_f.w, FS2_BF16));
+    CHK(upload_f32(e, bf.data(), bf.size(), &L->in_proj_f.b));
+    CHK(upload_f32(e, wg.data(), wg.size(), &L->in_wg));
+    L->has_fold = true;
+    return FS2_OK;
+}
+
 int make_predictor(fs2_engine* e, const std::string& p, int nl, int filt, bool dw, PredictorW* P, int dt, bool cwt = false) {
     P->filt = filt;
     P->dt = dt;
@@ -525,12 +560,17 @@ struct LnFuse {  // optional fused epilogue: y = LN(act(gemm) [+ res]) [-> head]
     void* tmp = nullptr;  // (M, N) scratch for the unfused fallback
 };
 
+struct RowScale {  // x of the GEMM is a pre-norm tensor whose LayerNorm is folded into w (GemmArgs::rs_stats)
+    const float* rowstats;  // (M) float2 (rstd, rstd * mean): launch_rowstats_finish
+    const float* wg;
+};
 int gemm(fs2_engine* e, hipStream_t st, const ConvW& w, const void* x, void* c, int M, int S, bool relu, int out_dt,
          const LnFuse* ln = nullptr, int extra_class = -1, const uint8_t* zero_rows = nullptr, const Deferred* df = nullptr,
-         void* c_lo = nullptr) {
+         void* c_lo = nullptr, const RowScale* rs = nullptr) {
     GemmArgs a;
     a.zero_rows = zero_rows;
     a.C_lo = c_lo;
+    if (rs) { a.rs_stats = rs->rowstats; a.rs_wg = rs->wg; }
     if (df) {
         a.epi_res = df->res; a.epi_res_stats = df->res_stats; a.epi_res_g = df->res_g; a.epi_res_b = df->res_b;
         a.epi_res_parts = ln_parts(w.N); a.stats_out = df->stats_out; a.ln_eps = 1e-5f;
@@ -593,6 +633,7 @@ int norm_only(fs2_engine* e, hipStream_t st, int dt, const void* v, const float*
 
 struct LayerScratch {
     float *st1, *st2;  // deferred-LayerNorm row statistics (M, ln_parts(max width)) float2 each
+    float* rsf;        // (M) float2 (rstd, rstd * mean) of a block's pre-norm output (folded LayerNorm)
     void *qkv, *att, *proj, *hid, *u, *vt;
     uint64_t* bits;
     int Spad, nw64;
@@ -600,8 +641,12 @@ struct LayerScratch {
 
 // ConformerEncoderLayer.forward, post-LN (model.py:113-115); result back in x (tmp is the other
 // half of the ping-pong pair).
+// prenorm_in (wide depth-wise bf16 stacks, fs2_set_folded_layernorm): x holds the PREVIOUS block's pre-norm output v2 (its row
+// statistics in sc.st2, its norm2 in pg / pb) - this block's in-projection and residual normalise it on the fly; leave_prenorm:
+// this block in turn skips its closing normalise-only pass and leaves v2 + statistics for the next one.
 int conformer(fs2_engine* e, hipStream_t st, const LayerW& w, void* x, void* tmp, int B, int S, int heads,
-              const LayerScratch& sc, bool is_decoder) {
+              const LayerScratch& sc, bool is_decoder, bool prenorm_in = false, const float* pg = nullptr, const float* pb = nullptr,
+              bool leave_prenorm = false) {
     const int H = e->cfg.hidden, M = B * S, dt = w.in_proj.dt;
     const double dsz = dt == FS2_BF16 ? 2 : 4;
     // fp32 storage with the bf16 x 3 split products (FS2_F32_X3 / the front of FS2_MIXED_X3): the attention takes the split
@@ -614,7 +659,13 @@ int conformer(fs2_engine* e, hipStream_t st, const LayerW& w, void* x, void* tmp
     struct MhaEnd { Bracket*& b; ~MhaEnd() { delete b; b = nullptr; } } mha_end{mha};
     const bool x3 = e->front_split && dt == FS2_F32 && g_attn_x3;
     void* qkv_lo = x3 ? (void*)((char*)sc.qkv + (size_t)M * 3 * H * 2) : nullptr;
-    CHK(gemm(e, st, w.in_proj, x, sc.qkv, M, M, false, dt, nullptr, -1, nullptr, nullptr, qkv_lo));
+    if (prenorm_in) {
+        if (!w.has_fold || !(w.depthwise && H > 256 && e->defer_ln)) return fail(e, FS2_ERR_STATE, "pre-norm block input without folded weights");
+        const RowScale rs{sc.rsf, w.in_wg};
+        CHK(gemm(e, st, w.in_proj_f, x, sc.qkv, M, M, false, dt, nullptr, -1, nullptr, nullptr, nullptr, &rs));
+    } else {
+        CHK(gemm(e, st, w.in_proj, x, sc.qkv, M, M, false, dt, nullptr, -1, nullptr, nullptr, qkv_lo));
+    }
     AttnArgs a;
     a.qkv_lo = qkv_lo;
     a.qkv = sc.qkv; a.vt = sc.vt; a.kbits = sc.bits; a.out = sc.att;
@@ -638,6 +689,7 @@ int conformer(fs2_engine* e, hipStream_t st, const LayerW& w, void* x, void* tmp
         // conv2's epilogue normalises v1 once more for the residual; LN2 is a normalise-only pass over conv2's output.
         Deferred d1;
         d1.res = x; d1.stats_out = sc.st1;
+        if (prenorm_in) { d1.res_stats = sc.st2; d1.res_g = pg; d1.res_b = pb; }                      // x = LN2_prev(v2_prev), on load
         CHK(gemm(e, st, w.out_proj, sc.att, tmp, M, M, false, dt, nullptr, -1, nullptr, &d1));       // tmp = v1
         delete mha; mha = nullptr;
         LnOnLoad l1{sc.st1, w.g1, w.b1};
@@ -646,6 +698,10 @@ int conformer(fs2_engine* e, hipStream_t st, const LayerW& w, void* x, void* tmp
         Deferred d2;
         d2.res = tmp; d2.res_stats = sc.st1; d2.res_g = w.g1; d2.res_b = w.b1; d2.stats_out = sc.st2;
         CHK(gemm(e, st, w.c2, sc.hid, x, M, S, false, dt, nullptr, -1, nullptr, &d2));                // x = v2 (x is free by now)
+        if (leave_prenorm) {  // the next block folds LN2 in: its in-projection wants (rstd, rstd * mean) per row
+            if (launch_rowstats_finish(sc.st2, ln_parts(H), H, 1e-5f, sc.rsf, M, st) != FS2_OK) return fail(e, FS2_ERR_HIP, "row statistics launch failed");
+            return FS2_OK;
+        }
         return norm_only(e, st, dt, x, sc.st2, w.g2, w.b2, x, M, H);                                   // x = LN2(v2), in place
     }
     {   // tmp = LN1(x + out_proj(att))
@@ -664,6 +720,23 @@ int conformer(fs2_engine* e, hipStream_t st, const LayerW& w, void* x, void* tmp
         LnFuse ln;
         ln.res = tmp; ln.g = w.g2; ln.b = w.b2; ln.tmp = sc.proj;
         CHK(gemm(e, st, w.c2, sc.hid, x, M, S, false, dt, &ln));
+    }
+    return FS2_OK;
+}
+
+// The torch-1.10 container loop (fastspeech2.py:249-262: for layer in layers: x = layer(x, ...), no final norm).  Between two wide
+// depth-wise bf16 blocks the closing LayerNorm is never materialised (fs2_set_folded_layernorm): block i leaves v2 + row statistics,
+// block i + 1 runs its in-projection on v2 with norm2 folded into the weights and normalises the residual on load.
+int run_stack(fs2_engine* e, hipStream_t st, const std::vector<LayerW>& Ls, void* x, void* tmp, int B, int S, int heads,
+              const LayerScratch& sc, bool is_decoder) {
+    const int H = e->cfg.hidden;
+    bool pre = false;
+    for (size_t i = 0; i < Ls.size(); ++i) {
+        const LayerW& w = Ls[i];
+        const bool deferred = w.depthwise && H > 256 && e->defer_ln;
+        const bool leave = e->fold_ln && deferred && i + 1 < Ls.size() && Ls[i + 1].has_fold && Ls[i + 1].depthwise;
+        CHK(conformer(e, st, w, x, tmp, B, S, heads, sc, is_decoder, pre, pre ? Ls[i - 1].g2 : nullptr, pre ? Ls[i - 1].b2 : nullptr, leave));
+        pre = leave;
     }
     return FS2_OK;
 }
@@ -774,7 +847,7 @@ size_t layer_scratch_bytes(const fs2_engine* e, int B, int S) {
     if ((size_t)c.dur_filter > Pm) Pm = c.dur_filter;
     const size_t Spad = ((size_t)S + 63) / 64 * 64;
     return al(M * 3 * H * esz) + 3 * al(M * Pm * esz) + al(M * Fm * esz) + al((size_t)B * H * Spad * esz) +
-           al((size_t)B * (Spad / 64) * 8) + 2 * al(M * (size_t)ln_parts((int)Pm) * 8) + 4096;
+           al((size_t)B * (Spad / 64) * 8) + 2 * al(M * (size_t)ln_parts((int)Pm) * 8) + al(M * 8) + 4096;
 }
 int take_layer_scratch(fs2_engine* e, Arena& ar, int B, int S, LayerScratch* sc) {
     const fs2_config& c = e->cfg;
@@ -787,6 +860,7 @@ int take_layer_scratch(fs2_engine* e, Arena& ar, int B, int S, LayerScratch* sc)
     sc->nw64 = sc->Spad / 64;
     sc->st1 = (float*)ar.take(M * (size_t)ln_parts((int)Pm) * 8);
     sc->st2 = (float*)ar.take(M * (size_t)ln_parts((int)Pm) * 8);
+    sc->rsf = (float*)ar.take(M * 8);
     sc->qkv = ar.take(M * 3 * H * esz);
     sc->att = ar.take(M * Pm * esz);
     sc->proj = ar.take(M * Pm * esz);
@@ -794,7 +868,7 @@ int take_layer_scratch(fs2_engine* e, Arena& ar, int B, int S, LayerScratch* sc)
     sc->u = ar.take(M * Pm * esz);
     sc->vt = ar.take((size_t)B * H * sc->Spad * esz);
     sc->bits = (uint64_t*)ar.take((size_t)B * sc->nw64 * 8);
-    if (!sc->st1 || !sc->st2 || !sc->qkv || !sc->att || !sc->proj || !sc->hid || !sc->u || !sc->vt || !sc->bits)
+    if (!sc->st1 || !sc->st2 || !sc->rsf || !sc->qkv || !sc->att || !sc->proj || !sc->hid || !sc->u || !sc->vt || !sc->bits)
         return fail(e, FS2_ERR_NOMEM, "scratch arena too small");
     return FS2_OK;
 }
@@ -884,6 +958,7 @@ int fs2_clone(const fs2_engine* src, fs2_engine** out) {
     e->use_graph = src->use_graph;
     e->zero_pad_mel = src->zero_pad_mel;
     e->defer_ln = src->defer_ln;
+    e->fold_ln = src->fold_ln;
     e->front_split = src->front_split;
     e->spec = src->spec;
     e->dev_allocs = src->dev_allocs;
@@ -947,6 +1022,12 @@ int fs2_finalize(fs2_engine* e) {
     e->dec.resize(c.dec_layers);
     for (int i = 0; i < c.dec_layers; ++i)
         CHK(make_layer(e, "decoder.layers." + std::to_string(i), H, c.dec_filter, c.dec_depthwise, &e->dec[i], e->bdt));
+    if (H > 256) {  // stacks of wide depth-wise bf16 blocks: norm2 of block i - 1 folded into the in-projection of block i
+        for (int i = 1; i < c.enc_layers && c.enc_depthwise && e->fdt == FS2_BF16; ++i)
+            CHK(make_folded_in_proj(e, "encoder.layers." + std::to_string(i), "encoder.layers." + std::to_string(i - 1), H, &e->enc[i]));
+        for (int i = 1; i < c.dec_layers && c.dec_depthwise && e->bdt == FS2_BF16; ++i)
+            CHK(make_folded_in_proj(e, "decoder.layers." + std::to_string(i), "decoder.layers." + std::to_string(i - 1), H, &e->dec[i]));
+    }
     CHK(make_predictor(e, "variance_adaptor.duration_predictor", c.dur_nlayers, c.dur_filter, c.dur_depthwise, &e->dur, e->fdt));
     e->vars.resize(c.n_variances);
     for (int v = 0; v < c.n_variances; ++v) {
@@ -989,6 +1070,12 @@ int fs2_set_debug(fs2_engine* e, int32_t on) {
 int fs2_set_deferred_layernorm(fs2_engine* e, int32_t on) {
     if (!e) return FS2_ERR_ARG;
     e->defer_ln = on != 0;
+    return FS2_OK;
+}
+
+int fs2_set_folded_layernorm(fs2_engine* e, int32_t on) {
+    if (!e) return FS2_ERR_ARG;
+    e->fold_ln = on != 0;
     return FS2_OK;
 }
 
@@ -1072,7 +1159,7 @@ int fs2_encode(fs2_engine* e, const int64_t* phones, const float* speaker, int32
     {
         std::vector<uint64_t> key = {(uint64_t)B, (uint64_t)L, (uint64_t)e->persist.base, (uint64_t)e->scratch.base, (uint64_t)phones,
                                      (uint64_t)speaker, (uint64_t)forced, (uint64_t)e->h_pinned, (uint64_t)e->fuse_predictor, (uint64_t)g_knob_gen,
-                                     (uint64_t)e->defer_ln, (uint64_t)e->front_split};
+                                     (uint64_t)e->defer_ln, (uint64_t)e->front_split, (uint64_t)e->fold_ln};
         const bool plain = c.n_priors != 0;  // a prior tensor is a one-shot pointer of the call
         CHK(run_phase(e, e->egraphs, key, plain, st, [&](hipStream_t s2) { return encode_body(e, phones, speaker, forced, sc, s2); }));
     }
@@ -1102,8 +1189,7 @@ static int encode_body(fs2_engine* e, const int64_t* phones, const float* speake
         MaskBitsArgs mb{e->src_mask, sc.bits, B, L, sc.nw64};
         if (launch_mask_bits(mb, st) != FS2_OK) return fail(e, FS2_ERR_HIP, "mask_bits launch failed");
     }
-    for (int i = 0; i < c.enc_layers; ++i)                                   // fastspeech2.py:685
-        CHK(conformer(e, st, e->enc[i], e->xA, e->xB, B, L, c.enc_heads, sc, false));
+    CHK(run_stack(e, st, e->enc, e->xA, e->xB, B, L, c.enc_heads, sc, false));  // fastspeech2.py:685
     if (e->debug) {  // the reference's encoder output, i.e. before the prior embeddings are added
         const size_t need_d = al(ML * H * 4) + 4096;
         if (need_d > e->dbg_enc.cap) HIPCHK(e, hipDeviceSynchronize());
@@ -1234,8 +1320,7 @@ static int decode_body(fs2_engine* e, const fs2_outputs* out, hipStream_t st) {
         if (launch_convert(ca, e->fdt, e->bdt, st) != FS2_OK) return fail(e, FS2_ERR_HIP, "front -> back conversion failed");
         std::swap(yA, yB);
     }
-    for (int i = 0; i < c.dec_layers; ++i)                                   // fastspeech2.py:719-721
-        CHK(conformer(e, st, e->dec[i], yA, yB, B, T, c.dec_heads, sc, true));
+    CHK(run_stack(e, st, e->dec, yA, yB, B, T, c.dec_heads, sc, true));       // fastspeech2.py:719-721
     if (e->debug) CHK(tap_store(e, st, "decoder_out", yA, MT * H, e->bdt));
     if (out->mel)                                                            // fastspeech2.py:723
         CHK(gemm(e, st, e->mel, yA, out->mel, (int)MT, (int)MT, false, FS2_F32, nullptr, -1, e->zero_pad_mel ? tmask : nullptr));
@@ -1328,7 +1413,7 @@ int fs2_decode(fs2_engine* e, const fs2_outputs* out, void* stream) {
     if (e->scratch.base != base0) drop_graphs(e);
     std::vector<uint64_t> key = {(uint64_t)e->B, (uint64_t)e->L, (uint64_t)e->T, (uint64_t)e->scratch.base, (uint64_t)e->persist.base,
                                  (uint64_t)e->xA, (uint64_t)e->d_cum, (uint64_t)e->spk, (uint64_t)e->zero_pad_mel, (uint64_t)e->fuse_predictor, (uint64_t)g_knob_gen,
-                                 (uint64_t)e->defer_ln, (uint64_t)e->front_split, (uint64_t)out->mel, (uint64_t)out->tgt_mask,
+                                 (uint64_t)e->defer_ln, (uint64_t)e->front_split, (uint64_t)e->fold_ln, (uint64_t)out->mel, (uint64_t)out->tgt_mask,
                                  (uint64_t)out->duration_prediction, (uint64_t)out->duration_rounded, (uint64_t)out->src_mask};
     for (int v = 0; v < FS2_MAX_VARIANCES; ++v) {
         key.push_back((uint64_t)out->variances[v]);

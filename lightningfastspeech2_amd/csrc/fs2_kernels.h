@@ -51,6 +51,12 @@ struct GemmArgs {
     float gate_scale = 1.f;
     float drop_p = 0.f;             // slab kernel, fused LayerNorm epilogue only: z = dropout(act(acc + bias)) [+ res] with the counter-based
     uint64_t drop_seed = 0, drop_key = 0;  // mask of fs2_op_dropout over the (M, N) product (element index row * N + col) - the residual sites of the training step
+    // Row-scaled product (plain epilogue of the slab / persistent kernels, no ReLU): X holds PRE-norm rows v whose LayerNorm the
+    // caller folded into W and bias (W' = W diag(gamma), bias' = bias + W beta, rs_wg[n] = sum_k W'[n][k] as stored):
+    //   C[m][n] = rstd[m] * acc - (rstd[m] * mean[m]) * rs_wg[n] + bias'[n]   =  (LayerNorm(v)[m] . W[n]) + bias[n]
+    // rs_stats = (M) float2 (rstd, rstd * mean) per row, finished from the deferred epilogue's parts by launch_rowstats_finish.
+    const float* rs_stats = nullptr;
+    const float* rs_wg = nullptr;
     int ksplit = 0;                 // > 1: split-K on the slab kernel (plain epilogue, fp32 out, no bias / ReLU / gate): split s sums the channel
                                     // blocks [s, s + 1) * Cin / ksplit of every tap into plane s of C (ksplit, M, ldc); launch_split_k_reduce adds them
 };
@@ -247,6 +253,10 @@ struct LayerNormArgs {
     uint64_t drop_seed = 0, drop_key = 0;
 };
 int launch_layernorm(const LayerNormArgs& a, int dtype, hipStream_t stream);
+
+// (M, nparts) float2 partial (sum, sum of squares) over ncols columns per row -> (M) float2 (rstd, rstd * mean): the per-row
+// constants of the row-scaled GEMM epilogue (GemmArgs::rs_stats), once per tensor instead of once per column tile of its consumer
+int launch_rowstats_finish(const float* parts, int nparts, int ncols, float eps, float* out, int M, hipStream_t stream);
 
 struct DwConvArgs {
     const void* x;      // (B*S, C)

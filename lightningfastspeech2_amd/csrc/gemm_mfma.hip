@@ -1187,7 +1187,24 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
     // LayerNorm epilogue above): at K = 256 this store loop is as many issue cycles as the K loop
     // gate_c: out = gate[row][col] > 0 ? v : 0 with `gate` a tensor of C's layout and dtype - the ReLU backward of a data-gradient
     // product (training step: dh = (dc2 . W2) o [h > 0]) folded into the store instead of a 3-tensor elementwise pass
-    auto store = [&](auto relu_c, auto full_c, auto gate_c, auto drop_c) {
+    auto store = [&](auto relu_c, auto full_c, auto gate_c, auto drop_c, auto rs_c) {
+    // rs_c: the row-scaled product (GemmArgs::rs_stats): v = rstd * acc - (rstd * mean) * wg + bias'
+    float rsr[decltype(rs_c)::value ? MI : 1], rsm[decltype(rs_c)::value ? MI : 1], wgv[decltype(rs_c)::value ? 2 : 1][8];
+    if constexpr (decltype(rs_c)::value) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int t = t0 + wm * (MI * 16) + mi * 16 + fr;
+            const float2 q = ((const float2*)p.rs_stats)[(size_t)ub * S + (t < S ? t : S - 1)];
+            rsr[mi] = q.x;
+            rsm[mi] = q.y;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + fg * 8;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) wgv[j][r] = n + r < p.N ? p.rs_wg[n + r] : 0.f;
+        }
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const int t = t0 + wm * (MI * 16) + mi * 16 + fr;
@@ -1199,7 +1216,8 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
             float v[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
-                v[r] = acc[2 * j + (r >> 2)][mi][r & 3] + bv[j][r];
+                if constexpr (decltype(rs_c)::value) v[r] = __builtin_fmaf(acc[2 * j + (r >> 2)][mi][r & 3], rsr[mi], __builtin_fmaf(-rsm[mi], wgv[j][r], bv[j][r]));
+                else v[r] = acc[2 * j + (r >> 2)][mi][r & 3] + bv[j][r];
                 if constexpr (decltype(relu_c)::value) v[r] = fmaxf(v[r], 0.f);
             }
             if constexpr (decltype(drop_c)::value) {
@@ -1379,18 +1397,23 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
         return;
     }
     const bool fulln = n0 + S_BN <= p.N;  // this column tile lies wholly inside N
-    if (p.gate) {  // (the launcher admits a gate without ReLU only)
-        if (fulln) store(BoolC<false>{}, BoolC<true>{}, BoolC<true>{}, BoolC<false>{});
-        else store(BoolC<false>{}, BoolC<false>{}, BoolC<true>{}, BoolC<false>{});
+    if (p.rs_stats) {  // (the launcher admits the row-scaled product without ReLU / gate / dropout / head + tail store, bf16 only)
+        if constexpr (sizeof(T) == 2 && sizeof(OutT) == 2 && !SPLIT) {
+            if (fulln) store(BoolC<false>{}, BoolC<true>{}, BoolC<false>{}, BoolC<false>{}, BoolC<true>{});
+            else store(BoolC<false>{}, BoolC<false>{}, BoolC<false>{}, BoolC<false>{}, BoolC<true>{});
+        }
+    } else if (p.gate) {  // (the launcher admits a gate without ReLU only)
+        if (fulln) store(BoolC<false>{}, BoolC<true>{}, BoolC<true>{}, BoolC<false>{}, BoolC<false>{});
+        else store(BoolC<false>{}, BoolC<false>{}, BoolC<true>{}, BoolC<false>{}, BoolC<false>{});
     } else if (p.drop_p > 0.f) {  // (the launcher admits the store's dropout with ReLU, bf16 / fp32 in = out, no gate)
-        if (fulln) store(BoolC<true>{}, BoolC<true>{}, BoolC<false>{}, BoolC<true>{});
-        else store(BoolC<true>{}, BoolC<false>{}, BoolC<false>{}, BoolC<true>{});
+        if (fulln) store(BoolC<true>{}, BoolC<true>{}, BoolC<false>{}, BoolC<true>{}, BoolC<false>{});
+        else store(BoolC<true>{}, BoolC<false>{}, BoolC<false>{}, BoolC<true>{}, BoolC<false>{});
     } else if (fulln) {
-        if (p.relu) store(BoolC<true>{}, BoolC<true>{}, BoolC<false>{}, BoolC<false>{});
-        else store(BoolC<false>{}, BoolC<true>{}, BoolC<false>{}, BoolC<false>{});
+        if (p.relu) store(BoolC<true>{}, BoolC<true>{}, BoolC<false>{}, BoolC<false>{}, BoolC<false>{});
+        else store(BoolC<false>{}, BoolC<true>{}, BoolC<false>{}, BoolC<false>{}, BoolC<false>{});
     } else {
-        if (p.relu) store(BoolC<true>{}, BoolC<false>{}, BoolC<false>{}, BoolC<false>{});
-        else store(BoolC<false>{}, BoolC<false>{}, BoolC<false>{}, BoolC<false>{});
+        if (p.relu) store(BoolC<true>{}, BoolC<false>{}, BoolC<false>{}, BoolC<false>{}, BoolC<false>{});
+        else store(BoolC<false>{}, BoolC<false>{}, BoolC<false>{}, BoolC<false>{}, BoolC<false>{});
     }
 #else
     (void)p;
@@ -1568,6 +1591,10 @@ static int launch_gemm_plain(const GemmArgs& a, int in_dtype, int out_dtype, hip
         if (in_dtype == FS2_BF16 && out_dtype == FS2_F32) return launch_t<bf16, float, true>(a, stream);
         return FS2_ERR_SHAPE;
     }
+    if (a.rs_stats && (fused || a.relu || a.gate || a.stats_out || a.epi_res || a.zero_rows || a.C_lo || a.ksplit > 1 || a.drop_p > 0.f || g_gemm_variant == 1 ||
+                       g_gemm_variant == 2 || !a.rs_wg || !(a.M % a.S == 0 && (a.taps & 1)) || a.N < 192 || in_dtype != FS2_BF16 ||
+                       out_dtype != FS2_BF16))
+        return FS2_ERR_SHAPE;  // the row-scaled product lives in the slab / persistent kernels' plain bf16 epilogue only
     if (a.gate && (fused || a.relu || a.stats_out || a.epi_res || g_gemm_variant != 0 || a.N < 192 || a.M % a.S || !(a.taps & 1) ||
                    in_dtype != out_dtype))
         return FS2_ERR_SHAPE;  // the gated store lives in the slab kernel's plain epilogue only
@@ -1626,7 +1653,7 @@ static int launch_gemm_plain(const GemmArgs& a, int in_dtype, int out_dtype, hip
             if (a.K / ksp >= 4096 && !wide) cost = cost > tiles ? cost : tiles;
             if (!best || cost < best_cost) { best = mi; best_cost = cost; best_rows = (long)nutt * tm * bm; }
         }
-        if (best_rows <= 2L * a.M || a.C_lo || a.w_presplit) {  // (the head + tail store / pre-split weights exist in this kernel only)
+        if (best_rows <= 2L * a.M || a.C_lo || a.w_presplit || a.rs_stats) {  // (the head + tail store / pre-split weights / row-scaled product exist in this kernel only)
             // more tiles than CUs: one workgroup per CU walks them, the next tile's first operands under this tile's epilogue
             // (gemm_persist.hip; same tile height, same arithmetic per element - bit-identical)
             if (!fused && g_gemm_persist && gemm_persist_supported(a, in_dtype, out_dtype, best) && gemm_persist_pays(a, best))
@@ -1640,7 +1667,7 @@ static int launch_gemm_plain(const GemmArgs& a, int in_dtype, int out_dtype, hip
         }
     }
     if (fused) return FS2_OK;  // not the slab kernel: caller falls back to GEMM + LayerNorm kernel
-    if (a.stats_out || a.epi_res || a.gate || ksp > 1 || a.drop_p > 0.f) return FS2_ERR_SHAPE;  // the deferred-LayerNorm epilogue lives in the slab kernel only
+    if (a.stats_out || a.epi_res || a.gate || ksp > 1 || a.drop_p > 0.f || a.rs_stats) return FS2_ERR_SHAPE;  // the deferred-LayerNorm epilogue lives in the slab kernel only
     if (in_dtype == FS2_F32 && out_dtype == FS2_F32) return launch_t<float, float>(a, stream);
     if (in_dtype == FS2_BF16 && out_dtype == FS2_BF16) return launch_t<bf16, bf16>(a, stream);
     if (in_dtype == FS2_BF16 && out_dtype == FS2_F32) return launch_t<bf16, float>(a, stream);

@@ -41,8 +41,11 @@ template <int I> struct IntCP { static constexpr int value = I; };
 // Pointwise launches only (taps == 1): the slab holds the tile's own rows, no conv halo.  (A conv form with the tap loops compiled,
 // spilled at every tile height - hipcc's allocation around the tap loops - and a spill reload in these loops is a vmcnt wait that
 // drains the operand requests: dropped; dense convs stay on the slab kernel, 36 steps per tile.)
-template <int MI, bool DEFER>
+// RS: the row-scaled product (GemmArgs::rs_stats; plain epilogue only): per-row (rstd, rstd * mean) and the wg row reach the epilogue
+// through LDS like the bias row - fetched at the top of the tile, published by waves 4-7 behind the first step's MFMAs.
+template <int MI, bool DEFER, bool RS = false>
 __global__ __launch_bounds__(512) void gemm_persist_kernel(GemmArgs p, int ntiles) {
+    static_assert(!(RS && DEFER), "the row-scaled product is a plain-epilogue form");
 #if defined(__HIP_DEVICE_COMPILE__)
     using T = bf16;
     constexpr int BMs = MI * 32;
@@ -54,6 +57,8 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(GemmArgs p, int ntile
     __shared__ __attribute__((aligned(16))) unsigned char wt0[PR_BN * PR_ROWB];
     __shared__ __attribute__((aligned(16))) unsigned char wt1[PR_BN * PR_ROWB];
     __shared__ __attribute__((aligned(16))) float sbias[PR_BN];                 // the tile's bias row (wave 7 brings it in under the tile's first step)
+    __shared__ __attribute__((aligned(16))) float swg[RS ? PR_BN : 4];          // RS: sum_k W'[n][k] of the tile's columns
+    __shared__ __attribute__((aligned(16))) float2 srow[RS ? BMs : 2];          // RS: (rstd, rstd * mean) of the tile's rows
     __shared__ __attribute__((aligned(16))) float2 red[DEFER ? 4 * BMs : 2];    // row statistics exchange (its own object: the operand buffers
                                                                                 // already hold the next tile's first step by then)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -168,10 +173,21 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(GemmArgs p, int ntile
     // LDS-DMA scoreboard did not keep the sixth destination apart.)
     // (every wave issues the load - unconditional, from a clamped index, so that no select or phi sits between the load and its
     //  one use and pulls the wait forward; columns past N receive values nobody reads)
-    float4 bq;
+    float4 bq, wq;
+    float2 rq;
     auto bias_publish = [&]() {
-        if (wave != 7) return;
-        *(float4*)(sbias + lane * 4) = bq;
+        if constexpr (RS) {
+            if (wave < 4) return;
+            const int row = (wave - 4) * 64 + lane;
+            if (row < BMs) srow[row] = rq;
+            if (wave == 7) {
+                *(float4*)(sbias + lane * 4) = bq;
+                *(float4*)(swg + lane * 4) = wq;
+            }
+        } else {
+            if (wave != 7) return;
+            *(float4*)(sbias + lane * 4) = bq;
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
 
@@ -308,6 +324,12 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(GemmArgs p, int ntile
             int nb = n0 + lane * 4;
             nb = nb < p.N - 4 ? nb : p.N - 4;
             bq = *(const float4*)(p.bias + nb);
+            if constexpr (RS) {
+                wq = *(const float4*)(p.rs_wg + nb);
+                int rr = t0 + (wave & 3) * 64 + lane;
+                rr = rr < S ? rr : S - 1;
+                rq = ((const float2*)p.rs_stats)[(size_t)ub * S + rr];
+            }
         }
         // the steps alternate between the two buffer pairs.  Step 0 stands outside the loop: it publishes the bias row, and with that
         // use of the pending load INSIDE the loop hipcc drains vmcnt in the loop's preheader - every wave's epilogue stores and the
@@ -338,6 +360,21 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(GemmArgs p, int ntile
             bv[j][4] = b1.x; bv[j][5] = b1.y; bv[j][6] = b1.z; bv[j][7] = b1.w;
         }
         if constexpr (!DEFER) {
+            float rsr[RS ? MI : 1], rsm[RS ? MI : 1], wgv[RS ? 2 : 1][8];
+            if constexpr (RS) {
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi) {
+                    const float2 q = srow[wm * (MI * 16) + mi * 16 + fre];
+                    rsr[mi] = q.x;
+                    rsm[mi] = q.y;
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float4 w0 = *(const float4*)(swg + wn * 64 + j * 32 + fge * 8), w1 = *(const float4*)(swg + wn * 64 + j * 32 + fge * 8 + 4);
+                    wgv[j][0] = w0.x; wgv[j][1] = w0.y; wgv[j][2] = w0.z; wgv[j][3] = w0.w;
+                    wgv[j][4] = w1.x; wgv[j][5] = w1.y; wgv[j][6] = w1.z; wgv[j][7] = w1.w;
+                }
+            }
             auto store = [&](auto relu_c, auto full_c, auto rows_c) {
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
@@ -350,7 +387,8 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(GemmArgs p, int ntile
                         float v[8];
 #pragma unroll
                         for (int r = 0; r < 8; ++r) {
-                            v[r] = acc[2 * j + (r >> 2)][mi][r & 3] + bv[j][r];
+                            if constexpr (RS) v[r] = __builtin_fmaf(acc[2 * j + (r >> 2)][mi][r & 3], rsr[mi], __builtin_fmaf(-rsm[mi], wgv[j][r], bv[j][r]));
+                            else v[r] = acc[2 * j + (r >> 2)][mi][r & 3] + bv[j][r];
                             if constexpr (decltype(relu_c)::value) v[r] = fmaxf(v[r], 0.f);
                         }
                         T* dst = (T*)((char*)C + (unsigned)(t * p.ldc + n) * (unsigned)sizeof(T));
@@ -457,6 +495,7 @@ int g_gemm_persist = 1;  // A/B knob (220 / 221): multi-round bf16 slab launches
 bool gemm_persist_supported(const GemmArgs& a, int in_dtype, int out_dtype, int mi) {
     if (in_dtype != FS2_BF16 || out_dtype != FS2_BF16) return false;
     if (a.ln_g || a.dot_w || a.z_out || a.res || a.gate || a.zero_rows || a.C_lo || a.split || a.w_presplit || a.ksplit > 1 || a.drop_p > 0.f) return false;
+    if (a.rs_stats && (a.relu || a.stats_out || a.epi_res || !a.rs_wg)) return false;
     if (!a.bias || !a.C) return false;
     const bool defer = a.stats_out || a.epi_res;
     if (defer && (mi != 6 || (a.epi_res && a.relu))) return false;
@@ -486,13 +525,13 @@ bool gemm_persist_pays(const GemmArgs& a, int mi) {
     return tiles > persist_cus();
 }
 
-template <int MI, bool DEFER>
+template <int MI, bool DEFER, bool RS = false>
 static int launch_persist_t(const GemmArgs& a, hipStream_t stream) {
     const int BMs = MI * 32;
     const int tiles = (a.M / a.S) * ((a.S + BMs - 1) / BMs) * ((a.N + PR_BN - 1) / PR_BN);
     int grid = persist_cus();
     if (grid > ((tiles + 7) & ~7)) grid = (tiles + 7) & ~7;
-    hipLaunchKernelGGL((gemm_persist_kernel<MI, DEFER>), dim3(grid), dim3(512), 0, stream, a, tiles);
+    hipLaunchKernelGGL((gemm_persist_kernel<MI, DEFER, RS>), dim3(grid), dim3(512), 0, stream, a, tiles);
     return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
 }
 
@@ -501,6 +540,7 @@ int launch_gemm_persist(const GemmArgs& a_in, int mi, hipStream_t stream) {
     if (a.taps == 1) a.S = a.M;
     const bool defer = a.stats_out || a.epi_res;
     if (defer) return launch_persist_t<6, true>(a, stream);
+    if (a.rs_stats) return mi == 8 ? launch_persist_t<8, false, true>(a, stream) : launch_persist_t<6, false, true>(a, stream);
     if (mi == 8) return launch_persist_t<8, false>(a, stream);
     return launch_persist_t<6, false>(a, stream);
 }

@@ -223,7 +223,7 @@ bool gemm_wres_supported(const GemmArgs& a, int in_dtype, int out_dtype, bool fo
     }
     return in_dtype == FS2_BF16 && out_dtype == FS2_BF16 && a.taps == 1 && a.K == WR_K && a.Cin == WR_K && a.N >= 256 && a.N % 256 == 0 &&
            a.N <= 2048 && a.M > 0 && !a.res && !a.ln_g && !a.dot_w && !a.z_out && !a.epi_res && !a.stats_out && !a.gate && !a.zero_rows &&
-           !a.split && a.ldx % 8 == 0 && a.ldc % 8 == 0 && (size_t)a.M * a.ldx * 2 < 0xFFFFF000ull && (size_t)a.M * a.ldc * 2 < 0xFFFFF000ull;
+           !a.split && !a.rs_stats && a.ldx % 8 == 0 && a.ldc % 8 == 0 && (size_t)a.M * a.ldx * 2 < 0xFFFFF000ull && (size_t)a.M * a.ldc * 2 < 0xFFFFF000ull;
 }
 
 int launch_gemm_wres(const GemmArgs& a, hipStream_t stream) {

@@ -124,6 +124,26 @@ int launch_layernorm(const LayerNormArgs& a, int dtype, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
 }
 
+// Row statistics of a pre-norm tensor, finished: the deferred-LayerNorm GEMM epilogue leaves one (sum, sum of squares) per row per
+// 256-column tile; the row-scaled GEMM epilogue (GemmArgs::rs_stats) wants (rstd, rstd * mean) per row.  One thread per row.
+__global__ __launch_bounds__(256) void rowstats_finish_kernel(const float2* __restrict__ parts, int nparts, float invn, float eps, float2* __restrict__ out, int M) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    float2 pq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pq[q] = q < nparts ? parts[(size_t)m * nparts + q] : make_float2(0.f, 0.f);
+    const float s1 = (pq[0].x + pq[1].x) + (pq[2].x + pq[3].x), s2 = (pq[0].y + pq[1].y) + (pq[2].y + pq[3].y);  // the consumers' order of the parts
+    const float mean = s1 * invn;
+    const float rstd = 1.0f / sqrtf(fmaxf(__builtin_fmaf(-mean, mean, s2 * invn), 0.f) + eps);
+    out[m] = make_float2(rstd, mean * rstd);
+}
+int launch_rowstats_finish(const float* parts, int nparts, int ncols, float eps, float* out, int M, hipStream_t stream) {
+    if (M <= 0) return FS2_OK;
+    if (!parts || !out || nparts < 1 || nparts > 4 || ncols <= 0) return FS2_ERR_ARG;
+    hipLaunchKernelGGL(rowstats_finish_kernel, dim3((M + 255) / 256), dim3(256), 0, stream, (const float2*)parts, nparts, 1.0f / (float)ncols, eps, (float2*)out, M);
+    return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
+}
+
 // =============================================================================================
 // Depth-wise Conv1d over time, zero "same" padding per utterance, unmasked — conv1.0 of the
 // LightSpeech FFN (model.py:75-81) and module.0 of the depth-wise predictor layer

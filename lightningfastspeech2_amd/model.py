@@ -245,6 +245,11 @@ class Engine:
         """A/B: wide depth-wise blocks with LayerNorm deferred into its consumers (default) or as its own launches."""
         _lib.check(self.lib.fs2_set_deferred_layernorm(self.handle, int(on)), self.handle, "set_deferred_layernorm")
 
+    def set_folded_layernorm(self, on: bool):
+        """A/B: inside a stack of wide depth-wise bf16 blocks, a block's closing LayerNorm folded into the next block's in-projection
+        (default) or one normalise-only pass per block."""
+        _lib.check(self.lib.fs2_set_folded_layernorm(self.handle, int(on)), self.handle, "set_folded_layernorm")
+
     def set_graphs(self, on: bool):
         """Replay the encode and the decode phase (~100 / ~50 launches) as hipGraphs once a shape + buffer signature repeats
         (include/fs2.h fs2_set_graphs); bit-identical results, the forward stops depending on how fast the host can issue

@@ -65,6 +65,23 @@ def gemm_add(dtype, x, w_packed, bias, addend, taps=1, S=None, in_place=True):
     return c.float().cpu()
 
 
+def gemm_rowscale(x, w_folded, bias_folded, parts, wg, eps=1e-5):
+    """fs2_op_rowstats_finish + fs2_op_gemm_rowscale (bf16): x = pre-norm rows, parts (M, nparts, 2) fp32 partial (sum, sum of
+    squares) per row as the deferred-LayerNorm epilogue leaves them"""
+    M, Cin = x.shape
+    N = w_folded.shape[0]
+    xd, wd = to_dev(x, BF16), to_dev(w_folded, BF16)
+    bd = torch.as_tensor(bias_folded).float().to(DEV).contiguous()
+    sd = torch.as_tensor(parts).float().to(DEV).contiguous()
+    gd = torch.as_tensor(wg).float().to(DEV).contiguous()
+    rs = torch.empty(M, 2, dtype=torch.float32, device=DEV)
+    ok(lib().fs2_op_rowstats_finish(p(sd), int(parts.shape[1]), Cin, float(eps), p(rs), M, stream()), "rowstats_finish")
+    c = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ok(lib().fs2_op_gemm_rowscale(p(xd), p(wd), p(bd), p(rs), p(gd), p(c), M, N, Cin, stream()), "gemm_rowscale")
+    torch.cuda.synchronize()
+    return c.float().cpu()
+
+
 def gemm_splitk(dtype, x, w_packed, ksplit, taps=1, S=None, out_dtype=None, into=None):
     """fs2_op_gemm_splitk: K slices as workgroups of one launch into fp32 planes + the plane sum; into = a tensor the result is
     ADDED to (the accumulating data-gradient call of the training step)."""

@@ -110,3 +110,33 @@ def test_persistent_gemm_whole_model_is_bit_identical():
         if torch.is_tensor(a[k]):
             assert torch.equal(a[k], b[k]), k
             assert torch.equal(b[k], c[k]), k
+
+
+def test_folded_layernorm_against_its_own_passes():
+    """Inside a stack of wide depth-wise bf16 blocks a block's closing LayerNorm is folded into the next block's in-projection
+    (fs2_set_folded_layernorm, default) instead of a normalise-only pass per block: the two differ by bf16 roundings only (the
+    activations are rounded before instead of after the normalisation, the folded weights once) - held to the bf16 tolerance
+    against each other and against the oracle under its decisions (shard == whole at the full configuration:
+    test_full_config_properties_bf16)."""
+    from lightningfastspeech2_amd.config import Fs2Config
+    from test_gpu_forward import BF16_MEL_MAX, BF16_MEL_MEAN
+    cfg = Fs2Config(**{**preset("c3").to_dict(), "encoder_layers": 3, "decoder_layers": 3, "variance_nlayers": [2, 2, 2]})
+    sd = synth_state_dict(cfg, 6, randomize_norm=True, duration_bias=1.4)
+    inp = synth_inputs(cfg, 3, 40, seed=61, lengths=[40, 22, 9])
+    ref = oracle_cpu.forward(sd, cfg, inp["phones"], inp["speaker"], return_intermediates=True)
+    batch = {"phones": torch.from_numpy(inp["phones"]), "speaker": torch.from_numpy(inp["speaker"])}
+    forced = dict(force_durations=ref["duration_rounded"], force_buckets={v: ref["_intermediates"][f"bucket_{v}"] for v in cfg.variances})
+    m = _model(cfg, sd, "bf16")
+    a = _cpu(m.forward(batch, **forced))
+    m.engine.set_folded_layernorm(False)
+    b = _cpu(m.forward(batch, **forced))
+    m.engine.set_folded_layernorm(True)
+    c = _cpu(m.forward(batch, **forced))
+    assert torch.equal(a["mel"], c["mel"])
+    d_ab = (a["mel"] - b["mel"]).abs()
+    e_a, e_b = (a["mel"] - ref["mel"]).abs(), (b["mel"] - ref["mel"]).abs()
+    _report(test="folded_ln", folded_vs_passes_max=float(d_ab.max()), folded_vs_oracle=[float(e_a.max()), float(e_a.mean())],
+            passes_vs_oracle=[float(e_b.max()), float(e_b.mean())])
+    assert float(d_ab.max()) <= BF16_MEL_MAX
+    assert float(e_a.max()) <= BF16_MEL_MAX and float(e_a.mean()) <= BF16_MEL_MEAN
+    assert float(e_a.mean()) <= 1.5 * float(e_b.mean()) + 1e-4   # no worse than the materialised form

@@ -110,6 +110,41 @@ def test_persistent_gemm_is_bit_identical_to_the_slab_kernel(M, N, K, relu, add)
     assert float((got - ref).abs().max()) <= tol(G.BF16, ref)
 
 
+@pytest.mark.parametrize("M,N,K", [(49152, 2304, 768), (8192, 2304, 768), (700, 2304, 768), (20000, 712, 384), (30000, 3072, 1024)])
+def test_gemm_rowscale_is_layernorm_then_gemm(M, N, K):
+    """fs2_op_gemm_rowscale: LayerNorm(v) W^T + b evaluated on the PRE-norm rows v with gamma / beta folded into the operands and
+    per-row (rstd, rstd * mean) applied in the epilogue - what the engine's in-projection does behind a deferred norm2
+    (model.py:113-115).  Against LayerNorm-then-GEMM in fp32 on the same bf16-rounded v (tolerance: one bf16 rounding of W' and of the
+    output, not of the normalised activations), and bit-equal between the one-tile-per-workgroup slab kernel (knob 220) and the
+    persistent kernel (221), ragged last tiles and a column tail included."""
+    g = torch.Generator().manual_seed(41)
+    v = (torch.randn(M, K, generator=g) * 1.7 + 0.4 * torch.randn(M, 1, generator=g)).bfloat16().float()   # rows with their own mean
+    w0 = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b0 = torch.randn(N, generator=g) * 0.1
+    gamma, beta = 1 + 0.2 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g)
+    wf = (w0 * gamma[None, :]).bfloat16().float()                      # as stored
+    bf = (b0.double() + w0.double() @ beta.double()).float()
+    wg = wf.double().sum(1).float()
+    parts = (K + 255) // 256
+    stats = torch.zeros(M, parts, 2)
+    for q in range(parts):                                            # what the deferred-LayerNorm epilogue leaves: per 256-column tile
+        blk = v[:, q * 256:(q + 1) * 256].double()
+        stats[:, q, 0] = blk.sum(1).float()
+        stats[:, q, 1] = (blk * blk).sum(1).float()
+    try:
+        G.lib().fs2_op_set_gemm_variant(220)
+        old = G.gemm_rowscale(v, wf, bf, stats, wg)
+        G.lib().fs2_op_set_gemm_variant(221)
+        got = G.gemm_rowscale(v, wf, bf, stats, wg)
+        again = G.gemm_rowscale(v, wf, bf, stats, wg)
+    finally:
+        G.lib().fs2_op_set_gemm_variant(221)
+    assert torch.equal(got, old) and torch.equal(got, again)
+    ref = F.layer_norm(v, (K,), gamma, beta, 1e-5) @ w0.T + b0
+    err = float((got - ref).abs().max())
+    assert err <= 2.5 * tol(G.BF16, ref), (err, tol(G.BF16, ref))      # bf16 W' (2^-9 per weight) + bf16 output
+
+
 @pytest.mark.parametrize("dtype", [G.BF16, G.F32])
 @pytest.mark.parametrize("M,N,K,variant,ln", [(8192, 256, 1024, 6, True), (8192, 256, 256, 6, True), (2048, 768, 256, 7, False),
                                               (1024, 256, 320, 6, True), (96 * 5 + 7, 512, 192, 3, False), (2048, 256, 1024, 3, True),
