@@ -318,10 +318,8 @@ def main():
         model.engine.set_deferred_layernorm(False)
     if os.environ.get("FS2_FOLD_LN") == "0":  # A/B: a normalise-only pass per wide depth-wise block instead of folding norm2 into the next in-projection
         model.engine.set_folded_layernorm(False)
-    def set_knob(k):  # a mistyped knob must not yield an unlabeled default-config measurement
-        r = _lib.load().fs2_op_set_gemm_variant(int(k))
-        if r != 0:
-            raise SystemExit(f"fs2_op_set_gemm_variant({k}) was rejected (status {r}): not a defined knob value (include/fs2.h)")
+    def set_knob(k):  # a mistyped knob must not yield an unlabeled default-config measurement: set_tuning raises
+        model.engine.set_tuning(int(k))  # this engine's (replicas made later inherit it); the switches are not process state
     if os.environ.get("FS2_GEMM_KNOBS"):  # A/B: comma-separated fs2_op_set_gemm_variant values (include/fs2.h)
         for k in os.environ["FS2_GEMM_KNOBS"].split(","):
             set_knob(int(k))

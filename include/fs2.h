@@ -186,6 +186,8 @@ int fs2_set_deferred_layernorm(fs2_engine* e, int32_t on);
  * next block's in-projection runs on the pre-norm rows with gamma / beta folded into its weights (fs2_op_gemm_rowscale) and its
  * out-projection normalises the residual on load; 0 = one normalise-only pass per block.  Needs deferred LayerNorm on. */
 int fs2_set_folded_layernorm(fs2_engine* e, int32_t on);
+/* one kernel-selection switch of THIS engine: the values of fs2_op_set_gemm_variant below; clones made afterwards inherit it */
+int fs2_set_tuning(fs2_engine* e, int32_t knob);
 /* Parity aid (the analogue of the reference's teacher forcing of variance targets,
  * model.py:417-422): the NEXT fs2_decode embeds these (B, T) int32 device bucket indices for
  * variance `variance_index` instead of bucketizing its own prediction.  One-shot. */
@@ -218,13 +220,16 @@ int fs2_profile_read(fs2_engine* e, int32_t kernel_class, double* total_ms, int6
                      double* flops, double* bytes);
 
 /* ---- single-operator entry points (device pointers; used by the parity tests) ------------- */
-/* process-wide kernel selection knobs for the parity tests and A/B runs:
+/* Kernel-selection switches for the parity tests and A/B runs.  They are NOT process state: fs2_op_set_gemm_variant sets a switch of
+ * the CALLING THREAD, read by the operator-level entry points below (fs2_op_*) that thread calls; an engine owns its own set
+ * (defaults at fs2_create; fs2_set_tuning changes one; fs2_clone copies them) and never looks at a thread's.  An undefined value is
+ * FS2_ERR_ARG.  Every non-default form is pinned bit-identical (or within a stated tolerance) to the default by a test.
  *   0       auto (by problem size)
  *   1       128x128 register-staged GEMM      2       128x256 LDS-DMA ring GEMM
  *   3/4/5   slab kernel, 128/192/256-row tiles   6/7   slab kernel, 32/64-row tiles
  *   200/201 slab kernel tile order: plain / XCD-contiguous (default)
- *   300/301 LayerNorm epilogue for rows wider than 256: GEMM + stand-alone LayerNorm launch (default) / in-place fused
- *   500/501 fp32 slab-kernel launches: fp32 MFMA (default) / bf16 x 3 split products (what FS2_MIXED_X3 uses in its front)
+ *   220/221 bf16 pointwise launches of more tiles than CUs: one tile per workgroup / the persistent kernel (default); bit-identical
+ *   500/501 fp32 slab-kernel launches: fp32 MFMA (default) / bf16 x 3 split products (what FS2_MIXED_X3 uses in its front; operator level)
  *   700/701 bf16 fs2_op_bgemm tile order: plain / XCD-contiguous (default)
  *   800/801 bf16 fs2_op_bgemm: generic instantiation only / the bounds-free one for full, aligned tiles (default)
  *   900/901 fs2_op_attention_bwd, dK / dV launch: one (default, also 909) / two 16-row blocks per wave, 905/906 three / four (one wave
@@ -232,18 +237,15 @@ int fs2_profile_read(fs2_engine* e, int32_t kernel_class, double* total_ms, int6
  *              907/908 three / four
  *   1000/1001 bf16 fs2_op_bgemm: 256 x 256 LDS-DMA kernel for eligible TN products off / on (default)
  *   1100/1101 fs2_op_col_sum: two launches (default) / one (last workgroup reduces; measured slower)
- *   1200..1203 fused attention: 1200 = the phase-serial kernel only; 1201 / 1202 = the software-pipelined kernel (bf16, head dim
- *              128, no attention dropout) with 32 / 64 queries per wave (1204: 96); 1203 = by size (default)
- *   1210/1211  fused attention over at most 256 keys (bf16, head dim 128): K / V streamed tile by tile (default) / all resident
- *              in LDS (measured no faster, kept for A/B); bit-identical outputs
+ *   1200..1204 fused attention: 1200 = the phase-serial kernel only; 1201 / 1202 / 1204 = the software-pipelined kernel (bf16, head dim
+ *              128, no attention dropout) with 32 / 64 / 96 queries per wave; 1203 = by size (default)
  *   1400..1402 bf16 GEMMs with K = 256 (no fused epilogue): slab kernel / weight-resident kernel from three row tiles per
  *              workgroup on (default) / wherever it applies; bit-identical outputs
- *   310/311    deferred-LayerNorm GEMM epilogue on 192-row tiles only (default) / 256-row tiles admitted (spills; measured no faster)
  *   1320/1321  inference engine, bf16: the VarianceEncoder's bucketize + embedding add as the tail of its predictor's launch: off / on (default;
  *              bit-identical either way)
- *   1300..1302 single-launch predictor: 112- / 64-row tiles only (default); 1301 = 208-row tiles, one workgroup per CU; 1302 = two
- *              112-row tiles per workgroup, one tile's LayerNorm between the other's MFMAs - both only where the launch fills the
- *              chip, both measured slower and kept for A/B; bit-identical outputs */
+ *   1500/1501  fp32-storage split modes: attention on fp32 MFMA / on bf16 x 3 split products (default)
+ * (Removed in r05, measured slower or neutral in r02-r04 and kept until then behind switches: 1211 resident-K/V attention, 211 operand
+ *  ring, 1301 / 1302 tall / paired predictor tiles, 301 in-place wide-row LayerNorm epilogue, 311 256-row deferred epilogue.) */
 int fs2_op_set_gemm_variant(int32_t variant);
 /* tuning knob: cap (KiB) on the LDS operand slab of a vocoder conv workgroup; 0 = built-in heuristic */
 int fs2_op_set_vocoder_lds_limit(int32_t kib);

@@ -125,6 +125,7 @@ def load():
     lib.fs2_graph_replays.argtypes = [vp]
     lib.fs2_set_deferred_layernorm.argtypes = [vp, i32]
     lib.fs2_set_folded_layernorm.argtypes = [vp, i32]
+    lib.fs2_set_tuning.argtypes = [vp, i32]
     lib.fs2_debug_copy.argtypes = [vp, C.c_char_p, vp, vp]
     lib.fs2_force_buckets.argtypes = [vp, i32, vp]
     lib.fs2_force_variance_targets.argtypes = [vp, i32, vp]

@@ -87,23 +87,14 @@ __device__ inline float half_sum(float x) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-// RES > 0 (bf16, head dim 128, at most RES key tiles = 64 RES keys: the encoder's 256 phonemes): ALL of the (utterance, head)'s
-// K and V are requested at the top of the kernel - K tiles first, then V - into RES-tile LDS images (128 KiB at RES = 4, one
-// workgroup per CU), and the tile loop runs without DMA issue or barrier after its first iteration.  The streaming form pays a
-// DMA round trip (~1 us) at each of its two barriers per tile because a tile is requested only one phase ahead; with four tiles
-// in all there is nothing else to hide it under.  The arithmetic per row is the streaming kernel's, instruction for instruction.
-// (Knob 1211; measured no faster - see g_attn_resident below.)
-template <int N>
-__device__ inline void vm_wait() { __builtin_amdgcn_s_waitcnt(0x0F70 | (N & 15) | ((N >> 4) << 14)); }
-
 // X3 (r04; T = bf16 operands, fp32 output): the parity-grade arithmetic of the fp32x3 / mixed3 modes.  q, k, v arrive as TWO bf16
 // tensors each - head and tail of the fp32 values, x = hi + lo up to 2^-17 |x|, written by the in-projection's own store
 // (GemmArgs::C_lo) or by split_hi_lo_kernel - and every product is three bf16 MFMAs, lo*hi + hi*lo + hi*hi in the fp32 accumulator
 // (small terms first; the dropped lo*lo is 2^-16 of the product), P split the same way in registers.  Softmax, running max, the
 // denominator and O stay fp32.  Against the fp32-MFMA form of this kernel (32x32x2, 1/16 of the bf16 rate): 3/16 of the matrix
 // time; the decoder launch at C2 went 714 us -> see DESIGN 5.
-template <typename T, int D, int NW, int RES = 0, bool X3 = false>
-__global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128 && RES == 0) ? 2 : 1) void attention_kernel(AttnArgs p) {
+template <typename T, int D, int NW, bool X3 = false>
+__global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128) ? 2 : 1) void attention_kernel(AttnArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins exist in the device pass only
     constexpr int KVB = sizeof(T) == 2 ? 64 : 32;      // keys per tile
     constexpr int E16 = Num<T>::kPer16B;
@@ -123,10 +114,9 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128 && RES == 0) ?
     constexpr bool TRV = sizeof(T) == 2;  // bf16: V stays row-major (straight from qkv), hardware transpose read
     static_assert(TILE_B % (1024 * NDW) == 0 && NDW <= NW, "tile must split into whole wave DMAs");
 
-    static_assert(RES == 0 || (TRV && NINST * RES <= 32), "resident K / V: bf16 only, the counted wait must fit vmcnt");
-    static_assert(!X3 || (TRV && RES == 0), "split arithmetic: bf16 head / tail operands, streaming form");
-    __shared__ __attribute__((aligned(16))) unsigned char sKa[TILE_B * (RES ? RES : 1)];
-    __shared__ __attribute__((aligned(16))) unsigned char sVa[TILE_B * (RES ? RES : 1)];
+    static_assert(!X3 || TRV, "split arithmetic: bf16 head / tail operands");
+    __shared__ __attribute__((aligned(16))) unsigned char sKa[TILE_B];
+    __shared__ __attribute__((aligned(16))) unsigned char sVa[TILE_B];
     __shared__ __attribute__((aligned(16))) unsigned char sKl[X3 ? TILE_B : 16];  // the tails' tiles, same layout
     __shared__ __attribute__((aligned(16))) unsigned char sVl[X3 ? TILE_B : 16];
 
@@ -242,32 +232,17 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128 && RES == 0) ?
     // This half's tile range; all halves run the same number of (two-barrier) iterations.
     const int nhalf = ntiles, jbeg = 0, jend = ntiles;
     auto run = [&](unsigned char* sK0, unsigned char* sV0) {
-        if constexpr (RES > 0) {  // everything in flight at once: K tiles, then V tiles (padded tiles too: the waits below count)
-            for (int j = 0; j < ntiles; ++j) issue_k(j, sK0 + j * TILE_B);
-            for (int j = 0; j < ntiles; ++j) issue_v(j, sV0 + j * TILE_B);
-        } else {
-            if (jbeg < jend && tile_bits(jbeg) != 0ull) issue_k(jbeg, sK0);
-        }
+        if (jbeg < jend && tile_bits(jbeg) != 0ull) issue_k(jbeg, sK0);
         for (int it = 0; it < nhalf; ++it) {
             const int j = jbeg + it;
             const unsigned long long bits = j < jend ? tile_bits(j) : 0ull;
             const bool valid = bits != 0ull;  // fully padded tiles cost two barriers, nothing else
-            unsigned char* const sK = sK0 + (RES > 0 ? j * TILE_B : 0);
-            unsigned char* const sV = sV0 + (RES > 0 ? j * TILE_B : 0);
-            if constexpr (RES > 0) {
-                if (it == 0) {  // this wave's share of every K tile has landed: all but the V requests (in issue order) are done
-                    if (ntiles == 1) vm_wait<NINST>();
-                    else if (ntiles == 2) vm_wait<2 * NINST>();
-                    else if (ntiles == 3) vm_wait<(RES >= 3 ? 3 : 1) * NINST>();
-                    else vm_wait<(RES >= 4 ? 4 : 1) * NINST>();
-                    __syncthreads();
-                }
-            } else {
+            unsigned char* const sK = sK0;
+            unsigned char* const sV = sV0;
             dma_drain();       // this wave's share of K_j has landed (explicit: never left to hipcc's
             __syncthreads();   // placement); after the barrier everyone's has, and every wave is
                                // done with P.V of the previous tile -> sV is free
             if (valid) issue_v(j, sV);  // V_j streams in underneath Q.K^T
-            }
             uint4 pf[4], pfl[X3 ? 4 : 1];
             if (valid) {
             // the running max rides in the accumulator's initial value, so the common path is
@@ -387,16 +362,9 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128 && RES == 0) ?
                 }
             }
             }
-            if constexpr (RES > 0) {
-                if (it == 0) {  // every V tile landed (they streamed in under the first tile's Q.K^T and softmax)
-                    dma_drain();
-                    __syncthreads();
-                }
-            } else {
             dma_drain();
             __syncthreads();   // V_j landed; every wave is done reading sK
             if (j + 1 < jend && tile_bits(j + 1) != 0ull) issue_k(j + 1, sK);  // next K under P.V
-            }
             if (valid) {
             // ---- O^T += V^T P^T ----
             if constexpr (TRV) {
@@ -509,11 +477,10 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(AttnArgs p) {
     }
 }
 
-// Measured r03 (rocprof, tools/probes/attn_resident_ab.sh): C2 encoder (64 heads x 256 keys) 13.1 us resident vs 13.6 streaming (min 12.0 vs
-// 10.1), C3 encoder (192 heads) 28.1 vs 19.3 - the 128 KiB a workgroup pulls before its first MFMA arrive at the CU's ~30 GB/s
-// whatever the request pattern, and the streaming form's two co-resident workgroups hide each other's round trips.  Off.
-int g_attn_resident = 0;  // 1: sequences of at most 256 keys (bf16, head dim 128) keep K and V resident in LDS; 0: streaming form
-
+// (r03: a resident-K/V form for <= 256 keys - all of an (utterance, head)'s K and V requested at the top of the kernel into 128 KiB of
+// LDS, two barriers in all - was built, bit-identical, and measured no faster: C2 encoder 13.1 us vs 13.6 streaming, C3 encoder 28.1
+// vs 19.3; the 128 KiB a workgroup pulls before its first MFMA arrive at the CU's ingest rate whatever the request pattern, and two
+// co-resident streaming workgroups hide each other's round trips.  Removed in r05; DESIGN 4 keeps the numbers.)
 template <typename T, int D>
 static int launch_tv(const AttnArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL((transpose_v_kernel<T, D>), dim3(a.Spad / 64, a.B * a.heads), dim3(256), 0, stream, a);
@@ -529,16 +496,6 @@ static int launch_td(const AttnArgs& a, hipStream_t stream) {
     // (192-query / 6-wave workgroups - 512 of them for the C2 decoder, two per CU, a third less K/V streamed - need three
     // waves per SIMD, i.e. <= 168 VGPRs; this kernel holds 234 (O^T 64, S^T 32, Q 32, K/V/P fragments 56 ...) and with the cap
     // spills 84 of them: 195 us against 101 us for the 128-query form.  Measured r02, removed.)
-    if constexpr (sizeof(T) == 2 && D == 128) {
-        // at most 256 keys: K and V resident (one 128-KiB workgroup per CU); 64-query workgroups while they fit one round
-        if (g_attn_resident && a.S <= 256) {
-            if ((long)((a.S + 63) / 64) * BH > 256)
-                hipLaunchKernelGGL((attention_kernel<T, D, 4, 4>), dim3(((a.S + 127) / 128) * BH8), dim3(256), 0, stream, a);
-            else
-                hipLaunchKernelGGL((attention_kernel<T, D, 2, 4>), dim3(((a.S + 63) / 64) * BH8), dim3(128), 0, stream, a);
-            return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
-        }
-    }
     if (blocks4 >= 512) {
         hipLaunchKernelGGL((attention_kernel<T, D, 4>), dim3(((a.S + 127) / 128) * BH8), dim3(256), 0, stream, a);
     } else {
@@ -582,13 +539,11 @@ template <int D>
 static int launch_x3(const AttnArgs& a, hipStream_t stream) {
     const int BH = a.B * a.heads, BH8 = (BH + 7) / 8 * 8;
     const long blocks4 = (long)((a.S + 127) / 128) * BH;
-    if (blocks4 >= 512) hipLaunchKernelGGL((attention_kernel<bf16, D, 4, 0, true>), dim3(((a.S + 127) / 128) * BH8), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((attention_kernel<bf16, D, 2, 0, true>), dim3(((a.S + 63) / 64) * BH8), dim3(128), 0, stream, a);
+    if (blocks4 >= 512) hipLaunchKernelGGL((attention_kernel<bf16, D, 4, true>), dim3(((a.S + 127) / 128) * BH8), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((attention_kernel<bf16, D, 2, true>), dim3(((a.S + 63) / 64) * BH8), dim3(128), 0, stream, a);
     return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
 }
 
-int g_attn_x3 = 1;    // 1: the fp32-storage split modes (fp32x3 / mixed3) run attention on bf16 x 3 split products; 0: fp32 MFMA
-int g_attn_pipe = 3;  // 0: attention_kernel only; 1 / 2 / 4: the pipelined kernel with 32 / 64 / 96 queries per wave where it applies; 3: by size
 
 int launch_attention(const AttnArgs& a, int dtype, hipStream_t stream) {
     if (a.B <= 0 || a.S <= 0) return FS2_OK;
@@ -601,6 +556,7 @@ int launch_attention(const AttnArgs& a, int dtype, hipStream_t stream) {
         if (d3 == 128) return launch_x3<128>(a, stream);
         return FS2_ERR_SHAPE;
     }
+    const int g_attn_pipe = tuning_of(a.tune).attn_pipe;
     if (g_attn_pipe && attention_pipe_supported(a, dtype)) {
         // WHICH kernel family computes an utterance may depend on the utterance only (its length, the head count), never on the
         // batch around it: a shard run alone must be bit-equal to its rows of the whole batch (the data-parallel invariant,

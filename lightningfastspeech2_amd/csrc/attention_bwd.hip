@@ -319,14 +319,9 @@ __global__ __launch_bounds__(256, NB == 1 ? 3 : (NB == 2 ? 2 : 1)) void attn_bwd
 // operands (tools/bench_ops.py flash) the C2 decoder pair goes 370 -> 329 us with the 3-block dK / dV launch; inside the training
 // step, on the model's own activations, that launch takes 221 us against 219 us at 1 block (rocprof, same box, both ways) - the
 // gain does not survive real data (the launch is power / clock limited there), so the default stays 1.
-int g_attn_bwd_nb = 1, g_attn_bwd_nb_dq = 0;  // dQ: 0 = by size (2 when that still leaves two workgroups per CU: C2 encoder 24 us at 1, 28 at 2)  // dQ: 0 = by size (2 when that still leaves two workgroups per CU: C2 encoder 24 us at 1, 28 at 2)
+// (Tuning::attn_bwd_nb / attn_bwd_nb_dq; dQ: 0 = by size - 2 when that still leaves two workgroups per CU: C2 encoder 24 us at 1, 28 at 2)
 
 }  // namespace
-
-void attention_bwd_set_blocks(int which, int nb) {
-    if (which) g_attn_bwd_nb_dq = nb >= 0 && nb <= 4 ? nb : 0;
-    else g_attn_bwd_nb = nb >= 1 && nb <= 4 ? nb : 1;
-}
 
 bool attention_bwd_supported(int dtype, int H, int heads) { return dtype == FS2_BF16 && heads > 0 && H == heads * D; }
 
@@ -336,12 +331,13 @@ int launch_attention_bwd(const AttnBwdArgs& a, int dtype, hipStream_t stream) {
     const bool drop = a.drop_p > 0.f;
 #define FS2_AB(KERNEL, NBV, DR) \
     hipLaunchKernelGGL((KERNEL<NBV, DR>), dim3((a.S + NBV * TB - 1) / (NBV * TB), a.B * a.heads), dim3(256), 0, stream, a)
-    const int nb_kv = g_attn_bwd_nb;
+    const Tuning& tn = tuning_of(a.tune);
+    const int nb_kv = tn.attn_bwd_nb;
     if (nb_kv == 4 && !drop) FS2_AB(attn_bwd_dkdv_kernel, 4, false);
     else if (nb_kv == 3 && !drop) FS2_AB(attn_bwd_dkdv_kernel, 3, false);
     else if (nb_kv == 2) { if (drop) FS2_AB(attn_bwd_dkdv_kernel, 2, true); else FS2_AB(attn_bwd_dkdv_kernel, 2, false); }
     else { if (drop) FS2_AB(attn_bwd_dkdv_kernel, 1, true); else FS2_AB(attn_bwd_dkdv_kernel, 1, false); }
-    const int nb_dq = g_attn_bwd_nb_dq ? g_attn_bwd_nb_dq : ((long)((a.S + 2 * TB - 1) / (2 * TB)) * a.B * a.heads >= 512 ? 2 : 1);
+    const int nb_dq = tn.attn_bwd_nb_dq ? tn.attn_bwd_nb_dq : ((long)((a.S + 2 * TB - 1) / (2 * TB)) * a.B * a.heads >= 512 ? 2 : 1);
     if (nb_dq == 4 && !drop) FS2_AB(attn_bwd_dq_kernel, 4, false);
     else if (nb_dq == 3 && !drop) FS2_AB(attn_bwd_dq_kernel, 3, false);
     else if (nb_dq >= 2) { if (drop) FS2_AB(attn_bwd_dq_kernel, 2, true); else FS2_AB(attn_bwd_dq_kernel, 2, false); }

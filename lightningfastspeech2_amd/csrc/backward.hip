@@ -977,7 +977,7 @@ int launch_layernorm_bwd(const LayerNormBwdArgs& a, int dtype, hipStream_t strea
 // A/B knob: one-launch column sums (last workgroup reduces) / two launches.  OFF: measured on MI355X the one-launch form costs
 // ~50 us per launch more than it saves (C2 training step 13.5 -> 18.0 ms over its 90 column sums): each workgroup's device-scope
 // __threadfence() is an L2 write-back + invalidate on this 8-XCD part, thousands of them per launch.
-int g_colsum_fused = 0;
+// (Tuning::colsum_fused, default 0)
 static int cs_chunks(int M, int seg) { return ((seg > 0 ? seg : M) + CS_CHUNK - 1) / CS_CHUNK; }
 size_t col_sum_ws_bytes(int M, int N, int seg) {
     const int nseg = seg > 0 ? M / seg : 1;
@@ -988,7 +988,7 @@ int launch_col_sum(const ColSumArgs& a, int dtype, hipStream_t stream) {
     if (a.out2 && (a.n1 <= 0 || a.n1 >= a.N)) return FS2_ERR_ARG;
     const int nseg = a.seg > 0 ? a.M / a.seg : 1, nchunk = cs_chunks(a.M, a.seg);
     const dim3 g1((a.N + 63) / 64, nchunk, nseg);
-    const bool fused = g_colsum_fused && (long)g1.x * nseg <= CS_CTR;
+    const bool fused = tuning_of(a.tune).colsum_fused && (long)g1.x * nseg <= CS_CTR;
     if (fused) {
         if (dtype == FS2_BF16) hipLaunchKernelGGL((col_sum_pass1<bf16, true>), g1, dim3(256), 0, stream, a, nchunk);
         else hipLaunchKernelGGL((col_sum_pass1<float, true>), g1, dim3(256), 0, stream, a, nchunk);

@@ -885,13 +885,12 @@ inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 }  // namespace
 
-int g_bgemm_full = 1;  // A/B knob: the bounds-free instantiation for full, aligned tiles
-int g_bgemm_xcd = 1;   // A/B knob: XCD-contiguous tile order of the bf16 kernel
-int g_bgemm_tn256 = 1; // A/B knob: the 256 x 256 LDS-DMA kernel for eligible TN products (fs2_op_bgemm_tn256)
+// A/B knobs (Tuning): bgemm_full - the bounds-free instantiation for full, aligned tiles; bgemm_xcd - XCD-contiguous tile order of
+// the bf16 kernel; bgemm_tn256 - the 256 x 256 LDS-DMA kernel for eligible TN products (fs2_op_bgemm_tn256)
 
 // bf16 TN product in the plain or wgrad form, whole 256 x 256 x 32 tiles, fp32 output, operands inside 32-bit buffer offsets
 bool bgemm_tn256_eligible(const BGemmArgs& a) {
-    if (!g_bgemm_tn256 || a.sAm != 1 || a.sBn != 1 || a.sAk == 1 || a.sBk == 1) return false;
+    if (!tuning_of(a.tune).bgemm_tn256 || a.sAm != 1 || a.sBn != 1 || a.sAk == 1 || a.sBk == 1) return false;
     if (a.M % GT || a.N % GT || a.K % GK || a.taps > 1 || a.c_dtype != FS2_F32 || a.epi_p) return false;
     if (a.seg && (a.seg % GK != 0 || a.K % a.seg != 0)) return false;  // (seg == 0: the k shifts are not applied, as in the general kernel)
     if (!aligned16(a.A) || !aligned16(a.B) || a.sAk % 8 || a.sBk % 8 || a.sA1 % 8 || a.sA2 % 8 || a.sB1 % 8 || a.sB2 % 8) return false;
@@ -931,7 +930,7 @@ int launch_bgemm(const BGemmArgs& a0, int dtype, hipStream_t stream) {
     };
     a.vecA = vec_ok(a.A, a.sAk == 1 ? a.sAm : a.sAk, a.sA1, a.sA2, 0) ? 1 : 0;
     a.vecB = vec_ok(a.B, a.sBk == 1 ? a.sBn : a.sBk, a.sB1, a.sB2, a.taps > 1 ? a.sBtap : 0) ? 1 : 0;
-    a.xcd_remap = g_bgemm_xcd;
+    a.xcd_remap = tuning_of(a.tune).bgemm_xcd;
     const int splitk = a.splitk > 1 ? a.splitk : 1;
     dim3 grid((a.N + BN - 1) / BN, (a.M + BM - 1) / BM, a.nb1 * a.nb2 * splitk);
     const long per = (long)a.M * a.N;
@@ -953,7 +952,7 @@ int launch_bgemm(const BGemmArgs& a0, int dtype, hipStream_t stream) {
         }
         // (measured: a win for the TN products - weight gradients, dV, dK: conv1 wgrad 377 -> 350 us, conv2 wgrad 86 -> 67 - and a
         // loss with a k-contiguous A - P V 87 -> 136 us - where the fourth wave per SIMD only adds LDS pressure: TN only)
-        const bool full = g_bgemm_full && !akc && a.M % BM == 0 && a.N % BN == 0 && a.K % HBK == 0 && a.vecA && a.vecB && a.taps <= 1 &&
+        const bool full = tuning_of(a.tune).bgemm_full && !akc && a.M % BM == 0 && a.N % BN == 0 && a.K % HBK == 0 && a.vecA && a.vecB && a.taps <= 1 &&
                           (a.seg == 0 || (a.seg >= HBK && !bkc));
 #define FS2_BG2(OT, FL) \
         do { \

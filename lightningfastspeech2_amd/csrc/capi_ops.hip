@@ -30,6 +30,39 @@ int launch_convert(const ConvertArgs& a, int sdt, int ddt, hipStream_t st) {
 
 }  // namespace fs2
 
+// A/B switches: one value of fs2_op_set_gemm_variant / fs2_set_tuning applied to a Tuning (fs2_kernels.h).  Every value is listed: an
+// undefined one is FS2_ERR_ARG (a typo in FS2_GEMM_KNOBS must not pass silently); every accepted call bumps Tuning::gen, which is part
+// of an engine's hipGraph keys - a captured phase is never replayed with kernels chosen under other switches.
+namespace fs2 {
+int apply_knob(Tuning& t, int variant) {
+    int ok = 1;
+    if (variant == 1500 || variant == 1501) t.attn_x3 = variant - 1500;               // fp32-storage split modes: attention on fp32 MFMA / on bf16 x 3 split products (default)
+    else if (variant >= 1400 && variant <= 1402) t.gemm_wres = variant - 1400;        // bf16 K = 256 plain GEMMs: slab kernel / weight-resident kernel where it pays (default) / wherever it applies
+    else if (variant == 1320 || variant == 1321) t.pred_fuse_embed = variant - 1320;  // engine: variance encoder (bucketize + embedding add) as the tail of its predictor launch: off / on (default)
+    else if (variant >= 1200 && variant <= 1204) t.attn_pipe = variant - 1200;        // 1200: attention.hip only; 1201 / 1202 / 1204: the software-pipelined kernel with 32 / 64 / 96 queries per wave where it applies; 1203: by size (default)
+    else if (variant == 1100 || variant == 1101) t.colsum_fused = variant - 1100;     // column sums in two launches (default) / one
+    else if (variant == 1000 || variant == 1001) t.bgemm_tn256 = variant - 1000;      // 256 x 256 LDS-DMA kernel for eligible bf16 TN products off / on (default)
+    else if (variant >= 905 && variant <= 908) { if (variant >= 907) t.attn_bwd_nb_dq = 3 + ((variant - 905) & 1); else t.attn_bwd_nb = 3 + ((variant - 905) & 1); }  // 905 / 906: dK,dV launch 3 / 4 blocks per wave; 907 / 908: the dQ launch
+    else if (variant == 909) t.attn_bwd_nb = 1;                                         // dK,dV launch back to its default (1 block per wave)
+    else if (variant >= 900 && variant <= 903) { if (variant >= 902) t.attn_bwd_nb_dq = ((variant - 900) & 1) + 1; else t.attn_bwd_nb = ((variant - 900) & 1) + 1; }  // 900 / 901: dK,dV launch 1 / 2 blocks per wave; 902 / 903: the dQ launch
+    else if (variant == 904) t.attn_bwd_nb_dq = 0;                                      // the dQ launch by size (default)
+    else if (variant == 800 || variant == 801) t.bgemm_full = variant - 800;           // bf16 strided-batched GEMM: generic instantiation only / bounds-free one for full aligned tiles (default)
+    else if (variant == 700 || variant == 701) t.bgemm_xcd = variant - 700;            // bf16 strided-batched GEMM tile order plain / XCD-contiguous (default)
+    else if (variant == 500 || variant == 501) t.split_f32 = variant - 500;            // operator level: fp32 slab launches as fp32 MFMA (default) / bf16 x 3 split
+    else if (variant == 220 || variant == 221) t.gemm_persist = variant - 220;         // multi-round bf16 pointwise launches one tile per workgroup / on the persistent kernel (default)
+    else if (variant == 200 || variant == 201) t.slab_xcd_remap = variant - 200;       // slab kernel tile order plain / XCD-contiguous (default)
+    else if (variant >= 0 && variant <= 7) t.gemm_variant = variant;                    // kernel family / forced tile height of the forward GEMM launcher (gemm_mfma.hip: launch_gemm)
+    else ok = 0;
+    if (!ok) return FS2_ERR_ARG;
+    ++t.gen;
+    return FS2_OK;
+}
+Tuning& op_tuning() {
+    static thread_local Tuning t;
+    return t;
+}
+}  // namespace fs2
+
 extern "C" {
 
 int fs2_op_convert(int32_t sdt, int32_t ddt, const void* src, void* dst, size_t n, void* stream) {
@@ -82,49 +115,18 @@ int fs2_op_masked_loss(const float* pred, const void* truth, int32_t truth_kind,
 }
 
 int fs2_op_set_vocoder_fused_resblock(int32_t on) {
-    fs2::g_voc_fused_resblock = on;
+    fs2::op_tuning().voc_fused_resblock = on;
     return FS2_OK;
 }
 
 int fs2_op_set_vocoder_lds_limit(int32_t kib) {
-    fs2::g_voc_lds_limit = kib;
+    fs2::op_tuning().voc_lds_limit = kib;
     return FS2_OK;
 }
 
 
 
-// Process-global A/B knobs.  Every value is listed: an undefined one is FS2_ERR_ARG (a typo in FS2_GEMM_KNOBS must not pass
-// silently), and every accepted call bumps g_knob_gen, which is part of the engines' hipGraph keys - a captured phase is
-// never replayed with kernels chosen under other knobs.
-static int set_gemm_variant(int32_t variant) {
-    if (variant == 1500 || variant == 1501) { fs2::g_attn_x3 = variant - 1500; return FS2_OK; }        // fp32-storage split modes: attention on fp32 MFMA / on bf16 x 3 split products (default)
-    if (variant >= 1400 && variant <= 1402) { fs2::g_gemm_wres = variant - 1400; return FS2_OK; }      // bf16 K = 256 plain GEMMs: slab kernel / weight-resident kernel where it pays (default) / wherever it applies
-    if (variant == 1320 || variant == 1321) { fs2::g_pred_fuse_embed = variant - 1320; return FS2_OK; }  // engine: variance encoder (bucketize + embedding add) as the tail of its predictor launch: off / on (default)
-    if (variant >= 1300 && variant <= 1302) { fs2::g_pred_tall = variant - 1300; return FS2_OK; }      // 1300 / 1301 / 1302: single-launch predictor on 112-row tiles only / 208-row tiles (one workgroup per CU) / two 112-row tiles per workgroup, when they fill the chip
-    if (variant == 1210 || variant == 1211) { fs2::g_attn_resident = variant - 1210; return FS2_OK; }  // <= 256 keys: K / V streamed tile by tile (default) / resident in LDS
-    if (variant >= 1200 && variant <= 1204) { fs2::g_attn_pipe = variant - 1200; return FS2_OK; }      // 1200: attention.hip only; 1201 / 1202 / 1204: the software-pipelined kernel with 32 / 64 / 96 queries per wave where it applies; 1203: by size (default)
-    if (variant == 1100 || variant == 1101) { fs2::g_colsum_fused = variant - 1100; return FS2_OK; }   // 1100 / 1101: column sums in two launches / one
-    if (variant == 1000 || variant == 1001) { fs2::g_bgemm_tn256 = variant - 1000; return FS2_OK; }    // 1000 / 1001: 256 x 256 LDS-DMA kernel for eligible bf16 TN products off / on
-    if (variant >= 905 && variant <= 908) { fs2::attention_bwd_set_blocks(variant >= 907, 3 + ((variant - 905) & 1)); return FS2_OK; }  // 905 / 906: dK,dV launch 3 / 4 blocks per wave (one wave per SIMD); 907 / 908: the dQ launch
-    if (variant == 909) { fs2::attention_bwd_set_blocks(0, 1); return FS2_OK; }  // dK,dV launch back to its default (1 block per wave)
-    if (variant >= 900 && variant <= 904) { if (variant == 904) fs2::attention_bwd_set_blocks(1, 0); else fs2::attention_bwd_set_blocks((variant - 900) >> 1, ((variant - 900) & 1) + 1); return FS2_OK; }  // 900 / 901: attention backward dK,dV launch 1 / 2 blocks per wave; 902 / 903: the dQ launch, 904: by size
-    if (variant == 800 || variant == 801) { fs2::g_bgemm_full = variant - 800; return FS2_OK; }       // 800 / 801: bf16 strided-batched GEMM generic instantiation only / bounds-free one for full aligned tiles
-    if (variant == 700 || variant == 701) { fs2::g_bgemm_xcd = variant - 700; return FS2_OK; }        // 700 / 701: bf16 strided-batched GEMM tile order plain / XCD-contiguous
-    if (variant == 500 || variant == 501) { fs2::g_split_f32 = variant - 500; return FS2_OK; }       // 500 / 501: fp32 slab launches as fp32 MFMA / bf16 x 3 split
-    if (variant == 310 || variant == 311) { fs2::g_defer_mi8 = variant - 310; return FS2_OK; }  // deferred-LayerNorm GEMM epilogue: 192-row tiles only / 256-row tiles admitted
-    if (variant == 300 || variant == 301) { fs2::g_wide_ln = variant - 300; return FS2_OK; }         // 300 / 301: fused LayerNorm for N > 256 off / on
-    if (variant == 220 || variant == 221) { fs2::g_gemm_persist = variant - 220; return FS2_OK; }    // 220 / 221: multi-round bf16 slab launches one tile per workgroup / on the persistent kernel (default)
-    if (variant == 210 || variant == 211) { fs2::g_slab_ring = variant - 210; return FS2_OK; }       // 210 / 211: pointwise launches on <= 128-row tiles: two-stage loop (default) / operand ring
-    if (variant == 200 || variant == 201) { fs2::g_slab_xcd_remap = variant - 200; return FS2_OK; }  // 200 / 201: tile order knob
-    if (variant >= 0 && variant < 200) { fs2::g_gemm_variant = variant; return FS2_OK; }              // kernel family / forced tile height of the forward GEMM launcher (gemm_mfma.hip: launch_gemm)
-    return FS2_ERR_ARG;
-}
-
-int fs2_op_set_gemm_variant(int32_t variant) {
-    const int st = set_gemm_variant(variant);
-    if (st == FS2_OK) ++fs2::g_knob_gen;
-    return st;
-}
+int fs2_op_set_gemm_variant(int32_t variant) { return fs2::apply_knob(fs2::op_tuning(), variant); }
 
 int fs2_op_gemm(int32_t dtype, int32_t out_dtype, const void* x, const void* w, const float* bias, void* c,
                 int32_t M, int32_t N, int32_t Cin, int32_t taps, int32_t S, int32_t relu, void* stream) {

@@ -141,6 +141,7 @@ struct fs2_engine {
     long graph_replays = 0;
     bool zero_pad_mel = false;
     bool defer_ln = true;      // hidden > 256, depth-wise blocks: LayerNorm deferred into its consumers (A/B: fs2_set_deferred_layernorm)
+    Tuning tune;               // this engine's A/B switches (fs2_set_tuning; copied by fs2_clone): every launch of the engine points at them
     bool fold_ln = true;       // ... and a block's closing norm2 folded into the next block's in-projection (bf16; A/B: fs2_set_folded_layernorm)
     bool front_split = false;  // FS2_MIXED_X3 / FS2_F32_X3: the fp32 GEMMs / convs (the front's / all of them) run as bf16 x 3 split products
     std::map<std::string, HostTensor> host;
@@ -568,6 +569,7 @@ int gemm(fs2_engine* e, hipStream_t st, const ConvW& w, const void* x, void* c, 
          const LnFuse* ln = nullptr, int extra_class = -1, const uint8_t* zero_rows = nullptr, const Deferred* df = nullptr,
          void* c_lo = nullptr, const RowScale* rs = nullptr) {
     GemmArgs a;
+    a.tune = &e->tune;
     a.zero_rows = zero_rows;
     a.C_lo = c_lo;
     if (rs) { a.rs_stats = rs->rowstats; a.rs_wg = rs->wg; }
@@ -657,7 +659,7 @@ int conformer(fs2_engine* e, hipStream_t st, const LayerW& w, void* x, void* tmp
     Bracket* mha = is_decoder ? nullptr : new Bracket(e, FS2_K_ENC_MHA, st, 8.0 * M * (double)H * H + 4.0 * B * (double)S * S * H,
                                                       2.0 * M * H * dsz + 4.0 * H * H * dsz);
     struct MhaEnd { Bracket*& b; ~MhaEnd() { delete b; b = nullptr; } } mha_end{mha};
-    const bool x3 = e->front_split && dt == FS2_F32 && g_attn_x3;
+    const bool x3 = e->front_split && dt == FS2_F32 && e->tune.attn_x3;
     void* qkv_lo = x3 ? (void*)((char*)sc.qkv + (size_t)M * 3 * H * 2) : nullptr;
     if (prenorm_in) {
         if (!w.has_fold || !(w.depthwise && H > 256 && e->defer_ln)) return fail(e, FS2_ERR_STATE, "pre-norm block input without folded weights");
@@ -667,6 +669,7 @@ int conformer(fs2_engine* e, hipStream_t st, const LayerW& w, void* x, void* tmp
         CHK(gemm(e, st, w.in_proj, x, sc.qkv, M, M, false, dt, nullptr, -1, nullptr, nullptr, qkv_lo));
     }
     AttnArgs a;
+    a.tune = &e->tune;
     a.qkv_lo = qkv_lo;
     a.qkv = sc.qkv; a.vt = sc.vt; a.kbits = sc.bits; a.out = sc.att;
     a.B = B; a.S = S; a.H = H; a.heads = heads; a.Spad = sc.Spad; a.nw64 = sc.nw64;
@@ -959,6 +962,7 @@ int fs2_clone(const fs2_engine* src, fs2_engine** out) {
     e->zero_pad_mel = src->zero_pad_mel;
     e->defer_ln = src->defer_ln;
     e->fold_ln = src->fold_ln;
+    e->tune = src->tune;
     e->front_split = src->front_split;
     e->spec = src->spec;
     e->dev_allocs = src->dev_allocs;
@@ -1073,6 +1077,14 @@ int fs2_set_deferred_layernorm(fs2_engine* e, int32_t on) {
     return FS2_OK;
 }
 
+// One A/B switch of THIS engine (the values of fs2_op_set_gemm_variant, include/fs2.h); clones made afterwards inherit it.
+int fs2_set_tuning(fs2_engine* e, int32_t knob) {
+    if (!e) return FS2_ERR_ARG;
+    const int r = apply_knob(e->tune, knob);
+    if (r != FS2_OK) return fail(e, r, "fs2_set_tuning(%d): not a defined switch", (int)knob);
+    return FS2_OK;
+}
+
 int fs2_set_folded_layernorm(fs2_engine* e, int32_t on) {
     if (!e) return FS2_ERR_ARG;
     e->fold_ln = on != 0;
@@ -1158,7 +1170,7 @@ int fs2_encode(fs2_engine* e, const int64_t* phones, const float* speaker, int32
     // every launch of the phase (no host decision among them), plainly or as a replayed hipGraph (fs2_set_graphs)
     {
         std::vector<uint64_t> key = {(uint64_t)B, (uint64_t)L, (uint64_t)e->persist.base, (uint64_t)e->scratch.base, (uint64_t)phones,
-                                     (uint64_t)speaker, (uint64_t)forced, (uint64_t)e->h_pinned, (uint64_t)e->fuse_predictor, (uint64_t)g_knob_gen,
+                                     (uint64_t)speaker, (uint64_t)forced, (uint64_t)e->h_pinned, (uint64_t)e->fuse_predictor, (uint64_t)e->tune.gen,
                                      (uint64_t)e->defer_ln, (uint64_t)e->front_split, (uint64_t)e->fold_ln};
         const bool plain = c.n_priors != 0;  // a prior tensor is a one-shot pointer of the call
         CHK(run_phase(e, e->egraphs, key, plain, st, [&](hipStream_t s2) { return encode_body(e, phones, speaker, forced, sc, s2); }));
@@ -1287,7 +1299,7 @@ static int decode_body(fs2_engine* e, const fs2_outputs* out, hipStream_t st) {
         const bool last = v + 1 == c.n_variances;
         // the encoder's bucketize + embedding add rides in the predictor launch where nothing else wants its by-products
         // (bucket indices for the debug taps, forced buckets / targets of the teacher-forced and oracle paths)
-        const bool tail_ok = g_pred_fuse_embed && !e->debug && !e->forced_idx[v] && !e->forced_tgt[v] && !c.var_cwt[v] &&
+        const bool tail_ok = e->tune.pred_fuse_embed && !e->debug && !e->forced_idx[v] && !e->forced_tgt[v] && !c.var_cwt[v] &&
                              e->fdt == FS2_BF16 && H == 256;
         const EmbedTail tl{yB, e->vars[v].bins, e->vars[v].emb, c.var_nbins, c.var_std[v], c.var_mean[v],
                            (last && fuse_pe) ? e->pe : nullptr, (last && fuse_pe) ? e->spk : nullptr};
@@ -1412,7 +1424,7 @@ int fs2_decode(fs2_engine* e, const fs2_outputs* out, void* stream) {
     CHK(ensure_arena(e, e->scratch, decode_scratch_bytes(e, e->B, e->T), "scratch"));
     if (e->scratch.base != base0) drop_graphs(e);
     std::vector<uint64_t> key = {(uint64_t)e->B, (uint64_t)e->L, (uint64_t)e->T, (uint64_t)e->scratch.base, (uint64_t)e->persist.base,
-                                 (uint64_t)e->xA, (uint64_t)e->d_cum, (uint64_t)e->spk, (uint64_t)e->zero_pad_mel, (uint64_t)e->fuse_predictor, (uint64_t)g_knob_gen,
+                                 (uint64_t)e->xA, (uint64_t)e->d_cum, (uint64_t)e->spk, (uint64_t)e->zero_pad_mel, (uint64_t)e->fuse_predictor, (uint64_t)e->tune.gen,
                                  (uint64_t)e->defer_ln, (uint64_t)e->front_split, (uint64_t)e->fold_ln, (uint64_t)out->mel, (uint64_t)out->tgt_mask,
                                  (uint64_t)out->duration_prediction, (uint64_t)out->duration_rounded, (uint64_t)out->src_mask};
     for (int v = 0; v < FS2_MAX_VARIANCES; ++v) {

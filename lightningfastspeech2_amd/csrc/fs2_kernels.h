@@ -7,6 +7,31 @@
 
 namespace fs2 {
 
+// A/B switches of the launchers (kernel family, tile order, which fused form a launch takes).  NOT process state: an engine owns one
+// (fs2_set_tuning, copied by fs2_clone), the operator-level entry points (fs2_op_*: tests, the training step) use the CALLING
+// THREAD's (fs2_op_set_gemm_variant -> op_tuning()).  Every launcher reads the one its arguments point at (Args::tune; null = the
+// calling thread's).  Defaults are what measured fastest; every non-default value is kept for A/B or for the tests that pin two
+// forms against each other.  (Until r05 these were ~20 process-wide ints read unsynchronised by every engine and pipeline thread.)
+struct Tuning {
+    int gemm_variant = 0;      // 0 auto; 1 128x128 register-staged; 2 128x256 DMA ring; 3/4/5 slab kernel 128/192/256-row tiles; 6/7 32/64-row
+    int gemm_wres = 1;         // bf16 K = 256 plain GEMMs on the weight-resident kernel: 0 never, 1 where it pays, 2 wherever it applies
+    int gemm_persist = 1;      // bf16 pointwise launches of more tiles than CUs on the persistent kernel (gemm_persist.hip)
+    int slab_xcd_remap = 1;    // XCD-contiguous tile order in the slab kernel
+    int split_f32 = 0;         // operator level only (tests): every fp32 slab launch in the bf16 x 3 split arithmetic
+    int attn_pipe = 3;         // 0 attention_kernel only; 1 / 2 / 4 the pipelined kernel with 32 / 64 / 96 queries per wave; 3 by size
+    int attn_x3 = 1;           // fp32-storage split modes: attention on bf16 x 3 split products (1) or fp32 MFMA (0)
+    int pred_fuse_embed = 1;   // engine: the variance encoder's bucketize + embedding add as the tail of its predictor launch
+    int attn_bwd_nb = 1, attn_bwd_nb_dq = 0;  // attention backward: 16-row blocks per wave of the (dK, dV) / dQ launch (dQ: 0 = by size)
+    int colsum_fused = 0;      // column sums in one launch (device-scope fences: slower) / two
+    int bgemm_full = 1, bgemm_xcd = 1, bgemm_tn256 = 1;
+    int voc_lds_limit = 0;     // KiB cap on a vocoder conv workgroup's slab; 0 = heuristic
+    int voc_fused_resblock = 1;
+    unsigned long long gen = 0;  // bumped by every accepted change: part of an engine's hipGraph keys
+};
+Tuning& op_tuning();                       // the calling thread's (capi_ops.hip)
+int apply_knob(Tuning& t, int variant);    // one fs2_op_set_gemm_variant / fs2_set_tuning value; FS2_ERR_ARG for an undefined one
+inline const Tuning& tuning_of(const Tuning* t) { return t ? *t : op_tuning(); }
+
 struct GemmArgs {
     const void* X;      // (M, ldx) activations, row-major
     const void* W;      // (N, K) weights, K = taps*Cin (tap-major)
@@ -35,6 +60,7 @@ struct GemmArgs {
     void* z_out = nullptr;          // (M, ldc), C's dtype: the fused epilogue also stores the PRE-norm rows act(acc + bias) [+ res] (the
                                     // training tape: LayerNorm's backward needs them); slab kernel only, null otherwise
     int xcd_remap = 0;              // set by the launcher
+    const Tuning* tune = nullptr;   // null: the calling thread's (op_tuning())
     // Deferred-LayerNorm epilogue of the slab kernel (no ln_g): C = v = act(acc + bias) + res, and per row the partial
     // sums (sum v, sum v^2) of every 64-column wave slice -> stats_out (M, ceil(N/256)*4) float2.  epi_res_stats != null:
     // the residual is a pre-norm tensor normalised on load from ITS parts (epi_res_parts per row) with epi_res_g / _b.
@@ -70,19 +96,12 @@ bool gemm_presplit_eligible(int N, int K);
 int launch_split_k_reduce(const float* part, void* out, size_t n, int ksplit, int accumulate, int out_dtype, hipStream_t stream);
 // the split a long-K, few-tile GEMM / conv is worth (1 = none): tools/bench_ops.py dgrad
 int gemm_splitk_choice(int M, int N, int Cin, int taps, int S, int in_dtype);
-extern int g_gemm_variant;
-extern int g_gemm_wres;  // 1 = bf16 K = 256 plain GEMMs on the weight-resident kernel (gemm_wres.hip)
 bool gemm_wres_supported(const GemmArgs& a, int in_dtype, int out_dtype, bool force);
 int launch_gemm_wres(const GemmArgs& a, hipStream_t stream);
 // gemm_persist.hip: the slab kernel's persistent form (one workgroup per CU walks its tiles; bit-identical results)
-extern int g_gemm_persist;
 bool gemm_persist_supported(const GemmArgs& a, int in_dtype, int out_dtype, int mi);
 bool gemm_persist_pays(const GemmArgs& a, int mi);
 int launch_gemm_persist(const GemmArgs& a, int mi, hipStream_t stream);
-extern int g_wide_ln;
-extern int g_defer_mi8;
-extern int g_split_f32;
-extern int g_slab_xcd_remap;  // 1 = XCD-contiguous tile order in the slab kernel (A/B knob)  // test/bench knob: 0 auto, 1 force the 128x128 kernel, 2 force the DMA kernel
 
 struct AttnArgs {
     const void* qkv;        // (B*S, 3H): [q | k | v] columns, head h at h*d
@@ -98,6 +117,7 @@ struct AttnArgs {
     float* lse2 = nullptr;  // (B, heads, S) or null
     float drop_p = 0.f;
     uint64_t drop_seed = 0, drop_key = 0;
+    const Tuning* tune = nullptr;
 };
 // Recomputing (flash) backward of the same attention, bf16, head dim 128 (attention_bwd.hip): dqkv (B*S, 3H) from dout (B*S, H),
 // the forward's qkv / lse2 and delta = fs2 attn_delta(dout, out).  Two launches: (dK, dV) per key block, dQ per query block.
@@ -112,9 +132,9 @@ struct AttnBwdArgs {
     float scale_log2e, scale;
     float drop_p;
     uint64_t drop_seed, drop_key;
+    const Tuning* tune = nullptr;
 };
 bool attention_bwd_supported(int dtype, int H, int heads);
-void attention_bwd_set_blocks(int which, int nb);  // A/B knob: 16-row blocks per wave (1 or 2) of the dK,dV (which = 0) / dQ (1) launch
 int launch_attention_bwd(const AttnBwdArgs& a, int dtype, hipStream_t stream);
 int launch_transpose_v(const AttnArgs& a, int dtype, hipStream_t stream);  // fills a.vt from a.qkv
 int launch_split_hi_lo(const float* x, void* hi, void* lo, size_t n, hipStream_t stream);  // fp32 -> bf16 head + bf16 tail, n % 8 == 0
@@ -122,9 +142,6 @@ int launch_attention(const AttnArgs& a, int dtype, hipStream_t stream);    // ne
 // attention_pipe.hip: the software-pipelined kernel for the MFMA-bound instance (bf16, head dim 128, no attention dropout)
 bool attention_pipe_supported(const AttnArgs& a, int dtype);
 int launch_attention_pipe(const AttnArgs& a, int variant, hipStream_t stream);
-extern int g_attn_pipe;
-extern int g_attn_resident;
-extern int g_pred_tall;  // predictor_fused.hip: 208-row tiles (one workgroup per CU) where they fill the chip
 
 // Whole dense VariancePredictor (n x [conv k=3 -> ReLU -> LN] -> Linear(H,1) -> mask) in one launch;
 // bf16, H = 256, k = 3 (predictor_fused.hip).  wpk = per-layer weights in MFMA fragment order
@@ -152,10 +169,6 @@ struct PredictorArgs {
     const float* be_pe = nullptr;    // (>= S, H) fp32 or null
     const float* be_spk = nullptr;   // (B, H) fp32 or null
 };
-extern int g_attn_x3;   // A/B knob (1500 / 1501): fp32-storage split modes with fp32-MFMA attention / the bf16 x 3 split attention (default)
-extern int g_slab_ring;  // A/B knob (210 / 211): the slab kernel's operand ring for pointwise launches on short tiles
-extern unsigned long long g_knob_gen;  // bumped by every accepted fs2_op_set_gemm_variant call; part of the hipGraph keys (capi_ops.hip)
-extern int g_pred_fuse_embed;  // A/B knob (1320 / 1321): the engine's frame-level variance encoders as the tail of their predictor launch
 bool predictor_fused_supported(int dtype, int H, int taps, int nlayers, int S);
 size_t predictor_packed_bytes_per_layer();
 int launch_pack_predictor_weights(const void* w_layer /*(H, taps*H) tap-major bf16*/, void* out_layer, hipStream_t stream);
@@ -181,6 +194,7 @@ struct VocConvArgs {
     int in_fp32;
     int post;               // conv_post: one channel, tanh, fp32 out
     float out_slope = 1.f;  // store LeakyReLU(result): every consumer is a resident resblock launch with x_act
+    const Tuning* tune = nullptr;
 };
 // A whole ResBlock "1" (npairs = 3 (c1 dilated, c2) pairs) or one pair (npairs = 1) on an LDS-resident
 // tile, vocoder_resblock.hip.  out = (x after the pairs) * scale (+ previous contents).
@@ -197,8 +211,8 @@ struct VocResblockArgs {
     int accumulate;
     int x_act = 0;          // x already holds lrelu(x) (written by a launch with out_act): the fill is a plain LDS-DMA copy
     int out_act = 0;        // store lrelu(result) for such a consumer (pairs inside a block; never with accumulate)
+    const Tuning* tune = nullptr;
 };
-extern int g_voc_fused_resblock;  // 1 = use the fused kernel where it applies
 struct LossArgs {
     const float* pred;   // (rows, inner) fp32
     const void* truth;   // truth_kind 0: fp32 (rows, inner); 1: int64 durations, compared as log(d + 1)
@@ -223,7 +237,6 @@ size_t masked_loss_ws_bytes();
 int launch_masked_loss(const LossArgs& a, hipStream_t stream);
 int voc_resblock_mi16(const VocResblockArgs& a, int dtype);  // 0 = shape not covered
 int launch_vocoder_resblock(const VocResblockArgs& a, int dtype, hipStream_t stream);
-extern int g_voc_lds_limit;  // KiB cap on a conv workgroup's slab; 0 = heuristic
 int voc_steps_padded(int taps, int cin_pad, int dtype);
 int launch_vocoder_conv(const VocConvArgs& a, int dtype, hipStream_t stream);
 
@@ -386,11 +399,9 @@ struct BGemmArgs {
     int c_dtype = FS2_F32;        // dtype of C: bf16 operands may write bf16 (activations) or fp32 (weight gradients, scores)
     int vecA = 0, vecB = 0;       // set by the launcher
     int xcd_remap = 0;            // set by the launcher
+    const Tuning* tune = nullptr;
 };
 size_t bgemm_ws_bytes(const BGemmArgs& a);
-extern int g_bgemm_xcd;
-extern int g_bgemm_full;
-extern int g_bgemm_tn256;
 bool bgemm_tn256_eligible(const BGemmArgs& a);  // bf16 operands only
 int launch_bgemm(const BGemmArgs& a, int dtype, hipStream_t stream);
 
@@ -429,8 +440,8 @@ struct ColSumArgs {
     int n1 = 0;
     int accumulate2 = 0;
     const float* row_w = nullptr;  // (M) or null: rows are weighted, out[s][n] (+)= scale * sum_r row_w[r] x[r][n]
+    const Tuning* tune = nullptr;
 };
-extern int g_colsum_fused;
 size_t col_sum_ws_bytes(int M, int N, int seg);
 int launch_col_sum(const ColSumArgs& a, int dtype, hipStream_t stream);
 

@@ -363,13 +363,11 @@ template <int MI> struct SlabCfg {
 static constexpr int S_BN = 256;
 template <bool B> struct BoolC { static constexpr bool value = B; };
 
-// WIDE (with LN): the fused LayerNorm epilogue for N > 256.  A workgroup still owns whole rows, but walks the
-// N / 256 column tiles one after the other (each a complete K loop): per tile it stores the pre-norm values
-// v = act(acc + bias) + res and keeps per-row partial sums of v and v^2 in registers; after the last tile the
-// row statistics are exchanged through LDS and the workgroup re-reads ITS OWN rows (just written, L2-resident),
-// normalises them in place and, for a predictor's last layer, evaluates the Linear(filter, 1) head.  That
-// replaces a GEMM launch + a stand-alone LayerNorm launch (one more HBM round trip of the (M, N) tensor and of
-// the residual) for hidden sizes 768 / 1024 (BASELINE configs C3 / C5).
+// (r02 built an in-place WIDE fused LayerNorm epilogue for N > 256 - one workgroup per row tile walks the column tiles, stores pre-norm
+// rows, re-reads and normalises its own rows - which only tied two launches at M = 49152, K = 768 (118 vs 120 us) and lost elsewhere
+// (K = 3072: 357 vs 294 us; M = 8192 / 12288: 1.5-2.2x slower); r04 an operand RING of 3 / 4 stages for pointwise launches on short
+// tiles, measured neutral (these launches are bound by what a CU ingests per second, not by a step's round trip).  Both removed in r05;
+// DESIGN 4 keeps the measurements.)
 // SPLIT (T = float only): fp32 operands, bf16 x 3 arithmetic.  Each fp32 value is split in registers into a bf16 head
 // and a bf16 tail (x = hi + lo up to 2^-17 |x|) and a product becomes three bf16 MFMAs, hi*hi + hi*lo + lo*hi, accumulated
 // in fp32 (the dropped lo*lo term is 2^-16 of the product): ~1e-5 relative, ~400x closer to fp32 than bf16 storage, at
@@ -388,33 +386,20 @@ __device__ unsigned long long g_slab_stamps[4][8];
 #define SLAB_STAMP(i) do { } while (0)
 #endif
 
-// NST > 2 (pointwise launches only, taps == 1; r04): the operand RING.  With two stages a step's DMAs are requested one step ahead;
-// where a step is short (32- / 64- / 128-row tiles: 256 .. 1100 MFMA cycles) that is less than the round trip of an L2 miss, and
-// inside a forward every launch finds its weights L2-cold (last touched a layer ago): the encoder's conv2 + LayerNorm launch took
-// 22 us in the forward against 13.9 us back to back on hot caches (tools/bench_ops.py --flush: 19.9 us with the L2s flushed, 26.1
-// with the Infinity Cache flushed too) - a latency-bound loop, PMC waits 0.74 of its wave cycles.  NST stages of (row tile x 64
-// channels, 256 x 64 weight tile), NST - 1 steps in flight, a COUNTED vmcnt per step (the builtin, so that hipcc's own LDS-DMA
-// scoreboard sees it) and the raw s_barrier (a __syncthreads() would drain every DMA in flight).  The slabs of this mode hold
-// the tile's rows only (no conv halo), so 4 stages fit at 32-row tiles (160 KiB) and 3 at 64 / 128 rows.
-template <typename T, typename OutT, int MI, bool LN, bool WIDE = false, bool SPLIT = false, bool DEFER = false, int NST = 2, bool XPRE = false>
+template <typename T, typename OutT, int MI, bool LN, bool SPLIT = false, bool DEFER = false, bool XPRE = false>
 __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
     static_assert(!XPRE || SPLIT, "XPRE: the split arithmetic's conv form (activation slab split in place when it lands)");
     static_assert(!SPLIT || sizeof(T) == 4, "the split arithmetic takes fp32 operands");
     static_assert(!(DEFER && LN), "deferred LayerNorm is what a launch WITHOUT the fused epilogue leaves behind");
-    static_assert(NST >= 2 && NST <= 4 && !(NST > 2 && (WIDE || SPLIT)), "operand ring: 2 (two-stage loop), 3 or 4 stages");
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-resource builtins only exist in the device pass
     using Cfg = SlabCfg<MI>;
     constexpr int BMs = Cfg::BM;
-    constexpr int SI = NST > 2 ? (BMs / 8 + 7) / 8 : Cfg::SI;                       // ring mode: the tile's own rows, no halo
-    constexpr int SLAB_B = NST > 2 ? SI * 8 * 1024 : Cfg::SLAB_BYTES;
+    constexpr int SI = Cfg::SI;
+    constexpr int SLAB_B = Cfg::SLAB_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char slab0[SLAB_B];
     __shared__ __attribute__((aligned(16))) unsigned char slab1[SLAB_B];
-    __shared__ __attribute__((aligned(16))) unsigned char slab2[NST > 2 ? SLAB_B : 16];
-    __shared__ __attribute__((aligned(16))) unsigned char slab3[NST > 3 ? SLAB_B : 16];
     __shared__ __attribute__((aligned(16))) unsigned char wt0[S_BN * ROWB];  // 32 KiB weight tile per stage
     __shared__ __attribute__((aligned(16))) unsigned char wt1[S_BN * ROWB];
-    __shared__ __attribute__((aligned(16))) unsigned char wt2[NST > 2 ? S_BN * ROWB : 16];
-    __shared__ __attribute__((aligned(16))) unsigned char wt3[NST > 3 ? S_BN * ROWB : 16];
     constexpr int KE = ROWB / (int)sizeof(T);
     SLAB_STAMP(0);
 
@@ -435,15 +420,15 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
     // taps) and stores its partial sums into plane ks of C, (ksplit, M, ldc); split_k_reduce_kernel adds the planes up.  ks is the
     // SLOWEST tile index, so an XCD's contiguous tile range reads one or two weight slices, not the whole panel.
     int ks = 0;
-    if constexpr (!LN && !WIDE && !DEFER) {
+    if constexpr (!LN && !DEFER) {
         if (p.ksplit > 1) {
             const int per_split = gridDim.x / p.ksplit;
             ks = bid / per_split;
             bid -= ks * per_split;
         }
     }
-    int bn = 0;
-    if constexpr (!WIDE) { bn = bid % tiles_n; bid /= tiles_n; }
+    const int bn = bid % tiles_n;
+    bid /= tiles_n;
     const int tm = bid % tiles_m, ub = bid / tiles_m;
     if (ub >= nutt) return;
     const int t0 = tm * BMs;
@@ -616,30 +601,12 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
         }                                                                                   \
         compute(slab_cur, w_cur, (tapv));                                                   \
     }
-    float ws1[WIDE ? MI : 1], ws2[WIDE ? MI : 1];  // WIDE: this lane's share of sum(v), sum(v^2) per row, over all tiles
-    if constexpr (WIDE) {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) ws1[mi] = ws2[mi] = 0.f;
-    }
-    const int nct = WIDE ? tiles_n : 1;
-    for (int ct = 0; ct < nct; ++ct) {  // WIDE: one pass of the whole K loop per 256-column tile; otherwise once
-    if constexpr (WIDE) {
-        n0 = ct * S_BN;
-        if (ct) {
-            __syncthreads();  // every wave has left the previous tile's last step: its operand buffers are free
-            set_wvoff();
-        }
-    }
     // the first operand DMAs go out BEFORE the residual preload below: that preload waits for its own global loads (11 k of a
     // 35 k-tick out-projection + LayerNorm launch sat in front of the first DMA, tools/probes/slab_phase_stamps.py) and the two
     // round trips now overlap
     SLAB_STAMP(1);
     issue_slab(slab0, 0);
     issue_w(wt0, 0, 0);
-    if constexpr (NST > 2) {  // the ring's other NST - 2 leading steps: everything the first steps need is requested before any wait
-        if (ncc > 1) { issue_slab(slab1, 1); issue_w(wt1, 1, 0); }
-        if (NST > 3 && ncc > 2) { issue_slab(slab2, 2); issue_w(wt2, 2, 0); }
-    }
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -756,37 +723,6 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
         else preload(BoolC<false>{});
     }
     SLAB_STAMP(6);
-    if constexpr (NST > 2) {
-        // ---- operand ring (taps == 1): step cc multiplies stage cc % NST; steps cc + 1 .. cc + NST - 2 are in flight across its barrier,
-        // step cc + NST - 1 is requested right behind the barrier into the stage step cc - 1 has just left.  A DMA wave issues G
-        // instructions per step, in order, so "all but the youngest (NST - 2) G have landed" is this wave's share of step cc.
-        constexpr int G = DSI + DWI;
-#define FS2_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (7 << 4) | (15 << 8) | (((n) >> 4) << 14))
-#define FS2_RING_STEP(slab_cur, w_cur, slab_nxt, w_nxt, ccv)                                                   \
-    {                                                                                                          \
-        const int left = ncc - 1 - (ccv); /* steps requested behind this one */                               \
-        if (left >= NST - 2) FS2_VMCNT((NST - 2) * G);                                                         \
-        else if (NST == 4 && left == 1) FS2_VMCNT(G);                                                          \
-        else FS2_VMCNT(0);                                                                                     \
-        __builtin_amdgcn_s_barrier();                                                                          \
-        if ((ccv) + NST - 1 < ncc) { issue_slab(slab_nxt, (ccv) + NST - 1); issue_w(w_nxt, (ccv) + NST - 1, 0); } \
-        compute(slab_cur, w_cur, 0);                                                                           \
-    }
-        for (int cc = 0; cc < ncc; cc += NST) {
-            if constexpr (NST == 3) {
-                FS2_RING_STEP(slab0, wt0, slab2, wt2, cc)
-                if (cc + 1 < ncc) FS2_RING_STEP(slab1, wt1, slab0, wt0, cc + 1)
-                if (cc + 2 < ncc) FS2_RING_STEP(slab2, wt2, slab1, wt1, cc + 2)
-            } else {
-                FS2_RING_STEP(slab0, wt0, slab3, wt3, cc)
-                if (cc + 1 < ncc) FS2_RING_STEP(slab1, wt1, slab0, wt0, cc + 1)
-                if (cc + 2 < ncc) FS2_RING_STEP(slab2, wt2, slab1, wt1, cc + 2)
-                if (cc + 3 < ncc) FS2_RING_STEP(slab3, wt3, slab2, wt2, cc + 3)
-            }
-        }
-#undef FS2_RING_STEP
-#undef FS2_VMCNT
-    } else
     for (int cc = 0; cc < ncc; cc += 2) {
         for (int tap = 0; tap < ntap; tap += 2) {
             FS2_SLAB_STEP(slab0, slab1, wt0, wt1, cc, tap)
@@ -800,134 +736,9 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
         }
     }
     SLAB_STAMP(2);
-    if constexpr (WIDE) {
-        // this column tile's pre-norm values v = act(acc + bias) + res: row partial sums + one 16-byte store per
-        // 8 consecutive channels (columns past N come out of the K loop as exact zeros and stay zero)
-        const float lo = p.relu ? 0.f : -__builtin_inff();
-        OutT* __restrict__ Cp = (OutT*)(p.C ? p.C : p.ln_tmp) + (size_t)ub * S * p.ldc;
-        const T* R = (p.res && !res_in_acc) ? (const T*)p.res + (size_t)ub * S * p.ldc : nullptr;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = n0 + wn * 64 + j * 32 + fg * 8;
-            float bv[8];
-#pragma unroll
-            for (int r = 0; r < 8; ++r) bv[r] = (p.bias && n + r < p.N) ? p.bias[n + r] : 0.f;
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                const int t = t0 + wm * (MI * 16) + mi * 16 + fr;
-                float v[8];
-#pragma unroll
-                for (int r = 0; r < 8; ++r) v[r] = fmaxf(acc[2 * j + (r >> 2)][mi][r & 3] + bv[r], lo);
-                if (R) {
-                    const T* src = R + (size_t)(t < S ? t : S - 1) * p.ldc + n;
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) if (n + r < p.N) v[r] += Num<T>::to_f32(src[r]);
-                }
-                if (n + 7 >= p.N) {
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) if (n + r >= p.N) v[r] = 0.f;
-                }
-                float a1 = 0.f, a2 = 0.f;
-#pragma unroll
-                for (int r = 0; r < 8; ++r) { a1 += v[r]; a2 = __builtin_fmaf(v[r], v[r], a2); }
-                ws1[mi] += a1;
-                ws2[mi] += a2;
-                if (t < S && n < p.N) {
-                    OutT* dst = Cp + (size_t)t * p.ldc + n;
-                    if (n + 7 < p.N) {
-                        if constexpr (sizeof(OutT) == 4) {
-                            *(float4*)dst = make_float4(v[0], v[1], v[2], v[3]);
-                            *(float4*)(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
-                        } else {
-                            *(uint4*)dst = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]),
-                                                      pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
-                        }
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 8; ++r) if (n + r < p.N) dst[r] = Num<OutT>::from_f32(v[r]);
-                    }
-                }
-            }
-        }
-    }
-    }  // column tiles
 #undef FS2_SLAB_STEP
 
-    if constexpr (WIDE) {
-        // ---- row statistics over all column tiles, then normalise this workgroup's own rows in place ----
-        static_assert(sizeof(T) == sizeof(OutT), "the wide LayerNorm epilogue rewrites its own output");
-        const size_t rowbase = (size_t)ub * S;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pre-norm stores have left the CU ...
-        __syncthreads();  // ... and so have everyone else's (one CU, one L1: visible to the whole workgroup); buffers free
-        float* red = (float*)slab0;  // [2][4 column waves][BMs rows]
-        float* lnp = (float*)wt0;    // [gamma N | beta N | head weight N], N <= 1024
-        for (int i = tid; i < p.N; i += 512) {
-            lnp[i] = p.ln_g[i];
-            lnp[p.N + i] = p.ln_b[i];
-            lnp[2 * p.N + i] = p.dot_w ? p.dot_w[i] : 0.f;
-        }
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const float a1 = group4_sum(ws1[mi]), a2 = group4_sum(ws2[mi]);
-            if (fg == 0) {
-                const int row = wm * (MI * 16) + mi * 16 + fr;
-                red[wn * BMs + row] = a1;
-                red[(4 + wn) * BMs + row] = a2;
-            }
-        }
-        __syncthreads();
-        constexpr int E16 = 16 / (int)sizeof(T);          // elements per 16-byte chunk
-        constexpr int MAXC = 1024 / E16 / 64;             // chunks per lane at N = 1024
-        constexpr int RB = sizeof(T) == 2 ? 4 : 2;        // rows in flight per wave
-        const int nch = p.N / E16;
-        const float invn = 1.0f / (float)p.N;
-        T* __restrict__ Cp = (T*)(p.C ? p.C : p.ln_tmp) + rowbase * p.ldc;
-        for (int rb = wave * RB; rb < BMs; rb += 8 * RB) {
-            uint4 q[RB][MAXC];
-#pragma unroll
-            for (int k = 0; k < RB; ++k) {
-                const int t = t0 + rb + k;
-#pragma unroll
-                for (int c = 0; c < MAXC; ++c) {
-                    const int ch = lane + 64 * c;
-                    if (ch < nch && t < S) q[k][c] = *(const uint4*)(Cp + (size_t)t * p.ldc + ch * E16);
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < RB; ++k) {
-                const int row = rb + k, t = t0 + row;
-                if (t >= S) continue;
-                const float s1 = (red[row] + red[BMs + row]) + (red[2 * BMs + row] + red[3 * BMs + row]);
-                const float s2 = (red[4 * BMs + row] + red[5 * BMs + row]) + (red[6 * BMs + row] + red[7 * BMs + row]);
-                const float mean = s1 * invn;
-                const float var = fmaxf(__builtin_fmaf(-mean, mean, s2 * invn), 0.f);
-                const float rstd = 1.0f / sqrtf(var + p.ln_eps);
-                float dsum = 0.f;
-#pragma unroll
-                for (int c = 0; c < MAXC; ++c) {
-                    const int ch = lane + 64 * c;
-                    if (ch < nch) {
-                        float f[E16], y[E16];
-                        Vec16<T>::unpack(q[k][c], f);
-#pragma unroll
-                        for (int e = 0; e < E16; ++e) {
-                            const int n = ch * E16 + e;
-                            y[e] = __builtin_fmaf((f[e] - mean) * rstd, lnp[n], lnp[p.N + n]);
-                            dsum = __builtin_fmaf(y[e], lnp[2 * p.N + n], dsum);
-                        }
-                        if (p.C) *(uint4*)(Cp + (size_t)t * p.ldc + ch * E16) = Vec16<T>::pack(y);
-                    }
-                }
-                if (p.dot_w) {
-                    dsum = wave_sum(dsum) + p.dot_b;
-                    if (lane == 0) p.pred[rowbase + t] = (p.mask && p.mask[rowbase + t]) ? 0.f : dsum;
-                }
-            }
-        }
-        return;
-    }
-
-    if constexpr (LN && !WIDE) {
+    if constexpr (LN) {
         // ---- fused row epilogue: the workgroup owns whole rows (tiles_n == 1) ----
         // LayerNorm(act(acc + bias) [+ res]) with two-pass statistics: lane partials -> lane-group
         // shuffles -> one LDS exchange between the four column waves; optional predictor head.
@@ -1420,99 +1231,78 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
 #endif
 }
 
-template <typename T, typename OutT, int MI, bool LN, bool WIDE = false, bool SPLIT = false, bool DEFER = false, int NST = 2>
+template <typename T, typename OutT, int MI, bool LN, bool SPLIT = false, bool DEFER = false>
 static int launch_slab_t(const GemmArgs& a0, hipStream_t stream) {
-    if constexpr (SPLIT && NST == 2) {  // conv launches of the split arithmetic: the slab is split in place when it lands
-        if (a0.taps > 1) {
-            GemmArgs a = a0;
-            a.xcd_remap = g_slab_xcd_remap;
-            const int BMs = SlabCfg<MI>::BM;
-            const int tiles = (a.M / a.S) * ((a.S + BMs - 1) / BMs) * (WIDE ? 1 : (a.N + S_BN - 1) / S_BN) * (a.ksplit > 1 ? a.ksplit : 1);
-            hipLaunchKernelGGL((gemm_conv_slab_kernel<T, OutT, MI, LN, WIDE, SPLIT, DEFER, NST, true>), dim3(tiles), dim3(512), 0, stream, a);
+    GemmArgs a = a0;
+    a.xcd_remap = tuning_of(a0.tune).slab_xcd_remap;
+    const int BMs = SlabCfg<MI>::BM;
+    if constexpr (SPLIT) {  // conv launches of the split arithmetic: the slab is split in place when it lands
+        if (a.taps > 1) {
+            const int tiles = (a.M / a.S) * ((a.S + BMs - 1) / BMs) * ((a.N + S_BN - 1) / S_BN) * (a.ksplit > 1 ? a.ksplit : 1);
+            hipLaunchKernelGGL((gemm_conv_slab_kernel<T, OutT, MI, LN, SPLIT, DEFER, true>), dim3(tiles), dim3(512), 0, stream, a);
             return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
         }
     }
-    GemmArgs a = a0;
     if (a.taps == 1) a.S = a.M;  // plain GEMM: one "utterance" of M rows
-    a.xcd_remap = g_slab_xcd_remap;
-    const int BMs = SlabCfg<MI>::BM;
-    const int tiles = (a.M / a.S) * ((a.S + BMs - 1) / BMs) * (WIDE ? 1 : (a.N + S_BN - 1) / S_BN) * (a.ksplit > 1 ? a.ksplit : 1);
-    hipLaunchKernelGGL((gemm_conv_slab_kernel<T, OutT, MI, LN, WIDE, SPLIT, DEFER, NST>), dim3(tiles), dim3(512), 0, stream, a);
+    const int tiles = (a.M / a.S) * ((a.S + BMs - 1) / BMs) * ((a.N + S_BN - 1) / S_BN) * (a.ksplit > 1 ? a.ksplit : 1);
+    hipLaunchKernelGGL((gemm_conv_slab_kernel<T, OutT, MI, LN, SPLIT, DEFER>), dim3(tiles), dim3(512), 0, stream, a);
     return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
 }
 
-int g_split_f32 = 0;  // test knob: every fp32 slab launch in the bf16 x 3 split arithmetic
-int g_slab_ring = 0;  // A/B knob (210 / 211): pointwise launches on 32- / 64- / 128-row tiles through the 4- / 4- / 3-stage operand ring.
-                      // OFF: measured neutral (tools/bench_ops.py ln / gemm --flush 48, r04: enc conv2 + LN 19.9 -> 21.6 us, conv2 plain 18.4 ->
-                      // 15.9, in-proj 12.9 -> 12.9) - these launches are bound by what a CU ingests per second, not by a step's round trip
-// Split launches whose caller holds plain fp32 weights (the operator-level entry points, knob 501: tests): packed on the fly into a
-// process-wide grow-only buffer.  The engine never comes here - it packs its weights once at fs2_finalize (GemmArgs::w_presplit).
-static int presplit_on_the_fly(GemmArgs& a, hipStream_t stream) {
-    static void* buf = nullptr;
-    static size_t cap = 0;
+// Split launches whose caller holds plain fp32 weights (the operator-level entry points with Tuning::split_f32, knob 501: tests
+// only - an engine packs its weights once at fs2_finalize, GemmArgs::w_presplit): packed on the fly into a block that lives for
+// this launch, allocated and freed in STREAM ORDER (no process-wide buffer: until r05 one static grow-only block was shared by
+// every caller and stream).  Not under stream capture.
+static int presplit_on_the_fly(GemmArgs& a, hipStream_t stream, void** tmp) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return FS2_ERR_STATE;
     const size_t bytes = (size_t)a.N * a.K * 4;
-    if (bytes > cap) {
-        if (hipDeviceSynchronize() != hipSuccess) return FS2_ERR_HIP;  // an earlier launch may still read the old block
-        if (buf) (void)hipFree(buf);
-        buf = nullptr;
-        cap = 0;
-        if (hipMalloc(&buf, bytes + bytes / 4) != hipSuccess) return FS2_ERR_NOMEM;
-        cap = bytes + bytes / 4;
-    }
-    const int r = launch_presplit_pack((const float*)a.W, buf, (size_t)a.N * a.K, stream);
-    a.W = buf;
+    if (hipMallocAsync(tmp, bytes, stream) != hipSuccess) return FS2_ERR_NOMEM;
+    const int r = launch_presplit_pack((const float*)a.W, *tmp, (size_t)a.N * a.K, stream);
+    a.W = *tmp;
     a.w_presplit = 1;
     return r;
 }
 
 template <int MI>
-static int launch_slab(const GemmArgs& a_in, int in_dtype, int out_dtype, hipStream_t stream) {
-    GemmArgs a = a_in;
-    if (in_dtype == FS2_F32 && out_dtype == FS2_F32 && (a.split || g_split_f32) && !a.w_presplit) {
-        const int r = presplit_on_the_fly(a, stream);
-        if (r != FS2_OK) return r;
-    }
-    if constexpr (MI <= 4) {
-        // short steps, long round trips: the operand ring (see the kernel).  Same MFMA order per element: bit-identical results.
-        constexpr int R = MI == 4 ? 3 : 4;
-        if (g_slab_ring && a.taps == 1 && a.ksplit <= 1 && !a.stats_out && !a.epi_res && (!a.ln_g || a.N <= S_BN) && in_dtype == out_dtype) {
-            const bool sp = a.split || g_split_f32;
-            if (a.ln_g) {
-                if (in_dtype == FS2_F32 && !sp) return launch_slab_t<float, float, MI, true, false, false, false, R>(a, stream);
-                if (in_dtype == FS2_BF16) return launch_slab_t<bf16, bf16, MI, true, false, false, false, R>(a, stream);
-            } else {
-                if (in_dtype == FS2_F32 && !sp) return launch_slab_t<float, float, MI, false, false, false, false, R>(a, stream);
-                if (in_dtype == FS2_BF16) return launch_slab_t<bf16, bf16, MI, false, false, false, false, R>(a, stream);
-            }
-        }
-    }
-    if (a.ln_g) {  // fused LayerNorm epilogue: whole rows per workgroup, tile heights 128 / 192 only
+static int launch_slab_do(const GemmArgs& a, int in_dtype, int out_dtype, bool sp, hipStream_t stream) {
+    if (a.ln_g) {  // fused LayerNorm epilogue: whole rows per workgroup (N <= 256), tile heights up to 192
         if constexpr (MI <= 6) {
-            if (a.N > S_BN) {  // wide rows: column tiles walked inside the workgroup, normalised in place
-                if (a.N > 1024 || (!a.C && !a.ln_tmp)) return FS2_ERR_SHAPE;
-                if (in_dtype == FS2_F32 && out_dtype == FS2_F32) return launch_slab_t<float, float, MI, true, true>(a, stream);
-                if (in_dtype == FS2_BF16 && out_dtype == FS2_BF16) return launch_slab_t<bf16, bf16, MI, true, true>(a, stream);
-                return FS2_ERR_SHAPE;
-            }
+            if (a.N > S_BN) return FS2_ERR_SHAPE;
             if (in_dtype == FS2_F32 && out_dtype == FS2_F32)
-                return (a.split || g_split_f32) ? launch_slab_t<float, float, MI, true, false, true>(a, stream) : launch_slab_t<float, float, MI, true>(a, stream);
+                return sp ? launch_slab_t<float, float, MI, true, true>(a, stream) : launch_slab_t<float, float, MI, true>(a, stream);
             if (in_dtype == FS2_BF16 && out_dtype == FS2_BF16) return launch_slab_t<bf16, bf16, MI, true>(a, stream);
         }
         return FS2_ERR_SHAPE;
     }
-    if (a.stats_out || a.epi_res) {  // deferred-LayerNorm epilogue
+    if (a.stats_out || a.epi_res) {  // deferred-LayerNorm epilogue (tile heights up to 192: the 256-row form spills)
         if (a.epi_res && a.relu) return FS2_ERR_SHAPE;  // the residual rides in the accumulators' initial value: no activation in between
-        if (in_dtype == FS2_F32 && out_dtype == FS2_F32)
-            return (a.split || g_split_f32) ? launch_slab_t<float, float, MI, false, false, true, true>(a, stream)
-                                            : launch_slab_t<float, float, MI, false, false, false, true>(a, stream);
-        if (in_dtype == FS2_BF16 && out_dtype == FS2_BF16) return launch_slab_t<bf16, bf16, MI, false, false, false, true>(a, stream);
+        if constexpr (MI <= 6) {
+            if (in_dtype == FS2_F32 && out_dtype == FS2_F32)
+                return sp ? launch_slab_t<float, float, MI, false, true, true>(a, stream) : launch_slab_t<float, float, MI, false, false, true>(a, stream);
+            if (in_dtype == FS2_BF16 && out_dtype == FS2_BF16) return launch_slab_t<bf16, bf16, MI, false, false, true>(a, stream);
+        }
         return FS2_ERR_SHAPE;
     }
     if (in_dtype == FS2_F32 && out_dtype == FS2_F32)
-        return (a.split || g_split_f32) ? launch_slab_t<float, float, MI, false, false, true>(a, stream) : launch_slab_t<float, float, MI, false>(a, stream);
+        return sp ? launch_slab_t<float, float, MI, false, true>(a, stream) : launch_slab_t<float, float, MI, false>(a, stream);
     if (in_dtype == FS2_BF16 && out_dtype == FS2_BF16) return launch_slab_t<bf16, bf16, MI, false>(a, stream);
     if (in_dtype == FS2_BF16 && out_dtype == FS2_F32) return launch_slab_t<bf16, float, MI, false>(a, stream);
     return FS2_ERR_SHAPE;
+}
+
+template <int MI>
+static int launch_slab(const GemmArgs& a_in, int in_dtype, int out_dtype, hipStream_t stream) {
+    GemmArgs a = a_in;
+    const bool sp = a.split || tuning_of(a.tune).split_f32;
+    void* tmp = nullptr;
+    if (in_dtype == FS2_F32 && out_dtype == FS2_F32 && sp && !a.w_presplit) {
+        const int r = presplit_on_the_fly(a, stream, &tmp);
+        if (r != FS2_OK) { if (tmp) (void)hipFreeAsync(tmp, stream); return r; }
+    }
+    const int r = launch_slab_do<MI>(a, in_dtype, out_dtype, sp, stream);
+    if (tmp) (void)hipFreeAsync(tmp, stream);  // behind the launch that reads it, in stream order
+    return r;
 }
 
 template <typename T, typename OutT, bool ZR = false>
@@ -1530,19 +1320,11 @@ static int launch_t(const GemmArgs& a, hipStream_t stream) {
     return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
 }
 
-int g_gemm_variant = 0;
-unsigned long long g_knob_gen = 0;  // bumped by every accepted fs2_op_set_gemm_variant call; part of the hipGraph keys
-int g_slab_xcd_remap = 1;
-// 1 = rows wider than 256 by the in-place WIDE epilogue, 0 = GEMM launch + stand-alone LayerNorm launch.  Measured on
-// MI355X (tools/bench_ops.py wide, r02): the WIDE form only ties at M = 49152, K = 768 (118 vs 120 us) and LOSES
-// elsewhere (K = 3072: 357 vs 294 us - a workgroup re-streams its x tile once per column tile and 32 such tiles per XCD
-// do not fit the 4 MiB L2; M = 8192 / 12288: 1.5-2.2x slower - a third or a quarter of the workgroups), so it is OFF.
-int g_wide_ln = 0;
-int g_defer_mi8 = 0;  // 1: the deferred-LayerNorm epilogue may take 256-row tiles (spills ~600 registers, almost all outside the K loop)
-
 static int launch_gemm_plain(const GemmArgs& a, int in_dtype, int out_dtype, hipStream_t stream, bool* fused);
 
 int launch_gemm(const GemmArgs& a, int in_dtype, int out_dtype, hipStream_t stream) {
+    const Tuning& tn = tuning_of(a.tune);
+    const int g_gemm_variant = tn.gemm_variant, g_gemm_wres = tn.gemm_wres;
     if (!a.ln_g && a.drop_p > 0.f) {  // the plain store's dropout: slab kernel, behind a ReLU (the FFN's hidden tensor)
         if (!a.relu || a.gate || a.stats_out || a.epi_res || a.ksplit > 1 || a.zero_rows || g_gemm_variant != 0 || a.N < 192 || a.M % a.S ||
             !(a.taps & 1) || in_dtype != out_dtype)
@@ -1559,7 +1341,7 @@ int launch_gemm(const GemmArgs& a, int in_dtype, int out_dtype, hipStream_t stre
     bool fused = false;
     if (a.z_out && a.N > S_BN) return FS2_ERR_SHAPE;  // the pre-norm store exists in the one-column-tile epilogue only
     if (a.drop_p > 0.f && (a.N > S_BN || !a.z_out)) return FS2_ERR_SHAPE;  // the epilogue's dropout: one-column-tile fused form only (training tape)
-    if ((a.N <= S_BN || (g_wide_ln && a.N <= 1024 && (a.C || a.ln_tmp))) && in_dtype == out_dtype) {
+    if (a.N <= S_BN && in_dtype == out_dtype) {
         const int r = launch_gemm_plain(a, in_dtype, out_dtype, stream, &fused);
         if (r != FS2_OK || fused) return r;
     }
@@ -1580,6 +1362,9 @@ int launch_gemm(const GemmArgs& a, int in_dtype, int out_dtype, hipStream_t stre
 // fused != nullptr: the caller wants the LN epilogue; only the slab kernel provides it.  If the slab
 // kernel is not selected, nothing is launched and *fused stays false.
 static int launch_gemm_plain(const GemmArgs& a, int in_dtype, int out_dtype, hipStream_t stream, bool* fused) {
+    const Tuning& tn_ = tuning_of(a.tune);
+    const int g_gemm_variant = tn_.gemm_variant;
+    const bool g_split_f32 = tn_.split_f32 != 0;
     if (a.M <= 0 || a.N <= 0) return FS2_OK;
     const int ke = in_dtype == FS2_BF16 ? 64 : 32;
     const int e16 = in_dtype == FS2_BF16 ? 8 : 4;
@@ -1641,22 +1426,21 @@ static int launch_gemm_plain(const GemmArgs& a, int in_dtype, int out_dtype, hip
         for (int hi = 0; hi < 5; ++hi) {                  // (the encoder's) spread over all CUs
             const int mi = kHeights[hi];
             if (fused && mi > 6) continue;                                    // 256-row tiles spill with the fused LayerNorm epilogue
-            if ((a.stats_out || a.epi_res) && mi > 6 && !g_defer_mi8) continue;  // ... and with the deferred one (knob 311 admits them: A/B)
+            if ((a.stats_out || a.epi_res) && mi > 6) continue;                // ... and with the deferred one (r04: 24 spills even without its in-epilogue residual path; selected nowhere)
             const long bm = mi * 32, tm = (S + bm - 1) / bm;
-            const bool wide = fused && tn > 1;  // one workgroup per row tile walks all tn column tiles
-            const long tiles = (long)nutt * tm * (wide ? 1 : tn) * ksp;
-            long cost = ((tiles + 255) / 256) * (bm + 40) * (wide ? tn : 1);
+            const long tiles = (long)nutt * tm * tn * ksp;
+            long cost = ((tiles + 255) / 256) * (bm + 40);
             // long reductions (K >= 4096: the data-gradient convs of the training step, K = taps * filter): every workgroup
             // streams the whole K x 256 weight panel out of L2, and tiles x panel bytes over the ~10 TB/s the L2s deliver
             // together becomes the bound before the CUs fill - in the same units (one row of MFMA work per K) that is ~1 per
             // tile.  C5 encoder conv1 dgrad (M = 2048, N = 1024, K = 36864): 256 x 32-row tiles 500 us -> 128 x 64-row tiles.
-            if (a.K / ksp >= 4096 && !wide) cost = cost > tiles ? cost : tiles;
+            if (a.K / ksp >= 4096) cost = cost > tiles ? cost : tiles;
             if (!best || cost < best_cost) { best = mi; best_cost = cost; best_rows = (long)nutt * tm * bm; }
         }
         if (best_rows <= 2L * a.M || a.C_lo || a.w_presplit || a.rs_stats) {  // (the head + tail store / pre-split weights / row-scaled product exist in this kernel only)
             // more tiles than CUs: one workgroup per CU walks them, the next tile's first operands under this tile's epilogue
             // (gemm_persist.hip; same tile height, same arithmetic per element - bit-identical)
-            if (!fused && g_gemm_persist && gemm_persist_supported(a, in_dtype, out_dtype, best) && gemm_persist_pays(a, best))
+            if (!fused && tn_.gemm_persist && gemm_persist_supported(a, in_dtype, out_dtype, best) && gemm_persist_pays(a, best))
                 return launch_gemm_persist(a, best, stream);
             if (fused) *fused = true;
             if (best == 1) return launch_slab<1>(a, in_dtype, out_dtype, stream);

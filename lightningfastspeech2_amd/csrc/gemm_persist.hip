@@ -489,7 +489,7 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(GemmArgs p, int ntile
 
 }  // namespace
 
-int g_gemm_persist = 1;  // A/B knob (220 / 221): multi-round bf16 slab launches on the persistent kernel (default) / always one tile per workgroup
+// (Tuning::gemm_persist - knob 220 / 221: always one tile per workgroup / multi-round bf16 pointwise launches on this kernel (default))
 
 // The tile height comes from the slab launcher's cost model (mi); this only says whether the persistent form can run the launch.
 bool gemm_persist_supported(const GemmArgs& a, int in_dtype, int out_dtype, int mi) {

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(512) void gemm_wres_kernel(GemmArgs p, int ncol, in
 
 }  // namespace
 
-int g_gemm_wres = 1;  // 1: bf16 K = 256 plain GEMMs take the weight-resident kernel where it pays; 2: wherever it applies (tests); 0: never
+// (Tuning::gemm_wres - 1: bf16 K = 256 plain GEMMs take this kernel where it pays; 2: wherever it applies (tests); 0: never)
 
 static int wres_row_groups(int ncol, int tiles) {
     int nrg = (256 / ncol) & ~7;  // row groups: a multiple of 8 (one per XCD and round), every CU at most one workgroup

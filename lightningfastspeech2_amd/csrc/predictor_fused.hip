@@ -459,294 +459,11 @@ __device__ unsigned long long g_pred_stamps[64];
 #else
 #define PRED_STAMP(i) do { } while (0)
 #endif
-
-template <int MI16>
-__global__ __launch_bounds__(256, 1) void predictor_pair_kernel(PredictorArgs p, int total_tiles) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int NWV = 4, R = MI16 * 16, HFA = (MI16 + 1) / 2, HFB = MI16 - HFA, NFR = 4, NP = 2;
-    constexpr int SLABB = (R + 2) * PF_ROWB;
-    __shared__ __attribute__((aligned(16))) unsigned char slab2[2][SLABB];
-    __shared__ float red2[2][2][NWV * R];
-    __shared__ __attribute__((aligned(16))) float lnp[3][PF_H];  // gamma | beta | head weights of the layer whose epilogue is in flight
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int fr = lane & 15, fg = lane >> 4;
-    const int S = p.S, nl = p.nlayers, halo = nl - 1, V = R - 2 * halo;
-    const int tiles = (S + V - 1) / V;
-    int ubs[2], t0s[2];
-    bool valid[2];
-#pragma unroll
-    for (int X = 0; X < 2; ++X) {
-        int gt = blockIdx.x * 2 + X;
-        valid[X] = gt < total_tiles;
-        if (!valid[X]) gt = total_tiles - 1;  // an odd tile count: the last workgroup computes its tile twice, stores it once
-        ubs[X] = gt / tiles;
-        t0s[X] = (gt % tiles) * V - halo;
-    }
-    // ---- slab fills (as above), both tiles
-#pragma unroll
-    for (int X = 0; X < 2; ++X) {
-        const bf16* xu = (const bf16*)p.x + (size_t)ubs[X] * S * PF_H;
-        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)xu, 0, (unsigned)((size_t)S * PF_ROWB), 0x00020000);
-        constexpr int NCH = (R + 2) / 2;
-#pragma unroll
-        for (int k = 0; k < (NCH + NWV - 1) / NWV; ++k) {
-            const int c = k * NWV + wv;
-            if (c < NCH) {
-                const int i = 2 * c + (lane >> 5), ps = lane & 31, t = t0s[X] - 1 + i;
-                const int ls = (ps & 16) | ((((ps & 7) ^ (i & 7)) << 1) | ((ps >> 3) & 1));
-                const unsigned voff = (t >= 0 && t < S) ? (unsigned)(t * PF_ROWB + (ls << 4)) : 0xFFFFF000u;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)(slab2[X] + c * 1024), 16, voff, 0, 0, 0);
-            }
-        }
-    }
-    // ---- weight stream over the segment sequence K(A,0), K(B,0), K(A,1), ...: global step gs = segment * 24 + tap * 8 + kb
-    const uint4* __restrict__ wbase = (const uint4*)p.wpk + wv * NFR * 64 + lane;
-    const int total = nl * PF_STEPS;
-    // segment seg uses layer seg >> 1; st = step inside the segment, may run up to two steps into the next one
-    auto loadB = [&](uint4 (&b)[NFR], int seg, int st) {
-        const int sg = st >= PF_STEPS ? seg + 1 : seg, ss = st >= PF_STEPS ? st - PF_STEPS : st;
-        int g = (sg >> 1) * PF_STEPS + ss;
-        g = g < total ? g : total - 1;
-#pragma unroll
-        for (int ni = 0; ni < NFR; ++ni) b[ni] = wbase[(size_t)g * PF_STEP_U4 + ni * 64];
-    };
-    constexpr int RING = 4;  // weight fragments three k-steps ahead (~1500 cycles of MFMAs: the L2 round trip under load)
-    uint4 bw[RING][NFR];
-    loadB(bw[0], 0, 0);
-    loadB(bw[1], 0, 1);
-    loadB(bw[2], 0, 2);
-    dma_drain();
-    __syncthreads();
-
-    const int n0 = wv * (NFR * 16) + fg * 8;
-    f32x4_t acc[2][NFR][MI16];
-    // epilogue state of the tile whose LayerNorm is in flight
-    uint32_t pw[4] = {0u, 0u, 0u, 0u};
-    float sm[MI16], mean[MI16], gg[8], ee[8], hw[8], yv[8], tu = 0.f, tvv = 0.f, r0 = 0.f, r1 = 0.f, r2 = 0.f, r3 = 0.f;
-    const float invn = 1.0f / (float)PF_H;
-    constexpr int GAPS = PF_KB * MI16 * NFR;  // MFMAs per tap: 224 at MI16 = 7
-    static_assert(MI16 == 7, "the stage tables below are laid out for 7 row fragments (224 gaps per tap)");
-
-    // one micro-step of the epilogue of tile Y at layer le (w = gap index inside the tap, compile-time after unrolling)
-    auto epi_step = [&](auto YC, int le, auto STAGE, auto LASTC, int w) {
-        constexpr int Y = decltype(YC)::value, ST = decltype(STAGE)::value;
-        constexpr bool last = decltype(LASTC)::value;
-        float* redY0 = red2[Y][0];
-        float* redY1 = red2[Y][1];
-        if constexpr (ST == 0) {
-            if (w < 112) {
-                const int f = w >> 2, m = f >> 2, ni = f & 3, sub = w & 3;
-                f32x4_t& a = acc[Y][ni][m];
-                // (asm: hipcc puts a canonicalising v_max in front of every fmaxf on an MFMA result - twice the instructions)
-                auto relu = [](float x) { asm volatile("v_max_f32 %0, %0, 0" : "+v"(x)); return x; };
-                if (sub == 0) { if (ni == 0) sm[m] = 0.f; a[0] = relu(a[0]); a[1] = relu(a[1]); }
-                if (sub == 1) { a[2] = relu(a[2]); a[3] = relu(a[3]); }
-                if (sub == 2) { tu = a[0] + a[1]; tvv = a[2] + a[3]; }
-                if (sub == 3) sm[m] += tu + tvv;
-            } else if (w < 140) {
-                const int m = (w - 112) >> 2, sub = (w - 112) & 3;
-                if (sub == 0) {
-                    const auto x = __builtin_amdgcn_permlane16_swap(__float_as_uint(sm[m]), __float_as_uint(sm[m]), false, false);
-                    sm[m] = __uint_as_float(x[0]) + __uint_as_float(x[1]);
-                }
-                if (sub == 1) {
-                    const auto x = __builtin_amdgcn_permlane32_swap(__float_as_uint(sm[m]), __float_as_uint(sm[m]), false, false);
-                    sm[m] = __uint_as_float(x[0]) + __uint_as_float(x[1]);
-                }
-                if (sub == 2 && fg == 0) redY0[wv * R + m * 16 + fr] = sm[m];
-            }
-        } else if constexpr (ST == 1) {
-            if (w == 0) {  // the layer's gamma / beta (/ head weights) into LDS: read in stage 2, behind this stage's barrier
-                lnp[0][tid] = p.ln_g[le * PF_H + tid];
-                lnp[1][tid] = p.ln_b[le * PF_H + tid];
-                if (last) lnp[2][tid] = p.head_w[tid];
-            }
-            if (w < 28) {
-                const int m = w >> 2, sub = w & 3, row = m * 16 + fr;
-                if (sub == 0) { r0 = redY0[row]; r1 = redY0[R + row]; }
-                if (sub == 1) { r2 = redY0[2 * R + row]; r3 = redY0[3 * R + row]; }
-                if (sub == 2) { float t8 = 0.f; t8 += r0; t8 += r1; tu = t8; }
-                if (sub == 3) { float t8 = tu; t8 += r2; t8 += r3; mean[m] = t8 * invn; sm[m] = 0.f; }  // sm: the squares' accumulator from here on
-            } else if (w < 140) {
-                const int f = (w - 28) >> 2, m = f >> 2, ni = f & 3, r = (w - 28) & 3;
-                const float d = acc[Y][ni][m][r] - mean[m];
-                acc[Y][ni][m][r] = d;
-                sm[m] = __builtin_fmaf(d, d, sm[m]);
-            } else if (w < 168) {
-                const int m = (w - 140) >> 2, sub = (w - 140) & 3;
-                if (sub == 0) {
-                    const auto x = __builtin_amdgcn_permlane16_swap(__float_as_uint(sm[m]), __float_as_uint(sm[m]), false, false);
-                    sm[m] = __uint_as_float(x[0]) + __uint_as_float(x[1]);
-                }
-                if (sub == 1) {
-                    const auto x = __builtin_amdgcn_permlane32_swap(__float_as_uint(sm[m]), __float_as_uint(sm[m]), false, false);
-                    sm[m] = __uint_as_float(x[0]) + __uint_as_float(x[1]);
-                }
-                if (sub == 2 && fg == 0) redY1[wv * R + m * 16 + fr] = sm[m];
-            }
-        } else {
-            auto load_ln = [&](int j) {  // this lane's 8 channels n0 + 32 j + 0..7 of the pair about to be normalised
-                const int n = n0 + 32 * j;
-                const float4 g0 = *(const float4*)(lnp[0] + n), g1 = *(const float4*)(lnp[0] + n + 4);
-                const float4 e0 = *(const float4*)(lnp[1] + n), e1 = *(const float4*)(lnp[1] + n + 4);
-                gg[0] = g0.x; gg[1] = g0.y; gg[2] = g0.z; gg[3] = g0.w; gg[4] = g1.x; gg[5] = g1.y; gg[6] = g1.z; gg[7] = g1.w;
-                ee[0] = e0.x; ee[1] = e0.y; ee[2] = e0.z; ee[3] = e0.w; ee[4] = e1.x; ee[5] = e1.y; ee[6] = e1.z; ee[7] = e1.w;
-                if (last) {
-                    const float4 h0 = *(const float4*)(lnp[2] + n), h1 = *(const float4*)(lnp[2] + n + 4);
-                    hw[0] = h0.x; hw[1] = h0.y; hw[2] = h0.z; hw[3] = h0.w; hw[4] = h1.x; hw[5] = h1.y; hw[6] = h1.z; hw[7] = h1.w;
-                }
-            };
-            if (w == 26) load_ln(0);
-            if (w < 28) {
-                const int m = w >> 2, sub = w & 3, row = m * 16 + fr;
-                if (sub == 0) { r0 = redY1[row]; r1 = redY1[R + row]; }
-                if (sub == 1) { r2 = redY1[2 * R + row]; r3 = redY1[3 * R + row]; }
-                if (sub == 2) { float t8 = 0.f; t8 += r0; t8 += r1; tu = t8; }
-                if (sub == 3) { float t8 = tu; t8 += r2; t8 += r3; mean[m] = 1.0f / sqrtf(t8 * invn + p.eps); sm[m] = 0.f; }  // mean[] holds rstd, sm[] the head's dot product from here on
-            } else {
-                const int pq = (w - 28) / 14, sub = (w - 28) % 14, j = pq / MI16, m = pq % MI16;
-                if (sub < 8) {
-                    yv[sub] = __builtin_fmaf(acc[Y][2 * j + (sub >> 2)][m][sub & 3] * mean[m], gg[sub], ee[sub]);
-                } else if (last) {
-                    if (sub < 12) {
-                        const int r = (sub - 8) * 2;
-                        sm[m] = __builtin_fmaf(yv[r], hw[r], sm[m]);
-                        sm[m] = __builtin_fmaf(yv[r + 1], hw[r + 1], sm[m]);
-                    }
-                }
-                if (sub == 12 && pq + 1 < NP * MI16) load_ln((pq + 1) / MI16);
-                if (!last && sub >= 8) {
-                    // next layer's input, in place; rows outside the utterance stay the conv's zero padding.  Two instructions per
-                    // gap: pack (8, 9), zero outside rows (10, 11), store (13)
-                    const int row = m * 16 + fr, t = t0s[Y] + row, i = row + 1, n = n0 + 32 * j;
-                    const bool inside = t >= 0 && t < S;
-                    if (sub == 8) { pw[0] = pack_bf16x2(yv[0], yv[1]); pw[1] = pack_bf16x2(yv[2], yv[3]); }
-                    if (sub == 9) { pw[2] = pack_bf16x2(yv[4], yv[5]); pw[3] = pack_bf16x2(yv[6], yv[7]); }
-                    if (sub == 10) { pw[0] = inside ? pw[0] : 0u; pw[1] = inside ? pw[1] : 0u; }
-                    if (sub == 11) { pw[2] = inside ? pw[2] : 0u; pw[3] = inside ? pw[3] : 0u; }
-                    if (sub == 13) *(uint4*)(slab2[Y] + i * PF_ROWB + (SlabSwizzle(PF_ROWB / 16).slot(n >> 3, i) << 4)) = make_uint4(pw[0], pw[1], pw[2], pw[3]);
-                }
-            }
-        }
-    };
-
-    // K loop of tile X at layer l (global segment index seg), with the epilogue of the other tile at layer le between its MFMAs
-    auto segment = [&](auto XC, int l, int seg, auto EPI, auto LASTC, int le, auto DOK) {
-        constexpr int X = decltype(XC)::value;
-        constexpr bool epi = decltype(EPI)::value, dok = decltype(DOK)::value;  // dok = false: the other tile's epilogue alone
-#pragma unroll
-        for (int j = 0; j < NP && dok; ++j) {  // bias rides in as the accumulators' initial value
-            const float* bias = p.bias + l * PF_H + n0 + 32 * j;
-            const float4 b0 = *(const float4*)bias, b1 = *(const float4*)(bias + 4);
-#pragma unroll
-            for (int b = 0; b < MI16; ++b) {
-                acc[X][2 * j][b] = (f32x4_t){b0.x, b0.y, b0.z, b0.w};
-                acc[X][2 * j + 1][b] = (f32x4_t){b1.x, b1.y, b1.z, b1.w};
-            }
-        }
-        auto tap = [&](auto TPC) {
-            constexpr int tp = decltype(TPC)::value;
-            const int i0 = fr + tp;
-            const unsigned char* arow_p = slab2[X] + i0 * PF_ROWB;
-            const int acx = (((fg & 1) << 3) | ((fg >> 1) ^ (i0 & 7))) << 4;
-            auto loadA = [&](uint4 (&fx)[HFA], int kb, int hf) {
-                const int m0 = hf * HFA, cnt = hf ? HFB : HFA;
-#pragma unroll
-                for (int mi = 0; mi < HFA; ++mi)
-                    if (mi < cnt) fx[mi] = *(const uint4*)(arow_p + (m0 + mi) * 16 * PF_ROWB + (acx ^ ((((kb & 3) << 1) | ((kb >> 2) << 4)) << 4)));
-            };
-            // one wave per SIMD: nobody covers an LDS round trip, so a half's activation fragments are requested before the MFMAs of
-            // the half before it
-            uint4 fxa[HFA], fxb[HFA];
-            if (dok) loadA(fxa, 0, 0);
-#pragma unroll
-            for (int kb = 0; kb < PF_KB; ++kb) {
-                if (dok) loadB(bw[(tp * PF_KB + kb + RING - 1) % RING], seg, tp * PF_KB + kb + RING - 1);
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    const int m0 = hf * HFA, cnt = hf ? HFB : HFA;
-                    if (dok) {
-                        if (hf == 0) loadA(fxb, kb, 1);
-                        else if (kb + 1 < PF_KB) loadA(fxa, kb + 1, 0);
-                    }
-#pragma unroll
-                    for (int ni = 0; ni < NFR; ++ni)
-#pragma unroll
-                        for (int mi = 0; mi < HFA; ++mi)
-                            if (mi < cnt) {
-                                if (dok) Mma16<bf16>::step(bw[(tp * PF_KB + kb) % RING][ni], hf ? fxb[mi] : fxa[mi], acc[X][ni][m0 + mi]);
-                                if (epi) {
-                                    const int w = kb * (MI16 * NFR) + (hf ? HFA * NFR : 0) + ni * cnt + mi;
-                                    epi_step(std::integral_constant<int, 1 - X>{}, le, TPC, LASTC, w);
-                                    if (dok) __builtin_amdgcn_sched_barrier(0);  // alone (the drain), the walk is the compiler's to pack
-                                }
-                            }
-                }
-            }
-#ifdef FS2_PRED_PROBE
-            if (seg == 3) PRED_STAMP(32 + 2 * tp);
-#endif
-            if (epi) __syncthreads();  // the stage's LDS exchange (row sums | squares | the rewritten slab) is complete
-#ifdef FS2_PRED_PROBE
-            if (seg == 3) PRED_STAMP(33 + 2 * tp);
-#endif
-        };
-        tap(std::integral_constant<int, 0>{});
-        tap(std::integral_constant<int, 1>{});
-        tap(std::integral_constant<int, 2>{});
-    };
-    // Linear(256, 1) head + mask of tile Y (model.py:519-522), after its last epilogue: sm holds this lane's partial dot
-    auto head = [&](auto YC) {
-        constexpr int Y = decltype(YC)::value;
-#pragma unroll
-        for (int m = 0; m < MI16; ++m) {
-            const float d = group4_sum(sm[m]);
-            if (fg == 0) red2[Y][0][wv * R + m * 16 + fr] = d;
-        }
-        __syncthreads();
-        if (tid < R && valid[Y]) {
-            const int row = tid, t = t0s[Y] + row;
-            if (row >= halo && row < R - halo && t < S) {
-                float d = p.head_b;
-#pragma unroll
-                for (int w = 0; w < NWV; ++w) d += red2[Y][0][w * R + row];
-                const size_t o = (size_t)ubs[Y] * S + t;
-                p.pred[o] = (p.mask && p.mask[o]) ? 0.f : d;
-            }
-        }
-        __syncthreads();
-    };
-    using C0 = std::integral_constant<int, 0>;
-    using C1 = std::integral_constant<int, 1>;
-    PRED_STAMP(0);
-    segment(C0{}, 0, 0, std::false_type{}, std::false_type{}, 0, std::true_type{});
-    __syncthreads();
-    PRED_STAMP(1);
-    for (int l = 0; l + 1 < nl; ++l) {
-        segment(C1{}, l, 2 * l + 1, std::true_type{}, std::false_type{}, l, std::true_type{});      // K(B, l)   + E(A, l)
-        PRED_STAMP(2 + 2 * l);
-        segment(C0{}, l + 1, 2 * l + 2, std::true_type{}, std::false_type{}, l, std::true_type{});  // K(A, l+1) + E(B, l)
-        PRED_STAMP(3 + 2 * l);
-    }
-    segment(C1{}, nl - 1, 2 * nl - 1, std::true_type{}, std::true_type{}, nl - 1, std::true_type{});  // K(B, n-1) + E(A, n-1), the head's dots
-    PRED_STAMP(2 * nl);
-    head(C0{});
-    segment(C0{}, 0, 0, std::true_type{}, std::true_type{}, nl - 1, std::false_type{});               // E(B, n-1) alone: the same gap walk, no MFMAs
-    PRED_STAMP(2 * nl + 1);
-    head(C1{});
-    PRED_STAMP(2 * nl + 2);
-#else
-    (void)p; (void)total_tiles;
-#endif
-}
-
-// 208-row tiles, one 4-wave workgroup per CU (knob 1301): measured r03 148-152 us against 112 us for two 112-row workgroups per CU
-// on the C2 variance predictor - with one wave per SIMD nothing runs under the LayerNorm epilogue, whose VALU stream (~2.9 k
-// instructions per layer and wave) is as long as the layer's MFMA stream.  Off by default; bit-identical outputs either way.
-int g_pred_fuse_embed = 1;
-int g_pred_tall = 0;  // 0: 112- / 64-row tiles, two workgroups per CU; 1: 208-row tiles; 2: two 112-row tiles per workgroup (predictor_pair_kernel)
-
+// (r03: two further forms of this kernel were built, bit-identical, measured slower and - r05 - removed: 208-row tiles on one
+// 4-wave workgroup per CU (148-152 us against 112 for two 112-row workgroups per CU on the C2 variance predictor: with one wave per
+// SIMD nothing runs under the LayerNorm epilogue, whose VALU stream is as long as the layer's MFMA stream) and a one-wave-per-SIMD
+// workgroup that owns two 112-row tiles and issues one tile's epilogue between the other's MFMAs (120.4 us: the K loop itself runs
+// at 22-30 cycles per 16-cycle MFMA and a 16x16x32 gap absorbs about two fillers).  DESIGN 4 "Round 3" keeps the measurements.)
 bool predictor_fused_supported(int dtype, int H, int taps, int nlayers, int S) {
     return dtype == FS2_BF16 && H == PF_H && taps == PF_TAPS && nlayers >= 1 && nlayers <= 16 && S >= 1 &&
            (size_t)S * PF_ROWB < 0xFFFFF000ull;
@@ -770,12 +487,7 @@ int launch_predictor_fused(const PredictorArgs& a, hipStream_t stream) {
     // the tile HEIGHT does not enter the arithmetic (rows are independent), the wave layout does: one
     // layout for everything, shorter tiles when 112-row tiles would leave most CUs without work
     if (a.be_y && (a.be_y == a.x || !a.be_bins || !a.be_emb || a.be_nbins < 2 || a.be_nbins - 1 > 512)) return FS2_ERR_ARG;
-    if (g_pred_tall == 2 && tiles(112) >= 256 && !a.be_y) {  // two 112-row tiles per workgroup, one workgroup per CU
-        const long n = tiles(112);
-        hipLaunchKernelGGL((predictor_pair_kernel<7>), dim3((unsigned)((n + 1) / 2)), dim3(256), 0, stream, a, (int)n);
-    } else if (g_pred_tall == 1 && tiles(208) >= 200) {
-        hipLaunchKernelGGL((predictor_fused_kernel<13, 4, 1>), dim3((unsigned)tiles(208)), dim3(256), 0, stream, a);
-    } else if (tiles(112) < 200 && 64 - halo2 >= 32) {
+    if (tiles(112) < 200 && 64 - halo2 >= 32) {
         hipLaunchKernelGGL((predictor_fused_kernel<4, 4, 2>), dim3((unsigned)tiles(64)), dim3(256), 0, stream, a);
     } else {
         hipLaunchKernelGGL((predictor_fused_kernel<7, 4, 2>), dim3((unsigned)tiles(112)), dim3(256), 0, stream, a);
@@ -785,18 +497,3 @@ int launch_predictor_fused(const PredictorArgs& a, hipStream_t stream) {
 
 }  // namespace fs2
 
-#ifdef FS2_PRED_PROBE
-extern "C" size_t pack_for_probe(const void* w, void* out, int nl) {
-    const size_t per = fs2::predictor_packed_bytes_per_layer();
-    for (int l = 0; l < nl; ++l) fs2::launch_pack_predictor_weights((const char*)w + (size_t)l * 256 * 768 * 2, (char*)out + l * per, nullptr);
-    return per;
-}
-extern "C" int pred_pair_stamps(const void* x, const void* wpk, const float* bias, const float* g, const float* be, const float* hw, float* pred,
-                                int B, int S, int nl, unsigned long long* out /*64, host*/) {
-    fs2::PredictorArgs a{x, wpk, bias, g, be, hw, 0.1f, nullptr, pred, B, S, fs2::PF_H, nl, fs2::PF_TAPS, 1e-5f};
-    fs2::g_pred_tall = 2;
-    for (int i = 0; i < 3; ++i) fs2::launch_predictor_fused(a, nullptr);
-    if (hipDeviceSynchronize() != hipSuccess) return -1;
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(fs2::g_pred_stamps), 64 * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
-}
-#endif

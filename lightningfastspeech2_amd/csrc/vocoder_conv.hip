@@ -292,7 +292,7 @@ __global__ __launch_bounds__(512) void vocoder_conv_kernel(VocConvArgs p) {
     }
 }
 
-int g_voc_lds_limit = 0;  // KiB; 0 = heuristic (tuning knob, fs2_op_set_vocoder_lds_limit)
+// (Tuning::voc_lds_limit: KiB; 0 = heuristic - fs2_op_set_vocoder_lds_limit)
 
 // rows per wave (x16) the slab of this layer leaves room for
 static int voc_pick_mi16(const VocConvArgs& a, int esz, size_t* smem) {
@@ -303,6 +303,7 @@ static int voc_pick_mi16(const VocConvArgs& a, int esz, size_t* smem) {
     // frames, every conv through this kernel): 62.6 ms per pass at 150 KiB, 46.8 at 76, 47.7 at 52, 51.2
     // at 36; with the narrow stages on the resident-resblock kernel: 42.1 / 39.0 / 39.8 / 40.6 ms at
     // 150 / 110 / 76 / 52 (110 = 128-row tiles at 256 channels, 256-row tiles x 2 workgroups at 128).
+    const int g_voc_lds_limit = tuning_of(a.tune).voc_lds_limit;
     const size_t limit = (size_t)(g_voc_lds_limit > 0 ? g_voc_lds_limit : 110) * 1024;
     for (int c = 0; c < 4; ++c) {
         const size_t b = ((size_t)(WM * cand[c] * 16 + (a.taps - 1) * a.dil) * a.cin_pad * esz + 1023) & ~(size_t)1023;  // whole DMA chunks

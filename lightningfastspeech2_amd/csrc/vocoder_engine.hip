@@ -196,6 +196,7 @@ int run_conv(fs2_vocoder* v, hipStream_t st, const VocLayer& L, const void* x, v
              const int32_t* lengths, int len_scale, int B, int S, float in_slope, float scale, bool accumulate,
              bool in_fp32 = false, bool post = false, float out_slope = 1.f) {
     VocConvArgs a;
+    a.tune = &op_tuning();  // the calling thread's A/B switches (fs2_op_set_vocoder_*)
     a.out_slope = out_slope;
     a.x = x; a.w = L.w; a.bias = L.b; a.res = res; a.out = out; a.lengths = lengths; a.len_scale = len_scale;
     a.B = B; a.S = S; a.cin = L.cin; a.cin_pad = L.cin_pad; a.n = L.n; a.taps = L.taps; a.dil = L.dil; a.pad = L.pad;
@@ -376,11 +377,13 @@ int fs2_voc_synthesize(fs2_vocoder* v, const float* mel, const int32_t* lengths,
         const int S = T * v->upf[i + 1], sc = v->upf[i + 1];
         // when every resblock of this stage runs on LDS-resident tiles, the upsampled stream travels as lrelu(x):
         // all its consumers then fill their slabs by plain LDS-DMA (x_act, vocoder_resblock.hip)
+        const int g_voc_fused_resblock = op_tuning().voc_fused_resblock;
         bool stage_act = g_voc_fused_resblock != 9;
         for (int j = 0; j < c.n_kernels && stage_act; ++j) {
             const fs2_vocoder::FusedRb& f = v->rb[(size_t)i * c.n_kernels + j];
             if (!f.w) { stage_act = false; break; }
             VocResblockArgs ra;
+                ra.tune = &op_tuning();
             ra.x = u; ra.out = v->stage_out[i + 1]; ra.w = f.w; ra.bias = f.b; ra.lengths = lengths; ra.len_scale = sc;
             ra.B = B; ra.S = S; ra.C = v->chan[i + 1]; ra.taps = c.rb_kernels[j]; ra.wn = ra.C / 32; ra.npairs = 3;
             for (int m = 0; m < 3; ++m) ra.dil[m] = c.rb_dilations[j][m];
@@ -399,6 +402,7 @@ int fs2_voc_synthesize(fs2_vocoder* v, const float* mel, const int32_t* lengths,
             const fs2_vocoder::FusedRb& f = v->rb[(size_t)i * c.n_kernels + j];
             if (f.w) {
                 VocResblockArgs ra;
+                ra.tune = &op_tuning();
                 ra.x = u; ra.out = v->stage_out[i + 1]; ra.w = f.w; ra.bias = f.b; ra.lengths = lengths; ra.len_scale = sc;
                 ra.B = B; ra.S = S; ra.C = v->chan[i + 1]; ra.taps = c.rb_kernels[j]; ra.wn = ra.C / 32; ra.npairs = 3;
                 for (int m = 0; m < 3; ++m) ra.dil[m] = c.rb_dilations[j][m];

@@ -296,7 +296,7 @@ __global__ __launch_bounds__(NW * 64, 2) void vocoder_resblock_kernel(VocResbloc
     }
 }
 
-int g_voc_fused_resblock = 1;  // A/B knob (fs2_op_set_vocoder_fused_resblock): 0 off, 1 auto, 2 pairs only, 4 = full-height 8-wave tiles only
+// (Tuning::voc_fused_resblock - fs2_op_set_vocoder_fused_resblock: 0 off, 1 auto, 2 pairs only, 4 = full-height 8-wave tiles only)
 
 static void rb_geom(const VocResblockArgs& a, int nw, int mi16, int* R, int* H, int* G) {
     const int c = (a.taps - 1) / 2;
@@ -322,6 +322,7 @@ static size_t rb_lds_bytes(const VocResblockArgs& a, int nw, int mi16, int esz) 
 // is taken when >= 85 % of its rows are useful: 3-9 % faster than the 8-wave full-height tile on the 32/64-
 // channel stages and on the 128-channel k=7 pairs, equal elsewhere (repeated A/B runs).
 int voc_resblock_mi16(const VocResblockArgs& a, int dtype) {
+    const int g_voc_fused_resblock = tuning_of(a.tune).voc_fused_resblock;
     if (!g_voc_fused_resblock || (g_voc_fused_resblock == 2 && a.npairs != 1)) return 0;
     const int esz = dtype == FS2_BF16 ? 2 : 4;
     if (a.C != 32 && a.C != 64 && a.C != 128) return 0;

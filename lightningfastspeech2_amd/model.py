@@ -245,6 +245,11 @@ class Engine:
         """A/B: wide depth-wise blocks with LayerNorm deferred into its consumers (default) or as its own launches."""
         _lib.check(self.lib.fs2_set_deferred_layernorm(self.handle, int(on)), self.handle, "set_deferred_layernorm")
 
+    def set_tuning(self, knob: int):
+        """One kernel-selection switch of this engine (include/fs2.h, the values of fs2_op_set_gemm_variant): A/B runs and the tests
+        that pin two forms of a kernel against each other.  Replicas made afterwards (``FastSpeech2.replicate``) inherit it."""
+        _lib.check(self.lib.fs2_set_tuning(self.handle, int(knob)), self.handle, f"set_tuning({knob})")
+
     def set_folded_layernorm(self, on: bool):
         """A/B: inside a stack of wide depth-wise bf16 blocks, a block's closing LayerNorm folded into the next block's in-projection
         (default) or one normalise-only pass per block."""

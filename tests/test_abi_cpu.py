@@ -137,11 +137,27 @@ def test_split_k_choice_is_a_pure_shape_function(lib):
 
 
 def test_knob_setter_rejects_undefined_values(lib):
-    """fs2_op_set_gemm_variant takes closed ranges - a typo in FS2_GEMM_KNOBS is an error, not a silent global."""
+    """fs2_op_set_gemm_variant takes closed ranges - a typo in FS2_GEMM_KNOBS is an error, not a silent default; the
+    switches removed in r05 (measured-slower forms: 1211, 211, 1301 / 1302, 301, 311 and their "off" values) are undefined now."""
     FS2_OK, FS2_ERR_ARG = 0, lib.fs2_op_set_gemm_variant(-1)
     assert FS2_ERR_ARG != FS2_OK
-    for bad in (1303, 1319, 1322, 1399, 1403, 1205, 1209, 1212, 1299, 1102, 1002, 910, 802, 702, 502, 312, 302, 202, 100000):
+    for bad in (1300, 1301, 1302, 1319, 1322, 1399, 1403, 1205, 1210, 1211, 1299, 1102, 1002, 910, 802, 702, 502, 310, 311, 300, 301, 210, 211, 222, 202, 8, 100000):
         assert lib.fs2_op_set_gemm_variant(bad) == FS2_ERR_ARG, bad
     # the defaults (each is a defined value) leave the process as it was
-    for ok in (0, 201, 300, 310, 500, 701, 801, 909, 904, 1001, 1100, 1203, 1210, 1300, 1321, 1401):
+    for ok in (0, 201, 221, 500, 701, 801, 909, 904, 1001, 1100, 1203, 1321, 1401, 1501):
         assert lib.fs2_op_set_gemm_variant(ok) == FS2_OK, ok
+
+
+def test_library_has_no_mutable_tuning_globals():
+    """SURVEY 8b "no global state (one handle per device)" / VERDICT r04 item 6: the A/B switches live in a per-engine / per-thread
+    `fs2::Tuning`, not in process-wide `int g_*` variables every engine and pipeline thread reads unsynchronised.  By `nm`: no
+    defined data symbol named fs2::g_* except the read-only device zero page."""
+    import subprocess
+    from lightningfastspeech2_amd import _lib
+    out = subprocess.run(["nm", "-C", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    bad = []
+    for line in out.splitlines():
+        parts = line.split(None, 2)
+        if len(parts) == 3 and parts[1] in "bBdD" and "fs2::g_" in parts[2] and "(" not in parts[2] and "g_zero_page" not in parts[2]:
+            bad.append(parts[2])
+    assert not bad, bad

@@ -158,6 +158,51 @@ def test_forward_pipeline_is_bit_identical_and_ordered():
                 assert torch.equal(g[k], w[k]), (n, k)
 
 
+def test_two_engines_with_different_tuning_run_concurrently():
+    """The kernel-selection switches are per engine (fs2_set_tuning), not process state: two replicas of one model -
+    one on the defaults, one with the GEMM and predictor-tail forms switched to their other, bit-identical kernels - driven
+    by two host threads on two streams at once give the same bits as the synchronous default engine, batch for batch; and a
+    thread-level fs2_op_set_gemm_variant in between touches neither."""
+    import concurrent.futures as cf
+    from lightningfastspeech2_amd.config import preset
+    cfg = preset("c2")
+    sd = synth_state_dict(cfg, 3, randomize_norm=True, duration_bias=1.5)
+    m = _model(cfg, sd, "bf16")
+    rs = np.random.RandomState(7)
+    batches = []
+    for i in range(6):
+        B, L = int(rs.randint(2, 6)), int(rs.randint(30, 90))
+        lens = sorted((int(rs.randint(1, L + 1)) for _ in range(B)), reverse=True)
+        lens[0] = L
+        x = synth_inputs(cfg, B, L, seed=70 + i, lengths=lens)
+        batches.append({"phones": torch.from_numpy(x["phones"]).cuda(), "speaker": torch.from_numpy(x["speaker"]).cuda()})
+    want = [m(b, inference=True) for b in batches]
+    torch.cuda.synchronize()
+    a, b = m.replicate(), m.replicate()
+    for knob in (1400, 1320, 220, 200):   # slab-kernel in-projection, stand-alone bucket_embed, no persistent GEMM, plain tile order
+        b.engine.set_tuning(knob)
+    assert _lib.load().fs2_op_set_gemm_variant(1204) == 0   # this thread's operator-level switch: no engine reads it
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+
+    def run(model, stream):
+        out = []
+        with torch.cuda.stream(stream):
+            for bt in batches:
+                out.append(model(bt, inference=True))
+            stream.synchronize()
+        return out
+    try:
+        with cf.ThreadPoolExecutor(max_workers=2) as pool:
+            fa, fb = pool.submit(run, a, streams[0]), pool.submit(run, b, streams[1])
+            ga, gb = fa.result(), fb.result()
+    finally:
+        _lib.load().fs2_op_set_gemm_variant(1203)
+    for i, w in enumerate(want):
+        for k in w:
+            assert torch.equal(ga[i][k], w[k]), ("defaults", i, k)
+            assert torch.equal(gb[i][k], w[k]), ("switched", i, k)
+
+
 def test_engine_clone_shares_weights_and_outlives_its_parent():
     """fs2_clone: a second engine over the same device weights; the weights are freed with the LAST holder, so a clone keeps working
     after its parent is destroyed, and gives the parent's results bit for bit."""

@@ -89,21 +89,19 @@ def test_persistent_gemm_whole_model_is_bit_identical():
     (gemm_persist.hip: 12 x 1536 frames = 96 row tiles x 3 .. 12 column tiles > 256 CUs) against the same model with every
     GEMM one tile per workgroup (knob 220): the deferred epilogue's pre-norm rows + row statistics, the residual normalised on
     load, ReLU, the predictor chain - the same bits in mel, variances and durations."""
-    from lightningfastspeech2_amd import _lib
     from lightningfastspeech2_amd.config import Fs2Config
     cfg = Fs2Config(**{**preset("c3").to_dict(), "encoder_layers": 1, "decoder_layers": 2, "variance_nlayers": [2, 2, 2]})
     sd = synth_state_dict(cfg, 2, randomize_norm=True, duration_bias=float(np.log(7.0)), duration_weight_scale=0.0)
     inp = synth_inputs(cfg, 12, 256, seed=99)
     batch = {"phones": torch.from_numpy(inp["phones"]), "speaker": torch.from_numpy(inp["speaker"])}
     m = _model(cfg, sd, "bf16")
-    lib = _lib.load()
     outs = {}
     try:
         for knob in (220, 221, 221):
-            assert lib.fs2_op_set_gemm_variant(knob) == 0
+            m.engine.set_tuning(knob)
             outs.setdefault(knob, []).append(_cpu(m(batch, inference=True)))
     finally:
-        lib.fs2_op_set_gemm_variant(221)
+        m.engine.set_tuning(221)
     a, b, c = outs[220][0], outs[221][0], outs[221][1]
     assert tuple(b["mel"].shape) == (12, 1536, 80) and bool(torch.isfinite(b["mel"]).all())
     for k in a:

@@ -309,14 +309,13 @@ def test_variance_encoder_in_the_predictor_launch_is_bit_identical(case):
         inp = synth_inputs(cfg, 3, 97, seed=77, lengths=[97, 61, 1])
     m = _model(cfg, sd, "bf16")
     batch = {"phones": torch.from_numpy(inp["phones"]), "speaker": torch.from_numpy(inp["speaker"])}
-    lib = _lib.load()
     outs = {}
     try:
         for knob in (1320, 1321, 1320, 1321):
-            lib.fs2_op_set_gemm_variant(knob)
+            m.engine.set_tuning(knob)
             outs.setdefault(knob, []).append(_cpu(m(batch, inference=True)))
     finally:
-        lib.fs2_op_set_gemm_variant(1321)
+        m.engine.set_tuning(1321)
     a, b = outs[1320][0], outs[1321][0]
     assert torch.isfinite(b["mel"]).all() and b["mel"].shape[1] > 0
     for k in a:

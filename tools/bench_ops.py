@@ -302,20 +302,6 @@ def main():
             gemm_case("c5 conv1 k=9", 12288, 4096, 1024, 9, 1536, a.reps, v)
             gemm_case("c5 conv1 as plain GEMM", 12288, 4096, 9216, 1, 12288, a.reps, v)
             gemm_case("square 4096^3", 4096, 4096, 4096, 1, 4096, a.reps, v)
-    if a.what in ("wide",):  # rows wider than one tile (C3 N = 768, C5 N = 1024): fused in-place LayerNorm vs GEMM + LayerNorm launches
-        for knob in (300, 301):
-            lib.fs2_op_set_gemm_variant(knob)
-            print("---- two launches (GEMM, LayerNorm)" if knob == 300 else "---- fused wide-row LayerNorm epilogue")
-            for v in ([0] if a.variant < 0 else [a.variant]):
-                gemm_ln_case("c3 dec out_proj +res+LN", 49152, 768, 768, 1, 49152, a.reps, v)
-                gemm_ln_case("c3 dec conv2 +res+LN", 49152, 768, 3072, 1, 49152, a.reps, v)
-                gemm_ln_case("c3 pred pw +relu+LN", 49152, 768, 768, 1, 1536, a.reps, v, res=False, relu=True)
-                gemm_ln_case("c3 enc out_proj +res+LN", 8192, 768, 768, 1, 8192, a.reps, v)
-                gemm_ln_case("c3 enc conv2 +res+LN", 8192, 768, 3072, 1, 8192, a.reps, v)
-                gemm_ln_case("c5 dec out_proj +res+LN", 12288, 1024, 1024, 1, 12288, a.reps, v)
-                gemm_ln_case("c5 dec conv2 +res+LN", 12288, 1024, 4096, 1, 12288, a.reps, v)
-                gemm_ln_case("c5 pred conv k=3 +relu+LN", 12288, 1024, 1024, 3, 1536, a.reps, v, res=False, relu=True)
-        lib.fs2_op_set_gemm_variant(301)
     if a.what in ("flash",):
         flash_bwd_case("c2 decoder attention backward", 32, 1536, 256, 2, a.reps)
         flash_bwd_case("c3 decoder attention backward", 32, 1536, 768, 6, a.reps)
@@ -323,7 +309,6 @@ def main():
     if a.what in ("bwd",):
         bwd_cases(a.reps)
     if a.what in ("pred", "all"):
-        if a.variant >= 1300: lib.fs2_op_set_gemm_variant(a.variant)   # 1300: 112-row tiles only, 1301: 208-row tiles where they fill the chip
         predictor_case("variance predictor fused", 32, 1536, 5, a.reps)
         predictor_case("duration predictor fused", 32, 256, 2, a.reps)
     if a.what in ("attn", "all"):
