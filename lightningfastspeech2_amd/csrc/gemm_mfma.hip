@@ -400,6 +400,12 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
     __shared__ __attribute__((aligned(16))) unsigned char slab1[SLAB_B];
     __shared__ __attribute__((aligned(16))) unsigned char wt0[S_BN * ROWB];  // 32 KiB weight tile per stage
     __shared__ __attribute__((aligned(16))) unsigned char wt1[S_BN * ROWB];
+    // The column tile's per-channel epilogue constants - bias, and for the fused LayerNorm epilogue gamma, beta, the predictor head's
+    // weights - fetched at the TOP of the kernel (one value per thread, their round trip under the first operand DMAs') and parked
+    // in LDS.  (Until r05 the epilogues fetched them behind the K loop: sixteen bias loads per lane, then gamma / beta - the
+    // "barrier 3.1 k" and part of the "row statistics 4.5 k" of a 48 k-tick out-projection + LayerNorm launch,
+    // tools/probes/slab_phase_stamps.py, with nothing to hide the two round trips under.)
+    __shared__ __attribute__((aligned(16))) float sprm[(LN ? 4 : 1) * S_BN];
     constexpr int KE = ROWB / (int)sizeof(T);
     SLAB_STAMP(0);
 
@@ -607,6 +613,17 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
     SLAB_STAMP(1);
     issue_slab(slab0, 0);
     issue_w(wt0, 0, 0);
+    float prm[LN ? 4 : 1];
+    if (tid < S_BN) {
+        const int n = n0 + tid;
+        const bool nv = n < p.N;
+        prm[0] = (p.bias && nv) ? p.bias[n] : 0.f;
+        if constexpr (LN) {  // (one column tile: n0 == 0)
+            prm[1] = nv ? p.ln_g[n] : 0.f;
+            prm[2] = nv ? p.ln_b[n] : 0.f;
+            prm[3] = (nv && p.dot_w) ? p.dot_w[n] : 0.f;
+        }
+    }
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -722,6 +739,14 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
         if (n0 + S_BN <= p.N) preload(BoolC<true>{});
         else preload(BoolC<false>{});
     }
+    if (tid < S_BN) {  // (published by the first step's barrier; the epilogues read them after many more)
+        sprm[tid] = prm[0];
+        if constexpr (LN) {
+            sprm[S_BN + tid] = prm[1];
+            sprm[2 * S_BN + tid] = prm[2];
+            sprm[3 * S_BN + tid] = prm[3];
+        }
+    }
     SLAB_STAMP(6);
     for (int cc = 0; cc < ncc; cc += 2) {
         for (int tap = 0; tap < ntap; tap += 2) {
@@ -755,7 +780,7 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
                 const int n = wn * 64 + wcol(ni, fg);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float bvv = (p.bias && n + r < p.N) ? p.bias[n + r] : 0.f;
+                    const float bvv = sprm[n + r];
 #pragma unroll
                     for (int mi = 0; mi < MI; ++mi) acc[ni][mi][r] = fmaxf(acc[ni][mi][r] + bvv, lo);
                 }
@@ -852,13 +877,7 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
         __syncthreads();  // every wave is done with the operand buffers: reuse them for the exchange
         SLAB_STAMP(3);
         float* red = (float*)slab0;  // [4 column waves][BMs rows]
-        float* lnp = (float*)wt0;    // [gamma 256 | beta 256 | head weight 256]
-        if (tid < S_BN) {
-            const bool nv = tid < p.N;
-            lnp[tid] = nv ? p.ln_g[tid] : 0.f;
-            lnp[S_BN + tid] = nv ? p.ln_b[tid] : 0.f;
-            lnp[2 * S_BN + tid] = (nv && p.dot_w) ? p.dot_w[tid] : 0.f;
-        }
+        const float* lnp = sprm + S_BN;  // [gamma 256 | beta 256 | head weight 256], parked at the top of the kernel
         const float invn = 1.0f / (float)p.N;
         float mean[MI], rstd[MI];
 #pragma unroll
@@ -992,7 +1011,7 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
     for (int j = 0; j < 2; ++j) {
         const int n = n0 + wn * 64 + j * 32 + fg * 8;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) bv[j][r] = (p.bias && n + r < p.N) ? p.bias[n + r] : 0.f;
+        for (int r = 0; r < 8; ++r) bv[j][r] = sprm[n - n0 + r];
     }
     // ReLU and the N-tail checks are compiled out of the common case by workgroup-uniform dispatch (see the
     // LayerNorm epilogue above): at K = 256 this store loop is as many issue cycles as the K loop
