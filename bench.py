@@ -37,7 +37,7 @@ import torch.distributed as dist
 
 MFMA_PEAK = {"bf16": 2.5e15, "fp32": 157.3e12}  # dense, /opt/skills/guides/MI355X_MICROARCH.md
 HOP, SR = 256, 22050
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")  # regenerated every round: tools/pmc_traffic.sh
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")  # regenerated every round: tools/pmc_traffic.sh
 
 
 def parse():

@@ -149,22 +149,38 @@ int launch_rowstats_finish(const float* parts, int nparts, int ncols, float eps,
 // LightSpeech FFN (model.py:75-81) and module.0 of the depth-wise predictor layer
 // (model.py:545-551).  LDS-staged (TR + k - 1) x 64 slab, one output channel per lane.
 // =============================================================================================
-static constexpr int DW_TR = 256, DW_CT = 64, DW_KMAX = 32, DW_RR = 16, DW_TC = 8;
+#ifndef FS2_DW_PAD
+#define FS2_DW_PAD 0
+#endif
+static constexpr int DW_TR = 256, DW_CT = 64, DW_KMAX = 32, DW_KP = 36, DW_RR = 16, DW_LS = DW_CT + FS2_DW_PAD;  // DW_LS: slab row stride in LDS
+typedef float dw_f2 __attribute__((ext_vector_type(2)));
+template <typename T> __device__ inline void load4v(const T* p, dw_f2& a, dw_f2& b);
+template <> __device__ inline void load4v<float>(const float* p, dw_f2& a, dw_f2& b) {
+    const float4 v = *(const float4*)p;
+    a = dw_f2{v.x, v.y}; b = dw_f2{v.z, v.w};
+}
+template <> __device__ inline void load4v<bf16>(const bf16* p, dw_f2& a, dw_f2& b) {
+    const uint2 v = *(const uint2*)p;
+    a = dw_f2{__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u)};
+    b = dw_f2{__uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u)};
+}
 
 // Workgroup = 256 rows x 64 channels of one utterance; a thread owns 16 consecutive rows x 4 channels.  The
-// (256 + k' - 1) x 64 input slab (k' = k rounded up to a multiple of 8; zeros outside the utterance) sits in LDS in the
-// activation dtype, the k' x 64 weights (zeros past k) as fp32.  (r03: with 8 rows per thread and an fp32 slab the kernel moved
+// (256 + k' - 1) x 64 input slab (k' = k rounded up to a multiple of the tap chunk TC; zeros outside the utterance) sits in LDS in
+// the activation dtype, the k' x 64 weights (zeros past k) as fp32.  (r03: with 8 rows per thread and an fp32 slab the kernel moved
 // 1.44 LDS bytes per multiply-add - 368 B of slab + weight reads per 256 - against a CU's 128 B and 128 multiply-adds per
-// cycle: LDS-bound at 42 % of the HBM rate; 16 rows on a bf16 slab move 0.61.)  Taps go in chunks of 8: the chunk's 8 x 4 weights sit
-// in registers and the thread walks the 15 input rows the chunk touches ONCE - one 16-byte LDS read feeds up
-// to 8 x 4 multiply-adds (input row o + j contributes tap c*8 + j to output row o).  The previous kernel read an
-// input row per output row per tap (5 LDS reads per 16 MACs) and sat on the LDS port at k = 17..25, 2.6x off
-// the HBM time of its 0.15 GB.  Per output the taps are still added in ascending order: bit-identical results.
-template <typename T>
-__global__ __launch_bounds__(256) void dwconv_kernel(DwConvArgs p) {
-    __shared__ __attribute__((aligned(16))) T tile[(DW_TR + DW_KMAX - 1) * DW_CT];
-    __shared__ __attribute__((aligned(16))) float wl[DW_KMAX * DW_CT];  // [tap][channel]
-    __shared__ float rstat[(DW_TR + DW_KMAX - 1) * 2];                   // LayerNorm-on-load: (mean, rstd) per slab row
+// cycle: LDS-bound at 42 % of the HBM rate; 16 rows on a bf16 slab move 0.61.)  Taps go in chunks of TC: the chunk's TC x 4 weights
+// sit in registers and the thread walks the 15 + TC input rows the chunk touches ONCE - one 8-byte LDS read feeds up
+// to TC x 4 multiply-adds (input row o + j contributes tap c*TC + j to output row o).  Per output the taps are added in
+// ascending order whatever TC is: the results do not depend on it, bit for bit.
+// r05: the decoder-sized launches (k = 17 / 21 on 49152 rows) were bound by VALU issue, not by HBM (2.7 TB/s): (a) the chunk
+// size follows k (launch_dwconv: the TC in {3, 5, 7, 8, 9} that pads k least - k = 17 computed 24 taps in chunks of 8, 18 in chunks
+// of 9), (b) the multiply-adds go two channels at a time (v_pk_fma_f32 - the same fused multiply-add per channel).
+template <typename T, int DW_TC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 2 ? 3 : 1))) void dwconv_kernel(DwConvArgs p) {  // 3 workgroups per CU (LDS): <= 168 VGPRs
+    __shared__ __attribute__((aligned(16))) T tile[(DW_TR + DW_KP - 1) * DW_LS];
+    __shared__ __attribute__((aligned(16))) float wl[DW_KP * DW_CT];  // [tap][channel]
+    __shared__ float rstat[(DW_TR + DW_KP - 1) * 2];                   // LayerNorm-on-load: (mean, rstd) per slab row
     const int tid = threadIdx.x;
     const int t0 = blockIdx.x * DW_TR, c0 = blockIdx.y * DW_CT, b = blockIdx.z;
     const T* x = (const T*)p.x + (size_t)b * p.S * p.C;
@@ -173,7 +189,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwConvArgs p) {
     const bool full_c = c0 + DW_CT <= p.C;
     const bool lnl = p.ln_stats != nullptr;
     float lg[4] = {1.f, 1.f, 1.f, 1.f}, lb[4] = {0.f, 0.f, 0.f, 0.f};
-    float2 pq[2][4];  // row-statistic parts of slab rows tid and tid + 256 (rows <= 287)
+    float2 pq[2][4];  // row-statistic parts of slab rows tid and tid + 256 (rows <= 291)
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -194,6 +210,16 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwConvArgs p) {
             if (c < p.C) { lg[e] = p.ln_g[c]; lb[e] = p.ln_b[c]; }
         }
     }
+    // the taps of this channel tile, requested with the slab (r05: a load-then-store loop behind the fill cost a memory round trip per
+    // 4 taps - the k-dependence of the launch time was this loop, not the multiply-adds)
+    constexpr int WB = DW_KP * DW_CT / 256;
+    float wv[WB];
+#pragma unroll
+    for (int u = 0; u < WB; ++u) {
+        const int i = tid + u * 256, tap = i / DW_CT, c = i % DW_CT;
+        const bool ok = tap < p.k && c0 + c < p.C;
+        wv[u] = p.w[ok ? (size_t)(c0 + c) * p.k + (p.flip ? p.k - 1 - tap : tap) : 0];
+    }
     auto publish_rstat = [&]() {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -210,7 +236,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwConvArgs p) {
     if (full_c) {
         // every load of the slab is issued before the first is used (unconditional, clamped row, zeroed afterwards):
         // ONE memory round trip for the fill instead of one per 256 pieces
-        constexpr int FB = ((DW_TR + DW_KMAX - 1) * (DW_CT / 4) + 255) / 256;
+        constexpr int FB = ((DW_TR + DW_KP - 1) * (DW_CT / 4) + 255) / 256;
         float v[FB][4];
         const int npc = rows * (DW_CT / 4);
 #pragma unroll
@@ -235,7 +261,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwConvArgs p) {
 #pragma unroll
         for (int u = 0; u < FB; ++u) {
             const int i = tid + u * 256;
-            if (i < npc) store4<T>(tile + (i >> 4) * DW_CT + (i & 15) * 4, v[u]);
+            if (i < npc) store4<T>(tile + (i >> 4) * DW_LS + (i & 15) * 4, v[u]);
         }
     } else {
         if (lnl) publish_rstat();
@@ -251,38 +277,39 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwConvArgs p) {
                         if (lnl) v[e] = __builtin_fmaf((v[e] - rstat[2 * r]) * rstat[2 * r + 1], p.ln_g[c0 + cq + e], p.ln_b[c0 + cq + e]);
                     }
             }
-            store4<T>(tile + r * DW_CT + cq, v);
+            store4<T>(tile + r * DW_LS + cq, v);
         }
     }
-    for (int i = tid; i < DW_CT * kp; i += 256) {
-        const int tap = i / DW_CT, c = i % DW_CT;
-        wl[tap * DW_CT + c] = (tap < p.k && c0 + c < p.C) ? p.w[(size_t)(c0 + c) * p.k + (p.flip ? p.k - 1 - tap : tap)] : 0.f;
+#pragma unroll
+    for (int u = 0; u < WB; ++u) {
+        const int i = tid + u * 256, tap = i / DW_CT, c = i % DW_CT;
+        if (i < DW_CT * kp) wl[i] = (tap < p.k && c0 + c < p.C) ? wv[u] : 0.f;
     }
     __syncthreads();
     const int cq = (tid & 15) * 4, r0 = (tid >> 4) * DW_RR;
-    float acc[DW_RR][4];
+    dw_f2 acc[DW_RR][2];
 #pragma unroll
-    for (int o = 0; o < DW_RR; ++o)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[o][e] = 0.f;
+    for (int o = 0; o < DW_RR; ++o) acc[o][0] = acc[o][1] = dw_f2{0.f, 0.f};
 #pragma unroll 1
     for (int c = 0; c < nch; ++c) {
-        float4 w[DW_TC];
+        dw_f2 w[DW_TC][2];
 #pragma unroll
-        for (int j = 0; j < DW_TC; ++j) w[j] = *(const float4*)(wl + (c * DW_TC + j) * DW_CT + cq);
-        const T* trow = tile + (r0 + c * DW_TC) * DW_CT + cq;
+        for (int j = 0; j < DW_TC; ++j) {
+            const float4 wv = *(const float4*)(wl + (c * DW_TC + j) * DW_CT + cq);
+            w[j][0] = dw_f2{wv.x, wv.y};
+            w[j][1] = dw_f2{wv.z, wv.w};
+        }
+        const T* trow = tile + (r0 + c * DW_TC) * DW_LS + cq;
 #pragma unroll
         for (int rr = 0; rr < DW_RR + DW_TC - 1; ++rr) {
-            float x4[4];
-            load4<T>(trow + rr * DW_CT, x4);
+            dw_f2 xa, xb;
+            load4v<T>(trow + rr * DW_LS, xa, xb);
 #pragma unroll
             for (int o = 0; o < DW_RR; ++o) {
-                const int j = rr - o;  // compile-time after unrolling: tap c*8 + j of output row o
+                const int j = rr - o;  // compile-time after unrolling: tap c*TC + j of output row o
                 if (j >= 0 && j < DW_TC) {
-                    acc[o][0] = fmaf(w[j].x, x4[0], acc[o][0]);
-                    acc[o][1] = fmaf(w[j].y, x4[1], acc[o][1]);
-                    acc[o][2] = fmaf(w[j].z, x4[2], acc[o][2]);
-                    acc[o][3] = fmaf(w[j].w, x4[3], acc[o][3]);
+                    acc[o][0] = __builtin_elementwise_fma(w[j][0], xa, acc[o][0]);
+                    acc[o][1] = __builtin_elementwise_fma(w[j][1], xb, acc[o][1]);
                 }
             }
         }
@@ -297,7 +324,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwConvArgs p) {
         if (t >= p.S) break;
         float ov[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) ov[e] = acc[o][e] + bias[e];
+        for (int e = 0; e < 4; ++e) ov[e] = acc[o][e >> 1][e & 1] + bias[e];
         if (full_c) {
             store4<T>(y + (size_t)t * p.C + c0 + cq, ov);
         } else {
@@ -308,12 +335,28 @@ __global__ __launch_bounds__(256) void dwconv_kernel(DwConvArgs p) {
     }
 }
 
+int dwconv_tap_chunk(int k) {  // the chunk that pads k least; the larger one on a tie (fewer slab rows read twice)
+    static const int cand[5] = {9, 8, 7, 5, 3};
+    int best = 8, bestp = 1 << 30;
+    for (int t : cand) {
+        const int kp = (k + t - 1) / t * t;
+        if (kp < bestp && kp <= DW_KP) { bestp = kp; best = t; }
+    }
+    return best;
+}
 int launch_dwconv(const DwConvArgs& a, int dtype, hipStream_t stream) {
     if (a.B <= 0 || a.S <= 0) return FS2_OK;
     if (a.k < 1 || a.k > DW_KMAX || a.C % 4) return FS2_ERR_SHAPE;
     const dim3 grid((a.S + DW_TR - 1) / DW_TR, (a.C + DW_CT - 1) / DW_CT, a.B), block(256);
-    if (dtype == FS2_BF16) hipLaunchKernelGGL(dwconv_kernel<bf16>, grid, block, 0, stream, a);
-    else hipLaunchKernelGGL(dwconv_kernel<float>, grid, block, 0, stream, a);
+    switch (dwconv_tap_chunk(a.k)) {
+#define FS2_DW(TC)                                                                                      \
+    case TC:                                                                                            \
+        if (dtype == FS2_BF16) hipLaunchKernelGGL((dwconv_kernel<bf16, TC>), grid, block, 0, stream, a); \
+        else hipLaunchKernelGGL((dwconv_kernel<float, TC>), grid, block, 0, stream, a);                  \
+        break;
+        FS2_DW(3) FS2_DW(5) FS2_DW(7) FS2_DW(8) FS2_DW(9)
+#undef FS2_DW
+    }
     return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
 }
 

@@ -659,7 +659,8 @@ def test_layernorm_residual_and_head(dtype, M, H):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("B,S,C,k", [(3, 37, 64, 3), (2, 130, 256, 25), (2, 70, 768, 17), (1, 4, 64, 9), (2, 64, 128, 1)])
+@pytest.mark.parametrize("B,S,C,k", [(3, 37, 64, 3), (2, 130, 256, 25), (2, 70, 768, 17), (1, 4, 64, 9), (2, 64, 128, 1),
+                                     (2, 300, 128, 5), (1, 517, 64, 7), (2, 260, 192, 13), (1, 700, 64, 21), (1, 280, 72, 31), (1, 33, 64, 32)])
 def test_dwconv(dtype, B, S, C, k):
     x, w, b = rnd(B, S, C, seed=18), rnd(C, 1, k, seed=19, scale=k ** -0.5), rnd(C, seed=20)
     ref = F.conv1d(G.rounded(x, dtype).transpose(1, 2), w, b, padding="same", groups=C).transpose(1, 2)

@@ -234,6 +234,17 @@ def attn_case(name, B, S, H, heads, reps):
     print(f"{name:28s} B={B} S={S} H={H} heads={heads}  {t*1e6:8.1f} us (incl. mask bits + V^T staging)  {fl/t/1e12:7.1f} TF")
 
 
+def dwconv_case(name, B, S, Cc, k, reps):
+    """Depth-wise conv launch (rowops.hip dwconv_kernel): HBM-bound, priced against 8 TB/s on read + write of the activations."""
+    x = torch.randn(B * S, Cc, device=DEV).to(torch.bfloat16)
+    w = torch.randn(Cc, k, device=DEV) * k ** -0.5
+    b = torch.randn(Cc, device=DEV)
+    y = torch.empty_like(x)
+    t = timeit(lambda st: lib.fs2_op_dwconv(BF16, p(x), p(w), p(b), p(y), B, S, Cc, k, st), reps)
+    by = 2.0 * x.numel() * 2
+    print(f"{name:28s} B={B} S={S} C={Cc} k={k:2d}   {t * 1e6:8.1f} us   {by / t / 1e12:6.2f} TB/s  ({by / t / 8e12 * 100:4.1f}% of 8 TB/s)", flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("what", nargs="?", default="all")
@@ -289,6 +300,11 @@ def main():
             gemm_ln_case("enc conv2 1x1 +res+LN", 8192, 256, 1024, 1, 8192, a.reps, v)
             gemm_ln_case("enc out_proj +res+LN", 8192, 256, 256, 1, 8192, a.reps, v)
             gemm_ln_case("dur-pred conv k=3 +LN", 8192, 256, 256, 3, 256, a.reps, v, res=False, relu=True)
+    if a.what in ("rows",):  # the LS-76M depth-wise convs: the variance predictors' (k = 3 / 5) and the decoder's
+        for k in (3, 5, 9, 13, 17, 21, 25, 31):
+            dwconv_case("c3 dwconv T rows", 32, 1536, 768, k, a.reps)
+        for k in (5, 25, 13, 9):
+            dwconv_case("c3 dwconv enc rows", 32, 256, 768, k, a.reps)
     if a.what in ("c3gemm",):  # the LS-76M decoder's pointwise GEMMs, by tile height
         for v in ([3, 4, 5] if a.variant < 0 else [a.variant]):
             gemm_case("c3 in_proj", 49152, 2304, 768, 1, 49152, a.reps, v)
