@@ -229,6 +229,8 @@ int fs2_profile_read(fs2_engine* e, int32_t kernel_class, double* total_ms, int6
  *   3/4/5   slab kernel, 128/192/256-row tiles   6/7   slab kernel, 32/64-row tiles
  *   200/201 slab kernel tile order: plain / XCD-contiguous (default)
  *   220/221 bf16 pointwise launches of more tiles than CUs: one tile per workgroup / the persistent kernel (default); bit-identical
+ *   230/231 wide depth-wise predictors: the last LayerNorm + Linear(filter, 1) head as a normalise pass over stored activations / from
+ *           row sums the last GEMM's epilogue leaves (fs2_op_gemm_head, default); equal to fp32 rounding of another summation order
  *   500/501 fp32 slab-kernel launches: fp32 MFMA (default) / bf16 x 3 split products (what FS2_MIXED_X3 uses in its front; operator level)
  *   700/701 bf16 fs2_op_bgemm tile order: plain / XCD-contiguous (default)
  *   800/801 bf16 fs2_op_bgemm: generic instantiation only / the bounds-free one for full, aligned tiles (default)
@@ -266,12 +268,23 @@ int fs2_op_gemm_add(int32_t dtype, const void* x, const void* w, const float* bi
  * (w = w0 diag(gamma) as stored in bf16, bias = bias0 + w0 beta, wg[n] = sum_k w[n][k]) and hands over v's finished row
  * statistics rowstats (M) float2 (rstd, rstd * mean) (fs2_op_rowstats_finish); the epilogue applies
  * c[m][n] = rstd[m] * acc - rstd[m] * mean[m] * wg[n] + bias[n].  What the engine's in-projection does behind a deferred norm2
- * (litfass/fastspeech2/model.py:113-115) instead of a normalise-only pass.  bf16 only, N >= 192; FS2_ERR_SHAPE otherwise. */
+ * (litfass/fastspeech2/model.py:113-115) instead of a normalise-only pass, and the mel Linear behind the last decoder block's
+ * (fastspeech2.py:723; N < 192: the 128 x 128 kernel's epilogue).  bf16 only; FS2_ERR_SHAPE otherwise. */
 int fs2_op_gemm_rowscale(const void* x, const void* w, const float* bias, const float* rowstats, const float* wg,
                          void* c, int32_t M, int32_t N, int32_t Cin, void* hip_stream);
 /* parts (M, nparts) float2 partial (sum, sum of squares) over ncols columns per row - what the deferred-LayerNorm GEMM epilogue
  * leaves, one per 256-column tile - -> out (M) float2 (rstd, rstd * mean) */
 int fs2_op_rowstats_finish(const float* parts, int32_t nparts, int32_t ncols, float eps, float* out, int32_t M, void* hip_stream);
+/* The last layer of a wide VariancePredictor (litfass/fastspeech2/model.py:512-518,538: ... -> ReLU -> LayerNorm -> Linear(N, 1) ->
+ * masked_fill) without storing its activations: v = act(x w^T + bias) (bf16 operands, fp32 v) is reduced in the GEMM epilogue to the
+ * row statistics stats_out (M, ceil(N/256)) float2 (sum, sum of squares per 256-column tile) and head_out (M, ceil(N/256)) =
+ * sum_n v[m][n] * head_gw[n] per tile, head_gw = gamma * w_head; fs2_op_head_finish then gives
+ * pred[m] = mask[m] ? 0 : rstd * (sum of head_out[m][:] - mean * sum_gw) + cst  =  LayerNorm(v)[m] . w_head + b_head with
+ * sum_gw = sum_n head_gw[n], cst = beta . w_head + b_head.  bf16, N >= 192, N % 8 == 0, Cin % 128 == 0; FS2_ERR_SHAPE otherwise. */
+int fs2_op_gemm_head(const void* x, const void* w, const float* bias, const float* head_gw, float* stats_out, float* head_out, int32_t M,
+                     int32_t N, int32_t Cin, int32_t relu, void* hip_stream);
+int fs2_op_head_finish(const float* parts, const float* dots, int32_t nparts, int32_t ncols, float eps, float sum_gw, float cst,
+                       const uint8_t* mask, float* pred, int32_t M, void* hip_stream);
 /* Split-K form for long reductions over few row tiles (training step: the encoder-side data-gradient convs, M = B L rows, K = taps x
  * filter): ksplit (from fs2_op_gemm_splitk_choice; 1 = not worth it -> use fs2_op_gemm) slices of the input channels run as separate
  * workgroups of ONE launch into fp32 planes part (ksplit, M, N), a second launch adds the planes in order:

@@ -150,6 +150,8 @@ def load():
     lib.fs2_op_gemm_add.argtypes = [i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
     lib.fs2_op_gemm_rowscale.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]
     lib.fs2_op_rowstats_finish.argtypes = [vp, i32, i32, C.c_float, vp, i32, vp]
+    lib.fs2_op_gemm_head.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.fs2_op_head_finish.argtypes = [vp, vp, i32, i32, C.c_float, C.c_float, C.c_float, vp, vp, i32, vp]
     lib.fs2_op_gemm_splitk_choice.argtypes = [i32, i32, i32, i32, i32, i32]
     lib.fs2_op_gemm_splitk.argtypes = [i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.fs2_op_gemm_gated.argtypes = [i32, vp, vp, vp, vp, C.c_float, vp, i32, i32, i32, i32, i32, vp]

@@ -49,6 +49,7 @@ int apply_knob(Tuning& t, int variant) {
     else if (variant == 800 || variant == 801) t.bgemm_full = variant - 800;           // bf16 strided-batched GEMM: generic instantiation only / bounds-free one for full aligned tiles (default)
     else if (variant == 700 || variant == 701) t.bgemm_xcd = variant - 700;            // bf16 strided-batched GEMM tile order plain / XCD-contiguous (default)
     else if (variant == 500 || variant == 501) t.split_f32 = variant - 500;            // operator level: fp32 slab launches as fp32 MFMA (default) / bf16 x 3 split
+    else if (variant == 230 || variant == 231) t.head_sums = variant - 230;           // predictor head from a normalise pass / from the last GEMM's epilogue sums (default)
     else if (variant == 220 || variant == 221) t.gemm_persist = variant - 220;         // multi-round bf16 pointwise launches one tile per workgroup / on the persistent kernel (default)
     else if (variant == 200 || variant == 201) t.slab_xcd_remap = variant - 200;       // slab kernel tile order plain / XCD-contiguous (default)
     else if (variant >= 0 && variant <= 7) t.gemm_variant = variant;                    // kernel family / forced tile height of the forward GEMM launcher (gemm_mfma.hip: launch_gemm)
@@ -168,11 +169,24 @@ int fs2_op_gemm_rowscale(const void* x, const void* w, const float* bias, const 
     a.M = M; a.N = N; a.K = Cin; a.ldx = Cin; a.ldc = N;
     a.Cin = Cin; a.taps = 1; a.pad = 0; a.S = M; a.relu = 0;
     a.rs_stats = rowstats; a.rs_wg = wg;
-    if (N < 192) return FS2_ERR_SHAPE;
     return launch_gemm(a, FS2_BF16, FS2_BF16, (hipStream_t)stream);
 }
 int fs2_op_rowstats_finish(const float* parts, int32_t nparts, int32_t ncols, float eps, float* out, int32_t M, void* stream) {
     return launch_rowstats_finish(parts, nparts, ncols, eps, out, M, (hipStream_t)stream);
+}
+int fs2_op_gemm_head(const void* x, const void* w, const float* bias, const float* head_gw, float* stats_out, float* head_out, int32_t M,
+                     int32_t N, int32_t Cin, int32_t relu, void* stream) {
+    if (!x || !w || !bias || !head_gw || !stats_out || !head_out) return FS2_ERR_ARG;
+    GemmArgs a;
+    a.X = x; a.W = w; a.bias = bias; a.C = nullptr;
+    a.M = M; a.N = N; a.K = Cin; a.ldx = Cin; a.ldc = N;
+    a.Cin = Cin; a.taps = 1; a.pad = 0; a.S = M; a.relu = relu;
+    a.stats_out = stats_out; a.head_gw = head_gw; a.head_out = head_out; a.ln_eps = 1e-5f;
+    return launch_gemm(a, FS2_BF16, FS2_BF16, (hipStream_t)stream);
+}
+int fs2_op_head_finish(const float* parts, const float* dots, int32_t nparts, int32_t ncols, float eps, float sum_gw, float cst,
+                       const uint8_t* mask, float* pred, int32_t M, void* stream) {
+    return launch_head_finish(parts, dots, nparts, ncols, eps, sum_gw, cst, mask, pred, M, (hipStream_t)stream);
 }
 
 int fs2_op_gemm_splitk_choice(int32_t dtype, int32_t M, int32_t N, int32_t Cin, int32_t taps, int32_t S) {

@@ -101,6 +101,10 @@ struct PredictorW {
     std::vector<PredLayerW> layers;
     float* head_w = nullptr;
     float head_b = 0.f;
+    // wide depth-wise predictors (deferred LayerNorms): the last LayerNorm + head from the last GEMM's epilogue sums (GemmArgs::head_out):
+    // head_gw = gamma_last * w_head, its sum, and beta_last . w_head + head_b
+    float* head_gw = nullptr;
+    float head_sum_gw = 0.f, head_cst = 0.f;
     int filt = 0;
     // one-launch path (predictor_fused.hip): weights in MFMA fragment order, per-layer vectors stacked
     void* wpk = nullptr;
@@ -158,6 +162,9 @@ struct fs2_engine {
     PredictorW dur;
     std::vector<VarianceW> vars;
     ConvW mel;
+    ConvW mel_f;               // the mel head with the last decoder block's norm2 folded in (wide depth-wise bf16 decoders), mel_wg its row sums
+    float* mel_wg = nullptr;
+    bool mel_fold = false;
     std::vector<VarianceW> priors_w;  // bins + relu(embedding) per prior (predictor unused)
     const float* priors_dev = nullptr;
     int priors_B = 0;
@@ -493,6 +500,20 @@ int make_predictor(fs2_engine* e, const std::string& p, int nl, int filt, bool d
     }
     CHK(up_vec(e, p + ".linear.weight", &P->head_w));
     P->head_b = W(e, p + ".linear.bias").data[0];
+    if (dw && nl && filt > 256) {
+        const std::string q = p + ".layers." + std::to_string(nl - 1) + ".layers";
+        const auto &hw = W(e, p + ".linear.weight").data, &hg = W(e, q + ".2.weight").data, &hbe = W(e, q + ".2.bias").data;
+        std::vector<float> gw(filt);
+        double sg = 0, cst = P->head_b;
+        for (int n = 0; n < filt; ++n) {
+            gw[n] = hg[n] * hw[n];
+            sg += (double)gw[n];
+            cst += (double)hbe[n] * hw[n];
+        }
+        CHK(upload_f32(e, gw.data(), gw.size(), &P->head_gw));
+        P->head_sum_gw = (float)sg;
+        P->head_cst = (float)cst;
+    }
     const int taps = nl ? P->layers[0].c.taps : 0, cin = nl ? P->layers[0].c.Cin : 0;
     if (!dw && nl && cin == filt && predictor_fused_supported(dt, filt, taps, nl, 1)) {
         const size_t lb = predictor_packed_bytes_per_layer();
@@ -547,6 +568,11 @@ struct Deferred {  // deferred-LayerNorm epilogue of a GEMM (rows wider than one
     const float* res_g = nullptr;
     const float* res_b = nullptr;
     float* stats_out = nullptr;       // (M, parts) float2
+    // the consumer is LayerNorm -> Linear(N, 1): leave sum_n v[n] head_gw[n] per row and column tile in head_out (M, parts) instead of
+    // the rows, where the launch can (gemm_head_supported; *head_done says whether it did - if not, the rows were stored as usual)
+    const float* head_gw = nullptr;
+    float* head_out = nullptr;
+    bool* head_done = nullptr;
 };
 inline int ln_parts(int N) { return (N + 255) / 256; }  // one (sum, sum of squares) per row per 256-column GEMM tile, <= 4
 
@@ -597,6 +623,11 @@ int gemm(fs2_engine* e, hipStream_t st, const ConvW& w, const void* x, void* c, 
         a.res = ln->res; a.ln_g = ln->g; a.ln_b = ln->b; a.ln_eps = 1e-5f;
         a.dot_w = ln->dot_w; a.dot_b = ln->dot_b; a.mask = ln->mask; a.pred = ln->pred; a.ln_tmp = ln->tmp;
     }
+    if (df && df->head_out && df->head_done) {
+        a.head_gw = df->head_gw; a.head_out = df->head_out;
+        *df->head_done = gemm_head_supported(a, w.dt, out_dt);
+        if (!*df->head_done) { a.head_gw = nullptr; a.head_out = nullptr; }
+    }
     const double osz = out_dt == FS2_BF16 ? 2 : 4;
     const double fl = 2.0 * M * (double)a.N * a.K;
     const double wsz = w.dt == FS2_BF16 ? 2 : 4;
@@ -636,6 +667,7 @@ int norm_only(fs2_engine* e, hipStream_t st, int dt, const void* v, const float*
 struct LayerScratch {
     float *st1, *st2;  // deferred-LayerNorm row statistics (M, ln_parts(max width)) float2 each
     float* rsf;        // (M) float2 (rstd, rstd * mean) of a block's pre-norm output (folded LayerNorm)
+    float* hd;         // (M, 4) head sums of a predictor's last GEMM (GemmArgs::head_out)
     void *qkv, *att, *proj, *hid, *u, *vt;
     uint64_t* bits;
     int Spad, nw64;
@@ -731,16 +763,17 @@ int conformer(fs2_engine* e, hipStream_t st, const LayerW& w, void* x, void* tmp
 // depth-wise bf16 blocks the closing LayerNorm is never materialised (fs2_set_folded_layernorm): block i leaves v2 + row statistics,
 // block i + 1 runs its in-projection on v2 with norm2 folded into the weights and normalises the residual on load.
 int run_stack(fs2_engine* e, hipStream_t st, const std::vector<LayerW>& Ls, void* x, void* tmp, int B, int S, int heads,
-              const LayerScratch& sc, bool is_decoder) {
+              const LayerScratch& sc, bool is_decoder, bool leave_last = false, bool* left = nullptr) {
     const int H = e->cfg.hidden;
     bool pre = false;
     for (size_t i = 0; i < Ls.size(); ++i) {
         const LayerW& w = Ls[i];
         const bool deferred = w.depthwise && H > 256 && e->defer_ln;
-        const bool leave = e->fold_ln && deferred && i + 1 < Ls.size() && Ls[i + 1].has_fold && Ls[i + 1].depthwise;
+        const bool leave = e->fold_ln && deferred && (i + 1 < Ls.size() ? Ls[i + 1].has_fold && Ls[i + 1].depthwise : leave_last);
         CHK(conformer(e, st, w, x, tmp, B, S, heads, sc, is_decoder, pre, pre ? Ls[i - 1].g2 : nullptr, pre ? Ls[i - 1].b2 : nullptr, leave));
         pre = leave;
     }
+    if (left) *left = pre;  // the stack's output is the last block's pre-norm v2 (+ finished statistics in sc.rsf): the caller folds norm2 in
     return FS2_OK;
 }
 
@@ -791,6 +824,7 @@ int predictor(fs2_engine* e, hipStream_t st, const PredictorW& P, const void* x,
         const void* src = x;
         float* stats[2] = {sc.st1, sc.st2};
         const PredLayerW* prev = nullptr;
+        bool head_done = false;
         for (size_t j = 0; j < P.layers.size(); ++j) {
             const PredLayerW& Lw = P.layers[j];
             void* out = (j & 1) ? sc.proj : sc.att;
@@ -798,11 +832,18 @@ int predictor(fs2_engine* e, hipStream_t st, const PredictorW& P, const void* x,
             CHK(dwconv(e, st, Lw.dw, src, sc.u, B, S, P.dt, prev ? &lp : nullptr));
             Deferred d;
             d.stats_out = stats[j & 1];
+            if (j + 1 == P.layers.size() && !P.cwt && P.head_gw) { d.head_gw = P.head_gw; d.head_out = sc.hd; d.head_done = &head_done; }
             CHK(gemm(e, st, Lw.c, sc.u, out, M, S, true, P.dt, nullptr, -1, nullptr, &d));
             src = out;
             prev = &Lw;
         }
         float* stl = stats[(P.layers.size() - 1) & 1];
+        if (head_done) {  // the last LayerNorm + head: a row-sized pass over the epilogue's sums
+            Bracket br(e, FS2_K_ROWOPS, st, 0, (double)M * ln_parts(P.filt) * 12);
+            if (launch_head_finish(stl, sc.hd, ln_parts(P.filt), P.filt, 1e-5f, P.head_sum_gw, P.head_cst, mask, pred, M, st) != FS2_OK)
+                return fail(e, FS2_ERR_HIP, "head finish launch failed");
+            return FS2_OK;
+        }
         if (!P.cwt) return norm_only(e, st, P.dt, src, stl, prev->g, prev->b, nullptr, M, P.filt, P.head_w, P.head_b, mask, pred);
         CHK(norm_only(e, st, P.dt, src, stl, prev->g, prev->b, (void*)src, M, P.filt));
         CHK(gemm(e, st, P.head_mat, src, cw->spec12, M, M, false, FS2_F32));
@@ -850,7 +891,7 @@ size_t layer_scratch_bytes(const fs2_engine* e, int B, int S) {
     if ((size_t)c.dur_filter > Pm) Pm = c.dur_filter;
     const size_t Spad = ((size_t)S + 63) / 64 * 64;
     return al(M * 3 * H * esz) + 3 * al(M * Pm * esz) + al(M * Fm * esz) + al((size_t)B * H * Spad * esz) +
-           al((size_t)B * (Spad / 64) * 8) + 2 * al(M * (size_t)ln_parts((int)Pm) * 8) + al(M * 8) + 4096;
+           al((size_t)B * (Spad / 64) * 8) + 2 * al(M * (size_t)ln_parts((int)Pm) * 8) + al(M * 8) + al(M * 16) + 4096;
 }
 int take_layer_scratch(fs2_engine* e, Arena& ar, int B, int S, LayerScratch* sc) {
     const fs2_config& c = e->cfg;
@@ -864,6 +905,7 @@ int take_layer_scratch(fs2_engine* e, Arena& ar, int B, int S, LayerScratch* sc)
     sc->st1 = (float*)ar.take(M * (size_t)ln_parts((int)Pm) * 8);
     sc->st2 = (float*)ar.take(M * (size_t)ln_parts((int)Pm) * 8);
     sc->rsf = (float*)ar.take(M * 8);
+    sc->hd = (float*)ar.take(M * 16);
     sc->qkv = ar.take(M * 3 * H * esz);
     sc->att = ar.take(M * Pm * esz);
     sc->proj = ar.take(M * Pm * esz);
@@ -968,6 +1010,7 @@ int fs2_clone(const fs2_engine* src, fs2_engine** out) {
     e->dev_allocs = src->dev_allocs;
     e->phone_table = src->phone_table; e->pe = src->pe; e->spk_w = src->spk_w; e->spk_b = src->spk_b;
     e->enc = src->enc; e->dec = src->dec; e->dur = src->dur; e->vars = src->vars; e->mel = src->mel; e->priors_w = src->priors_w;
+    e->mel_f = src->mel_f; e->mel_wg = src->mel_wg; e->mel_fold = src->mel_fold;
     *out = e;
     return FS2_OK;
 }
@@ -1045,6 +1088,29 @@ int fs2_finalize(fs2_engine* e) {
         CHK(up_vec(e, p + ".embedding.weight", &e->vars[v].emb));
     }
     CHK(make_conv(e, "linear.weight", "linear.bias", &e->mel, e->bdt));
+    if (H > 256 && c.dec_layers > 0 && c.dec_depthwise && e->bdt == FS2_BF16) {
+        // mel = Linear(LN2_last(v2)) evaluated on v2: W' = W diag(gamma2), b' = b + W beta2, wg[n] = sum_k W'[n][k] as stored (make_folded_in_proj)
+        const std::string pp = "decoder.layers." + std::to_string(c.dec_layers - 1);
+        const HostTensor &w = W(e, "linear.weight"), &b = W(e, "linear.bias"), &g = W(e, pp + ".norm2.weight"), &be = W(e, pp + ".norm2.bias");
+        const int N = (int)b.data.size();
+        std::vector<float> wf((size_t)N * H), bf(N), wg(N);
+        for (int n = 0; n < N; ++n) {
+            double bacc = b.data[n], gacc = 0;
+            for (int k = 0; k < H; ++k) {
+                const float v = (float)((double)w.data[(size_t)n * H + k] * g.data[k]);
+                wf[(size_t)n * H + k] = v;
+                bacc += (double)w.data[(size_t)n * H + k] * be.data[k];
+                gacc += (double)bf16_to_f32(f32_to_bf16(v));
+            }
+            bf[n] = (float)bacc;
+            wg[n] = (float)gacc;
+        }
+        e->mel_f.N = N; e->mel_f.Cin = H; e->mel_f.taps = 1; e->mel_f.dt = FS2_BF16;
+        CHK(upload_mat(e, wf.data(), wf.size(), &e->mel_f.w, FS2_BF16));
+        CHK(upload_f32(e, bf.data(), bf.size(), &e->mel_f.b));
+        CHK(upload_f32(e, wg.data(), wg.size(), &e->mel_wg));
+        e->mel_fold = true;
+    }
     e->priors_w.resize(c.n_priors);
     for (int p = 0; p < c.n_priors; ++p) {
         const std::string q = std::string("prior_embeddings.") + c.prior_names[p];
@@ -1332,10 +1398,16 @@ static int decode_body(fs2_engine* e, const fs2_outputs* out, hipStream_t st) {
         if (launch_convert(ca, e->fdt, e->bdt, st) != FS2_OK) return fail(e, FS2_ERR_HIP, "front -> back conversion failed");
         std::swap(yA, yB);
     }
-    CHK(run_stack(e, st, e->dec, yA, yB, B, T, c.dec_heads, sc, true));       // fastspeech2.py:719-721
+    // (the mel head takes the last block's norm2 folded in where it can: nothing else reads the decoder's normalised output)
+    bool dec_pre = false;
+    CHK(run_stack(e, st, e->dec, yA, yB, B, T, c.dec_heads, sc, true, e->mel_fold && out->mel && !e->debug, &dec_pre));  // fastspeech2.py:719-721
     if (e->debug) CHK(tap_store(e, st, "decoder_out", yA, MT * H, e->bdt));
-    if (out->mel)                                                            // fastspeech2.py:723
+    if (out->mel && dec_pre) {                                               // fastspeech2.py:723
+        const RowScale rs{sc.rsf, e->mel_wg};
+        CHK(gemm(e, st, e->mel_f, yA, out->mel, (int)MT, (int)MT, false, FS2_F32, nullptr, -1, e->zero_pad_mel ? tmask : nullptr, nullptr, nullptr, &rs));
+    } else if (out->mel) {
         CHK(gemm(e, st, e->mel, yA, out->mel, (int)MT, (int)MT, false, FS2_F32, nullptr, -1, e->zero_pad_mel ? tmask : nullptr));
+    }
     for (int v = 0; v < FS2_MAX_VARIANCES; ++v) e->forced_idx[v] = nullptr, e->forced_tgt[v] = nullptr;  // one-shot
     return phone_outputs();
 }

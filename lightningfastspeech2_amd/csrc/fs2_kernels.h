@@ -15,6 +15,7 @@ namespace fs2 {
 struct Tuning {
     int gemm_variant = 0;      // 0 auto; 1 128x128 register-staged; 2 128x256 DMA ring; 3/4/5 slab kernel 128/192/256-row tiles; 6/7 32/64-row
     int gemm_wres = 1;         // bf16 K = 256 plain GEMMs on the weight-resident kernel: 0 never, 1 where it pays, 2 wherever it applies
+    int head_sums = 1;         // wide predictors: last LayerNorm + Linear head from the last GEMM's epilogue sums (GemmArgs::head_out) / a normalise pass
     int gemm_persist = 1;      // bf16 pointwise launches of more tiles than CUs on the persistent kernel (gemm_persist.hip)
     int slab_xcd_remap = 1;    // XCD-contiguous tile order in the slab kernel
     int split_f32 = 0;         // operator level only (tests): every fp32 slab launch in the bf16 x 3 split arithmetic
@@ -83,6 +84,11 @@ struct GemmArgs {
     // rs_stats = (M) float2 (rstd, rstd * mean) per row, finished from the deferred epilogue's parts by launch_rowstats_finish.
     const float* rs_stats = nullptr;
     const float* rs_wg = nullptr;
+    // Head behind the deferred LayerNorm (persistent kernel only; with stats_out, C unused): the rows are not stored, per row and
+    // 256-column tile sum_n v[m][n] * head_gw[n] -> head_out (M, ceil(N/256)) beside the statistics; launch_head_finish turns both
+    // into pred[m] = mask[m] ? 0 : (LayerNorm(v)[m] . w) + b with head_gw = gamma * w.
+    const float* head_gw = nullptr;
+    float* head_out = nullptr;
     int ksplit = 0;                 // > 1: split-K on the slab kernel (plain epilogue, fp32 out, no bias / ReLU / gate): split s sums the channel
                                     // blocks [s, s + 1) * Cin / ksplit of every tap into plane s of C (ksplit, M, ldc); launch_split_k_reduce adds them
 };
@@ -100,6 +106,7 @@ bool gemm_wres_supported(const GemmArgs& a, int in_dtype, int out_dtype, bool fo
 int launch_gemm_wres(const GemmArgs& a, hipStream_t stream);
 // gemm_persist.hip: the slab kernel's persistent form (one workgroup per CU walks its tiles; bit-identical results)
 bool gemm_persist_supported(const GemmArgs& a, int in_dtype, int out_dtype, int mi);
+bool gemm_head_supported(const GemmArgs& a, int in_dtype, int out_dtype);  // can this launch take GemmArgs::head_out (persistent kernel, switch on)
 bool gemm_persist_pays(const GemmArgs& a, int mi);
 int launch_gemm_persist(const GemmArgs& a, int mi, hipStream_t stream);
 
@@ -270,6 +277,9 @@ int launch_layernorm(const LayerNormArgs& a, int dtype, hipStream_t stream);
 // (M, nparts) float2 partial (sum, sum of squares) over ncols columns per row -> (M) float2 (rstd, rstd * mean): the per-row
 // constants of the row-scaled GEMM epilogue (GemmArgs::rs_stats), once per tensor instead of once per column tile of its consumer
 int launch_rowstats_finish(const float* parts, int nparts, int ncols, float eps, float* out, int M, hipStream_t stream);
+// pred[m] = mask[m] ? 0 : rstd (sum of dots[m][:] - mean * sum_gw) + cst from the deferred epilogue's parts (GemmArgs::head_out)
+int launch_head_finish(const float* parts, const float* dots, int nparts, int ncols, float eps, float sum_gw, float cst, const uint8_t* mask, float* pred,
+                       int M, hipStream_t stream);
 
 struct DwConvArgs {
     const void* x;      // (B*S, C)

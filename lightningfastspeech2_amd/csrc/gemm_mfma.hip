@@ -129,20 +129,26 @@ __global__ __launch_bounds__(256) void gemm_conv_kernel(GemmArgs p) {
     for (int ni = 0; ni < 4; ++ni) {
         const int n = n0 + wn * 64 + ni * 16 + fg * 4;
         if (n >= p.N) continue;
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
+        float bv[4] = {0.f, 0.f, 0.f, 0.f}, wgv[4] = {0.f, 0.f, 0.f, 0.f};
         if (p.bias) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) if (n + r < p.N) bv[r] = p.bias[n + r];
+        }
+        if (p.rs_stats) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (n + r < p.N) wgv[r] = p.rs_wg[n + r];
         }
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
             const int m = m0 + wm * 64 + mi * 16 + fr;
             if (m >= p.M) continue;
             const bool zr = ZR && p.zero_rows[m];
+            float2 rq = make_float2(1.f, 0.f);
+            if (p.rs_stats) rq = ((const float2*)p.rs_stats)[m];  // the row-scaled product (GemmArgs::rs_stats): narrow heads (N < 192) take it here
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                v[r] = acc[ni][mi][r] + bv[r];
+                v[r] = p.rs_stats ? __builtin_fmaf(acc[ni][mi][r], rq.x, __builtin_fmaf(-rq.y, wgv[r], bv[r])) : acc[ni][mi][r] + bv[r];
                 if (p.relu) v[r] = fmaxf(v[r], 0.f);
                 if (ZR) v[r] = zr ? 0.f : v[r];
             }
@@ -1344,6 +1350,10 @@ static int launch_gemm_plain(const GemmArgs& a, int in_dtype, int out_dtype, hip
 int launch_gemm(const GemmArgs& a, int in_dtype, int out_dtype, hipStream_t stream) {
     const Tuning& tn = tuning_of(a.tune);
     const int g_gemm_variant = tn.gemm_variant, g_gemm_wres = tn.gemm_wres;
+    if (a.head_out) {  // head sums instead of the rows: the persistent kernel's deferred epilogue only (callers ask gemm_head_supported first)
+        if (a.ln_g || !gemm_head_supported(a, in_dtype, out_dtype)) return FS2_ERR_SHAPE;
+        return launch_gemm_persist(a, 6, stream);
+    }
     if (!a.ln_g && a.drop_p > 0.f) {  // the plain store's dropout: slab kernel, behind a ReLU (the FFN's hidden tensor)
         if (!a.relu || a.gate || a.stats_out || a.epi_res || a.ksplit > 1 || a.zero_rows || g_gemm_variant != 0 || a.N < 192 || a.M % a.S ||
             !(a.taps & 1) || in_dtype != out_dtype)
@@ -1389,6 +1399,13 @@ static int launch_gemm_plain(const GemmArgs& a, int in_dtype, int out_dtype, hip
     const int e16 = in_dtype == FS2_BF16 ? 8 : 4;
     if (a.K % ke || a.Cin % ke || a.ldx % e16 || a.K != a.taps * a.Cin) return FS2_ERR_SHAPE;
     if (a.ldc % 4) return FS2_ERR_SHAPE;
+    if (a.rs_stats && a.N < 192) {  // a narrow head behind a folded LayerNorm (the mel Linear): 128x128 kernel, bf16 operands
+        if (fused || a.relu || a.gate || a.stats_out || a.epi_res || a.C_lo || a.ksplit > 1 || a.drop_p > 0.f || !a.rs_wg || a.taps != 1 || in_dtype != FS2_BF16)
+            return FS2_ERR_SHAPE;
+        if (out_dtype == FS2_F32) return a.zero_rows ? launch_t<bf16, float, true>(a, stream) : launch_t<bf16, float>(a, stream);
+        if (out_dtype == FS2_BF16 && !a.zero_rows) return launch_t<bf16, bf16>(a, stream);
+        return FS2_ERR_SHAPE;
+    }
     if (a.zero_rows) {  // the mel head with zeroed pad rows: 128x128 kernel only
         if (fused) return FS2_ERR_SHAPE;
         if (in_dtype == FS2_F32 && out_dtype == FS2_F32) return launch_t<float, float, true>(a, stream);

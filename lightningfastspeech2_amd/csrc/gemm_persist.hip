@@ -43,9 +43,13 @@ template <int I> struct IntCP { static constexpr int value = I; };
 // drains the operand requests: dropped; dense convs stay on the slab kernel, 36 steps per tile.)
 // RS: the row-scaled product (GemmArgs::rs_stats; plain epilogue only): per-row (rstd, rstd * mean) and the wg row reach the epilogue
 // through LDS like the bias row - fetched at the top of the tile, published by waves 4-7 behind the first step's MFMAs.
-template <int MI, bool DEFER, bool RS = false>
+// HEAD (deferred epilogue only; GemmArgs::head_out): the tile's rows are NOT stored - the consumer is a Linear(N, 1) head behind the
+// LayerNorm, and sum_n LN(v)[n] w[n] = rstd (sum_n v[n] gw[n] - mean sum_n gw[n]) + const with gw = gamma * w.  The epilogue leaves
+// the row statistics as always plus sum_n v[n] gw[n] over the tile's columns; launch_head_finish makes the prediction of them.
+template <int MI, bool DEFER, bool RS = false, bool HEAD = false>
 __global__ __launch_bounds__(512) void gemm_persist_kernel(GemmArgs p, int ntiles) {
     static_assert(!(RS && DEFER), "the row-scaled product is a plain-epilogue form");
+    static_assert(!HEAD || DEFER, "the head sums ride the deferred-LayerNorm epilogue");
 #if defined(__HIP_DEVICE_COMPILE__)
     using T = bf16;
     constexpr int BMs = MI * 32;
@@ -57,7 +61,8 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(GemmArgs p, int ntile
     __shared__ __attribute__((aligned(16))) unsigned char wt0[PR_BN * PR_ROWB];
     __shared__ __attribute__((aligned(16))) unsigned char wt1[PR_BN * PR_ROWB];
     __shared__ __attribute__((aligned(16))) float sbias[PR_BN];                 // the tile's bias row (wave 7 brings it in under the tile's first step)
-    __shared__ __attribute__((aligned(16))) float swg[RS ? PR_BN : 4];          // RS: sum_k W'[n][k] of the tile's columns
+    __shared__ __attribute__((aligned(16))) float swg[RS || HEAD ? PR_BN : 4];  // RS: sum_k W'[n][k] of the tile's columns; HEAD: gamma[n] * w_head[n]
+    __shared__ __attribute__((aligned(16))) float red3[HEAD ? 4 * BMs : 4];     // HEAD: the head sums' exchange
     __shared__ __attribute__((aligned(16))) float2 srow[RS ? BMs : 2];          // RS: (rstd, rstd * mean) of the tile's rows
     __shared__ __attribute__((aligned(16))) float2 red[DEFER ? 4 * BMs : 2];    // row statistics exchange (its own object: the operand buffers
                                                                                 // already hold the next tile's first step by then)
@@ -187,6 +192,7 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(GemmArgs p, int ntile
         } else {
             if (wave != 7) return;
             *(float4*)(sbias + lane * 4) = bq;
+            if constexpr (HEAD) *(float4*)(swg + lane * 4) = wq;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
@@ -324,6 +330,7 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(GemmArgs p, int ntile
             int nb = n0 + lane * 4;
             nb = nb < p.N - 4 ? nb : p.N - 4;
             bq = *(const float4*)(p.bias + nb);
+            if constexpr (HEAD) wq = *(const float4*)(p.head_gw + nb);
             if constexpr (RS) {
                 wq = *(const float4*)(p.rs_wg + nb);
                 int rr = t0 + (wave & 3) * 64 + lane;
@@ -420,13 +427,23 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(GemmArgs p, int ntile
             // (sum v, sum v^2) per row -> stats_out[row][column tile]   (gemm_mfma.hip, DEFER)
             const size_t rowbase = (size_t)ub * S;
             const float lo = p.relu ? 0.f : -__builtin_inff();
-            float a1[MI], a2[MI];
+            float a1[MI], a2[MI], a3[HEAD ? MI : 1];
+            float gwv[HEAD ? 2 : 1][8];
+            if constexpr (HEAD) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float4 w0 = *(const float4*)(swg + wn * 64 + j * 32 + fge * 8), w1 = *(const float4*)(swg + wn * 64 + j * 32 + fge * 8 + 4);
+                    gwv[j][0] = w0.x; gwv[j][1] = w0.y; gwv[j][2] = w0.z; gwv[j][3] = w0.w;
+                    gwv[j][4] = w1.x; gwv[j][5] = w1.y; gwv[j][6] = w1.z; gwv[j][7] = w1.w;
+                }
+            }
             auto body = [&](auto full_c, auto rows_c) {
                 constexpr bool FULL = decltype(full_c)::value, ROWS = decltype(rows_c)::value;
 #pragma unroll
                 for (int mi = 0; mi < MI; ++mi) {
                     const int t = t0 + wm * (MI * 16) + mi * 16 + fre;
                     a1[mi] = a2[mi] = 0.f;
+                    if constexpr (HEAD) a3[mi] = 0.f;
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
                         const int n = n0 + wn * 64 + j * 32 + fge * 8;
@@ -438,8 +455,9 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(GemmArgs p, int ntile
                             if (!FULL && n + r >= p.N) v[r] = 0.f;
                             a1[mi] += v[r];
                             a2[mi] = __builtin_fmaf(v[r], v[r], a2[mi]);
+                            if constexpr (HEAD) a3[mi] = __builtin_fmaf(v[r], gwv[j][r], a3[mi]);  // (columns past N: v = 0)
                         }
-                        if ((ROWS || t < S) && (FULL || n < p.N)) {
+                        if (!HEAD && (ROWS || t < S) && (FULL || n < p.N)) {
                             T* dst = (T*)((char*)C + (unsigned)(t * p.ldc + n) * (unsigned)sizeof(T));
                             if (FULL || n + 7 < p.N) {
                                 *(uint4*)dst = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
@@ -459,6 +477,10 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(GemmArgs p, int ntile
                 for (int mi = 0; mi < MI; ++mi) {
                     const float s1 = group4_sum(a1[mi]), s2 = group4_sum(a2[mi]);
                     if (fge == 0) red[wn * BMs + wm * (MI * 16) + mi * 16 + fre] = make_float2(s1, s2);
+                    if constexpr (HEAD) {
+                        const float s3 = group4_sum(a3[mi]);
+                        if (fge == 0) red3[wn * BMs + wm * (MI * 16) + mi * 16 + fre] = s3;
+                    }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
@@ -470,11 +492,13 @@ __global__ __launch_bounds__(512) void gemm_persist_kernel(GemmArgs p, int ntile
                         const float2 q0 = red[row], q1 = red[BMs + row], q2 = red[2 * BMs + row], q3 = red[3 * BMs + row];
                         ((float2*)p.stats_out)[(rowbase + t) * (size_t)tiles_n + bn] =
                             make_float2((q0.x + q1.x) + (q2.x + q3.x), (q0.y + q1.y) + (q2.y + q3.y));
+                        if constexpr (HEAD)
+                            p.head_out[(rowbase + t) * (size_t)tiles_n + bn] = (red3[row] + red3[BMs + row]) + (red3[2 * BMs + row] + red3[3 * BMs + row]);
                     }
                 }
             }
             // DMA waves (0-3): exactly NSTORE stores behind the requests on the full path; waves 4-7 requested nothing
-            if (fulln && fullt && dma_wave) PR_VMCNT(NSTORE);
+            if (!HEAD && fulln && fullt && dma_wave) PR_VMCNT(NSTORE);
             else PR_VMCNT(0);
         }
         if (!has_next) break;
@@ -496,7 +520,12 @@ bool gemm_persist_supported(const GemmArgs& a, int in_dtype, int out_dtype, int 
     if (in_dtype != FS2_BF16 || out_dtype != FS2_BF16) return false;
     if (a.ln_g || a.dot_w || a.z_out || a.res || a.gate || a.zero_rows || a.C_lo || a.split || a.w_presplit || a.ksplit > 1 || a.drop_p > 0.f) return false;
     if (a.rs_stats && (a.relu || a.stats_out || a.epi_res || !a.rs_wg)) return false;
-    if (!a.bias || !a.C) return false;
+    if (!a.bias) return false;
+    if (a.head_out) {  // rows not stored: statistics + head sums only
+        if (!a.head_gw || !a.stats_out || a.epi_res || a.rs_stats || mi != 6) return false;
+    } else if (!a.C) {
+        return false;
+    }
     const bool defer = a.stats_out || a.epi_res;
     if (defer && (mi != 6 || (a.epi_res && a.relu))) return false;
     if (!defer && mi != 6 && mi != 8) return false;
@@ -506,6 +535,10 @@ bool gemm_persist_supported(const GemmArgs& a, int in_dtype, int out_dtype, int 
     if (a.ldx % 8 || a.ldc % 8) return false;
     if ((size_t)a.M * a.ldx * 2 >= 0xFFFFF000ull || (size_t)S * a.ldc * 2 >= 0xFFFFF000ull || (size_t)a.N * a.K * 2 >= 0xFFFFF000ull) return false;
     return true;
+}
+
+bool gemm_head_supported(const GemmArgs& a, int in_dtype, int out_dtype) {
+    return tuning_of(a.tune).head_sums && gemm_persist_supported(a, in_dtype, out_dtype, 6);  // (this kernel is the only form: independent of Tuning::gemm_persist)
 }
 
 static int persist_cus() {
@@ -525,13 +558,13 @@ bool gemm_persist_pays(const GemmArgs& a, int mi) {
     return tiles > persist_cus();
 }
 
-template <int MI, bool DEFER, bool RS = false>
+template <int MI, bool DEFER, bool RS = false, bool HEAD = false>
 static int launch_persist_t(const GemmArgs& a, hipStream_t stream) {
     const int BMs = MI * 32;
     const int tiles = (a.M / a.S) * ((a.S + BMs - 1) / BMs) * ((a.N + PR_BN - 1) / PR_BN);
     int grid = persist_cus();
     if (grid > ((tiles + 7) & ~7)) grid = (tiles + 7) & ~7;
-    hipLaunchKernelGGL((gemm_persist_kernel<MI, DEFER, RS>), dim3(grid), dim3(512), 0, stream, a, tiles);
+    hipLaunchKernelGGL((gemm_persist_kernel<MI, DEFER, RS, HEAD>), dim3(grid), dim3(512), 0, stream, a, tiles);
     return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
 }
 
@@ -539,6 +572,7 @@ int launch_gemm_persist(const GemmArgs& a_in, int mi, hipStream_t stream) {
     GemmArgs a = a_in;
     if (a.taps == 1) a.S = a.M;
     const bool defer = a.stats_out || a.epi_res;
+    if (defer && a.head_out) return launch_persist_t<6, true, false, true>(a, stream);
     if (defer) return launch_persist_t<6, true>(a, stream);
     if (a.rs_stats) return mi == 8 ? launch_persist_t<8, false, true>(a, stream) : launch_persist_t<6, false, true>(a, stream);
     if (mi == 8) return launch_persist_t<8, false>(a, stream);

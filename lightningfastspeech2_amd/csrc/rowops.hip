@@ -144,6 +144,36 @@ int launch_rowstats_finish(const float* parts, int nparts, int ncols, float eps,
     return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
 }
 
+// The Linear(N, 1) head behind a deferred LayerNorm, from what the GEMM epilogue left (GemmArgs::head_out): per row the statistic
+// parts and the parts of sum_n v[n] * gw[n], gw = gamma * w.  pred = mask ? 0 : rstd * (dot - mean * sum_gw) + (beta . w + b)
+// = LayerNorm(v) . w + b  (VariancePredictor's LayerNorm -> Linear -> masked_fill, model.py:512-518,538).  One thread per row.
+__global__ __launch_bounds__(256) void head_finish_kernel(const float2* __restrict__ parts, const float* __restrict__ dots, int nparts, float invn, float eps,
+                                                          float sum_gw, float cst, const uint8_t* __restrict__ mask, float* __restrict__ pred, int M) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    float2 pq[4];
+    float dq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        pq[q] = q < nparts ? parts[(size_t)m * nparts + q] : make_float2(0.f, 0.f);
+        dq[q] = q < nparts ? dots[(size_t)m * nparts + q] : 0.f;
+    }
+    const float s1 = (pq[0].x + pq[1].x) + (pq[2].x + pq[3].x), s2 = (pq[0].y + pq[1].y) + (pq[2].y + pq[3].y);
+    const float dot = (dq[0] + dq[1]) + (dq[2] + dq[3]);
+    const float mean = s1 * invn;
+    const float rstd = 1.0f / sqrtf(fmaxf(__builtin_fmaf(-mean, mean, s2 * invn), 0.f) + eps);
+    const float v = __builtin_fmaf(rstd, __builtin_fmaf(-mean, sum_gw, dot), cst);
+    pred[m] = (mask && mask[m]) ? 0.f : v;
+}
+int launch_head_finish(const float* parts, const float* dots, int nparts, int ncols, float eps, float sum_gw, float cst, const uint8_t* mask, float* pred,
+                       int M, hipStream_t stream) {
+    if (M <= 0) return FS2_OK;
+    if (!parts || !dots || !pred || nparts < 1 || nparts > 4 || ncols <= 0) return FS2_ERR_ARG;
+    hipLaunchKernelGGL(head_finish_kernel, dim3((M + 255) / 256), dim3(256), 0, stream, (const float2*)parts, dots, nparts, 1.0f / (float)ncols, eps, sum_gw, cst,
+                       mask, pred, M);
+    return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
+}
+
 // =============================================================================================
 // Depth-wise Conv1d over time, zero "same" padding per utterance, unmasked — conv1.0 of the
 // LightSpeech FFN (model.py:75-81) and module.0 of the depth-wise predictor layer

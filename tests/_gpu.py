@@ -82,6 +82,27 @@ def gemm_rowscale(x, w_folded, bias_folded, parts, wg, eps=1e-5):
     return c.float().cpu()
 
 
+def gemm_head(x, w, bias, gamma, beta, w_head, b_head, mask=None, relu=True, eps=1e-5):
+    """fs2_op_gemm_head + fs2_op_head_finish (bf16): pred = masked(LayerNorm(act(x w^T + bias)) . w_head + b_head) from the epilogue's
+    row sums; also returns the statistic parts (M, nparts, 2) and the head sums (M, nparts)"""
+    M, Cin = x.shape
+    N = w.shape[0]
+    nparts = (N + 255) // 256
+    xd, wd = to_dev(x, BF16), to_dev(w, BF16)
+    bd = torch.as_tensor(bias).float().to(DEV).contiguous()
+    gw = (torch.as_tensor(gamma).float() * torch.as_tensor(w_head).float())
+    gd = gw.to(DEV).contiguous()
+    st = torch.full((M, nparts, 2), float("nan"), dtype=torch.float32, device=DEV)
+    hd = torch.full((M, nparts), float("nan"), dtype=torch.float32, device=DEV)
+    ok(lib().fs2_op_gemm_head(p(xd), p(wd), p(bd), p(gd), p(st), p(hd), M, N, Cin, int(relu), stream()), "gemm_head")
+    md = None if mask is None else torch.as_tensor(mask).to(torch.uint8).to(DEV).contiguous()
+    pred = torch.empty(M, dtype=torch.float32, device=DEV)
+    cst = float((torch.as_tensor(beta).double() * torch.as_tensor(w_head).double()).sum() + b_head)
+    ok(lib().fs2_op_head_finish(p(st), p(hd), nparts, N, float(eps), float(gw.double().sum()), cst, p(md), p(pred), M, stream()), "head_finish")
+    torch.cuda.synchronize()
+    return pred.cpu(), st.cpu(), hd.cpu()
+
+
 def gemm_splitk(dtype, x, w_packed, ksplit, taps=1, S=None, out_dtype=None, into=None):
     """fs2_op_gemm_splitk: K slices as workgroups of one launch into fp32 planes + the plane sum; into = a tensor the result is
     ADDED to (the accumulating data-gradient call of the training step)."""

@@ -110,6 +110,34 @@ def test_persistent_gemm_whole_model_is_bit_identical():
             assert torch.equal(b[k], c[k]), k
 
 
+def test_predictor_head_from_the_epilogue_sums_against_the_normalise_pass():
+    """Wide depth-wise predictors (C3 / C4): the last layer's LayerNorm + Linear head is computed from row sums the last GEMM's epilogue
+    leaves (GemmArgs::head_out; persistent kernel) instead of a normalise pass over stored activations (knob 230: the pass).  Same predictions to fp32 rounding of a different summation order - the pass
+    reads bf16-rounded activations, the epilogue the fp32 ones, so the epilogue form is the closer one to the oracle."""
+    from lightningfastspeech2_amd.config import Fs2Config
+    cfg = Fs2Config(**{**preset("c3").to_dict(), "encoder_layers": 2, "decoder_layers": 2, "variance_nlayers": [2, 2, 2]})
+    sd = synth_state_dict(cfg, 7, randomize_norm=True, duration_bias=1.4)
+    inp = synth_inputs(cfg, 3, 40, seed=62, lengths=[40, 22, 9])
+    ref = oracle_cpu.forward(sd, cfg, inp["phones"], inp["speaker"], return_intermediates=True)
+    batch = {"phones": torch.from_numpy(inp["phones"]), "speaker": torch.from_numpy(inp["speaker"])}
+    forced = dict(force_durations=ref["duration_rounded"], force_buckets={v: ref["_intermediates"][f"bucket_{v}"] for v in cfg.variances})
+    m = _model(cfg, sd, "bf16")
+    a = _cpu(m.forward(batch, **forced))
+    m.engine.set_tuning(230)
+    b = _cpu(m.forward(batch, **forced))
+    m.engine.set_tuning(231)
+    rep = {}
+    for v in cfg.variances:
+        k = f"variances_{v}"
+        ra = torch.as_tensor(ref[k]).float()
+        ea, eb = (a[k] - ra).abs(), (b[k] - ra).abs()
+        rep[v] = [float((a[k] - b[k]).abs().max()), float(ea.max()), float(eb.max()), float(ea.mean()), float(eb.mean())]
+        assert float((a[k] - b[k]).abs().max()) <= 0.05 * (float(ra.abs().max()) + 1), v   # two bf16 evaluations of the same predictor
+        assert float(ea.mean()) <= 1.25 * float(eb.mean()) + 1e-4, v                        # no further from the oracle than the pass
+    _report(test="head_sums", per_variance_sums_vs_pass_max__err_sums_max__err_pass_max__err_sums_mean__err_pass_mean=rep)
+    assert torch.equal(a["tgt_mask"], b["tgt_mask"])
+
+
 def test_folded_layernorm_against_its_own_passes():
     """Inside a stack of wide depth-wise bf16 blocks a block's closing LayerNorm is folded into the next block's in-projection
     (fs2_set_folded_layernorm, default) instead of a normalise-only pass per block: the two differ by bf16 roundings only (the

@@ -110,7 +110,8 @@ def test_persistent_gemm_is_bit_identical_to_the_slab_kernel(M, N, K, relu, add)
     assert float((got - ref).abs().max()) <= tol(G.BF16, ref)
 
 
-@pytest.mark.parametrize("M,N,K", [(49152, 2304, 768), (8192, 2304, 768), (700, 2304, 768), (20000, 712, 384), (30000, 3072, 1024)])
+@pytest.mark.parametrize("M,N,K", [(49152, 2304, 768), (8192, 2304, 768), (700, 2304, 768), (20000, 712, 384), (30000, 3072, 1024),
+                                   (5000, 80, 768), (333, 100, 384)])
 def test_gemm_rowscale_is_layernorm_then_gemm(M, N, K):
     """fs2_op_gemm_rowscale: LayerNorm(v) W^T + b evaluated on the PRE-norm rows v with gamma / beta folded into the operands and
     per-row (rstd, rstd * mean) applied in the epilogue - what the engine's in-projection does behind a deferred norm2
@@ -656,6 +657,26 @@ def test_layernorm_residual_and_head(dtype, M, H):
     assert float((y2 - ref2).abs().max()) <= tol(dtype, ref2)
     _, pred2 = G.layernorm(dtype, x, r, g, b, dot_w=w, dot_b=0.25, mask=mask, want_y=False)
     assert torch.equal(pred, pred2)
+
+
+@pytest.mark.parametrize("M,N,Cin", [(1000, 768, 768), (77, 200, 128), (49152 // 8, 768, 768)])
+def test_gemm_head_sums_are_layernorm_then_linear_head(M, N, Cin):
+    """fs2_op_gemm_head + fs2_op_head_finish: the last VariancePredictor layer's ReLU -> LayerNorm -> Linear(N, 1) -> masked_fill from
+    the GEMM epilogue's row sums, against torch on the fp32 product of the same bf16 operands; partial column tiles and row tiles."""
+    x, w = rnd(M, Cin, seed=71), rnd(N, Cin, seed=72, scale=Cin ** -0.5)
+    b = rnd(N, seed=73)
+    g, be = 1 + 0.2 * rnd(N, seed=74), 0.1 * rnd(N, seed=75)
+    wh = rnd(N, seed=76, scale=N ** -0.5)
+    mask = torch.zeros(M, dtype=torch.bool)
+    mask[::5] = True
+    pred, st, hd = G.gemm_head(x, w, b, g, be, wh, 0.3, mask=mask)
+    v = torch.relu(G.rounded(x, G.BF16) @ G.rounded(w, G.BF16).T + b)
+    ref = (F.layer_norm(v, (N,), g, be, 1e-5) @ wh + 0.3).masked_fill(mask, 0)
+    assert torch.isfinite(st).all() and torch.isfinite(hd).all()
+    assert float((st[:, :, 0].sum(1) - v.sum(1)).abs().max()) <= 2e-3 * (float(v.sum(1).abs().max()) + 1)
+    assert float((hd.sum(1) - v @ (g * wh)).abs().max()) <= 1e-4 * (float((v @ (g * wh)).abs().max()) + 1)
+    assert float((pred - ref).abs().max()) <= 2e-4 * (float(ref.abs().max()) + 1)
+    assert bool((pred[mask] == 0).all())
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
