@@ -268,6 +268,46 @@ def training_block(cfg, sd, args, inp, T):
             "loss_total": float(losses["total"]), "extra_mem_GB": (torch.cuda.max_memory_allocated() - del_model_mem) / 2**30}
 
 
+CU_INGEST_GBS = 64.0   # per-CU L2 -> LDS ceiling measured on this part (tools/probes/cu_ingest.hip: 61-69 GB/s)
+N_CUS = 256
+
+
+def encoder_mha_ingest_bound(cfg, B, L, block_s):
+    """Roofline of the encoder self-attention block (in-projection, attention, out-projection + residual + LayerNorm) against the
+    per-CU ingest ceiling: the bytes ONE CU has to pull through L2 into LDS / registers for its share of each launch, at the tile
+    shapes the launchers pick for M = B L rows (gemm_mfma.hip launch_gemm_plain's cost model: 128-row x 256-column tiles for the
+    in-projection, 32-row tiles with the whole row for the LayerNorm epilogue; attention.hip: 64 queries of one head per workgroup
+    with all of that head's K and V).  bound_us = sum over the launches of rounds x bytes per workgroup / 64 GB/s."""
+    H, heads, M, e = cfg.hidden, cfg.encoder_head, B * L, 2
+    if H != 256:  # the tile shapes below are the H = 256 launchers' (C2); wider rows take the deferred-LayerNorm forms
+        return None
+    d = H // heads
+    launches = []
+    # in-projection: M x 3H, K = H: tiles of 128 rows x 256 columns, each pulls its weight tile (256 x H) and its rows (128 x H)
+    t_in = -(-M // 128) * -(-3 * H // 256)
+    launches.append(("in_proj", t_in, (256 * H + 128 * H) * e))
+    # attention: 64 queries x one head per workgroup: Q (64 x d) + K, V of the head (2 x L x d)
+    t_at = B * heads * -(-L // 64)
+    launches.append(("attention", t_at, (64 * d + 2 * L * d) * e))
+    # out-projection + residual + LayerNorm: 32-row tiles over whole rows: the H x H weights, 32 rows of input, 32 rows of residual
+    t_out = -(-M // 32)
+    launches.append(("out_proj+LN", t_out, (H * H + 2 * 32 * H) * e))
+    per = []
+    bound = 0.0
+    for name, wgs, by in launches:
+        rounds = -(-wgs // N_CUS)
+        us = rounds * by / (CU_INGEST_GBS * 1e3)
+        bound += us
+        per.append({"launch": name, "workgroups": wgs, "bytes_per_workgroup": by, "rounds_over_256_cus": rounds, "bound_us": round(us, 2)})
+    return {"bound": "cu-ingest (L2 -> LDS)", "peak": CU_INGEST_GBS, "unit": "GB/s per CU", "bound_us": round(bound, 2),
+            "measured_us": round(block_s * 1e6, 2), "frac": bound / (block_s * 1e6) if block_s > 0 else 0.0, "launches": per,
+            "reading": "the three launches stream for bound_us of the measured time; the rest is what a 10-us launch is made of besides its "
+                       "stream - dispatch and ramp over 256 CUs, the first operand round trip, the LayerNorm epilogue's row exchange, the store "
+                       "drain - per launch ~2.5 us of stream against ~8 us of fixed cost (DESIGN 4, 'the encoder launches').  Fusing the block "
+                       "per utterance was sized and not built: 32 utterances x 4 query blocks = 128 workgroups, each re-projecting its head's K "
+                       "and V for all 256 keys (101 MFLOP per workgroup) = ~25 us on half the CUs against the ~33 us of the three launches"}
+
+
 def main():
     args = parse()
     # The forward issues ~150 launches around one host sync: on a loaded pool host (load average 30-55 seen) the launching thread
@@ -616,9 +656,12 @@ def main():
                 "achieved": (prof_mha["flops"] / n_) / s_ / 1e12 if s_ > 0 else 0.0, "peak": peak / 1e12, "unit": "TFLOP/s",
                 "frac": (prof_mha["flops"] / n_) / s_ / peak if s_ > 0 else 0.0, "avg_block_us": s_ * 1e6, "blocks_timed": prof_mha["launches"],
                 "flops_per_block": prof_mha["flops"] / n_,
+                "ingest_roofline": encoder_mha_ingest_bound(cfg, args.batch, args.phones, s_),
                 "what": "BASELINE.json north_star names the encoder attention; SURVEY 8d: only the fused block (8 B L H^2 + 4 B L^2 H, AI ~ 724) can "
-                        "be MFMA-bound.  NOT fused here (DESIGN 0 item 1: the block's three launches are bound by what a CU ingests for 32 / 64 "
-                        "rows); HIP events around the block, one forward at a time"})(max(prof_mha["launches"], 1), prof_mha["ms"] / max(prof_mha["launches"], 1) * 1e-3),
+                        "be MFMA-bound.  NOT fused here (DESIGN 0 item 1): at B x L = 8192 rows the block's three launches are neither MFMA- nor "
+                        "HBM-bound - `ingest_roofline` prices them against what bounds a launch of this size, the bytes each CU pulls through "
+                        "L2 -> LDS at the measured per-CU ceiling; `frac` against the MFMA peak is kept for the record; HIP events around the "
+                        "block, one forward at a time"})(max(prof_mha["launches"], 1), prof_mha["ms"] / max(prof_mha["launches"], 1) * 1e-3),
             "gpu_ms_per_step": gpu_ms,
             "gpu_ms_per_step_is": f"sum of HIP-event intervals around every kernel launch of a forward, {psteps} eager steps behind the timed region",
             "in_flight": n_pick,
