@@ -227,7 +227,9 @@ int fs2_profile_read(fs2_engine* e, int32_t kernel_class, double* total_ms, int6
  *   0       auto (by problem size)
  *   1       128x128 register-staged GEMM      2       128x256 LDS-DMA ring GEMM
  *   3/4/5   slab kernel, 128/192/256-row tiles   6/7   slab kernel, 32/64-row tiles
- *   200/201 slab kernel tile order: plain / XCD-contiguous (default)
+ *   200/201/202 slab kernel tile order: plain / XCD-contiguous (default) / XCD-contiguous with column-tile PAIRS per XCD where the launch
+ *           has 4, 8 or 16 column tiles and a weight panel larger than an XCD's L2 (the decoder FFN conv1: 109 MB fetched instead of 139,
+ *           1 % slower - measured r05); same results
  *   220/221 bf16 pointwise launches of more tiles than CUs: one tile per workgroup / the persistent kernel (default); bit-identical
  *   230/231 wide depth-wise predictors: the last LayerNorm + Linear(filter, 1) head as a normalise pass over stored activations / from
  *           row sums the last GEMM's epilogue leaves (fs2_op_gemm_head, default); equal to fp32 rounding of another summation order

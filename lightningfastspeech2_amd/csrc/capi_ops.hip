@@ -51,7 +51,7 @@ int apply_knob(Tuning& t, int variant) {
     else if (variant == 500 || variant == 501) t.split_f32 = variant - 500;            // operator level: fp32 slab launches as fp32 MFMA (default) / bf16 x 3 split
     else if (variant == 230 || variant == 231) t.head_sums = variant - 230;           // predictor head from a normalise pass / from the last GEMM's epilogue sums (default)
     else if (variant == 220 || variant == 221) t.gemm_persist = variant - 220;         // multi-round bf16 pointwise launches one tile per workgroup / on the persistent kernel (default)
-    else if (variant == 200 || variant == 201) t.slab_xcd_remap = variant - 200;       // slab kernel tile order plain / XCD-contiguous (default)
+    else if (variant >= 200 && variant <= 202) t.slab_xcd_remap = variant - 200;       // slab kernel tile order plain / XCD-contiguous (default) / + column pairs per XCD for wide weight panels
     else if (variant >= 0 && variant <= 7) t.gemm_variant = variant;                    // kernel family / forced tile height of the forward GEMM launcher (gemm_mfma.hip: launch_gemm)
     else ok = 0;
     if (!ok) return FS2_ERR_ARG;

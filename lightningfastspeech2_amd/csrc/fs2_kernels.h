@@ -17,7 +17,7 @@ struct Tuning {
     int gemm_wres = 1;         // bf16 K = 256 plain GEMMs on the weight-resident kernel: 0 never, 1 where it pays, 2 wherever it applies
     int head_sums = 1;         // wide predictors: last LayerNorm + Linear head from the last GEMM's epilogue sums (GemmArgs::head_out) / a normalise pass
     int gemm_persist = 1;      // bf16 pointwise launches of more tiles than CUs on the persistent kernel (gemm_persist.hip)
-    int slab_xcd_remap = 1;    // XCD-contiguous tile order in the slab kernel
+    int slab_xcd_remap = 1;    // slab kernel tile order: 0 plain, 1 XCD-contiguous (default), 2 = 1 + column pairs per XCD where the weight panel exceeds an L2 (fewer bytes fetched, 1 % slower: r05)
     int split_f32 = 0;         // operator level only (tests): every fp32 slab launch in the bf16 x 3 split arithmetic
     int attn_pipe = 3;         // 0 attention_kernel only; 1 / 2 / 4 the pipelined kernel with 32 / 64 / 96 queries per wave; 3 by size
     int attn_x3 = 1;           // fp32-storage split modes: attention on bf16 x 3 split products (1) or fp32 MFMA (0)

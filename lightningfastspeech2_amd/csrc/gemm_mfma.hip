@@ -421,7 +421,16 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
     const int tiles_n = (p.N + S_BN - 1) / S_BN;
     const int tiles_m = (S + BMs - 1) / BMs;
     int bid = blockIdx.x;
-    if (p.xcd_remap) {
+    if (p.xcd_remap == 2) {
+        // Column PAIRS per XCD (the launcher checks the divisibilities): XCD x owns the column tiles {2 cg, 2 cg + 1}, cg = x % (tiles_n / 2),
+        // and every (8 / (tiles_n / 2))-th row tile.  r05 counters on the decoder conv1 (4 column tiles, W = 4.7 MB, 4 MB of L2 per XCD): with
+        // whole row tiles per XCD (mode 1) the slab is fetched once but every XCD streams the whole weight panel through its L2 once per
+        // ROUND (25 + 113 MB fetched); with one column tile per XCD (what the plain order happens to give at 4 column tiles) the
+        // weights stay (9 MB) and the slab is fetched four times (100 MB).  Pairs: 2.4 MB of weights per XCD stay resident, the slab
+        // is fetched twice.
+        const int ncg = tiles_n >> 1, xg = 8 / ncg, xcd = bid & 7, k = bid >> 3;
+        bid = ((k >> 1) * xg + xcd / ncg) * tiles_n + (xcd % ncg) * 2 + (k & 1);
+    } else if (p.xcd_remap) {
         // Workgroup i is dispatched to XCD i % 8.  Hand every XCD a CONTIGUOUS range of tiles, so that
         // the column tiles of one row tile (which read the same activation slab) run on the same XCD at
         // the same time and share it in that XCD's L2 instead of fetching it once per XCD.
@@ -1261,6 +1270,12 @@ static int launch_slab_t(const GemmArgs& a0, hipStream_t stream) {
     GemmArgs a = a0;
     a.xcd_remap = tuning_of(a0.tune).slab_xcd_remap;
     const int BMs = SlabCfg<MI>::BM;
+    if (a.xcd_remap == 2) {  // column pairs per XCD: 4 / 8 / 16 column tiles, a weight panel that does not fit an XCD's L2, whole rounds of row tiles
+        const int tn = (a.N + S_BN - 1) / S_BN, rows = (a.M / a.S) * ((a.S + BMs - 1) / BMs);
+        const bool ok = (tn == 4 || tn == 8 || tn == 16) && a.ksplit <= 1 && rows % (16 / tn) == 0 &&
+                        (size_t)a.N * a.K * sizeof(T) > (size_t)3 << 20;
+        if (!ok) a.xcd_remap = 1;
+    }
     if constexpr (SPLIT) {  // conv launches of the split arithmetic: the slab is split in place when it lands
         if (a.taps > 1) {
             const int tiles = (a.M / a.S) * ((a.S + BMs - 1) / BMs) * ((a.N + S_BN - 1) / S_BN) * (a.ksplit > 1 ? a.ksplit : 1);

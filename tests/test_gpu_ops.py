@@ -110,6 +110,25 @@ def test_persistent_gemm_is_bit_identical_to_the_slab_kernel(M, N, K, relu, add)
     assert float((got - ref).abs().max()) <= tol(G.BF16, ref)
 
 
+@pytest.mark.parametrize("B,S,Cin,N,taps", [(8, 768, 256, 1024, 9), (4, 512, 256, 2048, 3), (6, 1000, 1024, 1024, 1), (3, 700, 256, 1024, 9)])
+def test_slab_tile_orders_are_bit_identical(B, S, Cin, N, taps):
+    """Slab kernel tile orders (knobs 200 / 201 / 202: plain, XCD-contiguous, XCD-contiguous with column-tile pairs per XCD for weight
+    panels wider than an L2 - the decoder FFN conv1): which workgroup computes which tile changes, nothing inside a tile; every tile
+    computed exactly once (an order that skipped or doubled tiles would leave the poisoned output or differ).  The last case's row-tile
+    count does not divide over the XCD groups: the launcher falls back to 201."""
+    x, w = rnd(B * S, Cin, seed=35), rnd(N, taps * Cin, seed=36) / math.sqrt(taps * Cin)
+    b = rnd(N, seed=37)
+    outs = []
+    try:
+        for knob in (200, 201, 202):
+            G.lib().fs2_op_set_gemm_variant(knob)
+            outs.append(G.gemm(G.BF16, x, w, b, taps=taps, S=S, relu=True))
+    finally:
+        G.lib().fs2_op_set_gemm_variant(201)
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 @pytest.mark.parametrize("M,N,K", [(49152, 2304, 768), (8192, 2304, 768), (700, 2304, 768), (20000, 712, 384), (30000, 3072, 1024),
                                    (5000, 80, 768), (333, 100, 384)])
 def test_gemm_rowscale_is_layernorm_then_gemm(M, N, K):
