@@ -637,7 +637,7 @@ int launch_regulate(const RegulateArgs& a, int dtype, hipStream_t stream) {
 // of edges < v: the wave holds the edges in registers (BE_MAXB per lane, loaded once) and counts with
 // a ballot + popcount per register instead of walking a chain of dependent loads per row.
 constexpr int BE_ROWS = 8, BE_MAXB = 8;  // up to 512 edges on the fast path
-template <typename T>
+template <typename T, int NV>
 __global__ __launch_bounds__(256) void bucket_embed_kernel(BucketArgs p) {
     const int lane = threadIdx.x & 63;
     const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * BE_ROWS;
@@ -685,6 +685,34 @@ __global__ __launch_bounds__(256) void bucket_embed_kernel(BucketArgs p) {
         T* y = (T*)p.y + (size_t)row * p.H;
         const float* pe = p.pe ? p.pe + (size_t)t * p.H : nullptr;
         const float* sp = p.spk ? p.spk + (size_t)b * p.H : nullptr;
+        if constexpr (NV > 0) {
+            // H <= 1024: the row's NV 256-column chunks unrolled, every load of the row requested before the first add (r05: the
+            // rolled loop was three dependent load -> add -> store trips per row)
+            float v[NV][4], ae[NV][4], ap[NV][4], as[NV][4];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = (i * 64 + lane) * 4;
+                if (c < p.H) {
+                    load4<T>(x + c, v[i]);
+                    if (e) load4<float>(e + c, ae[i]);
+                    if (pe) load4<float>(pe + c, ap[i]);
+                    if (sp) load4<float>(sp + c, as[i]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = (i * 64 + lane) * 4;
+                if (c < p.H) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (e) v[i][k] = __fadd_rn(v[i][k], ae[i][k]);
+                        if (pe) v[i][k] = __fadd_rn(v[i][k], ap[i][k]);
+                        if (sp) v[i][k] = __fadd_rn(v[i][k], as[i][k]);
+                    }
+                    store4<T>(y + c, v[i]);
+                }
+            }
+        } else
         for (int c = lane * 4; c < p.H; c += 256) {
             float v[4], a[4];
             load4<T>(x + c, v);
@@ -712,8 +740,15 @@ int launch_bucket_embed(const BucketArgs& a, int dtype, hipStream_t stream) {
     if (a.B * a.T <= 0) return FS2_OK;
     if (a.H % 4) return FS2_ERR_SHAPE;
     const dim3 grid((a.B * a.T + 4 * BE_ROWS - 1) / (4 * BE_ROWS)), block(256);
-    if (dtype == FS2_BF16) hipLaunchKernelGGL(bucket_embed_kernel<bf16>, grid, block, 0, stream, a);
-    else hipLaunchKernelGGL(bucket_embed_kernel<float>, grid, block, 0, stream, a);
+    switch (a.H <= 1024 ? (a.H + 255) / 256 : 0) {
+#define FS2_BE(NVV)                                                                                             \
+    case NVV:                                                                                                   \
+        if (dtype == FS2_BF16) hipLaunchKernelGGL((bucket_embed_kernel<bf16, NVV>), grid, block, 0, stream, a); \
+        else hipLaunchKernelGGL((bucket_embed_kernel<float, NVV>), grid, block, 0, stream, a);                  \
+        break;
+        FS2_BE(0) FS2_BE(1) FS2_BE(2) FS2_BE(3) FS2_BE(4)
+#undef FS2_BE
+    }
     return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
 }
 
