@@ -231,9 +231,10 @@ int fs2_profile_read(fs2_engine* e, int32_t kernel_class, double* total_ms, int6
  *           has 4, 8 or 16 column tiles and a weight panel larger than an XCD's L2 (the decoder FFN conv1: 109 MB fetched instead of 139,
  *           1 % slower - measured r05); same results
  *   220/221 bf16 pointwise launches of more tiles than CUs: one tile per workgroup / the persistent kernel (default); bit-identical
- *   250/251/252 bf16 plain-epilogue launches at 256-row tiles: the 8-wave slab kernel (default) / the 4-wave one-wave-per-SIMD kernel
- *           (gemm_quad.hip) / the same with a 4-stage operand ring of 32-wide K steps (gemm_ring.hip); both bit-identical and measured
- *           8-25 % slower in r05 (a lone wave pays ~100 issue cycles per operand request) - kept as the checked A/B forms
+ *   250/251/252/253 bf16 plain-epilogue launches at 192- / 256-row tiles: the 8-wave slab kernel (default) / the 4-wave one-wave-per-SIMD
+ *           kernel (gemm_quad.hip) / the same with a 4-stage operand ring of 32-wide K steps (gemm_ring.hip) / pointwise launches on
+ *           four MFMA-only + four request-only waves (gemm_pc.hip); all bit-identical, all measured 5-25 % slower in r05 (DESIGN 4
+ *           "Round 5") - kept as the checked A/B forms
  *   230/231 wide depth-wise predictors: the last LayerNorm + Linear(filter, 1) head as a normalise pass over stored activations / from
  *           row sums the last GEMM's epilogue leaves (fs2_op_gemm_head, default); equal to fp32 rounding of another summation order
  *   500/501 fp32 slab-kernel launches: fp32 MFMA (default) / bf16 x 3 split products (what FS2_MIXED_X3 uses in its front; operator level)

@@ -113,6 +113,9 @@ int launch_gemm_quad(const GemmArgs& a, hipStream_t stream);
 // gemm_ring.hip: the one-wave-per-SIMD form with a 4-stage operand ring of 32-wide K steps (bit-identical to the slab kernel)
 bool gemm_ring_supported(const GemmArgs& a, int in_dtype, int out_dtype);
 int launch_gemm_ring(const GemmArgs& a, hipStream_t stream);
+// gemm_pc.hip: producer / consumer waves (pointwise launches; 192 x 256 tiles; bit-identical to the slab kernel)
+bool gemm_pc_supported(const GemmArgs& a, int in_dtype, int out_dtype);
+int launch_gemm_pc(const GemmArgs& a, hipStream_t stream);
 bool gemm_head_supported(const GemmArgs& a, int in_dtype, int out_dtype);  // can this launch take GemmArgs::head_out (persistent kernel, switch on)
 bool gemm_persist_pays(const GemmArgs& a, int mi);
 int launch_gemm_persist(const GemmArgs& a, int mi, hipStream_t stream);

@@ -161,6 +161,27 @@ def test_ring_gemm_is_bit_identical_to_the_slab_kernel(B, S, Cin, N, taps, relu)
     assert torch.equal(got, old)
 
 
+@pytest.mark.parametrize("M,N,K,relu", [(49152, 3072, 768, True), (24576, 712, 768, False), (5000, 256, 128, False), (70001, 768, 3072, True)])
+def test_pc_gemm_is_bit_identical_to_the_slab_kernel(M, N, K, relu):
+    """gemm_pc.hip (knob 253): pointwise launches on 192 x 256 tiles with four MFMA-only waves and four request-only waves (5-stage
+    operand ring, one barrier per 32-wide K step), against the slab kernel with the persistent form off (220): the same 32-k chunks
+    in the same order per output element, so the same bits; a ragged last row tile, a column tail, the shortest K, twice."""
+    x, w = rnd(M, K, seed=38), rnd(N, K, seed=39) / math.sqrt(K)
+    b = rnd(N, seed=40)
+    try:
+        G.lib().fs2_op_set_gemm_variant(220)
+        G.lib().fs2_op_set_gemm_variant(250)
+        old = G.gemm(G.BF16, x, w, b, relu=relu)
+        G.lib().fs2_op_set_gemm_variant(253)
+        got = G.gemm(G.BF16, x, w, b, relu=relu)
+        again = G.gemm(G.BF16, x, w, b, relu=relu)
+    finally:
+        G.lib().fs2_op_set_gemm_variant(250)
+        G.lib().fs2_op_set_gemm_variant(221)
+    assert torch.equal(got, again)
+    assert torch.equal(got, old)
+
+
 @pytest.mark.parametrize("B,S,Cin,N,taps", [(8, 768, 256, 1024, 9), (4, 512, 256, 2048, 3), (6, 1000, 1024, 1024, 1), (3, 700, 256, 1024, 9)])
 def test_slab_tile_orders_are_bit_identical(B, S, Cin, N, taps):
     """Slab kernel tile orders (knobs 200 / 201 / 202: plain, XCD-contiguous, XCD-contiguous with column-tile pairs per XCD for weight
