@@ -1141,30 +1141,14 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
         // column tile's sum(v), sum(v^2) per row -> stats_out[row][column tile]; the consumers (depth-wise conv,
         // normalise-only LayerNorm, the next epilogue's residual) finish mean / rstd from the tiles' parts.
         // The residual may itself be such a pre-norm tensor: then it is normalised on load from ITS parts.
-        const T* R = (p.epi_res && !res_in_acc) ? (const T*)p.epi_res + (size_t)ub * S * p.ldc : nullptr;  // else: already in acc
         const size_t rowbase = (size_t)ub * S;
         const float lo = p.relu ? 0.f : -__builtin_inff();
-        const bool rnorm = R && p.epi_res_stats;
         float a1[MI], a2[MI];
         auto body = [&](auto full_c) {
             constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const int t = t0 + wm * (MI * 16) + mi * 16 + fr;
-            const int tc = t < S ? t : S - 1;
-            float rmean = 0.f, rrstd = 1.f;
-#if 0
-            if (rnorm) {
-                const float2* ps = (const float2*)p.epi_res_stats + (rowbase + tc) * p.epi_res_parts;
-                float2 pq[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) pq[q] = q < p.epi_res_parts ? ps[q] : make_float2(0.f, 0.f);
-                const float s1 = (pq[0].x + pq[1].x) + (pq[2].x + pq[3].x), s2 = (pq[0].y + pq[1].y) + (pq[2].y + pq[3].y);
-                const float invn = 1.0f / (float)p.N;
-                rmean = s1 * invn;
-                rrstd = 1.0f / sqrtf(fmaxf(__builtin_fmaf(-rmean, rmean, s2 * invn), 0.f) + p.ln_eps);
-            }
-#endif
             a1[mi] = a2[mi] = 0.f;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -1172,29 +1156,8 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
                 float v[8];
 #pragma unroll
                 for (int r = 0; r < 8; ++r) v[r] = fmaxf(acc[2 * j + (r >> 2)][mi][r & 3] + bv[j][r], lo);
-#if 0  // (a residual behind a ReLU never reaches this epilogue: the launcher refuses it - the path cost 35 registers at 192-row tiles and
-       //  spilled 500 at 256 rows, dead code in every launch of the forward)
-                if (R && (FULL || n < p.N)) {
-                    const T* src = R + (size_t)tc * p.ldc + n;
-                    float x[8];
-                    if (FULL || n + 7 < p.N) {
-                        if constexpr (sizeof(T) == 4) {
-                            const float4 q0 = *(const float4*)src, q1 = *(const float4*)(src + 4);
-                            x[0] = q0.x; x[1] = q0.y; x[2] = q0.z; x[3] = q0.w; x[4] = q1.x; x[5] = q1.y; x[6] = q1.z; x[7] = q1.w;
-                        } else {
-                            Vec16<T>::unpack(*(const uint4*)src, x);
-                        }
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 8; ++r) x[r] = n + r < p.N ? Num<T>::to_f32(src[r]) : 0.f;
-                    }
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        if (rnorm) x[r] = (FULL || n + r < p.N) ? __builtin_fmaf((x[r] - rmean) * rrstd, p.epi_res_g[n + r], p.epi_res_b[n + r]) : 0.f;
-                        v[r] += x[r];
-                    }
-                }
-#endif
+                // (a residual reaches this epilogue inside the accumulators only: res_in_acc; one behind a ReLU the launcher refuses -
+                //  the in-epilogue path cost 35 registers at 192-row tiles and was dead code in every launch of the forward)
 #pragma unroll
                 for (int r = 0; r < 8; ++r) {
                     if (!FULL && n + r >= p.N) v[r] = 0.f;

@@ -29,9 +29,10 @@ namespace fs2 {
 namespace {
 
 constexpr int PR_ROWB = 128, PR_BN = 256, PR_KE = 64;
-__device__ inline int pr_swz(int row, int slot) { return row * PR_ROWB + ((slot ^ (row & 7)) << 4); }  // = gemm_mfma.hip's swz
-__device__ inline int pr_wcol(int ni, int fgq) { return (ni >> 1) * 32 + fgq * 8 + (ni & 1) * 4; }    // = wcol
-__device__ inline int pr_wswz(int row) { return ((row >> 1) & 1) | (((row >> 3) & 3) << 1); }         // = wswz
+static_assert(PR_KE == 64, "K step");
+__device__ __attribute__((unused)) inline int pr_swz(int row, int slot) { return row * PR_ROWB + ((slot ^ (row & 7)) << 4); }  // = gemm_mfma.hip's swz
+__device__ __attribute__((unused)) inline int pr_wcol(int ni, int fgq) { return (ni >> 1) * 32 + fgq * 8 + (ni & 1) * 4; }    // = wcol
+__device__ __attribute__((unused)) inline int pr_wswz(int row) { return ((row >> 1) & 1) | (((row >> 3) & 3) << 1); }         // = wswz
 
 template <bool B> struct BoolCP { static constexpr bool value = B; };
 template <int I> struct IntCP { static constexpr int value = I; };

@@ -25,9 +25,9 @@ namespace {
 
 constexpr int WR_K = 256, WR_ROWB = WR_K * 2, WR_MI = 3, WR_RT = 2 * WR_MI * 16;  // 96 rows per tile, 48 per wave row
 constexpr int WR_TILEB = WR_RT * WR_ROWB;                                        // 48 KiB
-constexpr int WR_NDMA = WR_TILEB / 1024 / 8;                                     // 1-KiB DMA instructions per wave per tile
+__attribute__((unused)) constexpr int WR_NDMA = WR_TILEB / 1024 / 8;                                     // 1-KiB DMA instructions per wave per tile
 
-__device__ inline int wr_wcol(int ni, int fgq) { return (ni >> 1) * 32 + fgq * 8 + (ni & 1) * 4; }  // = gemm_mfma.hip's wcol
+__device__ __attribute__((unused)) inline int wr_wcol(int ni, int fgq) { return (ni >> 1) * 32 + fgq * 8 + (ni & 1) * 4; }  // = gemm_mfma.hip's wcol
 
 #ifdef FS2_WRES_PROBE  // tools/probes/wres_stamps.py: s_memtime of waves 0 and 7 of workgroup 0 around the phases of its first tiles
 __device__ unsigned long long g_wres_stamps[2][64];
