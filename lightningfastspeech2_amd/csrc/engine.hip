@@ -109,6 +109,8 @@ struct PredictorW {
     // one-launch path (predictor_fused.hip): weights in MFMA fragment order, per-layer vectors stacked
     void* wpk = nullptr;
     float *bias_all = nullptr, *g_all = nullptr, *b_all = nullptr;
+    // ... in the split arithmetic (fp32x3 / mixed3 engines): wpk = the weights' bf16 heads, wpk_lo their tails (launch_predictor_fused_x3)
+    void* wpk_lo = nullptr;
 };
 struct VarianceW {
     PredictorW pred;
@@ -531,6 +533,44 @@ int make_predictor(fs2_engine* e, const std::string& p, int nl, int filt, bool d
         CHK(upload_f32(e, bias.data(), bias.size(), &P->bias_all));
         CHK(upload_f32(e, g.data(), g.size(), &P->g_all));
         CHK(upload_f32(e, b.data(), b.size(), &P->b_all));
+    } else if (!dw && nl && cin == filt && dt == FS2_F32 && e->front_split && predictor_fused_x3_supported(filt, taps, nl, 1)) {
+        // the same launch in the split arithmetic: the weights' bf16 heads and tails in the kernel's fragment order
+        // [layer][step = tap * 8 + kb][32-channel group][2][lane] x 8 values (pack_predictor_weights_kernel's map), packed here
+        const size_t per = predictor_packed_bytes_per_layer() / 2;  // bf16 values per layer
+        std::vector<unsigned short> hi(per * nl), lo(per * nl);
+        std::vector<float> bias, g, b;
+        for (int j = 0; j < nl; ++j) {
+            const std::string q = p + ".layers." + std::to_string(j) + ".layers";
+            const HostTensor& w = W(e, q + ".0.module.weight");  // (filt, filt, 3)
+            for (int step = 0; step < 24; ++step) {
+                const int tap = step / 8, kb = step % 8;
+                for (int grp = 0; grp < 8; ++grp)
+                    for (int ni = 0; ni < 2; ++ni)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int fr = lane & 15, fg = lane >> 4;
+                            const int ch = grp * 32 + (fr >> 2) * 8 + ni * 4 + (fr & 3);
+                            const size_t o = (size_t)j * per + ((((size_t)step * 8 + grp) * 2 + ni) * 64 + lane) * 8;
+                            for (int k8 = 0; k8 < 8; ++k8) {
+                                const int c = kb * 32 + fg * 8 + k8;
+                                const float v = w.data[((size_t)ch * filt + c) * 3 + tap];
+                                const bf16 h = f32_to_bf16(v);
+                                hi[o + k8] = h.v;
+                                lo[o + k8] = f32_to_bf16(v - bf16_to_f32(h)).v;
+                            }
+                        }
+            }
+            const auto &hb = W(e, q + ".0.module.bias").data, &hg = W(e, q + ".2.weight").data, &hbe = W(e, q + ".2.bias").data;
+            bias.insert(bias.end(), hb.begin(), hb.end());
+            g.insert(g.end(), hg.begin(), hg.end());
+            b.insert(b.end(), hbe.begin(), hbe.end());
+        }
+        CHK(dev_alloc(e, &P->wpk, hi.size() * 2));
+        CHK(dev_alloc(e, &P->wpk_lo, lo.size() * 2));
+        HIPCHK(e, hipMemcpy(P->wpk, hi.data(), hi.size() * 2, hipMemcpyHostToDevice));
+        HIPCHK(e, hipMemcpy(P->wpk_lo, lo.data(), lo.size() * 2, hipMemcpyHostToDevice));
+        CHK(upload_f32(e, bias.data(), bias.size(), &P->bias_all));
+        CHK(upload_f32(e, g.data(), g.size(), &P->g_all));
+        CHK(upload_f32(e, b.data(), b.size(), &P->b_all));
     }
     return FS2_OK;
 }
@@ -799,7 +839,26 @@ int predictor(fs2_engine* e, hipStream_t st, const PredictorW& P, const void* x,
     const int M = B * S;
     if (tail_done) *tail_done = false;
     if (P.cwt && !cw) return fail(e, FS2_ERR_STATE, "CWT predictor without its output buffers");
-    if (P.wpk && e->fuse_predictor && predictor_fused_supported(P.dt, P.filt, P.layers[0].c.taps, (int)P.layers.size(), S)) {
+    if (P.wpk && P.wpk_lo && e->fuse_predictor && P.dt == FS2_F32 && e->front_split &&
+        predictor_fused_x3_supported(P.filt, P.layers[0].c.taps, (int)P.layers.size(), S)) {
+        // the split arithmetic's single launch (fp32 rows in, and out of the embedding tail)
+        PredictorArgs a;
+        a.x = x; a.wpk = P.wpk; a.wpk_lo = P.wpk_lo; a.bias = P.bias_all; a.ln_g = P.g_all; a.ln_b = P.b_all;
+        a.head_w = P.head_w; a.head_b = P.head_b; a.mask = mask; a.pred = pred;
+        a.B = B; a.S = S; a.H = P.filt; a.nlayers = (int)P.layers.size(); a.taps = P.layers[0].c.taps; a.eps = 1e-5f;
+        const bool with_tail = tail && tail_done && !P.cwt && tail->y != x && tail->nbins >= 2 && tail->nbins - 1 <= 512;
+        if (with_tail) {
+            a.be_y = tail->y; a.be_bins = tail->bins; a.be_emb = tail->emb; a.be_nbins = tail->nbins;
+            a.be_std = tail->std; a.be_mean = tail->mean; a.be_pe = tail->pe; a.be_spk = tail->spk;
+        }
+        const double fl = 2.0 * M * (double)P.filt * P.filt * a.taps * a.nlayers;
+        Bracket br(e, FS2_K_CONV_GEMM, st, fl, (double)M * P.filt * 4 + (double)M * 4 + (with_tail ? 2.0 * M * P.filt * 4 : 0.0));
+        const int r = launch_predictor_fused_x3(a, st);
+        if (r != FS2_OK) return fail(e, r, "fused predictor (split arithmetic) launch failed (B=%d S=%d)", B, S);
+        if (with_tail) *tail_done = true;
+        return FS2_OK;
+    }
+    if (P.wpk && !P.wpk_lo && e->fuse_predictor && predictor_fused_supported(P.dt, P.filt, P.layers[0].c.taps, (int)P.layers.size(), S)) {
         PredictorArgs a;
         a.x = x; a.wpk = P.wpk; a.bias = P.bias_all; a.ln_g = P.g_all; a.ln_b = P.b_all;
         a.head_w = P.head_w; a.head_b = P.head_b; a.mask = mask; a.pred = pred;
@@ -1366,7 +1425,7 @@ static int decode_body(fs2_engine* e, const fs2_outputs* out, hipStream_t st) {
         // the encoder's bucketize + embedding add rides in the predictor launch where nothing else wants its by-products
         // (bucket indices for the debug taps, forced buckets / targets of the teacher-forced and oracle paths)
         const bool tail_ok = e->tune.pred_fuse_embed && !e->debug && !e->forced_idx[v] && !e->forced_tgt[v] && !c.var_cwt[v] &&
-                             e->fdt == FS2_BF16 && H == 256;
+                             (e->fdt == FS2_BF16 || (e->fdt == FS2_F32 && e->front_split && e->vars[v].pred.wpk_lo)) && H == 256;
         const EmbedTail tl{yB, e->vars[v].bins, e->vars[v].emb, c.var_nbins, c.var_std[v], c.var_mean[v],
                            (last && fuse_pe) ? e->pe : nullptr, (last && fuse_pe) ? e->spk : nullptr};
         bool tail_done = false;

@@ -166,6 +166,7 @@ int launch_attention_pipe(const AttnArgs& a, int variant, hipStream_t stream);
 struct PredictorArgs {
     const void* x;          // (B*S, H) bf16
     const void* wpk;        // nlayers * predictor_packed_bytes_per_layer()
+    const void* wpk_lo = nullptr;  // split-arithmetic form (launch_predictor_fused_x3): wpk = the weights' bf16 heads, wpk_lo their tails; x is fp32
     const float* bias;
     const float* ln_g;
     const float* ln_b;
@@ -190,6 +191,8 @@ bool predictor_fused_supported(int dtype, int H, int taps, int nlayers, int S);
 size_t predictor_packed_bytes_per_layer();
 int launch_pack_predictor_weights(const void* w_layer /*(H, taps*H) tap-major bf16*/, void* out_layer, hipStream_t stream);
 int launch_predictor_fused(const PredictorArgs& a, hipStream_t stream);
+bool predictor_fused_x3_supported(int H, int taps, int nlayers, int S);
+int launch_predictor_fused_x3(const PredictorArgs& a, hipStream_t stream);
 
 // One Conv1d of the HiFi-GAN generator (vocoder_conv.hip).  Activations are (B, S, channels)
 // time-major in the engine dtype; w is the layer's weights in MFMA fragment order

@@ -89,12 +89,20 @@ __global__ void pack_predictor_weights_kernel(const bf16* __restrict__ W, uint4*
 //   112-row tiles: 106 -> ~104 us (FS2_PF_FENCE=0 builds the unfenced form for A/B).  Then the weight ring at 3 stages instead of 4 (two
 //   k-steps ahead; 16 registers fewer: 34 -> 14 spilled; the layer's 24 k-steps unrolled so that the ring index stays static):
 //   ~103 -> ~98 us (-DFS2_PF_RING=4 builds the 4-stage form).
-template <int MI16, int NWV, int MINW>
+// X3 (r05; the fp32x3 / mixed3 engines' predictors): fp32 input, every product as bf16 x 3 split products - the slab holds the
+// activations as bf16 heads AND tails (two planes, same swizzle; x = hi + lo to 2^-17, split_bf16x3), the weights stream as two
+// fragment sets (heads, tails: PredictorArgs::wpk / wpk_lo), and a product is three MFMAs, small terms first (w_lo x_hi, w_hi x_lo,
+// w_hi x_hi) - the arithmetic of the per-layer split launches (gemm_mfma.hip SPLIT) with the K sum in this kernel's order.  The
+// LayerNorm epilogue splits its fp32 rows again for the next layer.  One 4-wave workgroup per CU (two planes = 117 KB), a lone wave
+// per SIMD with the 512-register file: both fragment sets, both weight rings.  The embedding tail reads and writes fp32 rows.
+template <int MI16, int NWV, int MINW, bool X3 = false>
 __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(PredictorArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins exist in the device pass only
     constexpr int R = MI16 * 16, HFA = (MI16 + 1) / 2;  // row fragments: first half HFA, second MI16 - HFA
     constexpr int NFR = PF_H / (NWV * 16), NP = NFR / 2;
-    __shared__ __attribute__((aligned(16))) unsigned char slab[(R + 2) * PF_ROWB];  // slab index i <-> t = t0 - 1 + i
+    constexpr int PLANE = (R + 2) * PF_ROWB;
+    constexpr int RING = X3 ? 4 : PF_RING;  // X3: the 4-stage ring with the taps in a rolled loop (the unrolled 3-stage form spilled 43 registers, 35 of them inside the K loops)
+    __shared__ __attribute__((aligned(16))) unsigned char slab[(X3 ? 2 : 1) * PLANE];  // slab index i <-> t = t0 - 1 + i; X3: heads, then tails
     __shared__ float red[2][NWV * R];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -105,6 +113,21 @@ __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(Predict
     const int ub = blockIdx.x / tiles, tm = blockIdx.x % tiles;
     const int t0 = tm * V - halo;  // time of tile row 0
 
+    if constexpr (X3) {
+        // fp32 rows -> heads + tails, through registers: physical slot ps of slab row i holds logical slot ls (8 channels)
+        const float* xu = (const float*)p.x + (size_t)ub * S * PF_H;
+        for (int sidx = tid; sidx < (R + 2) * 32; sidx += NWV * 64) {
+            const int i = sidx >> 5, ps = sidx & 31, t = t0 - 1 + i;
+            const int ls = (ps & 16) | ((((ps & 7) ^ (i & 7)) << 1) | ((ps >> 3) & 1));
+            uint4 hi = make_uint4(0u, 0u, 0u, 0u), lo = hi;
+            if (t >= 0 && t < S) {
+                const uint4 c0 = *(const uint4*)(xu + (size_t)t * PF_H + ls * 8), c1 = *(const uint4*)(xu + (size_t)t * PF_H + ls * 8 + 4);
+                split_bf16x3(c0, c1, hi, lo);
+            }
+            *(uint4*)(slab + i * PF_ROWB + (ps << 4)) = hi;
+            *(uint4*)(slab + PLANE + i * PF_ROWB + (ps << 4)) = lo;
+        }
+    } else
     // ---- slab fill: 2 rows (1 KiB) per DMA instruction, 16-byte XOR swizzle applied on the source side
     {
         const bf16* xu = (const bf16*)p.x + (size_t)ub * S * PF_H;
@@ -128,6 +151,7 @@ __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(Predict
     // ---- weight stream: step g = (layer*3 + tap)*8 + kb, 16 KiB per step, this wave's NFR fragments
     // (fragment order [step][32-channel group][2][lane]: a wave's fragments are contiguous for any NWV)
     const uint4* __restrict__ wbase = (const uint4*)p.wpk + wv * NFR * 64 + lane;
+    const uint4* __restrict__ wbase_lo = X3 ? (const uint4*)p.wpk_lo + wv * NFR * 64 + lane : nullptr;
     const int total = nl * PF_STEPS;
     auto loadB = [&](uint4 (&b)[NFR], int g) {
         g = g < total ? g : total - 1;  // past the end: a harmless re-read instead of a branch
@@ -137,10 +161,20 @@ __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(Predict
 #pragma unroll
         for (int ni = 0; ni < NFR; ++ni) b[ni] = wbase[(size_t)g * PF_STEP_U4 + ni * 64];
     };
-    uint4 bw[PF_RING][NFR];
+    auto loadBL = [&](uint4 (&b)[NFR], int g) {  // X3: the tails' stream
+        g = g < total ? g : total - 1;
+#pragma unroll
+        for (int ni = 0; ni < NFR; ++ni) b[ni] = wbase_lo[(size_t)g * PF_STEP_U4 + ni * 64];
+    };
+    uint4 bw[RING][NFR], bwl[X3 ? RING : 1][NFR];
     loadB(bw[0], 0);
     loadB(bw[1], 1);
-    if constexpr (PF_RING == 4) loadB(bw[2], 2);
+    if constexpr (RING == 4) loadB(bw[2], 2);
+    if constexpr (X3) {
+        loadBL(bwl[0], 0);
+        loadBL(bwl[1], 1);
+        if constexpr (RING == 4) loadBL(bwl[2], 2);
+    }
 
     dma_drain();
     __syncthreads();
@@ -168,6 +202,12 @@ __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(Predict
             else
                 Mma16<bf16>::step(bfrag, afrag, a);
         };
+        // X3: (w_lo x_hi) + (w_hi x_lo) + (w_hi x_hi), small terms first; the bias rides in the first of the three
+        auto mma3 = [&](auto FIRSTKB, const uint4& bh, const uint4& bl, const uint4& ah, const uint4& al, int ni, f32x4_t& a) {
+            mma(FIRSTKB, bl, ah, ni, a);
+            Mma16<bf16>::step(bh, al, a);
+            Mma16<bf16>::step(bh, ah, a);
+        };
         auto tap = [&](int tp, auto FIRST) {
             constexpr bool first = decltype(FIRST)::value;
             const int i0 = fr + tp;
@@ -180,10 +220,36 @@ __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(Predict
                 for (int mi = 0; mi < HFA; ++mi)
                     if (mi < cnt) fx[mi] = *(const uint4*)(arow_p + (m0 + mi) * 16 * PF_ROWB + (acx ^ ((((kb & 3) << 1) | ((kb >> 2) << 4)) << 4)));
             };
-            auto kblock = [&](auto KB0, int kb, uint4 (&fxa)[HFA], uint4 (&fxb)[HFA]) {
-                const int rs = (tp * PF_KB + kb) % PF_RING, rn = (tp * PF_KB + kb + PF_RING - 1) % PF_RING;  // static after unrolling
-                loadB(bw[rn], (l * PF_TAPS + tp) * PF_KB + kb + PF_RING - 1);
-                if constexpr (MINW == 1 || PF_PREFETCH) {
+            auto loadAL = [&](uint4 (&fx)[HFA], int kb, int hf) {  // X3: the tails' plane
+                const int m0 = hf * HFA, cnt = hf ? HFB : HFA;
+#pragma unroll
+                for (int mi = 0; mi < HFA; ++mi)
+                    if (mi < cnt) fx[mi] = *(const uint4*)(arow_p + PLANE + (m0 + mi) * 16 * PF_ROWB + (acx ^ ((((kb & 3) << 1) | ((kb >> 2) << 4)) << 4)));
+            };
+            auto kblock = [&](auto KB0, int kb, uint4 (&fxa)[HFA], uint4 (&fxb)[HFA], uint4 (&fla)[HFA], uint4 (&flb)[HFA]) {
+                const int rs = (tp * PF_KB + kb) % RING, rn = (tp * PF_KB + kb + RING - 1) % RING;  // static after unrolling
+                loadB(bw[rn], (l * PF_TAPS + tp) * PF_KB + kb + RING - 1);
+                if constexpr (X3) {
+                    // row block by row block: one (head, tail) fragment pair and its 3 NFR MFMAs (192 cycles), the next pair requested
+                    // one block ahead (a two-deep ring in fxa[0..1] / fla[0..1], indexed by the running block count - static after
+                    // unrolling): 16 fragment registers instead of the 64 of two half-tile sets of both planes
+                    loadBL(bwl[rn], (l * PF_TAPS + tp) * PF_KB + kb + RING - 1);
+#pragma unroll
+                    for (int mi = 0; mi < MI16; ++mi) {
+                        const int c = kb * MI16 + mi, cur = c & 1, nxt = cur ^ 1;
+                        const int nmi = mi + 1 < MI16 ? mi + 1 : 0, nkb = mi + 1 < MI16 ? kb : kb + 1;
+                        if (nkb < PF_KB) {
+                            const int off = nmi * 16 * PF_ROWB + (acx ^ ((((nkb & 3) << 1) | ((nkb >> 2) << 4)) << 4));
+                            fxa[nxt] = *(const uint4*)(arow_p + off);
+                            fla[nxt] = *(const uint4*)(arow_p + PLANE + off);
+                        }
+                        PF_FENCE();
+#pragma unroll
+                        for (int ni = 0; ni < NFR; ++ni) mma3(KB0, bw[rs][ni], bwl[rs][ni], fxa[cur], fla[cur], ni, acc[ni][mi]);
+                        PF_FENCE();
+                    }
+                    (void)fxb; (void)flb;
+                } else if constexpr (MINW == 1 || PF_PREFETCH) {
                     // the next half's activation fragments are requested before this half's MFMAs (two fragment sets alive): an LDS
                     // round trip behind every half otherwise (r03: 113 -> 107 us for the C2 variance predictor with two workgroups per CU)
                     loadA(fxb, kb, 1);
@@ -213,14 +279,26 @@ __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(Predict
                     }
                 }
             };
-            uint4 fxa[HFA], fxb[HFA];
-            if constexpr (MINW == 1 || PF_PREFETCH) loadA(fxa, 0, 0);
-            kblock(std::integral_constant<bool, first>{}, 0, fxa, fxb);
+            uint4 fxa[HFA], fxb[HFA], fla[X3 ? HFA : 1], flb[X3 ? HFA : 1];
+            if constexpr (X3) {  // the tap's first fragment pair (ring slot 0)
+                fxa[0] = *(const uint4*)(arow_p + acx);
+                fla[0] = *(const uint4*)(arow_p + PLANE + acx);
+            } else if constexpr (MINW == 1 || PF_PREFETCH) {
+                loadA(fxa, 0, 0);
+            }
+            if constexpr (X3) {
+                kblock(std::integral_constant<bool, first>{}, 0, fxa, fxb, fla, flb);
 #pragma unroll
-            for (int kb = 1; kb < PF_KB; ++kb) kblock(std::false_type{}, kb, fxa, fxb);
+                for (int kb = 1; kb < PF_KB; ++kb) kblock(std::false_type{}, kb, fxa, fxb, fla, flb);
+            } else {
+                uint4 (&d0)[HFA] = fxa, (&d1)[HFA] = fxb;  // (unused tails' sets)
+                kblock(std::integral_constant<bool, first>{}, 0, fxa, fxb, d0, d1);
+#pragma unroll
+                for (int kb = 1; kb < PF_KB; ++kb) kblock(std::false_type{}, kb, fxa, fxb, d0, d1);
+            }
         };
         tap(0, std::true_type{});
-        if constexpr (PF_RING == 4) {
+        if constexpr (RING == 4) {
 #pragma unroll 1
             for (int tp = 1; tp < PF_TAPS; ++tp) tap(tp, std::false_type{});
         } else {
@@ -340,7 +418,16 @@ __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(Predict
                     const uint4 o = inside ? make_uint4(pack_bf16x2(y[0].x, y[0].y), pack_bf16x2(y[1].x, y[1].y),
                                                         pack_bf16x2(y[2].x, y[2].y), pack_bf16x2(y[3].x, y[3].y))
                                            : make_uint4(0u, 0u, 0u, 0u);
-                    *(uint4*)(slab + i * PF_ROWB + (SlabSwizzle(PF_ROWB / 16).slot(n >> 3, i) << 4)) = o;
+                    const int so = i * PF_ROWB + (SlabSwizzle(PF_ROWB / 16).slot(n >> 3, i) << 4);
+                    *(uint4*)(slab + so) = o;
+                    if constexpr (X3) {  // the tails: RNE(y - head), the subtraction exact in fp32 (split_bf16x3)
+                        const unsigned hw4[4] = {o.x, o.y, o.z, o.w};
+                        unsigned lw[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            lw[r] = pack_bf16x2(y[r].x - __uint_as_float(hw4[r] << 16), y[r].y - __uint_as_float(hw4[r] & 0xffff0000u));
+                        *(uint4*)(slab + PLANE + so) = inside ? make_uint4(lw[0], lw[1], lw[2], lw[3]) : make_uint4(0u, 0u, 0u, 0u);
+                    }
                 }
             }
         }
@@ -384,13 +471,15 @@ __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(Predict
             const int i = lane_t + 64 * k;
             bl[k] = i < nedge ? p.be_bins[i] : __builtin_inff();
         }
-        const bf16* xg = (const bf16*)p.x + (size_t)ub * S * PF_H + lane_t * 4;
-        bf16* yg = (bf16*)p.be_y + (size_t)ub * S * PF_H + lane_t * 4;
+        using XT = typename std::conditional<X3, float, bf16>::type;  // X3: fp32 rows in and out
+        using XV = typename std::conditional<X3, float4, uint2>::type;
+        const XT* xg = (const XT*)p.x + (size_t)ub * S * PF_H + lane_t * 4;
+        XT* yg = (XT*)p.be_y + (size_t)ub * S * PF_H + lane_t * 4;
         const float* spr = p.be_spk ? p.be_spk + (size_t)ub * PF_H + lane_t * 4 : nullptr;
         float4 sp4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (spr) sp4 = *(const float4*)spr;
         for (int base = halo + wv * EB; base < R - halo; base += NWV * EB) {
-            uint2 xv[EB];
+            XV xv[EB];
             float4 ev[EB], pv[EB];
             bool okr[EB];
 #pragma unroll
@@ -403,15 +492,20 @@ __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(Predict
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
                     if (k < nb) lo += __popcll(__ballot(bl[k] < v));
-                xv[j] = *(const uint2*)(xg + (size_t)tc * PF_H);
+                xv[j] = *(const XV*)(xg + (size_t)tc * PF_H);
                 ev[j] = *(const float4*)(p.be_emb + (size_t)lo * PF_H + lane_t * 4);
                 if (p.be_pe) pv[j] = *(const float4*)(p.be_pe + (size_t)tc * PF_H + lane_t * 4);
             }
 #pragma unroll
             for (int j = 0; j < EB; ++j) {
                 if (!okr[j]) continue;
-                float v[4] = {__uint_as_float(xv[j].x << 16), __uint_as_float(xv[j].x & 0xffff0000u), __uint_as_float(xv[j].y << 16),
-                              __uint_as_float(xv[j].y & 0xffff0000u)};
+                float v[4];
+                if constexpr (X3) {
+                    v[0] = xv[j].x; v[1] = xv[j].y; v[2] = xv[j].z; v[3] = xv[j].w;
+                } else {
+                    v[0] = __uint_as_float(xv[j].x << 16); v[1] = __uint_as_float(xv[j].x & 0xffff0000u);
+                    v[2] = __uint_as_float(xv[j].y << 16); v[3] = __uint_as_float(xv[j].y & 0xffff0000u);
+                }
                 const float e4[4] = {ev[j].x, ev[j].y, ev[j].z, ev[j].w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = __fadd_rn(v[i], e4[i]);
@@ -425,7 +519,8 @@ __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(Predict
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] = __fadd_rn(v[i], q4[i]);
                 }
-                *(uint2*)(yg + (size_t)(t0 + base + j) * PF_H) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+                if constexpr (X3) *(float4*)(yg + (size_t)(t0 + base + j) * PF_H) = make_float4(v[0], v[1], v[2], v[3]);
+                else *(uint2*)(yg + (size_t)(t0 + base + j) * PF_H) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
             }
         }
     }
@@ -477,6 +572,22 @@ int launch_pack_predictor_weights(const void* w_layer, void* out_layer, hipStrea
 }
 
 size_t predictor_packed_bytes_per_layer() { return (size_t)PF_STEPS * PF_STEP_U4 * 16; }
+
+// the split-arithmetic form (fp32 rows in, PredictorArgs::wpk = the weights' bf16 heads, wpk_lo their tails; no embedding tail)
+bool predictor_fused_x3_supported(int H, int taps, int nlayers, int S) {
+    return H == PF_H && taps == PF_TAPS && nlayers >= 1 && nlayers <= 16 && S >= 1 && 112 - 2 * (nlayers - 1) >= 32;
+}
+int launch_predictor_fused_x3(const PredictorArgs& a, hipStream_t stream) {
+    if (!predictor_fused_x3_supported(a.H, a.taps, a.nlayers, a.S) || !a.wpk_lo) return FS2_ERR_SHAPE;
+    if (a.be_y && (a.be_y == a.x || !a.be_bins || !a.be_emb || a.be_nbins < 2 || a.be_nbins - 1 > 512)) return FS2_ERR_ARG;
+    if (a.B <= 0) return FS2_OK;
+    const int halo2 = 2 * (a.nlayers - 1);
+    auto tiles = [&](int R) { return (long)a.B * ((a.S + (R - halo2) - 1) / (R - halo2)); };
+    // (one tile height for every shape: the wave layout, not the height, enters the arithmetic - but a shorter tile is another
+    //  instantiation to carry; 112 rows x 2 planes = 117 KB, one workgroup per CU)
+    hipLaunchKernelGGL((predictor_fused_kernel<7, 4, 1, true>), dim3((unsigned)tiles(112)), dim3(256), 0, stream, a);
+    return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
+}
 
 int launch_predictor_fused(const PredictorArgs& a, hipStream_t stream) {
     if (!predictor_fused_supported(FS2_BF16, a.H, a.taps, a.nlayers, a.S)) return FS2_ERR_SHAPE;

@@ -152,6 +152,40 @@ def test_fp32x3_matches_oracle_at_the_fp32_tolerance(case):
     assert dflips <= max(1, ref["duration_rounded"].numel() // 100) and sum(bflips.values()) <= max(2, sum(ref["_intermediates"][f"bucket_{v}"].numel() for v in cfg.variances) // 50)
 
 
+@pytest.mark.parametrize("mode", ["fp32x3", "mixed3"])
+def test_split_arithmetic_predictor_single_launch_against_its_layer_launches(mode):
+    """r05: in the split-arithmetic engines a dense 256-channel predictor is ONE launch (predictor_fused_kernel<..., X3>: activations as
+    bf16 heads + tails in LDS, three MFMAs per product, fp32 LayerNorm) instead of a conv + LayerNorm launch per layer
+    (fs2_set_fused_predictor(0)).  Same split products, another order of the K sum: the predictions agree to fp32 rounding of that
+    order, the decisions with the oracle's as often, and both sit at the fp32 bar against the oracle."""
+    mk, B, L, lengths, skw = CASES["c2arch_ragged"]
+    cfg = mk()
+    sd, inp, ref = _oracle_case(cfg, B, L, lengths, seed=3, **skw)
+    batch = {"phones": torch.from_numpy(inp["phones"]), "speaker": torch.from_numpy(inp["speaker"])}
+    forced = dict(force_durations=ref["duration_rounded"], force_buckets={v: ref["_intermediates"][f"bucket_{v}"] for v in cfg.variances})
+    m = _model(cfg, sd, mode)
+    a_free = _cpu(m(batch, inference=True))
+    a = _cpu(m.forward(batch, **forced))
+    m.engine.set_fused_predictor(False)
+    b_free = _cpu(m(batch, inference=True))
+    b = _cpu(m.forward(batch, **forced))
+    m.engine.set_fused_predictor(True)
+    rep = {"duration_prediction": float((a["duration_prediction"] - b["duration_prediction"]).abs().max())}
+    assert rep["duration_prediction"] <= 2e-4
+    for v in cfg.variances:
+        k = f"variances_{v}"
+        rep[k] = [float((a[k] - b[k]).abs().max()), float((a[k] - ref[k]).abs().max()), float((b[k] - ref[k]).abs().max())]
+        assert rep[k][0] <= 2e-4 * (float(ref[k].abs().max()) + 1), (k, rep[k])
+        assert rep[k][1] <= 1e-3, (k, rep[k])
+    dfa = int((a_free["duration_rounded"] != ref["duration_rounded"]).sum())
+    dfb = int((b_free["duration_rounded"] != ref["duration_rounded"]).sum())
+    rep["duration_flips_single_vs_layers"] = [dfa, dfb]
+    _report(test="x3_predictor_single_launch", mode=mode, **rep)
+    assert dfa <= dfb + 1
+    if mode == "fp32x3":
+        assert float((a["mel"] - ref["mel"]).abs().max()) <= MEL_TOL_FP32
+
+
 @pytest.mark.parametrize("case", ["c2arch_ragged", "refdefault_dw"])
 def test_bf16_close_under_forced_durations(case):
     mk, B, L, lengths, skw = CASES[case]
