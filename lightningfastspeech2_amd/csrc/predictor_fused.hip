@@ -116,16 +116,31 @@ __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(Predict
     if constexpr (X3) {
         // fp32 rows -> heads + tails, through registers: physical slot ps of slab row i holds logical slot ls (8 channels)
         const float* xu = (const float*)p.x + (size_t)ub * S * PF_H;
-        for (int sidx = tid; sidx < (R + 2) * 32; sidx += NWV * 64) {
+        // every load of the fill is requested before the first split (unconditional, from a clamped row; rows outside the utterance are
+        // zeroed afterwards): one memory round trip instead of fifteen
+        constexpr int NIT = ((R + 2) * 32 + NWV * 64 - 1) / (NWV * 64);
+        uint4 c0[NIT], c1[NIT];
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            int sidx = tid + u * NWV * 64;
+            sidx = sidx < (R + 2) * 32 ? sidx : (R + 2) * 32 - 1;
             const int i = sidx >> 5, ps = sidx & 31, t = t0 - 1 + i;
             const int ls = (ps & 16) | ((((ps & 7) ^ (i & 7)) << 1) | ((ps >> 3) & 1));
-            uint4 hi = make_uint4(0u, 0u, 0u, 0u), lo = hi;
-            if (t >= 0 && t < S) {
-                const uint4 c0 = *(const uint4*)(xu + (size_t)t * PF_H + ls * 8), c1 = *(const uint4*)(xu + (size_t)t * PF_H + ls * 8 + 4);
-                split_bf16x3(c0, c1, hi, lo);
+            const int tc = t < 0 ? 0 : (t < S ? t : S - 1);
+            c0[u] = *(const uint4*)(xu + (size_t)tc * PF_H + ls * 8);
+            c1[u] = *(const uint4*)(xu + (size_t)tc * PF_H + ls * 8 + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < NIT; ++u) {
+            const int sidx = tid + u * NWV * 64;
+            if (sidx < (R + 2) * 32) {
+                const int i = sidx >> 5, ps = sidx & 31, t = t0 - 1 + i;
+                uint4 hi, lo;
+                split_bf16x3(c0[u], c1[u], hi, lo);
+                if (t < 0 || t >= S) hi = lo = make_uint4(0u, 0u, 0u, 0u);
+                *(uint4*)(slab + i * PF_ROWB + (ps << 4)) = hi;
+                *(uint4*)(slab + PLANE + i * PF_ROWB + (ps << 4)) = lo;
             }
-            *(uint4*)(slab + i * PF_ROWB + (ps << 4)) = hi;
-            *(uint4*)(slab + PLANE + i * PF_ROWB + (ps << 4)) = lo;
         }
     } else
     // ---- slab fill: 2 rows (1 KiB) per DMA instruction, 16-byte XOR swizzle applied on the source side
