@@ -358,8 +358,17 @@ def main():
         model.engine.set_deferred_layernorm(False)
     if os.environ.get("FS2_FOLD_LN") == "0":  # A/B: a normalise-only pass per wide depth-wise block instead of folding norm2 into the next in-projection
         model.engine.set_folded_layernorm(False)
+    applied_knobs = []
     def set_knob(k):  # a mistyped knob must not yield an unlabeled default-config measurement: set_tuning raises
-        model.engine.set_tuning(int(k))  # this engine's (replicas made later inherit it); the switches are not process state
+        # operator-level switches (the training step's kernels, the strided-batched GEMM, the vocoder run on THIS thread's switches):
+        # applied to the bench thread, which is what training_block / the vocoder read; the engine refuses them
+        op_only = 900 <= k <= 909 or k in (1000, 1001, 1100, 1101, 700, 701, 800, 801, 500, 501)
+        if op_only:
+            _lib.check(_lib.load().fs2_op_set_gemm_variant(int(k)), None, f"fs2_op_set_gemm_variant({k})")
+        else:
+            model.engine.set_tuning(int(k))  # this engine's (replicas made later inherit it); the switches are not process state
+            _lib.load().fs2_op_set_gemm_variant(int(k))  # ... and the bench thread's, for the operator-level launches of the same kernels
+        applied_knobs.append({"knob": int(k), "scope": "thread" if op_only else "engine+thread"})
     if os.environ.get("FS2_GEMM_KNOBS"):  # A/B: comma-separated fs2_op_set_gemm_variant values (include/fs2.h)
         for k in os.environ["FS2_GEMM_KNOBS"].split(","):
             set_knob(int(k))
@@ -678,6 +687,8 @@ def main():
         }
         if dist_info is not None:
             line["dist"] = dist_info
+        if applied_knobs:
+            line["knobs_applied"] = applied_knobs  # FS2_GEMM_KNOBS / FS2_XCD_REMAP: an A/B line says which switches it ran under
         if not multi:
             # the boundary takes device pointers; a host caller also pays H2D of phones + speaker and D2H of the
             # fp32 mels + mask per batch (SURVEY 8d's metric definition): timed separately, never `value`
@@ -699,9 +710,33 @@ def main():
                 pcie_step()
             torch.cuda.synchronize()
             el2 = time.perf_counter() - t0
-            line["value_incl_pcie"] = {"value": frames_rank * k2 / el2, "ms_per_step": el2 / k2 * 1e3, "steps": k2,
+            one = {"value": frames_rank * k2 / el2, "ms_per_step": el2 / k2 * 1e3, "steps": k2, "in_flight": 1}
+            # the same boundary inside the pipeline (r06): two forwards in flight, inputs copied on the forward's own stream, batch i's
+            # mels + mask crossing PCIe on a copy stream under batch i + 1's forward (model.ForwardPipeline(host_outputs=...))
+            hb = {"phones": hp, "speaker": hs}
+            hpipe = model.pipeline(max(2, n_pick), host_outputs=("mel", "tgt_mask"))
+            hpipe.set_graphs(getattr(model.engine, "_graphs_on", False))
+            try:
+                for _ in range(3):
+                    hpipe.submit(hb)
+                hpipe.drain()
+                torch.cuda.synchronize()
+                k3 = max(6, min(args.steps, 20))
+                t0 = time.perf_counter()
+                got = 0
+                for _ in range(k3):
+                    got += len(hpipe.submit(hb))
+                got += len(hpipe.drain())  # every result's host copy has landed when drain returns
+                el3 = time.perf_counter() - t0
+                assert got == k3
+                two = {"value": frames_rank * k3 / el3, "ms_per_step": el3 / k3 * 1e3, "steps": k3, "in_flight": len(hpipe.models)}
+            finally:
+                hpipe.close()
+            best = two if two["ms_per_step"] <= one["ms_per_step"] else one
+            line["value_incl_pcie"] = {**best, "one_at_a_time_ms_per_step": one["ms_per_step"], "pipelined_ms_per_step": two["ms_per_step"],
                                        "what": "inputs from / mels + mask to pinned host memory every step (66 KB H2D, "
-                                               f"{hmel.numel() * 4 / 1e6:.1f} MB D2H)"}
+                                               f"{hmel.numel() * 4 / 1e6:.1f} MB D2H); in_flight > 1: the device-to-host copy of batch i on a "
+                                               "copy stream under batch i + 1's forward; timed until the last host copy has landed"}
         if not multi and not args.no_parity:
             try:
                 line["parity"] = parity_block(cfg, sd, args, dev, model)

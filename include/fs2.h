@@ -231,10 +231,6 @@ int fs2_profile_read(fs2_engine* e, int32_t kernel_class, double* total_ms, int6
  *           has 4, 8 or 16 column tiles and a weight panel larger than an XCD's L2 (the decoder FFN conv1: 109 MB fetched instead of 139,
  *           1 % slower - measured r05); same results
  *   220/221 bf16 pointwise launches of more tiles than CUs: one tile per workgroup / the persistent kernel (default); bit-identical
- *   250/251/252/253 bf16 plain-epilogue launches at 192- / 256-row tiles: the 8-wave slab kernel (default) / the 4-wave one-wave-per-SIMD
- *           kernel (gemm_quad.hip) / the same with a 4-stage operand ring of 32-wide K steps (gemm_ring.hip) / pointwise launches on
- *           four MFMA-only + four request-only waves (gemm_pc.hip); all bit-identical, all measured 5-25 % slower in r05 (DESIGN 4
- *           "Round 5") - kept as the checked A/B forms
  *   230/231 wide depth-wise predictors: the last LayerNorm + Linear(filter, 1) head as a normalise pass over stored activations / from
  *           row sums the last GEMM's epilogue leaves (fs2_op_gemm_head, default); equal to fp32 rounding of another summation order
  *   500/501 fp32 slab-kernel launches: fp32 MFMA (default) / bf16 x 3 split products (what FS2_MIXED_X3 uses in its front; operator level)
@@ -253,9 +249,13 @@ int fs2_profile_read(fs2_engine* e, int32_t kernel_class, double* total_ms, int6
  *              bit-identical either way)
  *   1500/1501  fp32-storage split modes: attention on fp32 MFMA / on bf16 x 3 split products (default)
  * (Removed in r05, measured slower or neutral in r02-r04 and kept until then behind switches: 1211 resident-K/V attention, 211 operand
- *  ring, 1301 / 1302 tall / paired predictor tiles, 301 in-place wide-row LayerNorm epilogue, 311 256-row deferred epilogue.) */
+ *  ring, 1301 / 1302 tall / paired predictor tiles, 301 in-place wide-row LayerNorm epilogue, 311 256-row deferred epilogue.
+ *  Removed in r06: 250..253, three one-wave-per-SIMD / operand-ring / producer-consumer forms of the slab GEMM that measured 5-25 % slower
+ *  in r05 - their sources and measurements are kept as probes under tools/probes/gemm_forms/, outside the library.) */
 int fs2_op_set_gemm_variant(int32_t variant);
-/* tuning knob: cap (KiB) on the LDS operand slab of a vocoder conv workgroup; 0 = built-in heuristic */
+/* The two vocoder knobs below are PER CALLING THREAD, like fs2_op_set_gemm_variant: fs2_voc_synthesize reads the switches of the thread
+ * that calls it - a value set on the main thread does not reach a vocoder driven from a pipeline / executor worker thread (set it there).
+ * tuning knob: cap (KiB) on the LDS operand slab of a vocoder conv workgroup; 0 = built-in heuristic */
 int fs2_op_set_vocoder_lds_limit(int32_t kib);
 /* A/B knob: 1 (default) = whole resblocks of the 32/64-channel stages as one LDS-resident launch, 0 = conv by conv */
 int fs2_op_set_vocoder_fused_resblock(int32_t on);

@@ -49,7 +49,6 @@ int apply_knob(Tuning& t, int variant) {
     else if (variant == 800 || variant == 801) t.bgemm_full = variant - 800;           // bf16 strided-batched GEMM: generic instantiation only / bounds-free one for full aligned tiles (default)
     else if (variant == 700 || variant == 701) t.bgemm_xcd = variant - 700;            // bf16 strided-batched GEMM tile order plain / XCD-contiguous (default)
     else if (variant == 500 || variant == 501) t.split_f32 = variant - 500;            // operator level: fp32 slab launches as fp32 MFMA (default) / bf16 x 3 split
-    else if (variant >= 250 && variant <= 253) t.gemm_quad = variant - 250;           // 256-row plain bf16 launches: 8-wave slab kernel / 4-wave one-wave-per-SIMD kernel
     else if (variant == 230 || variant == 231) t.head_sums = variant - 230;           // predictor head from a normalise pass / from the last GEMM's epilogue sums (default)
     else if (variant == 220 || variant == 221) t.gemm_persist = variant - 220;         // multi-round bf16 pointwise launches one tile per workgroup / on the persistent kernel (default)
     else if (variant >= 200 && variant <= 202) t.slab_xcd_remap = variant - 200;       // slab kernel tile order plain / XCD-contiguous (default) / + column pairs per XCD for wide weight panels

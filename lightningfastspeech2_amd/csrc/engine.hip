@@ -972,7 +972,7 @@ int take_layer_scratch(fs2_engine* e, Arena& ar, int B, int S, LayerScratch* sc)
     sc->u = ar.take(M * Pm * esz);
     sc->vt = ar.take((size_t)B * H * sc->Spad * esz);
     sc->bits = (uint64_t*)ar.take((size_t)B * sc->nw64 * 8);
-    if (!sc->st1 || !sc->st2 || !sc->rsf || !sc->qkv || !sc->att || !sc->proj || !sc->hid || !sc->u || !sc->vt || !sc->bits)
+    if (!sc->st1 || !sc->st2 || !sc->rsf || !sc->hd || !sc->qkv || !sc->att || !sc->proj || !sc->hid || !sc->u || !sc->vt || !sc->bits)
         return fail(e, FS2_ERR_NOMEM, "scratch arena too small");
     return FS2_OK;
 }
@@ -1147,7 +1147,9 @@ int fs2_finalize(fs2_engine* e) {
         CHK(up_vec(e, p + ".embedding.weight", &e->vars[v].emb));
     }
     CHK(make_conv(e, "linear.weight", "linear.bias", &e->mel, e->bdt));
-    if (H > 256 && c.dec_layers > 0 && c.dec_depthwise && e->bdt == FS2_BF16) {
+    // (the row-scaled product with an fp32 store exists for narrow heads only - launch_gemm_plain: N < 192 -; a wider mel head keeps the
+    //  normalise-only pass + the plain mel GEMM)
+    if (H > 256 && c.dec_layers > 0 && c.dec_depthwise && e->bdt == FS2_BF16 && c.n_mels < 192) {
         // mel = Linear(LN2_last(v2)) evaluated on v2: W' = W diag(gamma2), b' = b + W beta2, wg[n] = sum_k W'[n][k] as stored (make_folded_in_proj)
         const std::string pp = "decoder.layers." + std::to_string(c.dec_layers - 1);
         const HostTensor &w = W(e, "linear.weight"), &b = W(e, "linear.bias"), &g = W(e, pp + ".norm2.weight"), &be = W(e, pp + ".norm2.bias");
@@ -1205,6 +1207,12 @@ int fs2_set_deferred_layernorm(fs2_engine* e, int32_t on) {
 // One A/B switch of THIS engine (the values of fs2_op_set_gemm_variant, include/fs2.h); clones made afterwards inherit it.
 int fs2_set_tuning(fs2_engine* e, int32_t knob) {
     if (!e) return FS2_ERR_ARG;
+    // knobs no launch of the engine reads (the training step's backward kernels, the strided-batched GEMM, fs2_op_col_sum, the operator-level
+    // on-the-fly weight split - which allocates per launch and cannot run under graph capture): accepted by fs2_op_set_gemm_variant on the
+    // calling thread only; here they would label a default-configuration measurement as switched
+    const bool op_only = (knob >= 900 && knob <= 909) || knob == 1000 || knob == 1001 || knob == 1100 || knob == 1101 ||
+                         knob == 700 || knob == 701 || knob == 800 || knob == 801 || knob == 500 || knob == 501;
+    if (op_only) return fail(e, FS2_ERR_ARG, "fs2_set_tuning(%d): an operator-level switch no engine launch reads (use fs2_op_set_gemm_variant on the calling thread)", (int)knob);
     const int r = apply_knob(e->tune, knob);
     if (r != FS2_OK) return fail(e, r, "fs2_set_tuning(%d): not a defined switch", (int)knob);
     return FS2_OK;

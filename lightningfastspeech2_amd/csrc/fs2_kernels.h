@@ -15,7 +15,6 @@ namespace fs2 {
 struct Tuning {
     int gemm_variant = 0;      // 0 auto; 1 128x128 register-staged; 2 128x256 DMA ring; 3/4/5 slab kernel 128/192/256-row tiles; 6/7 32/64-row
     int gemm_wres = 1;         // bf16 K = 256 plain GEMMs on the weight-resident kernel: 0 never, 1 where it pays, 2 wherever it applies
-    int gemm_quad = 0;         // bf16 plain-epilogue launches of 256-row tiles on the one-wave-per-SIMD kernel (gemm_quad.hip)
     int head_sums = 1;         // wide predictors: last LayerNorm + Linear head from the last GEMM's epilogue sums (GemmArgs::head_out) / a normalise pass
     int gemm_persist = 1;      // bf16 pointwise launches of more tiles than CUs on the persistent kernel (gemm_persist.hip)
     int slab_xcd_remap = 1;    // slab kernel tile order: 0 plain, 1 XCD-contiguous (default), 2 = 1 + column pairs per XCD where the weight panel exceeds an L2 (fewer bytes fetched, 1 % slower: r05)
@@ -107,15 +106,6 @@ bool gemm_wres_supported(const GemmArgs& a, int in_dtype, int out_dtype, bool fo
 int launch_gemm_wres(const GemmArgs& a, hipStream_t stream);
 // gemm_persist.hip: the slab kernel's persistent form (one workgroup per CU walks its tiles; bit-identical results)
 bool gemm_persist_supported(const GemmArgs& a, int in_dtype, int out_dtype, int mi);
-// gemm_quad.hip: 256 x 256 tiles on four waves, one per SIMD (bit-identical to the slab kernel)
-bool gemm_quad_supported(const GemmArgs& a, int in_dtype, int out_dtype);
-int launch_gemm_quad(const GemmArgs& a, hipStream_t stream);
-// gemm_ring.hip: the one-wave-per-SIMD form with a 4-stage operand ring of 32-wide K steps (bit-identical to the slab kernel)
-bool gemm_ring_supported(const GemmArgs& a, int in_dtype, int out_dtype);
-int launch_gemm_ring(const GemmArgs& a, hipStream_t stream);
-// gemm_pc.hip: producer / consumer waves (pointwise launches; 192 x 256 tiles; bit-identical to the slab kernel)
-bool gemm_pc_supported(const GemmArgs& a, int in_dtype, int out_dtype);
-int launch_gemm_pc(const GemmArgs& a, hipStream_t stream);
 bool gemm_head_supported(const GemmArgs& a, int in_dtype, int out_dtype);  // can this launch take GemmArgs::head_out (persistent kernel, switch on)
 bool gemm_persist_pays(const GemmArgs& a, int mi);
 int launch_gemm_persist(const GemmArgs& a, int mi, hipStream_t stream);

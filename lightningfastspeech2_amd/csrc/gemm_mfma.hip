@@ -1454,9 +1454,6 @@ static int launch_gemm_plain(const GemmArgs& a, int in_dtype, int out_dtype, hip
         if (best_rows <= 2L * a.M || a.C_lo || a.w_presplit || a.rs_stats) {  // (the head + tail store / pre-split weights / row-scaled product exist in this kernel only)
             // more tiles than CUs: one workgroup per CU walks them, the next tile's first operands under this tile's epilogue
             // (gemm_persist.hip; same tile height, same arithmetic per element - bit-identical)
-            if (!fused && tn_.gemm_quad == 3 && best >= 6 && gemm_pc_supported(a, in_dtype, out_dtype)) return launch_gemm_pc(a, stream);
-            if (!fused && tn_.gemm_quad == 2 && best == 8 && gemm_ring_supported(a, in_dtype, out_dtype)) return launch_gemm_ring(a, stream);
-            if (!fused && tn_.gemm_quad == 1 && best == 8 && gemm_quad_supported(a, in_dtype, out_dtype)) return launch_gemm_quad(a, stream);
             if (!fused && tn_.gemm_persist && gemm_persist_supported(a, in_dtype, out_dtype, best) && gemm_persist_pays(a, best))
                 return launch_gemm_persist(a, best, stream);
             if (fused) *fused = true;

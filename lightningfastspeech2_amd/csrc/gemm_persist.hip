@@ -522,6 +522,8 @@ bool gemm_persist_supported(const GemmArgs& a, int in_dtype, int out_dtype, int 
     if (a.ln_g || a.dot_w || a.z_out || a.res || a.gate || a.zero_rows || a.C_lo || a.split || a.w_presplit || a.ksplit > 1 || a.drop_p > 0.f) return false;
     if (a.rs_stats && (a.relu || a.stats_out || a.epi_res || !a.rs_wg)) return false;
     if (!a.bias) return false;
+    // the kernel reads bias / rs_wg / head_gw as float4 (the slab kernel takes any 4-byte-aligned pointer): unaligned callers stay on it
+    if (((uintptr_t)a.bias & 15) || ((uintptr_t)a.rs_wg & 15) || ((uintptr_t)a.head_gw & 15)) return false;
     if (a.head_out) {  // rows not stored: statistics + head sums only
         if (!a.head_gw || !a.stats_out || a.epi_res || a.rs_stats || mi != 6) return false;
     } else if (!a.C) {

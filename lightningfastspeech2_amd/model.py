@@ -319,8 +319,8 @@ class FastSpeech2:
         other._t_guess = {}
         return other
 
-    def pipeline(self, in_flight: int = 2) -> "ForwardPipeline":
-        return ForwardPipeline(self, in_flight)
+    def pipeline(self, in_flight: int = 2, host_outputs=()) -> "ForwardPipeline":
+        return ForwardPipeline(self, in_flight, host_outputs)
 
     # ---- reference-style construction from a Lightning checkpoint dict (fastspeech2.py:530-634) --
     @classmethod
@@ -469,17 +469,29 @@ class ForwardPipeline:
 
     A result's tensors were produced on the pipeline's own streams; ``submit`` / ``drain`` make the caller's current stream wait for
     them (an event per forward) before handing them over.
+
+    ``host_outputs`` (r06; e.g. ``("mel", "tgt_mask")``): the host boundary inside the pipeline - what
+    ``SpeechGenerator.generate_samples`` does right behind the forward (generator.py:158-165: ``mel[i][~tgt_mask[i]].cpu()``).  A batch
+    may then be HOST tensors (pinned: copied to the device on the forward's own stream, no host wait), and the named outputs come back
+    as PINNED HOST tensors: their device-to-host copies are queued on a per-replica copy stream behind the forward, so batch i's 15.7 MB
+    of mels cross PCIe while batch i + 1's forward runs.  The bytes are those of ``model(batch, inference=True)[key].cpu()``.  A host
+    output is a view of a per-replica ring slot: it stays valid for the next ``in_flight`` calls of ``submit`` after it was handed over
+    (copy it or consume it before); the other outputs stay device tensors.
     """
 
-    def __init__(self, model: FastSpeech2, in_flight: int = 2):
+    def __init__(self, model: FastSpeech2, in_flight: int = 2, host_outputs=()):
         import concurrent.futures as cf
         if in_flight < 1:
             raise ValueError("in_flight >= 1")
+        self.host_outputs = tuple(host_outputs)
+        self._ring = [[{} for _ in range(3)] for _ in range(in_flight)]  # [replica][slot] -> {key: flat pinned uint8 buffer}
+        self._nrun = [0] * in_flight
         self.models = [model] + [model.replicate() for _ in range(in_flight - 1)]
         for m in self.models[1:]:
             m.engine.set_graphs(getattr(model.engine, "_graphs_on", False))
         self.device = model.device
         self.streams = [torch.cuda.Stream(self.device) for _ in self.models]
+        self.copy_streams = [torch.cuda.Stream(self.device) for _ in self.models] if self.host_outputs else []
         # one single-thread executor per replica: a replica's forwards run in submission order on its own thread and stream
         self.pools = [cf.ThreadPoolExecutor(max_workers=1) for _ in self.models]
         self.pending = []  # futures in submission order
@@ -509,16 +521,47 @@ class ForwardPipeline:
         with torch.cuda.device(self.device), torch.cuda.stream(self.streams[k]):
             self.streams[k].wait_event(ready)  # the caller's stream produced the batch
             self._record(batch, self.streams[k])  # ... and may release it before this stream has finished reading it
+            if self.host_outputs:  # host inputs ride this stream (pinned memory: no host wait; pageable memory degrades to a synchronous copy)
+                batch = {key: (v.to(self.device, non_blocking=True) if isinstance(v, torch.Tensor) and not v.is_cuda and key in ("phones", "speaker") else v)
+                         for key, v in batch.items()}
             out = self.models[k](batch, inference=True)
             done = torch.cuda.Event()
             done.record(self.streams[k])
+            if self.host_outputs:
+                out, done = self._to_host(k, out, done)
         return out, done
+
+    def _to_host(self, k, out, fwd_done):
+        """Queue the device-to-host copies of the named outputs on replica k's copy stream (behind the forward, beside the next one)."""
+        cs = self.copy_streams[k]
+        slot = self._ring[k][self._nrun[k] % 3]
+        self._nrun[k] += 1
+        cs.wait_event(fwd_done)
+        res = dict(out)
+        with torch.cuda.stream(cs):
+            for key in self.host_outputs:
+                src = out[key]
+                if not isinstance(src, torch.Tensor) or not src.is_cuda:
+                    continue
+                nbytes = src.numel() * src.element_size()
+                buf = slot.get(key)
+                if buf is None or buf.numel() < nbytes:
+                    buf = slot[key] = torch.empty(max(nbytes, 1), dtype=torch.uint8).pin_memory()
+                dst = buf[:nbytes].view(src.dtype).view(src.shape)
+                dst.copy_(src.contiguous(), non_blocking=True)
+                src.record_stream(cs)
+                res[key] = dst
+            done = torch.cuda.Event()
+            done.record(cs)
+        return res, done
 
     def _hand_over(self, fut):
         out, done = fut.result()
         cur = torch.cuda.current_stream(self.device)
         cur.wait_event(done)
         self._record(out, cur)  # allocated on the pipeline's stream, consumed (and possibly dropped) on the caller's
+        if self.host_outputs:
+            done.synchronize()  # a host tensor is read by the host: the copy has landed (what .cpu() waits for in the reference's caller)
         return out
 
     def submit(self, batch):

@@ -158,6 +158,43 @@ def test_forward_pipeline_is_bit_identical_and_ordered():
                 assert torch.equal(g[k], w[k]), (n, k)
 
 
+def test_forward_pipeline_with_the_host_boundary_inside_is_bit_identical():
+    """model.pipeline(n, host_outputs=("mel", "tgt_mask")) (r06; the consumer modelled: generator.py:158-165, `mel[i][~tgt_mask[i]].cpu()`):
+    pinned HOST batches in, the named outputs back as pinned host tensors whose device-to-host copies ran on a copy stream under the next
+    forward.  Every batch: the same bytes as model(batch)[key].cpu(), in submission order, the other outputs still device tensors; results
+    are consumed at hand-over (a host output's ring slot is reused three runs of its replica later)."""
+    cfg, sd, inp, batch = _case()
+    m = _model(cfg, sd, "bf16")
+    rs = np.random.RandomState(5)
+    batches = []
+    for i in range(11):
+        B = int(rs.randint(1, 5))
+        L = int(rs.randint(5, 25))
+        lens = sorted((int(rs.randint(1, L + 1)) for _ in range(B)), reverse=True)
+        lens[0] = L
+        x = synth_inputs(cfg, B, L, seed=90 + i, lengths=lens)
+        batches.append({"phones": torch.from_numpy(x["phones"]).pin_memory(), "speaker": torch.from_numpy(x["speaker"]).pin_memory()})
+    want = [{k: v.cpu() for k, v in m(b, inference=True).items()} for b in batches]
+    for n in (1, 2, 3):
+        pipe = m.pipeline(n, host_outputs=("mel", "tgt_mask"))
+        got = []
+
+        def take(outs):
+            for o in outs:
+                assert not o["mel"].is_cuda and o["mel"].is_pinned() and not o["tgt_mask"].is_cuda
+                assert o["duration_rounded"].is_cuda
+                got.append({k: v.cpu().clone() for k, v in o.items()})  # consumed at hand-over
+        for b in batches:
+            take(pipe.submit(b))
+        take(pipe.drain())
+        pipe.close()
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            assert g.keys() == w.keys()
+            for k in w:
+                assert g[k].dtype == w[k].dtype and torch.equal(g[k], w[k]), (n, k)
+
+
 def test_two_engines_with_different_tuning_run_concurrently():
     """The kernel-selection switches are per engine (fs2_set_tuning), not process state: two replicas of one model -
     one on the defaults, one with the GEMM and predictor-tail forms switched to their other, bit-identical kernels - driven

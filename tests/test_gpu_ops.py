@@ -110,78 +110,6 @@ def test_persistent_gemm_is_bit_identical_to_the_slab_kernel(M, N, K, relu, add)
     assert float((got - ref).abs().max()) <= tol(G.BF16, ref)
 
 
-@pytest.mark.parametrize("B,S,Cin,N,taps,relu", [(8, 768, 256, 1024, 9, True), (3, 1000, 256, 712, 3, False), (1, 24576, 768, 3072, 1, True),
-                                                 (2, 300, 128, 256, 5, True), (40, 256, 256, 1024, 9, True)])
-def test_quad_gemm_is_bit_identical_to_the_slab_kernel(B, S, Cin, N, taps, relu):
-    """gemm_quad.hip (knob 251): 256 x 256 tiles on FOUR waves, one per SIMD, each with a 128 x 128 patch of accumulators, against the
-    8-wave slab kernel at its 256-row tiles (knob 5 pins the height; 250): the same MFMA sequence per output element, so the same
-    bits; conv and pointwise, ragged utterance tails (S not a multiple of 256), a column tail, utterances of one tile."""
-    x, w = rnd(B * S, Cin, seed=38), rnd(N, taps * Cin, seed=39) / math.sqrt(taps * Cin)
-    b = rnd(N, seed=40)
-    try:
-        G.lib().fs2_op_set_gemm_variant(5)
-        G.lib().fs2_op_set_gemm_variant(250)
-        old = G.gemm(G.BF16, x, w, b, taps=taps, S=S, relu=relu)
-        G.lib().fs2_op_set_gemm_variant(0)
-        G.lib().fs2_op_set_gemm_variant(251)
-        got = G.gemm(G.BF16, x, w, b, taps=taps, S=S, relu=relu)
-        again = G.gemm(G.BF16, x, w, b, taps=taps, S=S, relu=relu)
-    finally:
-        G.lib().fs2_op_set_gemm_variant(0)
-        G.lib().fs2_op_set_gemm_variant(250)
-    assert torch.equal(got, old) and torch.equal(got, again)
-    xr = G.rounded(x, G.BF16).reshape(B, S, Cin)
-    ref = F.conv1d(xr.transpose(1, 2), G.rounded(w, G.BF16).reshape(N, taps, Cin).permute(0, 2, 1), b, padding=taps // 2).transpose(1, 2).reshape(B * S, N)
-    ref = ref.clamp_min(0) if relu else ref
-    assert float((got - ref).abs().max()) <= tol(G.BF16, ref)
-
-
-@pytest.mark.parametrize("B,S,Cin,N,taps,relu", [(8, 768, 256, 1024, 9, True), (3, 1000, 256, 712, 3, False), (1, 24576, 768, 3072, 1, True),
-                                                 (2, 300, 128, 256, 5, True), (40, 256, 256, 1024, 9, True), (2, 700, 192, 512, 7, False),
-                                                 (1, 5000, 128, 256, 1, False), (3, 520, 256, 256, 31, True)])
-def test_ring_gemm_is_bit_identical_to_the_slab_kernel(B, S, Cin, N, taps, relu):
-    """gemm_ring.hip (knob 252): four waves, one per SIMD, K steps of 32 through a 4-stage operand ring whose pieces are requested one
-    per row block three steps ahead, against the 8-wave slab kernel at 256-row tiles: the same 32-k chunks in the same order per output
-    element, so the same bits.  Pointwise and k = 3 / 5 / 7 / 9 / 31 convs (the three request schedules), ragged utterance tails, a
-    column tail, the shortest K (two 64-channel blocks), twice (a ring slot overwritten early would show as run-to-run differences)."""
-    x, w = rnd(B * S, Cin, seed=38), rnd(N, taps * Cin, seed=39) / math.sqrt(taps * Cin)
-    b = rnd(N, seed=40)
-    try:
-        G.lib().fs2_op_set_gemm_variant(5)
-        G.lib().fs2_op_set_gemm_variant(250)
-        old = G.gemm(G.BF16, x, w, b, taps=taps, S=S, relu=relu)
-        G.lib().fs2_op_set_gemm_variant(0)
-        G.lib().fs2_op_set_gemm_variant(252)
-        got = G.gemm(G.BF16, x, w, b, taps=taps, S=S, relu=relu)
-        again = G.gemm(G.BF16, x, w, b, taps=taps, S=S, relu=relu)
-    finally:
-        G.lib().fs2_op_set_gemm_variant(0)
-        G.lib().fs2_op_set_gemm_variant(250)
-    assert torch.equal(got, again)
-    assert torch.equal(got, old)
-
-
-@pytest.mark.parametrize("M,N,K,relu", [(49152, 3072, 768, True), (24576, 712, 768, False), (5000, 256, 128, False), (70001, 768, 3072, True)])
-def test_pc_gemm_is_bit_identical_to_the_slab_kernel(M, N, K, relu):
-    """gemm_pc.hip (knob 253): pointwise launches on 192 x 256 tiles with four MFMA-only waves and four request-only waves (5-stage
-    operand ring, one barrier per 32-wide K step), against the slab kernel with the persistent form off (220): the same 32-k chunks
-    in the same order per output element, so the same bits; a ragged last row tile, a column tail, the shortest K, twice."""
-    x, w = rnd(M, K, seed=38), rnd(N, K, seed=39) / math.sqrt(K)
-    b = rnd(N, seed=40)
-    try:
-        G.lib().fs2_op_set_gemm_variant(220)
-        G.lib().fs2_op_set_gemm_variant(250)
-        old = G.gemm(G.BF16, x, w, b, relu=relu)
-        G.lib().fs2_op_set_gemm_variant(253)
-        got = G.gemm(G.BF16, x, w, b, relu=relu)
-        again = G.gemm(G.BF16, x, w, b, relu=relu)
-    finally:
-        G.lib().fs2_op_set_gemm_variant(250)
-        G.lib().fs2_op_set_gemm_variant(221)
-    assert torch.equal(got, again)
-    assert torch.equal(got, old)
-
-
 @pytest.mark.parametrize("B,S,Cin,N,taps", [(8, 768, 256, 1024, 9), (4, 512, 256, 2048, 3), (6, 1000, 1024, 1024, 1), (3, 700, 256, 1024, 9)])
 def test_slab_tile_orders_are_bit_identical(B, S, Cin, N, taps):
     """Slab kernel tile orders (knobs 200 / 201 / 202: plain, XCD-contiguous, XCD-contiguous with column-tile pairs per XCD for weight
