@@ -717,7 +717,7 @@ def main():
             hpipe = model.pipeline(max(2, n_pick), host_outputs=("mel", "tgt_mask"))
             hpipe.set_graphs(getattr(model.engine, "_graphs_on", False))
             try:
-                for _ in range(3):
+                for _ in range(4 * len(hpipe.models) + 1):  # every ring slot of every replica has its pinned buffers (a 15.7 MB pinned allocation takes milliseconds)
                     hpipe.submit(hb)
                 hpipe.drain()
                 torch.cuda.synchronize()

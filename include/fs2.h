@@ -359,6 +359,12 @@ int fs2_op_predictor(int32_t dtype, const void* x, const void* w, const float* b
                      const float* ln_b, const float* head_w, float head_b, const uint8_t* mask, float* pred,
                      void* packed_scratch, int32_t B, int32_t S, int32_t H, int32_t nlayers, int32_t taps,
                      void* hip_stream);
+/* The same for DEPTH-WISE layers (VarianceConvolutionLayer with depthwise=True, model.py:541-558: Conv1d(H, H, 3, groups = H) ->
+ * Conv1d(H, H, 1) -> ReLU -> LayerNorm), H = 256, bf16, one launch: dw_w = (nlayers, 3, H) fp32 tap-major depth-wise taps, dw_b =
+ * (nlayers, H), w = (nlayers, H, H) bf16 pointwise weights, bias their bias; packed_scratch = nlayers * H * H * 2 bytes. */
+int fs2_op_predictor_dw(int32_t dtype, const void* x, const float* dw_w, const float* dw_b, const void* w, const float* bias,
+                        const float* ln_g, const float* ln_b, const float* head_w, float head_b, const uint8_t* mask, float* pred,
+                        void* packed_scratch, int32_t B, int32_t S, int32_t H, int32_t nlayers, void* hip_stream);
 /* FastSpeech2Loss.get_loss for "l1" / "mse" (litfass/fastspeech2/loss.py:57-81, called from forward :83-213):
  * out2[0] = mean over the rows whose pad_mask is 0 of |pred - truth| (kind 0) or (pred - truth)^2 (kind 1),
  * out2[1] = number of selected elements; pred = (rows, inner) fp32; truth_kind 0: fp32 (rows, inner),

@@ -89,6 +89,22 @@ int fs2_op_predictor(int32_t dtype, const void* x, const void* w, const float* b
     return launch_predictor_fused(a, (hipStream_t)stream);
 }
 
+int fs2_op_predictor_dw(int32_t dtype, const void* x, const float* dw_w, const float* dw_b, const void* w, const float* bias,
+                        const float* ln_g, const float* ln_b, const float* head_w, float head_b, const uint8_t* mask, float* pred,
+                        void* packed_scratch, int32_t B, int32_t S, int32_t H, int32_t nlayers, void* stream) {
+    if (!predictor_fused_supported(dtype, H, 3, nlayers, S)) return FS2_ERR_SHAPE;
+    if (!x || !dw_w || !dw_b || !w || !bias || !ln_g || !ln_b || !head_w || !pred || !packed_scratch) return FS2_ERR_ARG;
+    const size_t lb = predictor_packed_bytes_per_layer(1);
+    for (int l = 0; l < nlayers; ++l) {
+        const int r = launch_pack_predictor_weights((const char*)w + (size_t)l * H * H * 2, (char*)packed_scratch + lb * l, (hipStream_t)stream, 1);
+        if (r != FS2_OK) return r;
+    }
+    PredictorArgs a;
+    a.x = x; a.wpk = packed_scratch; a.dw_w = dw_w; a.dw_b = dw_b; a.bias = bias; a.ln_g = ln_g; a.ln_b = ln_b; a.head_w = head_w; a.head_b = head_b;
+    a.mask = mask; a.pred = pred; a.B = B; a.S = S; a.H = H; a.nlayers = nlayers; a.taps = 3; a.eps = 1e-5f;
+    return launch_predictor_fused(a, (hipStream_t)stream);
+}
+
 int fs2_op_soft_dtw(const float* x, const float* y, int32_t B, int32_t N, int32_t M, int32_t D, float gamma, float* out,
                     void* stream) {
     if (!x || !y || !out) return FS2_ERR_ARG;

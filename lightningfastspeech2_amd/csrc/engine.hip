@@ -109,6 +109,8 @@ struct PredictorW {
     // one-launch path (predictor_fused.hip): weights in MFMA fragment order, per-layer vectors stacked
     void* wpk = nullptr;
     float *bias_all = nullptr, *g_all = nullptr, *b_all = nullptr;
+    // ... of depth-wise layers (H = 256, k = 3; r06): wpk = the pointwise weights, dw_all (nl, 3, H) / dwb_all (nl, H) the depth-wise taps + bias
+    float *dw_all = nullptr, *dwb_all = nullptr;
     // ... in the split arithmetic (fp32x3 / mixed3 engines): wpk = the weights' bf16 heads, wpk_lo their tails (launch_predictor_fused_x3)
     void* wpk_lo = nullptr;
 };
@@ -533,6 +535,30 @@ int make_predictor(fs2_engine* e, const std::string& p, int nl, int filt, bool d
         CHK(upload_f32(e, bias.data(), bias.size(), &P->bias_all));
         CHK(upload_f32(e, g.data(), g.size(), &P->g_all));
         CHK(upload_f32(e, b.data(), b.size(), &P->b_all));
+    } else if (dw && nl && cin == filt && P->layers[0].dw.k == 3 && P->layers[0].dw.C == filt && predictor_fused_supported(dt, filt, 3, nl, 1)) {
+        // depth-wise layers in the single launch (predictor_fused_kernel<..., DW>): the pointwise weights in fragment order (one tap),
+        // the depth-wise taps as (layer, tap, channel) fp32
+        const size_t lb = predictor_packed_bytes_per_layer(1);
+        CHK(dev_alloc(e, &P->wpk, lb * nl));
+        std::vector<float> bias, g, b, dww((size_t)nl * 3 * filt), dwb;
+        for (int j = 0; j < nl; ++j) {
+            const std::string q = p + ".layers." + std::to_string(j) + ".layers";
+            CHK(launch_pack_predictor_weights(P->layers[j].c.w, (char*)P->wpk + lb * j, nullptr, 1));
+            const auto &hw = W(e, q + ".0.module.0.weight").data, &hdb = W(e, q + ".0.module.0.bias").data;  // (filt, 1, 3), (filt)
+            for (int c2 = 0; c2 < filt; ++c2)
+                for (int t = 0; t < 3; ++t) dww[((size_t)j * 3 + t) * filt + c2] = hw[(size_t)c2 * 3 + t];
+            dwb.insert(dwb.end(), hdb.begin(), hdb.end());
+            const auto &hb = W(e, q + ".0.module.1.bias").data, &hg = W(e, q + ".2.weight").data, &hbe = W(e, q + ".2.bias").data;
+            bias.insert(bias.end(), hb.begin(), hb.end());
+            g.insert(g.end(), hg.begin(), hg.end());
+            b.insert(b.end(), hbe.begin(), hbe.end());
+        }
+        HIPCHK(e, hipStreamSynchronize(nullptr));
+        CHK(upload_f32(e, bias.data(), bias.size(), &P->bias_all));
+        CHK(upload_f32(e, g.data(), g.size(), &P->g_all));
+        CHK(upload_f32(e, b.data(), b.size(), &P->b_all));
+        CHK(upload_f32(e, dww.data(), dww.size(), &P->dw_all));
+        CHK(upload_f32(e, dwb.data(), dwb.size(), &P->dwb_all));
     } else if (!dw && nl && cin == filt && dt == FS2_F32 && e->front_split && predictor_fused_x3_supported(filt, taps, nl, 1)) {
         // the same launch in the split arithmetic: the weights' bf16 heads and tails in the kernel's fragment order
         // [layer][step = tap * 8 + kb][32-channel group][2][lane] x 8 values (pack_predictor_weights_kernel's map), packed here
@@ -858,17 +884,18 @@ int predictor(fs2_engine* e, hipStream_t st, const PredictorW& P, const void* x,
         if (with_tail) *tail_done = true;
         return FS2_OK;
     }
-    if (P.wpk && !P.wpk_lo && e->fuse_predictor && predictor_fused_supported(P.dt, P.filt, P.layers[0].c.taps, (int)P.layers.size(), S)) {
+    if (P.wpk && !P.wpk_lo && e->fuse_predictor && predictor_fused_supported(P.dt, P.filt, P.dw_all ? 3 : P.layers[0].c.taps, (int)P.layers.size(), S)) {
         PredictorArgs a;
         a.x = x; a.wpk = P.wpk; a.bias = P.bias_all; a.ln_g = P.g_all; a.ln_b = P.b_all;
+        a.dw_w = P.dw_all; a.dw_b = P.dwb_all;  // depth-wise layers: wpk = their pointwise halves
         a.head_w = P.head_w; a.head_b = P.head_b; a.mask = mask; a.pred = pred;
-        a.B = B; a.S = S; a.H = P.filt; a.nlayers = (int)P.layers.size(); a.taps = P.layers[0].c.taps; a.eps = 1e-5f;
+        a.B = B; a.S = S; a.H = P.filt; a.nlayers = (int)P.layers.size(); a.taps = P.dw_all ? 3 : P.layers[0].c.taps; a.eps = 1e-5f;
         const bool with_tail = tail && tail_done && !P.cwt && tail->y != x && tail->nbins >= 2 && tail->nbins - 1 <= 512;
         if (with_tail) {
             a.be_y = tail->y; a.be_bins = tail->bins; a.be_emb = tail->emb; a.be_nbins = tail->nbins;
             a.be_std = tail->std; a.be_mean = tail->mean; a.be_pe = tail->pe; a.be_spk = tail->spk;
         }
-        const double fl = 2.0 * M * (double)P.filt * P.filt * a.taps * a.nlayers;
+        const double fl = (P.dw_all ? 2.0 * M * (double)P.filt * (P.filt + 3) : 2.0 * M * (double)P.filt * P.filt * a.taps) * a.nlayers;
         const double by = (double)M * P.filt * 2 + (double)M * 4 + (with_tail ? 2.0 * M * P.filt * 2 : 0.0);
         Bracket br(e, FS2_K_CONV_GEMM, st, fl, by);
         const int r = launch_predictor_fused(a, st);

@@ -156,6 +156,10 @@ int launch_attention_pipe(const AttnArgs& a, int variant, hipStream_t stream);
 struct PredictorArgs {
     const void* x;          // (B*S, H) bf16
     const void* wpk;        // nlayers * predictor_packed_bytes_per_layer()
+    // depth-wise layers (model.py:541-558; r06): dw_w = (nlayers, 3, H) fp32 tap-major depth-wise weights, dw_b = (nlayers, H); wpk then holds the
+    // POINTWISE weights (one tap per layer, predictor_packed_bytes_per_layer(1)) and bias the pointwise bias; taps stays 3 (the depth-wise k)
+    const float* dw_w = nullptr;
+    const float* dw_b = nullptr;
     const void* wpk_lo = nullptr;  // split-arithmetic form (launch_predictor_fused_x3): wpk = the weights' bf16 heads, wpk_lo their tails; x is fp32
     const float* bias;
     const float* ln_g;
@@ -178,8 +182,8 @@ struct PredictorArgs {
     const float* be_spk = nullptr;   // (B, H) fp32 or null
 };
 bool predictor_fused_supported(int dtype, int H, int taps, int nlayers, int S);
-size_t predictor_packed_bytes_per_layer();
-int launch_pack_predictor_weights(const void* w_layer /*(H, taps*H) tap-major bf16*/, void* out_layer, hipStream_t stream);
+size_t predictor_packed_bytes_per_layer(int taps = 3);
+int launch_pack_predictor_weights(const void* w_layer /*(H, taps*H) tap-major bf16*/, void* out_layer, hipStream_t stream, int taps = 3);
 int launch_predictor_fused(const PredictorArgs& a, hipStream_t stream);
 bool predictor_fused_x3_supported(int H, int taps, int nlayers, int S);
 int launch_predictor_fused_x3(const PredictorArgs& a, hipStream_t stream);

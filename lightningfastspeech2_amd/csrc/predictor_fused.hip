@@ -48,17 +48,18 @@ static_assert(PF_RING == 3 || PF_RING == 4, "ring depth 3 or 4");
 
 }  // namespace
 
-// W: (256, 3*256) tap-major bf16 rows of one layer -> fragment order [tap][kb][wave][ni][lane] x 16 B.
+// W: (256, taps*256) tap-major bf16 rows of one layer (taps = 3: the dense conv; 1: the pointwise half of a depth-wise layer) ->
+// fragment order [tap][kb][wave][ni][lane] x 16 B.
 // Wave wv owns output channels wv*32 .. +31; MFMA row i of fragment ni <-> channel
 // wv*32 + (i>>2)*8 + ni*4 + (i&3), so that a lane ends up with 8 consecutive channels (one 16-byte
 // slab slot) per row.
-__global__ void pack_predictor_weights_kernel(const bf16* __restrict__ W, uint4* __restrict__ out) {
+__global__ void pack_predictor_weights_kernel(const bf16* __restrict__ W, uint4* __restrict__ out, int taps) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= PF_STEPS * PF_STEP_U4) return;
+    if (idx >= taps * PF_KB * PF_STEP_U4) return;
     const int lane = idx & 63, ni = (idx >> 6) & 1, wv = (idx >> 7) & 7, step = idx >> 10;
     const int tap = step / PF_KB, kb = step % PF_KB, fr = lane & 15, fg = lane >> 4;
     const int ch = wv * 32 + (fr >> 2) * 8 + ni * 4 + (fr & 3);
-    out[idx] = *(const uint4*)(W + (size_t)ch * (PF_TAPS * PF_H) + tap * PF_H + kb * 32 + fg * 8);
+    out[idx] = *(const uint4*)(W + (size_t)ch * (taps * PF_H) + tap * PF_H + kb * 32 + fg * 8);
 }
 
 // NWV waves, each: ALL R rows x (256 / NWV) output channels = NFR MFMA column fragments (a lane owns 8
@@ -95,13 +96,23 @@ __global__ void pack_predictor_weights_kernel(const bf16* __restrict__ W, uint4*
 // w_hi x_hi) - the arithmetic of the per-layer split launches (gemm_mfma.hip SPLIT) with the K sum in this kernel's order.  The
 // LayerNorm epilogue splits its fp32 rows again for the next layer.  One 4-wave workgroup per CU (two planes = 117 KB), a lone wave
 // per SIMD with the 512-register file: both fragment sets, both weight rings.  The embedding tail reads and writes fp32 rows.
-template <int MI16, int NWV, int MINW, bool X3 = false>
+// DW (r06; the reference's own architecture - depth-wise VarianceConvolutionLayer, model.py:541-558: Conv1d(256, 256, 3, groups = 256) ->
+// Conv1d(256, 256, 1) -> ReLU -> LayerNorm): a layer is [depth-wise pass over the slab, in place] -> [ONE tap of the K loop on the
+// pointwise weights] -> the same epilogue.  The depth-wise pass: a thread owns one 16-byte slot (8 channels) of R / 8 consecutive
+// slab rows, walks its window once (each row unpacked once, three multiply-adds per channel in the order of rowops.hip's dwconv_kernel:
+// w0 x[t-1], + w1 x[t], + w2 x[t+1], + bias, one rounding to bf16 - the bits of the per-layer launch), holds the results in registers
+// across a barrier (every thread has read its window) and writes them back over the rows it read.  Rows 0 and R + 1 keep the layer-0
+// input: one more stale row per layer at both ends, the dense form's halo.  A third of the dense layer's MFMA work, ~450 VALU per thread
+// and layer for the depth-wise pass; ref-default's 15 + 2 layers = 4 launches instead of 34.
+template <int MI16, int NWV, int MINW, bool X3 = false, bool DW = false>
 __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(PredictorArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins exist in the device pass only
+    static_assert(!(X3 && DW), "no split-arithmetic depth-wise form");
     constexpr int R = MI16 * 16, HFA = (MI16 + 1) / 2;  // row fragments: first half HFA, second MI16 - HFA
     constexpr int NFR = PF_H / (NWV * 16), NP = NFR / 2;
     constexpr int PLANE = (R + 2) * PF_ROWB;
-    constexpr int RING = X3 ? 4 : PF_RING;  // X3: the 4-stage ring with the taps in a rolled loop (the unrolled 3-stage form spilled 43 registers, 35 of them inside the K loops)
+    constexpr int TAPS = DW ? 1 : PF_TAPS, STEPS = TAPS * PF_KB;  // K loop: taps x 8 k-steps of 32
+    constexpr int RING = (X3 || DW) ? 4 : PF_RING;  // X3: the 4-stage ring with the taps in a rolled loop (the unrolled 3-stage form spilled 43 registers, 35 of them inside the K loops); DW: 8 k-steps per layer, 8 % 4 == 0
     __shared__ __attribute__((aligned(16))) unsigned char slab[(X3 ? 2 : 1) * PLANE];  // slab index i <-> t = t0 - 1 + i; X3: heads, then tails
     __shared__ float red[2][NWV * R];
 
@@ -167,7 +178,7 @@ __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(Predict
     // (fragment order [step][32-channel group][2][lane]: a wave's fragments are contiguous for any NWV)
     const uint4* __restrict__ wbase = (const uint4*)p.wpk + wv * NFR * 64 + lane;
     const uint4* __restrict__ wbase_lo = X3 ? (const uint4*)p.wpk_lo + wv * NFR * 64 + lane : nullptr;
-    const int total = nl * PF_STEPS;
+    const int total = nl * STEPS;
     auto loadB = [&](uint4 (&b)[NFR], int g) {
         g = g < total ? g : total - 1;  // past the end: a harmless re-read instead of a branch
 #if defined(FS2_PF_PROBE) && (FS2_PF_PROBE & 1)
@@ -196,6 +207,60 @@ __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(Predict
 
     const int n0 = wv * (NFR * 16) + fg * 8;  // fragment pair j: this lane's channels n0 + 32*j .. +7
     for (int l = 0; l < nl; ++l) {
+        if constexpr (DW) {
+            // ---- depth-wise Conv1d(k = 3, groups = 256) over the slab, in place (model.py:545-551) ----
+            static_assert(NWV * 64 == 256 && R % 8 == 0, "depth-wise pass: 32 slots x 8 row groups");
+            constexpr int RPT = R / 8;  // rows per thread
+            int tid_d = tid;
+            asm volatile("" : "+v"(tid_d));  // (addresses re-derived per layer, not carried across the K loop)
+            const int L = tid_d & 31, i0 = 1 + (tid_d >> 5) * RPT;  // logical slot (channels 8 L ..), first slab row
+            f32x2_t wt[3][4], bs[4];
+            {
+                const float* wp = p.dw_w + (size_t)l * 3 * PF_H + L * 8;
+#pragma unroll
+                for (int tp = 0; tp < 3; ++tp) {
+                    const float4 a = *(const float4*)(wp + tp * PF_H), b = *(const float4*)(wp + tp * PF_H + 4);
+                    wt[tp][0] = (f32x2_t){a.x, a.y}; wt[tp][1] = (f32x2_t){a.z, a.w}; wt[tp][2] = (f32x2_t){b.x, b.y}; wt[tp][3] = (f32x2_t){b.z, b.w};
+                }
+                const float* bp = p.dw_b + (size_t)l * PF_H + L * 8;
+                const float4 a = *(const float4*)bp, b = *(const float4*)(bp + 4);
+                bs[0] = (f32x2_t){a.x, a.y}; bs[1] = (f32x2_t){a.z, a.w}; bs[2] = (f32x2_t){b.x, b.y}; bs[3] = (f32x2_t){b.z, b.w};
+            }
+            const SlabSwizzle sw(PF_ROWB / 16);
+            auto rowp = [&](int i) { return slab + i * PF_ROWB + (sw.slot(L, i) << 4); };
+            auto unpack = [](const uint4& v, f32x2_t (&f)[4]) {
+                const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) f[q] = (f32x2_t){__uint_as_float(u[q] << 16), __uint_as_float(u[q] & 0xffff0000u)};
+            };
+            uint4 raw[RPT + 2];
+#pragma unroll
+            for (int j = 0; j < RPT + 2; ++j) raw[j] = *(const uint4*)rowp(i0 - 1 + j);
+            uint4 o[RPT];
+            f32x2_t xa[4], xb[4], xc[4];
+            unpack(raw[0], xa);
+            unpack(raw[1], xb);
+#pragma unroll
+            for (int j = 0; j < RPT; ++j) {
+                unpack(raw[j + 2], xc);
+                unsigned w4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x2_t a = wt[0][q] * xa[q];  // = fma(w0, x, 0): dwconv_kernel's chain starts from a zero accumulator
+                    a = __builtin_elementwise_fma(wt[1][q], xb[q], a);
+                    a = __builtin_elementwise_fma(wt[2][q], xc[q], a);
+                    a = a + bs[q];
+                    w4[q] = pack_bf16x2(a.x, a.y);
+                    xa[q] = xb[q];
+                    xb[q] = xc[q];
+                }
+                o[j] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+            }
+            __syncthreads();  // every window has been read
+#pragma unroll
+            for (int j = 0; j < RPT; ++j) *(uint4*)rowp(i0 + j) = o[j];
+            __syncthreads();
+        }
         // The bias rides in as the C operand of a chain's FIRST MFMA (k-block 0 of tap 0 names the bias quad, the accumulator is
         // written, not read: no 112 v_mov per layer to seed the accumulators) - tap 0 is peeled for that.
         f32x4_t acc[NFR][MI16];
@@ -225,7 +290,7 @@ __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(Predict
         };
         auto tap = [&](int tp, auto FIRST) {
             constexpr bool first = decltype(FIRST)::value;
-            const int i0 = fr + tp;
+            const int i0 = fr + tp + (DW ? 1 : 0);  // DW: the pointwise conv reads its own row
             const unsigned char* arow_p = slab + i0 * PF_ROWB;
             const int acx = (((fg & 1) << 3) | ((fg >> 1) ^ (i0 & 7))) << 4;  // SlabSwizzle::slot(fg, i0); + kb below
             constexpr int HFB = MI16 - HFA;
@@ -243,12 +308,12 @@ __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(Predict
             };
             auto kblock = [&](auto KB0, int kb, uint4 (&fxa)[HFA], uint4 (&fxb)[HFA], uint4 (&fla)[HFA], uint4 (&flb)[HFA]) {
                 const int rs = (tp * PF_KB + kb) % RING, rn = (tp * PF_KB + kb + RING - 1) % RING;  // static after unrolling
-                loadB(bw[rn], (l * PF_TAPS + tp) * PF_KB + kb + RING - 1);
+                loadB(bw[rn], (l * TAPS + tp) * PF_KB + kb + RING - 1);
                 if constexpr (X3) {
                     // row block by row block: one (head, tail) fragment pair and its 3 NFR MFMAs (192 cycles), the next pair requested
                     // one block ahead (a two-deep ring in fxa[0..1] / fla[0..1], indexed by the running block count - static after
                     // unrolling): 16 fragment registers instead of the 64 of two half-tile sets of both planes
-                    loadBL(bwl[rn], (l * PF_TAPS + tp) * PF_KB + kb + RING - 1);
+                    loadBL(bwl[rn], (l * TAPS + tp) * PF_KB + kb + RING - 1);
 #pragma unroll
                     for (int mi = 0; mi < MI16; ++mi) {
                         const int c = kb * MI16 + mi, cur = c & 1, nxt = cur ^ 1;
@@ -315,7 +380,7 @@ __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(Predict
         tap(0, std::true_type{});
         if constexpr (RING == 4) {
 #pragma unroll 1
-            for (int tp = 1; tp < PF_TAPS; ++tp) tap(tp, std::false_type{});
+            for (int tp = 1; tp < TAPS; ++tp) tap(tp, std::false_type{});
         } else {
             tap(1, std::false_type{});
             tap(2, std::false_type{});
@@ -579,14 +644,15 @@ bool predictor_fused_supported(int dtype, int H, int taps, int nlayers, int S) {
            (size_t)S * PF_ROWB < 0xFFFFF000ull;
 }
 
-int launch_pack_predictor_weights(const void* w_layer, void* out_layer, hipStream_t stream) {
-    const int n = PF_STEPS * PF_STEP_U4;
+int launch_pack_predictor_weights(const void* w_layer, void* out_layer, hipStream_t stream, int taps) {
+    if (taps != 1 && taps != PF_TAPS) return FS2_ERR_SHAPE;
+    const int n = taps * PF_KB * PF_STEP_U4;
     hipLaunchKernelGGL(pack_predictor_weights_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (const bf16*)w_layer,
-                       (uint4*)out_layer);
+                       (uint4*)out_layer, taps);
     return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
 }
 
-size_t predictor_packed_bytes_per_layer() { return (size_t)PF_STEPS * PF_STEP_U4 * 16; }
+size_t predictor_packed_bytes_per_layer(int taps) { return (size_t)taps * PF_KB * PF_STEP_U4 * 16; }
 
 // the split-arithmetic form (fp32 rows in, PredictorArgs::wpk = the weights' bf16 heads, wpk_lo their tails; no embedding tail)
 bool predictor_fused_x3_supported(int H, int taps, int nlayers, int S) {
@@ -613,7 +679,12 @@ int launch_predictor_fused(const PredictorArgs& a, hipStream_t stream) {
     // the tile HEIGHT does not enter the arithmetic (rows are independent), the wave layout does: one
     // layout for everything, shorter tiles when 112-row tiles would leave most CUs without work
     if (a.be_y && (a.be_y == a.x || !a.be_bins || !a.be_emb || a.be_nbins < 2 || a.be_nbins - 1 > 512)) return FS2_ERR_ARG;
-    if (tiles(112) < 200 && 64 - halo2 >= 32) {
+    if ((a.dw_w != nullptr) != (a.dw_b != nullptr)) return FS2_ERR_ARG;
+    const bool small = tiles(112) < 200 && 64 - halo2 >= 32;
+    if (a.dw_w) {  // depth-wise layers: wpk holds the pointwise weights (one tap)
+        if (small) hipLaunchKernelGGL((predictor_fused_kernel<4, 4, 2, false, true>), dim3((unsigned)tiles(64)), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((predictor_fused_kernel<7, 4, 2, false, true>), dim3((unsigned)tiles(112)), dim3(256), 0, stream, a);
+    } else if (small) {
         hipLaunchKernelGGL((predictor_fused_kernel<4, 4, 2>), dim3((unsigned)tiles(64)), dim3(256), 0, stream, a);
     } else {
         hipLaunchKernelGGL((predictor_fused_kernel<7, 4, 2>), dim3((unsigned)tiles(112)), dim3(256), 0, stream, a);

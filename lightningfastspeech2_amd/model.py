@@ -475,8 +475,8 @@ class ForwardPipeline:
     may then be HOST tensors (pinned: copied to the device on the forward's own stream, no host wait), and the named outputs come back
     as PINNED HOST tensors: their device-to-host copies are queued on a per-replica copy stream behind the forward, so batch i's 15.7 MB
     of mels cross PCIe while batch i + 1's forward runs.  The bytes are those of ``model(batch, inference=True)[key].cpu()``.  A host
-    output is a view of a per-replica ring slot: it stays valid for the next ``in_flight`` calls of ``submit`` after it was handed over
-    (copy it or consume it before); the other outputs stay device tensors.
+    output is a view of a per-replica ring slot (four per replica, up to 2 x in_flight results pending): it stays valid for the next
+    ``in_flight`` calls of ``submit`` after it was handed over (copy it or consume it before); the other outputs stay device tensors.
     """
 
     def __init__(self, model: FastSpeech2, in_flight: int = 2, host_outputs=()):
@@ -484,7 +484,7 @@ class ForwardPipeline:
         if in_flight < 1:
             raise ValueError("in_flight >= 1")
         self.host_outputs = tuple(host_outputs)
-        self._ring = [[{} for _ in range(3)] for _ in range(in_flight)]  # [replica][slot] -> {key: flat pinned uint8 buffer}
+        self._ring = [[{} for _ in range(4)] for _ in range(in_flight)]  # [replica][slot] -> {key: flat pinned uint8 buffer}
         self._nrun = [0] * in_flight
         self.models = [model] + [model.replicate() for _ in range(in_flight - 1)]
         for m in self.models[1:]:
@@ -534,7 +534,7 @@ class ForwardPipeline:
     def _to_host(self, k, out, fwd_done):
         """Queue the device-to-host copies of the named outputs on replica k's copy stream (behind the forward, beside the next one)."""
         cs = self.copy_streams[k]
-        slot = self._ring[k][self._nrun[k] % 3]
+        slot = self._ring[k][self._nrun[k] % 4]
         self._nrun[k] += 1
         cs.wait_event(fwd_done)
         res = dict(out)
@@ -572,9 +572,15 @@ class ForwardPipeline:
         ready.record(torch.cuda.current_stream(self.device))
         self.pending.append(self.pools[k].submit(self._run, k, batch, ready))
         outs = []
-        while len(self.pending) > len(self.models):        # never more than in_flight behind: the host waits for the oldest
+        # never more than in_flight behind: the host waits for the oldest.  With host outputs a result is finished only when its copy has
+        # landed, which runs BESIDE the forwards (its replica is already on its next batch): the window counts one more round, so that
+        # waiting for batch i's copy does not keep batch i + in_flight + 1 from being queued
+        window = len(self.models) * (2 if self.host_outputs else 1)
+        while len(self.pending) > window:
             outs.append(self._hand_over(self.pending.pop(0)))
         while self.pending and self.pending[0].done():     # and whatever has finished in the meantime
+            if self.host_outputs and not self.pending[0].result()[1].query():
+                break                                       # (its host copy is still in flight: not finished yet)
             outs.append(self._hand_over(self.pending.pop(0)))
         return outs
 

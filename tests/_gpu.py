@@ -152,6 +152,24 @@ def predictor(x, ws, biases, gammas, betas, head_w, head_b, mask, B, S):
     return pred.cpu().reshape(B, S)
 
 
+def predictor_dw(x, dws, dwbs, ws, biases, gammas, betas, head_w, head_b, mask, B, S):
+    """Single-launch depth-wise VariancePredictor (bf16): dws = list of (H, 1, 3) depth-wise weights, ws = list of (H, H, 1) pointwise."""
+    H, nl = x.shape[-1], len(ws)
+    xd = to_dev(x.reshape(B * S, H), BF16)
+    wd = to_dev(torch.stack([w.reshape(H, H) for w in ws]), BF16)
+    f = lambda a: torch.stack([torch.as_tensor(v).float() for v in a]).to(DEV).contiguous()
+    dwd = f([w.reshape(H, 3).t().contiguous() for w in dws])   # (nl, 3, H) tap-major
+    dbd, bd, gd, bed = f(dwbs), f(biases), f(gammas), f(betas)
+    hw = torch.as_tensor(head_w).float().to(DEV)
+    mk = None if mask is None else torch.as_tensor(mask).to(torch.uint8).to(DEV).contiguous()
+    pred = torch.full((B * S,), float("nan"), dtype=torch.float32, device=DEV)
+    scratch = torch.empty(nl * H * H * 2, dtype=torch.uint8, device=DEV)
+    ok(lib().fs2_op_predictor_dw(BF16, p(xd), p(dwd), p(dbd), p(wd), p(bd), p(gd), p(bed), p(hw), float(head_b), p(mk), p(pred), p(scratch),
+                                 B, S, H, nl, stream()), "predictor_dw")
+    torch.cuda.synchronize()
+    return pred.cpu().reshape(B, S)
+
+
 def pack_conv_weight(w):
     """torch (N, Cin, k) -> (N, k*Cin) tap-major (what the engine builds at fs2_finalize)."""
     w = torch.as_tensor(w).float()

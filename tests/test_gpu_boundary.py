@@ -162,7 +162,7 @@ def test_forward_pipeline_with_the_host_boundary_inside_is_bit_identical():
     """model.pipeline(n, host_outputs=("mel", "tgt_mask")) (r06; the consumer modelled: generator.py:158-165, `mel[i][~tgt_mask[i]].cpu()`):
     pinned HOST batches in, the named outputs back as pinned host tensors whose device-to-host copies ran on a copy stream under the next
     forward.  Every batch: the same bytes as model(batch)[key].cpu(), in submission order, the other outputs still device tensors; results
-    are consumed at hand-over (a host output's ring slot is reused three runs of its replica later)."""
+    are consumed at hand-over (a host output's ring slot is reused four runs of its replica later)."""
     cfg, sd, inp, batch = _case()
     m = _model(cfg, sd, "bf16")
     rs = np.random.RandomState(5)

@@ -316,6 +316,65 @@ def test_predictor_single_launch(B, S, nl):
     assert torch.equal(again, got)
 
 
+def _predictor_dw_ref(x, dws, dwbs, ws, bs, gs, bes, hw, hb, mask):
+    """model.py:510-522 with depth-wise layers (:541-558) and the kernels' storage rounding: bf16 x / pointwise weights / depth-wise
+    outputs / inter-layer activations, fp32 arithmetic and fp32 depth-wise taps."""
+    r = lambda t: t.to(torch.bfloat16).float()
+    h = r(x)
+    H = x.shape[-1]
+    for j, (dw, dwb, w, b, g, be) in enumerate(zip(dws, dwbs, ws, bs, gs, bes)):
+        u = r(F.conv1d(h.transpose(1, 2), dw, dwb, padding=1, groups=H))
+        z = F.conv1d(u, r(w), b).transpose(1, 2)
+        h = F.layer_norm(torch.relu(z), (H,), g, be, 1e-5)
+        if j + 1 < len(ws):
+            h = r(h)
+    return (h @ hw + hb).masked_fill(mask, 0)
+
+
+def _dw_case(B, S, nl, seed):
+    H = 256
+    x = rnd(B, S, H, seed=seed)
+    dws = [rnd(H, 1, 3, seed=seed + 1 + j, scale=3 ** -0.5) for j in range(nl)]
+    dwbs = [0.2 * rnd(H, seed=seed + 20 + j) for j in range(nl)]
+    ws = [rnd(H, H, 1, seed=seed + 40 + j, scale=H ** -0.5) for j in range(nl)]
+    bs = [0.3 * rnd(H, seed=seed + 60 + j) for j in range(nl)]
+    gs = [1 + 0.2 * rnd(H, seed=seed + 80 + j) for j in range(nl)]
+    bes = [0.1 * rnd(H, seed=seed + 100 + j) for j in range(nl)]
+    hw, hb = rnd(H, seed=seed + 120, scale=H ** -0.5), 0.25
+    return x, dws, dwbs, ws, bs, gs, bes, hw, hb
+
+
+@pytest.mark.parametrize("B,S,nl", [(2, 300, 5), (3, 37, 2), (1, 1536, 5), (2, 217, 1), (4, 216, 5), (2, 450, 3), (5, 5, 5), (26, 1536, 5)])
+def test_depthwise_predictor_single_launch(B, S, nl):
+    """r06 (the reference's own predictor architecture, model.py:541-558): n x [dw conv k=3 -> pointwise -> ReLU -> LN] -> Linear -> mask
+    in ONE launch (predictor_fused_kernel<..., DW>: the depth-wise pass over the LDS-resident slab in place, one tap of the K loop):
+    tile seams (one stale row per layer and side), utterance edges (zero padding at every layer's depth-wise conv), masking, both tile
+    heights, against a torch restatement; repeatable."""
+    x, dws, dwbs, ws, bs, gs, bes, hw, hb = _dw_case(B, S, nl, 400)
+    mask = torch.zeros(B, S, dtype=torch.bool)
+    mask[:, S - S // 4:] = True
+    ref = _predictor_dw_ref(x, dws, dwbs, ws, bs, gs, bes, hw, hb, mask)
+    got = G.predictor_dw(x, dws, dwbs, ws, bs, gs, bes, hw, hb, mask, B, S)
+    assert not torch.isnan(got).any()
+    assert torch.equal(got[mask], torch.zeros_like(got[mask]))
+    err = float((got - ref).abs().max())
+    assert err <= 2e-2 * (float(ref.abs().max()) + 1), err
+    again = G.predictor_dw(x, dws, dwbs, ws, bs, gs, bes, hw, hb, mask, B, S)
+    assert torch.equal(again, got)
+
+
+def test_depthwise_predictor_tile_heights_are_bit_identical():
+    """As for the dense form: an utterance gives the same bits alone (64-row tiles) and inside a batch of 26 (112-row tiles)."""
+    B, S, nl = 26, 1536, 5
+    x, dws, dwbs, ws, bs, gs, bes, hw, hb = _dw_case(B, S, nl, 600)
+    mask = torch.zeros(B, S, dtype=torch.bool)
+    for b in range(B):
+        mask[b, S - 11 * b:] = True
+    whole = G.predictor_dw(x, dws, dwbs, ws, bs, gs, bes, hw, hb, mask, B, S)
+    alone = G.predictor_dw(x[3:5], dws, dwbs, ws, bs, gs, bes, hw, hb, mask[3:5], 2, S)
+    assert torch.equal(alone, whole[3:5])
+
+
 def test_predictor_tile_heights_are_bit_identical():
     """Which tile height runs (112-row tiles where they fill the chip, 64-row tiles for small launches) must not enter the
     arithmetic: same wave layout, same reduction tree - an utterance gives the same bits alone (64-row tiles) and inside a batch

@@ -221,6 +221,23 @@ def predictor_case(name, B, S, nl, reps):
           f"({fl/t/2.5e15*100:4.1f}% of 2.5 PF)")
 
 
+def predictor_dw_case(name, B, S, nl, reps):
+    """Whole depth-wise VariancePredictor (nl x [dw k=3 + pointwise + ReLU + LN], head) as one launch (r06)."""
+    H = 256
+    x = torch.randn(B * S, H, device=DEV).to(torch.bfloat16)
+    w = (torch.randn(nl, H, H, device=DEV) * H ** -0.5).to(torch.bfloat16)
+    dw = torch.randn(nl, 3, H, device=DEV) * 3 ** -0.5
+    dwb, b, g, be = (torch.randn(nl, H, device=DEV) for _ in range(4))
+    hw = torch.randn(H, device=DEV)
+    pred = torch.empty(B * S, device=DEV)
+    scratch = torch.empty(nl * H * H * 2, dtype=torch.uint8, device=DEV)
+    t = timeit(lambda st: lib.fs2_op_predictor_dw(BF16, p(x), p(dw), p(dwb), p(w), p(b), p(g), p(be), p(hw), C.c_float(0.1), None, p(pred),
+                                                  p(scratch), B, S, H, nl, st), reps)
+    fl = 2.0 * B * S * H * (H + 3) * nl
+    print(f"{name:28s} B={B} S={S} layers={nl}  {t*1e6:8.1f} us (incl. {nl} weight-pack launches)  {fl/t/1e12:7.1f} TF  "
+          f"({fl/t/2.5e15*100:4.1f}% of 2.5 PF)")
+
+
 def attn_case(name, B, S, H, heads, reps):
     qkv = torch.randn(B * S, 3 * H, device=DEV).to(torch.bfloat16)
     mask = torch.zeros(B, S, dtype=torch.uint8, device=DEV)
@@ -327,6 +344,8 @@ def main():
     if a.what in ("pred", "all"):
         predictor_case("variance predictor fused", 32, 1536, 5, a.reps)
         predictor_case("duration predictor fused", 32, 256, 2, a.reps)
+        predictor_dw_case("dw variance predictor fused", 32, 1536, 5, a.reps)
+        predictor_dw_case("dw duration predictor fused", 32, 256, 2, a.reps)
     if a.what in ("attn", "all"):
         if a.variant >= 1200: lib.fs2_op_set_gemm_variant(a.variant)   # 1200 phase-serial kernel, 1201 / 1202 pipelined, 1203 by size
         if a.shape: attn_case("custom attention", *[int(x) for x in a.shape.split(",")], a.reps)
