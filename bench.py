@@ -56,7 +56,8 @@ def parse():
     ap.add_argument("--no-fused-predictor", action="store_true", help="A/B: variance predictors layer by layer")
     ap.add_argument("--in-flight", type=int, default=2, help="forwards in flight (model.pipeline): 1 = one synchronous forward at a time; "
                     "the timed region takes the faster of 1 and this many, measured in the warm-up (FS2_BENCH_IN_FLIGHT pins it)")
-    ap.add_argument("--parity-sample", type=int, default=2, help="utterances of the workload the parity block checks")
+    ap.add_argument("--parity-sample", type=int, default=0,
+                    help="utterances of the workload the parity block checks against the oracle (0 = the whole batch, the default: ~3 s of CPU at C2)")
     return ap.parse_args()
 
 
@@ -143,7 +144,7 @@ def parity_block(cfg, sd, args, dev, timed_model):
     from lightningfastspeech2_amd.model import FastSpeech2
     from lightningfastspeech2_amd.weights import synth_inputs
     from oracle import oracle_cpu  # checker only
-    Bs = max(1, min(args.parity_sample, args.batch))
+    Bs = args.batch if args.parity_sample <= 0 else max(1, min(args.parity_sample, args.batch))
     inp = synth_inputs(cfg, args.batch, args.phones, seed=1234)
     ph, sp = inp["phones"][:Bs], inp["speaker"][:Bs]
     ref = oracle_cpu.forward(sd, cfg, ph, sp, return_intermediates=True)
@@ -192,8 +193,9 @@ def parity_block(cfg, sd, args, dev, timed_model):
         pipe.close()
         return one, piped
 
-    res = {"sample": f"first {Bs} of the {args.batch} utterances of the timed workload (as their own batch: utterances "
-                     f"are independent and unpadded here), oracle/oracle_cpu.py as the reference",
+    res = {"sample": (f"all {args.batch} utterances of the timed workload (the timed batch itself)" if Bs == args.batch else
+                      f"first {Bs} of the {args.batch} utterances of the timed workload (as their own batch: utterances "
+                      f"are independent and unpadded here)") + ", oracle/oracle_cpu.py as the reference; every mode below is checked on this sample",
            "buckets_compared": int(sum(ref_b[v].numel() for v in cfg.variances)),
            "durations_compared": int(ref["duration_rounded"].numel()),
            "note": "the workload's duration head is weight 0 / bias ln 7 (T fixed at 6 frames/phone), so duration flips are "

@@ -492,6 +492,8 @@ class ForwardPipeline:
         self.device = model.device
         self.streams = [torch.cuda.Stream(self.device) for _ in self.models]
         self.copy_streams = [torch.cuda.Stream(self.device) for _ in self.models] if self.host_outputs else []
+        self.up_streams = [torch.cuda.Stream(self.device) for _ in self.models] if self.host_outputs else []
+        self.copy_pools = [cf.ThreadPoolExecutor(max_workers=1) for _ in self.models] if self.host_outputs else []
         # one single-thread executor per replica: a replica's forwards run in submission order on its own thread and stream
         self.pools = [cf.ThreadPoolExecutor(max_workers=1) for _ in self.models]
         self.pending = []  # futures in submission order
@@ -521,14 +523,25 @@ class ForwardPipeline:
         with torch.cuda.device(self.device), torch.cuda.stream(self.streams[k]):
             self.streams[k].wait_event(ready)  # the caller's stream produced the batch
             self._record(batch, self.streams[k])  # ... and may release it before this stream has finished reading it
-            if self.host_outputs:  # host inputs ride this stream (pinned memory: no host wait; pageable memory degrades to a synchronous copy)
-                batch = {key: (v.to(self.device, non_blocking=True) if isinstance(v, torch.Tensor) and not v.is_cuda and key in ("phones", "speaker") else v)
-                         for key, v in batch.items()}
+            if self.host_outputs:
+                # host inputs go up on the replica's own (otherwise idle) upload stream: the runtime performs a SMALL copy synchronously with
+                # the host once the stream reaches it (measured r06, tools/probes/pcie_pipeline_probe.py: 66 KB of inputs queued behind the
+                # replica's previous forward cost +0.26 ms per batch) - on an idle stream that wait is the copy itself
+                with torch.cuda.stream(self.up_streams[k]):
+                    moved = {key: v.to(self.device, non_blocking=True) for key, v in batch.items()
+                             if isinstance(v, torch.Tensor) and not v.is_cuda and key in ("phones", "speaker")}
+                    up = torch.cuda.Event()
+                    up.record(self.up_streams[k])
+                self.streams[k].wait_event(up)
+                self._record(moved, self.streams[k])
+                batch = {**batch, **moved}
             out = self.models[k](batch, inference=True)
             done = torch.cuda.Event()
             done.record(self.streams[k])
             if self.host_outputs:
-                out, done = self._to_host(k, out, done)
+                # the device-to-host copies are queued by the replica's COPIER thread: the small ones (a 49 KB mask) block their caller until
+                # the copy stream reaches them, i.e. until this forward has finished - the forward thread must be back for the next batch by then
+                return self.copy_pools[k].submit(self._to_host, k, out, done), None
         return out, done
 
     def _to_host(self, k, out, fwd_done):
@@ -538,7 +551,7 @@ class ForwardPipeline:
         self._nrun[k] += 1
         cs.wait_event(fwd_done)
         res = dict(out)
-        with torch.cuda.stream(cs):
+        with torch.cuda.device(self.device), torch.cuda.stream(cs):
             for key in self.host_outputs:
                 src = out[key]
                 if not isinstance(src, torch.Tensor) or not src.is_cuda:
@@ -557,6 +570,8 @@ class ForwardPipeline:
 
     def _hand_over(self, fut):
         out, done = fut.result()
+        if done is None:  # host outputs: the copier's future
+            out, done = out.result()
         cur = torch.cuda.current_stream(self.device)
         cur.wait_event(done)
         self._record(out, cur)  # allocated on the pipeline's stream, consumed (and possibly dropped) on the caller's
@@ -579,8 +594,10 @@ class ForwardPipeline:
         while len(self.pending) > window:
             outs.append(self._hand_over(self.pending.pop(0)))
         while self.pending and self.pending[0].done():     # and whatever has finished in the meantime
-            if self.host_outputs and not self.pending[0].result()[1].query():
-                break                                       # (its host copy is still in flight: not finished yet)
+            if self.host_outputs:  # finished = its host copies have landed
+                cf_ = self.pending[0].result()[0]
+                if not cf_.done() or not cf_.result()[1].query():
+                    break
             outs.append(self._hand_over(self.pending.pop(0)))
         return outs
 
@@ -591,5 +608,5 @@ class ForwardPipeline:
 
     def close(self):
         self.drain()
-        for p in self.pools:
+        for p in self.pools + self.copy_pools:
             p.shutdown(wait=True)

@@ -5,7 +5,9 @@ Per config: (a) the size-independent properties at the full per-GPU batch in the
 bit-equal reruns, shard == whole (the data-parallel invariant), a speaker change touches exactly one utterance; (b) one
 full-length utterance in fp32 parity mode against the CPU oracle, mel <= 1e-3 under the oracle's decisions, free-running
 flips reported (a 5e-6 prediction difference next to one of 255 bucket edges flips a frame or two at this size, as it would
-between two CPUs - see test_gpu_forward.test_full_size_fp32_vs_oracle_one_utterance).
+between two CPUs - see test_gpu_forward.test_full_size_fp32_vs_oracle_one_utterance); (c) r06: the FULL per-GPU batch against the
+oracle - every entry of the (32, 1536, 80) / (8, 1536, 80) mel in fp32 at 1e-3 and in bf16 at the bf16 tolerance under the oracle's
+decisions, the free-running flips classified (0 unexplained), plus a ragged full-length C5 batch.
 """
 import functools
 
@@ -166,3 +168,83 @@ def test_folded_layernorm_against_its_own_passes():
     assert float(d_ab.max()) <= BF16_MEL_MAX
     assert float(e_a.max()) <= BF16_MEL_MAX and float(e_a.mean()) <= BF16_MEL_MEAN
     assert float(e_a.mean()) <= 1.5 * float(e_b.mean()) + 1e-4   # no worse than the materialised form
+
+
+# ---- r06 (VERDICT r05 "what's weak" 2): the oracle at the FULL per-GPU batch of configs[2] / configs[4] --------------------------------
+# The shapes the persistent GEMM, the folded LayerNorms and the head-sum epilogues actually run at (49152 rows at C3): every entry of the
+# (B, 1536, 80) mel against the CPU oracle, not properties only.
+
+def _oracle_full(name, B, lengths=None, ragged_head=False):
+    cfg = preset(name)
+    if ragged_head:
+        sd = synth_state_dict(cfg, 4, randomize_norm=True, duration_bias=float(np.log(6.0)), duration_weight_scale=0.5)
+    else:
+        sd = _weights(name)[1]
+    inp = synth_inputs(cfg, B, 256, seed=1234 if lengths is None else 4321, lengths=lengths)
+    ref = oracle_cpu.forward(sd, cfg, inp["phones"], inp["speaker"], return_intermediates=True)
+    return cfg, sd, inp, ref
+
+
+@pytest.mark.parametrize("name", ["c3", "c5"])
+def test_full_config_full_batch_vs_oracle(name):
+    """BASELINE configs[2] at B = 32 and the per-GPU share of configs[4] at B = 8, 256 phonemes -> T = 1536, every utterance against the
+    oracle: fp32 mode - durations equal, mel <= 1e-3 over the WHOLE (B, 1536, 80) tensor under the oracle's decisions, every free-running
+    bucket flip a near-tie or in the cone of one (0 unexplained); bf16 (the timed mode: persistent GEMM, folded LayerNorms, head sums from
+    the epilogue at C3) under the oracle's decisions at the bf16 tolerance."""
+    from test_gpu_parity_corners import BF16_MEL_MAX, BF16_MEL_MEAN, _free_buckets, _near_tie_report
+    B = FULL[name]
+    cfg, sd, inp, ref = _oracle_full(name, B)
+    batch = {"phones": torch.from_numpy(inp["phones"]), "speaker": torch.from_numpy(inp["speaker"])}
+    forced_kw = dict(force_durations=ref["duration_rounded"], force_buckets={v: ref["_intermediates"][f"bucket_{v}"] for v in cfg.variances})
+    m = _model(cfg, sd, "fp32")
+    m.engine.set_debug(True)
+    free = _cpu(m(batch, inference=True))
+    assert tuple(free["mel"].shape) == (B, 1536, 80)
+    assert torch.equal(free["duration_rounded"], ref["duration_rounded"]) and torch.equal(free["tgt_mask"], ref["tgt_mask"])
+    nt = _near_tie_report(cfg, sd, ref, _free_buckets(m, cfg))
+    forced = _cpu(m.forward(batch, **forced_kw))
+    err32 = float((forced["mel"] - ref["mel"]).abs().max())
+    enc = float((m.engine.debug_tensor("encoder_out").cpu() - ref["_intermediates"]["encoder_out"]).abs().max())
+    del m
+    torch.cuda.empty_cache()
+    m16 = _model(cfg, sd, "bf16")
+    out16 = _cpu(m16.forward(batch, **forced_kw))
+    e16 = (out16["mel"] - ref["mel"]).abs()
+    nb = B * 1536 * len(cfg.variances)
+    _report(test="full_config_full_batch", case=name, batch=B, buckets=nb, fp32_mel_forced=err32, fp32_encoder_out=enc, near_tie=nt,
+            bf16_mel_forced_max=float(e16.max()), bf16_mel_forced_mean=float(e16.mean()), mel_scale=float(ref["mel"].abs().max()))
+    assert err32 <= MEL_TOL_FP32 and enc <= MEL_TOL_FP32
+    assert nt["unexplained"] == 0, nt
+    assert sum(nt[v]["flips"] for v in cfg.variances) <= nb // 100, nt
+    assert float(e16.max()) <= BF16_MEL_MAX and float(e16.mean()) <= BF16_MEL_MEAN, (float(e16.max()), float(e16.mean()))
+
+
+def test_c5_ragged_full_length_batch_vs_oracle():
+    """configs[4]'s per-GPU batch (B = 8) RAGGED at full length: phone lengths [256] + U{128..256}, a random duration head (every utterance
+    its own frame count, a real tgt_mask, key padding in the 8-head decoder attention) - fp32 at 1e-3 under the oracle's decisions with 0
+    unexplained flips, bf16 at the bf16 tolerance."""
+    from test_gpu_parity_corners import BF16_MEL_MAX, BF16_MEL_MEAN, _free_buckets, _near_tie_report
+    rs = np.random.RandomState(28)
+    lengths = [256] + [int(rs.randint(128, 257)) for _ in range(7)]
+    cfg, sd, inp, ref = _oracle_full("c5", 8, lengths=lengths, ragged_head=True)
+    T = int(ref["mel"].shape[1])
+    assert bool(ref["tgt_mask"].any()) and bool(ref["src_mask"].any()) and 900 <= T <= 2756
+    batch = {"phones": torch.from_numpy(inp["phones"]), "speaker": torch.from_numpy(inp["speaker"])}
+    m = _model(cfg, sd, "fp32")
+    m.engine.set_debug(True)
+    free = _cpu(m(batch, inference=True))
+    got_d = free["duration_rounded"].numpy()
+    out = _cpu(m.forward(batch, force_durations=ref["duration_rounded"]))
+    assert torch.equal(out["tgt_mask"], ref["tgt_mask"])
+    nt = _near_tie_report(cfg, sd, ref, _free_buckets(m, cfg), got_d)
+    forced_kw = dict(force_durations=ref["duration_rounded"], force_buckets={v: ref["_intermediates"][f"bucket_{v}"] for v in cfg.variances})
+    forced = _cpu(m.forward(batch, **forced_kw))
+    err32 = float((forced["mel"] - ref["mel"]).abs().max())
+    del m
+    torch.cuda.empty_cache()
+    out16 = _cpu(_model(cfg, sd, "bf16").forward(batch, **forced_kw))
+    e16 = (out16["mel"] - ref["mel"]).abs()
+    _report(test="c5_ragged_full_length", T=T, lengths=lengths, fp32_mel_forced=err32, near_tie=nt, bf16_mel_forced_max=float(e16.max()),
+            bf16_mel_forced_mean=float(e16.mean()))
+    assert err32 <= MEL_TOL_FP32 and nt["unexplained"] == 0, (err32, nt)
+    assert float(e16.max()) <= BF16_MEL_MAX and float(e16.mean()) <= BF16_MEL_MEAN, (float(e16.max()), float(e16.mean()))
