@@ -270,7 +270,7 @@ def training_block(cfg, sd, args, inp, T):
             "loss_total": float(losses["total"]), "extra_mem_GB": (torch.cuda.max_memory_allocated() - del_model_mem) / 2**30}
 
 
-CU_INGEST_GBS = 64.0   # per-CU L2 -> LDS ceiling measured on this part (tools/probes/cu_ingest.hip: 61-69 GB/s)
+CU_INGEST_GBS = 64.0   # per-CU L2 -> LDS ceiling measured on this part (tools/probes/cu_ingest.hip: 61-69 GB/s, profiles/HISTORY.md §4)
 N_CUS = 256
 
 
@@ -305,7 +305,7 @@ def encoder_mha_ingest_bound(cfg, B, L, block_s):
             "measured_us": round(block_s * 1e6, 2), "frac": bound / (block_s * 1e6) if block_s > 0 else 0.0, "launches": per,
             "reading": "the three launches stream for bound_us of the measured time; the rest is what a 10-us launch is made of besides its "
                        "stream - dispatch and ramp over 256 CUs, the first operand round trip, the LayerNorm epilogue's row exchange, the store "
-                       "drain - per launch ~2.5 us of stream against ~8 us of fixed cost (DESIGN 4, 'the encoder launches').  Fusing the block "
+                       "drain - per launch ~2.5 us of stream against ~8 us of fixed cost (profiles/HISTORY.md §4, 'the encoder launches').  Fusing the block "
                        "per utterance was sized and not built: 32 utterances x 4 query blocks = 128 workgroups, each re-projecting its head's K "
                        "and V for all 256 keys (101 MFLOP per workgroup) = ~25 us on half the CUs against the ~33 us of the three launches"}
 
@@ -660,7 +660,7 @@ def main():
                 "achieved": att_tf, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": att_tf * 1e12 / peak,
                 "avg_launch_us": att_s * 1e6, "launches_timed": prof_att["launches"], "flops_per_launch": prof_att["flops"] / na,
                 "what": "BASELINE.json north_star: >= 40 % of the bf16 MFMA roofline on the attention GEMMs; the encoder's instance "
-                        "(256 keys) is ingest-bound (DESIGN 4), this is the MFMA-bound one; HIP events, own pass of eager steps"},
+                        "(256 keys) is ingest-bound (profiles/HISTORY.md §4), this is the MFMA-bound one; HIP events, own pass of eager steps"},
             "encoder_mha_block": (lambda n_, s_: {
                 "kernel": "encoder self-attention block = three launches per layer: in-projection GEMM, attention_kernel (256 keys: ingest-bound), "
                           "out-projection + residual + LayerNorm (fused epilogue)",
@@ -669,7 +669,7 @@ def main():
                 "flops_per_block": prof_mha["flops"] / n_,
                 "ingest_roofline": encoder_mha_ingest_bound(cfg, args.batch, args.phones, s_),
                 "what": "BASELINE.json north_star names the encoder attention; SURVEY 8d: only the fused block (8 B L H^2 + 4 B L^2 H, AI ~ 724) can "
-                        "be MFMA-bound.  NOT fused here (DESIGN 0 item 1): at B x L = 8192 rows the block's three launches are neither MFMA- nor "
+                        "be MFMA-bound.  NOT fused here (DESIGN.md §4.3): at B x L = 8192 rows the block's three launches are neither MFMA- nor "
                         "HBM-bound - `ingest_roofline` prices them against what bounds a launch of this size, the bytes each CU pulls through "
                         "L2 -> LDS at the measured per-CU ceiling; `frac` against the MFMA peak is kept for the record; HIP events around the "
                         "block, one forward at a time"})(max(prof_mha["launches"], 1), prof_mha["ms"] / max(prof_mha["launches"], 1) * 1e-3),

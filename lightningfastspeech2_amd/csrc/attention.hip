@@ -92,7 +92,7 @@ __device__ inline float half_sum(float x) {
 // (GemmArgs::C_lo) or by split_hi_lo_kernel - and every product is three bf16 MFMAs, lo*hi + hi*lo + hi*hi in the fp32 accumulator
 // (small terms first; the dropped lo*lo is 2^-16 of the product), P split the same way in registers.  Softmax, running max, the
 // denominator and O stay fp32.  Against the fp32-MFMA form of this kernel (32x32x2, 1/16 of the bf16 rate): 3/16 of the matrix
-// time; the decoder launch at C2 went 714 us -> see DESIGN 5.
+// time; the decoder launch at C2 went 714 us -> see profiles/HISTORY.md §5.
 template <typename T, int D, int NW, bool X3 = false>
 __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128) ? 2 : 1) void attention_kernel(AttnArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins exist in the device pass only
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(AttnArgs p) {
 // (r03: a resident-K/V form for <= 256 keys - all of an (utterance, head)'s K and V requested at the top of the kernel into 128 KiB of
 // LDS, two barriers in all - was built, bit-identical, and measured no faster: C2 encoder 13.1 us vs 13.6 streaming, C3 encoder 28.1
 // vs 19.3; the 128 KiB a workgroup pulls before its first MFMA arrive at the CU's ingest rate whatever the request pattern, and two
-// co-resident streaming workgroups hide each other's round trips.  Removed in r05; DESIGN 4 keeps the numbers.)
+// co-resident streaming workgroups hide each other's round trips.  Removed in r05; profiles/HISTORY.md §4 keeps the numbers.)
 template <typename T, int D>
 static int launch_tv(const AttnArgs& a, hipStream_t stream) {
     hipLaunchKernelGGL((transpose_v_kernel<T, D>), dim3(a.Spad / 64, a.B * a.heads), dim3(256), 0, stream, a);

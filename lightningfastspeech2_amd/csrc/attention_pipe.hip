@@ -5,7 +5,7 @@
 //
 //   attention.hip runs a KV tile as  [16 Q.K^T MFMAs] [softmax VALU] [16 P.V MFMAs]  per wave: the matrix pipe idles while the
 //   ~200 softmax instructions issue and the issue port idles while MFMAs drain (PMC: MFMA pipe 44 % busy, 5 VALU per MFMA), and
-//   a second wave on the SIMD does not fill the holes (the arbiter serves the oldest wave).  Here one wave per SIMD
+//   a second wave on the SIMD does not fill the holes (the arbiter serves the oldest wave; profiles/HISTORY.md §4).  Here one wave per SIMD
 //   runs [1 MFMA, <= 5 other instructions] over and over (an in-order wave gets issue slots only in the shadow of its own last
 //   MFMA; tools/probes/mfma_filler_cost.hip), and every MFMA phase carries the softmax "units" of ANOTHER 32-key half tile:
 //

@@ -373,7 +373,7 @@ template <bool B> struct BoolC { static constexpr bool value = B; };
 // rows, re-reads and normalises its own rows - which only tied two launches at M = 49152, K = 768 (118 vs 120 us) and lost elsewhere
 // (K = 3072: 357 vs 294 us; M = 8192 / 12288: 1.5-2.2x slower); r04 an operand RING of 3 / 4 stages for pointwise launches on short
 // tiles, measured neutral (these launches are bound by what a CU ingests per second, not by a step's round trip).  Both removed in r05;
-// DESIGN 4 keeps the measurements.)
+// profiles/HISTORY.md §4 keeps the measurements.)
 // SPLIT (T = float only): fp32 operands, bf16 x 3 arithmetic.  Each fp32 value is split in registers into a bf16 head
 // and a bf16 tail (x = hi + lo up to 2^-17 |x|) and a product becomes three bf16 MFMAs, hi*hi + hi*lo + lo*hi, accumulated
 // in fp32 (the dropped lo*lo term is 2^-16 of the product): ~1e-5 relative, ~400x closer to fp32 than bf16 storage, at
@@ -784,7 +784,7 @@ __global__ __launch_bounds__(512) void gemm_conv_slab_kernel(GemmArgs p) {
         // shuffles -> one LDS exchange between the four column waves; optional predictor head.
         const size_t rowbase = (size_t)ub * S;
         // On a SIMD the epilogue's VALU instructions and the MFMA passes of the other resident wave mostly ADD UP
-        // (for the K = 256 launches this epilogue is as many issue cycles as the K loop), so the
+        // (profiles/HISTORY.md §4, §7; for the K = 256 launches this epilogue is as many issue cycles as the K loop), so the
         // per-element selects that only matter for N < 256, for ReLU or for the predictor head are compiled out
         // of the common case by workgroup-uniform dispatch - same arithmetic, same order, same results.
         const bool full = p.N == S_BN;

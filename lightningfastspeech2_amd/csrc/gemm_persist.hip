@@ -1,7 +1,7 @@
 // Persistent form of the slab GEMM / implicit-GEMM conv (gemm_mfma.hip) for launches of MANY tiles per CU: bf16 in, bf16 out,
 // plain (bias [+ ReLU]) or deferred-LayerNorm epilogue.
 //
-// Why (r04 / r05 measurements): the K = 768 GEMMs of the LightSpeech configs (M = 49152; 768 .. 2304 tiles of 12
+// Why (r04 / r05 measurements, profiles/HISTORY.md §4): the K = 768 GEMMs of the LightSpeech configs (M = 49152; 768 .. 2304 tiles of 12
 // K-steps each on 256 CUs) ran at 0.95-1.0 PFLOP/s where the same K loop reaches 1.39 on the 36-step decoder conv - per tile a
 // workgroup pays its launch, the round trip of its first operand DMAs, a bias fetch, 128 KB of stores draining with nothing else
 // in flight and its teardown: ~7 k of ~44 k cycles.  Here ONE workgroup per CU walks its tiles:

@@ -2,7 +2,7 @@
 //
 // The slab kernel (gemm_mfma.hip) re-streams a column tile's 256 x 256 weight block (128 KiB) through LDS for every row tile:
 // the decoder's MHA in-projection (M = 49152, N = 768, K = 256) moves 672 KB per 128-row tile of which 512 KB are weights, and
-// runs at a third of the rate its 100 MB of activations would allow ("what bounds the GEMM launches").  Here a
+// runs at a third of the rate its 100 MB of activations would allow (profiles/HISTORY.md §4, "what bounds the GEMM launches").  Here a
 // workgroup (8 waves, 2 x 4 as in the slab kernel) loads its column tile's weights ONCE, straight from global memory into MFMA
 // fragments - a wave's 64 channels x 256 k = 32 KiB = 128 VGPRs per lane - and then walks row tiles of 96 rows: the only LDS
 // traffic is the activation tile (48 KiB, double-buffered, buffer-load-to-LDS DMA with the SlabSwizzle applied on the source

@@ -387,7 +387,7 @@ __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(Predict
         }
 
         // ---- ReLU + LayerNorm (r03: packed fp32) ----  lane: rows (m*16 + fr), channels n0 + 32*(ni>>1) + (ni&1)*4 + r.
-        // The epilogue's VALU stream runs NEXT to the co-resident workgroup's MFMAs on the same SIMD and the two add up:
+        // The epilogue's VALU stream runs NEXT to the co-resident workgroup's MFMAs on the same SIMD and the two add up (profiles/HISTORY.md §4):
         // before, ~1400 VALU per layer and wave against 672 MFMAs (fmaxf on an MFMA result = a canonicalising v_max + the v_max,
         // scalar adds / subtracts / squares, an IEEE 1/sqrt of ~35 instructions per row).  Now: one v_max per element, the row
         // sums / centring / squares on v_pk_add_f32 / v_pk_fma_f32 (two elements per instruction; the partial sums pair up as
@@ -613,7 +613,7 @@ __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(Predict
 // Two tiles per workgroup, one wave per SIMD (r03): the LayerNorm epilogue of one tile is issued BETWEEN the MFMAs of the other
 // tile's K loop.  In the kernel above a layer is [672 MFMAs] [~1300 VALU of ReLU / LayerNorm / pack] per wave, and the second
 // workgroup on the CU does not fill the VALU phase with its MFMAs (the issue arbiter serves the older wave; s_setprio changes
-// nothing: DESIGN 4) - MFMA pipe 0.48 busy.  Here a 4-wave workgroup owns tiles A and B (two 114-row slabs in LDS, both
+// nothing: profiles/HISTORY.md §4) - MFMA pipe 0.48 busy.  Here a 4-wave workgroup owns tiles A and B (two 114-row slabs in LDS, both
 // accumulator sets in the 512-register file) and runs
 //     K(A,0) | K(B,0) + E(A,0) | K(A,1) + E(B,0) | K(B,1) + E(A,1) | ... | K(B,n-1) + E(A,n-1) | E(B,n-1)
 // where K + E means: one MFMA, then the next one or two instructions of the other tile's epilogue, then the next MFMA (two
@@ -627,7 +627,7 @@ __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(Predict
 // K), but the K loop itself runs at 22-30 cycles per 16-cycle MFMA: its own loads, address arithmetic and waits (~1 instruction
 // per gap) plus two epilogue instructions per gap are more than a 16x16x32 gap absorbs, and fill + drain are a quarter of the
 // kernel.  The form that can pass 0.45 of peak is this schedule on 32x32x16 MFMAs (32-cycle gaps, five fillers each, as the
-// attention kernel) - in EVERY predictor variant at once, because the MFMA shape enters the rounding.
+// attention kernel) - in EVERY predictor variant at once, because the MFMA shape enters the rounding (profiles/HISTORY.md §4 "Round 3").
 #ifdef FS2_PRED_PROBE  // tools/probes/pred_pair_stamps.py: s_memtime of workgroup 0 / wave 0 at every segment boundary
 __device__ unsigned long long g_pred_stamps[64];
 #define PRED_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_pred_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -638,7 +638,7 @@ __device__ unsigned long long g_pred_stamps[64];
 // 4-wave workgroup per CU (148-152 us against 112 for two 112-row workgroups per CU on the C2 variance predictor: with one wave per
 // SIMD nothing runs under the LayerNorm epilogue, whose VALU stream is as long as the layer's MFMA stream) and a one-wave-per-SIMD
 // workgroup that owns two 112-row tiles and issues one tile's epilogue between the other's MFMAs (120.4 us: the K loop itself runs
-// at 22-30 cycles per 16-cycle MFMA and a 16x16x32 gap absorbs about two fillers).  DESIGN 4 "Round 3" keeps the measurements.)
+// at 22-30 cycles per 16-cycle MFMA and a 16x16x32 gap absorbs about two fillers).  profiles/HISTORY.md §4 "Round 3" keeps the measurements.)
 bool predictor_fused_supported(int dtype, int H, int taps, int nlayers, int S) {
     return dtype == FS2_BF16 && H == PF_H && taps == PF_TAPS && nlayers >= 1 && nlayers <= 16 && S >= 1 &&
            (size_t)S * PF_ROWB < 0xFFFFF000ull;

@@ -458,7 +458,7 @@ class ForwardPipeline:
     replica (own workspace arenas, own host-side state), one HIP stream and one host thread per forward in flight; ctypes
     releases the GIL inside the library, so the threads drive their streams concurrently.  Outputs are bit-identical to
     ``model(batch, inference=True)`` (same engine code, same kernels; tests/test_gpu_boundary.py).  Measured r04 at C2, batch 32:
-    2.06 -> ~1.9 ms per batch with two in flight.
+    2.06 -> ~1.9 ms per batch with two in flight (profiles/HISTORY.md §4).
 
         pipe = model.pipeline(2)
         for batch in batches:

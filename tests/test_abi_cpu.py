@@ -120,7 +120,7 @@ def test_product_package_never_imports_the_oracle():
 
 
 def test_split_k_choice_is_a_pure_shape_function(lib):
-    """fs2_op_gemm_splitk_choice runs on the host: the shapes the training step meets (DESIGN 9).  A long reduction over few row tiles
+    """fs2_op_gemm_splitk_choice runs on the host: the shapes the training step meets (DESIGN.md §9).  A long reduction over few row tiles
     splits (the encoder-side data-gradient convs), launches that already fill the chip or reduce over a short K do not."""
     BF16, F32 = 1, 0
     f = lib.fs2_op_gemm_splitk_choice
