@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define FS2_ABI_VERSION 3
+#define FS2_ABI_VERSION 4
 #define FS2_MAX_LAYERS 32
 #define FS2_MAX_VARIANCES 4
 #define FS2_MAX_PRIORS 8   /* hparams.priors: the shipped recipe lists five (scripts/train.sh:49: energy duration snr pitch srmr) */
@@ -82,7 +82,7 @@ typedef struct fs2_config {
     int32_t enc_kernels[FS2_MAX_LAYERS];
     int32_t dec_layers, dec_heads, dec_filter, dec_depthwise;
     int32_t dec_kernels[FS2_MAX_LAYERS];
-    int32_t n_variances;   /* frame-level, transform 'none', in hparams order */
+    int32_t n_variances;   /* hparams.variances in order; level per variance in var_level (ABI v4), transform in var_cwt */
     char var_names[FS2_MAX_VARIANCES][FS2_NAME_LEN];
     int32_t var_nlayers[FS2_MAX_VARIANCES];
     int32_t var_kernel[FS2_MAX_VARIANCES];
@@ -95,6 +95,9 @@ typedef struct fs2_config {
     int32_t var_cwt[FS2_MAX_VARIANCES];  /* variance_transforms[i] == "cwt" (the class default for pitch, fastspeech2.py:60):
                               the CWT head of VarianceEncoder (model.py:412-431,445-461): predictor.linear is (10, filter),
                               mean_std_linear (2, filter) exists, bins are log-spaced; var_mean/var_std must be 0 / 1 */
+    int32_t var_level[FS2_MAX_VARIANCES];  /* ABI v4: 0 = frame level (variance_levels[i] == "frame": predicted on the regulated frames,
+                              model.py:315-333), 1 = phone level ("phone", model.py:276-294: predicted on the encoder output after the
+                              duration predictor has run, its embedding added BEFORE the length regulator; (B, L) outputs) */
 } fs2_config;
 
 typedef struct fs2_engine fs2_engine;
@@ -107,9 +110,9 @@ typedef struct fs2_outputs {
     int32_t* duration_rounded;     /* (B, L) (model.py:299-309) */
     uint8_t* src_mask;             /* (B, L) phones == 0 (fastspeech2.py:651) */
     uint8_t* tgt_mask;             /* (B, T) t >= total_b (model.py:358-361) */
-    float* variances[FS2_MAX_VARIANCES];  /* (B, T) each, 0 at pads (model.py:328); for a CWT variance the recomposed
-                                             log-domain signal (exp of it = the reference's "reconstructed_signal") */
-    float* var_spectrogram[FS2_MAX_VARIANCES];  /* CWT variances only: (B, T, 10) wavelet spectrogram, 0 at pads */
+    float* variances[FS2_MAX_VARIANCES];  /* (B, T) each - (B, L) for a phone-level variance -, 0 at pads (model.py:328); for a CWT
+                                             variance the recomposed log-domain signal (exp of it = the reference's "reconstructed_signal") */
+    float* var_spectrogram[FS2_MAX_VARIANCES];  /* CWT variances only: (B, T, 10) ((B, L, 10) at phone level) wavelet spectrogram, 0 at pads */
     float* var_mean_std[FS2_MAX_VARIANCES];     /* CWT variances only: (B, 2) utterance-level mean, std (model.py:414-415) */
 } fs2_outputs;
 
@@ -190,13 +193,15 @@ int fs2_set_folded_layernorm(fs2_engine* e, int32_t on);
 int fs2_set_tuning(fs2_engine* e, int32_t knob);
 /* Parity aid (the analogue of the reference's teacher forcing of variance targets,
  * model.py:417-422): the NEXT fs2_decode embeds these (B, T) int32 device bucket indices for
- * variance `variance_index` instead of bucketizing its own prediction.  One-shot. */
+ * variance `variance_index` instead of bucketizing its own prediction.  One-shot.  For a PHONE-level variance the indices
+ * are (B, L) and are consumed by the NEXT fs2_encode (call before it). */
 int fs2_force_buckets(fs2_engine* e, int32_t variance_index, const int32_t* idx_device);
 /* Teacher forcing as the reference's non-inference forward does it (model.py:317-325,417-422): the
  * NEXT fs2_decode embeds bucketize(target*std + mean) of these (B, T) fp32 device target values for
  * variance `variance_index`; the prediction is still computed and returned.  One-shot.  Together
  * with fs2_encode's forced_durations (= targets["duration"], model.py:296-297) this is
- * FastSpeech2.forward(batch, inference=False) without the loss. */
+ * FastSpeech2.forward(batch, inference=False) without the loss.  A PHONE-level variance (model.py:278-286) takes (B, L)
+ * targets, consumed by the NEXT fs2_encode (call before it). */
 int fs2_force_variance_targets(fs2_engine* e, int32_t variance_index, const float* target_device);
 int fs2_debug_copy(fs2_engine* e, const char* what, void* dst_device, void* hip_stream);
 

@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("FS2_LIB") or os.path.join(_HERE, "libfs2_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "fs2.h")
 
-FS2_ABI_VERSION = 3
+FS2_ABI_VERSION = 4
 FS2_MAX_LAYERS = 32
 FS2_MAX_VARIANCES = 4
 FS2_MAX_PRIORS = 8
@@ -48,6 +48,7 @@ class Fs2ConfigC(C.Structure):
         ("n_priors", C.c_int32),
         ("prior_names", (C.c_char * FS2_NAME_LEN) * FS2_MAX_PRIORS),
         ("var_cwt", C.c_int32 * FS2_MAX_VARIANCES),
+        ("var_level", C.c_int32 * FS2_MAX_VARIANCES),
     ]
 
 
@@ -274,6 +275,7 @@ def config_to_c(cfg, dtype: int) -> Fs2ConfigC:
         c.var_kernel[i] = cfg.variance_kernel_size[i]
         cwt = cfg.is_cwt(i)  # the CWT head bucketises its recomposed log-domain signal directly (model.py:427-428)
         c.var_cwt[i] = int(cwt)
+        c.var_level[i] = int(cfg.is_phone_level(i))
         c.var_mean[i] = 0.0 if cwt else cfg.stats[v]["mean"]
         c.var_std[i] = 1.0 if cwt else cfg.stats[v]["std"]
     c.var_filter, c.var_nbins = cfg.variance_filter_size, cfg.variance_nbins

@@ -98,9 +98,8 @@ class Fs2Config:
                 and len(self.variance_nlayers) >= nv and len(self.variance_kernel_size) >= nv):
             raise ValueError("variance_* lists shorter than variances")
         for i, v in enumerate(self.variances):
-            if self.variance_levels[i] != "frame":
-                raise ValueError("only frame-level variances are on the accelerated path "
-                                 "(SURVEY §8a; phone-level loop model.py:276-294 is off-path)")
+            if self.variance_levels[i] not in ("frame", "phone"):  # model.py:276 / :316
+                raise ValueError(f"variance_levels[{i}]={self.variance_levels[i]!r}: the reference knows 'frame' and 'phone'")
             if self.variance_transforms[i] not in ("none", "cwt"):
                 raise ValueError(f"variance_transforms[{i}]={self.variance_transforms[i]!r}: the reference knows 'none' and 'cwt'")
             if self.variance_transforms[i] == "cwt":  # VarianceEncoder takes log(min), log(max) (model.py:394-396)
@@ -123,6 +122,10 @@ class Fs2Config:
     # ---- (de)serialisation ----------------------------------------------------------------
     def is_cwt(self, i: int) -> bool:
         return self.variance_transforms[i] == "cwt"
+
+    def is_phone_level(self, i: int) -> bool:
+        """variance i is predicted per phone, before the length regulator (model.py:276-294), not per frame (:315-333)"""
+        return self.variance_levels[i] == "phone"
 
     def to_dict(self) -> dict:
         return asdict(self)

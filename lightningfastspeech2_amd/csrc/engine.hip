@@ -180,6 +180,11 @@ struct fs2_engine {
     void *xA = nullptr, *xB = nullptr;  // (B*L, H) encoder ping-pong; xA = encoder_out
     float* spk = nullptr;
     float* dur_pred = nullptr;
+    // phone-level variances (fs2_config::var_level; model.py:276-294): predictions (B*L) and, for a CWT head, spectrogram (B*L, 10) +
+    // (B, 2) mean / std - produced by fs2_encode, kept in the persist arena, copied out by fs2_decode
+    float* pv_pred[FS2_MAX_VARIANCES] = {nullptr, nullptr, nullptr, nullptr};
+    float* pv_spec[FS2_MAX_VARIANCES] = {nullptr, nullptr, nullptr, nullptr};
+    float* pv_ms[FS2_MAX_VARIANCES] = {nullptr, nullptr, nullptr, nullptr};
     int32_t *d_dur = nullptr, *d_cum = nullptr, *d_totals = nullptr, *d_guard = nullptr;
     uint8_t* src_mask = nullptr;
     int32_t* h_pinned = nullptr;  // 2*B ints: totals, guard
@@ -324,6 +329,7 @@ int check_config(fs2_engine* e) {
     if (!(c.dur_kernel & 1) || c.dur_kernel > 31) return fail(e, FS2_ERR_SHAPE, "duration kernel must be odd, <= 31");
     for (int v = 0; v < c.n_variances; ++v) {
         if (c.var_nlayers[v] < 1) return fail(e, FS2_ERR_SHAPE, "variance_nlayers < 1");
+        if (c.var_level[v] != 0 && c.var_level[v] != 1) return fail(e, FS2_ERR_ARG, "var_level must be 0 (frame) or 1 (phone)");
         if (c.var_cwt[v] && (c.var_mean[v] != 0.f || c.var_std[v] != 1.f))
             return fail(e, FS2_ERR_ARG, "a CWT variance is bucketised as it is: var_mean / var_std must be 0 / 1");
         if (c.var_nlayers[v] > 1 && c.var_filter != H) return fail(e, FS2_ERR_SHAPE, "variance_filter_size != hidden with nlayers > 1");
@@ -1006,7 +1012,17 @@ int take_layer_scratch(fs2_engine* e, Arena& ar, int B, int S, LayerScratch* sc)
 
 size_t persist_bytes(const fs2_engine* e, int B, int L) {
     const size_t H = e->cfg.hidden, ML = (size_t)B * L, esz = e->esz;
-    return al((size_t)B * H * 4) + 2 * al(ML * H * esz) + al(ML * 4) + 2 * al(ML * 4) + 2 * al((size_t)B * 4) + al(ML) + 4096;
+    size_t pv = 0;
+    for (int v = 0; v < e->cfg.n_variances; ++v)
+        if (e->cfg.var_level[v]) pv += al(ML * 4) + (e->cfg.var_cwt[v] ? al(ML * 10 * 4) + al((size_t)B * 8) : 0);
+    return al((size_t)B * H * 4) + 2 * al(ML * H * esz) + al(ML * 4) + 2 * al(ML * 4) + 2 * al((size_t)B * 4) + al(ML) + pv + 4096;
+}
+// scratch of the encode phase: the encoder's layer scratch + the CWT head's (M, 12) spectrogram of a phone-level CWT variance
+size_t encode_scratch_bytes(const fs2_engine* e, int B, int L) {
+    size_t cw = 0;
+    for (int v = 0; v < e->cfg.n_variances; ++v)
+        if (e->cfg.var_level[v] && e->cfg.var_cwt[v]) cw = al((size_t)B * L * 12 * 4) + 512;
+    return layer_scratch_bytes(e, B, L) + cw;
 }
 size_t decode_scratch_bytes(const fs2_engine* e, int B, int T) {
     const size_t H = e->cfg.hidden, MT = (size_t)B * T, esz = e->esz;
@@ -1261,7 +1277,7 @@ int fs2_workspace_bytes(const fs2_engine* e, int32_t B, int32_t L, int32_t T, si
     if (!e || B <= 0 || L <= 0 || T < 0) return FS2_ERR_ARG;
     if (persist) *persist = persist_bytes(e, B, L);
     if (scratch) {
-        const size_t enc = layer_scratch_bytes(e, B, L), dec = T > 0 ? decode_scratch_bytes(e, B, T) : 0;
+        const size_t enc = encode_scratch_bytes(e, B, L), dec = T > 0 ? decode_scratch_bytes(e, B, T) : 0;
         *scratch = enc > dec ? enc : dec;
     }
     return FS2_OK;
@@ -1288,6 +1304,40 @@ int fs2_set_frames(fs2_engine* e, int32_t T) {
 
 static void drop_graphs(fs2_engine* e);
 static int encode_body(fs2_engine* e, const int64_t* phones, const float* speaker, const int32_t* forced, LayerScratch& sc, hipStream_t st);
+
+// One VarianceEncoder.forward (model.py:409-441) on the (B*S, H) rows x: the predictor, then x += Embedding[bucketize(pred * std + mean)]
+// (or of the forced indices / targets: model.py:417-422), optionally + pe + spk behind the last frame-level variance
+// (fastspeech2.py:705-718).  Used at the frame level by the decode phase (model.py:315-333) and at the phone level by the encode
+// phase (model.py:276-294).  x / xalt are the ping-pong pair: swapped when the embedding rode in the predictor launch.
+static int variance_stage(fs2_engine* e, hipStream_t st, int v, void*& x, void*& xalt, int B, int S, const uint8_t* mask, float* vpred,
+                          const LayerScratch& sc, const CwtOut* cwo, bool add_pe_spk, Arena& dbg) {
+    const fs2_config& c = e->cfg;
+    const size_t M = (size_t)B * S, H = c.hidden, esz = e->esz;
+    // the encoder's bucketize + embedding add rides in the predictor launch where nothing else wants its by-products
+    // (bucket indices for the debug taps, forced buckets / targets of the teacher-forced and oracle paths)
+    const bool tail_ok = e->tune.pred_fuse_embed && !e->debug && !e->forced_idx[v] && !e->forced_tgt[v] && !c.var_cwt[v] &&
+                         (e->fdt == FS2_BF16 || (e->fdt == FS2_F32 && e->front_split && e->vars[v].pred.wpk_lo)) && H == 256;
+    const EmbedTail tl{xalt, e->vars[v].bins, e->vars[v].emb, c.var_nbins, c.var_std[v], c.var_mean[v],
+                       add_pe_spk ? e->pe : nullptr, add_pe_spk ? e->spk : nullptr};
+    bool tail_done = false;
+    CHK(predictor(e, st, e->vars[v].pred, x, B, S, mask, vpred, sc, cwo, tail_ok ? &tl : nullptr, &tail_done));
+    if (tail_done) {
+        std::swap(x, xalt);
+        return FS2_OK;
+    }
+    int32_t* idx = nullptr;
+    if (e->debug) {
+        idx = (int32_t*)dbg.take(M * 4);
+        if (!idx) return fail(e, FS2_ERR_NOMEM, "debug arena too small");
+        e->taps[std::string("bucket_") + c.var_names[v]] = {idx, M * 4};
+    }
+    Bracket br(e, FS2_K_ROWOPS, st, 0, 2.0 * M * H * esz);
+    BucketArgs ba{x, vpred, e->vars[v].bins, e->vars[v].emb, c.var_nbins, c.var_std[v], c.var_mean[v],
+                  add_pe_spk ? e->pe : nullptr, add_pe_spk ? e->spk : nullptr, x, idx, B, S, (int)H,
+                  e->forced_idx[v], 0, e->forced_tgt[v]};
+    if (launch_bucket_embed(ba, e->fdt, st) != FS2_OK) return fail(e, FS2_ERR_HIP, "bucket_embed launch failed");
+    return FS2_OK;
+}
 static int run_phase(fs2_engine* e, std::vector<fs2_engine::GraphEntry>& cache, const std::vector<uint64_t>& key, bool plain,
                      hipStream_t st, const std::function<int(hipStream_t)>& body);
 
@@ -1307,7 +1357,7 @@ int fs2_encode(fs2_engine* e, const int64_t* phones, const float* speaker, int32
     // the arenas are reused across calls: earlier work on this stream that still reads them is
     // ordered before the kernels below; a (rare) growth reallocates after a device sync
     CHK(ensure_arena(e, e->persist, persist_bytes(e, B, L), "persist"));
-    CHK(ensure_arena(e, e->scratch, layer_scratch_bytes(e, B, L), "scratch"));
+    CHK(ensure_arena(e, e->scratch, encode_scratch_bytes(e, B, L), "scratch"));
     e->spk = (float*)e->persist.take((size_t)B * H * 4);
     e->xA = e->persist.take(ML * H * esz);
     e->xB = e->persist.take(ML * H * esz);
@@ -1317,7 +1367,19 @@ int fs2_encode(fs2_engine* e, const int64_t* phones, const float* speaker, int32
     e->d_totals = (int32_t*)e->persist.take((size_t)2 * B * 4);  // [totals | guard flags]: one read-back
     e->d_guard = e->d_totals ? e->d_totals + B : nullptr;
     e->src_mask = (uint8_t*)e->persist.take(ML);
-    if (!e->src_mask) return fail(e, FS2_ERR_NOMEM, "persist arena too small");
+    bool pv_ok = true, pv_forced = false;
+    for (int v = 0; v < c.n_variances; ++v) {
+        e->pv_pred[v] = e->pv_spec[v] = e->pv_ms[v] = nullptr;
+        if (!c.var_level[v]) continue;
+        e->pv_pred[v] = (float*)e->persist.take(ML * 4);
+        if (c.var_cwt[v]) {
+            e->pv_spec[v] = (float*)e->persist.take(ML * 10 * 4);
+            e->pv_ms[v] = (float*)e->persist.take((size_t)B * 8);
+        }
+        pv_ok = pv_ok && e->pv_pred[v] && (!c.var_cwt[v] || (e->pv_spec[v] && e->pv_ms[v]));
+        pv_forced = pv_forced || e->forced_idx[v] || e->forced_tgt[v];
+    }
+    if (!e->src_mask || !pv_ok) return fail(e, FS2_ERR_NOMEM, "persist arena too small");
     LayerScratch sc;
     CHK(take_layer_scratch(e, e->scratch, B, L, &sc));
     if (e->h_pinned_cap < 2 * B) {
@@ -1332,7 +1394,7 @@ int fs2_encode(fs2_engine* e, const int64_t* phones, const float* speaker, int32
         std::vector<uint64_t> key = {(uint64_t)B, (uint64_t)L, (uint64_t)e->persist.base, (uint64_t)e->scratch.base, (uint64_t)phones,
                                      (uint64_t)speaker, (uint64_t)forced, (uint64_t)e->h_pinned, (uint64_t)e->fuse_predictor, (uint64_t)e->tune.gen,
                                      (uint64_t)e->defer_ln, (uint64_t)e->front_split, (uint64_t)e->fold_ln};
-        const bool plain = c.n_priors != 0;  // a prior tensor is a one-shot pointer of the call
+        const bool plain = c.n_priors != 0 || pv_forced;  // a prior tensor / a phone-level forced target is a one-shot pointer of the call
         CHK(run_phase(e, e->egraphs, key, plain, st, [&](hipStream_t s2) { return encode_body(e, phones, speaker, forced, sc, s2); }));
     }
     HIPCHK(e, hipStreamSynchronize(st));  // the one host sync of the forward (output shape)
@@ -1363,7 +1425,7 @@ static int encode_body(fs2_engine* e, const int64_t* phones, const float* speake
     }
     CHK(run_stack(e, st, e->enc, e->xA, e->xB, B, L, c.enc_heads, sc, false));  // fastspeech2.py:685
     if (e->debug) {  // the reference's encoder output, i.e. before the prior embeddings are added
-        const size_t need_d = al(ML * H * 4) + 4096;
+        const size_t need_d = al(ML * H * 4) + (size_t)c.n_variances * al(ML * 4) + 4096;
         if (need_d > e->dbg_enc.cap) HIPCHK(e, hipDeviceSynchronize());
         if (e->dbg_enc.reserve(need_d) != FS2_OK) return fail(e, FS2_ERR_NOMEM, "debug arena");
         CHK(tap_store(e, st, "encoder_out", e->xA, ML * H, e->fdt, &e->dbg_enc));
@@ -1379,6 +1441,20 @@ static int encode_body(fs2_engine* e, const int64_t* phones, const float* speake
     }
     // duration predictor + rounding + prefix sums                          model.py:259,299-309
     CHK(predictor(e, st, e->dur, e->xA, B, L, e->src_mask, e->dur_pred, sc));
+    // phone-level variance encoders (variance_levels[i] == "phone"), in list order, AFTER the duration predictor has seen x and BEFORE
+    // the length regulator: each adds its embedding to the rows that get regulated                      model.py:276-294
+    for (int v = 0; v < c.n_variances; ++v) {
+        if (!c.var_level[v]) continue;
+        CwtOut cwo;
+        if (c.var_cwt[v]) {
+            cwo.spec12 = (float*)e->scratch.take(ML * 12 * 4);
+            if (!cwo.spec12) return fail(e, FS2_ERR_NOMEM, "scratch arena too small");
+            cwo.mean_std = e->pv_ms[v];
+            cwo.spec_out = e->pv_spec[v];
+        }
+        CHK(variance_stage(e, st, v, e->xA, e->xB, B, L, e->src_mask, e->pv_pred[v], sc, c.var_cwt[v] ? &cwo : nullptr, false, e->dbg_enc));
+        e->forced_idx[v] = nullptr, e->forced_tgt[v] = nullptr;  // one-shot, consumed here
+    }
     DurationArgs da{e->dur_pred, e->src_mask, forced, e->d_dur, e->d_cum, e->d_totals, e->d_guard, B, L};
     if (launch_durations(da, st) != FS2_OK) return fail(e, FS2_ERR_HIP, "durations launch failed");
     HIPCHK(e, hipMemcpyAsync(e->h_pinned, e->d_totals, (size_t)2 * B * 4, hipMemcpyDeviceToHost, st));
@@ -1410,6 +1486,12 @@ static int decode_body(fs2_engine* e, const fs2_outputs* out, hipStream_t st) {
         if (out->duration_prediction) HIPCHK(e, hipMemcpyAsync(out->duration_prediction, e->dur_pred, ML * 4, hipMemcpyDeviceToDevice, st));
         if (out->duration_rounded) HIPCHK(e, hipMemcpyAsync(out->duration_rounded, e->d_dur, ML * 4, hipMemcpyDeviceToDevice, st));
         if (out->src_mask) HIPCHK(e, hipMemcpyAsync(out->src_mask, e->src_mask, ML, hipMemcpyDeviceToDevice, st));
+        for (int v = 0; v < c.n_variances; ++v) {  // phone-level variances: (B, L) outputs, produced by the encode phase
+            if (!c.var_level[v]) continue;
+            if (out->variances[v]) HIPCHK(e, hipMemcpyAsync(out->variances[v], e->pv_pred[v], ML * 4, hipMemcpyDeviceToDevice, st));
+            if (c.var_cwt[v] && out->var_spectrogram[v]) HIPCHK(e, hipMemcpyAsync(out->var_spectrogram[v], e->pv_spec[v], ML * 10 * 4, hipMemcpyDeviceToDevice, st));
+            if (c.var_cwt[v] && out->var_mean_std[v]) HIPCHK(e, hipMemcpyAsync(out->var_mean_std[v], e->pv_ms[v], (size_t)B * 8, hipMemcpyDeviceToDevice, st));
+        }
         return FS2_OK;
     };
     if (T == 0) { e->encoded = false; e->mid_forward = false; return phone_outputs(); }
@@ -1421,11 +1503,16 @@ static int decode_body(fs2_engine* e, const fs2_outputs* out, hipStream_t st) {
     // mask / variance predictions go straight into the caller's buffers when it wants them
     uint8_t* tmask = out->tgt_mask ? out->tgt_mask : (uint8_t*)e->scratch.take(MT);
     float* vpred[FS2_MAX_VARIANCES] = {nullptr, nullptr, nullptr, nullptr};
-    for (int v = 0; v < c.n_variances; ++v)
+    int last_frame_v = -1;  // the last FRAME-level variance: pe + spk ride in its embedding add
+    for (int v = 0; v < c.n_variances; ++v) {
+        if (c.var_level[v]) continue;
+        last_frame_v = v;
         vpred[v] = out->variances[v] ? out->variances[v] : (float*)e->scratch.take(MT * 4);
+        if (!vpred[v]) return fail(e, FS2_ERR_NOMEM, "scratch arena too small");
+    }
     float *cw_spec = nullptr, *cw_ms = nullptr;
     for (int v = 0; v < c.n_variances; ++v)
-        if (c.var_cwt[v] && !cw_spec) {
+        if (c.var_cwt[v] && !c.var_level[v] && !cw_spec) {
             cw_spec = (float*)e->scratch.take(MT * 12 * 4);
             cw_ms = (float*)e->scratch.take((size_t)B * 8);
             if (!cw_spec || !cw_ms) return fail(e, FS2_ERR_NOMEM, "scratch arena too small");
@@ -1450,40 +1537,17 @@ static int decode_body(fs2_engine* e, const fs2_outputs* out, hipStream_t st) {
     // frame-level variance encoders, sequential                            model.py:315-333
     const bool fuse_pe = !e->debug;
     for (int v = 0; v < c.n_variances; ++v) {
+        if (c.var_level[v]) continue;  // phone level: done by the encode phase
         CwtOut cwo;
         if (c.var_cwt[v]) {
             cwo.spec12 = cw_spec;
             cwo.mean_std = out->var_mean_std[v] ? out->var_mean_std[v] : cw_ms;
             cwo.spec_out = out->var_spectrogram[v];
         }
-        const bool last = v + 1 == c.n_variances;
-        // the encoder's bucketize + embedding add rides in the predictor launch where nothing else wants its by-products
-        // (bucket indices for the debug taps, forced buckets / targets of the teacher-forced and oracle paths)
-        const bool tail_ok = e->tune.pred_fuse_embed && !e->debug && !e->forced_idx[v] && !e->forced_tgt[v] && !c.var_cwt[v] &&
-                             (e->fdt == FS2_BF16 || (e->fdt == FS2_F32 && e->front_split && e->vars[v].pred.wpk_lo)) && H == 256;
-        const EmbedTail tl{yB, e->vars[v].bins, e->vars[v].emb, c.var_nbins, c.var_std[v], c.var_mean[v],
-                           (last && fuse_pe) ? e->pe : nullptr, (last && fuse_pe) ? e->spk : nullptr};
-        bool tail_done = false;
-        CHK(predictor(e, st, e->vars[v].pred, yA, B, T, tmask, vpred[v], sc, c.var_cwt[v] ? &cwo : nullptr, tail_ok ? &tl : nullptr,
-                      &tail_done));
-        if (tail_done) {
-            std::swap(yA, yB);
-            continue;
-        }
-        int32_t* idx = nullptr;
-        if (e->debug) {
-            idx = (int32_t*)e->dbg.take(MT * 4);
-            if (!idx) return fail(e, FS2_ERR_NOMEM, "debug arena too small");
-            e->taps[std::string("bucket_") + c.var_names[v]] = {idx, MT * 4};
-        }
-        Bracket br(e, FS2_K_ROWOPS, st, 0, 2.0 * MT * H * esz);
-        BucketArgs ba{yA, vpred[v], e->vars[v].bins, e->vars[v].emb, c.var_nbins, c.var_std[v], c.var_mean[v],
-                      (last && fuse_pe) ? e->pe : nullptr, (last && fuse_pe) ? e->spk : nullptr, yA, idx, B, T, (int)H,
-                      e->forced_idx[v], 0, e->forced_tgt[v]};
-        if (launch_bucket_embed(ba, e->fdt, st) != FS2_OK) return fail(e, FS2_ERR_HIP, "bucket_embed launch failed");
+        CHK(variance_stage(e, st, v, yA, yB, B, T, tmask, vpred[v], sc, c.var_cwt[v] ? &cwo : nullptr, v == last_frame_v && fuse_pe, e->dbg));
     }
     if (e->debug) CHK(tap_store(e, st, "adaptor_out", yA, MT * H, e->fdt));
-    if (!fuse_pe || c.n_variances == 0) {  // y = (x + pe) + spk               fastspeech2.py:705-718
+    if (!fuse_pe || last_frame_v < 0) {  // y = (x + pe) + spk               fastspeech2.py:705-718
         BucketArgs ba{yA, nullptr, nullptr, nullptr, 0, 0.f, 0.f, e->pe, e->spk, yA, nullptr, B, T, (int)H, nullptr};
         if (launch_bucket_embed(ba, e->fdt, st) != FS2_OK) return fail(e, FS2_ERR_HIP, "pe/spk add launch failed");
     }

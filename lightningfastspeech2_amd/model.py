@@ -190,9 +190,10 @@ class Engine:
             res["src_mask"] = torch.empty(B, L, dtype=torch.bool, device=dev)
             res["tgt_mask"] = torch.empty(B, T, dtype=torch.bool, device=dev)
             for i, var in enumerate(self.cfg.variances):
-                res[f"variances_{var}"] = torch.empty(B, T, dtype=torch.float32, device=dev)
+                S = L if self.cfg.is_phone_level(i) else T  # a phone-level variance is predicted per phone (model.py:276-294)
+                res[f"variances_{var}"] = torch.empty(B, S, dtype=torch.float32, device=dev)
                 if self.cfg.is_cwt(i):  # by-products of the CWT head (model.py:445-461)
-                    res[f"_cwt_spectrogram_{var}"] = torch.empty(B, T, 10, dtype=torch.float32, device=dev)
+                    res[f"_cwt_spectrogram_{var}"] = torch.empty(B, S, 10, dtype=torch.float32, device=dev)
                     res[f"_cwt_mean_std_{var}"] = torch.empty(B, 2, dtype=torch.float32, device=dev)
         return res
 
@@ -234,7 +235,9 @@ class Engine:
         if what == "encoder_out":
             t = torch.empty(B, L, H, dtype=torch.float32, device=self.device)
         elif what.startswith("bucket_"):
-            t = torch.empty(B, T, dtype=torch.int32, device=self.device)
+            var = what[len("bucket_"):]
+            phone = var in self.cfg.variances and self.cfg.is_phone_level(self.cfg.variances.index(var))
+            t = torch.empty(B, L if phone else T, dtype=torch.int32, device=self.device)
         else:
             t = torch.empty(B, T, H, dtype=torch.float32, device=self.device)
         _lib.check(self.lib.fs2_debug_copy(self.handle, what.encode(), _ptr(t), self._stream()), self.handle,
@@ -410,6 +413,25 @@ class FastSpeech2:
             rows = [(v if isinstance(v, torch.Tensor) else torch.as_tensor(np.asarray(v, dtype=np.float32)))
                     .to(self.device, dtype=torch.float32).reshape(B) for v in (targets[f"priors_{pr}"] for pr in self.cfg.priors)]
             priors = torch.stack(rows).contiguous()
+        # phone-level variances are embedded by the encode phase (model.py:276-294): their teacher-forcing targets / forced buckets
+        # are (B, L) and go in BEFORE it
+        for vi, var in enumerate(self.cfg.variances):
+            if not self.cfg.is_phone_level(vi):
+                continue
+            if teacher:
+                key = self._target_key(vi)
+                tgt = torch.as_tensor(np.asarray(targets[key]) if not isinstance(targets[key], torch.Tensor)
+                                      else targets[key]).to(self.device, dtype=torch.float32)
+                if tgt.dim() != 2 or tgt.shape[0] != B or tgt.shape[1] < L:
+                    raise ValueError(f"targets[{key!r}] (phone level) must be (B, >= L) = ({B}, >= {L})")
+                if self.cfg.is_cwt(vi):
+                    tgt = torch.log(tgt)
+                self.engine.force_variance_targets(vi, tgt[:, :L].contiguous())
+            if force_buckets and var in force_buckets:
+                idx = torch.as_tensor(force_buckets[var]).to(self.device, dtype=torch.int32).contiguous()
+                if tuple(idx.shape) != (B, L):
+                    raise ValueError(f"force_buckets[{var!r}] (phone level) must be (B, L)=({B}, {L})")
+                self.engine.force_buckets(vi, idx)
         T = self.engine.encode(phones, speaker, forced, priors)
         if frames_hook is not None:
             Tg = int(frames_hook(T))
@@ -419,6 +441,8 @@ class FastSpeech2:
         self._t_guess[(B, L)] = T
         if teacher:
             for vi, var in enumerate(self.cfg.variances):
+                if self.cfg.is_phone_level(vi):
+                    continue
                 key = self._target_key(vi)
                 tgt = torch.as_tensor(np.asarray(targets[key]) if not isinstance(targets[key], torch.Tensor)
                                       else targets[key]).to(self.device, dtype=torch.float32)
@@ -428,6 +452,8 @@ class FastSpeech2:
                     tgt = torch.log(tgt)
                 self.engine.force_variance_targets(vi, tgt[:, :T].contiguous())
         for var, idx in (force_buckets or {}).items():
+            if self.cfg.is_phone_level(self.cfg.variances.index(var)):
+                continue  # handed over before the encode phase
             idx = torch.as_tensor(idx).to(self.device, dtype=torch.int32).contiguous()
             if tuple(idx.shape) != (phones.shape[0], T):
                 raise ValueError(f"force_buckets[{var!r}] must be (B, T)=({phones.shape[0]}, {T})")

@@ -226,6 +226,20 @@ def forward(sd, cfg, phones, speaker, *, return_intermediates: bool = False,
     # ---- VarianceAdaptor.forward, model.py:249-341 ----
     dur_pred = variance_predictor(sd, "variance_adaptor.duration_predictor", x, cfg.duration_nlayers,
                                   cfg.duration_kernel_size, cfg.duration_depthwise_conv, src_mask)
+    result = {}
+
+    def teacher_target(vi, var):  # model.py:278-286 / :317-325 (a CWT variance is forced with its raw signal)
+        if teacher_targets is None:
+            return None
+        key = f"variances_{var}_signal" if cfg.variance_transforms[vi] == "cwt" else f"variances_{var}"
+        return torch.as_tensor(np.asarray(teacher_targets[key])).float()
+    for vi, var in enumerate(cfg.variances):                                  # phone-level variances, model.py:276-294:
+        if cfg.variance_levels[vi] != "phone":                               # after the duration predictor, before the regulator
+            continue
+        pred, emb, idx = variance_encoder(sd, cfg, vi, x, src_mask, teacher_target(vi, var))
+        result[f"variances_{var}"] = pred
+        inter[f"bucket_{var}"] = idx
+        x = x + emb
     if teacher_targets is not None:   # inference=False: targets["duration"], no rounding/guard (model.py:296-297)
         dur_rounded, guarded = torch.as_tensor(np.asarray(teacher_targets["duration"])), []
     elif force_durations is None:
@@ -239,13 +253,10 @@ def forward(sd, cfg, phones, speaker, *, return_intermediates: bool = False,
             x = F.pad(x, (0, 0, 0, Tg - x.shape[1]))
             tgt_mask = F.pad(tgt_mask, (0, Tg - tgt_mask.shape[1]), value=True)
     inter["regulated"] = x
-    result = {}
-    for vi, var in enumerate(cfg.variances):                                  # model.py:315-333
-        tgt = None
-        if teacher_targets is not None:  # model.py:317-325 (a CWT variance is forced with its raw signal)
-            key = f"variances_{var}_signal" if cfg.variance_transforms[vi] == "cwt" else f"variances_{var}"
-            tgt = torch.as_tensor(np.asarray(teacher_targets[key])).float()
-        pred, emb, idx = variance_encoder(sd, cfg, vi, x, tgt_mask, tgt)
+    for vi, var in enumerate(cfg.variances):                                  # frame-level variances, model.py:315-333
+        if cfg.variance_levels[vi] != "frame":
+            continue
+        pred, emb, idx = variance_encoder(sd, cfg, vi, x, tgt_mask, teacher_target(vi, var))
         result[f"variances_{var}"] = pred
         inter[f"bucket_{var}"] = idx
         x = x + emb

@@ -29,8 +29,8 @@ def test_library_exports_every_declared_symbol(lib):
 def test_struct_layout_matches_header():
     # sizes follow from include/fs2.h: 8 + (4+32)*2 ints, 1 int, 4*32 chars, 2*4 ints, 2*4 floats, 7 ints, n_priors,
     # FS2_MAX_PRIORS names (ABI v3: the shipped recipe lists five priors, scripts/train.sh:49), var_cwt
-    assert _lib.FS2_ABI_VERSION == 3 and _lib.FS2_MAX_PRIORS == 8
-    assert C.sizeof(_lib.Fs2ConfigC) == 4 * (8 + 36 + 36 + 1) + 4 * 32 + 4 * (4 + 4) + 4 * (4 + 4) + 4 * 7 + 4 + 8 * 32 + 4 * 4
+    assert _lib.FS2_ABI_VERSION == 4 and _lib.FS2_MAX_PRIORS == 8  # v4: var_level (phone-level variances)
+    assert C.sizeof(_lib.Fs2ConfigC) == 4 * (8 + 36 + 36 + 1) + 4 * 32 + 4 * (4 + 4) + 4 * (4 + 4) + 4 * 7 + 4 + 8 * 32 + 4 * 4 + 4 * 4  # ... var_cwt, var_level
     assert C.sizeof(_lib.Fs2OutputsC) == 8 * (5 + 3 * _lib.FS2_MAX_VARIANCES)
 
 

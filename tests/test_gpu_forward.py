@@ -324,7 +324,7 @@ def test_full_size_properties_bf16():
     assert same.count(False) == 1 and not same[3]
 
 
-@pytest.mark.parametrize("case", ["c2arch_ragged", "c2_full", "c2_priorless_tail_rows"])
+@pytest.mark.parametrize("case", ["c2arch_ragged", "c2_full", "c2_priorless_tail_rows", "c2_phone_level", "refdefault_phone_level"])
 def test_variance_encoder_in_the_predictor_launch_is_bit_identical(case):
     """bf16 engine: bucketize + embedding add (+ pe + spk after the last variance) as the tail of the single-launch predictor
     (predictor_fused.hip, knob 1321 = default) against the stand-alone bucket_embed launch (knob 1320): same arithmetic, same
@@ -332,7 +332,12 @@ def test_variance_encoder_in_the_predictor_launch_is_bit_identical(case):
     multiple of the tile's finished rows."""
     from lightningfastspeech2_amd import _lib
     cfg = preset("c2")
-    if case == "c2_full":
+    if case.endswith("phone_level"):  # r06: phone-level variances ride in the ENCODE phase's predictor launches (dense / depth-wise)
+        base = preset("c2" if case.startswith("c2") else "ref-default").to_dict()
+        cfg = Fs2Config(**{**base, "variance_levels": ["phone", "frame", "phone"]})
+        sd = synth_state_dict(cfg, 6, randomize_norm=True, duration_bias=1.45)
+        inp = synth_inputs(cfg, 3, 150, seed=91, lengths=[150, 77, 149])
+    elif case == "c2_full":
         sd = synth_state_dict(cfg, 0, duration_bias=float(np.log(7.0)), duration_weight_scale=0.0, randomize_norm=True)
         inp = synth_inputs(cfg, 8, 256, seed=1234)
     elif case == "c2arch_ragged":
@@ -437,7 +442,8 @@ def _random_gpu_cfg(rs):
         encoder_layers=nl_e, decoder_layers=nl_d, encoder_kernel_sizes=[odd() for _ in range(nl_e)],
         decoder_kernel_sizes=[odd() for _ in range(nl_d)], encoder_depthwise_conv=dw[0], decoder_depthwise_conv=dw[1],
         encoder_conv_filter_size=H * int(rs.choice([1, 2, 4])), decoder_conv_filter_size=H * int(rs.choice([1, 2, 4])),
-        variances=variances, variance_levels=["frame"] * nv, variance_transforms=["cwt" if c else "none" for c in cwt],
+        variances=variances, variance_levels=[str(rs.choice(["frame", "frame", "phone"])) for _ in range(nv)],
+        variance_transforms=["cwt" if c else "none" for c in cwt],
         variance_nlayers=[int(rs.randint(1, 5)) for _ in range(nv)], variance_kernel_size=[odd(9) for _ in range(nv)],
         variance_filter_size=H, variance_nbins=int(rs.choice([8, 33, 256])), variance_depthwise_conv=dw[2],
         duration_nlayers=int(rs.randint(1, 3)), duration_kernel_size=odd(9), duration_filter_size=H,

@@ -15,7 +15,7 @@ ORACLE_TOL = 2e-5  # fp32 restatement vs the reference's own fp32 forward (obser
 def test_fixtures_present():
     names = golden_names()
     for want in ("dense_small", "dw_small", "mixed_small", "guard_small", "clip_small", "priors_small", "teacher_small",
-                 "mid_dense_d128", "mid_dw_d64", "cwt_small", "cwt_teacher_small"):
+                 "mid_dense_d128", "mid_dw_d64", "cwt_small", "cwt_teacher_small", "phone_small", "phone_teacher_small", "phone_cwt_small"):
         assert want in names
 
 
@@ -61,7 +61,7 @@ def _random_cfg(rs):
         encoder_layers=nl_e, decoder_layers=nl_d, encoder_kernel_sizes=[odd() for _ in range(nl_e)],
         decoder_kernel_sizes=[odd() for _ in range(nl_d)], encoder_depthwise_conv=dw[0], decoder_depthwise_conv=dw[1],
         encoder_conv_filter_size=H * int(rs.choice([1, 2, 4])), decoder_conv_filter_size=H * int(rs.choice([1, 2, 4])),
-        variances=variances, variance_levels=["frame"] * nv, variance_transforms=["none"] * nv,
+        variances=variances, variance_levels=[str(rs.choice(["frame", "frame", "phone"])) for _ in range(nv)], variance_transforms=["none"] * nv,
         variance_nlayers=[int(rs.randint(1, 4)) for _ in range(nv)], variance_kernel_size=[odd() for _ in range(nv)],
         variance_filter_size=H, variance_nbins=int(rs.choice([8, 33, 256])), variance_depthwise_conv=dw[2],
         duration_nlayers=int(rs.randint(1, 3)), duration_kernel_size=odd(), duration_filter_size=H,
@@ -70,7 +70,7 @@ def _random_cfg(rs):
                    "std": float(.5 + rs.rand())} for v in variances})
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(10))
 def test_oracle_matches_live_reference(seed):
     from tools.ref_import import reference_available, run_reference
     if not reference_available():

@@ -108,6 +108,16 @@ CASES = {
     # depth-wise blocks / encoder kernels [5, 25, 13, 9] / five-layer variance predictors, at a fixture-sized hidden width
     "recipe_small": (RECIPE, 3, 12, [12, 8, 5], dict(duration_bias=1.1), {"slim": True, "bucket_margin": 5e-4}),
     "recipe_teacher_small": (RECIPE, 3, 12, [12, 8, 5], dict(duration_bias=1.1), {"slim": True, "teacher": True}),
+    # phone-level variances (variance_levels[i] == "phone", model.py:276-294; r06): predicted on the encoder output after the duration
+    # predictor, embedded BEFORE the length regulator, (B, L) outputs; mixed with a frame-level one in list order
+    "phone_small": (small(variance_levels=["phone", "frame", "phone"]), 3, 11, [11, 7, 4], dict(duration_bias=1.2), {}),
+    "phone_teacher_small": (small(variance_levels=["phone", "frame", "phone"]), 3, 11, [11, 7, 4], dict(duration_bias=1.2), {"teacher": True}),
+    "phone_cwt_small": (small(variance_levels=["phone", "phone", "frame"], variance_transforms=["cwt", "none", "none"],
+                              encoder_depthwise_conv=True, variance_depthwise_conv=True, encoder_conv_filter_size=256,
+                              stats={"pitch": {"min": 0.2, "max": 5.0, "mean": 0.1, "std": 1.5},
+                                     "energy": {"min": -3.0, "max": 3.0, "mean": 0.0, "std": 1.0},
+                                     "snr": {"min": -1.0, "max": 4.0, "mean": 1.2, "std": 2.0}}),
+                        3, 12, [12, 9, 5], dict(duration_bias=1.1), {}),
     "mid_dense_d128": (Fs2Config(n_phones=80, encoder_hidden=256, decoder_hidden=256, encoder_head=2,
                                  decoder_head=2, encoder_layers=1, decoder_layers=2,
                                  encoder_kernel_sizes=[9], decoder_kernel_sizes=[9, 9],
@@ -153,11 +163,13 @@ def margins(cfg, out):
             if "reconstructed_signal" not in v:
                 continue  # teacher-forced: the embedding came from the target
             val = torch.log(v["reconstructed_signal"].double())
+            if cfg.is_phone_level(vi):
+                val = val[~out["src_mask"]]  # (pad phones carry whatever the z-normalisation made of their zeros: never asserted)
         else:
             bins = torch.linspace(st["min"], st["max"], cfg.variance_nbins - 1).double()
             # pad frames carry pred == 0 exactly (masked_fill, model.py:518) -> value == mean in any
             # implementation, so only valid frames can flip
-            val = (out[f"variances_{var}"].double() * st["std"] + st["mean"])[~out["tgt_mask"]]
+            val = (out[f"variances_{var}"].double() * st["std"] + st["mean"])[~out["src_mask" if cfg.is_phone_level(vi) else "tgt_mask"]]
         bucket_margin = min(bucket_margin, float((val[..., None] - bins).abs().min()))
     return round_margin, bucket_margin
 
@@ -174,10 +186,12 @@ def make_case(name, cfg, B, L, lengths, skw, want):
             for b, n in enumerate(lengths):
                 dur[b, n:] = 0
             Tt = int(dur.sum(1).max())
-            tt = {"duration": dur, **{f"variances_{v}": (1.2 * rs.randn(B, Tt)).astype(np.float32) for v in cfg.variances}}
+            # a phone-level variance is forced per phone (model.py:278-286): (B, L) targets
+            tlen = lambda vi: L if cfg.is_phone_level(vi) else Tt
+            tt = {"duration": dur, **{f"variances_{v}": (1.2 * rs.randn(B, tlen(vi))).astype(np.float32) for vi, v in enumerate(cfg.variances)}}
             for vi, v in enumerate(cfg.variances):
                 if cfg.is_cwt(vi):  # the raw (positive) signal; model.py:319-321 reads variances_<var>_signal
-                    tt[f"variances_{v}_signal"] = np.exp(0.8 * rs.randn(B, Tt)).astype(np.float32)
+                    tt[f"variances_{v}_signal"] = np.exp(0.8 * rs.randn(B, tlen(vi))).astype(np.float32)
         out = run_reference(cfg, sd, inp["phones"], inp["speaker"], capture=True, priors=pri, teacher_targets=tt)
         rm, bm = margins(cfg, out)
         n_guard = out["_stdout"].count("Zero duration")
