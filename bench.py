@@ -496,6 +496,11 @@ def main():
     # their own BEHIND the timed region (same workload, same launch shapes, same stream): the timed steps replay both phases as
     # hipGraphs (Engine default), which cannot hold event records, and the timed region carries no measurement traffic.
     kcls = _lib.K_DEC_FFN_CONV1
+    # Python's cyclic collector is held off over the timed steps (as `timeit` does): what it would collect here is host garbage of the
+    # warm-up - an engine replica among it means fs2_destroy -> hipFree -> a device-wide stall of tens of ms inside the region
+    import gc
+    gc.collect()
+    gc.disable()
     sync()
     trace = [] if os.environ.get("FS2_BENCH_TRACE") else None  # host-side time of each step() call (diagnostics)
     t0 = time.perf_counter()
@@ -509,6 +514,7 @@ def main():
     t_sync = time.perf_counter()
     sync()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if trace is not None and rank == 0:
         print(f"closing sync: {(time.perf_counter() - t_sync) * 1e3:.2f} ms", file=sys.stderr)
         print("host ms per step():", " ".join(f"{t * 1e3:.2f}" for t in trace), file=sys.stderr)
@@ -724,6 +730,10 @@ def main():
                 for _ in range(4 * len(hpipe.models) + 1):  # every ring slot of every replica has its pinned buffers (a 15.7 MB pinned allocation takes milliseconds)
                     hpipe.submit(hb)
                 hpipe.drain()
+                torch.cuda.synchronize()
+                # garbage collected INSIDE the timed loop can be an engine replica of an earlier pipeline: fs2_destroy -> hipFree -> a
+                # device-wide stall of tens of ms (measured r06, tools/probes/pcie_pipeline_probe3.py: one 40-90 ms submit in 40)
+                gc.collect()
                 torch.cuda.synchronize()
                 k3 = max(6, min(args.steps, 20))
                 n_dev_alloc = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)

@@ -47,7 +47,13 @@ def timeline(db, title=""):
     g = [c for c in ("grid_x", "grid_size_x") if c in cols][0]
     rows = con.execute(f"select name, start, end, {g} from kernels order by start").fetchall()
     idx = [i for i, r in enumerate(rows) if "embed_kernel<" in r[0] and "bucket" not in r[0]]  # the phone embedding opens a forward
-    a, b = idx[-2], idx[-1]
+    # one forward at a time = the launch count between two phone embeddings that occurs most often (the bench's pipelined sections
+    # interleave two forwards, its tail sections run other things): the last such pair
+    from collections import Counter
+    diffs = [idx[i + 1] - idx[i] for i in range(len(idx) - 1)]
+    common = Counter(diffs).most_common(1)[0][0]
+    j = max(i for i, d in enumerate(diffs) if d == common)
+    a, b = idx[j], idx[j + 1]
     print(f"# {title or db}: launches of one forward ({b - a} launches, {(rows[b][1] - rows[a][1]) / 1e3:.1f} us start to start)\n")
     print("| # | kernel | grid x | us | gap before, us |")
     print("|---|---|---|---|---|")
