@@ -37,7 +37,7 @@ import torch.distributed as dist
 
 MFMA_PEAK = {"bf16": 2.5e15, "fp32": 157.3e12}  # dense, /opt/skills/guides/MI355X_MICROARCH.md
 HOP, SR = 256, 22050
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")  # regenerated every round: tools/pmc_traffic.sh
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r06_pmc_traffic.json")  # regenerated every round: tools/pmc_traffic.sh
 
 
 def parse():
@@ -141,6 +141,7 @@ def cpu_baseline(cfg, sd, args):
 def parity_block(cfg, sd, args, dev, timed_model):
     """fp32 parity mode timed + checked against the oracle on a sample of the workload, and the timed mode's
     decision flips / forced-decision mel error on the same sample (rank 0, N=1)."""
+    from lightningfastspeech2_amd import _lib
     from lightningfastspeech2_amd.model import FastSpeech2
     from lightningfastspeech2_amd.weights import synth_inputs
     from oracle import oracle_cpu  # checker only
@@ -231,8 +232,30 @@ def parity_block(cfg, sd, args, dev, timed_model):
         one, piped = timed(m3, 5)
         res["decision_safe"] = {"mode": "mixed3 (front: fp32 storage, bf16 x 3 split products incl. attention; decoder: bf16)",
                                 "ms_per_step": min(one, piped), "ms_per_step_one_in_flight": one, "in_flight": args.in_flight if piped < one else 1,
-                                "duration_flips": dfl, "bucket_flips": bfl,
+                                "value": float(args.batch * ref["mel"].shape[1] / (min(one, piped) * 1e-3)) if Bs == args.batch else None,
+                                "unit": "mel-frames/s", "duration_flips": dfl, "bucket_flips": bfl,
                                 "mel_maxabs_forced": forced}
+        # its own roofline: the mode's dominant kernel is the single-launch variance predictor in the split
+        # arithmetic - three bf16 MFMAs per product, so the dense peak for its ALGORITHMIC flops is a third of the bf16 peak
+        try:
+            m3.engine.profile_reserve(_lib.K_PREDICTOR, 64)
+            m3.engine.profile_enable(_lib.K_PREDICTOR, True)
+            for _ in range(3):
+                m3(full, inference=True)
+            torch.cuda.synchronize()
+            pp = m3.engine.profile_read(_lib.K_PREDICTOR)
+            m3.engine.profile_enable(_lib.K_PREDICTOR, False)
+            if pp["launches"]:
+                ach = pp["flops"] / (pp["ms"] * 1e-3)
+                res["decision_safe"]["roofline"] = {
+                    "bound": "mfma", "kernel": "predictor_fused_kernel<7, 4, 1, X3>: a whole dense VariancePredictor per launch, every product as "
+                                               "three bf16 MFMAs on head / tail splits of the fp32 operands",
+                    "achieved": ach / 1e12, "peak": 2500.0 / 3, "unit": "TFLOP/s", "frac": ach / (2.5e15 / 3),
+                    "peak_is": "dense bf16 MFMA peak / 3 (three MFMAs per algorithmic product)",
+                    "avg_launch_us": pp["ms"] / pp["launches"] * 1e3, "launches_timed": pp["launches"], "flops_per_launch": pp["flops"] / pp["launches"],
+                    "measured": "HIP events on the launch stream around the decode phase's predictor launches, 3 eager forwards"}
+        except Exception as ex:
+            res["decision_safe"]["roofline"] = {"error": repr(ex)}
         del m3
     dfl, bfl, free, forced = check(timed_model)
     p = args.precision
@@ -722,34 +745,36 @@ def main():
             # the same boundary inside the pipeline (r06): two forwards in flight, inputs copied on the forward's own stream, batch i's
             # mels + mask crossing PCIe on a copy stream under batch i + 1's forward (model.ForwardPipeline(host_outputs=...))
             hb = {"phones": hp, "speaker": hs}
-            hpipe = model.pipeline(max(2, n_pick), host_outputs=("mel", "tgt_mask"))
-            # eager launches here: a hipGraph signature holds every buffer address, and with host batches the device copies of the
-            # inputs (and, with copies still in flight, the outputs) are fresh allocations every step - each would be captured anew
-            hpipe.set_graphs(False)
-            try:
-                for _ in range(4 * len(hpipe.models) + 1):  # every ring slot of every replica has its pinned buffers (a 15.7 MB pinned allocation takes milliseconds)
-                    hpipe.submit(hb)
-                hpipe.drain()
-                torch.cuda.synchronize()
-                # garbage collected INSIDE the timed loop can be an engine replica of an earlier pipeline: fs2_destroy -> hipFree -> a
-                # device-wide stall of tens of ms (measured r06, tools/probes/pcie_pipeline_probe3.py: one 40-90 ms submit in 40)
-                gc.collect()
-                torch.cuda.synchronize()
-                k3 = max(6, min(args.steps, 20))
-                n_dev_alloc = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
-                t0 = time.perf_counter()
-                got = 0
-                for _ in range(k3):
-                    got += len(hpipe.submit(hb))
-                got += len(hpipe.drain())  # every result's host copy has landed when drain returns
-                el3 = time.perf_counter() - t0
-                assert got == k3
-                two = {"value": frames_rank * k3 / el3, "ms_per_step": el3 / k3 * 1e3, "steps": k3, "in_flight": len(hpipe.models),
-                       "device_allocations_during": torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - n_dev_alloc}
-            finally:
-                hpipe.close()
-            best = two if two["ms_per_step"] <= one["ms_per_step"] else one
-            line["value_incl_pcie"] = {**best, "one_at_a_time_ms_per_step": one["ms_per_step"], "pipelined_ms_per_step": two["ms_per_step"],
+            two = None
+            if pin_n != 1:  # (FS2_BENCH_IN_FLIGHT=1 = the rocprof traces: one forward at a time, a launch's duration is its own - no pipelined leg)
+                hpipe = model.pipeline(max(2, n_pick), host_outputs=("mel", "tgt_mask"))
+                # eager launches here: a hipGraph signature holds every buffer address, and with host batches the device copies of the
+                # inputs (and, with copies still in flight, the outputs) are fresh allocations every step - each would be captured anew
+                hpipe.set_graphs(False)
+                try:
+                    for _ in range(4 * len(hpipe.models) + 1):  # every ring slot of every replica gets its pinned buffers (a 15.7 MB pinned allocation takes milliseconds)
+                        hpipe.submit(hb)
+                    hpipe.drain()
+                    torch.cuda.synchronize()
+                    # garbage collected INSIDE the timed loop can be an engine replica of an earlier pipeline: fs2_destroy -> hipFree -> a
+                    # device-wide stall of tens of ms (measured r06, tools/probes/pcie_pipeline_probe3.py: one 40-90 ms submit in 40)
+                    gc.collect()
+                    torch.cuda.synchronize()
+                    k3 = max(6, min(args.steps, 20))
+                    n_dev_alloc = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
+                    t0 = time.perf_counter()
+                    got = 0
+                    for _ in range(k3):
+                        got += len(hpipe.submit(hb))
+                    got += len(hpipe.drain())  # every result's host copy has landed when drain returns
+                    el3 = time.perf_counter() - t0
+                    assert got == k3
+                    two = {"value": frames_rank * k3 / el3, "ms_per_step": el3 / k3 * 1e3, "steps": k3, "in_flight": len(hpipe.models),
+                           "device_allocations_during": torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - n_dev_alloc}
+                finally:
+                    hpipe.close()
+            best = two if two is not None and two["ms_per_step"] <= one["ms_per_step"] else one
+            line["value_incl_pcie"] = {**best, "one_at_a_time_ms_per_step": one["ms_per_step"], "pipelined_ms_per_step": two["ms_per_step"] if two else None,
                                        "what": "inputs from / mels + mask to pinned host memory every step (66 KB H2D, "
                                                f"{hmel.numel() * 4 / 1e6:.1f} MB D2H); in_flight > 1: the device-to-host copy of batch i on a "
                                                "copy stream under batch i + 1's forward; timed until the last host copy has landed"}

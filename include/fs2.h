@@ -215,7 +215,9 @@ enum fs2_kernel_class {
     FS2_K_DEC_ATTENTION = 5, /* the decoder stack's self-attention launches only: the MFMA-bound attention instance (north_star) */
     FS2_K_ENC_MHA = 6,     /* the encoder stack's whole self-attention block: in-projection + attention + out-projection (+ residual +
                             * LayerNorm) launches - nn.MultiheadAttention inside ConformerEncoderLayer.forward, model.py:108-116 */
-    FS2_K_COUNT = 7
+    FS2_K_PREDICTOR = 7,   /* the decode phase's single-launch VariancePredictor launches (model.py:482-522 at the frame level): the dominant
+                            * kernel of the decision-safe modes, whose matrix work is three bf16 MFMAs per product (r06) */
+    FS2_K_COUNT = 8
 };
 int fs2_profile_enable(fs2_engine* e, int32_t kernel_class, int32_t enable);
 /* pre-create the event pairs of `pairs` bracketed launches (otherwise they are created on first use, inside the caller's timed region) */

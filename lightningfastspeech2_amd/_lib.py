@@ -26,7 +26,7 @@ FS2_NAME_LEN = 32
 FS2_OK = 0
 FS2_ERR_HIP, FS2_ERR_SHAPE, FS2_ERR_ARG, FS2_ERR_WEIGHT, FS2_ERR_STATE, FS2_ERR_NOMEM = 1, 2, 3, 4, 5, 6
 FS2_F32, FS2_BF16, FS2_MIXED, FS2_MIXED_X3, FS2_F32_X3 = 0, 1, 2, 3, 4
-K_CONV_GEMM, K_GEMM, K_ATTENTION, K_ROWOPS, K_DEC_FFN_CONV1, K_DEC_ATTENTION, K_ENC_MHA = 0, 1, 2, 3, 4, 5, 6
+K_CONV_GEMM, K_GEMM, K_ATTENTION, K_ROWOPS, K_DEC_FFN_CONV1, K_DEC_ATTENTION, K_ENC_MHA, K_PREDICTOR = 0, 1, 2, 3, 4, 5, 6, 7
 
 
 class Fs2ConfigC(C.Structure):

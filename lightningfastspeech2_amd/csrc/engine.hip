@@ -885,6 +885,7 @@ int predictor(fs2_engine* e, hipStream_t st, const PredictorW& P, const void* x,
         }
         const double fl = 2.0 * M * (double)P.filt * P.filt * a.taps * a.nlayers;
         Bracket br(e, FS2_K_CONV_GEMM, st, fl, (double)M * P.filt * 4 + (double)M * 4 + (with_tail ? 2.0 * M * P.filt * 4 : 0.0));
+        Bracket brp(e, FS2_K_PREDICTOR, st, fl, (double)M * P.filt * 4 + (double)M * 4 + (with_tail ? 2.0 * M * P.filt * 4 : 0.0), x != e->xA && x != e->xB);
         const int r = launch_predictor_fused_x3(a, st);
         if (r != FS2_OK) return fail(e, r, "fused predictor (split arithmetic) launch failed (B=%d S=%d)", B, S);
         if (with_tail) *tail_done = true;
@@ -904,6 +905,7 @@ int predictor(fs2_engine* e, hipStream_t st, const PredictorW& P, const void* x,
         const double fl = (P.dw_all ? 2.0 * M * (double)P.filt * (P.filt + 3) : 2.0 * M * (double)P.filt * P.filt * a.taps) * a.nlayers;
         const double by = (double)M * P.filt * 2 + (double)M * 4 + (with_tail ? 2.0 * M * P.filt * 2 : 0.0);
         Bracket br(e, FS2_K_CONV_GEMM, st, fl, by);
+        Bracket brp(e, FS2_K_PREDICTOR, st, fl, by, x != e->xA && x != e->xB);
         const int r = launch_predictor_fused(a, st);
         if (r != FS2_OK) return fail(e, r, "fused predictor launch failed (B=%d S=%d)", B, S);
         if (with_tail) *tail_done = true;

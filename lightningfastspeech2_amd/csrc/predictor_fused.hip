@@ -207,7 +207,11 @@ __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(Predict
 
     const int n0 = wv * (NFR * 16) + fg * 8;  // fragment pair j: this lane's channels n0 + 32*j .. +7
     for (int l = 0; l < nl; ++l) {
+#if defined(FS2_PF_PROBE) && (FS2_PF_PROBE & 4)
+        if constexpr (false) {  // probe: no depth-wise pass - what does it cost?
+#else
         if constexpr (DW) {
+#endif
             // ---- depth-wise Conv1d(k = 3, groups = 256) over the slab, in place (model.py:545-551) ----
             static_assert(NWV * 64 == 256 && R % 8 == 0, "depth-wise pass: 32 slots x 8 row groups");
             constexpr int RPT = R / 8;  // rows per thread
@@ -680,6 +684,10 @@ int launch_predictor_fused(const PredictorArgs& a, hipStream_t stream) {
     // layout for everything, shorter tiles when 112-row tiles would leave most CUs without work
     if (a.be_y && (a.be_y == a.x || !a.be_bins || !a.be_emb || a.be_nbins < 2 || a.be_nbins - 1 > 512)) return FS2_ERR_ARG;
     if ((a.dw_w != nullptr) != (a.dw_b != nullptr)) return FS2_ERR_ARG;
+    // the kernel reads the per-layer vectors 16 bytes at a time (float4 / uint4): every pointer 16-byte aligned
+    if (((uintptr_t)a.x | (uintptr_t)a.wpk | (uintptr_t)a.bias | (uintptr_t)a.ln_g | (uintptr_t)a.ln_b | (uintptr_t)a.head_w | (uintptr_t)a.dw_w |
+         (uintptr_t)a.dw_b | (uintptr_t)a.be_y | (uintptr_t)a.be_emb | (uintptr_t)a.be_pe | (uintptr_t)a.be_spk) & 15)
+        return FS2_ERR_ARG;
     const bool small = tiles(112) < 200 && 64 - halo2 >= 32;
     if (a.dw_w) {  // depth-wise layers: wpk holds the pointwise weights (one tap)
         if (small) hipLaunchKernelGGL((predictor_fused_kernel<4, 4, 2, false, true>), dim3((unsigned)tiles(64)), dim3(256), 0, stream, a);

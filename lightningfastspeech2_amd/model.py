@@ -572,7 +572,7 @@ class ForwardPipeline:
 
     def _to_host(self, k, out, fwd_done):
         """Queue the device-to-host copies of the named outputs on replica k's copy stream (behind the forward, beside the next one)."""
-        cs = self.streams[k] if os.environ.get("FS2_PIPE_COPY_STREAM") == "same" else self.copy_streams[k]  # (A/B: tools/probes/pcie_pipeline_probe.py)
+        cs = self.copy_streams[k]
         slot = self._ring[k][self._nrun[k] % 4]
         self._nrun[k] += 1
         cs.wait_event(fwd_done)
