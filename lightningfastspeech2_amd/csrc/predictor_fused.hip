@@ -104,6 +104,8 @@ __global__ void pack_predictor_weights_kernel(const bf16* __restrict__ W, uint4*
 // across a barrier (every thread has read its window) and writes them back over the rows it read.  Rows 0 and R + 1 keep the layer-0
 // input: one more stale row per layer at both ends, the dense form's halo.  A third of the dense layer's MFMA work, ~450 VALU per thread
 // and layer for the depth-wise pass; ref-default's 15 + 2 layers = 4 launches instead of 34.
+// Where its 67 us go (C2-sized launch, 5 layers; probe builds -DFS2_PF_PROBE=2|4|6, profiles/r06_v10_dw_predictor_ablation.txt):
+// ReLU + LayerNorm epilogues 25 us, depth-wise passes 16 us, the rest (fill, five 8-step K loops = ~17 us of MFMA passes, head, tail) 28 us.
 template <int MI16, int NWV, int MINW, bool X3 = false, bool DW = false>
 __global__ __launch_bounds__(NWV * 64, MINW) void predictor_fused_kernel(PredictorArgs p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins exist in the device pass only
