@@ -206,8 +206,14 @@ template <> __device__ inline void load4v<bf16>(const bf16* p, dw_f2& a, dw_f2& 
 // r05: the decoder-sized launches (k = 17 / 21 on 49152 rows) were bound by VALU issue, not by HBM (2.7 TB/s): (a) the chunk
 // size follows k (launch_dwconv: the TC in {3, 5, 7, 8, 9} that pads k least - k = 17 computed 24 taps in chunks of 8, 18 in chunks
 // of 9), (b) the multiply-adds go two channels at a time (v_pk_fma_f32 - the same fused multiply-add per channel).
-template <typename T, int DW_TC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 2 ? 3 : 1))) void dwconv_kernel(DwConvArgs p) {  // 3 workgroups per CU (LDS): <= 168 VGPRs
+// r06: the tile height is a template parameter (TRT = 256 or 128 rows, a thread owns TRT / 16 consecutive rows).  Measured
+// (profiles/r06_v13_dwconv_tile_rows.txt): 256-row tiles win wherever they give every CU its three workgroups (all frame-level launches,
+// C = 256 and 768: 12-18 / 29-52 us against 13-19 / 29-55 at 128 rows and 14-21 / 34-68 at 64), 128-row tiles where they do not (the
+// encoder-side launches, 256 phonemes: C = 768 9.6-14.3 -> 8.3-12.8 us, C = 256 6.8-9.4 -> 5.4-6.8).  Per output the taps are added in
+// the same order at either height: the choice is invisible in the results (test_dwconv_tile_heights_are_bit_identical).
+template <typename T, int DW_TC, int TRT = 256>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(sizeof(T) == 2 ? 3 : 1))) void dwconv_kernel(DwConvArgs p) {  // 3 workgroups per CU (LDS at 256 rows): <= 168 VGPRs
+    constexpr int DW_TR = TRT, DW_RR = TRT / 16;
     __shared__ __attribute__((aligned(16))) T tile[(DW_TR + DW_KP - 1) * DW_LS];
     __shared__ __attribute__((aligned(16))) float wl[DW_KP * DW_CT];  // [tap][channel]
     __shared__ float rstat[(DW_TR + DW_KP - 1) * 2];                   // LayerNorm-on-load: (mean, rstd) per slab row
@@ -374,15 +380,21 @@ int dwconv_tap_chunk(int k) {  // the chunk that pads k least; the larger one on
     }
     return best;
 }
+int dwconv_tile_rows(int B, int S, int C) {  // 256 rows where that fills the chip's 3 x 256 workgroup slots once, else 128
+    const long ct = (C + DW_CT - 1) / DW_CT;
+    return (long)B * ((S + 255) / 256) * ct >= 768 ? 256 : 128;
+}
 int launch_dwconv(const DwConvArgs& a, int dtype, hipStream_t stream) {
     if (a.B <= 0 || a.S <= 0) return FS2_OK;
     if (a.k < 1 || a.k > DW_KMAX || a.C % 4) return FS2_ERR_SHAPE;
-    const dim3 grid((a.S + DW_TR - 1) / DW_TR, (a.C + DW_CT - 1) / DW_CT, a.B), block(256);
+    const int tr = dtype == FS2_BF16 ? dwconv_tile_rows(a.B, a.S, a.C) : 256;
+    const dim3 grid((a.S + tr - 1) / tr, (a.C + DW_CT - 1) / DW_CT, a.B), block(256);
     switch (dwconv_tap_chunk(a.k)) {
-#define FS2_DW(TC)                                                                                      \
-    case TC:                                                                                            \
-        if (dtype == FS2_BF16) hipLaunchKernelGGL((dwconv_kernel<bf16, TC>), grid, block, 0, stream, a); \
-        else hipLaunchKernelGGL((dwconv_kernel<float, TC>), grid, block, 0, stream, a);                  \
+#define FS2_DW(TC)                                                                                                     \
+    case TC:                                                                                                           \
+        if (dtype != FS2_BF16) hipLaunchKernelGGL((dwconv_kernel<float, TC>), grid, block, 0, stream, a);               \
+        else if (tr == 256) hipLaunchKernelGGL((dwconv_kernel<bf16, TC, 256>), grid, block, 0, stream, a);              \
+        else hipLaunchKernelGGL((dwconv_kernel<bf16, TC, 128>), grid, block, 0, stream, a);                             \
         break;
         FS2_DW(3) FS2_DW(5) FS2_DW(7) FS2_DW(8) FS2_DW(9)
 #undef FS2_DW

@@ -767,6 +767,20 @@ def test_dwconv(dtype, B, S, C, k):
     assert float((got - ref).abs().max()) <= tol(dtype, ref)
 
 
+@pytest.mark.parametrize("k", [3, 9, 21])
+def test_dwconv_tile_heights_are_bit_identical(k):
+    """r06: a bf16 depth-wise launch that cannot give every CU three workgroups runs 128-row tiles, a larger one 256-row tiles (a
+    performance choice by launch size).  The taps of an output are added in the same order either way: an utterance gives the same
+    bits alone (4 x 2 tiles of 128 rows) and inside a batch of 64 (64 x 2 x 4 tiles of 256 rows)."""
+    B, S, C = 64, 300, 256
+    x, w, b = rnd(B, S, C, seed=180), rnd(C, 1, k, seed=190, scale=k ** -0.5), rnd(C, seed=200)
+    whole = G.dwconv(G.BF16, x.reshape(B * S, C), w, b, B, S).reshape(B, S, C)
+    alone = G.dwconv(G.BF16, x[5:6].reshape(S, C), w, b, 1, S).reshape(1, S, C)
+    assert torch.equal(alone, whole[5:6])
+    ref = F.conv1d(G.rounded(x[:3], G.BF16).transpose(1, 2), w, b, padding="same", groups=C).transpose(1, 2)
+    assert float((whole[:3] - ref).abs().max()) <= tol(G.BF16, ref)
+
+
 # ------------------------------------------------------------------------------------------------
 def test_durations_round_guard_prefix():
     B, L = 6, 300

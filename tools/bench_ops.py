@@ -322,6 +322,10 @@ def main():
             dwconv_case("c3 dwconv T rows", 32, 1536, 768, k, a.reps)
         for k in (5, 25, 13, 9):
             dwconv_case("c3 dwconv enc rows", 32, 256, 768, k, a.reps)
+        for k in (3, 9, 13, 17, 21):  # the reference-default model (H = 256): 768 tiles of 256 rows = one round of three workgroups per CU
+            dwconv_case("ref-default dwconv T rows", 32, 1536, 256, k, a.reps)
+        for k in (5, 25, 13, 9):
+            dwconv_case("ref-default dwconv enc rows", 32, 256, 256, k, a.reps)
     if a.what in ("c3gemm",):  # the LS-76M decoder's pointwise GEMMs, by tile height
         for v in ([3, 4, 5] if a.variant < 0 else [a.variant]):
             gemm_case("c3 in_proj", 49152, 2304, 768, 1, 49152, a.reps, v)
