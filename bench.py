@@ -36,6 +36,7 @@ import torch
 import torch.distributed as dist
 
 MFMA_PEAK = {"bf16": 2.5e15, "fp32": 157.3e12}  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK = 8.0e12  # HBM3E spec (same guide; ~6.3e12 measured-achievable)
 HOP, SR = 256, 22050
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r06_pmc_traffic.json")  # regenerated every round: tools/pmc_traffic.sh
 
@@ -673,12 +674,22 @@ def main():
                        "frames_per_utterance": T, "global_batch": args.batch * world,
                        "parallelism": f"dp{world} (utterance shards, RCCL all-gather of mels only)" if multi else "single GPU",
                        "params": cfg.param_count()},
-            "roofline": {"bound": "mfma", "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
-                         "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
+            # which roof bounds the dominant launch: its algorithmic intensity (FLOPs / algorithmic bytes, both accounted by the engine)
+            # against the machine balance 2.5 PF / 8 TB/s = 312 FLOP/B.  The dense conv (1.8 kFLOP/B) and the K = 768 pointwise GEMM
+            # (607) are MFMA-bound; the K = 256 pointwise GEMM of the reference-default model (204: 25 MB in, 101 MB out) is HBM-bound
+            "roofline": (lambda ai, bpl: {
+                         **({"bound": "mfma", "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": achieved / peak}
+                            if ai >= peak / HBM_PEAK else
+                            {"bound": "hbm", "achieved": bpl / avg_s / 1e9 if avg_s > 0 else 0.0, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                             "frac": bpl / avg_s / HBM_PEAK if avg_s > 0 else 0.0, "mfma_frac": achieved / peak}),
+                         "algorithmic_intensity_flop_per_byte": ai, "bytes_per_launch": bpl,
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": ("gemm_conv_slab_kernel: decoder FFN conv1, implicit-GEMM Conv1d "
                                     f"M={args.batch * T} N={cfg.decoder_conv_filter_size} K={cfg.decoder_kernel_sizes[0]}x{cfg.hidden}")
                          if not cfg.decoder_depthwise_conv else
-                         f"gemm_conv_slab_kernel: decoder FFN pointwise conv1.1 M={args.batch * T} N={cfg.decoder_conv_filter_size} K={cfg.hidden}",
+                         (f"{'gemm_persist_kernel' if cfg.hidden > 256 else 'gemm_wres_kernel'}: decoder FFN pointwise conv1.1 (behind the depth-wise conv) "
+                          f"M={args.batch * T} N={cfg.decoder_conv_filter_size} K={cfg.hidden}")})(
+                             prof["flops"] / max(prof["bytes"], 1.0), prof["bytes"] / n) | {
                          "launches_timed": prof["launches"], "avg_launch_us": avg_s * 1e6,
                          "flops_per_launch": prof["flops"] / n,
                          "measured": f"HIP events on the launch stream around every launch of this class in {psteps} eager steps of the same "
