@@ -298,7 +298,7 @@ CU_INGEST_GBS = 64.0   # per-CU L2 -> LDS ceiling measured on this part (tools/p
 N_CUS = 256
 
 
-def encoder_mha_ingest_bound(cfg, B, L, block_s):
+def encoder_mha_ingest_bound(cfg, B, L, block_s, fused_tail=False):
     """Roofline of the encoder self-attention block (in-projection, attention, out-projection + residual + LayerNorm) against the
     per-CU ingest ceiling: the bytes ONE CU has to pull through L2 into LDS / registers for its share of each launch, at the tile
     shapes the launchers pick for M = B L rows (gemm_mfma.hip launch_gemm_plain's cost model: 128-row x 256-column tiles for the
@@ -312,12 +312,17 @@ def encoder_mha_ingest_bound(cfg, B, L, block_s):
     # in-projection: M x 3H, K = H: tiles of 128 rows x 256 columns, each pulls its weight tile (256 x H) and its rows (128 x H)
     t_in = -(-M // 128) * -(-3 * H // 256)
     launches.append(("in_proj", t_in, (256 * H + 128 * H) * e))
-    # attention: 64 queries x one head per workgroup: Q (64 x d) + K, V of the head (2 x L x d)
-    t_at = B * heads * -(-L // 64)
-    launches.append(("attention", t_at, (64 * d + 2 * L * d) * e))
-    # out-projection + residual + LayerNorm: 32-row tiles over whole rows: the H x H weights, 32 rows of input, 32 rows of residual
-    t_out = -(-M // 32)
-    launches.append(("out_proj+LN", t_out, (H * H + 2 * 32 * H) * e))
+    if fused_tail:
+        # r06, attn_out_ln_kernel: 64 queries x BOTH heads per workgroup: Q (64 x H) + K, V of both heads (2 x L x H) + the H x H out-projection
+        # weights + 64 residual rows
+        launches.append(("attention+out_proj+LN", B * -(-L // 64), (64 * H + 2 * L * H + H * H + 64 * H) * e))
+    else:
+        # attention: 64 queries x one head per workgroup: Q (64 x d) + K, V of the head (2 x L x d)
+        t_at = B * heads * -(-L // 64)
+        launches.append(("attention", t_at, (64 * d + 2 * L * d) * e))
+        # out-projection + residual + LayerNorm: 32-row tiles over whole rows: the H x H weights, 32 rows of input, 32 rows of residual
+        t_out = -(-M // 32)
+        launches.append(("out_proj+LN", t_out, (H * H + 2 * 32 * H) * e))
     per = []
     bound = 0.0
     for name, wgs, by in launches:
@@ -327,11 +332,11 @@ def encoder_mha_ingest_bound(cfg, B, L, block_s):
         per.append({"launch": name, "workgroups": wgs, "bytes_per_workgroup": by, "rounds_over_256_cus": rounds, "bound_us": round(us, 2)})
     return {"bound": "cu-ingest (L2 -> LDS)", "peak": CU_INGEST_GBS, "unit": "GB/s per CU", "bound_us": round(bound, 2),
             "measured_us": round(block_s * 1e6, 2), "frac": bound / (block_s * 1e6) if block_s > 0 else 0.0, "launches": per,
-            "reading": "the three launches stream for bound_us of the measured time; the rest is what a 10-us launch is made of besides its "
+            "reading": "the launches stream for bound_us of the measured time; the rest is what a 10-us launch is made of besides its "
                        "stream - dispatch and ramp over 256 CUs, the first operand round trip, the LayerNorm epilogue's row exchange, the store "
-                       "drain - per launch ~2.5 us of stream against ~8 us of fixed cost (profiles/HISTORY.md §4, 'the encoder launches').  Fusing the block "
-                       "per utterance was sized and not built: 32 utterances x 4 query blocks = 128 workgroups, each re-projecting its head's K "
-                       "and V for all 256 keys (101 MFLOP per workgroup) = ~25 us on half the CUs against the ~33 us of the three launches"}
+                       "drain (profiles/HISTORY.md §4, 'the encoder launches').  r06: attention + out-projection + residual + LayerNorm are ONE "
+                       "launch (attn_out_ln_kernel, 128 workgroups; 34 -> 31 us per block); folding the in-projection in as well would have every "
+                       "workgroup re-project its utterance's K and V (4 x redundant, ~67 MFLOP each): sized at no gain, not built"}
 
 
 def main():
@@ -702,15 +707,17 @@ def main():
                 "what": "BASELINE.json north_star: >= 40 % of the bf16 MFMA roofline on the attention GEMMs; the encoder's instance "
                         "(256 keys) is ingest-bound (profiles/HISTORY.md §4), this is the MFMA-bound one; HIP events, own pass of eager steps"},
             "encoder_mha_block": (lambda n_, s_: {
-                "kernel": "encoder self-attention block = three launches per layer: in-projection GEMM, attention_kernel (256 keys: ingest-bound), "
-                          "out-projection + residual + LayerNorm (fused epilogue)",
+                "kernel": "encoder self-attention block = two launches per layer (r06): in-projection GEMM; attn_out_ln_kernel = self-attention of both "
+                          "heads + out-projection + residual + LayerNorm (three launches where that kernel does not apply: H != 256, fp32, knob 1340)",
                 "achieved": (prof_mha["flops"] / n_) / s_ / 1e12 if s_ > 0 else 0.0, "peak": peak / 1e12, "unit": "TFLOP/s",
                 "frac": (prof_mha["flops"] / n_) / s_ / peak if s_ > 0 else 0.0, "avg_block_us": s_ * 1e6, "blocks_timed": prof_mha["launches"],
                 "flops_per_block": prof_mha["flops"] / n_,
-                "ingest_roofline": encoder_mha_ingest_bound(cfg, args.batch, args.phones, s_),
+                "ingest_roofline": encoder_mha_ingest_bound(cfg, args.batch, args.phones, s_,
+                                                            fused_tail=args.precision == "bf16" and cfg.hidden == 256 and cfg.encoder_head == 2
+                                                            and 1340 not in [k["knob"] for k in applied_knobs]),
                 "what": "BASELINE.json north_star names the encoder attention; SURVEY 8d: only the fused block (8 B L H^2 + 4 B L^2 H, AI ~ 724) can "
-                        "be MFMA-bound.  NOT fused here (DESIGN.md §4.3): at B x L = 8192 rows the block's three launches are neither MFMA- nor "
-                        "HBM-bound - `ingest_roofline` prices them against what bounds a launch of this size, the bytes each CU pulls through "
+                        "be MFMA-bound.  Two of its three launches are fused (r06, DESIGN.md §4.3): at B x L = 8192 rows the block is neither MFMA- nor "
+                        "HBM-bound - `ingest_roofline` prices it against what bounds launches of this size, the bytes each CU pulls through "
                         "L2 -> LDS at the measured per-CU ceiling; `frac` against the MFMA peak is kept for the record; HIP events around the "
                         "block, one forward at a time"})(max(prof_mha["launches"], 1), prof_mha["ms"] / max(prof_mha["launches"], 1) * 1e-3),
             "gpu_ms_per_step": gpu_ms,

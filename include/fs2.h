@@ -254,6 +254,9 @@ int fs2_profile_read(fs2_engine* e, int32_t kernel_class, double* total_ms, int6
  *              workgroup on (default) / wherever it applies; bit-identical outputs
  *   1320/1321  inference engine, bf16: the VarianceEncoder's bucketize + embedding add as the tail of its predictor's launch: off / on (default;
  *              bit-identical either way)
+ *   1340/1341  inference engine, bf16, H = 256 with two heads, ENCODER stack: self-attention and out-projection + residual + LayerNorm as two
+ *              launches / as one (attn_out_ln_kernel, default; r06): the attention rows are the same bits, the out-projection sums its 256
+ *              products in another order (equal to fp32 rounding before the bf16 store)
  *   1500/1501  fp32-storage split modes: attention on fp32 MFMA / on bf16 x 3 split products (default)
  * (Removed in r05, measured slower or neutral in r02-r04 and kept until then behind switches: 1211 resident-K/V attention, 211 operand
  *  ring, 1301 / 1302 tall / paired predictor tiles, 301 in-place wide-row LayerNorm epilogue, 311 256-row deferred epilogue.
@@ -359,6 +362,13 @@ int fs2_op_embed(int32_t dtype, const int64_t* phones, const float* table, const
                  void* x, uint8_t* src_mask, int32_t B, int32_t L, int32_t H, int32_t n_phones, void* hip_stream);
 int fs2_op_spk_proj(const float* dvec, const float* w, const float* b, float* spk, int32_t B, int32_t H,
                     int32_t Din, void* hip_stream);
+/* The encoder-side fused launch (r06; nn.MultiheadAttention's core + out_proj + the residual + norm1 of ConformerEncoderLayer.forward,
+ * model.py:108-116, behind the in-projection GEMM): out = LayerNorm(res + softmax(q k^T / sqrt(d) + key padding) v w_out^T + bias), bf16,
+ * H = 256, two heads.  qkv (B*S, 3H), key_pad_mask (B, S) 1 = pad, w_out (H, H) bf16, res / out (B*S, H) bf16 (out may alias res),
+ * scratch = H * H * 2 + B * ceil(S / 64) * 8 bytes.  FS2_ERR_SHAPE for other shapes / dtypes. */
+int fs2_op_attn_out_ln(int32_t dtype, const void* qkv, const uint8_t* key_pad_mask, const void* w_out, const float* bias, const void* res,
+                       const float* ln_g, const float* ln_b, void* out, void* scratch, int32_t B, int32_t S, int32_t H, int32_t heads,
+                       void* hip_stream);
 /* VariancePredictor (model.py:482-522), dense k=3, H=256, bf16, one launch: w = (nlayers, H, taps*H)
  * tap-major rows, bias / ln_g / ln_b = (nlayers, H) fp32, packed_scratch = nlayers * H * taps * H * 2
  * bytes (fragment-ordered copy of w, built by this call).  FS2_ERR_SHAPE if the shape is not covered. */

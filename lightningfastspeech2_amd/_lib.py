@@ -136,6 +136,7 @@ def load():
                                      C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.fs2_op_convert.argtypes = [i32, i32, vp, vp, C.c_size_t, vp]
     lib.fs2_op_predictor.argtypes = [i32, vp, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    lib.fs2_op_attn_out_ln.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     lib.fs2_op_predictor_dw.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, i32, i32, i32, i32, vp]
     lib.fs2_op_masked_loss_ws_bytes.restype = C.c_size_t
     lib.fs2_op_masked_loss_ws_bytes.argtypes = []

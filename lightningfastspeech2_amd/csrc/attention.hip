@@ -447,6 +447,354 @@ __global__ __launch_bounds__(NW * 64, (sizeof(T) == 2 && D == 128) ? 2 : 1) void
 #endif
 }
 
+// =====================================================================================================================================
+// r06: the encoder's self-attention + out-projection + residual + LayerNorm as ONE launch (bf16, H = 256, two heads of 128) - two thirds
+// of the block BASELINE.json's north star names (nn.MultiheadAttention inside ConformerEncoderLayer.forward, model.py:108-116; the
+// in-projection stays a GEMM launch in front).  A 4-wave workgroup owns 64 queries of one utterance: waves 0-1 run head 0, waves 2-3 head 1 -
+// each pair exactly attention_kernel<bf16, 128, 2>'s loop (same per-row instruction sequence: O is the same bits) on its own K / V tiles, in
+// lock step (same utterance, same key mask, same barriers).  The normalised O rows (64 x 256 bf16) go into LDS where the K tiles were, in
+// the single-launch predictor's slab layout, and become the A operand of the out-projection: each wave owns all 64 rows x 64 output
+// channels, the 256 x 256 weights stream from L2 straight into MFMA fragments (packed at fs2_finalize in predictor_fused.hip's fragment
+// order, launch_pack_predictor_weights(taps = 1)), the bias is the
+// accumulators' initial value, the residual rows are requested before the K loop, LayerNorm as in the predictor's epilogue (two-pass
+// statistics, lane-group sums by permlane swaps, one LDS exchange between the four waves per pass).  Replaces a 256-workgroup attention
+// launch + a 256-workgroup GEMM + LayerNorm launch (10.7 + 14.8 us at C2: 5.2 k CU-us) by 128 workgroups.
+struct AttnOutSmem {
+    static constexpr int TILE_B = 128 * 128;  // a 64-key x 128-dim bf16 K (or row-major V) tile
+};
+__global__ __launch_bounds__(256, 2) void attn_out_ln_kernel(AttnOutArgs p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using T = bf16;
+    constexpr int D = 128, HH = 256, KVB = 64, E16 = 8, KC = Mma32<T>::K_PER_CHUNK, NQC = D / KC, KRB = D * 2, KNS = KRB / 16;
+    constexpr int NKB = KVB / 32, ND = D / 32, TILE_B = AttnOutSmem::TILE_B, NINST = TILE_B / 1024 / 2;
+    constexpr float THR = 6.0f;
+    // (measured and dropped, r06: K and V tiles double-buffered - K_{j+1} / V_{j+1} requested a whole tile ahead, one barrier per tile, four
+    //  LDS objects with static names, 133 KB - 22.3 us against 20.2 for this two-barrier form in tools/bench_ops.py encmha: the loop is not
+    //  bound by the tiles' round trips, as r02's one-barrier ring and r03's resident-K/V form of attention_kernel had already measured)
+    __shared__ __attribute__((aligned(16))) unsigned char sK[2 * TILE_B];  // [head]; afterwards: the O slab (64 rows x 512 B)
+    __shared__ __attribute__((aligned(16))) unsigned char sV[2 * TILE_B];
+    __shared__ float red[2][4 * 64];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = wave >> 1, wq = wave & 1;  // head; query group (32 queries) inside the head's pair of waves
+    const int li = lane & 31, hi = lane >> 5;
+    const int nq = (p.S + 63) / 64;
+    const int xcd = blockIdx.x & 7, r8 = blockIdx.x >> 3;  // all query blocks of an utterance on one XCD's L2
+    const int b = (r8 / nq) * 8 + xcd;
+    if (b >= p.B) return;
+    const int q0 = (r8 % nq) * 64;
+    const int ld = 3 * HH;
+    const T* __restrict__ qkv = (const T*)p.qkv;
+    const uint64_t* kbits = p.kbits + (size_t)b * p.nw64;
+    const int ntiles = (p.S + KVB - 1) / KVB;
+
+    // ---- out-projection weight stream: this wave's 4 fragments per 32-k step, 4-stage ring, first three stages requested now ----
+    constexpr int NFR = 4, MI16 = 4, PKB = HH / 32, STEP_U4 = (HH / 32) * 2 * 64, RING = PKB;  // the whole 8-step stream in flight at once (128 registers: O's are dead by then)
+    const uint4* __restrict__ wbase = (const uint4*)p.wpk + wave * NFR * 64 + lane;
+    uint4 bw[RING][NFR];
+    auto loadB = [&](uint4 (&bb)[NFR], int g) {
+        g = g < PKB ? g : PKB - 1;
+#pragma unroll
+        for (int ni = 0; ni < NFR; ++ni) bb[ni] = wbase[(size_t)g * STEP_U4 + ni * 64];
+    };
+
+    const unsigned utt_bytes = (unsigned)((size_t)p.S * ld * sizeof(T));
+    const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc((void*)(qkv + (size_t)b * p.S * ld), 0, utt_bytes, 0x00020000);
+    unsigned kvo[NINST], vvo[NINST];
+#pragma unroll
+    for (int i = 0; i < NINST; ++i) {
+        const int P = (i * 2 + wq) * 64 + lane;
+        const int row = P / KNS, ps = P % KNS;
+        kvo[i] = (unsigned)((row * ld + HH + h * D) * 2 + (unswz_slot<KRB>(row, ps) << 4));
+        vvo[i] = (unsigned)((row * ld + 2 * HH + h * D) * 2 + ((ps ^ vswz<KRB>(row)) << 4));
+    }
+    const unsigned ktile = (unsigned)(KVB * ld * 2);
+    auto dma16 = [&](unsigned char* dst, unsigned voff) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(qrs, (__attribute__((address_space(3))) void*)dst, 16, voff, 0, 0, 0);
+    };
+    auto issue_k = [&](int j, unsigned char* buf) {
+        unsigned char* const d = buf + h * TILE_B;
+#pragma unroll
+        for (int i = 0; i < NINST; ++i) dma16(d + (i * 2 + wq) * 1024, kvo[i] + (unsigned)j * ktile);
+    };
+    auto issue_v = [&](int j, unsigned char* buf) {
+        unsigned char* const d = buf + h * TILE_B;
+#pragma unroll
+        for (int i = 0; i < NINST; ++i) dma16(d + (i * 2 + wq) * 1024, vvo[i] + (unsigned)j * ktile);
+    };
+    auto tile_bits = [&](int j) -> unsigned long long { return kbits[(j * KVB) >> 6]; };
+
+    // ---- Q fragments, scaled by log2(e) / sqrt(d) ----
+    uint4 qf[NQC];
+    {
+        int qrow = q0 + wq * 32 + li;
+        if (qrow >= p.S) qrow = p.S - 1;
+        const T* src = qkv + (size_t)(b * p.S + qrow) * ld + h * D + hi * E16;
+#pragma unroll
+        for (int c = 0; c < NQC; ++c) {
+            float f[8];
+            Vec16<T>::unpack(*(const uint4*)(src + c * KC), f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] *= p.scale_log2e;
+            qf[c] = Vec16<T>::pack(f);
+        }
+    }
+    f32x16_t oacc[ND];
+#pragma unroll
+    for (int i = 0; i < ND; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // ---- the attention loop: attention_kernel<bf16, 128, 2>'s, per head pair ----
+    const unsigned char* const sKh = sK + h * TILE_B;
+    const unsigned char* const sVh = sV + h * TILE_B;
+    if (ntiles > 0 && tile_bits(0) != 0ull) issue_k(0, sK);
+    for (int j = 0; j < ntiles; ++j) {
+        const unsigned long long bits = tile_bits(j);
+        const bool valid = bits != 0ull;
+        dma_drain();
+        __syncthreads();  // K_j has landed; everyone is past P.V of tile j - 1: sV is free
+        if (valid) issue_v(j, sV);  // V_j streams in underneath Q.K^T
+        uint4 pf[4];
+        if (valid) {
+            const float m_eff = (m_run == -INFINITY) ? 0.f : m_run;
+            const float m_init = -m_eff;
+            f32x16_t sacc[NKB];
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[kb][r] = m_init;
+            {
+                constexpr int NF = NQC * NKB, PD = NF < 6 ? NF : 6;
+                uint4 kq[PD];
+                auto kaddr = [&](int i) { return sKh + swz_row<KRB>((i % NKB) * 32 + li, (i / NKB) * 2 + hi); };
+#pragma unroll
+                for (int i = 0; i < PD; ++i) kq[i] = *(const uint4*)kaddr(i);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < NF; ++i) {
+                    Mma32<T>::step(kq[i % PD], qf[i / NKB], sacc[i % NKB]);
+                    if (i + PD < NF) kq[i % PD] = *(const uint4*)kaddr(i + PD);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (bits != ~0ull) {
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ko = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        if (!((bits >> ko) & 1ull)) sacc[kb][r] = -INFINITY;
+                    }
+            }
+            float mx = sacc[0][0];
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
+            mx = half_max(mx);
+            if (__any(m_run == -INFINITY || mx > THR)) {
+                const float m_new = fmaxf(m_run, m_eff + mx);
+                const float alpha = (m_new == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m_run - m_new);
+                const float delta = (m_new == -INFINITY) ? 0.f : m_new - m_eff;
+                l_run *= alpha;
+#pragma unroll
+                for (int i = 0; i < ND; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+                m_run = m_new;
+#pragma unroll
+                for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sacc[kb][r] -= delta;
+            }
+            float rs = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(sacc[kb][r]);
+                    sacc[kb][r] = e;
+                    rs += e;
+                }
+            rs = half_sum(rs);
+            l_run += rs;
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) {
+                float f[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int flat = ch * 8 + e;
+                    f[e] = sacc[flat >> 4][flat & 15];
+                }
+                pf[ch] = Vec16<T>::pack(f);
+            }
+        }
+        dma_drain();
+        __syncthreads();  // V_j has landed; every wave is done reading sK
+        if (j + 1 < ntiles && tile_bits(j + 1) != 0ull) issue_k(j + 1, sK);  // next K under P.V
+        if (valid) {
+            const int i16 = lane & 15, g1 = (lane >> 4) & 1;
+            const int rsub = i16 >> 2;
+            const int rowb = (4 * hi + rsub) * KRB + (i16 & 1) * 8;
+            int vcol[ND];
+#pragma unroll
+            for (int nd = 0; nd < ND; ++nd) vcol[nd] = rowb + (((nd * 4 + g1 * 2 + ((i16 & 3) >> 1)) ^ vswz<KRB>(rsub)) << 4);
+            constexpr int NF = 4 * ND, PD = 4;
+            uint4 vq[PD];
+            auto vload = [&](int i) {
+                const unsigned char* vb = sVh + vcol[i % ND] + (i / ND) * 16 * KRB;
+                const uint2 lo = tr_read_b64(vb);
+                const uint2 hi2 = tr_read_b64(vb + 8 * KRB);
+                return make_uint4(lo.x, lo.y, hi2.x, hi2.y);
+            };
+#pragma unroll
+            for (int i = 0; i < PD; ++i) vq[i] = vload(i);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < NF; ++i) {
+                Mma32<T>::step(vq[i % PD], pf[i / ND], oacc[i % ND]);
+                if (i + PD < NF) vq[i % PD] = vload(i + PD);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < RING; ++g) loadB(bw[g], g);  // (requested here, not at the top: registers held across the attention loop spill)
+    // ---- O rows -> the slab (where the K tiles were: nobody reads sK after the loop's last barrier) ----
+    // lane owns query row wq*32 + li and channels h*128 + nd*32 + 8g + 4hi + 0..3: half a 16-byte slot
+    const SlabSwizzle sw(HH * 2 / 16);
+    unsigned char* const slab = sK;
+    {
+        const float inv = 1.f / l_run;  // all keys padded -> NaN, as the reference's softmax gives
+        const int row = wq * 32 + li;
+#pragma unroll
+        for (int nd = 0; nd < ND; ++nd)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int L = h * 16 + nd * 4 + g;
+                const uint2 o2 = make_uint2(pack_bf16x2(oacc[nd][4 * g + 0] * inv, oacc[nd][4 * g + 1] * inv),
+                                            pack_bf16x2(oacc[nd][4 * g + 2] * inv, oacc[nd][4 * g + 3] * inv));
+                *(uint2*)(slab + row * (HH * 2) + (sw.slot(L, row) << 4) + hi * 8) = o2;
+            }
+    }
+    // ---- residual rows (requested before the K loop) and bias ----
+    const int fr = lane & 15, fg = lane >> 4;
+    const int n0 = wave * (NFR * 16) + fg * 8;  // fragment pair j: this lane's channels n0 + 32 j .. + 7
+    uint4 resv[MI16][2];
+    {
+        const T* rs_ = (const T*)p.res + (size_t)b * p.S * HH;
+#pragma unroll
+        for (int m = 0; m < MI16; ++m) {
+            int t = q0 + m * 16 + fr;
+            t = t < p.S ? t : p.S - 1;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) resv[m][j] = *(const uint4*)(rs_ + (size_t)t * HH + n0 + 32 * j);
+        }
+    }
+    f32x4_t acc[NFR][MI16];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float4 b0 = *(const float4*)(p.bias + n0 + 32 * j), b1 = *(const float4*)(p.bias + n0 + 32 * j + 4);
+#pragma unroll
+        for (int m = 0; m < MI16; ++m) {
+            acc[2 * j][m] = (f32x4_t){b0.x, b0.y, b0.z, b0.w};
+            acc[2 * j + 1][m] = (f32x4_t){b1.x, b1.y, b1.z, b1.w};
+        }
+    }
+    __syncthreads();  // the slab holds O
+    // ---- out-projection: 8 steps of 32 k ----
+    {
+        const unsigned char* arow_p = slab + fr * (HH * 2);
+        const int acx = (((fg & 1) << 3) | ((fg >> 1) ^ (fr & 7))) << 4;  // SlabSwizzle::slot(fg, fr); + kb below
+#pragma unroll
+        for (int kb = 0; kb < PKB; ++kb) {
+            uint4 fx[MI16];
+#pragma unroll
+            for (int mi = 0; mi < MI16; ++mi) fx[mi] = *(const uint4*)(arow_p + mi * 16 * (HH * 2) + (acx ^ ((((kb & 3) << 1) | ((kb >> 2) << 4)) << 4)));
+#pragma unroll
+            for (int ni = 0; ni < NFR; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI16; ++mi) Mma16<T>::step(bw[kb % RING][ni], fx[mi], acc[ni][mi]);
+        }
+    }
+    // ---- + residual, LayerNorm (the single-launch predictor's epilogue without the ReLU), store ----
+    const float invn = 1.0f / (float)HH;
+    float mean[MI16], rstd[MI16];
+#pragma unroll
+    for (int m = 0; m < MI16; ++m) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float rf[8];
+            Vec16<T>::unpack(resv[m][j], rf);
+            f32x4_t& a0 = acc[2 * j][m];
+            f32x4_t& a1 = acc[2 * j + 1][m];
+            a0 = (f32x4_t){a0[0] + rf[0], a0[1] + rf[1], a0[2] + rf[2], a0[3] + rf[3]};
+            a1 = (f32x4_t){a1[0] + rf[4], a1[1] + rf[5], a1[2] + rf[6], a1[3] + rf[7]};
+            s += (a0[0] + a0[1]) + (a0[2] + a0[3]) + (a1[0] + a1[1]) + (a1[2] + a1[3]);
+        }
+        s = group4_sum(s);
+        if (fg == 0) red[0][wave * 64 + m * 16 + fr] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < MI16; ++m) {
+        const int row = m * 16 + fr;
+        const float t4 = (red[0][row] + red[0][64 + row]) + (red[0][128 + row] + red[0][192 + row]);
+        mean[m] = t4 * invn;
+        float q = 0.f;
+#pragma unroll
+        for (int ni = 0; ni < NFR; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d = acc[ni][m][r] - mean[m];
+                acc[ni][m][r] = d;
+                q = __builtin_fmaf(d, d, q);
+            }
+        q = group4_sum(q);
+        if (fg == 0) red[1][wave * 64 + row] = q;
+    }
+    __syncthreads();
+    T* out = (T*)p.out + (size_t)b * p.S * HH;
+#pragma unroll
+    for (int m = 0; m < MI16; ++m) {
+        const int row = m * 16 + fr, t = q0 + row;
+        const float t4 = (red[1][row] + red[1][64 + row]) + (red[1][128 + row] + red[1][192 + row]);
+        rstd[m] = 1.0f / sqrtf(t4 * invn + p.eps);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + 32 * j;
+            const float4 g0 = *(const float4*)(p.ln_g + n), g1 = *(const float4*)(p.ln_g + n + 4);
+            const float4 e0 = *(const float4*)(p.ln_b + n), e1 = *(const float4*)(p.ln_b + n + 4);
+            const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            const float ee[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+            float y[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) y[r] = __builtin_fmaf(acc[2 * j + (r >> 2)][m][r & 3] * rstd[m], gg[r], ee[r]);
+            if (t < p.S) *(uint4*)(out + (size_t)t * HH + n) = Vec16<T>::pack(y);
+        }
+    }
+#else
+    (void)p;
+#endif
+}
+
+bool attn_out_ln_supported(int dtype, int H, int heads, int S) {
+    return dtype == FS2_BF16 && H == 256 && heads == 2 && S >= 1 && (size_t)S * 3 * H * 2 < 0xFFFFF000ull;
+}
+int launch_attn_out_ln(const AttnOutArgs& a, hipStream_t stream) {
+    if (!attn_out_ln_supported(FS2_BF16, a.H, a.heads, a.S)) return FS2_ERR_SHAPE;
+    if (!a.qkv || !a.kbits || !a.wpk || !a.bias || !a.res || !a.ln_g || !a.ln_b || !a.out || a.out == a.qkv) return FS2_ERR_ARG;
+    if (((uintptr_t)a.qkv | (uintptr_t)a.wpk | (uintptr_t)a.bias | (uintptr_t)a.res | (uintptr_t)a.ln_g | (uintptr_t)a.ln_b | (uintptr_t)a.out) & 15) return FS2_ERR_ARG;
+    if (a.B <= 0) return FS2_OK;
+    const int nq = (a.S + 63) / 64, B8 = (a.B + 7) / 8 * 8;
+    hipLaunchKernelGGL(attn_out_ln_kernel, dim3((unsigned)(B8 * nq)), dim3(256), 0, stream, a);
+    return hipGetLastError() == hipSuccess ? FS2_OK : FS2_ERR_HIP;
+}
+
 // ---- V^T staging: qkv's V columns -> Vt[(b*heads+h)][dv][Spad], zero padded to Spad; for bf16
 // the keys inside each 16-group are permuted to the order the S^T register layout consumes:
 //   pos(o) = ((o>>2)&1)*8 + (o&3) + 4*(o>>3).

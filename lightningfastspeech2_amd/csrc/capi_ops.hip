@@ -38,6 +38,7 @@ int apply_knob(Tuning& t, int variant) {
     int ok = 1;
     if (variant == 1500 || variant == 1501) t.attn_x3 = variant - 1500;               // fp32-storage split modes: attention on fp32 MFMA / on bf16 x 3 split products (default)
     else if (variant >= 1400 && variant <= 1402) t.gemm_wres = variant - 1400;        // bf16 K = 256 plain GEMMs: slab kernel / weight-resident kernel where it pays (default) / wherever it applies
+    else if (variant == 1340 || variant == 1341) t.enc_attn_out = variant - 1340;     // engine, bf16, H = 256, 2 heads: encoder attention + out-projection + LayerNorm as two launches / one (default)
     else if (variant == 1320 || variant == 1321) t.pred_fuse_embed = variant - 1320;  // engine: variance encoder (bucketize + embedding add) as the tail of its predictor launch: off / on (default)
     else if (variant >= 1200 && variant <= 1204) t.attn_pipe = variant - 1200;        // 1200: attention.hip only; 1201 / 1202 / 1204: the software-pipelined kernel with 32 / 64 / 96 queries per wave where it applies; 1203: by size (default)
     else if (variant == 1100 || variant == 1101) t.colsum_fused = variant - 1100;     // column sums in two launches (default) / one
@@ -293,6 +294,27 @@ int fs2_op_attention(int32_t dtype, const void* qkv, const uint8_t* key_pad_mask
     r = launch_transpose_v(a, dtype, st);
     if (r != FS2_OK) return r;
     return launch_attention(a, dtype, st);
+}
+
+// Encoder-side fused launch (attention.hip attn_out_ln_kernel, r06): out = LayerNorm(res + MHA-core(qkv) w_out^T + bias), bf16, H = 256, 2 heads.
+// scratch: H * H * 2 bytes (w_out in fragment order) + B * ceil(S / 64) * 8 bytes (valid-key words), 16-byte aligned.
+int fs2_op_attn_out_ln(int32_t dtype, const void* qkv, const uint8_t* key_pad_mask, const void* w_out, const float* bias, const void* res,
+                       const float* ln_g, const float* ln_b, void* out, void* scratch, int32_t B, int32_t S, int32_t H, int32_t heads, void* stream) {
+    if (!qkv || !key_pad_mask || !w_out || !bias || !res || !ln_g || !ln_b || !out || !scratch || B <= 0) return FS2_ERR_ARG;
+    if (!attn_out_ln_supported(dtype, H, heads, S)) return FS2_ERR_SHAPE;
+    hipStream_t st = (hipStream_t)stream;
+    const int nw64 = (S + 63) / 64;
+    uint64_t* bits = (uint64_t*)((char*)scratch + (size_t)H * H * 2);
+    MaskBitsArgs mb{key_pad_mask, bits, B, S, nw64};
+    int r = launch_mask_bits(mb, st);
+    if (r != FS2_OK) return r;
+    r = launch_pack_predictor_weights(w_out, scratch, st, 1);
+    if (r != FS2_OK) return r;
+    AttnOutArgs a;
+    a.qkv = qkv; a.kbits = bits; a.wpk = scratch; a.bias = bias; a.res = res; a.ln_g = ln_g; a.ln_b = ln_b; a.out = out;
+    a.B = B; a.S = S; a.H = H; a.heads = heads; a.nw64 = nw64;
+    a.scale_log2e = (float)(1.4426950408889634 / sqrt((double)(H / heads))); a.eps = 1e-5f;
+    return launch_attn_out_ln(a, st);
 }
 
 // The split-arithmetic attention on an fp32 (B*S, 3H) qkv tensor: head / tail split pass (the engine's in-projection writes the two

@@ -76,6 +76,7 @@ struct DwW {       // depth-wise conv weights fp32 (C, k) + bias
 };
 struct LayerW {
     ConvW in_proj, out_proj;
+    void* wo_pk = nullptr;  // out_proj.weight in the single-launch predictor's fragment order (attn_out_ln_kernel; bf16 encoder layers, H = 256, 2 heads)
     float *g1 = nullptr, *b1 = nullptr, *g2 = nullptr, *b2 = nullptr;
     bool depthwise = false;
     DwW dw;          // conv1.0 (depth-wise only)
@@ -449,6 +450,11 @@ int make_layer(fs2_engine* e, const std::string& p, int H, int F, bool dw, Layer
         CHK(make_conv(e, p + ".conv1.weight", p + ".conv1.bias", &L->c1, dt));
         CHK(make_conv(e, p + ".conv2.weight", p + ".conv2.bias", &L->c2, dt));
     }
+    if (dt == FS2_BF16 && H == 256 && p.compare(0, 8, "encoder.") == 0 && e->cfg.enc_heads == 2) {  // attn_out_ln_kernel's weight stream
+        CHK(dev_alloc(e, &L->wo_pk, predictor_packed_bytes_per_layer(1)));
+        CHK(launch_pack_predictor_weights(L->out_proj.w, L->wo_pk, nullptr, 1));
+        HIPCHK(e, hipStreamSynchronize(nullptr));
+    }
     return FS2_OK;
 }
 // The in-projection of block `p` with the previous block's norm2 (`pp`.norm2) folded in: see LayerW::in_proj_f.  bf16 stacks of wide
@@ -778,6 +784,29 @@ int conformer(fs2_engine* e, hipStream_t st, const LayerW& w, void* x, void* tmp
     a.qkv = sc.qkv; a.vt = sc.vt; a.kbits = sc.bits; a.out = sc.att;
     a.B = B; a.S = S; a.H = H; a.heads = heads; a.Spad = sc.Spad; a.nw64 = sc.nw64;
     a.scale_log2e = (float)(1.4426950408889634 / sqrt((double)(H / heads)));
+    if (!is_decoder && w.wo_pk && e->tune.enc_attn_out && !x3 && !prenorm_in && attn_out_ln_supported(dt, H, heads, S) &&
+        !(w.depthwise && H > 256 && e->defer_ln)) {
+        // r06: attention (both heads) + out-projection + residual + norm1 in ONE launch: tmp = LN1(x + out_proj(attention(qkv)))
+        AttnOutArgs ao;
+        ao.qkv = sc.qkv; ao.kbits = sc.bits; ao.wpk = w.wo_pk; ao.bias = w.out_proj.b; ao.res = x; ao.ln_g = w.g1; ao.ln_b = w.b1; ao.out = tmp;
+        ao.B = B; ao.S = S; ao.H = H; ao.heads = heads; ao.nw64 = sc.nw64; ao.scale_log2e = a.scale_log2e; ao.eps = 1e-5f;
+        {
+            Bracket br(e, FS2_K_ATTENTION, st, 4.0 * B * (double)S * S * H + 2.0 * M * (double)H * H, 5.0 * M * H * dsz + (double)H * H * dsz);
+            const int r = launch_attn_out_ln(ao, st);
+            if (r != FS2_OK) return fail(e, r, "fused attention + out-projection launch failed");
+        }
+        delete mha; mha = nullptr;
+        if (w.depthwise) {
+            CHK(dwconv(e, st, w.dw, tmp, sc.u, B, S, dt));
+            CHK(gemm(e, st, w.c1, sc.u, sc.hid, M, S, true, dt, nullptr, -1));
+        } else {
+            CHK(gemm(e, st, w.c1, tmp, sc.hid, M, S, true, dt, nullptr, -1));
+        }
+        LnFuse ln;  // x = LN2(tmp + conv2(hid))
+        ln.res = tmp; ln.g = w.g2; ln.b = w.b2; ln.tmp = sc.proj;
+        CHK(gemm(e, st, w.c2, sc.hid, x, M, S, false, dt, &ln));
+        return FS2_OK;
+    }
     {
         Bracket br(e, FS2_K_ROWOPS, st, 0, 2.0 * M * H * dsz);
         const int r = x3 ? FS2_OK : launch_transpose_v(a, dt, st);  // (the split form reads V row-major, like the bf16 one)

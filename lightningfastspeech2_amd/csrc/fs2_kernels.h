@@ -21,6 +21,7 @@ struct Tuning {
     int split_f32 = 0;         // operator level only (tests): every fp32 slab launch in the bf16 x 3 split arithmetic
     int attn_pipe = 3;         // 0 attention_kernel only; 1 / 2 / 4 the pipelined kernel with 32 / 64 / 96 queries per wave; 3 by size
     int attn_x3 = 1;           // fp32-storage split modes: attention on bf16 x 3 split products (1) or fp32 MFMA (0)
+    int enc_attn_out = 1;      // engine: the encoder's attention + out-projection + residual + LayerNorm as one launch (attn_out_ln_kernel; bf16, H = 256, 2 heads)
     int pred_fuse_embed = 1;   // engine: the variance encoder's bucketize + embedding add as the tail of its predictor launch
     int attn_bwd_nb = 1, attn_bwd_nb_dq = 0;  // attention backward: 16-row blocks per wave of the (dK, dV) / dQ launch (dQ: 0 = by size)
     int colsum_fused = 0;      // column sums in one launch (device-scope fences: slower) / two
@@ -126,6 +127,23 @@ struct AttnArgs {
     uint64_t drop_seed = 0, drop_key = 0;
     const Tuning* tune = nullptr;
 };
+// r06: encoder-side fused launch (attention.hip attn_out_ln_kernel): self-attention of both heads + out-projection + residual + LayerNorm,
+// bf16, H = 256, two heads of 128: out = LayerNorm(res + attention(qkv) W_o^T + bias).  wpk = W_o (256 x 256) in the single-launch predictor's
+// fragment order (launch_pack_predictor_weights(w, out, stream, 1)).
+struct AttnOutArgs {
+    const void* qkv;        // (B*S, 3H) bf16 [q | k | v]
+    const uint64_t* kbits;  // (B, nw64) valid-key words
+    const void* wpk;        // packed W_o
+    const float* bias;      // (H)
+    const void* res;        // (B*S, H) bf16 residual
+    const float* ln_g;
+    const float* ln_b;
+    void* out;              // (B*S, H) bf16; may alias res
+    int B, S, H, heads, nw64;
+    float scale_log2e, eps;
+};
+bool attn_out_ln_supported(int dtype, int H, int heads, int S);
+int launch_attn_out_ln(const AttnOutArgs& a, hipStream_t stream);
 // Recomputing (flash) backward of the same attention, bf16, head dim 128 (attention_bwd.hip): dqkv (B*S, 3H) from dout (B*S, H),
 // the forward's qkv / lse2 and delta = fs2 attn_delta(dout, out).  Two launches: (dK, dV) per key block, dQ per query block.
 struct AttnBwdArgs {

@@ -189,6 +189,19 @@ def attention(dtype, qkv, key_pad_mask, B, S, H, heads):
     return out.float().cpu()
 
 
+def attn_out_ln(qkv, key_pad_mask, w_out, bias, res, gamma, beta, B, S, H, heads):
+    """fs2_op_attn_out_ln (bf16): LayerNorm(res + MHA-core(qkv) w_out^T + bias)."""
+    qd, rd, wd = to_dev(qkv, BF16), to_dev(res, BF16), to_dev(w_out, BF16)
+    md = torch.as_tensor(key_pad_mask).to(torch.uint8).to(DEV).contiguous()
+    f = lambda v: torch.as_tensor(v).float().to(DEV).contiguous()
+    bd, gd, bed = f(bias), f(gamma), f(beta)
+    out = torch.empty(B * S, H, dtype=torch.bfloat16, device=DEV)
+    scratch = torch.empty(H * H * 2 + B * ((S + 63) // 64) * 8, dtype=torch.uint8, device=DEV)
+    ok(lib().fs2_op_attn_out_ln(BF16, p(qd), p(md), p(wd), p(bd), p(rd), p(gd), p(bed), p(out), p(scratch), B, S, H, heads, stream()), "attn_out_ln")
+    torch.cuda.synchronize()
+    return out.float().cpu()
+
+
 def attention_x3(qkv, key_pad_mask, B, S, H, heads):
     """fs2_op_attention_x3: fp32 qkv, bf16 x 3 split products, fp32 out."""
     qd = torch.as_tensor(qkv).float().to(DEV).contiguous()

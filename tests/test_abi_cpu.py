@@ -144,7 +144,7 @@ def test_knob_setter_rejects_undefined_values(lib):
     for bad in (1300, 1301, 1302, 1319, 1322, 1399, 1403, 1205, 1210, 1211, 1299, 1102, 1002, 910, 802, 702, 502, 310, 311, 300, 301, 210, 211, 222, 203, 250, 251, 252, 253, 8, 100000):
         assert lib.fs2_op_set_gemm_variant(bad) == FS2_ERR_ARG, bad
     # the defaults (each is a defined value) leave the process as it was
-    for ok in (0, 202, 201, 221, 230, 231, 500, 701, 801, 909, 904, 1001, 1100, 1203, 1321, 1401, 1501):
+    for ok in (0, 202, 201, 221, 230, 231, 500, 701, 801, 909, 904, 1001, 1100, 1203, 1321, 1340, 1341, 1401, 1501):
         assert lib.fs2_op_set_gemm_variant(ok) == FS2_OK, ok
 
 

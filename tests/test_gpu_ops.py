@@ -533,6 +533,41 @@ def test_attention(dtype, B, S, H, heads, mask_kind):
     assert err <= tol(dtype, ref, f32=5e-5, bf16=2e-2), (err, tol(dtype, ref))
 
 
+@pytest.mark.parametrize("B,S,mask_kind", [(2, 40, "suffix"), (3, 130, "suffix"), (2, 200, "suffix"), (2, 64, "none"), (2, 257, "scatter"),
+                                            (1, 700, "suffix"), (9, 256, "suffix"), (32, 256, "none"), (3, 1, "none")])
+def test_encoder_attention_out_projection_layernorm_one_launch(B, S, mask_kind):
+    """r06, the block the north star names (nn.MultiheadAttention's core + out_proj + residual + norm1 of ConformerEncoderLayer.forward,
+    model.py:108-116): self-attention of both heads + out-projection + residual + LayerNorm in ONE launch (attn_out_ln_kernel; bf16,
+    H = 256, two heads) against (a) torch, (b) the two launches it replaces (fs2_op_attention, then fs2_op_gemm_ln): the attention rows are
+    the same bits, so the outputs differ by the out-projection's summation order only (fp32 rounding before the bf16 store); key padding
+    of every shape, skipped tiles, ragged last query block, more utterances than XCDs, a single row; repeatable."""
+    H, heads = 256, 2
+    qkv = rnd(B * S, 3 * H, seed=10)
+    w, bias = rnd(H, H, seed=12, scale=H ** -0.5), 0.3 * rnd(H, seed=13)
+    res = rnd(B * S, H, seed=14)
+    g, be = 1 + 0.2 * rnd(H, seed=15), 0.1 * rnd(H, seed=16)
+    mask = torch.zeros(B, S, dtype=torch.bool)
+    if mask_kind == "suffix":
+        for b in range(B):
+            mask[b, S - (7 + 13 * b) % S:] = True
+        mask[0, :] = False
+        mask[0, S - S // 2:] = True
+    elif mask_kind == "scatter":
+        gen = torch.Generator().manual_seed(11)
+        mask = torch.rand(B, S, generator=gen) < 0.3
+        mask[:, 0] = False
+    r = lambda t: G.rounded(t, G.BF16)
+    att = r(_attn_ref(r(qkv), mask, B, S, H, heads))
+    ref = F.layer_norm(r(res) + att @ r(w).T + bias, (H,), g, be, 1e-5)
+    got = G.attn_out_ln(qkv, mask, w, bias, res, g, be, B, S, H, heads)
+    assert not torch.isnan(got).any()
+    assert float((got - ref).abs().max()) <= 4e-2 * (float(ref.abs().max()) + 1)
+    two = G.gemm_ln(G.BF16, G.attention(G.BF16, qkv, mask, B, S, H, heads), w, bias, res, g, be)[0]
+    assert float((got - two).abs().max()) <= 2e-2 * (float(two.abs().max()) + 1)    # one bf16 ulp of an O(1) value at most
+    assert float((got - two).abs().mean()) <= 1e-3
+    assert torch.equal(G.attn_out_ln(qkv, mask, w, bias, res, g, be, B, S, H, heads), got)
+
+
 @pytest.mark.parametrize("B,S,H,heads,mask_kind", [
     (2, 40, 64, 2, "suffix"), (3, 130, 128, 2, "suffix"), (2, 200, 256, 2, "suffix"), (2, 64, 256, 2, "none"),
     (2, 257, 256, 2, "scatter"), (1, 700, 256, 2, "suffix"), (2, 33, 128, 4, "scatter"), (4, 1536, 256, 2, "none")])

@@ -251,6 +251,32 @@ def attn_case(name, B, S, H, heads, reps):
     print(f"{name:28s} B={B} S={S} H={H} heads={heads}  {t*1e6:8.1f} us (incl. mask bits + V^T staging)  {fl/t/1e12:7.1f} TF")
 
 
+def attn_out_case(name, B, S, reps):
+    """Encoder block tail: attention + out-projection + residual + LayerNorm as one launch (r06) against the two launches it replaces."""
+    H, heads = 256, 2
+    qkv = torch.randn(B * S, 3 * H, device=DEV).to(torch.bfloat16)
+    mask = torch.zeros(B, S, dtype=torch.uint8, device=DEV)
+    w = (torch.randn(H, H, device=DEV) * H ** -0.5).to(torch.bfloat16)
+    bias, g, be = (torch.randn(H, device=DEV) for _ in range(3))
+    res = torch.randn(B * S, H, device=DEV).to(torch.bfloat16)
+    out = torch.empty_like(res)
+    att = torch.empty_like(res)
+    tmp = torch.empty_like(res)
+    scratch = torch.empty(H * H * 2 + B * ((S + 63) // 64) * 8, dtype=torch.uint8, device=DEV)
+    bb = C.c_size_t()
+    vb = lib.fs2_op_attention_scratch_bytes(BF16, B, S, H, heads, C.byref(bb))
+    vt = torch.empty(max(vb, 16), dtype=torch.uint8, device=DEV)
+    bits = torch.empty(bb.value, dtype=torch.uint8, device=DEV)
+    t1 = timeit(lambda st: lib.fs2_op_attn_out_ln(BF16, p(qkv), p(mask), p(w), p(bias), p(res), p(g), p(be), p(out), p(scratch), B, S, H, heads, st), reps)
+    def two(st):
+        lib.fs2_op_attention(BF16, p(qkv), p(mask), p(att), p(vt), p(bits), B, S, H, heads, st)
+        lib.fs2_op_gemm_ln(BF16, p(att), p(w), p(bias), p(res), p(g), p(be), None, C.c_float(0.0), None, None, p(out), p(tmp), B * S, H, H, 1, B * S, 0, st)
+    t2 = timeit(two, reps)
+    fl = 4.0 * B * S * S * H + 2.0 * B * S * H * H
+    print(f"{name:28s} B={B} S={S}  one launch {t1 * 1e6:7.1f} us (incl. mask bits + weight pack)   two launches {t2 * 1e6:7.1f} us (incl. mask bits)   "
+          f"{fl / t1 / 1e12:6.1f} TF", flush=True)
+
+
 def dwconv_case(name, B, S, Cc, k, reps):
     """Depth-wise conv launch (rowops.hip dwconv_kernel): HBM-bound, priced against 8 TB/s on read + write of the activations."""
     x = torch.randn(B * S, Cc, device=DEV).to(torch.bfloat16)
@@ -317,6 +343,10 @@ def main():
             gemm_ln_case("enc conv2 1x1 +res+LN", 8192, 256, 1024, 1, 8192, a.reps, v)
             gemm_ln_case("enc out_proj +res+LN", 8192, 256, 256, 1, 8192, a.reps, v)
             gemm_ln_case("dur-pred conv k=3 +LN", 8192, 256, 256, 3, 256, a.reps, v, res=False, relu=True)
+    if a.what in ("encmha",):
+        attn_out_case("enc attention + out-proj + LN", 32, 256, a.reps)
+        attn_out_case("enc attention + out-proj + LN", 8, 256, a.reps)
+        attn_out_case("enc attention + out-proj + LN", 32, 128, a.reps)
     if a.what in ("rows",):  # the LS-76M depth-wise convs: the variance predictors' (k = 3 / 5) and the decoder's
         for k in (3, 5, 9, 13, 17, 21, 25, 31):
             dwconv_case("c3 dwconv T rows", 32, 1536, 768, k, a.reps)
