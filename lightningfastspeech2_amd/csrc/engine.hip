@@ -450,7 +450,8 @@ int make_layer(fs2_engine* e, const std::string& p, int H, int F, bool dw, Layer
         CHK(make_conv(e, p + ".conv1.weight", p + ".conv1.bias", &L->c1, dt));
         CHK(make_conv(e, p + ".conv2.weight", p + ".conv2.bias", &L->c2, dt));
     }
-    if (dt == FS2_BF16 && H == 256 && p.compare(0, 8, "encoder.") == 0 && e->cfg.enc_heads == 2) {  // attn_out_ln_kernel's weight stream
+    const bool is_enc = p.compare(0, 8, "encoder.") == 0;
+    if (dt == FS2_BF16 && H == 256 && (is_enc ? e->cfg.enc_heads : e->cfg.dec_heads) == 2) {  // attn_out_ln_kernel's weight stream
         CHK(dev_alloc(e, &L->wo_pk, predictor_packed_bytes_per_layer(1)));
         CHK(launch_pack_predictor_weights(L->out_proj.w, L->wo_pk, nullptr, 1));
         HIPCHK(e, hipStreamSynchronize(nullptr));
@@ -784,7 +785,11 @@ int conformer(fs2_engine* e, hipStream_t st, const LayerW& w, void* x, void* tmp
     a.qkv = sc.qkv; a.vt = sc.vt; a.kbits = sc.bits; a.out = sc.att;
     a.B = B; a.S = S; a.H = H; a.heads = heads; a.Spad = sc.Spad; a.nw64 = sc.nw64;
     a.scale_log2e = (float)(1.4426950408889634 / sqrt((double)(H / heads)));
-    if (!is_decoder && w.wo_pk && e->tune.enc_attn_out && !x3 && !prenorm_in && attn_out_ln_supported(dt, H, heads, S) &&
+    // (by the utterance length only, never by the batch: a shard alone must take the kernels its rows take inside the whole batch.  Measured,
+    //  tools/bench_ops.py encmha at B = 32: 256 rows 13.7 us against 10.7 + 14.8, 384: 23.8 vs 30.6, 512: 28.4 vs 36.1, 768: 47.7 vs 50.6, 1000:
+    //  59.6 vs 53.5 - the 64-query workgroups re-read K / V twice as often as the 128-query ones of the stand-alone kernel; from 1024 rows on the
+    //  pipelined attention kernel takes over anyway)
+    if (w.wo_pk && S <= 768 && e->tune.enc_attn_out && !x3 && !prenorm_in && attn_out_ln_supported(dt, H, heads, S) &&
         !(w.depthwise && H > 256 && e->defer_ln)) {
         // r06: attention (both heads) + out-projection + residual + norm1 in ONE launch: tmp = LN1(x + out_proj(attention(qkv)))
         AttnOutArgs ao;
@@ -798,9 +803,9 @@ int conformer(fs2_engine* e, hipStream_t st, const LayerW& w, void* x, void* tmp
         delete mha; mha = nullptr;
         if (w.depthwise) {
             CHK(dwconv(e, st, w.dw, tmp, sc.u, B, S, dt));
-            CHK(gemm(e, st, w.c1, sc.u, sc.hid, M, S, true, dt, nullptr, -1));
+            CHK(gemm(e, st, w.c1, sc.u, sc.hid, M, S, true, dt, nullptr, is_decoder ? FS2_K_DEC_FFN_CONV1 : -1));
         } else {
-            CHK(gemm(e, st, w.c1, tmp, sc.hid, M, S, true, dt, nullptr, -1));
+            CHK(gemm(e, st, w.c1, tmp, sc.hid, M, S, true, dt, nullptr, is_decoder ? FS2_K_DEC_FFN_CONV1 : -1));
         }
         LnFuse ln;  // x = LN2(tmp + conv2(hid))
         ln.res = tmp; ln.g = w.g2; ln.b = w.b2; ln.tmp = sc.proj;

@@ -347,6 +347,9 @@ def main():
         attn_out_case("enc attention + out-proj + LN", 32, 256, a.reps)
         attn_out_case("enc attention + out-proj + LN", 8, 256, a.reps)
         attn_out_case("enc attention + out-proj + LN", 32, 128, a.reps)
+        for S in (384, 512, 768, 1000):  # decoder-side lengths below the pipelined attention kernel's range (S < 1024)
+            attn_out_case("attention + out-proj + LN", 32, S, a.reps)
+        attn_out_case("attention + out-proj + LN", 4, 640, a.reps)
     if a.what in ("rows",):  # the LS-76M depth-wise convs: the variance predictors' (k = 3 / 5) and the decoder's
         for k in (3, 5, 9, 13, 17, 21, 25, 31):
             dwconv_case("c3 dwconv T rows", 32, 1536, 768, k, a.reps)
