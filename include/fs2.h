@@ -254,8 +254,8 @@ int fs2_profile_read(fs2_engine* e, int32_t kernel_class, double* total_ms, int6
  *              workgroup on (default) / wherever it applies; bit-identical outputs
  *   1320/1321  inference engine, bf16: the VarianceEncoder's bucketize + embedding add as the tail of its predictor's launch: off / on (default;
  *              bit-identical either way)
- *   1340/1341  inference engine, bf16, H = 256 with two heads, ENCODER stack: self-attention and out-projection + residual + LayerNorm as two
- *              launches / as one (attn_out_ln_kernel, default; r06): the attention rows are the same bits, the out-projection sums its 256
+ *   1340/1341  inference engine, bf16, H = 256 with two heads, sequences of up to 768 rows (the encoder stack; the decoder stack for short
+ *              utterances): self-attention and out-projection + residual + LayerNorm as two launches / as one (attn_out_ln_kernel, default; r06): the attention rows are the same bits, the out-projection sums its 256
  *              products in another order (equal to fp32 rounding before the bf16 store)
  *   1500/1501  fp32-storage split modes: attention on fp32 MFMA / on bf16 x 3 split products (default)
  * (Removed in r05, measured slower or neutral in r02-r04 and kept until then behind switches: 1211 resident-K/V attention, 211 operand
