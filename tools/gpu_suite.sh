@@ -1,3 +1,4 @@
+# tools/gpu_suite.sh : what the driver runs at round end - the full -m gpu suite, smoke(), the default bench line (profiles/r06_v15_*)
 R=$PWD; O=$R/gpurun_out; mkdir -p $O
 python -m pytest tests -x -q -m gpu --durations=6 > $O/r06_v12_pytest.txt 2>&1; tail -12 $O/r06_v12_pytest.txt
 python -c "import __graft_entry__ as g; g.smoke()" > $O/r06_v12_smoke.txt 2>&1; tail -1 $O/r06_v12_smoke.txt

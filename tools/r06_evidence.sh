@@ -1,3 +1,4 @@
+# tools/r06_evidence.sh : the gpurun command behind profiles/r06_v9_* (kernel stats, timelines, bench lines for c2 / c3 / c5 / ref-default)
 R=$PWD; O=$R/gpurun_out; mkdir -p $O
 bash tools/prof_configs.sh r06_v9 > /dev/null 2>&1
 for c in c2 c3 ref-default; do bash tools/forward_timeline.sh $c; mv $O/timeline_${c}_eager.md $O/r06_v9_timeline_${c}_eager.md; done
