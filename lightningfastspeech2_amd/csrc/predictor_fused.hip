@@ -22,7 +22,7 @@
 namespace fs2 {
 
 namespace {
-constexpr int PF_H = 256, PF_TAPS = 3, PF_KB = PF_H / 32, PF_STEPS = PF_TAPS * PF_KB;  // 24 k-steps of 32
+constexpr int PF_H = 256, PF_TAPS = 3, PF_KB = PF_H / 32;  // a dense layer: 3 taps x 8 k-steps of 32
 constexpr int PF_STEP_U4 = 8 * 2 * 64;  // 16-byte fragments per k-step: [wave][fragment][lane]
 constexpr int PF_ROWB = PF_H * 2;       // slab row bytes (bf16)
 #ifndef FS2_PF_PREFETCH

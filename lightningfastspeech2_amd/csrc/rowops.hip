@@ -182,7 +182,7 @@ int launch_head_finish(const float* parts, const float* dots, int nparts, int nc
 #ifndef FS2_DW_PAD
 #define FS2_DW_PAD 0
 #endif
-static constexpr int DW_TR = 256, DW_CT = 64, DW_KMAX = 32, DW_KP = 36, DW_RR = 16, DW_LS = DW_CT + FS2_DW_PAD;  // DW_LS: slab row stride in LDS
+static constexpr int DW_CT = 64, DW_KMAX = 32, DW_KP = 36, DW_LS = DW_CT + FS2_DW_PAD;  // DW_LS: slab row stride in LDS (tile rows: the kernel's TRT)
 typedef float dw_f2 __attribute__((ext_vector_type(2)));
 template <typename T> __device__ inline void load4v(const T* p, dw_f2& a, dw_f2& b);
 template <> __device__ inline void load4v<float>(const float* p, dw_f2& a, dw_f2& b) {

@@ -498,7 +498,7 @@ class ForwardPipeline:
 
     ``host_outputs`` (r06; e.g. ``("mel", "tgt_mask")``): the host boundary inside the pipeline - what
     ``SpeechGenerator.generate_samples`` does right behind the forward (generator.py:158-165: ``mel[i][~tgt_mask[i]].cpu()``).  A batch
-    may then be HOST tensors (pinned: copied to the device on the forward's own stream, no host wait), and the named outputs come back
+    may then be HOST tensors (pinned: copied to the device on the replica's upload stream, which the forward's stream waits for), and the named outputs come back
     as PINNED HOST tensors: their device-to-host copies are queued on a per-replica copy stream behind the forward, so batch i's 15.7 MB
     of mels cross PCIe while batch i + 1's forward runs.  The bytes are those of ``model(batch, inference=True)[key].cpu()``.  A host
     output is a view of a per-replica ring slot (four per replica, up to 2 x in_flight results pending): it stays valid for the next
