@@ -26,7 +26,14 @@ template <typename T> struct VocT;
 template <> struct VocT<bf16> { static constexpr int KE = 32; };   // elements per 64-byte k-step
 template <> struct VocT<float> { static constexpr int KE = 16; };
 
-__device__ inline float lrelu(float v, float slope) { return fmaxf(v, v * slope); }  // 0 < slope <= 1
+// 0 < slope <= 1.  The bare instruction: fmaxf puts a canonicalising v_max(v, v) in front of every value that did not
+// come out of an arithmetic instruction (vocoder_resblock.hip)
+__device__ inline float lrelu(float v, float slope) {
+    float r;
+    const float m = v * slope;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(m));
+    return r;
+}
 
 }  // namespace
 

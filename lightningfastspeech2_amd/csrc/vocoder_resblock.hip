@@ -15,6 +15,8 @@
 // Every conv but the first (whose guard rows hold real samples) makes (k-1)/2 * dil more rows at both tile
 // edges stale, so a tile of R rows finishes R - 2H rows, H = (k-1)/2 * (sum over pairs of (d + 1) - d_first)
 // - for a single pair just the (k-1)/2 rows of its c2; tiles overlap by that halo.
+#include <type_traits>
+
 #include "fs2_common.h"
 #include "fs2_kernels.h"
 
@@ -24,8 +26,47 @@ namespace {
 template <typename T> struct RbT;
 template <> struct RbT<bf16> { static constexpr int KE = 32; };
 template <> struct RbT<float> { static constexpr int KE = 16; };
-// 0 < slope <= 1: LeakyReLU(v) = max(v, slope*v), its inverse = min(a, a/slope) - two VALU ops each
-__device__ inline float rb_lrelu(float v, float slope) { return fmaxf(v, v * slope); }
+// 0 < slope <= 1: LeakyReLU(v) = max(v, slope*v), its inverse = min(a, a/slope).  fmaxf / fminf put a
+// canonicalising v_max(v, v) in front of every value that did not come out of an arithmetic instruction (MFMA
+// results, unpacked bf16): 3 VALU instructions per element, and the epilogues of the narrow stages are VALU-bound
+// (32 channels, k = 3: ~800 VALU instructions = 3200 cycles per conv beside 1024 cycles of MFMA).  The bare
+// instruction returns the same value for every non-NaN input; the multiply pairs up into v_pk_mul_f32.
+__device__ inline float rb_max(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ inline float rb_min(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// N values at a time, the multiplies on float pairs (v_pk_mul_f32)
+typedef float rb_f2 __attribute__((ext_vector_type(2)));
+template <int N> __device__ inline void rb_lrelu_n(float (&v)[N], float slope) {
+    static_assert(N % 2 == 0, "pairs");
+#pragma unroll
+    for (int r = 0; r < N; r += 2) {
+        const rb_f2 x = {v[r], v[r + 1]};
+        const rb_f2 m = x * slope;
+        v[r] = rb_max(x.x, m.x);
+        v[r + 1] = rb_max(x.y, m.y);
+    }
+}
+__device__ inline void rb_lrelu8(float (&v)[8], float slope) { rb_lrelu_n<8>(v, slope); }
+// v = acc + (a < 0 ? a / slope : a)
+__device__ inline void rb_add_raw8(float (&v)[8], const float (&a)[8], float inv_slope) {
+#pragma unroll
+    for (int r = 0; r < 8; r += 2) {
+        const rb_f2 x = {a[r], a[r + 1]};
+        const rb_f2 m = x * inv_slope;
+        const rb_f2 raw = {rb_min(x.x, m.x), rb_min(x.y, m.y)};
+        const rb_f2 acc = {v[r], v[r + 1]};
+        const rb_f2 o = acc + raw;
+        v[r] = o.x;
+        v[r + 1] = o.y;
+    }
+}
 }  // namespace
 
 // CH = channels (32 / 64 / 128) as a compile-time constant: row strides, fragment offsets and the swizzle
@@ -113,8 +154,7 @@ __global__ __launch_bounds__(NW * 64, 2) void vocoder_resblock_kernel(VocResbloc
                 if (dst[u] < 0) continue;
                 float f[E16];
                 Vec16<T>::unpack(raw[u], f);
-#pragma unroll
-                for (int e = 0; e < E16; ++e) f[e] = rb_lrelu(f[e], p.slope);
+                rb_lrelu_n<E16>(f, p.slope);
                 *(uint4*)(slabX + dst[u]) = Vec16<T>::pack(f);
             }
         }
@@ -155,23 +195,50 @@ __global__ __launch_bounds__(NW * 64, 2) void vocoder_resblock_kernel(VocResbloc
     if (p.x_act) dma_drain();  // this wave's slab DMAs have landed before the barrier publishes them
     __syncthreads();
 
-#pragma unroll 1
-    for (int j = 0; j < nconv; ++j) {
-        const int second = j & 1;
+    // byte offsets of this lane's 8 output channels in its fragment-0 row of X / Y; the swizzle reads row bits 0-2
+    // only, so fragment m lies m * 16 rows further on at the same slot (an immediate offset)
+    int xo[SPL], yo[SPL];
+#pragma unroll
+    for (int q = 0; q < SPL; ++q) {
+        xo[q] = slot_off(G + wrow0 + fr, n0 / E16 + q);
+        yo[q] = slot_off(GY + wrow0 + fr, n0 / E16 + q);
+    }
+    const bool edge = tbase + wrow0 < 0 || tbase + wrow0 + RW > len;  // this wave's rows cross an utterance end
+
+    // one conv: SECOND = the c2 of a pair (reads Y, adds the residual, writes X or - the last one - the output)
+    auto conv = [&](auto second_c, const int j) {
+        constexpr bool second = decltype(second_c)::value;
         const int dil = second ? 1 : p.dil[j >> 1];
         const unsigned char* src = second ? slabY : slabX;
         const int ibase = (second ? GY : G) - c * dil + wrow0 + fr;  // slab index of this lane's fragment-0 row at tap 0
+        const bool last = second && j == nconv - 1;
 
-        // the bias rides in as the accumulators' initial value (lane: channels n0 .. n0+7 of every row)
-        f32x4_t acc[2][MI16];
+        // the block's result is added to the previous output: those rows are requested before the K loop that hides
+        // them (unconditional loads, clamped rows)
+        // (bf16; the fp32 build has no registers for that and fetches them chunk by chunk in the epilogue)
+        constexpr bool OO_EARLY = sizeof(T) == 2;
+        constexpr int MC = sizeof(T) == 2 ? MI16 : 2;  // rows of X (and of the previous output) in flight, x16
+        uint4 oo[(!MID && second) ? (OO_EARLY ? MI16 : MC) : 1][SPL];
+        if constexpr (!MID && second && OO_EARLY) {
+            if (last && p.accumulate) {
+#pragma unroll
+                for (int m = 0; m < MI16; ++m) {
+                    const int tt = tbase + wrow0 + m * 16 + fr, tc = tt < 0 ? 0 : (tt < len ? tt : len - 1);
+                    const uint4* po = (const uint4*)(ob + (unsigned)(tc * rowb) + nb);
+#pragma unroll
+                    for (int q = 0; q < SPL; ++q) oo[m][q] = po[q];
+                }
+            }
+        }
+
+        // the bias is the C operand of every accumulator's first MFMA (lane: channels n0 .. n0+7 of every row): copying
+        // it into the 16 accumulators first was 56-64 v_mov per conv
+        f32x4_t acc[2][MI16], bia[2];
         {
             const float* bp = p.bias + j * C + n0;
             const float4 b0 = *(const float4*)bp, b1 = *(const float4*)(bp + 4);
-#pragma unroll
-            for (int b = 0; b < MI16; ++b) {
-                acc[0][b] = (f32x4_t){b0.x, b0.y, b0.z, b0.w};
-                acc[1][b] = (f32x4_t){b1.x, b1.y, b1.z, b1.w};
-            }
+            bia[0] = (f32x4_t){b0.x, b0.y, b0.z, b0.w};
+            bia[1] = (f32x4_t){b1.x, b1.y, b1.z, b1.w};
         }
         // operand fragments run one group (PF fragments) ahead of the MFMAs that use them (two register sets, issue order
         // pinned): left to itself the compiler reads a fragment right before its MFMA and every MFMA group
@@ -196,8 +263,8 @@ __global__ __launch_bounds__(NW * 64, 2) void vocoder_resblock_kernel(VocResbloc
 #pragma unroll
             for (int mi = 0; mi < PF; ++mi) fx[gi][mi] = *(const uint4*)(a0 + mi * 16 * rowb);
         }
-#pragma unroll 1
-        for (int g0 = 0; g0 < nsteps4; g0 += 4) {
+        auto trip = [&](auto first_c, const int g0) {  // four K steps; the conv's first trip starts the accumulators
+            constexpr bool first = decltype(first_c)::value;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int g = g0 + u;
@@ -215,84 +282,119 @@ __global__ __launch_bounds__(NW * 64, 2) void vocoder_resblock_kernel(VocResbloc
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                        for (int mi = 0; mi < PF; ++mi) Mma16<T>::step(bw[u][ni], fx[cur][mi], acc[ni][q * PF + mi]);
+                        for (int mi = 0; mi < PF; ++mi) {
+                            if (first && u == 0) acc[ni][q * PF + mi] = bia[ni];
+                            Mma16<T>::step(bw[u][ni], fx[cur][mi], acc[ni][q * PF + mi]);
+                        }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-        }
+        };
+        trip(std::true_type{}, 0);
+#pragma unroll 1
+        for (int g0 = 4; g0 < nsteps4; g0 += 4) trip(std::false_type{}, g0);
 
         // ---- epilogue: lane = rows (m*16 + fr), channels n0 .. n0+7 ----
-        const bool last = j == nconv - 1;
-        // the block's result is added to the previous output: those rows are fetched MC at a time before any
-        // row of the chunk is stored (unconditional loads, clamped rows) - one memory round trip per chunk
-        constexpr int MC = MI16 == 4 ? 2 : 4;
-        uint4 oo[MC][SPL];
+        if constexpr (!second) {  // Y <- lrelu(c1)
 #pragma unroll
-        for (int m = 0; m < MI16; ++m) {
-            if (!MID && m % MC == 0 && last && p.accumulate) {
+            for (int m = 0; m < MI16; ++m) {
+                float v[8];
 #pragma unroll
-                for (int mm = 0; mm < MC; ++mm) {
-                    const int tt = tbase + wrow0 + (m + mm) * 16 + fr, tc = tt < 0 ? 0 : (tt < len ? tt : len - 1);
-                    const uint4* src = (const uint4*)(ob + (unsigned)(tc * rowb) + nb);
+                for (int r = 0; r < 8; ++r) v[r] = acc[r >> 2][m][r & 3];
+                rb_lrelu8(v, p.slope);
 #pragma unroll
-                    for (int q = 0; q < SPL; ++q) oo[mm][q] = src[q];
-                }
+                for (int q = 0; q < SPL; ++q) *(uint4*)(slabY + yo[q] + m * 16 * rowb) = Vec16<T>::pack(v + q * E16);
             }
-            const int row = wrow0 + m * 16 + fr, t = tbase + row, i = G + row, iy = GY + row;
-            const bool inside = t >= 0 && t < len;
-            float v[8];
+        } else {
+            // + residual, recovered from the activated copy; all of this wave's rows of X are requested first
+            uint4 xa[MC][SPL];
+            auto fetch = [&](int m) {  // at the head of every chunk of MC fragments
 #pragma unroll
-            for (int r = 0; r < 8; ++r) v[r] = acc[r >> 2][m][r & 3];
-            if (second) {  // + residual, recovered from the activated copy
+                for (int mm = 0; mm < MC; ++mm)
+#pragma unroll
+                    for (int q = 0; q < SPL; ++q) xa[mm][q] = *(const uint4*)(slabX + xo[q] + (m + mm) * 16 * rowb);
+            };
+            auto with_res = [&](int m, float (&v)[8]) {
                 float a[8];
 #pragma unroll
-                for (int q = 0; q < SPL; ++q) Vec16<T>::unpack(*(const uint4*)(slabX + slot_off(i, n0 / E16 + q)), a + q * E16);
+                for (int q = 0; q < SPL; ++q) Vec16<T>::unpack(xa[m % MC][q], a + q * E16);
 #pragma unroll
-                for (int r = 0; r < 8; ++r) v[r] += fminf(a[r], a[r] * inv_slope);
-            }
-            if (!last) {
-                unsigned char* dstb = second ? slabX : slabY;
-                const int id = second ? i : iy;
+                for (int r = 0; r < 8; ++r) v[r] = acc[r >> 2][m][r & 3];
+                rb_add_raw8(v, a, inv_slope);
+            };
+            if (!last) {  // X <- lrelu(x + c2), in place
 #pragma unroll
-                for (int r = 0; r < 8; ++r) v[r] = rb_lrelu(v[r], p.slope);
+                for (int m = 0; m < MI16; ++m) {
+                    if (m % MC == 0) fetch(m);
+                    float v[8];
+                    with_res(m, v);
+                    rb_lrelu8(v, p.slope);
 #pragma unroll
-                for (int q = 0; q < SPL; ++q) *(uint4*)(dstb + slot_off(id, n0 / E16 + q)) = Vec16<T>::pack(v + q * E16);
-            } else if (inside && row >= H && row < H + V) {
-                uint4* dst = (uint4*)(ob + (unsigned)(t * rowb) + nb);
-                if constexpr (MID) {  // the next pair of this block reads it with x_act
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) v[r] = rb_lrelu(v[r], p.slope);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) v[r] *= p.scale;
+                    for (int q = 0; q < SPL; ++q) *(uint4*)(slabX + xo[q] + m * 16 * rowb) = Vec16<T>::pack(v + q * E16);
                 }
-                if (!MID && p.accumulate) {
-                    float ov[8];
+            } else {
 #pragma unroll
-                    for (int q = 0; q < SPL; ++q) Vec16<T>::unpack(oo[m % MC][q], ov + q * E16);
+                for (int m = 0; m < MI16; ++m) {
+                    if (m % MC == 0) {
+                        fetch(m);
+                        if constexpr (!MID && !OO_EARLY) {
+                            if (p.accumulate) {
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) v[r] += ov[r];
+                                for (int mm = 0; mm < MC; ++mm) {
+                                    const int tt = tbase + wrow0 + (m + mm) * 16 + fr, tc = tt < 0 ? 0 : (tt < len ? tt : len - 1);
+                                    const uint4* po = (const uint4*)(ob + (unsigned)(tc * rowb) + nb);
+#pragma unroll
+                                    for (int q = 0; q < SPL; ++q) oo[mm][q] = po[q];
+                                }
+                            }
+                        }
+                    }
+                    float v[8];
+                    with_res(m, v);
+                    const int row = wrow0 + m * 16 + fr, t = tbase + row;
+                    if constexpr (MID) {  // the next pair of this block reads it with x_act
+                        rb_lrelu8(v, p.slope);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] *= p.scale;
+                        if (p.accumulate) {
+                            float ov[8];
+#pragma unroll
+                            for (int q = 0; q < SPL; ++q) Vec16<T>::unpack(oo[OO_EARLY ? m : m % MC][q], ov + q * E16);
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) v[r] += ov[r];
+                        }
+                    }
+                    if (t >= 0 && t < len && row >= H && row < H + V) {
+                        uint4* dst = (uint4*)(ob + (unsigned)(t * rowb) + nb);
+#pragma unroll
+                        for (int q = 0; q < SPL; ++q) dst[q] = Vec16<T>::pack(v + q * E16);
+                    }
                 }
-#pragma unroll
-                for (int q = 0; q < SPL; ++q) dst[q] = Vec16<T>::pack(v + q * E16);
             }
         }
         if (!last) {
             // rows outside the utterance are the next conv's zero padding: only a wave whose rows cross an utterance
             // end re-zeroes them (a per-element select in the loop above cost 64 VALU instructions per conv)
-            if (tbase + wrow0 < 0 || tbase + wrow0 + RW > len) {
+            if (edge) {
                 unsigned char* dstb = second ? slabX : slabY;
 #pragma unroll
                 for (int m = 0; m < MI16; ++m) {
-                    const int row = wrow0 + m * 16 + fr, t = tbase + row, id = (second ? G : GY) + row;
+                    const int t = tbase + wrow0 + m * 16 + fr;
                     if (t < 0 || t >= len) {
 #pragma unroll
-                        for (int q = 0; q < SPL; ++q) *(uint4*)(dstb + slot_off(id, n0 / E16 + q)) = make_uint4(0u, 0u, 0u, 0u);
+                        for (int q = 0; q < SPL; ++q) *(uint4*)(dstb + (second ? xo[q] : yo[q]) + m * 16 * rowb) = make_uint4(0u, 0u, 0u, 0u);
                     }
                 }
             }
             __syncthreads();
         }
+    };
+
+#pragma unroll 1
+    for (int pr = 0; pr < p.npairs; ++pr) {
+        conv(std::false_type{}, 2 * pr);
+        conv(std::true_type{}, 2 * pr + 1);
     }
 }
 
