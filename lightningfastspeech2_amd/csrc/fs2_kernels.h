@@ -227,6 +227,8 @@ struct VocConvArgs {
     int post;               // conv_post: one channel, tanh, fp32 out
     float out_slope = 1.f;  // store LeakyReLU(result): every consumer is a resident resblock launch with x_act
     const Tuning* tune = nullptr;
+    int shift_from = 0;     // output channels >= shift_from read their taps one row further on (x[t - pad + 1 + tap*dil]):
+                            // the two tap windows of a transposed conv's phases (vocoder_engine.hip up_layer); 0 = none
 };
 // A whole ResBlock "1" (npairs = 3 (c1 dilated, c2) pairs) or one pair (npairs = 1) on an LDS-resident
 // tile, vocoder_resblock.hip.  out = (x after the pairs) * scale (+ previous contents).

@@ -51,7 +51,7 @@ __global__ __launch_bounds__(512) void vocoder_conv_kernel(VocConvArgs p) {
     const int WN = p.wn, WM = 8 / WN;
     const int wn = wave % WN, wm = wave / WN;
     const int fr = lane & 15, fg = lane >> 4;
-    const int BM = WM * RW, halo = (p.taps - 1) * p.dil;
+    const int BM = WM * RW, halo = (p.taps - 1 + (p.shift_from ? 1 : 0)) * p.dil;
     const int tiles = (p.S + BM - 1) / BM;
     const int ub = blockIdx.x / tiles, tm = blockIdx.x % tiles, nt = blockIdx.y;
     const int len = p.lengths ? p.lengths[ub] * p.len_scale : p.S;  // valid rows of this utterance
@@ -175,6 +175,7 @@ __global__ __launch_bounds__(512) void vocoder_conv_kernel(VocConvArgs p) {
 
     const int wrow0 = wm * RW;
     const int nkc_shift = __builtin_ctz(nkc);
+    const int tsh = (p.shift_from && nt * WN * 32 + wn * 32 >= p.shift_from) ? 1 : 0;  // wave-uniform
     // operand fragments run one group (PF fragments) ahead of the MFMAs that use them (two register sets, issue order
     // pinned): left to itself the compiler reads a fragment right before its MFMA and every MFMA group then
     // waits out an LDS round trip
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(512) void vocoder_conv_kernel(VocConvArgs p) {
         int tap = g >> nkc_shift;
         const int kc = g & (nkc - 1);
         tap = tap < p.taps ? tap : p.taps - 1;  // padded steps multiply zero weights by any valid rows
-        const int i0 = wrow0 + fr + tap * p.dil;
+        const int i0 = wrow0 + fr + (tap + tsh) * p.dil;
         return slab + i0 * rowb + (swz.slot(kc * 4 + fg, i0) << 4);
     };
     constexpr int PF = 2, NG = MI16 / PF;  // fragments per group, groups per step
@@ -313,7 +314,7 @@ static int voc_pick_mi16(const VocConvArgs& a, int esz, size_t* smem) {
     const int g_voc_lds_limit = tuning_of(a.tune).voc_lds_limit;
     const size_t limit = (size_t)(g_voc_lds_limit > 0 ? g_voc_lds_limit : 110) * 1024;
     for (int c = 0; c < 4; ++c) {
-        const size_t b = ((size_t)(WM * cand[c] * 16 + (a.taps - 1) * a.dil) * a.cin_pad * esz + 1023) & ~(size_t)1023;  // whole DMA chunks
+        const size_t b = ((size_t)(WM * cand[c] * 16 + (a.taps - 1 + (a.shift_from ? 1 : 0)) * a.dil) * a.cin_pad * esz + 1023) & ~(size_t)1023;  // whole DMA chunks
         if (b <= limit || (c == 3 && b <= 150 * 1024)) {
             *smem = b;
             return cand[c];
@@ -362,6 +363,7 @@ int launch_vocoder_conv(const VocConvArgs& a, int dtype, hipStream_t stream) {
     if (a.cin_pad < 32 || (a.cin_pad & (a.cin_pad - 1)) || a.cin > a.cin_pad || a.cin % 4) return FS2_ERR_SHAPE;
     if (!a.post && (a.n % 32 || a.n % (a.wn * 32))) return FS2_ERR_SHAPE;
     if (!a.in_fp32 && a.cin % (dtype == FS2_BF16 ? 8 : 4)) return FS2_ERR_SHAPE;
+    if (a.shift_from % 32 || a.shift_from < 0 || a.shift_from >= (a.post ? 1 : a.n)) return FS2_ERR_SHAPE;
     size_t smem = 0;
     const int mi = voc_pick_mi16(a, dtype == FS2_BF16 ? 2 : 4, &smem);
     if (!mi) return FS2_ERR_SHAPE;

@@ -36,6 +36,7 @@ struct VocLayer {     // one conv in kernel form
     void* w = nullptr;
     float* b = nullptr;
     int cin = 0, cin_pad = 0, n = 0, taps = 1, dil = 1, pad = 0, wn = 1;
+    int shift_from = 0;  // VocConvArgs::shift_from
 };
 struct HostT {
     std::vector<int64_t> shape;
@@ -178,18 +179,39 @@ int up_layer(fs2_vocoder* v, const std::string& name, int cin, int cout, int k, 
             if (kk >= 0 && kk < k) { m_lo = m < m_lo ? m : m_lo; m_hi = m > m_hi ? m : m_hi; }
         }
     const int K = m_hi - m_lo + 1, pad = m_hi;  // tap j reads x[q - pad + j]  <->  m = pad - j
-    std::vector<float> W((size_t)s * cout * cin * K, 0.f), bias((size_t)s * cout);
+    // A phase f only has the taps with 0 <= (pad - j)*s + f + p < k.  With k = 2s (every HiFi-GAN config) that is two of
+    // the K = 3: j in {0, 1} for f < s/2, {1, 2} above - the kernel runs K - 1 taps and reads one row further on for
+    // the channels from shift_from upwards (a wave column is 32 channels, cout a multiple of 32) instead of
+    // multiplying a third of its steps by zeros.
+    std::vector<int> jlo(s, K), jhi(s, -1);
+    for (int f = 0; f < s; ++f)
+        for (int j = 0; j < K; ++j) {
+            const int kk = (pad - j) * s + f + p;
+            if (kk >= 0 && kk < k) { jlo[f] = j < jlo[f] ? j : jlo[f]; jhi[f] = j > jhi[f] ? j : jhi[f]; }
+        }
+    int fshift = s;  // first phase whose window starts at tap 1
+    bool two = K >= 2;
+    for (int f = 0; f < s && two; ++f) {
+        if (jlo[f] > 1 || jhi[f] - (jlo[f] >= 1 ? 1 : 0) > K - 2) two = false;
+        if (jlo[f] >= 1 && fshift == s) fshift = f;
+        if (jlo[f] < 1 && fshift != s) two = false;  // one switch point only
+    }
+    const int K2 = two ? K - 1 : K;
+    std::vector<float> W((size_t)s * cout * cin * K2, 0.f), bias((size_t)s * cout);
     for (int f = 0; f < s; ++f)
         for (int co = 0; co < cout; ++co) {
             bias[(size_t)f * cout + co] = b.data[co];
-            for (int j = 0; j < K; ++j) {
+            for (int j2 = 0; j2 < K2; ++j2) {
+                const int j = j2 + (two && f >= fshift ? 1 : 0);
                 const int kk = (pad - j) * s + f + p;
                 if (kk < 0 || kk >= k) continue;
                 for (int ci = 0; ci < cin; ++ci)
-                    W[(((size_t)f * cout + co) * cin + ci) * K + j] = w.data[((size_t)ci * cout + co) * k + kk];
+                    W[(((size_t)f * cout + co) * cin + ci) * K2 + j2] = w.data[((size_t)ci * cout + co) * k + kk];
             }
         }
-    return pack_layer(v, W, bias, s * cout, cin, K, 1, pad, false, L);
+    VCHK(pack_layer(v, W, bias, s * cout, cin, K2, 1, pad, false, L));
+    L->shift_from = two && fshift < s ? fshift * cout : 0;
+    return FS2_OK;
 }
 
 int run_conv(fs2_vocoder* v, hipStream_t st, const VocLayer& L, const void* x, void* out, const void* res,
@@ -202,6 +224,7 @@ int run_conv(fs2_vocoder* v, hipStream_t st, const VocLayer& L, const void* x, v
     a.B = B; a.S = S; a.cin = L.cin; a.cin_pad = L.cin_pad; a.n = L.n; a.taps = L.taps; a.dil = L.dil; a.pad = L.pad;
     a.wn = L.wn; a.in_slope = in_slope; a.scale = scale; a.accumulate = accumulate ? 1 : 0;
     a.in_fp32 = in_fp32 ? 1 : 0; a.post = post ? 1 : 0;
+    a.shift_from = L.shift_from;
     const int r = launch_vocoder_conv(a, v->dt, st);
     if (r != FS2_OK) return vfail(v, r, "vocoder conv launch failed (cin=%d n=%d k=%d dil=%d S=%d)", L.cin, L.n, L.taps, L.dil, S);
     return FS2_OK;
