@@ -213,3 +213,27 @@ def test_full_size_time_shift_equivariance(precision):
     assert torch.isfinite(full).all() and float(full.abs().max()) <= 1.0
     assert torch.equal(a, b)
     assert not torch.equal(full[:, :margin * hop // 2], shifted[:, :margin * hop // 2])   # edges do differ
+
+
+@pytest.mark.parametrize("rates,kernels", [((4, 2), (8, 4)), ((4, 2), (12, 6)), ((2, 2), (2, 2)), ((8, 2), (16, 6))])
+def test_transposed_conv_tap_windows(rates, kernels):
+    """ConvTranspose1d(k, stride s, padding (k - s) / 2) for k = 2s (every phase has two of the three taps: the engine runs
+    two tap windows, `shift_from`), k = 3s (all three taps everywhere: the plain three-tap form) and k = s (one tap), fp32 against
+    the oracle on ragged lengths that cross several tiles (reference: third_party/hifigan/models.py:131-136, 149-150)."""
+    cfg = HifiGanConfig(upsample_rates=list(rates), upsample_kernel_sizes=list(kernels), upsample_initial_channel=128,
+                        resblock_kernel_sizes=[3, 7], resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5]])
+    sd = synth_state_dict(cfg, 11)
+    rs = np.random.RandomState(3)
+    mel = torch.from_numpy((rs.standard_normal((3, 150, 80)) * 1.5 - 4.0).astype(np.float32))
+    lengths = torch.tensor([150, 97, 2], dtype=torch.int32)
+    ref_wav, ref_stages = hifigan_cpu.synthesize(sd, cfg, mel, lengths, return_stages=True)
+    g = HifiGan(cfg, sd, precision="fp32")
+    wav = g.synthesize(mel, lengths).cpu()
+    for s in range(len(rates) + 1):
+        got = g.debug_stage(s).cpu()
+        up = int(np.prod(rates[:s])) if s else 1
+        for b, n in enumerate(lengths.tolist()):
+            ref = ref_stages[b][s]
+            d = float((got[b, :n * up] - ref).abs().max())
+            assert d <= 1e-4 * (float(ref.abs().max()) + 1.0), (rates, kernels, s, b, d)
+    assert float((wav - ref_wav).abs().max()) <= F32_TOL
