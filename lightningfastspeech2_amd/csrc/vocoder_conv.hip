@@ -141,12 +141,25 @@ __global__ __launch_bounds__(512) void vocoder_conv_kernel(VocConvArgs p) {
 
     // ---- weight stream: [n-tile][step][wave column][fragment][lane] x 16 B, 4-deep ring ----
     const int nkc = cin_pad / KE, nsteps = p.taps * nkc, nsteps4 = (nsteps + 3) & ~3;
-    const uint4* __restrict__ wbase = (const uint4*)p.w + ((size_t)nt * nsteps4 * WN + wn) * 128 + lane;
-    const size_t wstep = (size_t)WN * 128;
+    // (buffer loads: one per-lane byte offset for the whole launch, the step's offset in a scalar register)
+    typedef unsigned vc_u4 __attribute__((ext_vector_type(4)));
+    const int ntiles_w = p.post ? 1 : (p.n + WN * 32 - 1) / (WN * 32);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __amdgpu_buffer_rsrc_t wrs =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (unsigned)((size_t)ntiles_w * nsteps4 * WN * 2048), 0x00020000);
+#endif
+    const int wvoff = (wn * 128 + lane) * 16, wsbase = nt * nsteps4 * WN * 2048;
     auto loadB = [&](uint4 (&b)[2], int g) {
         g = g < nsteps4 ? g : nsteps4 - 1;
-        b[0] = wbase[g * wstep];
-        b[1] = wbase[g * wstep + 64];
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int so = wsbase + g * (WN * 2048);
+        const vc_u4 v0 = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff, so, 0);
+        const vc_u4 v1 = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + 1024, so, 0);
+        b[0] = make_uint4(v0.x, v0.y, v0.z, v0.w);
+        b[1] = make_uint4(v1.x, v1.y, v1.z, v1.w);
+#else
+        (void)b;
+#endif
     };
     uint4 bw[4][2];
     loadB(bw[0], 0);
@@ -179,10 +192,24 @@ __global__ __launch_bounds__(512) void vocoder_conv_kernel(VocConvArgs p) {
     // operand fragments run one group (PF fragments) ahead of the MFMAs that use them (two register sets, issue order
     // pinned): left to itself the compiler reads a fragment right before its MFMA and every MFMA group then
     // waits out an LDS round trip
-    auto a_addr = [&](int g) {  // this lane's fragment-0 address of step g
-        g = g < nsteps4 ? g : nsteps4 - 1;
-        int tap = g >> nkc_shift;
-        const int kc = g & (nkc - 1);
+    // this lane's fragment-0 address of step g0 + u of a trip (g0 % 4 == 0; u = 4: the next trip's first step).  With the
+    // channel count a template parameter a step's channel block is a compile-time number after unrolling and the tap a scalar
+    // that moves once per tap - decomposing a running step index cost ~19 scalar + ~10 vector instructions per step beside
+    // its 16 MFMAs (vocoder_resblock.hip)
+    constexpr int NKC = CP ? CP / KE : 0;
+    auto a_addr = [&](const int g0, const int u) {
+        int tap, kc;
+        if constexpr (NKC >= 4) {        // a trip lies inside one tap
+            tap = g0 / NKC;
+            kc = (g0 & (NKC - 1)) + u;   // (g0 & (NKC - 1)) is 0 for NKC = 4
+            if (kc >= NKC) { kc -= NKC; ++tap; }
+        } else if constexpr (NKC > 0) {  // 4 / NKC taps per trip
+            tap = g0 / NKC + u / NKC;
+            kc = u % NKC;
+        } else {
+            tap = (g0 + u) >> nkc_shift;
+            kc = (g0 + u) & (nkc - 1);
+        }
         tap = tap < p.taps ? tap : p.taps - 1;  // padded steps multiply zero weights by any valid rows
         const int i0 = wrow0 + fr + (tap + tsh) * p.dil;
         return slab + i0 * rowb + (swz.slot(kc * 4 + fg, i0) << 4);
@@ -190,7 +217,7 @@ __global__ __launch_bounds__(512) void vocoder_conv_kernel(VocConvArgs p) {
     constexpr int PF = 2, NG = MI16 / PF;  // fragments per group, groups per step
     uint4 fx[2][PF];
     {
-        const unsigned char* a0 = a_addr(0);
+        const unsigned char* a0 = a_addr(0, 0);
 #pragma unroll
         for (int mi = 0; mi < PF; ++mi) fx[0][mi] = *(const uint4*)(a0 + mi * 16 * rowb);
     }
@@ -200,8 +227,8 @@ __global__ __launch_bounds__(512) void vocoder_conv_kernel(VocConvArgs p) {
         for (int u = 0; u < 4; ++u) {
             const int g = g0 + u;
             loadB(bw[(u + 3) & 3], g + 3);
-            const unsigned char* acur = a_addr(g);
-            const unsigned char* anext = a_addr(g + 1);
+            const unsigned char* acur = a_addr(g0, u);
+            const unsigned char* anext = a_addr(g0, u + 1);
 #pragma unroll
             for (int q = 0; q < NG; ++q) {
                 const int cur = (u * NG + q) & 1;  // 4 * NG groups per trip: the parity restarts at 0

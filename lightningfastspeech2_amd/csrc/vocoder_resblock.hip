@@ -172,12 +172,24 @@ __global__ __launch_bounds__(NW * 64, 2) void vocoder_resblock_kernel(VocResbloc
     constexpr int nkc = C / KE;
     const int nsteps = p.taps * nkc, nsteps4 = (nsteps + 3) & ~3;
     const int nconv = 2 * p.npairs, total = nconv * nsteps4;
-    const uint4* __restrict__ wbase = (const uint4*)p.w + (size_t)wn * 128 + lane;
-    const size_t wstep = (size_t)WN * 128;
+    // (buffer loads: one per-lane byte offset for the whole launch, the step's offset in a scalar register - the flat form
+    // built a 64-bit address per step)
+    typedef unsigned rb_u4 __attribute__((ext_vector_type(4)));
+#if defined(__HIP_DEVICE_COMPILE__)
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (unsigned)((size_t)total * WN * 2048), 0x00020000);
+#endif
+    const int wvoff = (wn * 128 + lane) * 16;
     auto loadB = [&](uint4 (&b)[2], int g) {
         g = g < total ? g : total - 1;
-        b[0] = wbase[g * wstep];
-        b[1] = wbase[g * wstep + 64];
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int so = g * (WN * 2048);
+        const rb_u4 v0 = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff, so, 0);
+        const rb_u4 v1 = __builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff + 1024, so, 0);
+        b[0] = make_uint4(v0.x, v0.y, v0.z, v0.w);
+        b[1] = make_uint4(v1.x, v1.y, v1.z, v1.w);
+#else
+        (void)b;
+#endif
     };
     uint4 bw[4][2];
     loadB(bw[0], 0);
@@ -243,10 +255,19 @@ __global__ __launch_bounds__(NW * 64, 2) void vocoder_resblock_kernel(VocResbloc
         // operand fragments run one group (PF fragments) ahead of the MFMAs that use them (two register sets, issue order
         // pinned): left to itself the compiler reads a fragment right before its MFMA and every MFMA group
         // then waits out an LDS round trip
-        auto a_addr = [&](int g) {  // this lane's fragment-0 address of step g
-            g = g < nsteps4 ? g : nsteps4 - 1;
-            int tap = g >> nkc_shift;
-            const int kc = g & (nkc - 1);
+        // this lane's fragment-0 address of step g0 + u of a trip (g0 % 4 == 0; u may run into the next trip).  The channel
+        // block kc of the step is a compile-time number after unrolling (nkc <= 4) and the tap a scalar that moves once per
+        // 4 / nkc steps: decomposing a running step index per step was 7-19 scalar + ~10 vector instructions per step beside
+        // its 16 MFMAs - more than their issue shadow holds
+        auto a_addr = [&](const int g0, const int u) {
+            int tap, kc;
+            if constexpr (nkc <= 4) {
+                tap = (g0 >> nkc_shift) + (u >> nkc_shift);
+                kc = u & (nkc - 1);
+            } else {
+                tap = (g0 + u) >> nkc_shift;
+                kc = (g0 + u) & (nkc - 1);
+            }
             tap = tap < p.taps ? tap : p.taps - 1;  // padded steps: zero weights x any valid rows
             const int i0 = ibase + tap * dil;
             return src + i0 * rowb + (swz.slot(kc * 4 + fg, i0) << 4);
@@ -259,7 +280,7 @@ __global__ __launch_bounds__(NW * 64, 2) void vocoder_resblock_kernel(VocResbloc
         uint4 fx[NS][PF];
 #pragma unroll
         for (int gi = 0; gi < D; ++gi) {
-            const unsigned char* a0 = a_addr(gi / NG) + (gi % NG) * PF * 16 * rowb;
+            const unsigned char* a0 = a_addr(0, gi / NG) + (gi % NG) * PF * 16 * rowb;
 #pragma unroll
             for (int mi = 0; mi < PF; ++mi) fx[gi][mi] = *(const uint4*)(a0 + mi * 16 * rowb);
         }
@@ -271,7 +292,7 @@ __global__ __launch_bounds__(NW * 64, 2) void vocoder_resblock_kernel(VocResbloc
                 loadB(bw[(u + 3) & 3], j * nsteps4 + g + 3);
                 const unsigned char* as[NA];
 #pragma unroll
-                for (int k = 0; k < NA; ++k) as[k] = a_addr(g + k);
+                for (int k = 0; k < NA; ++k) as[k] = a_addr(g0, u + k);
 #pragma unroll
                 for (int q = 0; q < NG; ++q) {
                     const int gi = u * NG + q, cur = gi % NS, tgt = (gi + D) % NS;
