@@ -237,3 +237,18 @@ def test_transposed_conv_tap_windows(rates, kernels):
             d = float((got[b, :n * up] - ref).abs().max())
             assert d <= 1e-4 * (float(ref.abs().max()) + 1.0), (rates, kernels, s, b, d)
     assert float((wav - ref_wav).abs().max()) <= F32_TOL
+
+
+def test_wide_generator_takes_the_runtime_stride_conv_build():
+    """1024 initial channels: the first transposed conv reads 1024-channel rows, a width outside the kernel's compile-time set
+    (32 ... 512), so its K loop runs the runtime-stride build - fp32 against the oracle, ragged lengths."""
+    cfg = HifiGanConfig(upsample_rates=[2, 2, 2], upsample_kernel_sizes=[4, 4, 4], upsample_initial_channel=1024,
+                        resblock_kernel_sizes=[3], resblock_dilation_sizes=[[1, 3, 5]])
+    sd = synth_state_dict(cfg, 4)
+    rs = np.random.RandomState(1)
+    mel = torch.from_numpy((rs.standard_normal((2, 40, 80)) * 1.5 - 4.0).astype(np.float32))
+    lengths = torch.tensor([40, 23], dtype=torch.int32)
+    ref = hifigan_cpu.synthesize(sd, cfg, mel, lengths)
+    ref = ref[0] if isinstance(ref, tuple) else ref
+    wav = HifiGan(cfg, sd, precision="fp32").synthesize(mel, lengths).cpu()
+    assert float((wav - ref).abs().max()) <= F32_TOL
